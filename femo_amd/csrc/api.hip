@@ -1,0 +1,542 @@
+// C-ABI entry points: handles, host<->device movement, and the small
+// elementwise kernels (fill / axpy / Dirichlet lifting).  See include/femo_hip.h
+// for the reference call site each entry replaces.
+#include <algorithm>
+
+#include "femo_internal.h"
+
+namespace {
+
+__global__ void k_fill(int64_t n, double v, double* __restrict__ x) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] = v;
+}
+
+__global__ void k_axpy(int64_t n, double a, const double* __restrict__ x, double* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] += a * x[i];
+}
+
+__global__ void k_bc_mask(int64_t n, const int32_t* __restrict__ dofs, uint8_t* __restrict__ mask) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) mask[dofs[i]] = 1;
+}
+
+// w = (g - u) on the Dirichlet set, 0 elsewhere (w pre-zeroed)
+__global__ void k_bc_lift_vec(int64_t n, const int32_t* __restrict__ dofs, const double* __restrict__ g,
+                              const double* __restrict__ u, double* __restrict__ w) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t d = dofs[i];
+    w[d] = g[i] - u[d];
+  }
+}
+
+// b = F + Kw ; then b[bc] = u - g
+__global__ void k_add_into(int64_t n, const double* __restrict__ a, double* __restrict__ b) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) b[i] += a[i];
+}
+
+__global__ void k_bc_set_rhs(int64_t n, int64_t n_rows, const int32_t* __restrict__ dofs, const double* __restrict__ g,
+                             const double* __restrict__ u, double* __restrict__ b) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t d = dofs[i];
+    if (d < n_rows) b[d] = u[d] - g[i];
+  }
+}
+
+__global__ void k_export_rows(int64_t n_rows, const int64_t* __restrict__ mptr, const int32_t* __restrict__ cols,
+                              const int32_t* __restrict__ rowlen, const double* __restrict__ diag,
+                              const double* __restrict__ vals, const int64_t* __restrict__ rowptr,
+                              int32_t* __restrict__ ocol, double* __restrict__ oval) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n_rows) return;
+  const int64_t base = mptr[row >> 6];
+  const int lane = (int)(row & 63);
+  const int len = rowlen[row];
+  int64_t o = rowptr[row];
+  bool placed = false;
+  for (int k = 0; k < len; ++k) {
+    const int64_t e = femo_sell_index(base, k, lane);
+    const int32_t c = cols[e];
+    if (!placed && c > row) {
+      ocol[o] = (int32_t)row; oval[o] = diag[row]; ++o; placed = true;
+    }
+    ocol[o] = c; oval[o] = vals[e]; ++o;
+  }
+  if (!placed) { ocol[o] = (int32_t)row; oval[o] = diag[row]; }
+}
+
+inline unsigned grid_for(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+template <class T>
+int upload(T** dptr, const std::vector<T>& h, hipStream_t st) {
+  const size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+  FEMO_HIP_CHECK(hipMalloc(dptr, bytes + 64));
+  if (!h.empty()) FEMO_HIP_CHECK(hipMemcpyAsync(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int femo_abi_version(void) { return FEMO_ABI_VERSION; }
+
+int femo_device_count(int* n) {
+  FEMO_REQUIRE(n != nullptr, "null argument");
+  hipError_t e = hipGetDeviceCount(n);
+  if (e != hipSuccess) {
+    *n = 0;
+    femo_set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+    return 1;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------ ctx -----
+int femo_ctx_create(int device_id, void* stream, femo_ctx** out) {
+  FEMO_REQUIRE(out != nullptr, "null argument");
+  *out = nullptr;
+  int ndev = 0;
+  FEMO_HIP_CHECK(hipGetDeviceCount(&ndev));
+  FEMO_REQUIRE(ndev > 0, "no HIP device visible: libfemo_hip has no CPU fallback");
+  FEMO_REQUIRE(device_id >= 0 && device_id < ndev, "device %d out of range (%d visible)", device_id, ndev);
+  FEMO_HIP_CHECK(hipSetDevice(device_id));
+  femo_ctx* c = new femo_ctx();
+  c->device = device_id;
+  if (stream) {
+    c->stream = reinterpret_cast<hipStream_t>(stream);
+  } else {
+    FEMO_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+  hipDeviceProp_t prop;
+  FEMO_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+  c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  FEMO_HIP_CHECK(hipMalloc(&c->d_partials, 4 * FEMO_MAX_PARTIALS * sizeof(double)));
+  FEMO_HIP_CHECK(hipMalloc(&c->d_scal, FEMO_NSCAL * sizeof(double)));
+  FEMO_HIP_CHECK(hipMalloc(&c->d_flags, 8 * sizeof(int32_t)));
+  FEMO_HIP_CHECK(hipMemsetAsync(c->d_flags, 0, 8 * sizeof(int32_t), c->stream));
+  FEMO_HIP_CHECK(hipHostMalloc(&c->h_scal, (FEMO_NSCAL + 8) * sizeof(double), hipHostMallocDefault));
+  FEMO_HIP_CHECK(hipEventCreate(&c->ev0));
+  FEMO_HIP_CHECK(hipEventCreate(&c->ev1));
+  c->ev_pool.resize(16);
+  for (auto& e : c->ev_pool) FEMO_HIP_CHECK(hipEventCreate(&e));
+  *out = c;
+  return 0;
+}
+
+int femo_ctx_destroy(femo_ctx* c) {
+  if (!c) return 0;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  if (c->comm) ncclCommDestroy(c->comm);
+  hipFree(c->d_partials); hipFree(c->d_scal); hipFree(c->d_flags);
+  hipFree(c->cg_r); hipFree(c->cg_p); hipFree(c->cg_q); hipFree(c->cg_dinv);
+  hipHostFree(c->h_scal);
+  hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
+  for (auto& e : c->ev_pool) hipEventDestroy(e);
+  if (c->own_stream) hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+int femo_ctx_sync(femo_ctx* c) {
+  FEMO_REQUIRE(c != nullptr, "null context");
+  FEMO_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+void* femo_ctx_stream(femo_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+// ------------------------------------------------------------------ vec -----
+int femo_vec_create(femo_ctx* ctx, int64_t n, femo_vec** out) {
+  FEMO_REQUIRE(ctx && out && n >= 0, "bad argument");
+  FEMO_HIP_CHECK(hipSetDevice(ctx->device));
+  femo_vec* v = new femo_vec();
+  v->ctx = ctx; v->n = n; v->owned = true;
+  FEMO_HIP_CHECK(hipMalloc(&v->d, (n + 2) * sizeof(double)));
+  FEMO_HIP_CHECK(hipMemsetAsync(v->d, 0, (n + 2) * sizeof(double), ctx->stream));
+  *out = v;
+  return 0;
+}
+
+int femo_vec_wrap(femo_ctx* ctx, void* device_ptr, int64_t n, femo_vec** out) {
+  FEMO_REQUIRE(ctx && out && device_ptr && n >= 0, "bad argument");
+  FEMO_REQUIRE((reinterpret_cast<uintptr_t>(device_ptr) & 15) == 0, "wrapped pointer must be 16-byte aligned");
+  femo_vec* v = new femo_vec();
+  v->ctx = ctx; v->n = n; v->owned = false; v->d = static_cast<double*>(device_ptr);
+  *out = v;
+  return 0;
+}
+
+int femo_vec_destroy(femo_vec* v) {
+  if (!v) return 0;
+  if (v->owned && v->d) {
+    hipStreamSynchronize(v->ctx->stream);
+    hipFree(v->d);
+  }
+  delete v;
+  return 0;
+}
+
+int64_t femo_vec_size(const femo_vec* v) { return v ? v->n : -1; }
+void* femo_vec_device_ptr(femo_vec* v) { return v ? v->d : nullptr; }
+
+int femo_vec_set_host(femo_vec* v, const double* host, int64_t n) {
+  FEMO_REQUIRE(v && host, "null argument");
+  FEMO_REQUIRE(n == v->n, "size mismatch: vector has %lld entries, host array %lld", (long long)v->n, (long long)n);
+  FEMO_HIP_CHECK(hipMemcpyAsync(v->d, host, n * sizeof(double), hipMemcpyHostToDevice, v->ctx->stream));
+  FEMO_HIP_CHECK(hipStreamSynchronize(v->ctx->stream));
+  return 0;
+}
+
+int femo_vec_get_host(const femo_vec* v, double* host, int64_t n) {
+  FEMO_REQUIRE(v && host, "null argument");
+  FEMO_REQUIRE(n <= v->n, "size mismatch: vector has %lld entries, host array %lld", (long long)v->n, (long long)n);
+  FEMO_HIP_CHECK(hipMemcpyAsync(host, v->d, n * sizeof(double), hipMemcpyDeviceToHost, v->ctx->stream));
+  FEMO_HIP_CHECK(hipStreamSynchronize(v->ctx->stream));
+  return 0;
+}
+
+int femo_vec_fill(femo_vec* v, double value) {
+  FEMO_REQUIRE(v != nullptr, "null argument");
+  if (v->n == 0) return 0;
+  hipLaunchKernelGGL(k_fill, dim3(grid_for(v->n)), dim3(256), 0, v->ctx->stream, v->n, value, v->d);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int femo_vec_copy(femo_vec* dst, const femo_vec* src) {
+  FEMO_REQUIRE(dst && src, "null argument");
+  FEMO_REQUIRE(dst->n == src->n, "size mismatch in vec_copy");
+  FEMO_HIP_CHECK(hipMemcpyAsync(dst->d, src->d, src->n * sizeof(double), hipMemcpyDeviceToDevice, dst->ctx->stream));
+  return 0;
+}
+
+int femo_vec_axpy(femo_vec* y, double a, const femo_vec* x) {
+  FEMO_REQUIRE(y && x, "null argument");
+  FEMO_REQUIRE(y->n == x->n, "size mismatch in vec_axpy");
+  if (y->n == 0) return 0;
+  hipLaunchKernelGGL(k_axpy, dim3(grid_for(y->n)), dim3(256), 0, y->ctx->stream, y->n, a, x->d, y->d);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ----------------------------------------------------------------- mesh -----
+int femo_mesh_create(femo_ctx* ctx, int tdim, int64_t n_vert, int64_t n_rows, const double* x,
+                     int64_t n_cell, const int32_t* conn, femo_mesh** out) {
+  FEMO_REQUIRE(ctx && x && conn && out, "null argument");
+  FEMO_HIP_CHECK(hipSetDevice(ctx->device));
+  FemoTopology T;
+  FEMO_TRY(femo_build_topology(tdim, n_vert, n_rows, n_cell, conn, T));
+  femo_mesh* m = new femo_mesh();
+  m->ctx = ctx; m->tdim = tdim; m->n_vert = n_vert; m->n_rows = n_rows; m->n_cell = n_cell;
+  m->n_slices = T.n_slices; m->nnz = T.nnz; m->sell_entries = T.mptr[T.n_slices];
+  m->visit_entries = T.vptr[T.n_slices]; m->max_rowlen = T.max_rowlen; m->max_valence = T.max_valence;
+  m->h_mptr = T.mptr;
+  hipStream_t st = ctx->stream;
+  FEMO_HIP_CHECK(hipMalloc(&m->d_x, std::max<int64_t>(n_vert * tdim, 1) * sizeof(double) + 64));
+  FEMO_HIP_CHECK(hipMemcpyAsync(m->d_x, x, n_vert * tdim * sizeof(double), hipMemcpyHostToDevice, st));
+  FEMO_HIP_CHECK(hipMalloc(&m->d_conn, std::max<int64_t>(n_cell * (tdim + 1), 1) * sizeof(int32_t) + 64));
+  FEMO_HIP_CHECK(hipMemcpyAsync(m->d_conn, conn, n_cell * (tdim + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  FEMO_TRY(upload(&m->d_vptr, T.vptr, st));
+  FEMO_TRY(upload(&m->d_visit_cell, T.visit_cell, st));
+  FEMO_TRY(upload(&m->d_visit_slots, T.visit_slots, st));
+  FEMO_TRY(upload(&m->d_mptr, T.mptr, st));
+  FEMO_TRY(upload(&m->d_cols, T.cols, st));
+  FEMO_TRY(upload(&m->d_rowlen, T.rowlen, st));
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));  // T's host buffers die with this scope
+  *out = m;
+  return 0;
+}
+
+int femo_mesh_destroy(femo_mesh* m) {
+  if (!m) return 0;
+  hipStreamSynchronize(m->ctx->stream);
+  hipFree(m->d_x); hipFree(m->d_conn); hipFree(m->d_vptr); hipFree(m->d_visit_cell);
+  hipFree(m->d_visit_slots); hipFree(m->d_mptr); hipFree(m->d_cols); hipFree(m->d_rowlen);
+  hipFree(m->d_tperm); hipFree(m->d_send_idx); hipFree(m->d_send_buf);
+  delete m;
+  return 0;
+}
+
+int femo_mesh_info(const femo_mesh* m, int64_t info[FEMO_MESH_INFO_COUNT]) {
+  FEMO_REQUIRE(m && info, "null argument");
+  info[FEMO_MESH_TDIM] = m->tdim;
+  info[FEMO_MESH_N_VERT] = m->n_vert;
+  info[FEMO_MESH_N_ROWS] = m->n_rows;
+  info[FEMO_MESH_N_CELL] = m->n_cell;
+  info[FEMO_MESH_NNZ] = m->nnz;
+  info[FEMO_MESH_SELL_ENTRIES] = m->sell_entries;
+  info[FEMO_MESH_MAX_ROWLEN] = m->max_rowlen;
+  info[FEMO_MESH_MAX_VALENCE] = m->max_valence;
+  info[FEMO_MESH_N_SLICES] = m->n_slices;
+  info[FEMO_MESH_VISIT_ENTRIES] = m->visit_entries;
+  return 0;
+}
+
+static int pattern_rowptr(const femo_mesh* m, std::vector<int64_t>& rowptr) {
+  std::vector<int32_t> rl(m->n_slices * FEMO_WAVE);
+  if (!rl.empty()) {
+    FEMO_HIP_CHECK(hipMemcpyAsync(rl.data(), m->d_rowlen, rl.size() * sizeof(int32_t), hipMemcpyDeviceToHost, m->ctx->stream));
+    FEMO_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+  }
+  rowptr.assign(m->n_rows + 1, 0);
+  for (int64_t v = 0; v < m->n_rows; ++v) rowptr[v + 1] = rowptr[v] + rl[v] + 1;
+  return 0;
+}
+
+// ------------------------------------------------------------------- bc -----
+int femo_bc_create(femo_mesh* m, int64_t n, const int32_t* dofs, const double* vals, femo_bc** out) {
+  FEMO_REQUIRE(m && out && n >= 0 && (n == 0 || (dofs && vals)), "bad argument");
+  for (int64_t i = 0; i < n; ++i)
+    FEMO_REQUIRE(dofs[i] >= 0 && dofs[i] < m->n_vert, "Dirichlet dof %d out of range", dofs[i]);
+  femo_bc* b = new femo_bc();
+  b->mesh = m; b->n = n;
+  hipStream_t st = m->ctx->stream;
+  FEMO_HIP_CHECK(hipMalloc(&b->d_dofs, std::max<int64_t>(n, 1) * sizeof(int32_t)));
+  FEMO_HIP_CHECK(hipMalloc(&b->d_vals, std::max<int64_t>(n, 1) * sizeof(double)));
+  FEMO_HIP_CHECK(hipMalloc(&b->d_mask, std::max<int64_t>(m->n_vert, 1) + 64));
+  FEMO_HIP_CHECK(hipMemsetAsync(b->d_mask, 0, std::max<int64_t>(m->n_vert, 1) + 64, st));
+  if (n > 0) {
+    FEMO_HIP_CHECK(hipMemcpyAsync(b->d_dofs, dofs, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    FEMO_HIP_CHECK(hipMemcpyAsync(b->d_vals, vals, n * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_bc_mask, dim3(grid_for(n)), dim3(256), 0, st, n, b->d_dofs, b->d_mask);
+    FEMO_HIP_CHECK(hipGetLastError());
+  }
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  *out = b;
+  return 0;
+}
+
+int femo_bc_destroy(femo_bc* b) {
+  if (!b) return 0;
+  hipStreamSynchronize(b->mesh->ctx->stream);
+  hipFree(b->d_dofs); hipFree(b->d_vals); hipFree(b->d_mask);
+  delete b;
+  return 0;
+}
+
+// ------------------------------------------------------------------ mat -----
+int femo_mat_create(femo_mesh* m, femo_mat** out) {
+  FEMO_REQUIRE(m && out, "null argument");
+  femo_mat* A = new femo_mat();
+  A->mesh = m;
+  const int64_t nd = std::max<int64_t>(m->n_slices * FEMO_WAVE, 1);
+  FEMO_HIP_CHECK(hipMalloc(&A->d_diag, nd * sizeof(double)));
+  FEMO_HIP_CHECK(hipMalloc(&A->d_vals, std::max<int64_t>(m->sell_entries, 1) * sizeof(double) + 64));
+  FEMO_HIP_CHECK(hipMemsetAsync(A->d_diag, 0, nd * sizeof(double), m->ctx->stream));
+  FEMO_HIP_CHECK(hipMemsetAsync(A->d_vals, 0, std::max<int64_t>(m->sell_entries, 1) * sizeof(double), m->ctx->stream));
+  *out = A;
+  return 0;
+}
+
+int femo_mat_destroy(femo_mat* A) {
+  if (!A) return 0;
+  hipStreamSynchronize(A->mesh->ctx->stream);
+  hipFree(A->d_diag); hipFree(A->d_vals); hipFree(A->d_valsT);
+  delete A;
+  return 0;
+}
+
+int femo_assemble_residual(femo_mesh* m, int pde, const double* params, const femo_vec* u,
+                           const femo_vec* f, femo_vec* r) {
+  FEMO_REQUIRE(m && u && f && r, "null argument");
+  FEMO_REQUIRE(u->n >= m->n_vert && f->n >= m->n_cell && r->n >= m->n_rows, "vector size mismatch in assemble_residual");
+  if (m->n_nbr > 0) FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(u)));
+  return femo_launch_residual(m, pde, params, u->d, f->d, r->d);
+}
+
+int femo_assemble_jacobian(femo_mesh* m, int pde, const double* params, const femo_vec* u,
+                           const femo_vec* f, const femo_bc* bc, femo_mat* J) {
+  FEMO_REQUIRE(m && J, "null argument");
+  FEMO_REQUIRE(J->mesh == m, "matrix belongs to another mesh");
+  FEMO_REQUIRE(bc == nullptr || bc->mesh == m, "Dirichlet set belongs to another mesh");
+  J->valsT_valid = false;
+  return femo_launch_jacobian(m, pde, params, u ? u->d : nullptr, f ? f->d : nullptr,
+                              bc ? bc->d_mask : nullptr, J->d_diag, J->d_vals);
+}
+
+int femo_assemble_dRdf(femo_mesh* m, int pde, const double* params, const femo_vec* u,
+                       const femo_vec* f, femo_vec* vals) {
+  FEMO_REQUIRE(m && vals, "null argument");
+  FEMO_REQUIRE(vals->n >= m->n_cell * (m->tdim + 1), "dRdf value buffer too small");
+  return femo_launch_dRdf(m, pde, params, u ? u->d : nullptr, f ? f->d : nullptr, vals->d);
+}
+
+int femo_newton_rhs(const femo_mat* K, const femo_vec* F, const femo_vec* u, const femo_bc* bc, femo_vec* b) {
+  FEMO_REQUIRE(K && F && u && bc && b, "null argument");
+  femo_mesh* m = K->mesh;
+  femo_ctx* ctx = m->ctx;
+  FEMO_REQUIRE(u->n >= m->n_vert && F->n >= m->n_rows && b->n >= m->n_rows, "vector size mismatch in newton_rhs");
+  FEMO_REQUIRE(b->d != F->d, "newton_rhs cannot run in place");
+  // w (n_vert) lives in the CG p-workspace? keep it simple: a scratch vector
+  femo_vec* w = nullptr;
+  FEMO_TRY(femo_vec_create(ctx, m->n_vert, &w));
+  if (bc->n > 0) {
+    hipLaunchKernelGGL(k_bc_lift_vec, dim3(grid_for(bc->n)), dim3(256), 0, ctx->stream, bc->n, bc->d_dofs, bc->d_vals, u->d, w->d);
+  }
+  int rc = femo_launch_spmv(K, K->d_vals, w->d, b->d, nullptr);
+  if (rc == 0 && m->n_rows > 0) {
+    hipLaunchKernelGGL(k_add_into, dim3(grid_for(m->n_rows)), dim3(256), 0, ctx->stream, m->n_rows, F->d, b->d);
+    if (bc->n > 0)
+      hipLaunchKernelGGL(k_bc_set_rhs, dim3(grid_for(bc->n)), dim3(256), 0, ctx->stream, bc->n, m->n_rows, bc->d_dofs, bc->d_vals, u->d, b->d);
+  }
+  hipError_t e = hipGetLastError();
+  femo_vec_destroy(w);
+  if (rc) return rc;
+  FEMO_HIP_CHECK(e);
+  return 0;
+}
+
+int femo_dRdf_apply(femo_mesh* m, const femo_vec* vals, int transpose, const femo_vec* x, femo_vec* y, int accumulate) {
+  FEMO_REQUIRE(m && vals && x && y, "null argument");
+  FEMO_REQUIRE(vals->n >= m->n_cell * (m->tdim + 1), "dRdf value buffer too small");
+  if (transpose) {
+    FEMO_REQUIRE(x->n >= m->n_vert && y->n >= m->n_cell, "vector size mismatch in dRdf^T apply");
+    if (m->n_nbr > 0) FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(x)));
+  } else {
+    FEMO_REQUIRE(x->n >= m->n_cell && y->n >= m->n_rows, "vector size mismatch in dRdf apply");
+  }
+  return femo_launch_dRdf_apply(m, vals->d, transpose, x->d, y->d, accumulate);
+}
+
+int femo_mesh_pattern_csr(const femo_mesh* m, int64_t* rowptr, int32_t* col) {
+  FEMO_REQUIRE(m && rowptr, "null argument");
+  std::vector<int64_t> rp;
+  FEMO_TRY(pattern_rowptr(m, rp));
+  std::copy(rp.begin(), rp.end(), rowptr);
+  if (!col) return 0;
+  // reuse the matrix exporter with throw-away values
+  femo_mat* A = nullptr;
+  FEMO_TRY(femo_mat_create(const_cast<femo_mesh*>(m), &A));
+  std::vector<double> val(m->nnz);
+  int rc = femo_mat_export_csr(A, rowptr, col, val.data());
+  femo_mat_destroy(A);
+  return rc;
+}
+
+int femo_mat_export_csr(const femo_mat* A, int64_t* rowptr, int32_t* col, double* val) {
+  FEMO_REQUIRE(A && rowptr && col && val, "null argument");
+  const femo_mesh* m = A->mesh;
+  hipStream_t st = m->ctx->stream;
+  std::vector<int64_t> rp;
+  FEMO_TRY(pattern_rowptr(m, rp));
+  std::copy(rp.begin(), rp.end(), rowptr);
+  if (m->n_rows == 0) return 0;
+  int64_t* d_rp = nullptr; int32_t* d_col = nullptr; double* d_val = nullptr;
+  FEMO_HIP_CHECK(hipMalloc(&d_rp, rp.size() * sizeof(int64_t)));
+  FEMO_HIP_CHECK(hipMalloc(&d_col, m->nnz * sizeof(int32_t)));
+  FEMO_HIP_CHECK(hipMalloc(&d_val, m->nnz * sizeof(double)));
+  FEMO_HIP_CHECK(hipMemcpyAsync(d_rp, rp.data(), rp.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_export_rows, dim3((unsigned)((m->n_rows + 255) / 256)), dim3(256), 0, st, m->n_rows, m->d_mptr, m->d_cols, m->d_rowlen, A->d_diag, A->d_vals, d_rp, d_col, d_val);
+  FEMO_HIP_CHECK(hipGetLastError());
+  FEMO_HIP_CHECK(hipMemcpyAsync(col, d_col, m->nnz * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  FEMO_HIP_CHECK(hipMemcpyAsync(val, d_val, m->nnz * sizeof(double), hipMemcpyDeviceToHost, st));
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  hipFree(d_rp); hipFree(d_col); hipFree(d_val);
+  return 0;
+}
+
+int femo_mat_diagonal(const femo_mat* A, femo_vec* d) {
+  FEMO_REQUIRE(A && d, "null argument");
+  FEMO_REQUIRE(d->n >= A->mesh->n_rows, "vector too small");
+  FEMO_HIP_CHECK(hipMemcpyAsync(d->d, A->d_diag, A->mesh->n_rows * sizeof(double), hipMemcpyDeviceToDevice, A->mesh->ctx->stream));
+  return 0;
+}
+
+// ----------------------------------------------------------- functional -----
+int femo_functional_value(femo_mesh* m, int kind, const double* params, const femo_vec* u,
+                          const femo_vec* f, const femo_vec* u_d, double* value) {
+  FEMO_REQUIRE(m && u && f && u_d && value, "null argument");
+  FEMO_REQUIRE(u->n >= m->n_vert && u_d->n >= m->n_vert && f->n >= m->n_cell, "vector size mismatch in functional");
+  if (m->n_nbr > 0) FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(u)));
+  return femo_launch_functional_value(m, kind, params, u->d, f->d, u_d->d, value);
+}
+
+int femo_functional_grad_u(femo_mesh* m, int kind, const double* params, const femo_vec* u,
+                           const femo_vec* f, const femo_vec* u_d, femo_vec* g) {
+  FEMO_REQUIRE(m && u && u_d && g, "null argument");
+  FEMO_REQUIRE(u->n >= m->n_vert && u_d->n >= m->n_vert && g->n >= m->n_rows, "vector size mismatch in functional grad_u");
+  if (m->n_nbr > 0) FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(u)));
+  return femo_launch_functional_grad_u(m, kind, params, u->d, f ? f->d : nullptr, u_d->d, g->d);
+}
+
+int femo_functional_grad_f(femo_mesh* m, int kind, const double* params, const femo_vec* u,
+                           const femo_vec* f, const femo_vec* u_d, femo_vec* g) {
+  FEMO_REQUIRE(m && f && g, "null argument");
+  FEMO_REQUIRE(f->n >= m->n_cell && g->n >= m->n_cell, "vector size mismatch in functional grad_f");
+  return femo_launch_functional_grad_f(m, kind, params, u ? u->d : nullptr, f->d, u_d ? u_d->d : nullptr, g->d);
+}
+
+// ----------------------------------------------------------------- comm -----
+int femo_comm_unique_id(char id[128]) {
+  FEMO_REQUIRE(id != nullptr, "null argument");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId u;
+  FEMO_NCCL_CHECK(ncclGetUniqueId(&u));
+  memcpy(id, &u, 128);
+  return 0;
+}
+
+int femo_comm_init(femo_ctx* ctx, const char id[128], int rank, int nranks) {
+  FEMO_REQUIRE(ctx && id, "null argument");
+  FEMO_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank %d of %d", rank, nranks);
+  FEMO_REQUIRE(ctx->comm == nullptr, "communicator already initialised");
+  FEMO_HIP_CHECK(hipSetDevice(ctx->device));
+  ncclUniqueId u;
+  memcpy(&u, id, 128);
+  FEMO_NCCL_CHECK(ncclCommInitRank(&ctx->comm, nranks, u, rank));
+  ctx->rank = rank;
+  ctx->nranks = nranks;
+  return 0;
+}
+
+int femo_comm_rank(const femo_ctx* ctx, int* rank, int* nranks) {
+  FEMO_REQUIRE(ctx && rank && nranks, "null argument");
+  *rank = ctx->rank;
+  *nranks = ctx->nranks;
+  return 0;
+}
+
+int femo_mesh_set_halo(femo_mesh* m, int n_nbr, const int32_t* nbr, const int64_t* send_ptr,
+                       const int32_t* send_idx, const int64_t* recv_ptr) {
+  FEMO_REQUIRE(m && n_nbr >= 0, "bad argument");
+  FEMO_REQUIRE(n_nbr == 0 || (nbr && send_ptr && recv_ptr), "null halo plan");
+  hipFree(m->d_send_idx); hipFree(m->d_send_buf);
+  m->d_send_idx = nullptr; m->d_send_buf = nullptr;
+  m->n_nbr = n_nbr;
+  m->nbr.assign(nbr, nbr + n_nbr);
+  m->send_ptr.assign(send_ptr, send_ptr + n_nbr + (n_nbr ? 1 : 0));
+  m->recv_ptr.assign(recv_ptr, recv_ptr + n_nbr + (n_nbr ? 1 : 0));
+  if (n_nbr == 0) return 0;
+  const int64_t ns = send_ptr[n_nbr], nr = recv_ptr[n_nbr];
+  FEMO_REQUIRE(nr == m->n_vert - m->n_rows, "halo plan receives %lld values but the mesh has %lld ghosts",
+               (long long)nr, (long long)(m->n_vert - m->n_rows));
+  for (int64_t i = 0; i < ns; ++i)
+    FEMO_REQUIRE(send_idx[i] >= 0 && send_idx[i] < m->n_rows, "halo send index out of the owned range");
+  FEMO_HIP_CHECK(hipMalloc(&m->d_send_idx, std::max<int64_t>(ns, 1) * sizeof(int32_t)));
+  FEMO_HIP_CHECK(hipMalloc(&m->d_send_buf, std::max<int64_t>(ns, 1) * sizeof(double)));
+  if (ns > 0) {
+    FEMO_HIP_CHECK(hipMemcpyAsync(m->d_send_idx, send_idx, ns * sizeof(int32_t), hipMemcpyHostToDevice, m->ctx->stream));
+    FEMO_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+  }
+  return 0;
+}
+
+int femo_allreduce_sum(femo_ctx* ctx, double* host_inout, int n) {
+  FEMO_REQUIRE(ctx && host_inout && n >= 0 && n <= FEMO_NSCAL, "bad argument");
+  if (ctx->nranks == 1 || n == 0) return 0;
+  memcpy(ctx->h_scal, host_inout, n * sizeof(double));
+  FEMO_HIP_CHECK(hipMemcpyAsync(ctx->d_scal, ctx->h_scal, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  FEMO_NCCL_CHECK(ncclAllReduce(ctx->d_scal, ctx->d_scal, n, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+  FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  FEMO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  memcpy(host_inout, ctx->h_scal, n * sizeof(double));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,493 @@
+// Element-local P1 quadrature kernels for gfx950: residual, dR/du, dR/df,
+// functional and its partials.
+//
+// Design: "owner computes".  One lane owns one matrix row /
+// vector entry (= one vertex) and walks the cells incident to it through the
+// SELL-64 vertex->cell incidence, so consecutive lanes stream consecutive
+// words of the incidence (coalesced), element geometry is recomputed in
+// registers from gathered coordinates (L2-resident), and every output word is
+// written exactly once by its owner: no fp64 atomics, bitwise reproducible,
+// and K[i][j] == K[j][i] bitwise because both rows evaluate vol * g_a.g_b from
+// the same canonical cell ordering in the same (sorted) cell order.
+//
+// Replaces, per call site of the reference:
+//   residual  -> utils_dolfinx.py:175-179 assembleVector   (state_model.py:85)
+//   jacobian  -> utils_dolfinx.py:181-187 assembleMatrix   (state_model.py:132)
+//                utils_dolfinx.py:189-202 assembleSystem   (state_model.py:149)
+//   dRdf      -> state_model.py:141 assembleMatrix(computePartials(res, f))
+//   functional value / partials -> output_model.py:69-87
+#include "femo_internal.h"
+
+namespace {
+
+template <int D>
+struct CellGeom {
+  double vol;
+  double g[D + 1][D];
+};
+
+template <int D>
+__device__ __forceinline__ void load_conn(const int32_t* __restrict__ conn, int64_t c, int32_t v[D + 1]) {
+  if constexpr (D == 3) {
+    const int4 q = *reinterpret_cast<const int4*>(conn + c * 4);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+  } else {
+    v[0] = conn[c * 3 + 0]; v[1] = conn[c * 3 + 1]; v[2] = conn[c * 3 + 2];
+  }
+}
+
+template <int D>
+__device__ __forceinline__ void cell_geom(const double* __restrict__ x, const int32_t v[D + 1], CellGeom<D>& G) {
+  if constexpr (D == 3) {
+    double p[4][3];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const double* q = x + (int64_t)v[a] * 3;
+      p[a][0] = q[0]; p[a][1] = q[1]; p[a][2] = q[2];
+    }
+    double e1[3], e2[3], e3[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      e1[k] = p[1][k] - p[0][k];
+      e2[k] = p[2][k] - p[0][k];
+      e3[k] = p[3][k] - p[0][k];
+    }
+    double c1[3] = {e2[1] * e3[2] - e2[2] * e3[1], e2[2] * e3[0] - e2[0] * e3[2], e2[0] * e3[1] - e2[1] * e3[0]};
+    double c2[3] = {e3[1] * e1[2] - e3[2] * e1[1], e3[2] * e1[0] - e3[0] * e1[2], e3[0] * e1[1] - e3[1] * e1[0]};
+    double c3[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const double det = e1[0] * c1[0] + e1[1] * c1[1] + e1[2] * c1[2];
+    const double inv = 1.0 / det;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      G.g[1][k] = c1[k] * inv;
+      G.g[2][k] = c2[k] * inv;
+      G.g[3][k] = c3[k] * inv;
+      G.g[0][k] = -(G.g[1][k] + G.g[2][k] + G.g[3][k]);
+    }
+    G.vol = fabs(det) * (1.0 / 6.0);
+  } else {
+    double p[3][2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double* q = x + (int64_t)v[a] * 2;
+      p[a][0] = q[0]; p[a][1] = q[1];
+    }
+    const double a = p[1][0] - p[0][0], b = p[1][1] - p[0][1];
+    const double c = p[2][0] - p[0][0], d = p[2][1] - p[0][1];
+    const double det = a * d - b * c;
+    const double inv = 1.0 / det;
+    G.g[1][0] = d * inv;  G.g[1][1] = -c * inv;
+    G.g[2][0] = -b * inv; G.g[2][1] = a * inv;
+    G.g[0][0] = -(G.g[1][0] + G.g[2][0]);
+    G.g[0][1] = -(G.g[1][1] + G.g[2][1]);
+    G.vol = fabs(det) * 0.5;
+  }
+}
+
+template <int D>
+__device__ __forceinline__ void select_row(const CellGeom<D>& G, int a, double ga[D]) {
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    double s = G.g[0][k];
+#pragma unroll
+    for (int b = 1; b <= D; ++b) s = (a == b) ? G.g[b][k] : s;
+    ga[k] = s;
+  }
+}
+
+template <int D>
+__device__ __forceinline__ double dotD(const double* p, const double* q) {
+  double s = p[0] * q[0];
+#pragma unroll
+  for (int k = 1; k < D; ++k) s += p[k] * q[k];
+  return s;
+}
+
+// ---------------------------------------------------------------- residual --
+template <int D, int PDE>
+__global__ __launch_bounds__(FEMO_BLOCK) void k_residual(
+    int64_t n_rows, int64_t n_blocks, const int64_t* __restrict__ vptr,
+    const int32_t* __restrict__ visit_cell, const int32_t* __restrict__ conn,
+    const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ f,
+    double* __restrict__ r) {
+  const int64_t blk = femo_xcd_block(blockIdx.x, n_blocks);
+  const int64_t row = blk * FEMO_BLOCK + threadIdx.x;
+  const int64_t slice = row >> 6;
+  const int lane = threadIdx.x & 63;
+  if ((slice << 6) >= n_rows) return;
+  const int64_t vb = vptr[slice];
+  const int nvis = (int)((vptr[slice + 1] - vb) >> 6);
+  double acc = 0.0;
+  for (int s = 0; s < nvis; ++s) {
+    const int32_t ca = visit_cell[vb + (int64_t)s * 64 + lane];
+    if (ca < 0) continue;
+    const int64_t c = ca >> 2;
+    const int a = ca & 3;
+    int32_t v[D + 1];
+    load_conn<D>(conn, c, v);
+    CellGeom<D> G;
+    cell_geom<D>(x, v, G);
+    double gu[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) gu[k] = 0.0;
+#pragma unroll
+    for (int b = 0; b <= D; ++b) {
+      const double ub = u[v[b]];
+#pragma unroll
+      for (int k = 0; k < D; ++k) gu[k] += G.g[b][k] * ub;
+    }
+    double ga[D];
+    select_row<D>(G, a, ga);
+    acc += G.vol * dotD<D>(ga, gu) - f[c] * G.vol * (1.0 / (D + 1));
+  }
+  if (row < n_rows) r[row] = acc;
+}
+
+// ---------------------------------------------------------------- jacobian --
+// LDS strip acc[k][tid]: bank = (k*256 + tid)*2 mod 64 depends on tid only ->
+// conflict-free for any per-lane k.
+template <int D, int PDE>
+__global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
+    int64_t n_rows, int64_t n_blocks, int cap, const int64_t* __restrict__ vptr,
+    const int32_t* __restrict__ visit_cell, const uint32_t* __restrict__ visit_slots,
+    const int64_t* __restrict__ mptr, const int32_t* __restrict__ cols,
+    const int32_t* __restrict__ rowlen, const int32_t* __restrict__ conn,
+    const double* __restrict__ x, const double* __restrict__ u, const uint8_t* __restrict__ bcmask,
+    double* __restrict__ diag, double* __restrict__ vals) {
+  extern __shared__ double strip[];
+  const int tid = threadIdx.x;
+  const int64_t blk = femo_xcd_block(blockIdx.x, n_blocks);
+  const int64_t row = blk * FEMO_BLOCK + tid;
+  const int64_t slice = row >> 6;
+  const int lane = tid & 63;
+  if ((slice << 6) >= n_rows) return;
+  const int len = rowlen[row];
+  for (int k = 0; k < len; ++k) strip[k * FEMO_BLOCK + tid] = 0.0;
+  const int64_t vb = vptr[slice];
+  const int nvis = (int)((vptr[slice + 1] - vb) >> 6);
+  double dsum = 0.0;
+  for (int s = 0; s < nvis; ++s) {
+    const int64_t vi = vb + (int64_t)s * 64 + lane;
+    const int32_t ca = visit_cell[vi];
+    if (ca < 0) continue;
+    const uint32_t slots = visit_slots[vi];
+    const int64_t c = ca >> 2;
+    const int a = ca & 3;
+    int32_t v[D + 1];
+    load_conn<D>(conn, c, v);
+    CellGeom<D> G;
+    cell_geom<D>(x, v, G);
+    double ga[D];
+    select_row<D>(G, a, ga);
+#pragma unroll
+    for (int b = 0; b <= D; ++b) {
+      const double kab = G.vol * dotD<D>(ga, G.g[b]);
+      if (b == a) {
+        dsum += kab;
+      } else {
+        const int pos = (slots >> (8 * b)) & 0xFF;
+        strip[pos * FEMO_BLOCK + tid] += kab;
+      }
+    }
+  }
+  const bool row_bc = bcmask != nullptr && row < n_rows && bcmask[row];
+  if (row < n_rows) diag[row] = row_bc ? 1.0 : dsum;
+  else diag[row] = 1.0;  // padded rows of the last slice: harmless identity
+  const int64_t mb = mptr[slice];
+  const int wm = (int)((mptr[slice + 1] - mb) >> 6);
+  for (int k = 0; k < wm; k += 2) {
+    const int64_t idx = mb + (int64_t)(k >> 1) * 128 + lane * 2;
+    double2 o;
+    o.x = k < len ? strip[k * FEMO_BLOCK + tid] : 0.0;
+    o.y = (k + 1) < len ? strip[(k + 1) * FEMO_BLOCK + tid] : 0.0;
+    if (bcmask != nullptr) {
+      const int2 cc = *reinterpret_cast<const int2*>(cols + idx);
+      if (row_bc || bcmask[cc.x]) o.x = 0.0;
+      if (row_bc || bcmask[cc.y]) o.y = 0.0;
+    }
+    *reinterpret_cast<double2*>(vals + idx) = o;
+  }
+}
+
+// -------------------------------------------------------------------- dRdf --
+template <int D, int PDE>
+__global__ __launch_bounds__(FEMO_BLOCK) void k_dRdf(int64_t n_cell, const int32_t* __restrict__ conn,
+                                                     const double* __restrict__ x,
+                                                     double* __restrict__ vals) {
+  for (int64_t c = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; c < n_cell;
+       c += (int64_t)gridDim.x * FEMO_BLOCK) {
+    int32_t v[D + 1];
+    load_conn<D>(conn, c, v);
+    CellGeom<D> G;
+    cell_geom<D>(x, v, G);
+    const double w = -G.vol * (1.0 / (D + 1));
+    if constexpr (D == 3) {
+      double2 o = {w, w};
+      *reinterpret_cast<double2*>(vals + c * 4) = o;
+      *reinterpret_cast<double2*>(vals + c * 4 + 2) = o;
+    } else {
+      vals[c * 3 + 0] = w; vals[c * 3 + 1] = w; vals[c * 3 + 2] = w;
+    }
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(FEMO_BLOCK) void k_dRdf_apply_T(int64_t n_cell, const int32_t* __restrict__ conn,
+                                                             const double* __restrict__ vals,
+                                                             const double* __restrict__ xin,
+                                                             double* __restrict__ y, int accumulate) {
+  for (int64_t c = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; c < n_cell;
+       c += (int64_t)gridDim.x * FEMO_BLOCK) {
+    int32_t v[D + 1];
+    load_conn<D>(conn, c, v);
+    double s = 0.0;
+#pragma unroll
+    for (int a = 0; a <= D; ++a) s += vals[c * (D + 1) + a] * xin[v[a]];
+    y[c] = accumulate ? y[c] + s : s;
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(FEMO_BLOCK) void k_dRdf_apply_N(
+    int64_t n_rows, int64_t n_blocks, const int64_t* __restrict__ vptr,
+    const int32_t* __restrict__ visit_cell, const double* __restrict__ vals,
+    const double* __restrict__ xin, double* __restrict__ y, int accumulate) {
+  const int64_t blk = femo_xcd_block(blockIdx.x, n_blocks);
+  const int64_t row = blk * FEMO_BLOCK + threadIdx.x;
+  const int64_t slice = row >> 6;
+  const int lane = threadIdx.x & 63;
+  if ((slice << 6) >= n_rows) return;
+  const int64_t vb = vptr[slice];
+  const int nvis = (int)((vptr[slice + 1] - vb) >> 6);
+  double acc = 0.0;
+  for (int s = 0; s < nvis; ++s) {
+    const int32_t ca = visit_cell[vb + (int64_t)s * 64 + lane];
+    if (ca < 0) continue;
+    const int64_t c = ca >> 2;
+    acc += vals[c * (D + 1) + (ca & 3)] * xin[c];
+  }
+  if (row < n_rows) y[row] = accumulate ? y[row] + acc : acc;
+}
+
+// -------------------------------------------------------------- functional --
+// J = 1/2 int (u-u_d)^2 + alpha/2 int f^2 ; P1 mass matrix in closed form:
+// int_T e^2 = |T|/((d+1)(d+2)) (sum e_a^2 + (sum e_a)^2).
+template <int D>
+__global__ __launch_bounds__(FEMO_BLOCK) void k_functional_value(
+    int64_t n_cell, int64_t n_rows, double alpha, const int32_t* __restrict__ conn,
+    const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ f,
+    const double* __restrict__ ud, double* __restrict__ partials) {
+  __shared__ double lds[FEMO_BLOCK / 64];
+  double acc = 0.0;
+  for (int64_t c = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; c < n_cell;
+       c += (int64_t)gridDim.x * FEMO_BLOCK) {
+    int32_t v[D + 1];
+    load_conn<D>(conn, c, v);
+    if (v[0] >= n_rows) continue;  // cell owned by the rank that owns its first vertex
+    CellGeom<D> G;
+    cell_geom<D>(x, v, G);
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int a = 0; a <= D; ++a) {
+      const double e = u[v[a]] - ud[v[a]];
+      s1 += e;
+      s2 += e * e;
+    }
+    const double fc = f[c];
+    acc += 0.5 * G.vol * (1.0 / ((D + 1) * (D + 2))) * (s2 + s1 * s1) + 0.5 * alpha * fc * fc * G.vol;
+  }
+  const double s = femo_block_sum<FEMO_BLOCK>(acc, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+template <int D>
+__global__ __launch_bounds__(FEMO_BLOCK) void k_functional_grad_u(
+    int64_t n_rows, int64_t n_blocks, const int64_t* __restrict__ vptr,
+    const int32_t* __restrict__ visit_cell, const int32_t* __restrict__ conn,
+    const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ ud,
+    double* __restrict__ g) {
+  const int64_t blk = femo_xcd_block(blockIdx.x, n_blocks);
+  const int64_t row = blk * FEMO_BLOCK + threadIdx.x;
+  const int64_t slice = row >> 6;
+  const int lane = threadIdx.x & 63;
+  if ((slice << 6) >= n_rows) return;
+  const int64_t vb = vptr[slice];
+  const int nvis = (int)((vptr[slice + 1] - vb) >> 6);
+  double acc = 0.0;
+  for (int s = 0; s < nvis; ++s) {
+    const int32_t ca = visit_cell[vb + (int64_t)s * 64 + lane];
+    if (ca < 0) continue;
+    const int64_t c = ca >> 2;
+    const int a = ca & 3;
+    int32_t v[D + 1];
+    load_conn<D>(conn, c, v);
+    CellGeom<D> G;
+    cell_geom<D>(x, v, G);
+    double s1 = 0.0, ea = 0.0;
+#pragma unroll
+    for (int b = 0; b <= D; ++b) {
+      const double e = u[v[b]] - ud[v[b]];
+      s1 += e;
+      ea = (a == b) ? e : ea;
+    }
+    acc += G.vol * (1.0 / ((D + 1) * (D + 2))) * (ea + s1);
+  }
+  if (row < n_rows) g[row] = acc;
+}
+
+template <int D>
+__global__ __launch_bounds__(FEMO_BLOCK) void k_functional_grad_f(int64_t n_cell, double alpha,
+                                                                  const int32_t* __restrict__ conn,
+                                                                  const double* __restrict__ x,
+                                                                  const double* __restrict__ f,
+                                                                  double* __restrict__ g) {
+  for (int64_t c = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; c < n_cell;
+       c += (int64_t)gridDim.x * FEMO_BLOCK) {
+    int32_t v[D + 1];
+    load_conn<D>(conn, c, v);
+    CellGeom<D> G;
+    cell_geom<D>(x, v, G);
+    g[c] = alpha * f[c] * G.vol;
+  }
+}
+
+__global__ void k_reduce_partials(int nblocks, int nsums, const double* __restrict__ partials,
+                                  double* __restrict__ out) {
+  __shared__ double lds[1024 / 64];
+  for (int j = 0; j < nsums; ++j) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 1024) acc += partials[(int64_t)j * FEMO_MAX_PARTIALS + i];
+    const double s = femo_block_sum<1024>(acc, lds);
+    if (threadIdx.x == 0) out[j] = s;
+  }
+}
+
+inline int cell_grid(int64_t n_cell) {
+  int64_t g = (n_cell + FEMO_BLOCK - 1) / FEMO_BLOCK;
+  if (g > FEMO_MAX_PARTIALS) g = FEMO_MAX_PARTIALS;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+inline int64_t row_blocks(const femo_mesh* m) { return (m->n_slices * FEMO_WAVE + FEMO_BLOCK - 1) / FEMO_BLOCK; }
+
+}  // namespace
+
+// tdim dispatch: KERNEL<3, extra...> or KERNEL<2, extra...>
+#define FEMO_LAUNCH_D(m, KERNEL, grid, lds, st, ...)                                          \
+  do {                                                                                        \
+    if ((m)->tdim == 3) hipLaunchKernelGGL((KERNEL<3>), dim3(grid), dim3(FEMO_BLOCK), lds, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<2>), dim3(grid), dim3(FEMO_BLOCK), lds, st, __VA_ARGS__);  \
+  } while (0)
+#define FEMO_LAUNCH_DP(m, KERNEL, P, grid, lds, st, ...)                                      \
+  do {                                                                                        \
+    if ((m)->tdim == 3) hipLaunchKernelGGL((KERNEL<3, P>), dim3(grid), dim3(FEMO_BLOCK), lds, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<2, P>), dim3(grid), dim3(FEMO_BLOCK), lds, st, __VA_ARGS__); \
+  } while (0)
+
+int femo_launch_residual(femo_mesh* m, int pde, const double* params, const double* u,
+                         const double* f, double* r) {
+  FEMO_REQUIRE(pde == FEMO_PDE_POISSON, "pde kind %d not implemented", pde);
+  const int64_t nb = row_blocks(m);
+  if (nb == 0) return 0;
+  hipStream_t st = m->ctx->stream;
+  FEMO_LAUNCH_DP(m, k_residual, FEMO_PDE_POISSON, nb, 0, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_conn, m->d_x, u, f, r);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int femo_launch_jacobian(femo_mesh* m, int pde, const double* params, const double* u,
+                         const double* f, const uint8_t* bcmask, double* diag, double* vals) {
+  FEMO_REQUIRE(pde == FEMO_PDE_POISSON, "pde kind %d not implemented", pde);
+  const int64_t nb = row_blocks(m);
+  if (nb == 0) return 0;
+  int cap = 16;
+  while (cap < m->max_rowlen) cap *= 2;
+  const size_t lds = (size_t)cap * FEMO_BLOCK * sizeof(double);
+  FEMO_REQUIRE(lds <= 160 * 1024, "row length %d exceeds the LDS strip capacity", m->max_rowlen);
+  hipStream_t st = m->ctx->stream;
+  if (m->tdim == 3) {
+    auto k = k_jacobian<3, FEMO_PDE_POISSON>;
+    if (lds > 64 * 1024) FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(nb), dim3(FEMO_BLOCK), lds, st, m->n_rows, nb, cap, m->d_vptr, m->d_visit_cell, m->d_visit_slots, m->d_mptr, m->d_cols, m->d_rowlen, m->d_conn, m->d_x, u, bcmask, diag, vals);
+  } else {
+    auto k = k_jacobian<2, FEMO_PDE_POISSON>;
+    if (lds > 64 * 1024) FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(nb), dim3(FEMO_BLOCK), lds, st, m->n_rows, nb, cap, m->d_vptr, m->d_visit_cell, m->d_visit_slots, m->d_mptr, m->d_cols, m->d_rowlen, m->d_conn, m->d_x, u, bcmask, diag, vals);
+  }
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int femo_launch_dRdf(femo_mesh* m, int pde, const double* params, const double* u,
+                     const double* f, double* vals) {
+  FEMO_REQUIRE(pde == FEMO_PDE_POISSON || pde == FEMO_PDE_NL_POISSON, "pde kind %d not implemented", pde);
+  if (m->n_cell == 0) return 0;
+  const int g = cell_grid(m->n_cell);
+  hipStream_t st = m->ctx->stream;
+  FEMO_LAUNCH_DP(m, k_dRdf, 0, g, 0, st, m->n_cell, m->d_conn, m->d_x, vals);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int femo_launch_dRdf_apply(femo_mesh* m, const double* vals, int transpose, const double* x,
+                           double* y, int accumulate) {
+  hipStream_t st = m->ctx->stream;
+  if (transpose) {
+    if (m->n_cell == 0) return 0;
+    const int g = cell_grid(m->n_cell);
+    FEMO_LAUNCH_D(m, k_dRdf_apply_T, g, 0, st, m->n_cell, m->d_conn, vals, x, y, accumulate);
+  } else {
+    const int64_t nb = row_blocks(m);
+    if (nb == 0) return 0;
+    FEMO_LAUNCH_D(m, k_dRdf_apply_N, nb, 0, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, vals, x, y, accumulate);
+  }
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int femo_reduce_to_host(femo_ctx* ctx, int nblocks, int nsums, double* host_out) {
+  FEMO_REQUIRE(nsums <= FEMO_NSCAL && nblocks <= FEMO_MAX_PARTIALS, "reduction too large");
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, nblocks, nsums, ctx->d_partials, ctx->d_scal);
+  FEMO_HIP_CHECK(hipGetLastError());
+  if (ctx->nranks > 1)
+    FEMO_NCCL_CHECK(ncclAllReduce(ctx->d_scal, ctx->d_scal, nsums, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+  FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, nsums * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  FEMO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  for (int j = 0; j < nsums; ++j) host_out[j] = ctx->h_scal[j];
+  return 0;
+}
+
+int femo_launch_functional_value(femo_mesh* m, int kind, const double* params, const double* u,
+                                 const double* f, const double* ud, double* host_value) {
+  FEMO_REQUIRE(kind == FEMO_J_L2_TRACKING, "functional kind %d not implemented", kind);
+  const double alpha = params ? params[0] : 0.0;
+  const int g = cell_grid(m->n_cell);
+  hipStream_t st = m->ctx->stream;
+  FEMO_LAUNCH_D(m, k_functional_value, g, 0, st, m->n_cell, m->n_rows, alpha, m->d_conn, m->d_x, u, f, ud, m->ctx->d_partials);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return femo_reduce_to_host(m->ctx, g, 1, host_value);
+}
+
+int femo_launch_functional_grad_u(femo_mesh* m, int kind, const double* params, const double* u,
+                                  const double* f, const double* ud, double* gout) {
+  FEMO_REQUIRE(kind == FEMO_J_L2_TRACKING, "functional kind %d not implemented", kind);
+  const int64_t nb = row_blocks(m);
+  if (nb == 0) return 0;
+  hipStream_t st = m->ctx->stream;
+  FEMO_LAUNCH_D(m, k_functional_grad_u, nb, 0, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_conn, m->d_x, u, ud, gout);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int femo_launch_functional_grad_f(femo_mesh* m, int kind, const double* params, const double* u,
+                                  const double* f, const double* ud, double* gout) {
+  FEMO_REQUIRE(kind == FEMO_J_L2_TRACKING, "functional kind %d not implemented", kind);
+  if (m->n_cell == 0) return 0;
+  const double alpha = params ? params[0] : 0.0;
+  const int g = cell_grid(m->n_cell);
+  hipStream_t st = m->ctx->stream;
+  FEMO_LAUNCH_D(m, k_functional_grad_f, g, 0, st, m->n_cell, alpha, m->d_conn, m->d_x, f, gout);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}

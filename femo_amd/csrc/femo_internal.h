@@ -1,0 +1,206 @@
+// Internal declarations shared by the translation units of libfemo_hip.so.
+// Not part of the ABI (see include/femo_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "femo_hip.h"
+
+// ---------------------------------------------------------------- errors ----
+void femo_set_error(const char* fmt, ...);
+
+#define FEMO_HIP_CHECK(expr)                                                        \
+  do {                                                                              \
+    hipError_t e__ = (expr);                                                        \
+    if (e__ != hipSuccess) {                                                        \
+      femo_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr,             \
+                     hipGetErrorString(e__));                                       \
+      return 1;                                                                     \
+    }                                                                               \
+  } while (0)
+
+#define FEMO_NCCL_CHECK(expr)                                                       \
+  do {                                                                              \
+    ncclResult_t r__ = (expr);                                                      \
+    if (r__ != ncclSuccess) {                                                       \
+      femo_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr,             \
+                     ncclGetErrorString(r__));                                      \
+      return 1;                                                                     \
+    }                                                                               \
+  } while (0)
+
+#define FEMO_REQUIRE(cond, ...)                                                     \
+  do {                                                                              \
+    if (!(cond)) {                                                                  \
+      femo_set_error(__VA_ARGS__);                                                  \
+      return 2;                                                                     \
+    }                                                                               \
+  } while (0)
+
+#define FEMO_TRY(expr)                                                              \
+  do {                                                                              \
+    int rc__ = (expr);                                                              \
+    if (rc__ != 0) return rc__;                                                     \
+  } while (0)
+
+// ------------------------------------------------------------- constants ----
+constexpr int FEMO_WAVE = 64;            // gfx950 wavefront
+constexpr int FEMO_BLOCK = 256;          // 4 waves = 4 SELL slices per workgroup
+constexpr int FEMO_MAX_PARTIALS = 2048;  // persistent reduction grids: 256 CUs x 8
+constexpr int FEMO_NSCAL = 16;           // device scalars of the CG recurrence
+
+// SELL-64 with pair interleave: entry k of lane l in a slice starting at P:
+//   P + (k >> 1) * 128 + l * 2 + (k & 1)
+__host__ __device__ inline int64_t femo_sell_index(int64_t base, int k, int lane) {
+  return base + (int64_t)(k >> 1) * (2 * FEMO_WAVE) + lane * 2 + (k & 1);
+}
+
+// ------------------------------------------------------------- topology ----
+struct FemoTopology {
+  int tdim = 0;
+  int64_t n_vert = 0, n_rows = 0, n_cell = 0, n_slices = 0;
+  // vertex -> cell incidence, SELL-64 (entry s of lane l: vptr[slice] + s*64 + l)
+  std::vector<int64_t> vptr;
+  std::vector<int32_t> visit_cell;    // (cell << 2) | local index, -1 = padding
+  std::vector<uint32_t> visit_slots;  // byte b = off-diagonal slot of conn[cell][b]
+  // off-diagonal sparsity pattern, SELL-64 pair-interleaved
+  std::vector<int64_t> mptr;
+  std::vector<int32_t> cols;          // padding entries carry the row's own index
+  std::vector<int32_t> rowlen;        // off-diagonal entries per row (n_slices*64)
+  int64_t nnz = 0;                    // true nonzeros incl. diagonal
+  int max_rowlen = 0, max_valence = 0;
+};
+
+// Returns 0 or sets the error string.
+int femo_build_topology(int tdim, int64_t n_vert, int64_t n_rows, int64_t n_cell,
+                        const int32_t* conn, FemoTopology& T);
+void femo_topology_csr(const FemoTopology& T, int64_t* rowptr, int32_t* col);
+
+// -------------------------------------------------------------- handles ----
+struct femo_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  double* d_partials = nullptr;  // [4][FEMO_MAX_PARTIALS]
+  double* d_scal = nullptr;      // [FEMO_NSCAL]
+  int32_t* d_flags = nullptr;    // [4]: done, iterations, breakdown, spare
+  double* h_scal = nullptr;      // pinned mirror: FEMO_NSCAL doubles + 4 int32
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> ev_pool;
+  ncclComm_t comm = nullptr;
+  int rank = 0, nranks = 1;
+  int n_cu = 256;
+  // CG workspace, grown on demand and reused across solves
+  double *cg_r = nullptr, *cg_p = nullptr, *cg_q = nullptr, *cg_dinv = nullptr;
+  int64_t cg_n = 0, cg_nvert = 0;
+};
+
+struct femo_vec {
+  femo_ctx* ctx = nullptr;
+  double* d = nullptr;
+  int64_t n = 0;
+  bool owned = true;
+};
+
+struct femo_mesh {
+  femo_ctx* ctx = nullptr;
+  int tdim = 0;
+  int64_t n_vert = 0, n_rows = 0, n_cell = 0, n_slices = 0;
+  int64_t nnz = 0, sell_entries = 0, visit_entries = 0;
+  int max_rowlen = 0, max_valence = 0;
+  double* d_x = nullptr;
+  int32_t* d_conn = nullptr;
+  int64_t* d_vptr = nullptr;
+  int32_t* d_visit_cell = nullptr;
+  uint32_t* d_visit_slots = nullptr;
+  int64_t* d_mptr = nullptr;
+  int32_t* d_cols = nullptr;
+  int32_t* d_rowlen = nullptr;
+  int32_t* d_tperm = nullptr;  // lazily built: SELL entry -> SELL entry of the transposed nonzero
+  std::vector<int64_t> h_mptr;
+  // halo plan (n_nbr == 0 on a single GPU)
+  int n_nbr = 0;
+  std::vector<int32_t> nbr;
+  std::vector<int64_t> send_ptr, recv_ptr;
+  int32_t* d_send_idx = nullptr;
+  double* d_send_buf = nullptr;
+};
+
+struct femo_bc {
+  femo_mesh* mesh = nullptr;
+  int64_t n = 0;
+  int32_t* d_dofs = nullptr;
+  double* d_vals = nullptr;
+  uint8_t* d_mask = nullptr;  // n_vert
+};
+
+struct femo_mat {
+  femo_mesh* mesh = nullptr;
+  double* d_diag = nullptr;   // n_slices*64
+  double* d_vals = nullptr;   // sell_entries
+  double* d_valsT = nullptr;  // lazily built transposed values
+  bool valsT_valid = false;
+};
+
+// ------------------------------------------------------ device utilities ----
+#if defined(__HIPCC__)
+__device__ __forceinline__ double femo_wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // valid in lane 0
+}
+
+// Deterministic block sum (fixed tree), result valid in thread 0.
+template <int NT>
+__device__ __forceinline__ double femo_block_sum(double v, double* lds /* NT/64 */) {
+  v = femo_wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) lds[w] = v;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) s += lds[i];
+  }
+  return s;
+}
+
+// Blocks are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD
+// group); give each XCD one contiguous range of logical blocks so that its L2
+// sees one contiguous slab of rows.  Speed only, never correctness.
+__device__ __forceinline__ int64_t femo_xcd_block(int64_t b, int64_t nb) {
+  const int64_t per = nb >> 3;          // blocks per XCD in the divisible part
+  const int64_t main = per << 3;
+  if (b >= main) return b;              // tail blocks keep their index
+  return (b & 7) * per + (b >> 3);
+}
+#endif
+
+// kernel launchers implemented in the .hip files -------------------------------
+int femo_launch_residual(femo_mesh* m, int pde, const double* params, const double* u,
+                         const double* f, double* r);
+int femo_launch_jacobian(femo_mesh* m, int pde, const double* params, const double* u,
+                         const double* f, const uint8_t* bcmask, double* diag, double* vals);
+int femo_launch_dRdf(femo_mesh* m, int pde, const double* params, const double* u,
+                     const double* f, double* vals);
+int femo_launch_dRdf_apply(femo_mesh* m, const double* vals, int transpose, const double* x,
+                           double* y, int accumulate);
+int femo_launch_functional_value(femo_mesh* m, int kind, const double* params, const double* u,
+                                 const double* f, const double* ud, double* host_value);
+int femo_launch_functional_grad_u(femo_mesh* m, int kind, const double* params, const double* u,
+                                  const double* f, const double* ud, double* g);
+int femo_launch_functional_grad_f(femo_mesh* m, int kind, const double* params, const double* u,
+                                  const double* f, const double* ud, double* g);
+int femo_launch_spmv(const femo_mat* A, const double* vals, const double* x, double* y,
+                     double* partials /* or null: fused dot(x,y) partials */);
+int femo_spmv_grid(const femo_mesh* m);
+int femo_mat_ensure_transpose(femo_mat* A);
+int femo_reduce_to_host(femo_ctx* ctx, int nblocks, int nsums, double* host_out);

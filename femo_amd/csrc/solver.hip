@@ -1,0 +1,532 @@
+// SELL-64 SpMV and Jacobi-preconditioned CG for gfx950.
+//
+// Replaces the reference's PETSc calls:
+//   Mat*Vec / multTranspose  utils_dolfinx.py:256-264, 275-287   (state_model.py:176-200)
+//   KSP preonly + LU(MUMPS)  utils_dolfinx.py:476-512            (fea_dolfinx.py:192-222)
+// CG + Jacobi instead of LU is BASELINE.json's design: a sparse
+// LU of the 10 M-DOF 3-D operator does not fit, and CSR/SELL SpMV streams at the
+// HBM roofline.
+//
+// SpMV layout: the diagonal is a dense vector; off-diagonals live in SELL-64
+// slices with pair interleave, so lane l of a wave owns row 64*slice+l and each
+// wave-instruction reads 1 KiB of values (16 B/lane) and 512 B of columns
+// (8 B/lane), fully coalesced.  Consecutive lanes are consecutive rows, so for
+// any bandwidth-reducing vertex order the x-gathers of one instruction fall in
+// a few cache lines.  Row sums are sequential per lane: deterministic.
+//
+// CG keeps every scalar of the recurrence on the device: kernels reduce into
+// per-block partials, a one-block kernel folds them (plus an RCCL all-reduce
+// when nranks > 1) and the consumers read the folded scalars.  The host only
+// polls a "done" flag every `check_every` iterations, two batches deep.
+#include <cmath>
+
+#include "femo_internal.h"
+
+namespace {
+
+// ------------------------------------------------------------------- SpMV ---
+template <bool DOT>
+__global__ __launch_bounds__(FEMO_BLOCK) void k_spmv_sell(
+    int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ mptr,
+    const int32_t* __restrict__ cols, const double* __restrict__ vals,
+    const double* __restrict__ diag, const double* __restrict__ x, double* __restrict__ y,
+    double* __restrict__ partials, const int32_t* __restrict__ done) {
+  if (done != nullptr && *done) return;
+  __shared__ double lds[FEMO_BLOCK / 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  // XCD-aware: blockIdx % 8 labels the XCD group; each group walks its own
+  // contiguous eighth of the slices, its waves interleaved slice by slice.
+  const int xcd = blockIdx.x & 7;
+  const int64_t blk_in_xcd = blockIdx.x >> 3;
+  const int64_t waves_per_xcd = (int64_t)(gridDim.x >> 3) * (FEMO_BLOCK / 64);
+  const int64_t s_lo = n_slices * xcd / 8, s_hi = n_slices * (xcd + 1) / 8;
+  double dot = 0.0;
+  for (int64_t slice = s_lo + blk_in_xcd * (FEMO_BLOCK / 64) + wave; slice < s_hi;
+       slice += waves_per_xcd) {
+    const int64_t base = mptr[slice];
+    const int npair = (int)((mptr[slice + 1] - base) >> 7);
+    const int64_t row = (slice << 6) + lane;
+    const double xr = x[row < n_rows ? row : 0];
+    double acc = diag[row] * xr;
+    const double2* __restrict__ v2 = reinterpret_cast<const double2*>(vals + base) + lane;
+    const int2* __restrict__ c2 = reinterpret_cast<const int2*>(cols + base) + lane;
+    int m = 0;
+    for (; m + 4 <= npair; m += 4) {
+      const double2 a0 = v2[(m + 0) * 64], a1 = v2[(m + 1) * 64], a2 = v2[(m + 2) * 64], a3 = v2[(m + 3) * 64];
+      const int2 j0 = c2[(m + 0) * 64], j1 = c2[(m + 1) * 64], j2 = c2[(m + 2) * 64], j3 = c2[(m + 3) * 64];
+      const double x0 = x[j0.x], x1 = x[j0.y], x2 = x[j1.x], x3 = x[j1.y];
+      const double x4 = x[j2.x], x5 = x[j2.y], x6 = x[j3.x], x7 = x[j3.y];
+      acc += a0.x * x0; acc += a0.y * x1; acc += a1.x * x2; acc += a1.y * x3;
+      acc += a2.x * x4; acc += a2.y * x5; acc += a3.x * x6; acc += a3.y * x7;
+    }
+    for (; m < npair; ++m) {
+      const double2 a0 = v2[m * 64];
+      const int2 j0 = c2[m * 64];
+      acc += a0.x * x[j0.x];
+      acc += a0.y * x[j0.y];
+    }
+    if (row < n_rows) {
+      y[row] = acc;
+      if (DOT) dot += acc * xr;
+    }
+  }
+  if (DOT) {
+    const double s = femo_block_sum<FEMO_BLOCK>(dot, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+  }
+}
+
+// ------------------------------------------------------------ transposition --
+__global__ void k_build_tperm(int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ mptr,
+                              const int32_t* __restrict__ cols, const int32_t* __restrict__ rowlen,
+                              int32_t* __restrict__ tperm, int32_t* __restrict__ err) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n_slices * 64) return;
+  const int64_t slice = row >> 6;
+  const int lane = (int)(row & 63);
+  const int64_t base = mptr[slice];
+  const int wm = (int)((mptr[slice + 1] - base) >> 6);
+  const int len = rowlen[row];
+  for (int k = 0; k < wm; ++k) {
+    const int64_t e = femo_sell_index(base, k, lane);
+    int32_t t = (int32_t)e;  // padding maps to itself (value 0)
+    if (k < len) {
+      const int64_t j = cols[e];
+      if (j >= n_rows) {
+        atomicExch(err, 1);  // transposed entry lives on another rank
+      } else {
+        const int64_t sj = j >> 6;
+        const int lj = (int)(j & 63);
+        const int64_t bj = mptr[sj];
+        const int lenj = rowlen[j];
+        int found = -1;
+        for (int kk = 0; kk < lenj; ++kk) {
+          const int64_t ej = femo_sell_index(bj, kk, lj);
+          if (cols[ej] == row) { found = (int)ej; break; }
+        }
+        if (found < 0) atomicExch(err, 2);  // structurally unsymmetric pattern
+        else t = found;
+      }
+    }
+    tperm[e] = t;
+  }
+}
+
+__global__ void k_gather(int64_t n, const int32_t* __restrict__ perm, const double* __restrict__ in,
+                         double* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = in[perm[i]];
+}
+
+// ------------------------------------------------------------- CG kernels ---
+// scal layout: [0],[1] = (gamma, rr) of even iterations; [2],[3] of odd; [4] = delta;
+// [5] = tol^2; [6] = ||b||^2.   flags: [0] done, [1] iterations, [2] breakdown.
+constexpr int S_DELTA = 4, S_TOL2 = 5, S_BB = 6;
+
+// r = b - q (q = A x0, or 0), dinv = 1/diag, p = dinv r; partials: r.z, r.r, b.b
+__global__ __launch_bounds__(FEMO_BLOCK) void k_cg_init(int64_t n, const double* __restrict__ b,
+                                                        const double* __restrict__ q, const double* __restrict__ diag,
+                                                        double* __restrict__ r, double* __restrict__ p,
+                                                        double* __restrict__ dinv, double* __restrict__ partials) {
+  __shared__ double lds[FEMO_BLOCK / 64];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FEMO_BLOCK) {
+    const double bi = b[i];
+    const double ri = q ? bi - q[i] : bi;
+    const double di = 1.0 / diag[i];
+    const double zi = di * ri;
+    r[i] = ri; dinv[i] = di; p[i] = zi;
+    s0 += ri * zi; s1 += ri * ri; s2 += bi * bi;
+  }
+  double t = femo_block_sum<FEMO_BLOCK>(s0, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  t = femo_block_sum<FEMO_BLOCK>(s1, lds);
+  if (threadIdx.x == 0) partials[FEMO_MAX_PARTIALS + blockIdx.x] = t;
+  t = femo_block_sum<FEMO_BLOCK>(s2, lds);
+  if (threadIdx.x == 0) partials[2 * FEMO_MAX_PARTIALS + blockIdx.x] = t;
+}
+
+// fold `nsums` partial arrays into scal[dst + j]
+__global__ __launch_bounds__(1024) void k_cg_fold(int nblocks, int nsums, int dst0, int dst1,
+                                                  const double* __restrict__ partials, double* __restrict__ scal,
+                                                  const int32_t* __restrict__ done) {
+  if (*done) return;
+  __shared__ double lds[1024 / 64];
+  for (int j = 0; j < nsums; ++j) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 1024) acc += partials[(int64_t)j * FEMO_MAX_PARTIALS + i];
+    const double s = femo_block_sum<1024>(acc, lds);
+    if (threadIdx.x == 0) scal[j == 0 ? dst0 : dst1] = s;
+  }
+}
+
+// x += alpha p ; r -= alpha q ; partials: r.(dinv r), r.r
+__global__ __launch_bounds__(FEMO_BLOCK) void k_cg_update_xr(int64_t n, int cur, const double* __restrict__ scal,
+                                                             const double* __restrict__ p, const double* __restrict__ q,
+                                                             const double* __restrict__ dinv, double* __restrict__ x,
+                                                             double* __restrict__ r, double* __restrict__ partials,
+                                                             const int32_t* __restrict__ done) {
+  if (*done) return;
+  __shared__ double lds[FEMO_BLOCK / 64];
+  const double gamma = scal[2 * cur], delta = scal[S_DELTA];
+  const double alpha = delta != 0.0 ? gamma / delta : 0.0;
+  double s0 = 0.0, s1 = 0.0;
+  const int64_t n2 = n >> 1;
+  const double2* p2 = reinterpret_cast<const double2*>(p);
+  const double2* q2 = reinterpret_cast<const double2*>(q);
+  const double2* d2 = reinterpret_cast<const double2*>(dinv);
+  double2* x2 = reinterpret_cast<double2*>(x);
+  double2* r2 = reinterpret_cast<double2*>(r);
+  for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n2; i += (int64_t)gridDim.x * FEMO_BLOCK) {
+    const double2 pi = p2[i], qi = q2[i], di = d2[i];
+    double2 xi = x2[i], ri = r2[i];
+    xi.x += alpha * pi.x; xi.y += alpha * pi.y;
+    ri.x -= alpha * qi.x; ri.y -= alpha * qi.y;
+    x2[i] = xi; r2[i] = ri;
+    s0 += ri.x * ri.x * di.x + ri.y * ri.y * di.y;
+    s1 += ri.x * ri.x + ri.y * ri.y;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    const double xi = x[i] + alpha * p[i];
+    const double ri = r[i] - alpha * q[i];
+    x[i] = xi; r[i] = ri;
+    s0 += ri * ri * dinv[i];
+    s1 += ri * ri;
+  }
+  double t = femo_block_sum<FEMO_BLOCK>(s0, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  t = femo_block_sum<FEMO_BLOCK>(s1, lds);
+  if (threadIdx.x == 0) partials[FEMO_MAX_PARTIALS + blockIdx.x] = t;
+}
+
+// beta = gamma'/gamma ; p = dinv r + beta p ; convergence bookkeeping
+__global__ __launch_bounds__(FEMO_BLOCK) void k_cg_update_p(int64_t n, int cur, int it, const double* __restrict__ scal,
+                                                            const double* __restrict__ r, const double* __restrict__ dinv,
+                                                            double* __restrict__ p, int32_t* __restrict__ flags) {
+  if (flags[0]) return;
+  const int nxt = cur ^ 1;
+  const double gamma = scal[2 * cur], gamma1 = scal[2 * nxt], rr = scal[2 * nxt + 1];
+  const bool bad = !(rr == rr);  // NaN
+  if (rr <= scal[S_TOL2] || bad) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      flags[1] = it + 1;
+      flags[2] = bad ? 1 : 0;
+      __threadfence();
+      flags[0] = 1;
+    }
+    return;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) flags[1] = it + 1;
+  const double beta = gamma != 0.0 ? gamma1 / gamma : 0.0;
+  const int64_t n2 = n >> 1;
+  const double2* r2 = reinterpret_cast<const double2*>(r);
+  const double2* d2 = reinterpret_cast<const double2*>(dinv);
+  double2* p2 = reinterpret_cast<double2*>(p);
+  for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n2; i += (int64_t)gridDim.x * FEMO_BLOCK) {
+    const double2 ri = r2[i], di = d2[i];
+    double2 pi = p2[i];
+    pi.x = di.x * ri.x + beta * pi.x;
+    pi.y = di.y * ri.y + beta * pi.y;
+    p2[i] = pi;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    p[i] = dinv[i] * r[i] + beta * p[i];
+  }
+}
+
+__global__ __launch_bounds__(FEMO_BLOCK) void k_dot(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
+                                                    double* __restrict__ partials) {
+  __shared__ double lds[FEMO_BLOCK / 64];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FEMO_BLOCK) s += a[i] * b[i];
+  const double t = femo_block_sum<FEMO_BLOCK>(s, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+__global__ void k_pack(int64_t n, const int32_t* __restrict__ idx, const double* __restrict__ x, double* __restrict__ buf) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) buf[i] = x[idx[i]];
+}
+
+inline int vec_grid(const femo_ctx* ctx, int64_t n) {
+  int64_t g = (n / 2 + FEMO_BLOCK - 1) / FEMO_BLOCK;
+  const int64_t cap = (int64_t)ctx->n_cu * 8;
+  if (g > cap) g = cap;
+  if (g > FEMO_MAX_PARTIALS) g = FEMO_MAX_PARTIALS;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+int femo_spmv_grid(const femo_mesh* m) {
+  int64_t g = (m->n_slices + 3) / 4;           // one slice per wave if the mesh is small
+  const int64_t cap = (int64_t)m->ctx->n_cu * 8;
+  if (g > cap) g = cap;
+  if (g > FEMO_MAX_PARTIALS) g = FEMO_MAX_PARTIALS;
+  g = (g + 7) & ~int64_t(7);                   // whole XCD groups
+  if (g < 8) g = 8;
+  return (int)g;
+}
+
+static int launch_spmv(const femo_mat* A, const double* vals, const double* x, double* y,
+                       double* partials, const int32_t* done) {
+  const femo_mesh* m = A->mesh;
+  if (m->n_slices == 0) return 0;
+  const int g = femo_spmv_grid(m);
+  hipStream_t st = m->ctx->stream;
+  if (partials)
+    hipLaunchKernelGGL(k_spmv_sell<true>, dim3(g), dim3(FEMO_BLOCK), 0, st, m->n_rows, m->n_slices, m->d_mptr, m->d_cols, vals, A->d_diag, x, y, partials, done);
+  else
+    hipLaunchKernelGGL(k_spmv_sell<false>, dim3(g), dim3(FEMO_BLOCK), 0, st, m->n_rows, m->n_slices, m->d_mptr, m->d_cols, vals, A->d_diag, x, y, partials, done);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int femo_launch_spmv(const femo_mat* A, const double* vals, const double* x, double* y, double* partials) {
+  return launch_spmv(A, vals, x, y, partials, nullptr);
+}
+
+int femo_mat_ensure_transpose(femo_mat* A) {
+  femo_mesh* m = A->mesh;
+  femo_ctx* ctx = m->ctx;
+  if (A->valsT_valid) return 0;
+  if (m->sell_entries == 0) { A->valsT_valid = true; return 0; }
+  if (!m->d_tperm) {
+    FEMO_REQUIRE(m->sell_entries < (int64_t(1) << 31), "pattern too large for int32 transpose map");
+    FEMO_HIP_CHECK(hipMalloc(&m->d_tperm, m->sell_entries * sizeof(int32_t)));
+    FEMO_HIP_CHECK(hipMemsetAsync(ctx->d_flags + 3, 0, sizeof(int32_t), ctx->stream));
+    const int64_t nr = m->n_slices * 64;
+    hipLaunchKernelGGL(k_build_tperm, dim3((nr + 255) / 256), dim3(256), 0, ctx->stream, m->n_rows, m->n_slices, m->d_mptr, m->d_cols, m->d_rowlen, m->d_tperm, ctx->d_flags + 3);
+    FEMO_HIP_CHECK(hipGetLastError());
+    int32_t err = 0;
+    FEMO_HIP_CHECK(hipMemcpyAsync(&err, ctx->d_flags + 3, sizeof err, hipMemcpyDeviceToHost, ctx->stream));
+    FEMO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (err != 0) {
+      hipFree(m->d_tperm);
+      m->d_tperm = nullptr;
+      femo_set_error(err == 1 ? "transposed operator needs entries owned by another rank"
+                              : "sparsity pattern is not structurally symmetric");
+      return 3;
+    }
+  }
+  if (!A->d_valsT) FEMO_HIP_CHECK(hipMalloc(&A->d_valsT, m->sell_entries * sizeof(double)));
+  hipLaunchKernelGGL(k_gather, dim3(2048), dim3(256), 0, ctx->stream, m->sell_entries, m->d_tperm, A->d_vals, A->d_valsT);
+  FEMO_HIP_CHECK(hipGetLastError());
+  A->valsT_valid = true;
+  return 0;
+}
+
+// ---------------------------------------------------------------- halo ------
+extern "C" int femo_halo_exchange(femo_mesh* m, femo_vec* x) {
+  FEMO_REQUIRE(m && x, "null argument");
+  if (m->n_nbr == 0) return 0;
+  femo_ctx* ctx = m->ctx;
+  FEMO_REQUIRE(ctx->comm != nullptr, "halo exchange before femo_comm_init");
+  FEMO_REQUIRE(x->n >= m->n_vert, "vector shorter than n_vert");
+  const int64_t ns = m->send_ptr[m->n_nbr];
+  if (ns > 0) {
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, ns, m->d_send_idx, x->d, m->d_send_buf);
+    FEMO_HIP_CHECK(hipGetLastError());
+  }
+  FEMO_NCCL_CHECK(ncclGroupStart());
+  for (int k = 0; k < m->n_nbr; ++k) {
+    const int64_t sc = m->send_ptr[k + 1] - m->send_ptr[k];
+    const int64_t rc = m->recv_ptr[k + 1] - m->recv_ptr[k];
+    if (sc > 0) FEMO_NCCL_CHECK(ncclSend(m->d_send_buf + m->send_ptr[k], sc, ncclDouble, m->nbr[k], ctx->comm, ctx->stream));
+    if (rc > 0) FEMO_NCCL_CHECK(ncclRecv(x->d + m->n_rows + m->recv_ptr[k], rc, ncclDouble, m->nbr[k], ctx->comm, ctx->stream));
+  }
+  FEMO_NCCL_CHECK(ncclGroupEnd());
+  return 0;
+}
+
+static int halo_raw(femo_mesh* m, double* x) {
+  femo_vec v;
+  v.ctx = m->ctx; v.d = x; v.n = m->n_vert; v.owned = false;
+  return femo_halo_exchange(m, &v);
+}
+
+// ----------------------------------------------------------------- API ------
+extern "C" int femo_mat_spmv(const femo_mat* A, int transpose, const femo_vec* x, femo_vec* y) {
+  FEMO_REQUIRE(A && x && y, "null argument");
+  femo_mesh* m = A->mesh;
+  FEMO_REQUIRE(x->n >= m->n_vert && y->n >= m->n_rows, "vector size mismatch in spmv");
+  FEMO_REQUIRE(x->d != y->d, "spmv cannot run in place");
+  const double* vals = A->d_vals;
+  if (transpose) {
+    FEMO_TRY(femo_mat_ensure_transpose(const_cast<femo_mat*>(A)));
+    vals = A->d_valsT;
+  }
+  if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, x->d));
+  return launch_spmv(A, vals, x->d, y->d, nullptr, nullptr);
+}
+
+extern "C" int femo_vec_dot(const femo_vec* x, const femo_vec* y, int64_t n, double* out) {
+  FEMO_REQUIRE(x && y && out, "null argument");
+  FEMO_REQUIRE(n <= x->n && n <= y->n, "dot length exceeds vector size");
+  femo_ctx* ctx = x->ctx;
+  const int g = vec_grid(ctx, n);
+  hipLaunchKernelGGL(k_dot, dim3(g), dim3(FEMO_BLOCK), 0, ctx->stream, n, x->d, y->d, ctx->d_partials);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return femo_reduce_to_host(ctx, g, 1, out);
+}
+
+extern "C" int femo_bench_spmv(const femo_mat* A, const femo_vec* x, femo_vec* y, int reps, double* ms_per_launch) {
+  FEMO_REQUIRE(A && x && y && ms_per_launch && reps > 0, "bad argument");
+  femo_ctx* ctx = A->mesh->ctx;
+  FEMO_REQUIRE(x->n >= A->mesh->n_vert && y->n >= A->mesh->n_rows, "vector size mismatch");
+  for (int i = 0; i < 3; ++i) FEMO_TRY(launch_spmv(A, A->d_vals, x->d, y->d, ctx->d_partials, nullptr));
+  FEMO_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
+  for (int i = 0; i < reps; ++i) FEMO_TRY(launch_spmv(A, A->d_vals, x->d, y->d, ctx->d_partials, nullptr));
+  FEMO_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
+  FEMO_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  FEMO_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *ms_per_launch = (double)ms / reps;
+  return 0;
+}
+
+namespace {
+struct CgWork {
+  double *r, *p, *q, *dinv;
+};
+
+int ensure_work(femo_ctx* ctx, int64_t n_rows, int64_t n_vert, CgWork& w) {
+  if (ctx->cg_n < n_rows || ctx->cg_nvert < n_vert) {
+    if (ctx->cg_r) { hipFree(ctx->cg_r); hipFree(ctx->cg_p); hipFree(ctx->cg_q); hipFree(ctx->cg_dinv); }
+    ctx->cg_r = ctx->cg_p = ctx->cg_q = ctx->cg_dinv = nullptr;
+    ctx->cg_n = ctx->cg_nvert = 0;
+    FEMO_HIP_CHECK(hipMalloc(&ctx->cg_r, (n_rows + 2) * sizeof(double)));
+    FEMO_HIP_CHECK(hipMalloc(&ctx->cg_p, (n_vert + 2) * sizeof(double)));
+    FEMO_HIP_CHECK(hipMalloc(&ctx->cg_q, (n_rows + 2) * sizeof(double)));
+    FEMO_HIP_CHECK(hipMalloc(&ctx->cg_dinv, (n_rows + 2) * sizeof(double)));
+    ctx->cg_n = n_rows; ctx->cg_nvert = n_vert;
+  }
+  FEMO_HIP_CHECK(hipMemsetAsync(ctx->cg_p, 0, (ctx->cg_nvert + 2) * sizeof(double), ctx->stream));
+  w.r = ctx->cg_r; w.p = ctx->cg_p; w.q = ctx->cg_q; w.dinv = ctx->cg_dinv;
+  return 0;
+}
+}  // namespace
+
+extern "C" int femo_solve_cg(const femo_mat* A, int transpose, const femo_vec* b, femo_vec* x,
+                             const femo_solver_opts* opts, femo_solve_info* info) {
+  FEMO_REQUIRE(A && b && x && opts && info, "null argument");
+  femo_mesh* m = A->mesh;
+  femo_ctx* ctx = m->ctx;
+  const int64_t n = m->n_rows;
+  FEMO_REQUIRE(b->n >= n && x->n >= m->n_vert, "vector size mismatch in solve_cg");
+  const double* vals = A->d_vals;
+  if (transpose) {
+    FEMO_TRY(femo_mat_ensure_transpose(const_cast<femo_mat*>(A)));
+    vals = A->d_valsT;
+  }
+  memset(info, 0, sizeof *info);
+  CgWork w;
+  FEMO_TRY(ensure_work(ctx, n, m->n_vert, w));
+  hipStream_t st = ctx->stream;
+  const int gv = vec_grid(ctx, n);
+  const int gs = femo_spmv_grid(m);
+  const bool multi = ctx->nranks > 1;
+  int32_t* h_flags = reinterpret_cast<int32_t*>(ctx->h_scal + FEMO_NSCAL);  // 2 slots x 4 ints
+
+  FEMO_HIP_CHECK(hipEventRecord(ctx->ev0, st));
+  FEMO_HIP_CHECK(hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int32_t), st));
+  // r0 = b - A x0
+  const double* q0 = nullptr;
+  if (opts->zero_guess) {
+    FEMO_HIP_CHECK(hipMemsetAsync(x->d, 0, x->n * sizeof(double), st));
+  } else {
+    if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, x->d));
+    FEMO_TRY(launch_spmv(A, vals, x->d, w.q, nullptr, nullptr));
+    q0 = w.q;
+  }
+  hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, b->d, q0, A->d_diag, w.r, w.p, w.dinv, ctx->d_partials);
+  FEMO_HIP_CHECK(hipGetLastError());
+  double s3[3];
+  FEMO_TRY(femo_reduce_to_host(ctx, gv, 3, s3));  // gamma0, rr0, bb (all-reduced when multi)
+  const double bnorm = std::sqrt(s3[2]);
+  double tol = opts->rtol * bnorm;
+  if (opts->atol > tol) tol = opts->atol;
+  info->rhs_norm = bnorm;
+  const int max_it = opts->max_it > 0 ? opts->max_it : 10000;
+  if (!(std::sqrt(s3[1]) > tol)) {  // also catches NaN -> report below
+    info->iterations = 0;
+    info->converged = (s3[1] == s3[1]) ? 1 : -1;
+    info->residual_norm = std::sqrt(s3[1]);
+    FEMO_HIP_CHECK(hipEventRecord(ctx->ev1, st));
+    FEMO_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    FEMO_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    info->solve_ms = ms;
+    return 0;
+  }
+  double hs[FEMO_NSCAL] = {0};
+  hs[0] = s3[0]; hs[1] = s3[1]; hs[S_TOL2] = tol * tol; hs[S_BB] = s3[2];
+  memcpy(ctx->h_scal, hs, sizeof hs);
+  FEMO_HIP_CHECK(hipMemcpyAsync(ctx->d_scal, ctx->h_scal, sizeof hs, hipMemcpyHostToDevice, st));
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));  // h_scal is reused below
+
+  const int batch = opts->check_every > 0 ? opts->check_every : 32;
+  const int n_sample = 4, sample_from = 4;
+  int it = 0, polled = 0, n_ev = 0;
+  bool done = false;
+  int pending[2] = {-1, -1};  // iteration count at which slot was recorded
+  while (!done) {
+    const int it_end = it + batch < max_it ? it + batch : max_it;
+    for (; it < it_end; ++it) {
+      const int cur = it & 1, nxt = cur ^ 1;
+      if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, w.p));
+      const bool sample = it >= sample_from && it < sample_from + n_sample && (int)ctx->ev_pool.size() >= 2 * n_sample;
+      if (sample) FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev], st));
+      FEMO_TRY(launch_spmv(A, vals, w.p, w.q, ctx->d_partials, ctx->d_flags));
+      if (sample) { FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev + 1], st)); ++n_ev; }
+      hipLaunchKernelGGL(k_cg_fold, dim3(1), dim3(1024), 0, st, gs, 1, S_DELTA, S_DELTA, ctx->d_partials, ctx->d_scal, ctx->d_flags);
+      if (multi) FEMO_NCCL_CHECK(ncclAllReduce(ctx->d_scal + S_DELTA, ctx->d_scal + S_DELTA, 1, ncclDouble, ncclSum, ctx->comm, st));
+      hipLaunchKernelGGL(k_cg_update_xr, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, ctx->d_scal, w.p, w.q, w.dinv, x->d, w.r, ctx->d_partials, ctx->d_flags);
+      hipLaunchKernelGGL(k_cg_fold, dim3(1), dim3(1024), 0, st, gv, 2, 2 * nxt, 2 * nxt + 1, ctx->d_partials, ctx->d_scal, ctx->d_flags);
+      if (multi) FEMO_NCCL_CHECK(ncclAllReduce(ctx->d_scal + 2 * nxt, ctx->d_scal + 2 * nxt, 2, ncclDouble, ncclSum, ctx->comm, st));
+      hipLaunchKernelGGL(k_cg_update_p, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, it, ctx->d_scal, w.r, w.dinv, w.p, ctx->d_flags);
+    }
+    FEMO_HIP_CHECK(hipGetLastError());
+    // record this batch in slot (polled & 1); then inspect the previous batch
+    const int slot = polled & 1;
+    FEMO_HIP_CHECK(hipMemcpyAsync(h_flags + 4 * slot, ctx->d_flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_sample + slot], st));
+    pending[slot] = it;
+    ++polled;
+    const int prev = polled & 1;  // the other slot
+    const bool last = it >= max_it;
+    if (pending[prev] >= 0) {
+      FEMO_HIP_CHECK(hipEventSynchronize(ctx->ev_pool[2 * n_sample + prev]));
+      if (h_flags[4 * prev]) done = true;
+      pending[prev] = -1;
+    }
+    if (!done && last) {
+      FEMO_HIP_CHECK(hipEventSynchronize(ctx->ev_pool[2 * n_sample + slot]));
+      done = true;
+    }
+  }
+  FEMO_HIP_CHECK(hipEventRecord(ctx->ev1, st));
+  FEMO_HIP_CHECK(hipMemcpyAsync(h_flags, ctx->d_flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, FEMO_NSCAL * sizeof(double), hipMemcpyDeviceToHost, st));
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  const int iters = h_flags[1];
+  info->iterations = iters;
+  info->converged = h_flags[0] ? (h_flags[2] ? -1 : 1) : 0;
+  // rr of the last completed iteration lives in the (iters & 1) pair
+  info->residual_norm = std::sqrt(ctx->h_scal[2 * (iters & 1) + 1]);
+  float ms = 0.f;
+  FEMO_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  info->solve_ms = ms;
+  double acc = 0.0;
+  for (int i = 0; i < n_ev; ++i) {
+    float t = 0.f;
+    FEMO_HIP_CHECK(hipEventElapsedTime(&t, ctx->ev_pool[2 * i], ctx->ev_pool[2 * i + 1]));
+    acc += t;
+  }
+  info->spmv_ms = acc;
+  info->spmv_samples = n_ev;
+  return 0;
+}

@@ -1,0 +1,234 @@
+// Host-side mesh topology: vertex->cell incidence and the P1 sparsity pattern,
+// both emitted directly in the SELL-64 layouts the device kernels stream.
+//
+// Replaces dolfinx's sparsity-pattern / create_matrix step [ext] that the
+// reference reaches through utils_dolfinx.py:385 (create_matrix) and every
+// assemble_matrix call (utils_dolfinx.py:185,193).  Runs once per mesh, on the
+// host cores, so it can be tested without a GPU (femo_topology_build_host).
+#include <algorithm>
+#include <atomic>
+#include <cstdarg>
+#include <thread>
+
+#include "femo_internal.h"
+
+static thread_local std::string g_err;
+
+void femo_set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+extern "C" const char* femo_last_error(void) { return g_err.c_str(); }
+
+namespace {
+
+template <class F>
+void parallel_for(int64_t n, F&& body) {
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt == 0) nt = 1;
+  if (nt > 64) nt = 64;
+  if (n < 1 << 14) nt = 1;
+  if (nt == 1) {
+    body(0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  const int64_t chunk = (n + nt - 1) / nt;
+  for (unsigned t = 0; t < nt; ++t) {
+    const int64_t lo = t * chunk, hi = std::min<int64_t>(n, lo + chunk);
+    if (lo >= hi) break;
+    th.emplace_back([=, &body] { body(lo, hi); });
+  }
+  for (auto& t : th) t.join();
+}
+
+}  // namespace
+
+int femo_build_topology(int tdim, int64_t n_vert, int64_t n_rows, int64_t n_cell,
+                        const int32_t* conn, FemoTopology& T) {
+  FEMO_REQUIRE(tdim == 2 || tdim == 3, "tdim must be 2 or 3 (got %d)", tdim);
+  FEMO_REQUIRE(n_rows >= 0 && n_rows <= n_vert, "n_rows must be in [0, n_vert]");
+  FEMO_REQUIRE(n_cell < (int64_t(1) << 29), "n_cell too large for packed visit words");
+  FEMO_REQUIRE(n_vert < (int64_t(1) << 31), "n_vert exceeds int32 indices");
+  const int nv = tdim + 1;
+  T.tdim = tdim;
+  T.n_vert = n_vert;
+  T.n_rows = n_rows;
+  T.n_cell = n_cell;
+  T.n_slices = (n_rows + FEMO_WAVE - 1) / FEMO_WAVE;
+  const int64_t n_pad = T.n_slices * FEMO_WAVE;
+
+  // validate connectivity
+  {
+    std::atomic<int> bad{0};
+    parallel_for(n_cell * nv, [&](int64_t lo, int64_t hi) {
+      for (int64_t e = lo; e < hi; ++e)
+        if (conn[e] < 0 || conn[e] >= n_vert) bad.store(1, std::memory_order_relaxed);
+    });
+    FEMO_REQUIRE(!bad.load(), "connectivity entry out of range [0, n_vert)");
+  }
+
+  // 1. valence of owned vertices
+  std::vector<int32_t> deg(n_pad, 0);
+  parallel_for(n_cell, [&](int64_t lo, int64_t hi) {
+    for (int64_t c = lo; c < hi; ++c)
+      for (int a = 0; a < nv; ++a) {
+        const int32_t v = conn[c * nv + a];
+        if (v < n_rows) __atomic_fetch_add(&deg[v], 1, __ATOMIC_RELAXED);
+      }
+  });
+  // 2. CSR incidence, sorted by cell index per vertex
+  std::vector<int64_t> off(n_pad + 1, 0);
+  for (int64_t v = 0; v < n_pad; ++v) off[v + 1] = off[v] + deg[v];
+  std::vector<int32_t> inc(off[n_pad]);
+  {
+    std::vector<int32_t> cur(n_pad, 0);
+    parallel_for(n_cell, [&](int64_t lo, int64_t hi) {
+      for (int64_t c = lo; c < hi; ++c)
+        for (int a = 0; a < nv; ++a) {
+          const int32_t v = conn[c * nv + a];
+          if (v < n_rows) {
+            const int32_t s = __atomic_fetch_add(&cur[v], 1, __ATOMIC_RELAXED);
+            inc[off[v] + s] = (int32_t)((c << 2) | a);
+          }
+        }
+    });
+  }
+  int max_val = 0;
+  for (int64_t v = 0; v < n_rows; ++v) max_val = std::max(max_val, deg[v]);
+  T.max_valence = max_val;
+  parallel_for(n_rows, [&](int64_t lo, int64_t hi) {
+    for (int64_t v = lo; v < hi; ++v) std::sort(inc.begin() + off[v], inc.begin() + off[v + 1]);
+  });
+
+  // 3. sorted unique neighbours per row
+  T.rowlen.assign(n_pad, 0);
+  std::vector<int64_t> noff(n_pad + 1, 0);
+  {
+    // upper bound tdim * valence per row, compacted afterwards
+    std::vector<int64_t> uoff(n_pad + 1, 0);
+    for (int64_t v = 0; v < n_pad; ++v) uoff[v + 1] = uoff[v] + (int64_t)deg[v] * tdim;
+    std::vector<int32_t> tmp(uoff[n_pad]);
+    parallel_for(n_rows, [&](int64_t lo, int64_t hi) {
+      for (int64_t v = lo; v < hi; ++v) {
+        int32_t* w = tmp.data() + uoff[v];
+        int n = 0;
+        for (int64_t e = off[v]; e < off[v + 1]; ++e) {
+          const int64_t c = inc[e] >> 2;
+          const int a = inc[e] & 3;
+          for (int b = 0; b < nv; ++b)
+            if (b != a) w[n++] = conn[c * nv + b];
+        }
+        std::sort(w, w + n);
+        n = (int)(std::unique(w, w + n) - w);
+        // a degenerate cell could repeat the row's own vertex
+        int m = 0;
+        for (int i = 0; i < n; ++i)
+          if (w[i] != v) w[m++] = w[i];
+        T.rowlen[v] = m;
+      }
+    });
+    for (int64_t v = 0; v < n_pad; ++v) noff[v + 1] = noff[v] + T.rowlen[v];
+    int max_len = 0;
+    for (int64_t v = 0; v < n_rows; ++v) max_len = std::max(max_len, T.rowlen[v]);
+    T.max_rowlen = max_len;
+    FEMO_REQUIRE(max_len <= 254, "row with %d off-diagonal entries exceeds the 8-bit slot map",
+                 max_len);
+    T.nnz = noff[n_pad] + n_rows;
+
+    // 4. SELL layouts
+    T.vptr.assign(T.n_slices + 1, 0);
+    T.mptr.assign(T.n_slices + 1, 0);
+    for (int64_t s = 0; s < T.n_slices; ++s) {
+      int wv = 0, wm = 0;
+      for (int l = 0; l < FEMO_WAVE; ++l) {
+        wv = std::max(wv, deg[s * FEMO_WAVE + l]);
+        wm = std::max(wm, T.rowlen[s * FEMO_WAVE + l]);
+      }
+      wm = (wm + 1) & ~1;
+      T.vptr[s + 1] = T.vptr[s] + (int64_t)wv * FEMO_WAVE;
+      T.mptr[s + 1] = T.mptr[s] + (int64_t)wm * FEMO_WAVE;
+    }
+    T.visit_cell.assign(T.vptr[T.n_slices], -1);
+    T.visit_slots.assign(T.vptr[T.n_slices], 0xFFFFFFFFu);
+    T.cols.resize(T.mptr[T.n_slices]);
+    parallel_for(T.n_slices, [&](int64_t lo, int64_t hi) {
+      for (int64_t s = lo; s < hi; ++s) {
+        const int wm = (int)((T.mptr[s + 1] - T.mptr[s]) / FEMO_WAVE);
+        for (int l = 0; l < FEMO_WAVE; ++l) {
+          const int64_t v = s * FEMO_WAVE + l;
+          const int32_t* w = tmp.data() + uoff[v];
+          const int len = T.rowlen[v];
+          const int32_t self = (int32_t)std::min<int64_t>(v, n_vert - 1);
+          for (int k = 0; k < wm; ++k)
+            T.cols[femo_sell_index(T.mptr[s], k, l)] = k < len ? w[k] : self;
+          for (int64_t e = off[v]; e < off[v + 1]; ++e) {
+            const int64_t c = inc[e] >> 2;
+            const int a = inc[e] & 3;
+            uint32_t slots = 0xFFFFFFFFu;
+            for (int b = 0; b < nv; ++b) {
+              if (b == a) continue;
+              const int32_t nb = conn[c * nv + b];
+              const int pos = (int)(std::lower_bound(w, w + len, nb) - w);
+              const uint32_t byte = (pos < len && w[pos] == nb) ? (uint32_t)pos : 0xFFu;
+              slots = (slots & ~(0xFFu << (8 * b))) | (byte << (8 * b));
+            }
+            const int64_t idx = T.vptr[s] + (e - off[v]) * FEMO_WAVE + l;
+            T.visit_cell[idx] = inc[e];
+            T.visit_slots[idx] = slots;
+          }
+        }
+      }
+    });
+  }
+  return 0;
+}
+
+void femo_topology_csr(const FemoTopology& T, int64_t* rowptr, int32_t* col) {
+  rowptr[0] = 0;
+  for (int64_t v = 0; v < T.n_rows; ++v) rowptr[v + 1] = rowptr[v] + T.rowlen[v] + 1;
+  if (!col) return;
+  parallel_for(T.n_rows, [&](int64_t lo, int64_t hi) {
+    for (int64_t v = lo; v < hi; ++v) {
+      const int64_t s = v / FEMO_WAVE;
+      const int l = (int)(v % FEMO_WAVE);
+      int32_t* out = col + rowptr[v];
+      bool placed = false;
+      int n = 0;
+      for (int k = 0; k < T.rowlen[v]; ++k) {
+        const int32_t c = T.cols[femo_sell_index(T.mptr[s], k, l)];
+        if (!placed && c > v) {
+          out[n++] = (int32_t)v;
+          placed = true;
+        }
+        out[n++] = c;
+      }
+      if (!placed) out[n++] = (int32_t)v;
+    }
+  });
+}
+
+extern "C" int femo_topology_build_host(int tdim, int64_t n_vert, int64_t n_rows, int64_t n_cell,
+                                        const int32_t* conn, int64_t info[FEMO_MESH_INFO_COUNT],
+                                        int64_t* rowptr, int32_t* col) {
+  FEMO_REQUIRE(conn != nullptr && info != nullptr, "null argument");
+  FemoTopology T;
+  FEMO_TRY(femo_build_topology(tdim, n_vert, n_rows, n_cell, conn, T));
+  info[FEMO_MESH_TDIM] = tdim;
+  info[FEMO_MESH_N_VERT] = n_vert;
+  info[FEMO_MESH_N_ROWS] = n_rows;
+  info[FEMO_MESH_N_CELL] = n_cell;
+  info[FEMO_MESH_NNZ] = T.nnz;
+  info[FEMO_MESH_SELL_ENTRIES] = T.mptr[T.n_slices];
+  info[FEMO_MESH_MAX_ROWLEN] = T.max_rowlen;
+  info[FEMO_MESH_MAX_VALENCE] = T.max_valence;
+  info[FEMO_MESH_N_SLICES] = T.n_slices;
+  info[FEMO_MESH_VISIT_ENTRIES] = T.vptr[T.n_slices];
+  if (rowptr) femo_topology_csr(T, rowptr, col);
+  return 0;
+}

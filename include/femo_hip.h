@@ -1,0 +1,214 @@
+/* femo_hip.h -- C-ABI of libfemo_hip.so: MI355X (gfx950) engine for femo's
+ * PDE-residual hot path (assemble residual / dR/du / dR/df, forward and
+ * transposed linear solves, functional and its partials).
+ *
+ * The reference (RuruX/femo @ 2024_08_07) has NO FFI: its hot path is Python
+ * calling dolfinx/PETSc through pybind/petsc4py.  Each entry point below
+ * therefore cites the *Python call site* it replaces (paths relative to the
+ * reference tree).  INTEGRATION.md shows the ctypes stub a maintainer would add
+ * to femo/fea/utils_dolfinx.py to bind them.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - every function returns 0 on success, non-zero on error; the message is
+ *     available from femo_last_error() (thread-local).  No exception crosses
+ *     the ABI.
+ *   - the caller owns every host buffer; the library owns device memory behind
+ *     opaque handles.  A femo_ctx owns one HIP stream; all work of the handles
+ *     created from it is enqueued on that stream.  Handles are not thread-safe;
+ *     distinct contexts may be used from distinct threads.
+ *   - all arithmetic is fp64; indices are int32 (dolfinx/PETSc default), sizes
+ *     and offsets int64.
+ *   - host<->device copies are synchronous w.r.t. the host (they synchronise the
+ *     context's stream); compute entry points are asynchronous unless they
+ *     return a scalar to the host.
+ */
+#ifndef FEMO_HIP_H
+#define FEMO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FEMO_ABI_VERSION 1
+
+typedef struct femo_ctx  femo_ctx;   /* device + stream + reduction workspace (+ RCCL communicator) */
+typedef struct femo_vec  femo_vec;   /* fp64 device vector  (dolfinx Function.vector / PETSc Vec)     */
+typedef struct femo_mesh femo_mesh;  /* P1 simplex mesh + vertex->cell incidence + sparsity pattern   */
+typedef struct femo_bc   femo_bc;    /* strong Dirichlet set (fea_dolfinx.py:169-176 add_strong_bc)   */
+typedef struct femo_mat  femo_mat;   /* N x N sparse matrix on the mesh pattern (PETSc Mat)           */
+
+/* closed catalogue of residual forms (UFL is not available) */
+enum femo_pde_kind {
+  FEMO_PDE_POISSON = 0,       /* examples/poisson_opt/run_poisson_opt.py:32-38            */
+  FEMO_PDE_NL_POISSON = 1     /* examples/nonlinear_poisson_opt/...py:88-96 (interior)    */
+};
+
+/* closed catalogue of scalar output forms */
+enum femo_functional_kind {
+  FEMO_J_L2_TRACKING = 0      /* 1/2 int (u-u_d)^2 + alpha/2 int f^2 ; run_poisson_opt.py:74-76 */
+};
+
+enum femo_mesh_info_key {
+  FEMO_MESH_TDIM = 0, FEMO_MESH_N_VERT = 1, FEMO_MESH_N_ROWS = 2, FEMO_MESH_N_CELL = 3,
+  FEMO_MESH_NNZ = 4,            /* true nonzeros of the N x N pattern incl. diagonal   */
+  FEMO_MESH_SELL_ENTRIES = 5,   /* padded off-diagonal entries stored                  */
+  FEMO_MESH_MAX_ROWLEN = 6, FEMO_MESH_MAX_VALENCE = 7, FEMO_MESH_N_SLICES = 8,
+  FEMO_MESH_VISIT_ENTRIES = 9,
+  FEMO_MESH_INFO_COUNT = 10
+};
+
+typedef struct femo_solver_opts {
+  double rtol;          /* stop when ||r||_2 <= max(rtol*||b||_2, atol)                 */
+  double atol;
+  int32_t max_it;
+  int32_t zero_guess;   /* 1: x is taken as 0 on entry (skips the initial SpMV)         */
+  int32_t check_every;  /* iterations enqueued between host convergence polls (0 = 32)  */
+  int32_t reserved;
+} femo_solver_opts;
+
+typedef struct femo_solve_info {
+  int32_t iterations;
+  int32_t converged;    /* 1 converged, 0 hit max_it, -1 breakdown                      */
+  double  residual_norm;/* ||r||_2 at exit (recurrence residual)                        */
+  double  rhs_norm;     /* ||b||_2                                                      */
+  double  solve_ms;     /* device time of the solve (HIP events on the ctx stream)      */
+  double  spmv_ms;      /* accumulated device time of sampled SpMV launches             */
+  int32_t spmv_samples; /* number of SpMV launches that were individually timed         */
+  int32_t reserved;
+} femo_solve_info;
+
+/* ---- errors / probing ---------------------------------------------------- */
+const char* femo_last_error(void);
+int  femo_abi_version(void);
+int  femo_device_count(int* n);
+
+/* ---- context --------------------------------------------------------------
+ * stream: a hipStream_t created by the caller (e.g. torch.cuda.Stream().cuda_stream)
+ * or NULL to let the library create one.  Replaces the implicit PETSc/MPI
+ * global state (utils_dolfinx.py:32 comm = MPI.COMM_WORLD).                  */
+int   femo_ctx_create(int device_id, void* stream, femo_ctx** out);
+int   femo_ctx_destroy(femo_ctx* ctx);
+int   femo_ctx_sync(femo_ctx* ctx);
+void* femo_ctx_stream(femo_ctx* ctx);
+
+/* ---- vectors --------------------------------------------------------------
+ * utils_dolfinx.py:155-167 getFuncArray / setFuncArray, :300-311 update.     */
+int     femo_vec_create(femo_ctx* ctx, int64_t n, femo_vec** out);          /* zero-filled */
+int     femo_vec_wrap(femo_ctx* ctx, void* device_ptr, int64_t n, femo_vec** out); /* borrow */
+int     femo_vec_destroy(femo_vec* v);
+int64_t femo_vec_size(const femo_vec* v);
+void*   femo_vec_device_ptr(femo_vec* v);
+int     femo_vec_set_host(femo_vec* v, const double* host, int64_t n);      /* setFuncArray */
+int     femo_vec_get_host(const femo_vec* v, double* host, int64_t n);      /* getFuncArray */
+int     femo_vec_fill(femo_vec* v, double value);                           /* Vec.set      */
+int     femo_vec_copy(femo_vec* dst, const femo_vec* src);
+int     femo_vec_axpy(femo_vec* y, double a, const femo_vec* x);            /* y += a x     */
+int     femo_vec_dot(const femo_vec* x, const femo_vec* y, int64_t n, double* out);
+
+/* ---- mesh -----------------------------------------------------------------
+ * x: (n_vert, tdim) row-major; conn: (n_cell, tdim+1).  n_rows <= n_vert is
+ * the number of *owned* vertices (rows of every operator); vertices
+ * [n_rows, n_vert) are ghosts (single-GPU: n_rows == n_vert).  Builds the
+ * vertex->cell incidence and the sparsity pattern once (dolfinx create_matrix /
+ * sparsity pattern [ext], utils_dolfinx.py:385).                              */
+int femo_mesh_create(femo_ctx* ctx, int tdim, int64_t n_vert, int64_t n_rows,
+                     const double* x, int64_t n_cell, const int32_t* conn,
+                     femo_mesh** out);
+int femo_mesh_destroy(femo_mesh* mesh);
+int femo_mesh_info(const femo_mesh* mesh, int64_t info[FEMO_MESH_INFO_COUNT]);
+/* CSR view of the pattern (rowptr: n_rows+1, col: NNZ; sorted columns).       */
+int femo_mesh_pattern_csr(const femo_mesh* mesh, int64_t* rowptr, int32_t* col);
+
+/* Host-only topology build (no GPU touched): fills the same arrays that
+ * femo_mesh_create uploads.  Used by the CPU test-suite.  Buffers may be NULL
+ * to query sizes via info[].                                                  */
+int femo_topology_build_host(int tdim, int64_t n_vert, int64_t n_rows, int64_t n_cell,
+                             const int32_t* conn, int64_t info[FEMO_MESH_INFO_COUNT],
+                             int64_t* rowptr, int32_t* col);
+
+/* ---- Dirichlet set (fea_dolfinx.py:169-176; dolfinx dirichletbc [ext]) ---- */
+int femo_bc_create(femo_mesh* mesh, int64_t n, const int32_t* dofs, const double* vals,
+                   femo_bc** out);
+int femo_bc_destroy(femo_bc* bc);
+
+/* ---- assembly -------------------------------------------------------------
+ * params: up to 8 doubles of form constants (unused for POISSON).
+ * residual: state_model.py:85 assembleVector(residual_form) -> utils:175-179; NO BCs.
+ * jacobian: state_model.py:132 assembleMatrix(dR_du) (bc == NULL) and
+ *           state_model.py:149 assembleSystem(dR_du, res, bcs) -> utils:189-202
+ *           (bc != NULL: rows and columns of the set zeroed, diagonal 1).
+ * dRdf:     state_model.py:141 assembleMatrix(derivative(res, f)); stored
+ *           cell-major as (n_cell, tdim+1) values aligned with conn, i.e. the
+ *           CSC of the N x n_cell matrix (column c has rows conn[c,:]).        */
+int femo_assemble_residual(femo_mesh* mesh, int pde, const double* params,
+                           const femo_vec* u, const femo_vec* f, femo_vec* r);
+int femo_mat_create(femo_mesh* mesh, femo_mat** out);
+int femo_mat_destroy(femo_mat* A);
+int femo_assemble_jacobian(femo_mesh* mesh, int pde, const double* params,
+                           const femo_vec* u, const femo_vec* f, const femo_bc* bc,
+                           femo_mat* J);
+int femo_assemble_dRdf(femo_mesh* mesh, int pde, const double* params,
+                       const femo_vec* u, const femo_vec* f, femo_vec* vals);
+/* Newton right-hand side with Dirichlet lifting, dolfinx NonlinearProblem.F
+ * [ext] as driven by utils_dolfinx.py:431:  b = F + K[:,bc](g-u); b[bc] = u-g. */
+int femo_newton_rhs(const femo_mat* K_nobc, const femo_vec* F, const femo_vec* u,
+                    const femo_bc* bc, femo_vec* b);
+
+/* ---- operator application (state_model.py:161-200) -------------------------
+ * mat_spmv:   utils_dolfinx.py:256-264 (A*x) / :275-287 (A^T*R).
+ * dRdf_apply: transpose=1: y (n_cell) = dRdf^T x (n_vert); transpose=0:
+ *             y (n_rows) = dRdf x (n_cell).  accumulate=1 adds into y.         */
+int femo_mat_spmv(const femo_mat* A, int transpose, const femo_vec* x, femo_vec* y);
+int femo_dRdf_apply(femo_mesh* mesh, const femo_vec* vals, int transpose,
+                    const femo_vec* x, femo_vec* y, int accumulate);
+int femo_mat_export_csr(const femo_mat* A, int64_t* rowptr, int32_t* col, double* val);
+int femo_mat_diagonal(const femo_mat* A, femo_vec* d);
+
+/* ---- linear solve (fea_dolfinx.py:192-222; utils_dolfinx.py:476-512) --------
+ * Jacobi-preconditioned CG on A (transpose=0) or A^T (transpose=1).  The
+ * reference factorises with MUMPS; CG+Jacobi is the BASELINE.json design.
+ * A must be symmetric positive definite (Poisson with Dirichlet elimination).  */
+int femo_solve_cg(const femo_mat* A, int transpose, const femo_vec* b, femo_vec* x,
+                  const femo_solver_opts* opts, femo_solve_info* info);
+
+/* ---- scalar output and its partials (output_model.py:69-87) ---------------- */
+int femo_functional_value(femo_mesh* mesh, int kind, const double* params,
+                          const femo_vec* u, const femo_vec* f, const femo_vec* u_d,
+                          double* value);
+int femo_functional_grad_u(femo_mesh* mesh, int kind, const double* params,
+                           const femo_vec* u, const femo_vec* f, const femo_vec* u_d,
+                           femo_vec* g);
+int femo_functional_grad_f(femo_mesh* mesh, int kind, const double* params,
+                           const femo_vec* u, const femo_vec* f, const femo_vec* u_d,
+                           femo_vec* g);
+
+/* ---- measurement helper ------------------------------------------------------
+ * Launches `reps` SpMVs of A on x bracketed by HIP events on the ctx stream and
+ * returns the mean device milliseconds per launch (bench.py roofline leg).     */
+int femo_bench_spmv(const femo_mat* A, const femo_vec* x, femo_vec* y, int reps,
+                    double* ms_per_launch);
+
+/* ---- multi-GPU (new design; the reference is single-rank) ----
+ * One process per GPU.  unique id = ncclUniqueId (128 bytes) created on rank 0
+ * and broadcast by the host (torch.distributed).  After comm_init every dot
+ * product inside femo_solve_cg / femo_vec_dot / femo_functional_value is
+ * all-reduced over xGMI; femo_mesh_set_halo installs the ghost exchange plan:
+ * for neighbour k, send_idx[send_ptr[k]:send_ptr[k+1]] are owned local indices
+ * whose values go to rank nbr[k]; values received from nbr[k] land in local
+ * ghost slots [n_rows + recv_ptr[k], n_rows + recv_ptr[k+1]).                  */
+int femo_comm_unique_id(char id[128]);
+int femo_comm_init(femo_ctx* ctx, const char id[128], int rank, int nranks);
+int femo_comm_rank(const femo_ctx* ctx, int* rank, int* nranks);
+int femo_mesh_set_halo(femo_mesh* mesh, int n_nbr, const int32_t* nbr,
+                       const int64_t* send_ptr, const int32_t* send_idx,
+                       const int64_t* recv_ptr);
+int femo_halo_exchange(femo_mesh* mesh, femo_vec* x);
+int femo_allreduce_sum(femo_ctx* ctx, double* host_inout, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEMO_HIP_H */
