@@ -1,0 +1,130 @@
+"""ctypes binding of ``libfemo_hip.so`` (include/femo_hip.h).
+
+The product has no CPU fallback: if the shared library is missing, or a compute
+entry point is called without a HIP device, an exception is raised -- nothing is
+silently routed elsewhere.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libfemo_hip.so")
+
+c_i64 = C.c_int64
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+c_f64p = C.POINTER(C.c_double)
+H = C.c_void_p  # opaque handle
+
+MESH_INFO_COUNT = 10
+MESH_INFO_KEYS = ("tdim", "n_vert", "n_rows", "n_cell", "nnz", "sell_entries", "max_rowlen",
+                  "max_valence", "n_slices", "visit_entries")
+
+PDE_POISSON = 0
+PDE_NL_POISSON = 1
+J_L2_TRACKING = 0
+
+
+class SolverOpts(C.Structure):
+    _fields_ = [("rtol", C.c_double), ("atol", C.c_double), ("max_it", C.c_int32),
+                ("zero_guess", C.c_int32), ("check_every", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SolveInfo(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32),
+                ("residual_norm", C.c_double), ("rhs_norm", C.c_double),
+                ("solve_ms", C.c_double), ("spmv_ms", C.c_double),
+                ("spmv_samples", C.c_int32), ("reserved", C.c_int32)]
+
+
+# name -> (restype, argtypes); every symbol include/femo_hip.h declares
+PROTOTYPES = {
+    "femo_last_error": (C.c_char_p, []),
+    "femo_abi_version": (C.c_int, []),
+    "femo_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "femo_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(H)]),
+    "femo_ctx_destroy": (C.c_int, [H]),
+    "femo_ctx_sync": (C.c_int, [H]),
+    "femo_ctx_stream": (C.c_void_p, [H]),
+    "femo_vec_create": (C.c_int, [H, c_i64, C.POINTER(H)]),
+    "femo_vec_wrap": (C.c_int, [H, C.c_void_p, c_i64, C.POINTER(H)]),
+    "femo_vec_destroy": (C.c_int, [H]),
+    "femo_vec_size": (c_i64, [H]),
+    "femo_vec_device_ptr": (C.c_void_p, [H]),
+    "femo_vec_set_host": (C.c_int, [H, C.c_void_p, c_i64]),
+    "femo_vec_get_host": (C.c_int, [H, C.c_void_p, c_i64]),
+    "femo_vec_fill": (C.c_int, [H, C.c_double]),
+    "femo_vec_copy": (C.c_int, [H, H]),
+    "femo_vec_axpy": (C.c_int, [H, C.c_double, H]),
+    "femo_vec_dot": (C.c_int, [H, H, c_i64, c_f64p]),
+    "femo_mesh_create": (C.c_int, [H, C.c_int, c_i64, c_i64, C.c_void_p, c_i64, C.c_void_p, C.POINTER(H)]),
+    "femo_mesh_destroy": (C.c_int, [H]),
+    "femo_mesh_info": (C.c_int, [H, c_i64p]),
+    "femo_mesh_pattern_csr": (C.c_int, [H, C.c_void_p, C.c_void_p]),
+    "femo_topology_build_host": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, C.c_void_p, c_i64p, C.c_void_p, C.c_void_p]),
+    "femo_bc_create": (C.c_int, [H, c_i64, C.c_void_p, C.c_void_p, C.POINTER(H)]),
+    "femo_bc_destroy": (C.c_int, [H]),
+    "femo_assemble_residual": (C.c_int, [H, C.c_int, C.c_void_p, H, H, H]),
+    "femo_mat_create": (C.c_int, [H, C.POINTER(H)]),
+    "femo_mat_destroy": (C.c_int, [H]),
+    "femo_assemble_jacobian": (C.c_int, [H, C.c_int, C.c_void_p, H, H, H, H]),
+    "femo_assemble_dRdf": (C.c_int, [H, C.c_int, C.c_void_p, H, H, H]),
+    "femo_newton_rhs": (C.c_int, [H, H, H, H, H]),
+    "femo_mat_spmv": (C.c_int, [H, C.c_int, H, H]),
+    "femo_dRdf_apply": (C.c_int, [H, H, C.c_int, H, H, C.c_int]),
+    "femo_mat_export_csr": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "femo_mat_diagonal": (C.c_int, [H, H]),
+    "femo_solve_cg": (C.c_int, [H, C.c_int, H, H, C.POINTER(SolverOpts), C.POINTER(SolveInfo)]),
+    "femo_functional_value": (C.c_int, [H, C.c_int, C.c_void_p, H, H, H, c_f64p]),
+    "femo_functional_grad_u": (C.c_int, [H, C.c_int, C.c_void_p, H, H, H, H]),
+    "femo_functional_grad_f": (C.c_int, [H, C.c_int, C.c_void_p, H, H, H, H]),
+    "femo_bench_spmv": (C.c_int, [H, H, H, C.c_int, c_f64p]),
+    "femo_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "femo_comm_init": (C.c_int, [H, C.c_char_p, C.c_int, C.c_int]),
+    "femo_comm_rank": (C.c_int, [H, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "femo_mesh_set_halo": (C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "femo_halo_exchange": (C.c_int, [H, H]),
+    "femo_allreduce_sum": (C.c_int, [H, c_f64p, C.c_int]),
+}
+
+
+class FemoError(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libfemo_hip.so and bind every prototype.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FemoError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C femo_amd/csrc`).  femo_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    if lib.femo_abi_version() != 1:
+        raise FemoError("libfemo_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().femo_last_error()
+        raise FemoError(msg.decode() if msg else f"libfemo_hip error {rc}")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = load().femo_device_count(C.byref(n))
+    return n.value if rc == 0 else 0

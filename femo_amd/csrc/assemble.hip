@@ -97,9 +97,11 @@ __device__ __forceinline__ void select_row(const CellGeom<D>& G, int a, double g
 
 template <int D>
 __device__ __forceinline__ double dotD(const double* p, const double* q) {
-  double s = p[0] * q[0];
+  // explicit roundings: the value must not depend on which operand the
+  // compiler happens to fuse, so that K[i][j] == K[j][i] bitwise
+  double s = __dmul_rn(p[0], q[0]);
 #pragma unroll
-  for (int k = 1; k < D; ++k) s += p[k] * q[k];
+  for (int k = 1; k < D; ++k) s = __fma_rn(p[k], q[k], s);
   return s;
 }
 
@@ -181,12 +183,12 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
     select_row<D>(G, a, ga);
 #pragma unroll
     for (int b = 0; b <= D; ++b) {
-      const double kab = G.vol * dotD<D>(ga, G.g[b]);
+      const double kab = __dmul_rn(G.vol, dotD<D>(ga, G.g[b]));
       if (b == a) {
         dsum += kab;
       } else {
         const int pos = (slots >> (8 * b)) & 0xFF;
-        strip[pos * FEMO_BLOCK + tid] += kab;
+        strip[pos * FEMO_BLOCK + tid] = __dadd_rn(strip[pos * FEMO_BLOCK + tid], kab);
       }
     }
   }

@@ -1,0 +1,308 @@
+"""Thin object layer over the C-ABI handles (no numerics here).
+
+Each class owns one opaque handle of ``libfemo_hip.so``; NumPy arrays cross the
+boundary as plain pointers + sizes.  The dolfinx/PETSc objects these stand in
+for are named per class.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import FemoError, H, SolveInfo, SolverOpts, check
+
+
+def _f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _h(obj) -> Optional[H]:
+    return None if obj is None else obj.handle
+
+
+class Context:
+    """Device + HIP stream (+ RCCL communicator).  Stands in for PETSc/MPI global state."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self.lib = _lib.load()
+        h = H()
+        check(self.lib.femo_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.handle = h
+        self.device = device
+        self.rank, self.nranks = 0, 1
+
+    def sync(self) -> None:
+        check(self.lib.femo_ctx_sync(self.handle))
+
+    @property
+    def stream(self) -> int:
+        return int(self.lib.femo_ctx_stream(self.handle) or 0)
+
+    def comm_init(self, unique_id: bytes, rank: int, nranks: int) -> None:
+        assert len(unique_id) == 128
+        check(self.lib.femo_comm_init(self.handle, unique_id, rank, nranks))
+        self.rank, self.nranks = rank, nranks
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        check(_lib.load().femo_comm_unique_id(buf))
+        return buf.raw
+
+    def allreduce_sum(self, values: Sequence[float]) -> np.ndarray:
+        a = _f64(values).copy()
+        check(self.lib.femo_allreduce_sum(self.handle, a.ctypes.data_as(_lib.c_f64p), a.size))
+        return a
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.femo_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Vec:
+    """fp64 device vector (PETSc Vec / dolfinx Function.vector)."""
+
+    def __init__(self, ctx: Context, n: int, device_ptr: Optional[int] = None):
+        self.ctx, self.lib, self.n = ctx, ctx.lib, int(n)
+        h = H()
+        if device_ptr is None:
+            check(self.lib.femo_vec_create(ctx.handle, self.n, C.byref(h)))
+        else:
+            check(self.lib.femo_vec_wrap(ctx.handle, C.c_void_p(device_ptr), self.n, C.byref(h)))
+        self.handle = h
+
+    def set(self, a) -> "Vec":
+        a = _f64(a)
+        check(self.lib.femo_vec_set_host(self.handle, _ptr(a), a.size))
+        return self
+
+    def get(self, n: Optional[int] = None) -> np.ndarray:
+        out = np.empty(self.n if n is None else n, dtype=np.float64)
+        check(self.lib.femo_vec_get_host(self.handle, _ptr(out), out.size))
+        return out
+
+    def fill(self, value: float) -> "Vec":
+        check(self.lib.femo_vec_fill(self.handle, float(value)))
+        return self
+
+    def copy_from(self, other: "Vec") -> "Vec":
+        check(self.lib.femo_vec_copy(self.handle, other.handle))
+        return self
+
+    def axpy(self, a: float, x: "Vec") -> "Vec":
+        check(self.lib.femo_vec_axpy(self.handle, float(a), x.handle))
+        return self
+
+    def dot(self, other: "Vec", n: Optional[int] = None) -> float:
+        out = C.c_double(0.0)
+        check(self.lib.femo_vec_dot(self.handle, other.handle, self.n if n is None else n, C.byref(out)))
+        return out.value
+
+    @property
+    def device_ptr(self) -> int:
+        return int(self.lib.femo_vec_device_ptr(self.handle) or 0)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+                self.lib.femo_vec_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class DeviceMesh:
+    """P1 simplex mesh on the device + incidence + sparsity pattern (dolfinx Mesh + dofmap)."""
+
+    def __init__(self, ctx: Context, x: np.ndarray, conn: np.ndarray, n_rows: Optional[int] = None):
+        self.ctx, self.lib = ctx, ctx.lib
+        x = _f64(x)
+        conn = _i32(conn)
+        self.tdim = x.shape[1]
+        assert conn.shape[1] == self.tdim + 1
+        self.n_vert, self.n_cell = x.shape[0], conn.shape[0]
+        self.n_rows = self.n_vert if n_rows is None else int(n_rows)
+        h = H()
+        check(self.lib.femo_mesh_create(ctx.handle, self.tdim, self.n_vert, self.n_rows, _ptr(x),
+                                        self.n_cell, _ptr(conn), C.byref(h)))
+        self.handle = h
+        self.info = self._info()
+
+    def _info(self) -> Dict[str, int]:
+        buf = (C.c_int64 * _lib.MESH_INFO_COUNT)()
+        check(self.lib.femo_mesh_info(self.handle, buf))
+        return dict(zip(_lib.MESH_INFO_KEYS, (int(v) for v in buf)))
+
+    def pattern_csr(self):
+        rowptr = np.zeros(self.n_rows + 1, np.int64)
+        col = np.zeros(self.info["nnz"], np.int32)
+        check(self.lib.femo_mesh_pattern_csr(self.handle, _ptr(rowptr), _ptr(col)))
+        return rowptr, col
+
+    def set_halo(self, nbr, send_ptr, send_idx, recv_ptr) -> None:
+        nbr = _i32(nbr)
+        send_ptr = np.ascontiguousarray(send_ptr, np.int64)
+        recv_ptr = np.ascontiguousarray(recv_ptr, np.int64)
+        send_idx = _i32(send_idx)
+        check(self.lib.femo_mesh_set_halo(self.handle, len(nbr), _ptr(nbr), _ptr(send_ptr),
+                                          _ptr(send_idx), _ptr(recv_ptr)))
+
+    def halo_exchange(self, v: Vec) -> None:
+        check(self.lib.femo_halo_exchange(self.handle, v.handle))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+                self.lib.femo_mesh_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class DirichletSet:
+    """Strong Dirichlet dofs + values (list of dolfinx dirichletbc)."""
+
+    def __init__(self, mesh: DeviceMesh, dofs, vals):
+        self.mesh, self.lib = mesh, mesh.lib
+        dofs = _i32(dofs)
+        vals = _f64(np.broadcast_to(vals, dofs.shape))
+        self.dofs, self.vals = dofs, vals
+        h = H()
+        check(self.lib.femo_bc_create(mesh.handle, dofs.size, _ptr(dofs), _ptr(vals), C.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and getattr(self.mesh.ctx, "handle", None):
+                self.lib.femo_bc_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class Mat:
+    """N x N sparse matrix on the mesh pattern (PETSc Mat)."""
+
+    def __init__(self, mesh: DeviceMesh):
+        self.mesh, self.lib = mesh, mesh.lib
+        h = H()
+        check(self.lib.femo_mat_create(mesh.handle, C.byref(h)))
+        self.handle = h
+
+    def mult(self, x: Vec, y: Vec, transpose: bool = False) -> Vec:
+        check(self.lib.femo_mat_spmv(self.handle, int(transpose), x.handle, y.handle))
+        return y
+
+    def export_csr(self):
+        m = self.mesh
+        rowptr = np.zeros(m.n_rows + 1, np.int64)
+        col = np.zeros(m.info["nnz"], np.int32)
+        val = np.zeros(m.info["nnz"], np.float64)
+        check(self.lib.femo_mat_export_csr(self.handle, _ptr(rowptr), _ptr(col), _ptr(val)))
+        return rowptr, col, val
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        rowptr, col, val = self.export_csr()
+        return sp.csr_matrix((val, col, rowptr), shape=(self.mesh.n_rows, self.mesh.n_vert))
+
+    def diagonal(self, out: Vec) -> Vec:
+        check(self.lib.femo_mat_diagonal(self.handle, out.handle))
+        return out
+
+    def solve_cg(self, b: Vec, x: Vec, transpose: bool = False, rtol: float = 1e-12, atol: float = 0.0,
+                 max_it: int = 100000, zero_guess: bool = True, check_every: int = 32) -> SolveInfo:
+        opts = SolverOpts(rtol, atol, max_it, int(zero_guess), check_every, 0)
+        info = SolveInfo()
+        check(self.lib.femo_solve_cg(self.handle, int(transpose), b.handle, x.handle, C.byref(opts), C.byref(info)))
+        return info
+
+    def bench_spmv(self, x: Vec, y: Vec, reps: int = 50) -> float:
+        ms = C.c_double(0.0)
+        check(self.lib.femo_bench_spmv(self.handle, x.handle, y.handle, reps, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and getattr(self.mesh.ctx, "handle", None):
+                self.lib.femo_mat_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def _params(params) -> Optional[np.ndarray]:
+    if params is None:
+        return None
+    p = np.zeros(8)
+    p[:len(params)] = params
+    return p
+
+
+def assemble_residual(mesh: DeviceMesh, pde: int, params, u: Vec, f: Vec, r: Vec) -> Vec:
+    check(mesh.lib.femo_assemble_residual(mesh.handle, pde, _ptr(_params(params)), u.handle, f.handle, r.handle))
+    return r
+
+
+def assemble_jacobian(mesh: DeviceMesh, pde: int, params, u: Optional[Vec], f: Optional[Vec],
+                      bc: Optional[DirichletSet], J: Mat) -> Mat:
+    check(mesh.lib.femo_assemble_jacobian(mesh.handle, pde, _ptr(_params(params)), _h(u), _h(f), _h(bc), J.handle))
+    return J
+
+
+def assemble_dRdf(mesh: DeviceMesh, pde: int, params, u: Optional[Vec], f: Optional[Vec], vals: Vec) -> Vec:
+    check(mesh.lib.femo_assemble_dRdf(mesh.handle, pde, _ptr(_params(params)), _h(u), _h(f), vals.handle))
+    return vals
+
+
+def newton_rhs(K: Mat, F: Vec, u: Vec, bc: DirichletSet, b: Vec) -> Vec:
+    check(K.lib.femo_newton_rhs(K.handle, F.handle, u.handle, bc.handle, b.handle))
+    return b
+
+
+def dRdf_apply(mesh: DeviceMesh, vals: Vec, x: Vec, y: Vec, transpose: bool, accumulate: bool = False) -> Vec:
+    check(mesh.lib.femo_dRdf_apply(mesh.handle, vals.handle, int(transpose), x.handle, y.handle, int(accumulate)))
+    return y
+
+
+def functional_value(mesh: DeviceMesh, kind: int, params, u: Vec, f: Vec, u_d: Vec) -> float:
+    out = C.c_double(0.0)
+    check(mesh.lib.femo_functional_value(mesh.handle, kind, _ptr(_params(params)), u.handle, f.handle, u_d.handle, C.byref(out)))
+    return out.value
+
+
+def functional_grad_u(mesh: DeviceMesh, kind: int, params, u: Vec, f: Optional[Vec], u_d: Vec, g: Vec) -> Vec:
+    check(mesh.lib.femo_functional_grad_u(mesh.handle, kind, _ptr(_params(params)), u.handle, _h(f), u_d.handle, g.handle))
+    return g
+
+
+def functional_grad_f(mesh: DeviceMesh, kind: int, params, u: Optional[Vec], f: Vec, u_d: Optional[Vec], g: Vec) -> Vec:
+    check(mesh.lib.femo_functional_grad_f(mesh.handle, kind, _ptr(_params(params)), _h(u), f.handle, _h(u_d), g.handle))
+    return g
+
+
+def topology_host(tdim: int, n_vert: int, n_rows: int, conn: np.ndarray):
+    """Host-only pattern build (no GPU): returns (info dict, rowptr, col)."""
+    lib = _lib.load()
+    conn = _i32(conn)
+    info = (C.c_int64 * _lib.MESH_INFO_COUNT)()
+    check(lib.femo_topology_build_host(tdim, n_vert, n_rows, conn.shape[0], _ptr(conn), info, None, None))
+    d = dict(zip(_lib.MESH_INFO_KEYS, (int(v) for v in info)))
+    rowptr = np.zeros(n_rows + 1, np.int64)
+    col = np.zeros(d["nnz"], np.int32)
+    check(lib.femo_topology_build_host(tdim, n_vert, n_rows, conn.shape[0], _ptr(conn), info, _ptr(rowptr), _ptr(col)))
+    return d, rowptr, col
