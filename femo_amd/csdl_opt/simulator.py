@@ -1,0 +1,180 @@
+"""A small driver that plays python_csdl_backend.Simulator [ext] for FEAModel graphs.
+
+It exists so the operators can be exercised (tests, smoke, bench) without CSDL:
+``run()`` walks the operations in the order FEAModel added them and calls
+``solve_residual_equations`` / ``compute``;
+``compute_totals`` does the reverse sweep of section 3.3:
+
+    explicit op :  adj[arg] += seed * dJ/darg           (compute_derivatives)
+    implicit op :  lam = (dR/du)^-T adj[u]               (apply_inverse_jacobian 'rev')
+                   adj[f] -= (dR/df)^T lam               (compute_jacvec_product 'rev')
+
+Variables are promoted by bare name, as the reference's run scripts rely on
+(run_poisson_opt.py:168-176); ``sim['l2_functional_output_model.l2_functional']``
+style addresses resolve to the same store.  ``device=True`` keeps every value
+in HBM (``DeviceArray``) instead of NumPy arrays.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence, Tuple, Union
+
+import numpy as np
+
+from femo_amd.csdl_opt._csdl_compat import CustomExplicitOperation, CustomImplicitOperation
+from femo_amd.engine import DeviceArray, Vec
+from femo_amd.fea.utils_hip import get_context
+
+
+class Simulator:
+    def __init__(self, model, device: bool = False):
+        self.model = model
+        self.device = device
+        self.values: Dict[str, object] = {}
+        self.ops: List[Tuple[str, object]] = []          # (submodel name, operation)
+        self._build(model)
+
+    # ------------------------------------------------------------- graph ----
+    def _build(self, model) -> None:
+        model.define()
+        for name, var in model.variables.items():
+            if var.kind == "input":
+                self._store(name, self._initial(var))
+        for sub_name, sub in model.submodels:
+            sub.define()
+            for name, var in sub.variables.items():
+                if var.kind == "declared" and name not in self.values:
+                    self._store(name, self._initial(var))
+                elif var.kind == "output" and var.op is not None:
+                    self.ops.append((sub_name, var.op))
+                    for oname, meta in var.op.output_meta.items():
+                        if oname not in self.values:
+                            self._store(oname, np.full(meta["shape"], float(np.asarray(meta["val"]).ravel()[0])))
+
+    @staticmethod
+    def _initial(var) -> np.ndarray:
+        val = np.asarray(var.val, dtype=np.float64)
+        return np.broadcast_to(val, var.shape).astype(np.float64).copy() if val.shape != var.shape else val.copy()
+
+    def _store(self, name: str, value) -> None:
+        if self.device and not isinstance(value, DeviceArray):
+            a = np.asarray(value, dtype=np.float64).ravel()
+            cur = self.values.get(name)
+            if isinstance(cur, DeviceArray) and cur.n == a.size:
+                cur.vec.set(a)
+                return
+            value = DeviceArray(Vec(get_context(), a.size).set(a))
+        elif not self.device and isinstance(value, DeviceArray):
+            value = value.numpy()
+        self.values[name] = value
+
+    @staticmethod
+    def _key(name: str) -> str:
+        return name.split(".")[-1]
+
+    def __getitem__(self, name: str):
+        v = self.values[self._key(name)]
+        return v.numpy() if isinstance(v, DeviceArray) else v
+
+    def __setitem__(self, name: str, value) -> None:
+        self._store(self._key(name), value)
+
+    def device_value(self, name: str):
+        return self.values[self._key(name)]
+
+    # --------------------------------------------------------------- run ----
+    def run(self) -> None:
+        for _, op in self.ops:
+            inputs = {k: self.values[k] for k in op.input_meta}
+            if isinstance(op, CustomImplicitOperation):
+                outputs = {k: self.values[k] for k in op.output_meta}
+                op.solve_residual_equations(inputs, outputs)
+            else:
+                outputs = {}
+                op.compute(inputs, outputs)
+            for k, v in outputs.items():
+                if self.device and isinstance(v, DeviceArray):
+                    self.values[k] = v
+                else:
+                    self._store(k, np.atleast_1d(np.asarray(v, dtype=np.float64)))
+
+    # ------------------------------------------------------------ totals ----
+    def _zeros_like(self, name: str):
+        v = self.values[name]
+        if isinstance(v, DeviceArray):
+            return DeviceArray.zeros(get_context(), v.n)
+        return np.zeros_like(np.asarray(v, dtype=np.float64))
+
+    def compute_totals(self, of: Union[str, Sequence[str]], wrt: Union[str, Sequence[str]]):
+        """Reverse-mode total derivatives of scalar outputs ``of`` w.r.t. ``wrt``."""
+        single = isinstance(of, str) and isinstance(wrt, str)
+        ofs = [of] if isinstance(of, str) else list(of)
+        wrts = [wrt] if isinstance(wrt, str) else list(wrt)
+        result = {}
+        for o in ofs:
+            o = self._key(o)
+            if np.size(self[o]) != 1:
+                raise NotImplementedError("compute_totals handles scalar outputs")
+            adj: Dict[str, object] = {}
+            seed_done = False
+            for _, op in reversed(self.ops):
+                inputs = {k: self.values[k] for k in op.input_meta}
+                if isinstance(op, CustomExplicitOperation):
+                    if o not in op.output_meta:
+                        continue
+                    derivatives = {}
+                    op.compute_derivatives(inputs, derivatives)
+                    for (oo, arg), val in derivatives.items():
+                        if arg not in adj:
+                            adj[arg] = self._zeros_like(arg)
+                        adj[arg] += val if isinstance(val, DeviceArray) else np.asarray(val, dtype=np.float64).ravel()
+                    seed_done = True
+                else:
+                    (state,) = tuple(op.output_meta)
+                    if state not in adj:
+                        continue
+                    outputs = {state: self.values[state]}
+                    op.compute_derivatives(inputs, outputs, {})
+                    d_outputs = {state: adj.pop(state)}
+                    d_residuals = {state: self._zeros_like(state)}
+                    op.apply_inverse_jacobian(d_outputs, d_residuals, 'rev')
+                    d_inputs = {k: self._zeros_like(k) for k in op.input_meta}
+                    op.compute_jacvec_product(inputs, outputs, d_inputs, {}, d_residuals, 'rev')
+                    for k, v in d_inputs.items():
+                        if k not in adj:
+                            adj[k] = self._zeros_like(k)
+                        if isinstance(v, DeviceArray):
+                            adj[k].vec.axpy(-1.0, v.vec)
+                        else:
+                            adj[k] = adj[k] - v
+            if not seed_done:
+                raise KeyError(f"no operation produces {o!r}")
+            for w in wrts:
+                w = self._key(w)
+                val = adj.get(w, self._zeros_like(w))
+                result[(o, w)] = val
+        if single:
+            return result[(self._key(of), self._key(wrt))]
+        return result
+
+    def check_totals(self, of: str, wrt: str, step: float = 1e-6, n_dir: int = 3, seed: int = 0) -> dict:
+        """Directional central finite differences vs the adjoint total (the idiom of
+        run_aeroelasticity_static_wo_feedback.py:389-394, on random directions)."""
+        g = np.asarray(self.compute_totals(of, wrt), dtype=np.float64).ravel()
+        x0 = np.array(self[wrt], dtype=np.float64, copy=True)
+        rng = np.random.default_rng(seed)
+        out = dict(analytical=[], fd=[], rel_error=[])
+        for _ in range(n_dir):
+            d = rng.standard_normal(x0.shape)
+            vals = []
+            for s in (+1.0, -1.0):
+                self[wrt] = x0 + s * step * d
+                self.run()
+                vals.append(float(np.asarray(self[of]).ravel()[0]))
+            fd = (vals[0] - vals[1]) / (2 * step)
+            an = float(g @ d)
+            out["analytical"].append(an)
+            out["fd"].append(fd)
+            out["rel_error"].append(abs(an - fd) / max(abs(fd), 1e-300))
+        self[wrt] = x0
+        self.run()
+        return out

@@ -120,11 +120,14 @@ __global__ void k_gather(int64_t n, const int32_t* __restrict__ perm, const doub
 }
 
 // ------------------------------------------------------------- CG kernels ---
-// scal layout: [0],[1] = (gamma, rr) of even iterations; [2],[3] of odd; [4] = delta;
-// [5] = tol^2; [6] = ||b||^2.   flags: [0] done, [1] iterations, [2] breakdown.
+// scal layout: [0],[1] = (gamma = r.z, zz = ||D^-1 r||^2) of even iterations; [2],[3] of odd;
+// [4] = delta = p.Ap; [5] = tol^2; [6] = ||D^-1 b||^2.  Convergence is tested on the
+// preconditioned residual ||D^-1 r||_2 (PETSc's default norm for left-preconditioned CG [ext]):
+// it bounds the relative error by cond(D^-1 A) * rtol and is not inflated by the O(1)
+// Dirichlet rows of the right-hand side.   flags: [0] done, [1] iterations, [2] breakdown.
 constexpr int S_DELTA = 4, S_TOL2 = 5, S_BB = 6;
 
-// r = b - q (q = A x0, or 0), dinv = 1/diag, p = dinv r; partials: r.z, r.r, b.b
+// r = b - q (q = A x0, or 0), dinv = 1/diag, p = z = dinv r; partials: r.z, z.z, (dinv b).(dinv b)
 __global__ __launch_bounds__(FEMO_BLOCK) void k_cg_init(int64_t n, const double* __restrict__ b,
                                                         const double* __restrict__ q, const double* __restrict__ diag,
                                                         double* __restrict__ r, double* __restrict__ p,
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_cg_init(int64_t n, const double*
     const double di = 1.0 / diag[i];
     const double zi = di * ri;
     r[i] = ri; dinv[i] = di; p[i] = zi;
-    s0 += ri * zi; s1 += ri * ri; s2 += bi * bi;
+    s0 += ri * zi; s1 += zi * zi; s2 += (di * bi) * (di * bi);
   }
   double t = femo_block_sum<FEMO_BLOCK>(s0, lds);
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(1024) void k_cg_fold(int nblocks, int nsums, int ds
   }
 }
 
-// x += alpha p ; r -= alpha q ; partials: r.(dinv r), r.r
+// x += alpha p ; r -= alpha q ; partials: r.z, z.z with z = dinv r
 __global__ __launch_bounds__(FEMO_BLOCK) void k_cg_update_xr(int64_t n, int cur, const double* __restrict__ scal,
                                                              const double* __restrict__ p, const double* __restrict__ q,
                                                              const double* __restrict__ dinv, double* __restrict__ x,
@@ -184,16 +187,18 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_cg_update_xr(int64_t n, int cur,
     xi.x += alpha * pi.x; xi.y += alpha * pi.y;
     ri.x -= alpha * qi.x; ri.y -= alpha * qi.y;
     x2[i] = xi; r2[i] = ri;
-    s0 += ri.x * ri.x * di.x + ri.y * ri.y * di.y;
-    s1 += ri.x * ri.x + ri.y * ri.y;
+    const double zx = ri.x * di.x, zy = ri.y * di.y;
+    s0 += ri.x * zx + ri.y * zy;
+    s1 += zx * zx + zy * zy;
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
     const double xi = x[i] + alpha * p[i];
     const double ri = r[i] - alpha * q[i];
     x[i] = xi; r[i] = ri;
-    s0 += ri * ri * dinv[i];
-    s1 += ri * ri;
+    const double zi = ri * dinv[i];
+    s0 += ri * zi;
+    s1 += zi * zi;
   }
   double t = femo_block_sum<FEMO_BLOCK>(s0, lds);
   if (threadIdx.x == 0) partials[blockIdx.x] = t;

@@ -128,6 +128,50 @@ class Vec:
             pass
 
 
+class DeviceArray:
+    """A value that stays in HBM while it crosses the operator boundary.
+
+    The CSDL backend hands NumPy arrays to the operators; the in-repo driver
+    (and bench.py) may hand these instead, so that ``update`` becomes a
+    device-to-device copy and ``getFuncArray`` no PCIe transfer.  Supports the
+    three things the operators do with a value: ``len``, ``+=`` and conversion
+    to NumPy."""
+
+    __array_priority__ = 100
+
+    def __init__(self, vec: Vec, n: Optional[int] = None):
+        self.vec = vec
+        self.n = vec.n if n is None else int(n)
+
+    def __len__(self) -> int:
+        return self.n
+
+    @property
+    def shape(self):
+        return (self.n,)
+
+    def __iadd__(self, other):
+        if isinstance(other, DeviceArray):
+            self.vec.axpy(1.0, other.vec)
+        else:
+            tmp = Vec(self.vec.ctx, self.vec.n).set(np.asarray(other, dtype=np.float64))
+            self.vec.axpy(1.0, tmp)
+        return self
+
+    def numpy(self) -> np.ndarray:
+        return self.vec.get(self.n)
+
+    def __array__(self, dtype=None, copy=None):
+        return self.numpy()
+
+    def copy(self) -> "DeviceArray":
+        return DeviceArray(Vec(self.vec.ctx, self.vec.n).copy_from(self.vec), self.n)
+
+    @staticmethod
+    def zeros(ctx: Context, n: int) -> "DeviceArray":
+        return DeviceArray(Vec(ctx, n), n)
+
+
 class DeviceMesh:
     """P1 simplex mesh on the device + incidence + sparsity pattern (dolfinx Mesh + dofmap)."""
 

@@ -1,0 +1,92 @@
+"""Closed catalogue of variational forms (UFL is not available).
+
+A form object plays the role of the UFL form the reference's run scripts build:
+it records *which* integrand is meant and the Functions it reads, and
+``utils_hip.assemble*`` dispatch on it to the matching HIP kernels.
+``derivative(form, function)`` mirrors ``ufl.derivative`` for the Gateaux
+derivatives the operators request (utils_dolfinx.py:313-314).
+
+Catalogue
+  PoissonResidual        inner(grad u, grad v) dx - inner(f, v) dx
+                         (examples/poisson_opt/run_poisson_opt.py:32-38, 62-70)
+  L2TrackingFunctional   1/2 (u-u_ex)^2 dx + alpha/2 f^2 dx   (run_poisson_opt.py:74-76)
+"""
+from __future__ import annotations
+
+from .. import _lib
+from .function import Function
+
+
+class Form:
+    rank = None           # 0 scalar, 1 vector, 2 matrix
+
+    def functions(self):
+        return ()
+
+
+class PoissonResidual(Form):
+    rank = 1
+    pde_kind = _lib.PDE_POISSON
+    is_linear = True      # Jacobian independent of u and f
+    is_symmetric = True
+
+    def __init__(self, u: Function, f: Function):
+        if u.function_space.family != "CG" or f.function_space.family != "DG":
+            raise NotImplementedError("PoissonResidual needs a CG1 state and a DG0 source")
+        self.u, self.f = u, f
+        self.params = None
+
+    def functions(self):
+        return (self.u, self.f)
+
+
+class L2TrackingFunctional(Form):
+    rank = 0
+    functional_kind = _lib.J_L2_TRACKING
+
+    def __init__(self, u: Function, f: Function, u_exact: Function, alpha: float):
+        self.u, self.f, self.u_exact, self.alpha = u, f, u_exact, float(alpha)
+        self.params = [self.alpha]
+
+    def functions(self):
+        return (self.u, self.f, self.u_exact)
+
+
+class DerivativeForm(Form):
+    """Gateaux derivative of ``form`` w.r.t. ``wrt`` (ufl.derivative)."""
+
+    def __init__(self, form: Form, wrt: Function):
+        if not any(wrt is fn for fn in form.functions()):
+            raise ValueError("derivative w.r.t. a Function the form does not depend on")
+        self.form, self.wrt = form, wrt
+        self.rank = form.rank + 1
+
+
+def derivative(form: Form, function: Function) -> DerivativeForm:
+    return DerivativeForm(form, function)
+
+
+# --- the user-level builders of examples/poisson_opt -------------------------
+ALPHA = 1e-6  # run_poisson_opt.py:28,112
+
+
+def interiorResidual(u, v, f):
+    """run_poisson_opt.py:32-38.  ``v`` (the test function) is implied by the catalogue."""
+    return PoissonResidual(u, f)
+
+
+def pdeRes(u, v, f, u_exact=None, weak_bc=False, sym=False):
+    """run_poisson_opt.py:62-70."""
+    if weak_bc:
+        raise NotImplementedError("Nitsche boundary terms are not in the catalogue yet")
+    return interiorResidual(u, v, f)
+
+
+def outputForm(u, f, u_exact, alpha: float = ALPHA):
+    """run_poisson_opt.py:74-76."""
+    return L2TrackingFunctional(u, f, u_exact, alpha)
+
+
+def TestFunction(function_space):
+    """Placeholder so run scripts keep their shape; the catalogue fixes the test space."""
+    return None

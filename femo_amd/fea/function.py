@@ -1,0 +1,106 @@
+"""Function spaces and functions (replaces dolfinx.fem.FunctionSpace / Function).
+
+Only the two spaces on the hot path exist: ("CG", 1) on vertices and ("DG", 0)
+on cells (run_poisson_opt.py:98-105).  A Function owns one device vector; its
+``vector`` attribute offers the three PETSc idioms the reference uses
+(utils_dolfinx.py:155-167, 308): ``getArray()``, ``[:] = array`` and ``set(x)``.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from ..engine import Vec
+
+
+class FunctionSpace:
+    def __init__(self, mesh, element=("CG", 1)):
+        family, degree = element
+        if (family, degree) not in (("CG", 1), ("Lagrange", 1), ("DG", 0)):
+            raise NotImplementedError(
+                f"function space {element}: the HIP engine implements CG1 states and DG0 inputs only")
+        self.mesh = mesh
+        self.family = "DG" if family == "DG" else "CG"
+        self.degree = degree
+        self.num_sub_spaces = 0
+
+    @property
+    def dim(self) -> int:
+        return self.mesh.n_cell if self.family == "DG" else self.mesh.n_vert
+
+    def tabulate_dof_coordinates(self) -> np.ndarray:
+        return self.mesh.centroids() if self.family == "DG" else self.mesh.x
+
+    def __eq__(self, other):
+        return (isinstance(other, FunctionSpace) and other.mesh is self.mesh
+                and other.family == self.family and other.degree == self.degree)
+
+    __hash__ = object.__hash__
+
+
+class _VectorView:
+    """PETSc-Vec-flavoured access to a Function's device vector."""
+
+    def __init__(self, fn: "Function"):
+        self._fn = fn
+
+    def getArray(self) -> np.ndarray:
+        return self._fn.vec.get()
+
+    def set(self, value) -> None:
+        self._fn.vec.fill(float(np.asarray(value).ravel()[0]))
+
+    def __setitem__(self, key, value) -> None:
+        if key != slice(None):
+            raise NotImplementedError("only v.vector[:] = array is supported")
+        arr = np.asarray(value, dtype=np.float64)
+        if arr.ndim == 0:
+            self._fn.vec.fill(float(arr))
+        else:
+            self._fn.vec.set(arr)
+
+    # no-ops kept so reference call sequences read the same (utils_dolfinx.py:166-167)
+    def assemble(self) -> None:
+        pass
+
+    def ghostUpdate(self, *a, **k) -> None:
+        pass
+
+
+class _XView:
+    def __init__(self, fn):
+        self._fn = fn
+
+    @property
+    def array(self):
+        return _ArrayProxy(self._fn)
+
+
+class _ArrayProxy:
+    def __init__(self, fn):
+        self._fn = fn
+
+    def __setitem__(self, key, value):
+        self._fn.vector[key] = value
+
+    def __array__(self, dtype=None, copy=None):
+        return self._fn.vector.getArray()
+
+
+class Function:
+    def __init__(self, function_space: FunctionSpace, name: str = "f"):
+        from .utils_hip import get_context
+        self.function_space = function_space
+        self.name = name
+        self.vec = Vec(get_context(), function_space.dim)
+        self.vector = _VectorView(self)
+        self.x = _XView(self)
+
+    def interpolate(self, fn) -> None:
+        """fn receives coordinates shaped (3, n_dofs) like dolfinx [ext] (fea_dolfinx.py:163-167)."""
+        x = self.function_space.tabulate_dof_coordinates()
+        xt = np.zeros((3, x.shape[0]))
+        xt[:x.shape[1]] = x.T
+        self.vec.set(np.asarray(fn(xt), dtype=np.float64))
+
+    def rename(self, name, label=None) -> None:
+        self.name = name

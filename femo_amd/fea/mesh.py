@@ -1,0 +1,111 @@
+"""Host-side P1 simplex meshes (replaces dolfinx.mesh for the hot path).
+
+``createUnitSquareMesh`` mirrors femo/fea/utils_dolfinx.py:136-140 (dolfinx
+``create_unit_square``, right diagonals [ext]); ``createUnitCubeMesh`` is the 3-D
+analogue the BASELINE.json configs need (dolfinx ``create_unit_cube``: six
+tetrahedra per cell around the main diagonal [ext]).  Vertices are numbered
+lexicographically (x fastest); DOF numbering == vertex numbering.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import numpy as np
+
+
+class Mesh:
+    """tdim in {2, 3}; ``x`` (n_vert, tdim) float64, ``conn`` (n_cell, tdim+1) int32."""
+
+    def __init__(self, x: np.ndarray, conn: np.ndarray, n: int = 0):
+        self.x = np.ascontiguousarray(x, dtype=np.float64)
+        self.conn = np.ascontiguousarray(conn, dtype=np.int32)
+        self.tdim = self.x.shape[1]
+        if self.conn.shape[1] != self.tdim + 1:
+            raise ValueError("connectivity width must be tdim+1 (P1 simplices)")
+        self.n = n
+        self._device = None
+        self._ctx = None
+
+    @property
+    def n_vert(self) -> int:
+        return self.x.shape[0]
+
+    @property
+    def n_cell(self) -> int:
+        return self.conn.shape[0]
+
+    def device(self, ctx):
+        """The DeviceMesh (incidence + sparsity pattern) of this mesh on ``ctx``."""
+        if self._device is None or self._ctx is not ctx:
+            from ..engine import DeviceMesh
+            self._device = DeviceMesh(ctx, self.x, self.conn)
+            self._ctx = ctx
+        return self._device
+
+    def centroids(self) -> np.ndarray:
+        return self.x[self.conn].mean(axis=1)
+
+
+def _apply_jitter(x: np.ndarray, n: int, jitter: float, seed: int) -> np.ndarray:
+    """Seeded interior perturbation x += jitter*h*U(-1,1)."""
+    if jitter == 0.0:
+        return x
+    rng = np.random.default_rng(seed)
+    d = rng.uniform(-1.0, 1.0, size=x.shape) * (jitter / n)
+    interior = np.all((x > 1e-9) & (x < 1.0 - 1e-9), axis=1)
+    x = x.copy()
+    x[interior] += d[interior]
+    return x
+
+
+def createUnitSquareMesh(n: int, jitter: float = 0.0, seed: int = 20240807) -> Mesh:
+    np1 = n + 1
+    g = np.arange(np1) / n
+    g[-1] = 1.0
+    x = np.empty((np1 * np1, 2))
+    x[:, 0] = np.tile(g, np1)
+    x[:, 1] = np.repeat(g, np1)
+    jj, ii = np.divmod(np.arange(n * n), n)
+    v0 = jj * np1 + ii
+    conn = np.empty((2 * n * n, 3), dtype=np.int32)
+    conn[0::2, 0] = v0; conn[0::2, 1] = v0 + 1; conn[0::2, 2] = v0 + np1 + 1
+    conn[1::2, 0] = v0; conn[1::2, 1] = v0 + np1 + 1; conn[1::2, 2] = v0 + np1
+    return Mesh(_apply_jitter(x, n, jitter, seed), conn, n)
+
+
+_KUHN = ((0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0))
+
+
+def createUnitCubeMesh(n: int, jitter: float = 0.0, seed: int = 20240807) -> Mesh:
+    np1 = n + 1
+    g = np.arange(np1) / n
+    g[-1] = 1.0
+    x = np.empty((np1 ** 3, 3))
+    x[:, 0] = np.tile(g, np1 * np1)
+    x[:, 1] = np.tile(np.repeat(g, np1), np1)
+    x[:, 2] = np.repeat(g, np1 * np1)
+    c = np.arange(n ** 3)
+    kk, rem = np.divmod(c, n * n)
+    jj, ii = np.divmod(rem, n)
+    base = (kk * np1 * np1 + jj * np1 + ii).astype(np.int64)
+    stride = (1, np1, np1 * np1)
+    conn = np.empty((6 * n ** 3, 4), dtype=np.int32)
+    for t, perm in enumerate(_KUHN):
+        v = base.copy()
+        conn[t::6, 0] = v
+        for s, ax in enumerate(perm):
+            v = v + stride[ax]
+            conn[t::6, s + 1] = v
+    return Mesh(_apply_jitter(x, n, jitter, seed), conn, n)
+
+
+def locate_dofs_geometrical(V, marker: Callable[[np.ndarray], np.ndarray]) -> np.ndarray:
+    """dolfinx.fem.locate_dofs_geometrical [ext] for CG1: ``marker`` receives the
+    coordinates as an array of shape (3, n_dofs) (gdim rows used, rest zero) and
+    returns a boolean mask (run_poisson_opt.py:124-133)."""
+    if isinstance(V, (tuple, list)):
+        V = V[0]
+    x = V.tabulate_dof_coordinates()
+    xt = np.zeros((3, x.shape[0]))
+    xt[:x.shape[1]] = x.T
+    return np.nonzero(np.asarray(marker(xt), dtype=bool))[0].astype(np.int32)

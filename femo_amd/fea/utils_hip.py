@@ -1,0 +1,520 @@
+"""Mirror of femo/fea/utils_dolfinx.py on the HIP engine.
+
+Same function names, argument meaning and return conventions as the reference
+(file:line cited per function); dolfinx/PETSc objects are replaced by the
+handle classes of ``femo_amd.engine``.  Values may cross as NumPy arrays (the
+CSDL convention) or as ``DeviceArray`` (stay in HBM).
+"""
+from __future__ import annotations
+
+import os
+from timeit import default_timer
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from .. import _lib
+from .. import engine as E
+from ..engine import Context, DeviceArray, Vec
+from .forms import (DerivativeForm, Form, L2TrackingFunctional, PoissonResidual, derivative)
+from .function import Function, FunctionSpace, _VectorView
+from .mesh import (Mesh, createUnitCubeMesh, createUnitSquareMesh, locate_dofs_geometrical)
+
+DOLFIN_EPS = 3E-16
+
+# ---------------------------------------------------------------- context ----
+_CTX: Optional[Context] = None
+
+
+def get_context() -> Context:
+    """One context (device + stream) per process: device = LOCAL_RANK (one
+    process per GPU), replacing ``comm = MPI.COMM_WORLD`` (utils_dolfinx.py:32)."""
+    global _CTX
+    if _CTX is None:
+        _CTX = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return _CTX
+
+
+def set_context(ctx: Optional[Context]) -> None:
+    global _CTX
+    _CTX = ctx
+
+
+# Linear-solver options: the analogue of the global PETSc options database the
+# reference mutates (utils_dolfinx.py:393-403, 446).  CG + Jacobi replaces MUMPS.
+# rtol acts on the Jacobi-preconditioned residual; the relative error of the
+# solution is bounded by cond(D^-1 A) * rtol (cond ~ 0.4 n^2 on an n^d grid), and
+# 1e-14 keeps states and sensitivities within 1e-10 of the LU oracle on every
+# parity case (measured sweep: DESIGN.md section 6).
+KSP_OPTIONS = dict(rtol=1e-14, atol=0.0, max_it=100000, check_every=32)
+LAST_KSP_INFO: List[dict] = []   # appended by every linear solve (iteration counts for reports)
+
+
+# ------------------------------------------------------- array <-> function ----
+def getFuncArray(v: Function, device: bool = False):
+    """utils_dolfinx.py:155-159."""
+    if device:
+        return DeviceArray(v.vec)
+    return v.vector.getArray()
+
+
+def setFuncArray(v: Function, v_array) -> None:
+    """utils_dolfinx.py:161-167."""
+    if isinstance(v_array, DeviceArray):
+        if v_array.vec is not v.vec:
+            v.vec.copy_from(v_array.vec)
+        return
+    v.vector[:] = v_array
+    v.vector.assemble()
+    v.vector.ghostUpdate()
+
+
+def update(v: Function, v_values) -> None:
+    """utils_dolfinx.py:300-311: a length-1 value broadcasts via Vec.set."""
+    if not isinstance(v_values, DeviceArray) and len(v_values) == 1 and v.function_space.dim != 1:
+        v.vector.set(v_values)
+    else:
+        setFuncArray(v, v_values)
+
+
+def createFunction(function: Function) -> Function:
+    """utils_dolfinx.py:316-317."""
+    return Function(function.function_space)
+
+
+def computePartials(form: Form, function: Function) -> DerivativeForm:
+    """utils_dolfinx.py:313-314."""
+    return derivative(form, function)
+
+
+# ------------------------------------------------------------ Dirichlet BCs ----
+class DirichletBC:
+    """dolfinx.fem.dirichletbc(value, dofs[, V]) [ext] (fea_dolfinx.py:169-176)."""
+
+    def __init__(self, value, dofs, function_space: Optional[FunctionSpace] = None):
+        if isinstance(dofs, (tuple, list)) and len(dofs) == 2 and not np.isscalar(dofs[0]):
+            dofs = dofs[0]        # (V, V) locate returns a pair of identical arrays [ext]
+        self.dofs = np.asarray(dofs, dtype=np.int32).ravel()
+        self.value = value
+        self.function_space = function_space
+
+    def values(self) -> np.ndarray:
+        if isinstance(self.value, Function):
+            return self.value.vector.getArray()[self.dofs]
+        return np.full(self.dofs.shape, float(self.value))
+
+
+def dirichletbc(value, dofs, function_space=None) -> DirichletBC:
+    return DirichletBC(value, dofs, function_space)
+
+
+_BC_CACHE: dict = {}
+
+
+def _dirichlet_set(mesh: Mesh, bcs: Sequence[DirichletBC]) -> Optional[E.DirichletSet]:
+    """Merge a bc list into one device set (first bc wins on duplicates, as
+    dolfinx applies them in order).  Cached per (mesh, list identity, values)."""
+    if not bcs:
+        return None
+    key = (id(mesh), tuple(id(b) for b in bcs))
+    vals = np.concatenate([b.values() for b in bcs])
+    hit = _BC_CACHE.get(key)
+    if hit is not None and np.array_equal(hit[1], vals):
+        return hit[0]
+    dofs = np.concatenate([b.dofs for b in bcs])
+    _, first = np.unique(dofs, return_index=True)
+    ds = E.DirichletSet(mesh.device(get_context()), dofs[first], vals[first])
+    _BC_CACHE[key] = (ds, vals, bcs)
+    return ds
+
+
+# ------------------------------------------------------------------ matrices ----
+class SparseMatrix:
+    """PETSc Mat stand-in for N x N operators on the mesh pattern."""
+
+    def __init__(self, mesh: Mesh, symmetric: bool = False):
+        self.mesh = mesh
+        self.dmesh = mesh.device(get_context())
+        self.mat = E.Mat(self.dmesh)
+        self.symmetric = symmetric
+
+    def getSizes(self):
+        return (self.dmesh.n_rows, self.dmesh.n_vert)
+
+    @property
+    def size(self):
+        return self.getSizes()
+
+    def mult(self, x: Vec, y: Vec) -> Vec:
+        return self.mat.mult(x, y, transpose=False)
+
+    def multTranspose(self, x: Vec, y: Vec) -> Vec:
+        return self.mat.mult(x, y, transpose=not self.symmetric)
+
+    def new_row_vec(self) -> Vec:
+        return Vec(get_context(), self.dmesh.n_vert)
+
+    def new_col_vec(self) -> Vec:
+        return Vec(get_context(), self.dmesh.n_vert)
+
+    def to_scipy(self):
+        return self.mat.to_scipy()
+
+    def getValuesCSR(self):
+        rowptr, col, val = self.mat.export_csr()
+        return rowptr, col, val
+
+
+class CellMatrix:
+    """dR/df for a DG0 argument: N x n_cell, stored cell-major (tdim+1 values per
+    cell aligned with the connectivity), i.e. the CSC of the PETSc Mat the
+    reference assembles at state_model.py:141."""
+
+    def __init__(self, mesh: Mesh):
+        self.mesh = mesh
+        self.dmesh = mesh.device(get_context())
+        self.vals = Vec(get_context(), mesh.n_cell * (mesh.tdim + 1))
+
+    def getSizes(self):
+        return (self.dmesh.n_rows, self.mesh.n_cell)
+
+    def mult(self, x: Vec, y: Vec) -> Vec:
+        return E.dRdf_apply(self.dmesh, self.vals, x, y, transpose=False)
+
+    def multTranspose(self, x: Vec, y: Vec) -> Vec:
+        return E.dRdf_apply(self.dmesh, self.vals, x, y, transpose=True)
+
+    def new_row_vec(self) -> Vec:
+        return Vec(get_context(), self.dmesh.n_vert)
+
+    def new_col_vec(self) -> Vec:
+        return Vec(get_context(), self.mesh.n_cell)
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        d1 = self.mesh.tdim + 1
+        v = self.vals.get()
+        rows = self.mesh.conn.ravel()
+        cols = np.repeat(np.arange(self.mesh.n_cell), d1)
+        A = sp.coo_matrix((v, (rows, cols)), shape=(self.mesh.n_vert, self.mesh.n_cell)).tocsr()
+        A.sort_indices()
+        return A
+
+
+class TransposedMatrix:
+    """Result of ``transpose(A)``: a view, no data is moved (utils_dolfinx.py:241-245)."""
+
+    def __init__(self, A: SparseMatrix):
+        self.A = A
+
+
+def transpose(A: SparseMatrix) -> TransposedMatrix:
+    return TransposedMatrix(A)
+
+
+def convertToCOO(A):
+    """utils_dolfinx.py:248-254."""
+    return A.to_scipy().tocoo()
+
+
+def convertToDense(A) -> np.ndarray:
+    """utils_dolfinx.py:290-297 (debug only)."""
+    return A.to_scipy().toarray()
+
+
+# ------------------------------------------------------------------ assembly ----
+def _mesh_of(form: Form) -> Mesh:
+    base = form.form if isinstance(form, DerivativeForm) else form
+    return base.functions()[0].function_space.mesh
+
+
+def assembleScalar(c: Form) -> float:
+    """utils_dolfinx.py:169-173; local value (all-reduced over ranks inside the engine)."""
+    if isinstance(c, L2TrackingFunctional):
+        dm = _mesh_of(c).device(get_context())
+        return E.functional_value(dm, c.functional_kind, c.params, c.u.vec, c.f.vec, c.u_exact.vec)
+    raise NotImplementedError(f"assembleScalar: {type(c).__name__} is not in the form catalogue")
+
+
+def _assemble_vector_dev(v: Form, out: Optional[Vec] = None) -> Vec:
+    ctx = get_context()
+    mesh = _mesh_of(v)
+    dm = mesh.device(ctx)
+    if isinstance(v, PoissonResidual):
+        out = out or Vec(ctx, dm.n_vert)
+        return E.assemble_residual(dm, v.pde_kind, v.params, v.u.vec, v.f.vec, out)
+    if isinstance(v, DerivativeForm) and isinstance(v.form, L2TrackingFunctional):
+        J = v.form
+        if v.wrt is J.u:
+            out = out or Vec(ctx, dm.n_vert)
+            return E.functional_grad_u(dm, J.functional_kind, J.params, J.u.vec, J.f.vec, J.u_exact.vec, out)
+        if v.wrt is J.f:
+            out = out or Vec(ctx, mesh.n_cell)
+            return E.functional_grad_f(dm, J.functional_kind, J.params, J.u.vec, J.f.vec, J.u_exact.vec, out)
+    raise NotImplementedError(f"assembleVector: {type(v).__name__} is not in the form catalogue")
+
+
+def assembleVector(v: Form, device: bool = False):
+    """utils_dolfinx.py:175-179; no BC treatment."""
+    vec = _assemble_vector_dev(v)
+    return DeviceArray(vec) if device else vec.get()
+
+
+def assembleMatrix(M: Form, bcs: Sequence[DirichletBC] = (), out=None):
+    """utils_dolfinx.py:181-187.  ``out`` lets callers re-use a matrix."""
+    if not isinstance(M, DerivativeForm) or not isinstance(M.form, PoissonResidual):
+        raise NotImplementedError(f"assembleMatrix: {type(M).__name__} is not in the form catalogue")
+    res = M.form
+    mesh = _mesh_of(M)
+    dm = mesh.device(get_context())
+    if M.wrt is res.u:
+        A = out if isinstance(out, SparseMatrix) else SparseMatrix(mesh, symmetric=res.is_symmetric)
+        E.assemble_jacobian(dm, res.pde_kind, res.params, res.u.vec, res.f.vec, _dirichlet_set(mesh, bcs), A.mat)
+        return A
+    if M.wrt is res.f:
+        if bcs:
+            raise NotImplementedError("dR/df with Dirichlet rows eliminated")
+        D = out if isinstance(out, CellMatrix) else CellMatrix(mesh)
+        E.assemble_dRdf(dm, res.pde_kind, res.params, res.u.vec, res.f.vec, D.vals)
+        return D
+    raise NotImplementedError("derivative of the residual w.r.t. this Function")
+
+
+def assembleSystem(J: Form, F: Form, bcs: Sequence[DirichletBC] = (), rhs: bool = True, out=None):
+    """utils_dolfinx.py:189-202: A with Dirichlet rows/cols eliminated (diag 1) and
+    b = F - K[:,bc] g, b[bc] = g (apply_lifting + set_bc [ext]).  The operator
+    layer passes ``rhs=False`` because it discards b (state_model.py:149)."""
+    A = assembleMatrix(J, bcs=bcs, out=out)
+    if not rhs:
+        return A, None
+    mesh = _mesh_of(J)
+    b = _assemble_vector_dev(F)
+    if bcs:
+        ctx = get_context()
+        K = assembleMatrix(J)
+        ds = _dirichlet_set(mesh, bcs)
+        zero = Vec(ctx, b.n)
+        lifted = Vec(ctx, b.n)
+        E.newton_rhs(K.mat, b, zero, ds, lifted)      # F + K g, rows bc = -g
+        # apply_lifting subtracts: b - K g ; set_bc puts g.  Recover from the pieces:
+        bh, lh = b.get(), lifted.get()
+        out_b = 2.0 * bh - lh
+        out_b[ds.dofs] = ds.vals
+        return A, out_b
+    return A, b.get()
+
+
+def assemble(f: Form, dim: int = 0, bcs: Sequence[DirichletBC] = (), device: bool = False):
+    """utils_dolfinx.py:204-213."""
+    if dim == 0:
+        return assembleScalar(f)
+    elif dim == 1:
+        return assembleVector(f, device=device)
+    elif dim == 2:
+        M = assembleMatrix(f, bcs=bcs)
+        return convertToDense(M)
+    else:
+        return TypeError("Invalid type for assembly.")
+
+
+def assemble_partials(of=None, wrt=None, dim=1):
+    """utils_dolfinx.py:216-222."""
+    return assemble(derivative(of, wrt), dim=dim)
+
+
+# --------------------------------------------------------------------- SpMV ----
+def _as_vec(x) -> Vec:
+    if isinstance(x, Function):
+        return x.vec
+    if isinstance(x, _VectorView):
+        return x._fn.vec
+    if isinstance(x, DeviceArray):
+        return x.vec
+    if isinstance(x, Vec):
+        return x
+    raise TypeError(f"expected a Function / vector, got {type(x).__name__}")
+
+
+def computeMatVecProductFwd(A, x: Function, device: bool = False):
+    """utils_dolfinx.py:256-264:  y = A x."""
+    y = A.new_row_vec()
+    A.mult(_as_vec(x), y)
+    n = A.getSizes()[0]
+    return DeviceArray(y, n) if device else y.get(n)
+
+
+def computeMatVecProductBwd(A, R: Function, device: bool = False):
+    """utils_dolfinx.py:275-287:  y = A^T R."""
+    y = A.new_col_vec()
+    A.multTranspose(_as_vec(R), y)
+    n = A.getSizes()[1]
+    return DeviceArray(y, n) if device else y.get(n)
+
+
+# ------------------------------------------------------------- linear solves ----
+class KSP:
+    """A configured Jacobi-CG solve on a fixed operator (PETSc KSP stand-in).
+    ``solve(b, x)`` follows petsc4py's argument order (utils_dolfinx.py:493)."""
+
+    def __init__(self, A, options: Optional[dict] = None):
+        self.transposed = isinstance(A, TransposedMatrix)
+        self.A = A.A if self.transposed else A
+        self.options = dict(KSP_OPTIONS)
+        if options:
+            self.options.update(options)
+        self.info = None
+
+    def solve(self, b, x) -> None:
+        o = self.options
+        tr = self.transposed and not self.A.symmetric
+        self.info = self.A.mat.solve_cg(_as_vec(b), _as_vec(x), transpose=tr, rtol=o["rtol"], atol=o["atol"],
+                                        max_it=o["max_it"], zero_guess=True, check_every=o["check_every"])
+        LAST_KSP_INFO.append(dict(iterations=self.info.iterations, converged=self.info.converged,
+                                  residual_norm=self.info.residual_norm, rhs_norm=self.info.rhs_norm,
+                                  solve_ms=self.info.solve_ms, spmv_ms=self.info.spmv_ms,
+                                  spmv_samples=self.info.spmv_samples))
+        del LAST_KSP_INFO[:-64]
+        if self.info.converged != 1:
+            raise RuntimeError(f"CG did not converge: {self.info.iterations} iterations, "
+                               f"||r|| = {self.info.residual_norm:.3e}, ||b|| = {self.info.rhs_norm:.3e}")
+
+
+def solveKSP_mumps(A, b, x, options: Optional[dict] = None) -> None:
+    """utils_dolfinx.py:476-493: solve A x = b.  Name kept for drop-in; the factorisation
+    is replaced by Jacobi-preconditioned CG on the device (BASELINE.json design)."""
+    KSP(A, options).solve(b, x)
+
+
+solveKSP = solveKSP_mumps   # utils_dolfinx.py:451-474 (ASM/GMRES variant) maps to the same solve
+
+
+def setUpKSP_MUMPS(A, options: Optional[dict] = None) -> KSP:
+    """utils_dolfinx.py:495-512: a reusable solver object for repeated right-hand sides."""
+    return KSP(A, options)
+
+
+# ---------------------------------------------------------- nonlinear solves ----
+class _NewtonBase:
+    def __init__(self, F: Form, w: Function, bcs, abs_tol, rel_tol, max_it, report, error_on_nonconvergence):
+        if not isinstance(F, PoissonResidual):
+            raise NotImplementedError(f"nonlinear solve of {type(F).__name__}")
+        self.F, self.w, self.bcs = F, w, list(bcs)
+        self.atol, self.rtol, self.max_it = abs_tol, rel_tol, max_it
+        self.report, self.error_on_nonconvergence = report, error_on_nonconvergence
+        self.mesh = _mesh_of(F)
+        self.dJ = derivative(F, w)
+        self.iterations = 0
+        self.residual_norms: List[float] = []
+        self.ksp_iterations: List[int] = []
+
+    def _rhs(self, K: Optional[SparseMatrix], Fv: Vec, b: Vec) -> Vec:
+        ds = _dirichlet_set(self.mesh, self.bcs)
+        if ds is None:
+            return b.copy_from(Fv)
+        return E.newton_rhs(K.mat, Fv, self.w.vec, ds, b)
+
+    def solve(self, func: Function):
+        """dolfinx.nls.petsc.NewtonSolver.solve [ext]: F; while not converged and
+        it < max_it: J, solve J dx = b, x -= dx, F, convergence test on ||b||."""
+        ctx = get_context()
+        n = self.mesh.n_vert
+        Fv, b, dx = Vec(ctx, n), Vec(ctx, n), Vec(ctx, n)
+        K = A = None
+        _assemble_vector_dev(self.F, Fv)
+        if self.bcs:
+            K = assembleMatrix(self.dJ)
+        self._rhs(K, Fv, b)
+        r0 = r = float(np.sqrt(b.dot(b)))
+        self.residual_norms = [r]
+        converged = r < self.atol or (r0 > 0 and 1.0 < self.rtol)
+        it = 0
+        opts = dict(KSP_OPTIONS)
+        opts["atol"] = max(opts["atol"], opts["rtol"] * r0)   # never solve below the first residual's target
+        while not converged and it < self.max_it:
+            A = assembleMatrix(self.dJ, bcs=self.bcs, out=A)
+            ksp = KSP(A, opts)
+            ksp.solve(b, dx)
+            self.ksp_iterations.append(ksp.info.iterations)
+            func.vec.axpy(-1.0, dx)
+            it += 1
+            _assemble_vector_dev(self.F, Fv)
+            if self.bcs:
+                K = assembleMatrix(self.dJ, out=K)
+            self._rhs(K, Fv, b)
+            r = float(np.sqrt(b.dot(b)))
+            self.residual_norms.append(r)
+            converged = r < self.atol or (r0 > 0 and r / r0 < self.rtol)
+            if self.report:
+                print(f"Newton iteration {it}: r (abs) = {r:.6e} (tol = {self.atol:g}) "
+                      f"r (rel) = {r / r0 if r0 > 0 else 0.0:.6e} (tol = {self.rtol:g})")
+        self.iterations = it
+        if not converged and self.error_on_nonconvergence:
+            raise RuntimeError("Newton solver did not converge")
+        return it, converged
+
+
+class NewtonSolverHIP(_NewtonBase):
+    pass
+
+
+def NewtonSolver(F, w, bcs=[], abs_tol=1e-50, rel_tol=1e-30, max_it=3, initialize=False,
+                 error_on_nonconvergence=False, report=False):
+    """utils_dolfinx.py:419-449.  Tolerances as in the reference => always
+    ``max_it`` iterations; non-convergence is silent."""
+    if initialize is True:
+        w.vector.set(0.1)                               # utils_dolfinx.py:433-435
+    return NewtonSolverHIP(F, w, bcs, abs_tol, rel_tol, max_it, report, error_on_nonconvergence)
+
+
+class SNESSolverHIP(_NewtonBase):
+    def getConvergedReason(self):
+        return 3 if self._converged else -5             # SNES_CONVERGED_FNORM_RELATIVE / DIVERGED_MAX_IT
+
+    def solve(self, b_unused, x):
+        func = self.w
+        it, self._converged = super().solve(func)
+        return it
+
+
+def SNESSolver(F, w, bcs=[], abs_tol=1e-13, rel_tol=1e-13, max_it=100, report=False):
+    """utils_dolfinx.py:376-416: newtonls, full step, atol = rtol = 1e-13, LU -> CG."""
+    return SNESSolverHIP(F, w, bcs, abs_tol, rel_tol, max_it, report, True)
+
+
+def solveNonlinear(res, func, bc, solver, report, initialize):
+    """utils_dolfinx.py:319-333."""
+    start = default_timer()
+    if solver == 'Newton':
+        newton_solver = NewtonSolver(res, func, bc, initialize=initialize, report=report)
+        newton_solver.solve(func)
+    elif solver == 'SNES':
+        snes_solver = SNESSolver(res, func, bc, report=report)
+        snes_solver.solve(None, func.vector)
+        if report is True:
+            print("Converged reason:", snes_solver.getConvergedReason())
+    else:
+        raise ValueError(f"unknown PDE_SOLVER {solver!r}")
+    stop = default_timer()
+    if report is True:
+        print("Solve nonlinear finished in ", stop - start, "seconds")
+
+
+# --------------------------------------------------------------------- norms ----
+def errorNorm(v: Function, v_ex: Function, norm: str = 'L2') -> float:
+    """utils_dolfinx.py:225-238 (L2 only; host-side, not on the hot path)."""
+    if norm != 'L2':
+        raise NotImplementedError("only the L2 norm is implemented")
+    mesh = v.function_space.mesh
+    X = mesh.x[mesh.conn]
+    E_ = X[:, 1:, :] - X[:, :1, :]
+    vol = np.abs(np.linalg.det(E_)) / (2.0 if mesh.tdim == 2 else 6.0)
+    d = mesh.tdim
+
+    def nodal(fn):
+        a = fn.vector.getArray()
+        return a[mesh.conn] if fn.function_space.family == "CG" else np.repeat(a[:, None], d + 1, axis=1)
+
+    e = nodal(v) - nodal(v_ex)
+    s = e.sum(axis=1)
+    val = (vol / ((d + 1) * (d + 2)) * ((e ** 2).sum(axis=1) + s ** 2)).sum()
+    return float(np.sqrt(val))

@@ -355,14 +355,16 @@ def total_gradient(mesh: OMesh, f: np.ndarray, u: np.ndarray, u_d: np.ndarray,
 def pcg_jacobi(A: sp.csr_matrix, b: np.ndarray, x0: Optional[np.ndarray] = None,
                rtol: float = 1e-12, atol: float = 0.0, max_it: int = 100000
                ) -> Tuple[np.ndarray, int, float]:
+    """Stops on the preconditioned residual ||D^-1 r||_2 <= max(rtol ||D^-1 b||_2, atol)
+    (PETSc's default norm for left-preconditioned CG [ext])."""
     dinv = 1.0 / A.diagonal()
     x = np.zeros_like(b) if x0 is None else x0.copy()
     r = b - A @ x
-    tol = max(rtol * np.linalg.norm(b), atol)
-    rr = float(r @ r)
-    if math.sqrt(rr) <= tol:
-        return x, 0, math.sqrt(rr)
+    tol = max(rtol * np.linalg.norm(dinv * b), atol)
     z = dinv * r
+    zz = float(z @ z)
+    if not math.sqrt(zz) > tol:
+        return x, 0, math.sqrt(zz)
     p = z.copy()
     rz = float(r @ z)
     it = 0
@@ -373,15 +375,15 @@ def pcg_jacobi(A: sp.csr_matrix, b: np.ndarray, x0: Optional[np.ndarray] = None,
         x += alpha * p
         r -= alpha * q
         it += 1
-        rr = float(r @ r)
-        if math.sqrt(rr) <= tol:
-            break
         z = dinv * r
+        zz = float(z @ z)
+        if math.sqrt(zz) <= tol:
+            break
         rz_new = float(r @ z)
         beta = rz_new / rz
         rz = rz_new
         p = z + beta * p
-    return x, it, math.sqrt(rr)
+    return x, it, math.sqrt(zz)
 
 
 # --------------------------------------------------------------------------
