@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Benchmark of femo's hot path on MI355X: DOFs/s of one assemble + adjoint-solve cycle.
+
+One *step* = one full cycle of SURVEY.md section 8(d) through the operator surface
+(FEAModel / StateOperation / OutputOperation):
+
+    set f -> solve_residual_equations (Newton x3: assemble R, dR/du, A; CG)
+          -> OutputOperation.compute (J) -> compute_totals:
+             OutputOperation.compute_derivatives (dJ/du, dJ/df)
+             StateOperation.compute_derivatives (dR/du, dR/df, A)
+             apply_inverse_jacobian 'rev' (transposed CG solve)
+             compute_jacvec_product 'rev' (dR/df^T lambda)   -> dJ/df
+
+Every step gets a different synthetic source f_k and a cold start u = 0, so no
+result of a previous step can be reused.  Inputs and outputs stay in HBM
+(``DeviceArray``); the PCIe-inclusive rate is measured separately and reported
+in the ``pcie_inclusive`` field (never as ``value``).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "DOFs/sec assemble+adjoint-solve, 10M-DOF Poisson, 1/2/4/8 MI355X"
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
+ALPHA = 1e-6                   # run_poisson_opt.py:112
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--n", type=int, default=215, help="cube resolution (215 -> 10,077,696 DOFs)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-n", type=int, default=64, help="cube resolution of the bounded CPU sample")
+    p.add_argument("--no-pcie", action="store_true")
+    return p.parse_args()
+
+
+def spmv_algorithmic_bytes(nnz: int, n: int) -> int:
+    """B_A = nnz*12 + (N+1)*4 + 2N*8 (CSR values+columns, row pointer, x, y)."""
+    return nnz * 12 + (n + 1) * 4 + 2 * n * 8
+
+
+def source_fields(mesh, count: int, seed: int = 20240807):
+    """f_k = f*(centroid) * (0.5 + smooth seeded modulation): K+W different inputs."""
+    xc = mesh.centroids()
+    base = np.prod(np.sin(np.pi * xc), axis=1) / (1.0 + ALPHA * 4.0 * np.pi ** 4)
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        a = rng.uniform(0.2, 0.8, size=3)
+        k = rng.integers(1, 4, size=3)
+        mod = 0.5 + a[0] * np.cos(np.pi * k[0] * xc[:, 0]) * a[1] * np.cos(np.pi * k[1] * xc[:, 1]) \
+            + a[2] * xc[:, 2]
+        out.append(base * mod)
+    return out
+
+
+def build_problem(mesh, device: bool):
+    """The set-up of examples/poisson_opt/run_poisson_opt.py:95-179 on the HIP mirror (3-D)."""
+    from femo_amd.csdl_opt.fea_model import FEAModel
+    from femo_amd.csdl_opt.simulator import Simulator
+    from femo_amd.fea.fea_hip import (FEA, Function, FunctionSpace, TestFunction, locate_dofs_geometrical,
+                                      outputForm, pdeRes)
+    d = mesh.tdim
+    fea = FEA(mesh)
+    fea.REPORT = False
+    Vf, Vu = FunctionSpace(mesh, ('DG', 0)), FunctionSpace(mesh, ('CG', 1))
+    f_fn, u_fn = Function(Vf), Function(Vu)
+    v = TestFunction(Vu)
+
+    class Expression_u:
+        def eval(self, x):
+            return np.prod(np.sin(np.pi * x[:d]), axis=0) / (d * np.pi ** 2)
+
+    u_ex = fea.add_exact_solution(Expression_u, Vu)
+    ubc = Function(Vu)
+    ubc.vector.set(0.0)
+    locs = []
+    for k in range(d):
+        locs.append(locate_dofs_geometrical((Vu, Vu), lambda x, k=k: np.isclose(x[k], 0., atol=1e-6)))
+        locs.append(locate_dofs_geometrical((Vu, Vu), lambda x, k=k: np.isclose(x[k], 1., atol=1e-6)))
+    fea.add_strong_bc(ubc, locs, Vu)
+    fea.add_input('f', f_fn)
+    fea.add_state(name='u', function=u_fn, residual_form=pdeRes(u_fn, v, f_fn), arguments=['f'])
+    fea.add_output(name='l2_functional', type='scalar', form=outputForm(u_fn, f_fn, u_ex, ALPHA),
+                   arguments=['f', 'u'])
+    fea.PDE_SOLVER = 'Newton'
+    model = FEAModel(fea=[fea])
+    model.create_input('f', shape=fea.inputs_dict['f']['shape'], val=0.086)
+    model.add_design_variable('f')
+    model.add_objective('l2_functional', scaler=1e5)
+    return Simulator(model, device=device), fea
+
+
+def one_cycle(sim, fea, f_value):
+    sim['f'] = f_value
+    fea.states_dict['u']['function'].vector.set(0.0)          # cold start: nothing carried over
+    if 'u' in sim.values and hasattr(sim.values['u'], 'vec'):
+        sim.values['u'].vec.fill(0.0)
+    elif 'u' in sim.values:
+        sim.values['u'] = np.zeros_like(sim.values['u'])
+    sim.run()
+    return sim.compute_totals('l2_functional', 'f')
+
+
+def usable_cores() -> int:
+    """Cores this process may actually use: min(affinity, cgroup v2 cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(args, gpu_counts, n_dof_gpu, n_cell_gpu, nnz_gpu):
+    """Bounded sample of the same cycle on the host cores with the C/OpenMP oracle port."""
+    from oracle import c_port
+    from oracle import femo_oracle as fo
+    n = args.cpu_n
+    m = fo.unit_cube_mesh(n)
+    f = source_fields(_Centroid(m), 1)[0]
+    bd = fo.boundary_vertices_box(m.x)
+    threads = usable_cores()
+    out = c_port.poisson_cycle(3, m.x, m.conn, f, fo.u_target(m.x), bd, ALPHA, rtol=1e-14, threads=threads)
+    T = out["times"]
+    t_sample = T["cycle"]
+    dofs_sample = m.n_vert / t_sample
+    # scale the sample to the benchmark mesh: assembly-like phases by cell count, CG by
+    # nnz x iteration count (the GPU run's counts; same algorithm, same stopping rule)
+    it_s = sum(out["it_fwd"]) + out["it_adj"]
+    t_cg = T["cg_fwd"] + T["cg_adj"]
+    per_it_per_nnz = t_cg / max(out["it_fwd"][0] + out["it_adj"], 1) / out["nnz"]
+    t_other = t_sample - t_cg
+    t_scaled = t_other * (n_cell_gpu / m.n_cell) + per_it_per_nnz * nnz_gpu * sum(gpu_counts)
+    return {
+        "value": n_dof_gpu / t_scaled, "unit": "DOFs/s", "cores": int(out["threads"]), "kind": "port",
+        "sample": (f"oracle/femo_oracle_c.c (C/OpenMP restatement, not FEniCSx), same cycle on the n={n} cube "
+                   f"({m.n_vert} DOFs): {t_sample:.2f} s = {dofs_sample:.3e} DOFs/s with CG its {out['it_fwd']}+{out['it_adj']}; "
+                   f"scaled to n={args.n} by cell count (assembly, {t_other:.2f} s) and nnz x GPU iteration counts "
+                   f"{gpu_counts} (CG, {per_it_per_nnz * out['nnz'] * 1e3:.2f} ms/it at n={n})"),
+    }
+
+
+class _Centroid:
+    def __init__(self, m):
+        self._m = m
+
+    def centroids(self):
+        return self._m.x[self._m.conn].mean(axis=1)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        from femo_amd.dist import bench_distributed
+        return bench_distributed(args, rank, world, local_rank)
+
+    from femo_amd.engine import Context, DeviceArray, Vec
+    from femo_amd.fea import utils_hip
+    from femo_amd.fea.mesh import createUnitCubeMesh
+
+    ctx = Context(local_rank)
+    utils_hip.set_context(ctx)
+    t0 = time.perf_counter()
+    mesh = createUnitCubeMesh(args.n)
+    sim, fea = build_problem(mesh, device=True)
+    dm = mesh.device(ctx)
+    n_dof, nnz = mesh.n_vert, dm.info["nnz"]
+    K, W = args.steps, args.warmup
+    f_host = source_fields(mesh, min(K + W, 4))
+    f_dev = [DeviceArray(Vec(ctx, mesh.n_cell).set(f)) for f in f_host]
+    setup_s = time.perf_counter() - t0
+
+    for w in range(W):
+        one_cycle(sim, fea, f_dev[w % len(f_dev)])
+    ctx.sync()
+    del utils_hip.LAST_KSP_INFO[:]
+    t0 = time.perf_counter()
+    for k in range(K):
+        g = one_cycle(sim, fea, f_dev[(W + k) % len(f_dev)])
+    ctx.sync()
+    elapsed = time.perf_counter() - t0
+    ms_per_step = elapsed / K * 1e3
+
+    infos = list(utils_hip.LAST_KSP_INFO)
+    solves = [i for i in infos if i["iterations"] > 0]
+    spmv_ms = sum(i["spmv_ms"] for i in solves)
+    spmv_n = sum(i["spmv_samples"] for i in solves)
+    its_per_step = [i["iterations"] for i in infos[:len(infos) // K]] if K else []
+    cg_ms = sum(i["solve_ms"] for i in infos) / K
+    spmv_avg_ms = spmv_ms / spmv_n if spmv_n else float("nan")
+    B_A = spmv_algorithmic_bytes(nnz, n_dof)
+    achieved = B_A / (spmv_avg_ms * 1e-3) / 1e9
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(prof):
+        try:
+            traffic = json.load(open(prof)).get(f"spmv_n{args.n}")
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": METRIC, "value": n_dof / (ms_per_step * 1e-3), "unit": "DOFs/s",
+        "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": (f"3-D linear Poisson, P1 tets, unit cube n={args.n}: {n_dof} DOFs, {mesh.n_cell} cells, "
+                         f"nnz {nnz}; per step: Newton x3 (assemble R, dR/du, A; Jacobi-CG) + J + dJ/du, dJ/df + "
+                         f"dR/du, dR/df, A + transposed Jacobi-CG + dR/df^T lambda; CG rtol 1e-14; cold start"),
+            "n": args.n, "n_dof": n_dof, "n_cell": mesh.n_cell, "nnz": nnz,
+            "cg_iterations_per_step": its_per_step, "cg_ms_per_step": cg_ms,
+            "non_cg_ms_per_step": ms_per_step - cg_ms, "setup_s": setup_s,
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "kernel": "k_spmv_sell<true> (SELL-64 SpMV + fused p.Ap, one launch per CG iteration)",
+            "algorithmic_bytes_per_launch": B_A, "avg_launch_ms": spmv_avg_ms, "launches_timed": spmv_n,
+        },
+    }
+
+    if not args.no_pcie:
+        sim_h, fea_h = build_problem(mesh, device=False)
+        one_cycle(sim_h, fea_h, f_host[0])
+        ctx.sync()
+        t0 = time.perf_counter()
+        one_cycle(sim_h, fea_h, f_host[1 % len(f_host)])
+        ctx.sync()
+        t_h = time.perf_counter() - t0
+        result["pcie_inclusive"] = {"value": n_dof / t_h, "unit": "DOFs/s", "ms_per_step": t_h * 1e3,
+                                    "note": "NumPy arrays at the operator boundary (H2D/D2H on every update/getFuncArray)"}
+    if not args.no_cpu_baseline:
+        counts = its_per_step if its_per_step else [0]
+        result["cpu_baseline"] = cpu_baseline(args, counts, n_dof, mesh.n_cell, nnz)
+    print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

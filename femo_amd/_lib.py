@@ -19,9 +19,9 @@ c_i64p = C.POINTER(C.c_int64)
 c_f64p = C.POINTER(C.c_double)
 H = C.c_void_p  # opaque handle
 
-MESH_INFO_COUNT = 10
+MESH_INFO_COUNT = 11
 MESH_INFO_KEYS = ("tdim", "n_vert", "n_rows", "n_cell", "nnz", "sell_entries", "max_rowlen",
-                  "max_valence", "n_slices", "visit_entries")
+                  "max_valence", "n_slices", "visit_entries", "regular_slices")
 
 PDE_POISSON = 0
 PDE_NL_POISSON = 1
@@ -72,6 +72,8 @@ PROTOTYPES = {
     "femo_mat_destroy": (C.c_int, [H]),
     "femo_assemble_jacobian": (C.c_int, [H, C.c_int, C.c_void_p, H, H, H, H]),
     "femo_assemble_dRdf": (C.c_int, [H, C.c_int, C.c_void_p, H, H, H]),
+    "femo_assemble_system": (C.c_int, [H, C.c_int, C.c_void_p, H, H, H, H, H, H]),
+    "femo_bc_apply_rhs": (C.c_int, [H, H, H]),
     "femo_newton_rhs": (C.c_int, [H, H, H, H, H]),
     "femo_mat_spmv": (C.c_int, [H, C.c_int, H, H]),
     "femo_dRdf_apply": (C.c_int, [H, H, C.c_int, H, H, C.c_int]),

@@ -98,10 +98,19 @@ class Simulator:
                     self._store(k, np.atleast_1d(np.asarray(v, dtype=np.float64)))
 
     # ------------------------------------------------------------ totals ----
-    def _zeros_like(self, name: str):
+    def _zeros_like(self, name: str, role: str = ""):
+        """Zero array shaped like variable ``name``.  Device arrays are pooled per
+        (name, role) and re-zeroed, so a sweep does not allocate."""
         v = self.values[name]
         if isinstance(v, DeviceArray):
-            return DeviceArray.zeros(get_context(), v.n)
+            pool = self.__dict__.setdefault("_pool", {})
+            a = pool.get((name, role))
+            if a is None or a.n != v.n:
+                a = DeviceArray.zeros(get_context(), v.n)
+                pool[(name, role)] = a
+            else:
+                a.vec.fill(0.0)
+            return a
         return np.zeros_like(np.asarray(v, dtype=np.float64))
 
     def compute_totals(self, of: Union[str, Sequence[str]], wrt: Union[str, Sequence[str]]):
@@ -125,7 +134,7 @@ class Simulator:
                     op.compute_derivatives(inputs, derivatives)
                     for (oo, arg), val in derivatives.items():
                         if arg not in adj:
-                            adj[arg] = self._zeros_like(arg)
+                            adj[arg] = self._zeros_like(arg, 'adj')
                         adj[arg] += val if isinstance(val, DeviceArray) else np.asarray(val, dtype=np.float64).ravel()
                     seed_done = True
                 else:
@@ -135,13 +144,13 @@ class Simulator:
                     outputs = {state: self.values[state]}
                     op.compute_derivatives(inputs, outputs, {})
                     d_outputs = {state: adj.pop(state)}
-                    d_residuals = {state: self._zeros_like(state)}
+                    d_residuals = {state: self._zeros_like(state, 'd_res')}
                     op.apply_inverse_jacobian(d_outputs, d_residuals, 'rev')
-                    d_inputs = {k: self._zeros_like(k) for k in op.input_meta}
+                    d_inputs = {k: self._zeros_like(k, 'd_in') for k in op.input_meta}
                     op.compute_jacvec_product(inputs, outputs, d_inputs, {}, d_residuals, 'rev')
                     for k, v in d_inputs.items():
                         if k not in adj:
-                            adj[k] = self._zeros_like(k)
+                            adj[k] = self._zeros_like(k, 'adj')
                         if isinstance(v, DeviceArray):
                             adj[k].vec.axpy(-1.0, v.vec)
                         else:
@@ -150,7 +159,7 @@ class Simulator:
                 raise KeyError(f"no operation produces {o!r}")
             for w in wrts:
                 w = self._key(w)
-                val = adj.get(w, self._zeros_like(w))
+                val = adj[w] if w in adj else self._zeros_like(w, 'adj')
                 result[(o, w)] = val
         if single:
             return result[(self._key(of), self._key(wrt))]

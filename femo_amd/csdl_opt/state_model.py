@@ -7,7 +7,7 @@ Values may be NumPy arrays (CSDL backend) or ``DeviceArray`` (stay in HBM).
 """
 from femo_amd.fea.fea_hip import *                     # noqa: F401,F403  (state_model.py:1)
 from femo_amd.fea.fea_hip import FEA
-from femo_amd.fea.utils_hip import (DeviceArray, assembleMatrix, assembleSystem, assembleVector,
+from femo_amd.fea.utils_hip import (DeviceArray, SparseMatrix, assembleMatrix, assembleSystem, assembleVector,
                                     computeMatVecProductBwd, computeMatVecProductFwd, computePartials,
                                     createFunction, getFuncArray, setUpKSP_MUMPS, update)
 from femo_amd.csdl_opt._csdl_compat import Model, CustomImplicitOperation, custom
@@ -136,7 +136,11 @@ class StateOperation(CustomImplicitOperation):
         dR_du = state['dR_du']
         if dR_du == None:
             dR_du = computePartials(state['residual_form'], state['function'])
-        self.dRdu = assembleMatrix(dR_du, out=getattr(self, 'dRdu', None))
+        # dRdu (no BCs, state_model.py:132) and A (BCs, state_model.py:149) come out of
+        # ONE pass over the mesh below (assembleSystem(..., out_nobc=self.dRdu)).
+        if getattr(self, 'dRdu', None) is None:
+            self.dRdu = SparseMatrix(state['function'].function_space.mesh,
+                                     symmetric=getattr(state['residual_form'], 'is_symmetric', False))
         dRdf_dict = dict()
         dR_df_list = state['dR_df_list']
         arg_list = state['arguments']
@@ -157,7 +161,8 @@ class StateOperation(CustomImplicitOperation):
         self.dRdf_dict = dRdf_dict
         self.A, _ = assembleSystem(dR_du,
                                    state['residual_form'],
-                                   bcs=self.bcs, rhs=False, out=getattr(self, 'A', None))
+                                   bcs=self.bcs, rhs=False, out=getattr(self, 'A', None),
+                                   out_nobc=self.dRdu)
         self.dR = self.state['d_residual']
         self.du = self.state['d_state']
         if self.linear is True:

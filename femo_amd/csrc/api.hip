@@ -15,8 +15,12 @@ __global__ void k_axpy(int64_t n, double a, const double* __restrict__ x, double
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] += a * x[i];
 }
 
-__global__ void k_bc_mask(int64_t n, const int32_t* __restrict__ dofs, uint8_t* __restrict__ mask) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) mask[dofs[i]] = 1;
+__global__ void k_bc_mask(int64_t n, const int32_t* __restrict__ dofs, const double* __restrict__ vals,
+                          uint8_t* __restrict__ mask, double* __restrict__ dense) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    mask[dofs[i]] = 1;
+    dense[dofs[i]] = vals[i];
+  }
 }
 
 // w = (g - u) on the Dirichlet set, 0 elsewhere (w pre-zeroed)
@@ -248,6 +252,8 @@ int femo_mesh_create(femo_ctx* ctx, int tdim, int64_t n_vert, int64_t n_rows, co
   FEMO_TRY(upload(&m->d_mptr, T.mptr, st));
   FEMO_TRY(upload(&m->d_cols, T.cols, st));
   FEMO_TRY(upload(&m->d_rowlen, T.rowlen, st));
+  FEMO_TRY(upload(&m->d_sdelta, T.sdelta, st));
+  m->sdelta_stride = T.sdelta_stride; m->n_regular = T.n_regular;
   FEMO_HIP_CHECK(hipStreamSynchronize(st));  // T's host buffers die with this scope
   *out = m;
   return 0;
@@ -258,7 +264,7 @@ int femo_mesh_destroy(femo_mesh* m) {
   hipStreamSynchronize(m->ctx->stream);
   hipFree(m->d_x); hipFree(m->d_conn); hipFree(m->d_vptr); hipFree(m->d_visit_cell);
   hipFree(m->d_visit_slots); hipFree(m->d_mptr); hipFree(m->d_cols); hipFree(m->d_rowlen);
-  hipFree(m->d_tperm); hipFree(m->d_send_idx); hipFree(m->d_send_buf);
+  hipFree(m->d_sdelta); hipFree(m->d_tperm); hipFree(m->d_send_idx); hipFree(m->d_send_buf); hipFree(m->d_scratch);
   delete m;
   return 0;
 }
@@ -275,6 +281,7 @@ int femo_mesh_info(const femo_mesh* m, int64_t info[FEMO_MESH_INFO_COUNT]) {
   info[FEMO_MESH_MAX_VALENCE] = m->max_valence;
   info[FEMO_MESH_N_SLICES] = m->n_slices;
   info[FEMO_MESH_VISIT_ENTRIES] = m->visit_entries;
+  info[FEMO_MESH_REGULAR_SLICES] = m->n_regular;
   return 0;
 }
 
@@ -301,10 +308,12 @@ int femo_bc_create(femo_mesh* m, int64_t n, const int32_t* dofs, const double* v
   FEMO_HIP_CHECK(hipMalloc(&b->d_vals, std::max<int64_t>(n, 1) * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&b->d_mask, std::max<int64_t>(m->n_vert, 1) + 64));
   FEMO_HIP_CHECK(hipMemsetAsync(b->d_mask, 0, std::max<int64_t>(m->n_vert, 1) + 64, st));
+  FEMO_HIP_CHECK(hipMalloc(&b->d_dense, (std::max<int64_t>(m->n_vert, 1) + 2) * sizeof(double)));
+  FEMO_HIP_CHECK(hipMemsetAsync(b->d_dense, 0, (std::max<int64_t>(m->n_vert, 1) + 2) * sizeof(double), st));
   if (n > 0) {
     FEMO_HIP_CHECK(hipMemcpyAsync(b->d_dofs, dofs, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
     FEMO_HIP_CHECK(hipMemcpyAsync(b->d_vals, vals, n * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_bc_mask, dim3(grid_for(n)), dim3(256), 0, st, n, b->d_dofs, b->d_mask);
+    hipLaunchKernelGGL(k_bc_mask, dim3(grid_for(n)), dim3(256), 0, st, n, b->d_dofs, b->d_vals, b->d_mask, b->d_dense);
     FEMO_HIP_CHECK(hipGetLastError());
   }
   FEMO_HIP_CHECK(hipStreamSynchronize(st));
@@ -315,7 +324,7 @@ int femo_bc_create(femo_mesh* m, int64_t n, const int32_t* dofs, const double* v
 int femo_bc_destroy(femo_bc* b) {
   if (!b) return 0;
   hipStreamSynchronize(b->mesh->ctx->stream);
-  hipFree(b->d_dofs); hipFree(b->d_vals); hipFree(b->d_mask);
+  hipFree(b->d_dofs); hipFree(b->d_vals); hipFree(b->d_mask); hipFree(b->d_dense);
   delete b;
   return 0;
 }
@@ -356,8 +365,44 @@ int femo_assemble_jacobian(femo_mesh* m, int pde, const double* params, const fe
   FEMO_REQUIRE(J->mesh == m, "matrix belongs to another mesh");
   FEMO_REQUIRE(bc == nullptr || bc->mesh == m, "Dirichlet set belongs to another mesh");
   J->valsT_valid = false;
-  return femo_launch_jacobian(m, pde, params, u ? u->d : nullptr, f ? f->d : nullptr,
-                              bc ? bc->d_mask : nullptr, J->d_diag, J->d_vals);
+  if (bc)
+    return femo_launch_system(m, pde, params, u ? u->d : nullptr, f ? f->d : nullptr, bc->d_mask, bc->d_dense,
+                              nullptr, nullptr, J->d_diag, J->d_vals, nullptr);
+  return femo_launch_system(m, pde, params, u ? u->d : nullptr, f ? f->d : nullptr, nullptr, nullptr,
+                            J->d_diag, J->d_vals, nullptr, nullptr, nullptr);
+}
+
+int femo_assemble_system(femo_mesh* m, int pde, const double* params, const femo_vec* u,
+                         const femo_vec* f, const femo_bc* bc, femo_mat* J_nobc, femo_mat* A_bc,
+                         femo_vec* rhs) {
+  FEMO_REQUIRE(m != nullptr, "null argument");
+  FEMO_REQUIRE(J_nobc || A_bc || rhs, "nothing to assemble");
+  FEMO_REQUIRE((!J_nobc || J_nobc->mesh == m) && (!A_bc || A_bc->mesh == m), "matrix belongs to another mesh");
+  FEMO_REQUIRE(bc == nullptr || bc->mesh == m, "Dirichlet set belongs to another mesh");
+  FEMO_REQUIRE(J_nobc != A_bc || J_nobc == nullptr, "the two matrices must be distinct");
+  if (rhs) {
+    FEMO_REQUIRE(u && f, "the Newton right-hand side needs u and f");
+    FEMO_REQUIRE(u->n >= m->n_vert && f->n >= m->n_cell && rhs->n >= m->n_rows, "vector size mismatch in assemble_system");
+    if (m->n_nbr > 0) FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(u)));
+  }
+  if (J_nobc) J_nobc->valsT_valid = false;
+  if (A_bc) A_bc->valsT_valid = false;
+  return femo_launch_system(m, pde, params, u ? u->d : nullptr, f ? f->d : nullptr,
+                            bc ? bc->d_mask : nullptr, bc ? bc->d_dense : nullptr,
+                            J_nobc ? J_nobc->d_diag : nullptr, J_nobc ? J_nobc->d_vals : nullptr,
+                            A_bc ? A_bc->d_diag : nullptr, A_bc ? A_bc->d_vals : nullptr,
+                            rhs ? rhs->d : nullptr);
+}
+
+int femo_bc_apply_rhs(const femo_bc* bc, const femo_vec* u, femo_vec* b) {
+  FEMO_REQUIRE(bc && u && b, "null argument");
+  femo_mesh* m = bc->mesh;
+  FEMO_REQUIRE(u->n >= m->n_vert && b->n >= m->n_rows, "vector size mismatch in bc_apply_rhs");
+  if (bc->n > 0) {
+    hipLaunchKernelGGL(k_bc_set_rhs, dim3(grid_for(bc->n)), dim3(256), 0, m->ctx->stream, bc->n, m->n_rows, bc->d_dofs, bc->d_vals, u->d, b->d);
+    FEMO_HIP_CHECK(hipGetLastError());
+  }
+  return 0;
 }
 
 int femo_assemble_dRdf(femo_mesh* m, int pde, const double* params, const femo_vec* u,
@@ -373,22 +418,18 @@ int femo_newton_rhs(const femo_mat* K, const femo_vec* F, const femo_vec* u, con
   femo_ctx* ctx = m->ctx;
   FEMO_REQUIRE(u->n >= m->n_vert && F->n >= m->n_rows && b->n >= m->n_rows, "vector size mismatch in newton_rhs");
   FEMO_REQUIRE(b->d != F->d, "newton_rhs cannot run in place");
-  // w (n_vert) lives in the CG p-workspace? keep it simple: a scratch vector
-  femo_vec* w = nullptr;
-  FEMO_TRY(femo_vec_create(ctx, m->n_vert, &w));
-  if (bc->n > 0) {
-    hipLaunchKernelGGL(k_bc_lift_vec, dim3(grid_for(bc->n)), dim3(256), 0, ctx->stream, bc->n, bc->d_dofs, bc->d_vals, u->d, w->d);
-  }
-  int rc = femo_launch_spmv(K, K->d_vals, w->d, b->d, nullptr);
-  if (rc == 0 && m->n_rows > 0) {
+  if (!m->d_scratch) FEMO_HIP_CHECK(hipMalloc(&m->d_scratch, (std::max<int64_t>(m->n_vert, 1) + 2) * sizeof(double)));
+  double* w = m->d_scratch;  // w = (g - u) on the set, 0 elsewhere
+  FEMO_HIP_CHECK(hipMemsetAsync(w, 0, (m->n_vert + 2) * sizeof(double), ctx->stream));
+  if (bc->n > 0)
+    hipLaunchKernelGGL(k_bc_lift_vec, dim3(grid_for(bc->n)), dim3(256), 0, ctx->stream, bc->n, bc->d_dofs, bc->d_vals, u->d, w);
+  FEMO_TRY(femo_launch_spmv(K, K->d_vals, w, b->d, nullptr));
+  if (m->n_rows > 0) {
     hipLaunchKernelGGL(k_add_into, dim3(grid_for(m->n_rows)), dim3(256), 0, ctx->stream, m->n_rows, F->d, b->d);
     if (bc->n > 0)
       hipLaunchKernelGGL(k_bc_set_rhs, dim3(grid_for(bc->n)), dim3(256), 0, ctx->stream, bc->n, m->n_rows, bc->d_dofs, bc->d_vals, u->d, b->d);
   }
-  hipError_t e = hipGetLastError();
-  femo_vec_destroy(w);
-  if (rc) return rc;
-  FEMO_HIP_CHECK(e);
+  FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
 

@@ -146,16 +146,24 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_residual(
 }
 
 // ---------------------------------------------------------------- jacobian --
+// One pass over the incidence produces any subset of
+//   (diag0, vals0)  dR/du without BCs            state_model.py:132
+//   (diag1, vals1)  dR/du with Dirichlet rows/cols eliminated, diagonal 1
+//                                                 state_model.py:149 / dolfinx NonlinearProblem.J [ext]
+//   rhs             Newton right-hand side  F + K[:,bc](g-u), rows bc = u-g
+//                                                 dolfinx NonlinearProblem.F [ext], utils_dolfinx.py:431
 // LDS strip acc[k][tid]: bank = (k*256 + tid)*2 mod 64 depends on tid only ->
 // conflict-free for any per-lane k.
 template <int D, int PDE>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
-    int64_t n_rows, int64_t n_blocks, int cap, const int64_t* __restrict__ vptr,
+    int64_t n_rows, int64_t n_blocks, const int64_t* __restrict__ vptr,
     const int32_t* __restrict__ visit_cell, const uint32_t* __restrict__ visit_slots,
     const int64_t* __restrict__ mptr, const int32_t* __restrict__ cols,
     const int32_t* __restrict__ rowlen, const int32_t* __restrict__ conn,
-    const double* __restrict__ x, const double* __restrict__ u, const uint8_t* __restrict__ bcmask,
-    double* __restrict__ diag, double* __restrict__ vals) {
+    const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ f,
+    const uint8_t* __restrict__ bcmask, const double* __restrict__ bcval,
+    double* __restrict__ diag0, double* __restrict__ vals0, double* __restrict__ diag1,
+    double* __restrict__ vals1, double* __restrict__ rhs) {
   extern __shared__ double strip[];
   const int tid = threadIdx.x;
   const int64_t blk = femo_xcd_block(blockIdx.x, n_blocks);
@@ -167,7 +175,8 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
   for (int k = 0; k < len; ++k) strip[k * FEMO_BLOCK + tid] = 0.0;
   const int64_t vb = vptr[slice];
   const int nvis = (int)((vptr[slice + 1] - vb) >> 6);
-  double dsum = 0.0;
+  const bool want_rhs = rhs != nullptr;
+  double dsum = 0.0, racc = 0.0;
   for (int s = 0; s < nvis; ++s) {
     const int64_t vi = vb + (int64_t)s * 64 + lane;
     const int32_t ca = visit_cell[vi];
@@ -181,9 +190,11 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
     cell_geom<D>(x, v, G);
     double ga[D];
     select_row<D>(G, a, ga);
+    if (want_rhs) racc -= f[c] * G.vol * (1.0 / (D + 1));
 #pragma unroll
     for (int b = 0; b <= D; ++b) {
       const double kab = __dmul_rn(G.vol, dotD<D>(ga, G.g[b]));
+      if (want_rhs) racc += kab * u[v[b]];
       if (b == a) {
         dsum += kab;
       } else {
@@ -192,23 +203,32 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
       }
     }
   }
-  const bool row_bc = bcmask != nullptr && row < n_rows && bcmask[row];
-  if (row < n_rows) diag[row] = row_bc ? 1.0 : dsum;
-  else diag[row] = 1.0;  // padded rows of the last slice: harmless identity
+  const bool valid = row < n_rows;
+  const bool row_bc = bcmask != nullptr && valid && bcmask[row];
+  if (diag0) diag0[row] = valid ? dsum : 1.0;  // padded rows of the last slice: harmless identity
+  if (diag1) diag1[row] = (valid && !row_bc) ? dsum : 1.0;
   const int64_t mb = mptr[slice];
   const int wm = (int)((mptr[slice + 1] - mb) >> 6);
+  double lift = 0.0;
   for (int k = 0; k < wm; k += 2) {
     const int64_t idx = mb + (int64_t)(k >> 1) * 128 + lane * 2;
     double2 o;
     o.x = k < len ? strip[k * FEMO_BLOCK + tid] : 0.0;
     o.y = (k + 1) < len ? strip[(k + 1) * FEMO_BLOCK + tid] : 0.0;
+    if (vals0) *reinterpret_cast<double2*>(vals0 + idx) = o;
     if (bcmask != nullptr) {
       const int2 cc = *reinterpret_cast<const int2*>(cols + idx);
-      if (row_bc || bcmask[cc.x]) o.x = 0.0;
-      if (row_bc || bcmask[cc.y]) o.y = 0.0;
+      const bool bx = bcmask[cc.x], by = bcmask[cc.y];
+      if (want_rhs && !row_bc) {
+        if (bx) lift += o.x * (bcval[cc.x] - u[cc.x]);
+        if (by) lift += o.y * (bcval[cc.y] - u[cc.y]);
+      }
+      if (row_bc || bx) o.x = 0.0;
+      if (row_bc || by) o.y = 0.0;
     }
-    *reinterpret_cast<double2*>(vals + idx) = o;
+    if (vals1) *reinterpret_cast<double2*>(vals1 + idx) = o;
   }
+  if (want_rhs && valid) rhs[row] = row_bc ? (u[row] - bcval[row]) : (racc + lift);
 }
 
 // -------------------------------------------------------------------- dRdf --
@@ -398,9 +418,12 @@ int femo_launch_residual(femo_mesh* m, int pde, const double* params, const doub
   return 0;
 }
 
-int femo_launch_jacobian(femo_mesh* m, int pde, const double* params, const double* u,
-                         const double* f, const uint8_t* bcmask, double* diag, double* vals) {
+int femo_launch_system(femo_mesh* m, int pde, const double* params, const double* u, const double* f,
+                       const uint8_t* bcmask, const double* bcval, double* diag0, double* vals0,
+                       double* diag1, double* vals1, double* rhs) {
   FEMO_REQUIRE(pde == FEMO_PDE_POISSON, "pde kind %d not implemented", pde);
+  FEMO_REQUIRE(rhs == nullptr || (u != nullptr && f != nullptr), "the Newton right-hand side needs u and f");
+  FEMO_REQUIRE((diag1 == nullptr && rhs == nullptr) || bcmask == nullptr || bcval != nullptr, "missing Dirichlet values");
   const int64_t nb = row_blocks(m);
   if (nb == 0) return 0;
   int cap = 16;
@@ -411,11 +434,11 @@ int femo_launch_jacobian(femo_mesh* m, int pde, const double* params, const doub
   if (m->tdim == 3) {
     auto k = k_jacobian<3, FEMO_PDE_POISSON>;
     if (lds > 64 * 1024) FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(nb), dim3(FEMO_BLOCK), lds, st, m->n_rows, nb, cap, m->d_vptr, m->d_visit_cell, m->d_visit_slots, m->d_mptr, m->d_cols, m->d_rowlen, m->d_conn, m->d_x, u, bcmask, diag, vals);
+    hipLaunchKernelGGL(k, dim3(nb), dim3(FEMO_BLOCK), lds, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_visit_slots, m->d_mptr, m->d_cols, m->d_rowlen, m->d_conn, m->d_x, u, f, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
   } else {
     auto k = k_jacobian<2, FEMO_PDE_POISSON>;
     if (lds > 64 * 1024) FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(nb), dim3(FEMO_BLOCK), lds, st, m->n_rows, nb, cap, m->d_vptr, m->d_visit_cell, m->d_visit_slots, m->d_mptr, m->d_cols, m->d_rowlen, m->d_conn, m->d_x, u, bcmask, diag, vals);
+    hipLaunchKernelGGL(k, dim3(nb), dim3(FEMO_BLOCK), lds, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_visit_slots, m->d_mptr, m->d_cols, m->d_rowlen, m->d_conn, m->d_x, u, f, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
   }
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;

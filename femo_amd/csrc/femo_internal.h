@@ -74,6 +74,11 @@ struct FemoTopology {
   std::vector<int64_t> mptr;
   std::vector<int32_t> cols;          // padding entries carry the row's own index
   std::vector<int32_t> rowlen;        // off-diagonal entries per row (n_slices*64)
+  // Slices whose 64 rows all have cols[k] = row + delta[k] (locally regular numbering)
+  // carry their deltas here; SpMV then needs no column indices for them.
+  std::vector<int32_t> sdelta;        // n_slices * sdelta_stride, sdelta[s*stride] = INT32_MIN if irregular
+  int sdelta_stride = 0;              // = padded max row length
+  int64_t n_regular = 0;
   int64_t nnz = 0;                    // true nonzeros incl. diagonal
   int max_rowlen = 0, max_valence = 0;
 };
@@ -123,6 +128,9 @@ struct femo_mesh {
   int64_t* d_mptr = nullptr;
   int32_t* d_cols = nullptr;
   int32_t* d_rowlen = nullptr;
+  int32_t* d_sdelta = nullptr;   // per-slice column deltas (see FemoTopology::sdelta)
+  int sdelta_stride = 0;
+  int64_t n_regular = 0;
   int32_t* d_tperm = nullptr;  // lazily built: SELL entry -> SELL entry of the transposed nonzero
   std::vector<int64_t> h_mptr;
   // halo plan (n_nbr == 0 on a single GPU)
@@ -131,6 +139,7 @@ struct femo_mesh {
   std::vector<int64_t> send_ptr, recv_ptr;
   int32_t* d_send_idx = nullptr;
   double* d_send_buf = nullptr;
+  double* d_scratch = nullptr;  // n_vert doubles, lazily allocated (Dirichlet lifting)
 };
 
 struct femo_bc {
@@ -139,6 +148,7 @@ struct femo_bc {
   int32_t* d_dofs = nullptr;
   double* d_vals = nullptr;
   uint8_t* d_mask = nullptr;  // n_vert
+  double* d_dense = nullptr;  // n_vert: prescribed value on the set, 0 elsewhere
 };
 
 struct femo_mat {
@@ -187,8 +197,9 @@ __device__ __forceinline__ int64_t femo_xcd_block(int64_t b, int64_t nb) {
 // kernel launchers implemented in the .hip files -------------------------------
 int femo_launch_residual(femo_mesh* m, int pde, const double* params, const double* u,
                          const double* f, double* r);
-int femo_launch_jacobian(femo_mesh* m, int pde, const double* params, const double* u,
-                         const double* f, const uint8_t* bcmask, double* diag, double* vals);
+int femo_launch_system(femo_mesh* m, int pde, const double* params, const double* u, const double* f,
+                       const uint8_t* bcmask, const double* bcval, double* diag0, double* vals0,
+                       double* diag1, double* vals1, double* rhs);
 int femo_launch_dRdf(femo_mesh* m, int pde, const double* params, const double* u,
                      const double* f, double* vals);
 int femo_launch_dRdf_apply(femo_mesh* m, const double* vals, int transpose, const double* x,

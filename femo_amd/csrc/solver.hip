@@ -18,6 +18,7 @@
 // per-block partials, a one-block kernel folds them (plus an RCCL all-reduce
 // when nranks > 1) and the consumers read the folded scalars.  The host only
 // polls a "done" flag every `check_every` iterations, two batches deep.
+#include <climits>
 #include <cmath>
 
 #include "femo_internal.h"
@@ -25,46 +26,135 @@
 namespace {
 
 // ------------------------------------------------------------------- SpMV ---
+// NP pair-steps of one row, fully unrolled: all value/column loads are issued
+// before the first gather, all gathers before the first FMA, so one slice costs
+// two memory round trips whatever its width.  Summation order is k = 0, 1, 2, ...
+template <int NP, bool NT>
+__device__ __forceinline__ double row_pairs(const double2* __restrict__ v2, const int2* __restrict__ c2,
+                                            const double* __restrict__ x, double acc) {
+  double2 a[NP];
+  int2 j[NP];
+#pragma unroll
+  for (int m = 0; m < NP; ++m) {
+    if (NT) {
+      a[m].x = __builtin_nontemporal_load(&v2[m * 64].x);
+      a[m].y = __builtin_nontemporal_load(&v2[m * 64].y);
+      j[m].x = __builtin_nontemporal_load(&c2[m * 64].x);
+      j[m].y = __builtin_nontemporal_load(&c2[m * 64].y);
+    } else {
+      a[m] = v2[m * 64];
+      j[m] = c2[m * 64];
+    }
+  }
+  double xv[2 * NP];
+#pragma unroll
+  for (int m = 0; m < NP; ++m) {
+    xv[2 * m] = x[j[m].x];
+    xv[2 * m + 1] = x[j[m].y];
+  }
+#pragma unroll
+  for (int m = 0; m < NP; ++m) {
+    acc += a[m].x * xv[2 * m];
+    acc += a[m].y * xv[2 * m + 1];
+  }
+  return acc;
+}
+
+template <bool NT>
+__device__ __forceinline__ double row_sum(int npair, const double2* __restrict__ v2, const int2* __restrict__ c2,
+                                          const double* __restrict__ x, double acc) {
+  while (npair > 8) {
+    acc = row_pairs<8, NT>(v2, c2, x, acc);
+    v2 += 8 * 64; c2 += 8 * 64; npair -= 8;
+  }
+  switch (npair) {  // wave-uniform
+    case 8: return row_pairs<8, NT>(v2, c2, x, acc);
+    case 7: return row_pairs<7, NT>(v2, c2, x, acc);
+    case 6: return row_pairs<6, NT>(v2, c2, x, acc);
+    case 5: return row_pairs<5, NT>(v2, c2, x, acc);
+    case 4: return row_pairs<4, NT>(v2, c2, x, acc);
+    case 3: return row_pairs<3, NT>(v2, c2, x, acc);
+    case 2: return row_pairs<2, NT>(v2, c2, x, acc);
+    case 1: return row_pairs<1, NT>(v2, c2, x, acc);
+    default: return acc;
+  }
+}
+
+// Regular slice: column k of lane l is row + delta[k]; x is read as 64 consecutive
+// doubles per k (one coalesced 512-B load), no column indices are fetched.
+template <int NP>
+__device__ __forceinline__ double row_pairs_regular(const double2* __restrict__ v2, const int32_t* __restrict__ delta,
+                                                    const double* __restrict__ xrow, double acc) {
+  double2 a[NP];
+#pragma unroll
+  for (int m = 0; m < NP; ++m) {
+    a[m].x = __builtin_nontemporal_load(&v2[m * 64].x);
+    a[m].y = __builtin_nontemporal_load(&v2[m * 64].y);
+  }
+  double xv[2 * NP];
+#pragma unroll
+  for (int m = 0; m < NP; ++m) {
+    xv[2 * m] = xrow[delta[2 * m]];
+    xv[2 * m + 1] = xrow[delta[2 * m + 1]];
+  }
+#pragma unroll
+  for (int m = 0; m < NP; ++m) {
+    acc += a[m].x * xv[2 * m];
+    acc += a[m].y * xv[2 * m + 1];
+  }
+  return acc;
+}
+
+__device__ __forceinline__ double row_sum_regular(int npair, const double2* __restrict__ v2, const int32_t* __restrict__ delta,
+                                                  const double* __restrict__ xrow, double acc) {
+  while (npair > 8) {
+    acc = row_pairs_regular<8>(v2, delta, xrow, acc);
+    v2 += 8 * 64; delta += 16; npair -= 8;
+  }
+  switch (npair) {  // wave-uniform
+    case 8: return row_pairs_regular<8>(v2, delta, xrow, acc);
+    case 7: return row_pairs_regular<7>(v2, delta, xrow, acc);
+    case 6: return row_pairs_regular<6>(v2, delta, xrow, acc);
+    case 5: return row_pairs_regular<5>(v2, delta, xrow, acc);
+    case 4: return row_pairs_regular<4>(v2, delta, xrow, acc);
+    case 3: return row_pairs_regular<3>(v2, delta, xrow, acc);
+    case 2: return row_pairs_regular<2>(v2, delta, xrow, acc);
+    case 1: return row_pairs_regular<1>(v2, delta, xrow, acc);
+    default: return acc;
+  }
+}
+
 template <bool DOT>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_spmv_sell(
     int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ mptr,
-    const int32_t* __restrict__ cols, const double* __restrict__ vals,
-    const double* __restrict__ diag, const double* __restrict__ x, double* __restrict__ y,
-    double* __restrict__ partials, const int32_t* __restrict__ done) {
+    const int32_t* __restrict__ cols, const int32_t* __restrict__ sdelta, int sdelta_stride,
+    const double* __restrict__ vals, const double* __restrict__ diag, const double* __restrict__ x,
+    double* __restrict__ y, double* __restrict__ partials, const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
   __shared__ double lds[FEMO_BLOCK / 64];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   // XCD-aware: blockIdx % 8 labels the XCD group; each group walks its own
-  // contiguous eighth of the slices, its waves interleaved slice by slice.
+  // contiguous eighth of the slices, its waves interleaved slice by slice, so the
+  // x window the group gathers from stays in that XCD's L2.
   const int xcd = blockIdx.x & 7;
   const int64_t blk_in_xcd = blockIdx.x >> 3;
   const int64_t waves_per_xcd = (int64_t)(gridDim.x >> 3) * (FEMO_BLOCK / 64);
   const int64_t s_lo = n_slices * xcd / 8, s_hi = n_slices * (xcd + 1) / 8;
   double dot = 0.0;
-  for (int64_t slice = s_lo + blk_in_xcd * (FEMO_BLOCK / 64) + wave; slice < s_hi;
-       slice += waves_per_xcd) {
+  for (int64_t slice = s_lo + blk_in_xcd * (FEMO_BLOCK / 64) + wave; slice < s_hi; slice += waves_per_xcd) {
     const int64_t base = mptr[slice];
     const int npair = (int)((mptr[slice + 1] - base) >> 7);
     const int64_t row = (slice << 6) + lane;
     const double xr = x[row < n_rows ? row : 0];
     double acc = diag[row] * xr;
     const double2* __restrict__ v2 = reinterpret_cast<const double2*>(vals + base) + lane;
-    const int2* __restrict__ c2 = reinterpret_cast<const int2*>(cols + base) + lane;
-    int m = 0;
-    for (; m + 4 <= npair; m += 4) {
-      const double2 a0 = v2[(m + 0) * 64], a1 = v2[(m + 1) * 64], a2 = v2[(m + 2) * 64], a3 = v2[(m + 3) * 64];
-      const int2 j0 = c2[(m + 0) * 64], j1 = c2[(m + 1) * 64], j2 = c2[(m + 2) * 64], j3 = c2[(m + 3) * 64];
-      const double x0 = x[j0.x], x1 = x[j0.y], x2 = x[j1.x], x3 = x[j1.y];
-      const double x4 = x[j2.x], x5 = x[j2.y], x6 = x[j3.x], x7 = x[j3.y];
-      acc += a0.x * x0; acc += a0.y * x1; acc += a1.x * x2; acc += a1.y * x3;
-      acc += a2.x * x4; acc += a2.y * x5; acc += a3.x * x6; acc += a3.y * x7;
-    }
-    for (; m < npair; ++m) {
-      const double2 a0 = v2[m * 64];
-      const int2 j0 = c2[m * 64];
-      acc += a0.x * x[j0.x];
-      acc += a0.y * x[j0.y];
+    const int32_t* __restrict__ dl = sdelta + slice * sdelta_stride;
+    if (dl[0] != INT32_MIN) {  // wave-uniform (scalar load)
+      acc = row_sum_regular(npair, v2, dl, x + row, acc);
+    } else {
+      const int2* __restrict__ c2 = reinterpret_cast<const int2*>(cols + base) + lane;
+      acc = row_sum<true>(npair, v2, c2, x, acc);
     }
     if (row < n_rows) {
       y[row] = acc;
@@ -268,7 +358,7 @@ inline int vec_grid(const femo_ctx* ctx, int64_t n) {
 
 int femo_spmv_grid(const femo_mesh* m) {
   int64_t g = (m->n_slices + 3) / 4;           // one slice per wave if the mesh is small
-  const int64_t cap = (int64_t)m->ctx->n_cu * 8;
+  const int64_t cap = (int64_t)m->ctx->n_cu * 4;  // 4 x 256 threads resident per CU (~100 VGPRs)
   if (g > cap) g = cap;
   if (g > FEMO_MAX_PARTIALS) g = FEMO_MAX_PARTIALS;
   g = (g + 7) & ~int64_t(7);                   // whole XCD groups
@@ -283,9 +373,9 @@ static int launch_spmv(const femo_mat* A, const double* vals, const double* x, d
   const int g = femo_spmv_grid(m);
   hipStream_t st = m->ctx->stream;
   if (partials)
-    hipLaunchKernelGGL(k_spmv_sell<true>, dim3(g), dim3(FEMO_BLOCK), 0, st, m->n_rows, m->n_slices, m->d_mptr, m->d_cols, vals, A->d_diag, x, y, partials, done);
+    hipLaunchKernelGGL(k_spmv_sell<true>, dim3(g), dim3(FEMO_BLOCK), 0, st, m->n_rows, m->n_slices, m->d_mptr, m->d_cols, m->d_sdelta, m->sdelta_stride, vals, A->d_diag, x, y, partials, done);
   else
-    hipLaunchKernelGGL(k_spmv_sell<false>, dim3(g), dim3(FEMO_BLOCK), 0, st, m->n_rows, m->n_slices, m->d_mptr, m->d_cols, vals, A->d_diag, x, y, partials, done);
+    hipLaunchKernelGGL(k_spmv_sell<false>, dim3(g), dim3(FEMO_BLOCK), 0, st, m->n_rows, m->n_slices, m->d_mptr, m->d_cols, m->d_sdelta, m->sdelta_stride, vals, A->d_diag, x, y, partials, done);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }

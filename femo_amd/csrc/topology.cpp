@@ -7,6 +7,7 @@
 // host cores, so it can be tested without a GPU (femo_topology_build_host).
 #include <algorithm>
 #include <atomic>
+#include <climits>
 #include <cstdarg>
 #include <thread>
 
@@ -185,6 +186,34 @@ int femo_build_topology(int tdim, int64_t n_vert, int64_t n_rows, int64_t n_cell
         }
       }
     });
+    // 5. regular slices: every lane's k-th column is row + delta[k]
+    T.sdelta_stride = (T.max_rowlen + 1) & ~1;
+    if (T.sdelta_stride < 2) T.sdelta_stride = 2;
+    T.sdelta.assign((size_t)T.n_slices * T.sdelta_stride, INT32_MIN);
+    std::atomic<int64_t> nreg{0};
+    parallel_for(T.n_slices, [&](int64_t lo, int64_t hi) {
+      int64_t local = 0;
+      for (int64_t s = lo; s < hi; ++s) {
+        if ((s + 1) * FEMO_WAVE > n_rows) continue;          // partial last slice: general path
+        const int wm = (int)((T.mptr[s + 1] - T.mptr[s]) / FEMO_WAVE);
+        bool regular = wm > 0;
+        const int len0 = T.rowlen[s * FEMO_WAVE];
+        if (len0 != wm) regular = false;                      // padding would break the delta form
+        for (int l = 1; l < FEMO_WAVE && regular; ++l)
+          if (T.rowlen[s * FEMO_WAVE + l] != len0) regular = false;
+        for (int k = 0; k < wm && regular; ++k) {
+          const int64_t d0 = (int64_t)T.cols[femo_sell_index(T.mptr[s], k, 0)] - s * FEMO_WAVE;
+          for (int l = 1; l < FEMO_WAVE; ++l)
+            if ((int64_t)T.cols[femo_sell_index(T.mptr[s], k, l)] - (s * FEMO_WAVE + l) != d0) { regular = false; break; }
+        }
+        if (!regular) continue;
+        for (int k = 0; k < wm; ++k)
+          T.sdelta[s * T.sdelta_stride + k] = (int32_t)((int64_t)T.cols[femo_sell_index(T.mptr[s], k, 0)] - s * FEMO_WAVE);
+        ++local;
+      }
+      nreg += local;
+    });
+    T.n_regular = nreg.load();
   }
   return 0;
 }
@@ -229,6 +258,7 @@ extern "C" int femo_topology_build_host(int tdim, int64_t n_vert, int64_t n_rows
   info[FEMO_MESH_MAX_VALENCE] = T.max_valence;
   info[FEMO_MESH_N_SLICES] = T.n_slices;
   info[FEMO_MESH_VISIT_ENTRIES] = T.vptr[T.n_slices];
+  info[FEMO_MESH_REGULAR_SLICES] = T.n_regular;
   if (rowptr) femo_topology_csr(T, rowptr, col);
   return 0;
 }

@@ -66,9 +66,9 @@ class Context:
         return a
 
     def close(self) -> None:
-        if getattr(self, "handle", None):
-            self.lib.femo_ctx_destroy(self.handle)
-            self.handle = None
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            self.lib.femo_ctx_destroy(h)
 
     def __del__(self):
         try:
@@ -121,9 +121,12 @@ class Vec:
         return int(self.lib.femo_vec_device_ptr(self.handle) or 0)
 
     def __del__(self):
+        # destroy only while the owning context is alive (interpreter shutdown tears
+        # objects down in arbitrary order; a dead parent means the device is gone too)
         try:
-            if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
-                self.lib.femo_vec_destroy(self.handle)
+            h, self.handle = getattr(self, "handle", None), None
+            if h and getattr(self.ctx, "handle", None):
+                self.lib.femo_vec_destroy(h)
         except Exception:
             pass
 
@@ -213,8 +216,9 @@ class DeviceMesh:
 
     def __del__(self):
         try:
-            if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
-                self.lib.femo_mesh_destroy(self.handle)
+            h, self.handle = getattr(self, "handle", None), None
+            if h and getattr(self.ctx, "handle", None):
+                self.lib.femo_mesh_destroy(h)
         except Exception:
             pass
 
@@ -233,8 +237,9 @@ class DirichletSet:
 
     def __del__(self):
         try:
-            if getattr(self, "handle", None) and getattr(self.mesh.ctx, "handle", None):
-                self.lib.femo_bc_destroy(self.handle)
+            h, self.handle = getattr(self, "handle", None), None
+            if h and getattr(self.mesh, "handle", None) and getattr(self.mesh.ctx, "handle", None):
+                self.lib.femo_bc_destroy(h)
         except Exception:
             pass
 
@@ -283,8 +288,9 @@ class Mat:
 
     def __del__(self):
         try:
-            if getattr(self, "handle", None) and getattr(self.mesh.ctx, "handle", None):
-                self.lib.femo_mat_destroy(self.handle)
+            h, self.handle = getattr(self, "handle", None), None
+            if h and getattr(self.mesh, "handle", None) and getattr(self.mesh.ctx, "handle", None):
+                self.lib.femo_mat_destroy(h)
         except Exception:
             pass
 
@@ -306,6 +312,19 @@ def assemble_jacobian(mesh: DeviceMesh, pde: int, params, u: Optional[Vec], f: O
                       bc: Optional[DirichletSet], J: Mat) -> Mat:
     check(mesh.lib.femo_assemble_jacobian(mesh.handle, pde, _ptr(_params(params)), _h(u), _h(f), _h(bc), J.handle))
     return J
+
+
+def assemble_system(mesh: DeviceMesh, pde: int, params, u: Optional[Vec], f: Optional[Vec],
+                    bc: Optional[DirichletSet], J_nobc: Optional[Mat], A_bc: Optional[Mat],
+                    rhs: Optional[Vec]) -> None:
+    """One pass for any subset of dR/du (no BCs), A (BCs eliminated) and the Newton rhs."""
+    check(mesh.lib.femo_assemble_system(mesh.handle, pde, _ptr(_params(params)), _h(u), _h(f), _h(bc),
+                                        _h(J_nobc), _h(A_bc), _h(rhs)))
+
+
+def bc_apply_rhs(bc: DirichletSet, u: Vec, b: Vec) -> Vec:
+    check(bc.lib.femo_bc_apply_rhs(bc.handle, u.handle, b.handle))
+    return b
 
 
 def assemble_dRdf(mesh: DeviceMesh, pde: int, params, u: Optional[Vec], f: Optional[Vec], vals: Vec) -> Vec:

@@ -47,12 +47,14 @@ class _VectorView:
         return self._fn.vec.get()
 
     def set(self, value) -> None:
+        self._fn.version += 1
         self._fn.vec.fill(float(np.asarray(value).ravel()[0]))
 
     def __setitem__(self, key, value) -> None:
         if key != slice(None):
             raise NotImplementedError("only v.vector[:] = array is supported")
         arr = np.asarray(value, dtype=np.float64)
+        self._fn.version += 1
         if arr.ndim == 0:
             self._fn.vec.fill(float(arr))
         else:
@@ -92,6 +94,7 @@ class Function:
         self.function_space = function_space
         self.name = name
         self.vec = Vec(get_context(), function_space.dim)
+        self.version = 0          # bumped by every host-side write (cache key for Dirichlet values)
         self.vector = _VectorView(self)
         self.x = _XView(self)
 
@@ -100,6 +103,7 @@ class Function:
         x = self.function_space.tabulate_dof_coordinates()
         xt = np.zeros((3, x.shape[0]))
         xt[:x.shape[1]] = x.T
+        self.version += 1
         self.vec.set(np.asarray(fn(xt), dtype=np.float64))
 
     def rename(self, name, label=None) -> None:

@@ -57,7 +57,8 @@ enum femo_mesh_info_key {
   FEMO_MESH_SELL_ENTRIES = 5,   /* padded off-diagonal entries stored                  */
   FEMO_MESH_MAX_ROWLEN = 6, FEMO_MESH_MAX_VALENCE = 7, FEMO_MESH_N_SLICES = 8,
   FEMO_MESH_VISIT_ENTRIES = 9,
-  FEMO_MESH_INFO_COUNT = 10
+  FEMO_MESH_REGULAR_SLICES = 10, /* slices whose column indices are row + per-slice deltas */
+  FEMO_MESH_INFO_COUNT = 11
 };
 
 typedef struct femo_solver_opts {
@@ -152,6 +153,15 @@ int femo_assemble_jacobian(femo_mesh* mesh, int pde, const double* params,
                            femo_mat* J);
 int femo_assemble_dRdf(femo_mesh* mesh, int pde, const double* params,
                        const femo_vec* u, const femo_vec* f, femo_vec* vals);
+/* One pass over the mesh for any subset of: J_nobc (state_model.py:132), A_bc
+ * (state_model.py:149) and the Newton right-hand side  rhs = F + K[:,bc](g-u),
+ * rhs[bc] = u-g  (dolfinx NonlinearProblem.F/J [ext], utils_dolfinx.py:431).
+ * Unused outputs are NULL.  Results are identical to the separate calls.       */
+int femo_assemble_system(femo_mesh* mesh, int pde, const double* params,
+                         const femo_vec* u, const femo_vec* f, const femo_bc* bc,
+                         femo_mat* J_nobc, femo_mat* A_bc, femo_vec* rhs);
+/* b[bc] = u[bc] - g  (dolfinx set_bc(b, bcs, x, -1.0) [ext]).                    */
+int femo_bc_apply_rhs(const femo_bc* bc, const femo_vec* u, femo_vec* b);
 /* Newton right-hand side with Dirichlet lifting, dolfinx NonlinearProblem.F
  * [ext] as driven by utils_dolfinx.py:431:  b = F + K[:,bc](g-u); b[bc] = u-g. */
 int femo_newton_rhs(const femo_mat* K_nobc, const femo_vec* F, const femo_vec* u,

@@ -1,0 +1,165 @@
+"""ctypes front-end of oracle/femo_oracle_c.c (TEST INFRASTRUCTURE ONLY; see the
+header of femo_oracle.py).  ``poisson_cycle`` runs the benchmark cycle of
+SURVEY.md section 8(d) on the host cores and returns results + a timing split."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import time
+from typing import Dict, Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libfemo_oracle.so")
+_lib = None
+
+
+def build() -> str:
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.oc_functional.restype = C.c_double
+        _lib.oc_pcg_jacobi.restype = C.c_int
+        _lib.oc_pattern.restype = C.c_int
+        _lib.oc_num_threads.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _i64(v):
+    return C.c_int64(int(v))
+
+
+def pattern(tdim, n_vert, conn):
+    L = lib()
+    conn = np.ascontiguousarray(conn, np.int32)
+    rowptr = np.zeros(n_vert + 1, np.int64)
+    assert L.oc_pattern(tdim, _i64(n_vert), _i64(conn.shape[0]), _p(conn), _p(rowptr), None) == 0
+    col = np.zeros(rowptr[-1], np.int32)
+    assert L.oc_pattern(tdim, _i64(n_vert), _i64(conn.shape[0]), _p(conn), _p(rowptr), _p(col)) == 0
+    return rowptr, col
+
+
+def stiffness(tdim, x, conn, rowptr, col):
+    val = np.empty(rowptr[-1], np.float64)
+    lib().oc_assemble_stiffness(tdim, _i64(x.shape[0]), _p(x), _i64(conn.shape[0]), _p(conn), _p(rowptr), _p(col), _p(val))
+    return val
+
+
+def residual(tdim, x, conn, u, f):
+    r = np.empty(x.shape[0])
+    lib().oc_residual(tdim, _i64(x.shape[0]), _p(x), _i64(conn.shape[0]), _p(conn), _p(u), _p(f), _p(r))
+    return r
+
+
+def eliminate_bc(rowptr, col, val, isbc):
+    out = val.copy()
+    lib().oc_eliminate_bc(_i64(len(rowptr) - 1), _p(rowptr), _p(col), _p(out), _p(isbc))
+    return out
+
+
+def spmv(rowptr, col, val, x):
+    y = np.empty(len(rowptr) - 1)
+    lib().oc_spmv(_i64(len(y)), _p(rowptr), _p(col), _p(val), _p(x), _p(y))
+    return y
+
+
+def pcg(rowptr, col, val, b, rtol=1e-14, atol=0.0, max_it=100000):
+    x = np.empty_like(b)
+    res = C.c_double(0.0)
+    it = lib().oc_pcg_jacobi(_i64(len(b)), _p(rowptr), _p(col), _p(val), _p(b), _p(x), C.c_double(rtol),
+                             C.c_double(atol), int(max_it), C.byref(res))
+    return x, it, res.value
+
+
+def poisson_cycle(tdim: int, x: np.ndarray, conn: np.ndarray, f: np.ndarray, u_d: np.ndarray,
+                  bc_dofs: np.ndarray, alpha: float, rtol: float = 1e-14,
+                  cg_cap: Optional[int] = None, threads: Optional[int] = None) -> Dict:
+    """One assemble + forward solve + functional + linearise + adjoint solve + gradient
+    cycle with homogeneous Dirichlet values, cold start u = 0 (the cycle bench.py times).
+    ``cg_cap`` bounds the iterations of each CG solve (bounded baseline sample)."""
+    L = lib()
+    if threads:
+        L.oc_set_num_threads(int(threads))
+    x = np.ascontiguousarray(x, np.float64)
+    conn = np.ascontiguousarray(conn, np.int32)
+    f = np.ascontiguousarray(f, np.float64)
+    u_d = np.ascontiguousarray(u_d, np.float64)
+    nv, nc = x.shape[0], conn.shape[0]
+    isbc = np.zeros(nv, np.uint8)
+    isbc[bc_dofs] = 1
+    T: Dict[str, float] = {}
+    t0 = time.perf_counter()
+    rowptr, col = pattern(tdim, nv, conn)
+    T["pattern_setup"] = time.perf_counter() - t0           # set-up: not part of the cycle
+    max_it = cg_cap if cg_cap else 100000
+
+    t_cycle = time.perf_counter()
+    t0 = time.perf_counter()
+    u = np.zeros(nv)
+    its_newton = []
+    atol = 0.0
+    # Newton, always 3 iterations (utils_dolfinx.py:419-449); F assembled 4 times
+    F = residual(tdim, x, conn, u, f)
+    for k in range(3):
+        K = stiffness(tdim, x, conn, rowptr, col)
+        A = eliminate_bc(rowptr, col, K, isbc)
+        b = F.copy()
+        b[bc_dofs] = u[bc_dofs]                            # g = 0: lifting vanishes, b[bc] = u - g
+        if k == 0:
+            T["assembly_fwd"] = time.perf_counter() - t0
+            t1 = time.perf_counter()
+        dx, it, res = pcg(rowptr, col, A, b, rtol, atol, max_it)
+        if k == 0:
+            T["cg_fwd"] = time.perf_counter() - t1
+            dinv = 1.0 / A[_diag_index(rowptr, col)]
+            atol = rtol * float(np.linalg.norm(dinv * b))
+        its_newton.append(it)
+        u -= dx
+        F = residual(tdim, x, conn, u, f)
+    T["newton_total"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    J = L.oc_functional(tdim, _p(x), _i64(nc), _p(conn), _p(u), _p(f), _p(u_d), C.c_double(alpha))
+    dJdu = np.empty(nv)
+    L.oc_functional_du(tdim, _i64(nv), _p(x), _i64(nc), _p(conn), _p(u), _p(u_d), _p(dJdu))
+    dJdf = np.empty(nc)
+    L.oc_functional_df(tdim, _p(x), _i64(nc), _p(conn), _p(f), C.c_double(alpha), _p(dJdf))
+    # linearise: dRdu (no BC), A (BC); dR/df is applied matrix-free below
+    K = stiffness(tdim, x, conn, rowptr, col)
+    A = eliminate_bc(rowptr, col, K, isbc)
+    T["output_linearize"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    lam, it_adj, _ = pcg(rowptr, col, A, dJdu, rtol, 0.0, max_it)     # A symmetric: A^T = A
+    T["cg_adj"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    g = np.empty(nc)
+    L.oc_dRdfT_apply(tdim, _p(x), _i64(nc), _p(conn), _p(lam), _p(g))
+    grad = dJdf - g
+    T["gradient"] = time.perf_counter() - t0
+    T["cycle"] = time.perf_counter() - t_cycle
+    return dict(u=u, J=J, grad=grad, lam=lam, it_fwd=its_newton, it_adj=it_adj, times=T,
+                threads=L.oc_num_threads(), nnz=int(rowptr[-1]))
+
+
+_DIAG_CACHE: dict = {}
+
+
+def _diag_index(rowptr, col):
+    key = (rowptr.ctypes.data, col.ctypes.data)
+    if key not in _DIAG_CACHE:
+        rows = np.repeat(np.arange(len(rowptr) - 1), np.diff(rowptr))
+        _DIAG_CACHE.clear()
+        _DIAG_CACHE[key] = np.nonzero(rows == col)[0]
+    return _DIAG_CACHE[key]

@@ -1,0 +1,318 @@
+/* C/OpenMP restatement of femo's Poisson hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Same role and rules as oracle/femo_oracle.py (read its header): a checker and
+ * the "port" CPU baseline of bench.py; never imported by femo_amd/.  PARITY
+ * UNPINNED against FEniCSx (not installable here); pinned against the NumPy
+ * oracle and its closed-form known answers by tests/test_oracle_c.py.
+ *
+ * It exists because the NumPy oracle cannot assemble the 10 M-DOF / 60 M-cell
+ * benchmark mesh in reasonable time or memory.  Algorithms follow the
+ * reference's call sequence (paths relative to /root/reference):
+ *   cell loop + insertion into CSR   dolfinx assemble_matrix / MatSetValues [ext],
+ *                                    utils_dolfinx.py:181-187, 189-202
+ *   residual cell loop               utils_dolfinx.py:175-179 (run_poisson_opt.py:32-38)
+ *   Dirichlet rows/cols              utils_dolfinx.py:189-202
+ *   functional and partials          output_model.py:69-87 (run_poisson_opt.py:74-76)
+ *   dR/df^T lambda                   state_model.py:196-200
+ * The linear solver is Jacobi-preconditioned CG with the stopping rule of the
+ * HIP engine (BASELINE.json design; the reference factorises with MUMPS).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static void geom(int d, const double* x, const int32_t* v, double* vol, double g[4][3]) {
+  if (d == 3) {
+    const double *p0 = x + 3 * (int64_t)v[0], *p1 = x + 3 * (int64_t)v[1], *p2 = x + 3 * (int64_t)v[2],
+                 *p3 = x + 3 * (int64_t)v[3];
+    double e1[3], e2[3], e3[3];
+    for (int k = 0; k < 3; ++k) { e1[k] = p1[k] - p0[k]; e2[k] = p2[k] - p0[k]; e3[k] = p3[k] - p0[k]; }
+    double c1[3] = {e2[1] * e3[2] - e2[2] * e3[1], e2[2] * e3[0] - e2[0] * e3[2], e2[0] * e3[1] - e2[1] * e3[0]};
+    double c2[3] = {e3[1] * e1[2] - e3[2] * e1[1], e3[2] * e1[0] - e3[0] * e1[2], e3[0] * e1[1] - e3[1] * e1[0]};
+    double c3[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const double det = e1[0] * c1[0] + e1[1] * c1[1] + e1[2] * c1[2];
+    for (int k = 0; k < 3; ++k) {
+      g[1][k] = c1[k] / det; g[2][k] = c2[k] / det; g[3][k] = c3[k] / det;
+      g[0][k] = -(g[1][k] + g[2][k] + g[3][k]);
+    }
+    *vol = fabs(det) / 6.0;
+  } else {
+    const double *p0 = x + 2 * (int64_t)v[0], *p1 = x + 2 * (int64_t)v[1], *p2 = x + 2 * (int64_t)v[2];
+    const double a = p1[0] - p0[0], b = p1[1] - p0[1], c = p2[0] - p0[0], e = p2[1] - p0[1];
+    const double det = a * e - b * c;
+    g[1][0] = e / det; g[1][1] = -c / det;
+    g[2][0] = -b / det; g[2][1] = a / det;
+    g[0][0] = -(g[1][0] + g[2][0]); g[0][1] = -(g[1][1] + g[2][1]);
+    *vol = fabs(det) / 2.0;
+  }
+}
+
+static int cmp_i32(const void* a, const void* b) {
+  const int32_t x = *(const int32_t*)a, y = *(const int32_t*)b;
+  return (x > y) - (x < y);
+}
+
+/* CSR pattern (sorted columns, diagonal included).  Call with col == NULL to
+ * get rowptr (and nnz = rowptr[n_vert]), then again with col allocated. */
+int oc_pattern(int d, int64_t n_vert, int64_t n_cell, const int32_t* conn, int64_t* rowptr, int32_t* col) {
+  const int nv = d + 1;
+  int64_t* off = (int64_t*)calloc(n_vert + 1, sizeof(int64_t));
+  if (!off) return 1;
+  for (int64_t e = 0; e < n_cell * nv; ++e) off[conn[e] + 1]++;
+  for (int64_t v = 0; v < n_vert; ++v) off[v + 1] += off[v];
+  int32_t* inc = (int32_t*)malloc((size_t)off[n_vert] * sizeof(int32_t));
+  int64_t* cur = (int64_t*)malloc((size_t)n_vert * sizeof(int64_t));
+  if (!inc || !cur) return 1;
+  memcpy(cur, off, n_vert * sizeof(int64_t));
+  for (int64_t c = 0; c < n_cell; ++c)
+    for (int a = 0; a < nv; ++a) inc[cur[conn[c * nv + a]]++] = (int32_t)c;
+  free(cur);
+  int fail = 0;
+  if (!col) {
+#pragma omp parallel for schedule(static)
+    for (int64_t v = 0; v < n_vert; ++v) {
+      const int64_t m = (off[v + 1] - off[v]) * nv;
+      int32_t stackbuf[256];
+      int32_t* w = m <= 256 ? stackbuf : (int32_t*)malloc(m * sizeof(int32_t));
+      int n = 0;
+      for (int64_t e = off[v]; e < off[v + 1]; ++e)
+        for (int a = 0; a < nv; ++a) w[n++] = conn[(int64_t)inc[e] * nv + a];
+      qsort(w, n, sizeof(int32_t), cmp_i32);
+      int u = 0;
+      for (int i = 0; i < n; ++i)
+        if (i == 0 || w[i] != w[i - 1]) ++u;
+      if (n == 0) u = 1; /* isolated vertex: diagonal only */
+      rowptr[v + 1] = u;
+      if (w != stackbuf) free(w);
+    }
+    rowptr[0] = 0;
+    for (int64_t v = 0; v < n_vert; ++v) rowptr[v + 1] += rowptr[v];
+  } else {
+#pragma omp parallel for schedule(static)
+    for (int64_t v = 0; v < n_vert; ++v) {
+      const int64_t m = (off[v + 1] - off[v]) * nv;
+      int32_t stackbuf[256];
+      int32_t* w = m <= 256 ? stackbuf : (int32_t*)malloc(m * sizeof(int32_t));
+      int n = 0;
+      for (int64_t e = off[v]; e < off[v + 1]; ++e)
+        for (int a = 0; a < nv; ++a) w[n++] = conn[(int64_t)inc[e] * nv + a];
+      qsort(w, n, sizeof(int32_t), cmp_i32);
+      int64_t o = rowptr[v];
+      if (n == 0) col[o++] = (int32_t)v;
+      for (int i = 0; i < n; ++i)
+        if (i == 0 || w[i] != w[i - 1]) col[o++] = w[i];
+      if (o != rowptr[v + 1]) {
+#pragma omp atomic write
+        fail = 1;
+      }
+      if (w != stackbuf) free(w);
+    }
+  }
+  free(inc);
+  free(off);
+  return fail;
+}
+
+static inline int64_t find(const int64_t* rowptr, const int32_t* col, int32_t i, int32_t j) {
+  int64_t lo = rowptr[i], hi = rowptr[i + 1] - 1;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (col[mid] < j) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+/* dR/du of inner(grad u, grad v) dx: cell loop, insertion by binary search. */
+void oc_assemble_stiffness(int d, int64_t n_vert, const double* x, int64_t n_cell, const int32_t* conn,
+                           const int64_t* rowptr, const int32_t* col, double* val) {
+  const int nv = d + 1;
+  memset(val, 0, (size_t)rowptr[n_vert] * sizeof(double));
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < n_cell; ++c) {
+    const int32_t* v = conn + c * nv;
+    double vol, g[4][3];
+    geom(d, x, v, &vol, g);
+    for (int a = 0; a < nv; ++a)
+      for (int b = 0; b < nv; ++b) {
+        double s = 0.0;
+        for (int k = 0; k < d; ++k) s += g[a][k] * g[b][k];
+        const int64_t p = find(rowptr, col, v[a], v[b]);
+#pragma omp atomic
+        val[p] += vol * s;
+      }
+  }
+}
+
+/* R_i = int grad u . grad phi_i - int f phi_i ; no BC treatment. */
+void oc_residual(int d, int64_t n_vert, const double* x, int64_t n_cell, const int32_t* conn,
+                 const double* u, const double* f, double* r) {
+  const int nv = d + 1;
+  memset(r, 0, (size_t)n_vert * sizeof(double));
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < n_cell; ++c) {
+    const int32_t* v = conn + c * nv;
+    double vol, g[4][3], gu[3] = {0, 0, 0};
+    geom(d, x, v, &vol, g);
+    for (int b = 0; b < nv; ++b)
+      for (int k = 0; k < d; ++k) gu[k] += g[b][k] * u[v[b]];
+    for (int a = 0; a < nv; ++a) {
+      double s = 0.0;
+      for (int k = 0; k < d; ++k) s += g[a][k] * gu[k];
+      const double t = vol * s - f[c] * vol / nv;
+#pragma omp atomic
+      r[v[a]] += t;
+    }
+  }
+}
+
+/* Rows and columns of the Dirichlet set zeroed, diagonal 1 (pattern kept). */
+void oc_eliminate_bc(int64_t n, const int64_t* rowptr, const int32_t* col, double* val, const uint8_t* isbc) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i)
+    for (int64_t p = rowptr[i]; p < rowptr[i + 1]; ++p)
+      if (isbc[i] || isbc[col[p]]) val[p] = (col[p] == i) ? 1.0 : 0.0;
+}
+
+void oc_spmv(int64_t n, const int64_t* rowptr, const int32_t* col, const double* val, const double* x, double* y) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    double s = 0.0;
+    for (int64_t p = rowptr[i]; p < rowptr[i + 1]; ++p) s += val[p] * x[col[p]];
+    y[i] = s;
+  }
+}
+
+/* Jacobi-PCG from x = 0; stops when ||D^-1 r|| <= max(rtol ||D^-1 b||, atol) or after
+ * max_it iterations.  Returns the iteration count; *res = ||D^-1 r||. */
+int oc_pcg_jacobi(int64_t n, const int64_t* rowptr, const int32_t* col, const double* val, const double* b,
+                  double* x, double rtol, double atol, int max_it, double* res) {
+  double* r = (double*)malloc(n * sizeof(double));
+  double* p = (double*)malloc(n * sizeof(double));
+  double* q = (double*)malloc(n * sizeof(double));
+  double* dinv = (double*)malloc(n * sizeof(double));
+  double rz = 0.0, zz = 0.0, bb = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : rz, zz, bb)
+  for (int64_t i = 0; i < n; ++i) {
+    double dg = 1.0;
+    for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
+      if (col[k] == i) dg = val[k];
+    dinv[i] = 1.0 / dg;
+    x[i] = 0.0;
+    r[i] = b[i];
+    const double z = dinv[i] * r[i];
+    p[i] = z;
+    rz += r[i] * z; zz += z * z; bb += z * z;
+  }
+  double tol = rtol * sqrt(bb);
+  if (atol > tol) tol = atol;
+  int it = 0;
+  if (sqrt(zz) > tol) {
+    while (it < max_it) {
+      double pq = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : pq)
+      for (int64_t i = 0; i < n; ++i) {
+        double s = 0.0;
+        for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) s += val[k] * p[col[k]];
+        q[i] = s;
+        pq += p[i] * s;
+      }
+      const double alpha = pq != 0.0 ? rz / pq : 0.0;
+      double rz1 = 0.0;
+      zz = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : rz1, zz)
+      for (int64_t i = 0; i < n; ++i) {
+        x[i] += alpha * p[i];
+        r[i] -= alpha * q[i];
+        const double z = dinv[i] * r[i];
+        rz1 += r[i] * z; zz += z * z;
+      }
+      ++it;
+      if (sqrt(zz) <= tol) break;
+      const double beta = rz != 0.0 ? rz1 / rz : 0.0;
+      rz = rz1;
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; ++i) p[i] = dinv[i] * r[i] + beta * p[i];
+    }
+  }
+  *res = sqrt(zz);
+  free(r); free(p); free(q); free(dinv);
+  return it;
+}
+
+/* J = 1/2 int (u-u_d)^2 + alpha/2 int f^2 */
+double oc_functional(int d, const double* x, int64_t n_cell, const int32_t* conn, const double* u,
+                     const double* f, const double* ud, double alpha) {
+  const int nv = d + 1;
+  double J = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : J)
+  for (int64_t c = 0; c < n_cell; ++c) {
+    const int32_t* v = conn + c * nv;
+    double vol, g[4][3], s1 = 0.0, s2 = 0.0;
+    geom(d, x, v, &vol, g);
+    for (int a = 0; a < nv; ++a) { const double e = u[v[a]] - ud[v[a]]; s1 += e; s2 += e * e; }
+    J += 0.5 * vol / ((d + 1) * (d + 2)) * (s2 + s1 * s1) + 0.5 * alpha * f[c] * f[c] * vol;
+  }
+  return J;
+}
+
+void oc_functional_du(int d, int64_t n_vert, const double* x, int64_t n_cell, const int32_t* conn,
+                      const double* u, const double* ud, double* gout) {
+  const int nv = d + 1;
+  memset(gout, 0, (size_t)n_vert * sizeof(double));
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < n_cell; ++c) {
+    const int32_t* v = conn + c * nv;
+    double vol, g[4][3], e[4], s1 = 0.0;
+    geom(d, x, v, &vol, g);
+    for (int a = 0; a < nv; ++a) { e[a] = u[v[a]] - ud[v[a]]; s1 += e[a]; }
+    for (int a = 0; a < nv; ++a) {
+      const double t = vol / ((d + 1) * (d + 2)) * (e[a] + s1);
+#pragma omp atomic
+      gout[v[a]] += t;
+    }
+  }
+}
+
+void oc_functional_df(int d, const double* x, int64_t n_cell, const int32_t* conn, const double* f,
+                      double alpha, double* gout) {
+  const int nv = d + 1;
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < n_cell; ++c) {
+    double vol, g[4][3];
+    geom(d, x, conn + c * nv, &vol, g);
+    gout[c] = alpha * f[c] * vol;
+  }
+}
+
+/* out[c] = sum_a dRdf[v_a, c] lam[v_a] = -|T_c|/(d+1) sum_a lam[v_a] */
+void oc_dRdfT_apply(int d, const double* x, int64_t n_cell, const int32_t* conn, const double* lam, double* out) {
+  const int nv = d + 1;
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < n_cell; ++c) {
+    const int32_t* v = conn + c * nv;
+    double vol, g[4][3], s = 0.0;
+    geom(d, x, v, &vol, g);
+    for (int a = 0; a < nv; ++a) s += lam[v[a]];
+    out[c] = -vol / nv * s;
+  }
+}
+
+int oc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+void oc_set_num_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}

@@ -17,7 +17,8 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
-CASES = [(2, 5, 0.0), (2, 33, 0.2), (3, 4, 0.0), (3, 13, 0.2), (2, 64, 0.0)]
+# the last two have slices with regular column offsets (delta-compressed SpMV path)
+CASES = [(2, 5, 0.0), (2, 33, 0.2), (3, 4, 0.0), (3, 13, 0.2), (2, 64, 0.0), (2, 200, 0.2), (3, 70, 0.0)]
 
 
 @pytest.mark.parametrize("d,n,jit", CASES)
@@ -29,6 +30,7 @@ def test_assembly_parity(ctx, d, n, jit):
     f = rng.standard_normal(m.n_cell)
     ud = rng.standard_normal(m.n_vert)
     dm = E.DeviceMesh(ctx, m.x, m.conn)
+    assert (dm.info['regular_slices'] > 0) == (n >= 70)
     K = fo.stiffness(m)
     rowptr, col = dm.pattern_csr()
     assert np.array_equal(rowptr, K.indptr) and np.array_equal(col, K.indices)
@@ -87,7 +89,19 @@ def test_assembly_parity(ctx, d, n, jit):
     bc2 = E.DirichletSet(dm, bdofs, g)
     B = E.Vec(ctx, m.n_vert)
     E.newton_rhs(J, R, U, bc2, B)
-    assert _rel(B.get(), fo.newton_rhs(K, fo.residual(m, u, f), u, bdofs, g)) < RTOL
+    b_ref = fo.newton_rhs(K, fo.residual(m, u, f), u, bdofs, g)
+    assert _rel(B.get(), b_ref) < RTOL
+    # fused pass: dR/du, A and the Newton right-hand side in one launch
+    J2, A2, B2 = E.Mat(dm), E.Mat(dm), E.Vec(ctx, m.n_vert)
+    E.assemble_system(dm, 0, None, U, F, bc2, J2, A2, B2)
+    assert np.array_equal(J2.to_scipy().data, Kg.data)
+    assert np.array_equal(A2.to_scipy().data, Ag.data)
+    assert _rel(B2.get(), b_ref) < RTOL
+    B3 = E.Vec(ctx, m.n_vert).set(fo.residual(m, u, f))
+    E.bc_apply_rhs(bc2, U, B3)
+    ref3 = fo.residual(m, u, f)
+    ref3[bdofs] = u[bdofs] - g
+    assert _rel(B3.get(), ref3) < RTOL
 
 
 @pytest.mark.parametrize("d,n,jit", [(2, 32, 0.0), (3, 12, 0.2), (3, 24, 0.0)])

@@ -1,0 +1,149 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every
+symbol the header declares (no compute without a GPU), the host topology build, the
+mesh generators, the form catalogue and the CSDL protocol stubs."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import femo_oracle as fo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "femo_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(femo_[a-zA-Z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from femo_amd import _lib
+    lib = _lib.load()
+    syms = _header_symbols()
+    assert len(syms) >= 40
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/femo_hip.h but not exported"
+    assert set(_lib.PROTOTYPES) == set(syms), set(_lib.PROTOTYPES) ^ set(syms)
+    assert lib.femo_abi_version() == 1
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device the product refuses to compute (it never routes to the oracle)."""
+    from femo_amd import _lib
+    from femo_amd.engine import Context
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.FemoError):
+        Context(0)
+    import femo_amd
+    src = []
+    for dp, _, fs in os.walk(os.path.dirname(femo_amd.__file__)):
+        src += [open(os.path.join(dp, f)).read() for f in fs if f.endswith((".py", ".hip", ".cpp", ".h"))]
+    assert not any(re.search(r"^\s*(from|import)\s+oracle\b", s, flags=re.M) for s in src)
+
+
+@pytest.mark.parametrize("d,n,jit", [(2, 7, 0.0), (2, 33, 0.2), (3, 5, 0.0), (3, 17, 0.2)])
+def test_mesh_generators_match_oracle(d, n, jit):
+    from femo_amd.fea.mesh import createUnitCubeMesh, createUnitSquareMesh
+    m = createUnitSquareMesh(n, jit) if d == 2 else createUnitCubeMesh(n, jit)
+    o = fo.unit_square_mesh(n, jit) if d == 2 else fo.unit_cube_mesh(n, jit)
+    assert np.array_equal(m.conn, o.conn)
+    assert np.abs(m.x - o.x).max() < 1e-15
+    assert m.conn.dtype == np.int32 and m.x.flags.c_contiguous
+
+
+@pytest.mark.parametrize("d,n", [(2, 9), (3, 7), (3, 20)])
+def test_host_topology_matches_oracle_pattern(d, n):
+    from femo_amd.engine import topology_host
+    m = fo.unit_square_mesh(n) if d == 2 else fo.unit_cube_mesh(n)
+    info, rowptr, col = topology_host(d, m.n_vert, m.n_vert, m.conn)
+    K = fo.stiffness(m)
+    assert info["nnz"] == K.nnz and np.array_equal(rowptr, K.indptr) and np.array_equal(col, K.indices)
+    assert info["max_rowlen"] == (6 if d == 2 else 14) and info["max_valence"] == (6 if d == 2 else 24)
+    assert info["n_slices"] == -(-m.n_vert // 64) and info["sell_entries"] % 128 == 0
+
+
+def test_host_topology_ragged_and_edge_cases():
+    from femo_amd import _lib
+    from femo_amd.engine import topology_host
+    # shuffled vertex numbering of an unstructured-looking mesh: pattern must follow
+    m = fo.unit_cube_mesh(4, jitter=0.2)
+    perm = np.random.default_rng(1).permutation(m.n_vert)
+    conn = perm[m.conn].astype(np.int32)
+    info, rowptr, col = topology_host(3, m.n_vert, m.n_vert, conn)
+    inv = np.argsort(perm)
+    K = fo.stiffness(fo.OMesh(3, m.x[inv], conn))
+    assert np.array_equal(rowptr, K.indptr) and np.array_equal(col, K.indices)
+    # owned rows only (multi-GPU local mesh): rows [0, n_rows) of the full pattern
+    n_rows = 37
+    info2, rowptr2, col2 = topology_host(3, m.n_vert, n_rows, conn)
+    assert np.array_equal(rowptr2, K.indptr[:n_rows + 1]) and np.array_equal(col2, K.indices[:K.indptr[n_rows]])
+    # empty mesh and a single cell
+    info3, rp3, _ = topology_host(2, 0, 0, np.zeros((0, 3), np.int32))
+    assert info3["nnz"] == 0 and rp3.tolist() == [0]
+    info4, rp4, col4 = topology_host(2, 3, 3, np.array([[0, 1, 2]], np.int32))
+    assert rp4.tolist() == [0, 3, 6, 9] and col4.tolist() == [0, 1, 2] * 3
+    # isolated vertex keeps a diagonal-only row; out-of-range connectivity is an error
+    info5, rp5, col5 = topology_host(2, 4, 4, np.array([[0, 1, 2]], np.int32))
+    assert rp5.tolist() == [0, 3, 6, 9, 10] and col5[-1] == 3
+    with pytest.raises(_lib.FemoError):
+        topology_host(2, 3, 3, np.array([[0, 1, 3]], np.int32))
+    with pytest.raises(_lib.FemoError):
+        topology_host(4, 3, 3, np.array([[0, 1, 2, 3, 4]], np.int32))
+
+
+def test_csdl_protocol_stubs():
+    from femo_amd.csdl_opt import _csdl_compat as cc
+    if cc.HAVE_CSDL:
+        pytest.skip("real csdl present")
+
+    class Op(cc.CustomImplicitOperation):
+        def initialize(self):
+            self.parameters.declare('k', default=2)
+
+        def define(self):
+            self.add_input('a', shape=(3,))
+            self.add_output('b', shape=(3,))
+            self.declare_derivatives('*', '*')
+
+    class M(cc.Model):
+        def initialize(self):
+            self.parameters.declare('n', types=int)
+
+        def define(self):
+            a = self.declare_variable('a', shape=(3,), val=1.0)
+            out = cc.custom(a, op=Op(k=5))
+            self.register_output('b', out)
+
+    m = M(n=3)
+    m.define()
+    assert m.variables['b'].kind == 'output' and m.variables['b'].op.parameters['k'] == 5
+    assert m.variables['b'].op.input_meta['a']['shape'] == (3,)
+    with pytest.raises(TypeError):
+        M(n='x')
+    with pytest.raises(KeyError):
+        M(zz=1)
+
+
+def test_form_catalogue_is_closed():
+    """Forms outside the catalogue are refused (module import needs no GPU)."""
+    import femo_amd.fea.forms as forms
+
+    class FakeSpace:
+        family = "CG"
+
+    class FakeFn:
+        function_space = FakeSpace()
+
+    u, f = FakeFn(), FakeFn()
+    with pytest.raises(NotImplementedError):
+        forms.PoissonResidual(u, f)            # f must be DG0
+    f.function_space = type("S", (), {"family": "DG"})()
+    r = forms.PoissonResidual(u, f)
+    assert forms.derivative(r, u).rank == 2 and forms.derivative(r, f).wrt is f
+    with pytest.raises(ValueError):
+        forms.derivative(r, FakeFn())
+    with pytest.raises(NotImplementedError):
+        forms.pdeRes(u, None, f, weak_bc=True)

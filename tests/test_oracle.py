@@ -1,0 +1,153 @@
+"""Pins the CPU oracle (NumPy and C ports) against closed-form known answers and the
+committed golden vectors.  Parity against FEniCSx itself is UNPINNED (not installable
+here; the reference ships no fixtures) -- see oracle/femo_oracle.py."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import c_port
+from oracle import femo_oracle as fo
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _ref_simplex(d):
+    x = np.vstack([np.zeros(d), np.eye(d)])
+    return fo.OMesh(d, x, np.arange(d + 1, dtype=np.int32)[None, :])
+
+
+def test_element_kats():
+    k = np.load(os.path.join(GOLD, "element_kats.npz"))
+    for d, tag in [(2, "tri"), (3, "tet")]:
+        m = _ref_simplex(d)
+        assert np.allclose(fo.stiffness(m).toarray(), k[f"k_{tag}"], rtol=0, atol=1e-15)
+        assert np.allclose(-fo.dRdf(m).toarray().ravel(), k[f"load_{tag}"], rtol=0, atol=1e-16)
+        # functional Hessian in u is the P1 mass matrix
+        M = np.array([fo.functional_du(m, e, np.zeros(d + 1)) for e in np.eye(d + 1)])
+        assert np.allclose(M, k[f"m_{tag}"], rtol=0, atol=1e-16)
+        # residual of a linear field against a constant source
+        u = m.x @ np.arange(1, d + 1)
+        assert np.allclose(fo.residual(m, u, np.array([2.0])), k[f"k_{tag}"] @ u - 2.0 * k[f"load_{tag}"], atol=1e-15)
+
+
+@pytest.mark.parametrize("d,n", [(2, 16), (3, 8)])
+def test_structured_mesh_counts_and_stencil(d, n):
+    m = fo.unit_square_mesh(n) if d == 2 else fo.unit_cube_mesh(n)
+    K = fo.stiffness(m)
+    nv = (n + 1) ** d
+    nnz = nv + 2 * (2 * n * (n + 1) + n * n) if d == 2 else nv + 2 * (3 * n * (n + 1) ** 2 + 3 * n * n * (n + 1) + n ** 3)
+    assert m.n_vert == nv and m.n_cell == (2 * n * n if d == 2 else 6 * n ** 3) and K.nnz == nnz
+    assert abs(K @ np.ones(nv)).max() < 1e-13 and abs(K - K.T).max() < 1e-15
+    # interior rows reproduce the 5-point stencil (2-D) / h x 7-point stencil (3-D)
+    i = np.ravel_multi_index((n // 2,) * d, (n + 1,) * d)
+    row = K[i].toarray().ravel()
+    h = 1.0 / n
+    assert np.isclose(row[i], 4.0 if d == 2 else 6.0 * h)
+    assert np.isclose(np.sort(row)[:2 * d], -1.0 if d == 2 else -h).all()
+    assert np.isclose(fo.cell_geometry(m)[0].sum(), 1.0)
+
+
+@pytest.mark.parametrize("d,n", [(2, 24), (3, 10)])
+def test_newton_matches_dst_exact_and_pcg(d, n):
+    m = fo.unit_square_mesh(n) if d == 2 else fo.unit_cube_mesh(n)
+    bd = fo.boundary_vertices_box(m.x)
+    f = fo.f_star(fo.centroids(m))
+    u, info = fo.newton_solve(m, f, np.ones(m.n_vert), bd, np.zeros(len(bd)))
+    assert info.newton_its == 3                       # utils_dolfinx.py:419-449: always 3
+    assert info.residual_norms[1] < 1e-12 * info.residual_norms[0]
+    b = fo.load_vector(m, f)
+    b[bd] = 0.0
+    assert np.abs(fo.dst_solve(m, b) - u).max() < 1e-13 * np.abs(u).max()
+    A = fo.eliminate_bc(fo.stiffness(m), bd)
+    x, it, _ = fo.pcg_jacobi(A, b, rtol=1e-14)
+    assert np.abs(x - u).max() < 1e-11 * np.abs(u).max() and it > 0
+    # P1 interpolation error of the smooth target is O(h^2)
+    assert np.abs(u - fo.u_target(m.x)).max() < 2.0 * (1.0 / n) ** 2
+
+
+def test_adjoint_gradient_vs_finite_differences():
+    m = fo.unit_square_mesh(8, jitter=0.2)
+    bd = fo.boundary_vertices_box(m.x)
+    g0 = np.zeros(len(bd))
+    rng = np.random.default_rng(0)
+    f = 0.086 * (1 + 0.3 * rng.uniform(-1, 1, m.n_cell))
+    ud = fo.u_target(m.x)
+    alpha = 1e-3
+
+    def J(ff):
+        u, _ = fo.newton_solve(m, ff, np.zeros(m.n_vert), bd, g0)
+        return fo.functional(m, u, ff, ud, alpha)
+
+    u, _ = fo.newton_solve(m, f, np.zeros(m.n_vert), bd, g0)
+    g_exact, _ = fo.total_gradient(m, f, u, ud, bd, alpha, consistent_bc=True)
+    g_ref, _ = fo.total_gradient(m, f, u, ud, bd, alpha, consistent_bc=False)
+    for _ in range(3):
+        d = rng.standard_normal(m.n_cell)
+        fd = (J(f + 1e-5 * d) - J(f - 1e-5 * d)) / 2e-5
+        assert abs(fd - g_exact @ d) < 1e-7 * abs(fd)
+    # the reference's un-eliminated Dirichlet rows (state_model.py:132-146) leak lam on the boundary
+    assert 1e-4 < np.abs(g_ref - g_exact).max() / np.abs(g_exact).max() < 0.2
+    # fwd-mode quirk of the reference (fea_dolfinx.py:192-206) returns zeros
+    A = fo.eliminate_bc(fo.stiffness(m), bd)
+    assert np.all(fo.solve_linear_fwd_reference(A, np.ones(m.n_vert)) == 0.0)
+    assert np.allclose(A @ fo.solve_linear_fwd_intended(A, np.ones(m.n_vert)), 1.0)
+
+
+def test_dirichlet_algebra_with_inhomogeneous_values():
+    m = fo.unit_cube_mesh(4, jitter=0.2)
+    bd = fo.boundary_vertices_box(m.x)
+    g = np.sin(3 * m.x[bd, 0]) + m.x[bd, 1]
+    f = np.ones(m.n_cell)
+    u, _ = fo.newton_solve(m, f, np.full(m.n_vert, 0.1), bd, g, initialize=True)
+    assert np.abs(u[bd] - g).max() < 1e-14
+    interior = np.setdiff1d(np.arange(m.n_vert), bd)
+    assert np.abs(fo.residual(m, u, f)[interior]).max() < 1e-13
+    A = fo.eliminate_bc(fo.stiffness(m), bd).toarray()
+    assert np.all(A[bd][:, interior] == 0) and np.all(A[interior][:, bd] == 0) and np.all(np.diag(A)[bd] == 1)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "poisson_*.npz"))))
+def test_golden_vectors(path):
+    g = np.load(path)
+    d = g["x"].shape[1]
+    m = fo.OMesh(d, g["x"], g["conn"])
+    bd = g["bc_dofs"]
+    lin = fo.linearize(m, bd)
+    assert np.array_equal(lin.dRdu.indptr, g["dRdu_indptr"]) and np.array_equal(lin.dRdu.indices, g["dRdu_indices"])
+    for name, got in [("dRdu_data", lin.dRdu.data), ("A_data", lin.A.data), ("dRdf_data", lin.dRdf.data)]:
+        assert np.abs(got - g[name]).max() <= 1e-14 * np.abs(g[name]).max()
+    ref = fo.reference_cycle(m, g["f"], g["u_d"], bd, np.zeros(len(bd)))
+    for k in ("u", "J", "grad", "lam"):
+        assert np.abs(ref[k] - g[k]).max() <= 1e-12 * np.abs(g[k]).max()
+    assert np.abs(fo.residual(m, g["u_rand"], g["f"]) - g["residual_u_rand"]).max() < 1e-13
+    # the C port reproduces the same vectors
+    rp, col = c_port.pattern(d, m.n_vert, m.conn)
+    assert np.array_equal(rp, g["dRdu_indptr"]) and np.array_equal(col, g["dRdu_indices"])
+    assert np.abs(c_port.stiffness(d, m.x, m.conn, rp, col) - g["dRdu_data"]).max() < 1e-14 * np.abs(g["dRdu_data"]).max()
+    out = c_port.poisson_cycle(d, m.x, m.conn, g["f"], g["u_d"], bd, fo.ALPHA_POISSON)
+    for k in ("u", "grad", "lam"):
+        assert np.abs(out[k] - g[k]).max() <= 1e-11 * np.abs(g[k]).max()
+    assert abs(out["J"] - g["J"][0]) <= 1e-12 * abs(g["J"][0])
+
+
+def test_c_port_pieces():
+    m = fo.unit_cube_mesh(5, jitter=0.2)
+    rng = np.random.default_rng(2)
+    u, f = rng.standard_normal(m.n_vert), rng.standard_normal(m.n_cell)
+    assert np.abs(c_port.residual(3, m.x, m.conn, u, f) - fo.residual(m, u, f)).max() < 1e-13
+    K = fo.stiffness(m)
+    rp, col = c_port.pattern(3, m.n_vert, m.conn)
+    val = c_port.stiffness(3, m.x, m.conn, rp, col)
+    bd = fo.boundary_vertices_box(m.x)
+    isbc = np.zeros(m.n_vert, np.uint8)
+    isbc[bd] = 1
+    assert np.abs(c_port.eliminate_bc(rp, col, val, isbc) - fo.eliminate_bc(K, bd).data).max() < 1e-14
+    assert np.abs(c_port.spmv(rp, col, val, u) - K @ u).max() < 1e-13
+    A = sp.csr_matrix((c_port.eliminate_bc(rp, col, val, isbc), col, rp))
+    b = rng.standard_normal(m.n_vert)
+    x, it, res = c_port.pcg(rp, col, A.data, b, rtol=1e-13)
+    xo, it_o, _ = fo.pcg_jacobi(A, b, rtol=1e-13)
+    assert abs(it - it_o) <= 1 and np.abs(x - xo).max() < 1e-10 * np.abs(xo).max()
