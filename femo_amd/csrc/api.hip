@@ -346,7 +346,7 @@ int femo_mat_create(femo_mesh* m, femo_mat** out) {
 int femo_mat_destroy(femo_mat* A) {
   if (!A) return 0;
   hipStreamSynchronize(A->mesh->ctx->stream);
-  hipFree(A->d_diag); hipFree(A->d_vals); hipFree(A->d_valsT);
+  hipFree(A->d_diag); hipFree(A->d_vals); hipFree(A->d_valsT); hipFree(A->d_valsS); hipFree(A->d_s);
   delete A;
   return 0;
 }
@@ -364,7 +364,7 @@ int femo_assemble_jacobian(femo_mesh* m, int pde, const double* params, const fe
   FEMO_REQUIRE(m && J, "null argument");
   FEMO_REQUIRE(J->mesh == m, "matrix belongs to another mesh");
   FEMO_REQUIRE(bc == nullptr || bc->mesh == m, "Dirichlet set belongs to another mesh");
-  J->valsT_valid = false;
+  J->valsT_valid = false; J->scaled_valid = false;
   if (bc)
     return femo_launch_system(m, pde, params, u ? u->d : nullptr, f ? f->d : nullptr, bc->d_mask, bc->d_dense,
                               nullptr, nullptr, J->d_diag, J->d_vals, nullptr);
@@ -385,8 +385,8 @@ int femo_assemble_system(femo_mesh* m, int pde, const double* params, const femo
     FEMO_REQUIRE(u->n >= m->n_vert && f->n >= m->n_cell && rhs->n >= m->n_rows, "vector size mismatch in assemble_system");
     if (m->n_nbr > 0) FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(u)));
   }
-  if (J_nobc) J_nobc->valsT_valid = false;
-  if (A_bc) A_bc->valsT_valid = false;
+  if (J_nobc) { J_nobc->valsT_valid = false; J_nobc->scaled_valid = false; }
+  if (A_bc) { A_bc->valsT_valid = false; A_bc->scaled_valid = false; }
   return femo_launch_system(m, pde, params, u ? u->d : nullptr, f ? f->d : nullptr,
                             bc ? bc->d_mask : nullptr, bc ? bc->d_dense : nullptr,
                             J_nobc ? J_nobc->d_diag : nullptr, J_nobc ? J_nobc->d_vals : nullptr,

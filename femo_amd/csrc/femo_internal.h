@@ -157,6 +157,9 @@ struct femo_mat {
   double* d_vals = nullptr;   // sell_entries
   double* d_valsT = nullptr;  // lazily built transposed values
   bool valsT_valid = false;
+  double* d_valsS = nullptr;  // S A S (or S A^T S), S = diag^-1/2: what the CG iterates on
+  double* d_s = nullptr;      // S, n_vert entries (ghosts filled by halo exchange)
+  bool scaled_valid = false, scaled_transposed = false;
 };
 
 // ------------------------------------------------------ device utilities ----

@@ -18,6 +18,7 @@
 // per-block partials, a one-block kernel folds them (plus an RCCL all-reduce
 // when nranks > 1) and the consumers read the folded scalars.  The host only
 // polls a "done" flag every `check_every` iterations, two batches deep.
+#include <algorithm>
 #include <climits>
 #include <cmath>
 
@@ -124,7 +125,7 @@ __device__ __forceinline__ double row_sum_regular(int npair, const double2* __re
   }
 }
 
-template <bool DOT>
+template <bool DOT, bool UNIT>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_spmv_sell(
     int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ mptr,
     const int32_t* __restrict__ cols, const int32_t* __restrict__ sdelta, int sdelta_stride,
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_spmv_sell(
     const int npair = (int)((mptr[slice + 1] - base) >> 7);
     const int64_t row = (slice << 6) + lane;
     const double xr = x[row < n_rows ? row : 0];
-    double acc = diag[row] * xr;
+    double acc = UNIT ? xr : diag[row] * xr;   // UNIT: symmetrically scaled operator, diagonal == 1
     const double2* __restrict__ v2 = reinterpret_cast<const double2*>(vals + base) + lane;
     const int32_t* __restrict__ dl = sdelta + slice * sdelta_stride;
     if (dl[0] != INT32_MIN) {  // wave-uniform (scalar load)
@@ -210,126 +211,204 @@ __global__ void k_gather(int64_t n, const int32_t* __restrict__ perm, const doub
 }
 
 // ------------------------------------------------------------- CG kernels ---
-// scal layout: [0],[1] = (gamma = r.z, zz = ||D^-1 r||^2) of even iterations; [2],[3] of odd;
-// [4] = delta = p.Ap; [5] = tol^2; [6] = ||D^-1 b||^2.  Convergence is tested on the
-// preconditioned residual ||D^-1 r||_2 (PETSc's default norm for left-preconditioned CG [ext]):
-// it bounds the relative error by cond(D^-1 A) * rtol and is not inflated by the O(1)
-// Dirichlet rows of the right-hand side.   flags: [0] done, [1] iterations, [2] breakdown.
-constexpr int S_DELTA = 4, S_TOL2 = 5, S_BB = 6;
+// Jacobi-preconditioned CG is run as plain CG on the symmetrically scaled system
+//     (S A S) xh = S b,   x = S xh,   S = diag(A)^-1/2
+// which generates the same iterates in exact arithmetic, has a unit diagonal (no
+// diagonal or D^-1 stream per iteration) and makes gamma = rh.rh = r^T D^-1 r the
+// only norm needed.  Convergence: sqrt(gamma) <= max(rtol sqrt(bh.bh), atol), the
+// "natural" norm of preconditioned CG (PETSc KSP_NORM_NATURAL [ext]).
+//
+// Per iteration (single GPU, 3 launches, 10 N-vectors of traffic besides the matrix):
+//   k_spmv_sell<true,true>   qh = Ah ph, partial ph.qh                  (x gather N, y write N)
+//   k_cg_update_r            alpha = gamma/delta; rh -= alpha qh; partial rh.rh     (3 N)
+//   k_cg_update_xp           xh += alpha ph; ph = rh + beta ph; convergence flag    (5 N)
+// Scalars never visit the host: every block folds the producers' per-block partials
+// itself in a fixed order (FOLD = true), so all blocks see bitwise identical values.
+// With nranks > 1 a one-block fold + RCCL all-reduce sits between producer and
+// consumer and the consumers read the reduced scalars (FOLD = false).
+// partial slots: 0 = delta, 1/2 = gamma of even/odd iterations, 3 = scratch.
+// scal: [0],[1] = gamma even/odd, [2] = delta, [3] = tol^2.   flags: [0] done, [1] iterations, [2] breakdown.
+constexpr int S_GAMMA = 0, S_DELTA = 2, S_TOL2 = 3;
+constexpr int P_DELTA = 0, P_GAMMA = 1;
 
-// r = b - q (q = A x0, or 0), dinv = 1/diag, p = z = dinv r; partials: r.z, z.z, (dinv b).(dinv b)
-__global__ __launch_bounds__(FEMO_BLOCK) void k_cg_init(int64_t n, const double* __restrict__ b,
-                                                        const double* __restrict__ q, const double* __restrict__ diag,
-                                                        double* __restrict__ r, double* __restrict__ p,
-                                                        double* __restrict__ dinv, double* __restrict__ partials) {
+template <int NT>
+__device__ __forceinline__ double femo_block_sum_bcast(double v, double* lds /* NT/64 */) {
+  v = femo_wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) lds[w] = v;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) s += lds[i];
+  return s;
+}
+
+template <bool FOLD>
+__device__ __forceinline__ double cg_scalar(const double* __restrict__ partials, int nb, const double* __restrict__ slot, double* lds) {
+  if (!FOLD) return *slot;
+  double a = 0.0;
+  for (int i = threadIdx.x; i < nb; i += FEMO_BLOCK) a += partials[i];
+  return femo_block_sum_bcast<FEMO_BLOCK>(a, lds);
+}
+
+__global__ void k_invsqrt_diag(int64_t n, const double* __restrict__ diag, double* __restrict__ s) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    s[i] = 1.0 / sqrt(diag[i]);
+}
+
+// valsS[row][k] = s[row] * vals[row][k] * s[col]   (one wave per slice)
+__global__ __launch_bounds__(FEMO_BLOCK) void k_scale_sell(int64_t n_slices, const int64_t* __restrict__ mptr,
+                                                           const int32_t* __restrict__ cols, const int32_t* __restrict__ sdelta,
+                                                           int sdelta_stride, const double* __restrict__ vals,
+                                                           const double* __restrict__ s, int64_t n_vert, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (int64_t)gridDim.x * (FEMO_BLOCK / 64);
+  for (int64_t slice = (int64_t)blockIdx.x * (FEMO_BLOCK / 64) + (threadIdx.x >> 6); slice < n_slices; slice += nw) {
+    const int64_t base = mptr[slice];
+    const int wm = (int)((mptr[slice + 1] - base) >> 6);
+    const int64_t row = (slice << 6) + lane;
+    const double si = s[row < n_vert ? row : 0];
+    const int32_t* dl = sdelta + slice * sdelta_stride;
+    const bool regular = dl[0] != INT32_MIN;
+    for (int k = 0; k < wm; k += 2) {
+      const int64_t idx = base + (int64_t)(k >> 1) * 128 + lane * 2;
+      const double2 v = *reinterpret_cast<const double2*>(vals + idx);
+      int64_t c0, c1;
+      if (regular) { c0 = row + dl[k]; c1 = row + dl[k + 1]; }
+      else { const int2 cc = *reinterpret_cast<const int2*>(cols + idx); c0 = cc.x; c1 = cc.y; }
+      double2 o;
+      o.x = si * v.x * s[c0];
+      o.y = si * v.y * s[c1];
+      *reinterpret_cast<double2*>(out + idx) = o;
+    }
+  }
+}
+
+// rh = S (b - q) (q = A x0 or null); ph = rh; xh = 0; partials: slot 1 = rh.rh, slot 2 = (S b).(S b)
+__global__ __launch_bounds__(FEMO_BLOCK) void k_cg_init(int64_t n, const double* __restrict__ b, const double* __restrict__ q,
+                                                        const double* __restrict__ s, double* __restrict__ r,
+                                                        double* __restrict__ p, double* __restrict__ xh,
+                                                        double* __restrict__ partials) {
   __shared__ double lds[FEMO_BLOCK / 64];
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  double s0 = 0.0, s1 = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FEMO_BLOCK) {
-    const double bi = b[i];
-    const double ri = q ? bi - q[i] : bi;
-    const double di = 1.0 / diag[i];
-    const double zi = di * ri;
-    r[i] = ri; dinv[i] = di; p[i] = zi;
-    s0 += ri * zi; s1 += zi * zi; s2 += (di * bi) * (di * bi);
+    const double si = s[i], bi = si * b[i];
+    const double ri = q ? si * (b[i] - q[i]) : bi;
+    r[i] = ri; p[i] = ri; xh[i] = 0.0;
+    s0 += ri * ri; s1 += bi * bi;
   }
   double t = femo_block_sum<FEMO_BLOCK>(s0, lds);
-  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  if (threadIdx.x == 0) partials[1 * FEMO_MAX_PARTIALS + blockIdx.x] = t;
   t = femo_block_sum<FEMO_BLOCK>(s1, lds);
-  if (threadIdx.x == 0) partials[FEMO_MAX_PARTIALS + blockIdx.x] = t;
-  t = femo_block_sum<FEMO_BLOCK>(s2, lds);
   if (threadIdx.x == 0) partials[2 * FEMO_MAX_PARTIALS + blockIdx.x] = t;
 }
 
-// fold `nsums` partial arrays into scal[dst + j]
-__global__ __launch_bounds__(1024) void k_cg_fold(int nblocks, int nsums, int dst0, int dst1,
-                                                  const double* __restrict__ partials, double* __restrict__ scal,
+// multi-GPU only: fold one partial array into scal[dst]
+__global__ __launch_bounds__(1024) void k_cg_fold(int nblocks, const double* __restrict__ partials, double* __restrict__ dst,
                                                   const int32_t* __restrict__ done) {
   if (*done) return;
   __shared__ double lds[1024 / 64];
-  for (int j = 0; j < nsums; ++j) {
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += 1024) acc += partials[(int64_t)j * FEMO_MAX_PARTIALS + i];
-    const double s = femo_block_sum<1024>(acc, lds);
-    if (threadIdx.x == 0) scal[j == 0 ? dst0 : dst1] = s;
-  }
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 1024) acc += partials[i];
+  const double t = femo_block_sum<1024>(acc, lds);
+  if (threadIdx.x == 0) *dst = t;
 }
 
-// x += alpha p ; r -= alpha q ; partials: r.z, z.z with z = dinv r
-__global__ __launch_bounds__(FEMO_BLOCK) void k_cg_update_xr(int64_t n, int cur, const double* __restrict__ scal,
-                                                             const double* __restrict__ p, const double* __restrict__ q,
-                                                             const double* __restrict__ dinv, double* __restrict__ x,
-                                                             double* __restrict__ r, double* __restrict__ partials,
-                                                             const int32_t* __restrict__ done) {
+// rh -= alpha qh ; partial rh.rh into the gamma slot of the next parity
+template <bool FOLD>
+__global__ __launch_bounds__(FEMO_BLOCK) void k_cg_update_r(int64_t n, int cur, int nb_d, int nb_g,
+                                                            double* __restrict__ partials, const double* __restrict__ scal,
+                                                            const double* __restrict__ q, double* __restrict__ r,
+                                                            const int32_t* __restrict__ done) {
   if (*done) return;
   __shared__ double lds[FEMO_BLOCK / 64];
-  const double gamma = scal[2 * cur], delta = scal[S_DELTA];
+  const double gamma = cg_scalar<FOLD>(partials + (P_GAMMA + cur) * FEMO_MAX_PARTIALS, nb_g, scal + S_GAMMA + cur, lds);
+  const double delta = cg_scalar<FOLD>(partials + P_DELTA * FEMO_MAX_PARTIALS, nb_d, scal + S_DELTA, lds);
   const double alpha = delta != 0.0 ? gamma / delta : 0.0;
-  double s0 = 0.0, s1 = 0.0;
+  double s0 = 0.0;
   const int64_t n2 = n >> 1;
-  const double2* p2 = reinterpret_cast<const double2*>(p);
   const double2* q2 = reinterpret_cast<const double2*>(q);
-  const double2* d2 = reinterpret_cast<const double2*>(dinv);
-  double2* x2 = reinterpret_cast<double2*>(x);
   double2* r2 = reinterpret_cast<double2*>(r);
   for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n2; i += (int64_t)gridDim.x * FEMO_BLOCK) {
-    const double2 pi = p2[i], qi = q2[i], di = d2[i];
-    double2 xi = x2[i], ri = r2[i];
-    xi.x += alpha * pi.x; xi.y += alpha * pi.y;
+    const double2 qi = q2[i];
+    double2 ri = r2[i];
     ri.x -= alpha * qi.x; ri.y -= alpha * qi.y;
-    x2[i] = xi; r2[i] = ri;
-    const double zx = ri.x * di.x, zy = ri.y * di.y;
-    s0 += ri.x * zx + ri.y * zy;
-    s1 += zx * zx + zy * zy;
+    r2[i] = ri;
+    s0 += ri.x * ri.x + ri.y * ri.y;
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-    const int64_t i = n - 1;
-    const double xi = x[i] + alpha * p[i];
-    const double ri = r[i] - alpha * q[i];
-    x[i] = xi; r[i] = ri;
-    const double zi = ri * dinv[i];
-    s0 += ri * zi;
-    s1 += zi * zi;
+    const double ri = r[n - 1] - alpha * q[n - 1];
+    r[n - 1] = ri;
+    s0 += ri * ri;
   }
-  double t = femo_block_sum<FEMO_BLOCK>(s0, lds);
-  if (threadIdx.x == 0) partials[blockIdx.x] = t;
-  t = femo_block_sum<FEMO_BLOCK>(s1, lds);
-  if (threadIdx.x == 0) partials[FEMO_MAX_PARTIALS + blockIdx.x] = t;
+  const double t = femo_block_sum<FEMO_BLOCK>(s0, lds);
+  if (threadIdx.x == 0) partials[(P_GAMMA + (cur ^ 1)) * FEMO_MAX_PARTIALS + blockIdx.x] = t;
 }
 
-// beta = gamma'/gamma ; p = dinv r + beta p ; convergence bookkeeping
-__global__ __launch_bounds__(FEMO_BLOCK) void k_cg_update_p(int64_t n, int cur, int it, const double* __restrict__ scal,
-                                                            const double* __restrict__ r, const double* __restrict__ dinv,
-                                                            double* __restrict__ p, int32_t* __restrict__ flags) {
-  if (flags[0]) return;
+// xh += alpha ph ; then (unless converged) ph = rh + beta ph
+template <bool FOLD>
+__global__ __launch_bounds__(FEMO_BLOCK) void k_cg_update_xp(int64_t n, int cur, int it, int nb_d, int nb_g,
+                                                             const double* __restrict__ partials, const double* __restrict__ scal,
+                                                             const double* __restrict__ r, double* __restrict__ p,
+                                                             double* __restrict__ xh, int32_t* __restrict__ flags) {
+  // flags[0] = (iteration index + 1) at which convergence was detected, 0 while running.
+  // A block of THIS launch may already have set it; only an earlier iteration's stamp
+  // means "done" here, otherwise late blocks would skip their part of the x update.
+  const int32_t stamp = flags[0];
+  if (stamp != 0 && stamp != it + 1) return;
+  __shared__ double lds[FEMO_BLOCK / 64];
   const int nxt = cur ^ 1;
-  const double gamma = scal[2 * cur], gamma1 = scal[2 * nxt], rr = scal[2 * nxt + 1];
-  const bool bad = !(rr == rr);  // NaN
-  if (rr <= scal[S_TOL2] || bad) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      flags[1] = it + 1;
-      flags[2] = bad ? 1 : 0;
-      __threadfence();
-      flags[0] = 1;
-    }
-    return;
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) flags[1] = it + 1;
+  const double gamma = cg_scalar<FOLD>(partials + (P_GAMMA + cur) * FEMO_MAX_PARTIALS, nb_g, scal + S_GAMMA + cur, lds);
+  const double gamma1 = cg_scalar<FOLD>(partials + (P_GAMMA + nxt) * FEMO_MAX_PARTIALS, nb_g, scal + S_GAMMA + nxt, lds);
+  const double delta = cg_scalar<FOLD>(partials + P_DELTA * FEMO_MAX_PARTIALS, nb_d, scal + S_DELTA, lds);
+  const double alpha = delta != 0.0 ? gamma / delta : 0.0;
+  const bool bad = !(gamma1 == gamma1) || !(alpha == alpha);  // NaN: not SPD or diverged
+  const bool converged = gamma1 <= scal[S_TOL2] || bad;
   const double beta = gamma != 0.0 ? gamma1 / gamma : 0.0;
   const int64_t n2 = n >> 1;
   const double2* r2 = reinterpret_cast<const double2*>(r);
-  const double2* d2 = reinterpret_cast<const double2*>(dinv);
   double2* p2 = reinterpret_cast<double2*>(p);
-  for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n2; i += (int64_t)gridDim.x * FEMO_BLOCK) {
-    const double2 ri = r2[i], di = d2[i];
-    double2 pi = p2[i];
-    pi.x = di.x * ri.x + beta * pi.x;
-    pi.y = di.y * ri.y + beta * pi.y;
-    p2[i] = pi;
+  double2* x2 = reinterpret_cast<double2*>(xh);
+  if (converged) {
+    if (!bad) {
+      for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n2; i += (int64_t)gridDim.x * FEMO_BLOCK) {
+        const double2 pi = p2[i];
+        double2 xi = x2[i];
+        xi.x += alpha * pi.x; xi.y += alpha * pi.y;
+        x2[i] = xi;
+      }
+      if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) xh[n - 1] += alpha * p[n - 1];
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n2; i += (int64_t)gridDim.x * FEMO_BLOCK) {
+      const double2 ri = r2[i];
+      double2 pi = p2[i], xi = x2[i];
+      xi.x += alpha * pi.x; xi.y += alpha * pi.y;
+      pi.x = ri.x + beta * pi.x; pi.y = ri.y + beta * pi.y;
+      x2[i] = xi; p2[i] = pi;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+      const int64_t i = n - 1;
+      const double pi = p[i];
+      xh[i] += alpha * pi;
+      p[i] = r[i] + beta * pi;
+    }
   }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-    const int64_t i = n - 1;
-    p[i] = dinv[i] * r[i] + beta * p[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    flags[1] = it + 1;
+    if (converged) {
+      flags[2] = bad ? 1 : 0;
+      __threadfence();
+      flags[0] = it + 1;
+    }
   }
+}
+
+// x = (add ? x : 0) + s .* xh
+__global__ void k_unscale(int64_t n, int add, const double* __restrict__ s, const double* __restrict__ xh, double* __restrict__ x) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = (add ? x[i] : 0.0) + s[i] * xh[i];
 }
 
 __global__ __launch_bounds__(FEMO_BLOCK) void k_dot(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
@@ -339,6 +418,18 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_dot(int64_t n, const double* __r
   for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FEMO_BLOCK) s += a[i] * b[i];
   const double t = femo_block_sum<FEMO_BLOCK>(s, lds);
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// out[j] = sum of partial slot j (consecutive slots starting at `partials`)
+__global__ __launch_bounds__(1024) void k_reduce_partials_at(int nblocks, int nsums, const double* __restrict__ partials,
+                                                             double* __restrict__ out) {
+  __shared__ double lds[1024 / 64];
+  for (int j = 0; j < nsums; ++j) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 1024) acc += partials[(int64_t)j * FEMO_MAX_PARTIALS + i];
+    const double t = femo_block_sum<1024>(acc, lds);
+    if (threadIdx.x == 0) out[j] = t;
+  }
 }
 
 __global__ void k_pack(int64_t n, const int32_t* __restrict__ idx, const double* __restrict__ x, double* __restrict__ buf) {
@@ -367,15 +458,17 @@ int femo_spmv_grid(const femo_mesh* m) {
 }
 
 static int launch_spmv(const femo_mat* A, const double* vals, const double* x, double* y,
-                       double* partials, const int32_t* done) {
+                       double* partials, const int32_t* done, bool unit = false) {
   const femo_mesh* m = A->mesh;
   if (m->n_slices == 0) return 0;
   const int g = femo_spmv_grid(m);
   hipStream_t st = m->ctx->stream;
-  if (partials)
-    hipLaunchKernelGGL(k_spmv_sell<true>, dim3(g), dim3(FEMO_BLOCK), 0, st, m->n_rows, m->n_slices, m->d_mptr, m->d_cols, m->d_sdelta, m->sdelta_stride, vals, A->d_diag, x, y, partials, done);
-  else
-    hipLaunchKernelGGL(k_spmv_sell<false>, dim3(g), dim3(FEMO_BLOCK), 0, st, m->n_rows, m->n_slices, m->d_mptr, m->d_cols, m->d_sdelta, m->sdelta_stride, vals, A->d_diag, x, y, partials, done);
+#define FEMO_SPMV_ARGS m->n_rows, m->n_slices, m->d_mptr, m->d_cols, m->d_sdelta, m->sdelta_stride, vals, A->d_diag, x, y, partials, done
+  if (partials && unit) hipLaunchKernelGGL((k_spmv_sell<true, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
+  else if (partials) hipLaunchKernelGGL((k_spmv_sell<true, false>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
+  else if (unit) hipLaunchKernelGGL((k_spmv_sell<false, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
+  else hipLaunchKernelGGL((k_spmv_sell<false, false>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
+#undef FEMO_SPMV_ARGS
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -468,13 +561,17 @@ extern "C" int femo_vec_dot(const femo_vec* x, const femo_vec* y, int64_t n, dou
   return femo_reduce_to_host(ctx, g, 1, out);
 }
 
+static int ensure_scaled(femo_mat* A, bool transpose);
+
 extern "C" int femo_bench_spmv(const femo_mat* A, const femo_vec* x, femo_vec* y, int reps, double* ms_per_launch) {
   FEMO_REQUIRE(A && x && y && ms_per_launch && reps > 0, "bad argument");
   femo_ctx* ctx = A->mesh->ctx;
   FEMO_REQUIRE(x->n >= A->mesh->n_vert && y->n >= A->mesh->n_rows, "vector size mismatch");
-  for (int i = 0; i < 3; ++i) FEMO_TRY(launch_spmv(A, A->d_vals, x->d, y->d, ctx->d_partials, nullptr));
+  // the launch the CG loop issues: scaled operator, unit diagonal, fused p.Ap partials
+  FEMO_TRY(ensure_scaled(const_cast<femo_mat*>(A), false));
+  for (int i = 0; i < 3; ++i) FEMO_TRY(launch_spmv(A, A->d_valsS, x->d, y->d, ctx->d_partials + 3 * FEMO_MAX_PARTIALS, nullptr, true));
   FEMO_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
-  for (int i = 0; i < reps; ++i) FEMO_TRY(launch_spmv(A, A->d_vals, x->d, y->d, ctx->d_partials, nullptr));
+  for (int i = 0; i < reps; ++i) FEMO_TRY(launch_spmv(A, A->d_valsS, x->d, y->d, ctx->d_partials + 3 * FEMO_MAX_PARTIALS, nullptr, true));
   FEMO_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
   FEMO_HIP_CHECK(hipEventSynchronize(ctx->ev1));
   float ms = 0.f;
@@ -485,7 +582,7 @@ extern "C" int femo_bench_spmv(const femo_mat* A, const femo_vec* x, femo_vec* y
 
 namespace {
 struct CgWork {
-  double *r, *p, *q, *dinv;
+  double *r, *p, *q, *xh;
 };
 
 int ensure_work(femo_ctx* ctx, int64_t n_rows, int64_t n_vert, CgWork& w) {
@@ -496,69 +593,112 @@ int ensure_work(femo_ctx* ctx, int64_t n_rows, int64_t n_vert, CgWork& w) {
     FEMO_HIP_CHECK(hipMalloc(&ctx->cg_r, (n_rows + 2) * sizeof(double)));
     FEMO_HIP_CHECK(hipMalloc(&ctx->cg_p, (n_vert + 2) * sizeof(double)));
     FEMO_HIP_CHECK(hipMalloc(&ctx->cg_q, (n_rows + 2) * sizeof(double)));
-    FEMO_HIP_CHECK(hipMalloc(&ctx->cg_dinv, (n_rows + 2) * sizeof(double)));
+    FEMO_HIP_CHECK(hipMalloc(&ctx->cg_dinv, (n_rows + 2) * sizeof(double)));   // holds xh
     ctx->cg_n = n_rows; ctx->cg_nvert = n_vert;
   }
   FEMO_HIP_CHECK(hipMemsetAsync(ctx->cg_p, 0, (ctx->cg_nvert + 2) * sizeof(double), ctx->stream));
-  w.r = ctx->cg_r; w.p = ctx->cg_p; w.q = ctx->cg_q; w.dinv = ctx->cg_dinv;
+  w.r = ctx->cg_r; w.p = ctx->cg_p; w.q = ctx->cg_q; w.xh = ctx->cg_dinv;
   return 0;
 }
 }  // namespace
 
-extern "C" int femo_solve_cg(const femo_mat* A, int transpose, const femo_vec* b, femo_vec* x,
+// S = diag^-1/2 and the scaled values S A S (or S A^T S) of the current assembly
+static int ensure_scaled(femo_mat* A, bool transpose) {
+  femo_mesh* m = A->mesh;
+  femo_ctx* ctx = m->ctx;
+  if (A->scaled_valid && A->scaled_transposed == transpose) return 0;
+  const double* src = A->d_vals;
+  if (transpose) {
+    FEMO_TRY(femo_mat_ensure_transpose(A));
+    src = A->d_valsT;
+  }
+  const int64_t nd = std::max<int64_t>(m->n_vert, m->n_slices * FEMO_WAVE) + 2;
+  if (!A->d_s) FEMO_HIP_CHECK(hipMalloc(&A->d_s, nd * sizeof(double)));
+  if (!A->d_valsS) FEMO_HIP_CHECK(hipMalloc(&A->d_valsS, std::max<int64_t>(m->sell_entries, 1) * sizeof(double) + 64));
+  if (m->n_rows > 0) {
+    hipLaunchKernelGGL(k_invsqrt_diag, dim3(2048), dim3(256), 0, ctx->stream, m->n_rows, A->d_diag, A->d_s);
+    FEMO_HIP_CHECK(hipGetLastError());
+  }
+  if (m->n_nbr > 0) {   // ghost columns need the owner's scale factor
+    femo_vec v; v.ctx = ctx; v.d = A->d_s; v.n = m->n_vert; v.owned = false;
+    FEMO_TRY(femo_halo_exchange(m, &v));
+  }
+  if (m->n_slices > 0) {
+    hipLaunchKernelGGL(k_scale_sell, dim3(2048), dim3(FEMO_BLOCK), 0, ctx->stream, m->n_slices, m->d_mptr, m->d_cols, m->d_sdelta, m->sdelta_stride, src, A->d_s, m->n_vert, A->d_valsS);
+    FEMO_HIP_CHECK(hipGetLastError());
+  }
+  A->scaled_valid = true;
+  A->scaled_transposed = transpose;
+  return 0;
+}
+
+extern "C" int femo_solve_cg(const femo_mat* A_, int transpose, const femo_vec* b, femo_vec* x,
                              const femo_solver_opts* opts, femo_solve_info* info) {
-  FEMO_REQUIRE(A && b && x && opts && info, "null argument");
+  FEMO_REQUIRE(A_ && b && x && opts && info, "null argument");
+  femo_mat* A = const_cast<femo_mat*>(A_);
   femo_mesh* m = A->mesh;
   femo_ctx* ctx = m->ctx;
   const int64_t n = m->n_rows;
   FEMO_REQUIRE(b->n >= n && x->n >= m->n_vert, "vector size mismatch in solve_cg");
-  const double* vals = A->d_vals;
-  if (transpose) {
-    FEMO_TRY(femo_mat_ensure_transpose(const_cast<femo_mat*>(A)));
-    vals = A->d_valsT;
-  }
+  FEMO_REQUIRE(b->d != x->d, "solve_cg cannot run in place");
   memset(info, 0, sizeof *info);
+  hipStream_t st = ctx->stream;
+  FEMO_HIP_CHECK(hipEventRecord(ctx->ev0, st));
+  FEMO_TRY(ensure_scaled(A, transpose != 0));
   CgWork w;
   FEMO_TRY(ensure_work(ctx, n, m->n_vert, w));
-  hipStream_t st = ctx->stream;
   const int gv = vec_grid(ctx, n);
   const int gs = femo_spmv_grid(m);
   const bool multi = ctx->nranks > 1;
   int32_t* h_flags = reinterpret_cast<int32_t*>(ctx->h_scal + FEMO_NSCAL);  // 2 slots x 4 ints
+  double* P = ctx->d_partials;
 
-  FEMO_HIP_CHECK(hipEventRecord(ctx->ev0, st));
   FEMO_HIP_CHECK(hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int32_t), st));
-  // r0 = b - A x0
+  // r0 = b - A x0 with the unscaled operator; the iteration then solves for the correction
   const double* q0 = nullptr;
   if (opts->zero_guess) {
     FEMO_HIP_CHECK(hipMemsetAsync(x->d, 0, x->n * sizeof(double), st));
   } else {
     if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, x->d));
+    const double* vals = A->d_vals;
+    if (transpose) vals = A->d_valsT;   // ensure_scaled built it
     FEMO_TRY(launch_spmv(A, vals, x->d, w.q, nullptr, nullptr));
     q0 = w.q;
   }
-  hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, b->d, q0, A->d_diag, w.r, w.p, w.dinv, ctx->d_partials);
+  hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, b->d, q0, A->d_s, w.r, w.p, w.xh, P);
   FEMO_HIP_CHECK(hipGetLastError());
-  double s3[3];
-  FEMO_TRY(femo_reduce_to_host(ctx, gv, 3, s3));  // gamma0, rr0, bb (all-reduced when multi)
-  const double bnorm = std::sqrt(s3[2]);
+  // gamma0 and ||S b||^2 (all-reduced when multi): partial slots 1 and 2
+  hipLaunchKernelGGL(k_reduce_partials_at, dim3(1), dim3(1024), 0, st, gv, 2, P + FEMO_MAX_PARTIALS, ctx->d_scal);
+  FEMO_HIP_CHECK(hipGetLastError());
+  if (multi) FEMO_NCCL_CHECK(ncclAllReduce(ctx->d_scal, ctx->d_scal, 2, ncclDouble, ncclSum, ctx->comm, st));
+  FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  const double gamma0 = ctx->h_scal[0], bb = ctx->h_scal[1];
+  const double bnorm = std::sqrt(bb);
   double tol = opts->rtol * bnorm;
   if (opts->atol > tol) tol = opts->atol;
   info->rhs_norm = bnorm;
   const int max_it = opts->max_it > 0 ? opts->max_it : 10000;
-  if (!(std::sqrt(s3[1]) > tol)) {  // also catches NaN -> report below
-    info->iterations = 0;
-    info->converged = (s3[1] == s3[1]) ? 1 : -1;
-    info->residual_norm = std::sqrt(s3[1]);
+  auto finish = [&](int iters, int conv, double gamma) -> int {
+    if (n > 0) {
+      hipLaunchKernelGGL(k_unscale, dim3(2048), dim3(256), 0, st, n, opts->zero_guess ? 0 : 1, A->d_s, w.xh, x->d);
+      FEMO_HIP_CHECK(hipGetLastError());
+    }
     FEMO_HIP_CHECK(hipEventRecord(ctx->ev1, st));
     FEMO_HIP_CHECK(hipEventSynchronize(ctx->ev1));
     float ms = 0.f;
     FEMO_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    info->iterations = iters;
+    info->converged = conv;
+    info->residual_norm = std::sqrt(gamma);
     info->solve_ms = ms;
     return 0;
-  }
+  };
+  if (!(std::sqrt(gamma0) > tol))   // converged at once, or NaN (reported as breakdown)
+    return finish(0, gamma0 == gamma0 ? 1 : -1, gamma0);
+
   double hs[FEMO_NSCAL] = {0};
-  hs[0] = s3[0]; hs[1] = s3[1]; hs[S_TOL2] = tol * tol; hs[S_BB] = s3[2];
+  hs[S_GAMMA + 0] = gamma0; hs[S_TOL2] = tol * tol;
   memcpy(ctx->h_scal, hs, sizeof hs);
   FEMO_HIP_CHECK(hipMemcpyAsync(ctx->d_scal, ctx->h_scal, sizeof hs, hipMemcpyHostToDevice, st));
   FEMO_HIP_CHECK(hipStreamSynchronize(st));  // h_scal is reused below
@@ -567,31 +707,35 @@ extern "C" int femo_solve_cg(const femo_mat* A, int transpose, const femo_vec* b
   const int n_sample = 4, sample_from = 4;
   int it = 0, polled = 0, n_ev = 0;
   bool done = false;
-  int pending[2] = {-1, -1};  // iteration count at which slot was recorded
+  int pending[2] = {-1, -1};
   while (!done) {
     const int it_end = it + batch < max_it ? it + batch : max_it;
     for (; it < it_end; ++it) {
       const int cur = it & 1, nxt = cur ^ 1;
       if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, w.p));
-      const bool sample = it >= sample_from && it < sample_from + n_sample && (int)ctx->ev_pool.size() >= 2 * n_sample;
+      const bool sample = it >= sample_from && it < sample_from + n_sample;
       if (sample) FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev], st));
-      FEMO_TRY(launch_spmv(A, vals, w.p, w.q, ctx->d_partials, ctx->d_flags));
+      FEMO_TRY(launch_spmv(A, A->d_valsS, w.p, w.q, P + P_DELTA * FEMO_MAX_PARTIALS, ctx->d_flags, true));
       if (sample) { FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev + 1], st)); ++n_ev; }
-      hipLaunchKernelGGL(k_cg_fold, dim3(1), dim3(1024), 0, st, gs, 1, S_DELTA, S_DELTA, ctx->d_partials, ctx->d_scal, ctx->d_flags);
-      if (multi) FEMO_NCCL_CHECK(ncclAllReduce(ctx->d_scal + S_DELTA, ctx->d_scal + S_DELTA, 1, ncclDouble, ncclSum, ctx->comm, st));
-      hipLaunchKernelGGL(k_cg_update_xr, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, ctx->d_scal, w.p, w.q, w.dinv, x->d, w.r, ctx->d_partials, ctx->d_flags);
-      hipLaunchKernelGGL(k_cg_fold, dim3(1), dim3(1024), 0, st, gv, 2, 2 * nxt, 2 * nxt + 1, ctx->d_partials, ctx->d_scal, ctx->d_flags);
-      if (multi) FEMO_NCCL_CHECK(ncclAllReduce(ctx->d_scal + 2 * nxt, ctx->d_scal + 2 * nxt, 2, ncclDouble, ncclSum, ctx->comm, st));
-      hipLaunchKernelGGL(k_cg_update_p, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, it, ctx->d_scal, w.r, w.dinv, w.p, ctx->d_flags);
+      if (multi) {
+        hipLaunchKernelGGL(k_cg_fold, dim3(1), dim3(1024), 0, st, gs, P + P_DELTA * FEMO_MAX_PARTIALS, ctx->d_scal + S_DELTA, ctx->d_flags);
+        FEMO_NCCL_CHECK(ncclAllReduce(ctx->d_scal + S_DELTA, ctx->d_scal + S_DELTA, 1, ncclDouble, ncclSum, ctx->comm, st));
+        hipLaunchKernelGGL(k_cg_update_r<false>, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, gs, gv, P, ctx->d_scal, w.q, w.r, ctx->d_flags);
+        hipLaunchKernelGGL(k_cg_fold, dim3(1), dim3(1024), 0, st, gv, P + (P_GAMMA + nxt) * FEMO_MAX_PARTIALS, ctx->d_scal + S_GAMMA + nxt, ctx->d_flags);
+        FEMO_NCCL_CHECK(ncclAllReduce(ctx->d_scal + S_GAMMA + nxt, ctx->d_scal + S_GAMMA + nxt, 1, ncclDouble, ncclSum, ctx->comm, st));
+        hipLaunchKernelGGL(k_cg_update_xp<false>, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, it, gs, gv, P, ctx->d_scal, w.r, w.p, w.xh, ctx->d_flags);
+      } else {
+        hipLaunchKernelGGL(k_cg_update_r<true>, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, gs, gv, P, ctx->d_scal, w.q, w.r, ctx->d_flags);
+        hipLaunchKernelGGL(k_cg_update_xp<true>, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, it, gs, gv, P, ctx->d_scal, w.r, w.p, w.xh, ctx->d_flags);
+      }
     }
     FEMO_HIP_CHECK(hipGetLastError());
-    // record this batch in slot (polled & 1); then inspect the previous batch
     const int slot = polled & 1;
     FEMO_HIP_CHECK(hipMemcpyAsync(h_flags + 4 * slot, ctx->d_flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_sample + slot], st));
     pending[slot] = it;
     ++polled;
-    const int prev = polled & 1;  // the other slot
+    const int prev = polled & 1;
     const bool last = it >= max_it;
     if (pending[prev] >= 0) {
       FEMO_HIP_CHECK(hipEventSynchronize(ctx->ev_pool[2 * n_sample + prev]));
@@ -603,18 +747,22 @@ extern "C" int femo_solve_cg(const femo_mat* A, int transpose, const femo_vec* b
       done = true;
     }
   }
-  FEMO_HIP_CHECK(hipEventRecord(ctx->ev1, st));
+  // final scalars: gamma of the last completed iteration sits in the (iters & 1) slot
   FEMO_HIP_CHECK(hipMemcpyAsync(h_flags, ctx->d_flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, FEMO_NSCAL * sizeof(double), hipMemcpyDeviceToHost, st));
   FEMO_HIP_CHECK(hipStreamSynchronize(st));
   const int iters = h_flags[1];
-  info->iterations = iters;
-  info->converged = h_flags[0] ? (h_flags[2] ? -1 : 1) : 0;
-  // rr of the last completed iteration lives in the (iters & 1) pair
-  info->residual_norm = std::sqrt(ctx->h_scal[2 * (iters & 1) + 1]);
-  float ms = 0.f;
-  FEMO_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-  info->solve_ms = ms;
+  const int conv = h_flags[0] ? (h_flags[2] ? -1 : 1) : 0;
+  double gamma_f = 0.0;
+  if (multi) {
+    FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, FEMO_NSCAL * sizeof(double), hipMemcpyDeviceToHost, st));
+    FEMO_HIP_CHECK(hipStreamSynchronize(st));
+    gamma_f = ctx->h_scal[S_GAMMA + (iters & 1)];
+  } else {
+    hipLaunchKernelGGL(k_reduce_partials_at, dim3(1), dim3(1024), 0, st, gv, 1, P + (P_GAMMA + (iters & 1)) * FEMO_MAX_PARTIALS, ctx->d_scal + 8);
+    FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal + 8, sizeof(double), hipMemcpyDeviceToHost, st));
+    FEMO_HIP_CHECK(hipStreamSynchronize(st));
+    gamma_f = ctx->h_scal[0];
+  }
   double acc = 0.0;
   for (int i = 0; i < n_ev; ++i) {
     float t = 0.f;
@@ -623,5 +771,5 @@ extern "C" int femo_solve_cg(const femo_mat* A, int transpose, const femo_vec* b
   }
   info->spmv_ms = acc;
   info->spmv_samples = n_ev;
-  return 0;
+  return finish(iters, conv, gamma_f);
 }

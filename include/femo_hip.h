@@ -62,7 +62,7 @@ enum femo_mesh_info_key {
 };
 
 typedef struct femo_solver_opts {
-  double rtol;          /* stop when ||D^-1 r||_2 <= max(rtol*||D^-1 b||_2, atol), D = diag(A) */
+  double rtol;          /* stop when sqrt(r^T D^-1 r) <= max(rtol*sqrt(b^T D^-1 b), atol), D = diag(A) */
   double atol;
   int32_t max_it;
   int32_t zero_guess;   /* 1: x is taken as 0 on entry (skips the initial SpMV)         */
@@ -73,8 +73,8 @@ typedef struct femo_solver_opts {
 typedef struct femo_solve_info {
   int32_t iterations;
   int32_t converged;    /* 1 converged, 0 hit max_it, -1 breakdown                      */
-  double  residual_norm;/* ||D^-1 r||_2 at exit (recurrence residual)                   */
-  double  rhs_norm;     /* ||D^-1 b||_2                                                 */
+  double  residual_norm;/* sqrt(r^T D^-1 r) at exit (recurrence residual)               */
+  double  rhs_norm;     /* sqrt(b^T D^-1 b)                                             */
   double  solve_ms;     /* device time of the solve (HIP events on the ctx stream)      */
   double  spmv_ms;      /* accumulated device time of sampled SpMV launches             */
   int32_t spmv_samples; /* number of SpMV launches that were individually timed         */

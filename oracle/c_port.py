@@ -125,7 +125,7 @@ def poisson_cycle(tdim: int, x: np.ndarray, conn: np.ndarray, f: np.ndarray, u_d
         if k == 0:
             T["cg_fwd"] = time.perf_counter() - t1
             dinv = 1.0 / A[_diag_index(rowptr, col)]
-            atol = rtol * float(np.linalg.norm(dinv * b))
+            atol = rtol * float(np.sqrt(b @ (dinv * b)))
         its_newton.append(it)
         u -= dx
         F = residual(tdim, x, conn, u, f)

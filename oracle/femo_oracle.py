@@ -355,18 +355,17 @@ def total_gradient(mesh: OMesh, f: np.ndarray, u: np.ndarray, u_d: np.ndarray,
 def pcg_jacobi(A: sp.csr_matrix, b: np.ndarray, x0: Optional[np.ndarray] = None,
                rtol: float = 1e-12, atol: float = 0.0, max_it: int = 100000
                ) -> Tuple[np.ndarray, int, float]:
-    """Stops on the preconditioned residual ||D^-1 r||_2 <= max(rtol ||D^-1 b||_2, atol)
-    (PETSc's default norm for left-preconditioned CG [ext])."""
+    """Jacobi-PCG; stops on the natural norm sqrt(r^T D^-1 r) <= max(rtol sqrt(b^T D^-1 b), atol)
+    (PETSc KSP_NORM_NATURAL [ext]), the rule of the HIP engine."""
     dinv = 1.0 / A.diagonal()
     x = np.zeros_like(b) if x0 is None else x0.copy()
     r = b - A @ x
-    tol = max(rtol * np.linalg.norm(dinv * b), atol)
+    tol = max(rtol * math.sqrt(float(b @ (dinv * b))), atol)
     z = dinv * r
-    zz = float(z @ z)
-    if not math.sqrt(zz) > tol:
-        return x, 0, math.sqrt(zz)
-    p = z.copy()
     rz = float(r @ z)
+    if not math.sqrt(rz) > tol:
+        return x, 0, math.sqrt(rz)
+    p = z.copy()
     it = 0
     while it < max_it:
         q = A @ p
@@ -376,14 +375,14 @@ def pcg_jacobi(A: sp.csr_matrix, b: np.ndarray, x0: Optional[np.ndarray] = None,
         r -= alpha * q
         it += 1
         z = dinv * r
-        zz = float(z @ z)
-        if math.sqrt(zz) <= tol:
-            break
         rz_new = float(r @ z)
+        if math.sqrt(rz_new) <= tol:
+            rz = rz_new
+            break
         beta = rz_new / rz
         rz = rz_new
         p = z + beta * p
-    return x, it, math.sqrt(zz)
+    return x, it, math.sqrt(rz)
 
 
 # --------------------------------------------------------------------------

@@ -186,8 +186,8 @@ void oc_spmv(int64_t n, const int64_t* rowptr, const int32_t* col, const double*
   }
 }
 
-/* Jacobi-PCG from x = 0; stops when ||D^-1 r|| <= max(rtol ||D^-1 b||, atol) or after
- * max_it iterations.  Returns the iteration count; *res = ||D^-1 r||. */
+/* Jacobi-PCG from x = 0; stops when sqrt(r^T D^-1 r) <= max(rtol sqrt(b^T D^-1 b), atol)
+ * or after max_it iterations.  Returns the iteration count; *res = sqrt(r^T D^-1 r). */
 int oc_pcg_jacobi(int64_t n, const int64_t* rowptr, const int32_t* col, const double* val, const double* b,
                   double* x, double rtol, double atol, int max_it, double* res) {
   double* r = (double*)malloc(n * sizeof(double));
@@ -205,7 +205,7 @@ int oc_pcg_jacobi(int64_t n, const int64_t* rowptr, const int32_t* col, const do
     r[i] = b[i];
     const double z = dinv[i] * r[i];
     p[i] = z;
-    rz += r[i] * z; zz += z * z; bb += z * z;
+    rz += r[i] * z; zz += r[i] * z; bb += r[i] * z;
   }
   double tol = rtol * sqrt(bb);
   if (atol > tol) tol = atol;
@@ -228,7 +228,7 @@ int oc_pcg_jacobi(int64_t n, const int64_t* rowptr, const int32_t* col, const do
         x[i] += alpha * p[i];
         r[i] -= alpha * q[i];
         const double z = dinv[i] * r[i];
-        rz1 += r[i] * z; zz += z * z;
+        rz1 += r[i] * z; zz += r[i] * z;
       }
       ++it;
       if (sqrt(zz) <= tol) break;
