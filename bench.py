@@ -181,7 +181,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if world > 1:
+    if world > 1 or os.environ.get("FEMO_BENCH_FORCE_DIST"):   # the env switch runs the N>1 code path on one rank (tests)
         from femo_amd.dist import bench_distributed
         return bench_distributed(args, rank, world, local_rank)
 

@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 
 #include "femo_internal.h"
 
@@ -649,7 +650,8 @@ extern "C" int femo_solve_cg(const femo_mat* A_, int transpose, const femo_vec* 
   FEMO_TRY(ensure_work(ctx, n, m->n_vert, w));
   const int gv = vec_grid(ctx, n);
   const int gs = femo_spmv_grid(m);
-  const bool multi = ctx->nranks > 1;
+  // FEMO_FORCE_MULTI=1 runs the fold + all-reduce code path on a 1-rank communicator (tests)
+  const bool multi = ctx->nranks > 1 || (ctx->comm != nullptr && getenv("FEMO_FORCE_MULTI") != nullptr);
   int32_t* h_flags = reinterpret_cast<int32_t*>(ctx->h_scal + FEMO_NSCAL);  // 2 slots x 4 ints
   double* P = ctx->d_partials;
 
@@ -670,7 +672,7 @@ extern "C" int femo_solve_cg(const femo_mat* A_, int transpose, const femo_vec* 
   // gamma0 and ||S b||^2 (all-reduced when multi): partial slots 1 and 2
   hipLaunchKernelGGL(k_reduce_partials_at, dim3(1), dim3(1024), 0, st, gv, 2, P + FEMO_MAX_PARTIALS, ctx->d_scal);
   FEMO_HIP_CHECK(hipGetLastError());
-  if (multi) FEMO_NCCL_CHECK(ncclAllReduce(ctx->d_scal, ctx->d_scal, 2, ncclDouble, ncclSum, ctx->comm, st));
+  if (ctx->comm != nullptr && multi) FEMO_NCCL_CHECK(ncclAllReduce(ctx->d_scal, ctx->d_scal, 2, ncclDouble, ncclSum, ctx->comm, st));
   FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
   FEMO_HIP_CHECK(hipStreamSynchronize(st));
   const double gamma0 = ctx->h_scal[0], bb = ctx->h_scal[1];

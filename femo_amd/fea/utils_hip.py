@@ -481,7 +481,8 @@ class _NewtonBase:
         A = _work(mesh, "newton_A", lambda: SparseMatrix(mesh, symmetric=F.is_symmetric))
         ds = _dirichlet_set(mesh, self.bcs)
         E.assemble_system(dm, F.pde_kind, F.params, F.u.vec, F.f.vec, ds, None, A.mat, b)
-        r0 = r = float(np.sqrt(b.dot(b)))
+        n_own = dm.n_rows          # dots run over owned rows (all-reduced across ranks in the library)
+        r0 = r = float(np.sqrt(b.dot(b, n_own)))
         self.residual_norms = [r]
         converged = r < self.atol or (r0 > 0 and 1.0 < self.rtol)
         it = 0
@@ -491,7 +492,7 @@ class _NewtonBase:
         while not converged and it < self.max_it:
             if it > 0:
                 E.assemble_system(dm, F.pde_kind, F.params, F.u.vec, F.f.vec, ds, None, A.mat, None)
-                unorm = float(np.sqrt(func.vec.dot(func.vec)))
+                unorm = float(np.sqrt(func.vec.dot(func.vec, n_own)))
                 opts["atol"] = max(KSP_OPTIONS["atol"], KSP_OPTIONS["rtol"] * z0, self.NOISE_FACTOR * eps * unorm)
             ksp = KSP(A, opts)
             ksp.solve(b, dx)
@@ -504,7 +505,7 @@ class _NewtonBase:
             E.assemble_residual(dm, F.pde_kind, F.params, F.u.vec, F.f.vec, b)
             if ds is not None:
                 E.bc_apply_rhs(ds, func.vec, b)
-            r = float(np.sqrt(b.dot(b)))
+            r = float(np.sqrt(b.dot(b, n_own)))
             self.residual_norms.append(r)
             converged = r < self.atol or (r0 > 0 and r / r0 < self.rtol)
             if self.report:

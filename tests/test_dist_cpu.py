@@ -1,0 +1,167 @@
+"""CPU tests of the multi-GPU host logic (femo_amd.dist.partition): partition and halo
+plans, checked (a) in-process with emulated ranks and (b) with two real processes over
+gloo running a distributed Jacobi-CG whose local kernels are NumPy stand-ins for the HIP
+ones (the plans, not the kernels, are under test here)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from femo_amd.dist.partition import build_local_mesh, rcb_partition
+from oracle import femo_oracle as fo
+
+
+def _locals(m, nparts):
+    part = rcb_partition(m.x, nparts)
+    return part, [build_local_mesh(m.x, m.conn, part, r, nparts) for r in range(nparts)]
+
+
+@pytest.mark.parametrize("d,n,nparts", [(2, 12, 2), (2, 13, 3), (3, 6, 4), (3, 8, 8), (3, 5, 1)])
+def test_partition_and_halo_plans(d, n, nparts):
+    m = fo.unit_square_mesh(n, 0.2) if d == 2 else fo.unit_cube_mesh(n, 0.2)
+    part, L = _locals(m, nparts)
+    counts = np.bincount(part, minlength=nparts)
+    assert counts.sum() == m.n_vert and counts.max() - counts.min() <= nparts      # balanced
+    owned_all = np.concatenate([l.vert_global[:l.n_owned] for l in L])
+    assert np.array_equal(np.sort(owned_all), np.arange(m.n_vert))                # every vertex owned once
+    cells_owned = np.concatenate([l.cell_global[l.cell_owned] for l in L])
+    assert np.array_equal(np.sort(cells_owned), np.arange(m.n_cell))              # every cell owned once
+    for l in L:
+        assert np.all(part[l.vert_global[:l.n_owned]] == l.rank) and np.all(part[l.vert_global[l.n_owned:]] != l.rank)
+        assert np.array_equal(m.conn[l.cell_global], l.vert_global[l.conn])       # local connectivity consistent
+        assert np.all(l.send_idx < l.n_owned) and l.recv_ptr[-1] == len(l.vert_global) - l.n_owned
+        # every cell touching an owned vertex is local (one ghost-cell layer)
+        touching = np.nonzero((part[m.conn] == l.rank).any(axis=1))[0]
+        assert np.array_equal(touching, l.cell_global)
+    # plans are pairwise consistent: what r sends to q is, in order, what q expects from r
+    for r in L:
+        for k, q in enumerate(r.nbr):
+            sent = r.vert_global[r.send_idx[r.send_ptr[k]:r.send_ptr[k + 1]]]
+            lq = L[q]
+            kk = int(np.nonzero(lq.nbr == r.rank)[0][0])
+            expect = lq.vert_global[lq.n_owned + lq.recv_ptr[kk]: lq.n_owned + lq.recv_ptr[kk + 1]]
+            assert np.array_equal(sent, expect)
+
+
+def _halo_emulated(L, vecs):
+    for r in L:
+        for k, q in enumerate(r.nbr):
+            lq = L[q]
+            kk = int(np.nonzero(lq.nbr == r.rank)[0][0])
+            buf = vecs[r.rank][r.send_idx[r.send_ptr[k]:r.send_ptr[k + 1]]]
+            vecs[q][lq.n_owned + lq.recv_ptr[kk]: lq.n_owned + lq.recv_ptr[kk + 1]] = buf
+
+
+@pytest.mark.parametrize("d,n,nparts", [(2, 10, 3), (3, 6, 8)])
+def test_emulated_distributed_operators(d, n, nparts):
+    """Owner-computes with one ghost-cell layer reproduces the global operators row for row."""
+    m = fo.unit_square_mesh(n, 0.2) if d == 2 else fo.unit_cube_mesh(n, 0.2)
+    _, L = _locals(m, nparts)
+    rng = np.random.default_rng(4)
+    u, f = rng.standard_normal(m.n_vert), rng.standard_normal(m.n_cell)
+    K = fo.stiffness(m)
+    y_ref, r_ref = K @ u, fo.residual(m, u, f)
+    vecs = [np.zeros(len(l.vert_global)) for l in L]
+    for l, v in zip(L, vecs):
+        v[:l.n_owned] = u[l.vert_global[:l.n_owned]]
+    _halo_emulated(L, vecs)
+    for l, v in zip(L, vecs):
+        assert np.array_equal(v, u[l.vert_global])                                 # ghosts filled
+        lm = fo.OMesh(d, l.x, l.conn)
+        Kl = fo.stiffness(lm)[:l.n_owned]
+        own = l.vert_global[:l.n_owned]
+        assert np.abs(Kl @ v - y_ref[own]).max() < 1e-12
+        assert np.abs(fo.residual(lm, v, f[l.cell_global])[:l.n_owned] - r_ref[own]).max() < 1e-12
+        # dR/df^T lambda on owned cells needs only local (owned + ghost) vertex values
+        D = fo.dRdf(lm)
+        g = (D.T @ v)[l.cell_owned]
+        assert np.abs(g - (fo.dRdf(m).T @ u)[l.cell_global[l.cell_owned]]).max() < 1e-13
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, d, n, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = fo.unit_square_mesh(n) if d == 2 else fo.unit_cube_mesh(n)
+    part = rcb_partition(m.x, world)
+    l = build_local_mesh(m.x, m.conn, part, rank, world)
+    lm = fo.OMesh(d, l.x, l.conn)
+    bd = fo.boundary_vertices_box(l.x)
+    A = fo.eliminate_bc(fo.stiffness(lm), bd)[:l.n_owned].tocsr()       # owned rows, local columns
+    dinv = 1.0 / A.diagonal()                                            # A is (n_owned, n_local): main diagonal
+    f = fo.f_star(fo.centroids(lm))
+    b = fo.load_vector(lm, f)
+    b[bd] = 0.0
+    b = b[:l.n_owned]
+
+    def halo(v):
+        reqs, bufs = [], []
+        for k, q in enumerate(l.nbr):
+            sb = torch.from_numpy(np.ascontiguousarray(v[l.send_idx[l.send_ptr[k]:l.send_ptr[k + 1]]]))
+            rb = torch.zeros(int(l.recv_ptr[k + 1] - l.recv_ptr[k]), dtype=torch.float64)
+            reqs.append(dist.isend(sb, int(q)))
+            reqs.append(dist.irecv(rb, int(q)))
+            bufs.append((k, rb, sb))
+        for r_ in reqs:
+            r_.wait()
+        for k, rb, _ in bufs:
+            v[l.n_owned + l.recv_ptr[k]: l.n_owned + l.recv_ptr[k + 1]] = rb.numpy()
+
+    def gsum(x):
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t)
+        return float(t[0])
+
+    no = l.n_owned
+    x = np.zeros(no)
+    r = b.copy()
+    z = dinv * r
+    p = np.zeros(len(l.vert_global))
+    p[:no] = z
+    rz = gsum(r @ z)
+    tol2 = (1e-13 ** 2) * gsum(b @ (dinv * b))
+    its = 0
+    while rz > tol2 and its < 10000:
+        halo(p)
+        q = A @ p
+        alpha = rz / gsum(p[:no] @ q)
+        x += alpha * p[:no]
+        r -= alpha * q
+        z = dinv * r
+        rz1 = gsum(r @ z)
+        p[:no] = z + (rz1 / rz) * p[:no]
+        rz = rz1
+        its += 1
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=x, gid=l.vert_global[:no], its=its)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("d,n", [(2, 16), (3, 6)])
+def test_two_process_gloo_cg(tmp_path, d, n):
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), d, n, str(tmp_path)), nprocs=world, join=True)
+    m = fo.unit_square_mesh(n) if d == 2 else fo.unit_cube_mesh(n)
+    bd = fo.boundary_vertices_box(m.x)
+    f = fo.f_star(fo.centroids(m))
+    u, _ = fo.newton_solve(m, f, np.zeros(m.n_vert), bd, np.zeros(len(bd)))
+    got = np.zeros(m.n_vert)
+    its = []
+    for r in range(world):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        got[z["gid"]] = z["x"]
+        its.append(int(z["its"]))
+    assert its[0] == its[1] and its[0] > 3
+    assert np.abs(got - u).max() < 1e-10 * np.abs(u).max()

@@ -1,0 +1,77 @@
+"""What of the multi-GPU path can be exercised on ONE GPU: a 1-rank RCCL communicator
+(init, all-reduce, the fold + all-reduce CG code path) and the ghost-DOF halo exchange
+through ncclSend/ncclRecv to self on a mesh whose ghosts duplicate owned vertices."""
+import numpy as np
+import pytest
+
+from oracle import femo_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def comm_ctx():
+    from femo_amd import _lib
+    from femo_amd.engine import Context
+    if _lib.device_count() < 1:
+        pytest.fail("no HIP device")
+    c = Context(0)
+    c.comm_init(Context.comm_unique_id(), 0, 1)
+    yield c
+
+
+def test_single_rank_communicator(comm_ctx):
+    assert np.allclose(comm_ctx.allreduce_sum([1.5, -2.0, 3.25]), [1.5, -2.0, 3.25])
+
+
+def test_cg_fold_allreduce_path_matches_single_gpu_path(comm_ctx, monkeypatch):
+    from femo_amd import engine as E
+    m = fo.unit_cube_mesh(20, 0.2)
+    dm = E.DeviceMesh(comm_ctx, m.x, m.conn)
+    bd = fo.boundary_vertices_box(m.x)
+    A = E.Mat(dm)
+    E.assemble_jacobian(dm, 0, None, None, None, E.DirichletSet(dm, bd, 0.0), A)
+    b = np.random.default_rng(1).standard_normal(m.n_vert)
+    B, X1, X2 = E.Vec(comm_ctx, m.n_vert).set(b), E.Vec(comm_ctx, m.n_vert), E.Vec(comm_ctx, m.n_vert)
+    i1 = A.solve_cg(B, X1, rtol=1e-13)
+    monkeypatch.setenv("FEMO_FORCE_MULTI", "1")
+    i2 = A.solve_cg(B, X2, rtol=1e-13)
+    assert i1.converged == 1 and i2.converged == 1 and i1.iterations == i2.iterations
+    assert np.array_equal(X1.get(), X2.get())          # same arithmetic, scalars via fold + all-reduce
+    assert abs(i1.residual_norm - i2.residual_norm) <= 1e-12 * i1.residual_norm
+
+
+def test_halo_exchange_to_self(comm_ctx):
+    """Ghost vertices duplicating owned ones, refreshed by ncclSend/ncclRecv to rank 0 itself."""
+    from femo_amd import engine as E
+    m = fo.unit_cube_mesh(9, 0.2)
+    rng = np.random.default_rng(3)
+    nv = m.n_vert
+    dup = np.sort(rng.choice(nv, size=40, replace=False)).astype(np.int32)
+    x_ext = np.vstack([m.x, m.x[dup]])
+    conn = m.conn.copy()
+    ghost_id = {int(v): nv + k for k, v in enumerate(dup)}
+    for c in rng.choice(m.n_cell, size=m.n_cell // 3, replace=False):      # reroute some references to the copies
+        for a in range(4):
+            if int(conn[c, a]) in ghost_id and rng.random() < 0.7:
+                conn[c, a] = ghost_id[int(conn[c, a])]
+    used = np.unique(conn)
+    assert np.all(np.isin(np.arange(nv, nv + len(dup)), used))            # every ghost referenced
+    dm = E.DeviceMesh(comm_ctx, x_ext, conn, n_rows=nv)
+    dm.set_halo([0], [0, len(dup)], dup, [0, len(dup)])
+    ext = fo.OMesh(3, x_ext, conn)
+    K = fo.stiffness(ext)[:nv]
+    u, f = rng.standard_normal(nv), rng.standard_normal(m.n_cell)
+    u_ext = np.concatenate([u, u[dup]])
+    U = E.Vec(comm_ctx, nv + len(dup)).set(np.concatenate([u, np.full(len(dup), 1e30)]))   # ghosts hold garbage
+    J = E.Mat(dm)
+    E.assemble_jacobian(dm, 0, None, None, None, None, J)
+    Y = E.Vec(comm_ctx, nv + len(dup))
+    J.mult(U, Y)                                                             # halo exchange, then SpMV
+    assert np.array_equal(U.get()[nv:], u[dup])
+    assert np.abs(Y.get(nv) - K @ u_ext).max() < 1e-12 * np.abs(K @ u_ext).max()
+    U.set(np.concatenate([u, np.zeros(len(dup))]))
+    F, R = E.Vec(comm_ctx, m.n_cell).set(f), E.Vec(comm_ctx, nv)
+    E.assemble_residual(dm, 0, None, U, F, R)
+    ref = fo.residual(ext, u_ext, f)[:nv]
+    assert np.abs(R.get() - ref).max() < 1e-12 * np.abs(ref).max()
