@@ -42,7 +42,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--n", type=int, default=215, help="cube resolution (215 -> 10,077,696 DOFs)")
+    p.add_argument("--mesh-n", dest="n", type=int, default=215, help="cube resolution (215 -> 10,077,696 DOFs)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-n", type=int, default=128, help="cube resolution of the bounded CPU sample")
     p.add_argument("--no-pcie", action="store_true")
