@@ -138,7 +138,7 @@ int femo_ctx_destroy(femo_ctx* c) {
   hipStreamSynchronize(c->stream);
   if (c->comm) ncclCommDestroy(c->comm);
   hipFree(c->d_partials); hipFree(c->d_scal); hipFree(c->d_flags);
-  hipFree(c->cg_r); hipFree(c->cg_p); hipFree(c->cg_q); hipFree(c->cg_dinv);
+  hipFree(c->cg_r); hipFree(c->cg_p); hipFree(c->cg_q); hipFree(c->cg_dinv); hipFree(c->cg_s);
   hipHostFree(c->h_scal);
   hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
   for (auto& e : c->ev_pool) hipEventDestroy(e);

@@ -103,8 +103,8 @@ struct femo_ctx {
   int rank = 0, nranks = 1;
   int n_cu = 256;
   // CG workspace, grown on demand and reused across solves
-  double *cg_r = nullptr, *cg_p = nullptr, *cg_q = nullptr, *cg_dinv = nullptr;
-  int64_t cg_n = 0, cg_nvert = 0;
+  double *cg_r = nullptr, *cg_p = nullptr, *cg_q = nullptr, *cg_dinv = nullptr, *cg_s = nullptr;
+  int64_t cg_n = 0;
 };
 
 struct femo_vec {

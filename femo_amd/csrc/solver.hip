@@ -126,7 +126,8 @@ __device__ __forceinline__ double row_sum_regular(int npair, const double2* __re
   }
 }
 
-template <bool DOT, bool UNIT>
+// DOT: 0 none; 1 partial x.Ax into partials[block]; 2 additionally partial x.x into the next slot
+template <int DOT, bool UNIT>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_spmv_sell(
     int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ mptr,
     const int32_t* __restrict__ cols, const int32_t* __restrict__ sdelta, int sdelta_stride,
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_spmv_sell(
   const int64_t blk_in_xcd = blockIdx.x >> 3;
   const int64_t waves_per_xcd = (int64_t)(gridDim.x >> 3) * (FEMO_BLOCK / 64);
   const int64_t s_lo = n_slices * xcd / 8, s_hi = n_slices * (xcd + 1) / 8;
-  double dot = 0.0;
+  double dot = 0.0, dot2 = 0.0;
   for (int64_t slice = s_lo + blk_in_xcd * (FEMO_BLOCK / 64) + wave; slice < s_hi; slice += waves_per_xcd) {
     const int64_t base = mptr[slice];
     const int npair = (int)((mptr[slice + 1] - base) >> 7);
@@ -161,11 +162,16 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_spmv_sell(
     if (row < n_rows) {
       y[row] = acc;
       if (DOT) dot += acc * xr;
+      if (DOT == 2) dot2 += xr * xr;
     }
   }
   if (DOT) {
     const double s = femo_block_sum<FEMO_BLOCK>(dot, lds);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
+  }
+  if (DOT == 2) {
+    const double s = femo_block_sum<FEMO_BLOCK>(dot2, lds);
+    if (threadIdx.x == 0) partials[FEMO_MAX_PARTIALS + blockIdx.x] = s;
   }
 }
 
@@ -305,17 +311,6 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_cg_init(int64_t n, const double*
   if (threadIdx.x == 0) partials[2 * FEMO_MAX_PARTIALS + blockIdx.x] = t;
 }
 
-// multi-GPU only: fold one partial array into scal[dst]
-__global__ __launch_bounds__(1024) void k_cg_fold(int nblocks, const double* __restrict__ partials, double* __restrict__ dst,
-                                                  const int32_t* __restrict__ done) {
-  if (*done) return;
-  __shared__ double lds[1024 / 64];
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < nblocks; i += 1024) acc += partials[i];
-  const double t = femo_block_sum<1024>(acc, lds);
-  if (threadIdx.x == 0) *dst = t;
-}
-
 // rh -= alpha qh ; partial rh.rh into the gamma slot of the next parity
 template <bool FOLD>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_cg_update_r(int64_t n, int cur, int nb_d, int nb_g,
@@ -406,6 +401,80 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_cg_update_xp(int64_t n, int cur,
   }
 }
 
+// ---- single-reduction CG (Chronopoulos & Gear) for nranks > 1 ---------------------
+// One all-reduce of (gamma = r.r, delta = r.Ar) and one halo exchange per iteration:
+//   beta = gamma/gamma_old; alpha = gamma / (delta - beta*gamma/alpha_old)
+//   p = r + beta p; s = w + beta s; x += alpha p; r -= alpha s;   then w = A r with both dots
+// fused into the SpMV.  scal: (delta, gamma) of parity c at [2c], [2c+1] (contiguous for one
+// all-reduce); alpha of parity c at [4+c]; tol^2 at [6].
+constexpr int M_A = 4, M_TOL2 = 6;
+
+__global__ __launch_bounds__(FEMO_BLOCK) void k_cgm_update(int64_t n, int it, double* __restrict__ scal,
+                                                           const double* __restrict__ w, double* __restrict__ r,
+                                                           double* __restrict__ p, double* __restrict__ sv,
+                                                           double* __restrict__ xh, int32_t* __restrict__ flags) {
+  const int32_t stamp = flags[0];
+  if (stamp != 0 && stamp != it + 1) return;
+  const int cur = it & 1, prv = cur ^ 1;
+  const double delta = scal[2 * cur], gamma = scal[2 * cur + 1];
+  const bool bad = !(gamma == gamma) || !(delta == delta);
+  if (gamma <= scal[M_TOL2] || bad) {              // converged before this update: `it` iterations done
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      flags[1] = it;
+      flags[2] = bad ? 1 : 0;
+      __threadfence();
+      flags[0] = it + 1;
+    }
+    return;
+  }
+  double beta = 0.0, alpha;
+  if (it == 0) {
+    alpha = delta != 0.0 ? gamma / delta : 0.0;
+  } else {
+    const double g_old = scal[2 * prv + 1], a_old = scal[M_A + prv];
+    beta = g_old != 0.0 ? gamma / g_old : 0.0;
+    const double den = delta - beta * gamma / a_old;
+    alpha = den != 0.0 ? gamma / den : 0.0;
+  }
+  const int64_t n2 = n >> 1;
+  const double2* w2 = reinterpret_cast<const double2*>(w);
+  double2* r2 = reinterpret_cast<double2*>(r);
+  double2* p2 = reinterpret_cast<double2*>(p);
+  double2* s2 = reinterpret_cast<double2*>(sv);
+  double2* x2 = reinterpret_cast<double2*>(xh);
+  for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n2; i += (int64_t)gridDim.x * FEMO_BLOCK) {
+    const double2 wi = w2[i];
+    double2 ri = r2[i], pi = p2[i], si = s2[i], xi = x2[i];
+    pi.x = ri.x + beta * pi.x; pi.y = ri.y + beta * pi.y;
+    si.x = wi.x + beta * si.x; si.y = wi.y + beta * si.y;
+    xi.x += alpha * pi.x; xi.y += alpha * pi.y;
+    ri.x -= alpha * si.x; ri.y -= alpha * si.y;
+    p2[i] = pi; s2[i] = si; x2[i] = xi; r2[i] = ri;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    const double pi = r[i] + beta * p[i], si = w[i] + beta * sv[i];
+    p[i] = pi; sv[i] = si; xh[i] += alpha * pi; r[i] -= alpha * si;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    scal[M_A + cur] = alpha;                         // read by the next iteration (other parity slot)
+    flags[1] = it + 1;
+  }
+}
+
+// fold partial slots 0 (delta) and 1 (gamma) into buf[0], buf[1] = scal + 2*parity
+__global__ __launch_bounds__(1024) void k_cgm_fold(int nblocks, const double* __restrict__ partials, double* __restrict__ buf,
+                                                   const int32_t* __restrict__ done) {
+  if (*done) return;
+  __shared__ double lds[1024 / 64];
+  for (int j = 0; j < 2; ++j) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 1024) acc += partials[(int64_t)j * FEMO_MAX_PARTIALS + i];
+    const double t = femo_block_sum<1024>(acc, lds);
+    if (threadIdx.x == 0) buf[j] = t;                // buf = {delta, gamma}, contiguous for one all-reduce
+  }
+}
+
 // x = (add ? x : 0) + s .* xh
 __global__ void k_unscale(int64_t n, int add, const double* __restrict__ s, const double* __restrict__ xh, double* __restrict__ x) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -459,16 +528,17 @@ int femo_spmv_grid(const femo_mesh* m) {
 }
 
 static int launch_spmv(const femo_mat* A, const double* vals, const double* x, double* y,
-                       double* partials, const int32_t* done, bool unit = false) {
+                       double* partials, const int32_t* done, bool unit = false, bool dot2 = false) {
   const femo_mesh* m = A->mesh;
   if (m->n_slices == 0) return 0;
   const int g = femo_spmv_grid(m);
   hipStream_t st = m->ctx->stream;
 #define FEMO_SPMV_ARGS m->n_rows, m->n_slices, m->d_mptr, m->d_cols, m->d_sdelta, m->sdelta_stride, vals, A->d_diag, x, y, partials, done
-  if (partials && unit) hipLaunchKernelGGL((k_spmv_sell<true, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
-  else if (partials) hipLaunchKernelGGL((k_spmv_sell<true, false>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
-  else if (unit) hipLaunchKernelGGL((k_spmv_sell<false, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
-  else hipLaunchKernelGGL((k_spmv_sell<false, false>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
+  if (partials && unit && dot2) hipLaunchKernelGGL((k_spmv_sell<2, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
+  else if (partials && unit) hipLaunchKernelGGL((k_spmv_sell<1, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
+  else if (partials) hipLaunchKernelGGL((k_spmv_sell<1, false>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
+  else if (unit) hipLaunchKernelGGL((k_spmv_sell<0, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
+  else hipLaunchKernelGGL((k_spmv_sell<0, false>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
 #undef FEMO_SPMV_ARGS
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
@@ -583,22 +653,26 @@ extern "C" int femo_bench_spmv(const femo_mat* A, const femo_vec* x, femo_vec* y
 
 namespace {
 struct CgWork {
-  double *r, *p, *q, *xh;
+  double *r, *p, *q, *xh, *sv;
 };
 
-int ensure_work(femo_ctx* ctx, int64_t n_rows, int64_t n_vert, CgWork& w) {
-  if (ctx->cg_n < n_rows || ctx->cg_nvert < n_vert) {
-    if (ctx->cg_r) { hipFree(ctx->cg_r); hipFree(ctx->cg_p); hipFree(ctx->cg_q); hipFree(ctx->cg_dinv); }
-    ctx->cg_r = ctx->cg_p = ctx->cg_q = ctx->cg_dinv = nullptr;
-    ctx->cg_n = ctx->cg_nvert = 0;
-    FEMO_HIP_CHECK(hipMalloc(&ctx->cg_r, (n_rows + 2) * sizeof(double)));
-    FEMO_HIP_CHECK(hipMalloc(&ctx->cg_p, (n_vert + 2) * sizeof(double)));
-    FEMO_HIP_CHECK(hipMalloc(&ctx->cg_q, (n_rows + 2) * sizeof(double)));
-    FEMO_HIP_CHECK(hipMalloc(&ctx->cg_dinv, (n_rows + 2) * sizeof(double)));   // holds xh
-    ctx->cg_n = n_rows; ctx->cg_nvert = n_vert;
+int ensure_work(femo_ctx* ctx, int64_t n_rows, int64_t n_vert, CgWork& w, bool need_sv) {
+  const int64_t len = std::max(n_rows, n_vert) + 2;
+  if (ctx->cg_n < len) {
+    hipFree(ctx->cg_r); hipFree(ctx->cg_p); hipFree(ctx->cg_q); hipFree(ctx->cg_dinv); hipFree(ctx->cg_s);
+    ctx->cg_r = ctx->cg_p = ctx->cg_q = ctx->cg_dinv = ctx->cg_s = nullptr;
+    ctx->cg_n = 0;
+    FEMO_HIP_CHECK(hipMalloc(&ctx->cg_r, len * sizeof(double)));
+    FEMO_HIP_CHECK(hipMalloc(&ctx->cg_p, len * sizeof(double)));
+    FEMO_HIP_CHECK(hipMalloc(&ctx->cg_q, len * sizeof(double)));
+    FEMO_HIP_CHECK(hipMalloc(&ctx->cg_dinv, len * sizeof(double)));   // holds xh
+    ctx->cg_n = len;
   }
-  FEMO_HIP_CHECK(hipMemsetAsync(ctx->cg_p, 0, (ctx->cg_nvert + 2) * sizeof(double), ctx->stream));
-  w.r = ctx->cg_r; w.p = ctx->cg_p; w.q = ctx->cg_q; w.xh = ctx->cg_dinv;
+  if (need_sv && !ctx->cg_s) FEMO_HIP_CHECK(hipMalloc(&ctx->cg_s, ctx->cg_n * sizeof(double)));
+  FEMO_HIP_CHECK(hipMemsetAsync(ctx->cg_p, 0, ctx->cg_n * sizeof(double), ctx->stream));
+  FEMO_HIP_CHECK(hipMemsetAsync(ctx->cg_r, 0, ctx->cg_n * sizeof(double), ctx->stream));
+  if (need_sv) FEMO_HIP_CHECK(hipMemsetAsync(ctx->cg_s, 0, ctx->cg_n * sizeof(double), ctx->stream));
+  w.r = ctx->cg_r; w.p = ctx->cg_p; w.q = ctx->cg_q; w.xh = ctx->cg_dinv; w.sv = ctx->cg_s;
   return 0;
 }
 }  // namespace
@@ -647,11 +721,11 @@ extern "C" int femo_solve_cg(const femo_mat* A_, int transpose, const femo_vec* 
   FEMO_HIP_CHECK(hipEventRecord(ctx->ev0, st));
   FEMO_TRY(ensure_scaled(A, transpose != 0));
   CgWork w;
-  FEMO_TRY(ensure_work(ctx, n, m->n_vert, w));
+  // FEMO_FORCE_MULTI=1 runs the all-reduce code path on a 1-rank communicator (tests)
+  const bool multi = ctx->nranks > 1 || (ctx->comm != nullptr && getenv("FEMO_FORCE_MULTI") != nullptr);
+  FEMO_TRY(ensure_work(ctx, n, m->n_vert, w, multi));
   const int gv = vec_grid(ctx, n);
   const int gs = femo_spmv_grid(m);
-  // FEMO_FORCE_MULTI=1 runs the fold + all-reduce code path on a 1-rank communicator (tests)
-  const bool multi = ctx->nranks > 1 || (ctx->comm != nullptr && getenv("FEMO_FORCE_MULTI") != nullptr);
   int32_t* h_flags = reinterpret_cast<int32_t*>(ctx->h_scal + FEMO_NSCAL);  // 2 slots x 4 ints
   double* P = ctx->d_partials;
 
@@ -672,7 +746,7 @@ extern "C" int femo_solve_cg(const femo_mat* A_, int transpose, const femo_vec* 
   // gamma0 and ||S b||^2 (all-reduced when multi): partial slots 1 and 2
   hipLaunchKernelGGL(k_reduce_partials_at, dim3(1), dim3(1024), 0, st, gv, 2, P + FEMO_MAX_PARTIALS, ctx->d_scal);
   FEMO_HIP_CHECK(hipGetLastError());
-  if (ctx->comm != nullptr && multi) FEMO_NCCL_CHECK(ncclAllReduce(ctx->d_scal, ctx->d_scal, 2, ncclDouble, ncclSum, ctx->comm, st));
+  if (multi) FEMO_NCCL_CHECK(ncclAllReduce(ctx->d_scal, ctx->d_scal, 2, ncclDouble, ncclSum, ctx->comm, st));
   FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
   FEMO_HIP_CHECK(hipStreamSynchronize(st));
   const double gamma0 = ctx->h_scal[0], bb = ctx->h_scal[1];
@@ -700,33 +774,43 @@ extern "C" int femo_solve_cg(const femo_mat* A_, int transpose, const femo_vec* 
     return finish(0, gamma0 == gamma0 ? 1 : -1, gamma0);
 
   double hs[FEMO_NSCAL] = {0};
-  hs[S_GAMMA + 0] = gamma0; hs[S_TOL2] = tol * tol;
+  if (multi) hs[M_TOL2] = tol * tol;
+  else { hs[S_GAMMA + 0] = gamma0; hs[S_TOL2] = tol * tol; }
   memcpy(ctx->h_scal, hs, sizeof hs);
   FEMO_HIP_CHECK(hipMemcpyAsync(ctx->d_scal, ctx->h_scal, sizeof hs, hipMemcpyHostToDevice, st));
   FEMO_HIP_CHECK(hipStreamSynchronize(st));  // h_scal is reused below
 
-  const int batch = opts->check_every > 0 ? opts->check_every : 32;
   const int n_sample = 4, sample_from = 4;
-  int it = 0, polled = 0, n_ev = 0;
+  int n_ev = 0;
+  // w = Ah r with both dots, folded and all-reduced into the (delta, gamma) pair of `parity`
+  auto merged_spmv = [&](int parity, bool sample) -> int {
+    if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, w.r));
+    if (sample) FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev], st));
+    FEMO_TRY(launch_spmv(A, A->d_valsS, w.r, w.q, P, ctx->d_flags, true, true));
+    if (sample) { FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev + 1], st)); ++n_ev; }
+    hipLaunchKernelGGL(k_cgm_fold, dim3(1), dim3(1024), 0, st, gs, P, ctx->d_scal + 2 * parity, ctx->d_flags);
+    FEMO_NCCL_CHECK(ncclAllReduce(ctx->d_scal + 2 * parity, ctx->d_scal + 2 * parity, 2, ncclDouble, ncclSum, ctx->comm, st));
+    return 0;
+  };
+  if (multi) FEMO_TRY(merged_spmv(0, false));
+
+  const int batch = opts->check_every > 0 ? opts->check_every : 32;
+  int it = 0, polled = 0;
   bool done = false;
   int pending[2] = {-1, -1};
   while (!done) {
     const int it_end = it + batch < max_it ? it + batch : max_it;
     for (; it < it_end; ++it) {
       const int cur = it & 1, nxt = cur ^ 1;
-      if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, w.p));
       const bool sample = it >= sample_from && it < sample_from + n_sample;
-      if (sample) FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev], st));
-      FEMO_TRY(launch_spmv(A, A->d_valsS, w.p, w.q, P + P_DELTA * FEMO_MAX_PARTIALS, ctx->d_flags, true));
-      if (sample) { FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev + 1], st)); ++n_ev; }
       if (multi) {
-        hipLaunchKernelGGL(k_cg_fold, dim3(1), dim3(1024), 0, st, gs, P + P_DELTA * FEMO_MAX_PARTIALS, ctx->d_scal + S_DELTA, ctx->d_flags);
-        FEMO_NCCL_CHECK(ncclAllReduce(ctx->d_scal + S_DELTA, ctx->d_scal + S_DELTA, 1, ncclDouble, ncclSum, ctx->comm, st));
-        hipLaunchKernelGGL(k_cg_update_r<false>, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, gs, gv, P, ctx->d_scal, w.q, w.r, ctx->d_flags);
-        hipLaunchKernelGGL(k_cg_fold, dim3(1), dim3(1024), 0, st, gv, P + (P_GAMMA + nxt) * FEMO_MAX_PARTIALS, ctx->d_scal + S_GAMMA + nxt, ctx->d_flags);
-        FEMO_NCCL_CHECK(ncclAllReduce(ctx->d_scal + S_GAMMA + nxt, ctx->d_scal + S_GAMMA + nxt, 1, ncclDouble, ncclSum, ctx->comm, st));
-        hipLaunchKernelGGL(k_cg_update_xp<false>, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, it, gs, gv, P, ctx->d_scal, w.r, w.p, w.xh, ctx->d_flags);
+        // single-reduction CG: update from the reduced (delta, gamma) of parity cur, then the next SpMV
+        hipLaunchKernelGGL(k_cgm_update, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, it, ctx->d_scal, w.q, w.r, w.p, w.sv, w.xh, ctx->d_flags);
+        FEMO_TRY(merged_spmv(nxt, sample));
       } else {
+        if (sample) FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev], st));
+        FEMO_TRY(launch_spmv(A, A->d_valsS, w.p, w.q, P + P_DELTA * FEMO_MAX_PARTIALS, ctx->d_flags, true));
+        if (sample) { FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev + 1], st)); ++n_ev; }
         hipLaunchKernelGGL(k_cg_update_r<true>, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, gs, gv, P, ctx->d_scal, w.q, w.r, ctx->d_flags);
         hipLaunchKernelGGL(k_cg_update_xp<true>, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, it, gs, gv, P, ctx->d_scal, w.r, w.p, w.xh, ctx->d_flags);
       }
@@ -758,7 +842,7 @@ extern "C" int femo_solve_cg(const femo_mat* A_, int transpose, const femo_vec* 
   if (multi) {
     FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, FEMO_NSCAL * sizeof(double), hipMemcpyDeviceToHost, st));
     FEMO_HIP_CHECK(hipStreamSynchronize(st));
-    gamma_f = ctx->h_scal[S_GAMMA + (iters & 1)];
+    gamma_f = ctx->h_scal[2 * (iters & 1) + 1];
   } else {
     hipLaunchKernelGGL(k_reduce_partials_at, dim3(1), dim3(1024), 0, st, gv, 1, P + (P_GAMMA + (iters & 1)) * FEMO_MAX_PARTIALS, ctx->d_scal + 8);
     FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal + 8, sizeof(double), hipMemcpyDeviceToHost, st));

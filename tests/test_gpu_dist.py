@@ -24,21 +24,29 @@ def test_single_rank_communicator(comm_ctx):
     assert np.allclose(comm_ctx.allreduce_sum([1.5, -2.0, 3.25]), [1.5, -2.0, 3.25])
 
 
-def test_cg_fold_allreduce_path_matches_single_gpu_path(comm_ctx, monkeypatch):
+def test_single_reduction_cg_matches_standard_cg(comm_ctx, monkeypatch):
+    """nranks > 1 uses the Chronopoulos-Gear recurrence (one fold + all-reduce per iteration);
+    FEMO_FORCE_MULTI runs it on the 1-rank communicator."""
     from femo_amd import engine as E
-    m = fo.unit_cube_mesh(20, 0.2)
-    dm = E.DeviceMesh(comm_ctx, m.x, m.conn)
-    bd = fo.boundary_vertices_box(m.x)
-    A = E.Mat(dm)
-    E.assemble_jacobian(dm, 0, None, None, None, E.DirichletSet(dm, bd, 0.0), A)
-    b = np.random.default_rng(1).standard_normal(m.n_vert)
-    B, X1, X2 = E.Vec(comm_ctx, m.n_vert).set(b), E.Vec(comm_ctx, m.n_vert), E.Vec(comm_ctx, m.n_vert)
-    i1 = A.solve_cg(B, X1, rtol=1e-13)
-    monkeypatch.setenv("FEMO_FORCE_MULTI", "1")
-    i2 = A.solve_cg(B, X2, rtol=1e-13)
-    assert i1.converged == 1 and i2.converged == 1 and i1.iterations == i2.iterations
-    assert np.array_equal(X1.get(), X2.get())          # same arithmetic, scalars via fold + all-reduce
-    assert abs(i1.residual_norm - i2.residual_norm) <= 1e-12 * i1.residual_norm
+    import scipy.sparse.linalg as spla
+    for d, n in [(3, 20), (2, 150)]:
+        m = fo.unit_cube_mesh(n, 0.2) if d == 3 else fo.unit_square_mesh(n, 0.2)
+        dm = E.DeviceMesh(comm_ctx, m.x, m.conn)
+        bd = fo.boundary_vertices_box(m.x)
+        A = E.Mat(dm)
+        E.assemble_jacobian(dm, 0, None, None, None, E.DirichletSet(dm, bd, 0.0), A)
+        b = np.random.default_rng(1).standard_normal(m.n_vert)
+        B, X1, X2 = E.Vec(comm_ctx, m.n_vert).set(b), E.Vec(comm_ctx, m.n_vert), E.Vec(comm_ctx, m.n_vert)
+        monkeypatch.delenv("FEMO_FORCE_MULTI", raising=False)
+        i1 = A.solve_cg(B, X1, rtol=1e-13)
+        monkeypatch.setenv("FEMO_FORCE_MULTI", "1")
+        i2 = A.solve_cg(B, X2, rtol=1e-13)
+        i3 = A.solve_cg(B, X1, rtol=1e-13, zero_guess=False)       # warm start from the solution
+        monkeypatch.delenv("FEMO_FORCE_MULTI")
+        assert i1.converged == 1 and i2.converged == 1 and abs(i1.iterations - i2.iterations) <= 3
+        xo = spla.splu(fo.eliminate_bc(fo.stiffness(m), bd).tocsc()).solve(b)
+        assert np.abs(X2.get() - xo).max() < 1e-10 * np.abs(xo).max()
+        assert i3.converged == 1 and i3.iterations <= 2
 
 
 def test_halo_exchange_to_self(comm_ctx):
