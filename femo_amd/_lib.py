@@ -63,16 +63,17 @@ PROTOTYPES = {
     "femo_mesh_create": (C.c_int, [H, C.c_int, c_i64, c_i64, C.c_void_p, c_i64, C.c_void_p, C.POINTER(H)]),
     "femo_mesh_destroy": (C.c_int, [H]),
     "femo_mesh_info": (C.c_int, [H, c_i64p]),
+    "femo_mesh_set_boundary_facets": (C.c_int, [H, C.c_void_p]),
     "femo_mesh_pattern_csr": (C.c_int, [H, C.c_void_p, C.c_void_p]),
     "femo_topology_build_host": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, C.c_void_p, c_i64p, C.c_void_p, C.c_void_p]),
     "femo_bc_create": (C.c_int, [H, c_i64, C.c_void_p, C.c_void_p, C.POINTER(H)]),
     "femo_bc_destroy": (C.c_int, [H]),
-    "femo_assemble_residual": (C.c_int, [H, C.c_int, C.c_void_p, H, H, H]),
+    "femo_assemble_residual": (C.c_int, [H, C.c_int, C.c_void_p, H, H, H, H]),
     "femo_mat_create": (C.c_int, [H, C.POINTER(H)]),
     "femo_mat_destroy": (C.c_int, [H]),
-    "femo_assemble_jacobian": (C.c_int, [H, C.c_int, C.c_void_p, H, H, H, H]),
+    "femo_assemble_jacobian": (C.c_int, [H, C.c_int, C.c_void_p, H, H, H, H, H]),
     "femo_assemble_dRdf": (C.c_int, [H, C.c_int, C.c_void_p, H, H, H]),
-    "femo_assemble_system": (C.c_int, [H, C.c_int, C.c_void_p, H, H, H, H, H, H]),
+    "femo_assemble_system": (C.c_int, [H, C.c_int, C.c_void_p, H, H, H, H, H, H, H]),
     "femo_bc_apply_rhs": (C.c_int, [H, H, H]),
     "femo_newton_rhs": (C.c_int, [H, H, H, H, H]),
     "femo_mat_spmv": (C.c_int, [H, C.c_int, H, H]),

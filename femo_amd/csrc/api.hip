@@ -264,7 +264,7 @@ int femo_mesh_destroy(femo_mesh* m) {
   hipStreamSynchronize(m->ctx->stream);
   hipFree(m->d_x); hipFree(m->d_conn); hipFree(m->d_vptr); hipFree(m->d_visit_cell);
   hipFree(m->d_visit_slots); hipFree(m->d_mptr); hipFree(m->d_cols); hipFree(m->d_rowlen);
-  hipFree(m->d_sdelta); hipFree(m->d_tperm); hipFree(m->d_send_idx); hipFree(m->d_send_buf); hipFree(m->d_scratch);
+  hipFree(m->d_sdelta); hipFree(m->d_bfacets); hipFree(m->d_tperm); hipFree(m->d_send_idx); hipFree(m->d_send_buf); hipFree(m->d_scratch);
   delete m;
   return 0;
 }
@@ -282,6 +282,17 @@ int femo_mesh_info(const femo_mesh* m, int64_t info[FEMO_MESH_INFO_COUNT]) {
   info[FEMO_MESH_N_SLICES] = m->n_slices;
   info[FEMO_MESH_VISIT_ENTRIES] = m->visit_entries;
   info[FEMO_MESH_REGULAR_SLICES] = m->n_regular;
+  return 0;
+}
+
+int femo_mesh_set_boundary_facets(femo_mesh* m, const uint8_t* mask) {
+  FEMO_REQUIRE(m != nullptr, "null argument");
+  hipFree(m->d_bfacets);
+  m->d_bfacets = nullptr;
+  if (!mask || m->n_cell == 0) return 0;
+  FEMO_HIP_CHECK(hipMalloc(&m->d_bfacets, m->n_cell + 64));
+  FEMO_HIP_CHECK(hipMemcpyAsync(m->d_bfacets, mask, m->n_cell, hipMemcpyHostToDevice, m->ctx->stream));
+  FEMO_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
   return 0;
 }
 
@@ -352,29 +363,33 @@ int femo_mat_destroy(femo_mat* A) {
 }
 
 int femo_assemble_residual(femo_mesh* m, int pde, const double* params, const femo_vec* u,
-                           const femo_vec* f, femo_vec* r) {
+                           const femo_vec* f, const femo_vec* aux, femo_vec* r) {
   FEMO_REQUIRE(m && u && f && r, "null argument");
   FEMO_REQUIRE(u->n >= m->n_vert && f->n >= m->n_cell && r->n >= m->n_rows, "vector size mismatch in assemble_residual");
+  FEMO_REQUIRE(aux == nullptr || aux->n >= m->n_vert, "aux field shorter than n_vert");
   if (m->n_nbr > 0) FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(u)));
-  return femo_launch_residual(m, pde, params, u->d, f->d, r->d);
+  return femo_launch_residual(m, pde, params, u->d, f->d, aux ? aux->d : nullptr, r->d);
 }
 
 int femo_assemble_jacobian(femo_mesh* m, int pde, const double* params, const femo_vec* u,
-                           const femo_vec* f, const femo_bc* bc, femo_mat* J) {
+                           const femo_vec* f, const femo_vec* aux, const femo_bc* bc, femo_mat* J) {
   FEMO_REQUIRE(m && J, "null argument");
   FEMO_REQUIRE(J->mesh == m, "matrix belongs to another mesh");
   FEMO_REQUIRE(bc == nullptr || bc->mesh == m, "Dirichlet set belongs to another mesh");
   J->valsT_valid = false; J->scaled_valid = false;
+  FEMO_REQUIRE(aux == nullptr || aux->n >= m->n_vert, "aux field shorter than n_vert");
+  if (u && m->n_nbr > 0 && pde != FEMO_PDE_POISSON) FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(u)));
+  const double* ax = aux ? aux->d : nullptr;
   if (bc)
-    return femo_launch_system(m, pde, params, u ? u->d : nullptr, f ? f->d : nullptr, bc->d_mask, bc->d_dense,
+    return femo_launch_system(m, pde, params, u ? u->d : nullptr, f ? f->d : nullptr, ax, bc->d_mask, bc->d_dense,
                               nullptr, nullptr, J->d_diag, J->d_vals, nullptr);
-  return femo_launch_system(m, pde, params, u ? u->d : nullptr, f ? f->d : nullptr, nullptr, nullptr,
+  return femo_launch_system(m, pde, params, u ? u->d : nullptr, f ? f->d : nullptr, ax, nullptr, nullptr,
                             J->d_diag, J->d_vals, nullptr, nullptr, nullptr);
 }
 
 int femo_assemble_system(femo_mesh* m, int pde, const double* params, const femo_vec* u,
-                         const femo_vec* f, const femo_bc* bc, femo_mat* J_nobc, femo_mat* A_bc,
-                         femo_vec* rhs) {
+                         const femo_vec* f, const femo_vec* aux, const femo_bc* bc, femo_mat* J_nobc,
+                         femo_mat* A_bc, femo_vec* rhs) {
   FEMO_REQUIRE(m != nullptr, "null argument");
   FEMO_REQUIRE(J_nobc || A_bc || rhs, "nothing to assemble");
   FEMO_REQUIRE((!J_nobc || J_nobc->mesh == m) && (!A_bc || A_bc->mesh == m), "matrix belongs to another mesh");
@@ -384,10 +399,13 @@ int femo_assemble_system(femo_mesh* m, int pde, const double* params, const femo
     FEMO_REQUIRE(u && f, "the Newton right-hand side needs u and f");
     FEMO_REQUIRE(u->n >= m->n_vert && f->n >= m->n_cell && rhs->n >= m->n_rows, "vector size mismatch in assemble_system");
     if (m->n_nbr > 0) FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(u)));
+  } else if (u && m->n_nbr > 0 && pde != FEMO_PDE_POISSON) {
+    FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(u)));
   }
+  FEMO_REQUIRE(aux == nullptr || aux->n >= m->n_vert, "aux field shorter than n_vert");
   if (J_nobc) { J_nobc->valsT_valid = false; J_nobc->scaled_valid = false; }
   if (A_bc) { A_bc->valsT_valid = false; A_bc->scaled_valid = false; }
-  return femo_launch_system(m, pde, params, u ? u->d : nullptr, f ? f->d : nullptr,
+  return femo_launch_system(m, pde, params, u ? u->d : nullptr, f ? f->d : nullptr, aux ? aux->d : nullptr,
                             bc ? bc->d_mask : nullptr, bc ? bc->d_dense : nullptr,
                             J_nobc ? J_nobc->d_diag : nullptr, J_nobc ? J_nobc->d_vals : nullptr,
                             A_bc ? A_bc->d_diag : nullptr, A_bc ? A_bc->d_vals : nullptr,

@@ -113,12 +113,102 @@ __device__ __forceinline__ double dotD(const double* p, const double* q) {
   return s;
 }
 
+// ------------------------------------------------ nonlinear Poisson + Nitsche --
+// examples/nonlinear_poisson_opt/run_nonlinear_poisson_opt.py:88-125 (sym = True, beta):
+//   + int u^3 v                       closed-form P1 monomial integrals (exact, = degree-4 rule)
+//   - int_dO (grad u . n) v           nitsche_1
+//   + int_dO (u_ex - u) (grad v . n)  nitsche_2
+//   + beta/h_E int_dO (u - u_ex) v    penalty, h_E = largest vertex distance (UFL CellDiameter [ext])
+// u_ex is the CG1 interpolant `aux`.  The facet opposite local vertex k has outward normal
+// -g_k/|g_k| and measure D |T| |g_k|; bit k of bfacets[cell] marks it as a boundary facet.
+template <int D>
+__device__ __forceinline__ double cell_diameter(const double* __restrict__ x, const int32_t v[D + 1]) {
+  double h2 = 0.0;
+#pragma unroll
+  for (int a = 0; a <= D; ++a)
+#pragma unroll
+    for (int b = a + 1; b <= D; ++b) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const double t = x[(int64_t)v[a] * D + k] - x[(int64_t)v[b] * D + k];
+        s += t * t;
+      }
+      h2 = fmax(h2, s);
+    }
+  return sqrt(h2);
+}
+
+// Adds the nonlinear/boundary parts of row a: Jacobian entries into krow[b] (if WANT_J) and
+// the residual into *res (if WANT_R).  w[b] = (a == b) as 1.0/0.0; ue = u at the cell vertices.
+template <int D, bool WANT_J, bool WANT_R>
+__device__ __forceinline__ void nl_row(const CellGeom<D>& G, int a, const double w[D + 1], const double ue[D + 1],
+                                       const double* __restrict__ x, const int32_t v[D + 1],
+                                       const double* __restrict__ aux, unsigned bits, double beta,
+                                       double krow[D + 1], double* res) {
+  constexpr double coef = (D == 2) ? 1.0 / 360.0 : 1.0 / 840.0;   // D!/(D+4)!
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0, ua = 0.0;
+#pragma unroll
+  for (int b = 0; b <= D; ++b) {
+    s1 += ue[b]; s2 += ue[b] * ue[b]; s3 += ue[b] * ue[b] * ue[b];
+    ua += w[b] * ue[b];
+  }
+  const double h2 = 0.5 * (s1 * s1 + s2);
+  if (WANT_R) {
+    const double h3 = (s1 * s1 * s1 + 3.0 * s1 * s2 + 2.0 * s3) * (1.0 / 6.0);
+    *res += G.vol * coef * 6.0 * (h3 + ua * (h2 + ua * s1 + ua * ua));
+  }
+  if (WANT_J) {
+#pragma unroll
+    for (int b = 0; b <= D; ++b) {
+      const double ub = ue[b];
+      const double off = 2.0 * (h2 + ua * (s1 + ua) + ub * (s1 + ub) + ua * ub);
+      const double dia = 2.0 * (4.0 * ua * s1 + 6.0 * ua * ua + 2.0 * h2);
+      krow[b] += 3.0 * G.vol * coef * (w[b] * dia + (1.0 - w[b]) * off);
+    }
+  }
+  if (bits == 0u) return;
+  const double hE = cell_diameter<D>(x, v);
+  double e[D + 1], ea = 0.0;
+#pragma unroll
+  for (int b = 0; b <= D; ++b) {
+    e[b] = ue[b] - aux[v[b]];
+    ea += w[b] * e[b];
+  }
+#pragma unroll
+  for (int k = 0; k <= D; ++k) {
+    if (!((bits >> k) & 1u)) continue;
+    const double ng = sqrt(dotD<D>(G.g[k], G.g[k]));
+    const double meas = D * G.vol * ng, inv = -1.0 / ng;
+    double gn[D + 1], gna = 0.0, dun = 0.0, son = 0.0;
+#pragma unroll
+    for (int b = 0; b <= D; ++b) {
+      gn[b] = dotD<D>(G.g[b], G.g[k]) * inv;
+      gna += w[b] * gn[b];
+      dun += gn[b] * ue[b];
+      if (b != k) son += e[b];
+    }
+    const double a_on = 1.0 - w[k];                    // 1 if a is a vertex of the facet
+    const double pen = beta / hE * meas * (1.0 / (D * (D + 1)));
+    if (WANT_R) *res += gna * (-(son * (1.0 / D))) * meas + a_on * (-dun * meas * (1.0 / D) + pen * (ea + son));
+    if (WANT_J) {
+#pragma unroll
+      for (int b = 0; b <= D; ++b) {
+        double t = a_on * (-gn[b] * meas * (1.0 / D));
+        if (b != k) t += -gna * meas * (1.0 / D) + a_on * pen * (1.0 + w[b]);
+        krow[b] += t;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- residual --
 template <int D, int PDE>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_residual(
     int64_t n_rows, int64_t n_blocks, const int64_t* __restrict__ vptr,
     const int32_t* __restrict__ visit_cell, const int32_t* __restrict__ conn,
     const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ f,
+    const double* __restrict__ aux, const uint8_t* __restrict__ bfacets, double beta,
     double* __restrict__ r) {
   const int64_t blk = femo_xcd_block(blockIdx.x, n_blocks);
   const int64_t row = blk * FEMO_BLOCK + threadIdx.x;
@@ -137,18 +227,25 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_residual(
     load_conn<D>(conn, c, v);
     CellGeom<D> G;
     cell_geom<D>(x, v, G);
-    double gu[D];
+    double gu[D], ue[D + 1];
 #pragma unroll
     for (int k = 0; k < D; ++k) gu[k] = 0.0;
 #pragma unroll
     for (int b = 0; b <= D; ++b) {
-      const double ub = u[v[b]];
+      ue[b] = u[v[b]];
 #pragma unroll
-      for (int k = 0; k < D; ++k) gu[k] += G.g[b][k] * ub;
+      for (int k = 0; k < D; ++k) gu[k] += G.g[b][k] * ue[b];
     }
     double ga[D];
     select_row<D>(G, a, ga);
     acc += G.vol * dotD<D>(ga, gu) - f[c] * G.vol * (1.0 / (D + 1));
+    if constexpr (PDE == FEMO_PDE_NL_POISSON) {
+      double w[D + 1], dummy[D + 1];
+#pragma unroll
+      for (int b = 0; b <= D; ++b) w[b] = (a == b) ? 1.0 : 0.0;
+      const unsigned bits = bfacets ? bfacets[c] : 0u;
+      nl_row<D, false, true>(G, a, w, ue, x, v, aux, bits, beta, dummy, &acc);
+    }
   }
   if (row < n_rows) r[row] = acc;
 }
@@ -169,6 +266,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
     const int64_t* __restrict__ mptr, const int32_t* __restrict__ cols,
     const int32_t* __restrict__ rowlen, const int32_t* __restrict__ conn,
     const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ f,
+    const double* __restrict__ aux, const uint8_t* __restrict__ bfacets, double beta,
     const uint8_t* __restrict__ bcmask, const double* __restrict__ bcval,
     double* __restrict__ diag0, double* __restrict__ vals0, double* __restrict__ diag1,
     double* __restrict__ vals1, double* __restrict__ rhs) {
@@ -199,15 +297,30 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
     double ga[D];
     select_row<D>(G, a, ga);
     if (want_rhs) racc -= f[c] * G.vol * (1.0 / (D + 1));
+    double krow[D + 1];
 #pragma unroll
     for (int b = 0; b <= D; ++b) {
-      const double kab = __dmul_rn(G.vol, dotD<D>(ga, G.g[b]));
-      if (want_rhs) racc += kab * u[v[b]];
+      krow[b] = __dmul_rn(G.vol, dotD<D>(ga, G.g[b]));
+      if (want_rhs) racc += krow[b] * u[v[b]];           // linear part of the residual: K u
+    }
+    if constexpr (PDE == FEMO_PDE_NL_POISSON) {
+      double w[D + 1], ue[D + 1];
+#pragma unroll
+      for (int b = 0; b <= D; ++b) {
+        w[b] = (a == b) ? 1.0 : 0.0;
+        ue[b] = u[v[b]];
+      }
+      const unsigned bits = bfacets ? bfacets[c] : 0u;
+      if (want_rhs) nl_row<D, true, true>(G, a, w, ue, x, v, aux, bits, beta, krow, &racc);
+      else nl_row<D, true, false>(G, a, w, ue, x, v, aux, bits, beta, krow, &racc);
+    }
+#pragma unroll
+    for (int b = 0; b <= D; ++b) {
       if (b == a) {
-        dsum += kab;
+        dsum += krow[b];
       } else {
         const int pos = (slots >> (8 * b)) & 0xFF;
-        strip[pos * FEMO_BLOCK + tid] = __dadd_rn(strip[pos * FEMO_BLOCK + tid], kab);
+        strip[pos * FEMO_BLOCK + tid] = __dadd_rn(strip[pos * FEMO_BLOCK + tid], krow[b]);
       }
     }
   }
@@ -415,21 +528,45 @@ inline int64_t row_blocks(const femo_mesh* m) { return (m->n_slices * FEMO_WAVE 
     else hipLaunchKernelGGL((KERNEL<2, P>), dim3(grid), dim3(FEMO_BLOCK), lds, st, __VA_ARGS__); \
   } while (0)
 
+static int check_nl(femo_mesh* m, int pde, const double* u, const double* aux) {
+  FEMO_REQUIRE(pde == FEMO_PDE_POISSON || pde == FEMO_PDE_NL_POISSON, "pde kind %d not implemented", pde);
+  if (pde == FEMO_PDE_NL_POISSON) {
+    FEMO_REQUIRE(u != nullptr, "the nonlinear Poisson form needs the state u");
+    FEMO_REQUIRE(m->d_bfacets == nullptr || aux != nullptr, "Nitsche terms need the boundary data u_exact (aux)");
+  }
+  return 0;
+}
+
 int femo_launch_residual(femo_mesh* m, int pde, const double* params, const double* u,
-                         const double* f, double* r) {
-  FEMO_REQUIRE(pde == FEMO_PDE_POISSON, "pde kind %d not implemented", pde);
+                         const double* f, const double* aux, double* r) {
+  FEMO_TRY(check_nl(m, pde, u, aux));
   const int64_t nb = row_blocks(m);
   if (nb == 0) return 0;
   hipStream_t st = m->ctx->stream;
-  FEMO_LAUNCH_DP(m, k_residual, FEMO_PDE_POISSON, nb, 0, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_conn, m->d_x, u, f, r);
+  const double beta = params ? params[0] : 0.0;
+  if (pde == FEMO_PDE_NL_POISSON)
+    FEMO_LAUNCH_DP(m, k_residual, FEMO_PDE_NL_POISSON, nb, 0, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_conn, m->d_x, u, f, aux, m->d_bfacets, beta, r);
+  else
+    FEMO_LAUNCH_DP(m, k_residual, FEMO_PDE_POISSON, nb, 0, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_conn, m->d_x, u, f, aux, m->d_bfacets, beta, r);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+template <int D, int PDE>
+static int launch_system_t(femo_mesh* m, int64_t nb, size_t lds, const double* u, const double* f, const double* aux,
+                           double beta, const uint8_t* bcmask, const double* bcval, double* diag0, double* vals0,
+                           double* diag1, double* vals1, double* rhs) {
+  auto k = k_jacobian<D, PDE>;
+  if (lds > 64 * 1024) FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k, dim3(nb), dim3(FEMO_BLOCK), lds, m->ctx->stream, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_visit_slots, m->d_mptr, m->d_cols, m->d_rowlen, m->d_conn, m->d_x, u, f, aux, m->d_bfacets, beta, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 int femo_launch_system(femo_mesh* m, int pde, const double* params, const double* u, const double* f,
-                       const uint8_t* bcmask, const double* bcval, double* diag0, double* vals0,
-                       double* diag1, double* vals1, double* rhs) {
-  FEMO_REQUIRE(pde == FEMO_PDE_POISSON, "pde kind %d not implemented", pde);
+                       const double* aux, const uint8_t* bcmask, const double* bcval, double* diag0,
+                       double* vals0, double* diag1, double* vals1, double* rhs) {
+  FEMO_TRY(check_nl(m, pde, u, aux));
   FEMO_REQUIRE(rhs == nullptr || (u != nullptr && f != nullptr), "the Newton right-hand side needs u and f");
   FEMO_REQUIRE((diag1 == nullptr && rhs == nullptr) || bcmask == nullptr || bcval != nullptr, "missing Dirichlet values");
   const int64_t nb = row_blocks(m);
@@ -438,18 +575,13 @@ int femo_launch_system(femo_mesh* m, int pde, const double* params, const double
   while (cap < m->max_rowlen) cap *= 2;
   const size_t lds = (size_t)cap * FEMO_BLOCK * sizeof(double);
   FEMO_REQUIRE(lds <= 160 * 1024, "row length %d exceeds the LDS strip capacity", m->max_rowlen);
-  hipStream_t st = m->ctx->stream;
+  const double beta = params ? params[0] : 0.0;
   if (m->tdim == 3) {
-    auto k = k_jacobian<3, FEMO_PDE_POISSON>;
-    if (lds > 64 * 1024) FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(nb), dim3(FEMO_BLOCK), lds, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_visit_slots, m->d_mptr, m->d_cols, m->d_rowlen, m->d_conn, m->d_x, u, f, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
-  } else {
-    auto k = k_jacobian<2, FEMO_PDE_POISSON>;
-    if (lds > 64 * 1024) FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(nb), dim3(FEMO_BLOCK), lds, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_visit_slots, m->d_mptr, m->d_cols, m->d_rowlen, m->d_conn, m->d_x, u, f, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
+    if (pde == FEMO_PDE_NL_POISSON) return launch_system_t<3, FEMO_PDE_NL_POISSON>(m, nb, lds, u, f, aux, beta, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
+    return launch_system_t<3, FEMO_PDE_POISSON>(m, nb, lds, u, f, aux, beta, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
   }
-  FEMO_HIP_CHECK(hipGetLastError());
-  return 0;
+  if (pde == FEMO_PDE_NL_POISSON) return launch_system_t<2, FEMO_PDE_NL_POISSON>(m, nb, lds, u, f, aux, beta, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
+  return launch_system_t<2, FEMO_PDE_POISSON>(m, nb, lds, u, f, aux, beta, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
 }
 
 int femo_launch_dRdf(femo_mesh* m, int pde, const double* params, const double* u,

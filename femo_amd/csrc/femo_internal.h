@@ -131,6 +131,7 @@ struct femo_mesh {
   int32_t* d_sdelta = nullptr;   // per-slice column deltas (see FemoTopology::sdelta)
   int sdelta_stride = 0;
   int64_t n_regular = 0;
+  uint8_t* d_bfacets = nullptr;  // per cell: bit k = facet opposite local vertex k is on the boundary (optional)
   int32_t* d_tperm = nullptr;  // lazily built: SELL entry -> SELL entry of the transposed nonzero
   std::vector<int64_t> h_mptr;
   // halo plan (n_nbr == 0 on a single GPU)
@@ -199,9 +200,9 @@ __device__ __forceinline__ int64_t femo_xcd_block(int64_t b, int64_t nb) {
 
 // kernel launchers implemented in the .hip files -------------------------------
 int femo_launch_residual(femo_mesh* m, int pde, const double* params, const double* u,
-                         const double* f, double* r);
+                         const double* f, const double* aux, double* r);
 int femo_launch_system(femo_mesh* m, int pde, const double* params, const double* u, const double* f,
-                       const uint8_t* bcmask, const double* bcval, double* diag0, double* vals0,
+                       const double* aux, const uint8_t* bcmask, const double* bcval, double* diag0, double* vals0,
                        double* diag1, double* vals1, double* rhs);
 int femo_launch_dRdf(femo_mesh* m, int pde, const double* params, const double* u,
                      const double* f, double* vals);

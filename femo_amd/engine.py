@@ -203,6 +203,15 @@ class DeviceMesh:
         check(self.lib.femo_mesh_pattern_csr(self.handle, _ptr(rowptr), _ptr(col)))
         return rowptr, col
 
+    def set_boundary_facets(self, mask: Optional[np.ndarray]) -> None:
+        """mask[c] bit k <=> facet of cell c opposite local vertex k is an exterior facet."""
+        if mask is None:
+            check(self.lib.femo_mesh_set_boundary_facets(self.handle, None))
+            return
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        assert mask.shape == (self.n_cell,)
+        check(self.lib.femo_mesh_set_boundary_facets(self.handle, _ptr(mask)))
+
     def set_halo(self, nbr, send_ptr, send_idx, recv_ptr) -> None:
         nbr = _i32(nbr)
         send_ptr = np.ascontiguousarray(send_ptr, np.int64)
@@ -303,22 +312,22 @@ def _params(params) -> Optional[np.ndarray]:
     return p
 
 
-def assemble_residual(mesh: DeviceMesh, pde: int, params, u: Vec, f: Vec, r: Vec) -> Vec:
-    check(mesh.lib.femo_assemble_residual(mesh.handle, pde, _ptr(_params(params)), u.handle, f.handle, r.handle))
+def assemble_residual(mesh: DeviceMesh, pde: int, params, u: Vec, f: Vec, r: Vec, aux: Optional[Vec] = None) -> Vec:
+    check(mesh.lib.femo_assemble_residual(mesh.handle, pde, _ptr(_params(params)), u.handle, f.handle, _h(aux), r.handle))
     return r
 
 
 def assemble_jacobian(mesh: DeviceMesh, pde: int, params, u: Optional[Vec], f: Optional[Vec],
-                      bc: Optional[DirichletSet], J: Mat) -> Mat:
-    check(mesh.lib.femo_assemble_jacobian(mesh.handle, pde, _ptr(_params(params)), _h(u), _h(f), _h(bc), J.handle))
+                      bc: Optional[DirichletSet], J: Mat, aux: Optional[Vec] = None) -> Mat:
+    check(mesh.lib.femo_assemble_jacobian(mesh.handle, pde, _ptr(_params(params)), _h(u), _h(f), _h(aux), _h(bc), J.handle))
     return J
 
 
 def assemble_system(mesh: DeviceMesh, pde: int, params, u: Optional[Vec], f: Optional[Vec],
                     bc: Optional[DirichletSet], J_nobc: Optional[Mat], A_bc: Optional[Mat],
-                    rhs: Optional[Vec]) -> None:
+                    rhs: Optional[Vec], aux: Optional[Vec] = None) -> None:
     """One pass for any subset of dR/du (no BCs), A (BCs eliminated) and the Newton rhs."""
-    check(mesh.lib.femo_assemble_system(mesh.handle, pde, _ptr(_params(params)), _h(u), _h(f), _h(bc),
+    check(mesh.lib.femo_assemble_system(mesh.handle, pde, _ptr(_params(params)), _h(u), _h(f), _h(aux), _h(bc),
                                         _h(J_nobc), _h(A_bc), _h(rhs)))
 
 

@@ -45,6 +45,28 @@ class Mesh:
     def centroids(self) -> np.ndarray:
         return self.x[self.conn].mean(axis=1)
 
+    def boundary_facet_mask(self) -> np.ndarray:
+        """uint8 per cell: bit k set <=> the facet opposite local vertex k belongs to one cell only,
+        i.e. it is an exterior facet (the `ds` measure of UFL [ext])."""
+        if getattr(self, "_bfacets", None) is None:
+            d1 = self.tdim + 1
+            base = np.int64(self.n_vert + 1)
+            keys = np.empty((d1, self.n_cell), dtype=np.int64)
+            for k in range(d1):
+                fv = np.sort(np.delete(self.conn, k, axis=1).astype(np.int64), axis=1)
+                key = fv[:, 0].copy()
+                for j in range(1, fv.shape[1]):
+                    key *= base
+                    key += fv[:, j]
+                keys[k] = key
+            _, inv, cnt = np.unique(keys.ravel(), return_inverse=True, return_counts=True)
+            once = (cnt[inv] == 1).reshape(d1, self.n_cell)
+            mask = np.zeros(self.n_cell, dtype=np.uint8)
+            for k in range(d1):
+                mask |= once[k].astype(np.uint8) << np.uint8(k)
+            self._bfacets = mask
+        return self._bfacets
+
 
 def _apply_jitter(x: np.ndarray, n: int, jitter: float, seed: int) -> np.ndarray:
     """Seeded interior perturbation x += jitter*h*U(-1,1)."""

@@ -16,7 +16,8 @@ import numpy as np
 from .. import _lib
 from .. import engine as E
 from ..engine import Context, DeviceArray, Vec
-from .forms import (DerivativeForm, Form, L2TrackingFunctional, PoissonResidual, derivative)
+from .forms import (DerivativeForm, Form, L2TrackingFunctional, NonlinearPoissonResidual, PoissonResidual,
+                    derivative)
 from .function import Function, FunctionSpace, _VectorView
 from .mesh import (Mesh, createUnitCubeMesh, createUnitSquareMesh, locate_dofs_geometrical)
 
@@ -277,6 +278,22 @@ def _mesh_of(form: Form) -> Mesh:
     return base.functions()[0].function_space.mesh
 
 
+_RESIDUALS = (PoissonResidual, NonlinearPoissonResidual)
+
+
+def _aux(res) -> Optional[Vec]:
+    """Extra device field of a residual form + one-time mesh data it needs (exterior facets)."""
+    if isinstance(res, NonlinearPoissonResidual):
+        if res.weak_bc:
+            mesh = res.u.function_space.mesh
+            dm = mesh.device(get_context())
+            if not getattr(dm, "_bfacets_set", False):
+                dm.set_boundary_facets(mesh.boundary_facet_mask())
+                dm._bfacets_set = True
+            return res.u_exact.vec
+    return None
+
+
 def assembleScalar(c: Form) -> float:
     """utils_dolfinx.py:169-173; local value (all-reduced over ranks inside the engine)."""
     if isinstance(c, L2TrackingFunctional):
@@ -291,9 +308,9 @@ def _assemble_vector_dev(v: Form, out: Optional[Vec] = None) -> Vec:
     ctx = get_context()
     mesh = _mesh_of(v)
     dm = mesh.device(ctx)
-    if isinstance(v, PoissonResidual):
+    if isinstance(v, _RESIDUALS):
         out = out or _work(mesh, "vec_residual", lambda: Vec(ctx, dm.n_vert))
-        return E.assemble_residual(dm, v.pde_kind, v.params, v.u.vec, v.f.vec, out)
+        return E.assemble_residual(dm, v.pde_kind, v.params, v.u.vec, v.f.vec, out, aux=_aux(v))
     if isinstance(v, DerivativeForm) and isinstance(v.form, L2TrackingFunctional):
         J = v.form
         if v.wrt is J.u:
@@ -313,14 +330,15 @@ def assembleVector(v: Form, device: bool = False):
 
 def assembleMatrix(M: Form, bcs: Sequence[DirichletBC] = (), out=None):
     """utils_dolfinx.py:181-187.  ``out`` lets callers re-use a matrix."""
-    if not isinstance(M, DerivativeForm) or not isinstance(M.form, PoissonResidual):
+    if not isinstance(M, DerivativeForm) or not isinstance(M.form, _RESIDUALS):
         raise NotImplementedError(f"assembleMatrix: {type(M).__name__} is not in the form catalogue")
     res = M.form
     mesh = _mesh_of(M)
     dm = mesh.device(get_context())
     if M.wrt is res.u:
         A = out if isinstance(out, SparseMatrix) else SparseMatrix(mesh, symmetric=res.is_symmetric)
-        E.assemble_jacobian(dm, res.pde_kind, res.params, res.u.vec, res.f.vec, _dirichlet_set(mesh, bcs), A.mat)
+        E.assemble_jacobian(dm, res.pde_kind, res.params, res.u.vec, res.f.vec, _dirichlet_set(mesh, bcs), A.mat,
+                            aux=_aux(res))
         return A
     if M.wrt is res.f:
         if bcs:
@@ -337,7 +355,7 @@ def assembleSystem(J: Form, F: Form, bcs: Sequence[DirichletBC] = (), rhs: bool 
     b = F - K[:,bc] g, b[bc] = g (apply_lifting + set_bc [ext]).  The operator
     layer passes ``rhs=False`` because it discards b (state_model.py:149), and
     ``out_nobc`` to get dR/du without BCs from the same pass over the mesh."""
-    if not isinstance(J, DerivativeForm) or not isinstance(J.form, PoissonResidual) or J.wrt is not J.form.u:
+    if not isinstance(J, DerivativeForm) or not isinstance(J.form, _RESIDUALS) or J.wrt is not J.form.u:
         raise NotImplementedError("assembleSystem: J must be derivative(residual, state)")
     res = J.form
     mesh = _mesh_of(J)
@@ -345,7 +363,7 @@ def assembleSystem(J: Form, F: Form, bcs: Sequence[DirichletBC] = (), rhs: bool 
     A = out if isinstance(out, SparseMatrix) else SparseMatrix(mesh, symmetric=res.is_symmetric)
     ds = _dirichlet_set(mesh, bcs)
     E.assemble_system(dm, res.pde_kind, res.params, res.u.vec, res.f.vec, ds,
-                      out_nobc.mat if out_nobc is not None else None, A.mat, None)
+                      out_nobc.mat if out_nobc is not None else None, A.mat, None, aux=_aux(res))
     if not rhs:
         return A, None
     b = _assemble_vector_dev(F).get()
@@ -453,7 +471,7 @@ def setUpKSP_MUMPS(A, options: Optional[dict] = None) -> KSP:
 # ---------------------------------------------------------- nonlinear solves ----
 class _NewtonBase:
     def __init__(self, F: Form, w: Function, bcs, abs_tol, rel_tol, max_it, report, error_on_nonconvergence):
-        if not isinstance(F, PoissonResidual):
+        if not isinstance(F, _RESIDUALS):
             raise NotImplementedError(f"nonlinear solve of {type(F).__name__}")
         self.F, self.w, self.bcs = F, w, list(bcs)
         self.atol, self.rtol, self.max_it = abs_tol, rel_tol, max_it
@@ -462,6 +480,7 @@ class _NewtonBase:
         self.iterations = 0
         self.residual_norms: List[float] = []
         self.ksp_iterations: List[int] = []
+        self.stol = 0.0           # relative step tolerance (PETSc SNES only, see SNESSolver)
 
     # Newton corrections below the rounding error of the assembled residual are noise:
     # ||D^-1 (fl(F(u)) - F(u))||_2 ~ c eps ||u||_2 (measured c ~ 20 on the 10 M-DOF cube,
@@ -480,7 +499,9 @@ class _NewtonBase:
         dx = _work(mesh, "newton_dx", lambda: Vec(ctx, n))
         A = _work(mesh, "newton_A", lambda: SparseMatrix(mesh, symmetric=F.is_symmetric))
         ds = _dirichlet_set(mesh, self.bcs)
-        E.assemble_system(dm, F.pde_kind, F.params, F.u.vec, F.f.vec, ds, None, A.mat, b)
+        aux = _aux(F)
+        # F (with Dirichlet lifting) and J at the current iterate, one pass over the mesh
+        E.assemble_system(dm, F.pde_kind, F.params, F.u.vec, F.f.vec, ds, None, A.mat, b, aux=aux)
         n_own = dm.n_rows          # dots run over owned rows (all-reduced across ranks in the library)
         r0 = r = float(np.sqrt(b.dot(b, n_own)))
         self.residual_norms = [r]
@@ -491,7 +512,6 @@ class _NewtonBase:
         eps = np.finfo(np.float64).eps
         while not converged and it < self.max_it:
             if it > 0:
-                E.assemble_system(dm, F.pde_kind, F.params, F.u.vec, F.f.vec, ds, None, A.mat, None)
                 unorm = float(np.sqrt(func.vec.dot(func.vec, n_own)))
                 opts["atol"] = max(KSP_OPTIONS["atol"], KSP_OPTIONS["rtol"] * z0, self.NOISE_FACTOR * eps * unorm)
             ksp = KSP(A, opts)
@@ -501,13 +521,16 @@ class _NewtonBase:
             self.ksp_iterations.append(ksp.info.iterations)
             func.vec.axpy(-1.0, dx)
             it += 1
-            # residual for the convergence test of the next pass (rhs rows on the Dirichlet set = u - g)
-            E.assemble_residual(dm, F.pde_kind, F.params, F.u.vec, F.f.vec, b)
-            if ds is not None:
-                E.bc_apply_rhs(ds, func.vec, b)
+            step_small = False
+            if self.stol > 0.0:
+                step_small = dx.dot(dx, n_own) < (self.stol ** 2) * func.vec.dot(func.vec, n_own)
+            # next pass: residual for the convergence test and, in the same launch, the Jacobian the
+            # next iteration would use (the reference assembles J only when it iterates again; the
+            # extra matrix of the last pass is wasted work, never skipped work)
+            E.assemble_system(dm, F.pde_kind, F.params, F.u.vec, F.f.vec, ds, None, A.mat, b, aux=aux)
             r = float(np.sqrt(b.dot(b, n_own)))
             self.residual_norms.append(r)
-            converged = r < self.atol or (r0 > 0 and r / r0 < self.rtol)
+            converged = r < self.atol or (r0 > 0 and r / r0 < self.rtol) or step_small
             if self.report:
                 print(f"Newton iteration {it}: r (abs) = {r:.6e} (tol = {self.atol:g}) "
                       f"r (rel) = {r / r0 if r0 > 0 else 0.0:.6e} (tol = {self.rtol:g})")
@@ -541,8 +564,12 @@ class SNESSolverHIP(_NewtonBase):
 
 
 def SNESSolver(F, w, bcs=[], abs_tol=1e-13, rel_tol=1e-13, max_it=100, report=False):
-    """utils_dolfinx.py:376-416: newtonls, full step, atol = rtol = 1e-13, LU -> CG."""
-    return SNESSolverHIP(F, w, bcs, abs_tol, rel_tol, max_it, report, True)
+    """utils_dolfinx.py:376-416: newtonls, full step, atol = rtol = 1e-13, LU -> CG.  The
+    reference leaves PETSc's step tolerance at its default (stol = 1e-8: converged when
+    ||dx|| < stol ||x|| [ext]), which is what ends the iteration once ||F|| sits on round-off."""
+    s = SNESSolverHIP(F, w, bcs, abs_tol, rel_tol, max_it, report, True)
+    s.stol = 1e-8
+    return s
 
 
 def solveNonlinear(res, func, bc, solver, report, initialize):

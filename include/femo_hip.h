@@ -120,6 +120,10 @@ int femo_mesh_create(femo_ctx* ctx, int tdim, int64_t n_vert, int64_t n_rows,
                      femo_mesh** out);
 int femo_mesh_destroy(femo_mesh* mesh);
 int femo_mesh_info(const femo_mesh* mesh, int64_t info[FEMO_MESH_INFO_COUNT]);
+/* mask[c] bit k set <=> the facet of cell c opposite its local vertex k is an exterior facet
+ * (the `ds` measure of the reference's boundaryResidual, run_nonlinear_poisson_opt.py:98-117).
+ * NULL clears it.                                                              */
+int femo_mesh_set_boundary_facets(femo_mesh* mesh, const uint8_t* mask);
 /* CSR view of the pattern (rowptr: n_rows+1, col: NNZ; sorted columns).       */
 int femo_mesh_pattern_csr(const femo_mesh* mesh, int64_t* rowptr, int32_t* col);
 
@@ -136,7 +140,10 @@ int femo_bc_create(femo_mesh* mesh, int64_t n, const int32_t* dofs, const double
 int femo_bc_destroy(femo_bc* bc);
 
 /* ---- assembly -------------------------------------------------------------
- * params: up to 8 doubles of form constants (unused for POISSON).
+ * params: up to 8 doubles of form constants (unused for POISSON; NL_POISSON: params[0] = Nitsche
+ *         beta).  aux: extra CG1 field of the form or NULL (NL_POISSON: the boundary data u_exact).
+ *         FEMO_PDE_NL_POISSON = POISSON + int u^3 v (run_nonlinear_poisson_opt.py:88-96) and, when
+ *         femo_mesh_set_boundary_facets was called, the symmetric Nitsche terms of :98-117.
  * residual: state_model.py:85 assembleVector(residual_form) -> utils:175-179; NO BCs.
  * jacobian: state_model.py:132 assembleMatrix(dR_du) (bc == NULL) and
  *           state_model.py:149 assembleSystem(dR_du, res, bcs) -> utils:189-202
@@ -145,12 +152,12 @@ int femo_bc_destroy(femo_bc* bc);
  *           cell-major as (n_cell, tdim+1) values aligned with conn, i.e. the
  *           CSC of the N x n_cell matrix (column c has rows conn[c,:]).        */
 int femo_assemble_residual(femo_mesh* mesh, int pde, const double* params,
-                           const femo_vec* u, const femo_vec* f, femo_vec* r);
+                           const femo_vec* u, const femo_vec* f, const femo_vec* aux, femo_vec* r);
 int femo_mat_create(femo_mesh* mesh, femo_mat** out);
 int femo_mat_destroy(femo_mat* A);
 int femo_assemble_jacobian(femo_mesh* mesh, int pde, const double* params,
-                           const femo_vec* u, const femo_vec* f, const femo_bc* bc,
-                           femo_mat* J);
+                           const femo_vec* u, const femo_vec* f, const femo_vec* aux,
+                           const femo_bc* bc, femo_mat* J);
 int femo_assemble_dRdf(femo_mesh* mesh, int pde, const double* params,
                        const femo_vec* u, const femo_vec* f, femo_vec* vals);
 /* One pass over the mesh for any subset of: J_nobc (state_model.py:132), A_bc
@@ -158,8 +165,8 @@ int femo_assemble_dRdf(femo_mesh* mesh, int pde, const double* params,
  * rhs[bc] = u-g  (dolfinx NonlinearProblem.F/J [ext], utils_dolfinx.py:431).
  * Unused outputs are NULL.  Results are identical to the separate calls.       */
 int femo_assemble_system(femo_mesh* mesh, int pde, const double* params,
-                         const femo_vec* u, const femo_vec* f, const femo_bc* bc,
-                         femo_mat* J_nobc, femo_mat* A_bc, femo_vec* rhs);
+                         const femo_vec* u, const femo_vec* f, const femo_vec* aux,
+                         const femo_bc* bc, femo_mat* J_nobc, femo_mat* A_bc, femo_vec* rhs);
 /* b[bc] = u[bc] - g  (dolfinx set_bc(b, bcs, x, -1.0) [ext]).                    */
 int femo_bc_apply_rhs(const femo_bc* bc, const femo_vec* u, femo_vec* b);
 /* Newton right-hand side with Dirichlet lifting, dolfinx NonlinearProblem.F

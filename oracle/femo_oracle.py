@@ -438,3 +438,168 @@ def reference_cycle(mesh: OMesh, f: np.ndarray, u_d: np.ndarray, bc_dofs: np.nda
     J = functional(mesh, u, f, u_d, alpha)
     grad, lam = total_gradient(mesh, f, u, u_d, bc_dofs, alpha)
     return dict(u=u, J=np.array([J]), grad=grad, lam=lam)
+
+
+# ==========================================================================
+# examples/nonlinear_poisson_opt: -div grad u + u^3 = f with symmetric Nitsche
+# boundary terms  (run_nonlinear_poisson_opt.py:82-142, 196-210)
+#   interior   inner(grad u, grad v) dx + inner(u**3, v) dx - inner(f, v) dx      (:88-96)
+#   nitsche_1  - inner(dot(grad u, n), v) ds                                       (:109)
+#   nitsche_2  sgn * inner(u_exact - u, dot(grad v, n)) ds,  sgn = +1 (sym=True)   (:110-111)
+#   penalty    beta / h_E * inner(u - u_exact, v) ds,  beta = 10 (:98-100, :113-115)
+# u_exact is the UFL expression sin(2 pi x) sin(pi y) in the reference (:145); its
+# quadrature there uses an estimated degree [ext], which cannot be reproduced
+# without FFCx.  Here u_exact is its CG1 interpolant, so every
+# integrand is polynomial and integrated exactly: u^3 v by the closed-form P1
+# monomial integrals (= any degree-4 rule), facet terms by the P1 facet mass matrix.
+# h_E = UFL CellDiameter = largest vertex distance of the cell [ext].
+# ==========================================================================
+ALPHA_NL = 6e-7      # run_nonlinear_poisson_opt.py:80 ALPHA_1
+BETA_NITSCHE = 10.0  # :98 beta_value=1e1
+
+
+def u_exact_nl(x: np.ndarray) -> np.ndarray:
+    """run_nonlinear_poisson_opt.py:145 (2-D); the 3-D analogue multiplies by sin(pi z)."""
+    v = np.sin(2 * np.pi * x[:, 0]) * np.sin(np.pi * x[:, 1])
+    if x.shape[1] == 3:
+        v = v * np.sin(np.pi * x[:, 2])
+    return v
+
+
+def boundary_facets(mesh: OMesh) -> np.ndarray:
+    """Bit k of mask[c] set <=> the facet of cell c opposite local vertex k lies on the boundary
+    (it belongs to exactly one cell)."""
+    d1 = mesh.tdim + 1
+    nc = mesh.n_cell
+    keys = []
+    for k in range(d1):
+        fv = np.sort(np.delete(mesh.conn, k, axis=1), axis=1).astype(np.int64)
+        key = fv[:, 0]
+        for j in range(1, fv.shape[1]):
+            key = key * (mesh.n_vert + 1) + fv[:, j]
+        keys.append(key)
+    allk = np.concatenate(keys)
+    _, inv, cnt = np.unique(allk, return_inverse=True, return_counts=True)
+    onb = (cnt[inv] == 1).reshape(d1, nc)
+    mask = np.zeros(nc, np.uint8)
+    for k in range(d1):
+        mask |= (onb[k].astype(np.uint8) << k)
+    return mask
+
+
+def _p1_cubic_tables(d: int):
+    """T3[a,b,c,e] = int phi_a phi_b phi_c phi_e / |T| on a d-simplex (monomial formula
+    int prod phi^alpha = |T| d! prod(alpha!) / (|alpha| + d)!)."""
+    d1 = d + 1
+    T = np.zeros((d1,) * 4)
+    from itertools import product
+    for idx in product(range(d1), repeat=4):
+        mult = np.bincount(idx, minlength=d1)
+        T[idx] = math.factorial(d) * np.prod([math.factorial(int(m)) for m in mult]) / math.factorial(4 + d)
+    return T
+
+
+def _facet_pieces(mesh: OMesh, bmask: np.ndarray):
+    """Per (cell, local facet k) on the boundary: facet measure, outward unit normal, h_E."""
+    vol, g = cell_geometry(mesh)
+    d = mesh.tdim
+    X = mesh.x[mesh.conn]
+    hE = np.zeros(mesh.n_cell)
+    for a in range(d + 1):
+        for b in range(a + 1, d + 1):
+            hE = np.maximum(hE, np.linalg.norm(X[:, a] - X[:, b], axis=1))
+    out = []
+    for k in range(d + 1):
+        cells = np.nonzero((bmask >> k) & 1)[0]
+        if cells.size == 0:
+            continue
+        gk = g[cells, k, :]
+        ng = np.linalg.norm(gk, axis=1)
+        nrm = -gk / ng[:, None]                       # outward normal of the facet opposite vertex k
+        meas = d * vol[cells] * ng                    # |F_k| = d |T| |grad phi_k|
+        out.append((k, cells, meas, nrm, hE[cells], g[cells]))
+    return out
+
+
+def nl_residual(mesh: OMesh, u: np.ndarray, f: np.ndarray, u_ex: np.ndarray, bmask: np.ndarray,
+                beta: float = BETA_NITSCHE) -> np.ndarray:
+    d = mesh.tdim
+    d1 = d + 1
+    R = residual(mesh, u, f)                                            # grad-grad and load
+    vol, _ = cell_geometry(mesh)
+    T3 = _p1_cubic_tables(d)
+    ue = u[mesh.conn]
+    cub = vol[:, None] * np.einsum("abce,nb,nc,ne->na", T3, ue, ue, ue)
+    np.add.at(R, mesh.conn.ravel(), cub.ravel())
+    for k, cells, meas, nrm, hE, g in _facet_pieces(mesh, bmask):
+        conn = mesh.conn[cells]
+        on = [a for a in range(d1) if a != k]                            # facet vertices (local)
+        e = (u - u_ex)[conn]                                             # (nf, d1)
+        gn = np.einsum("nad,nd->na", g, nrm)                             # grad phi_a . n
+        dun = np.einsum("na,na->n", gn, u[conn])                         # grad u . n
+        Re = np.zeros((len(cells), d1))
+        mean_e = e[:, on].sum(axis=1) / d                                # int_F e / |F|
+        for a in range(d1):
+            Re[:, a] += gn[:, a] * (-mean_e) * meas                      # nitsche_2: (g_a.n) int_F (u_ex - u)
+        s_on = e[:, on].sum(axis=1)
+        for a in on:
+            Re[:, a] += -dun * meas / d                                  # nitsche_1
+            Re[:, a] += beta / hE * meas / (d * (d + 1)) * (e[:, a] + s_on)   # penalty (facet mass)
+        np.add.at(R, conn.ravel(), Re.ravel())
+    return R
+
+
+def nl_jacobian(mesh: OMesh, u: np.ndarray, bmask: np.ndarray, beta: float = BETA_NITSCHE) -> sp.csr_matrix:
+    d = mesh.tdim
+    d1 = d + 1
+    vol, g = cell_geometry(mesh)
+    T3 = _p1_cubic_tables(d)
+    ue = u[mesh.conn]
+    Ke = vol[:, None, None] * (np.einsum("cad,cbd->cab", g, g) + 3.0 * np.einsum("abce,nc,ne->nab", T3, ue, ue))
+    for k, cells, meas, nrm, hE, gg in _facet_pieces(mesh, bmask):
+        on = [a for a in range(d1) if a != k]
+        gn = np.einsum("nad,nd->na", gg, nrm)
+        Fe = np.zeros((len(cells), d1, d1))
+        for a in on:
+            Fe[:, a, :] += -(gn * (meas / d)[:, None])                   # nitsche_1: -(g_b.n) int_F phi_a
+            Fe[:, :, a] += -(gn * (meas / d)[:, None])                   # nitsche_2: -(g_a.n) int_F phi_b
+            for b in on:
+                Fe[:, a, b] += beta / hE * meas / (d * (d + 1)) * (2.0 if a == b else 1.0)
+        Ke[cells] += Fe
+    r = np.repeat(mesh.conn[:, :, None], d1, axis=2)
+    c = np.repeat(mesh.conn[:, None, :], d1, axis=1)
+    return _scatter_matrix(mesh, Ke, mesh.n_vert, mesh.n_vert, r, c)
+
+
+def nl_newton_solve(mesh: OMesh, f: np.ndarray, u0: np.ndarray, u_ex: np.ndarray, bmask: np.ndarray,
+                    beta: float = BETA_NITSCHE, atol: float = 1e-13, rtol: float = 1e-13, max_it: int = 100
+                    ) -> Tuple[np.ndarray, SolveInfo]:
+    """utils_dolfinx.py:376-416 SNES newtonls, line search basic (full step), LU; no strong BCs."""
+    u = u0.copy()
+    info = SolveInfo()
+    F = nl_residual(mesh, u, f, u_ex, bmask, beta)
+    r0 = float(np.linalg.norm(F))
+    info.residual_norms.append(r0)
+    while info.newton_its < max_it:
+        r = info.residual_norms[-1]
+        if r < atol or (info.newton_its > 0 and r < rtol * r0):
+            break
+        J = nl_jacobian(mesh, u, bmask, beta)
+        u -= spla.splu(J.tocsc()).solve(F)
+        info.newton_its += 1
+        F = nl_residual(mesh, u, f, u_ex, bmask, beta)
+        info.residual_norms.append(float(np.linalg.norm(F)))
+    return u, info
+
+
+def nl_reference_cycle(mesh: OMesh, f: np.ndarray, u_ex: np.ndarray, bmask: np.ndarray,
+                       alpha: float = ALPHA_NL, beta: float = BETA_NITSCHE) -> Dict[str, np.ndarray]:
+    """run_nonlinear_poisson_opt.py: SNES solve from u = 1 (CSDL's default state value), J, adjoint
+    gradient.  No Dirichlet rows, so A = dR/du and the reduced gradient is exact."""
+    u, info = nl_newton_solve(mesh, f, np.ones(mesh.n_vert), u_ex, bmask, beta)
+    J = functional(mesh, u, f, u_ex, alpha)
+    dJdu = functional_du(mesh, u, u_ex)
+    A = nl_jacobian(mesh, u, bmask, beta)
+    lam = spla.splu(A.T.tocsc()).solve(dJdu)
+    grad = functional_df(mesh, f, alpha) - dRdf(mesh).T @ lam
+    return dict(u=u, J=np.array([J]), grad=grad, lam=lam, newton_its=info.newton_its)
