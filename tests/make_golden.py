@@ -50,4 +50,12 @@ if __name__ == "__main__":
     np.savez(os.path.join(OUT, "element_kats.npz"), **element_kats())
     for d, n, jit in [(2, 4, 0.0), (2, 8, 0.2), (3, 4, 0.0), (3, 6, 0.2)]:
         np.savez_compressed(os.path.join(OUT, f"poisson_d{d}_n{n}_j{int(jit * 10)}.npz"), **assembled(d, n, jit))
+    # nonlinear Poisson + symmetric Nitsche (examples/nonlinear_poisson_opt): f = 0.1, u from 1
+    m = fo.unit_square_mesh(8, 0.2)
+    bm = fo.boundary_facets(m)
+    f = 0.1 * np.ones(m.n_cell)
+    uex = fo.u_exact_nl(m.x)
+    ref = fo.nl_reference_cycle(m, f, uex, bm)
+    np.savez_compressed(os.path.join(OUT, "nl_poisson_d2_n8.npz"), x=m.x, conn=m.conn, bmask=bm, f=f, u_ex=uex,
+                        u=ref["u"], J=ref["J"], grad=ref["grad"], lam=ref["lam"], newton_its=ref["newton_its"])
     print("wrote", sorted(os.listdir(OUT)))

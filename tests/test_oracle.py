@@ -151,3 +151,47 @@ def test_c_port_pieces():
     x, it, res = c_port.pcg(rp, col, A.data, b, rtol=1e-13)
     xo, it_o, _ = fo.pcg_jacobi(A, b, rtol=1e-13)
     assert abs(it - it_o) <= 1 and np.abs(x - xo).max() < 1e-10 * np.abs(xo).max()
+
+
+# ---- nonlinear Poisson + symmetric Nitsche (examples/nonlinear_poisson_opt) ----
+@pytest.mark.parametrize("d,n", [(2, 8), (3, 4)])
+def test_nl_oracle_consistency(d, n):
+    m = fo.unit_square_mesh(n, 0.2) if d == 2 else fo.unit_cube_mesh(n, 0.2)
+    bm = fo.boundary_facets(m)
+    assert sum(bin(int(b)).count("1") for b in bm) == (4 * n if d == 2 else 12 * n * n)
+    rng = np.random.default_rng(0)
+    u, f = 0.5 * rng.standard_normal(m.n_vert), rng.standard_normal(m.n_cell)
+    uex = fo.u_exact_nl(m.x)
+    J = fo.nl_jacobian(m, u, bm)
+    assert abs(J - J.T).max() < 1e-14                     # sym=True Nitsche: symmetric Jacobian
+    du = rng.standard_normal(m.n_vert)
+    fd = (fo.nl_residual(m, u + 1e-6 * du, f, uex, bm) - fo.nl_residual(m, u - 1e-6 * du, f, uex, bm)) / 2e-6
+    assert np.abs(fd - J @ du).max() < 1e-8 * np.abs(J @ du).max()
+    # cubic term: closed-form P1 monomial integrals vs brute-force tensor on one cell
+    T3 = fo._p1_cubic_tables(d)
+    assert np.isclose(T3.sum(), 1.0)                      # sum_abce int phi_a phi_b phi_c phi_e = |T|
+
+
+def test_nl_manufactured_solution_converges():
+    """u = sin 2pi x sin pi y, f = 5 pi^2 u + u^3 (run_nonlinear_poisson_opt.py:145-168): O(h^2) in L2."""
+    errs = []
+    for n in (8, 16, 32):
+        m = fo.unit_square_mesh(n)
+        bm = fo.boundary_facets(m)
+        xc = fo.centroids(m)
+        uc = np.sin(2 * np.pi * xc[:, 0]) * np.sin(np.pi * xc[:, 1])
+        uex = fo.u_exact_nl(m.x)
+        u, info = fo.nl_newton_solve(m, 5 * np.pi ** 2 * uc + uc ** 3, np.ones(m.n_vert), uex, bm)
+        assert info.newton_its <= 6 and info.residual_norms[-1] < 1e-12
+        errs.append(np.sqrt(2 * fo.functional(m, u, np.zeros(m.n_cell), uex, 0.0)))
+    assert np.log2(errs[0] / errs[1]) > 1.7 and np.log2(errs[1] / errs[2]) > 1.85
+
+
+def test_nl_golden_vector():
+    g = np.load(os.path.join(GOLD, "nl_poisson_d2_n8.npz"))
+    m = fo.OMesh(2, g["x"], g["conn"])
+    assert np.array_equal(fo.boundary_facets(m), g["bmask"])
+    ref = fo.nl_reference_cycle(m, g["f"], g["u_ex"], g["bmask"])
+    for k in ("u", "J", "grad", "lam"):
+        assert np.abs(ref[k] - g[k]).max() <= 1e-11 * np.abs(g[k]).max()
+    assert int(ref["newton_its"]) == int(g["newton_its"])
