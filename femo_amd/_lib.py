@@ -25,6 +25,7 @@ MESH_INFO_KEYS = ("tdim", "n_vert", "n_rows", "n_cell", "nnz", "sell_entries", "
 
 PDE_POISSON = 0
 PDE_NL_POISSON = 1
+PDE_MASS = 2
 J_L2_TRACKING = 0
 
 
@@ -84,6 +85,8 @@ PROTOTYPES = {
     "femo_functional_value": (C.c_int, [H, C.c_int, C.c_void_p, H, H, H, c_f64p]),
     "femo_functional_grad_u": (C.c_int, [H, C.c_int, C.c_void_p, H, H, H, H]),
     "femo_functional_grad_f": (C.c_int, [H, C.c_int, C.c_void_p, H, H, H, H]),
+    "femo_cell_expression": (C.c_int, [H, C.c_int, C.c_void_p, H, H]),
+    "femo_vec_pointwise_divide": (C.c_int, [H, H, H, c_i64]),
     "femo_bench_spmv": (C.c_int, [H, H, H, C.c_int, c_f64p]),
     "femo_comm_unique_id": (C.c_int, [C.c_char_p]),
     "femo_comm_init": (C.c_int, [H, C.c_char_p, C.c_int, C.c_int]),

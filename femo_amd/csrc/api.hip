@@ -15,6 +15,10 @@ __global__ void k_axpy(int64_t n, double a, const double* __restrict__ x, double
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] += a * x[i];
 }
 
+__global__ void k_pdiv(int64_t n, const double* __restrict__ x, const double* __restrict__ d, double* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = x[i] / d[i];
+}
+
 __global__ void k_bc_mask(int64_t n, const int32_t* __restrict__ dofs, const double* __restrict__ vals,
                           uint8_t* __restrict__ mask, double* __restrict__ dense) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -529,6 +533,22 @@ int femo_functional_grad_f(femo_mesh* m, int kind, const double* params, const f
   FEMO_REQUIRE(m && f && g, "null argument");
   FEMO_REQUIRE(f->n >= m->n_cell && g->n >= m->n_cell, "vector size mismatch in functional grad_f");
   return femo_launch_functional_grad_f(m, kind, params, u ? u->d : nullptr, f->d, u_d ? u_d->d : nullptr, g->d);
+}
+
+int femo_cell_expression(femo_mesh* m, int kind, const double* params, const femo_vec* in, femo_vec* out) {
+  FEMO_REQUIRE(m && in && out, "null argument");
+  FEMO_REQUIRE(out->n >= m->n_cell && in->n >= (kind == 0 ? m->n_vert : m->n_cell), "vector size mismatch in cell_expression");
+  if (kind == 0 && m->n_nbr > 0) FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(in)));
+  return femo_launch_cell_expr(m, kind, params, in->d, out->d);
+}
+
+int femo_vec_pointwise_divide(femo_vec* y, const femo_vec* x, const femo_vec* d, int64_t n) {
+  FEMO_REQUIRE(y && x && d, "null argument");
+  FEMO_REQUIRE(n <= y->n && n <= x->n && n <= d->n, "length exceeds vector size");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_pdiv, dim3(grid_for(n)), dim3(256), 0, y->ctx->stream, n, x->d, d->d, y->d);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
 }
 
 // ----------------------------------------------------------------- comm -----

@@ -300,7 +300,12 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
     double krow[D + 1];
 #pragma unroll
     for (int b = 0; b <= D; ++b) {
-      krow[b] = __dmul_rn(G.vol, dotD<D>(ga, G.g[b]));
+      if constexpr (PDE == FEMO_PDE_MASS) {
+        // P1 mass matrix |T| (1 + delta_ab) / ((d+1)(d+2))  (utils_dolfinx.py:569 inner(Pv, w) dx)
+        krow[b] = G.vol * (1.0 / ((D + 1) * (D + 2))) * ((a == b) ? 2.0 : 1.0);
+      } else {
+        krow[b] = __dmul_rn(G.vol, dotD<D>(ga, G.g[b]));
+      }
       if (want_rhs) racc += krow[b] * u[v[b]];           // linear part of the residual: K u
     }
     if constexpr (PDE == FEMO_PDE_NL_POISSON) {
@@ -494,6 +499,34 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_functional_grad_f(int64_t n_cell
   }
 }
 
+// DG0 field expressions for L2-projected outputs (fea_dolfinx.py:148-161, utils_dolfinx.py:549-583)
+//   kind 0: |grad u| per cell (u CG1)      kind 1: w_c ** p (w DG0, p = params[0])
+template <int D>
+__global__ __launch_bounds__(FEMO_BLOCK) void k_cell_expr(int64_t n_cell, int kind, double p0, const int32_t* __restrict__ conn,
+                                                          const double* __restrict__ x, const double* __restrict__ in,
+                                                          double* __restrict__ out) {
+  for (int64_t c = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; c < n_cell; c += (int64_t)gridDim.x * FEMO_BLOCK) {
+    if (kind == 1) {
+      out[c] = pow(in[c], p0);
+      continue;
+    }
+    int32_t v[D + 1];
+    load_conn<D>(conn, c, v);
+    CellGeom<D> G;
+    cell_geom<D>(x, v, G);
+    double gu[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) gu[k] = 0.0;
+#pragma unroll
+    for (int b = 0; b <= D; ++b) {
+      const double ub = in[v[b]];
+#pragma unroll
+      for (int k = 0; k < D; ++k) gu[k] += G.g[b][k] * ub;
+    }
+    out[c] = sqrt(dotD<D>(gu, gu));
+  }
+}
+
 __global__ void k_reduce_partials(int nblocks, int nsums, const double* __restrict__ partials,
                                   double* __restrict__ out) {
   __shared__ double lds[1024 / 64];
@@ -529,7 +562,7 @@ inline int64_t row_blocks(const femo_mesh* m) { return (m->n_slices * FEMO_WAVE 
   } while (0)
 
 static int check_nl(femo_mesh* m, int pde, const double* u, const double* aux) {
-  FEMO_REQUIRE(pde == FEMO_PDE_POISSON || pde == FEMO_PDE_NL_POISSON, "pde kind %d not implemented", pde);
+  FEMO_REQUIRE(pde == FEMO_PDE_POISSON || pde == FEMO_PDE_NL_POISSON || pde == FEMO_PDE_MASS, "pde kind %d not implemented", pde);
   if (pde == FEMO_PDE_NL_POISSON) {
     FEMO_REQUIRE(u != nullptr, "the nonlinear Poisson form needs the state u");
     FEMO_REQUIRE(m->d_bfacets == nullptr || aux != nullptr, "Nitsche terms need the boundary data u_exact (aux)");
@@ -540,6 +573,7 @@ static int check_nl(femo_mesh* m, int pde, const double* u, const double* aux) {
 int femo_launch_residual(femo_mesh* m, int pde, const double* params, const double* u,
                          const double* f, const double* aux, double* r) {
   FEMO_TRY(check_nl(m, pde, u, aux));
+  FEMO_REQUIRE(pde != FEMO_PDE_MASS, "the mass form has no residual");
   const int64_t nb = row_blocks(m);
   if (nb == 0) return 0;
   hipStream_t st = m->ctx->stream;
@@ -576,6 +610,11 @@ int femo_launch_system(femo_mesh* m, int pde, const double* params, const double
   const size_t lds = (size_t)cap * FEMO_BLOCK * sizeof(double);
   FEMO_REQUIRE(lds <= 160 * 1024, "row length %d exceeds the LDS strip capacity", m->max_rowlen);
   const double beta = params ? params[0] : 0.0;
+  if (pde == FEMO_PDE_MASS) {
+    FEMO_REQUIRE(rhs == nullptr, "the mass form has no residual");
+    if (m->tdim == 3) return launch_system_t<3, FEMO_PDE_MASS>(m, nb, lds, u, f, aux, beta, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
+    return launch_system_t<2, FEMO_PDE_MASS>(m, nb, lds, u, f, aux, beta, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
+  }
   if (m->tdim == 3) {
     if (pde == FEMO_PDE_NL_POISSON) return launch_system_t<3, FEMO_PDE_NL_POISSON>(m, nb, lds, u, f, aux, beta, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
     return launch_system_t<3, FEMO_PDE_POISSON>(m, nb, lds, u, f, aux, beta, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
@@ -607,6 +646,17 @@ int femo_launch_dRdf_apply(femo_mesh* m, const double* vals, int transpose, cons
     if (nb == 0) return 0;
     FEMO_LAUNCH_D(m, k_dRdf_apply_N, nb, 0, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, vals, x, y, accumulate);
   }
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int femo_launch_cell_expr(femo_mesh* m, int kind, const double* params, const double* in, double* out) {
+  FEMO_REQUIRE(kind == 0 || kind == 1, "cell expression kind %d not implemented", kind);
+  if (m->n_cell == 0) return 0;
+  const int g = cell_grid(m->n_cell);
+  const double p0 = params ? params[0] : 1.0;
+  hipStream_t st = m->ctx->stream;
+  FEMO_LAUNCH_D(m, k_cell_expr, g, 0, st, m->n_cell, kind, p0, m->d_conn, m->d_x, in, out);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -204,6 +204,7 @@ int femo_launch_residual(femo_mesh* m, int pde, const double* params, const doub
 int femo_launch_system(femo_mesh* m, int pde, const double* params, const double* u, const double* f,
                        const double* aux, const uint8_t* bcmask, const double* bcval, double* diag0, double* vals0,
                        double* diag1, double* vals1, double* rhs);
+int femo_launch_cell_expr(femo_mesh* m, int kind, const double* params, const double* in, double* out);
 int femo_launch_dRdf(femo_mesh* m, int pde, const double* params, const double* u,
                      const double* f, double* vals);
 int femo_launch_dRdf_apply(femo_mesh* m, const double* vals, int transpose, const double* x,

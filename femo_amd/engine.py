@@ -367,6 +367,16 @@ def functional_grad_f(mesh: DeviceMesh, kind: int, params, u: Optional[Vec], f: 
     return g
 
 
+def cell_expression(mesh: DeviceMesh, kind: int, params, vin: Vec, out: Vec) -> Vec:
+    check(mesh.lib.femo_cell_expression(mesh.handle, kind, _ptr(_params(params)), vin.handle, out.handle))
+    return out
+
+
+def pointwise_divide(y: Vec, x: Vec, d: Vec, n: int) -> Vec:
+    check(y.lib.femo_vec_pointwise_divide(y.handle, x.handle, d.handle, n))
+    return y
+
+
 def topology_host(tdim: int, n_vert: int, n_rows: int, conn: np.ndarray):
     """Host-only pattern build (no GPU): returns (info dict, rowptr, col)."""
     lib = _lib.load()

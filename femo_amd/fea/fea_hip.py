@@ -12,9 +12,10 @@ import os
 import numpy as np
 
 from .utils_hip import *          # noqa: F401,F403  (the reference star-imports its utils too, fea_dolfinx.py:5)
-from .utils_hip import (DeviceArray, DirichletBC, KSP, dirichletbc, getFuncArray, setFuncArray,
+from .utils_hip import (DeviceArray, DirichletBC, KSP, dirichletbc, getFuncArray, project, setFuncArray,
                         solveKSP_mumps, solveNonlinear, transpose)
-from .forms import (ALPHA, DerivativeForm, Form, L2TrackingFunctional, PoissonResidual, TestFunction,
+from .forms import (ALPHA, DerivativeForm, FieldExpression, Form, FunctionExpr, GradientMagnitude,
+                    L2TrackingFunctional, NonlinearPoissonResidual, PoissonResidual, PowerExpr, TestFunction,
                     derivative, interiorResidual, outputForm, pdeRes)
 from .function import Function, FunctionSpace
 from .mesh import Mesh, createUnitCubeMesh, createUnitSquareMesh, locate_dofs_geometrical
@@ -124,8 +125,20 @@ class FEA(object):
         )
 
     def add_field_output(self, name, form, arguments, record=False):
-        """fea_dolfinx.py:148-161 (L2 projection outputs: SURVEY.md 8(f) rank 1, not built yet)."""
-        raise NotImplementedError("field outputs (L2 projection) are not implemented in this round")
+        """fea_dolfinx.py:148-161: a CG1 field obtained by L2 projection of ``form``
+        (a catalogue FieldExpression instead of a UFL expression)."""
+        V = FunctionSpace(self.mesh, ("CG", 1))
+        output_func = Function(V)
+        partials = []
+        self.outputs_field_dict[name] = dict(
+            form=form,
+            func=output_func,
+            shape=len(getFuncArray(output_func)),
+            arguments=arguments,
+            partials=partials,
+            recorder=self.createRecorder(name, record),
+            record=record
+        )
 
     def add_exact_solution(self, Expression, function_space):
         """fea_dolfinx.py:163-167"""
@@ -191,7 +204,7 @@ class FEA(object):
 
     def projectFieldOutput(self, form, func):
         """fea_dolfinx.py:224-225"""
-        raise NotImplementedError("project() is not implemented in this round")
+        project(form, func, lump_mass=False)
 
     def createRecorder(self, name, record=False):
         """fea_dolfinx.py:228-234"""

@@ -80,6 +80,43 @@ class L2TrackingFunctional(Form):
         return (self.u, self.f, self.u_exact)
 
 
+class FieldExpression(Form):
+    """A field to be L2-projected onto CG1 (fea_dolfinx.py:148-161, utils_dolfinx.py:549-583).
+    The reference accepts any UFL expression; the catalogue offers
+      FunctionExpr(fn)          a DG0 or CG1 Function itself
+      GradientMagnitude(u)      sqrt(inner(grad u, grad u)), cell-wise constant for CG1 u
+      PowerExpr(fn, p)          fn ** p for a DG0 Function (run_topo_opt_cantilever_beam.py:257)"""
+    rank = 1
+
+
+class FunctionExpr(FieldExpression):
+    def __init__(self, fn: Function):
+        self.fn = fn
+
+    def functions(self):
+        return (self.fn,)
+
+
+class GradientMagnitude(FieldExpression):
+    def __init__(self, u: Function):
+        if u.function_space.family != "CG":
+            raise NotImplementedError("GradientMagnitude needs a CG1 Function")
+        self.fn = u
+
+    def functions(self):
+        return (self.fn,)
+
+
+class PowerExpr(FieldExpression):
+    def __init__(self, fn: Function, p: float):
+        if fn.function_space.family != "DG":
+            raise NotImplementedError("PowerExpr needs a DG0 Function")
+        self.fn, self.p = fn, float(p)
+
+    def functions(self):
+        return (self.fn,)
+
+
 class DerivativeForm(Form):
     """Gateaux derivative of ``form`` w.r.t. ``wrt`` (ufl.derivative)."""
 

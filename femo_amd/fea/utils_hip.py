@@ -16,8 +16,8 @@ import numpy as np
 from .. import _lib
 from .. import engine as E
 from ..engine import Context, DeviceArray, Vec
-from .forms import (DerivativeForm, Form, L2TrackingFunctional, NonlinearPoissonResidual, PoissonResidual,
-                    derivative)
+from .forms import (DerivativeForm, FieldExpression, Form, FunctionExpr, GradientMagnitude,
+                    L2TrackingFunctional, NonlinearPoissonResidual, PoissonResidual, PowerExpr, derivative)
 from .function import Function, FunctionSpace, _VectorView
 from .mesh import (Mesh, createUnitCubeMesh, createUnitSquareMesh, locate_dofs_geometrical)
 
@@ -588,6 +588,73 @@ def solveNonlinear(res, func, bc, solver, report, initialize):
     stop = default_timer()
     if report is True:
         print("Solve nonlinear finished in ", stop - start, "seconds")
+
+
+# ---------------------------------------------------------------- projection ----
+def _cell_values(expr: FieldExpression, mesh: Mesh) -> Optional[Vec]:
+    """DG0 values of a cell-wise constant expression, or None for a CG1 Function."""
+    ctx = get_context()
+    dm = mesh.device(ctx)
+    if isinstance(expr, FunctionExpr):
+        return expr.fn.vec if expr.fn.function_space.family == "DG" else None
+    out = _work(mesh, "proj_cells", lambda: Vec(ctx, mesh.n_cell))
+    if isinstance(expr, GradientMagnitude):
+        return E.cell_expression(dm, 0, None, expr.fn.vec, out)
+    if isinstance(expr, PowerExpr):
+        return E.cell_expression(dm, 1, [expr.p], expr.fn.vec, out)
+    raise NotImplementedError(f"project: {type(expr).__name__} is not in the form catalogue")
+
+
+def project(v, target_func: Function, bcs=[], lump_mass=False):
+    """utils_dolfinx.py:549-583: L2 projection onto the (CG1) space of ``target_func``.
+    b_i = int v phi_i; lump_mass: x = b / (M 1); else solve M x = b (the reference uses PETSc's
+    default KSP, rtol 1e-5 [ext]; here Jacobi-CG at the KSP_OPTIONS tolerance)."""
+    if isinstance(v, Function):
+        v = FunctionExpr(v)
+    if not isinstance(v, FieldExpression):
+        raise NotImplementedError(f"project: {type(v).__name__} is not in the form catalogue")
+    if bcs:
+        raise NotImplementedError("project with Dirichlet conditions")
+    V = target_func.function_space
+    if V.family != "CG":
+        raise NotImplementedError("project onto a space other than CG1")
+    mesh = V.mesh
+    ctx = get_context()
+    dm = mesh.device(ctx)
+    n = mesh.n_vert
+    b = _work(mesh, "proj_b", lambda: Vec(ctx, n))
+    load = _work(mesh, "proj_load", lambda: CellMatrix(mesh))       # -(int_c phi_a) per (cell, a)
+    E.assemble_dRdf(dm, _lib.PDE_POISSON, None, None, None, load.vals)
+    cells = _cell_values(v, mesh)
+    M = None
+    if cells is not None:
+        load.mult(cells, b)                                          # b = -(sum_c w_c |T_c|/(d+1))
+        sign = -1.0
+    else:
+        M = _work(mesh, "proj_M", lambda: SparseMatrix(mesh, symmetric=True))
+        E.assemble_jacobian(dm, _lib.PDE_MASS, None, None, None, None, M.mat)
+        M.mult(v.fn.vec, b)
+        sign = 1.0
+    if lump_mass:
+        ones = _work(mesh, "proj_ones", lambda: Vec(ctx, mesh.n_cell)).fill(1.0)
+        lumped = _work(mesh, "proj_lumped", lambda: Vec(ctx, n))
+        load.mult(ones, lumped)                                      # -(M 1)
+        E.pointwise_divide(target_func.vec, b, lumped, dm.n_rows)    # (sign b') / (-(M 1)) handled below
+        if sign > 0:                                                 # b = +M v: flip (lumped carries a minus)
+            tmp = _work(mesh, "proj_tmp", lambda: Vec(ctx, n)).fill(0.0)
+            tmp.axpy(-1.0, target_func.vec)
+            target_func.vec.copy_from(tmp)
+    else:
+        if M is None:
+            M = _work(mesh, "proj_M", lambda: SparseMatrix(mesh, symmetric=True))
+            E.assemble_jacobian(dm, _lib.PDE_MASS, None, None, None, None, M.mat)
+        if sign < 0:
+            rhs = _work(mesh, "proj_tmp", lambda: Vec(ctx, n)).fill(0.0)
+            rhs.axpy(-1.0, b)
+        else:
+            rhs = b
+        KSP(M).solve(rhs, target_func.vec)
+    target_func.version += 1
 
 
 # --------------------------------------------------------------------- norms ----

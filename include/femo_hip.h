@@ -43,7 +43,8 @@ typedef struct femo_mat  femo_mat;   /* N x N sparse matrix on the mesh pattern 
 /* closed catalogue of residual forms (UFL is not available) */
 enum femo_pde_kind {
   FEMO_PDE_POISSON = 0,       /* examples/poisson_opt/run_poisson_opt.py:32-38            */
-  FEMO_PDE_NL_POISSON = 1     /* examples/nonlinear_poisson_opt/...py:88-96 (interior)    */
+  FEMO_PDE_NL_POISSON = 1,    /* examples/nonlinear_poisson_opt/...py:88-125              */
+  FEMO_PDE_MASS = 2           /* inner(Pv, w) dx, matrix only (utils_dolfinx.py:567-572)  */
 };
 
 /* closed catalogue of scalar output forms */
@@ -201,6 +202,13 @@ int femo_functional_grad_u(femo_mesh* mesh, int kind, const double* params,
 int femo_functional_grad_f(femo_mesh* mesh, int kind, const double* params,
                            const femo_vec* u, const femo_vec* f, const femo_vec* u_d,
                            femo_vec* g);
+
+/* ---- DG0 field expressions for projected outputs (fea_dolfinx.py:148-161) --------
+ * kind 0: out_c = |grad in| (in: CG1, n_vert);  kind 1: out_c = in_c ** params[0] (in: DG0). */
+int femo_cell_expression(femo_mesh* mesh, int kind, const double* params,
+                         const femo_vec* in, femo_vec* out);
+/* y_i = x_i / d_i  (Vec.pointwiseDivide, utils_dolfinx.py:566)                       */
+int femo_vec_pointwise_divide(femo_vec* y, const femo_vec* x, const femo_vec* d, int64_t n);
 
 /* ---- measurement helper ------------------------------------------------------
  * Launches `reps` SpMVs of A on x bracketed by HIP events on the ctx stream and

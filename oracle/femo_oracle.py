@@ -603,3 +603,30 @@ def nl_reference_cycle(mesh: OMesh, f: np.ndarray, u_ex: np.ndarray, bmask: np.n
     lam = spla.splu(A.T.tocsc()).solve(dJdu)
     grad = functional_df(mesh, f, alpha) - dRdf(mesh).T @ lam
     return dict(u=u, J=np.array([J]), grad=grad, lam=lam, newton_its=info.newton_its)
+
+
+# --------------------------------------------------------------------------
+# L2 projection onto CG1 (utils_dolfinx.py:549-583), field outputs (fea_dolfinx.py:148-161)
+# --------------------------------------------------------------------------
+def mass_matrix(mesh: OMesh) -> sp.csr_matrix:
+    vol, _ = cell_geometry(mesh)
+    d1 = mesh.tdim + 1
+    Me = (vol / (d1 * (d1 + 1)))[:, None, None] * (np.ones((d1, d1)) + np.eye(d1))[None]
+    r = np.repeat(mesh.conn[:, :, None], d1, axis=2)
+    c = np.repeat(mesh.conn[:, None, :], d1, axis=1)
+    return _scatter_matrix(mesh, Me, mesh.n_vert, mesh.n_vert, r, c)
+
+
+def project_l2(mesh: OMesh, cell_values: Optional[np.ndarray] = None, nodal_values: Optional[np.ndarray] = None,
+               lump_mass: bool = False) -> np.ndarray:
+    M = mass_matrix(mesh)
+    b = load_vector(mesh, cell_values) if cell_values is not None else M @ nodal_values
+    if lump_mass:
+        return b / (M @ np.ones(mesh.n_vert))
+    return spla.splu(M.tocsc()).solve(b)
+
+
+def grad_magnitude(mesh: OMesh, u: np.ndarray) -> np.ndarray:
+    _, g = cell_geometry(mesh)
+    gu = np.einsum("cbd,cb->cd", g, u[mesh.conn])
+    return np.sqrt((gu ** 2).sum(axis=1))
