@@ -31,6 +31,20 @@ namespace {
 // NP pair-steps of one row, fully unrolled: all value/column loads are issued
 // before the first gather, all gathers before the first FMA, so one slice costs
 // two memory round trips whatever its width.  Summation order is k = 0, 1, 2, ...
+// 16-B / 8-B native vectors so that the nontemporal builtin emits ONE global_load_dwordx4 / x2
+// per lane (on HIP's struct double2 it splits into two 8-B loads: half the access width)
+typedef double femo_v2d __attribute__((ext_vector_type(2)));
+typedef int femo_v2i __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double2 nt_load2(const double2* p) {
+  const femo_v2d v = __builtin_nontemporal_load(reinterpret_cast<const femo_v2d*>(p));
+  return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ int2 nt_load2(const int2* p) {
+  const femo_v2i v = __builtin_nontemporal_load(reinterpret_cast<const femo_v2i*>(p));
+  return make_int2(v.x, v.y);
+}
+
 template <int NP, bool NT>
 __device__ __forceinline__ double row_pairs(const double2* __restrict__ v2, const int2* __restrict__ c2,
                                             const double* __restrict__ x, double acc) {
@@ -39,10 +53,8 @@ __device__ __forceinline__ double row_pairs(const double2* __restrict__ v2, cons
 #pragma unroll
   for (int m = 0; m < NP; ++m) {
     if (NT) {
-      a[m].x = __builtin_nontemporal_load(&v2[m * 64].x);
-      a[m].y = __builtin_nontemporal_load(&v2[m * 64].y);
-      j[m].x = __builtin_nontemporal_load(&c2[m * 64].x);
-      j[m].y = __builtin_nontemporal_load(&c2[m * 64].y);
+      a[m] = nt_load2(&v2[m * 64]);
+      j[m] = nt_load2(&c2[m * 64]);
     } else {
       a[m] = v2[m * 64];
       j[m] = c2[m * 64];
@@ -90,8 +102,7 @@ __device__ __forceinline__ double row_pairs_regular(const double2* __restrict__ 
   double2 a[NP];
 #pragma unroll
   for (int m = 0; m < NP; ++m) {
-    a[m].x = __builtin_nontemporal_load(&v2[m * 64].x);
-    a[m].y = __builtin_nontemporal_load(&v2[m * 64].y);
+    a[m] = nt_load2(&v2[m * 64]);
   }
   double xv[2 * NP];
 #pragma unroll
@@ -136,7 +147,9 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_spmv_sell(
   if (done != nullptr && *done) return;
   __shared__ double lds[FEMO_BLOCK / 64];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  // wave-uniform by construction: tell the compiler, so that slice metadata (offsets, the
+  // per-slice delta table) comes through scalar loads instead of 64 identical vector loads
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // XCD-aware: blockIdx % 8 labels the XCD group; each group walks its own
   // contiguous eighth of the slices, its waves interleaved slice by slice, so the
   // x window the group gathers from stays in that XCD's L2.
