@@ -130,6 +130,9 @@ int femo_ctx_create(int device_id, void* stream, femo_ctx** out) {
   FEMO_HIP_CHECK(hipHostMalloc(&c->h_scal, (FEMO_NSCAL + 8) * sizeof(double), hipHostMallocDefault));
   FEMO_HIP_CHECK(hipEventCreate(&c->ev0));
   FEMO_HIP_CHECK(hipEventCreate(&c->ev1));
+  FEMO_HIP_CHECK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  FEMO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
+  FEMO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
   c->ev_pool.resize(16);
   for (auto& e : c->ev_pool) FEMO_HIP_CHECK(hipEventCreate(&e));
   *out = c;
@@ -140,7 +143,11 @@ int femo_ctx_destroy(femo_ctx* c) {
   if (!c) return 0;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
+  if (c->comm_stream) hipStreamSynchronize(c->comm_stream);
   if (c->comm) ncclCommDestroy(c->comm);
+  if (c->comm_stream) hipStreamDestroy(c->comm_stream);
+  if (c->ev_main) hipEventDestroy(c->ev_main);
+  if (c->ev_comm) hipEventDestroy(c->ev_comm);
   hipFree(c->d_partials); hipFree(c->d_scal); hipFree(c->d_flags);
   hipFree(c->cg_r); hipFree(c->cg_p); hipFree(c->cg_q); hipFree(c->cg_dinv); hipFree(c->cg_s);
   hipHostFree(c->h_scal);
@@ -268,7 +275,7 @@ int femo_mesh_destroy(femo_mesh* m) {
   hipStreamSynchronize(m->ctx->stream);
   hipFree(m->d_x); hipFree(m->d_conn); hipFree(m->d_vptr); hipFree(m->d_visit_cell);
   hipFree(m->d_visit_slots); hipFree(m->d_mptr); hipFree(m->d_cols); hipFree(m->d_rowlen);
-  hipFree(m->d_sdelta); hipFree(m->d_bfacets); hipFree(m->d_tperm); hipFree(m->d_send_idx); hipFree(m->d_send_buf); hipFree(m->d_scratch);
+  hipFree(m->d_sdelta); hipFree(m->d_bfacets); hipFree(m->d_tperm); hipFree(m->d_send_idx); hipFree(m->d_send_buf); hipFree(m->d_scratch); hipFree(m->d_slices_int); hipFree(m->d_slices_bnd);
   delete m;
   return 0;
 }
@@ -585,8 +592,9 @@ int femo_mesh_set_halo(femo_mesh* m, int n_nbr, const int32_t* nbr, const int64_
                        const int32_t* send_idx, const int64_t* recv_ptr) {
   FEMO_REQUIRE(m && n_nbr >= 0, "bad argument");
   FEMO_REQUIRE(n_nbr == 0 || (nbr && send_ptr && recv_ptr), "null halo plan");
-  hipFree(m->d_send_idx); hipFree(m->d_send_buf);
-  m->d_send_idx = nullptr; m->d_send_buf = nullptr;
+  hipFree(m->d_send_idx); hipFree(m->d_send_buf); hipFree(m->d_slices_int); hipFree(m->d_slices_bnd);
+  m->d_send_idx = nullptr; m->d_send_buf = nullptr; m->d_slices_int = m->d_slices_bnd = nullptr;
+  m->n_int = m->n_bnd = 0;
   m->n_nbr = n_nbr;
   m->nbr.assign(nbr, nbr + n_nbr);
   m->send_ptr.assign(send_ptr, send_ptr + n_nbr + (n_nbr ? 1 : 0));
@@ -603,7 +611,8 @@ int femo_mesh_set_halo(femo_mesh* m, int n_nbr, const int32_t* nbr, const int64_
     FEMO_HIP_CHECK(hipMemcpyAsync(m->d_send_idx, send_idx, ns * sizeof(int32_t), hipMemcpyHostToDevice, m->ctx->stream));
     FEMO_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
   }
-  return 0;
+  // slices without ghost columns can be multiplied while the halo is in flight
+  return femo_mesh_classify_slices(m);
 }
 
 int femo_allreduce_sum(femo_ctx* ctx, double* host_inout, int n) {

@@ -101,6 +101,8 @@ struct femo_ctx {
   std::vector<hipEvent_t> ev_pool;
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
+  hipStream_t comm_stream = nullptr;          // halo exchange overlapped with interior rows
+  hipEvent_t ev_main = nullptr, ev_comm = nullptr;
   int n_cu = 256;
   // CG workspace, grown on demand and reused across solves
   double *cg_r = nullptr, *cg_p = nullptr, *cg_q = nullptr, *cg_dinv = nullptr, *cg_s = nullptr;
@@ -141,6 +143,9 @@ struct femo_mesh {
   int32_t* d_send_idx = nullptr;
   double* d_send_buf = nullptr;
   double* d_scratch = nullptr;  // n_vert doubles, lazily allocated (Dirichlet lifting)
+  // slices without / with ghost columns (set with the halo plan)
+  int32_t* d_slices_int = nullptr; int32_t* d_slices_bnd = nullptr;
+  int64_t n_int = 0, n_bnd = 0;
 };
 
 struct femo_bc {
@@ -218,5 +223,7 @@ int femo_launch_functional_grad_f(femo_mesh* m, int kind, const double* params, 
 int femo_launch_spmv(const femo_mat* A, const double* vals, const double* x, double* y,
                      double* partials /* or null: fused dot(x,y) partials */);
 int femo_spmv_grid(const femo_mesh* m);
+int femo_halo_exchange_on(femo_mesh* m, femo_vec* x, hipStream_t st);
+int femo_mesh_classify_slices(femo_mesh* m);
 int femo_mat_ensure_transpose(femo_mat* A);
 int femo_reduce_to_host(femo_ctx* ctx, int nblocks, int nsums, double* host_out);

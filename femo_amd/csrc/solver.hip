@@ -143,7 +143,8 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_spmv_sell(
     int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ mptr,
     const int32_t* __restrict__ cols, const int32_t* __restrict__ sdelta, int sdelta_stride,
     const double* __restrict__ vals, const double* __restrict__ diag, const double* __restrict__ x,
-    double* __restrict__ y, double* __restrict__ partials, const int32_t* __restrict__ done) {
+    double* __restrict__ y, double* __restrict__ partials, const int32_t* __restrict__ done,
+    const int32_t* __restrict__ slice_list, int64_t n_list) {
   if (done != nullptr && *done) return;
   __shared__ double lds[FEMO_BLOCK / 64];
   const int lane = threadIdx.x & 63;
@@ -156,9 +157,12 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_spmv_sell(
   const int xcd = blockIdx.x & 7;
   const int64_t blk_in_xcd = blockIdx.x >> 3;
   const int64_t waves_per_xcd = (int64_t)(gridDim.x >> 3) * (FEMO_BLOCK / 64);
-  const int64_t s_lo = n_slices * xcd / 8, s_hi = n_slices * (xcd + 1) / 8;
+  // slice_list != null: walk that subset (interior or boundary slices of a partitioned mesh)
+  const int64_t n_walk = slice_list ? n_list : n_slices;
+  const int64_t s_lo = n_walk * xcd / 8, s_hi = n_walk * (xcd + 1) / 8;
   double dot = 0.0, dot2 = 0.0;
-  for (int64_t slice = s_lo + blk_in_xcd * (FEMO_BLOCK / 64) + wave; slice < s_hi; slice += waves_per_xcd) {
+  for (int64_t si = s_lo + blk_in_xcd * (FEMO_BLOCK / 64) + wave; si < s_hi; si += waves_per_xcd) {
+    const int64_t slice = slice_list ? (int64_t)slice_list[si] : si;
     const int64_t base = mptr[slice];
     const int npair = (int)((mptr[slice + 1] - base) >> 7);
     const int64_t row = (slice << 6) + lane;
@@ -476,13 +480,15 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_cgm_update(int64_t n, int it, do
 }
 
 // fold partial slots 0 (delta) and 1 (gamma) into buf[0], buf[1] = scal + 2*parity
-__global__ __launch_bounds__(1024) void k_cgm_fold(int nblocks, const double* __restrict__ partials, double* __restrict__ buf,
-                                                   const int32_t* __restrict__ done) {
+__global__ __launch_bounds__(1024) void k_cgm_fold(int nblocks, int nblocks2, const double* __restrict__ partials,
+                                                   double* __restrict__ buf, const int32_t* __restrict__ done) {
   if (*done) return;
   __shared__ double lds[1024 / 64];
   for (int j = 0; j < 2; ++j) {
     double acc = 0.0;
     for (int i = threadIdx.x; i < nblocks; i += 1024) acc += partials[(int64_t)j * FEMO_MAX_PARTIALS + i];
+    // second launch of an overlapped SpMV (boundary slices): slots 2, 3
+    for (int i = threadIdx.x; i < nblocks2; i += 1024) acc += partials[(int64_t)(j + 2) * FEMO_MAX_PARTIALS + i];
     const double t = femo_block_sum<1024>(acc, lds);
     if (threadIdx.x == 0) buf[j] = t;                // buf = {delta, gamma}, contiguous for one all-reduce
   }
@@ -541,12 +547,17 @@ int femo_spmv_grid(const femo_mesh* m) {
 }
 
 static int launch_spmv(const femo_mat* A, const double* vals, const double* x, double* y,
-                       double* partials, const int32_t* done, bool unit = false, bool dot2 = false) {
+                       double* partials, const int32_t* done, bool unit = false, bool dot2 = false,
+                       const int32_t* slice_list = nullptr, int64_t n_list = 0, hipStream_t stream = nullptr) {
   const femo_mesh* m = A->mesh;
-  if (m->n_slices == 0) return 0;
-  const int g = femo_spmv_grid(m);
-  hipStream_t st = m->ctx->stream;
-#define FEMO_SPMV_ARGS m->n_rows, m->n_slices, m->d_mptr, m->d_cols, m->d_sdelta, m->sdelta_stride, vals, A->d_diag, x, y, partials, done
+  const int64_t n_walk = slice_list ? n_list : m->n_slices;
+  if (n_walk == 0 && !partials) return 0;
+  int64_t g = femo_spmv_grid(m);
+  if (slice_list) {                                  // size the grid for the subset (same rules)
+    g = std::min<int64_t>(g, std::max<int64_t>(8, ((n_walk + 3) / 4 + 7) & ~int64_t(7)));
+  }
+  hipStream_t st = stream ? stream : m->ctx->stream;
+#define FEMO_SPMV_ARGS m->n_rows, m->n_slices, m->d_mptr, m->d_cols, m->d_sdelta, m->sdelta_stride, vals, A->d_diag, x, y, partials, done, slice_list, n_list
   if (partials && unit && dot2) hipLaunchKernelGGL((k_spmv_sell<2, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
   else if (partials && unit) hipLaunchKernelGGL((k_spmv_sell<1, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
   else if (partials) hipLaunchKernelGGL((k_spmv_sell<1, false>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
@@ -554,6 +565,37 @@ static int launch_spmv(const femo_mat* A, const double* vals, const double* x, d
   else hipLaunchKernelGGL((k_spmv_sell<0, false>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
 #undef FEMO_SPMV_ARGS
   FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// Ghost refresh of x overlapped with the interior rows of y = A x (nranks > 1):
+//   comm stream : pack + grouped ncclSend/ncclRecv into the ghost tail of x
+//   main stream : SpMV over the slices without ghost columns, then (after the halo
+//                 event) over the slices that read ghosts.
+// Partials (if requested) land in slot pairs: interior at `partials`, boundary at
+// `partials + 2*FEMO_MAX_PARTIALS`; *g_int / *g_bnd return the block counts to fold.
+static int halo_spmv_overlapped(const femo_mat* A, const double* vals, double* x, double* y, double* partials,
+                                const int32_t* done, bool unit, bool dot2, int* g_int, int* g_bnd) {
+  femo_mesh* m = A->mesh;
+  femo_ctx* ctx = m->ctx;
+  hipStream_t st = ctx->stream, cs = ctx->comm_stream;
+  FEMO_HIP_CHECK(hipEventRecord(ctx->ev_main, st));
+  FEMO_HIP_CHECK(hipStreamWaitEvent(cs, ctx->ev_main, 0));
+  {
+    femo_vec v; v.ctx = ctx; v.d = x; v.n = m->n_vert; v.owned = false;
+    FEMO_TRY(femo_halo_exchange_on(m, &v, cs));
+  }
+  FEMO_HIP_CHECK(hipEventRecord(ctx->ev_comm, cs));
+  auto grid_of = [&](int64_t n_walk) {
+    int64_t g = femo_spmv_grid(m);
+    return (int)std::min<int64_t>(g, std::max<int64_t>(8, ((n_walk + 3) / 4 + 7) & ~int64_t(7)));
+  };
+  if (g_int) *g_int = grid_of(m->n_int);
+  if (g_bnd) *g_bnd = grid_of(m->n_bnd);
+  FEMO_TRY(launch_spmv(A, vals, x, y, partials, done, unit, dot2, m->d_slices_int, m->n_int, st));
+  FEMO_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_comm, 0));
+  FEMO_TRY(launch_spmv(A, vals, x, y, partials ? partials + 2 * FEMO_MAX_PARTIALS : nullptr, done, unit, dot2,
+                       m->d_slices_bnd, m->n_bnd, st));
   return 0;
 }
 
@@ -591,8 +633,46 @@ int femo_mat_ensure_transpose(femo_mat* A) {
   return 0;
 }
 
+// flag[slice] = 1 if any stored column of the slice is a ghost (>= n_rows)
+__global__ void k_flag_ghost_slices(int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ mptr,
+                                    const int32_t* __restrict__ cols, int32_t* __restrict__ flag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t slice = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (slice >= n_slices) return;
+  const int64_t base = mptr[slice];
+  const int wm = (int)((mptr[slice + 1] - base) >> 6);
+  int any = 0;
+  for (int k = 0; k < wm; ++k) any |= cols[femo_sell_index(base, k, lane)] >= n_rows;   // padding = own row < n_rows
+  const unsigned long long b = __ballot(any);
+  if (lane == 0) flag[slice] = b != 0ull;
+}
+
+int femo_mesh_classify_slices(femo_mesh* m) {
+  femo_ctx* ctx = m->ctx;
+  hipFree(m->d_slices_int); hipFree(m->d_slices_bnd);
+  m->d_slices_int = m->d_slices_bnd = nullptr;
+  m->n_int = m->n_bnd = 0;
+  if (m->n_slices == 0) return 0;
+  int32_t* d_flag = nullptr;
+  FEMO_HIP_CHECK(hipMalloc(&d_flag, m->n_slices * sizeof(int32_t)));
+  hipLaunchKernelGGL(k_flag_ghost_slices, dim3((unsigned)((m->n_slices + 3) / 4)), dim3(256), 0, ctx->stream, m->n_rows, m->n_slices, m->d_mptr, m->d_cols, d_flag);
+  FEMO_HIP_CHECK(hipGetLastError());
+  std::vector<int32_t> flag(m->n_slices), li, lb;
+  FEMO_HIP_CHECK(hipMemcpyAsync(flag.data(), d_flag, m->n_slices * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  FEMO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  hipFree(d_flag);
+  for (int64_t s = 0; s < m->n_slices; ++s) (flag[s] ? lb : li).push_back((int32_t)s);
+  m->n_int = (int64_t)li.size(); m->n_bnd = (int64_t)lb.size();
+  FEMO_HIP_CHECK(hipMalloc(&m->d_slices_int, std::max<size_t>(li.size(), 1) * sizeof(int32_t)));
+  FEMO_HIP_CHECK(hipMalloc(&m->d_slices_bnd, std::max<size_t>(lb.size(), 1) * sizeof(int32_t)));
+  if (!li.empty()) FEMO_HIP_CHECK(hipMemcpyAsync(m->d_slices_int, li.data(), li.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  if (!lb.empty()) FEMO_HIP_CHECK(hipMemcpyAsync(m->d_slices_bnd, lb.data(), lb.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  FEMO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
 // ---------------------------------------------------------------- halo ------
-extern "C" int femo_halo_exchange(femo_mesh* m, femo_vec* x) {
+int femo_halo_exchange_on(femo_mesh* m, femo_vec* x, hipStream_t st) {
   FEMO_REQUIRE(m && x, "null argument");
   if (m->n_nbr == 0) return 0;
   femo_ctx* ctx = m->ctx;
@@ -600,18 +680,23 @@ extern "C" int femo_halo_exchange(femo_mesh* m, femo_vec* x) {
   FEMO_REQUIRE(x->n >= m->n_vert, "vector shorter than n_vert");
   const int64_t ns = m->send_ptr[m->n_nbr];
   if (ns > 0) {
-    hipLaunchKernelGGL(k_pack, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, ns, m->d_send_idx, x->d, m->d_send_buf);
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, ns, m->d_send_idx, x->d, m->d_send_buf);
     FEMO_HIP_CHECK(hipGetLastError());
   }
   FEMO_NCCL_CHECK(ncclGroupStart());
   for (int k = 0; k < m->n_nbr; ++k) {
     const int64_t sc = m->send_ptr[k + 1] - m->send_ptr[k];
     const int64_t rc = m->recv_ptr[k + 1] - m->recv_ptr[k];
-    if (sc > 0) FEMO_NCCL_CHECK(ncclSend(m->d_send_buf + m->send_ptr[k], sc, ncclDouble, m->nbr[k], ctx->comm, ctx->stream));
-    if (rc > 0) FEMO_NCCL_CHECK(ncclRecv(x->d + m->n_rows + m->recv_ptr[k], rc, ncclDouble, m->nbr[k], ctx->comm, ctx->stream));
+    if (sc > 0) FEMO_NCCL_CHECK(ncclSend(m->d_send_buf + m->send_ptr[k], sc, ncclDouble, m->nbr[k], ctx->comm, st));
+    if (rc > 0) FEMO_NCCL_CHECK(ncclRecv(x->d + m->n_rows + m->recv_ptr[k], rc, ncclDouble, m->nbr[k], ctx->comm, st));
   }
   FEMO_NCCL_CHECK(ncclGroupEnd());
   return 0;
+}
+
+extern "C" int femo_halo_exchange(femo_mesh* m, femo_vec* x) {
+  FEMO_REQUIRE(m && x, "null argument");
+  return femo_halo_exchange_on(m, x, m->ctx->stream);
 }
 
 static int halo_raw(femo_mesh* m, double* x) {
@@ -631,6 +716,8 @@ extern "C" int femo_mat_spmv(const femo_mat* A, int transpose, const femo_vec* x
     FEMO_TRY(femo_mat_ensure_transpose(const_cast<femo_mat*>(A)));
     vals = A->d_valsT;
   }
+  if (m->n_nbr > 0 && m->d_slices_int != nullptr)
+    return halo_spmv_overlapped(A, vals, x->d, y->d, nullptr, nullptr, false, false, nullptr, nullptr);
   if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, x->d));
   return launch_spmv(A, vals, x->d, y->d, nullptr, nullptr);
 }
@@ -797,11 +884,16 @@ extern "C" int femo_solve_cg(const femo_mat* A_, int transpose, const femo_vec* 
   int n_ev = 0;
   // w = Ah r with both dots, folded and all-reduced into the (delta, gamma) pair of `parity`
   auto merged_spmv = [&](int parity, bool sample) -> int {
-    if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, w.r));
+    int g1 = gs, g2 = 0;
     if (sample) FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev], st));
-    FEMO_TRY(launch_spmv(A, A->d_valsS, w.r, w.q, P, ctx->d_flags, true, true));
+    if (m->n_nbr > 0 && m->d_slices_int != nullptr) {
+      FEMO_TRY(halo_spmv_overlapped(A, A->d_valsS, w.r, w.q, P, ctx->d_flags, true, true, &g1, &g2));
+    } else {
+      if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, w.r));
+      FEMO_TRY(launch_spmv(A, A->d_valsS, w.r, w.q, P, ctx->d_flags, true, true));
+    }
     if (sample) { FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev + 1], st)); ++n_ev; }
-    hipLaunchKernelGGL(k_cgm_fold, dim3(1), dim3(1024), 0, st, gs, P, ctx->d_scal + 2 * parity, ctx->d_flags);
+    hipLaunchKernelGGL(k_cgm_fold, dim3(1), dim3(1024), 0, st, g1, g2, P, ctx->d_scal + 2 * parity, ctx->d_flags);
     FEMO_NCCL_CHECK(ncclAllReduce(ctx->d_scal + 2 * parity, ctx->d_scal + 2 * parity, 2, ncclDouble, ncclSum, ctx->comm, st));
     return 0;
   };

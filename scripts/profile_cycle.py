@@ -26,7 +26,7 @@ def wrap(mod, name):
         e = acc.setdefault(name, [0, 0.0]); e[0] += 1; e[1] += d
         return r
     setattr(mod, name, w)
-for name in ["assemble_residual", "assemble_jacobian", "assemble_dRdf", "newton_rhs", "dRdf_apply",
+for name in ["assemble_residual", "assemble_jacobian", "assemble_system", "assemble_dRdf", "newton_rhs", "dRdf_apply",
              "functional_value", "functional_grad_u", "functional_grad_f"]:
     wrap(E, name)
 for cls, name in [(E.Mat, "solve_cg"), (E.Mat, "mult"), (E.Vec, "__init__"), (E.Vec, "dot"), (E.Vec, "axpy"),
