@@ -43,6 +43,8 @@ def parse():
     p.add_argument("--steps", type=int, default=3)
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--mesh-n", dest="n", type=int, default=215, help="cube resolution (215 -> 10,077,696 DOFs)")
+    p.add_argument("--jitter", type=float, default=0.0,
+                   help="interior vertex jitter in units of h (SURVEY.md 8(d): 0.2); default: structured grid")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-n", type=int, default=128, help="cube resolution of the bounded CPU sample")
     p.add_argument("--no-pcie", action="store_true")
@@ -192,7 +194,7 @@ def main():
     ctx = Context(local_rank)
     utils_hip.set_context(ctx)
     t0 = time.perf_counter()
-    mesh = createUnitCubeMesh(args.n)
+    mesh = createUnitCubeMesh(args.n, jitter=args.jitter)
     sim, fea = build_problem(mesh, device=True)
     dm = mesh.device(ctx)
     n_dof, nnz = mesh.n_vert, dm.info["nnz"]
@@ -245,7 +247,7 @@ def main():
             "workload": (f"3-D linear Poisson, P1 tets, unit cube n={args.n}: {n_dof} DOFs, {mesh.n_cell} cells, "
                          f"nnz {nnz}; per step: Newton x3 (assemble R, dR/du, A; Jacobi-CG) + J + dJ/du, dJ/df + "
                          f"dR/du, dR/df, A + transposed Jacobi-CG + dR/df^T lambda; CG rtol 1e-14; cold start"),
-            "n": args.n, "n_dof": n_dof, "n_cell": mesh.n_cell, "nnz": nnz,
+            "n": args.n, "jitter": args.jitter, "n_dof": n_dof, "n_cell": mesh.n_cell, "nnz": nnz,
             "sell_slices": dm.info["n_slices"], "regular_slices": dm.info["regular_slices"],
             "cg_iterations_per_step": its_per_step, "cg_ms_per_step": cg_ms,
             "non_cg_ms_per_step": ms_per_step - cg_ms, "setup_s": setup_s,

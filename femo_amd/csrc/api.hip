@@ -149,7 +149,7 @@ int femo_ctx_destroy(femo_ctx* c) {
   if (c->ev_main) hipEventDestroy(c->ev_main);
   if (c->ev_comm) hipEventDestroy(c->ev_comm);
   hipFree(c->d_partials); hipFree(c->d_scal); hipFree(c->d_flags);
-  hipFree(c->cg_r); hipFree(c->cg_p); hipFree(c->cg_q); hipFree(c->cg_dinv); hipFree(c->cg_s);
+  hipFree(c->cg_r); hipFree(c->cg_p); hipFree(c->cg_q); hipFree(c->cg_dinv); hipFree(c->cg_s); hipFree(c->cg_t); hipFree(c->cg_r0);
   hipHostFree(c->h_scal);
   hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
   for (auto& e : c->ev_pool) hipEventDestroy(e);

@@ -144,7 +144,7 @@ __device__ __forceinline__ double cell_diameter(const double* __restrict__ x, co
 template <int D, bool WANT_J, bool WANT_R>
 __device__ __forceinline__ void nl_row(const CellGeom<D>& G, int a, const double w[D + 1], const double ue[D + 1],
                                        const double* __restrict__ x, const int32_t v[D + 1],
-                                       const double* __restrict__ aux, unsigned bits, double beta,
+                                       const double* __restrict__ aux, unsigned bits, double beta, double sgn,
                                        double krow[D + 1], double* res) {
   constexpr double coef = (D == 2) ? 1.0 / 360.0 : 1.0 / 840.0;   // D!/(D+4)!
   double s1 = 0.0, s2 = 0.0, s3 = 0.0, ua = 0.0;
@@ -190,12 +190,12 @@ __device__ __forceinline__ void nl_row(const CellGeom<D>& G, int a, const double
     }
     const double a_on = 1.0 - w[k];                    // 1 if a is a vertex of the facet
     const double pen = beta / hE * meas * (1.0 / (D * (D + 1)));
-    if (WANT_R) *res += gna * (-(son * (1.0 / D))) * meas + a_on * (-dun * meas * (1.0 / D) + pen * (ea + son));
+    if (WANT_R) *res += sgn * gna * (-(son * (1.0 / D))) * meas + a_on * (-dun * meas * (1.0 / D) + pen * (ea + son));
     if (WANT_J) {
 #pragma unroll
       for (int b = 0; b <= D; ++b) {
         double t = a_on * (-gn[b] * meas * (1.0 / D));
-        if (b != k) t += -gna * meas * (1.0 / D) + a_on * pen * (1.0 + w[b]);
+        if (b != k) t += -sgn * gna * meas * (1.0 / D) + a_on * pen * (1.0 + w[b]);
         krow[b] += t;
       }
     }
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_residual(
     int64_t n_rows, int64_t n_blocks, const int64_t* __restrict__ vptr,
     const int32_t* __restrict__ visit_cell, const int32_t* __restrict__ conn,
     const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ f,
-    const double* __restrict__ aux, const uint8_t* __restrict__ bfacets, double beta,
+    const double* __restrict__ aux, const uint8_t* __restrict__ bfacets, double beta, double sgn,
     double* __restrict__ r) {
   const int64_t blk = femo_xcd_block(blockIdx.x, n_blocks);
   const int64_t row = blk * FEMO_BLOCK + threadIdx.x;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_residual(
 #pragma unroll
       for (int b = 0; b <= D; ++b) w[b] = (a == b) ? 1.0 : 0.0;
       const unsigned bits = bfacets ? bfacets[c] : 0u;
-      nl_row<D, false, true>(G, a, w, ue, x, v, aux, bits, beta, dummy, &acc);
+      nl_row<D, false, true>(G, a, w, ue, x, v, aux, bits, beta, sgn, dummy, &acc);
     }
   }
   if (row < n_rows) r[row] = acc;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
     const int64_t* __restrict__ mptr, const int32_t* __restrict__ cols,
     const int32_t* __restrict__ rowlen, const int32_t* __restrict__ conn,
     const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ f,
-    const double* __restrict__ aux, const uint8_t* __restrict__ bfacets, double beta,
+    const double* __restrict__ aux, const uint8_t* __restrict__ bfacets, double beta, double sgn,
     const uint8_t* __restrict__ bcmask, const double* __restrict__ bcval,
     double* __restrict__ diag0, double* __restrict__ vals0, double* __restrict__ diag1,
     double* __restrict__ vals1, double* __restrict__ rhs) {
@@ -316,8 +316,8 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
         ue[b] = u[v[b]];
       }
       const unsigned bits = bfacets ? bfacets[c] : 0u;
-      if (want_rhs) nl_row<D, true, true>(G, a, w, ue, x, v, aux, bits, beta, krow, &racc);
-      else nl_row<D, true, false>(G, a, w, ue, x, v, aux, bits, beta, krow, &racc);
+      if (want_rhs) nl_row<D, true, true>(G, a, w, ue, x, v, aux, bits, beta, sgn, krow, &racc);
+      else nl_row<D, true, false>(G, a, w, ue, x, v, aux, bits, beta, sgn, krow, &racc);
     }
 #pragma unroll
     for (int b = 0; b <= D; ++b) {
@@ -578,21 +578,22 @@ int femo_launch_residual(femo_mesh* m, int pde, const double* params, const doub
   if (nb == 0) return 0;
   hipStream_t st = m->ctx->stream;
   const double beta = params ? params[0] : 0.0;
+  const double sgn = (params && params[1] != 0.0) ? params[1] : 1.0;
   if (pde == FEMO_PDE_NL_POISSON)
-    FEMO_LAUNCH_DP(m, k_residual, FEMO_PDE_NL_POISSON, nb, 0, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_conn, m->d_x, u, f, aux, m->d_bfacets, beta, r);
+    FEMO_LAUNCH_DP(m, k_residual, FEMO_PDE_NL_POISSON, nb, 0, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_conn, m->d_x, u, f, aux, m->d_bfacets, beta, sgn, r);
   else
-    FEMO_LAUNCH_DP(m, k_residual, FEMO_PDE_POISSON, nb, 0, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_conn, m->d_x, u, f, aux, m->d_bfacets, beta, r);
+    FEMO_LAUNCH_DP(m, k_residual, FEMO_PDE_POISSON, nb, 0, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_conn, m->d_x, u, f, aux, m->d_bfacets, beta, sgn, r);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 template <int D, int PDE>
 static int launch_system_t(femo_mesh* m, int64_t nb, size_t lds, const double* u, const double* f, const double* aux,
-                           double beta, const uint8_t* bcmask, const double* bcval, double* diag0, double* vals0,
+                           double beta, double sgn, const uint8_t* bcmask, const double* bcval, double* diag0, double* vals0,
                            double* diag1, double* vals1, double* rhs) {
   auto k = k_jacobian<D, PDE>;
   if (lds > 64 * 1024) FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k, dim3(nb), dim3(FEMO_BLOCK), lds, m->ctx->stream, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_visit_slots, m->d_mptr, m->d_cols, m->d_rowlen, m->d_conn, m->d_x, u, f, aux, m->d_bfacets, beta, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
+  hipLaunchKernelGGL(k, dim3(nb), dim3(FEMO_BLOCK), lds, m->ctx->stream, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_visit_slots, m->d_mptr, m->d_cols, m->d_rowlen, m->d_conn, m->d_x, u, f, aux, m->d_bfacets, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -610,17 +611,18 @@ int femo_launch_system(femo_mesh* m, int pde, const double* params, const double
   const size_t lds = (size_t)cap * FEMO_BLOCK * sizeof(double);
   FEMO_REQUIRE(lds <= 160 * 1024, "row length %d exceeds the LDS strip capacity", m->max_rowlen);
   const double beta = params ? params[0] : 0.0;
+  const double sgn = (params && params[1] != 0.0) ? params[1] : 1.0;
   if (pde == FEMO_PDE_MASS) {
     FEMO_REQUIRE(rhs == nullptr, "the mass form has no residual");
-    if (m->tdim == 3) return launch_system_t<3, FEMO_PDE_MASS>(m, nb, lds, u, f, aux, beta, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
-    return launch_system_t<2, FEMO_PDE_MASS>(m, nb, lds, u, f, aux, beta, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
+    if (m->tdim == 3) return launch_system_t<3, FEMO_PDE_MASS>(m, nb, lds, u, f, aux, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
+    return launch_system_t<2, FEMO_PDE_MASS>(m, nb, lds, u, f, aux, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
   }
   if (m->tdim == 3) {
-    if (pde == FEMO_PDE_NL_POISSON) return launch_system_t<3, FEMO_PDE_NL_POISSON>(m, nb, lds, u, f, aux, beta, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
-    return launch_system_t<3, FEMO_PDE_POISSON>(m, nb, lds, u, f, aux, beta, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
+    if (pde == FEMO_PDE_NL_POISSON) return launch_system_t<3, FEMO_PDE_NL_POISSON>(m, nb, lds, u, f, aux, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
+    return launch_system_t<3, FEMO_PDE_POISSON>(m, nb, lds, u, f, aux, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
   }
-  if (pde == FEMO_PDE_NL_POISSON) return launch_system_t<2, FEMO_PDE_NL_POISSON>(m, nb, lds, u, f, aux, beta, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
-  return launch_system_t<2, FEMO_PDE_POISSON>(m, nb, lds, u, f, aux, beta, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
+  if (pde == FEMO_PDE_NL_POISSON) return launch_system_t<2, FEMO_PDE_NL_POISSON>(m, nb, lds, u, f, aux, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
+  return launch_system_t<2, FEMO_PDE_POISSON>(m, nb, lds, u, f, aux, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
 }
 
 int femo_launch_dRdf(femo_mesh* m, int pde, const double* params, const double* u,

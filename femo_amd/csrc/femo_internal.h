@@ -106,6 +106,7 @@ struct femo_ctx {
   int n_cu = 256;
   // CG workspace, grown on demand and reused across solves
   double *cg_r = nullptr, *cg_p = nullptr, *cg_q = nullptr, *cg_dinv = nullptr, *cg_s = nullptr;
+  double *cg_t = nullptr, *cg_r0 = nullptr;
   int64_t cg_n = 0;
 };
 

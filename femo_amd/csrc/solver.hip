@@ -137,14 +137,15 @@ __device__ __forceinline__ double row_sum_regular(int npair, const double2* __re
   }
 }
 
-// DOT: 0 none; 1 partial x.Ax into partials[block]; 2 additionally partial x.x into the next slot
+// DOT: 0 none; 1 partial d.Ax into partials[block] (d = dvec or x); 2 additionally partial x.x,
+// 3 additionally partial Ax.Ax, into the next slot
 template <int DOT, bool UNIT>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_spmv_sell(
     int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ mptr,
     const int32_t* __restrict__ cols, const int32_t* __restrict__ sdelta, int sdelta_stride,
     const double* __restrict__ vals, const double* __restrict__ diag, const double* __restrict__ x,
     double* __restrict__ y, double* __restrict__ partials, const int32_t* __restrict__ done,
-    const int32_t* __restrict__ slice_list, int64_t n_list) {
+    const int32_t* __restrict__ slice_list, int64_t n_list, const double* __restrict__ dvec) {
   if (done != nullptr && *done) return;
   __shared__ double lds[FEMO_BLOCK / 64];
   const int lane = threadIdx.x & 63;
@@ -178,15 +179,16 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_spmv_sell(
     }
     if (row < n_rows) {
       y[row] = acc;
-      if (DOT) dot += acc * xr;
+      if (DOT) dot += acc * (dvec ? dvec[row] : xr);
       if (DOT == 2) dot2 += xr * xr;
+      if (DOT == 3) dot2 += acc * acc;
     }
   }
   if (DOT) {
     const double s = femo_block_sum<FEMO_BLOCK>(dot, lds);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
   }
-  if (DOT == 2) {
+  if (DOT >= 2) {
     const double s = femo_block_sum<FEMO_BLOCK>(dot2, lds);
     if (threadIdx.x == 0) partials[FEMO_MAX_PARTIALS + blockIdx.x] = s;
   }
@@ -494,6 +496,114 @@ __global__ __launch_bounds__(1024) void k_cgm_fold(int nblocks, int nblocks2, co
   }
 }
 
+// ---- BiCGSTAB on the scaled system (non-symmetric operators) --------------------------
+// van der Vorst's recurrence; S A S keeps a unit diagonal, i.e. Jacobi preconditioning.
+// Scalars live in scal[]; producers write partials, a one-block fold (plus all-reduce when
+// nranks > 1) sits between producer and consumer.  Not the headline path: kept simple.
+constexpr int B_RHO = 0, B_RHO_OLD = 1, B_ALPHA = 2, B_OMEGA = 3, B_R0V = 4, B_TS = 5, B_TT = 6, B_RR = 7, B_TOL2 = 8;
+
+__global__ __launch_bounds__(FEMO_BLOCK) void k_bi_init(int64_t n, const double* __restrict__ b, const double* __restrict__ q,
+                                                        const double* __restrict__ s, double* __restrict__ r, double* __restrict__ r0,
+                                                        double* __restrict__ p, double* __restrict__ v, double* __restrict__ xh,
+                                                        double* __restrict__ partials) {
+  __shared__ double lds[FEMO_BLOCK / 64];
+  double s0 = 0.0, s1 = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FEMO_BLOCK) {
+    const double si = s[i], bi = si * b[i];
+    const double ri = q ? si * (b[i] - q[i]) : bi;
+    r[i] = ri; r0[i] = ri; p[i] = 0.0; v[i] = 0.0; xh[i] = 0.0;
+    s0 += ri * ri; s1 += bi * bi;
+  }
+  double t = femo_block_sum<FEMO_BLOCK>(s0, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  t = femo_block_sum<FEMO_BLOCK>(s1, lds);
+  if (threadIdx.x == 0) partials[FEMO_MAX_PARTIALS + blockIdx.x] = t;
+}
+
+// fold `nsums` consecutive partial slots into scal[dst .. dst+nsums)
+__global__ __launch_bounds__(1024) void k_bi_fold(int nblocks, int nsums, const double* __restrict__ partials, double* __restrict__ dst,
+                                                  const int32_t* __restrict__ done) {
+  if (*done) return;
+  __shared__ double lds[1024 / 64];
+  for (int j = 0; j < nsums; ++j) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 1024) acc += partials[(int64_t)j * FEMO_MAX_PARTIALS + i];
+    const double t = femo_block_sum<1024>(acc, lds);
+    if (threadIdx.x == 0) dst[j] = t;
+  }
+}
+
+// convergence test on (rho, rr) after `it` finished iterations (one thread; every later launch sees the flag)
+__global__ void k_bi_check(int it, const double* __restrict__ scal, int32_t* __restrict__ flags) {
+  if (flags[0]) return;
+  const double rho = scal[B_RHO], rr = scal[B_RR];
+  const bool bad = !(rr == rr) || !(rho == rho);
+  if (rr <= scal[B_TOL2] || bad) {
+    flags[1] = it;
+    flags[2] = bad ? 1 : 0;
+    flags[0] = 1;
+  }
+}
+
+// p = r + beta (p - omega v)
+__global__ __launch_bounds__(FEMO_BLOCK) void k_bi_p(int64_t n, int it, const double* __restrict__ scal, const double* __restrict__ r,
+                                                     const double* __restrict__ v, double* __restrict__ p, const int32_t* __restrict__ flags) {
+  if (flags[0]) return;
+  double beta = 0.0, omega = 0.0;
+  if (it > 0) {
+    omega = scal[B_OMEGA];
+    beta = (scal[B_RHO] / scal[B_RHO_OLD]) * (scal[B_ALPHA] / omega);
+  }
+  for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FEMO_BLOCK)
+    p[i] = r[i] + beta * (p[i] - omega * v[i]);
+}
+
+// alpha = rho / (r0, v); s = r - alpha v
+__global__ __launch_bounds__(FEMO_BLOCK) void k_bi_s(int64_t n, double* __restrict__ scal, const double* __restrict__ r,
+                                                     const double* __restrict__ v, double* __restrict__ sv, const int32_t* __restrict__ done) {
+  if (*done) return;
+  const double alpha = scal[B_RHO] / scal[B_R0V];
+  for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FEMO_BLOCK)
+    sv[i] = r[i] - alpha * v[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) scal[B_ALPHA] = alpha;   // not read by this launch
+}
+
+// omega = (t,s)/(t,t); x += alpha p + omega s; r = s - omega t; partials (r0, r), (r, r)
+__global__ __launch_bounds__(FEMO_BLOCK) void k_bi_xr(int64_t n, int it, double* __restrict__ scal, const double* __restrict__ p,
+                                                      const double* __restrict__ sv, const double* __restrict__ t,
+                                                      const double* __restrict__ r0, double* __restrict__ xh, double* __restrict__ r,
+                                                      double* __restrict__ partials, int32_t* __restrict__ flags) {
+  if (flags[0]) return;
+  __shared__ double lds[FEMO_BLOCK / 64];
+  const double tt = scal[B_TT];
+  const double omega = tt != 0.0 ? scal[B_TS] / tt : 0.0;
+  const double alpha = scal[B_ALPHA];
+  double s0 = 0.0, s1 = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FEMO_BLOCK) {
+    const double si = sv[i];
+    xh[i] += alpha * p[i] + omega * si;
+    const double ri = si - omega * t[i];
+    r[i] = ri;
+    s0 += r0[i] * ri; s1 += ri * ri;
+  }
+  double f = femo_block_sum<FEMO_BLOCK>(s0, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = f;
+  f = femo_block_sum<FEMO_BLOCK>(s1, lds);
+  if (threadIdx.x == 0) partials[FEMO_MAX_PARTIALS + blockIdx.x] = f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    scal[B_OMEGA] = omega;               // read by the next launches only
+    scal[B_RHO_OLD] = scal[B_RHO];       // rho of this iteration; B_RHO is overwritten by the next fold
+    flags[1] = it + 1;
+  }
+}
+
+// (rho, rr) of one fold land in buf[0], buf[1]; move them to their scal slots
+__global__ void k_bi_set_rho(const double* __restrict__ buf, double* __restrict__ scal, const int32_t* __restrict__ done) {
+  if (*done) return;
+  scal[B_RHO] = buf[0];
+  scal[B_RR] = buf[1];
+}
+
 // x = (add ? x : 0) + s .* xh
 __global__ void k_unscale(int64_t n, int add, const double* __restrict__ s, const double* __restrict__ xh, double* __restrict__ x) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -548,7 +658,8 @@ int femo_spmv_grid(const femo_mesh* m) {
 
 static int launch_spmv(const femo_mat* A, const double* vals, const double* x, double* y,
                        double* partials, const int32_t* done, bool unit = false, bool dot2 = false,
-                       const int32_t* slice_list = nullptr, int64_t n_list = 0, hipStream_t stream = nullptr) {
+                       const int32_t* slice_list = nullptr, int64_t n_list = 0, hipStream_t stream = nullptr,
+                       const double* dvec = nullptr, bool dot_yy = false) {
   const femo_mesh* m = A->mesh;
   const int64_t n_walk = slice_list ? n_list : m->n_slices;
   if (n_walk == 0 && !partials) return 0;
@@ -557,8 +668,9 @@ static int launch_spmv(const femo_mat* A, const double* vals, const double* x, d
     g = std::min<int64_t>(g, std::max<int64_t>(8, ((n_walk + 3) / 4 + 7) & ~int64_t(7)));
   }
   hipStream_t st = stream ? stream : m->ctx->stream;
-#define FEMO_SPMV_ARGS m->n_rows, m->n_slices, m->d_mptr, m->d_cols, m->d_sdelta, m->sdelta_stride, vals, A->d_diag, x, y, partials, done, slice_list, n_list
-  if (partials && unit && dot2) hipLaunchKernelGGL((k_spmv_sell<2, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
+#define FEMO_SPMV_ARGS m->n_rows, m->n_slices, m->d_mptr, m->d_cols, m->d_sdelta, m->sdelta_stride, vals, A->d_diag, x, y, partials, done, slice_list, n_list, dvec
+  if (partials && unit && dot_yy) hipLaunchKernelGGL((k_spmv_sell<3, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
+  else if (partials && unit && dot2) hipLaunchKernelGGL((k_spmv_sell<2, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
   else if (partials && unit) hipLaunchKernelGGL((k_spmv_sell<1, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
   else if (partials) hipLaunchKernelGGL((k_spmv_sell<1, false>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
   else if (unit) hipLaunchKernelGGL((k_spmv_sell<0, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
@@ -753,14 +865,16 @@ extern "C" int femo_bench_spmv(const femo_mat* A, const femo_vec* x, femo_vec* y
 
 namespace {
 struct CgWork {
-  double *r, *p, *q, *xh, *sv;
+  double *r, *p, *q, *xh, *sv, *t, *r0;
 };
 
-int ensure_work(femo_ctx* ctx, int64_t n_rows, int64_t n_vert, CgWork& w, bool need_sv) {
+// need: 0 = standard CG, 1 = single-reduction CG (+sv), 2 = BiCGSTAB (+sv, t, r0)
+int ensure_work(femo_ctx* ctx, int64_t n_rows, int64_t n_vert, CgWork& w, int need) {
   const int64_t len = std::max(n_rows, n_vert) + 2;
   if (ctx->cg_n < len) {
     hipFree(ctx->cg_r); hipFree(ctx->cg_p); hipFree(ctx->cg_q); hipFree(ctx->cg_dinv); hipFree(ctx->cg_s);
-    ctx->cg_r = ctx->cg_p = ctx->cg_q = ctx->cg_dinv = ctx->cg_s = nullptr;
+    hipFree(ctx->cg_t); hipFree(ctx->cg_r0);
+    ctx->cg_r = ctx->cg_p = ctx->cg_q = ctx->cg_dinv = ctx->cg_s = ctx->cg_t = ctx->cg_r0 = nullptr;
     ctx->cg_n = 0;
     FEMO_HIP_CHECK(hipMalloc(&ctx->cg_r, len * sizeof(double)));
     FEMO_HIP_CHECK(hipMalloc(&ctx->cg_p, len * sizeof(double)));
@@ -768,11 +882,14 @@ int ensure_work(femo_ctx* ctx, int64_t n_rows, int64_t n_vert, CgWork& w, bool n
     FEMO_HIP_CHECK(hipMalloc(&ctx->cg_dinv, len * sizeof(double)));   // holds xh
     ctx->cg_n = len;
   }
-  if (need_sv && !ctx->cg_s) FEMO_HIP_CHECK(hipMalloc(&ctx->cg_s, ctx->cg_n * sizeof(double)));
+  if (need >= 1 && !ctx->cg_s) FEMO_HIP_CHECK(hipMalloc(&ctx->cg_s, ctx->cg_n * sizeof(double)));
+  if (need >= 2 && !ctx->cg_t) FEMO_HIP_CHECK(hipMalloc(&ctx->cg_t, ctx->cg_n * sizeof(double)));
+  if (need >= 2 && !ctx->cg_r0) FEMO_HIP_CHECK(hipMalloc(&ctx->cg_r0, ctx->cg_n * sizeof(double)));
   FEMO_HIP_CHECK(hipMemsetAsync(ctx->cg_p, 0, ctx->cg_n * sizeof(double), ctx->stream));
   FEMO_HIP_CHECK(hipMemsetAsync(ctx->cg_r, 0, ctx->cg_n * sizeof(double), ctx->stream));
-  if (need_sv) FEMO_HIP_CHECK(hipMemsetAsync(ctx->cg_s, 0, ctx->cg_n * sizeof(double), ctx->stream));
+  if (need >= 1) FEMO_HIP_CHECK(hipMemsetAsync(ctx->cg_s, 0, ctx->cg_n * sizeof(double), ctx->stream));
   w.r = ctx->cg_r; w.p = ctx->cg_p; w.q = ctx->cg_q; w.xh = ctx->cg_dinv; w.sv = ctx->cg_s;
+  w.t = ctx->cg_t; w.r0 = ctx->cg_r0;
   return 0;
 }
 }  // namespace
@@ -823,7 +940,7 @@ extern "C" int femo_solve_cg(const femo_mat* A_, int transpose, const femo_vec* 
   CgWork w;
   // FEMO_FORCE_MULTI=1 runs the all-reduce code path on a 1-rank communicator (tests)
   const bool multi = ctx->nranks > 1 || (ctx->comm != nullptr && getenv("FEMO_FORCE_MULTI") != nullptr);
-  FEMO_TRY(ensure_work(ctx, n, m->n_vert, w, multi));
+  FEMO_TRY(ensure_work(ctx, n, m->n_vert, w, multi ? 1 : 0));
   const int gv = vec_grid(ctx, n);
   const int gs = femo_spmv_grid(m);
   int32_t* h_flags = reinterpret_cast<int32_t*>(ctx->h_scal + FEMO_NSCAL);  // 2 slots x 4 ints
@@ -963,4 +1080,106 @@ extern "C" int femo_solve_cg(const femo_mat* A_, int transpose, const femo_vec* 
   info->spmv_ms = acc;
   info->spmv_samples = n_ev;
   return finish(iters, conv, gamma_f);
+}
+
+
+// ------------------------------------------------------------- BiCGSTAB ------
+extern "C" int femo_solve_bicgstab(const femo_mat* A_, int transpose, const femo_vec* b, femo_vec* x,
+                                   const femo_solver_opts* opts, femo_solve_info* info) {
+  FEMO_REQUIRE(A_ && b && x && opts && info, "null argument");
+  femo_mat* A = const_cast<femo_mat*>(A_);
+  femo_mesh* m = A->mesh;
+  femo_ctx* ctx = m->ctx;
+  const int64_t n = m->n_rows;
+  FEMO_REQUIRE(b->n >= n && x->n >= m->n_vert, "vector size mismatch in solve_bicgstab");
+  FEMO_REQUIRE(b->d != x->d, "solve_bicgstab cannot run in place");
+  memset(info, 0, sizeof *info);
+  hipStream_t st = ctx->stream;
+  FEMO_HIP_CHECK(hipEventRecord(ctx->ev0, st));
+  FEMO_TRY(ensure_scaled(A, transpose != 0));
+  CgWork w;
+  FEMO_TRY(ensure_work(ctx, n, m->n_vert, w, 2));
+  const bool multi = ctx->nranks > 1 || (ctx->comm != nullptr && getenv("FEMO_FORCE_MULTI") != nullptr);
+  const int gv = vec_grid(ctx, n);
+  const int gs = femo_spmv_grid(m);
+  double* P = ctx->d_partials;
+  double* S = ctx->d_scal;
+  int32_t* h_flags = reinterpret_cast<int32_t*>(ctx->h_scal + FEMO_NSCAL);
+  FEMO_HIP_CHECK(hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int32_t), st));
+  FEMO_HIP_CHECK(hipMemsetAsync(w.sv, 0, ctx->cg_n * sizeof(double), st));   // sv, p: gathered incl. ghosts
+  const double* q0 = nullptr;
+  if (opts->zero_guess) {
+    FEMO_HIP_CHECK(hipMemsetAsync(x->d, 0, x->n * sizeof(double), st));
+  } else {
+    if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, x->d));
+    FEMO_TRY(launch_spmv(A, transpose ? A->d_valsT : A->d_vals, x->d, w.q, nullptr, nullptr));
+    q0 = w.q;
+  }
+  hipLaunchKernelGGL(k_bi_init, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, b->d, q0, A->d_s, w.r, w.r0, w.p, w.q, w.xh, P);
+  FEMO_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(k_reduce_partials_at, dim3(1), dim3(1024), 0, st, gv, 2, P, S + 12);
+  if (multi) FEMO_NCCL_CHECK(ncclAllReduce(S + 12, S + 12, 2, ncclDouble, ncclSum, ctx->comm, st));
+  FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, S + 12, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  const double rr0 = ctx->h_scal[0], bb = ctx->h_scal[1];
+  const double bnorm = std::sqrt(bb);
+  double tol = opts->rtol * bnorm;
+  if (opts->atol > tol) tol = opts->atol;
+  info->rhs_norm = bnorm;
+  const int max_it = opts->max_it > 0 ? opts->max_it : 10000;
+  auto finish = [&](int iters, int conv, double rr) -> int {
+    if (n > 0) {
+      hipLaunchKernelGGL(k_unscale, dim3(2048), dim3(256), 0, st, n, opts->zero_guess ? 0 : 1, A->d_s, w.xh, x->d);
+      FEMO_HIP_CHECK(hipGetLastError());
+    }
+    FEMO_HIP_CHECK(hipEventRecord(ctx->ev1, st));
+    FEMO_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    FEMO_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    info->iterations = iters;
+    info->converged = conv;
+    info->residual_norm = std::sqrt(rr);
+    info->solve_ms = ms;
+    return 0;
+  };
+  if (!(std::sqrt(rr0) > tol)) return finish(0, rr0 == rr0 ? 1 : -1, rr0);
+  double hs[FEMO_NSCAL] = {0};
+  hs[B_RHO] = rr0; hs[B_RHO_OLD] = 1.0; hs[B_ALPHA] = 1.0; hs[B_OMEGA] = 1.0; hs[B_RR] = rr0; hs[B_TOL2] = tol * tol;
+  memcpy(ctx->h_scal, hs, sizeof hs);
+  FEMO_HIP_CHECK(hipMemcpyAsync(S, ctx->h_scal, sizeof hs, hipMemcpyHostToDevice, st));
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+
+  const int batch = opts->check_every > 0 ? opts->check_every : 32;
+  int it = 0;
+  bool done = false;
+  while (!done) {
+    const int it_end = it + batch < max_it ? it + batch : max_it;
+    for (; it < it_end; ++it) {
+      hipLaunchKernelGGL(k_bi_check, dim3(1), dim3(1), 0, st, it, S, ctx->d_flags);
+      hipLaunchKernelGGL(k_bi_p, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, it, S, w.r, w.q, w.p, ctx->d_flags);
+      if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, w.p));
+      FEMO_TRY(launch_spmv(A, A->d_valsS, w.p, w.q, P, ctx->d_flags, true, false, nullptr, 0, nullptr, w.r0));   // v, (r0, v)
+      hipLaunchKernelGGL(k_bi_fold, dim3(1), dim3(1024), 0, st, gs, 1, P, S + B_R0V, ctx->d_flags);
+      if (multi) FEMO_NCCL_CHECK(ncclAllReduce(S + B_R0V, S + B_R0V, 1, ncclDouble, ncclSum, ctx->comm, st));
+      hipLaunchKernelGGL(k_bi_s, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, S, w.r, w.q, w.sv, ctx->d_flags);
+      if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, w.sv));
+      FEMO_TRY(launch_spmv(A, A->d_valsS, w.sv, w.t, P, ctx->d_flags, true, false, nullptr, 0, nullptr, nullptr, true));  // t, (s,t), (t,t)
+      hipLaunchKernelGGL(k_bi_fold, dim3(1), dim3(1024), 0, st, gs, 2, P, S + B_TS, ctx->d_flags);
+      if (multi) FEMO_NCCL_CHECK(ncclAllReduce(S + B_TS, S + B_TS, 2, ncclDouble, ncclSum, ctx->comm, st));
+      hipLaunchKernelGGL(k_bi_xr, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, it, S, w.p, w.sv, w.t, w.r0, w.xh, w.r, P, ctx->d_flags);
+      hipLaunchKernelGGL(k_bi_fold, dim3(1), dim3(1024), 0, st, gv, 2, P, S + 12, ctx->d_flags);
+      if (multi) FEMO_NCCL_CHECK(ncclAllReduce(S + 12, S + 12, 2, ncclDouble, ncclSum, ctx->comm, st));
+      hipLaunchKernelGGL(k_bi_set_rho, dim3(1), dim3(1), 0, st, S + 12, S, ctx->d_flags);
+    }
+    hipLaunchKernelGGL(k_bi_check, dim3(1), dim3(1), 0, st, it, S, ctx->d_flags);
+    FEMO_HIP_CHECK(hipGetLastError());
+    FEMO_HIP_CHECK(hipMemcpyAsync(h_flags, ctx->d_flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    FEMO_HIP_CHECK(hipStreamSynchronize(st));
+    if (h_flags[0] || it >= max_it) done = true;
+  }
+  FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, S, FEMO_NSCAL * sizeof(double), hipMemcpyDeviceToHost, st));
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  const int conv = h_flags[0] ? (h_flags[2] ? -1 : 1) : 0;
+  const int iters = h_flags[0] ? h_flags[1] : it;
+  return finish(iters, conv, ctx->h_scal[B_RR]);
 }

@@ -83,7 +83,7 @@ def bench_distributed(args, rank: int, world: int, local_rank: int) -> None:
     utils_hip.set_context(ctx)
     init_comm(ctx, rank, world)
     t0 = time.perf_counter()
-    gmesh = createUnitCubeMesh(args.n)
+    gmesh = createUnitCubeMesh(args.n, jitter=getattr(args, 'jitter', 0.0))
     n_dof, n_cell_g = gmesh.n_vert, gmesh.n_cell
     mesh = partition_mesh(gmesh, rank, world)
     del gmesh

@@ -290,6 +290,13 @@ class Mat:
         check(self.lib.femo_solve_cg(self.handle, int(transpose), b.handle, x.handle, C.byref(opts), C.byref(info)))
         return info
 
+    def solve_bicgstab(self, b: Vec, x: Vec, transpose: bool = False, rtol: float = 1e-12, atol: float = 0.0,
+                       max_it: int = 100000, zero_guess: bool = True, check_every: int = 32) -> SolveInfo:
+        opts = SolverOpts(rtol, atol, max_it, int(zero_guess), check_every, 0)
+        info = SolveInfo()
+        check(self.lib.femo_solve_bicgstab(self.handle, int(transpose), b.handle, x.handle, C.byref(opts), C.byref(info)))
+        return info
+
     def bench_spmv(self, x: Vec, y: Vec, reps: int = 50) -> float:
         ms = C.c_double(0.0)
         check(self.lib.femo_bench_spmv(self.handle, x.handle, y.handle, reps, C.byref(ms)))

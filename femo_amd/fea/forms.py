@@ -41,28 +41,27 @@ class PoissonResidual(Form):
 
 
 class NonlinearPoissonResidual(Form):
-    """inner(grad u, grad v) dx + inner(u**3, v) dx - inner(f, v) dx  [+ symmetric Nitsche terms]
+    """inner(grad u, grad v) dx + inner(u**3, v) dx - inner(f, v) dx  [+ Nitsche boundary terms]
     (examples/nonlinear_poisson_opt/run_nonlinear_poisson_opt.py:88-125).  ``u_exact`` is a CG1
     Function (the reference passes a UFL expression whose quadrature cannot be reproduced without
-    FFCx; its interpolant is used)."""
+    FFCx; its interpolant is used).  As in boundaryResidual (:98-117):
+    sym=True -> sgn = +1 and the penalty term is on (symmetric Jacobian, CG);
+    sym=False -> sgn = -1, penalty only with overPenalize (non-symmetric Jacobian, BiCGSTAB)."""
     rank = 1
     pde_kind = _lib.PDE_NL_POISSON
     is_linear = False
-    is_symmetric = True
 
     def __init__(self, u: Function, f: Function, u_exact: Function = None, weak_bc: bool = False,
                  sym: bool = False, beta_value: float = 1e1, overPenalize: bool = False):
         if u.function_space.family != "CG" or f.function_space.family != "DG":
             raise NotImplementedError("NonlinearPoissonResidual needs a CG1 state and a DG0 source")
-        if weak_bc:
-            if not sym:
-                raise NotImplementedError("unsymmetric Nitsche (sym=False) gives a non-symmetric Jacobian; "
-                                          "only the symmetric variant (CG solver) is implemented")
-            if u_exact is None or u_exact.function_space.family != "CG":
-                raise ValueError("weak_bc=True needs the boundary data u_exact as a CG1 Function")
+        if weak_bc and (u_exact is None or u_exact.function_space.family != "CG"):
+            raise ValueError("weak_bc=True needs the boundary data u_exact as a CG1 Function")
         self.u, self.f, self.u_exact = u, f, u_exact
-        self.weak_bc, self.sym, self.beta = weak_bc, sym, float(beta_value)
-        self.params = [self.beta]
+        self.weak_bc, self.sym = weak_bc, sym
+        self.beta = float(beta_value) if (sym or overPenalize) else 0.0
+        self.is_symmetric = bool(sym) or not weak_bc
+        self.params = [self.beta, 1.0 if sym else -1.0]
 
     def functions(self):
         return (self.u, self.f)

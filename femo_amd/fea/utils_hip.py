@@ -440,17 +440,19 @@ class KSP:
         self.info = None
 
     def solve(self, b, x) -> None:
+        """Symmetric operators: Jacobi-CG; otherwise BiCGSTAB on A or its explicit transpose."""
         o = self.options
         tr = self.transposed and not self.A.symmetric
-        self.info = self.A.mat.solve_cg(_as_vec(b), _as_vec(x), transpose=tr, rtol=o["rtol"], atol=o["atol"],
-                                        max_it=o["max_it"], zero_guess=True, check_every=o["check_every"])
+        solver = self.A.mat.solve_cg if self.A.symmetric else self.A.mat.solve_bicgstab
+        self.info = solver(_as_vec(b), _as_vec(x), transpose=tr, rtol=o["rtol"], atol=o["atol"],
+                           max_it=o["max_it"], zero_guess=True, check_every=o["check_every"])
         LAST_KSP_INFO.append(dict(iterations=self.info.iterations, converged=self.info.converged,
                                   residual_norm=self.info.residual_norm, rhs_norm=self.info.rhs_norm,
                                   solve_ms=self.info.solve_ms, spmv_ms=self.info.spmv_ms,
                                   spmv_samples=self.info.spmv_samples))
         del LAST_KSP_INFO[:-64]
         if self.info.converged != 1:
-            raise RuntimeError(f"CG did not converge: {self.info.iterations} iterations, "
+            raise RuntimeError(f"{'CG' if self.A.symmetric else 'BiCGSTAB'} did not converge: {self.info.iterations} iterations, "
                                f"||r|| = {self.info.residual_norm:.3e}, ||b|| = {self.info.rhs_norm:.3e}")
 
 

@@ -142,7 +142,7 @@ int femo_bc_destroy(femo_bc* bc);
 
 /* ---- assembly -------------------------------------------------------------
  * params: up to 8 doubles of form constants (unused for POISSON; NL_POISSON: params[0] = Nitsche
- *         beta).  aux: extra CG1 field of the form or NULL (NL_POISSON: the boundary data u_exact).
+ *         penalty beta (0 = none), params[1] = sgn of the nitsche_2 term: +1 symmetric (default), -1 unsymmetric).  aux: extra CG1 field of the form or NULL (NL_POISSON: the boundary data u_exact).
  *         FEMO_PDE_NL_POISSON = POISSON + int u^3 v (run_nonlinear_poisson_opt.py:88-96) and, when
  *         femo_mesh_set_boundary_facets was called, the symmetric Nitsche terms of :98-117.
  * residual: state_model.py:85 assembleVector(residual_form) -> utils:175-179; NO BCs.
@@ -191,6 +191,12 @@ int femo_mat_diagonal(const femo_mat* A, femo_vec* d);
  * A must be symmetric positive definite (Poisson with Dirichlet elimination).  */
 int femo_solve_cg(const femo_mat* A, int transpose, const femo_vec* b, femo_vec* x,
                   const femo_solver_opts* opts, femo_solve_info* info);
+
+/* BiCGSTAB on A or A^T for non-symmetric operators (e.g. unsymmetric Nitsche terms), Jacobi
+ * preconditioning by symmetric diagonal scaling; stops on ||S r||_2 <= max(rtol ||S b||_2, atol),
+ * S = diag(A)^-1/2.  Same options / info as femo_solve_cg.                                      */
+int femo_solve_bicgstab(const femo_mat* A, int transpose, const femo_vec* b, femo_vec* x,
+                        const femo_solver_opts* opts, femo_solve_info* info);
 
 /* ---- scalar output and its partials (output_model.py:69-87) ---------------- */
 int femo_functional_value(femo_mesh* mesh, int kind, const double* params,

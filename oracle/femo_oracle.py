@@ -522,7 +522,8 @@ def _facet_pieces(mesh: OMesh, bmask: np.ndarray):
 
 
 def nl_residual(mesh: OMesh, u: np.ndarray, f: np.ndarray, u_ex: np.ndarray, bmask: np.ndarray,
-                beta: float = BETA_NITSCHE) -> np.ndarray:
+                beta: float = BETA_NITSCHE, sgn: float = 1.0) -> np.ndarray:
+    """sgn = +1: sym=True (penalty on); sgn = -1 with beta = 0: the unsymmetric variant of :98-117."""
     d = mesh.tdim
     d1 = d + 1
     R = residual(mesh, u, f)                                            # grad-grad and load
@@ -540,7 +541,7 @@ def nl_residual(mesh: OMesh, u: np.ndarray, f: np.ndarray, u_ex: np.ndarray, bma
         Re = np.zeros((len(cells), d1))
         mean_e = e[:, on].sum(axis=1) / d                                # int_F e / |F|
         for a in range(d1):
-            Re[:, a] += gn[:, a] * (-mean_e) * meas                      # nitsche_2: (g_a.n) int_F (u_ex - u)
+            Re[:, a] += sgn * gn[:, a] * (-mean_e) * meas                # nitsche_2: sgn (g_a.n) int_F (u_ex - u)
         s_on = e[:, on].sum(axis=1)
         for a in on:
             Re[:, a] += -dun * meas / d                                  # nitsche_1
@@ -549,7 +550,7 @@ def nl_residual(mesh: OMesh, u: np.ndarray, f: np.ndarray, u_ex: np.ndarray, bma
     return R
 
 
-def nl_jacobian(mesh: OMesh, u: np.ndarray, bmask: np.ndarray, beta: float = BETA_NITSCHE) -> sp.csr_matrix:
+def nl_jacobian(mesh: OMesh, u: np.ndarray, bmask: np.ndarray, beta: float = BETA_NITSCHE, sgn: float = 1.0) -> sp.csr_matrix:
     d = mesh.tdim
     d1 = d + 1
     vol, g = cell_geometry(mesh)
@@ -562,7 +563,7 @@ def nl_jacobian(mesh: OMesh, u: np.ndarray, bmask: np.ndarray, beta: float = BET
         Fe = np.zeros((len(cells), d1, d1))
         for a in on:
             Fe[:, a, :] += -(gn * (meas / d)[:, None])                   # nitsche_1: -(g_b.n) int_F phi_a
-            Fe[:, :, a] += -(gn * (meas / d)[:, None])                   # nitsche_2: -(g_a.n) int_F phi_b
+            Fe[:, :, a] += -sgn * (gn * (meas / d)[:, None])             # nitsche_2: -sgn (g_a.n) int_F phi_b
             for b in on:
                 Fe[:, a, b] += beta / hE * meas / (d * (d + 1)) * (2.0 if a == b else 1.0)
         Ke[cells] += Fe
@@ -572,34 +573,34 @@ def nl_jacobian(mesh: OMesh, u: np.ndarray, bmask: np.ndarray, beta: float = BET
 
 
 def nl_newton_solve(mesh: OMesh, f: np.ndarray, u0: np.ndarray, u_ex: np.ndarray, bmask: np.ndarray,
-                    beta: float = BETA_NITSCHE, atol: float = 1e-13, rtol: float = 1e-13, max_it: int = 100
-                    ) -> Tuple[np.ndarray, SolveInfo]:
+                    beta: float = BETA_NITSCHE, atol: float = 1e-13, rtol: float = 1e-13, max_it: int = 100,
+                    sgn: float = 1.0) -> Tuple[np.ndarray, SolveInfo]:
     """utils_dolfinx.py:376-416 SNES newtonls, line search basic (full step), LU; no strong BCs."""
     u = u0.copy()
     info = SolveInfo()
-    F = nl_residual(mesh, u, f, u_ex, bmask, beta)
+    F = nl_residual(mesh, u, f, u_ex, bmask, beta, sgn)
     r0 = float(np.linalg.norm(F))
     info.residual_norms.append(r0)
     while info.newton_its < max_it:
         r = info.residual_norms[-1]
         if r < atol or (info.newton_its > 0 and r < rtol * r0):
             break
-        J = nl_jacobian(mesh, u, bmask, beta)
+        J = nl_jacobian(mesh, u, bmask, beta, sgn)
         u -= spla.splu(J.tocsc()).solve(F)
         info.newton_its += 1
-        F = nl_residual(mesh, u, f, u_ex, bmask, beta)
+        F = nl_residual(mesh, u, f, u_ex, bmask, beta, sgn)
         info.residual_norms.append(float(np.linalg.norm(F)))
     return u, info
 
 
 def nl_reference_cycle(mesh: OMesh, f: np.ndarray, u_ex: np.ndarray, bmask: np.ndarray,
-                       alpha: float = ALPHA_NL, beta: float = BETA_NITSCHE) -> Dict[str, np.ndarray]:
+                       alpha: float = ALPHA_NL, beta: float = BETA_NITSCHE, sgn: float = 1.0) -> Dict[str, np.ndarray]:
     """run_nonlinear_poisson_opt.py: SNES solve from u = 1 (CSDL's default state value), J, adjoint
     gradient.  No Dirichlet rows, so A = dR/du and the reduced gradient is exact."""
-    u, info = nl_newton_solve(mesh, f, np.ones(mesh.n_vert), u_ex, bmask, beta)
+    u, info = nl_newton_solve(mesh, f, np.ones(mesh.n_vert), u_ex, bmask, beta, sgn=sgn)
     J = functional(mesh, u, f, u_ex, alpha)
     dJdu = functional_du(mesh, u, u_ex)
-    A = nl_jacobian(mesh, u, bmask, beta)
+    A = nl_jacobian(mesh, u, bmask, beta, sgn)
     lam = spla.splu(A.T.tocsc()).solve(dJdu)
     grad = functional_df(mesh, f, alpha) - dRdf(mesh).T @ lam
     return dict(u=u, J=np.array([J]), grad=grad, lam=lam, newton_its=info.newton_its)

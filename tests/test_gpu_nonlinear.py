@@ -78,6 +78,72 @@ def test_nl_cycle_matches_oracle(ctx, d, n, device):
     assert max(chk['rel_error']) < 1e-6
 
 
+@pytest.mark.parametrize("d,n", [(2, 40), (3, 14)])
+def test_bicgstab_matches_lu(ctx, d, n):
+    """Non-symmetric operator (unsymmetric Nitsche, sgn = -1, no penalty): forward and transposed solves."""
+    from femo_amd import engine as E
+    import scipy.sparse.linalg as spla
+    m = fo.unit_square_mesh(n, 0.2) if d == 2 else fo.unit_cube_mesh(n, 0.2)
+    rng = np.random.default_rng(9)
+    u, f, uex = 0.3 * rng.standard_normal(m.n_vert), rng.standard_normal(m.n_cell), fo.u_exact_nl(m.x)
+    bm = fo.boundary_facets(m)
+    dm = E.DeviceMesh(ctx, m.x, m.conn)
+    dm.set_boundary_facets(bm)
+    U, F, UEX = E.Vec(ctx, m.n_vert).set(u), E.Vec(ctx, m.n_cell).set(f), E.Vec(ctx, m.n_vert).set(uex)
+    J, R = E.Mat(dm), E.Vec(ctx, m.n_vert)
+    E.assemble_system(dm, 1, [0.0, -1.0], U, F, None, J, None, R, aux=UEX)
+    Jo = fo.nl_jacobian(m, u, bm, 0.0, -1.0)
+    assert _rel(J.to_scipy().data, Jo.data) < 1e-12 and abs(Jo - Jo.T).max() > 1e-3
+    assert _rel(R.get(), fo.nl_residual(m, u, f, uex, bm, 0.0, -1.0)) < 1e-12
+    b = rng.standard_normal(m.n_vert)
+    B, X = E.Vec(ctx, m.n_vert).set(b), E.Vec(ctx, m.n_vert)
+    lu = spla.splu(Jo.tocsc())
+    info = J.solve_bicgstab(B, X, rtol=1e-13)
+    assert info.converged == 1 and _rel(X.get(), lu.solve(b)) < 1e-9
+    info = J.solve_bicgstab(B, X, transpose=True, rtol=1e-13)
+    assert info.converged == 1 and _rel(X.get(), spla.splu(Jo.T.tocsc()).solve(b)) < 1e-9
+    info = J.solve_bicgstab(B, X, transpose=True, rtol=1e-13, zero_guess=False)     # warm start
+    assert info.converged == 1 and info.iterations <= 2
+    # transposed SpMV through the explicit transpose permutation
+    Y = E.Vec(ctx, m.n_vert)
+    J.mult(U, Y, transpose=True)
+    assert _rel(Y.get(), Jo.T @ u) < 1e-12
+
+
+def test_nl_unsymmetric_cycle(ctx):
+    """run_nonlinear_poisson_opt.py with sym=False: Newton with BiCGSTAB, adjoint with the true transpose."""
+    from femo_amd.csdl_opt.fea_model import FEAModel
+    from femo_amd.csdl_opt.simulator import Simulator
+    from femo_amd.fea import utils_hip
+    from femo_amd.fea.fea_hip import FEA, Function, FunctionSpace, TestFunction
+    from femo_amd.fea.mesh import createUnitSquareMesh
+    from femo_amd.fea.nonlinear_poisson import ALPHA_1, outputForm, pdeRes
+    utils_hip.set_context(ctx)
+    n = 20
+    mesh, om = createUnitSquareMesh(n), fo.unit_square_mesh(n)
+    fea = FEA(mesh)
+    fea.REPORT = False
+    Vf, Vu = FunctionSpace(mesh, ('DG', 0)), FunctionSpace(mesh, ('CG', 1))
+    f_fn, u_fn, u_ex = Function(Vf), Function(Vu), Function(Vu)
+    u_ex.interpolate(lambda x: np.sin(2 * np.pi * x[0]) * np.sin(np.pi * x[1]))
+    fea.add_input('f', f_fn)
+    fea.add_state(name='u', function=u_fn, arguments=['f'],
+                  residual_form=pdeRes(u_fn, TestFunction(Vu), f_fn, u_exact=u_ex, weak_bc=True, sym=False))
+    fea.add_output(name='l2_functional', type='scalar', form=outputForm(u_fn, f_fn, u_ex), arguments=['f', 'u'])
+    fea.PDE_SOLVER = 'SNES'
+    model = FEAModel(fea=[fea])
+    model.create_input('f', shape=mesh.n_cell, val=0.1)
+    sim = Simulator(model, device=True)
+    sim.run()
+    ref = fo.nl_reference_cycle(om, 0.1 * np.ones(om.n_cell), fo.u_exact_nl(om.x), fo.boundary_facets(om), ALPHA_1,
+                                beta=0.0, sgn=-1.0)
+    assert _rel(sim['u'], ref['u']) < 1e-9
+    g = np.asarray(sim.compute_totals('l2_functional', 'f'))
+    assert _rel(g, ref['grad']) < 1e-9
+    chk = sim.check_totals('l2_functional', 'f', step=1e-5, n_dir=2)
+    assert max(chk['rel_error']) < 1e-6
+
+
 def test_nl_catalogue_limits(ctx):
     from femo_amd.fea import utils_hip
     from femo_amd.fea.fea_hip import Function, FunctionSpace
@@ -86,7 +152,7 @@ def test_nl_catalogue_limits(ctx):
     utils_hip.set_context(ctx)
     mesh = createUnitSquareMesh(4)
     u, f = Function(FunctionSpace(mesh, ('CG', 1))), Function(FunctionSpace(mesh, ('DG', 0)))
-    with pytest.raises(NotImplementedError):
-        pdeRes(u, None, f, u_exact=u, weak_bc=True, sym=False)      # unsymmetric Nitsche needs BiCGSTAB
+    assert pdeRes(u, None, f, u_exact=u, weak_bc=True, sym=False).is_symmetric is False
+    assert pdeRes(u, None, f, u_exact=u, weak_bc=True, sym=True).is_symmetric is True
     with pytest.raises(ValueError):
         pdeRes(u, None, f, weak_bc=True, sym=True)                  # boundary data missing

@@ -172,6 +172,21 @@ def test_nl_oracle_consistency(d, n):
     assert np.isclose(T3.sum(), 1.0)                      # sum_abce int phi_a phi_b phi_c phi_e = |T|
 
 
+def test_nl_unsymmetric_nitsche_oracle():
+    """sym=False (run_nonlinear_poisson_opt.py:98-117): sgn = -1, no penalty -> non-symmetric Jacobian."""
+    m = fo.unit_square_mesh(10, 0.2)
+    bm = fo.boundary_facets(m)
+    rng = np.random.default_rng(0)
+    u, f, uex = 0.5 * rng.standard_normal(m.n_vert), rng.standard_normal(m.n_cell), fo.u_exact_nl(m.x)
+    J = fo.nl_jacobian(m, u, bm, 0.0, -1.0)
+    assert abs(J - J.T).max() > 0.1
+    du = rng.standard_normal(m.n_vert)
+    fd = (fo.nl_residual(m, u + 1e-6 * du, f, uex, bm, 0.0, -1.0) - fo.nl_residual(m, u - 1e-6 * du, f, uex, bm, 0.0, -1.0)) / 2e-6
+    assert np.abs(fd - J @ du).max() < 1e-8 * np.abs(J @ du).max()
+    out = fo.nl_reference_cycle(m, 0.1 * np.ones(m.n_cell), uex, bm, beta=0.0, sgn=-1.0)
+    assert out["newton_its"] <= 6
+
+
 def test_nl_manufactured_solution_converges():
     """u = sin 2pi x sin pi y, f = 5 pi^2 u + u^3 (run_nonlinear_poisson_opt.py:145-168): O(h^2) in L2."""
     errs = []
