@@ -26,6 +26,7 @@ MESH_INFO_KEYS = ("tdim", "n_vert", "n_rows", "n_cell", "nnz", "sell_entries", "
 PDE_POISSON = 0
 PDE_NL_POISSON = 1
 PDE_MASS = 2
+PDE_EB_BEAM = 3
 J_L2_TRACKING = 0
 
 

@@ -202,6 +202,24 @@ __device__ __forceinline__ void nl_row(const CellGeom<D>& G, int a, const double
   }
 }
 
+// ---------------------------------------- Euler-Bernoulli beam, cubic Hermite ---
+// examples/beam_thickness_opt/run_thickness_opt_cantilever_beam.py:71-79:
+//   inner(div grad v, EI div grad u) dx - f v(L),  EI = E * width * t^3 / 12, t DG0 per element.
+// A beam element couples its 4 DOFs (w_i, th_i, w_i+1, th_i+1) all-to-all, exactly like the
+// vertices of a tetrahedron, so the beam is stored as a tdim = 3 "mesh" whose vertices are the
+// DOFs (x[dof] = (node position, 0, 0), conn[e] = {2e, 2e+1, 2e+2, 2e+3}) and the incidence,
+// the SELL pattern and the owner-computes walk are reused unchanged.
+// Row a of the Hermite element matrix (12, 6h, -12, 6h; 6h, 4h^2, -6h, 2h^2; ...) / h^3.
+__device__ __forceinline__ void beam_khat_row(double h, const double w[4], double k[4]) {
+  const double i3 = 1.0 / (h * h * h);
+  const double r0[4] = {12.0, 6.0 * h, -12.0, 6.0 * h};
+  const double r1[4] = {6.0 * h, 4.0 * h * h, -6.0 * h, 2.0 * h * h};
+  const double r2[4] = {-12.0, -6.0 * h, 12.0, -6.0 * h};
+  const double r3[4] = {6.0 * h, 2.0 * h * h, -6.0 * h, 4.0 * h * h};
+#pragma unroll
+  for (int b = 0; b < 4; ++b) k[b] = (w[0] * r0[b] + w[1] * r1[b] + w[2] * r2[b] + w[3] * r3[b]) * i3;
+}
+
 // ---------------------------------------------------------------- residual --
 template <int D, int PDE>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_residual(
@@ -225,6 +243,18 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_residual(
     const int a = ca & 3;
     int32_t v[D + 1];
     load_conn<D>(conn, c, v);
+    if constexpr (PDE == FEMO_PDE_EB_BEAM) {
+      double w[4], k[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) w[b] = (a == b) ? 1.0 : 0.0;
+      const double h = x[(int64_t)v[2] * 3] - x[(int64_t)v[0] * 3];
+      const double t = f[c];
+      const double EI = beta * sgn * t * t * t * (1.0 / 12.0);         // params: E, width
+      beam_khat_row(h, w, k);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc += EI * k[b] * u[v[b]];
+      continue;
+    }
     CellGeom<D> G;
     cell_geom<D>(x, v, G);
     double gu[D], ue[D + 1];
@@ -246,6 +276,9 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_residual(
       const unsigned bits = bfacets ? bfacets[c] : 0u;
       nl_row<D, false, true>(G, a, w, ue, x, v, aux, bits, beta, sgn, dummy, &acc);
     }
+  }
+  if constexpr (PDE == FEMO_PDE_EB_BEAM) {
+    if (row < n_rows && aux != nullptr) acc -= aux[row];            // nodal load vector f v(L)
   }
   if (row < n_rows) r[row] = acc;
 }
@@ -292,12 +325,26 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
     const int a = ca & 3;
     int32_t v[D + 1];
     load_conn<D>(conn, c, v);
+    double krow[D + 1];
     CellGeom<D> G;
-    cell_geom<D>(x, v, G);
     double ga[D];
+    if constexpr (PDE == FEMO_PDE_EB_BEAM) {
+      double w[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) w[b] = (a == b) ? 1.0 : 0.0;
+      const double h = x[(int64_t)v[2] * 3] - x[(int64_t)v[0] * 3];
+      const double t = f[c];
+      const double EI = beta * sgn * t * t * t * (1.0 / 12.0);         // params: E, width
+      beam_khat_row(h, w, krow);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        krow[b] *= EI;
+        if (want_rhs) racc += krow[b] * u[v[b]];
+      }
+    } else {
+    cell_geom<D>(x, v, G);
     select_row<D>(G, a, ga);
     if (want_rhs) racc -= f[c] * G.vol * (1.0 / (D + 1));
-    double krow[D + 1];
 #pragma unroll
     for (int b = 0; b <= D; ++b) {
       if constexpr (PDE == FEMO_PDE_MASS) {
@@ -307,6 +354,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
         krow[b] = __dmul_rn(G.vol, dotD<D>(ga, G.g[b]));
       }
       if (want_rhs) racc += krow[b] * u[v[b]];           // linear part of the residual: K u
+    }
     }
     if constexpr (PDE == FEMO_PDE_NL_POISSON) {
       double w[D + 1], ue[D + 1];
@@ -330,6 +378,9 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
     }
   }
   const bool valid = row < n_rows;
+  if constexpr (PDE == FEMO_PDE_EB_BEAM) {
+    if (want_rhs && valid && aux != nullptr) racc -= aux[row];      // nodal load vector f v(L)
+  }
   const bool row_bc = bcmask != nullptr && valid && bcmask[row];
   if (diag0) diag0[row] = valid ? dsum : 1.0;  // padded rows of the last slice: harmless identity
   if (diag1) diag1[row] = (valid && !row_bc) ? dsum : 1.0;
@@ -358,6 +409,29 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
 }
 
 // -------------------------------------------------------------------- dRdf --
+// dR/dt of the beam: column e = (E width t_e^2 / 4) * Khat u_e  (4 entries aligned with conn[e])
+__global__ __launch_bounds__(FEMO_BLOCK) void k_dRdt_beam(int64_t n_cell, double Ey, double width, const int32_t* __restrict__ conn,
+                                                          const double* __restrict__ x, const double* __restrict__ u,
+                                                          const double* __restrict__ t, double* __restrict__ vals) {
+  for (int64_t c = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; c < n_cell; c += (int64_t)gridDim.x * FEMO_BLOCK) {
+    int32_t v[4];
+    load_conn<3>(conn, c, v);
+    const double h = x[(int64_t)v[2] * 3] - x[(int64_t)v[0] * 3];
+    const double tc = t[c];
+    const double dEI = Ey * width * tc * tc * 0.25;
+    double ue[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) ue[b] = u[v[b]];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      double w[4] = {0.0, 0.0, 0.0, 0.0}, k[4];
+      w[a] = 1.0;
+      beam_khat_row(h, w, k);
+      vals[c * 4 + a] = dEI * (k[0] * ue[0] + k[1] * ue[1] + k[2] * ue[2] + k[3] * ue[3]);
+    }
+  }
+}
+
 template <int D, int PDE>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_dRdf(int64_t n_cell, const int32_t* __restrict__ conn,
                                                      const double* __restrict__ x,
@@ -562,7 +636,12 @@ inline int64_t row_blocks(const femo_mesh* m) { return (m->n_slices * FEMO_WAVE 
   } while (0)
 
 static int check_nl(femo_mesh* m, int pde, const double* u, const double* aux) {
-  FEMO_REQUIRE(pde == FEMO_PDE_POISSON || pde == FEMO_PDE_NL_POISSON || pde == FEMO_PDE_MASS, "pde kind %d not implemented", pde);
+  FEMO_REQUIRE(pde == FEMO_PDE_POISSON || pde == FEMO_PDE_NL_POISSON || pde == FEMO_PDE_MASS || pde == FEMO_PDE_EB_BEAM,
+               "pde kind %d not implemented", pde);
+  if (pde == FEMO_PDE_EB_BEAM) {
+    FEMO_REQUIRE(m->tdim == 3, "the Hermite beam lives on a 4-DOF-per-element (tdim = 3) mesh");
+    FEMO_REQUIRE(u != nullptr, "the beam form needs the state u");
+  }
   if (pde == FEMO_PDE_NL_POISSON) {
     FEMO_REQUIRE(u != nullptr, "the nonlinear Poisson form needs the state u");
     FEMO_REQUIRE(m->d_bfacets == nullptr || aux != nullptr, "Nitsche terms need the boundary data u_exact (aux)");
@@ -579,7 +658,9 @@ int femo_launch_residual(femo_mesh* m, int pde, const double* params, const doub
   hipStream_t st = m->ctx->stream;
   const double beta = params ? params[0] : 0.0;
   const double sgn = (params && params[1] != 0.0) ? params[1] : 1.0;
-  if (pde == FEMO_PDE_NL_POISSON)
+  if (pde == FEMO_PDE_EB_BEAM)
+    hipLaunchKernelGGL((k_residual<3, FEMO_PDE_EB_BEAM>), dim3(nb), dim3(FEMO_BLOCK), 0, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_conn, m->d_x, u, f, aux, m->d_bfacets, params ? params[0] : 1.0, params ? params[1] : 1.0, r);
+  else if (pde == FEMO_PDE_NL_POISSON)
     FEMO_LAUNCH_DP(m, k_residual, FEMO_PDE_NL_POISSON, nb, 0, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_conn, m->d_x, u, f, aux, m->d_bfacets, beta, sgn, r);
   else
     FEMO_LAUNCH_DP(m, k_residual, FEMO_PDE_POISSON, nb, 0, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_conn, m->d_x, u, f, aux, m->d_bfacets, beta, sgn, r);
@@ -612,6 +693,11 @@ int femo_launch_system(femo_mesh* m, int pde, const double* params, const double
   FEMO_REQUIRE(lds <= 160 * 1024, "row length %d exceeds the LDS strip capacity", m->max_rowlen);
   const double beta = params ? params[0] : 0.0;
   const double sgn = (params && params[1] != 0.0) ? params[1] : 1.0;
+  if (pde == FEMO_PDE_EB_BEAM) {
+    FEMO_REQUIRE(f != nullptr, "the beam form needs the thickness field");
+    return launch_system_t<3, FEMO_PDE_EB_BEAM>(m, nb, lds, u, f, aux, params ? params[0] : 1.0, params ? params[1] : 1.0,
+                                                bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
+  }
   if (pde == FEMO_PDE_MASS) {
     FEMO_REQUIRE(rhs == nullptr, "the mass form has no residual");
     if (m->tdim == 3) return launch_system_t<3, FEMO_PDE_MASS>(m, nb, lds, u, f, aux, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
@@ -627,10 +713,16 @@ int femo_launch_system(femo_mesh* m, int pde, const double* params, const double
 
 int femo_launch_dRdf(femo_mesh* m, int pde, const double* params, const double* u,
                      const double* f, double* vals) {
-  FEMO_REQUIRE(pde == FEMO_PDE_POISSON || pde == FEMO_PDE_NL_POISSON, "pde kind %d not implemented", pde);
+  FEMO_REQUIRE(pde == FEMO_PDE_POISSON || pde == FEMO_PDE_NL_POISSON || pde == FEMO_PDE_EB_BEAM, "pde kind %d not implemented", pde);
   if (m->n_cell == 0) return 0;
   const int g = cell_grid(m->n_cell);
   hipStream_t st = m->ctx->stream;
+  if (pde == FEMO_PDE_EB_BEAM) {
+    FEMO_REQUIRE(m->tdim == 3 && u != nullptr && f != nullptr, "dR/dt of the beam needs u, t and a tdim = 3 mesh");
+    hipLaunchKernelGGL(k_dRdt_beam, dim3(g), dim3(FEMO_BLOCK), 0, st, m->n_cell, params ? params[0] : 1.0, params ? params[1] : 1.0, m->d_conn, m->d_x, u, f, vals);
+    FEMO_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   FEMO_LAUNCH_DP(m, k_dRdf, 0, g, 0, st, m->n_cell, m->d_conn, m->d_x, vals);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;

@@ -18,7 +18,8 @@ from .forms import (ALPHA, DerivativeForm, FieldExpression, Form, FunctionExpr, 
                     L2TrackingFunctional, NonlinearPoissonResidual, PoissonResidual, PowerExpr, TestFunction,
                     derivative, interiorResidual, outputForm, pdeRes)
 from .function import Function, FunctionSpace
-from .mesh import Mesh, createUnitCubeMesh, createUnitSquareMesh, locate_dofs_geometrical
+from .mesh import (BeamMesh, Mesh, createIntervalMesh, createUnitCubeMesh, createUnitSquareMesh,
+                   locate_dofs_geometrical)
 
 
 class _NullRecorder:

@@ -67,6 +67,41 @@ class NonlinearPoissonResidual(Form):
         return (self.u, self.f)
 
 
+class BeamResidual(Form):
+    """inner(div grad v, EI div grad u) dx - f v(L),  EI = E width t^3 / 12
+    (examples/beam_thickness_opt/run_thickness_opt_cantilever_beam.py:71-79).  ``load`` is the nodal
+    load vector of the point force (a Hermite-space Function)."""
+    rank = 1
+    pde_kind = _lib.PDE_EB_BEAM
+    is_linear = True
+    is_symmetric = True
+
+    def __init__(self, u: Function, t: Function, load: Function, E: float, width: float):
+        if u.function_space.family != "HERMITE" or t.function_space.family != "DG":
+            raise NotImplementedError("BeamResidual needs a Hermite-3 state and a DG0 thickness")
+        self.u, self.f, self.load = u, t, load
+        self.E, self.width = float(E), float(width)
+        self.params = [self.E, self.width]
+
+    def functions(self):
+        return (self.u, self.f)
+
+
+class LinearFunctional(Form):
+    """J = sum_i coeff_i * arg_i for a fixed coefficient Function of the same space as ``arg``:
+    compliance f u(L) (coeff = nodal load) and volume t width L dx (coeff = width * h_e) of the beam
+    example (:81-85)."""
+    rank = 0
+
+    def __init__(self, coeff: Function, arg: Function, others=()):
+        if coeff.function_space.dim != arg.function_space.dim:
+            raise ValueError("coefficient and argument live in different spaces")
+        self.coeff, self.arg, self.others = coeff, arg, tuple(others)
+
+    def functions(self):
+        return (self.arg,) + self.others
+
+
 class L2TrackingFunctional(Form):
     rank = 0
     functional_kind = _lib.J_L2_TRACKING
@@ -120,9 +155,12 @@ class DerivativeForm(Form):
     """Gateaux derivative of ``form`` w.r.t. ``wrt`` (ufl.derivative)."""
 
     def __init__(self, form: Form, wrt: Function):
-        if not any(wrt is fn for fn in form.functions()):
-            raise ValueError("derivative w.r.t. a Function the form does not depend on")
+        if not isinstance(wrt, Function) and not hasattr(wrt, "function_space"):
+            raise ValueError("derivative is taken w.r.t. a Function")
+        # like ufl.derivative, differentiating w.r.t. a Function the form does not depend on is legal
+        # (the result assembles to zero); ``depends`` lets the assemblers short-cut it
         self.form, self.wrt = form, wrt
+        self.depends = any(wrt is fn for fn in form.functions())
         self.rank = form.rank + 1
 
 

@@ -15,11 +15,17 @@ from ..engine import Vec
 class FunctionSpace:
     def __init__(self, mesh, element=("CG", 1)):
         family, degree = element
-        if (family, degree) not in (("CG", 1), ("Lagrange", 1), ("DG", 0)):
+        from .mesh import BeamMesh
+        if (family, degree) == ("Hermite", 3):
+            if not isinstance(mesh, BeamMesh):
+                raise NotImplementedError("the cubic Hermite element is implemented on interval (beam) meshes only")
+        elif (family, degree) not in (("CG", 1), ("Lagrange", 1), ("DG", 0)):
             raise NotImplementedError(
-                f"function space {element}: the HIP engine implements CG1 states and DG0 inputs only")
+                f"function space {element}: the HIP engine implements CG1 / Hermite-3 states and DG0 inputs only")
+        elif isinstance(mesh, BeamMesh) and family != "DG":
+            raise NotImplementedError("on a beam mesh the state space is ('Hermite', 3)")
         self.mesh = mesh
-        self.family = "DG" if family == "DG" else "CG"
+        self.family = "DG" if family == "DG" else ("HERMITE" if family == "Hermite" else "CG")
         self.degree = degree
         self.num_sub_spaces = 0
 
@@ -28,7 +34,9 @@ class FunctionSpace:
         return self.mesh.n_cell if self.family == "DG" else self.mesh.n_vert
 
     def tabulate_dof_coordinates(self) -> np.ndarray:
-        return self.mesh.centroids() if self.family == "DG" else self.mesh.x
+        if self.family == "DG":
+            return self.mesh.centroids()
+        return self.mesh.x[:, :1] if self.family == "HERMITE" else self.mesh.x
 
     def __eq__(self, other):
         return (isinstance(other, FunctionSpace) and other.mesh is self.mesh

@@ -121,6 +121,37 @@ def createUnitCubeMesh(n: int, jitter: float = 0.0, seed: int = 20240807) -> Mes
     return Mesh(_apply_jitter(x, n, jitter, seed), conn, n)
 
 
+class BeamMesh(Mesh):
+    """Interval mesh for the cubic-Hermite Euler-Bernoulli beam (utils_dolfinx.py:142-146
+    createIntervalMesh -> dolfinx create_interval [ext]).  The engine sees the DOF graph: vertices
+    are the DOFs (w_i, th_i), element e couples {2e, 2e+1, 2e+2, 2e+3} like a tetrahedron couples
+    its vertices, so the tdim = 3 incidence / pattern / assembly walk is reused as is."""
+
+    def __init__(self, n: int, x0: float, x1: float):
+        self.nel = int(n)
+        self.nodes = x0 + (x1 - x0) * np.arange(n + 1) / n
+        self.nodes[-1] = x1
+        x = np.zeros((2 * (n + 1), 3))
+        x[:, 0] = np.repeat(self.nodes, 2)
+        conn = (2 * np.arange(n)[:, None] + np.arange(4)[None, :]).astype(np.int32)
+        super().__init__(x, conn, n)
+        self.gdim = 1
+
+    def cell_lengths(self) -> np.ndarray:
+        return np.diff(self.nodes)
+
+    def centroids(self) -> np.ndarray:
+        return (0.5 * (self.nodes[1:] + self.nodes[:-1]))[:, None]
+
+    def boundary_facet_mask(self):
+        raise NotImplementedError("exterior facets of the beam are its two end points")
+
+
+def createIntervalMesh(n: int, x0: float, x1: float) -> BeamMesh:
+    """utils_dolfinx.py:142-146"""
+    return BeamMesh(n, x0, x1)
+
+
 def locate_dofs_geometrical(V, marker: Callable[[np.ndarray], np.ndarray]) -> np.ndarray:
     """dolfinx.fem.locate_dofs_geometrical [ext] for CG1: ``marker`` receives the
     coordinates as an array of shape (3, n_dofs) (gdim rows used, rest zero) and

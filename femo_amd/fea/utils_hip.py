@@ -16,10 +16,11 @@ import numpy as np
 from .. import _lib
 from .. import engine as E
 from ..engine import Context, DeviceArray, Vec
-from .forms import (DerivativeForm, FieldExpression, Form, FunctionExpr, GradientMagnitude,
-                    L2TrackingFunctional, NonlinearPoissonResidual, PoissonResidual, PowerExpr, derivative)
+from .forms import (BeamResidual, DerivativeForm, FieldExpression, Form, FunctionExpr, GradientMagnitude,
+                    L2TrackingFunctional, LinearFunctional, NonlinearPoissonResidual, PoissonResidual, PowerExpr, derivative)
 from .function import Function, FunctionSpace, _VectorView
-from .mesh import (Mesh, createUnitCubeMesh, createUnitSquareMesh, locate_dofs_geometrical)
+from .mesh import (BeamMesh, Mesh, createIntervalMesh, createUnitCubeMesh, createUnitSquareMesh,
+                   locate_dofs_geometrical)
 
 DOLFIN_EPS = 3E-16
 
@@ -278,7 +279,7 @@ def _mesh_of(form: Form) -> Mesh:
     return base.functions()[0].function_space.mesh
 
 
-_RESIDUALS = (PoissonResidual, NonlinearPoissonResidual)
+_RESIDUALS = (PoissonResidual, NonlinearPoissonResidual, BeamResidual)
 
 
 def _aux(res) -> Optional[Vec]:
@@ -291,6 +292,8 @@ def _aux(res) -> Optional[Vec]:
                 dm.set_boundary_facets(mesh.boundary_facet_mask())
                 dm._bfacets_set = True
             return res.u_exact.vec
+    if isinstance(res, BeamResidual):
+        return res.load.vec
     return None
 
 
@@ -299,6 +302,9 @@ def assembleScalar(c: Form) -> float:
     if isinstance(c, L2TrackingFunctional):
         dm = _mesh_of(c).device(get_context())
         return E.functional_value(dm, c.functional_kind, c.params, c.u.vec, c.f.vec, c.u_exact.vec)
+    if isinstance(c, LinearFunctional):
+        n = c.arg.function_space.dim
+        return c.coeff.vec.dot(c.arg.vec, n)
     raise NotImplementedError(f"assembleScalar: {type(c).__name__} is not in the form catalogue")
 
 
@@ -319,6 +325,13 @@ def _assemble_vector_dev(v: Form, out: Optional[Vec] = None) -> Vec:
         if v.wrt is J.f:
             out = out or _work(mesh, "vec_dJdf", lambda: Vec(ctx, mesh.n_cell))
             return E.functional_grad_f(dm, J.functional_kind, J.params, J.u.vec, J.f.vec, J.u_exact.vec, out)
+    if isinstance(v, DerivativeForm) and isinstance(v.form, LinearFunctional):
+        J = v.form
+        n = v.wrt.function_space.dim
+        out = out or _work(mesh, f"vec_lin_{n}", lambda: Vec(ctx, n))
+        if v.wrt is J.arg:
+            return out.copy_from(J.coeff.vec)
+        return out.fill(0.0)
     raise NotImplementedError(f"assembleVector: {type(v).__name__} is not in the form catalogue")
 
 

@@ -44,7 +44,10 @@ typedef struct femo_mat  femo_mat;   /* N x N sparse matrix on the mesh pattern 
 enum femo_pde_kind {
   FEMO_PDE_POISSON = 0,       /* examples/poisson_opt/run_poisson_opt.py:32-38            */
   FEMO_PDE_NL_POISSON = 1,    /* examples/nonlinear_poisson_opt/...py:88-125              */
-  FEMO_PDE_MASS = 2           /* inner(Pv, w) dx, matrix only (utils_dolfinx.py:567-572)  */
+  FEMO_PDE_MASS = 2,          /* inner(Pv, w) dx, matrix only (utils_dolfinx.py:567-572)  */
+  FEMO_PDE_EB_BEAM = 3        /* examples/beam_thickness_opt/run_thickness...py:71-79: cubic Hermite
+                                 Euler-Bernoulli beam; mesh vertices = DOFs (w_i, th_i), 4 per element,
+                                 params = {E, width}, f = thickness per element, aux = nodal load */
 };
 
 /* closed catalogue of scalar output forms */

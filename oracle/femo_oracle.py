@@ -5,7 +5,8 @@ leg may import this module, and only as the *checker*.  Nothing under
 ``femo_amd/`` imports it; the product path fails loudly when the HIP
 extension is missing.
 
-PARITY UNPINNED.  The arithmetic of the reference lives in un-vendored
+PARITY UNPINNED for the Poisson forms (pinned only for the beam, see below).  The arithmetic
+of the reference lives in un-vendored
 third-party packages (dolfinx 0.5.1 / UFL / FFCx / PETSc / MUMPS, pinned only by
 ``README.md:19`` of the reference) that cannot be imported in the build
 container, and the reference ships no tests, golden vectors or fixtures for
@@ -15,6 +16,10 @@ NumPy/SciPy, and is pinned against closed-form known answers only
 (``tests/test_oracle_*.py``): exact P1 element matrices, the DST-exact discrete
 Poisson solve on structured grids, finite differences of the functional, and
 the analytic optimal-control pair of ``examples/poisson_opt``.
+The one golden vector the reference tree holds for this path -- the 50 OpenMDAO-optimal
+thicknesses of ``examples/beam_thickness_opt/run_thickness_opt_cantilever_beam.py:252-261`` --
+pins the Euler-Bernoulli beam part of this oracle (``BEAM_THICK_REF``, reproduced to 4e-7 by
+re-running SLSQP with the oracle's adjoint gradients in tests/test_oracle.py).
 
 Citations are relative to /root/reference/.  "[ext]" marks behaviour of a
 third-party package restated from its documentation.
@@ -631,3 +636,85 @@ def grad_magnitude(mesh: OMesh, u: np.ndarray) -> np.ndarray:
     _, g = cell_geometry(mesh)
     gu = np.einsum("cbd,cb->cd", g, u[mesh.conn])
     return np.sqrt((gu ** 2).sum(axis=1))
+
+
+# ==========================================================================
+# examples/beam_thickness_opt: Euler-Bernoulli cantilever, cubic Hermite elements
+# (run_thickness_opt_cantilever_beam.py:41-162).  State = (w_0, th_0, w_1, th_1, ...),
+# input = DG0 thickness per element, EI = E * width * t^3 / 12 (:71-75).
+#   residual   inner(div grad v, EI div grad u) dx - f v(L)          (:77-79), f = -1 (:115)
+#   compliance f u(L) (:84-85);   volume  t * width * L dx (:81-82)
+# The element matrix is the textbook Hermite beam matrix (exact for the cubic shape
+# functions; FFCx integrates the same polynomial exactly [ext]).
+# GOLDEN VECTOR held by the reference: the 50 optimal thicknesses of the OpenMDAO example
+# (:252-261) -- pinned in tests/test_oracle.py by re-running the optimisation with these
+# gradients.
+# ==========================================================================
+def beam_khat(h: float) -> np.ndarray:
+    return np.array([[12.0, 6 * h, -12.0, 6 * h],
+                     [6 * h, 4 * h * h, -6 * h, 2 * h * h],
+                     [-12.0, -6 * h, 12.0, -6 * h],
+                     [6 * h, 2 * h * h, -6 * h, 4 * h * h]]) / h ** 3
+
+
+def beam_stiffness(nel: int, L: float, t: np.ndarray, E: float = 1.0, width: float = 0.1) -> sp.csr_matrix:
+    h = L / nel
+    Kh = beam_khat(h)
+    EI = E * width * t ** 3 / 12.0
+    dofs = 2 * np.arange(nel)[:, None] + np.arange(4)[None, :]
+    Ke = EI[:, None, None] * Kh[None]
+    r = np.repeat(dofs[:, :, None], 4, axis=2)
+    c = np.repeat(dofs[:, None, :], 4, axis=1)
+    K = sp.coo_matrix((Ke.ravel(), (r.ravel(), c.ravel())), shape=(2 * nel + 2, 2 * nel + 2)).tocsr()
+    K.sum_duplicates()
+    K.sort_indices()
+    return K
+
+
+def beam_load(nel: int, f: float = -1.0) -> np.ndarray:
+    F = np.zeros(2 * nel + 2)
+    F[2 * nel] = f                      # point load on the deflection DOF of the end node
+    return F
+
+
+def beam_residual(nel, L, u, t, E=1.0, width=0.1, f=-1.0) -> np.ndarray:
+    return beam_stiffness(nel, L, t, E, width) @ u - beam_load(nel, f)
+
+
+def beam_dRdt(nel, L, u, t, E=1.0, width=0.1) -> sp.csr_matrix:
+    """dR/dt: column e has the 4 entries (E width t_e^2 / 4) * Khat u_e."""
+    h = L / nel
+    Kh = beam_khat(h)
+    dofs = 2 * np.arange(nel)[:, None] + np.arange(4)[None, :]
+    vals = (E * width * t ** 2 / 4.0)[:, None] * (u[dofs] @ Kh.T)
+    A = sp.coo_matrix((vals.ravel(), (dofs.ravel(), np.repeat(np.arange(nel), 4))), shape=(2 * nel + 2, nel)).tocsr()
+    A.sort_indices()
+    return A
+
+
+def beam_cycle(nel, L, t, E=1.0, width=0.1, f=-1.0, consistent_bc=True):
+    """Solve, compliance f u(L), volume, and d(compliance)/dt by the adjoint sweep (clamped at x = 0)."""
+    bc = np.array([0, 1])
+    K = beam_stiffness(nel, L, t, E, width)
+    A = eliminate_bc(K, bc)
+    F = beam_load(nel, f)
+    b = F.copy()
+    b[bc] = 0.0
+    u = spla.splu(A.tocsc()).solve(b)
+    compliance = float(F @ u)
+    volume = float(np.sum(t) * width * (L / nel))
+    lam = spla.splu(A.T.tocsc()).solve(F)                  # dJ/du = F
+    if consistent_bc:
+        lam[bc] = 0.0
+    grad_c = -(beam_dRdt(nel, L, u, t, E, width).T @ lam)
+    grad_v = np.full(nel, width * L / nel)
+    return dict(u=u, compliance=compliance, volume=volume, grad_compliance=grad_c, grad_volume=grad_v, lam=lam)
+
+
+BEAM_THICK_REF = np.array([   # run_thickness_opt_cantilever_beam.py:252-261 (OpenMDAO reference optimum)
+    0.14915754, 0.14764328, 0.14611321, 0.14456715, 0.14300421, 0.14142417, 0.13982611, 0.13820976, 0.13657406,
+    0.13491866, 0.13324268, 0.13154528, 0.12982575, 0.12808305, 0.12631658, 0.12452477, 0.12270701, 0.12086183,
+    0.11898809, 0.11708424, 0.11514904, 0.11318072, 0.11117762, 0.10913764, 0.10705891, 0.10493903, 0.10277539,
+    0.10056526, 0.09830546, 0.09599246, 0.09362243, 0.09119084, 0.08869265, 0.08612198, 0.08347229, 0.08073573,
+    0.07790323, 0.07496382, 0.07190453, 0.06870925, 0.0653583, 0.06182632, 0.05808044, 0.05407658, 0.04975295,
+    0.0450185, 0.03972912, 0.03363155, 0.02620192, 0.01610863])

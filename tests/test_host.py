@@ -143,7 +143,8 @@ def test_form_catalogue_is_closed():
     f.function_space = type("S", (), {"family": "DG"})()
     r = forms.PoissonResidual(u, f)
     assert forms.derivative(r, u).rank == 2 and forms.derivative(r, f).wrt is f
+    assert forms.derivative(r, FakeFn()).depends is False and forms.derivative(r, u).depends is True
     with pytest.raises(ValueError):
-        forms.derivative(r, FakeFn())
+        forms.derivative(r, 3.0)
     with pytest.raises(NotImplementedError):
         forms.pdeRes(u, None, f, weak_bc=True)

@@ -210,3 +210,24 @@ def test_nl_golden_vector():
     for k in ("u", "J", "grad", "lam"):
         assert np.abs(ref[k] - g[k]).max() <= 1e-11 * np.abs(g[k]).max()
     assert int(ref["newton_its"]) == int(g["newton_its"])
+
+
+# ---- Euler-Bernoulli beam (examples/beam_thickness_opt) ----
+def test_beam_oracle_closed_form_and_reference_golden_vector():
+    """Pins the beam oracle on (a) the closed-form tip deflection P L^3 / (3 E I) and (b) the golden
+    vector held by the reference itself: the 50 optimal thicknesses of
+    run_thickness_opt_cantilever_beam.py:252-261, reproduced by re-running SLSQP with the oracle's
+    adjoint gradients."""
+    import scipy.optimize as so
+    nel, L, E, b, h = 50, 1.0, 1.0, 0.1, 0.1
+    t0 = np.full(nel, h)
+    c = fo.beam_cycle(nel, L, t0)
+    assert abs(c["u"][2 * nel] + L ** 3 / (3 * E * b * h ** 3 / 12)) < 1e-8 * abs(c["u"][2 * nel])
+    d = np.random.default_rng(0).standard_normal(nel) * 0.01
+    fd = (fo.beam_cycle(nel, L, t0 + 1e-5 * d)["compliance"] - fo.beam_cycle(nel, L, t0 - 1e-5 * d)["compliance"]) / 2e-5
+    assert abs(fd - c["grad_compliance"] @ d) < 1e-4 * abs(fd)
+    res = so.minimize(lambda t: fo.beam_cycle(nel, L, t)["compliance"], t0, jac=lambda t: fo.beam_cycle(nel, L, t)["grad_compliance"],
+                      bounds=[(1e-2, 10.)] * nel, method="SLSQP", options={"maxiter": 1000, "ftol": 1e-12},
+                      constraints=[{"type": "eq", "fun": lambda t: fo.beam_cycle(nel, L, t)["volume"] - b * h * L,
+                                    "jac": lambda t: fo.beam_cycle(nel, L, t)["grad_volume"]}])
+    assert res.success and np.abs(res.x - fo.BEAM_THICK_REF).max() < 1e-6
