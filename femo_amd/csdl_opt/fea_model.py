@@ -1,48 +1,37 @@
-"""Mirror of femo/csdl_opt/fea_model.py:5-38: one StateModel per state and one
-OutputModel per output of every FEA in the list; sub-model names
-'{name}_state_model' / '{name}_output_model'."""
+"""``FEAModel(fea=[...])``: the composite CSDL model of femo (reference: femo/csdl_opt/fea_model.py).
+
+For every FEA in the list it adds one sub-model per registered state, scalar output and field output,
+named ``'<name>_state_model'`` / ``'<name>_output_model'`` -- the names the reference's run scripts
+address (``sim['l2_functional_output_model.l2_functional']``, run_poisson_opt.py:239).
+"""
 from femo_amd.csdl_opt._csdl_compat import Model
+from femo_amd.csdl_opt.output_model import OutputFieldModel, OutputModel
 from femo_amd.csdl_opt.state_model import StateModel
-from femo_amd.csdl_opt.output_model import OutputModel, OutputFieldModel
+
+# (FEA registry, sub-model class, name suffix, keyword of the registered name)
+_WIRING = (
+    ('states_dict', StateModel, 'state_model', 'state_name'),
+    ('outputs_dict', OutputModel, 'output_model', 'output_name'),
+    ('outputs_field_dict', OutputFieldModel, 'output_model', 'output_name'),
+)
 
 
 class FEAModel(Model):
-    # The reference hard-codes debug_mode=True for every StateModel (fea_model.py:15),
-    # which prints a banner per operator call; default to quiet, opt in per class/instance.
+    # The reference switches the per-call banners of every StateModel on (fea_model.py:15);
+    # here they are opt-in: set ``FEAModel.debug_mode = True`` (class or instance).
     debug_mode = False
 
     def initialize(self):
         self.parameters.declare('fea')
 
     def define(self):
-        self.fea_list = fea_list = self.parameters['fea']
-        if not isinstance(fea_list, (list, tuple)):
-            raise TypeError("FEAModel(fea=[...]) takes a list of FEA objects (fea_model.py:10-11)")
-        for fea in fea_list:
-            for state_name in fea.states_dict:
-                arg_name_list_state = fea.states_dict[state_name]['arguments']
-                state_model = StateModel(fea=fea,
-                                         debug_mode=self.debug_mode,
-                                         state_name=state_name,
-                                         arg_name_list=arg_name_list_state)
-
-                self.add(state_model,
-                         name='{}_state_model'.format(state_name))
-
-            for output_name in fea.outputs_dict:
-                arg_name_list_output = fea.outputs_dict[output_name]['arguments']
-                output_model = OutputModel(fea=fea,
-                                           output_name=output_name,
-                                           arg_name_list=arg_name_list_output)
-
-                self.add(output_model,
-                         name='{}_output_model'.format(output_name))
-
-            for output_name in fea.outputs_field_dict:
-                arg_name_list_output = fea.outputs_field_dict[output_name]['arguments']
-                output_model = OutputFieldModel(fea=fea,
-                                                output_name=output_name,
-                                                arg_name_list=arg_name_list_output)
-
-                self.add(output_model,
-                         name='{}_output_model'.format(output_name))
+        self.fea_list = self.parameters['fea']
+        if not isinstance(self.fea_list, (list, tuple)):
+            raise TypeError("FEAModel(fea=[...]) takes a list of FEA objects")
+        for fea in self.fea_list:
+            for registry, model_cls, suffix, key in _WIRING:
+                for name, entry in getattr(fea, registry).items():
+                    kwargs = {'fea': fea, key: name, 'arg_name_list': list(entry['arguments'])}
+                    if model_cls is StateModel:
+                        kwargs['debug_mode'] = self.debug_mode
+                    self.add(model_cls(**kwargs), name=f'{name}_{suffix}')

@@ -1,175 +1,102 @@
-"""Mirror of femo/csdl_opt/output_model.py (scalar outputs, lines 7-87) on the HIP engine.
+"""The explicit output operators of femo's CSDL layer on the HIP engine.
 
-``OutputFieldModel`` / ``OutputFieldOperation`` (output_model.py:90-159) project a catalogue
-field expression onto CG1 (mass-matrix Jacobi-CG on the device).
+Public surface = the reference's femo/csdl_opt/output_model.py: ``OutputModel`` /
+``OutputOperation`` for scalar functionals (value + partials w.r.t. every argument) and
+``OutputFieldModel`` / ``OutputFieldOperation`` for L2-projected fields (value only; the reference
+leaves their derivatives undeclared, output_model.py:147).  Model parameters ``fea, output_name,
+arg_name_list``; operation parameters ``fea, args_dict, output_name``.
 """
-from femo_amd.fea.fea_hip import *                     # noqa: F401,F403  (output_model.py:1)
-from femo_amd.fea.fea_hip import FEA
-from femo_amd.fea.utils_hip import DeviceArray, assemble, computePartials, getFuncArray, update
-from femo_amd.csdl_opt._csdl_compat import Model, CustomExplicitOperation, custom
 import numpy as np
 
-
-class OutputModel(Model):
-    """output_model.py:7-38"""
-
-    def initialize(self):
-        self.parameters.declare('fea', types=FEA)
-        self.parameters.declare('output_name', types=str)
-        self.parameters.declare('arg_name_list', types=list)
-
-    def define(self):
-        self.fea = self.parameters['fea']
-        arg_name_list = self.parameters['arg_name_list']
-        output_name = self.parameters['output_name']
-
-        args_dict = dict()
-        args_list = []
-        for arg_name in arg_name_list:
-            if arg_name in self.fea.inputs_dict:
-                args_dict[arg_name] = self.fea.inputs_dict[arg_name]
-            elif arg_name in self.fea.states_dict:
-                args_dict[arg_name] = self.fea.states_dict[arg_name]
-            arg = self.declare_variable(arg_name,
-                                        shape=(args_dict[arg_name]['shape'],),
-                                        val=1.0)
-            args_list.append(arg)
-
-        e = OutputOperation(fea=self.fea,
-                            args_dict=args_dict,
-                            output_name=output_name,
-                            )
-        output = custom(*args_list, op=e)
-        output_ = self.register_output(output_name, output)
-        self.print_var(output_)
+from femo_amd.csdl_opt._common import declare_all, gather_arguments, push_functions, stays_on_device
+from femo_amd.csdl_opt._csdl_compat import CustomExplicitOperation, Model, custom
+from femo_amd.fea.fea_hip import FEA
+from femo_amd.fea.utils_hip import assemble, computePartials, getFuncArray
 
 
-class OutputOperation(CustomExplicitOperation):
-    """
-    input: input/state variables
-    output: output
-    (output_model.py:40-87)
-    """
+class _OutputOperationBase(CustomExplicitOperation):
+    registry = 'outputs_dict'          # which FEA dict holds the output entry
 
     def initialize(self):
-        self.parameters.declare('fea')
-        self.parameters.declare('args_dict')
-        self.parameters.declare('output_name')
+        declare_all(self.parameters, [('fea',), ('args_dict',), ('output_name',)])
 
     def define(self):
-        self.fea = self.parameters['fea']
-        self.output_name = output_name = self.parameters['output_name']
-        self.args_dict = args_dict = self.parameters['args_dict']
-        for arg_name in args_dict:
-            arg = args_dict[arg_name]
-            self.add_input(arg_name,
-                           shape=(arg['shape'],),)
-        self.output = self.fea.outputs_dict[output_name]
+        P = self.parameters
+        self.fea, self.output_name, self.args_dict = P['fea'], P['output_name'], P['args_dict']
+        for name, entry in self.args_dict.items():
+            self.add_input(name, shape=(entry['shape'],))
+        self.output = getattr(self.fea, self.registry)[self.output_name]
         self.output_size = self.output['shape']
-        # for field output
-        self.output_dim = 1
-        # for scalar output
-        if self.output_size == 1:
-            self.output_dim = 0
-        self.add_output(output_name,
-                        shape=(self.output_size,))
+        self.output_dim = self._dimension()
+        self.add_output(self.output_name, shape=(self.output_size,))
+        self._declare()
+
+    def _dimension(self) -> int:
+        return 1
+
+    def _declare(self) -> None:
+        pass
+
+
+class OutputOperation(_OutputOperationBase):
+    """Scalar functional J(arguments) (output_model.py:40-87)."""
+
+    def _dimension(self) -> int:
+        return 0 if self.output_size == 1 else 1        # 0: scalar, 1: field-valued form
+
+    def _declare(self) -> None:
         self.declare_derivatives('*', '*')
 
     def compute(self, inputs, outputs):
         """output_model.py:69-75"""
-        for arg_name in inputs:
-            arg = self.args_dict[arg_name]
-            update(arg['function'], inputs[arg_name])
-
-        outputs[self.output_name] = np.array(assemble(self.output['form'],
-                                                      dim=self.output_dim))
+        push_functions(self.args_dict, inputs)
+        outputs[self.output_name] = np.array(assemble(self.output['form'], dim=self.output_dim))
 
     def compute_derivatives(self, inputs, derivatives):
-        """output_model.py:77-87"""
-        for arg_name in inputs:
-            arg = self.args_dict[arg_name]
-            update(arg['function'], inputs[arg_name])
-
-        dev = any(isinstance(inputs[k], DeviceArray) for k in inputs)
-        for arg_name in self.args_dict:
-            derivatives[self.output_name, arg_name] = assemble(
-                                    computePartials(
-                                        self.output['form'],
-                                        self.args_dict[arg_name]['function']),
-                                    dim=self.output_dim + 1, device=dev)
+        """One assembled partial per argument, rank = output rank + 1 (output_model.py:77-87)."""
+        push_functions(self.args_dict, inputs)
+        dev = stays_on_device(inputs)
+        form = self.output['form']
+        for name, entry in self.args_dict.items():
+            derivatives[self.output_name, name] = assemble(computePartials(form, entry['function']),
+                                                           dim=self.output_dim + 1, device=dev)
 
 
-class OutputFieldModel(Model):
-    """output_model.py:90-120"""
-
-    def initialize(self):
-        self.parameters.declare('fea', types=FEA)
-        self.parameters.declare('output_name', types=str)
-        self.parameters.declare('arg_name_list', types=list)
-
-    def define(self):
-        self.fea = self.parameters['fea']
-        arg_name_list = self.parameters['arg_name_list']
-        output_name = self.parameters['output_name']
-
-        args_dict = dict()
-        args_list = []
-        for arg_name in arg_name_list:
-            if arg_name in self.fea.inputs_dict:
-                args_dict[arg_name] = self.fea.inputs_dict[arg_name]
-            elif arg_name in self.fea.states_dict:
-                args_dict[arg_name] = self.fea.states_dict[arg_name]
-            arg = self.declare_variable(arg_name,
-                                        shape=(args_dict[arg_name]['shape'],),
-                                        val=1.0)
-            args_list.append(arg)
-
-        e = OutputFieldOperation(fea=self.fea,
-                                 args_dict=args_dict,
-                                 output_name=output_name,
-                                 )
-        output = custom(*args_list, op=e)
-        self.register_output(output_name, output)
-
-
-class OutputFieldOperation(CustomExplicitOperation):
-    """
-    input: input/state variables
-    output: output  (L2-projected field; no derivatives declared, output_model.py:122-159)
-    """
-
-    def initialize(self):
-        self.parameters.declare('fea')
-        self.parameters.declare('args_dict')
-        self.parameters.declare('output_name')
-
-    def define(self):
-        self.fea = self.parameters['fea']
-        self.output_name = output_name = self.parameters['output_name']
-        self.args_dict = args_dict = self.parameters['args_dict']
-        for arg_name in args_dict:
-            arg = args_dict[arg_name]
-            self.add_input(arg_name,
-                           shape=(arg['shape'],),)
-        self.output = self.fea.outputs_field_dict[output_name]
-        self.output_size = self.output['shape']
-        # for field output
-        self.output_dim = 1
-
-        self.add_output(output_name,
-                        shape=(self.output_size,))
-        # self.declare_derivatives('*', '*')
+class OutputFieldOperation(_OutputOperationBase):
+    """CG1 field obtained by L2 projection of the output's expression (output_model.py:122-159)."""
+    registry = 'outputs_field_dict'
 
     def compute(self, inputs, outputs):
-        """output_model.py:149-159"""
-        for arg_name in inputs:
-            arg = self.args_dict[arg_name]
-            update(arg['function'], inputs[arg_name])
+        push_functions(self.args_dict, inputs)
+        out = self.output
+        self.fea.projectFieldOutput(out['form'], out['func'])
+        if out['record']:
+            out['recorder'].write_function(out['func'], self.fea.opt_iter)
+        outputs[self.output_name] = getFuncArray(out['func'], device=stays_on_device(inputs))
 
-        self.fea.projectFieldOutput(self.output['form'], self.output['func'])
-        if self.output['record']:
-            self.output['recorder'].write_function(self.output['func'],
-                                                   self.fea.opt_iter)
 
-        dev = any(isinstance(inputs[k], DeviceArray) for k in inputs)
-        outputs[self.output_name] = getFuncArray(self.output['func'], device=dev)
+class _OutputModelBase(Model):
+    operation = OutputOperation
+
+    def initialize(self):
+        declare_all(self.parameters, [('fea', dict(types=FEA)), ('output_name', dict(types=str)),
+                                      ('arg_name_list', dict(types=list))])
+
+    def define(self):
+        P = self.parameters
+        self.fea = P['fea']
+        args_dict = gather_arguments(self.fea, P['arg_name_list'], allow_states=True)
+        variables = [self.declare_variable(name, shape=(entry['shape'],), val=1.0)
+                     for name, entry in args_dict.items()]
+        op = self.operation(fea=self.fea, args_dict=args_dict, output_name=P['output_name'])
+        self.print_var(self.register_output(P['output_name'], custom(*variables, op=op)))
+
+
+class OutputModel(_OutputModelBase):
+    """output_model.py:7-38"""
+    operation = OutputOperation
+
+
+class OutputFieldModel(_OutputModelBase):
+    """output_model.py:90-120"""
+    operation = OutputFieldOperation

@@ -1,9 +1,12 @@
-"""Mirror of femo/fea/fea_dolfinx.py: the ``FEA`` registry on the HIP engine.
+"""``FEA``: the per-PDE registry of femo on the HIP engine (reference: femo/fea/fea_dolfinx.py:70-234).
 
-Same attributes, method names, dict layouts and call order as the reference's
-``FEA`` (fea_dolfinx.py:70-234); forms come from the closed catalogue in
-``forms.py`` instead of UFL, and every dolfinx/PETSc call is replaced by the
-``utils_hip`` function of the same name.
+Same public attributes (``inputs_dict, states_dict, outputs_dict, outputs_field_dict, bc, PDE_SOLVER,
+REPORT, custom_solve, opt_iter, initial_solve, initialize, record, recorder_path, linear_problem``), the
+same registration methods and entry layouts, and the same solve entry points (``solve``,
+``solveLinearFwd``, ``solveLinearBwd``, ``projectFieldOutput``).  Forms come from the closed catalogue
+(``forms.py``, ``nonlinear_poisson.py``, ``beam.py``) instead of UFL; every dolfinx/PETSc call is the
+``utils_hip`` function of the same name.  Like the reference module, this one re-exports the utility
+layer so that run scripts can ``from ...fea_hip import *``.
 """
 from __future__ import annotations
 
@@ -11,197 +14,143 @@ import os
 
 import numpy as np
 
-from .utils_hip import *          # noqa: F401,F403  (the reference star-imports its utils too, fea_dolfinx.py:5)
+from .utils_hip import *          # noqa: F401,F403  re-export (the reference does the same, fea_dolfinx.py:5)
 from .utils_hip import (DeviceArray, DirichletBC, KSP, dirichletbc, getFuncArray, project, setFuncArray,
                         solveKSP_mumps, solveNonlinear, transpose)
-from .forms import (ALPHA, DerivativeForm, FieldExpression, Form, FunctionExpr, GradientMagnitude,
-                    L2TrackingFunctional, NonlinearPoissonResidual, PoissonResidual, PowerExpr, TestFunction,
-                    derivative, interiorResidual, outputForm, pdeRes)
+from .forms import (ALPHA, BeamResidual, DerivativeForm, FieldExpression, Form, FunctionExpr, GradientMagnitude,
+                    L2TrackingFunctional, LinearFunctional, NonlinearPoissonResidual, PoissonResidual, PowerExpr,
+                    TestFunction, derivative, interiorResidual, outputForm, pdeRes)
 from .function import Function, FunctionSpace
 from .mesh import (BeamMesh, Mesh, createIntervalMesh, createUnitCubeMesh, createUnitSquareMesh,
                    locate_dofs_geometrical)
 
 
-class _NullRecorder:
-    """XDMF recorders (fea_dolfinx.py:228-234) are out of scope:
-    ``record=True`` writes raw ``.npy`` snapshots instead."""
+class SnapshotRecorder:
+    """Stands in for the XDMF time-series writers (fea_dolfinx.py:228-234; out of scope, SURVEY.md
+    section 8(f) rank 4): ``write_function`` stores raw ``.npy`` snapshots keyed by the iteration."""
 
-    def __init__(self, path: str):
-        self.path = path
-        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    def __init__(self, stem: str):
+        self.stem = stem
+        os.makedirs(os.path.dirname(stem) or ".", exist_ok=True)
 
     def write_mesh(self, mesh) -> None:
-        np.savez(self.path + "_mesh.npz", x=mesh.x, conn=mesh.conn)
+        np.savez(self.stem + "_mesh.npz", x=mesh.x, conn=mesh.conn)
 
     def write_function(self, function, t=0) -> None:
-        np.save(f"{self.path}_{int(t):05d}.npy", function.vector.getArray())
+        np.save(f"{self.stem}_{int(t):05d}.npy", function.vector.getArray())
 
 
 class FEA(object):
-    """
-    The class of the FE wrapper: registers inputs / states / outputs of one PDE
-    and provides the nonlinear and the linearised forward / transposed solves.
-    (fea_dolfinx.py:70-234)
-    """
+    """Registers inputs, states and outputs of one PDE problem and owns its nonlinear and linearised
+    solves."""
 
     def __init__(self, mesh):
         self.mesh = mesh
-
-        self.inputs_dict = dict()
-        self.states_dict = dict()
-        self.outputs_dict = dict()
-        self.outputs_field_dict = dict()
+        self.inputs_dict, self.states_dict = {}, {}
+        self.outputs_dict, self.outputs_field_dict = {}, {}
         self.bc = []
-
-        self.PDE_SOLVER = "Newton"
-        self.REPORT = True
-
+        # solver switches read by solve() / StateOperation.define (fea_dolfinx.py:87-98)
+        self.PDE_SOLVER, self.REPORT = "Newton", True
         self.ubc = None
-        self.custom_solve = None
-
+        self.custom_solve, self.initial_solve = None, True
         self.opt_iter = 0
-        self.initial_solve = True
         self.initialize = False
-        self.record = False
-        self.recorder_path = "records"
+        self.record, self.recorder_path = False, "records"
         self.linear_problem = False
-        # not in the reference: zero the Dirichlet rows of dR/du and dR/df in the
-        # jac-vec products (the reference keeps them, SURVEY.md section 0 finding 5)
-        self.consistent_bc_partials = False
+        # additions (not in the reference)
+        self.consistent_bc_partials = False   # zero Dirichlet rows of dR/du, dR/df in the jac-vec products
+        self.reference_fwd_bug = False        # reproduce solveLinearFwd's zeros (fea_dolfinx.py:192-206)
+
+    # ------------------------------------------------------------------ registration ----
+    def _recorded(self, name, record, **fields):
+        entry = dict(fields)
+        entry['recorder'] = self.createRecorder(name, record)
+        entry['record'] = record
+        return entry
 
     def add_input(self, name, function, init_val=1.0, record=False):
-        """fea_dolfinx.py:100-110"""
+        """Every DOF of ``function`` is set to ``init_val``; duplicate names are an error
+        (fea_dolfinx.py:100-110)."""
         if name in self.inputs_dict:
             raise ValueError('name has already been used for an input')
         function.x.array[:] = init_val
-        self.inputs_dict[name] = dict(
-            function=function,
-            function_space=function.function_space,
-            shape=len(getFuncArray(function)),
-            recorder=self.createRecorder(name, record),
-            record=record
-        )
+        self.inputs_dict[name] = self._recorded(name, record, function=function,
+                                                function_space=function.function_space,
+                                                shape=len(getFuncArray(function)))
 
-    def add_state(self, name, function, residual_form, arguments,
-                  dR_du=None, dR_df_list=None, record=False):
-        """fea_dolfinx.py:112-127"""
-        self.states_dict[name] = dict(
-            function=function,
-            residual_form=residual_form,
-            function_space=function.function_space,
-            shape=len(getFuncArray(function)),
-            d_residual=Function(function.function_space),
-            d_state=Function(function.function_space),
-            dR_du=dR_du,
-            dR_df_list=dR_df_list,
-            arguments=arguments,
-            recorder=self.createRecorder(name, record),
-            record=record
-        )
+    def add_state(self, name, function, residual_form, arguments, dR_du=None, dR_df_list=None, record=False):
+        """Besides the state Function the entry carries two work Functions of the same space for the
+        linearised solves (fea_dolfinx.py:112-127)."""
+        V = function.function_space
+        self.states_dict[name] = self._recorded(
+            name, record, function=function, residual_form=residual_form, function_space=V,
+            shape=len(getFuncArray(function)), d_residual=Function(V), d_state=Function(V),
+            dR_du=dR_du, dR_df_list=dR_df_list, arguments=arguments)
 
     def add_output(self, name, type, form, arguments):
-        """fea_dolfinx.py:129-146.  type='field' is broken in the reference
-        (undefined getFormArray, :131); it raises here as well."""
+        """Scalar functional + its symbolic partials per argument (fea_dolfinx.py:129-146).  The
+        reference's type='field' branch calls an undefined helper (:131); use add_field_output."""
         if type == 'field':
-            raise NotImplementedError("add_output(type='field') calls an undefined helper in the reference; "
-                                      "use add_field_output")
-        elif type == 'scalar':
-            shape = 1
-        else:
+            raise NotImplementedError("add_output(type='field') is broken in the reference (undefined "
+                                      "getFormArray); use add_field_output")
+        if type != 'scalar':
             raise ValueError(f"unknown output type {type!r}")
         partials = []
-        for argument in arguments:
-            if argument in self.inputs_dict:
-                partial = derivative(form, self.inputs_dict[argument]['function'])
-            elif argument in self.states_dict:
-                partial = derivative(form, self.states_dict[argument]['function'])
-            else:
-                raise KeyError(f"output argument {argument!r} is neither an input nor a state")
-            partials.append(partial)
-        self.outputs_dict[name] = dict(
-            form=form,
-            shape=shape,
-            arguments=arguments,
-            partials=partials,
-        )
+        for arg in arguments:
+            owner = self.inputs_dict if arg in self.inputs_dict else self.states_dict
+            if arg not in owner:
+                raise KeyError(f"output argument {arg!r} is neither an input nor a state")
+            partials.append(derivative(form, owner[arg]['function']))
+        self.outputs_dict[name] = dict(form=form, shape=1, arguments=arguments, partials=partials)
 
     def add_field_output(self, name, form, arguments, record=False):
-        """fea_dolfinx.py:148-161: a CG1 field obtained by L2 projection of ``form``
-        (a catalogue FieldExpression instead of a UFL expression)."""
-        V = FunctionSpace(self.mesh, ("CG", 1))
-        output_func = Function(V)
-        partials = []
-        self.outputs_field_dict[name] = dict(
-            form=form,
-            func=output_func,
-            shape=len(getFuncArray(output_func)),
-            arguments=arguments,
-            partials=partials,
-            recorder=self.createRecorder(name, record),
-            record=record
-        )
+        """CG1 field obtained by L2 projection of ``form`` (fea_dolfinx.py:148-161)."""
+        func = Function(FunctionSpace(self.mesh, ("CG", 1)))
+        self.outputs_field_dict[name] = self._recorded(name, record, form=form, func=func,
+                                                       shape=len(getFuncArray(func)), arguments=arguments,
+                                                       partials=[])
 
     def add_exact_solution(self, Expression, function_space):
-        """fea_dolfinx.py:163-167"""
-        f_analytic = Expression()
+        """Interpolant of ``Expression().eval`` (fea_dolfinx.py:163-167)."""
         f_ex = Function(function_space)
-        f_ex.interpolate(f_analytic.eval)
+        f_ex.interpolate(Expression().eval)
         return f_ex
 
     def add_strong_bc(self, ubc, locate_BC_list, function_space=None):
-        """fea_dolfinx.py:169-176"""
-        if function_space == None:
-            for locate_BC in locate_BC_list:
-                self.bc.append(dirichletbc(ubc, locate_BC))
-        else:
-            for locate_BC in locate_BC_list:
-                self.bc.append(dirichletbc(ubc, locate_BC, function_space))
+        """One Dirichlet condition per located DOF set (fea_dolfinx.py:169-176)."""
+        self.bc.extend(dirichletbc(ubc, dofs, function_space) for dofs in locate_BC_list)
 
+    # ------------------------------------------------------------------------ solves ----
     def solve(self, res, func, bc):
-        """
-        Solve the PDE problem (fea_dolfinx.py:178-189)
-        """
-        solver_type = self.PDE_SOLVER
-        report = self.REPORT
-        initialize = self.initialize
+        """R(func) = 0 by the user hook or by solveNonlinear(PDE_SOLVER) (fea_dolfinx.py:178-189)."""
         if self.custom_solve is not None and self.initial_solve == True:
-            self.custom_solve(res, func, bc, report)
+            self.custom_solve(res, func, bc, self.REPORT)
         else:
-            solveNonlinear(res, func, bc, solver_type, report, initialize)
+            solveNonlinear(res, func, bc, self.PDE_SOLVER, self.REPORT, self.initialize)
+
+    def _linear_solve(self, operator, rhs_fn, rhs_values, sol_fn, ksp, device):
+        setFuncArray(rhs_fn, rhs_values)
+        sol_fn.vector.set(0.0)
+        if ksp is None:
+            solveKSP_mumps(operator, rhs_fn.vector, sol_fn.vector)
+        else:
+            ksp.solve(rhs_fn.vector, sol_fn.vector)
+        return getFuncArray(sol_fn, device=device)
 
     def solveLinearFwd(self, du, A, dR, dR_array, ksp=None, device=False):
-        """
-        solve linear system dR = dR_du (A) * du  (fea_dolfinx.py:192-206)
-
-        The reference passes (b=du, x=dR) to the solver and returns ``du``, i.e. zeros
-        (SURVEY.md section 8 row a13).  This implements the documented intent
-        du = A^{-1} dR; set ``FEA.reference_fwd_bug = True`` to get the zeros.
-        """
-        setFuncArray(dR, dR_array)
-        du.vector.set(0.0)
-        if not getattr(self, "reference_fwd_bug", False):
-            if ksp is None:
-                solveKSP_mumps(A, dR.vector, du.vector)
-            else:
-                ksp.solve(dR.vector, du.vector)
-        du.vector.assemble()
-        du.vector.ghostUpdate()
-        return getFuncArray(du, device=device)
+        """du = A^-1 dR.  The reference swaps right-hand side and solution and therefore returns
+        zeros (fea_dolfinx.py:192-206); the documented intent is
+        implemented, ``reference_fwd_bug = True`` restores the zeros."""
+        if self.reference_fwd_bug:
+            setFuncArray(dR, dR_array)
+            du.vector.set(0.0)
+            return getFuncArray(du, device=device)
+        return self._linear_solve(A, dR, dR_array, du, ksp, device)
 
     def solveLinearBwd(self, dR, A, du, du_array, ksp=None, device=False):
-        """
-        solve linear system du = dR_du.T (A_T) * dR  (fea_dolfinx.py:208-222)
-        """
-        setFuncArray(du, du_array)
-
-        dR.vector.set(0.0)
-        if ksp is None:
-            solveKSP_mumps(transpose(A), du.vector, dR.vector)
-        else:
-            ksp.solve(du.vector, dR.vector)
-        dR.vector.assemble()
-        dR.vector.ghostUpdate()
-        return getFuncArray(dR, device=device)
+        """dR = A^-T du (fea_dolfinx.py:208-222).  With a cached ``ksp`` (linear_problem) the
+        reference solves with A itself; here the cached object solves the same (symmetric) system."""
+        return self._linear_solve(transpose(A), du, du_array, dR, ksp, device)
 
     def projectFieldOutput(self, form, func):
         """fea_dolfinx.py:224-225"""
@@ -209,8 +158,8 @@ class FEA(object):
 
     def createRecorder(self, name, record=False):
         """fea_dolfinx.py:228-234"""
-        recorder = None
-        if record or self.record:
-            recorder = _NullRecorder(self.recorder_path + "/record_" + name)
-            recorder.write_mesh(self.mesh)
+        if not (record or self.record):
+            return None
+        recorder = SnapshotRecorder(os.path.join(self.recorder_path, "record_" + name))
+        recorder.write_mesh(self.mesh)
         return recorder
