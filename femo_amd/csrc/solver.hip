@@ -249,9 +249,11 @@ __global__ void k_gather(int64_t n, const int32_t* __restrict__ perm, const doub
 //   k_cg_update_r            alpha = gamma/delta; rh -= alpha qh; partial rh.rh     (3 N)
 //   k_cg_update_xp           xh += alpha ph; ph = rh + beta ph; convergence flag    (5 N)
 // Scalars never visit the host: every block folds the producers' per-block partials
-// itself in a fixed order (FOLD = true), so all blocks see bitwise identical values.
-// With nranks > 1 a one-block fold + RCCL all-reduce sits between producer and
-// consumer and the consumers read the reduced scalars (FOLD = false).
+// itself in a fixed order, so all blocks see bitwise identical values.  With nranks > 1
+// the single-reduction recurrence further down is used instead (one fold + one RCCL
+// all-reduce per iteration).  Not captured in a hipGraph on purpose: every launch runs
+// >= 40 us at the sizes of interest against ~3.5 us of host cost per launch, and the
+// device-side boundary costs the same eagerly or replayed (MI355X_MICROARCH.md price list).
 // partial slots: 0 = delta, 1/2 = gamma of even/odd iterations, 3 = scratch.
 // scal: [0],[1] = gamma even/odd, [2] = delta, [3] = tol^2.   flags: [0] done, [1] iterations, [2] breakdown.
 constexpr int S_GAMMA = 0, S_DELTA = 2, S_TOL2 = 3;
@@ -270,9 +272,7 @@ __device__ __forceinline__ double femo_block_sum_bcast(double v, double* lds /* 
   return s;
 }
 
-template <bool FOLD>
-__device__ __forceinline__ double cg_scalar(const double* __restrict__ partials, int nb, const double* __restrict__ slot, double* lds) {
-  if (!FOLD) return *slot;
+__device__ __forceinline__ double cg_scalar(const double* __restrict__ partials, int nb, double* lds) {
   double a = 0.0;
   for (int i = threadIdx.x; i < nb; i += FEMO_BLOCK) a += partials[i];
   return femo_block_sum_bcast<FEMO_BLOCK>(a, lds);
@@ -331,15 +331,14 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_cg_init(int64_t n, const double*
 }
 
 // rh -= alpha qh ; partial rh.rh into the gamma slot of the next parity
-template <bool FOLD>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_cg_update_r(int64_t n, int cur, int nb_d, int nb_g,
                                                             double* __restrict__ partials, const double* __restrict__ scal,
                                                             const double* __restrict__ q, double* __restrict__ r,
                                                             const int32_t* __restrict__ done) {
   if (*done) return;
   __shared__ double lds[FEMO_BLOCK / 64];
-  const double gamma = cg_scalar<FOLD>(partials + (P_GAMMA + cur) * FEMO_MAX_PARTIALS, nb_g, scal + S_GAMMA + cur, lds);
-  const double delta = cg_scalar<FOLD>(partials + P_DELTA * FEMO_MAX_PARTIALS, nb_d, scal + S_DELTA, lds);
+  const double gamma = cg_scalar(partials + (P_GAMMA + cur) * FEMO_MAX_PARTIALS, nb_g, lds);
+  const double delta = cg_scalar(partials + P_DELTA * FEMO_MAX_PARTIALS, nb_d, lds);
   const double alpha = delta != 0.0 ? gamma / delta : 0.0;
   double s0 = 0.0;
   const int64_t n2 = n >> 1;
@@ -362,7 +361,6 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_cg_update_r(int64_t n, int cur, 
 }
 
 // xh += alpha ph ; then (unless converged) ph = rh + beta ph
-template <bool FOLD>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_cg_update_xp(int64_t n, int cur, int it, int nb_d, int nb_g,
                                                              const double* __restrict__ partials, const double* __restrict__ scal,
                                                              const double* __restrict__ r, double* __restrict__ p,
@@ -374,9 +372,9 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_cg_update_xp(int64_t n, int cur,
   if (stamp != 0 && stamp != it + 1) return;
   __shared__ double lds[FEMO_BLOCK / 64];
   const int nxt = cur ^ 1;
-  const double gamma = cg_scalar<FOLD>(partials + (P_GAMMA + cur) * FEMO_MAX_PARTIALS, nb_g, scal + S_GAMMA + cur, lds);
-  const double gamma1 = cg_scalar<FOLD>(partials + (P_GAMMA + nxt) * FEMO_MAX_PARTIALS, nb_g, scal + S_GAMMA + nxt, lds);
-  const double delta = cg_scalar<FOLD>(partials + P_DELTA * FEMO_MAX_PARTIALS, nb_d, scal + S_DELTA, lds);
+  const double gamma = cg_scalar(partials + (P_GAMMA + cur) * FEMO_MAX_PARTIALS, nb_g, lds);
+  const double gamma1 = cg_scalar(partials + (P_GAMMA + nxt) * FEMO_MAX_PARTIALS, nb_g, lds);
+  const double delta = cg_scalar(partials + P_DELTA * FEMO_MAX_PARTIALS, nb_d, lds);
   const double alpha = delta != 0.0 ? gamma / delta : 0.0;
   const bool bad = !(gamma1 == gamma1) || !(alpha == alpha);  // NaN: not SPD or diverged
   const bool converged = gamma1 <= scal[S_TOL2] || bad;
@@ -1033,8 +1031,8 @@ extern "C" int femo_solve_cg(const femo_mat* A_, int transpose, const femo_vec* 
         if (sample) FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev], st));
         FEMO_TRY(launch_spmv(A, A->d_valsS, w.p, w.q, P + P_DELTA * FEMO_MAX_PARTIALS, ctx->d_flags, true));
         if (sample) { FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev + 1], st)); ++n_ev; }
-        hipLaunchKernelGGL(k_cg_update_r<true>, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, gs, gv, P, ctx->d_scal, w.q, w.r, ctx->d_flags);
-        hipLaunchKernelGGL(k_cg_update_xp<true>, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, it, gs, gv, P, ctx->d_scal, w.r, w.p, w.xh, ctx->d_flags);
+        hipLaunchKernelGGL(k_cg_update_r, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, gs, gv, P, ctx->d_scal, w.q, w.r, ctx->d_flags);
+        hipLaunchKernelGGL(k_cg_update_xp, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, it, gs, gv, P, ctx->d_scal, w.r, w.p, w.xh, ctx->d_flags);
       }
     }
     FEMO_HIP_CHECK(hipGetLastError());

@@ -88,3 +88,27 @@ def test_halo_exchange_to_self(comm_ctx, n):
     E.assemble_residual(dm, 0, None, U, F, R)
     ref = fo.residual(ext, u_ext, f)[:nv]
     assert np.abs(R.get() - ref).max() < 1e-12 * np.abs(ref).max()
+
+
+def test_operator_stack_on_a_partitioned_mesh(comm_ctx):
+    """The SPMD path of bench.py --gpus N with one rank: DistMesh (owned rows + halo plan) through
+    FEA / FEAModel / Simulator, single-reduction CG, all-reduced dots; checked against the oracle."""
+    import bench as B
+    from femo_amd.dist import partition_mesh
+    from femo_amd.fea import utils_hip
+    from femo_amd.fea.mesh import createUnitCubeMesh
+    utils_hip.set_context(comm_ctx)
+    utils_hip.clear_workspaces()
+    n = 12
+    gmesh = createUnitCubeMesh(n, jitter=0.2)
+    mesh = partition_mesh(gmesh, 0, 1)
+    assert mesh.n_owned == gmesh.n_vert and len(mesh.local.nbr) == 0 and mesh.local.cell_owned.all()
+    sim, fea = B.build_problem(mesh, device=True)
+    f = B.source_fields(mesh, 1)[0]
+    g = np.asarray(B.one_cycle(sim, fea, f))
+    om = fo.unit_cube_mesh(n, jitter=0.2)
+    bd = fo.boundary_vertices_box(om.x)
+    ref = fo.reference_cycle(om, f, fo.u_target(om.x), bd, np.zeros(len(bd)))
+    assert np.abs(sim['u'] - ref['u']).max() < 1e-10 * np.abs(ref['u']).max()
+    assert np.abs(g - ref['grad']).max() < 1e-10 * np.abs(ref['grad']).max()
+    utils_hip.clear_workspaces()
