@@ -32,7 +32,7 @@ J_L2_TRACKING = 0
 
 class SolverOpts(C.Structure):
     _fields_ = [("rtol", C.c_double), ("atol", C.c_double), ("max_it", C.c_int32),
-                ("zero_guess", C.c_int32), ("check_every", C.c_int32), ("reserved", C.c_int32)]
+                ("zero_guess", C.c_int32), ("check_every", C.c_int32), ("pc", C.c_int32)]
 
 
 class SolveInfo(C.Structure):
@@ -66,6 +66,8 @@ PROTOTYPES = {
     "femo_mesh_destroy": (C.c_int, [H]),
     "femo_mesh_info": (C.c_int, [H, c_i64p]),
     "femo_mesh_set_boundary_facets": (C.c_int, [H, C.c_void_p]),
+    "femo_mesh_set_global": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int64]),
+    "femo_mesh_pc_info": (C.c_int, [H, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "femo_mesh_pattern_csr": (C.c_int, [H, C.c_void_p, C.c_void_p]),
     "femo_topology_build_host": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, C.c_void_p, c_i64p, C.c_void_p, C.c_void_p]),
     "femo_bc_create": (C.c_int, [H, c_i64, C.c_void_p, C.c_void_p, C.POINTER(H)]),

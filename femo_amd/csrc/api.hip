@@ -19,6 +19,24 @@ __global__ void k_pdiv(int64_t n, const double* __restrict__ x, const double* __
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = x[i] / d[i];
 }
 
+// vertices of the marked boundary facets (facet k = the one opposite local vertex k)
+__global__ void k_boundary_vertices(int64_t n_cell, int tdim, const int32_t* __restrict__ conn,
+                                    const uint8_t* __restrict__ bfacets, uint8_t* __restrict__ bv) {
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_cell; c += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned bits = bfacets[c];
+    if (!bits) continue;
+    for (int k = 0; k <= tdim; ++k)
+      if (bits & (1u << k))
+        for (int j = 0; j <= tdim; ++j)
+          if (j != k) bv[conn[c * (tdim + 1) + j]] = 1;
+  }
+}
+
+__global__ void k_or_masks(int64_t n, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint8_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (a ? a[i] : 0) | (b ? b[i] : 0);
+}
+
 __global__ void k_bc_mask(int64_t n, const int32_t* __restrict__ dofs, const double* __restrict__ vals,
                           uint8_t* __restrict__ mask, double* __restrict__ dense) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -252,6 +270,16 @@ int femo_mesh_create(femo_ctx* ctx, int tdim, int64_t n_vert, int64_t n_rows, co
   m->n_slices = T.n_slices; m->nnz = T.nnz; m->sell_entries = T.mptr[T.n_slices];
   m->visit_entries = T.vptr[T.n_slices]; m->max_rowlen = T.max_rowlen; m->max_valence = T.max_valence;
   m->h_mptr = T.mptr;
+  m->n_vert_global = n_vert;
+  for (int k = 0; k < tdim && k < 3; ++k) {
+    double lo = 0.0, hi = 0.0;
+    if (n_vert > 0) { lo = hi = x[k]; }
+    for (int64_t v = 1; v < n_vert; ++v) {
+      const double c = x[v * tdim + k];
+      lo = c < lo ? c : lo; hi = c > hi ? c : hi;
+    }
+    m->bbox_lo[k] = lo; m->bbox_hi[k] = hi;
+  }
   hipStream_t st = ctx->stream;
   FEMO_HIP_CHECK(hipMalloc(&m->d_x, std::max<int64_t>(n_vert * tdim, 1) * sizeof(double) + 64));
   FEMO_HIP_CHECK(hipMemcpyAsync(m->d_x, x, n_vert * tdim * sizeof(double), hipMemcpyHostToDevice, st));
@@ -275,6 +303,8 @@ int femo_mesh_destroy(femo_mesh* m) {
   hipStreamSynchronize(m->ctx->stream);
   hipFree(m->d_x); hipFree(m->d_conn); hipFree(m->d_vptr); hipFree(m->d_visit_cell);
   hipFree(m->d_visit_slots); hipFree(m->d_mptr); hipFree(m->d_cols); hipFree(m->d_rowlen);
+  femo_pc_destroy(m);
+  hipFree(m->d_bvmask);
   hipFree(m->d_sdelta); hipFree(m->d_bfacets); hipFree(m->d_tperm); hipFree(m->d_send_idx); hipFree(m->d_send_buf); hipFree(m->d_scratch); hipFree(m->d_slices_int); hipFree(m->d_slices_bnd);
   delete m;
   return 0;
@@ -298,12 +328,37 @@ int femo_mesh_info(const femo_mesh* m, int64_t info[FEMO_MESH_INFO_COUNT]) {
 
 int femo_mesh_set_boundary_facets(femo_mesh* m, const uint8_t* mask) {
   FEMO_REQUIRE(m != nullptr, "null argument");
-  hipFree(m->d_bfacets);
-  m->d_bfacets = nullptr;
+  hipFree(m->d_bfacets); hipFree(m->d_bvmask);
+  m->d_bfacets = nullptr; m->d_bvmask = nullptr;
+  ++m->bfacets_version;
   if (!mask || m->n_cell == 0) return 0;
+  hipStream_t st = m->ctx->stream;
   FEMO_HIP_CHECK(hipMalloc(&m->d_bfacets, m->n_cell + 64));
-  FEMO_HIP_CHECK(hipMemcpyAsync(m->d_bfacets, mask, m->n_cell, hipMemcpyHostToDevice, m->ctx->stream));
-  FEMO_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+  FEMO_HIP_CHECK(hipMemcpyAsync(m->d_bfacets, mask, m->n_cell, hipMemcpyHostToDevice, st));
+  FEMO_HIP_CHECK(hipMalloc(&m->d_bvmask, std::max<int64_t>(m->n_vert, 1) + 64));
+  FEMO_HIP_CHECK(hipMemsetAsync(m->d_bvmask, 0, std::max<int64_t>(m->n_vert, 1) + 64, st));
+  hipLaunchKernelGGL(k_boundary_vertices, dim3(grid_for(m->n_cell)), dim3(256), 0, st, m->n_cell, m->tdim, m->d_conn, m->d_bfacets, m->d_bvmask);
+  FEMO_HIP_CHECK(hipGetLastError());
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  return 0;
+}
+
+int femo_mesh_pc_info(const femo_mesh* m, int32_t* n_levels, int64_t* finest_nodes) {
+  FEMO_REQUIRE(m && n_levels && finest_nodes, "null argument");
+  int nl = 0;
+  FEMO_TRY(femo_pc_levels(m, &nl, finest_nodes));
+  *n_levels = nl;
+  return 0;
+}
+
+int femo_mesh_set_global(femo_mesh* m, const double* lo, const double* hi, int64_t n_vert_global) {
+  FEMO_REQUIRE(m && lo && hi && n_vert_global >= m->n_rows, "bad argument");
+  FEMO_REQUIRE(m->pc == nullptr, "set the global geometry before the first preconditioned solve");
+  for (int k = 0; k < m->tdim && k < 3; ++k) {
+    FEMO_REQUIRE(lo[k] <= m->bbox_lo[k] && hi[k] >= m->bbox_hi[k], "global bounding box does not contain the local mesh");
+    m->bbox_lo[k] = lo[k]; m->bbox_hi[k] = hi[k];
+  }
+  m->n_vert_global = n_vert_global;
   return 0;
 }
 
@@ -324,7 +379,8 @@ int femo_bc_create(femo_mesh* m, int64_t n, const int32_t* dofs, const double* v
   for (int64_t i = 0; i < n; ++i)
     FEMO_REQUIRE(dofs[i] >= 0 && dofs[i] < m->n_vert, "Dirichlet dof %d out of range", dofs[i]);
   femo_bc* b = new femo_bc();
-  b->mesh = m; b->n = n;
+  static uint64_t next_uid = 0;
+  b->mesh = m; b->n = n; b->uid = ++next_uid;
   hipStream_t st = m->ctx->stream;
   FEMO_HIP_CHECK(hipMalloc(&b->d_dofs, std::max<int64_t>(n, 1) * sizeof(int32_t)));
   FEMO_HIP_CHECK(hipMalloc(&b->d_vals, std::max<int64_t>(n, 1) * sizeof(double)));
@@ -369,7 +425,30 @@ int femo_mat_destroy(femo_mat* A) {
   if (!A) return 0;
   hipStreamSynchronize(A->mesh->ctx->stream);
   hipFree(A->d_diag); hipFree(A->d_vals); hipFree(A->d_valsT); hipFree(A->d_valsS); hipFree(A->d_s);
+  hipFree(A->d_pcmask);
   delete A;
+  return 0;
+}
+
+// Records which vertices this assembly pins (strong Dirichlet set, Nitsche facets) for the BPX
+// preconditioner; the key identifies the combination so cached lattice data can be reused.
+static int note_pinned_vertices(femo_mat* A, int pde, const double* params, const femo_bc* bc) {
+  femo_mesh* m = A->mesh;
+  A->bpx_ok = (pde == FEMO_PDE_POISSON || pde == FEMO_PDE_NL_POISSON);
+  if (!A->bpx_ok) return 0;
+  const bool nitsche = m->d_bvmask != nullptr && params != nullptr && params[0] != 0.0;
+  const bool strong = bc != nullptr && bc->n > 0;
+  const uint64_t key = 1 + (strong ? bc->uid << 20 : 0) + (nitsche ? (m->bfacets_version << 1) | 1 : 0);
+  if (A->pc_key == key) return 0;
+  A->pc_has_mask = strong || nitsche;
+  if (A->pc_has_mask) {
+    const int64_t nb = std::max<int64_t>(m->n_vert, 1);
+    if (!A->d_pcmask) FEMO_HIP_CHECK(hipMalloc(&A->d_pcmask, nb + 64));
+    hipLaunchKernelGGL(k_or_masks, dim3(grid_for(nb)), dim3(256), 0, m->ctx->stream, m->n_vert,
+                       strong ? bc->d_mask : (const uint8_t*)nullptr, nitsche ? m->d_bvmask : (const uint8_t*)nullptr, A->d_pcmask);
+    FEMO_HIP_CHECK(hipGetLastError());
+  }
+  A->pc_key = key;
   return 0;
 }
 
@@ -391,6 +470,7 @@ int femo_assemble_jacobian(femo_mesh* m, int pde, const double* params, const fe
   FEMO_REQUIRE(aux == nullptr || aux->n >= m->n_vert, "aux field shorter than n_vert");
   if (u && m->n_nbr > 0 && pde != FEMO_PDE_POISSON) FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(u)));
   const double* ax = aux ? aux->d : nullptr;
+  FEMO_TRY(note_pinned_vertices(J, pde, params, bc));
   if (bc)
     return femo_launch_system(m, pde, params, u ? u->d : nullptr, f ? f->d : nullptr, ax, bc->d_mask, bc->d_dense,
                               nullptr, nullptr, J->d_diag, J->d_vals, nullptr);
@@ -414,8 +494,8 @@ int femo_assemble_system(femo_mesh* m, int pde, const double* params, const femo
     FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(u)));
   }
   FEMO_REQUIRE(aux == nullptr || aux->n >= m->n_vert, "aux field shorter than n_vert");
-  if (J_nobc) { J_nobc->valsT_valid = false; J_nobc->scaled_valid = false; }
-  if (A_bc) { A_bc->valsT_valid = false; A_bc->scaled_valid = false; }
+  if (J_nobc) { J_nobc->valsT_valid = false; J_nobc->scaled_valid = false; FEMO_TRY(note_pinned_vertices(J_nobc, pde, params, nullptr)); }
+  if (A_bc) { A_bc->valsT_valid = false; A_bc->scaled_valid = false; FEMO_TRY(note_pinned_vertices(A_bc, pde, params, bc)); }
   return femo_launch_system(m, pde, params, u ? u->d : nullptr, f ? f->d : nullptr, aux ? aux->d : nullptr,
                             bc ? bc->d_mask : nullptr, bc ? bc->d_dense : nullptr,
                             J_nobc ? J_nobc->d_diag : nullptr, J_nobc ? J_nobc->d_vals : nullptr,

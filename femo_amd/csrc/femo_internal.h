@@ -117,6 +117,8 @@ struct femo_vec {
   bool owned = true;
 };
 
+struct femo_pc;   // auxiliary-lattice BPX hierarchy (bpx.hip)
+
 struct femo_mesh {
   femo_ctx* ctx = nullptr;
   int tdim = 0;
@@ -147,6 +149,12 @@ struct femo_mesh {
   // slices without / with ghost columns (set with the halo plan)
   int32_t* d_slices_int = nullptr; int32_t* d_slices_bnd = nullptr;
   int64_t n_int = 0, n_bnd = 0;
+  // geometry of the whole (global) mesh for the BPX lattice; local values until femo_mesh_set_global
+  double bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};
+  int64_t n_vert_global = 0;
+  uint8_t* d_bvmask = nullptr;   // vertices on marked boundary facets (built with d_bfacets)
+  uint64_t bfacets_version = 0;
+  femo_pc* pc = nullptr;         // built on first use
 };
 
 struct femo_bc {
@@ -156,6 +164,7 @@ struct femo_bc {
   double* d_vals = nullptr;
   uint8_t* d_mask = nullptr;  // n_vert
   double* d_dense = nullptr;  // n_vert: prescribed value on the set, 0 elsewhere
+  uint64_t uid = 0;           // process-unique, never reused (keys cached preconditioner data)
 };
 
 struct femo_mat {
@@ -167,6 +176,11 @@ struct femo_mat {
   double* d_valsS = nullptr;  // S A S (or S A^T S), S = diag^-1/2: what the CG iterates on
   double* d_s = nullptr;      // S, n_vert entries (ghosts filled by halo exchange)
   bool scaled_valid = false, scaled_transposed = false;
+  // BPX: which vertices the last assembly pinned (strong Dirichlet set and/or Nitsche facets)
+  bool bpx_ok = false;          // assembled from a second-order scalar PDE on a geometric mesh
+  uint8_t* d_pcmask = nullptr;  // n_vert bytes, valid when pc_key != 0 and pc_has_mask
+  bool pc_has_mask = false;
+  uint64_t pc_key = 0;
 };
 
 // ------------------------------------------------------ device utilities ----
@@ -227,4 +241,9 @@ int femo_spmv_grid(const femo_mesh* m);
 int femo_halo_exchange_on(femo_mesh* m, femo_vec* x, hipStream_t st);
 int femo_mesh_classify_slices(femo_mesh* m);
 int femo_mat_ensure_transpose(femo_mat* A);
+int femo_pc_build(femo_mesh* m);
+void femo_pc_destroy(femo_mesh* m);
+int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const double* s, const double* rh, double* zh,
+                  double* partials, const int32_t* done, int gv);
+int femo_pc_levels(const femo_mesh* m, int* n_levels, int64_t* finest_nodes);
 int femo_reduce_to_host(femo_ctx* ctx, int nblocks, int nsums, double* host_out);

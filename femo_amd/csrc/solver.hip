@@ -418,6 +418,66 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_cg_update_xp(int64_t n, int cur,
   }
 }
 
+// ---- BPX-preconditioned CG (bpx.hip) ------------------------------------------------
+// scal: [0],[1] = gamma = rh.zh of even/odd iterations, [2] = delta = ph.Ah ph, [3] = tol^2,
+// [4] = rho = rh.rh (the natural-norm residual the stopping test uses, same as Jacobi-CG).
+constexpr int S_RHO = 4;
+
+// out[0] = sum of `nb` partials (+ `nb2` partials of the next slot pair, overlapped SpMV)
+__global__ __launch_bounds__(1024) void k_pcg_fold(int nb, const double* __restrict__ partials, int nb2,
+                                                   const double* __restrict__ partials2, double* __restrict__ out,
+                                                   const int32_t* __restrict__ done) {
+  if (*done) return;
+  __shared__ double lds[1024 / 64];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 1024) acc += partials[i];
+  for (int i = threadIdx.x; i < nb2; i += 1024) acc += partials2[i];
+  const double t = femo_block_sum<1024>(acc, lds);
+  if (threadIdx.x == 0) out[0] = t;
+}
+
+// xh += alpha ph ; rh -= alpha qh ; partial rh.rh
+__global__ __launch_bounds__(FEMO_BLOCK) void k_pcg_xr(int64_t n, int cur, const double* __restrict__ scal,
+                                                       const double* __restrict__ q, const double* __restrict__ p,
+                                                       double* __restrict__ r, double* __restrict__ xh,
+                                                       double* __restrict__ partials, const int32_t* __restrict__ done) {
+  if (*done) return;
+  __shared__ double lds[FEMO_BLOCK / 64];
+  const double gamma = scal[S_GAMMA + cur], delta = scal[S_DELTA];
+  const double alpha = delta != 0.0 ? gamma / delta : 0.0;
+  double s0 = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FEMO_BLOCK) {
+    xh[i] += alpha * p[i];
+    const double ri = r[i] - alpha * q[i];
+    r[i] = ri;
+    s0 += ri * ri;
+  }
+  const double t = femo_block_sum<FEMO_BLOCK>(s0, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// stopping test on the reduced rho; runs alone on the stream, so later kernels see a settled flag
+__global__ void k_pcg_check(int it, const double* __restrict__ scal, int32_t* __restrict__ flags) {
+  if (flags[0]) return;
+  const double rho = scal[S_RHO], delta = scal[S_DELTA];
+  const bool bad = !(rho == rho) || !(delta == delta);
+  flags[1] = it + 1;
+  if (rho <= scal[S_TOL2] || bad) {
+    flags[2] = bad ? 1 : 0;
+    flags[0] = it + 1;
+  }
+}
+
+// ph = zh + beta ph
+__global__ void k_pcg_p(int64_t n, int cur, const double* __restrict__ scal, const double* __restrict__ z,
+                        double* __restrict__ p, const int32_t* __restrict__ done) {
+  if (*done) return;
+  const double g0 = scal[S_GAMMA + cur], g1 = scal[S_GAMMA + (cur ^ 1)];
+  const double beta = g0 != 0.0 ? g1 / g0 : 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    p[i] = z[i] + beta * p[i];
+}
+
 // ---- single-reduction CG (Chronopoulos & Gear) for nranks > 1 ---------------------
 // One all-reduce of (gamma = r.r, delta = r.Ar) and one halo exchange per iteration:
 //   beta = gamma/gamma_old; alpha = gamma / (delta - beta*gamma/alpha_old)
@@ -922,6 +982,150 @@ static int ensure_scaled(femo_mat* A, bool transpose) {
   return 0;
 }
 
+// CG with the auxiliary-lattice BPX preconditioner.  Same scaled system, same stopping norm
+// (sqrt(rh.rh) = sqrt(r^T D^-1 r)) as the Jacobi path; scalars live on the device and are
+// all-reduced there when the mesh is partitioned.
+static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec* x,
+                         const femo_solver_opts* opts, femo_solve_info* info) {
+  femo_mesh* m = A->mesh;
+  femo_ctx* ctx = m->ctx;
+  const int64_t n = m->n_rows;
+  FEMO_REQUIRE(A->bpx_ok, "the BPX preconditioner needs an operator assembled from a Poisson-type form");
+  FEMO_REQUIRE(!transpose, "the BPX preconditioner is for symmetric operators");
+  hipStream_t st = ctx->stream;
+  FEMO_HIP_CHECK(hipEventRecord(ctx->ev0, st));
+  FEMO_TRY(ensure_scaled(A, false));
+  FEMO_TRY(femo_pc_build(m));
+  CgWork w;
+  const bool multi = ctx->nranks > 1 || (ctx->comm != nullptr && getenv("FEMO_FORCE_MULTI") != nullptr);
+  FEMO_TRY(ensure_work(ctx, n, m->n_vert, w, 1));
+  double* z = w.sv;
+  const int gv = vec_grid(ctx, n);
+  const int gs = femo_spmv_grid(m);
+  int32_t* h_flags = reinterpret_cast<int32_t*>(ctx->h_scal + FEMO_NSCAL);
+  double* P = ctx->d_partials;
+  double* S = ctx->d_scal;
+  const uint8_t* mask = A->pc_has_mask ? A->d_pcmask : nullptr;
+  auto allreduce1 = [&](double* d) -> int {
+    if (multi) FEMO_NCCL_CHECK(ncclAllReduce(d, d, 1, ncclDouble, ncclSum, ctx->comm, st));
+    return 0;
+  };
+
+  FEMO_HIP_CHECK(hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int32_t), st));
+  const double* q0 = nullptr;
+  if (opts->zero_guess) {
+    FEMO_HIP_CHECK(hipMemsetAsync(x->d, 0, x->n * sizeof(double), st));
+  } else {
+    if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, x->d));
+    FEMO_TRY(launch_spmv(A, A->d_vals, x->d, w.q, nullptr, nullptr));
+    q0 = w.q;
+  }
+  hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, b->d, q0, A->d_s, w.r, w.p, w.xh, P);
+  hipLaunchKernelGGL(k_reduce_partials_at, dim3(1), dim3(1024), 0, st, gv, 2, P + FEMO_MAX_PARTIALS, S);
+  FEMO_HIP_CHECK(hipGetLastError());
+  if (multi) FEMO_NCCL_CHECK(ncclAllReduce(S, S, 2, ncclDouble, ncclSum, ctx->comm, st));
+  FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, S, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  const double rho0 = ctx->h_scal[0], bb = ctx->h_scal[1];
+  const double bnorm = std::sqrt(bb);
+  double tol = opts->rtol * bnorm;
+  if (opts->atol > tol) tol = opts->atol;
+  info->rhs_norm = bnorm;
+  const int max_it = opts->max_it > 0 ? opts->max_it : 10000;
+  auto finish = [&](int iters, int conv, double rho) -> int {
+    if (n > 0) {
+      hipLaunchKernelGGL(k_unscale, dim3(2048), dim3(256), 0, st, n, opts->zero_guess ? 0 : 1, A->d_s, w.xh, x->d);
+      FEMO_HIP_CHECK(hipGetLastError());
+    }
+    FEMO_HIP_CHECK(hipEventRecord(ctx->ev1, st));
+    FEMO_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    FEMO_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    info->iterations = iters;
+    info->converged = conv;
+    info->residual_norm = std::sqrt(rho);
+    info->solve_ms = ms;
+    return 0;
+  };
+  if (!(std::sqrt(rho0) > tol)) return finish(0, rho0 == rho0 ? 1 : -1, rho0);
+
+  double hs[FEMO_NSCAL] = {0};
+  hs[S_TOL2] = tol * tol;
+  hs[S_RHO] = rho0;
+  memcpy(ctx->h_scal, hs, sizeof hs);
+  FEMO_HIP_CHECK(hipMemcpyAsync(S, ctx->h_scal, sizeof hs, hipMemcpyHostToDevice, st));
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  // zh0 = M^-1 rh0, ph0 = zh0, gamma0 = rh0.zh0
+  FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, z, P + 2 * FEMO_MAX_PARTIALS, ctx->d_flags, gv));
+  hipLaunchKernelGGL(k_pcg_fold, dim3(1), dim3(1024), 0, st, gv, P + 2 * FEMO_MAX_PARTIALS, 0, (const double*)nullptr, S + S_GAMMA, ctx->d_flags);
+  FEMO_TRY(allreduce1(S + S_GAMMA));
+  FEMO_HIP_CHECK(hipMemcpyAsync(w.p, z, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+
+  const int n_sample = 4, sample_from = 2;
+  int n_ev = 0;
+  const int batch = opts->check_every > 0 ? std::min(opts->check_every, 8) : 8;
+  int it = 0, polled = 0;
+  bool done = false;
+  int pending[2] = {-1, -1};
+  while (!done) {
+    const int it_end = it + batch < max_it ? it + batch : max_it;
+    for (; it < it_end; ++it) {
+      const int cur = it & 1, nxt = cur ^ 1;
+      const bool sample = it >= sample_from && it < sample_from + n_sample;
+      if (sample) FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev], st));
+      int g1 = gs, g2 = 0;
+      if (m->n_nbr > 0 && m->d_slices_int != nullptr) {
+        FEMO_TRY(halo_spmv_overlapped(A, A->d_valsS, w.p, w.q, P, ctx->d_flags, true, false, &g1, &g2));
+      } else {
+        if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, w.p));
+        FEMO_TRY(launch_spmv(A, A->d_valsS, w.p, w.q, P + P_DELTA * FEMO_MAX_PARTIALS, ctx->d_flags, true));
+      }
+      if (sample) { FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev + 1], st)); ++n_ev; }
+      hipLaunchKernelGGL(k_pcg_fold, dim3(1), dim3(1024), 0, st, g1, P + P_DELTA * FEMO_MAX_PARTIALS, g2, P + 2 * FEMO_MAX_PARTIALS, S + S_DELTA, ctx->d_flags);
+      FEMO_TRY(allreduce1(S + S_DELTA));
+      hipLaunchKernelGGL(k_pcg_xr, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, S, w.q, w.p, w.r, w.xh, P + 1 * FEMO_MAX_PARTIALS, ctx->d_flags);
+      hipLaunchKernelGGL(k_pcg_fold, dim3(1), dim3(1024), 0, st, gv, P + 1 * FEMO_MAX_PARTIALS, 0, (const double*)nullptr, S + S_RHO, ctx->d_flags);
+      FEMO_TRY(allreduce1(S + S_RHO));
+      hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(1), 0, st, it, S, ctx->d_flags);
+      FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, z, P + 2 * FEMO_MAX_PARTIALS, ctx->d_flags, gv));
+      hipLaunchKernelGGL(k_pcg_fold, dim3(1), dim3(1024), 0, st, gv, P + 2 * FEMO_MAX_PARTIALS, 0, (const double*)nullptr, S + S_GAMMA + nxt, ctx->d_flags);
+      FEMO_TRY(allreduce1(S + S_GAMMA + nxt));
+      hipLaunchKernelGGL(k_pcg_p, dim3(2048), dim3(256), 0, st, n, cur, S, z, w.p, ctx->d_flags);
+    }
+    FEMO_HIP_CHECK(hipGetLastError());
+    const int slot = polled & 1;
+    FEMO_HIP_CHECK(hipMemcpyAsync(h_flags + 4 * slot, ctx->d_flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_sample + slot], st));
+    pending[slot] = it;
+    ++polled;
+    const int prev = polled & 1;
+    const bool last = it >= max_it;
+    if (pending[prev] >= 0) {
+      FEMO_HIP_CHECK(hipEventSynchronize(ctx->ev_pool[2 * n_sample + prev]));
+      if (h_flags[4 * prev]) done = true;
+      pending[prev] = -1;
+    }
+    if (!done && last) {
+      FEMO_HIP_CHECK(hipEventSynchronize(ctx->ev_pool[2 * n_sample + slot]));
+      done = true;
+    }
+  }
+  FEMO_HIP_CHECK(hipMemcpyAsync(h_flags, ctx->d_flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, S, FEMO_NSCAL * sizeof(double), hipMemcpyDeviceToHost, st));
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  const int iters = h_flags[1];
+  const int conv = h_flags[0] ? (h_flags[2] ? -1 : 1) : 0;
+  double acc = 0.0;
+  for (int i = 0; i < n_ev; ++i) {
+    float t = 0.f;
+    FEMO_HIP_CHECK(hipEventElapsedTime(&t, ctx->ev_pool[2 * i], ctx->ev_pool[2 * i + 1]));
+    acc += t;
+  }
+  info->spmv_ms = acc;
+  info->spmv_samples = n_ev;
+  return finish(iters, conv, ctx->h_scal[S_RHO]);
+}
+
 extern "C" int femo_solve_cg(const femo_mat* A_, int transpose, const femo_vec* b, femo_vec* x,
                              const femo_solver_opts* opts, femo_solve_info* info) {
   FEMO_REQUIRE(A_ && b && x && opts && info, "null argument");
@@ -932,6 +1136,8 @@ extern "C" int femo_solve_cg(const femo_mat* A_, int transpose, const femo_vec* 
   FEMO_REQUIRE(b->n >= n && x->n >= m->n_vert, "vector size mismatch in solve_cg");
   FEMO_REQUIRE(b->d != x->d, "solve_cg cannot run in place");
   memset(info, 0, sizeof *info);
+  FEMO_REQUIRE(opts->pc == FEMO_PC_JACOBI || opts->pc == FEMO_PC_BPX, "unknown preconditioner %d", opts->pc);
+  if (opts->pc == FEMO_PC_BPX) return solve_pcg_bpx(A, transpose, b, x, opts, info);
   hipStream_t st = ctx->stream;
   FEMO_HIP_CHECK(hipEventRecord(ctx->ev0, st));
   FEMO_TRY(ensure_scaled(A, transpose != 0));

@@ -24,11 +24,12 @@ from .partition import LocalMesh, build_local_mesh, rcb_partition
 class DistMesh(Mesh):
     """A rank's local piece of a partitioned mesh; drop-in for ``Mesh`` in the FEA stack."""
 
-    def __init__(self, local: LocalMesh, n_vert_global: int, n_cell_global: int):
+    def __init__(self, local: LocalMesh, n_vert_global: int, n_cell_global: int, bbox=None):
         super().__init__(local.x, local.conn)
         self.local = local
         self.n_vert_global = int(n_vert_global)
         self.n_cell_global = int(n_cell_global)
+        self.bbox = bbox        # (lo, hi) of the whole mesh: every rank builds the same BPX lattice
 
     @property
     def n_owned(self) -> int:
@@ -39,6 +40,8 @@ class DistMesh(Mesh):
             from ..engine import DeviceMesh
             L = self.local
             dm = DeviceMesh(ctx, self.x, self.conn, n_rows=L.n_owned)
+            if self.bbox is not None:
+                dm.set_global(self.bbox[0], self.bbox[1], self.n_vert_global)
             if L.nranks > 1:
                 dm.set_halo(L.nbr, L.send_ptr, L.send_idx, L.recv_ptr)
             self._device, self._ctx = dm, ctx
@@ -48,7 +51,7 @@ class DistMesh(Mesh):
 def partition_mesh(mesh: Mesh, rank: int, nranks: int) -> DistMesh:
     part = rcb_partition(mesh.x, nranks)
     local = build_local_mesh(mesh.x, mesh.conn, part, rank, nranks)
-    return DistMesh(local, mesh.n_vert, mesh.n_cell)
+    return DistMesh(local, mesh.n_vert, mesh.n_cell, bbox=(mesh.x.min(axis=0), mesh.x.max(axis=0)))
 
 
 def init_process_group(rank: int, world: int):

@@ -15,6 +15,9 @@ from . import _lib
 from ._lib import FemoError, H, SolveInfo, SolverOpts, check
 
 
+PC_KINDS = {"jacobi": 0, "bpx": 1}     # include/femo_hip.h FEMO_PC_*
+
+
 def _f64(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float64)
 
@@ -212,6 +215,16 @@ class DeviceMesh:
         assert mask.shape == (self.n_cell,)
         check(self.lib.femo_mesh_set_boundary_facets(self.handle, _ptr(mask)))
 
+    def set_global(self, lo, hi, n_vert_global: int) -> None:
+        """Whole-mesh bounding box / vertex count of a partitioned mesh (BPX lattice geometry)."""
+        lo, hi = np.ascontiguousarray(lo, np.float64), np.ascontiguousarray(hi, np.float64)
+        check(self.lib.femo_mesh_set_global(self.handle, _ptr(lo), _ptr(hi), int(n_vert_global)))
+
+    def pc_info(self):
+        nl, nodes = C.c_int32(0), C.c_int64(0)
+        check(self.lib.femo_mesh_pc_info(self.handle, C.byref(nl), C.byref(nodes)))
+        return {"levels": nl.value, "finest_nodes": nodes.value}
+
     def set_halo(self, nbr, send_ptr, send_idx, recv_ptr) -> None:
         nbr = _i32(nbr)
         send_ptr = np.ascontiguousarray(send_ptr, np.int64)
@@ -284,8 +297,8 @@ class Mat:
         return out
 
     def solve_cg(self, b: Vec, x: Vec, transpose: bool = False, rtol: float = 1e-12, atol: float = 0.0,
-                 max_it: int = 100000, zero_guess: bool = True, check_every: int = 32) -> SolveInfo:
-        opts = SolverOpts(rtol, atol, max_it, int(zero_guess), check_every, 0)
+                 max_it: int = 100000, zero_guess: bool = True, check_every: int = 32, pc: str = "jacobi") -> SolveInfo:
+        opts = SolverOpts(rtol, atol, max_it, int(zero_guess), check_every, PC_KINDS[pc])
         info = SolveInfo()
         check(self.lib.femo_solve_cg(self.handle, int(transpose), b.handle, x.handle, C.byref(opts), C.byref(info)))
         return info

@@ -48,7 +48,10 @@ def set_context(ctx: Optional[Context]) -> None:
 # solution is bounded by cond(D^-1 A) * rtol (cond ~ 0.4 n^2 on an n^d grid), and
 # 1e-14 keeps states and sensitivities within 1e-10 of the LU oracle on every
 # parity case (measured sweep: DESIGN.md section 6).
-KSP_OPTIONS = dict(rtol=1e-14, atol=0.0, max_it=100000, check_every=32)
+# pc: 'bpx' = Jacobi + auxiliary-lattice multilevel correction (csrc/bpx.hip) wherever the operator
+# comes from a Poisson-type form, Jacobi elsewhere (mass matrix, beam); 'jacobi' = diagonal scaling only.
+KSP_OPTIONS = dict(rtol=1e-14, atol=0.0, max_it=100000, check_every=32, pc='bpx')
+_BPX_KINDS = (_lib.PDE_POISSON, _lib.PDE_NL_POISSON)
 LAST_KSP_INFO: List[dict] = []   # appended by every linear solve (iteration counts for reports)
 
 
@@ -188,6 +191,7 @@ class SparseMatrix:
         self.dmesh = mesh.device(get_context())
         self.mat = E.Mat(self.dmesh)
         self.symmetric = symmetric
+        self.pde_kind = None       # set by the assembly that fills the values
 
     def getSizes(self):
         return (self.dmesh.n_rows, self.dmesh.n_vert)
@@ -350,6 +354,7 @@ def assembleMatrix(M: Form, bcs: Sequence[DirichletBC] = (), out=None):
     dm = mesh.device(get_context())
     if M.wrt is res.u:
         A = out if isinstance(out, SparseMatrix) else SparseMatrix(mesh, symmetric=res.is_symmetric)
+        A.pde_kind = res.pde_kind
         E.assemble_jacobian(dm, res.pde_kind, res.params, res.u.vec, res.f.vec, _dirichlet_set(mesh, bcs), A.mat,
                             aux=_aux(res))
         return A
@@ -375,6 +380,9 @@ def assembleSystem(J: Form, F: Form, bcs: Sequence[DirichletBC] = (), rhs: bool 
     dm = mesh.device(get_context())
     A = out if isinstance(out, SparseMatrix) else SparseMatrix(mesh, symmetric=res.is_symmetric)
     ds = _dirichlet_set(mesh, bcs)
+    A.pde_kind = res.pde_kind
+    if out_nobc is not None:
+        out_nobc.pde_kind = res.pde_kind
     E.assemble_system(dm, res.pde_kind, res.params, res.u.vec, res.f.vec, ds,
                       out_nobc.mat if out_nobc is not None else None, A.mat, None, aux=_aux(res))
     if not rhs:
@@ -456,9 +464,15 @@ class KSP:
         """Symmetric operators: Jacobi-CG; otherwise BiCGSTAB on A or its explicit transpose."""
         o = self.options
         tr = self.transposed and not self.A.symmetric
-        solver = self.A.mat.solve_cg if self.A.symmetric else self.A.mat.solve_bicgstab
-        self.info = solver(_as_vec(b), _as_vec(x), transpose=tr, rtol=o["rtol"], atol=o["atol"],
-                           max_it=o["max_it"], zero_guess=True, check_every=o["check_every"])
+        kw = dict(transpose=tr, rtol=o["rtol"], atol=o["atol"], max_it=o["max_it"], zero_guess=True,
+                  check_every=o["check_every"])
+        if self.A.symmetric:
+            pc = o.get("pc", "jacobi")
+            if pc == "bpx" and self.A.pde_kind not in _BPX_KINDS:
+                pc = "jacobi"
+            self.info = self.A.mat.solve_cg(_as_vec(b), _as_vec(x), pc=pc, **kw)
+        else:
+            self.info = self.A.mat.solve_bicgstab(_as_vec(b), _as_vec(x), **kw)
         LAST_KSP_INFO.append(dict(iterations=self.info.iterations, converged=self.info.converged,
                                   residual_norm=self.info.residual_norm, rhs_norm=self.info.rhs_norm,
                                   solve_ms=self.info.solve_ms, spmv_ms=self.info.spmv_ms,
@@ -513,6 +527,7 @@ class _NewtonBase:
         b = _work(mesh, "newton_b", lambda: Vec(ctx, n))
         dx = _work(mesh, "newton_dx", lambda: Vec(ctx, n))
         A = _work(mesh, "newton_A", lambda: SparseMatrix(mesh, symmetric=F.is_symmetric))
+        A.pde_kind = F.pde_kind
         ds = _dirichlet_set(mesh, self.bcs)
         aux = _aux(F)
         # F (with Dirichlet lifting) and J at the current iterate, one pass over the mesh
@@ -647,6 +662,7 @@ def project(v, target_func: Function, bcs=[], lump_mass=False):
         sign = -1.0
     else:
         M = _work(mesh, "proj_M", lambda: SparseMatrix(mesh, symmetric=True))
+        M.pde_kind = _lib.PDE_MASS
         E.assemble_jacobian(dm, _lib.PDE_MASS, None, None, None, None, M.mat)
         M.mult(v.fn.vec, b)
         sign = 1.0
@@ -662,7 +678,8 @@ def project(v, target_func: Function, bcs=[], lump_mass=False):
     else:
         if M is None:
             M = _work(mesh, "proj_M", lambda: SparseMatrix(mesh, symmetric=True))
-            E.assemble_jacobian(dm, _lib.PDE_MASS, None, None, None, None, M.mat)
+            M.pde_kind = _lib.PDE_MASS
+        E.assemble_jacobian(dm, _lib.PDE_MASS, None, None, None, None, M.mat)
         if sign < 0:
             rhs = _work(mesh, "proj_tmp", lambda: Vec(ctx, n)).fill(0.0)
             rhs.axpy(-1.0, b)

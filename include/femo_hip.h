@@ -65,13 +65,20 @@ enum femo_mesh_info_key {
   FEMO_MESH_INFO_COUNT = 11
 };
 
+/* preconditioner of femo_solve_cg (femo_solver_opts.pc) */
+enum {
+  FEMO_PC_JACOBI = 0,   /* diagonal scaling only                                                    */
+  FEMO_PC_BPX    = 1    /* + additive multilevel correction on an auxiliary lattice (csrc/bpx.hip);  */
+                        /*   operators assembled from FEMO_PDE_POISSON / FEMO_PDE_NL_POISSON only    */
+};
+
 typedef struct femo_solver_opts {
   double rtol;          /* stop when sqrt(r^T D^-1 r) <= max(rtol*sqrt(b^T D^-1 b), atol), D = diag(A) */
   double atol;
   int32_t max_it;
   int32_t zero_guess;   /* 1: x is taken as 0 on entry (skips the initial SpMV)         */
   int32_t check_every;  /* iterations enqueued between host convergence polls (0 = 32)  */
-  int32_t reserved;
+  int32_t pc;           /* FEMO_PC_*; 0 keeps the round-1 behaviour                      */
 } femo_solver_opts;
 
 typedef struct femo_solve_info {
@@ -128,6 +135,11 @@ int femo_mesh_info(const femo_mesh* mesh, int64_t info[FEMO_MESH_INFO_COUNT]);
  * (the `ds` measure of the reference's boundaryResidual, run_nonlinear_poisson_opt.py:98-117).
  * NULL clears it.                                                              */
 int femo_mesh_set_boundary_facets(femo_mesh* mesh, const uint8_t* mask);
+/* Partitioned meshes: bounding box (tdim doubles each) and vertex count of the WHOLE mesh, so
+ * that every rank builds the same preconditioner lattice.  Call before the first BPX solve.  */
+int femo_mesh_set_global(femo_mesh* mesh, const double* lo, const double* hi, int64_t n_vert_global);
+/* Preconditioner lattice of the mesh (built on first use): levels and nodes of the finest one. */
+int femo_mesh_pc_info(const femo_mesh* mesh, int32_t* n_levels, int64_t* finest_nodes);
 /* CSR view of the pattern (rowptr: n_rows+1, col: NNZ; sorted columns).       */
 int femo_mesh_pattern_csr(const femo_mesh* mesh, int64_t* rowptr, int32_t* col);
 

@@ -1,0 +1,160 @@
+"""The auxiliary-lattice BPX preconditioner of femo_solve_cg (csrc/bpx.hip): same answers as the
+oracle's direct solve and as Jacobi-CG, mesh-independent iteration counts, loud refusal on
+operators it is not meant for.  Tolerance: 1e-10 relative (BASELINE.json), both solves run to
+rtol 1e-14 in the D^-1 norm."""
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spla
+
+from oracle import femo_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.abs(np.asarray(a) - b).max() / np.abs(b).max()
+
+
+def _poisson_system(ctx, m, seed=0):
+    from femo_amd import engine as E
+    dm = E.DeviceMesh(ctx, m.x, m.conn)
+    bd = fo.boundary_vertices_box(m.x)
+    rng = np.random.default_rng(seed)
+    g = 0.3 * rng.standard_normal(len(bd))
+    bc = E.DirichletSet(dm, bd, g)
+    f = 1.0 + rng.random(m.n_cell)
+    u = np.zeros(m.n_vert)
+    A, b = E.Mat(dm), E.Vec(ctx, m.n_vert)
+    E.assemble_system(dm, 0, None, E.Vec(ctx, m.n_vert).set(u), E.Vec(ctx, m.n_cell).set(f), bc, None, A, b)
+    return dm, bc, A, b
+
+
+@pytest.mark.parametrize("d,n,jit", [(2, 48, 0.0), (2, 64, 0.25), (3, 12, 0.0), (3, 16, 0.25)])
+def test_bpx_matches_direct_solve(ctx, d, n, jit):
+    from femo_amd import engine as E
+    m = fo.unit_square_mesh(n, jit) if d == 2 else fo.unit_cube_mesh(n, jit)
+    dm, bc, A, b = _poisson_system(ctx, m)
+    x_ref = spla.spsolve(A.to_scipy().tocsc(), b.get())
+    xj, xb = E.Vec(ctx, m.n_vert), E.Vec(ctx, m.n_vert)
+    ij = A.solve_cg(b, xj, rtol=1e-14, pc="jacobi")
+    ib = A.solve_cg(b, xb, rtol=1e-14, pc="bpx")
+    assert ij.converged == 1 and ib.converged == 1
+    assert _rel(xb.get(), x_ref) < 1e-10 and _rel(xj.get(), x_ref) < 1e-10
+    assert ib.iterations < ij.iterations
+    assert dm.pc_info()["levels"] >= 2
+
+
+def test_bpx_iterations_do_not_grow_with_the_mesh(ctx):
+    from femo_amd import engine as E
+    its = {}
+    for n in (16, 32, 64):
+        m = fo.unit_cube_mesh(n, 0.2)
+        dm, bc, A, b = _poisson_system(ctx, m, seed=n)
+        x = E.Vec(ctx, m.n_vert)
+        info = A.solve_cg(b, x, rtol=1e-14, pc="bpx")
+        assert info.converged == 1
+        its[n] = info.iterations
+        # residual of the returned solution against the assembled operator
+        y = E.Vec(ctx, m.n_vert)
+        A.mult(x, y)
+        assert np.abs(y.get() - b.get()).max() <= 1e-11 * max(1.0, np.abs(b.get()).max())
+    assert max(its.values()) <= 70, its
+    assert its[64] <= its[16] + 15, its
+
+
+def test_bpx_nonzero_guess_and_atol(ctx):
+    from femo_amd import engine as E
+    m = fo.unit_cube_mesh(14, 0.1)
+    dm, bc, A, b = _poisson_system(ctx, m)
+    x_ref = spla.spsolve(A.to_scipy().tocsc(), b.get())
+    x = E.Vec(ctx, m.n_vert).set(x_ref * (1.0 + 1e-3 * np.random.default_rng(1).standard_normal(m.n_vert)))
+    info = A.solve_cg(b, x, rtol=1e-14, pc="bpx", zero_guess=False)
+    assert info.converged == 1 and _rel(x.get(), x_ref) < 1e-10
+    # a loose absolute tolerance stops early and says so
+    x2 = E.Vec(ctx, m.n_vert)
+    loose = A.solve_cg(b, x2, rtol=1e-14, atol=1e-3 * info.rhs_norm, pc="bpx")
+    assert loose.converged == 1 and loose.iterations < info.iterations + 40
+    assert loose.residual_norm <= 1e-3 * info.rhs_norm
+
+
+def test_bpx_nitsche_jacobian(ctx):
+    """Weak (Nitsche) boundary conditions: the facet vertices are the pinned set."""
+    from femo_amd import engine as E
+    m = fo.unit_square_mesh(40, 0.15)
+    bm = fo.boundary_facets(m)
+    dm = E.DeviceMesh(ctx, m.x, m.conn)
+    dm.set_boundary_facets(bm)
+    rng = np.random.default_rng(3)
+    u = 0.3 * np.sin(3 * m.x[:, 0]) + 0.2
+    U, F, UEX = E.Vec(ctx, m.n_vert).set(u), E.Vec(ctx, m.n_cell).set(rng.standard_normal(m.n_cell)), E.Vec(ctx, m.n_vert).set(fo.u_exact_nl(m.x))
+    J, B = E.Mat(dm), E.Vec(ctx, m.n_vert)
+    E.assemble_system(dm, 1, [10.0], U, F, None, J, None, B, aux=UEX)
+    x_ref = spla.spsolve(J.to_scipy().tocsc(), B.get())
+    xj, xb = E.Vec(ctx, m.n_vert), E.Vec(ctx, m.n_vert)
+    ij = J.solve_cg(B, xj, rtol=1e-14, pc="jacobi")
+    ib = J.solve_cg(B, xb, rtol=1e-14, pc="bpx")
+    assert ib.converged == 1 and _rel(xb.get(), x_ref) < 1e-10
+    assert ib.iterations < ij.iterations and ib.iterations <= 80
+
+
+def test_bpx_refuses_other_operators(ctx):
+    from femo_amd import engine as E
+    from femo_amd._lib import FemoError
+    m = fo.unit_square_mesh(8)
+    dm = E.DeviceMesh(ctx, m.x, m.conn)
+    M = E.Mat(dm)
+    E.assemble_jacobian(dm, 2, None, None, None, None, M)      # mass matrix
+    b, x = E.Vec(ctx, m.n_vert).fill(1.0), E.Vec(ctx, m.n_vert)
+    with pytest.raises(FemoError, match="Poisson-type"):
+        M.solve_cg(b, x, pc="bpx")
+    assert M.solve_cg(b, x, pc="jacobi").converged == 1
+
+
+def test_bpx_allreduce_path_on_one_rank(monkeypatch):
+    """FEMO_FORCE_MULTI routes the lattice and scalar all-reduces through a 1-rank communicator,
+    and the self-halo mesh of test_gpu_dist exercises the overlapped SpMV inside the BPX loop."""
+    from femo_amd import engine as E
+    from femo_amd.engine import Context
+    c = Context(0)
+    c.comm_init(Context.comm_unique_id(), 0, 1)
+    m = fo.unit_cube_mesh(12, 0.2)
+    dm, bc, A, b = _poisson_system(c, m)
+    x0, x1 = E.Vec(c, m.n_vert), E.Vec(c, m.n_vert)
+    monkeypatch.delenv("FEMO_FORCE_MULTI", raising=False)
+    i0 = A.solve_cg(b, x0, rtol=1e-14, pc="bpx")
+    monkeypatch.setenv("FEMO_FORCE_MULTI", "1")
+    i1 = A.solve_cg(b, x1, rtol=1e-14, pc="bpx")
+    monkeypatch.delenv("FEMO_FORCE_MULTI")
+    assert i0.converged == 1 and i1.converged == 1 and abs(i1.iterations - i0.iterations) <= 1
+    assert _rel(x1.get(), x0.get()) < 1e-12
+
+
+@pytest.mark.parametrize("d,n", [(2, 40), (3, 10)])
+def test_operator_stack_with_bpx_matches_jacobi(ctx, d, n):
+    """The FEA stack picks BPX for Poisson operators by default; state, output and total
+    derivative agree with the Jacobi-CG run of the same cycle to solver tolerance."""
+    from femo_amd.fea import utils_hip
+    from femo_amd.fea.mesh import createUnitCubeMesh, createUnitSquareMesh
+    from tests.test_gpu_operators import make_sim
+    assert utils_hip.KSP_OPTIONS["pc"] == "bpx"
+    utils_hip.set_context(ctx)
+    out = {}
+    for pc in ("bpx", "jacobi"):
+        mesh = createUnitSquareMesh(n) if d == 2 else createUnitCubeMesh(n)
+        old = utils_hip.KSP_OPTIONS["pc"]
+        utils_hip.KSP_OPTIONS["pc"] = pc
+        try:
+            sim, fea, f_ex, u_ex = make_sim(mesh, True)
+            rng = np.random.default_rng(11)
+            sim['f'] = 0.086 * (1.0 + 0.3 * rng.uniform(-1, 1, mesh.n_cell))
+            del utils_hip.LAST_KSP_INFO[:]
+            sim.run()
+            g = np.asarray(sim.compute_totals('l2_functional', 'f')).ravel().copy()
+            out[pc] = (np.asarray(sim['u']).copy(), float(np.asarray(sim['l2_functional_output_model.l2_functional']).ravel()[0]), g,
+                       [i["iterations"] for i in utils_hip.LAST_KSP_INFO])
+        finally:
+            utils_hip.KSP_OPTIONS["pc"] = old
+    ub, jb, gb, itb = out["bpx"]
+    uj, jj, gj, itj = out["jacobi"]
+    assert _rel(ub, uj) < 1e-10 and abs(jb - jj) <= 1e-10 * abs(jj) and _rel(gb, gj) < 1e-9
+    assert max(itb) < max(itj)
