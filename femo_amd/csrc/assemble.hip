@@ -36,15 +36,10 @@ __device__ __forceinline__ void load_conn(const int32_t* __restrict__ conn, int6
   }
 }
 
+// Geometry of a cell from its vertex coordinates p[a][k] (a = local vertex, canonical order)
 template <int D>
-__device__ __forceinline__ void cell_geom(const double* __restrict__ x, const int32_t v[D + 1], CellGeom<D>& G) {
+__device__ __forceinline__ void cell_geom_p(const double (&p)[D + 1][D], CellGeom<D>& G) {
   if constexpr (D == 3) {
-    double p[4][3];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const double* q = x + (int64_t)v[a] * 3;
-      p[a][0] = q[0]; p[a][1] = q[1]; p[a][2] = q[2];
-    }
     double e1[3], e2[3], e3[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -66,12 +61,6 @@ __device__ __forceinline__ void cell_geom(const double* __restrict__ x, const in
     }
     G.vol = fabs(det) * (1.0 / 6.0);
   } else {
-    double p[3][2];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const double* q = x + (int64_t)v[a] * 2;
-      p[a][0] = q[0]; p[a][1] = q[1];
-    }
     const double a = p[1][0] - p[0][0], b = p[1][1] - p[0][1];
     const double c = p[2][0] - p[0][0], d = p[2][1] - p[0][1];
     const double det = a * d - b * c;
@@ -82,6 +71,18 @@ __device__ __forceinline__ void cell_geom(const double* __restrict__ x, const in
     G.g[0][1] = -(G.g[1][1] + G.g[2][1]);
     G.vol = fabs(det) * 0.5;
   }
+}
+
+template <int D>
+__device__ __forceinline__ void cell_geom(const double* __restrict__ x, const int32_t v[D + 1], CellGeom<D>& G) {
+  double p[D + 1][D];
+#pragma unroll
+  for (int a = 0; a <= D; ++a) {
+    const double* q = x + (int64_t)v[a] * D;
+#pragma unroll
+    for (int k = 0; k < D; ++k) p[a][k] = q[k];
+  }
+  cell_geom_p<D>(p, G);
 }
 
 // Row a of the gradient table with a lane-varying a.  Written as an exact blend
@@ -353,7 +354,9 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
       } else {
         krow[b] = __dmul_rn(G.vol, dotD<D>(ga, G.g[b]));
       }
-      if (want_rhs) racc += krow[b] * u[v[b]];           // linear part of the residual: K u
+      if constexpr (PDE != FEMO_PDE_POISSON) {
+        if (want_rhs) racc += krow[b] * u[v[b]];         // linear part of the residual: K u
+      }
     }
     }
     if constexpr (PDE == FEMO_PDE_NL_POISSON) {
@@ -387,12 +390,24 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
   const int64_t mb = mptr[slice];
   const int wm = (int)((mptr[slice + 1] - mb) >> 6);
   double lift = 0.0;
+  // linear Poisson: (K u)_i from the finished row, one u gather per column instead of D+1 per
+  // visited cell (padded entries hold 0 and point at the row itself)
+  constexpr bool ROW_KU = PDE == FEMO_PDE_POISSON;
+  if constexpr (ROW_KU) {
+    if (want_rhs && valid) racc += dsum * u[row];
+  }
   for (int k = 0; k < wm; k += 2) {
     const int64_t idx = mb + (int64_t)(k >> 1) * 128 + lane * 2;
     double2 o;
     o.x = k < len ? strip[k * FEMO_BLOCK + tid] : 0.0;
     o.y = (k + 1) < len ? strip[(k + 1) * FEMO_BLOCK + tid] : 0.0;
     if (vals0) *reinterpret_cast<double2*>(vals0 + idx) = o;
+    if (bcmask != nullptr || (ROW_KU && want_rhs)) {
+      const int2 cc = *reinterpret_cast<const int2*>(cols + idx);
+      if constexpr (ROW_KU) {
+        if (want_rhs && valid) racc += o.x * u[cc.x] + o.y * u[cc.y];
+      }
+    }
     if (bcmask != nullptr) {
       const int2 cc = *reinterpret_cast<const int2*>(cols + idx);
       const bool bx = bcmask[cc.x], by = bcmask[cc.y];

@@ -45,6 +45,8 @@ struct femo_pc {
   double lo[3] = {0, 0, 0}, hi[3] = {1, 1, 1};
   std::vector<LatticeLevel> L;
   uint64_t built_key = 0;   // identity of the Dirichlet mask the coef arrays were built for
+  double* g_all = nullptr;  // the g arrays of all levels, coarsest first, contiguous
+  int n_fused = 0;          // coarser levels the brick kernel restricts to directly (besides the finest)
   // owned vertices sorted by brick (BRICK^dim bins of the finest lattice), for the restriction
   int64_t n_bricks = 0;
   int32_t* d_perm = nullptr;        // sorted position -> vertex
@@ -120,10 +122,11 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
                                                                 const int32_t* __restrict__ brick_base, const int32_t* __restrict__ perm,
                                                                 const double* __restrict__ xs, Lat lat, const double* __restrict__ val,
                                                                 const double* __restrict__ s, const uint8_t* __restrict__ mask,
-                                                                double* __restrict__ g, const int32_t* __restrict__ done) {
+                                                                double* __restrict__ g, int n_fused, const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
   constexpr int B = Brick<D>::B, N1 = Brick<D>::N1, NLOC = Brick<D>::NLOC;
   __shared__ double acc[NLOC];
+  __shared__ double acc2[NLOC];
   for (int64_t brick = blockIdx.x; brick < n_bricks; brick += gridDim.x) {
     for (int j = threadIdx.x; j < NLOC; j += FEMO_BLOCK) acc[j] = 0.0;
     __syncthreads();
@@ -167,6 +170,46 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
         atomicAdd(&g[node_index(lat.n, i0, i1, i2)], a);
       }
     }
+    // the next n_fused coarser lattices straight from the LDS copy: the brick starts on a multiple
+    // of B bins, so its nodes' parents on those levels are its own corner/edge/face nodes
+    double* fine = acc;
+    double* coarse = acc2;
+    double* gl = g;
+    int nfine = B, ln[3] = {lat.n[0], lat.n[1], lat.n[2]};
+    int64_t level_nodes = (int64_t)(ln[0] + 1) * (ln[1] + 1) * (ln[2] + 1);
+    for (int lev = 1; lev <= n_fused; ++lev) {
+      const int nc = nfine >> 1, f1 = nfine + 1, c1 = nc + 1;
+      const int ncl = D == 3 ? c1 * c1 * c1 : c1 * c1;
+      int cn[3] = {ln[0] >> 1, ln[1] >> 1, ln[2] >> 1};
+      const int64_t coarse_nodes = (int64_t)(cn[0] + 1) * (cn[1] + 1) * (cn[2] + 1);
+      gl -= coarse_nodes;                       // levels are stored coarsest first, contiguously
+      __syncthreads();
+      for (int j = threadIdx.x; j < ncl; j += FEMO_BLOCK) {
+        const int J[3] = {j % c1, (j / c1) % c1, D == 3 ? j / (c1 * c1) : 0};
+        double a = 0.0;
+        for (int dz = (D == 3 ? -1 : 0); dz <= (D == 3 ? 1 : 0); ++dz) {
+          const int fz = D == 3 ? 2 * J[2] + dz : 0;
+          if (fz < 0 || fz > nfine) continue;
+          for (int dy = -1; dy <= 1; ++dy) {
+            const int fy = 2 * J[1] + dy;
+            if (fy < 0 || fy > nfine) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
+              const int fx = 2 * J[0] + dx;
+              if (fx < 0 || fx > nfine) continue;
+              const double w = (dx ? 0.5 : 1.0) * (dy ? 0.5 : 1.0) * (dz ? 0.5 : 1.0);
+              a += w * fine[(D == 3 ? fz * f1 * f1 : 0) + fy * f1 + fx];
+            }
+          }
+        }
+        coarse[j] = a;
+        const int i0 = (base[0] >> lev) + J[0], i1 = (base[1] >> lev) + J[1], i2 = D == 3 ? (base[2] >> lev) + J[2] : 0;
+        if (a != 0.0 && i0 <= cn[0] && i1 <= cn[1] && i2 <= cn[2]) atomicAdd(&gl[node_index(cn, i0, i1, i2)], a);
+      }
+      double* t = fine; fine = coarse; coarse = t;
+      nfine = nc; ln[0] = cn[0]; ln[1] = cn[1]; ln[2] = cn[2];
+      level_nodes = coarse_nodes;
+    }
+    (void)level_nodes;
     __syncthreads();
   }
 }
@@ -244,13 +287,14 @@ __global__ void k_lattice_restrict(int nc0, int nc1, int nc2, int nf0, int nf1, 
 
 // e_f[i] = (interpolation of e_c)(i) + coef_f[i] * g_f[i]     (e_c == nullptr: coarsest level)
 __global__ void k_lattice_prolong(int nf0, int nf1, int nf2, int nc0, int nc1, int nc2, int dim,
-                                  const double* __restrict__ ec, const double* __restrict__ coef, const double* __restrict__ g,
-                                  double* __restrict__ ef, const int32_t* __restrict__ done) {
+                                  const double* __restrict__ ec, const double* __restrict__ coef, double* __restrict__ g,
+                                  int zero_g, double* __restrict__ ef, const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
   const int64_t total = (int64_t)(nf0 + 1) * (nf1 + 1) * (nf2 + 1);
   const int nc[3] = {nc0, nc1, nc2};
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     double v = coef[idx] * g[idx];
+    if (zero_g) g[idx] = 0.0;      // accumulated by atomics: left clean for the next restriction
     if (ec != nullptr) {
       const int i = (int)(idx % (nf0 + 1));
       const int j = (int)((idx / (nf0 + 1)) % (nf1 + 1));
@@ -351,9 +395,17 @@ int femo_pc_build(femo_mesh* m) {
       }
       L.nodes *= (L.n[k] + 1);
     }
-    FEMO_HIP_CHECK(hipMalloc(&L.g, L.nodes * sizeof(double)));
     FEMO_HIP_CHECK(hipMalloc(&L.e, L.nodes * sizeof(double)));
     FEMO_HIP_CHECK(hipMalloc(&L.coef, L.nodes * sizeof(double)));
+  }
+  {
+    int64_t total = 0;
+    for (auto& L : pc->L) total += L.nodes;
+    FEMO_HIP_CHECK(hipMalloc(&pc->g_all, total * sizeof(double)));
+    FEMO_HIP_CHECK(hipMemset(pc->g_all, 0, total * sizeof(double)));
+    int64_t off = 0;
+    for (auto& L : pc->L) { L.g = pc->g_all + off; off += L.nodes; }
+    pc->n_fused = std::min(pc->dim == 3 ? 2 : 3, pc->n_levels - 1);
   }
   // sort the owned vertices by brick of the finest lattice (host counting sort, once per mesh)
   {
@@ -418,7 +470,8 @@ int femo_pc_build(femo_mesh* m) {
 
 void femo_pc_destroy(femo_mesh* m) {
   if (!m->pc) return;
-  for (auto& L : m->pc->L) { (void)hipFree(L.g); (void)hipFree(L.e); (void)hipFree(L.coef); }
+  for (auto& L : m->pc->L) { (void)hipFree(L.e); (void)hipFree(L.coef); }
+  (void)hipFree(m->pc->g_all);
   (void)hipFree(m->pc->d_perm); (void)hipFree(m->pc->d_xs); (void)hipFree(m->pc->d_brick_ptr); (void)hipFree(m->pc->d_brick_base);
   delete m->pc;
   m->pc = nullptr;
@@ -457,6 +510,7 @@ static int pc_prepare(femo_mesh* m, const uint8_t* mask, uint64_t key) {
     hipLaunchKernelGGL(k_lattice_coef_inject, dim3(lat_grid(C.nodes)), dim3(256), 0, st, C.n[0], C.n[1], C.n[2], Fi.n[0], Fi.n[1], Fi.n[2], pc->dim, level_c(C), Fi.coef, C.coef);
   }
   FEMO_HIP_CHECK(hipGetLastError());
+  FEMO_HIP_CHECK(hipMemsetAsync(F.g, 0, F.nodes * sizeof(double), st));   // the restriction expects clean accumulators
   pc->built_key = key;
   pc->coef_valid = true;
   return 0;
@@ -469,19 +523,23 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
   femo_ctx* ctx = m->ctx;
   hipStream_t st = ctx->stream;
   FEMO_TRY(pc_prepare(m, mask, mask_key));
-  const int nl = pc->n_levels;
+  const int nl = pc->n_levels, nf = pc->n_fused;
   LatticeLevel& F = pc->L[nl - 1];
   const Lat lat = make_lat(pc, F);
-  FEMO_HIP_CHECK(hipMemsetAsync(F.g, 0, F.nodes * sizeof(double), st));
+  // g of the finest nf+1 levels: zero on entry (femo_pc_begin, then k_lattice_prolong cleans up)
   if (pc->n_bricks > 0) {
     const unsigned gb = (unsigned)std::min<int64_t>(pc->n_bricks, 256 * 64);
     if (pc->dim == 3)
-      hipLaunchKernelGGL(k_restrict_bricks<3>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_perm, pc->d_xs, lat, rh, s, mask, F.g, done);
+      hipLaunchKernelGGL(k_restrict_bricks<3>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_perm, pc->d_xs, lat, rh, s, mask, F.g, nf, done);
     else
-      hipLaunchKernelGGL(k_restrict_bricks<2>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_perm, pc->d_xs, lat, rh, s, mask, F.g, done);
+      hipLaunchKernelGGL(k_restrict_bricks<2>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_perm, pc->d_xs, lat, rh, s, mask, F.g, nf, done);
   }
-  if (ctx->nranks > 1) FEMO_NCCL_CHECK(ncclAllReduce(F.g, F.g, F.nodes, ncclDouble, ncclSum, ctx->comm, st));
-  for (int l = nl - 2; l >= 0; --l) {
+  if (ctx->nranks > 1) {   // one all-reduce over the contiguous accumulators of the finest nf+1 levels
+    double* first = pc->L[nl - 1 - nf].g;
+    const int64_t count = (F.g + F.nodes) - first;
+    FEMO_NCCL_CHECK(ncclAllReduce(first, first, count, ncclDouble, ncclSum, ctx->comm, st));
+  }
+  for (int l = nl - 2 - nf; l >= 0; --l) {
     LatticeLevel& C = pc->L[l];
     const LatticeLevel& Fi = pc->L[l + 1];
     hipLaunchKernelGGL(k_lattice_restrict, dim3(lat_grid(C.nodes)), dim3(256), 0, st, C.n[0], C.n[1], C.n[2], Fi.n[0], Fi.n[1], Fi.n[2], pc->dim, Fi.g, C.g, done);
@@ -490,13 +548,23 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
     LatticeLevel& Fi = pc->L[l];
     const double* ec = l > 0 ? pc->L[l - 1].e : nullptr;
     const int* nc = l > 0 ? pc->L[l - 1].n : Fi.n;
-    hipLaunchKernelGGL(k_lattice_prolong, dim3(lat_grid(Fi.nodes)), dim3(256), 0, st, Fi.n[0], Fi.n[1], Fi.n[2], nc[0], nc[1], nc[2], pc->dim, ec, Fi.coef, Fi.g, Fi.e, done);
+    hipLaunchKernelGGL(k_lattice_prolong, dim3(lat_grid(Fi.nodes)), dim3(256), 0, st, Fi.n[0], Fi.n[1], Fi.n[2], nc[0], nc[1], nc[2], pc->dim, ec, Fi.coef, Fi.g, l >= nl - 1 - nf ? 1 : 0, Fi.e, done);
   }
   if (pc->dim == 3)
     hipLaunchKernelGGL(k_prolong_mesh<3>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, m->d_x, rh, s, mask, F.e, zh, partials, done);
   else
     hipLaunchKernelGGL(k_prolong_mesh<2>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, m->d_x, rh, s, mask, F.e, zh, partials, done);
   FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// start of a solve: the atomically accumulated g arrays must be zero
+int femo_pc_begin(femo_mesh* m) {
+  femo_pc* pc = m->pc;
+  const int nl = pc->n_levels;
+  double* first = pc->L[nl - 1 - pc->n_fused].g;
+  const int64_t count = (pc->L[nl - 1].g + pc->L[nl - 1].nodes) - first;
+  FEMO_HIP_CHECK(hipMemsetAsync(first, 0, count * sizeof(double), m->ctx->stream));
   return 0;
 }
 

@@ -996,6 +996,7 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
   FEMO_HIP_CHECK(hipEventRecord(ctx->ev0, st));
   FEMO_TRY(ensure_scaled(A, false));
   FEMO_TRY(femo_pc_build(m));
+  FEMO_TRY(femo_pc_begin(m));
   CgWork w;
   const bool multi = ctx->nranks > 1 || (ctx->comm != nullptr && getenv("FEMO_FORCE_MULTI") != nullptr);
   FEMO_TRY(ensure_work(ctx, n, m->n_vert, w, 1));

@@ -84,6 +84,7 @@ def bench_distributed(args, rank: int, world: int, local_rank: int) -> None:
     import torch
     ctx = Context(local_rank)
     utils_hip.set_context(ctx)
+    utils_hip.KSP_OPTIONS["pc"] = B.PC = getattr(args, "pc", "bpx")
     init_comm(ctx, rank, world)
     t0 = time.perf_counter()
     gmesh = createUnitCubeMesh(args.n, jitter=getattr(args, 'jitter', 0.0))
@@ -132,8 +133,9 @@ def bench_distributed(args, rank: int, world: int, local_rank: int) -> None:
             "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": (f"3-D linear Poisson, P1 tets, unit cube n={args.n}: {n_dof} DOFs, {n_cell_g} cells, "
-                             f"RCB {world}-way vertex partition, ghost-DOF halo (ncclSend/Recv) + RCCL all-reduce CG; "
-                             f"same cycle as N=1"),
+                             f"RCB {world}-way vertex partition, ghost-DOF halo (ncclSend/Recv) + RCCL all-reduce "
+                             f"{B.PC.upper()}-CG; same cycle as N=1"),
+                "preconditioner": B.PC, "pc_lattice": dm.pc_info(),
                 "n": args.n, "n_dof": n_dof, "n_cell": n_cell_g, "parallelism": f"rcb{world}",
                 "owned_per_rank": [int(g[0]) for g in gathered], "ghosts_per_rank": [int(g[1]) for g in gathered],
                 "neighbours_per_rank": [int(g[2]) for g in gathered],

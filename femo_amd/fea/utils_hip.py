@@ -555,9 +555,10 @@ class _NewtonBase:
             if self.stol > 0.0:
                 step_small = dx.dot(dx, n_own) < (self.stol ** 2) * func.vec.dot(func.vec, n_own)
             # next pass: residual for the convergence test and, in the same launch, the Jacobian the
-            # next iteration would use (the reference assembles J only when it iterates again; the
-            # extra matrix of the last pass is wasted work, never skipped work)
-            E.assemble_system(dm, F.pde_kind, F.params, F.u.vec, F.f.vec, ds, None, A.mat, b, aux=aux)
+            # next iteration will use.  After the last allowed iteration nothing consumes a Jacobian
+            # (the reference assembles J only when it iterates again), so that pass is residual-only.
+            E.assemble_system(dm, F.pde_kind, F.params, F.u.vec, F.f.vec, ds, None,
+                              A.mat if it < self.max_it else None, b, aux=aux)
             r = float(np.sqrt(b.dot(b, n_own)))
             self.residual_norms.append(r)
             converged = r < self.atol or (r0 > 0 and r / r0 < self.rtol) or step_small
