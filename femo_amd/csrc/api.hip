@@ -466,7 +466,7 @@ int femo_assemble_jacobian(femo_mesh* m, int pde, const double* params, const fe
   FEMO_REQUIRE(m && J, "null argument");
   FEMO_REQUIRE(J->mesh == m, "matrix belongs to another mesh");
   FEMO_REQUIRE(bc == nullptr || bc->mesh == m, "Dirichlet set belongs to another mesh");
-  J->valsT_valid = false; J->scaled_valid = false;
+  J->valsT_valid = false; J->scaled_valid = false; J->s_valid = false;
   FEMO_REQUIRE(aux == nullptr || aux->n >= m->n_vert, "aux field shorter than n_vert");
   if (u && m->n_nbr > 0 && pde != FEMO_PDE_POISSON) FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(u)));
   const double* ax = aux ? aux->d : nullptr;
@@ -494,8 +494,8 @@ int femo_assemble_system(femo_mesh* m, int pde, const double* params, const femo
     FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(u)));
   }
   FEMO_REQUIRE(aux == nullptr || aux->n >= m->n_vert, "aux field shorter than n_vert");
-  if (J_nobc) { J_nobc->valsT_valid = false; J_nobc->scaled_valid = false; FEMO_TRY(note_pinned_vertices(J_nobc, pde, params, nullptr)); }
-  if (A_bc) { A_bc->valsT_valid = false; A_bc->scaled_valid = false; FEMO_TRY(note_pinned_vertices(A_bc, pde, params, bc)); }
+  if (J_nobc) { J_nobc->valsT_valid = false; J_nobc->scaled_valid = false; J_nobc->s_valid = false; FEMO_TRY(note_pinned_vertices(J_nobc, pde, params, nullptr)); }
+  if (A_bc) { A_bc->valsT_valid = false; A_bc->scaled_valid = false; A_bc->s_valid = false; FEMO_TRY(note_pinned_vertices(A_bc, pde, params, bc)); }
   return femo_launch_system(m, pde, params, u ? u->d : nullptr, f ? f->d : nullptr, aux ? aux->d : nullptr,
                             bc ? bc->d_mask : nullptr, bc ? bc->d_dense : nullptr,
                             J_nobc ? J_nobc->d_diag : nullptr, J_nobc ? J_nobc->d_vals : nullptr,

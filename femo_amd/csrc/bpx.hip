@@ -9,7 +9,7 @@
 // P_l = multilinear interpolation from a regular lattice (2^l m_k bins per axis over the
 // bounding box of the mesh) to the mesh vertices, computed on the fly from the vertex
 // coordinates -- no coarse matrices, no coarse solves, nothing mesh-structure specific.
-// C_l = 1 / (diagonal of the Q1 Laplacian on lattice l) = 3/(8 H_l) in 3-D, 3/8 in 2-D
+// C_l = 0.6 / (diagonal of the Q1 Laplacian on lattice l) = 0.6 * 3/(8 H_l) in 3-D, 0.6 * 3/8 in 2-D
 // (classical BPX scaling; Galerkin diagonals measured the same iteration counts).  Dirichlet
 // vertices are masked out of P (their rows are identity rows; vertices on Nitsche facets count
 // as Dirichlet, the penalty pins them), and the lattice nodes sitting on that boundary are
@@ -24,6 +24,7 @@
 // Ah = S A S, so in scaled variables  zh = rh + S^-1 (sum_l P_l C_l P_l^T) S^-1 rh.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "femo_internal.h"
 
@@ -368,7 +369,10 @@ int femo_pc_build(femo_mesh* m) {
   // mesh size estimate and the finest lattice: spacing ~ 2 h, bins = m0 * 2^(levels-1) with m0 in {2, 3}
   const double n_glob = (double)(m->n_vert_global > 0 ? m->n_vert_global : m->n_vert);
   const double h = std::pow(vol / n_glob, 1.0 / pc->dim);
-  const double target = std::max(2.0, ext_max / (2.0 * h));
+  // FEMO_BPX_SPACING: finest lattice spacing in units of the mesh size (tuning knob, default 2)
+  double spacing = 2.0;
+  if (const char* e = getenv("FEMO_BPX_SPACING")) { const double v = atof(e); if (v >= 1.0 && v <= 8.0) spacing = v; }
+  const double target = std::max(2.0, ext_max / (spacing * h));
   int best_m0 = 2, best_lv = 1;
   double best = 1e300;
   for (int m0 = 2; m0 <= 3; ++m0)
@@ -502,7 +506,10 @@ static int pc_prepare(femo_mesh* m, const uint8_t* mask, uint64_t key) {
     FEMO_NCCL_CHECK(ncclAllReduce(F.g, F.g, F.nodes, ncclDouble, ncclSum, ctx->comm, st));
     FEMO_NCCL_CHECK(ncclAllReduce(F.e, F.e, F.nodes, ncclDouble, ncclSum, ctx->comm, st));
   }
-  auto level_c = [&](const LatticeLevel& L) { return pc->dim == 3 ? 3.0 / (8.0 * L.H) : 3.0 / 8.0; };
+  // 1 / diag of the Q1 Laplacian, damped: weighting the lattice terms by 0.6 against the Jacobi
+  // term measured 12-15 % fewer iterations than 1.0 on every case tried (0.35 and 1.0 are both worse)
+  constexpr double THETA = 0.6;
+  auto level_c = [&](const LatticeLevel& L) { return THETA * (pc->dim == 3 ? 3.0 / (8.0 * L.H) : 3.0 / 8.0); };
   hipLaunchKernelGGL(k_lattice_coef, dim3(lat_grid(F.nodes)), dim3(256), 0, st, F.nodes, level_c(F), F.g, F.e, F.coef);
   for (int l = nl - 2; l >= 0; --l) {
     LatticeLevel& C = pc->L[l];

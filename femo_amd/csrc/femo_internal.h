@@ -176,6 +176,7 @@ struct femo_mat {
   double* d_valsS = nullptr;  // S A S (or S A^T S), S = diag^-1/2: what the CG iterates on
   double* d_s = nullptr;      // S, n_vert entries (ghosts filled by halo exchange)
   bool scaled_valid = false, scaled_transposed = false;
+  bool s_valid = false;       // d_s matches the current diagonal (set before the values are scaled)
   // BPX: which vertices the last assembly pinned (strong Dirichlet set and/or Nitsche facets)
   bool bpx_ok = false;          // assembled from a second-order scalar PDE on a geometric mesh
   uint8_t* d_pcmask = nullptr;  // n_vert bytes, valid when pc_key != 0 and pc_has_mask

@@ -436,14 +436,18 @@ __global__ __launch_bounds__(1024) void k_pcg_fold(int nb, const double* __restr
   if (threadIdx.x == 0) out[0] = t;
 }
 
-// xh += alpha ph ; rh -= alpha qh ; partial rh.rh
-__global__ __launch_bounds__(FEMO_BLOCK) void k_pcg_xr(int64_t n, int cur, const double* __restrict__ scal,
+// xh += alpha ph ; rh -= alpha qh ; partial rh.rh.  nb_d > 0: delta is folded here from the
+// SpMV's per-block partials (single GPU: no fold kernel, no all-reduce), else read from scal.
+__global__ __launch_bounds__(FEMO_BLOCK) void k_pcg_xr(int64_t n, int cur, int nb_d, const double* __restrict__ partials_d,
+                                                       double* __restrict__ scal,
                                                        const double* __restrict__ q, const double* __restrict__ p,
                                                        double* __restrict__ r, double* __restrict__ xh,
                                                        double* __restrict__ partials, const int32_t* __restrict__ done) {
   if (*done) return;
   __shared__ double lds[FEMO_BLOCK / 64];
-  const double gamma = scal[S_GAMMA + cur], delta = scal[S_DELTA];
+  const double gamma = scal[S_GAMMA + cur];
+  const double delta = nb_d > 0 ? cg_scalar(partials_d, nb_d, lds) : scal[S_DELTA];
+  if (nb_d > 0 && blockIdx.x == 0 && threadIdx.x == 0) scal[S_DELTA] = delta;   // for the breakdown test
   const double alpha = delta != 0.0 ? gamma / delta : 0.0;
   double s0 = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FEMO_BLOCK) {
@@ -456,10 +460,21 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_pcg_xr(int64_t n, int cur, const
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 
-// stopping test on the reduced rho; runs alone on the stream, so later kernels see a settled flag
-__global__ void k_pcg_check(int it, const double* __restrict__ scal, int32_t* __restrict__ flags) {
+// stopping test on the reduced rho; runs alone on the stream, so later kernels see a settled flag.
+// nb > 0: folds the rho partials first (single GPU); else rho was folded and all-reduced before.
+__global__ __launch_bounds__(1024) void k_pcg_check(int it, int nb, const double* __restrict__ partials,
+                                                    double* __restrict__ scal, int32_t* __restrict__ flags) {
   if (flags[0]) return;
-  const double rho = scal[S_RHO], delta = scal[S_DELTA];
+  __shared__ double lds[1024 / 64];
+  double rho = 0.0;
+  if (nb > 0) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 1024) acc += partials[i];
+    rho = femo_block_sum<1024>(acc, lds);
+  }
+  if (threadIdx.x != 0) return;
+  if (nb > 0) scal[S_RHO] = rho; else rho = scal[S_RHO];
+  const double delta = scal[S_DELTA];
   const bool bad = !(rho == rho) || !(delta == delta);
   flags[1] = it + 1;
   if (rho <= scal[S_TOL2] || bad) {
@@ -468,13 +483,18 @@ __global__ void k_pcg_check(int it, const double* __restrict__ scal, int32_t* __
   }
 }
 
-// ph = zh + beta ph
-__global__ void k_pcg_p(int64_t n, int cur, const double* __restrict__ scal, const double* __restrict__ z,
-                        double* __restrict__ p, const int32_t* __restrict__ done) {
+// ph = zh + beta ph.  nb_g > 0: gamma' = rh.zh is folded here from the prolongation's partials and
+// left in scal for the next iteration's alpha (nobody reads that slot during this launch).
+__global__ __launch_bounds__(FEMO_BLOCK) void k_pcg_p(int64_t n, int cur, int nb_g, const double* __restrict__ partials_g,
+                                                      double* __restrict__ scal, const double* __restrict__ z,
+                                                      double* __restrict__ p, const int32_t* __restrict__ done) {
   if (*done) return;
-  const double g0 = scal[S_GAMMA + cur], g1 = scal[S_GAMMA + (cur ^ 1)];
+  __shared__ double lds[FEMO_BLOCK / 64];
+  const double g0 = scal[S_GAMMA + cur];
+  const double g1 = nb_g > 0 ? cg_scalar(partials_g, nb_g, lds) : scal[S_GAMMA + (cur ^ 1)];
+  if (nb_g > 0 && blockIdx.x == 0 && threadIdx.x == 0) scal[S_GAMMA + (cur ^ 1)] = g1;
   const double beta = g0 != 0.0 ? g1 / g0 : 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+  for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FEMO_BLOCK)
     p[i] = z[i] + beta * p[i];
 }
 
@@ -952,7 +972,27 @@ int ensure_work(femo_ctx* ctx, int64_t n_rows, int64_t n_vert, CgWork& w, int ne
 }
 }  // namespace
 
-// S = diag^-1/2 and the scaled values S A S (or S A^T S) of the current assembly
+// S = diag^-1/2 of the current assembly (ghost entries from their owners)
+static int ensure_s(femo_mat* A) {
+  femo_mesh* m = A->mesh;
+  femo_ctx* ctx = m->ctx;
+  if (A->s_valid) return 0;
+  const int64_t nd = std::max<int64_t>(m->n_vert, m->n_slices * FEMO_WAVE) + 2;
+  if (!A->d_s) FEMO_HIP_CHECK(hipMalloc(&A->d_s, nd * sizeof(double)));
+  if (m->n_rows > 0) {
+    hipLaunchKernelGGL(k_invsqrt_diag, dim3(2048), dim3(256), 0, ctx->stream, m->n_rows, A->d_diag, A->d_s);
+    FEMO_HIP_CHECK(hipGetLastError());
+  }
+  if (m->n_nbr > 0) {   // ghost columns need the owner's scale factor
+    femo_vec v; v.ctx = ctx; v.d = A->d_s; v.n = m->n_vert; v.owned = false;
+    FEMO_TRY(femo_halo_exchange(m, &v));
+  }
+  A->s_valid = true;
+  return 0;
+}
+
+// ... and the scaled values S A S (or S A^T S): what the Krylov loops iterate on.  Kept apart
+// from ensure_s because a solve that stops on its initial residual never needs them.
 static int ensure_scaled(femo_mat* A, bool transpose) {
   femo_mesh* m = A->mesh;
   femo_ctx* ctx = m->ctx;
@@ -962,17 +1002,8 @@ static int ensure_scaled(femo_mat* A, bool transpose) {
     FEMO_TRY(femo_mat_ensure_transpose(A));
     src = A->d_valsT;
   }
-  const int64_t nd = std::max<int64_t>(m->n_vert, m->n_slices * FEMO_WAVE) + 2;
-  if (!A->d_s) FEMO_HIP_CHECK(hipMalloc(&A->d_s, nd * sizeof(double)));
+  FEMO_TRY(ensure_s(A));
   if (!A->d_valsS) FEMO_HIP_CHECK(hipMalloc(&A->d_valsS, std::max<int64_t>(m->sell_entries, 1) * sizeof(double) + 64));
-  if (m->n_rows > 0) {
-    hipLaunchKernelGGL(k_invsqrt_diag, dim3(2048), dim3(256), 0, ctx->stream, m->n_rows, A->d_diag, A->d_s);
-    FEMO_HIP_CHECK(hipGetLastError());
-  }
-  if (m->n_nbr > 0) {   // ghost columns need the owner's scale factor
-    femo_vec v; v.ctx = ctx; v.d = A->d_s; v.n = m->n_vert; v.owned = false;
-    FEMO_TRY(femo_halo_exchange(m, &v));
-  }
   if (m->n_slices > 0) {
     hipLaunchKernelGGL(k_scale_sell, dim3(2048), dim3(FEMO_BLOCK), 0, ctx->stream, m->n_slices, m->d_mptr, m->d_cols, m->d_sdelta, m->sdelta_stride, src, A->d_s, m->n_vert, A->d_valsS);
     FEMO_HIP_CHECK(hipGetLastError());
@@ -994,7 +1025,7 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
   FEMO_REQUIRE(!transpose, "the BPX preconditioner is for symmetric operators");
   hipStream_t st = ctx->stream;
   FEMO_HIP_CHECK(hipEventRecord(ctx->ev0, st));
-  FEMO_TRY(ensure_scaled(A, false));
+  FEMO_TRY(ensure_s(A));
   FEMO_TRY(femo_pc_build(m));
   FEMO_TRY(femo_pc_begin(m));
   CgWork w;
@@ -1049,6 +1080,7 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
     return 0;
   };
   if (!(std::sqrt(rho0) > tol)) return finish(0, rho0 == rho0 ? 1 : -1, rho0);
+  FEMO_TRY(ensure_scaled(A, false));
 
   double hs[FEMO_NSCAL] = {0};
   hs[S_TOL2] = tol * tol;
@@ -1064,6 +1096,7 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
 
   const int n_sample = 4, sample_from = 2;
   int n_ev = 0;
+  const bool local_scalars = !multi && m->n_nbr == 0;
   const int batch = opts->check_every > 0 ? std::min(opts->check_every, 8) : 8;
   int it = 0, polled = 0;
   bool done = false;
@@ -1082,16 +1115,27 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
         FEMO_TRY(launch_spmv(A, A->d_valsS, w.p, w.q, P + P_DELTA * FEMO_MAX_PARTIALS, ctx->d_flags, true));
       }
       if (sample) { FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev + 1], st)); ++n_ev; }
-      hipLaunchKernelGGL(k_pcg_fold, dim3(1), dim3(1024), 0, st, g1, P + P_DELTA * FEMO_MAX_PARTIALS, g2, P + 2 * FEMO_MAX_PARTIALS, S + S_DELTA, ctx->d_flags);
-      FEMO_TRY(allreduce1(S + S_DELTA));
-      hipLaunchKernelGGL(k_pcg_xr, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, S, w.q, w.p, w.r, w.xh, P + 1 * FEMO_MAX_PARTIALS, ctx->d_flags);
-      hipLaunchKernelGGL(k_pcg_fold, dim3(1), dim3(1024), 0, st, gv, P + 1 * FEMO_MAX_PARTIALS, 0, (const double*)nullptr, S + S_RHO, ctx->d_flags);
-      FEMO_TRY(allreduce1(S + S_RHO));
-      hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(1), 0, st, it, S, ctx->d_flags);
-      FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, z, P + 2 * FEMO_MAX_PARTIALS, ctx->d_flags, gv));
-      hipLaunchKernelGGL(k_pcg_fold, dim3(1), dim3(1024), 0, st, gv, P + 2 * FEMO_MAX_PARTIALS, 0, (const double*)nullptr, S + S_GAMMA + nxt, ctx->d_flags);
-      FEMO_TRY(allreduce1(S + S_GAMMA + nxt));
-      hipLaunchKernelGGL(k_pcg_p, dim3(2048), dim3(256), 0, st, n, cur, S, z, w.p, ctx->d_flags);
+      double* Pd = P + P_DELTA * FEMO_MAX_PARTIALS;
+      double* Pr = P + 1 * FEMO_MAX_PARTIALS;
+      double* Pg = P + 2 * FEMO_MAX_PARTIALS;
+      if (local_scalars) {
+        // single GPU: the consumers fold the per-block partials themselves
+        hipLaunchKernelGGL(k_pcg_xr, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, g1, Pd, S, w.q, w.p, w.r, w.xh, Pr, ctx->d_flags);
+        hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(1024), 0, st, it, gv, Pr, S, ctx->d_flags);
+        FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, z, Pg, ctx->d_flags, gv));
+        hipLaunchKernelGGL(k_pcg_p, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, gv, Pg, S, z, w.p, ctx->d_flags);
+      } else {
+        hipLaunchKernelGGL(k_pcg_fold, dim3(1), dim3(1024), 0, st, g1, Pd, g2, Pg, S + S_DELTA, ctx->d_flags);
+        FEMO_TRY(allreduce1(S + S_DELTA));
+        hipLaunchKernelGGL(k_pcg_xr, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, 0, Pd, S, w.q, w.p, w.r, w.xh, Pr, ctx->d_flags);
+        hipLaunchKernelGGL(k_pcg_fold, dim3(1), dim3(1024), 0, st, gv, Pr, 0, (const double*)nullptr, S + S_RHO, ctx->d_flags);
+        FEMO_TRY(allreduce1(S + S_RHO));
+        hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(1024), 0, st, it, 0, Pr, S, ctx->d_flags);
+        FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, z, Pg, ctx->d_flags, gv));
+        hipLaunchKernelGGL(k_pcg_fold, dim3(1), dim3(1024), 0, st, gv, Pg, 0, (const double*)nullptr, S + S_GAMMA + nxt, ctx->d_flags);
+        FEMO_TRY(allreduce1(S + S_GAMMA + nxt));
+        hipLaunchKernelGGL(k_pcg_p, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, 0, Pg, S, z, w.p, ctx->d_flags);
+      }
     }
     FEMO_HIP_CHECK(hipGetLastError());
     const int slot = polled & 1;
@@ -1141,7 +1185,8 @@ extern "C" int femo_solve_cg(const femo_mat* A_, int transpose, const femo_vec* 
   if (opts->pc == FEMO_PC_BPX) return solve_pcg_bpx(A, transpose, b, x, opts, info);
   hipStream_t st = ctx->stream;
   FEMO_HIP_CHECK(hipEventRecord(ctx->ev0, st));
-  FEMO_TRY(ensure_scaled(A, transpose != 0));
+  FEMO_TRY(ensure_s(A));
+  if (transpose && !opts->zero_guess) FEMO_TRY(femo_mat_ensure_transpose(A));
   CgWork w;
   // FEMO_FORCE_MULTI=1 runs the all-reduce code path on a 1-rank communicator (tests)
   const bool multi = ctx->nranks > 1 || (ctx->comm != nullptr && getenv("FEMO_FORCE_MULTI") != nullptr);
@@ -1159,7 +1204,7 @@ extern "C" int femo_solve_cg(const femo_mat* A_, int transpose, const femo_vec* 
   } else {
     if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, x->d));
     const double* vals = A->d_vals;
-    if (transpose) vals = A->d_valsT;   // ensure_scaled built it
+    if (transpose) vals = A->d_valsT;
     FEMO_TRY(launch_spmv(A, vals, x->d, w.q, nullptr, nullptr));
     q0 = w.q;
   }
@@ -1194,6 +1239,7 @@ extern "C" int femo_solve_cg(const femo_mat* A_, int transpose, const femo_vec* 
   };
   if (!(std::sqrt(gamma0) > tol))   // converged at once, or NaN (reported as breakdown)
     return finish(0, gamma0 == gamma0 ? 1 : -1, gamma0);
+  FEMO_TRY(ensure_scaled(A, transpose != 0));
 
   double hs[FEMO_NSCAL] = {0};
   if (multi) hs[M_TOL2] = tol * tol;
