@@ -157,7 +157,7 @@ def cpu_baseline(args, gpu_counts, n_dof_gpu, n_cell_gpu, nnz_gpu):
     dofs_sample = m.n_vert / t_sample
     # scale the sample to the benchmark mesh: assembly-like phases by cell count; CG by nnz x
     # iteration count, where the port's Jacobi-CG count grows in proportion to n (measured on the
-    # GPU with the same Jacobi-CG: 526+556 at n=128, 971+963 at n=215; profiles/r01_bench_n1.json)
+    # GPU with the same Jacobi-CG: 526+556 at n=128, 971+963 at n=215; profiles/r01_jacobi_bench_n1.json)
     it_main = out["it_fwd"][0] + out["it_adj"]
     t_cg = T["cg_fwd"] + T["cg_adj"]
     per_it_per_nnz = t_cg / max(it_main, 1) / out["nnz"]

@@ -112,3 +112,52 @@ def test_operator_stack_on_a_partitioned_mesh(comm_ctx):
     assert np.abs(sim['u'] - ref['u']).max() < 1e-10 * np.abs(ref['u']).max()
     assert np.abs(g - ref['grad']).max() < 1e-10 * np.abs(ref['grad']).max()
     utils_hip.clear_workspaces()
+
+
+@pytest.mark.parametrize("pc", ["jacobi", "bpx"])
+def test_solve_on_self_halo_mesh(comm_ctx, monkeypatch, pc):
+    """The Krylov loops with a live halo plan (ghosts duplicating owned vertices, exchanged by
+    ncclSend/ncclRecv to self): overlapped SpMV inside the loop, all-reduced scalars and (bpx) the
+    all-reduced lattice accumulators.  Only Dirichlet vertices are duplicated: their rows are
+    replaced by identity rows anyway, so the eliminated operator is exactly the plain mesh's SPD one
+    (an owned row whose own cells point at a ghost copy would lose those cells' contributions)."""
+    from femo_amd import engine as E
+    import scipy.sparse.linalg as spla
+    m = fo.unit_cube_mesh(14, 0.2)
+    rng = np.random.default_rng(9)
+    nv = m.n_vert
+    dup = np.sort(rng.choice(fo.boundary_vertices_box(m.x), size=120, replace=False)).astype(np.int32)
+    x_ext = np.vstack([m.x, m.x[dup]])
+    conn = m.conn.copy()
+    ghost_id = {int(v): nv + k for k, v in enumerate(dup)}
+    for c in rng.choice(m.n_cell, size=m.n_cell // 2, replace=False):
+        for a in range(4):
+            if int(conn[c, a]) in ghost_id and rng.random() < 0.7:
+                conn[c, a] = ghost_id[int(conn[c, a])]
+    dm = E.DeviceMesh(comm_ctx, x_ext, conn, n_rows=nv)
+    dm.set_halo([0], [0, len(dup)], dup, [0, len(dup)])
+    bd_ext = fo.boundary_vertices_box(x_ext)
+    bc = E.DirichletSet(dm, bd_ext, 0.25)
+    f = 1.0 + rng.random(m.n_cell)
+    n_ext = nv + len(dup)
+    A, b = E.Mat(dm), E.Vec(comm_ctx, nv)
+    E.assemble_system(dm, 0, None, E.Vec(comm_ctx, n_ext).fill(0.0), E.Vec(comm_ctx, m.n_cell).set(f), bc, None, A, b)
+    # reference: the plain mesh, Newton right-hand side at u = 0 with g = 0.25 on the boundary
+    bd = fo.boundary_vertices_box(m.x)
+    K = fo.stiffness(m).tocsr()
+    g = np.zeros(nv)
+    g[bd] = 0.25
+    rhs = -fo.load_vector(m, f) - K @ (-g)          # F(0) - K[:,bc](u - g) with u = 0
+    rhs[bd] = -0.25                                  # rows of the set: u - g
+    x_ref = spla.spsolve(fo.eliminate_bc(K, bd).tocsc(), rhs)
+    assert np.abs(b.get() - rhs).max() < 1e-12 * np.abs(rhs).max()
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("FEMO_FORCE_MULTI", "1")
+        else:
+            monkeypatch.delenv("FEMO_FORCE_MULTI", raising=False)
+        x = E.Vec(comm_ctx, n_ext)
+        info = A.solve_cg(b, x, rtol=1e-14, pc=pc)
+        assert info.converged == 1
+        assert np.abs(x.get(nv) - x_ref).max() < 1e-10 * np.abs(x_ref).max()
+    monkeypatch.delenv("FEMO_FORCE_MULTI", raising=False)
