@@ -18,10 +18,12 @@
 // nodes are a subset of the finest ones).  Measured with this rule (rtol 1e-14): 40-44
 // iterations on the jittered 3-D cube, the 2-D square and both Nitsche Jacobians, against
 // 200-1200 with Jacobi; without the node rule 70-130.  Nested lattices: only the finest
-// one touches the mesh (restriction by fp64 atomics into a lattice that fits in L2 /
-// Infinity Cache, prolongation by gathers); the coarser levels are reached lattice to
-// lattice with 27-point (9-point) stencils.  CG runs on the symmetrically scaled system
-// Ah = S A S, so in scaled variables  zh = rh + S^-1 (sum_l P_l C_l P_l^T) S^-1 rh.
+// one touches the mesh (restriction brick by brick through LDS into a lattice that fits in
+// L2 / Infinity Cache, prolongation by gathers); the coarser levels are reached lattice to
+// lattice with 27-point (9-point) stencils.  Both mesh transfers read 12-byte packed lattice
+// coordinates (bin, 20-bit fraction per axis) instead of the vertex coordinates.  CG runs on
+// the symmetrically scaled system Ah = S A S, so in scaled variables
+//     zh = rh + S^-1 (sum_l P_l C_l P_l^T) S^-1 rh.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -51,8 +53,11 @@ struct femo_pc {
   // owned vertices sorted by brick (BRICK^dim bins of the finest lattice), for the restriction
   int64_t n_bricks = 0;
   int32_t* d_perm = nullptr;        // sorted position -> vertex
-  double* d_xs = nullptr;           // coordinates in sorted order
+  uint32_t* d_pk = nullptr;         // packed lattice coordinates, dim words per owned vertex (vertex order)
+  uint32_t* d_pk_sorted = nullptr;  // the same in sorted order
+  double* d_w_sorted = nullptr;     // 1/s (0 on pinned vertices) in sorted order, refreshed per solve
   int64_t* d_brick_ptr = nullptr;   // n_bricks + 1
+  uint32_t* d_bin_ptr = nullptr;    // 65 per brick: start of each of its 64 bins, relative to the brick
   int32_t* d_brick_base = nullptr;  // 3 per brick: first bin of the brick along each axis
   bool coef_valid = false;
 };
@@ -112,63 +117,109 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_mesh(int64_t n_rows, La
   }
 }
 
-// The restriction every iteration runs: vertices sorted by brick, one workgroup per brick
-// accumulates its (BRICK+1)^D lattice nodes in LDS (ds_add_f64) and flushes them with one global
-// atomic per node -- ~20x fewer L2 atomics than k_restrict_mesh, which is atomic-rate bound
-// (~32 G/s measured) and is kept for the one-off mass restrictions of pc_prepare.
-template <int D> struct Brick { static constexpr int B = D == 3 ? 4 : 8; static constexpr int N1 = B + 1; static constexpr int NLOC = D == 3 ? N1 * N1 * N1 : N1 * N1; };
+// Lattice coordinates of a vertex on the finest lattice, one 32-bit word per axis: bin << 20 | t,
+// t = fraction inside the bin in 20-bit fixed point.  Both transfers decode the same words, so P
+// and P^T stay exact transposes; the 1e-6 quantisation of the weights only perturbs the
+// preconditioner.  12 B per vertex instead of 24 B of coordinates.
+constexpr int PK_BITS = 20;
+constexpr uint32_t PK_MASK = (1u << PK_BITS) - 1u;
+__device__ __forceinline__ void unpack_coord(uint32_t w, int& bin, double& t) {
+  bin = (int)(w >> PK_BITS);
+  t = (double)(w & PK_MASK) * (1.0 / (double)(1u << PK_BITS));
+}
+
+// The restriction every iteration runs.  Vertices are sorted by brick (B^D bins of the finest
+// lattice) and, inside a brick, by bin.  One workgroup per brick:
+//   A. all lanes stage the brick's vertices in LDS (value r/s, t per axis) with coalesced loads;
+//   B. lane = bin (a brick has 64 bins = one wave; the 4 waves take every 4th vertex of a bin):
+//      the 2^D corner sums of the bin are accumulated in registers -- no atomics, no conflicts;
+//   C. a lattice node adds up its <= 2^D adjacent bins' corner sums (fixed order: reproducible
+//      per brick), keeps the result in LDS for the fused coarser levels and flushes it with one
+//      global atomic per node and brick.
+// The first version accumulated with ds_add_f64 per vertex and corner and was bound by same-address
+// LDS atomics (~11 vertices per bin): 101-150 us at C4 against ~65 us for this one.
+template <int D> struct Brick { static constexpr int B = D == 3 ? 4 : 8; static constexpr int N1 = B + 1; static constexpr int NLOC = D == 3 ? N1 * N1 * N1 : N1 * N1; static constexpr int NBIN = 64; static constexpr int NC = 1 << D; };
+constexpr int BRICK_CHUNK = 1024;   // vertices staged per pass (bricks with more loop)
+
+// w_sorted[i] = 1/s of the i-th sorted vertex, 0 for pinned vertices (once per solve: s changes with
+// every assembly).  Leaves one gather (the residual) in the restriction's staging loop.
+__global__ void k_pc_weights(int64_t n, const int32_t* __restrict__ perm, const double* __restrict__ s,
+                             const uint8_t* __restrict__ mask, double* __restrict__ w) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t v = perm[i];
+    w[i] = (mask != nullptr && mask[v]) ? 0.0 : 1.0 / s[v];
+  }
+}
 
 template <int D>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks, const int64_t* __restrict__ brick_ptr,
-                                                                const int32_t* __restrict__ brick_base, const int32_t* __restrict__ perm,
-                                                                const double* __restrict__ xs, Lat lat, const double* __restrict__ val,
-                                                                const double* __restrict__ s, const uint8_t* __restrict__ mask,
+                                                                const int32_t* __restrict__ brick_base, const uint32_t* __restrict__ bin_ptr,
+                                                                const int32_t* __restrict__ perm, const uint32_t* __restrict__ pk,
+                                                                Lat lat, const double* __restrict__ val,
+                                                                const double* __restrict__ w_sorted,
                                                                 double* __restrict__ g, int n_fused, const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
-  constexpr int B = Brick<D>::B, N1 = Brick<D>::N1, NLOC = Brick<D>::NLOC;
+  constexpr int B = Brick<D>::B, N1 = Brick<D>::N1, NLOC = Brick<D>::NLOC, NC = Brick<D>::NC;
   __shared__ double acc[NLOC];
   __shared__ double acc2[NLOC];
+  __shared__ double sval[BRICK_CHUNK];
+  __shared__ float st[D][BRICK_CHUNK];          // 20-bit fractions are exact in fp32
+  __shared__ double binsum[NC][64];
+  const int bin = threadIdx.x >> 2, sub = threadIdx.x & 3;   // 4 adjacent lanes share a bin
   for (int64_t brick = blockIdx.x; brick < n_bricks; brick += gridDim.x) {
-    for (int j = threadIdx.x; j < NLOC; j += FEMO_BLOCK) acc[j] = 0.0;
-    __syncthreads();
     int base[3] = {brick_base[brick * 3], brick_base[brick * 3 + 1], brick_base[brick * 3 + 2]};
-    const int64_t end = brick_ptr[brick + 1];
-    for (int64_t i = brick_ptr[brick] + threadIdx.x; i < end; i += FEMO_BLOCK) {
-      const int32_t v = perm[i];
-      if (mask != nullptr && mask[v]) continue;
-      const double r = val[v] / s[v];
-      int b[3] = {0, 0, 0};
-      double t[3] = {0.0, 0.0, 0.0};
+    const int64_t start = brick_ptr[brick], end = brick_ptr[brick + 1];
+    const uint32_t* bp = bin_ptr + brick * 65;
+    const int64_t bin_lo = start + bp[bin], bin_hi = start + bp[bin + 1];
+    double c[NC];
 #pragma unroll
-      for (int k = 0; k < D; ++k) {
-        const double gk = (xs[i * D + k] - lat.lo[k]) * lat.inv_h[k];
-        int bk = (int)floor(gk) - base[k];
-        const int top = min(B - 1, lat.n[k] - 1 - base[k]);
-        bk = bk < 0 ? 0 : (bk > top ? top : bk);
-        const double f = gk - (double)(base[k] + bk);
-        b[k] = bk;
-        t[k] = f < 0.0 ? 0.0 : (f > 1.0 ? 1.0 : f);
+    for (int q = 0; q < NC; ++q) c[q] = 0.0;
+    for (int64_t chunk = start; chunk < end; chunk += BRICK_CHUNK) {
+      const int64_t chunk_end = chunk + BRICK_CHUNK < end ? chunk + BRICK_CHUNK : end;
+      __syncthreads();
+      for (int64_t i = chunk + threadIdx.x; i < chunk_end; i += FEMO_BLOCK) {
+        sval[i - chunk] = val[perm[i]] * w_sorted[i];
+#pragma unroll
+        for (int k = 0; k < D; ++k) st[k][i - chunk] = (float)(pk[i * D + k] & PK_MASK) * (1.0f / (float)(1u << PK_BITS));
       }
+      __syncthreads();
+      for (int64_t j = bin_lo + sub; j < bin_hi; j += 4) {
+        if (j < chunk || j >= chunk_end) continue;      // only bricks above BRICK_CHUNK vertices take a second pass
+        const double r = sval[j - chunk];
+        double t[D];
 #pragma unroll
-      for (int c = 0; c < (1 << D); ++c) {
-        double w = r;
-        int idx = 0, stride = 1;
+        for (int k = 0; k < D; ++k) t[k] = (double)st[k][j - chunk];
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-          const int bit = (c >> k) & 1;
-          w *= bit ? t[k] : 1.0 - t[k];
-          idx += (b[k] + bit) * stride;
-          stride *= N1;
+        for (int q = 0; q < NC; ++q) {
+          double w = r;
+#pragma unroll
+          for (int k = 0; k < D; ++k) w *= ((q >> k) & 1) ? t[k] : 1.0 - t[k];
+          c[q] += w;
         }
-        if (w != 0.0) atomicAdd(&acc[idx], w);
       }
+    }
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+      double v = c[q];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      if (sub == 0) binsum[q][bin] = v;
     }
     __syncthreads();
     for (int j = threadIdx.x; j < NLOC; j += FEMO_BLOCK) {
-      const double a = acc[j];
+      const int J[3] = {j % N1, (j / N1) % N1, D == 3 ? j / (N1 * N1) : 0};
+      double a = 0.0;
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        // the bin for which this node is corner q
+        const int b0 = J[0] - (q & 1), b1 = J[1] - ((q >> 1) & 1), b2 = D == 3 ? J[2] - ((q >> 2) & 1) : 0;
+        if (b0 < 0 || b0 >= B || b1 < 0 || b1 >= B || b2 < 0 || (D == 3 && b2 >= B)) continue;
+        a += binsum[q][D == 3 ? (b2 * B + b1) * B + b0 : b1 * B + b0];
+      }
+      acc[j] = a;
       if (a != 0.0) {
-        const int i0 = base[0] + j % N1, i1 = base[1] + (j / N1) % N1, i2 = D == 3 ? base[2] + j / (N1 * N1) : 0;
-        atomicAdd(&g[node_index(lat.n, i0, i1, i2)], a);
+        const int i0 = base[0] + J[0], i1 = base[1] + J[1], i2 = D == 3 ? base[2] + J[2] : 0;
+        if (i0 <= lat.n[0] && i1 <= lat.n[1] && i2 <= lat.n[2]) atomicAdd(&g[node_index(lat.n, i0, i1, i2)], a);
       }
     }
     // the next n_fused coarser lattices straight from the LDS copy: the brick starts on a multiple
@@ -217,7 +268,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
 
 // zh = rh + (1/s) P_L e_L ; partial rh.zh
 template <int D>
-__global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat lat, const double* __restrict__ x,
+__global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat lat, const uint32_t* __restrict__ pk,
                                                              const double* __restrict__ rh, const double* __restrict__ s,
                                                              const uint8_t* __restrict__ mask, const double* __restrict__ e,
                                                              double* __restrict__ zh, double* __restrict__ partials,
@@ -229,9 +280,10 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat
     const double r = rh[v];
     double z = r;
     if (!(mask != nullptr && mask[v])) {
-      int i0[3];
-      double t[3];
-      locate<D>(lat, x, v, i0, t);
+      int i0[3] = {0, 0, 0};
+      double t[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int k = 0; k < D; ++k) unpack_coord(pk[v * D + k], i0[k], t[k]);
       double sum = 0.0;
 #pragma unroll
       for (int c = 0; c < (1 << D); ++c) {
@@ -245,7 +297,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat
         }
         sum += w * e[node_index(lat.n, ijk[0], ijk[1], ijk[2])];
       }
-      z += sum / s[v];
+      z += sum * (1.0 / s[v]);     // the same rounded 1/s the restriction multiplies with
     }
     zh[v] = z;
     acc += r * z;
@@ -411,12 +463,14 @@ int femo_pc_build(femo_mesh* m) {
     for (auto& L : pc->L) { L.g = pc->g_all + off; off += L.nodes; }
     pc->n_fused = std::min(pc->dim == 3 ? 2 : 3, pc->n_levels - 1);
   }
-  // sort the owned vertices by brick of the finest lattice (host counting sort, once per mesh)
+  // owned vertices: packed lattice coordinates, then a counting sort by (brick, bin) on the host
+  // (once per mesh; 0.5 s at C4)
   {
     const int D = pc->dim;
     const int B = D == 3 ? 4 : 8;
     const LatticeLevel& F = pc->L.back();
     const int64_t nr = m->n_rows;
+    for (int k = 0; k < D; ++k) FEMO_REQUIRE(F.n[k] < (1 << (32 - PK_BITS)), "preconditioner lattice too fine for packed coordinates");
     std::vector<double> hx((size_t)std::max<int64_t>(nr * D, 1));
     FEMO_HIP_CHECK(hipMemcpyAsync(hx.data(), m->d_x, nr * D * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     FEMO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -424,48 +478,70 @@ int femo_pc_build(femo_mesh* m) {
     double inv_h[3] = {0, 0, 0};
     for (int k = 0; k < D; ++k) { nbr[k] = (F.n[k] + B - 1) / B; inv_h[k] = F.n[k] / (pc->hi[k] - pc->lo[k]); }
     const int64_t n_all = (int64_t)nbr[0] * nbr[1] * nbr[2];
-    std::vector<int64_t> count((size_t)n_all + 1, 0);
-    std::vector<int32_t> key((size_t)std::max<int64_t>(nr, 1));
-    FEMO_REQUIRE(n_all < (int64_t(1) << 31), "preconditioner lattice too fine");
+    FEMO_REQUIRE(n_all < (int64_t(1) << 24), "preconditioner lattice too fine");
+    std::vector<uint32_t> pk((size_t)std::max<int64_t>(nr * D, 1));
+    std::vector<int32_t> key((size_t)std::max<int64_t>(nr, 1));     // brick id * 64 + bin inside the brick
+    std::vector<int64_t> count((size_t)n_all * 64 + 1, 0);
     for (int64_t v = 0; v < nr; ++v) {
-      int64_t id = 0, stride = 1;
+      int64_t brick = 0, bstride = 1;
+      int local = 0, lstride = 1;
       for (int k = 0; k < D; ++k) {
-        int b = (int)std::floor((hx[v * D + k] - pc->lo[k]) * inv_h[k]);
+        const double gk = (hx[v * D + k] - pc->lo[k]) * inv_h[k];
+        int b = (int)std::floor(gk);
         b = b < 0 ? 0 : (b > F.n[k] - 1 ? F.n[k] - 1 : b);
-        id += (int64_t)(b / B) * stride;
-        stride *= nbr[k];
+        double t = gk - b;
+        t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+        uint32_t tq = (uint32_t)(t * (double)(1u << PK_BITS) + 0.5);
+        if (tq > PK_MASK) tq = PK_MASK;
+        pk[v * D + k] = ((uint32_t)b << PK_BITS) | tq;
+        brick += (int64_t)(b / B) * bstride;
+        bstride *= nbr[k];
+        local += (b % B) * lstride;
+        lstride *= B;
       }
-      key[v] = (int32_t)id;
-      ++count[id + 1];
+      key[v] = (int32_t)(brick * 64 + local);
+      ++count[(size_t)key[v] + 1];
     }
-    std::vector<int64_t> ptr_c, slot((size_t)n_all, -1);
+    for (size_t i = 1; i < count.size(); ++i) count[i] += count[i - 1];   // count[key] = first sorted position
+    std::vector<int64_t> ptr_c;
     std::vector<int32_t> base_c;
+    std::vector<uint32_t> binp;
     ptr_c.push_back(0);
     for (int64_t id = 0; id < n_all; ++id) {
-      if (count[id + 1] == 0) continue;
-      slot[id] = (int64_t)ptr_c.size() - 1;
-      ptr_c.push_back(ptr_c.back() + count[id + 1]);
+      const int64_t first = count[(size_t)id * 64], last = count[(size_t)id * 64 + 64];
+      if (last == first) continue;
+      FEMO_REQUIRE(last - first < (int64_t(1) << 32), "brick too large");
+      ptr_c.push_back(last);
       base_c.push_back((int32_t)(id % nbr[0]) * B);
       base_c.push_back((int32_t)((id / nbr[0]) % nbr[1]) * B);
       base_c.push_back((int32_t)(id / ((int64_t)nbr[0] * nbr[1])) * B);
+      for (int q = 0; q <= 64; ++q) binp.push_back((uint32_t)(count[(size_t)id * 64 + q] - first));
     }
     pc->n_bricks = (int64_t)ptr_c.size() - 1;
-    std::vector<int64_t> fill(ptr_c.begin(), ptr_c.end() - 1);
     std::vector<int32_t> perm((size_t)std::max<int64_t>(nr, 1));
-    std::vector<double> xs((size_t)std::max<int64_t>(nr * D, 1));
-    for (int64_t v = 0; v < nr; ++v) {
-      const int64_t at = fill[slot[key[v]]]++;
-      perm[at] = (int32_t)v;
-      for (int k = 0; k < D; ++k) xs[at * D + k] = hx[v * D + k];
+    std::vector<uint32_t> pks((size_t)std::max<int64_t>(nr * D, 1));
+    {
+      std::vector<int64_t> fill(count.begin(), count.end() - 1);
+      for (int64_t v = 0; v < nr; ++v) {      // stable: vertices of a bin stay in index order
+        const int64_t at = fill[(size_t)key[v]]++;
+        perm[at] = (int32_t)v;
+        for (int k = 0; k < D; ++k) pks[at * D + k] = pk[v * D + k];
+      }
     }
     if (base_c.empty()) base_c.assign(3, 0);
+    if (binp.empty()) binp.assign(65, 0);
     FEMO_HIP_CHECK(hipMalloc(&pc->d_perm, perm.size() * sizeof(int32_t)));
-    FEMO_HIP_CHECK(hipMalloc(&pc->d_xs, xs.size() * sizeof(double)));
+    FEMO_HIP_CHECK(hipMalloc(&pc->d_pk, pk.size() * sizeof(uint32_t)));
+    FEMO_HIP_CHECK(hipMalloc(&pc->d_pk_sorted, pks.size() * sizeof(uint32_t)));
+    FEMO_HIP_CHECK(hipMalloc(&pc->d_w_sorted, perm.size() * sizeof(double)));
     FEMO_HIP_CHECK(hipMalloc(&pc->d_brick_ptr, ptr_c.size() * sizeof(int64_t)));
+    FEMO_HIP_CHECK(hipMalloc(&pc->d_bin_ptr, binp.size() * sizeof(uint32_t)));
     FEMO_HIP_CHECK(hipMalloc(&pc->d_brick_base, base_c.size() * sizeof(int32_t)));
     FEMO_HIP_CHECK(hipMemcpy(pc->d_perm, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    FEMO_HIP_CHECK(hipMemcpy(pc->d_xs, xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice));
+    FEMO_HIP_CHECK(hipMemcpy(pc->d_pk, pk.data(), pk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    FEMO_HIP_CHECK(hipMemcpy(pc->d_pk_sorted, pks.data(), pks.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     FEMO_HIP_CHECK(hipMemcpy(pc->d_brick_ptr, ptr_c.data(), ptr_c.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    FEMO_HIP_CHECK(hipMemcpy(pc->d_bin_ptr, binp.data(), binp.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     FEMO_HIP_CHECK(hipMemcpy(pc->d_brick_base, base_c.data(), base_c.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   m->pc = pc;
@@ -476,7 +552,8 @@ void femo_pc_destroy(femo_mesh* m) {
   if (!m->pc) return;
   for (auto& L : m->pc->L) { (void)hipFree(L.e); (void)hipFree(L.coef); }
   (void)hipFree(m->pc->g_all);
-  (void)hipFree(m->pc->d_perm); (void)hipFree(m->pc->d_xs); (void)hipFree(m->pc->d_brick_ptr); (void)hipFree(m->pc->d_brick_base);
+  (void)hipFree(m->pc->d_perm); (void)hipFree(m->pc->d_pk); (void)hipFree(m->pc->d_pk_sorted); (void)hipFree(m->pc->d_w_sorted);
+  (void)hipFree(m->pc->d_brick_ptr); (void)hipFree(m->pc->d_bin_ptr); (void)hipFree(m->pc->d_brick_base);
   delete m->pc;
   m->pc = nullptr;
 }
@@ -537,9 +614,9 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
   if (pc->n_bricks > 0) {
     const unsigned gb = (unsigned)std::min<int64_t>(pc->n_bricks, 256 * 64);
     if (pc->dim == 3)
-      hipLaunchKernelGGL(k_restrict_bricks<3>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_perm, pc->d_xs, lat, rh, s, mask, F.g, nf, done);
+      hipLaunchKernelGGL(k_restrict_bricks<3>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, rh, pc->d_w_sorted, F.g, nf, done);
     else
-      hipLaunchKernelGGL(k_restrict_bricks<2>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_perm, pc->d_xs, lat, rh, s, mask, F.g, nf, done);
+      hipLaunchKernelGGL(k_restrict_bricks<2>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, rh, pc->d_w_sorted, F.g, nf, done);
   }
   if (ctx->nranks > 1) {   // one all-reduce over the contiguous accumulators of the finest nf+1 levels
     double* first = pc->L[nl - 1 - nf].g;
@@ -558,16 +635,20 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
     hipLaunchKernelGGL(k_lattice_prolong, dim3(lat_grid(Fi.nodes)), dim3(256), 0, st, Fi.n[0], Fi.n[1], Fi.n[2], nc[0], nc[1], nc[2], pc->dim, ec, Fi.coef, Fi.g, l >= nl - 1 - nf ? 1 : 0, Fi.e, done);
   }
   if (pc->dim == 3)
-    hipLaunchKernelGGL(k_prolong_mesh<3>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, m->d_x, rh, s, mask, F.e, zh, partials, done);
+    hipLaunchKernelGGL(k_prolong_mesh<3>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, s, mask, F.e, zh, partials, done);
   else
-    hipLaunchKernelGGL(k_prolong_mesh<2>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, m->d_x, rh, s, mask, F.e, zh, partials, done);
+    hipLaunchKernelGGL(k_prolong_mesh<2>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, s, mask, F.e, zh, partials, done);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
-// start of a solve: the atomically accumulated g arrays must be zero
-int femo_pc_begin(femo_mesh* m) {
+// start of a solve: per-vertex weights of the current operator; the atomically accumulated g arrays must be zero
+int femo_pc_begin(femo_mesh* m, const double* s, const uint8_t* mask) {
   femo_pc* pc = m->pc;
+  if (m->n_rows > 0) {
+    hipLaunchKernelGGL(k_pc_weights, dim3(lat_grid(m->n_rows)), dim3(256), 0, m->ctx->stream, m->n_rows, pc->d_perm, s, mask, pc->d_w_sorted);
+    FEMO_HIP_CHECK(hipGetLastError());
+  }
   const int nl = pc->n_levels;
   double* first = pc->L[nl - 1 - pc->n_fused].g;
   const int64_t count = (pc->L[nl - 1].g + pc->L[nl - 1].nodes) - first;

@@ -246,6 +246,6 @@ int femo_pc_build(femo_mesh* m);
 void femo_pc_destroy(femo_mesh* m);
 int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const double* s, const double* rh, double* zh,
                   double* partials, const int32_t* done, int gv);
-int femo_pc_begin(femo_mesh* m);
+int femo_pc_begin(femo_mesh* m, const double* s, const uint8_t* mask);
 int femo_pc_levels(const femo_mesh* m, int* n_levels, int64_t* finest_nodes);
 int femo_reduce_to_host(femo_ctx* ctx, int nblocks, int nsums, double* host_out);

@@ -1027,7 +1027,6 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
   FEMO_HIP_CHECK(hipEventRecord(ctx->ev0, st));
   FEMO_TRY(ensure_s(A));
   FEMO_TRY(femo_pc_build(m));
-  FEMO_TRY(femo_pc_begin(m));
   CgWork w;
   const bool multi = ctx->nranks > 1 || (ctx->comm != nullptr && getenv("FEMO_FORCE_MULTI") != nullptr);
   FEMO_TRY(ensure_work(ctx, n, m->n_vert, w, 1));
@@ -1038,6 +1037,7 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
   double* P = ctx->d_partials;
   double* S = ctx->d_scal;
   const uint8_t* mask = A->pc_has_mask ? A->d_pcmask : nullptr;
+  FEMO_TRY(femo_pc_begin(m, A->d_s, mask));
   auto allreduce1 = [&](double* d) -> int {
     if (multi) FEMO_NCCL_CHECK(ncclAllReduce(d, d, 1, ncclDouble, ncclSum, ctx->comm, st));
     return 0;
