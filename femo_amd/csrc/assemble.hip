@@ -85,6 +85,32 @@ __device__ __forceinline__ void cell_geom(const double* __restrict__ x, const in
   cell_geom_p<D>(p, G);
 }
 
+// cell_geom for the row walks: the visiting lane owns local vertex a and already holds its
+// coordinates, so only the D other vertices are gathered (the walks are bound by the number of
+// scattered loads per visited cell).  Values and vertex order are those of cell_geom: same bits.
+template <int D>
+__device__ __forceinline__ void cell_geom_owner(const double* __restrict__ x, const int32_t v[D + 1], int a,
+                                                const double (&xo)[D], CellGeom<D>& G) {
+  double o[D][D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    const int32_t vj = (a <= j) ? v[j + 1] : v[j];       // the j-th vertex other than a
+    const double* q = x + (int64_t)vj * D;
+#pragma unroll
+    for (int k = 0; k < D; ++k) o[j][k] = q[k];
+  }
+  double p[D + 1][D];
+#pragma unroll
+  for (int b = 0; b <= D; ++b) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const double lo = o[b > 0 ? b - 1 : 0][k], hi = o[b < D ? b : D - 1][k];
+      p[b][k] = (a == b) ? xo[k] : ((a > b) ? hi : lo);
+    }
+  }
+  cell_geom_p<D>(p, G);
+}
+
 // Row a of the gradient table with a lane-varying a.  Written as an exact blend
 // (weights 1.0 / 0.0) rather than a select chain: LLVM folds select(load, load) on a
 // private array into a dynamically indexed load, which forces the whole table into
@@ -317,6 +343,12 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
   const int nvis = (int)((vptr[slice + 1] - vb) >> 6);
   const bool want_rhs = rhs != nullptr;
   double dsum = 0.0, racc = 0.0;
+  double xo[D];
+  {
+    const int64_t r0 = row < n_rows ? row : 0;      // padded lanes of the last slice visit nothing
+#pragma unroll
+    for (int k = 0; k < D; ++k) xo[k] = x[r0 * D + k];
+  }
   for (int s = 0; s < nvis; ++s) {
     const int64_t vi = vb + (int64_t)s * 64 + lane;
     const int32_t ca = visit_cell[vi];
@@ -343,7 +375,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
         if (want_rhs) racc += krow[b] * u[v[b]];
       }
     } else {
-    cell_geom<D>(x, v, G);
+    cell_geom_owner<D>(x, v, a, xo, G);
     select_row<D>(G, a, ga);
     if (want_rhs) racc -= f[c] * G.vol * (1.0 / (D + 1));
 #pragma unroll

@@ -30,6 +30,8 @@
 
 #include "femo_internal.h"
 
+constexpr int FEMO_PC_MAX_LEVELS = 14;
+
 namespace {
 
 struct LatticeLevel {
@@ -307,35 +309,54 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat
 }
 
 // coarse[I] = sum over the fine nodes 2I-1, 2I, 2I+1 (per axis) with weights 1/2, 1, 1/2
+__device__ __forceinline__ double lattice_restrict_node(int64_t idx, const int* nc, const int* nf, int dim,
+                                                        const double* __restrict__ fine) {
+  const int i = (int)(idx % (nc[0] + 1));
+  const int j = (int)((idx / (nc[0] + 1)) % (nc[1] + 1));
+  const int k = (int)(idx / ((int64_t)(nc[0] + 1) * (nc[1] + 1)));
+  double acc = 0.0;
+  const int kz0 = dim == 3 ? -1 : 0, kz1 = dim == 3 ? 1 : 0;
+  for (int dz = kz0; dz <= kz1; ++dz) {
+    const int fk = dim == 3 ? 2 * k + dz : 0;
+    if (fk < 0 || fk > nf[2]) continue;
+    const double wz = dz == 0 ? 1.0 : 0.5;
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int fj = 2 * j + dy;
+      if (fj < 0 || fj > nf[1]) continue;
+      const double wy = dy == 0 ? 1.0 : 0.5;
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int fi = 2 * i + dx;
+        if (fi < 0 || fi > nf[0]) continue;
+        const double wx = dx == 0 ? 1.0 : 0.5;
+        acc += wx * wy * wz * fine[node_index(nf, fi, fj, fk)];
+      }
+    }
+  }
+  return acc;
+}
+
+// (interpolation of e_c)(fine node idx)
+__device__ __forceinline__ double lattice_interp_node(int64_t idx, const int* nf, const int* nc, int dim,
+                                                      const double* __restrict__ ec) {
+  const int i = (int)(idx % (nf[0] + 1));
+  const int j = (int)((idx / (nf[0] + 1)) % (nf[1] + 1));
+  const int k = (int)(idx / ((int64_t)(nf[0] + 1) * (nf[1] + 1)));
+  const int ci[2] = {i >> 1, (i + 1) >> 1}, cj[2] = {j >> 1, (j + 1) >> 1};
+  const int ck[2] = {dim == 3 ? k >> 1 : 0, dim == 3 ? (k + 1) >> 1 : 0};
+  double acc = 0.0;
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b)
+      for (int c = 0; c < 2; ++c) acc += ec[node_index(nc, ci[a], cj[b], ck[c])];
+  return 0.125 * acc;   // even index: both parents coincide (2 x 1/2); odd: the two neighbours at 1/2 each
+}
+
 __global__ void k_lattice_restrict(int nc0, int nc1, int nc2, int nf0, int nf1, int nf2, int dim,
                                    const double* __restrict__ fine, double* __restrict__ coarse, const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
   const int64_t total = (int64_t)(nc0 + 1) * (nc1 + 1) * (nc2 + 1);
-  const int nf[3] = {nf0, nf1, nf2};
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int i = (int)(idx % (nc0 + 1));
-    const int j = (int)((idx / (nc0 + 1)) % (nc1 + 1));
-    const int k = (int)(idx / ((int64_t)(nc0 + 1) * (nc1 + 1)));
-    double acc = 0.0;
-    const int kz0 = dim == 3 ? -1 : 0, kz1 = dim == 3 ? 1 : 0;
-    for (int dz = kz0; dz <= kz1; ++dz) {
-      const int fk = dim == 3 ? 2 * k + dz : 0;
-      if (fk < 0 || fk > nf2) continue;
-      const double wz = dz == 0 ? 1.0 : 0.5;
-      for (int dy = -1; dy <= 1; ++dy) {
-        const int fj = 2 * j + dy;
-        if (fj < 0 || fj > nf1) continue;
-        const double wy = dy == 0 ? 1.0 : 0.5;
-        for (int dx = -1; dx <= 1; ++dx) {
-          const int fi = 2 * i + dx;
-          if (fi < 0 || fi > nf0) continue;
-          const double wx = dx == 0 ? 1.0 : 0.5;
-          acc += wx * wy * wz * fine[node_index(nf, fi, fj, fk)];
-        }
-      }
-    }
-    coarse[idx] = acc;
-  }
+  const int nc[3] = {nc0, nc1, nc2}, nf[3] = {nf0, nf1, nf2};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x)
+    coarse[idx] = lattice_restrict_node(idx, nc, nf, dim, fine);
 }
 
 // e_f[i] = (interpolation of e_c)(i) + coef_f[i] * g_f[i]     (e_c == nullptr: coarsest level)
@@ -344,23 +365,45 @@ __global__ void k_lattice_prolong(int nf0, int nf1, int nf2, int nc0, int nc1, i
                                   int zero_g, double* __restrict__ ef, const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
   const int64_t total = (int64_t)(nf0 + 1) * (nf1 + 1) * (nf2 + 1);
-  const int nc[3] = {nc0, nc1, nc2};
+  const int nc[3] = {nc0, nc1, nc2}, nf[3] = {nf0, nf1, nf2};
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     double v = coef[idx] * g[idx];
     if (zero_g) g[idx] = 0.0;      // accumulated by atomics: left clean for the next restriction
-    if (ec != nullptr) {
-      const int i = (int)(idx % (nf0 + 1));
-      const int j = (int)((idx / (nf0 + 1)) % (nf1 + 1));
-      const int k = (int)(idx / ((int64_t)(nf0 + 1) * (nf1 + 1)));
-      const int ci[2] = {i >> 1, (i + 1) >> 1}, cj[2] = {j >> 1, (j + 1) >> 1};
-      const int ck[2] = {dim == 3 ? k >> 1 : 0, dim == 3 ? (k + 1) >> 1 : 0};
-      double acc = 0.0;
-      for (int a = 0; a < 2; ++a)
-        for (int b = 0; b < 2; ++b)
-          for (int c = 0; c < 2; ++c) acc += ec[node_index(nc, ci[a], cj[b], ck[c])];
-      v += 0.125 * acc;   // even index: both parents coincide (2 x 1/2); odd: the two neighbours at 1/2 each
-    }
+    if (ec != nullptr) v += lattice_interp_node(idx, nf, nc, dim, ec);
     ef[idx] = v;
+  }
+}
+
+// The coarse end of the hierarchy in ONE single-workgroup launch: restrict g down from level `top`
+// (filled by the brick kernel or the last multi-block restriction) to level 0, then build the
+// corrections e_0 .. e_{top-1} on the way up.  These levels have a few thousand nodes; as separate
+// launches they cost ~4.7 us each in launch latency alone (2 x top launches per iteration).
+struct CoarseLevels {
+  int n_levels;                 // levels 0 .. n_levels-1 are handled here; level n_levels is `top`
+  int n[FEMO_PC_MAX_LEVELS][3];
+  double* g[FEMO_PC_MAX_LEVELS];
+  double* e[FEMO_PC_MAX_LEVELS];
+  const double* coef[FEMO_PC_MAX_LEVELS];
+};
+
+__global__ __launch_bounds__(1024) void k_lattice_coarse(CoarseLevels L, int dim, const int32_t* __restrict__ done) {
+  if (done != nullptr && *done) return;
+  const int top = L.n_levels;
+  for (int l = top - 1; l >= 0; --l) {
+    const int64_t total = (int64_t)(L.n[l][0] + 1) * (L.n[l][1] + 1) * (L.n[l][2] + 1);
+    for (int64_t idx = threadIdx.x; idx < total; idx += 1024) L.g[l][idx] = lattice_restrict_node(idx, L.n[l], L.n[l + 1], dim, L.g[l + 1]);
+    __threadfence_block();
+    __syncthreads();
+  }
+  for (int l = 0; l < top; ++l) {
+    const int64_t total = (int64_t)(L.n[l][0] + 1) * (L.n[l][1] + 1) * (L.n[l][2] + 1);
+    for (int64_t idx = threadIdx.x; idx < total; idx += 1024) {
+      double v = L.coef[l][idx] * L.g[l][idx];
+      if (l > 0) v += lattice_interp_node(idx, L.n[l], L.n[l - 1], dim, L.e[l - 1]);
+      L.e[l][idx] = v;
+    }
+    __threadfence_block();
+    __syncthreads();
   }
 }
 
@@ -623,12 +666,26 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
     const int64_t count = (F.g + F.nodes) - first;
     FEMO_NCCL_CHECK(ncclAllReduce(first, first, count, ncclDouble, ncclSum, ctx->comm, st));
   }
-  for (int l = nl - 2 - nf; l >= 0; --l) {
+  // levels with at most COARSE_NODES nodes (and below the brick-fused ones) go through the
+  // single-workgroup kernel; `cut` = first level handled by multi-block launches
+  constexpr int64_t COARSE_NODES = 6000;
+  int cut = 0;
+  while (cut < nl - 1 - nf && cut < FEMO_PC_MAX_LEVELS - 1 && pc->L[cut].nodes <= COARSE_NODES) ++cut;
+  for (int l = nl - 2 - nf; l >= cut; --l) {
     LatticeLevel& C = pc->L[l];
     const LatticeLevel& Fi = pc->L[l + 1];
     hipLaunchKernelGGL(k_lattice_restrict, dim3(lat_grid(C.nodes)), dim3(256), 0, st, C.n[0], C.n[1], C.n[2], Fi.n[0], Fi.n[1], Fi.n[2], pc->dim, Fi.g, C.g, done);
   }
-  for (int l = 0; l < nl; ++l) {
+  if (cut > 0) {
+    CoarseLevels CL;
+    CL.n_levels = cut;
+    for (int l = 0; l <= cut; ++l) {
+      for (int k = 0; k < 3; ++k) CL.n[l][k] = pc->L[l].n[k];
+      CL.g[l] = pc->L[l].g; CL.e[l] = pc->L[l].e; CL.coef[l] = pc->L[l].coef;
+    }
+    hipLaunchKernelGGL(k_lattice_coarse, dim3(1), dim3(1024), 0, st, CL, pc->dim, done);
+  }
+  for (int l = cut; l < nl; ++l) {
     LatticeLevel& Fi = pc->L[l];
     const double* ec = l > 0 ? pc->L[l - 1].e : nullptr;
     const int* nc = l > 0 ? pc->L[l - 1].n : Fi.n;
