@@ -85,6 +85,7 @@ PROTOTYPES = {
     "femo_mat_export_csr": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "femo_mat_diagonal": (C.c_int, [H, H]),
     "femo_solve_cg": (C.c_int, [H, C.c_int, H, H, C.POINTER(SolverOpts), C.POINTER(SolveInfo)]),
+    "femo_mat_pc_apply": (C.c_int, [H, H, H]),
     "femo_solve_bicgstab": (C.c_int, [H, C.c_int, H, H, C.POINTER(SolverOpts), C.POINTER(SolveInfo)]),
     "femo_functional_value": (C.c_int, [H, C.c_int, C.c_void_p, H, H, H, c_f64p]),
     "femo_functional_grad_u": (C.c_int, [H, C.c_int, C.c_void_p, H, H, H, H]),

@@ -1171,6 +1171,34 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
   return finish(iters, conv, ctx->h_scal[S_RHO]);
 }
 
+// z = M^-1 r with the BPX preconditioner of A, in unscaled variables:
+//   M^-1 = D^-1 + theta sum_l P_l C_l P_l^T   (oracle/bpx_oracle.py restates it; tests compare)
+extern "C" int femo_mat_pc_apply(const femo_mat* A_, const femo_vec* r, femo_vec* z) {
+  FEMO_REQUIRE(A_ && r && z, "null argument");
+  femo_mat* A = const_cast<femo_mat*>(A_);
+  femo_mesh* m = A->mesh;
+  femo_ctx* ctx = m->ctx;
+  const int64_t n = m->n_rows;
+  FEMO_REQUIRE(A->bpx_ok, "the BPX preconditioner needs an operator assembled from a Poisson-type form");
+  FEMO_REQUIRE(r->n >= n && z->n >= n && r->d != z->d, "vector size mismatch in pc_apply");
+  hipStream_t st = ctx->stream;
+  FEMO_TRY(ensure_s(A));
+  FEMO_TRY(femo_pc_build(m));
+  CgWork w;
+  FEMO_TRY(ensure_work(ctx, n, m->n_vert, w, 1));
+  const uint8_t* mask = A->pc_has_mask ? A->d_pcmask : nullptr;
+  FEMO_TRY(femo_pc_begin(m, A->d_s, mask));
+  const int gv = vec_grid(ctx, n);
+  FEMO_HIP_CHECK(hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int32_t), st));
+  if (n == 0) return 0;
+  // rh = S r, zh = Mh^-1 rh, z = S zh
+  hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, r->d, (const double*)nullptr, A->d_s, w.r, w.p, w.xh, ctx->d_partials);
+  FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, w.sv, ctx->d_partials + 2 * FEMO_MAX_PARTIALS, ctx->d_flags, gv));
+  hipLaunchKernelGGL(k_unscale, dim3(2048), dim3(256), 0, st, n, 0, A->d_s, w.sv, z->d);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 extern "C" int femo_solve_cg(const femo_mat* A_, int transpose, const femo_vec* b, femo_vec* x,
                              const femo_solver_opts* opts, femo_solve_info* info) {
   FEMO_REQUIRE(A_ && b && x && opts && info, "null argument");

@@ -303,6 +303,11 @@ class Mat:
         check(self.lib.femo_solve_cg(self.handle, int(transpose), b.handle, x.handle, C.byref(opts), C.byref(info)))
         return info
 
+    def pc_apply(self, r: Vec, z: Vec) -> Vec:
+        """z = M^-1 r with the BPX preconditioner of this operator (unscaled variables)."""
+        check(self.lib.femo_mat_pc_apply(self.handle, r.handle, z.handle))
+        return z
+
     def solve_bicgstab(self, b: Vec, x: Vec, transpose: bool = False, rtol: float = 1e-12, atol: float = 0.0,
                        max_it: int = 100000, zero_guess: bool = True, check_every: int = 32) -> SolveInfo:
         opts = SolverOpts(rtol, atol, max_it, int(zero_guess), check_every, 0)

@@ -207,6 +207,11 @@ int femo_mat_diagonal(const femo_mat* A, femo_vec* d);
 int femo_solve_cg(const femo_mat* A, int transpose, const femo_vec* b, femo_vec* x,
                   const femo_solver_opts* opts, femo_solve_info* info);
 
+/* z = M^-1 r with the BPX preconditioner femo_solve_cg uses for A (pc = FEMO_PC_BPX), in unscaled
+ * variables: M^-1 = D^-1 + 0.6 sum_l P_l C_l P_l^T (csrc/bpx.hip; restated in oracle/bpx_oracle.py).
+ * For callers that drive their own Krylov loop, and for the parity tests.                         */
+int femo_mat_pc_apply(const femo_mat* A, const femo_vec* r, femo_vec* z);
+
 /* BiCGSTAB on A or A^T for non-symmetric operators (e.g. unsymmetric Nitsche terms), Jacobi
  * preconditioning by symmetric diagonal scaling; stops on ||S r||_2 <= max(rtol ||S b||_2, atol),
  * S = diag(A)^-1/2.  Same options / info as femo_solve_cg.                                      */

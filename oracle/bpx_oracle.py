@@ -1,0 +1,183 @@
+"""NumPy/SciPy restatement of the auxiliary-lattice BPX preconditioner.  TEST INFRASTRUCTURE ONLY.
+
+Same access rule as ``femo_oracle.py``: only ``tests/`` (and smoke / the CPU-baseline leg of
+bench.py) may import this, as the checker of ``femo_amd/csrc/bpx.hip``.
+
+The preconditioner is this repository's own design (the reference factorises with MUMPS,
+``femo/fea/utils_dolfinx.py:476-512``; BASELINE.json asks for CG), so there is nothing in
+/root/reference to pin it against.  What is checked instead: (1) the HIP kernels apply exactly the
+operator written down here -- lattice choice, 20-bit packed coordinates, keep rule, level weights,
+nested transfers -- to rounding error (tests/test_gpu_bpx.py), (2) the operator is symmetric
+positive definite and PCG with it reaches the direct solution in a mesh-independent number of
+iterations (tests/test_oracle_bpx.py).
+
+    M^-1 = D^-1 + theta * sum_l P_l C_l P_l^T            theta = 0.6
+    P_l  = P_L I_L<-l   (P_L: multilinear interpolation finest lattice -> free vertices,
+                         I: multilinear lattice-to-lattice interpolation; pinned vertices masked)
+    C_l  = keep_l / diag(Q1 Laplacian) = keep_l * 3/(8 H_l) in 3-D, keep_l * 3/8 in 2-D
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Tuple
+
+import numpy as np
+import scipy.sparse as sp
+
+THETA = 0.6
+KEEP_FRACTION = 0.3
+PK_BITS = 20
+
+
+def choose_lattice(lo: np.ndarray, hi: np.ndarray, n_vert_global: int, spacing: float = 2.0
+                   ) -> Tuple[List[np.ndarray], List[float]]:
+    """Bins per axis of every level (coarsest first) and the level spacings H_l.
+    femo_pc_build: finest spacing ~ `spacing` mesh sizes, m0 * 2^l bins on the longest axis."""
+    dim = len(lo)
+    ext = hi - lo
+    ext_max = float(ext.max())
+    h = (float(np.prod(ext)) / float(n_vert_global)) ** (1.0 / dim)
+    target = max(2.0, ext_max / (spacing * h))
+    best, best_m0, best_lv = 1e300, 2, 1
+    for m0 in (2, 3):
+        for lv in range(1, 13):
+            score = abs(math.log(m0 * 2.0 ** (lv - 1) / target))
+            if score < best:
+                best, best_m0, best_lv = score, m0, lv
+    bins, H = [], []
+    for l in range(best_lv):
+        n = np.array([max(1, int(math.floor(best_m0 * e / ext_max + 0.5))) << l for e in ext], dtype=np.int64)   # lround
+        bins.append(n)
+        H.append(ext_max / (best_m0 << l))
+    return bins, H
+
+
+def _locate(x: np.ndarray, lo: np.ndarray, hi: np.ndarray, n: np.ndarray, quantise: bool):
+    g = (x - lo) * (n / (hi - lo))
+    b = np.clip(np.floor(g).astype(np.int64), 0, n - 1)
+    t = np.clip(g - b, 0.0, 1.0)
+    if quantise:                                   # the packed 20-bit fractions both HIP transfers decode
+        tq = np.minimum(np.floor(t * float(1 << PK_BITS) + 0.5), float((1 << PK_BITS) - 1))
+        t = tq / float(1 << PK_BITS)
+    return b, t
+
+
+def interpolation(x: np.ndarray, lo, hi, n: np.ndarray, quantise: bool) -> sp.csr_matrix:
+    """P: lattice nodes -> vertices (multilinear); node (i, j, k) has index (k (ny+1) + j)(nx+1) + i."""
+    N, d = x.shape
+    b, t = _locate(x, np.asarray(lo), np.asarray(hi), n, quantise)
+    n1 = n + 1
+    rows, cols, vals = [], [], []
+    for c in range(1 << d):
+        w = np.ones(N)
+        node = np.zeros(N, dtype=np.int64)
+        stride = 1
+        for k in range(d):
+            bit = (c >> k) & 1
+            w = w * (t[:, k] if bit else 1.0 - t[:, k])
+            node += (b[:, k] + bit) * stride
+            stride *= int(n1[k])
+        rows.append(np.arange(N)); cols.append(node); vals.append(w)
+    return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
+                         shape=(N, int(np.prod(n1))))
+
+
+def _interp_1d(nc: int) -> sp.csr_matrix:
+    """fine (2 nc + 1 nodes) <- coarse (nc + 1 nodes), linear."""
+    nf = 2 * nc
+    rows, cols, vals = [], [], []
+    for i in range(nf + 1):
+        if i % 2 == 0:
+            rows.append(i); cols.append(i // 2); vals.append(1.0)
+        else:
+            rows += [i, i]; cols += [i // 2, i // 2 + 1]; vals += [0.5, 0.5]
+    return sp.csr_matrix((vals, (rows, cols)), shape=(nf + 1, nc + 1))
+
+
+def lattice_interpolation(nc: np.ndarray) -> sp.csr_matrix:
+    """I: coarse lattice (nc bins per axis) -> fine lattice (2 nc bins), x fastest."""
+    out = _interp_1d(int(nc[0]))
+    for k in range(1, len(nc)):
+        out = sp.kron(_interp_1d(int(nc[k])), out, format="csr")
+    return out
+
+
+class BPX:
+    """The operator r -> M^-1 r for an SPD matrix A with diagonal `diag` on vertices `x`."""
+
+    def __init__(self, x: np.ndarray, diag: np.ndarray, pinned: Optional[np.ndarray] = None,
+                 lo=None, hi=None, n_vert_global: Optional[int] = None, spacing: float = 2.0):
+        x = np.asarray(x, float)
+        N, d = x.shape
+        self.dim = d
+        self.dinv = 1.0 / np.asarray(diag, float)
+        self.lo = x.min(axis=0) if lo is None else np.asarray(lo, float)
+        self.hi = x.max(axis=0) if hi is None else np.asarray(hi, float)
+        self.bins, self.H = choose_lattice(self.lo, self.hi, n_vert_global or N, spacing)
+        free = np.ones(N) if pinned is None else np.where(np.asarray(pinned, bool), 0.0, 1.0)
+        self.free = free
+        nL = self.bins[-1]
+        # keep rule on the finest lattice from the exact (unquantised) hat-function masses
+        P_exact = interpolation(x, self.lo, self.hi, nL, quantise=False)
+        wf, wd = P_exact.T @ free, P_exact.T @ (1.0 - free)
+        keep = (wf > 0.0) & (wd <= KEEP_FRACTION * (wf + wd))
+        self.P = (sp.diags(free) @ interpolation(x, self.lo, self.hi, nL, quantise=True)).tocsr()
+        self.I = [lattice_interpolation(self.bins[l]) for l in range(len(self.bins) - 1)]   # level l -> l+1
+        self.coef = [None] * len(self.bins)
+        keep_l = keep
+        for l in range(len(self.bins) - 1, -1, -1):
+            c = THETA * (3.0 / (8.0 * self.H[l]) if d == 3 else 3.0 / 8.0)
+            self.coef[l] = np.where(keep_l, c, 0.0)
+            if l > 0:                                # injection: coarse node I sits on fine node 2I
+                shape = tuple(int(v) + 1 for v in self.bins[l][::-1])
+                sl = tuple(slice(None, None, 2) for _ in range(d))
+                keep_l = keep_l.reshape(shape)[sl].ravel()
+
+    @property
+    def levels(self) -> int:
+        return len(self.bins)
+
+    def lattice_correction(self, r: np.ndarray) -> np.ndarray:
+        g = [None] * self.levels
+        g[-1] = self.P.T @ r
+        for l in range(self.levels - 2, -1, -1):
+            g[l] = self.I[l].T @ g[l + 1]
+        e = self.coef[0] * g[0]
+        for l in range(1, self.levels):
+            e = self.I[l - 1] @ e + self.coef[l] * g[l]
+        return self.P @ e
+
+    def apply(self, r: np.ndarray) -> np.ndarray:
+        return self.dinv * r + self.lattice_correction(r)
+
+    def matrix(self) -> np.ndarray:
+        """Dense M^-1 (small meshes only)."""
+        n = len(self.dinv)
+        return np.column_stack([self.apply(e) for e in np.eye(n)])
+
+
+def pcg(A: sp.csr_matrix, b: np.ndarray, M: BPX, rtol: float = 1e-12, atol: float = 0.0, max_it: int = 10000):
+    """PCG with the engine's stopping rule: sqrt(r^T D^-1 r) <= max(rtol sqrt(b^T D^-1 b), atol)."""
+    dinv = M.dinv
+    x = np.zeros_like(b)
+    r = b.copy()
+    tol = max(rtol * math.sqrt(float(b @ (dinv * b))), atol)
+    if not math.sqrt(float(r @ (dinv * r))) > tol:
+        return x, 0
+    z = M.apply(r)
+    p = z.copy()
+    rz = float(r @ z)
+    it = 0
+    while it < max_it:
+        q = A @ p
+        alpha = rz / float(p @ q)
+        x += alpha * p
+        r -= alpha * q
+        it += 1
+        if math.sqrt(float(r @ (dinv * r))) <= tol:
+            break
+        z = M.apply(r)
+        rz_new = float(r @ z)
+        p = z + (rz_new / rz) * p
+        rz = rz_new
+    return x, it

@@ -158,3 +158,50 @@ def test_operator_stack_with_bpx_matches_jacobi(ctx, d, n):
     uj, jj, gj, itj = out["jacobi"]
     assert _rel(ub, uj) < 1e-10 and abs(jb - jj) <= 1e-10 * abs(jj) and _rel(gb, gj) < 1e-9
     assert max(itb) < max(itj)
+
+
+@pytest.mark.parametrize("d,n,jit", [(2, 37, 0.2), (2, 64, 0.0), (3, 9, 0.25), (3, 20, 0.2), (3, 32, 0.0)])
+def test_pc_apply_matches_the_oracle_operator(ctx, d, n, jit):
+    """femo_mat_pc_apply = the operator oracle/bpx_oracle.py writes down (lattice choice, packed
+    coordinates, keep rule, level weights, nested transfers), to rounding error; and it is symmetric."""
+    from femo_amd import engine as E
+    from oracle import bpx_oracle as bo
+    m = fo.unit_square_mesh(n, jit) if d == 2 else fo.unit_cube_mesh(n, jit)
+    dm, bc, A, b = _poisson_system(ctx, m)
+    pinned = np.zeros(m.n_vert, bool)
+    pinned[fo.boundary_vertices_box(m.x)] = True
+    diag = A.to_scipy().diagonal()
+    M = bo.BPX(m.x, diag, pinned)
+    rng = np.random.default_rng(4)
+    R, Z = E.Vec(ctx, m.n_vert), E.Vec(ctx, m.n_vert)
+    zs = []
+    for k in range(2):
+        r = rng.standard_normal(m.n_vert)
+        A.pc_apply(R.set(r), Z)
+        z = Z.get()
+        ref = M.apply(r)
+        assert np.abs(z - ref).max() < 1e-12 * np.abs(ref).max()
+        zs.append((r, z))
+    info = dm.pc_info()
+    assert info["levels"] == M.levels and info["finest_nodes"] == int(np.prod(M.bins[-1] + 1))
+    (r0, z0), (r1, z1) = zs
+    assert abs(r1 @ z0 - r0 @ z1) < 1e-12 * abs(r1 @ z0)          # <r1, M^-1 r0> = <r0, M^-1 r1>
+
+
+def test_pc_apply_with_nitsche_pinning(ctx):
+    from femo_amd import engine as E
+    from oracle import bpx_oracle as bo
+    m = fo.unit_cube_mesh(10, 0.15)
+    dm = E.DeviceMesh(ctx, m.x, m.conn)
+    dm.set_boundary_facets(fo.boundary_facets(m))
+    u = 0.3 * np.sin(3 * m.x[:, 0]) + 0.2
+    U, F, UEX = E.Vec(ctx, m.n_vert).set(u), E.Vec(ctx, m.n_cell).fill(0.5), E.Vec(ctx, m.n_vert).set(fo.u_exact_nl(m.x))
+    J = E.Mat(dm)
+    E.assemble_jacobian(dm, 1, [10.0], U, F, None, J, aux=UEX)
+    pinned = np.zeros(m.n_vert, bool)
+    pinned[fo.boundary_vertices_box(m.x)] = True
+    M = bo.BPX(m.x, J.to_scipy().diagonal(), pinned)
+    r = np.random.default_rng(2).standard_normal(m.n_vert)
+    z = J.pc_apply(E.Vec(ctx, m.n_vert).set(r), E.Vec(ctx, m.n_vert)).get()
+    ref = M.apply(r)
+    assert np.abs(z - ref).max() < 1e-12 * np.abs(ref).max()
