@@ -151,26 +151,27 @@ def cpu_baseline(args, gpu_counts, n_dof_gpu, n_cell_gpu, nnz_gpu):
     f = source_fields(_Centroid(m), 1)[0]
     bd = fo.boundary_vertices_box(m.x)
     threads = usable_cores()
-    out = c_port.poisson_cycle(3, m.x, m.conn, f, fo.u_target(m.x), bd, ALPHA, rtol=1e-14, threads=threads)
+    out = c_port.poisson_cycle(3, m.x, m.conn, f, fo.u_target(m.x), bd, ALPHA, rtol=1e-14, threads=threads, pc=PC)
     T = out["times"]
     t_sample = T["cycle"]
     dofs_sample = m.n_vert / t_sample
-    # scale the sample to the benchmark mesh: assembly-like phases by cell count; CG by nnz x
-    # iteration count, where the port's Jacobi-CG count grows in proportion to n (measured on the
-    # GPU with the same Jacobi-CG: 526+556 at n=128, 971+963 at n=215; profiles/r01_jacobi_bench_n1.json)
+    # scale the sample to the benchmark mesh: assembly-like phases by cell count, CG by nnz x
+    # iteration count.  BPX counts do not grow with the mesh (the sample's own counts are used);
+    # Jacobi-CG counts grow in proportion to n (526+556 at n=128, 971+963 at n=215 on the GPU,
+    # profiles/r01_jacobi_bench_n1.json).
     it_main = out["it_fwd"][0] + out["it_adj"]
     t_cg = T["cg_fwd"] + T["cg_adj"]
     per_it_per_nnz = t_cg / max(it_main, 1) / out["nnz"]
     t_other = t_sample - t_cg
-    it_scaled = it_main * args.n / n
+    it_scaled = it_main * (args.n / n if PC == "jacobi" else 1.0)
     t_scaled = t_other * (n_cell_gpu / m.n_cell) + per_it_per_nnz * nnz_gpu * it_scaled
     return {
         "value": n_dof_gpu / t_scaled, "unit": "DOFs/s", "cores": int(out["threads"]), "kind": "port",
-        "sample": (f"oracle/femo_oracle_c.c (C/OpenMP restatement, not FEniCSx), same cycle on the n={n} cube "
-                   f"({m.n_vert} DOFs): {t_sample:.2f} s = {dofs_sample:.3e} DOFs/s with CG its {out['it_fwd']}+{out['it_adj']}; "
-                   f"scaled to n={args.n} by cell count (assembly, {t_other:.2f} s) and nnz x {it_scaled:.0f} Jacobi-CG "
-                   f"iterations (count grows ~ n; {per_it_per_nnz * out['nnz'] * 1e3:.2f} ms/it at n={n}).  The port "
-                   f"has no multilevel preconditioner; the GPU run used pc={PC} with CG its {gpu_counts}"),
+        "sample": (f"oracle/femo_oracle_c.c (C/OpenMP restatement, not FEniCSx), same cycle with the same {PC.upper()}-CG on the "
+                   f"n={n} cube ({m.n_vert} DOFs): {t_sample:.2f} s = {dofs_sample:.3e} DOFs/s with CG its "
+                   f"{out['it_fwd']}+{out['it_adj']}; scaled to n={args.n} by cell count (assembly, {t_other:.2f} s) and "
+                   f"nnz x {it_scaled:.0f} iterations ({per_it_per_nnz * out['nnz'] * 1e3:.2f} ms/it at n={n}); "
+                   f"the GPU run's CG its were {gpu_counts}"),
     }
 
 

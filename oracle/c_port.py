@@ -31,6 +31,9 @@ def lib():
         _lib.oc_pcg_jacobi.restype = C.c_int
         _lib.oc_pattern.restype = C.c_int
         _lib.oc_num_threads.restype = C.c_int
+        _lib.oc_bpx_create.restype = C.c_void_p
+        _lib.oc_bpx_levels.restype = C.c_int
+        _lib.oc_pcg_bpx.restype = C.c_int
     return _lib
 
 
@@ -84,9 +87,45 @@ def pcg(rowptr, col, val, b, rtol=1e-14, atol=0.0, max_it=100000):
     return x, it, res.value
 
 
+class Bpx:
+    """The BPX preconditioner of the port (oc_bpx_*): lattice hierarchy of one mesh + pinned set."""
+
+    def __init__(self, x: np.ndarray, pinned: Optional[np.ndarray] = None, spacing: float = 2.0):
+        x = np.ascontiguousarray(x, np.float64)
+        self.n, d = x.shape
+        lo, hi = np.ascontiguousarray(x.min(axis=0)), np.ascontiguousarray(x.max(axis=0))
+        pin = None if pinned is None else np.ascontiguousarray(pinned, np.uint8)
+        self._h = C.c_void_p(lib().oc_bpx_create(d, _i64(self.n), _p(x), _p(pin) if pin is not None else None,
+                                                 _p(lo), _p(hi), _i64(self.n), C.c_double(spacing)))
+        if not self._h:
+            raise ValueError("degenerate bounding box")
+
+    @property
+    def levels(self) -> int:
+        return lib().oc_bpx_levels(self._h)
+
+    def apply(self, dinv: np.ndarray, r: np.ndarray) -> np.ndarray:
+        z = np.empty(self.n)
+        lib().oc_bpx_apply(self._h, _p(np.ascontiguousarray(dinv)), _p(np.ascontiguousarray(r)), _p(z))
+        return z
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.oc_bpx_destroy(h)
+
+
+def pcg_bpx(B: Bpx, rowptr, col, val, b, rtol=1e-14, atol=0.0, max_it=100000):
+    x = np.empty_like(b)
+    res = C.c_double(0.0)
+    it = lib().oc_pcg_bpx(B._h, _i64(len(b)), _p(rowptr), _p(col), _p(val), _p(b), _p(x), C.c_double(rtol),
+                          C.c_double(atol), int(max_it), C.byref(res))
+    return x, it, res.value
+
+
 def poisson_cycle(tdim: int, x: np.ndarray, conn: np.ndarray, f: np.ndarray, u_d: np.ndarray,
                   bc_dofs: np.ndarray, alpha: float, rtol: float = 1e-14,
-                  cg_cap: Optional[int] = None, threads: Optional[int] = None) -> Dict:
+                  cg_cap: Optional[int] = None, threads: Optional[int] = None, pc: str = "jacobi") -> Dict:
     """One assemble + forward solve + functional + linearise + adjoint solve + gradient
     cycle with homogeneous Dirichlet values, cold start u = 0 (the cycle bench.py times).
     ``cg_cap`` bounds the iterations of each CG solve (bounded baseline sample)."""
@@ -105,6 +144,13 @@ def poisson_cycle(tdim: int, x: np.ndarray, conn: np.ndarray, f: np.ndarray, u_d
     rowptr, col = pattern(tdim, nv, conn)
     T["pattern_setup"] = time.perf_counter() - t0           # set-up: not part of the cycle
     max_it = cg_cap if cg_cap else 100000
+    if pc == "bpx":
+        t0 = time.perf_counter()
+        B = Bpx(x, isbc)
+        T["bpx_setup"] = time.perf_counter() - t0           # per mesh, like the pattern
+        solve = lambda A_, b_, atol_: pcg_bpx(B, rowptr, col, A_, b_, rtol, atol_, max_it)
+    else:
+        solve = lambda A_, b_, atol_: pcg(rowptr, col, A_, b_, rtol, atol_, max_it)
 
     t_cycle = time.perf_counter()
     t0 = time.perf_counter()
@@ -121,7 +167,7 @@ def poisson_cycle(tdim: int, x: np.ndarray, conn: np.ndarray, f: np.ndarray, u_d
         if k == 0:
             T["assembly_fwd"] = time.perf_counter() - t0
             t1 = time.perf_counter()
-        dx, it, res = pcg(rowptr, col, A, b, rtol, atol, max_it)
+        dx, it, res = solve(A, b, atol)
         if k == 0:
             T["cg_fwd"] = time.perf_counter() - t1
             dinv = 1.0 / A[_diag_index(rowptr, col)]
@@ -141,7 +187,7 @@ def poisson_cycle(tdim: int, x: np.ndarray, conn: np.ndarray, f: np.ndarray, u_d
     A = eliminate_bc(rowptr, col, K, isbc)
     T["output_linearize"] = time.perf_counter() - t0
     t0 = time.perf_counter()
-    lam, it_adj, _ = pcg(rowptr, col, A, dJdu, rtol, 0.0, max_it)     # A symmetric: A^T = A
+    lam, it_adj, _ = solve(A, dJdu, 0.0)     # A symmetric: A^T = A
     T["cg_adj"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     g = np.empty(nc)
@@ -150,7 +196,7 @@ def poisson_cycle(tdim: int, x: np.ndarray, conn: np.ndarray, f: np.ndarray, u_d
     T["gradient"] = time.perf_counter() - t0
     T["cycle"] = time.perf_counter() - t_cycle
     return dict(u=u, J=J, grad=grad, lam=lam, it_fwd=its_newton, it_adj=it_adj, times=T,
-                threads=L.oc_num_threads(), nnz=int(rowptr[-1]))
+                threads=L.oc_num_threads(), nnz=int(rowptr[-1]), pc=pc)
 
 
 _DIAG_CACHE: dict = {}

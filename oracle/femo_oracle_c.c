@@ -14,8 +14,10 @@
  *   Dirichlet rows/cols              utils_dolfinx.py:189-202
  *   functional and partials          output_model.py:69-87 (run_poisson_opt.py:74-76)
  *   dR/df^T lambda                   state_model.py:196-200
- * The linear solver is Jacobi-preconditioned CG with the stopping rule of the
- * HIP engine (BASELINE.json design; the reference factorises with MUMPS).
+ * The linear solver is CG with the stopping rule of the HIP engine (BASELINE.json
+ * design; the reference factorises with MUMPS), Jacobi-preconditioned (oc_pcg_jacobi)
+ * or with the auxiliary-lattice BPX preconditioner (oc_pcg_bpx: the algorithm of
+ * oracle/bpx_oracle.py, which restates femo_amd/csrc/bpx.hip).
  */
 #include <math.h>
 #include <stdint.h>
@@ -240,6 +242,274 @@ int oc_pcg_jacobi(int64_t n, const int64_t* rowptr, const int32_t* col, const do
   }
   *res = sqrt(zz);
   free(r); free(p); free(q); free(dinv);
+  return it;
+}
+
+/* ---- auxiliary-lattice BPX preconditioner (oracle/bpx_oracle.py in C/OpenMP) -------------
+ * M^-1 = D^-1 + theta sum_l P_l C_l P_l^T; nested multilinear lattices over the bounding box,
+ * 20-bit quantised vertex fractions, pinned vertices masked, lattice nodes on the pinned
+ * boundary dropped (30 % rule on the finest level, injection to the coarser ones).          */
+#define OC_MAX_LEVELS 14
+typedef struct {
+  int dim, n_levels;
+  int n[OC_MAX_LEVELS][3];
+  int64_t nodes[OC_MAX_LEVELS];
+  double* g[OC_MAX_LEVELS];
+  double* e[OC_MAX_LEVELS];
+  double* coef[OC_MAX_LEVELS];
+  int64_t n_vert;
+  int32_t* bin;    /* n_vert * dim */
+  double* t;       /* n_vert * dim, quantised */
+  uint8_t* pinned;
+} oc_bpx;
+
+static inline int64_t node_id(const int* n, int i, int j, int k) { return ((int64_t)k * (n[1] + 1) + j) * (n[0] + 1) + i; }
+
+static void bpx_restrict_mesh(const oc_bpx* B, const double* val, int only_pinned, int use_pinned_filter, double* g) {
+  const int d = B->dim, L = B->n_levels - 1;
+  memset(g, 0, B->nodes[L] * sizeof(double));
+#pragma omp parallel for schedule(static)
+  for (int64_t v = 0; v < B->n_vert; ++v) {
+    const int pin = B->pinned[v] != 0;
+    if (use_pinned_filter && (only_pinned ? !pin : pin)) continue;
+    const double r = val ? val[v] : 1.0;
+    for (int c = 0; c < (1 << d); ++c) {
+      double w = r;
+      int ijk[3] = {0, 0, 0};
+      for (int k = 0; k < d; ++k) {
+        const int bit = (c >> k) & 1;
+        w *= bit ? B->t[v * d + k] : 1.0 - B->t[v * d + k];
+        ijk[k] = B->bin[v * d + k] + bit;
+      }
+      if (w != 0.0) {
+#pragma omp atomic
+        g[node_id(B->n[L], ijk[0], ijk[1], ijk[2])] += w;
+      }
+    }
+  }
+}
+
+static void bpx_lattice_restrict(const oc_bpx* B, int l) {   /* g_l from g_{l+1} */
+  const int* nc = B->n[l];
+  const int* nf = B->n[l + 1];
+  const int d = B->dim;
+#pragma omp parallel for schedule(static)
+  for (int64_t idx = 0; idx < B->nodes[l]; ++idx) {
+    const int i = (int)(idx % (nc[0] + 1)), j = (int)((idx / (nc[0] + 1)) % (nc[1] + 1));
+    const int k = (int)(idx / ((int64_t)(nc[0] + 1) * (nc[1] + 1)));
+    double acc = 0.0;
+    for (int dz = (d == 3 ? -1 : 0); dz <= (d == 3 ? 1 : 0); ++dz) {
+      const int fk = d == 3 ? 2 * k + dz : 0;
+      if (fk < 0 || fk > nf[2]) continue;
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int fj = 2 * j + dy;
+        if (fj < 0 || fj > nf[1]) continue;
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int fi = 2 * i + dx;
+          if (fi < 0 || fi > nf[0]) continue;
+          acc += (dx ? 0.5 : 1.0) * (dy ? 0.5 : 1.0) * (dz ? 0.5 : 1.0) * B->g[l + 1][node_id(nf, fi, fj, fk)];
+        }
+      }
+    }
+    B->g[l][idx] = acc;
+  }
+}
+
+static void bpx_lattice_prolong(const oc_bpx* B, int l) {    /* e_l = I e_{l-1} + coef_l g_l */
+  const int* nf = B->n[l];
+  const int d = B->dim;
+#pragma omp parallel for schedule(static)
+  for (int64_t idx = 0; idx < B->nodes[l]; ++idx) {
+    double v = B->coef[l][idx] * B->g[l][idx];
+    if (l > 0) {
+      const int* nc = B->n[l - 1];
+      const int i = (int)(idx % (nf[0] + 1)), j = (int)((idx / (nf[0] + 1)) % (nf[1] + 1));
+      const int k = (int)(idx / ((int64_t)(nf[0] + 1) * (nf[1] + 1)));
+      const int ci[2] = {i >> 1, (i + 1) >> 1}, cj[2] = {j >> 1, (j + 1) >> 1};
+      const int ck[2] = {d == 3 ? k >> 1 : 0, d == 3 ? (k + 1) >> 1 : 0};
+      double acc = 0.0;
+      for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b)
+          for (int c = 0; c < 2; ++c) acc += B->e[l - 1][node_id(nc, ci[a], cj[b], ck[c])];
+      v += 0.125 * acc;
+    }
+    B->e[l][idx] = v;
+  }
+}
+
+void oc_bpx_destroy(oc_bpx* B) {
+  if (!B) return;
+  for (int l = 0; l < B->n_levels; ++l) { free(B->g[l]); free(B->e[l]); free(B->coef[l]); }
+  free(B->bin); free(B->t); free(B->pinned); free(B);
+}
+
+/* lo/hi: bounding box; pinned: per-vertex flag (may be NULL).  Returns NULL on a degenerate box. */
+oc_bpx* oc_bpx_create(int d, int64_t n_vert, const double* x, const uint8_t* pinned, const double* lo, const double* hi,
+                      int64_t n_vert_global, double spacing) {
+  oc_bpx* B = (oc_bpx*)calloc(1, sizeof(oc_bpx));
+  B->dim = d; B->n_vert = n_vert;
+  double ext[3] = {0, 0, 0}, ext_max = 0.0, vol = 1.0;
+  for (int k = 0; k < d; ++k) { ext[k] = hi[k] - lo[k]; if (ext[k] > ext_max) ext_max = ext[k]; vol *= ext[k]; }
+  if (!(vol > 0.0)) { free(B); return NULL; }
+  const double h = pow(vol / (double)n_vert_global, 1.0 / d);
+  double target = ext_max / (spacing * h);
+  if (target < 2.0) target = 2.0;
+  int best_m0 = 2, best_lv = 1;
+  double best = 1e300;
+  for (int m0 = 2; m0 <= 3; ++m0)
+    for (int lv = 1; lv <= 12; ++lv) {
+      const double score = fabs(log(m0 * ldexp(1.0, lv - 1) / target));
+      if (score < best) { best = score; best_m0 = m0; best_lv = lv; }
+    }
+  B->n_levels = best_lv;
+  double H[OC_MAX_LEVELS];
+  for (int l = 0; l < best_lv; ++l) {
+    H[l] = ext_max / (double)(best_m0 << l);
+    B->nodes[l] = 1;
+    for (int k = 0; k < 3; ++k) {
+      int base = 0;
+      if (k < d) { base = (int)lround(best_m0 * ext[k] / ext_max); if (base < 1) base = 1; }
+      B->n[l][k] = k < d ? base << l : 0;
+      B->nodes[l] *= B->n[l][k] + 1;
+    }
+    B->g[l] = (double*)calloc(B->nodes[l], sizeof(double));
+    B->e[l] = (double*)calloc(B->nodes[l], sizeof(double));
+    B->coef[l] = (double*)calloc(B->nodes[l], sizeof(double));
+  }
+  const int L = best_lv - 1;
+  B->bin = (int32_t*)malloc(n_vert * d * sizeof(int32_t));
+  B->t = (double*)malloc(n_vert * d * sizeof(double));
+  B->pinned = (uint8_t*)calloc(n_vert, 1);
+  if (pinned) memcpy(B->pinned, pinned, n_vert);
+  /* keep rule from the exact fractions, then quantise */
+#pragma omp parallel for schedule(static)
+  for (int64_t v = 0; v < n_vert; ++v)
+    for (int k = 0; k < d; ++k) {
+      const double g = (x[v * d + k] - lo[k]) * (B->n[L][k] / ext[k]);
+      int b = (int)floor(g);
+      if (b < 0) b = 0;
+      if (b > B->n[L][k] - 1) b = B->n[L][k] - 1;
+      double t = g - b;
+      if (t < 0.0) t = 0.0;
+      if (t > 1.0) t = 1.0;
+      B->bin[v * d + k] = b;
+      B->t[v * d + k] = t;
+    }
+  double* wf = B->g[L];
+  double* wd = B->e[L];
+  bpx_restrict_mesh(B, NULL, 0, 1, wf);
+  bpx_restrict_mesh(B, NULL, 1, 1, wd);
+  const double theta = 0.6;
+  for (int64_t i = 0; i < B->nodes[L]; ++i) {
+    const double c = theta * (d == 3 ? 3.0 / (8.0 * H[L]) : 3.0 / 8.0);
+    B->coef[L][i] = (wf[i] > 0.0 && wd[i] <= 0.3 * (wf[i] + wd[i])) ? c : 0.0;
+  }
+  for (int l = L - 1; l >= 0; --l) {
+    const double c = theta * (d == 3 ? 3.0 / (8.0 * H[l]) : 3.0 / 8.0);
+    const int* nc = B->n[l];
+    for (int64_t idx = 0; idx < B->nodes[l]; ++idx) {
+      const int i = (int)(idx % (nc[0] + 1)), j = (int)((idx / (nc[0] + 1)) % (nc[1] + 1));
+      const int k = (int)(idx / ((int64_t)(nc[0] + 1) * (nc[1] + 1)));
+      B->coef[l][idx] = B->coef[l + 1][node_id(B->n[l + 1], 2 * i, 2 * j, d == 3 ? 2 * k : 0)] != 0.0 ? c : 0.0;
+    }
+  }
+#pragma omp parallel for schedule(static)
+  for (int64_t v = 0; v < n_vert * d; ++v) {
+    double tq = floor(B->t[v] * 1048576.0 + 0.5);
+    if (tq > 1048575.0) tq = 1048575.0;
+    B->t[v] = tq / 1048576.0;
+  }
+  return B;
+}
+
+int oc_bpx_levels(const oc_bpx* B) { return B->n_levels; }
+
+/* z = dinv r + P (sum_l ...) P^T r */
+void oc_bpx_apply(oc_bpx* B, const double* dinv, const double* r, double* z) {
+  const int L = B->n_levels - 1, d = B->dim;
+  bpx_restrict_mesh(B, r, 0, 1, B->g[L]);
+  for (int l = L - 1; l >= 0; --l) bpx_lattice_restrict(B, l);
+  for (int l = 0; l <= L; ++l) bpx_lattice_prolong(B, l);
+  const double* e = B->e[L];
+#pragma omp parallel for schedule(static)
+  for (int64_t v = 0; v < B->n_vert; ++v) {
+    double zz = dinv[v] * r[v];
+    if (!B->pinned[v]) {
+      double sum = 0.0;
+      for (int c = 0; c < (1 << d); ++c) {
+        double w = 1.0;
+        int ijk[3] = {0, 0, 0};
+        for (int k = 0; k < d; ++k) {
+          const int bit = (c >> k) & 1;
+          w *= bit ? B->t[v * d + k] : 1.0 - B->t[v * d + k];
+          ijk[k] = B->bin[v * d + k] + bit;
+        }
+        sum += w * e[node_id(B->n[L], ijk[0], ijk[1], ijk[2])];
+      }
+      zz += sum;
+    }
+    z[v] = zz;
+  }
+}
+
+/* BPX-PCG from x = 0, same stopping rule as oc_pcg_jacobi (natural norm of the Jacobi scaling). */
+int oc_pcg_bpx(oc_bpx* B, int64_t n, const int64_t* rowptr, const int32_t* col, const double* val, const double* b,
+               double* x, double rtol, double atol, int max_it, double* res) {
+  double* r = (double*)malloc(n * sizeof(double));
+  double* p = (double*)malloc(n * sizeof(double));
+  double* q = (double*)malloc(n * sizeof(double));
+  double* z = (double*)malloc(n * sizeof(double));
+  double* dinv = (double*)malloc(n * sizeof(double));
+  double bb = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : bb)
+  for (int64_t i = 0; i < n; ++i) {
+    double dg = 1.0;
+    for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
+      if (col[k] == i) dg = val[k];
+    dinv[i] = 1.0 / dg;
+    x[i] = 0.0;
+    r[i] = b[i];
+    bb += r[i] * dinv[i] * r[i];
+  }
+  double tol = rtol * sqrt(bb), rho = bb;
+  if (atol > tol) tol = atol;
+  int it = 0;
+  if (sqrt(rho) > tol) {
+    oc_bpx_apply(B, dinv, r, z);
+    double rz = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : rz)
+    for (int64_t i = 0; i < n; ++i) { p[i] = z[i]; rz += r[i] * z[i]; }
+    while (it < max_it) {
+      double pq = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : pq)
+      for (int64_t i = 0; i < n; ++i) {
+        double s = 0.0;
+        for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) s += val[k] * p[col[k]];
+        q[i] = s;
+        pq += p[i] * s;
+      }
+      const double alpha = pq != 0.0 ? rz / pq : 0.0;
+      rho = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : rho)
+      for (int64_t i = 0; i < n; ++i) {
+        x[i] += alpha * p[i];
+        r[i] -= alpha * q[i];
+        rho += r[i] * dinv[i] * r[i];
+      }
+      ++it;
+      if (sqrt(rho) <= tol) break;
+      oc_bpx_apply(B, dinv, r, z);
+      double rz1 = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : rz1)
+      for (int64_t i = 0; i < n; ++i) rz1 += r[i] * z[i];
+      const double beta = rz != 0.0 ? rz1 / rz : 0.0;
+      rz = rz1;
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; ++i) p[i] = z[i] + beta * p[i];
+    }
+  }
+  *res = sqrt(rho);
+  free(r); free(p); free(q); free(z); free(dinv);
   return it;
 }
 

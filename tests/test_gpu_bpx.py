@@ -205,3 +205,44 @@ def test_pc_apply_with_nitsche_pinning(ctx):
     z = J.pc_apply(E.Vec(ctx, m.n_vert).set(r), E.Vec(ctx, m.n_vert)).get()
     ref = M.apply(r)
     assert np.abs(z - ref).max() < 1e-12 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("d,n", [(2, 1), (2, 2), (2, 3), (3, 1), (3, 2), (3, 3)])
+def test_bpx_on_tiny_meshes(ctx, d, n):
+    """Sub-wave meshes: one or two lattice levels, bricks with a handful of vertices, nearly (or
+    entirely) pinned vertex sets.  Same answer as the direct solve."""
+    from femo_amd import engine as E
+    from oracle import bpx_oracle as bo
+    m = fo.unit_square_mesh(n, 0.1) if d == 2 else fo.unit_cube_mesh(n, 0.1)
+    dm, bc, A, b = _poisson_system(ctx, m)
+    x_ref = spla.spsolve(A.to_scipy().tocsc(), b.get())
+    x = E.Vec(ctx, m.n_vert)
+    info = A.solve_cg(b, x, rtol=1e-14, pc="bpx")
+    assert info.converged == 1 and _rel(x.get(), x_ref) < 1e-12
+    pinned = np.zeros(m.n_vert, bool)
+    pinned[fo.boundary_vertices_box(m.x)] = True
+    M = bo.BPX(m.x, A.to_scipy().diagonal(), pinned)
+    r = np.random.default_rng(0).standard_normal(m.n_vert)
+    z = A.pc_apply(E.Vec(ctx, m.n_vert).set(r), E.Vec(ctx, m.n_vert)).get()
+    assert np.abs(z - M.apply(r)).max() < 1e-12 * np.abs(r).max()
+
+
+def test_bpx_without_any_pinned_vertex(ctx):
+    """Pure Neumann stiffness + mass shift (SPD, no Dirichlet set): no mask, every lattice node kept."""
+    from femo_amd import engine as E
+    from oracle import bpx_oracle as bo
+    m = fo.unit_cube_mesh(9, 0.2)
+    dm = E.DeviceMesh(ctx, m.x, m.conn)
+    # NL Poisson Jacobian without facets: K + 3 u^2 mass term, u = 1 -> SPD without any boundary condition
+    U, F = E.Vec(ctx, m.n_vert).fill(1.0), E.Vec(ctx, m.n_cell).fill(0.0)
+    J = E.Mat(dm)
+    E.assemble_jacobian(dm, 1, [0.0], U, F, None, J)
+    Js = J.to_scipy()
+    b = np.random.default_rng(3).standard_normal(m.n_vert)
+    x_ref = spla.spsolve(Js.tocsc(), b)
+    x = E.Vec(ctx, m.n_vert)
+    info = J.solve_cg(E.Vec(ctx, m.n_vert).set(b), x, rtol=1e-14, pc="bpx")
+    assert info.converged == 1 and _rel(x.get(), x_ref) < 1e-11
+    M = bo.BPX(m.x, Js.diagonal(), None)
+    z = J.pc_apply(E.Vec(ctx, m.n_vert).set(b), E.Vec(ctx, m.n_vert)).get()
+    assert np.abs(z - M.apply(b)).max() < 1e-12 * np.abs(M.apply(b)).max()

@@ -75,3 +75,30 @@ def test_weak_boundary_conditions_pin_the_facet_vertices():
     x, it = bo.pcg(J, b, bo.BPX(m.x, J.diagonal(), pinned), rtol=1e-13)
     x_ref = spla.spsolve(J.tocsc(), b)
     assert np.abs(x - x_ref).max() < 1e-9 * np.abs(x_ref).max() and it <= 60
+
+
+def test_c_port_bpx_matches_the_numpy_operator_and_solves():
+    """oracle/femo_oracle_c.c (the CPU-baseline port) applies the same operator and its BPX-PCG
+    reproduces the cycle of the Jacobi-CG port."""
+    from oracle import c_port
+    m = fo.unit_cube_mesh(14, 0.2)
+    A, b, pinned = _system(m)
+    M = bo.BPX(m.x, A.diagonal(), pinned)
+    B = c_port.Bpx(m.x, pinned)
+    assert B.levels == M.levels
+    r = np.random.default_rng(5).standard_normal(m.n_vert)
+    z = B.apply(M.dinv, r)
+    ref = M.apply(r)
+    assert np.abs(z - ref).max() < 1e-12 * np.abs(ref).max()
+    rowptr, col = c_port.pattern(3, m.n_vert, m.conn)
+    x, it, res = c_port.pcg_bpx(B, rowptr, col, A.data, b, rtol=1e-14)
+    x_np, it_np = bo.pcg(A, b, M, rtol=1e-14)
+    assert abs(it - it_np) <= 1 and np.abs(x - x_np).max() < 1e-11 * np.abs(x_np).max()
+    # whole cycle: same state / gradient with either preconditioner, far fewer iterations with BPX
+    bd = fo.boundary_vertices_box(m.x)
+    f = 0.086 * (1.0 + 0.3 * np.random.default_rng(11).uniform(-1, 1, m.n_cell))
+    cj = c_port.poisson_cycle(3, m.x, m.conn, f, fo.u_target(m.x), bd, 1e-6, pc="jacobi")
+    cb = c_port.poisson_cycle(3, m.x, m.conn, f, fo.u_target(m.x), bd, 1e-6, pc="bpx")
+    assert np.abs(cb["u"] - cj["u"]).max() < 1e-10 * np.abs(cj["u"]).max()
+    assert np.abs(cb["grad"] - cj["grad"]).max() < 1e-10 * np.abs(cj["grad"]).max()
+    assert cb["it_adj"] < cj["it_adj"]
