@@ -36,6 +36,23 @@ __device__ __forceinline__ void load_conn(const int32_t* __restrict__ conn, int6
   }
 }
 
+// The vertices of a visited cell without touching `conn`: local vertex a is the visiting row
+// itself, the others sit in the row's own column list at the positions the slot bytes name
+// (row + delta[pos] on regular slices).  `conn` rows of neighbouring lanes are 96 B apart (one
+// cache line per lane), the row's columns are the lane's own 14 contiguous words.
+template <int D>
+__device__ __forceinline__ void row_cell_vertices(int64_t row, int lane, int a, uint32_t slots, bool regular,
+                                                  const int32_t* __restrict__ dl, const int32_t* __restrict__ cols,
+                                                  int64_t mb, int32_t v[D + 1]) {
+#pragma unroll
+  for (int b = 0; b <= D; ++b) {
+    const int pos = (slots >> (8 * b)) & 0xFF;
+    int32_t vb = (int32_t)row;
+    if (b != a) vb = regular ? (int32_t)(row + dl[pos]) : cols[mb + (int64_t)(pos >> 1) * 128 + lane * 2 + (pos & 1)];
+    v[b] = vb;
+  }
+}
+
 // Geometry of a cell from its vertex coordinates p[a][k] (a = local vertex, canonical order)
 template <int D>
 __device__ __forceinline__ void cell_geom_p(const double (&p)[D + 1][D], CellGeom<D>& G) {
@@ -324,6 +341,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
     int64_t n_rows, int64_t n_blocks, const int64_t* __restrict__ vptr,
     const int32_t* __restrict__ visit_cell, const uint32_t* __restrict__ visit_slots,
     const int64_t* __restrict__ mptr, const int32_t* __restrict__ cols,
+    const int32_t* __restrict__ sdelta, int sdelta_stride,
     const int32_t* __restrict__ rowlen, const int32_t* __restrict__ conn,
     const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ f,
     const double* __restrict__ aux, const uint8_t* __restrict__ bfacets, double beta, double sgn,
@@ -342,6 +360,9 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
   const int64_t vb = vptr[slice];
   const int nvis = (int)((vptr[slice + 1] - vb) >> 6);
   const bool want_rhs = rhs != nullptr;
+  const int64_t mb = mptr[slice];
+  const int32_t* dl = sdelta + slice * sdelta_stride;
+  const bool regular = dl[0] != INT32_MIN;
   double dsum = 0.0, racc = 0.0;
   double xo[D];
   {
@@ -357,7 +378,8 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
     const int64_t c = ca >> 2;
     const int a = ca & 3;
     int32_t v[D + 1];
-    load_conn<D>(conn, c, v);
+    if constexpr (PDE == FEMO_PDE_EB_BEAM) load_conn<D>(conn, c, v);
+    else row_cell_vertices<D>(row, lane, a, slots, regular, dl, cols, mb, v);
     double krow[D + 1];
     CellGeom<D> G;
     double ga[D];
@@ -419,7 +441,6 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
   const bool row_bc = bcmask != nullptr && valid && bcmask[row];
   if (diag0) diag0[row] = valid ? dsum : 1.0;  // padded rows of the last slice: harmless identity
   if (diag1) diag1[row] = (valid && !row_bc) ? dsum : 1.0;
-  const int64_t mb = mptr[slice];
   const int wm = (int)((mptr[slice + 1] - mb) >> 6);
   double lift = 0.0;
   // linear Poisson: (K u)_i from the finished row, one u gather per column instead of D+1 per
@@ -721,7 +742,7 @@ static int launch_system_t(femo_mesh* m, int64_t nb, size_t lds, const double* u
                            double* diag1, double* vals1, double* rhs) {
   auto k = k_jacobian<D, PDE>;
   if (lds > 64 * 1024) FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k, dim3(nb), dim3(FEMO_BLOCK), lds, m->ctx->stream, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_visit_slots, m->d_mptr, m->d_cols, m->d_rowlen, m->d_conn, m->d_x, u, f, aux, m->d_bfacets, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
+  hipLaunchKernelGGL(k, dim3(nb), dim3(FEMO_BLOCK), lds, m->ctx->stream, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_visit_slots, m->d_mptr, m->d_cols, m->d_sdelta, m->sdelta_stride, m->d_rowlen, m->d_conn, m->d_x, u, f, aux, m->d_bfacets, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
