@@ -58,6 +58,7 @@ struct femo_pc {
   uint32_t* d_pk = nullptr;         // packed lattice coordinates, dim words per owned vertex (vertex order)
   uint32_t* d_pk_sorted = nullptr;  // the same in sorted order
   double* d_w_sorted = nullptr;     // 1/s (0 on pinned vertices) in sorted order, refreshed per solve
+  double* d_dot_partials = nullptr; // per-block partials of g_L.e_L (2048)
   int64_t* d_brick_ptr = nullptr;   // n_bricks + 1
   uint32_t* d_bin_ptr = nullptr;    // 65 per brick: start of each of its 64 bins, relative to the brick
   int32_t* d_brick_base = nullptr;  // 3 per brick: first bin of the brick along each axis
@@ -268,19 +269,40 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
   }
 }
 
-// zh = rh + (1/s) P_L e_L ; partial rh.zh
+// zh = rh + (1/s) P_L e_L, delivered as
+//   mode 0: out = zh
+//   mode 1: out = zh + beta out   (the next search direction; zh is never stored)
+//   mode 2: out = zh              (first direction)
+// In modes 1/2 gamma' = rh.zh = rho + g_L.e_L comes from the lattice (rho = rh.rh is already in
+// `rho`, the g.e partials of the finest k_lattice_prolong are folded here by every block in the
+// same order), beta = gamma'/gamma_cur, and gamma' is left in *gamma_nxt for the next alpha.
 template <int D>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat lat, const uint32_t* __restrict__ pk,
                                                              const double* __restrict__ rh, const double* __restrict__ s,
                                                              const uint8_t* __restrict__ mask, const double* __restrict__ e,
-                                                             double* __restrict__ zh, double* __restrict__ partials,
+                                                             double* __restrict__ out, int mode, int nb_dot,
+                                                             const double* __restrict__ dot_partials, const double* __restrict__ rho,
+                                                             const double* __restrict__ gamma_cur, double* __restrict__ gamma_nxt,
                                                              const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
   __shared__ double lds[FEMO_BLOCK / 64];
-  double acc = 0.0;
+  double beta = 0.0;
+  if (mode != 0) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < nb_dot; i += FEMO_BLOCK) a += dot_partials[i];
+    a = femo_wave_sum(a);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) lds[w] = a;
+    __syncthreads();
+    double ge = 0.0;
+#pragma unroll
+    for (int i = 0; i < FEMO_BLOCK / 64; ++i) ge += lds[i];
+    const double g1 = *rho + ge, g0 = *gamma_cur;
+    if (mode == 1) beta = g0 != 0.0 ? g1 / g0 : 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *gamma_nxt = g1;
+  }
   for (int64_t v = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; v < n_rows; v += (int64_t)gridDim.x * FEMO_BLOCK) {
-    const double r = rh[v];
-    double z = r;
+    double z = rh[v];
     if (!(mask != nullptr && mask[v])) {
       int i0[3] = {0, 0, 0};
       double t[3] = {0.0, 0.0, 0.0};
@@ -301,11 +323,8 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat
       }
       z += sum * (1.0 / s[v]);     // the same rounded 1/s the restriction multiplies with
     }
-    zh[v] = z;
-    acc += r * z;
+    out[v] = mode == 1 ? z + beta * out[v] : z;
   }
-  const double tsum = femo_block_sum<FEMO_BLOCK>(acc, lds);
-  if (threadIdx.x == 0 && partials != nullptr) partials[blockIdx.x] = tsum;
 }
 
 // coarse[I] = sum over the fine nodes 2I-1, 2I, 2I+1 (per axis) with weights 1/2, 1, 1/2
@@ -360,17 +379,28 @@ __global__ void k_lattice_restrict(int nc0, int nc1, int nc2, int nf0, int nf1, 
 }
 
 // e_f[i] = (interpolation of e_c)(i) + coef_f[i] * g_f[i]     (e_c == nullptr: coarsest level)
-__global__ void k_lattice_prolong(int nf0, int nf1, int nf2, int nc0, int nc1, int nc2, int dim,
-                                  const double* __restrict__ ec, const double* __restrict__ coef, double* __restrict__ g,
-                                  int zero_g, double* __restrict__ ef, const int32_t* __restrict__ done) {
+// dot_partials != nullptr (finest level): per-block partial of g.e -- with it the caller has
+// rh.zh = rh.rh + g_L.e_L without a pass over the mesh (see femo_pc_apply).
+__global__ __launch_bounds__(256) void k_lattice_prolong(int nf0, int nf1, int nf2, int nc0, int nc1, int nc2, int dim,
+                                                         const double* __restrict__ ec, const double* __restrict__ coef, double* __restrict__ g,
+                                                         int zero_g, double* __restrict__ ef, double* __restrict__ dot_partials,
+                                                         const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
+  __shared__ double lds[256 / 64];
   const int64_t total = (int64_t)(nf0 + 1) * (nf1 + 1) * (nf2 + 1);
   const int nc[3] = {nc0, nc1, nc2}, nf[3] = {nf0, nf1, nf2};
+  double dot = 0.0;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    double v = coef[idx] * g[idx];
+    const double gi = g[idx];
+    double v = coef[idx] * gi;
     if (zero_g) g[idx] = 0.0;      // accumulated by atomics: left clean for the next restriction
     if (ec != nullptr) v += lattice_interp_node(idx, nf, nc, dim, ec);
     ef[idx] = v;
+    dot += gi * v;
+  }
+  if (dot_partials != nullptr) {
+    const double t = femo_block_sum<256>(dot, lds);
+    if (threadIdx.x == 0) dot_partials[blockIdx.x] = t;
   }
 }
 
@@ -577,6 +607,7 @@ int femo_pc_build(femo_mesh* m) {
     FEMO_HIP_CHECK(hipMalloc(&pc->d_pk, pk.size() * sizeof(uint32_t)));
     FEMO_HIP_CHECK(hipMalloc(&pc->d_pk_sorted, pks.size() * sizeof(uint32_t)));
     FEMO_HIP_CHECK(hipMalloc(&pc->d_w_sorted, perm.size() * sizeof(double)));
+    FEMO_HIP_CHECK(hipMalloc(&pc->d_dot_partials, 2048 * sizeof(double)));
     FEMO_HIP_CHECK(hipMalloc(&pc->d_brick_ptr, ptr_c.size() * sizeof(int64_t)));
     FEMO_HIP_CHECK(hipMalloc(&pc->d_bin_ptr, binp.size() * sizeof(uint32_t)));
     FEMO_HIP_CHECK(hipMalloc(&pc->d_brick_base, base_c.size() * sizeof(int32_t)));
@@ -595,7 +626,7 @@ void femo_pc_destroy(femo_mesh* m) {
   if (!m->pc) return;
   for (auto& L : m->pc->L) { (void)hipFree(L.e); (void)hipFree(L.coef); }
   (void)hipFree(m->pc->g_all);
-  (void)hipFree(m->pc->d_perm); (void)hipFree(m->pc->d_pk); (void)hipFree(m->pc->d_pk_sorted); (void)hipFree(m->pc->d_w_sorted);
+  (void)hipFree(m->pc->d_perm); (void)hipFree(m->pc->d_pk); (void)hipFree(m->pc->d_pk_sorted); (void)hipFree(m->pc->d_w_sorted); (void)hipFree(m->pc->d_dot_partials);
   (void)hipFree(m->pc->d_brick_ptr); (void)hipFree(m->pc->d_bin_ptr); (void)hipFree(m->pc->d_brick_base);
   delete m->pc;
   m->pc = nullptr;
@@ -644,8 +675,8 @@ static int pc_prepare(femo_mesh* m, const uint8_t* mask, uint64_t key) {
 }
 
 // zh = M^-1 rh in scaled variables; partials[block] = rh.zh per block (gv blocks)
-int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const double* s, const double* rh, double* zh,
-                  double* partials, const int32_t* done, int gv) {
+int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const double* s, const double* rh, double* out,
+                  int mode, const double* rho, const double* gamma_cur, double* gamma_nxt, const int32_t* done, int gv) {
   femo_pc* pc = m->pc;
   femo_ctx* ctx = m->ctx;
   hipStream_t st = ctx->stream;
@@ -689,12 +720,14 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
     LatticeLevel& Fi = pc->L[l];
     const double* ec = l > 0 ? pc->L[l - 1].e : nullptr;
     const int* nc = l > 0 ? pc->L[l - 1].n : Fi.n;
-    hipLaunchKernelGGL(k_lattice_prolong, dim3(lat_grid(Fi.nodes)), dim3(256), 0, st, Fi.n[0], Fi.n[1], Fi.n[2], nc[0], nc[1], nc[2], pc->dim, ec, Fi.coef, Fi.g, l >= nl - 1 - nf ? 1 : 0, Fi.e, done);
+    double* dots = (l == nl - 1 && mode != 0) ? pc->d_dot_partials : nullptr;
+    hipLaunchKernelGGL(k_lattice_prolong, dim3(lat_grid(Fi.nodes)), dim3(256), 0, st, Fi.n[0], Fi.n[1], Fi.n[2], nc[0], nc[1], nc[2], pc->dim, ec, Fi.coef, Fi.g, l >= nl - 1 - nf ? 1 : 0, Fi.e, dots, done);
   }
+  const int nb_dot = (int)lat_grid(F.nodes);
   if (pc->dim == 3)
-    hipLaunchKernelGGL(k_prolong_mesh<3>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, s, mask, F.e, zh, partials, done);
+    hipLaunchKernelGGL(k_prolong_mesh<3>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, s, mask, F.e, out, mode, nb_dot, pc->d_dot_partials, rho, gamma_cur, gamma_nxt, done);
   else
-    hipLaunchKernelGGL(k_prolong_mesh<2>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, s, mask, F.e, zh, partials, done);
+    hipLaunchKernelGGL(k_prolong_mesh<2>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, s, mask, F.e, out, mode, nb_dot, pc->d_dot_partials, rho, gamma_cur, gamma_nxt, done);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -483,21 +483,6 @@ __global__ __launch_bounds__(1024) void k_pcg_check(int it, int nb, const double
   }
 }
 
-// ph = zh + beta ph.  nb_g > 0: gamma' = rh.zh is folded here from the prolongation's partials and
-// left in scal for the next iteration's alpha (nobody reads that slot during this launch).
-__global__ __launch_bounds__(FEMO_BLOCK) void k_pcg_p(int64_t n, int cur, int nb_g, const double* __restrict__ partials_g,
-                                                      double* __restrict__ scal, const double* __restrict__ z,
-                                                      double* __restrict__ p, const int32_t* __restrict__ done) {
-  if (*done) return;
-  __shared__ double lds[FEMO_BLOCK / 64];
-  const double g0 = scal[S_GAMMA + cur];
-  const double g1 = nb_g > 0 ? cg_scalar(partials_g, nb_g, lds) : scal[S_GAMMA + (cur ^ 1)];
-  if (nb_g > 0 && blockIdx.x == 0 && threadIdx.x == 0) scal[S_GAMMA + (cur ^ 1)] = g1;
-  const double beta = g0 != 0.0 ? g1 / g0 : 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FEMO_BLOCK)
-    p[i] = z[i] + beta * p[i];
-}
-
 // ---- single-reduction CG (Chronopoulos & Gear) for nranks > 1 ---------------------
 // One all-reduce of (gamma = r.r, delta = r.Ar) and one halo exchange per iteration:
 //   beta = gamma/gamma_old; alpha = gamma / (delta - beta*gamma/alpha_old)
@@ -1030,7 +1015,6 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
   CgWork w;
   const bool multi = ctx->nranks > 1 || (ctx->comm != nullptr && getenv("FEMO_FORCE_MULTI") != nullptr);
   FEMO_TRY(ensure_work(ctx, n, m->n_vert, w, 1));
-  double* z = w.sv;
   const int gv = vec_grid(ctx, n);
   const int gs = femo_spmv_grid(m);
   int32_t* h_flags = reinterpret_cast<int32_t*>(ctx->h_scal + FEMO_NSCAL);
@@ -1088,11 +1072,8 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
   memcpy(ctx->h_scal, hs, sizeof hs);
   FEMO_HIP_CHECK(hipMemcpyAsync(S, ctx->h_scal, sizeof hs, hipMemcpyHostToDevice, st));
   FEMO_HIP_CHECK(hipStreamSynchronize(st));
-  // zh0 = M^-1 rh0, ph0 = zh0, gamma0 = rh0.zh0
-  FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, z, P + 2 * FEMO_MAX_PARTIALS, ctx->d_flags, gv));
-  hipLaunchKernelGGL(k_pcg_fold, dim3(1), dim3(1024), 0, st, gv, P + 2 * FEMO_MAX_PARTIALS, 0, (const double*)nullptr, S + S_GAMMA, ctx->d_flags);
-  FEMO_TRY(allreduce1(S + S_GAMMA));
-  FEMO_HIP_CHECK(hipMemcpyAsync(w.p, z, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+  // ph0 = zh0 = M^-1 rh0, gamma0 = rh0.zh0 = rho0 + g_L.e_L (lattice dot: global on every rank, no all-reduce)
+  FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, w.p, 2, S + S_RHO, S + S_GAMMA + 1, S + S_GAMMA, ctx->d_flags, gv));
 
   const int n_sample = 4, sample_from = 2;
   int n_ev = 0;
@@ -1117,13 +1098,13 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
       if (sample) { FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev + 1], st)); ++n_ev; }
       double* Pd = P + P_DELTA * FEMO_MAX_PARTIALS;
       double* Pr = P + 1 * FEMO_MAX_PARTIALS;
-      double* Pg = P + 2 * FEMO_MAX_PARTIALS;
+      double* Pg = P + 2 * FEMO_MAX_PARTIALS;   // boundary-slice partials of the overlapped SpMV
       if (local_scalars) {
         // single GPU: the consumers fold the per-block partials themselves
         hipLaunchKernelGGL(k_pcg_xr, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, g1, Pd, S, w.q, w.p, w.r, w.xh, Pr, ctx->d_flags);
         hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(1024), 0, st, it, gv, Pr, S, ctx->d_flags);
-        FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, z, Pg, ctx->d_flags, gv));
-        hipLaunchKernelGGL(k_pcg_p, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, gv, Pg, S, z, w.p, ctx->d_flags);
+        // ph = M^-1 rh + beta ph in one pass: rh.zh = rho + g_L.e_L is known before the mesh prolongation
+        FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, w.p, 1, S + S_RHO, S + S_GAMMA + cur, S + S_GAMMA + nxt, ctx->d_flags, gv));
       } else {
         hipLaunchKernelGGL(k_pcg_fold, dim3(1), dim3(1024), 0, st, g1, Pd, g2, Pg, S + S_DELTA, ctx->d_flags);
         FEMO_TRY(allreduce1(S + S_DELTA));
@@ -1131,10 +1112,8 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
         hipLaunchKernelGGL(k_pcg_fold, dim3(1), dim3(1024), 0, st, gv, Pr, 0, (const double*)nullptr, S + S_RHO, ctx->d_flags);
         FEMO_TRY(allreduce1(S + S_RHO));
         hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(1024), 0, st, it, 0, Pr, S, ctx->d_flags);
-        FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, z, Pg, ctx->d_flags, gv));
-        hipLaunchKernelGGL(k_pcg_fold, dim3(1), dim3(1024), 0, st, gv, Pg, 0, (const double*)nullptr, S + S_GAMMA + nxt, ctx->d_flags);
-        FEMO_TRY(allreduce1(S + S_GAMMA + nxt));
-        hipLaunchKernelGGL(k_pcg_p, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, 0, Pg, S, z, w.p, ctx->d_flags);
+        // rho and the lattice accumulators are already global, so gamma' needs no all-reduce of its own
+        FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, w.p, 1, S + S_RHO, S + S_GAMMA + cur, S + S_GAMMA + nxt, ctx->d_flags, gv));
       }
     }
     FEMO_HIP_CHECK(hipGetLastError());
@@ -1193,7 +1172,7 @@ extern "C" int femo_mat_pc_apply(const femo_mat* A_, const femo_vec* r, femo_vec
   if (n == 0) return 0;
   // rh = S r, zh = Mh^-1 rh, z = S zh
   hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, r->d, (const double*)nullptr, A->d_s, w.r, w.p, w.xh, ctx->d_partials);
-  FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, w.sv, ctx->d_partials + 2 * FEMO_MAX_PARTIALS, ctx->d_flags, gv));
+  FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, w.sv, 0, nullptr, nullptr, nullptr, ctx->d_flags, gv));
   hipLaunchKernelGGL(k_unscale, dim3(2048), dim3(256), 0, st, n, 0, A->d_s, w.sv, z->d);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
