@@ -590,11 +590,15 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_functional_value(
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
+// dJ/du_i = sum_cells |T|/((D+1)(D+2)) (e_i + sum_b e_b), e = u - u_d  (mass matrix times e).
+// Same walk as the Jacobian: vertices from the row's own columns, own coordinates and own e in
+// registers, so a visited cell costs D coordinate gathers and D gathers of e.
 template <int D>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_functional_grad_u(
     int64_t n_rows, int64_t n_blocks, const int64_t* __restrict__ vptr,
-    const int32_t* __restrict__ visit_cell, const int32_t* __restrict__ conn,
-    const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ ud,
+    const int32_t* __restrict__ visit_cell, const uint32_t* __restrict__ visit_slots,
+    const int64_t* __restrict__ mptr, const int32_t* __restrict__ cols, const int32_t* __restrict__ sdelta,
+    int sdelta_stride, const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ ud,
     double* __restrict__ g) {
   const int64_t blk = femo_xcd_block(blockIdx.x, n_blocks);
   const int64_t row = blk * FEMO_BLOCK + threadIdx.x;
@@ -603,24 +607,32 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_functional_grad_u(
   if ((slice << 6) >= n_rows) return;
   const int64_t vb = vptr[slice];
   const int nvis = (int)((vptr[slice + 1] - vb) >> 6);
+  const int64_t mb = mptr[slice];
+  const int32_t* dl = sdelta + slice * sdelta_stride;
+  const bool regular = dl[0] != INT32_MIN;
+  const int64_t r0 = row < n_rows ? row : 0;
+  double xo[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) xo[k] = x[r0 * D + k];
+  const double eo = u[r0] - ud[r0];
   double acc = 0.0;
   for (int s = 0; s < nvis; ++s) {
-    const int32_t ca = visit_cell[vb + (int64_t)s * 64 + lane];
+    const int64_t vi = vb + (int64_t)s * 64 + lane;
+    const int32_t ca = visit_cell[vi];
     if (ca < 0) continue;
-    const int64_t c = ca >> 2;
     const int a = ca & 3;
     int32_t v[D + 1];
-    load_conn<D>(conn, c, v);
+    row_cell_vertices<D>(row, lane, a, visit_slots[vi], regular, dl, cols, mb, v);
     CellGeom<D> G;
-    cell_geom<D>(x, v, G);
-    double s1 = 0.0, ea = 0.0;
+    cell_geom_owner<D>(x, v, a, xo, G);
+    double s1 = eo;
 #pragma unroll
     for (int b = 0; b <= D; ++b) {
-      const double e = u[v[b]] - ud[v[b]];
+      const int32_t vb_ = v[b];
+      const double e = (b == a) ? 0.0 : u[vb_] - ud[vb_];
       s1 += e;
-      ea = (a == b) ? e : ea;
     }
-    acc += G.vol * (1.0 / ((D + 1) * (D + 2))) * (ea + s1);
+    acc += G.vol * (1.0 / ((D + 1) * (D + 2))) * (eo + s1);
   }
   if (row < n_rows) g[row] = acc;
 }
@@ -852,7 +864,7 @@ int femo_launch_functional_grad_u(femo_mesh* m, int kind, const double* params, 
   const int64_t nb = row_blocks(m);
   if (nb == 0) return 0;
   hipStream_t st = m->ctx->stream;
-  FEMO_LAUNCH_D(m, k_functional_grad_u, nb, 0, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_conn, m->d_x, u, ud, gout);
+  FEMO_LAUNCH_D(m, k_functional_grad_u, nb, 0, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_visit_slots, m->d_mptr, m->d_cols, m->d_sdelta, m->sdelta_stride, m->d_x, u, ud, gout);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
