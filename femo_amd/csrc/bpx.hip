@@ -52,6 +52,7 @@ struct femo_pc {
   uint64_t built_key = 0;   // identity of the Dirichlet mask the coef arrays were built for
   double* g_all = nullptr;  // the g arrays of all levels, coarsest first, contiguous
   int n_fused = 0;          // coarser levels the brick kernel restricts to directly (besides the finest)
+  bool coarse_lds_set = false;
   // owned vertices sorted by brick (BRICK^dim bins of the finest lattice), for the restriction
   int64_t n_bricks = 0;
   int32_t* d_perm = nullptr;        // sorted position -> vertex
@@ -408,31 +409,42 @@ __global__ __launch_bounds__(256) void k_lattice_prolong(int nf0, int nf1, int n
 // (filled by the brick kernel or the last multi-block restriction) to level 0, then build the
 // corrections e_0 .. e_{top-1} on the way up.  These levels have a few thousand nodes; as separate
 // launches they cost ~4.7 us each in launch latency alone (2 x top launches per iteration).
+// Their g and e stay in LDS: with global memory between the phases the kernel took 36 us at C4
+// (six dependent round trips), more than the launches it replaced.
 struct CoarseLevels {
   int n_levels;                 // levels 0 .. n_levels-1 are handled here; level n_levels is `top`
   int n[FEMO_PC_MAX_LEVELS][3];
   double* g[FEMO_PC_MAX_LEVELS];
   double* e[FEMO_PC_MAX_LEVELS];
   const double* coef[FEMO_PC_MAX_LEVELS];
+  int64_t nodes[FEMO_PC_MAX_LEVELS];
+  int64_t off[FEMO_PC_MAX_LEVELS];     // LDS offset (doubles) of level l: g at off, e at off + nodes
 };
 
 __global__ __launch_bounds__(1024) void k_lattice_coarse(CoarseLevels L, int dim, const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
+  // g and e of the levels below `top` live in LDS for the whole launch (a few thousand nodes);
+  // only e_{top-1}, which the next prolongation reads, goes back to global memory
+  extern __shared__ double coarse_lds[];
   const int top = L.n_levels;
   for (int l = top - 1; l >= 0; --l) {
     const int64_t total = (int64_t)(L.n[l][0] + 1) * (L.n[l][1] + 1) * (L.n[l][2] + 1);
-    for (int64_t idx = threadIdx.x; idx < total; idx += 1024) L.g[l][idx] = lattice_restrict_node(idx, L.n[l], L.n[l + 1], dim, L.g[l + 1]);
-    __threadfence_block();
+    const double* fine = l + 1 == top ? L.g[top] : coarse_lds + L.off[l + 1];
+    double* gl = coarse_lds + L.off[l];
+    for (int64_t idx = threadIdx.x; idx < total; idx += 1024) gl[idx] = lattice_restrict_node(idx, L.n[l], L.n[l + 1], dim, fine);
     __syncthreads();
   }
   for (int l = 0; l < top; ++l) {
     const int64_t total = (int64_t)(L.n[l][0] + 1) * (L.n[l][1] + 1) * (L.n[l][2] + 1);
+    const double* gl = coarse_lds + L.off[l];
+    double* el = coarse_lds + L.off[l] + L.nodes[l];
+    const double* ec = l > 0 ? coarse_lds + L.off[l - 1] + L.nodes[l - 1] : nullptr;
     for (int64_t idx = threadIdx.x; idx < total; idx += 1024) {
-      double v = L.coef[l][idx] * L.g[l][idx];
-      if (l > 0) v += lattice_interp_node(idx, L.n[l], L.n[l - 1], dim, L.e[l - 1]);
-      L.e[l][idx] = v;
+      double v = L.coef[l][idx] * gl[idx];
+      if (l > 0) v += lattice_interp_node(idx, L.n[l], L.n[l - 1], dim, ec);
+      el[idx] = v;
+      if (l == top - 1) L.e[l][idx] = v;
     }
-    __threadfence_block();
     __syncthreads();
   }
 }
@@ -699,9 +711,13 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
   }
   // levels with at most COARSE_NODES nodes (and below the brick-fused ones) go through the
   // single-workgroup kernel; `cut` = first level handled by multi-block launches
-  constexpr int64_t COARSE_NODES = 6000;
+  // levels 0 .. cut-1 go through the single-workgroup kernel, which reads g of level `cut` from
+  // global memory: one CU gathers 27 values per coarse node, so that level must stay small (with
+  // 15.6 k nodes the phase alone took 25 us at C4)
+  constexpr int64_t COARSE_TOP_NODES = 4096;
   int cut = 0;
-  while (cut < nl - 1 - nf && cut < FEMO_PC_MAX_LEVELS - 1 && pc->L[cut].nodes <= COARSE_NODES) ++cut;
+  int64_t coarse_total = 0;
+  while (cut < nl - 1 - nf && cut < FEMO_PC_MAX_LEVELS - 1 && pc->L[cut + 1].nodes <= COARSE_TOP_NODES) coarse_total += pc->L[cut++].nodes;
   for (int l = nl - 2 - nf; l >= cut; --l) {
     LatticeLevel& C = pc->L[l];
     const LatticeLevel& Fi = pc->L[l + 1];
@@ -713,8 +729,15 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
     for (int l = 0; l <= cut; ++l) {
       for (int k = 0; k < 3; ++k) CL.n[l][k] = pc->L[l].n[k];
       CL.g[l] = pc->L[l].g; CL.e[l] = pc->L[l].e; CL.coef[l] = pc->L[l].coef;
+      CL.nodes[l] = pc->L[l].nodes;
+      CL.off[l] = l == 0 ? 0 : CL.off[l - 1] + 2 * CL.nodes[l - 1];
     }
-    hipLaunchKernelGGL(k_lattice_coarse, dim3(1), dim3(1024), 0, st, CL, pc->dim, done);
+    const size_t lds = (size_t)coarse_total * 2 * sizeof(double);
+    if (lds > 64 * 1024 && !pc->coarse_lds_set) {
+      FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_coarse, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      pc->coarse_lds_set = true;
+    }
+    hipLaunchKernelGGL(k_lattice_coarse, dim3(1), dim3(1024), lds, st, CL, pc->dim, done);
   }
   for (int l = cut; l < nl; ++l) {
     LatticeLevel& Fi = pc->L[l];
