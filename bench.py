@@ -187,6 +187,14 @@ def main():
     global PC
     args = parse()
     PC = args.pc
+    from femo_amd.dist import _quiet_stdout
+    with _quiet_stdout():                       # library banners go to stderr: stdout carries ONE JSON line
+        result = _run(args)
+    if result is not None:
+        print(json.dumps(result), flush=True)
+
+
+def _run(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -286,7 +294,7 @@ def main():
     if not args.no_cpu_baseline:
         counts = its_per_step if its_per_step else [0]
         result["cpu_baseline"] = cpu_baseline(args, counts, n_dof, mesh.n_cell, nnz)
-    print(json.dumps(result), flush=True)
+    return result
 
 
 if __name__ == "__main__":

@@ -73,8 +73,37 @@ def init_comm(ctx, rank: int, world: int) -> None:
     ctx.comm_init(box[0], rank, world)
 
 
-def bench_distributed(args, rank: int, world: int, local_rank: int) -> None:
-    """bench.py for N > 1: the 10 M-DOF mesh is partitioned over the ranks (strong scaling)."""
+class _quiet_stdout:
+    """gloo and RCCL print banners on the C-level stdout; bench.py's contract is ONE JSON line there.
+    Route fd 1 to stderr while the run is set up and timed, restore it for the result."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+        import sys
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)          # RCCL's banner sits in the C stdio buffer until exit otherwise
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
+def bench_distributed(args, rank: int, world: int, local_rank: int):
+    """bench.py for N > 1: the 10 M-DOF mesh is partitioned over the ranks (strong scaling).
+    Returns the result line on rank 0 (None elsewhere); bench.py prints it."""
+    result = _bench_distributed(args, rank, world, local_rank)
+    import torch.distributed as dist
+    dist.barrier()
+    return result
+
+
+def _bench_distributed(args, rank: int, world: int, local_rank: int):
     import bench as B
     from ..engine import Context, DeviceArray, Vec
     from ..fea import utils_hip
@@ -149,5 +178,5 @@ def bench_distributed(args, rank: int, world: int, local_rank: int) -> None:
                 "algorithmic_bytes_per_launch": B_A, "avg_launch_ms": spmv_ms, "launches_timed": 150,
             },
         }
-        print(json.dumps(result), flush=True)
-    dist.barrier()
+        return result
+    return None
