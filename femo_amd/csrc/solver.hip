@@ -450,7 +450,21 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_pcg_xr(int64_t n, int cur, int n
   if (nb_d > 0 && blockIdx.x == 0 && threadIdx.x == 0) scal[S_DELTA] = delta;   // for the breakdown test
   const double alpha = delta != 0.0 ? gamma / delta : 0.0;
   double s0 = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FEMO_BLOCK) {
+  const int64_t n2 = n >> 1;
+  const double2* q2 = reinterpret_cast<const double2*>(q);
+  const double2* p2 = reinterpret_cast<const double2*>(p);
+  double2* r2 = reinterpret_cast<double2*>(r);
+  double2* x2 = reinterpret_cast<double2*>(xh);
+  for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n2; i += (int64_t)gridDim.x * FEMO_BLOCK) {
+    const double2 qi = q2[i], pi = p2[i];
+    double2 ri = r2[i], xi = x2[i];
+    xi.x += alpha * pi.x; xi.y += alpha * pi.y;
+    ri.x -= alpha * qi.x; ri.y -= alpha * qi.y;
+    x2[i] = xi; r2[i] = ri;
+    s0 += ri.x * ri.x + ri.y * ri.y;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
     xh[i] += alpha * p[i];
     const double ri = r[i] - alpha * q[i];
     r[i] = ri;
