@@ -106,7 +106,11 @@ class BPX:
     """The operator r -> M^-1 r for an SPD matrix A with diagonal `diag` on vertices `x`."""
 
     def __init__(self, x: np.ndarray, diag: np.ndarray, pinned: Optional[np.ndarray] = None,
-                 lo=None, hi=None, n_vert_global: Optional[int] = None, spacing: float = 2.0):
+                 lo=None, hi=None, n_vert_global: Optional[int] = None, spacing: float = 2.0, reduce=None):
+        """Partitioned meshes: `x`, `diag`, `pinned` are the rank's owned vertices, `lo`/`hi`/
+        `n_vert_global` describe the whole mesh and `reduce` sums a lattice array over the ranks
+        (what ncclAllReduce does to the accumulators in femo_pc_apply)."""
+        self.reduce = reduce if reduce is not None else (lambda a: a)
         x = np.asarray(x, float)
         N, d = x.shape
         self.dim = d
@@ -119,7 +123,7 @@ class BPX:
         nL = self.bins[-1]
         # keep rule on the finest lattice from the exact (unquantised) hat-function masses
         P_exact = interpolation(x, self.lo, self.hi, nL, quantise=False)
-        wf, wd = P_exact.T @ free, P_exact.T @ (1.0 - free)
+        wf, wd = self.reduce(P_exact.T @ free), self.reduce(P_exact.T @ (1.0 - free))
         keep = (wf > 0.0) & (wd <= KEEP_FRACTION * (wf + wd))
         self.P = (sp.diags(free) @ interpolation(x, self.lo, self.hi, nL, quantise=True)).tocsr()
         self.I = [lattice_interpolation(self.bins[l]) for l in range(len(self.bins) - 1)]   # level l -> l+1
@@ -137,18 +141,27 @@ class BPX:
     def levels(self) -> int:
         return len(self.bins)
 
-    def lattice_correction(self, r: np.ndarray) -> np.ndarray:
+    def lattice_correction(self, r: np.ndarray, with_dot: bool = False):
         g = [None] * self.levels
-        g[-1] = self.P.T @ r
+        g[-1] = self.reduce(self.P.T @ r)
         for l in range(self.levels - 2, -1, -1):
             g[l] = self.I[l].T @ g[l + 1]
         e = self.coef[0] * g[0]
         for l in range(1, self.levels):
             e = self.I[l - 1] @ e + self.coef[l] * g[l]
+        if with_dot:
+            return self.P @ e, float(g[-1] @ e)       # g_L.e_L: global on every rank after the reduction
         return self.P @ e
 
     def apply(self, r: np.ndarray) -> np.ndarray:
         return self.dinv * r + self.lattice_correction(r)
+
+    def apply_with_dot(self, r: np.ndarray):
+        """z = M^-1 r and the lattice dot g_L.e_L, for which  r.z = r.D^-1 r + g_L.e_L  (summed over
+        the ranks on the left, already global on the right): the identity the PCG loop uses to get
+        beta before the correction is interpolated back to the mesh."""
+        c, dot = self.lattice_correction(r, with_dot=True)
+        return self.dinv * r + c, dot
 
     def matrix(self) -> np.ndarray:
         """Dense M^-1 (small meshes only)."""
