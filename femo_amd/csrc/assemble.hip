@@ -44,13 +44,23 @@ template <int D>
 __device__ __forceinline__ void row_cell_vertices(int64_t row, int lane, int a, uint32_t slots, bool regular,
                                                   const int32_t* __restrict__ dl, const int32_t* __restrict__ cols,
                                                   int64_t mb, int32_t v[D + 1]) {
+  // branch-free per lane: the own slot byte is 0xFF, read position 0 instead and discard the value;
+  // `regular` is uniform over the wave (a property of the slice)
+  int pos[D + 1];
 #pragma unroll
   for (int b = 0; b <= D; ++b) {
-    const int pos = (slots >> (8 * b)) & 0xFF;
-    int32_t vb = (int32_t)row;
-    if (b != a) vb = regular ? (int32_t)(row + dl[pos]) : cols[mb + (int64_t)(pos >> 1) * 128 + lane * 2 + (pos & 1)];
-    v[b] = vb;
+    const int p = (slots >> (8 * b)) & 0xFF;
+    pos[b] = (b == a) ? 0 : p;
   }
+  if (regular) {
+#pragma unroll
+    for (int b = 0; b <= D; ++b) v[b] = (int32_t)row + dl[pos[b]];
+  } else {
+#pragma unroll
+    for (int b = 0; b <= D; ++b) v[b] = cols[mb + (int64_t)(pos[b] >> 1) * 128 + lane * 2 + (pos[b] & 1)];
+  }
+#pragma unroll
+  for (int b = 0; b <= D; ++b) v[b] = (b == a) ? (int32_t)row : v[b];
 }
 
 // Geometry of a cell from its vertex coordinates p[a][k] (a = local vertex, canonical order)
@@ -106,9 +116,8 @@ __device__ __forceinline__ void cell_geom(const double* __restrict__ x, const in
 // coordinates, so only the D other vertices are gathered (the walks are bound by the number of
 // scattered loads per visited cell).  Values and vertex order are those of cell_geom: same bits.
 template <int D>
-__device__ __forceinline__ void cell_geom_owner(const double* __restrict__ x, const int32_t v[D + 1], int a,
-                                                const double (&xo)[D], CellGeom<D>& G) {
-  double o[D][D];
+__device__ __forceinline__ void load_other_vertices(const double* __restrict__ x, const int32_t v[D + 1], int a,
+                                                    double (&o)[D][D]) {
 #pragma unroll
   for (int j = 0; j < D; ++j) {
     const int32_t vj = (a <= j) ? v[j + 1] : v[j];       // the j-th vertex other than a
@@ -116,6 +125,10 @@ __device__ __forceinline__ void cell_geom_owner(const double* __restrict__ x, co
 #pragma unroll
     for (int k = 0; k < D; ++k) o[j][k] = q[k];
   }
+}
+
+template <int D>
+__device__ __forceinline__ void cell_geom_others(const double (&o)[D][D], int a, const double (&xo)[D], CellGeom<D>& G) {
   double p[D + 1][D];
 #pragma unroll
   for (int b = 0; b <= D; ++b) {
@@ -126,6 +139,14 @@ __device__ __forceinline__ void cell_geom_owner(const double* __restrict__ x, co
     }
   }
   cell_geom_p<D>(p, G);
+}
+
+template <int D>
+__device__ __forceinline__ void cell_geom_owner(const double* __restrict__ x, const int32_t v[D + 1], int a,
+                                                const double (&xo)[D], CellGeom<D>& G) {
+  double o[D][D];
+  load_other_vertices<D>(x, v, a, o);
+  cell_geom_others<D>(o, a, xo, G);
 }
 
 // Row a of the gradient table with a lane-varying a.  Written as an exact blend
@@ -370,6 +391,66 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
 #pragma unroll
     for (int k = 0; k < D; ++k) xo[k] = x[r0 * D + k];
   }
+  if constexpr (PDE == FEMO_PDE_POISSON) {
+    // Software-pipelined walk.  A visit is a chain of dependent loads (incidence words -> the
+    // row's columns -> coordinates); taken one visit at a time the wave sits in s_waitcnt five
+    // times per cell.  Three stages in flight: incidence words of visit s+2, column lookup and
+    // coordinate / f gathers of visit s+1, arithmetic of visit s.  Same order of accumulation.
+    auto fetch_ids = [&](int s, int32_t& ca, uint32_t& sl) {
+      ca = -1; sl = 0u;
+      if (s < nvis) {
+        const int64_t vi = vb + (int64_t)s * 64 + lane;
+        ca = visit_cell[vi];
+        sl = visit_slots[vi];
+      }
+    };
+    auto gather = [&](int32_t ca, uint32_t sl, double (&o)[D][D], double& fc) {
+      if (ca >= 0) {
+        int32_t v[D + 1];
+        row_cell_vertices<D>(row, lane, ca & 3, sl, regular, dl, cols, mb, v);
+        load_other_vertices<D>(x, v, ca & 3, o);
+        if (want_rhs) fc = f[ca >> 2];
+      }
+    };
+    int32_t ca0, ca1, ca2;
+    uint32_t sl0, sl1, sl2;
+    double o0[D][D], o1[D][D], f0 = 0.0, f1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+#pragma unroll
+      for (int k = 0; k < D; ++k) { o0[j][k] = 0.0; o1[j][k] = 0.0; }
+    fetch_ids(0, ca0, sl0);
+    fetch_ids(1, ca1, sl1);
+    gather(ca0, sl0, o0, f0);
+    for (int s = 0; s < nvis; ++s) {
+      fetch_ids(s + 2, ca2, sl2);
+      gather(ca1, sl1, o1, f1);
+      if (ca0 >= 0) {
+        const int a = ca0 & 3;
+        CellGeom<D> G;
+        double ga[D];
+        cell_geom_others<D>(o0, a, xo, G);
+        select_row<D>(G, a, ga);
+        if (want_rhs) racc -= f0 * G.vol * (1.0 / (D + 1));
+#pragma unroll
+        for (int b = 0; b <= D; ++b) {
+          const double kab = __dmul_rn(G.vol, dotD<D>(ga, G.g[b]));
+          if (b == a) {
+            dsum += kab;
+          } else {
+            const int pos = (sl0 >> (8 * b)) & 0xFF;
+            strip[pos * FEMO_BLOCK + tid] = __dadd_rn(strip[pos * FEMO_BLOCK + tid], kab);
+          }
+        }
+      }
+      ca0 = ca1; sl0 = sl1; f0 = f1;
+#pragma unroll
+      for (int j = 0; j < D; ++j)
+#pragma unroll
+        for (int k = 0; k < D; ++k) o0[j][k] = o1[j][k];
+      ca1 = ca2; sl1 = sl2;
+    }
+  } else
   for (int s = 0; s < nvis; ++s) {
     const int64_t vi = vb + (int64_t)s * 64 + lane;
     const int32_t ca = visit_cell[vi];
