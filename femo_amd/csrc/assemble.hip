@@ -697,23 +697,54 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_functional_grad_u(
   for (int k = 0; k < D; ++k) xo[k] = x[r0 * D + k];
   const double eo = u[r0] - ud[r0];
   double acc = 0.0;
-  for (int s = 0; s < nvis; ++s) {
-    const int64_t vi = vb + (int64_t)s * 64 + lane;
-    const int32_t ca = visit_cell[vi];
-    if (ca < 0) continue;
-    const int a = ca & 3;
-    int32_t v[D + 1];
-    row_cell_vertices<D>(row, lane, a, visit_slots[vi], regular, dl, cols, mb, v);
-    CellGeom<D> G;
-    cell_geom_owner<D>(x, v, a, xo, G);
-    double s1 = eo;
-#pragma unroll
-    for (int b = 0; b <= D; ++b) {
-      const int32_t vb_ = v[b];
-      const double e = (b == a) ? 0.0 : u[vb_] - ud[vb_];
-      s1 += e;
+  // software-pipelined like the Jacobian walk: ids of visit s+2, gathers of s+1, arithmetic of s
+  auto fetch_ids = [&](int s, int32_t& ca, uint32_t& sl) {
+    ca = -1; sl = 0u;
+    if (s < nvis) {
+      const int64_t vi = vb + (int64_t)s * 64 + lane;
+      ca = visit_cell[vi];
+      sl = visit_slots[vi];
     }
-    acc += G.vol * (1.0 / ((D + 1) * (D + 2))) * (eo + s1);
+  };
+  auto gather = [&](int32_t ca, uint32_t sl, double (&o)[D][D], double& esum) {
+    if (ca >= 0) {
+      const int a = ca & 3;
+      int32_t v[D + 1];
+      row_cell_vertices<D>(row, lane, a, sl, regular, dl, cols, mb, v);
+      load_other_vertices<D>(x, v, a, o);
+      double e = 0.0;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const int32_t vj = (a <= j) ? v[j + 1] : v[j];
+        e += u[vj] - ud[vj];
+      }
+      esum = e;
+    }
+  };
+  int32_t ca0, ca1, ca2;
+  uint32_t sl0, sl1, sl2;
+  double o0[D][D], o1[D][D], e0 = 0.0, e1 = 0.0;
+#pragma unroll
+  for (int j = 0; j < D; ++j)
+#pragma unroll
+    for (int k = 0; k < D; ++k) { o0[j][k] = 0.0; o1[j][k] = 0.0; }
+  fetch_ids(0, ca0, sl0);
+  fetch_ids(1, ca1, sl1);
+  gather(ca0, sl0, o0, e0);
+  for (int s = 0; s < nvis; ++s) {
+    fetch_ids(s + 2, ca2, sl2);
+    gather(ca1, sl1, o1, e1);
+    if (ca0 >= 0) {
+      CellGeom<D> G;
+      cell_geom_others<D>(o0, ca0 & 3, xo, G);
+      acc += G.vol * (1.0 / ((D + 1) * (D + 2))) * (eo + (eo + e0));
+    }
+    ca0 = ca1; sl0 = sl1; e0 = e1;
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+#pragma unroll
+      for (int k = 0; k < D; ++k) o0[j][k] = o1[j][k];
+    ca1 = ca2; sl1 = sl2;
   }
   if (row < n_rows) g[row] = acc;
 }
