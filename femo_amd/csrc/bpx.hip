@@ -27,10 +27,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "femo_internal.h"
-
-constexpr int FEMO_PC_MAX_LEVELS = 14;
 
 namespace {
 
@@ -125,7 +124,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_mesh(int64_t n_rows, La
 // t = fraction inside the bin in 20-bit fixed point.  Both transfers decode the same words, so P
 // and P^T stay exact transposes; the 1e-6 quantisation of the weights only perturbs the
 // preconditioner.  12 B per vertex instead of 24 B of coordinates.
-constexpr int PK_BITS = 20;
+constexpr int PK_BITS = FEMO_PK_BITS;
 constexpr uint32_t PK_MASK = (1u << PK_BITS) - 1u;
 __device__ __forceinline__ void unpack_coord(uint32_t w, int& bin, double& t) {
   bin = (int)(w >> PK_BITS);
@@ -493,143 +492,52 @@ int femo_pc_build(femo_mesh* m) {
   if (m->pc) return 0;
   femo_ctx* ctx = m->ctx;
   FEMO_REQUIRE(m->n_vert > 0, "empty mesh");
+  // the plan is host work (pc_plan.cpp): lattice choice, packed coordinates, (brick, bin) sort -- 0.5 s at C4
+  const int D = m->tdim;
+  const int64_t nr = m->n_rows;
+  std::vector<double> hx((size_t)std::max<int64_t>(nr * D, 1));
+  FEMO_HIP_CHECK(hipMemcpyAsync(hx.data(), m->d_x, nr * D * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  FEMO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  FemoPcPlan P;
+  FEMO_TRY(femo_pc_make_plan(D, nr, hx.data(), m->bbox_lo, m->bbox_hi, m->n_vert_global > 0 ? m->n_vert_global : m->n_vert,
+                             femo_pc_spacing(), P));
   femo_pc* pc = new femo_pc();
-  pc->dim = m->tdim;
-  double ext_max = 0.0, vol = 1.0;
-  for (int k = 0; k < pc->dim; ++k) {
-    pc->lo[k] = m->bbox_lo[k]; pc->hi[k] = m->bbox_hi[k];
-    const double e = pc->hi[k] - pc->lo[k];
-    FEMO_REQUIRE(e > 0.0, "degenerate bounding box along axis %d", k);
-    ext_max = std::max(ext_max, e);
-    vol *= e;
-  }
-  // mesh size estimate and the finest lattice: spacing ~ 2 h, bins = m0 * 2^(levels-1) with m0 in {2, 3}
-  const double n_glob = (double)(m->n_vert_global > 0 ? m->n_vert_global : m->n_vert);
-  const double h = std::pow(vol / n_glob, 1.0 / pc->dim);
-  // FEMO_BPX_SPACING: finest lattice spacing in units of the mesh size (tuning knob, default 2)
-  double spacing = 2.0;
-  if (const char* e = getenv("FEMO_BPX_SPACING")) { const double v = atof(e); if (v >= 1.0 && v <= 8.0) spacing = v; }
-  const double target = std::max(2.0, ext_max / (spacing * h));
-  int best_m0 = 2, best_lv = 1;
-  double best = 1e300;
-  for (int m0 = 2; m0 <= 3; ++m0)
-    for (int lv = 1; lv <= 12; ++lv) {
-      const double nb = m0 * std::ldexp(1.0, lv - 1);
-      const double score = std::fabs(std::log(nb / target));
-      if (score < best) { best = score; best_m0 = m0; best_lv = lv; }
-    }
-  pc->n_levels = best_lv;
-  pc->L.resize(best_lv);
-  for (int l = 0; l < best_lv; ++l) {
+  pc->dim = D;
+  pc->n_levels = P.n_levels;
+  pc->L.resize(P.n_levels);
+  int64_t total = 0;
+  for (int k = 0; k < 3; ++k) { pc->lo[k] = P.lo[k]; pc->hi[k] = P.hi[k]; }
+  for (int l = 0; l < P.n_levels; ++l) {
     LatticeLevel& L = pc->L[l];
-    const int nb_long = best_m0 << l;
-    L.H = ext_max / nb_long;
-    L.nodes = 1;
-    for (int k = 0; k < 3; ++k) {
-      if (k < pc->dim) {
-        // same number of halvings on every axis: bins on the coarsest level proportional to the extent
-        const double e = pc->hi[k] - pc->lo[k];
-        const int base = std::max(1, (int)std::lround(best_m0 * e / ext_max));
-        L.n[k] = base << l;
-      } else {
-        L.n[k] = 0;
-      }
-      L.nodes *= (L.n[k] + 1);
-    }
+    for (int k = 0; k < 3; ++k) L.n[k] = P.n[l][k];
+    L.nodes = P.nodes[l];
+    L.H = P.H[l];
+    total += L.nodes;
     FEMO_HIP_CHECK(hipMalloc(&L.e, L.nodes * sizeof(double)));
     FEMO_HIP_CHECK(hipMalloc(&L.coef, L.nodes * sizeof(double)));
   }
+  FEMO_HIP_CHECK(hipMalloc(&pc->g_all, total * sizeof(double)));
+  FEMO_HIP_CHECK(hipMemset(pc->g_all, 0, total * sizeof(double)));
   {
-    int64_t total = 0;
-    for (auto& L : pc->L) total += L.nodes;
-    FEMO_HIP_CHECK(hipMalloc(&pc->g_all, total * sizeof(double)));
-    FEMO_HIP_CHECK(hipMemset(pc->g_all, 0, total * sizeof(double)));
     int64_t off = 0;
     for (auto& L : pc->L) { L.g = pc->g_all + off; off += L.nodes; }
-    pc->n_fused = std::min(pc->dim == 3 ? 2 : 3, pc->n_levels - 1);
   }
-  // owned vertices: packed lattice coordinates, then a counting sort by (brick, bin) on the host
-  // (once per mesh; 0.5 s at C4)
-  {
-    const int D = pc->dim;
-    const int B = D == 3 ? 4 : 8;
-    const LatticeLevel& F = pc->L.back();
-    const int64_t nr = m->n_rows;
-    for (int k = 0; k < D; ++k) FEMO_REQUIRE(F.n[k] < (1 << (32 - PK_BITS)), "preconditioner lattice too fine for packed coordinates");
-    std::vector<double> hx((size_t)std::max<int64_t>(nr * D, 1));
-    FEMO_HIP_CHECK(hipMemcpyAsync(hx.data(), m->d_x, nr * D * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    FEMO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    int nbr[3] = {1, 1, 1};
-    double inv_h[3] = {0, 0, 0};
-    for (int k = 0; k < D; ++k) { nbr[k] = (F.n[k] + B - 1) / B; inv_h[k] = F.n[k] / (pc->hi[k] - pc->lo[k]); }
-    const int64_t n_all = (int64_t)nbr[0] * nbr[1] * nbr[2];
-    FEMO_REQUIRE(n_all < (int64_t(1) << 24), "preconditioner lattice too fine");
-    std::vector<uint32_t> pk((size_t)std::max<int64_t>(nr * D, 1));
-    std::vector<int32_t> key((size_t)std::max<int64_t>(nr, 1));     // brick id * 64 + bin inside the brick
-    std::vector<int64_t> count((size_t)n_all * 64 + 1, 0);
-    for (int64_t v = 0; v < nr; ++v) {
-      int64_t brick = 0, bstride = 1;
-      int local = 0, lstride = 1;
-      for (int k = 0; k < D; ++k) {
-        const double gk = (hx[v * D + k] - pc->lo[k]) * inv_h[k];
-        int b = (int)std::floor(gk);
-        b = b < 0 ? 0 : (b > F.n[k] - 1 ? F.n[k] - 1 : b);
-        double t = gk - b;
-        t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
-        uint32_t tq = (uint32_t)(t * (double)(1u << PK_BITS) + 0.5);
-        if (tq > PK_MASK) tq = PK_MASK;
-        pk[v * D + k] = ((uint32_t)b << PK_BITS) | tq;
-        brick += (int64_t)(b / B) * bstride;
-        bstride *= nbr[k];
-        local += (b % B) * lstride;
-        lstride *= B;
-      }
-      key[v] = (int32_t)(brick * 64 + local);
-      ++count[(size_t)key[v] + 1];
-    }
-    for (size_t i = 1; i < count.size(); ++i) count[i] += count[i - 1];   // count[key] = first sorted position
-    std::vector<int64_t> ptr_c;
-    std::vector<int32_t> base_c;
-    std::vector<uint32_t> binp;
-    ptr_c.push_back(0);
-    for (int64_t id = 0; id < n_all; ++id) {
-      const int64_t first = count[(size_t)id * 64], last = count[(size_t)id * 64 + 64];
-      if (last == first) continue;
-      FEMO_REQUIRE(last - first < (int64_t(1) << 32), "brick too large");
-      ptr_c.push_back(last);
-      base_c.push_back((int32_t)(id % nbr[0]) * B);
-      base_c.push_back((int32_t)((id / nbr[0]) % nbr[1]) * B);
-      base_c.push_back((int32_t)(id / ((int64_t)nbr[0] * nbr[1])) * B);
-      for (int q = 0; q <= 64; ++q) binp.push_back((uint32_t)(count[(size_t)id * 64 + q] - first));
-    }
-    pc->n_bricks = (int64_t)ptr_c.size() - 1;
-    std::vector<int32_t> perm((size_t)std::max<int64_t>(nr, 1));
-    std::vector<uint32_t> pks((size_t)std::max<int64_t>(nr * D, 1));
-    {
-      std::vector<int64_t> fill(count.begin(), count.end() - 1);
-      for (int64_t v = 0; v < nr; ++v) {      // stable: vertices of a bin stay in index order
-        const int64_t at = fill[(size_t)key[v]]++;
-        perm[at] = (int32_t)v;
-        for (int k = 0; k < D; ++k) pks[at * D + k] = pk[v * D + k];
-      }
-    }
-    if (base_c.empty()) base_c.assign(3, 0);
-    if (binp.empty()) binp.assign(65, 0);
-    FEMO_HIP_CHECK(hipMalloc(&pc->d_perm, perm.size() * sizeof(int32_t)));
-    FEMO_HIP_CHECK(hipMalloc(&pc->d_pk, pk.size() * sizeof(uint32_t)));
-    FEMO_HIP_CHECK(hipMalloc(&pc->d_pk_sorted, pks.size() * sizeof(uint32_t)));
-    FEMO_HIP_CHECK(hipMalloc(&pc->d_w_sorted, perm.size() * sizeof(double)));
-    FEMO_HIP_CHECK(hipMalloc(&pc->d_dot_partials, 2048 * sizeof(double)));
-    FEMO_HIP_CHECK(hipMalloc(&pc->d_brick_ptr, ptr_c.size() * sizeof(int64_t)));
-    FEMO_HIP_CHECK(hipMalloc(&pc->d_bin_ptr, binp.size() * sizeof(uint32_t)));
-    FEMO_HIP_CHECK(hipMalloc(&pc->d_brick_base, base_c.size() * sizeof(int32_t)));
-    FEMO_HIP_CHECK(hipMemcpy(pc->d_perm, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    FEMO_HIP_CHECK(hipMemcpy(pc->d_pk, pk.data(), pk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    FEMO_HIP_CHECK(hipMemcpy(pc->d_pk_sorted, pks.data(), pks.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    FEMO_HIP_CHECK(hipMemcpy(pc->d_brick_ptr, ptr_c.data(), ptr_c.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-    FEMO_HIP_CHECK(hipMemcpy(pc->d_bin_ptr, binp.data(), binp.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    FEMO_HIP_CHECK(hipMemcpy(pc->d_brick_base, base_c.data(), base_c.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  }
+  pc->n_fused = std::min(D == 3 ? 2 : 3, pc->n_levels - 1);
+  pc->n_bricks = P.n_bricks;
+  auto upload = [&](auto** dst, const auto& src) -> int {
+    using T = typename std::remove_reference<decltype(src)>::type::value_type;
+    FEMO_HIP_CHECK(hipMalloc(dst, std::max<size_t>(src.size(), 1) * sizeof(T)));
+    if (!src.empty()) FEMO_HIP_CHECK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+  };
+  FEMO_TRY(upload(&pc->d_perm, P.perm));
+  FEMO_TRY(upload(&pc->d_pk, P.pk));
+  FEMO_TRY(upload(&pc->d_pk_sorted, P.pk_sorted));
+  FEMO_TRY(upload(&pc->d_brick_ptr, P.brick_ptr));
+  FEMO_TRY(upload(&pc->d_bin_ptr, P.bin_ptr));
+  FEMO_TRY(upload(&pc->d_brick_base, P.brick_base));
+  FEMO_HIP_CHECK(hipMalloc(&pc->d_w_sorted, std::max<size_t>(P.perm.size(), 1) * sizeof(double)));
+  FEMO_HIP_CHECK(hipMalloc(&pc->d_dot_partials, 2048 * sizeof(double)));
   m->pc = pc;
   return 0;
 }

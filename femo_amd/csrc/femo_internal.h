@@ -119,6 +119,26 @@ struct femo_vec {
 
 struct femo_pc;   // auxiliary-lattice BPX hierarchy (bpx.hip)
 
+// host-side plan of that hierarchy (pc_plan.cpp)
+constexpr int FEMO_PC_MAX_LEVELS = 14;
+constexpr int FEMO_PK_BITS = 20;          // packed lattice coordinate: bin << 20 | 20-bit fraction
+struct FemoPcPlan {
+  int dim = 0, n_levels = 0;
+  int n[FEMO_PC_MAX_LEVELS][3] = {};      // bins per axis, coarsest level first
+  int64_t nodes[FEMO_PC_MAX_LEVELS] = {};
+  double H[FEMO_PC_MAX_LEVELS] = {};
+  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  int64_t n_bricks = 0;
+  std::vector<uint32_t> pk, pk_sorted;    // dim words per owned vertex, vertex order / sorted order
+  std::vector<int32_t> perm;              // sorted position -> vertex
+  std::vector<int64_t> brick_ptr;         // n_bricks + 1
+  std::vector<int32_t> brick_base;        // 3 per brick
+  std::vector<uint32_t> bin_ptr;          // 65 per brick
+};
+int femo_pc_make_plan(int dim, int64_t n_rows, const double* x, const double* lo, const double* hi,
+                      int64_t n_vert_global, double spacing, FemoPcPlan& P);
+double femo_pc_spacing();
+
 struct femo_mesh {
   femo_ctx* ctx = nullptr;
   int tdim = 0;

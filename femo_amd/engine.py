@@ -413,3 +413,27 @@ def topology_host(tdim: int, n_vert: int, n_rows: int, conn: np.ndarray):
     col = np.zeros(d["nnz"], np.int32)
     check(lib.femo_topology_build_host(tdim, n_vert, n_rows, conn.shape[0], _ptr(conn), info, _ptr(rowptr), _ptr(col)))
     return d, rowptr, col
+
+
+def pc_plan_host(x: np.ndarray, lo=None, hi=None, n_vert_global: Optional[int] = None) -> Dict:
+    """Host-only plan of the BPX lattice for the vertices ``x`` (no GPU): levels, bins, packed lattice
+    coordinates and the (brick, bin) sort the restriction kernel walks."""
+    lib = _lib.load()
+    x = _f64(x)
+    n, d = x.shape
+    lo = _f64(x.min(axis=0) if lo is None else lo)
+    hi = _f64(x.max(axis=0) if hi is None else hi)
+    ng = int(n_vert_global or n)
+    nl, nb = C.c_int32(0), C.c_int64(0)
+    check(lib.femo_pc_plan_host(d, n, _ptr(x), _ptr(lo), _ptr(hi), ng, C.byref(nl), None, C.byref(nb),
+                                None, None, None, None, None))
+    bins = np.zeros((nl.value, 3), np.int32)
+    pk = np.zeros((n, d), np.uint32)
+    perm = np.zeros(n, np.int32)
+    brick_ptr = np.zeros(nb.value + 1, np.int64)
+    brick_base = np.zeros((max(nb.value, 1), 3), np.int32)
+    bin_ptr = np.zeros((max(nb.value, 1), 65), np.uint32)
+    check(lib.femo_pc_plan_host(d, n, _ptr(x), _ptr(lo), _ptr(hi), ng, C.byref(nl), _ptr(bins), C.byref(nb),
+                                _ptr(pk), _ptr(perm), _ptr(brick_ptr), _ptr(brick_base), _ptr(bin_ptr)))
+    return dict(levels=nl.value, bins=bins[:, :d], n_bricks=nb.value, pk=pk, perm=perm, brick_ptr=brick_ptr,
+                brick_base=brick_base[:nb.value], bin_ptr=bin_ptr[:nb.value])

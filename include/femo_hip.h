@@ -150,6 +150,15 @@ int femo_topology_build_host(int tdim, int64_t n_vert, int64_t n_rows, int64_t n
                              const int32_t* conn, int64_t info[FEMO_MESH_INFO_COUNT],
                              int64_t* rowptr, int32_t* col);
 
+/* Host-only plan of the BPX preconditioner lattice for `n_rows` owned vertices (no GPU touched; CPU
+ * test-suite): levels and bins per axis (bins[3*l + k], coarsest level first), packed lattice
+ * coordinates pk[n_rows*dim] (bin << 20 | 20-bit fraction), the (brick, bin) sort perm[n_rows] with
+ * brick_ptr[n_bricks+1], brick_base[3*n_bricks], bin_ptr[65*n_bricks].  Array arguments may be NULL
+ * (first call: sizes).                                                                           */
+int femo_pc_plan_host(int dim, int64_t n_rows, const double* x, const double* lo, const double* hi,
+                      int64_t n_vert_global, int32_t* n_levels, int32_t* bins, int64_t* n_bricks,
+                      uint32_t* pk, int32_t* perm, int64_t* brick_ptr, int32_t* brick_base, uint32_t* bin_ptr);
+
 /* ---- Dirichlet set (fea_dolfinx.py:169-176; dolfinx dirichletbc [ext]) ---- */
 int femo_bc_create(femo_mesh* mesh, int64_t n, const int32_t* dofs, const double* vals,
                    femo_bc** out);

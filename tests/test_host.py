@@ -148,3 +148,50 @@ def test_form_catalogue_is_closed():
         forms.derivative(r, 3.0)
     with pytest.raises(NotImplementedError):
         forms.pdeRes(u, None, f, weak_bc=True)
+
+
+@pytest.mark.parametrize("d,n,jit", [(2, 37, 0.2), (2, 64, 0.0), (3, 9, 0.25), (3, 21, 0.1), (3, 2, 0.0)])
+def test_pc_plan_host_matches_the_oracle(d, n, jit):
+    """femo_pc_plan_host (pc_plan.cpp, the host half of the BPX preconditioner) against the NumPy
+    restatement: same lattice hierarchy, same packed coordinates, and a sort whose bricks and bins
+    hold exactly the vertices that belong there."""
+    from femo_amd import engine as E
+    from oracle import bpx_oracle as bo
+    from oracle import femo_oracle as fo
+    m = fo.unit_square_mesh(n, jit) if d == 2 else fo.unit_cube_mesh(n, jit)
+    P = E.pc_plan_host(m.x)
+    lo, hi = m.x.min(axis=0), m.x.max(axis=0)
+    bins, H = bo.choose_lattice(lo, hi, m.n_vert)
+    assert P["levels"] == len(bins) and np.array_equal(P["bins"], np.array(bins))
+    nF = bins[-1]
+    b, t = bo._locate(m.x, lo, hi, nF, quantise=True)
+    assert np.array_equal(P["pk"] >> 20, b.astype(np.uint32))
+    assert np.array_equal((P["pk"] & 0xFFFFF).astype(np.float64) / (1 << 20), t)
+    # the sort: a permutation; every brick / bin range holds exactly the vertices whose bin says so
+    perm = P["perm"]
+    assert np.array_equal(np.sort(perm), np.arange(m.n_vert))
+    B = 4 if d == 3 else 8
+    bs = b[perm]
+    assert P["brick_ptr"][0] == 0 and P["brick_ptr"][-1] == m.n_vert and np.all(np.diff(P["brick_ptr"]) > 0)
+    for k in range(P["n_bricks"]):
+        lo_k, hi_k = P["brick_ptr"][k], P["brick_ptr"][k + 1]
+        base = P["brick_base"][k][:d]
+        inside = bs[lo_k:hi_k] - base
+        assert inside.min() >= 0 and inside.max() < B
+        local = inside[:, 0] + B * inside[:, 1] + (B * B * inside[:, 2] if d == 3 else 0)
+        assert np.all(np.diff(local) >= 0)                       # sorted by bin inside the brick
+        bp = P["bin_ptr"][k].astype(np.int64)
+        assert bp[0] == 0 and bp[64] == hi_k - lo_k
+        assert np.array_equal(np.searchsorted(local, np.arange(65)), bp)
+        # stable: vertices of one bin stay in index order
+        for q in np.unique(local)[:4]:
+            seg = perm[lo_k + bp[q]: lo_k + bp[q + 1]]
+            assert np.all(np.diff(seg) > 0)
+
+
+def test_pc_plan_host_errors():
+    from femo_amd import engine as E
+    from femo_amd._lib import FemoError
+    x = np.array([[0.0, 0.0], [1.0, 0.0], [2.0, 0.0]])           # all on a line: degenerate box in y
+    with pytest.raises(FemoError, match="degenerate bounding box"):
+        E.pc_plan_host(x)
