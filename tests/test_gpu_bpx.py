@@ -246,3 +246,51 @@ def test_bpx_without_any_pinned_vertex(ctx):
     M = bo.BPX(m.x, Js.diagonal(), None)
     z = J.pc_apply(E.Vec(ctx, m.n_vert).set(b), E.Vec(ctx, m.n_vert)).get()
     assert np.abs(z - M.apply(b)).max() < 1e-12 * np.abs(M.apply(b)).max()
+
+
+def _carved_mesh(d, n, jit):
+    """A non-convex domain: the unit square / cube with one quadrant / octant removed, vertices
+    renumbered compactly; returns the mesh and its boundary vertices (from the facet count)."""
+    m = fo.unit_square_mesh(n, jit) if d == 2 else fo.unit_cube_mesh(n, jit)
+    xc = m.x[m.conn].mean(axis=1)
+    keep = ~np.all(xc > 0.5, axis=1)
+    conn = m.conn[keep]
+    used = np.unique(conn)
+    new = -np.ones(m.n_vert, np.int64)
+    new[used] = np.arange(len(used))
+    cm = fo.OMesh(d, m.x[used], new[conn].astype(np.int32))
+    bm = fo.boundary_facets(cm)
+    bv = set()
+    for k in range(d + 1):
+        cells = np.nonzero(bm & (1 << k))[0]
+        bv.update(np.delete(cm.conn[cells], k, axis=1).ravel().tolist())
+    return cm, np.array(sorted(bv), np.int32)
+
+
+@pytest.mark.parametrize("d,n", [(2, 40), (3, 14)])
+def test_bpx_on_a_non_convex_domain(ctx, d, n):
+    """L-shaped domain: a quarter of the lattice lies outside the mesh (nodes without vertex mass
+    are dropped) and the re-entrant boundary cuts through lattice bins.  Operator = oracle operator,
+    solution = direct solve, far fewer iterations than Jacobi."""
+    from femo_amd import engine as E
+    from oracle import bpx_oracle as bo
+    cm, bd = _carved_mesh(d, n, 0.15)
+    dm = E.DeviceMesh(ctx, cm.x, cm.conn)
+    bc = E.DirichletSet(dm, bd, 0.0)
+    rng = np.random.default_rng(8)
+    A, b = E.Mat(dm), E.Vec(ctx, cm.n_vert)
+    E.assemble_system(dm, 0, None, E.Vec(ctx, cm.n_vert).fill(0.0), E.Vec(ctx, cm.n_cell).set(1.0 + rng.random(cm.n_cell)),
+                      bc, None, A, b)
+    As = A.to_scipy()
+    x_ref = spla.spsolve(As.tocsc(), b.get())
+    xj, xb = E.Vec(ctx, cm.n_vert), E.Vec(ctx, cm.n_vert)
+    ij = A.solve_cg(b, xj, rtol=1e-14, pc="jacobi")
+    ib = A.solve_cg(b, xb, rtol=1e-14, pc="bpx")
+    assert ib.converged == 1 and _rel(xb.get(), x_ref) < 1e-10
+    assert ib.iterations < ij.iterations and ib.iterations <= 70
+    pinned = np.zeros(cm.n_vert, bool)
+    pinned[bd] = True
+    M = bo.BPX(cm.x, As.diagonal(), pinned)
+    r = rng.standard_normal(cm.n_vert)
+    z = A.pc_apply(E.Vec(ctx, cm.n_vert).set(r), E.Vec(ctx, cm.n_vert)).get()
+    assert np.abs(z - M.apply(r)).max() < 1e-12 * np.abs(M.apply(r)).max()
