@@ -391,11 +391,13 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
 #pragma unroll
     for (int k = 0; k < D; ++k) xo[k] = x[r0 * D + k];
   }
-  if constexpr (PDE == FEMO_PDE_POISSON) {
+  if constexpr (PDE != FEMO_PDE_EB_BEAM) {
     // Software-pipelined walk.  A visit is a chain of dependent loads (incidence words -> the
-    // row's columns -> coordinates); taken one visit at a time the wave sits in s_waitcnt five
-    // times per cell.  Three stages in flight: incidence words of visit s+2, column lookup and
-    // coordinate / f gathers of visit s+1, arithmetic of visit s.  Same order of accumulation.
+    // row's columns -> coordinates, state values); taken one visit at a time the wave sits in
+    // s_waitcnt five times per cell.  Three stages in flight: incidence words of visit s+2, column
+    // lookup and the gathers of visit s+1, arithmetic of visit s.  Same order of accumulation.
+    constexpr bool NEED_U = PDE == FEMO_PDE_NL_POISSON;
+    constexpr bool NEED_F = PDE != FEMO_PDE_MASS;
     auto fetch_ids = [&](int s, int32_t& ca, uint32_t& sl) {
       ca = -1; sl = 0u;
       if (s < nvis) {
@@ -404,42 +406,70 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
         sl = visit_slots[vi];
       }
     };
-    auto gather = [&](int32_t ca, uint32_t sl, double (&o)[D][D], double& fc) {
+    auto gather = [&](int32_t ca, uint32_t sl, int32_t (&v)[D + 1], double (&o)[D][D], double& fc, double (&ue)[D + 1]) {
       if (ca >= 0) {
-        int32_t v[D + 1];
         row_cell_vertices<D>(row, lane, ca & 3, sl, regular, dl, cols, mb, v);
         load_other_vertices<D>(x, v, ca & 3, o);
-        if (want_rhs) fc = f[ca >> 2];
+        if constexpr (NEED_F) {
+          if (want_rhs) fc = f[ca >> 2];
+        }
+        if constexpr (NEED_U) {
+#pragma unroll
+          for (int b = 0; b <= D; ++b) ue[b] = u[v[b]];
+        }
       }
     };
-    int32_t ca0, ca1, ca2;
+    int32_t ca0, ca1, ca2, v0[D + 1], v1[D + 1];
     uint32_t sl0, sl1, sl2;
-    double o0[D][D], o1[D][D], f0 = 0.0, f1 = 0.0;
+    double o0[D][D], o1[D][D], f0 = 0.0, f1 = 0.0, ue0[D + 1], ue1[D + 1];
 #pragma unroll
     for (int j = 0; j < D; ++j)
 #pragma unroll
       for (int k = 0; k < D; ++k) { o0[j][k] = 0.0; o1[j][k] = 0.0; }
+#pragma unroll
+    for (int b = 0; b <= D; ++b) { v0[b] = 0; v1[b] = 0; ue0[b] = 0.0; ue1[b] = 0.0; }
     fetch_ids(0, ca0, sl0);
     fetch_ids(1, ca1, sl1);
-    gather(ca0, sl0, o0, f0);
+    gather(ca0, sl0, v0, o0, f0, ue0);
     for (int s = 0; s < nvis; ++s) {
       fetch_ids(s + 2, ca2, sl2);
-      gather(ca1, sl1, o1, f1);
+      gather(ca1, sl1, v1, o1, f1, ue1);
       if (ca0 >= 0) {
         const int a = ca0 & 3;
         CellGeom<D> G;
-        double ga[D];
+        double ga[D], krow[D + 1];
         cell_geom_others<D>(o0, a, xo, G);
         select_row<D>(G, a, ga);
-        if (want_rhs) racc -= f0 * G.vol * (1.0 / (D + 1));
+        if constexpr (NEED_F) {
+          if (want_rhs) racc -= f0 * G.vol * (1.0 / (D + 1));
+        }
 #pragma unroll
         for (int b = 0; b <= D; ++b) {
-          const double kab = __dmul_rn(G.vol, dotD<D>(ga, G.g[b]));
+          if constexpr (PDE == FEMO_PDE_MASS) {
+            // P1 mass matrix |T| (1 + delta_ab) / ((d+1)(d+2))  (utils_dolfinx.py:569 inner(Pv, w) dx)
+            krow[b] = G.vol * (1.0 / ((D + 1) * (D + 2))) * ((a == b) ? 2.0 : 1.0);
+          } else {
+            krow[b] = __dmul_rn(G.vol, dotD<D>(ga, G.g[b]));
+          }
+          if constexpr (NEED_U) {
+            if (want_rhs) racc += krow[b] * ue0[b];          // linear part of the residual: K u
+          }
+        }
+        if constexpr (PDE == FEMO_PDE_NL_POISSON) {
+          double w[D + 1];
+#pragma unroll
+          for (int b = 0; b <= D; ++b) w[b] = (a == b) ? 1.0 : 0.0;
+          const unsigned bits = bfacets ? bfacets[ca0 >> 2] : 0u;
+          if (want_rhs) nl_row<D, true, true>(G, a, w, ue0, x, v0, aux, bits, beta, sgn, krow, &racc);
+          else nl_row<D, true, false>(G, a, w, ue0, x, v0, aux, bits, beta, sgn, krow, &racc);
+        }
+#pragma unroll
+        for (int b = 0; b <= D; ++b) {
           if (b == a) {
-            dsum += kab;
+            dsum += krow[b];
           } else {
             const int pos = (sl0 >> (8 * b)) & 0xFF;
-            strip[pos * FEMO_BLOCK + tid] = __dadd_rn(strip[pos * FEMO_BLOCK + tid], kab);
+            strip[pos * FEMO_BLOCK + tid] = __dadd_rn(strip[pos * FEMO_BLOCK + tid], krow[b]);
           }
         }
       }
@@ -448,6 +478,8 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
       for (int j = 0; j < D; ++j)
 #pragma unroll
         for (int k = 0; k < D; ++k) o0[j][k] = o1[j][k];
+#pragma unroll
+      for (int b = 0; b <= D; ++b) { v0[b] = v1[b]; ue0[b] = ue1[b]; }
       ca1 = ca2; sl1 = sl2;
     }
   } else
