@@ -51,7 +51,9 @@ class DistMesh(Mesh):
 def partition_mesh(mesh: Mesh, rank: int, nranks: int) -> DistMesh:
     part = rcb_partition(mesh.x, nranks)
     local = build_local_mesh(mesh.x, mesh.conn, part, rank, nranks)
-    return DistMesh(local, mesh.n_vert, mesh.n_cell, bbox=(mesh.x.min(axis=0), mesh.x.max(axis=0)))
+    dm = DistMesh(local, mesh.n_vert, mesh.n_cell, bbox=(mesh.x.min(axis=0), mesh.x.max(axis=0)))
+    dm._occupancy = mesh.lattice_occupancy()      # of the WHOLE mesh: every rank must pick the same preconditioner
+    return dm
 
 
 def init_process_group(rank: int, world: int):

@@ -435,5 +435,8 @@ def pc_plan_host(x: np.ndarray, lo=None, hi=None, n_vert_global: Optional[int] =
     bin_ptr = np.zeros((max(nb.value, 1), 65), np.uint32)
     check(lib.femo_pc_plan_host(d, n, _ptr(x), _ptr(lo), _ptr(hi), ng, C.byref(nl), _ptr(bins), C.byref(nb),
                                 _ptr(pk), _ptr(perm), _ptr(brick_ptr), _ptr(brick_base), _ptr(bin_ptr)))
+    counts = np.diff(bin_ptr[:nb.value].astype(np.int64), axis=1).ravel()
+    filled = counts[counts > 0]
+    occupancy = float(filled.max() / filled.mean()) if filled.size else 1.0
     return dict(levels=nl.value, bins=bins[:, :d], n_bricks=nb.value, pk=pk, perm=perm, brick_ptr=brick_ptr,
-                brick_base=brick_base[:nb.value], bin_ptr=bin_ptr[:nb.value])
+                brick_base=brick_base[:nb.value], bin_ptr=bin_ptr[:nb.value], occupancy=occupancy)

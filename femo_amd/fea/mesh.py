@@ -45,6 +45,17 @@ class Mesh:
     def centroids(self) -> np.ndarray:
         return self.x[self.conn].mean(axis=1)
 
+    def lattice_occupancy(self) -> float:
+        """Largest over mean number of vertices in the non-empty bins of the finest BPX lattice: a
+        measure of mesh grading.  The lattice hierarchy has no levels between its finest spacing
+        (~2 average mesh sizes) and the local mesh size, so on strongly graded meshes BPX loses to
+        Jacobi (measured: ratio 4-12 -> 2-6x fewer iterations than Jacobi, ratio 35-40 -> 1.3-1.7x
+        more); the solver layer uses it only while this ratio stays below BPX_MAX_OCCUPANCY."""
+        if getattr(self, "_occupancy", None) is None:
+            from ..engine import pc_plan_host
+            self._occupancy = pc_plan_host(self.x)["occupancy"]
+        return self._occupancy
+
     def boundary_facet_mask(self) -> np.ndarray:
         """uint8 per cell: bit k set <=> the facet opposite local vertex k belongs to one cell only,
         i.e. it is an exterior facet (the `ds` measure of UFL [ext])."""

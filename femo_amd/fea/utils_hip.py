@@ -52,6 +52,7 @@ def set_context(ctx: Optional[Context]) -> None:
 # comes from a Poisson-type form, Jacobi elsewhere (mass matrix, beam); 'jacobi' = diagonal scaling only.
 KSP_OPTIONS = dict(rtol=1e-14, atol=0.0, max_it=100000, check_every=32, pc='bpx')
 _BPX_KINDS = (_lib.PDE_POISSON, _lib.PDE_NL_POISSON)
+BPX_MAX_OCCUPANCY = 20.0      # Mesh.lattice_occupancy() above this: graded mesh, Jacobi does better
 LAST_KSP_INFO: List[dict] = []   # appended by every linear solve (iteration counts for reports)
 
 
@@ -468,7 +469,8 @@ class KSP:
                   check_every=o["check_every"])
         if self.A.symmetric:
             pc = o.get("pc", "jacobi")
-            if pc == "bpx" and self.A.pde_kind not in _BPX_KINDS:
+            if pc == "bpx" and (self.A.pde_kind not in _BPX_KINDS
+                                or self.A.mesh.lattice_occupancy() > BPX_MAX_OCCUPANCY):
                 pc = "jacobi"
             self.info = self.A.mat.solve_cg(_as_vec(b), _as_vec(x), pc=pc, **kw)
         else:

@@ -294,3 +294,36 @@ def test_bpx_on_a_non_convex_domain(ctx, d, n):
     r = rng.standard_normal(cm.n_vert)
     z = A.pc_apply(E.Vec(ctx, cm.n_vert).set(r), E.Vec(ctx, cm.n_vert)).get()
     assert np.abs(z - M.apply(r)).max() < 1e-12 * np.abs(M.apply(r)).max()
+
+
+def test_solver_layer_keeps_jacobi_on_strongly_graded_meshes(ctx, monkeypatch):
+    """BPX has no levels between its finest lattice and the local mesh size: on a mesh graded like
+    x -> x^2.5 it needs more iterations than Jacobi, so KSP falls back (Mesh.lattice_occupancy)."""
+    from femo_amd import engine as E
+    from femo_amd.fea import utils_hip
+    from femo_amd.fea.mesh import Mesh, createUnitCubeMesh
+    utils_hip.set_context(ctx)
+    base = createUnitCubeMesh(14)
+    seen = []
+    real = E.Mat.solve_cg
+
+    def spy(self, b, x, **kw):
+        seen.append(kw.get("pc"))
+        return real(self, b, x, **kw)
+
+    monkeypatch.setattr(E.Mat, "solve_cg", spy)
+    for power, expect in ((1.0, "bpx"), (2.5, "jacobi")):
+        mesh = Mesh(base.x ** power, base.conn)
+        om = fo.OMesh(3, mesh.x, mesh.conn)
+        dm = mesh.device(ctx)
+        bd = fo.boundary_vertices_box(mesh.x)
+        A = utils_hip.SparseMatrix(mesh, symmetric=True)
+        A.pde_kind = 0
+        b = E.Vec(ctx, mesh.n_vert)
+        E.assemble_system(dm, 0, None, E.Vec(ctx, mesh.n_vert).fill(0.0), E.Vec(ctx, mesh.n_cell).fill(1.0),
+                          E.DirichletSet(dm, bd, 0.0), None, A.mat, b)
+        x = E.Vec(ctx, mesh.n_vert)
+        utils_hip.KSP(A).solve(b, x)
+        assert seen[-1] == expect
+        x_ref = spla.spsolve(fo.eliminate_bc(fo.stiffness(om), bd).tocsc(), b.get())
+        assert _rel(x.get(), x_ref) < 1e-10

@@ -195,3 +195,16 @@ def test_pc_plan_host_errors():
     x = np.array([[0.0, 0.0], [1.0, 0.0], [2.0, 0.0]])           # all on a line: degenerate box in y
     with pytest.raises(FemoError, match="degenerate bounding box"):
         E.pc_plan_host(x)
+
+
+def test_lattice_occupancy_flags_graded_meshes():
+    """Mesh.lattice_occupancy(): ~1-3 on (jittered) uniform meshes, > BPX_MAX_OCCUPANCY on strongly
+    graded ones, for which the solver layer keeps Jacobi (BPX has no levels below its finest lattice)."""
+    from femo_amd.fea import utils_hip
+    from femo_amd.fea.mesh import Mesh, createUnitCubeMesh, createUnitSquareMesh
+    for mesh in (createUnitSquareMesh(48), createUnitSquareMesh(48, 0.25), createUnitCubeMesh(12), createUnitCubeMesh(12, 0.25)):
+        assert 1.0 <= mesh.lattice_occupancy() <= 4.0
+    base = createUnitCubeMesh(16)
+    mild = Mesh(base.x ** 1.2, base.conn)
+    hard = Mesh(base.x ** 2.0, base.conn)
+    assert mild.lattice_occupancy() < utils_hip.BPX_MAX_OCCUPANCY < hard.lattice_occupancy()
