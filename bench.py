@@ -244,6 +244,9 @@ def _run(args):
     spmv_n = sum(i["spmv_samples"] for i in solves)
     its_per_step = [i["iterations"] for i in infos[:len(infos) // K]] if K else []
     cg_ms = sum(i["solve_ms"] for i in infos) / K
+    per = len(infos) // K if K else 0
+    adj_ms = sum(i["solve_ms"] for k, i in enumerate(infos) if per and k % per == per - 1) / max(K, 1)
+    fwd_ms = cg_ms - adj_ms
     spmv_in_cg_ms = spmv_ms / spmv_n if spmv_n else float("nan")   # single launches incl. event overhead
     spmv_avg_ms = spmv_loop_ms
     B_A = spmv_algorithmic_bytes(nnz, n_dof)
@@ -270,6 +273,10 @@ def _run(args):
             "sell_slices": dm.info["n_slices"], "regular_slices": dm.info["regular_slices"],
             "cg_iterations_per_step": its_per_step, "cg_ms_per_step": cg_ms,
             "non_cg_ms_per_step": ms_per_step - cg_ms, "setup_s": setup_s,
+            # SURVEY.md section 8(d) split: Newton's linear solves / the transposed (adjoint) solve / the rest
+            # (assembly passes, functional and its partials, dR/df^T lambda, host)
+            "split_ms_per_step": {"forward_solves": fwd_ms, "adjoint_solve": adj_ms,
+                                  "assembly_outputs_host": ms_per_step - cg_ms},
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
