@@ -231,7 +231,6 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
     double* coarse = acc2;
     double* gl = g;
     int nfine = B, ln[3] = {lat.n[0], lat.n[1], lat.n[2]};
-    int64_t level_nodes = (int64_t)(ln[0] + 1) * (ln[1] + 1) * (ln[2] + 1);
     for (int lev = 1; lev <= n_fused; ++lev) {
       const int nc = nfine >> 1, f1 = nfine + 1, c1 = nc + 1;
       const int ncl = D == 3 ? c1 * c1 * c1 : c1 * c1;
@@ -262,9 +261,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
       }
       double* t = fine; fine = coarse; coarse = t;
       nfine = nc; ln[0] = cn[0]; ln[1] = cn[1]; ln[2] = cn[2];
-      level_nodes = coarse_nodes;
     }
-    (void)level_nodes;
     __syncthreads();
   }
 }
