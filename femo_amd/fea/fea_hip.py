@@ -21,23 +21,9 @@ from .forms import (ALPHA, BeamResidual, DerivativeForm, FieldExpression, Form, 
                     L2TrackingFunctional, LinearFunctional, NonlinearPoissonResidual, PoissonResidual, PowerExpr,
                     TestFunction, derivative, interiorResidual, outputForm, pdeRes)
 from .function import Function, FunctionSpace
+from .io import XDMFRecorder
 from .mesh import (BeamMesh, Mesh, createIntervalMesh, createUnitCubeMesh, createUnitSquareMesh,
                    locate_dofs_geometrical)
-
-
-class SnapshotRecorder:
-    """Stands in for the XDMF time-series writers (fea_dolfinx.py:228-234; out of scope, SURVEY.md
-    section 8(f) rank 4): ``write_function`` stores raw ``.npy`` snapshots keyed by the iteration."""
-
-    def __init__(self, stem: str):
-        self.stem = stem
-        os.makedirs(os.path.dirname(stem) or ".", exist_ok=True)
-
-    def write_mesh(self, mesh) -> None:
-        np.savez(self.stem + "_mesh.npz", x=mesh.x, conn=mesh.conn)
-
-    def write_function(self, function, t=0) -> None:
-        np.save(f"{self.stem}_{int(t):05d}.npy", function.vector.getArray())
 
 
 class FEA(object):
@@ -160,6 +146,6 @@ class FEA(object):
         """fea_dolfinx.py:228-234"""
         if not (record or self.record):
             return None
-        recorder = SnapshotRecorder(os.path.join(self.recorder_path, "record_" + name))
+        recorder = XDMFRecorder(os.path.join(self.recorder_path, "record_" + name + ".xdmf"))
         recorder.write_mesh(self.mesh)
         return recorder
