@@ -177,3 +177,44 @@ def test_registry_errors(ctx):
         fea.add_input('f', f)                      # fea_dolfinx.py:101-102
     utils_hip.update(f, np.array([3.0]))           # length-1 broadcast, utils_dolfinx.py:308-309
     assert np.all(utils_hip.getFuncArray(f) == 3.0)
+
+
+def test_recorders_write_xdmf_series(ctx, tmp_path):
+    """fea.record = True (fea_dolfinx.py:228-234, state_model.py:98-104): every solve appends the
+    state to records/record_u.xdmf; the last binary block is the state the simulator returns."""
+    import xml.etree.ElementTree as ET
+    from femo_amd.csdl_opt.fea_model import FEAModel
+    from femo_amd.csdl_opt.simulator import Simulator
+    from femo_amd.fea import utils_hip
+    from femo_amd.fea.mesh import createUnitSquareMesh
+    utils_hip.set_context(ctx)
+    mesh = createUnitSquareMesh(12)
+    from femo_amd.fea.fea_hip import FEA, Function, FunctionSpace, TestFunction, locate_dofs_geometrical, outputForm, pdeRes
+    fea = FEA(mesh)
+    fea.REPORT = False
+    fea.record, fea.recorder_path = True, str(tmp_path / "records")
+    Vf, Vu = FunctionSpace(mesh, ('DG', 0)), FunctionSpace(mesh, ('CG', 1))
+    f_fn, u_fn, ubc = Function(Vf), Function(Vu), Function(Vu)
+    ubc.vector.set(0.0)
+    locs = [locate_dofs_geometrical((Vu, Vu), lambda x: np.isclose(x[0], 0.0) | np.isclose(x[0], 1.0)
+                                    | np.isclose(x[1], 0.0) | np.isclose(x[1], 1.0))]
+    fea.add_strong_bc(ubc, locs, Vu)
+    fea.add_input('f', f_fn)
+    fea.add_state(name='u', function=u_fn, residual_form=pdeRes(u_fn, TestFunction(Vu), f_fn), arguments=['f'])
+    u_ex = Function(Vu)
+    u_ex.vector.set(0.0)
+    fea.add_output(name='l2_functional', type='scalar', form=outputForm(u_fn, f_fn, u_ex, 1e-6), arguments=['f', 'u'])
+    model = FEAModel(fea=[fea])
+    model.create_input('f', shape=fea.inputs_dict['f']['shape'], val=1.0)
+    sim = Simulator(model, device=False)
+    sim.run()
+    sim['f'] = 2.0 * np.ones(mesh.n_cell)
+    sim.run()
+    path = tmp_path / "records" / "record_u.xdmf"
+    root = ET.parse(path).getroot()
+    grids = root.findall("Domain/Grid/Grid")
+    assert len(grids) == 2 and [g.find("Attribute").get("Center") for g in grids] == ["Node", "Node"]
+    last = np.fromfile(tmp_path / "records" / grids[-1].find("Attribute/DataItem").text, dtype="<f8")
+    assert np.array_equal(last, np.asarray(sim['u']))
+    first = np.fromfile(tmp_path / "records" / grids[0].find("Attribute/DataItem").text, dtype="<f8")
+    assert np.allclose(2.0 * first, last, rtol=1e-10, atol=1e-14)        # linear problem: u scales with f
