@@ -22,8 +22,8 @@ from .forms import (ALPHA, BeamResidual, DerivativeForm, FieldExpression, Form, 
                     TestFunction, derivative, interiorResidual, outputForm, pdeRes)
 from .function import Function, FunctionSpace
 from .io import XDMFRecorder
-from .mesh import (BeamMesh, Mesh, createIntervalMesh, createUnitCubeMesh, createUnitSquareMesh,
-                   locate_dofs_geometrical)
+from .mesh import (BeamMesh, Mesh, createIntervalMesh, createRectangleMesh, createUnitCubeMesh, createUnitSquareMesh,
+                   findNodeIndices, locate_dofs_geometrical, meshSize)
 
 
 class FEA(object):

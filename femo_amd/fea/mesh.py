@@ -106,6 +106,43 @@ def createUnitSquareMesh(n: int, jitter: float = 0.0, seed: int = 20240807) -> M
     return Mesh(_apply_jitter(x, n, jitter, seed), conn, n)
 
 
+def createRectangleMesh(pt1, pt2, nx: int, ny: int) -> Mesh:
+    """utils_dolfinx.py:148-153 creates quadrilaterals; the HIP engine is P1-simplex only, so every
+    cell of the nx x ny grid over [pt1, pt2] is split along its right diagonal like create_unit_square."""
+    (x0, y0), (x1, y1) = pt1, pt2
+    gx = x0 + (x1 - x0) * np.arange(nx + 1) / nx
+    gy = y0 + (y1 - y0) * np.arange(ny + 1) / ny
+    gx[-1], gy[-1] = x1, y1
+    x = np.empty(((nx + 1) * (ny + 1), 2))
+    x[:, 0] = np.tile(gx, ny + 1)
+    x[:, 1] = np.repeat(gy, nx + 1)
+    jj, ii = np.divmod(np.arange(nx * ny), nx)
+    v0 = jj * (nx + 1) + ii
+    conn = np.empty((2 * nx * ny, 3), dtype=np.int32)
+    conn[0::2, 0] = v0; conn[0::2, 1] = v0 + 1; conn[0::2, 2] = v0 + nx + 2
+    conn[1::2, 0] = v0; conn[1::2, 1] = v0 + nx + 2; conn[1::2, 2] = v0 + nx + 1
+    return Mesh(x, conn)
+
+
+def meshSize(mesh: Mesh) -> np.ndarray:
+    """utils_dolfinx.py:530-534 (dolfinx.cpp.mesh.h [ext]): per cell, the largest distance between two
+    of its vertices."""
+    p = mesh.x[mesh.conn]                                   # (n_cell, d+1, d)
+    h = np.zeros(mesh.n_cell)
+    d1 = mesh.conn.shape[1]
+    for a in range(d1):
+        for b in range(a + 1, d1):
+            np.maximum(h, np.linalg.norm(p[:, a] - p[:, b], axis=1), out=h)
+    return h
+
+
+def findNodeIndices(node_coordinates, coordinates) -> np.ndarray:
+    """utils_dolfinx.py:587-595: indices of the vertices of ``coordinates`` closest to the given points."""
+    from scipy.spatial import KDTree
+    _, idx = KDTree(np.asarray(coordinates)).query(np.asarray(node_coordinates))
+    return idx
+
+
 _KUHN = ((0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0))
 
 

@@ -19,7 +19,8 @@ from ..engine import Context, DeviceArray, Vec
 from .forms import (BeamResidual, DerivativeForm, FieldExpression, Form, FunctionExpr, GradientMagnitude,
                     L2TrackingFunctional, LinearFunctional, NonlinearPoissonResidual, PoissonResidual, PowerExpr, derivative)
 from .function import Function, FunctionSpace, _VectorView
-from .mesh import (BeamMesh, Mesh, createIntervalMesh, createUnitCubeMesh, createUnitSquareMesh,
+from .mesh import (BeamMesh, Mesh, createIntervalMesh, createRectangleMesh, createUnitCubeMesh, createUnitSquareMesh,
+                   findNodeIndices, meshSize,
                    locate_dofs_geometrical)
 
 DOLFIN_EPS = 3E-16
@@ -399,6 +400,13 @@ def assembleSystem(J: Form, F: Form, bcs: Sequence[DirichletBC] = (), rhs: bool 
         b = b - Kg.get()
         b[ds.dofs] = ds.vals
     return A, b
+
+
+def applyBC(res: Form, u: Function, bcs: Sequence[DirichletBC]) -> np.ndarray:
+    """utils_dolfinx.py:266-273: the residual vector with Dirichlet lifting, b = F - K[:,bc] g, b[bc] = g
+    (apply_lifting + set_bc [ext]), K = derivative(res, u)."""
+    _, b = assembleSystem(derivative(res, u), res, bcs)
+    return b
 
 
 def assemble(f: Form, dim: int = 0, bcs: Sequence[DirichletBC] = (), device: bool = False):

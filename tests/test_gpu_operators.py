@@ -218,3 +218,28 @@ def test_recorders_write_xdmf_series(ctx, tmp_path):
     assert np.array_equal(last, np.asarray(sim['u']))
     first = np.fromfile(tmp_path / "records" / grids[0].find("Attribute/DataItem").text, dtype="<f8")
     assert np.allclose(2.0 * first, last, rtol=1e-10, atol=1e-14)        # linear problem: u scales with f
+
+
+def test_applyBC_matches_oracle(ctx):
+    """applyBC (utils_dolfinx.py:266-273): b = F - K[:,bc] g, b[bc] = g."""
+    from femo_amd.fea import utils_hip
+    from femo_amd.fea.fea_hip import (Function, FunctionSpace, TestFunction, applyBC, dirichletbc, pdeRes,
+                                      setFuncArray)
+    from femo_amd.fea.mesh import createUnitSquareMesh
+    utils_hip.set_context(ctx)
+    mesh = createUnitSquareMesh(10, 0.2)
+    om = fo.unit_square_mesh(10, 0.2)
+    Vf, Vu = FunctionSpace(mesh, ('DG', 0)), FunctionSpace(mesh, ('CG', 1))
+    f_fn, u_fn, g_fn = Function(Vf), Function(Vu), Function(Vu)
+    rng = np.random.default_rng(2)
+    u, f = rng.standard_normal(mesh.n_vert), rng.standard_normal(mesh.n_cell)
+    bd = fo.boundary_vertices_box(om.x)
+    g = np.zeros(mesh.n_vert)
+    g[bd] = rng.standard_normal(len(bd))
+    setFuncArray(u_fn, u); setFuncArray(f_fn, f); setFuncArray(g_fn, g)
+    res = pdeRes(u_fn, TestFunction(Vu), f_fn)
+    b = applyBC(res, u_fn, [dirichletbc(g_fn, bd)])
+    K = fo.stiffness(om).tocsr()
+    ref = fo.residual(om, u, f) - K[:, bd] @ g[bd]
+    ref[bd] = g[bd]
+    assert np.abs(b - ref).max() < 1e-12 * np.abs(ref).max()

@@ -250,3 +250,19 @@ def test_xdmf_recorder_files(tmp_path):
     assert np.array_equal(geo, mesh.x) and np.array_equal(topo, mesh.conn)
     with pytest.raises(ValueError):
         rec.write_function(Fn("bad", np.zeros(5)), 2)
+
+
+def test_small_mesh_utilities():
+    """createRectangleMesh / meshSize / findNodeIndices (utils_dolfinx.py:148-153, 530-534, 587-595)."""
+    from femo_amd.fea.mesh import createRectangleMesh, createUnitSquareMesh, findNodeIndices, meshSize
+    m = createRectangleMesh((1.0, -1.0), (3.0, 0.0), 4, 2)
+    assert m.n_vert == 15 and m.n_cell == 16
+    assert np.allclose(m.x.min(axis=0), [1.0, -1.0]) and np.allclose(m.x.max(axis=0), [3.0, 0.0])
+    om = fo.OMesh(2, m.x, m.conn)
+    vol, _ = fo.cell_geometry(om)
+    assert np.allclose(vol, 0.125) and abs(vol.sum() - 2.0) < 1e-14          # positively oriented, exact cover
+    h = meshSize(m)
+    assert h.shape == (16,) and np.allclose(h, np.hypot(0.5, 0.5))
+    u = createUnitSquareMesh(8, 0.2)
+    pts = u.x[[3, 40, 77]] + 1e-4
+    assert list(findNodeIndices(pts, u.x)) == [3, 40, 77]
