@@ -55,8 +55,13 @@ class _VectorView:
         return self._fn.vec.get()
 
     def set(self, value) -> None:
+        """PETSc ``Vec.set(alpha)`` [ext]: one scalar for every entry (a length-1 array is accepted, as
+        ``update`` passes one, utils_dolfinx.py:308-309); arrays go through ``setFuncArray`` / ``v[:] =``."""
+        a = np.asarray(value)
+        if a.size != 1:
+            raise ValueError(f"Vec.set takes a scalar, got an array of size {a.size}; use setFuncArray")
         self._fn.version += 1
-        self._fn.vec.fill(float(np.asarray(value).ravel()[0]))
+        self._fn.vec.fill(float(a.ravel()[0]))
 
     def __setitem__(self, key, value) -> None:
         if key != slice(None):

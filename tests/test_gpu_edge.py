@@ -101,3 +101,22 @@ def test_external_stream(ctx):
     assert np.all(v.get() == 4.0)
     del v
     c2.close()
+
+
+def test_vector_set_is_scalar_only(ctx):
+    """Function.vector.set mirrors PETSc's Vec.set(alpha): a scalar (or the length-1 array `update`
+    passes, utils_dolfinx.py:308-309) broadcasts; a longer array fails loudly instead of using a[0]."""
+    from femo_amd.fea import utils_hip
+    from femo_amd.fea.fea_hip import Function, FunctionSpace, getFuncArray, setFuncArray, update
+    from femo_amd.fea.mesh import createUnitSquareMesh
+    utils_hip.set_context(ctx)
+    V = FunctionSpace(createUnitSquareMesh(3), ('CG', 1))
+    fn = Function(V)
+    fn.vector.set(2.5)
+    assert np.all(getFuncArray(fn) == 2.5)
+    update(fn, np.array([0.75]))
+    assert np.all(getFuncArray(fn) == 0.75)
+    with pytest.raises(ValueError, match="scalar"):
+        fn.vector.set(np.arange(16.0))
+    setFuncArray(fn, np.arange(16.0))
+    assert np.array_equal(getFuncArray(fn), np.arange(16.0))

@@ -266,3 +266,4 @@ def test_small_mesh_utilities():
     u = createUnitSquareMesh(8, 0.2)
     pts = u.x[[3, 40, 77]] + 1e-4
     assert list(findNodeIndices(pts, u.x)) == [3, 40, 77]
+
