@@ -702,9 +702,10 @@ def project(v, target_func: Function, bcs=[], lump_mass=False):
 
 # --------------------------------------------------------------------- norms ----
 def errorNorm(v: Function, v_ex: Function, norm: str = 'L2') -> float:
-    """utils_dolfinx.py:225-238 (L2 only; host-side, not on the hot path)."""
-    if norm != 'L2':
-        raise NotImplementedError("only the L2 norm is implemented")
+    """utils_dolfinx.py:225-238: sqrt(int (v - v_ex)^2 [+ |grad(v - v_ex)|^2 for 'H1']), exact for the
+    P1 / DG0 functions of the engine (host-side, not on the hot path)."""
+    if norm not in ('L2', 'H1'):
+        raise NotImplementedError("errorNorm: norm must be 'L2' or 'H1'")
     mesh = v.function_space.mesh
     X = mesh.x[mesh.conn]
     E_ = X[:, 1:, :] - X[:, :1, :]
@@ -718,4 +719,9 @@ def errorNorm(v: Function, v_ex: Function, norm: str = 'L2') -> float:
     e = nodal(v) - nodal(v_ex)
     s = e.sum(axis=1)
     val = (vol / ((d + 1) * (d + 2)) * ((e ** 2).sum(axis=1) + s ** 2)).sum()
+    if norm == 'H1':
+        # grad of the P1 interpolant of e per cell: solve E_^T-system for the gradient of the differences
+        de = e[:, 1:] - e[:, :1]                                   # (n_cell, d)
+        grad = np.linalg.solve(E_, de[:, :, None])[:, :, 0]        # rows of E_ are edge vectors: E_ grad = de
+        val += (vol * (grad ** 2).sum(axis=1)).sum()
     return float(np.sqrt(val))

@@ -70,3 +70,27 @@ def test_field_output_operation(ctx):
         u, _ = fo.newton_solve(om, 0.086 * np.ones(om.n_cell), np.ones(om.n_vert), bd, np.zeros(len(bd)))
         ref = fo.project_l2(om, cell_values=fo.grad_magnitude(om, u))
         assert sim['grad_u_mag'].shape == (om.n_vert,) and _rel(sim['grad_u_mag'], ref) < 1e-9
+
+
+@pytest.mark.parametrize("d,n", [(2, 9), (3, 5)])
+def test_error_norms(ctx, d, n):
+    """errorNorm (utils_dolfinx.py:225-238), L2 and H1, against the oracle's mass and stiffness matrices:
+    ||e||_L2^2 = e^T M e, |e|_H1^2 = e^T K e for P1 functions."""
+    from femo_amd.fea import utils_hip
+    from femo_amd.fea.fea_hip import Function, FunctionSpace, errorNorm, setFuncArray
+    from femo_amd.fea.mesh import createUnitCubeMesh, createUnitSquareMesh
+    utils_hip.set_context(ctx)
+    mesh = createUnitSquareMesh(n, 0.2) if d == 2 else createUnitCubeMesh(n, 0.2)
+    om = fo.unit_square_mesh(n, 0.2) if d == 2 else fo.unit_cube_mesh(n, 0.2)
+    V = FunctionSpace(mesh, ('CG', 1))
+    a, b = Function(V), Function(V)
+    rng = np.random.default_rng(4)
+    va, vb = rng.standard_normal(mesh.n_vert), rng.standard_normal(mesh.n_vert)
+    setFuncArray(a, va); setFuncArray(b, vb)
+    e = va - vb
+    l2 = np.sqrt(e @ (fo.mass_matrix(om) @ e))
+    h1 = np.sqrt(l2 ** 2 + e @ (fo.stiffness(om) @ e))
+    assert abs(errorNorm(a, b) - l2) < 1e-12 * l2
+    assert abs(errorNorm(a, b, norm='H1') - h1) < 1e-12 * h1
+    with pytest.raises(NotImplementedError):
+        errorNorm(a, b, norm='Linf')
