@@ -26,6 +26,33 @@ from .mesh import (BeamMesh, Mesh, createIntervalMesh, createRectangleMesh, crea
                    findNodeIndices, locate_dofs_geometrical, meshSize)
 
 
+class AbstractFEA(object):
+    """The bare registry the reference keeps next to ``FEA`` (fea_dolfinx.py:20-67): named inputs, states
+    with their residual forms and argument lists, outputs and a flat list of boundary conditions.  No
+    shapes, recorders or solvers -- those live in ``FEA``."""
+
+    def __init__(self, mesh):
+        self.mesh = mesh
+        self.inputs_dict, self.states_dict, self.outputs_dict = {}, {}, {}
+        self.bcs_list = []
+
+    def add_strong_bc(self, bc):
+        self.bcs_list.append(bc)
+
+    def add_input(self, name, function):
+        if name in self.inputs_dict:
+            raise ValueError('name has already been used for an input')
+        function.rename(name, name)
+        self.inputs_dict[name] = {'function': function}
+
+    def add_state(self, name, function, residual_form, *arguments):
+        function.rename(name, name)
+        self.states_dict[name] = {'function': function, 'residual_form': residual_form, 'arguments': arguments}
+
+    def add_output(self, name, form, *arguments):
+        self.outputs_dict[name] = {'form': form, 'arguments': arguments}
+
+
 class FEA(object):
     """Registers inputs, states and outputs of one PDE problem and owns its nonlinear and linearised
     solves."""

@@ -267,3 +267,25 @@ def test_small_mesh_utilities():
     pts = u.x[[3, 40, 77]] + 1e-4
     assert list(findNodeIndices(pts, u.x)) == [3, 40, 77]
 
+
+
+def test_abstract_fea_registry():
+    """AbstractFEA (fea_dolfinx.py:20-67): plain registries, duplicate input names rejected, variadic
+    argument lists kept as tuples."""
+    from femo_amd.fea.fea_hip import AbstractFEA
+
+    class Fn:
+        def rename(self, a, b):
+            self.name = a
+
+    fea = AbstractFEA(mesh="m")
+    f, u = Fn(), Fn()
+    fea.add_input('f', f)
+    with pytest.raises(ValueError, match="already been used"):
+        fea.add_input('f', Fn())
+    fea.add_state('u', u, 'R', 'f', 'g')
+    fea.add_output('J', 'form', 'u', 'f')
+    fea.add_strong_bc('bc0')
+    assert f.name == 'f' and u.name == 'u' and fea.mesh == "m"
+    assert fea.states_dict['u']['arguments'] == ('f', 'g') and fea.outputs_dict['J'] == {'form': 'form', 'arguments': ('u', 'f')}
+    assert fea.bcs_list == ['bc0'] and set(fea.inputs_dict['f']) == {'function'}
