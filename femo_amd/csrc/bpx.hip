@@ -519,7 +519,12 @@ int femo_pc_build(femo_mesh* m) {
     int64_t off = 0;
     for (auto& L : pc->L) { L.g = pc->g_all + off; off += L.nodes; }
   }
-  pc->n_fused = std::min(D == 3 ? 2 : 3, pc->n_levels - 1);
+  // Coarser levels the brick kernel restricts to by itself.  On one GPU fusing two (3-D) or three
+  // (2-D) levels and running the lattice restrictions separately measure the same (72-75 ms per bench
+  // cycle either way); on partitioned meshes every fused level adds its nodes to the all-reduce, so
+  // only the finest lattice is accumulated there.  FEMO_BPX_FUSED overrides (tests, tuning).
+  pc->n_fused = ctx->nranks > 1 ? 0 : std::min(D == 3 ? 2 : 3, pc->n_levels - 1);
+  if (const char* e = getenv("FEMO_BPX_FUSED")) pc->n_fused = std::max(0, std::min(std::min(D == 3 ? 2 : 3, pc->n_levels - 1), atoi(e)));
   pc->n_bricks = P.n_bricks;
   auto upload = [&](auto** dst, const auto& src) -> int {
     using T = typename std::remove_reference<decltype(src)>::type::value_type;

@@ -327,3 +327,24 @@ def test_solver_layer_keeps_jacobi_on_strongly_graded_meshes(ctx, monkeypatch):
         assert seen[-1] == expect
         x_ref = spla.spsolve(fo.eliminate_bc(fo.stiffness(om), bd).tocsc(), b.get())
         assert _rel(x.get(), x_ref) < 1e-10
+
+
+@pytest.mark.parametrize("fused", ["0", "1", "2"])
+def test_pc_apply_does_not_depend_on_the_fusion_depth(ctx, monkeypatch, fused):
+    """FEMO_BPX_FUSED: how many coarser lattices the brick kernel restricts to itself (0 on
+    partitioned meshes, where every fused level would enlarge the all-reduce).  Same operator."""
+    from femo_amd import engine as E
+    from oracle import bpx_oracle as bo
+    monkeypatch.setenv("FEMO_BPX_FUSED", fused)
+    for d, n in ((3, 18), (2, 50)):
+        m = fo.unit_cube_mesh(n, 0.2) if d == 3 else fo.unit_square_mesh(n, 0.2)
+        dm, bc, A, b = _poisson_system(ctx, m)
+        pinned = np.zeros(m.n_vert, bool)
+        pinned[fo.boundary_vertices_box(m.x)] = True
+        M = bo.BPX(m.x, A.to_scipy().diagonal(), pinned)
+        r = np.random.default_rng(7).standard_normal(m.n_vert)
+        z = A.pc_apply(E.Vec(ctx, m.n_vert).set(r), E.Vec(ctx, m.n_vert)).get()
+        assert np.abs(z - M.apply(r)).max() < 1e-12 * np.abs(M.apply(r)).max()
+        x = E.Vec(ctx, m.n_vert)
+        info = A.solve_cg(b, x, rtol=1e-14, pc="bpx")
+        assert info.converged == 1 and info.iterations <= 60
