@@ -11,7 +11,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libfemo_hip.so")
+LIB_PATH = os.environ.get("FEMO_LIB") or os.path.join(_HERE, "csrc", "libfemo_hip.so")    # FEMO_LIB: another build of the library (A/B measurements)
 
 c_i64 = C.c_int64
 c_i32p = C.POINTER(C.c_int32)
