@@ -348,3 +348,39 @@ def test_pc_apply_does_not_depend_on_the_fusion_depth(ctx, monkeypatch, fused):
         x = E.Vec(ctx, m.n_vert)
         info = A.solve_cg(b, x, rtol=1e-14, pc="bpx")
         assert info.converged == 1 and info.iterations <= 60
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_pc_apply_sweep_over_shapes(ctx, seed):
+    """Randomised sweep: dimension, resolution, jitter, anisotropic scaling and translation of the
+    domain (negative coordinates, extents that are not multiples of one another).  The HIP operator
+    must equal the oracle operator and PCG must reach the direct solution."""
+    from femo_amd import engine as E
+    from oracle import bpx_oracle as bo
+    rng = np.random.default_rng(1000 + seed)
+    d = 2 if seed % 2 == 0 else 3
+    n = int(rng.integers(6, 40)) if d == 2 else int(rng.integers(4, 15))
+    m0 = fo.unit_square_mesh(n, float(rng.uniform(0, 0.3))) if d == 2 else fo.unit_cube_mesh(n, float(rng.uniform(0, 0.3)))
+    scale = rng.uniform(0.3, 3.0, size=d)
+    shift = rng.uniform(-5.0, 5.0, size=d)
+    m = fo.OMesh(d, m0.x * scale + shift, m0.conn)
+    bd = fo.boundary_vertices_box(m0.x)                       # topology of the unit box
+    dm = E.DeviceMesh(ctx, m.x, m.conn)
+    bc = E.DirichletSet(dm, bd, 0.3 * rng.standard_normal(len(bd)))
+    A, b = E.Mat(dm), E.Vec(ctx, m.n_vert)
+    E.assemble_system(dm, 0, None, E.Vec(ctx, m.n_vert).fill(0.0), E.Vec(ctx, m.n_cell).set(1.0 + rng.random(m.n_cell)),
+                      bc, None, A, b)
+    As = A.to_scipy()
+    pinned = np.zeros(m.n_vert, bool)
+    pinned[bd] = True
+    M = bo.BPX(m.x, As.diagonal(), pinned)
+    r = rng.standard_normal(m.n_vert)
+    z = A.pc_apply(E.Vec(ctx, m.n_vert).set(r), E.Vec(ctx, m.n_vert)).get()
+    ref = M.apply(r)
+    assert np.abs(z - ref).max() < 1e-11 * np.abs(ref).max()
+    info_bins = dm.pc_info()
+    assert info_bins["levels"] == M.levels and info_bins["finest_nodes"] == int(np.prod(M.bins[-1] + 1))
+    x = E.Vec(ctx, m.n_vert)
+    info = A.solve_cg(b, x, rtol=1e-14, pc="bpx")
+    x_ref = spla.spsolve(As.tocsc(), b.get())
+    assert info.converged == 1 and _rel(x.get(), x_ref) < 1e-10
