@@ -68,6 +68,9 @@ PROTOTYPES = {
     "femo_mesh_set_boundary_facets": (C.c_int, [H, C.c_void_p]),
     "femo_pc_plan_host": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int32),
                           C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "femo_emu_group_create": (C.c_int, [C.c_int, C.POINTER(H)]),
+    "femo_emu_group_destroy": (C.c_int, [H]),
+    "femo_comm_emulate": (C.c_int, [H, H, C.c_int]),
     "femo_mesh_set_global": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int64]),
     "femo_mesh_pc_info": (C.c_int, [H, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "femo_mesh_pattern_csr": (C.c_int, [H, C.c_void_p, C.c_void_p]),

@@ -3,6 +3,8 @@
 // for the reference call site each entry replaces.
 #include <algorithm>
 
+#include <atomic>
+
 #include "femo_internal.h"
 
 namespace {
@@ -379,7 +381,7 @@ int femo_bc_create(femo_mesh* m, int64_t n, const int32_t* dofs, const double* v
   for (int64_t i = 0; i < n; ++i)
     FEMO_REQUIRE(dofs[i] >= 0 && dofs[i] < m->n_vert, "Dirichlet dof %d out of range", dofs[i]);
   femo_bc* b = new femo_bc();
-  static uint64_t next_uid = 0;
+  static std::atomic<uint64_t> next_uid{0};      // contexts may live on different host threads
   b->mesh = m; b->n = n; b->uid = ++next_uid;
   hipStream_t st = m->ctx->stream;
   FEMO_HIP_CHECK(hipMalloc(&b->d_dofs, std::max<int64_t>(n, 1) * sizeof(int32_t)));
@@ -700,7 +702,7 @@ int femo_allreduce_sum(femo_ctx* ctx, double* host_inout, int n) {
   if (ctx->nranks == 1 || n == 0) return 0;
   memcpy(ctx->h_scal, host_inout, n * sizeof(double));
   FEMO_HIP_CHECK(hipMemcpyAsync(ctx->d_scal, ctx->h_scal, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  FEMO_NCCL_CHECK(ncclAllReduce(ctx->d_scal, ctx->d_scal, n, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+  FEMO_TRY(femo_coll_allreduce(ctx, ctx->d_scal, n, ctx->stream));
   FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   FEMO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   memcpy(host_inout, ctx->h_scal, n * sizeof(double));

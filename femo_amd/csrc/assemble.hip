@@ -984,7 +984,7 @@ int femo_reduce_to_host(femo_ctx* ctx, int nblocks, int nsums, double* host_out)
   hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, nblocks, nsums, ctx->d_partials, ctx->d_scal);
   FEMO_HIP_CHECK(hipGetLastError());
   if (ctx->nranks > 1)
-    FEMO_NCCL_CHECK(ncclAllReduce(ctx->d_scal, ctx->d_scal, nsums, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+    FEMO_TRY(femo_coll_allreduce(ctx, ctx->d_scal, nsums, ctx->stream));
   FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, nsums * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   FEMO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   for (int j = 0; j < nsums; ++j) host_out[j] = ctx->h_scal[j];

@@ -576,8 +576,8 @@ static int pc_prepare(femo_mesh* m, const uint8_t* mask, uint64_t key) {
     if (mask) hipLaunchKernelGGL(k_restrict_mesh<2>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, m->d_x, none, none, mask, 1, F.e, (const int32_t*)nullptr);
   }
   if (ctx->nranks > 1) {
-    FEMO_NCCL_CHECK(ncclAllReduce(F.g, F.g, F.nodes, ncclDouble, ncclSum, ctx->comm, st));
-    FEMO_NCCL_CHECK(ncclAllReduce(F.e, F.e, F.nodes, ncclDouble, ncclSum, ctx->comm, st));
+    FEMO_TRY(femo_coll_allreduce(ctx, F.g, F.nodes, st));
+    FEMO_TRY(femo_coll_allreduce(ctx, F.e, F.nodes, st));
   }
   // 1 / diag of the Q1 Laplacian, damped: weighting the lattice terms by 0.6 against the Jacobi
   // term measured 12-15 % fewer iterations than 1.0 on every case tried (0.35 and 1.0 are both worse)
@@ -617,7 +617,7 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
   if (ctx->nranks > 1) {   // one all-reduce over the contiguous accumulators of the finest nf+1 levels
     double* first = pc->L[nl - 1 - nf].g;
     const int64_t count = (F.g + F.nodes) - first;
-    FEMO_NCCL_CHECK(ncclAllReduce(first, first, count, ncclDouble, ncclSum, ctx->comm, st));
+    FEMO_TRY(femo_coll_allreduce(ctx, first, count, st));
   }
   // levels with at most COARSE_NODES nodes (and below the brick-fused ones) go through the
   // single-workgroup kernel; `cut` = first level handled by multi-block launches

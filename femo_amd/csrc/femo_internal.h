@@ -100,6 +100,7 @@ struct femo_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> ev_pool;
   ncclComm_t comm = nullptr;
+  struct femo_emu_group* emu = nullptr;      // in-process rank emulation (tests; comm.cpp)
   int rank = 0, nranks = 1;
   hipStream_t comm_stream = nullptr;          // halo exchange overlapped with interior rows
   hipEvent_t ev_main = nullptr, ev_comm = nullptr;
@@ -262,6 +263,9 @@ int femo_spmv_grid(const femo_mesh* m);
 int femo_halo_exchange_on(femo_mesh* m, femo_vec* x, hipStream_t st);
 int femo_mesh_classify_slices(femo_mesh* m);
 int femo_mat_ensure_transpose(femo_mat* A);
+int femo_coll_allreduce(femo_ctx* ctx, double* d, int64_t count, hipStream_t st);
+int femo_coll_neighbors(femo_ctx* ctx, int n_nbr, const int32_t* nbr, const int64_t* send_ptr, const double* d_send,
+                        const int64_t* recv_ptr, double* d_recv, hipStream_t st);
 int femo_pc_build(femo_mesh* m);
 void femo_pc_destroy(femo_mesh* m);
 // mode 0: out = M^-1 rh (scaled variables).  mode 1: out = M^-1 rh + beta out with beta = gamma'/(*gamma_cur),

@@ -865,22 +865,15 @@ int femo_halo_exchange_on(femo_mesh* m, femo_vec* x, hipStream_t st) {
   FEMO_REQUIRE(m && x, "null argument");
   if (m->n_nbr == 0) return 0;
   femo_ctx* ctx = m->ctx;
-  FEMO_REQUIRE(ctx->comm != nullptr, "halo exchange before femo_comm_init");
+  FEMO_REQUIRE(ctx->comm != nullptr || ctx->emu != nullptr, "halo exchange before femo_comm_init");
   FEMO_REQUIRE(x->n >= m->n_vert, "vector shorter than n_vert");
   const int64_t ns = m->send_ptr[m->n_nbr];
   if (ns > 0) {
     hipLaunchKernelGGL(k_pack, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, ns, m->d_send_idx, x->d, m->d_send_buf);
     FEMO_HIP_CHECK(hipGetLastError());
   }
-  FEMO_NCCL_CHECK(ncclGroupStart());
-  for (int k = 0; k < m->n_nbr; ++k) {
-    const int64_t sc = m->send_ptr[k + 1] - m->send_ptr[k];
-    const int64_t rc = m->recv_ptr[k + 1] - m->recv_ptr[k];
-    if (sc > 0) FEMO_NCCL_CHECK(ncclSend(m->d_send_buf + m->send_ptr[k], sc, ncclDouble, m->nbr[k], ctx->comm, st));
-    if (rc > 0) FEMO_NCCL_CHECK(ncclRecv(x->d + m->n_rows + m->recv_ptr[k], rc, ncclDouble, m->nbr[k], ctx->comm, st));
-  }
-  FEMO_NCCL_CHECK(ncclGroupEnd());
-  return 0;
+  return femo_coll_neighbors(ctx, m->n_nbr, m->nbr.data(), m->send_ptr.data(), m->d_send_buf, m->recv_ptr.data(),
+                             x->d + m->n_rows, st);
 }
 
 extern "C" int femo_halo_exchange(femo_mesh* m, femo_vec* x) {
@@ -1037,7 +1030,7 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
   const uint8_t* mask = A->pc_has_mask ? A->d_pcmask : nullptr;
   FEMO_TRY(femo_pc_begin(m, A->d_s, mask));
   auto allreduce1 = [&](double* d) -> int {
-    if (multi) FEMO_NCCL_CHECK(ncclAllReduce(d, d, 1, ncclDouble, ncclSum, ctx->comm, st));
+    if (multi) FEMO_TRY(femo_coll_allreduce(ctx, d, 1, st));
     return 0;
   };
 
@@ -1053,7 +1046,7 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
   hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, b->d, q0, A->d_s, w.r, w.p, w.xh, P);
   hipLaunchKernelGGL(k_reduce_partials_at, dim3(1), dim3(1024), 0, st, gv, 2, P + FEMO_MAX_PARTIALS, S);
   FEMO_HIP_CHECK(hipGetLastError());
-  if (multi) FEMO_NCCL_CHECK(ncclAllReduce(S, S, 2, ncclDouble, ncclSum, ctx->comm, st));
+  if (multi) FEMO_TRY(femo_coll_allreduce(ctx, S, 2, st));
   FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, S, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
   FEMO_HIP_CHECK(hipStreamSynchronize(st));
   const double rho0 = ctx->h_scal[0], bb = ctx->h_scal[1];
@@ -1234,7 +1227,7 @@ extern "C" int femo_solve_cg(const femo_mat* A_, int transpose, const femo_vec* 
   // gamma0 and ||S b||^2 (all-reduced when multi): partial slots 1 and 2
   hipLaunchKernelGGL(k_reduce_partials_at, dim3(1), dim3(1024), 0, st, gv, 2, P + FEMO_MAX_PARTIALS, ctx->d_scal);
   FEMO_HIP_CHECK(hipGetLastError());
-  if (multi) FEMO_NCCL_CHECK(ncclAllReduce(ctx->d_scal, ctx->d_scal, 2, ncclDouble, ncclSum, ctx->comm, st));
+  if (multi) FEMO_TRY(femo_coll_allreduce(ctx, ctx->d_scal, 2, st));
   FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
   FEMO_HIP_CHECK(hipStreamSynchronize(st));
   const double gamma0 = ctx->h_scal[0], bb = ctx->h_scal[1];
@@ -1283,7 +1276,7 @@ extern "C" int femo_solve_cg(const femo_mat* A_, int transpose, const femo_vec* 
     }
     if (sample) { FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev + 1], st)); ++n_ev; }
     hipLaunchKernelGGL(k_cgm_fold, dim3(1), dim3(1024), 0, st, g1, g2, P, ctx->d_scal + 2 * parity, ctx->d_flags);
-    FEMO_NCCL_CHECK(ncclAllReduce(ctx->d_scal + 2 * parity, ctx->d_scal + 2 * parity, 2, ncclDouble, ncclSum, ctx->comm, st));
+    FEMO_TRY(femo_coll_allreduce(ctx, ctx->d_scal + 2 * parity, 2, st));
     return 0;
   };
   if (multi) FEMO_TRY(merged_spmv(0, false));
@@ -1390,7 +1383,7 @@ extern "C" int femo_solve_bicgstab(const femo_mat* A_, int transpose, const femo
   hipLaunchKernelGGL(k_bi_init, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, b->d, q0, A->d_s, w.r, w.r0, w.p, w.q, w.xh, P);
   FEMO_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(k_reduce_partials_at, dim3(1), dim3(1024), 0, st, gv, 2, P, S + 12);
-  if (multi) FEMO_NCCL_CHECK(ncclAllReduce(S + 12, S + 12, 2, ncclDouble, ncclSum, ctx->comm, st));
+  if (multi) FEMO_TRY(femo_coll_allreduce(ctx, S + 12, 2, st));
   FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, S + 12, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
   FEMO_HIP_CHECK(hipStreamSynchronize(st));
   const double rr0 = ctx->h_scal[0], bb = ctx->h_scal[1];
@@ -1432,15 +1425,15 @@ extern "C" int femo_solve_bicgstab(const femo_mat* A_, int transpose, const femo
       if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, w.p));
       FEMO_TRY(launch_spmv(A, A->d_valsS, w.p, w.q, P, ctx->d_flags, true, false, nullptr, 0, nullptr, w.r0));   // v, (r0, v)
       hipLaunchKernelGGL(k_bi_fold, dim3(1), dim3(1024), 0, st, gs, 1, P, S + B_R0V, ctx->d_flags);
-      if (multi) FEMO_NCCL_CHECK(ncclAllReduce(S + B_R0V, S + B_R0V, 1, ncclDouble, ncclSum, ctx->comm, st));
+      if (multi) FEMO_TRY(femo_coll_allreduce(ctx, S + B_R0V, 1, st));
       hipLaunchKernelGGL(k_bi_s, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, S, w.r, w.q, w.sv, ctx->d_flags);
       if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, w.sv));
       FEMO_TRY(launch_spmv(A, A->d_valsS, w.sv, w.t, P, ctx->d_flags, true, false, nullptr, 0, nullptr, nullptr, true));  // t, (s,t), (t,t)
       hipLaunchKernelGGL(k_bi_fold, dim3(1), dim3(1024), 0, st, gs, 2, P, S + B_TS, ctx->d_flags);
-      if (multi) FEMO_NCCL_CHECK(ncclAllReduce(S + B_TS, S + B_TS, 2, ncclDouble, ncclSum, ctx->comm, st));
+      if (multi) FEMO_TRY(femo_coll_allreduce(ctx, S + B_TS, 2, st));
       hipLaunchKernelGGL(k_bi_xr, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, it, S, w.p, w.sv, w.t, w.r0, w.xh, w.r, P, ctx->d_flags);
       hipLaunchKernelGGL(k_bi_fold, dim3(1), dim3(1024), 0, st, gv, 2, P, S + 12, ctx->d_flags);
-      if (multi) FEMO_NCCL_CHECK(ncclAllReduce(S + 12, S + 12, 2, ncclDouble, ncclSum, ctx->comm, st));
+      if (multi) FEMO_TRY(femo_coll_allreduce(ctx, S + 12, 2, st));
       hipLaunchKernelGGL(k_bi_set_rho, dim3(1), dim3(1), 0, st, S + 12, S, ctx->d_flags);
     }
     hipLaunchKernelGGL(k_bi_check, dim3(1), dim3(1), 0, st, it, S, ctx->d_flags);

@@ -34,6 +34,23 @@ def _h(obj) -> Optional[H]:
     return None if obj is None else obj.handle
 
 
+class EmuGroup:
+    """In-process rank emulation (tests): ``nranks`` contexts on one GPU, one host thread each, whose
+    collectives go through host memory and barriers instead of RCCL (include/femo_hip.h)."""
+
+    def __init__(self, nranks: int):
+        self.lib = _lib.load()
+        self.nranks = int(nranks)
+        h = H()
+        check(self.lib.femo_emu_group_create(self.nranks, C.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            self.lib.femo_emu_group_destroy(h)
+
+
 class Context:
     """Device + HIP stream (+ RCCL communicator).  Stands in for PETSc/MPI global state."""
 
@@ -51,6 +68,11 @@ class Context:
     @property
     def stream(self) -> int:
         return int(self.lib.femo_ctx_stream(self.handle) or 0)
+
+    def comm_emulate(self, group: "EmuGroup", rank: int) -> None:
+        check(self.lib.femo_comm_emulate(self.handle, group.handle, int(rank)))
+        self.rank, self.nranks = int(rank), group.nranks
+        self._emu_group = group            # keep it alive as long as the context
 
     def comm_init(self, unique_id: bytes, rank: int, nranks: int) -> None:
         assert len(unique_id) == 128

@@ -39,6 +39,7 @@ typedef struct femo_vec  femo_vec;   /* fp64 device vector  (dolfinx Function.ve
 typedef struct femo_mesh femo_mesh;  /* P1 simplex mesh + vertex->cell incidence + sparsity pattern   */
 typedef struct femo_bc   femo_bc;    /* strong Dirichlet set (fea_dolfinx.py:169-176 add_strong_bc)   */
 typedef struct femo_mat  femo_mat;   /* N x N sparse matrix on the mesh pattern (PETSc Mat)           */
+typedef struct femo_emu_group femo_emu_group;  /* in-process rank emulation, tests only (see below)  */
 
 /* closed catalogue of residual forms (UFL is not available) */
 enum femo_pde_kind {
@@ -267,6 +268,16 @@ int femo_mesh_set_halo(femo_mesh* mesh, int n_nbr, const int32_t* nbr,
                        const int64_t* recv_ptr);
 int femo_halo_exchange(femo_mesh* mesh, femo_vec* x);
 int femo_allreduce_sum(femo_ctx* ctx, double* host_inout, int n);
+
+/* ---- rank emulation on ONE GPU (tests) -----------------------------------------------------------
+ * RCCL cannot place two ranks on one device.  With a femo_emu_group, `nranks` contexts on the same GPU,
+ * each driven by its own host thread, behave as the ranks of a job: every collective of the library
+ * (halo exchange, all-reduced scalars, all-reduced lattice accumulators) is staged through host memory
+ * and a barrier instead of RCCL, so the multi-rank code paths run for real on a one-GPU box.  A rank
+ * that never reaches a collective makes the others fail after 60 s instead of hanging.             */
+int femo_emu_group_create(int nranks, femo_emu_group** out);
+int femo_emu_group_destroy(femo_emu_group* group);
+int femo_comm_emulate(femo_ctx* ctx, femo_emu_group* group, int rank);
 
 #ifdef __cplusplus
 }
