@@ -8,6 +8,7 @@ CSDL convention) or as ``DeviceArray`` (stay in HBM).
 from __future__ import annotations
 
 import os
+import threading
 from timeit import default_timer
 from typing import List, Optional, Sequence
 
@@ -27,20 +28,28 @@ DOLFIN_EPS = 3E-16
 
 # ---------------------------------------------------------------- context ----
 _CTX: Optional[Context] = None
+_TLS = threading.local()          # per-thread override (rank emulation: one rank per host thread)
 
 
 def get_context() -> Context:
     """One context (device + stream) per process: device = LOCAL_RANK (one
-    process per GPU), replacing ``comm = MPI.COMM_WORLD`` (utils_dolfinx.py:32)."""
+    process per GPU), replacing ``comm = MPI.COMM_WORLD`` (utils_dolfinx.py:32).
+    A thread that called ``set_context(ctx, thread_local=True)`` sees its own."""
     global _CTX
+    ctx = getattr(_TLS, "ctx", None)
+    if ctx is not None:
+        return ctx
     if _CTX is None:
         _CTX = Context(int(os.environ.get("LOCAL_RANK", "0")))
     return _CTX
 
 
-def set_context(ctx: Optional[Context]) -> None:
+def set_context(ctx: Optional[Context], thread_local: bool = False) -> None:
     global _CTX
-    _CTX = ctx
+    if thread_local:
+        _TLS.ctx = ctx
+    else:
+        _CTX = ctx
 
 
 # Linear-solver options: the analogue of the global PETSc options database the

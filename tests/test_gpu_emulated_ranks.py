@@ -76,7 +76,7 @@ def _reference(m, seed=0):
     return spla.spsolve(fo.eliminate_bc(K, bd).tocsc(), rhs), rhs
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 @pytest.mark.parametrize("pc", ["jacobi", "bpx"])
 def test_partitioned_solve_with_emulated_ranks(world, pc):
     from femo_amd import engine as E
@@ -149,3 +149,48 @@ def test_emulated_halo_and_dot_products():
         y[r["gid"]] = r["y"]
         assert abs(r["dot"] - u @ u) < 1e-12 * (u @ u)              # all-reduced: every rank has the global value
     assert np.abs(y - K @ u).max() < 1e-12 * np.abs(K @ u).max()
+
+
+def test_bench_cycle_on_two_emulated_ranks():
+    """The SPMD path of `bench.py --gpus 2` (DistMesh through FEA / FEAModel / Simulator, BPX-CG with
+    halo exchange and all-reduces) with two real ranks emulated on one GPU; state, functional and
+    total derivative against the oracle's reference cycle on the whole mesh."""
+    import bench as B
+    from femo_amd.dist import DistMesh
+    from femo_amd.fea import utils_hip
+    from femo_amd.fea.mesh import createUnitCubeMesh
+    world, n = 2, 10
+    gmesh = createUnitCubeMesh(n, jitter=0.2)
+    part = rcb_partition(gmesh.x, world)
+    f_global = B.source_fields(gmesh, 1)[0]
+    occupancy = gmesh.lattice_occupancy()
+
+    def rank_fn(rank, ctx):
+        utils_hip.set_context(ctx, thread_local=True)
+        try:
+            L = build_local_mesh(gmesh.x, gmesh.conn, part, rank, world)
+            mesh = DistMesh(L, gmesh.n_vert, gmesh.n_cell, bbox=(gmesh.x.min(axis=0), gmesh.x.max(axis=0)))
+            mesh._occupancy = occupancy
+            sim, fea = B.build_problem(mesh, device=True)
+            g = np.asarray(B.one_cycle(sim, fea, f_global[L.cell_global])).ravel()
+            u = np.asarray(sim['u'])
+            return dict(gid=L.vert_global[:L.n_owned], u=u[:L.n_owned], cells=L.cell_global[L.cell_owned],
+                        g=g[L.cell_owned], J=float(np.asarray(sim['l2_functional']).ravel()[0]))
+        finally:
+            utils_hip.set_context(None, thread_local=True)
+
+    res = _run_ranks(world, rank_fn)
+    om = fo.unit_cube_mesh(n, jitter=0.2)
+    bd = fo.boundary_vertices_box(om.x)
+    ref = fo.reference_cycle(om, f_global, fo.u_target(om.x), bd, np.zeros(len(bd)))
+    u = np.zeros(om.n_vert)
+    g = np.zeros(om.n_cell)
+    seen = np.zeros(om.n_cell, int)
+    for r in res:
+        u[r["gid"]] = r["u"]
+        g[r["cells"]] = r["g"]
+        seen[r["cells"]] += 1
+        assert abs(r["J"] - ref["J"][0]) < 1e-10 * abs(ref["J"][0])          # all-reduced: global on every rank
+    assert np.all(seen == 1)                                                   # every cell owned by exactly one rank
+    assert np.abs(u - ref["u"]).max() < 1e-10 * np.abs(ref["u"]).max()
+    assert np.abs(g - ref["grad"]).max() < 1e-10 * np.abs(ref["grad"]).max()
