@@ -59,6 +59,13 @@ struct femo_pc {
   uint32_t* d_pk_sorted = nullptr;  // the same in sorted order
   double* d_w_sorted = nullptr;     // 1/s (0 on pinned vertices) in sorted order, refreshed per solve
   double* d_dot_partials = nullptr; // per-block partials of g_L.e_L (2048)
+  // partitioned meshes: only the finest-lattice nodes that several ranks touch are exchanged
+  bool shared_ready = false;
+  int64_t n_shared = 0;
+  int32_t* d_shared_idx = nullptr;  // finest-lattice nodes touched by >= 2 ranks (same list on every rank)
+  double* d_dot_weight = nullptr;   // 1/(ranks touching the node) where this rank touches it, else 0
+  double* d_xbuf = nullptr;         // [shared nodes of level L | all of level L-1]: the one all-reduce per apply
+  double* d_dot_scalar = nullptr;
   int64_t* d_brick_ptr = nullptr;   // n_bricks + 1
   uint32_t* d_bin_ptr = nullptr;    // 65 per brick: start of each of its 64 bins, relative to the brick
   int32_t* d_brick_base = nullptr;  // 3 per brick: first bin of the brick along each axis
@@ -278,7 +285,8 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat
                                                              const double* __restrict__ rh, const double* __restrict__ s,
                                                              const uint8_t* __restrict__ mask, const double* __restrict__ e,
                                                              double* __restrict__ out, int mode, int nb_dot,
-                                                             const double* __restrict__ dot_partials, const double* __restrict__ rho,
+                                                             const double* __restrict__ dot_partials, const double* __restrict__ dot_global,
+                                                             const double* __restrict__ rho,
                                                              const double* __restrict__ gamma_cur, double* __restrict__ gamma_nxt,
                                                              const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
@@ -294,6 +302,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat
     double ge = 0.0;
 #pragma unroll
     for (int i = 0; i < FEMO_BLOCK / 64; ++i) ge += lds[i];
+    if (dot_global != nullptr) ge = *dot_global;      // already folded and all-reduced (nb_dot == 0)
     const double g1 = *rho + ge, g0 = *gamma_cur;
     if (mode == 1) beta = g0 != 0.0 ? g1 / g0 : 0.0;
     if (blockIdx.x == 0 && threadIdx.x == 0) *gamma_nxt = g1;
@@ -377,11 +386,13 @@ __global__ void k_lattice_restrict(int nc0, int nc1, int nc2, int nf0, int nf1, 
 
 // e_f[i] = (interpolation of e_c)(i) + coef_f[i] * g_f[i]     (e_c == nullptr: coarsest level)
 // dot_partials != nullptr (finest level): per-block partial of g.e -- with it the caller has
-// rh.zh = rh.rh + g_L.e_L without a pass over the mesh (see femo_pc_apply).
+// rh.zh = rh.rh + g_L.e_L without a pass over the mesh (see femo_pc_apply).  dot_weight (partitioned
+// meshes with the sparse exchange): 1/(number of ranks touching the node) on the nodes this rank
+// touches, 0 elsewhere, so that the per-rank dots add up to the global one.
 __global__ __launch_bounds__(256) void k_lattice_prolong(int nf0, int nf1, int nf2, int nc0, int nc1, int nc2, int dim,
                                                          const double* __restrict__ ec, const double* __restrict__ coef, double* __restrict__ g,
                                                          int zero_g, double* __restrict__ ef, double* __restrict__ dot_partials,
-                                                         const int32_t* __restrict__ done) {
+                                                         const double* __restrict__ dot_weight, const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
   __shared__ double lds[256 / 64];
   const int64_t total = (int64_t)(nf0 + 1) * (nf1 + 1) * (nf2 + 1);
@@ -393,7 +404,7 @@ __global__ __launch_bounds__(256) void k_lattice_prolong(int nf0, int nf1, int n
     if (zero_g) g[idx] = 0.0;      // accumulated by atomics: left clean for the next restriction
     if (ec != nullptr) v += lattice_interp_node(idx, nf, nc, dim, ec);
     ef[idx] = v;
-    dot += gi * v;
+    dot += dot_weight != nullptr ? gi * v * dot_weight[idx] : gi * v;
   }
   if (dot_partials != nullptr) {
     const double t = femo_block_sum<256>(dot, lds);
@@ -521,10 +532,10 @@ int femo_pc_build(femo_mesh* m) {
   }
   // Coarser levels the brick kernel restricts to by itself.  On one GPU fusing two (3-D) or three
   // (2-D) levels and running the lattice restrictions separately measure the same (72-75 ms per bench
-  // cycle either way); on partitioned meshes every fused level adds its nodes to the all-reduce, so
-  // only the finest lattice is accumulated there.  FEMO_BPX_FUSED overrides (tests, tuning).
-  pc->n_fused = ctx->nranks > 1 ? 0 : std::min(D == 3 ? 2 : 3, pc->n_levels - 1);
-  if (const char* e = getenv("FEMO_BPX_FUSED")) pc->n_fused = std::max(0, std::min(std::min(D == 3 ? 2 : 3, pc->n_levels - 1), atoi(e)));
+  // cycle either way).  On partitioned meshes the bricks produce the finest level (exchanged sparsely,
+  // pc_setup_shared) and the next one (summed densely); FEMO_BPX_FUSED overrides on one rank (tests, tuning).
+  pc->n_fused = ctx->nranks > 1 ? std::min(1, pc->n_levels - 1) : std::min(D == 3 ? 2 : 3, pc->n_levels - 1);
+  if (const char* e = getenv("FEMO_BPX_FUSED"); e != nullptr && ctx->nranks == 1) pc->n_fused = std::max(0, std::min(std::min(D == 3 ? 2 : 3, pc->n_levels - 1), atoi(e)));
   pc->n_bricks = P.n_bricks;
   auto upload = [&](auto** dst, const auto& src) -> int {
     using T = typename std::remove_reference<decltype(src)>::type::value_type;
@@ -549,9 +560,98 @@ void femo_pc_destroy(femo_mesh* m) {
   for (auto& L : m->pc->L) { (void)hipFree(L.e); (void)hipFree(L.coef); }
   (void)hipFree(m->pc->g_all);
   (void)hipFree(m->pc->d_perm); (void)hipFree(m->pc->d_pk); (void)hipFree(m->pc->d_pk_sorted); (void)hipFree(m->pc->d_w_sorted); (void)hipFree(m->pc->d_dot_partials);
+  (void)hipFree(m->pc->d_shared_idx); (void)hipFree(m->pc->d_dot_weight); (void)hipFree(m->pc->d_xbuf); (void)hipFree(m->pc->d_dot_scalar);
   (void)hipFree(m->pc->d_brick_ptr); (void)hipFree(m->pc->d_bin_ptr); (void)hipFree(m->pc->d_brick_base);
   delete m->pc;
   m->pc = nullptr;
+}
+
+// ---- sparse exchange of the finest lattice on partitioned meshes ---------------------------
+__global__ void k_mark_touched(int64_t n, const double* __restrict__ g, double* __restrict__ t) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) t[i] = g[i] != 0.0 ? 1.0 : 0.0;
+}
+__global__ void k_fill_ones(int64_t n, double* __restrict__ a) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a[i] = 1.0;
+}
+// buf = [g_fine[shared_idx] | g_coarse]
+__global__ void k_pack_shared(int64_t n_shared, const int32_t* __restrict__ idx, const double* __restrict__ g_fine,
+                              int64_t n_coarse, const double* __restrict__ g_coarse, double* __restrict__ buf,
+                              const int32_t* __restrict__ done) {
+  if (done != nullptr && *done) return;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_shared + n_coarse; i += (int64_t)gridDim.x * blockDim.x)
+    buf[i] = i < n_shared ? g_fine[idx[i]] : g_coarse[i - n_shared];
+}
+__global__ void k_unpack_shared(int64_t n_shared, const int32_t* __restrict__ idx, double* __restrict__ g_fine,
+                                int64_t n_coarse, double* __restrict__ g_coarse, const double* __restrict__ buf,
+                                const int32_t* __restrict__ done) {
+  if (done != nullptr && *done) return;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_shared + n_coarse; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < n_shared) g_fine[idx[i]] = buf[i];
+    else g_coarse[i - n_shared] = buf[i];
+  }
+}
+__global__ __launch_bounds__(1024) void k_fold_partials(int nb, const double* __restrict__ partials, double* __restrict__ out,
+                                                        const int32_t* __restrict__ done) {
+  if (done != nullptr && *done) return;
+  __shared__ double lds[1024 / 64];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 1024) acc += partials[i];
+  const double t = femo_block_sum<1024>(acc, lds);
+  if (threadIdx.x == 0) out[0] = t;
+}
+
+// Which finest-lattice nodes do several ranks touch?  A rank's restriction only reaches the nodes
+// around its own vertices and its prolongation only reads those, so between ranks it is enough to
+// complete the sums on the nodes that more than one rank touches (the layers along the partition
+// interfaces, ~10 % of the lattice for 8 blocks of the cube); the next coarser level is summed
+// densely because every rank runs the coarse hierarchy on the whole lattice.  Collective, once per mesh.
+static int pc_setup_shared(femo_mesh* m) {
+  femo_pc* pc = m->pc;
+  if (pc->shared_ready) return 0;
+  femo_ctx* ctx = m->ctx;
+  hipStream_t st = ctx->stream;
+  const int nl = pc->n_levels;
+  LatticeLevel& F = pc->L[nl - 1];
+  const Lat lat = make_lat(pc, F);
+  // touched pattern: restrict the constant 1 with unit weights (all interpolation weights are >= 0)
+  double* ones = nullptr;
+  FEMO_HIP_CHECK(hipMalloc(&ones, std::max<int64_t>(m->n_vert, 1) * sizeof(double)));
+  hipLaunchKernelGGL(k_fill_ones, dim3(lat_grid(m->n_vert)), dim3(256), 0, st, m->n_vert, ones);
+  hipLaunchKernelGGL(k_fill_ones, dim3(lat_grid(m->n_rows)), dim3(256), 0, st, std::max<int64_t>(m->n_rows, 0), pc->d_w_sorted);
+  FEMO_HIP_CHECK(hipMemsetAsync(F.g, 0, F.nodes * sizeof(double), st));
+  if (pc->n_bricks > 0) {
+    const unsigned gb = (unsigned)std::min<int64_t>(pc->n_bricks, 256 * 64);
+    if (pc->dim == 3)
+      hipLaunchKernelGGL(k_restrict_bricks<3>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, ones, pc->d_w_sorted, F.g, 0, (const int32_t*)nullptr);
+    else
+      hipLaunchKernelGGL(k_restrict_bricks<2>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, ones, pc->d_w_sorted, F.g, 0, (const int32_t*)nullptr);
+  }
+  hipLaunchKernelGGL(k_mark_touched, dim3(lat_grid(F.nodes)), dim3(256), 0, st, F.nodes, F.g, F.e);
+  FEMO_HIP_CHECK(hipGetLastError());
+  std::vector<double> mine((size_t)F.nodes), cnt((size_t)F.nodes);
+  FEMO_HIP_CHECK(hipMemcpyAsync(mine.data(), F.e, F.nodes * sizeof(double), hipMemcpyDeviceToHost, st));
+  FEMO_TRY(femo_coll_allreduce(ctx, F.e, F.nodes, st));
+  FEMO_HIP_CHECK(hipMemcpyAsync(cnt.data(), F.e, F.nodes * sizeof(double), hipMemcpyDeviceToHost, st));
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  (void)hipFree(ones);
+  std::vector<int32_t> shared;
+  std::vector<double> weight((size_t)F.nodes, 0.0);
+  for (int64_t i = 0; i < F.nodes; ++i) {
+    if (cnt[(size_t)i] >= 1.5) shared.push_back((int32_t)i);
+    if (mine[(size_t)i] != 0.0) weight[(size_t)i] = 1.0 / cnt[(size_t)i];
+  }
+  pc->n_shared = (int64_t)shared.size();
+  const int64_t n_coarse = nl >= 2 ? pc->L[nl - 2].nodes : 0;
+  FEMO_HIP_CHECK(hipMalloc(&pc->d_shared_idx, std::max<size_t>(shared.size(), 1) * sizeof(int32_t)));
+  FEMO_HIP_CHECK(hipMalloc(&pc->d_dot_weight, F.nodes * sizeof(double)));
+  FEMO_HIP_CHECK(hipMalloc(&pc->d_xbuf, std::max<int64_t>(pc->n_shared + n_coarse, 1) * sizeof(double)));
+  FEMO_HIP_CHECK(hipMalloc(&pc->d_dot_scalar, sizeof(double)));
+  if (!shared.empty()) FEMO_HIP_CHECK(hipMemcpy(pc->d_shared_idx, shared.data(), shared.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  FEMO_HIP_CHECK(hipMemcpy(pc->d_dot_weight, weight.data(), F.nodes * sizeof(double), hipMemcpyHostToDevice));
+  FEMO_HIP_CHECK(hipMemsetAsync(F.g, 0, F.nodes * sizeof(double), st));
+  FEMO_HIP_CHECK(hipMemsetAsync(F.e, 0, F.nodes * sizeof(double), st));
+  pc->shared_ready = true;
+  return 0;
 }
 
 // coef arrays for the Dirichlet mask identified by `key` (mask == nullptr: no Dirichlet vertices)
@@ -614,7 +714,18 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
     else
       hipLaunchKernelGGL(k_restrict_bricks<2>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, rh, pc->d_w_sorted, F.g, nf, done);
   }
-  if (ctx->nranks > 1) {   // one all-reduce over the contiguous accumulators of the finest nf+1 levels
+  const bool sparse = ctx->nranks > 1 && pc->shared_ready;
+  if (sparse) {
+    // one all-reduce per apply: the finest-level nodes several ranks touch + the whole next level
+    double* gc = nf >= 1 ? pc->L[nl - 2].g : nullptr;
+    const int64_t n_coarse = nf >= 1 ? pc->L[nl - 2].nodes : 0;
+    const int64_t count = pc->n_shared + n_coarse;
+    if (count > 0) {
+      hipLaunchKernelGGL(k_pack_shared, dim3(lat_grid(count)), dim3(256), 0, st, pc->n_shared, pc->d_shared_idx, F.g, n_coarse, gc, pc->d_xbuf, done);
+      FEMO_TRY(femo_coll_allreduce(ctx, pc->d_xbuf, count, st));
+      hipLaunchKernelGGL(k_unpack_shared, dim3(lat_grid(count)), dim3(256), 0, st, pc->n_shared, pc->d_shared_idx, F.g, n_coarse, gc, pc->d_xbuf, done);
+    }
+  } else if (ctx->nranks > 1) {   // dense: the contiguous accumulators of the finest nf+1 levels
     double* first = pc->L[nl - 1 - nf].g;
     const int64_t count = (F.g + F.nodes) - first;
     FEMO_TRY(femo_coll_allreduce(ctx, first, count, st));
@@ -654,13 +765,22 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
     const double* ec = l > 0 ? pc->L[l - 1].e : nullptr;
     const int* nc = l > 0 ? pc->L[l - 1].n : Fi.n;
     double* dots = (l == nl - 1 && mode != 0) ? pc->d_dot_partials : nullptr;
-    hipLaunchKernelGGL(k_lattice_prolong, dim3(lat_grid(Fi.nodes)), dim3(256), 0, st, Fi.n[0], Fi.n[1], Fi.n[2], nc[0], nc[1], nc[2], pc->dim, ec, Fi.coef, Fi.g, l >= nl - 1 - nf ? 1 : 0, Fi.e, dots, done);
+    const double* dotw = (l == nl - 1 && sparse) ? pc->d_dot_weight : nullptr;
+    hipLaunchKernelGGL(k_lattice_prolong, dim3(lat_grid(Fi.nodes)), dim3(256), 0, st, Fi.n[0], Fi.n[1], Fi.n[2], nc[0], nc[1], nc[2], pc->dim, ec, Fi.coef, Fi.g, l >= nl - 1 - nf ? 1 : 0, Fi.e, dots, dotw, done);
   }
-  const int nb_dot = (int)lat_grid(F.nodes);
+  int nb_dot = (int)lat_grid(F.nodes);
+  const double* dot_global = nullptr;
+  if (sparse && mode != 0) {
+    // each rank only holds the finest level on the nodes it touches: its weighted dot is a partial sum
+    hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(1024), 0, st, nb_dot, pc->d_dot_partials, pc->d_dot_scalar, done);
+    FEMO_TRY(femo_coll_allreduce(ctx, pc->d_dot_scalar, 1, st));
+    dot_global = pc->d_dot_scalar;
+    nb_dot = 0;
+  }
   if (pc->dim == 3)
-    hipLaunchKernelGGL(k_prolong_mesh<3>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, s, mask, F.e, out, mode, nb_dot, pc->d_dot_partials, rho, gamma_cur, gamma_nxt, done);
+    hipLaunchKernelGGL(k_prolong_mesh<3>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, s, mask, F.e, out, mode, nb_dot, pc->d_dot_partials, dot_global, rho, gamma_cur, gamma_nxt, done);
   else
-    hipLaunchKernelGGL(k_prolong_mesh<2>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, s, mask, F.e, out, mode, nb_dot, pc->d_dot_partials, rho, gamma_cur, gamma_nxt, done);
+    hipLaunchKernelGGL(k_prolong_mesh<2>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, s, mask, F.e, out, mode, nb_dot, pc->d_dot_partials, dot_global, rho, gamma_cur, gamma_nxt, done);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -668,6 +788,7 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
 // start of a solve: per-vertex weights of the current operator; the atomically accumulated g arrays must be zero
 int femo_pc_begin(femo_mesh* m, const double* s, const uint8_t* mask) {
   femo_pc* pc = m->pc;
+  if (m->ctx->nranks > 1 && getenv("FEMO_BPX_DENSE_ALLREDUCE") == nullptr) FEMO_TRY(pc_setup_shared(m));   // once; uses d_w_sorted as scratch
   if (m->n_rows > 0) {
     hipLaunchKernelGGL(k_pc_weights, dim3(lat_grid(m->n_rows)), dim3(256), 0, m->ctx->stream, m->n_rows, pc->d_perm, s, mask, pc->d_w_sorted);
     FEMO_HIP_CHECK(hipGetLastError());

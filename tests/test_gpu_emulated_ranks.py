@@ -194,3 +194,47 @@ def test_bench_cycle_on_two_emulated_ranks():
     assert np.all(seen == 1)                                                   # every cell owned by exactly one rank
     assert np.abs(u - ref["u"]).max() < 1e-10 * np.abs(ref["u"]).max()
     assert np.abs(g - ref["grad"]).max() < 1e-10 * np.abs(ref["grad"]).max()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_sparse_and_dense_lattice_exchange_agree(world, monkeypatch):
+    """Partitioned BPX exchanges only the finest-lattice nodes several ranks touch (+ the next level
+    densely); FEMO_BPX_DENSE_ALLREDUCE=1 sums the whole lattice instead.  Same operator: the
+    preconditioned vector agrees to rounding and so do the iteration counts."""
+    from femo_amd import engine as E
+    m = fo.unit_cube_mesh(12, 0.2)
+    part = rcb_partition(m.x, world)
+    r_global = np.random.default_rng(11).standard_normal(m.n_vert)
+    out = {}
+    for mode in ("sparse", "dense"):
+        if mode == "dense":
+            monkeypatch.setenv("FEMO_BPX_DENSE_ALLREDUCE", "1")
+        else:
+            monkeypatch.delenv("FEMO_BPX_DENSE_ALLREDUCE", raising=False)
+
+        def rank_fn(rank, ctx):
+            L, dm, A, b, _, _ = _local_problem(ctx, m, part, rank, world, seed=3)
+            r = E.Vec(ctx, len(L.x)).set(np.concatenate([r_global[L.vert_global[:L.n_owned]], np.zeros(len(L.x) - L.n_owned)]))
+            z = A.pc_apply(r, E.Vec(ctx, len(L.x))).get(L.n_owned)
+            x = E.Vec(ctx, len(L.x))
+            info = A.solve_cg(b, x, rtol=1e-14, pc="bpx")
+            return dict(gid=L.vert_global[:L.n_owned], z=z, its=info.iterations, x=x.get(L.n_owned))
+
+        res = _run_ranks(world, rank_fn)
+        z, x = np.zeros(m.n_vert), np.zeros(m.n_vert)
+        for r in res:
+            z[r["gid"]] = r["z"]
+            x[r["gid"]] = r["x"]
+        out[mode] = (z, x, res[0]["its"])
+    monkeypatch.delenv("FEMO_BPX_DENSE_ALLREDUCE", raising=False)
+    assert np.abs(out["sparse"][0] - out["dense"][0]).max() < 1e-12 * np.abs(out["dense"][0]).max()
+    assert np.abs(out["sparse"][1] - out["dense"][1]).max() < 1e-11 * np.abs(out["dense"][1]).max()
+    assert abs(out["sparse"][2] - out["dense"][2]) <= 1
+    # and the distributed operator is the serial oracle operator
+    from oracle import bpx_oracle as bo
+    bd = fo.boundary_vertices_box(m.x)
+    pinned = np.zeros(m.n_vert, bool)
+    pinned[bd] = True
+    diag = fo.eliminate_bc(fo.stiffness(m), bd).diagonal()
+    ref = bo.BPX(m.x, diag, pinned).apply(r_global)
+    assert np.abs(out["sparse"][0] - ref).max() < 1e-12 * np.abs(ref).max()
