@@ -573,18 +573,20 @@ __global__ void k_mark_touched(int64_t n, const double* __restrict__ g, double* 
 __global__ void k_fill_ones(int64_t n, double* __restrict__ a) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a[i] = 1.0;
 }
-// buf = [g_fine[shared_idx] | g_coarse]
+// buf = [g_fine[shared_idx] | g_coarse | *piggy]: a scalar of the caller rides along (r.r of the PCG loop)
 __global__ void k_pack_shared(int64_t n_shared, const int32_t* __restrict__ idx, const double* __restrict__ g_fine,
-                              int64_t n_coarse, const double* __restrict__ g_coarse, double* __restrict__ buf,
-                              const int32_t* __restrict__ done) {
+                              int64_t n_coarse, const double* __restrict__ g_coarse, const double* __restrict__ piggy,
+                              double* __restrict__ buf, const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_shared + n_coarse; i += (int64_t)gridDim.x * blockDim.x)
     buf[i] = i < n_shared ? g_fine[idx[i]] : g_coarse[i - n_shared];
+  if (piggy != nullptr && blockIdx.x == 0 && threadIdx.x == 0) buf[n_shared + n_coarse] = *piggy;
 }
 __global__ void k_unpack_shared(int64_t n_shared, const int32_t* __restrict__ idx, double* __restrict__ g_fine,
-                                int64_t n_coarse, double* __restrict__ g_coarse, const double* __restrict__ buf,
-                                const int32_t* __restrict__ done) {
+                                int64_t n_coarse, double* __restrict__ g_coarse, double* __restrict__ piggy,
+                                const double* __restrict__ buf, const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
+  if (piggy != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *piggy = buf[n_shared + n_coarse];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_shared + n_coarse; i += (int64_t)gridDim.x * blockDim.x) {
     if (i < n_shared) g_fine[idx[i]] = buf[i];
     else g_coarse[i - n_shared] = buf[i];
@@ -644,7 +646,7 @@ static int pc_setup_shared(femo_mesh* m) {
   const int64_t n_coarse = nl >= 2 ? pc->L[nl - 2].nodes : 0;
   FEMO_HIP_CHECK(hipMalloc(&pc->d_shared_idx, std::max<size_t>(shared.size(), 1) * sizeof(int32_t)));
   FEMO_HIP_CHECK(hipMalloc(&pc->d_dot_weight, F.nodes * sizeof(double)));
-  FEMO_HIP_CHECK(hipMalloc(&pc->d_xbuf, std::max<int64_t>(pc->n_shared + n_coarse, 1) * sizeof(double)));
+  FEMO_HIP_CHECK(hipMalloc(&pc->d_xbuf, (pc->n_shared + n_coarse + 1) * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&pc->d_dot_scalar, sizeof(double)));
   if (!shared.empty()) FEMO_HIP_CHECK(hipMemcpy(pc->d_shared_idx, shared.data(), shared.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   FEMO_HIP_CHECK(hipMemcpy(pc->d_dot_weight, weight.data(), F.nodes * sizeof(double), hipMemcpyHostToDevice));
@@ -698,7 +700,8 @@ static int pc_prepare(femo_mesh* m, const uint8_t* mask, uint64_t key) {
 
 // zh = M^-1 rh in scaled variables; partials[block] = rh.zh per block (gv blocks)
 int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const double* s, const double* rh, double* out,
-                  int mode, const double* rho, const double* gamma_cur, double* gamma_nxt, const int32_t* done, int gv) {
+                  int mode, double* rho, const double* gamma_cur, double* gamma_nxt, const int32_t* done, int gv,
+                  bool rho_is_partial) {
   femo_pc* pc = m->pc;
   femo_ctx* ctx = m->ctx;
   hipStream_t st = ctx->stream;
@@ -720,11 +723,15 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
     double* gc = nf >= 1 ? pc->L[nl - 2].g : nullptr;
     const int64_t n_coarse = nf >= 1 ? pc->L[nl - 2].nodes : 0;
     const int64_t count = pc->n_shared + n_coarse;
-    if (count > 0) {
-      hipLaunchKernelGGL(k_pack_shared, dim3(lat_grid(count)), dim3(256), 0, st, pc->n_shared, pc->d_shared_idx, F.g, n_coarse, gc, pc->d_xbuf, done);
-      FEMO_TRY(femo_coll_allreduce(ctx, pc->d_xbuf, count, st));
-      hipLaunchKernelGGL(k_unpack_shared, dim3(lat_grid(count)), dim3(256), 0, st, pc->n_shared, pc->d_shared_idx, F.g, n_coarse, gc, pc->d_xbuf, done);
+    // rho_is_partial: *rho holds this rank's part of rh.rh; it rides in the same all-reduce
+    double* piggy = rho_is_partial ? rho : nullptr;
+    if (count > 0 || piggy != nullptr) {
+      hipLaunchKernelGGL(k_pack_shared, dim3(lat_grid(std::max<int64_t>(count, 1))), dim3(256), 0, st, pc->n_shared, pc->d_shared_idx, F.g, n_coarse, gc, piggy, pc->d_xbuf, done);
+      FEMO_TRY(femo_coll_allreduce(ctx, pc->d_xbuf, count + (piggy ? 1 : 0), st));
+      hipLaunchKernelGGL(k_unpack_shared, dim3(lat_grid(std::max<int64_t>(count, 1))), dim3(256), 0, st, pc->n_shared, pc->d_shared_idx, F.g, n_coarse, gc, piggy, pc->d_xbuf, done);
     }
+  } else if (rho_is_partial) {
+    FEMO_REQUIRE(false, "femo_pc_apply: a partial rho needs the sparse exchange (femo_pc_can_piggyback)");
   } else if (ctx->nranks > 1) {   // dense: the contiguous accumulators of the finest nf+1 levels
     double* first = pc->L[nl - 1 - nf].g;
     const int64_t count = (F.g + F.nodes) - first;
@@ -799,6 +806,9 @@ int femo_pc_begin(femo_mesh* m, const double* s, const uint8_t* mask) {
   FEMO_HIP_CHECK(hipMemsetAsync(first, 0, count * sizeof(double), m->ctx->stream));
   return 0;
 }
+
+// can the PCG loop hand its partial rh.rh to femo_pc_apply instead of all-reducing it itself?
+bool femo_pc_can_piggyback(const femo_mesh* m) { return m->pc != nullptr && m->ctx->nranks > 1 && m->pc->shared_ready; }
 
 int femo_pc_levels(const femo_mesh* m, int* n_levels, int64_t* finest_nodes) {
   if (!m->pc) { *n_levels = 0; *finest_nodes = 0; return 0; }

@@ -271,7 +271,9 @@ void femo_pc_destroy(femo_mesh* m);
 // mode 0: out = M^-1 rh (scaled variables).  mode 1: out = M^-1 rh + beta out with beta = gamma'/(*gamma_cur),
 // gamma' = rh.M^-1 rh = *rho + g_L.e_L, written to *gamma_nxt.  mode 2: like 1 with beta = 0.
 int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const double* s, const double* rh, double* out,
-                  int mode, const double* rho, const double* gamma_cur, double* gamma_nxt, const int32_t* done, int gv);
+                  int mode, double* rho, const double* gamma_cur, double* gamma_nxt, const int32_t* done, int gv,
+                  bool rho_is_partial = false);
+bool femo_pc_can_piggyback(const femo_mesh* m);
 int femo_pc_begin(femo_mesh* m, const double* s, const uint8_t* mask);
 int femo_pc_levels(const femo_mesh* m, int* n_levels, int64_t* finest_nodes);
 int femo_reduce_to_host(femo_ctx* ctx, int nblocks, int nsums, double* host_out);

@@ -1085,6 +1085,7 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
   const int n_sample = 4, sample_from = 2;
   int n_ev = 0;
   const bool local_scalars = !multi && m->n_nbr == 0;
+  const bool piggyback = multi && femo_pc_can_piggyback(m);
   const int batch = opts->check_every > 0 ? std::min(opts->check_every, 8) : 8;
   int it = 0, polled = 0;
   bool done = false;
@@ -1117,10 +1118,16 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
         FEMO_TRY(allreduce1(S + S_DELTA));
         hipLaunchKernelGGL(k_pcg_xr, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, 0, Pd, S, w.q, w.p, w.r, w.xh, Pr, ctx->d_flags);
         hipLaunchKernelGGL(k_pcg_fold, dim3(1), dim3(1024), 0, st, gv, Pr, 0, (const double*)nullptr, S + S_RHO, ctx->d_flags);
-        FEMO_TRY(allreduce1(S + S_RHO));
-        hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(1024), 0, st, it, 0, Pr, S, ctx->d_flags);
-        // rho and the lattice accumulators are already global, so gamma' needs no all-reduce of its own
-        FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, w.p, 1, S + S_RHO, S + S_GAMMA + cur, S + S_GAMMA + nxt, ctx->d_flags, gv));
+        if (piggyback) {
+          // the rank's part of rh.rh rides in the lattice all-reduce of the preconditioner; the stopping
+          // test then runs after the apply (one wasted apply in the last iteration, one collective less in all)
+          FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, w.p, 1, S + S_RHO, S + S_GAMMA + cur, S + S_GAMMA + nxt, ctx->d_flags, gv, true));
+          hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(1024), 0, st, it, 0, Pr, S, ctx->d_flags);
+        } else {
+          FEMO_TRY(allreduce1(S + S_RHO));
+          hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(1024), 0, st, it, 0, Pr, S, ctx->d_flags);
+          FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, w.p, 1, S + S_RHO, S + S_GAMMA + cur, S + S_GAMMA + nxt, ctx->d_flags, gv));
+        }
       }
     }
     FEMO_HIP_CHECK(hipGetLastError());
