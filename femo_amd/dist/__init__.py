@@ -53,6 +53,8 @@ def partition_mesh(mesh: Mesh, rank: int, nranks: int) -> DistMesh:
     local = build_local_mesh(mesh.x, mesh.conn, part, rank, nranks)
     dm = DistMesh(local, mesh.n_vert, mesh.n_cell, bbox=(mesh.x.min(axis=0), mesh.x.max(axis=0)))
     dm._occupancy = mesh.lattice_occupancy()      # of the WHOLE mesh: every rank must pick the same preconditioner
+    # exterior facets are those of the whole mesh: the cut faces of the partition are not a boundary
+    dm._bfacets = np.ascontiguousarray(mesh.boundary_facet_mask()[local.cell_global])
     return dm
 
 

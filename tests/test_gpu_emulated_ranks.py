@@ -238,3 +238,47 @@ def test_sparse_and_dense_lattice_exchange_agree(world, monkeypatch):
     diag = fo.eliminate_bc(fo.stiffness(m), bd).diagonal()
     ref = bo.BPX(m.x, diag, pinned).apply(r_global)
     assert np.abs(out["sparse"][0] - ref).max() < 1e-12 * np.abs(ref).max()
+
+
+def test_nitsche_facets_on_partitioned_meshes():
+    """Weak (Nitsche) boundary terms on 2 emulated ranks: the exterior facets are those of the WHOLE
+    mesh -- the cut faces of the partition must not act as a boundary (partition_mesh hands every rank
+    the global facet mask of its cells).  Newton system of the nonlinear Poisson form vs the oracle."""
+    from femo_amd import engine as E
+    from femo_amd.dist import partition_mesh
+    from femo_amd.fea.mesh import Mesh
+    world = 2
+    om = fo.unit_square_mesh(16, 0.15)
+    gmesh = Mesh(om.x, om.conn)
+    bm = fo.boundary_facets(om)
+    rng = np.random.default_rng(6)
+    u = 0.3 * np.sin(3 * om.x[:, 0]) + 0.2
+    f = rng.standard_normal(om.n_cell)
+    uex = fo.u_exact_nl(om.x)
+    J_ref = fo.nl_jacobian(om, u, bm, 10.0).tocsc()
+    r_ref = fo.nl_residual(om, u, f, uex, bm, 10.0)
+    x_ref = spla.spsolve(J_ref, r_ref)
+
+    def rank_fn(rank, ctx):
+        mesh = partition_mesh(gmesh, rank, world)
+        L = mesh.local
+        assert np.array_equal(mesh.boundary_facet_mask(), bm[L.cell_global])
+        dm = mesh.device(ctx)
+        dm.set_boundary_facets(mesh.boundary_facet_mask())
+        nloc = len(L.x)
+        ul = np.concatenate([u[L.vert_global[:L.n_owned]], np.full(nloc - L.n_owned, 1e30)])      # ghosts refreshed by the library
+        U, F, UEX = E.Vec(ctx, nloc).set(ul), E.Vec(ctx, len(L.conn)).set(f[L.cell_global]), E.Vec(ctx, nloc).set(uex[L.vert_global])
+        J, b = E.Mat(dm), E.Vec(ctx, L.n_owned)
+        E.assemble_system(dm, 1, [10.0], U, F, None, J, None, b, aux=UEX)
+        x = E.Vec(ctx, nloc)
+        info = J.solve_cg(b, x, rtol=1e-14, pc="bpx")
+        return dict(gid=L.vert_global[:L.n_owned], b=b.get(), x=x.get(L.n_owned), conv=info.converged)
+
+    res = _run_ranks(world, rank_fn)
+    b, x = np.zeros(om.n_vert), np.zeros(om.n_vert)
+    for r in res:
+        assert r["conv"] == 1
+        b[r["gid"]] = r["b"]
+        x[r["gid"]] = r["x"]
+    assert np.abs(b - r_ref).max() < 1e-12 * np.abs(r_ref).max()
+    assert np.abs(x - x_ref).max() < 1e-9 * np.abs(x_ref).max()
