@@ -335,3 +335,47 @@ def test_nonlinear_cycle_on_two_emulated_ranks():
         assert abs(r["J"] - ref["J"][0]) < 1e-10 * abs(ref["J"][0])
     assert np.abs(u - ref["u"]).max() < 1e-10 * np.abs(ref["u"]).max()
     assert np.abs(g - ref["grad"]).max() < 1e-10 * np.abs(ref["grad"]).max()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bicgstab_on_emulated_ranks(world):
+    """Non-symmetric operator (unsymmetric Nitsche) on a partitioned mesh: BiCGSTAB with halo exchanges
+    and all-reduced inner products against LU.  The explicit transpose of a row-partitioned operator
+    needs matrix entries owned by other ranks; the library refuses it loudly (a limit of the
+    partitioned path)."""
+    from femo_amd import engine as E
+    from femo_amd.dist import partition_mesh
+    from femo_amd.fea.mesh import Mesh
+    om = fo.unit_square_mesh(20, 0.2)
+    gmesh = Mesh(om.x, om.conn)
+    gmesh.lattice_occupancy()
+    bm = fo.boundary_facets(om)
+    rng = np.random.default_rng(9)
+    u, f, uex = 0.3 * rng.standard_normal(om.n_vert), rng.standard_normal(om.n_cell), fo.u_exact_nl(om.x)
+    Jo = fo.nl_jacobian(om, u, bm, 0.0, -1.0)
+    rhs = rng.standard_normal(om.n_vert)
+    x_ref = spla.splu(Jo.tocsc()).solve(rhs)
+
+    def rank_fn(rank, ctx):
+        mesh = partition_mesh(gmesh, rank, world)
+        L = mesh.local
+        dm = mesh.device(ctx)
+        dm.set_boundary_facets(mesh.boundary_facet_mask())
+        nloc = len(L.x)
+        ul = np.concatenate([u[L.vert_global[:L.n_owned]], np.zeros(nloc - L.n_owned)])
+        U, F, UEX = E.Vec(ctx, nloc).set(ul), E.Vec(ctx, len(L.conn)).set(f[L.cell_global]), E.Vec(ctx, nloc).set(uex[L.vert_global])
+        J = E.Mat(dm)
+        E.assemble_jacobian(dm, 1, [0.0, -1.0], U, F, None, J, aux=UEX)
+        from femo_amd._lib import FemoError
+        B, X, XT = E.Vec(ctx, L.n_owned).set(rhs[L.vert_global[:L.n_owned]]), E.Vec(ctx, nloc), E.Vec(ctx, nloc)
+        i1 = J.solve_bicgstab(B, X, rtol=1e-13)
+        with pytest.raises(FemoError, match="owned by another rank"):
+            J.solve_bicgstab(B, XT, transpose=True, rtol=1e-13)
+        return dict(gid=L.vert_global[:L.n_owned], x=X.get(L.n_owned), conv=i1.converged)
+
+    res = _run_ranks(world, rank_fn)
+    x = np.zeros(om.n_vert)
+    for r in res:
+        assert r["conv"] == 1
+        x[r["gid"]] = r["x"]
+    assert np.abs(x - x_ref).max() < 1e-9 * np.abs(x_ref).max()
