@@ -379,3 +379,49 @@ def test_bicgstab_on_emulated_ranks(world):
         assert r["conv"] == 1
         x[r["gid"]] = r["x"]
     assert np.abs(x - x_ref).max() < 1e-9 * np.abs(x_ref).max()
+
+
+def test_projection_on_two_emulated_ranks():
+    """L2 projection onto CG1 (utils_dolfinx.py:549-583) on a partitioned mesh: consistent mass matrix
+    (Jacobi-CG with halo + all-reduces), lumped mass, gradient magnitude of a CG1 function."""
+    from femo_amd.dist import partition_mesh
+    from femo_amd.fea import utils_hip
+    from femo_amd.fea.fea_hip import Function, FunctionSpace, GradientMagnitude, project, setFuncArray
+    from femo_amd.fea.mesh import createUnitSquareMesh
+    world, n = 2, 15
+    gmesh = createUnitSquareMesh(n, 0.2)
+    gmesh.lattice_occupancy()
+    gmesh.boundary_facet_mask()
+    om = fo.unit_square_mesh(n, 0.2)
+    rng = np.random.default_rng(8)
+    un, wc = rng.standard_normal(om.n_vert), rng.uniform(0.5, 1.5, om.n_cell)
+
+    def rank_fn(rank, ctx):
+        utils_hip.set_context(ctx, thread_local=True)
+        try:
+            mesh = partition_mesh(gmesh, rank, world)
+            L = mesh.local
+            Vu, Vf = FunctionSpace(mesh, ('CG', 1)), FunctionSpace(mesh, ('DG', 0))
+            u, w, out = Function(Vu), Function(Vf), Function(Vu)
+            setFuncArray(u, un[L.vert_global])
+            setFuncArray(w, wc[L.cell_global])
+            got = {}
+            project(w, out)
+            got["dg0"] = out.vector.getArray()[:L.n_owned].copy()
+            project(w, out, lump_mass=True)
+            got["dg0_lumped"] = out.vector.getArray()[:L.n_owned].copy()
+            project(GradientMagnitude(u), out)
+            got["grad"] = out.vector.getArray()[:L.n_owned].copy()
+            got["gid"] = L.vert_global[:L.n_owned]
+            return got
+        finally:
+            utils_hip.set_context(None, thread_local=True)
+
+    res = _run_ranks(world, rank_fn)
+    refs = {"dg0": fo.project_l2(om, cell_values=wc), "dg0_lumped": fo.project_l2(om, cell_values=wc, lump_mass=True),
+            "grad": fo.project_l2(om, cell_values=fo.grad_magnitude(om, un))}
+    for key, ref in refs.items():
+        full = np.zeros(om.n_vert)
+        for r in res:
+            full[r["gid"]] = r[key]
+        assert np.abs(full - ref).max() < 1e-9 * np.abs(ref).max(), key
