@@ -30,10 +30,24 @@ class DistMesh(Mesh):
         self.n_vert_global = int(n_vert_global)
         self.n_cell_global = int(n_cell_global)
         self.bbox = bbox        # (lo, hi) of the whole mesh: every rank builds the same BPX lattice
+        self._global_mesh = None
 
     @property
     def n_owned(self) -> int:
         return self.local.n_owned
+
+    def boundary_facet_mask(self) -> np.ndarray:
+        """Exterior facets are those of the WHOLE mesh: the cut faces of the partition are not a
+        boundary (a facet seen once among the local cells may have its other cell on another rank).
+        Computed on first use from the global mesh -- only forms with facet terms (Nitsche) ask."""
+        if getattr(self, "_bfacets", None) is None:
+            g = getattr(self, "_global_mesh", None)
+            if g is None:
+                if self.local.nranks > 1:
+                    raise RuntimeError("DistMesh without its global mesh cannot tell exterior facets from partition cuts")
+                return super().boundary_facet_mask()
+            self._bfacets = np.ascontiguousarray(g.boundary_facet_mask()[self.local.cell_global])
+        return self._bfacets
 
     def device(self, ctx):
         if self._device is None or self._ctx is not ctx:
@@ -53,8 +67,7 @@ def partition_mesh(mesh: Mesh, rank: int, nranks: int) -> DistMesh:
     local = build_local_mesh(mesh.x, mesh.conn, part, rank, nranks)
     dm = DistMesh(local, mesh.n_vert, mesh.n_cell, bbox=(mesh.x.min(axis=0), mesh.x.max(axis=0)))
     dm._occupancy = mesh.lattice_occupancy()      # of the WHOLE mesh: every rank must pick the same preconditioner
-    # exterior facets are those of the whole mesh: the cut faces of the partition are not a boundary
-    dm._bfacets = np.ascontiguousarray(mesh.boundary_facet_mask()[local.cell_global])
+    dm._global_mesh = mesh                        # for boundary_facet_mask(), computed only if a form needs facets
     return dm
 
 
