@@ -1,0 +1,26 @@
+"""A handful of dispatches of the PCG kernels at C4 for hardware-counter passes (rocprofv3 --pmc ...):
+one BPX solve capped at 3 iterations + one fused assembly pass.  Keep it small: PMC serialises dispatches."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from femo_amd import engine as E
+from femo_amd.engine import Context, Vec
+from femo_amd.fea.mesh import createUnitCubeMesh
+
+n3 = int(sys.argv[1]) if len(sys.argv) > 1 else 215
+ctx = Context(0)
+mesh = createUnitCubeMesh(n3)
+dm = mesh.device(ctx)
+n = mesh.n_vert
+dofs = np.nonzero(np.any(np.isclose(mesh.x, 0.0) | np.isclose(mesh.x, 1.0), axis=1))[0]
+bc = E.DirichletSet(dm, dofs, np.zeros(len(dofs)))
+A, b = E.Mat(dm), Vec(ctx, n)
+f = Vec(ctx, mesh.n_cell).set(1.0 + np.random.default_rng(0).random(mesh.n_cell))
+E.assemble_system(dm, 0, None, Vec(ctx, n).fill(0.0), f, bc, None, A, b)
+x = Vec(ctx, n)
+info = A.solve_cg(b, x, rtol=1e-14, max_it=3, pc="bpx", check_every=3)
+ctx.sync()
+print("iterations", info.iterations)
