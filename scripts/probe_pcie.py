@@ -2,7 +2,7 @@
 import sys
 import time
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 
 from femo_amd.engine import Context, Vec

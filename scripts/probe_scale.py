@@ -1,7 +1,7 @@
 """Ad-hoc scale probe (not the benchmark): times setup, assembly, SpMV and CG."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from oracle import femo_oracle as fo
 from femo_amd import engine as E
 

@@ -2,7 +2,7 @@
 import os
 import sys
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 
 from femo_amd import engine as E

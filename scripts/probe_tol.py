@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import sys; sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))); sys.path.insert(0, "tests")
 import numpy as np
 from oracle import femo_oracle as fo
 from femo_amd.fea import utils_hip

@@ -1,7 +1,7 @@
 """Where does the non-CG time of one cycle go?  Wraps the utils_hip entry points with
 synchronising timers (diagnostic only)."""
 import sys, time, os, functools, collections
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 from femo_amd.engine import Context, DeviceArray, Vec
 from femo_amd.fea import utils_hip
