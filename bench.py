@@ -12,9 +12,11 @@ One *step* = one full cycle of SURVEY.md section 8(d) through the operator surfa
              compute_jacvec_product 'rev' (dR/df^T lambda)   -> dJ/df
 
 Every step gets a different synthetic source f_k and a cold start u = 0, so no
-result of a previous step can be reused.  Inputs and outputs stay in HBM
-(``DeviceArray``); the PCIe-inclusive rate is measured separately and reported
-in the ``pcie_inclusive`` field (never as ``value``).
+result of a previous step can be reused.  ``value`` is the SURVEY.md 8(d) metric:
+NumPy arrays at the operator boundary, host-to-device and device-to-host traffic
+inside the timed region.  ``device_resident`` is the same cycle with inputs and
+outputs kept in HBM (round 1's headline), ``pageable_boundary`` the cycle with a
+driver that keeps every array in pageable memory.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -47,7 +49,9 @@ def parse():
     p.add_argument("--jitter", type=float, default=0.0,
                    help="interior vertex jitter in units of h (SURVEY.md 8(d): 0.2); default: structured grid")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-n", type=int, default=128, help="cube resolution of the bounded CPU sample")
+    p.add_argument("--cpu-n", type=int, default=0, help="cube resolution of the CPU baseline (0: the benchmark's own size, one cycle)")
+    p.add_argument("--permute", action="store_true",
+                   help="random vertex numbering: no regular SELL slices, scattered gathers (the unstructured-mesh rate)")
     p.add_argument("--no-pcie", action="store_true")
     p.add_argument("--pc", choices=("bpx", "jacobi"), default="bpx",
                    help="CG preconditioner: bpx = Jacobi + auxiliary-lattice multilevel correction (default)")
@@ -82,7 +86,7 @@ def source_fields(mesh, count: int, seed: int = 20240807):
     return out
 
 
-def build_problem(mesh, device: bool):
+def build_problem(mesh, device: bool, pinned: bool = True):
     """The set-up of examples/poisson_opt/run_poisson_opt.py:95-179 on the HIP mirror (3-D)."""
     from femo_amd.csdl_opt.fea_model import FEAModel
     from femo_amd.csdl_opt.simulator import Simulator
@@ -116,16 +120,18 @@ def build_problem(mesh, device: bool):
     model.create_input('f', shape=fea.inputs_dict['f']['shape'], val=0.086)
     model.add_design_variable('f')
     model.add_objective('l2_functional', scaler=1e5)
-    return Simulator(model, device=device), fea
+    return Simulator(model, device=device, pinned=pinned), fea
 
 
-def one_cycle(sim, fea, f_value):
+def one_cycle(sim, fea, f_value, u0=None):
+    """One step: new source in, cold start (nothing carried over), forward run, reverse sweep.
+    Host mode: ``f_value`` / ``u0`` are NumPy arrays and the gradient comes back as one."""
     sim['f'] = f_value
-    fea.states_dict['u']['function'].vector.set(0.0)          # cold start: nothing carried over
-    if 'u' in sim.values and hasattr(sim.values['u'], 'vec'):
+    fea.states_dict['u']['function'].vector.set(0.0)
+    if sim.device:
         sim.values['u'].vec.fill(0.0)
-    elif 'u' in sim.values:
-        sim.values['u'] = np.zeros_like(sim.values['u'])
+    else:
+        sim['u'] = u0 if u0 is not None else np.zeros(fea.states_dict['u']['shape'])
     sim.run()
     return sim.compute_totals('l2_functional', 'f')
 
@@ -143,36 +149,37 @@ def usable_cores() -> int:
 
 
 def cpu_baseline(args, gpu_counts, n_dof_gpu, n_cell_gpu, nnz_gpu):
-    """Bounded sample of the same cycle on the host cores with the C/OpenMP oracle port."""
+    """The same cycle on the host cores with the C/OpenMP oracle port: ONE cycle at the benchmark's own
+    size by default (about 10 s of CPU work with BPX-CG), so nothing is extrapolated.  ``--cpu-n`` selects a
+    smaller cube; the figure is then scaled by cells / nnz and says so."""
     from oracle import c_port
     from oracle import femo_oracle as fo
-    n = args.cpu_n
-    m = fo.unit_cube_mesh(n)
+    n = args.cpu_n if args.cpu_n else args.n
+    m = fo.unit_cube_mesh(n, jitter=args.jitter)
     f = source_fields(_Centroid(m), 1)[0]
     bd = fo.boundary_vertices_box(m.x)
     threads = usable_cores()
     out = c_port.poisson_cycle(3, m.x, m.conn, f, fo.u_target(m.x), bd, ALPHA, rtol=1e-14, threads=threads, pc=PC)
     T = out["times"]
     t_sample = T["cycle"]
-    dofs_sample = m.n_vert / t_sample
-    # scale the sample to the benchmark mesh: assembly-like phases by cell count, CG by nnz x
-    # iteration count.  BPX counts do not grow with the mesh (the sample's own counts are used);
-    # Jacobi-CG counts grow in proportion to n (526+556 at n=128, 971+963 at n=215 on the GPU,
-    # profiles/r01_jacobi_bench_n1.json).
+    its = f"{out['it_fwd']}+{out['it_adj']}"
+    head = (f"oracle/femo_oracle_c.c (C/OpenMP restatement, not FEniCSx): one whole cycle with the same {PC.upper()}-CG and the "
+            f"same Newton noise-floor rule on the n={n} cube ({m.n_vert} DOFs), {t_sample:.2f} s, CG its {its}; "
+            f"the GPU run's CG its were {gpu_counts}")
+    if n == args.n:
+        return {"value": m.n_vert / t_sample, "unit": "DOFs/s", "cores": int(out["threads"]), "kind": "port",
+                "sample": head + "; measured at the benchmark's size, nothing scaled",
+                "split_s": {k: round(v, 3) for k, v in T.items()}}
+    # a smaller sample scaled to the benchmark mesh: assembly-like phases by cell count, CG by nnz x
+    # iteration count (BPX counts do not grow with the mesh; Jacobi-CG counts grow in proportion to n)
     it_main = out["it_fwd"][0] + out["it_adj"]
     t_cg = T["cg_fwd"] + T["cg_adj"]
     per_it_per_nnz = t_cg / max(it_main, 1) / out["nnz"]
     t_other = t_sample - t_cg
     it_scaled = it_main * (args.n / n if PC == "jacobi" else 1.0)
     t_scaled = t_other * (n_cell_gpu / m.n_cell) + per_it_per_nnz * nnz_gpu * it_scaled
-    return {
-        "value": n_dof_gpu / t_scaled, "unit": "DOFs/s", "cores": int(out["threads"]), "kind": "port",
-        "sample": (f"oracle/femo_oracle_c.c (C/OpenMP restatement, not FEniCSx), same cycle with the same {PC.upper()}-CG on the "
-                   f"n={n} cube ({m.n_vert} DOFs): {t_sample:.2f} s = {dofs_sample:.3e} DOFs/s with CG its "
-                   f"{out['it_fwd']}+{out['it_adj']}; scaled to n={args.n} by cell count (assembly, {t_other:.2f} s) and "
-                   f"nnz x {it_scaled:.0f} iterations ({per_it_per_nnz * out['nnz'] * 1e3:.2f} ms/it at n={n}); "
-                   f"the GPU run's CG its were {gpu_counts}"),
-    }
+    return {"value": n_dof_gpu / t_scaled, "unit": "DOFs/s", "cores": int(out["threads"]), "kind": "port",
+            "sample": head + f"; scaled to n={args.n} by cell count (assembly, {t_other:.2f} s) and nnz x {it_scaled:.0f} iterations"}
 
 
 class _Centroid:
@@ -183,10 +190,25 @@ class _Centroid:
         return self._m.x[self._m.conn].mean(axis=1)
 
 
+def _relaunch_multi_gpu(args) -> int:
+    """``python bench.py --gpus N`` without a launcher: start the N ranks as a child torchrun job
+    (before anything here touches the GPU) and pass its output and exit code on."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
 def main():
     global PC
     args = parse()
     PC = args.pc
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_relaunch_multi_gpu(args))
     from femo_amd.dist import _quiet_stdout
     with _quiet_stdout():                       # library banners go to stderr: stdout carries ONE JSON line
         result = _run(args)
@@ -194,16 +216,29 @@ def main():
         print(json.dumps(result), flush=True)
 
 
+def _timed_cycles(ctx, run_one, K, W):
+    for w in range(W):
+        run_one(w)
+    ctx.sync()
+    t0 = time.perf_counter()
+    g = None
+    for k in range(K):
+        g = run_one(W + k)
+    ctx.sync()
+    return (time.perf_counter() - t0) / max(K, 1) * 1e3, g
+
+
 def _run(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if world > 1 or os.environ.get("FEMO_BENCH_FORCE_DIST"):   # the env switch runs the N>1 code path on one rank (tests)
         from femo_amd.dist import bench_distributed
         return bench_distributed(args, rank, world, local_rank)
 
+    from femo_amd import engine as E
     from femo_amd.engine import Context, DeviceArray, Vec
     from femo_amd.fea import utils_hip
     from femo_amd.fea.mesh import createUnitCubeMesh
@@ -213,51 +248,84 @@ def _run(args):
     utils_hip.KSP_OPTIONS["pc"] = PC
     t0 = time.perf_counter()
     mesh = createUnitCubeMesh(args.n, jitter=args.jitter)
-    sim, fea = build_problem(mesh, device=True)
+    if args.permute:
+        mesh = mesh.permuted(seed=20240807)
+    sim, fea = build_problem(mesh, device=False)
     dm = mesh.device(ctx)
     n_dof, nnz = mesh.n_vert, dm.info["nnz"]
     K, W = args.steps, args.warmup
     f_host = source_fields(mesh, min(K + W, 4))
-    f_dev = [DeviceArray(Vec(ctx, mesh.n_cell).set(f)) for f in f_host]
+    # inputs "already on host" (SURVEY.md section 8(d)): NumPy arrays in pinned memory, as a driver that
+    # allocates its variables through femo_host_alloc holds them
+    f_pin = [E.pinned_array(f) for f in f_host]
+    u0 = E.pinned_array(np.zeros(n_dof))
     setup_s = time.perf_counter() - t0
 
+    # ---- headline: host arrays in, host arrays out ------------------------------------------------
+    def host_cycle(k):
+        return one_cycle(sim, fea, f_pin[k % len(f_pin)], u0)
+
     for w in range(W):
-        one_cycle(sim, fea, f_dev[w % len(f_dev)])
+        host_cycle(w)
     ctx.sync()
     del utils_hip.LAST_KSP_INFO[:]
-    t0 = time.perf_counter()
-    for k in range(K):
-        g = one_cycle(sim, fea, f_dev[(W + k) % len(f_dev)])
-    ctx.sync()
-    elapsed = time.perf_counter() - t0
-    ms_per_step = elapsed / K * 1e3
+    E.host_stats(reset=True)
+    ms_per_step, g = _timed_cycles(ctx, host_cycle, K, 0)
+    if not isinstance(g, np.ndarray) and K:
+        raise SystemExit("bench: the host-boundary cycle must return a NumPy gradient")
+    infos = list(utils_hip.LAST_KSP_INFO)
+    xfer = E.host_stats()
 
-    # dominant kernel timed live: back-to-back launches of the CG's SpMV (+ fused p.Ap) on the
-    # assembled operator, bracketed by HIP events on the library's stream
+    per = len(infos) // K if K else 0                      # linear solves per step: Newton's three + the adjoint
+    its_per_step = [i["iterations"] for i in infos[:per]]
+    cg_ms = sum(i["solve_ms"] for i in infos) / max(K, 1)
+    adj_ms = sum(i["solve_ms"] for k, i in enumerate(infos) if per and k % per == per - 1) / max(K, 1)
+    fwd_ms = cg_ms - adj_ms
+    solves = [i for i in infos if i["spmv_samples"] > 0]
+    spmv_in_cg_ms = (sum(i["spmv_ms"] for i in solves) / sum(i["spmv_samples"] for i in solves)) if solves else float("nan")
+    n_in_cg = sum(i["spmv_samples"] for i in solves)
+
+    # ---- the same cycle with inputs and outputs resident in HBM (no host boundary) ----------------
+    sim_d, fea_d = build_problem(mesh, device=True)
+    f_dev = [DeviceArray(Vec(ctx, mesh.n_cell).set(f)) for f in f_pin]
+    Kd = min(K, 5) if K else 0
+    dev_ms, _ = _timed_cycles(ctx, lambda k: one_cycle(sim_d, fea_d, f_dev[k % len(f_dev)]), Kd, 1)
+    del sim_d, fea_d, f_dev
+
+    # ---- dominant kernel: the CG's SpMV (+ fused p.Ap), HIP events on the library's stream ---------
     from femo_amd.fea.utils_hip import _WORK
     A_mat = [w[1] for k, w in _WORK.items() if k[1] == "newton_A"][0].mat
     xv, yv = Vec(ctx, n_dof).set(np.random.default_rng(0).standard_normal(n_dof)), Vec(ctx, n_dof)
     spmv_loop_ms = min(A_mat.bench_spmv(xv, yv, 50) for _ in range(3))
-    infos = list(utils_hip.LAST_KSP_INFO)
-    solves = [i for i in infos if i["iterations"] > 0]
-    spmv_ms = sum(i["spmv_ms"] for i in solves)
-    spmv_n = sum(i["spmv_samples"] for i in solves)
-    its_per_step = [i["iterations"] for i in infos[:len(infos) // K]] if K else []
-    cg_ms = sum(i["solve_ms"] for i in infos) / K
-    per = len(infos) // K if K else 0
-    adj_ms = sum(i["solve_ms"] for k, i in enumerate(infos) if per and k % per == per - 1) / max(K, 1)
-    fwd_ms = cg_ms - adj_ms
-    spmv_in_cg_ms = spmv_ms / spmv_n if spmv_n else float("nan")   # single launches incl. event overhead
-    spmv_avg_ms = spmv_loop_ms
+    del xv, yv
+    # `achieved` uses the launches inside the timed PCG loops (single launches between other kernels);
+    # back-to-back launches run a few per cent faster (part of the matrix stays in the Infinity Cache)
+    spmv_avg_ms = spmv_in_cg_ms if n_in_cg else spmv_loop_ms
     B_A = spmv_algorithmic_bytes(nnz, n_dof)
     achieved = B_A / (spmv_avg_ms * 1e-3) / 1e9
     traffic = None
-    prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(prof):
-        try:
-            traffic = json.load(open(prof)).get(f"spmv_n{args.n}")
-        except Exception:
-            traffic = None
+    for name in ("r02_pmc_traffic.json", "pmc_traffic.json"):
+        prof = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get(f"spmv_n{args.n}" + ("_permuted" if args.permute else ""))
+            except Exception:
+                traffic = None
+            if traffic is not None:
+                break
+    stored = stored_bytes(dm.info, n_dof)
+    physical = traffic if traffic else stored
+
+    # PCIe rate of the box: one pinned 477 MB array each way
+    probe = Vec(ctx, mesh.n_cell)
+    t0 = time.perf_counter(); probe.set(f_host[0]); t_pg = time.perf_counter() - t0
+    t0 = time.perf_counter(); probe.set(f_pin[-1]); t_up = time.perf_counter() - t0
+    out = E.pinned_empty(mesh.n_cell)
+    t0 = time.perf_counter(); probe.get(out=out); t_dn = time.perf_counter() - t0
+    del probe, out
+    nbytes = mesh.n_cell * 8
+    h2d_bytes = (xfer["h2d_pinned_bytes"] + xfer["h2d_staged_bytes"]) / max(K, 1)
+    d2h_bytes = (xfer["d2h_pinned_bytes"] + xfer["d2h_staged_bytes"]) / max(K, 1)
 
     result = {
         "metric": METRIC, "value": n_dof / (ms_per_step * 1e-3), "unit": "DOFs/s",
@@ -266,38 +334,56 @@ def _run(args):
         "dtype": "f64", "data": "synthetic",
         "config": {
             "workload": (f"3-D linear Poisson, P1 tets, unit cube n={args.n}: {n_dof} DOFs, {mesh.n_cell} cells, "
-                         f"nnz {nnz}; per step: Newton x3 (assemble R, dR/du, A; {PC.upper()}-CG) + J + dJ/du, dJ/df + "
+                         f"nnz {nnz}; per step, NumPy arrays at the operator boundary (f in; u, J, dJ/df out): "
+                         f"Newton x3 (assemble R, dR/du, A; {PC.upper()}-CG) + J + dJ/du, dJ/df + "
                          f"dR/du, dR/df, A + transposed {PC.upper()}-CG + dR/df^T lambda; CG rtol 1e-14; cold start"),
+            "boundary": "host (NumPy in pinned blocks of femo_host_alloc; H2D + D2H inside the timed region)",
             "preconditioner": PC, "pc_lattice": dm.pc_info(),
-            "n": args.n, "jitter": args.jitter, "n_dof": n_dof, "n_cell": mesh.n_cell, "nnz": nnz,
+            "n": args.n, "jitter": args.jitter, "permuted": bool(args.permute),
+            "n_dof": n_dof, "n_cell": mesh.n_cell, "nnz": nnz,
             "sell_slices": dm.info["n_slices"], "regular_slices": dm.info["regular_slices"],
-            "cg_iterations_per_step": its_per_step, "cg_ms_per_step": cg_ms,
+            "linear_solves_per_step": per, "cg_iterations_per_step": its_per_step, "cg_ms_per_step": cg_ms,
             "non_cg_ms_per_step": ms_per_step - cg_ms, "setup_s": setup_s,
-            # SURVEY.md section 8(d) split: Newton's linear solves / the transposed (adjoint) solve / the rest
-            # (assembly passes, functional and its partials, dR/df^T lambda, host)
+            # SURVEY.md section 8(d) split: Newton's linear solves / the transposed (adjoint) solve /
+            # host<->device traffic and host-side passes / the rest (assembly, functional, dR/df^T lambda)
             "split_ms_per_step": {"forward_solves": fwd_ms, "adjoint_solve": adj_ms,
-                                  "assembly_outputs_host": ms_per_step - cg_ms},
+                                  "h2d_d2h": ms_per_step - dev_ms,
+                                  "assembly_outputs": dev_ms - cg_ms},
+            "pcie": {"h2d_bytes_per_step": h2d_bytes, "d2h_bytes_per_step": d2h_bytes,
+                     "uploads_elided_per_step": (xfer["h2d_skipped"] + xfer["h2d_as_d2d"]) / max(K, 1),
+                     "upload_bytes_elided_per_step": (xfer["h2d_skipped_bytes"] + xfer["h2d_as_d2d_bytes"]) / max(K, 1),
+                     "h2d_pinned_GBs": nbytes / t_up / 1e9, "d2h_pinned_GBs": nbytes / t_dn / 1e9,
+                     "h2d_pageable_staged_GBs": nbytes / t_pg / 1e9, "host_threads": E._lib.load().femo_host_threads()},
         },
+        "device_resident": {"value": n_dof / (dev_ms * 1e-3) if dev_ms else None, "unit": "DOFs/s", "ms_per_step": dev_ms,
+                            "steps": Kd, "note": "same cycle with DeviceArray inputs/outputs (no PCIe); round 1's headline"},
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": "k_spmv_sell<true> (SELL-64 SpMV + fused p.Ap, one launch per CG iteration)",
-            "algorithmic_bytes_per_launch": B_A, "avg_launch_ms": spmv_avg_ms, "launches_timed": 150,
-            "avg_launch_ms_single_in_cg": spmv_in_cg_ms, "single_launches_timed": spmv_n,
-            "stored_bytes_per_launch": stored_bytes(dm.info, n_dof),
+            "frac_physical": physical / (spmv_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "physical_bytes_per_launch": physical,
+            "physical_bytes_source": "PMC (2*FETCH_SIZE + WRITE_SIZE, profiles/)" if traffic else "stored bytes of the SELL format",
+            "kernel": "k_spmv_sell<1,true> (SELL-64 SpMV + fused p.Ap, one launch per CG iteration)",
+            "algorithmic_bytes_per_launch": B_A, "avg_launch_ms": spmv_avg_ms, "launches_timed": n_in_cg,
+            "timed": "single launches inside the timed PCG loops (HIP events on the library's stream)",
+            "avg_launch_ms_back_to_back": spmv_loop_ms, "back_to_back_launches_timed": 150,
+            "stored_bytes_per_launch": stored,
         },
     }
 
     if not args.no_pcie:
-        sim_h, fea_h = build_problem(mesh, device=False)
-        one_cycle(sim_h, fea_h, f_host[0])
+        # a backend that keeps every array in its own pageable memory (copies results out, hands pageable inputs in)
+        sim_p, fea_p = build_problem(mesh, device=False, pinned=False)
+        one_cycle(sim_p, fea_p, f_host[0])
         ctx.sync()
         t0 = time.perf_counter()
-        one_cycle(sim_h, fea_h, f_host[1 % len(f_host)])
+        one_cycle(sim_p, fea_p, f_host[1 % len(f_host)])
         ctx.sync()
         t_h = time.perf_counter() - t0
-        result["pcie_inclusive"] = {"value": n_dof / t_h, "unit": "DOFs/s", "ms_per_step": t_h * 1e3,
-                                    "note": "NumPy arrays at the operator boundary (H2D/D2H on every update/getFuncArray)"}
+        result["pageable_boundary"] = {"value": n_dof / t_h, "unit": "DOFs/s", "ms_per_step": t_h * 1e3, "steps": 1,
+                                       "note": "pageable NumPy arrays owned by the driver on both sides of every operator call "
+                                               "(staged through pinned slots by host threads; no upload can be elided)"}
+        del sim_p, fea_p
     if not args.no_cpu_baseline:
         counts = its_per_step if its_per_step else [0]
         result["cpu_baseline"] = cpu_baseline(args, counts, n_dof, mesh.n_cell, nnz)

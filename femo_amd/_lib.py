@@ -42,6 +42,12 @@ class SolveInfo(C.Structure):
                 ("spmv_samples", C.c_int32), ("reserved", C.c_int32)]
 
 
+class HostStats(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("h2d_pinned", "h2d_pinned_bytes", "h2d_staged", "h2d_staged_bytes",
+                                         "h2d_skipped", "h2d_skipped_bytes", "h2d_as_d2d", "h2d_as_d2d_bytes",
+                                         "d2h_pinned", "d2h_pinned_bytes", "d2h_staged", "d2h_staged_bytes")]
+
+
 # name -> (restype, argtypes); every symbol include/femo_hip.h declares
 PROTOTYPES = {
     "femo_last_error": (C.c_char_p, []),
@@ -58,6 +64,19 @@ PROTOTYPES = {
     "femo_vec_device_ptr": (C.c_void_p, [H]),
     "femo_vec_set_host": (C.c_int, [H, C.c_void_p, c_i64]),
     "femo_vec_get_host": (C.c_int, [H, C.c_void_p, c_i64]),
+    "femo_vec_add_to_host": (C.c_int, [H, C.c_void_p, c_i64]),
+    "femo_host_alloc": (C.c_int, [c_i64, C.POINTER(C.c_void_p)]),
+    "femo_host_free": (C.c_int, [C.c_void_p]),
+    "femo_host_trim": (C.c_int, []),
+    "femo_host_register": (C.c_int, [C.c_void_p, c_i64]),
+    "femo_host_unregister": (C.c_int, [C.c_void_p]),
+    "femo_host_touch": (C.c_int, [C.c_void_p]),
+    "femo_host_is_pinned": (C.c_int, [C.c_void_p, c_i64]),
+    "femo_host_threads": (C.c_int, []),
+    "femo_host_copy": (C.c_int, [C.c_void_p, C.c_void_p, c_i64]),
+    "femo_host_axpby": (C.c_int, [c_i64, C.c_double, C.c_void_p, C.c_double, C.c_void_p]),
+    "femo_host_get_stats": (C.c_int, [C.POINTER(HostStats)]),
+    "femo_host_reset_stats": (C.c_int, []),
     "femo_vec_fill": (C.c_int, [H, C.c_double]),
     "femo_vec_copy": (C.c_int, [H, H]),
     "femo_vec_axpy": (C.c_int, [H, C.c_double, H]),

@@ -13,22 +13,40 @@ Variables are promoted by bare name, as the reference's run scripts rely on
 (run_poisson_opt.py:168-176); ``sim['l2_functional_output_model.l2_functional']``
 style addresses resolve to the same store.  ``device=True`` keeps every value
 in HBM (``DeviceArray``) instead of NumPy arrays.
+
+Host mode (``device=False``): like a CSDL backend the driver owns the storage of its variables, and
+it keeps them in pinned blocks of the engine (``engine.pinned_empty``): what the operators receive are
+read-only NumPy views of those blocks, what they return (read-only pinned arrays as well) is adopted by
+reference.  The engine can therefore tell that an array it is handed again is still the exact copy of a
+device vector and moves it over PCIe once (include/femo_hip.h, "host memory").  The reverse sweep
+accumulates in place: the adjoint right-hand side is negated (one pass over a state-sized array), so that
+``d_inputs[arg] += dRdf^T psi`` lands directly in the array that already holds the explicit partial.
 """
 from __future__ import annotations
 
 from typing import Dict, List, Sequence, Tuple, Union
 
+import sys
+
 import numpy as np
 
+from femo_amd import engine as E
 from femo_amd.csdl_opt._csdl_compat import CustomExplicitOperation, CustomImplicitOperation
 from femo_amd.engine import DeviceArray, Vec
 from femo_amd.fea.utils_hip import get_context
 
 
+def _readonly(a: np.ndarray) -> np.ndarray:
+    v = a.view()
+    v.flags.writeable = False
+    return v
+
+
 class Simulator:
-    def __init__(self, model, device: bool = False):
+    def __init__(self, model, device: bool = False, pinned: bool = True):
         self.model = model
         self.device = device
+        self.pinned = pinned          # host mode: variables in pinned engine blocks (False: plain pageable NumPy arrays)
         self.values: Dict[str, object] = {}
         self.ops: List[Tuple[str, object]] = []          # (submodel name, operation)
         self._build(model)
@@ -63,8 +81,21 @@ class Simulator:
                 cur.vec.set(a)
                 return
             value = DeviceArray(Vec(get_context(), a.size).set(a))
-        elif not self.device and isinstance(value, DeviceArray):
-            value = value.numpy()
+        elif not self.device:
+            if isinstance(value, DeviceArray):
+                value = value.numpy()
+            a = np.ascontiguousarray(value, dtype=np.float64).ravel()
+            if not self.pinned:
+                value = np.array(a, copy=True)              # a driver with pageable storage of its own
+            elif not a.flags.writeable and E.is_pinned(a):
+                value = a                                   # a result of the engine (or engine.pinned_array): adopt
+            else:
+                own = self.__dict__.setdefault("_own", {})
+                w = own.get(name)
+                if w is None or w.size != a.size:
+                    w = own[name] = E.pinned_empty(a.size)
+                E.host_copy(w, a)                           # the driver's own storage; announces the write
+                value = _readonly(w)
         self.values[name] = value
 
     @staticmethod
@@ -72,6 +103,7 @@ class Simulator:
         return name.split(".")[-1]
 
     def __getitem__(self, name: str):
+        """NumPy value of a variable.  Host mode returns the stored (read-only) array itself."""
         v = self.values[self._key(name)]
         return v.numpy() if isinstance(v, DeviceArray) else v
 
@@ -113,6 +145,32 @@ class Simulator:
             return a
         return np.zeros_like(np.asarray(v, dtype=np.float64))
 
+    def _result(self, key, val):
+        """What compute_totals hands out.  NumPy values are the caller's.  Device values are copied
+        out of the sweep's pooled work arrays into a per-(of, wrt) result buffer that is reused only
+        when the caller no longer holds the previous result."""
+        if not isinstance(val, DeviceArray):
+            return val
+        pool = self.__dict__.setdefault("_results", {})
+        out = pool.get(key)
+        if out is None or out.n != val.n or sys.getrefcount(out) > 3:      # pool + local + getrefcount's argument
+            out = pool[key] = DeviceArray.zeros(get_context(), val.n)
+        out.vec.copy_from(val.vec)
+        return out
+
+    @staticmethod
+    def _own(a: np.ndarray) -> np.ndarray:
+        """A writable array holding ``a``: the array itself, a writable alias of a result the engine
+        returned read-only (the sweep received it and is its only holder), or a copy."""
+        if a.flags.writeable:
+            return a
+        try:
+            return E.writable(a)
+        except ValueError:
+            w = E.pinned_empty(a.size)
+            E.host_copy(w, np.ascontiguousarray(a))
+            return w
+
     def compute_totals(self, of: Union[str, Sequence[str]], wrt: Union[str, Sequence[str]]):
         """Reverse-mode total derivatives of scalar outputs ``of`` w.r.t. ``wrt``."""
         single = isinstance(of, str) and isinstance(wrt, str)
@@ -133,9 +191,19 @@ class Simulator:
                     derivatives = {}
                     op.compute_derivatives(inputs, derivatives)
                     for (oo, arg), val in derivatives.items():
-                        if arg not in adj:
-                            adj[arg] = self._zeros_like(arg, 'adj')
-                        adj[arg] += val if isinstance(val, DeviceArray) else np.asarray(val, dtype=np.float64).ravel()
+                        if isinstance(val, DeviceArray):
+                            if arg not in adj:
+                                adj[arg] = self._zeros_like(arg, 'adj')
+                            adj[arg] += val
+                        else:
+                            val = np.ascontiguousarray(val, dtype=np.float64).ravel()
+                            if not self.pinned:
+                                val = np.array(val, copy=True)
+                            if arg not in adj:
+                                adj[arg] = val                      # by reference: no pass over the array
+                            else:
+                                adj[arg] = self._own(adj[arg])
+                                E.host_axpby(1.0, val, 1.0, adj[arg])
                     seed_done = True
                 else:
                     (state,) = tuple(op.output_meta)
@@ -143,24 +211,43 @@ class Simulator:
                         continue
                     outputs = {state: self.values[state]}
                     op.compute_derivatives(inputs, outputs, {})
-                    d_outputs = {state: adj.pop(state)}
-                    d_residuals = {state: self._zeros_like(state, 'd_res')}
-                    op.apply_inverse_jacobian(d_outputs, d_residuals, 'rev')
-                    d_inputs = {k: self._zeros_like(k, 'd_in') for k in op.input_meta}
-                    op.compute_jacvec_product(inputs, outputs, d_inputs, {}, d_residuals, 'rev')
-                    for k, v in d_inputs.items():
-                        if k not in adj:
-                            adj[k] = self._zeros_like(k, 'adj')
-                        if isinstance(v, DeviceArray):
+                    if isinstance(adj[state], DeviceArray):
+                        d_outputs = {state: adj.pop(state)}
+                        d_residuals = {state: self._zeros_like(state, 'd_res')}
+                        op.apply_inverse_jacobian(d_outputs, d_residuals, 'rev')
+                        d_inputs = {k: self._zeros_like(k, 'd_in') for k in op.input_meta}
+                        op.compute_jacvec_product(inputs, outputs, d_inputs, {}, d_residuals, 'rev')
+                        for k, v in d_inputs.items():
+                            if k not in adj:
+                                adj[k] = self._zeros_like(k, 'adj')
                             adj[k].vec.axpy(-1.0, v.vec)
-                        else:
-                            adj[k] = adj[k] - v
+                    else:
+                        # psi = -(dR/du)^-T adj[u]; then adj[arg] += (dR/darg)^T psi in place
+                        rhs = adj.pop(state)
+                        seed = self.__dict__.setdefault("_seed", {}).get(state)
+                        if seed is None or seed.size != rhs.size:
+                            seed = self._seed[state] = E.pinned_empty(rhs.size) if self.pinned else np.empty(rhs.size)
+                        E.host_axpby(-1.0, np.ascontiguousarray(rhs), 0.0, seed)
+                        d_outputs = {state: _readonly(seed)}
+                        d_residuals = {state: np.zeros(0)}          # assigned by the operation
+                        op.apply_inverse_jacobian(d_outputs, d_residuals, 'rev')
+                        d_inputs = {}
+                        for k in op.input_meta:
+                            if k in adj:
+                                d_inputs[k] = self._own(adj[k])
+                            elif self.pinned:
+                                d_inputs[k] = E.pinned_empty(np.size(self.values[k]))
+                                E.host_axpby(0.0, d_inputs[k], 0.0, d_inputs[k])
+                            else:
+                                d_inputs[k] = np.zeros(np.size(self.values[k]))
+                        op.compute_jacvec_product(inputs, outputs, d_inputs, {}, d_residuals, 'rev')
+                        adj.update(d_inputs)
             if not seed_done:
                 raise KeyError(f"no operation produces {o!r}")
             for w in wrts:
                 w = self._key(w)
                 val = adj[w] if w in adj else self._zeros_like(w, 'adj')
-                result[(o, w)] = val
+                result[(o, w)] = self._result((o, w), val)
         if single:
             return result[(self._key(of), self._key(wrt))]
         return result

@@ -16,9 +16,9 @@ from femo_amd.csdl_opt._common import (declare_all, gather_arguments, push_funct
                                        traced)
 from femo_amd.csdl_opt._csdl_compat import CustomImplicitOperation, Model, custom
 from femo_amd.fea.fea_hip import FEA
-from femo_amd.fea.utils_hip import (DeviceArray, SparseMatrix, assembleMatrix, assembleSystem,
-                                    assembleVector, computeMatVecProductBwd, computeMatVecProductFwd,
-                                    computePartials, createFunction, getFuncArray, setUpKSP_MUMPS, update)
+from femo_amd.fea.utils_hip import (DeviceArray, SparseMatrix, addMatVecProductBwd, addMatVecProductFwd,
+                                    assembleMatrix, assembleSystem, assembleVector, computePartials,
+                                    createFunction, getFuncArray, setUpKSP_MUMPS, update)
 
 
 class StateModel(Model):
@@ -133,26 +133,30 @@ class StateOperation(CustomImplicitOperation):
     def compute_jacvec_product(self, inputs, outputs, d_inputs, d_outputs, d_residuals, mode):
         """fwd: d_residuals += dRdu du + sum dRdf df.   rev: d_outputs += dRdu^T dR,
         d_inputs[arg] += dRdf^T dR.  Keys that are absent are skipped (state_model.py:161-200)."""
-        self._load(inputs, outputs)                            # "might be redundant" in the reference too
+        # The reference re-sends inputs and state here and calls it "might be redundant"
+        # (state_model.py:168-173): the products only use the matrices compute_derivatives kept, so
+        # the result does not depend on it.  Kept behind fea.reload_in_jacvec (default off): with
+        # pageable arrays it would be 0.5 GB over PCIe per call on the 10 M-DOF cube.
+        if getattr(self.fea, 'reload_in_jacvec', False):
+            self._load(inputs, outputs)
         u = self.state_name
         if u not in d_residuals:
             return
-        dev = stays_on_device(inputs)
         if mode == 'fwd':
             if u in d_outputs:
                 update(self.du, d_outputs[u])
-                d_residuals[u] += computeMatVecProductFwd(self.dRdu, self.du, device=dev)
+                d_residuals[u] = addMatVecProductFwd(d_residuals[u], self.dRdu, self.du)
             for name, pair in self.dRdf_dict.items():
                 if name in d_inputs:
                     update(pair['df'], d_inputs[name])
-                    d_residuals[u] += computeMatVecProductFwd(pair['dRdf'], pair['df'], device=dev)
+                    d_residuals[u] = addMatVecProductFwd(d_residuals[u], pair['dRdf'], pair['df'])
         elif mode == 'rev':
             update(self.dR, self._dirichlet_filtered(d_residuals[u]))
             if u in d_outputs:
-                d_outputs[u] += computeMatVecProductBwd(self.dRdu, self.dR, device=dev)
+                d_outputs[u] = addMatVecProductBwd(d_outputs[u], self.dRdu, self.dR)
             for name, pair in self.dRdf_dict.items():
                 if name in d_inputs:
-                    d_inputs[name] += computeMatVecProductBwd(pair['dRdf'], self.dR, device=dev)
+                    d_inputs[name] = addMatVecProductBwd(d_inputs[name], pair['dRdf'], self.dR)
 
     @traced()
     def apply_inverse_jacobian(self, d_outputs, d_residuals, mode):

@@ -171,6 +171,10 @@ int femo_ctx_destroy(femo_ctx* c) {
   hipFree(c->d_partials); hipFree(c->d_scal); hipFree(c->d_flags);
   hipFree(c->cg_r); hipFree(c->cg_p); hipFree(c->cg_q); hipFree(c->cg_dinv); hipFree(c->cg_s); hipFree(c->cg_t); hipFree(c->cg_r0);
   hipHostFree(c->h_scal);
+  for (int k = 0; k < FEMO_STAGE_SLOTS; ++k) {
+    if (c->stage[k]) hipHostFree(c->stage[k]);
+    if (c->stage_ev[k]) hipEventDestroy(c->stage_ev[k]);
+  }
   hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
   for (auto& e : c->ev_pool) hipEventDestroy(e);
   if (c->own_stream) hipStreamDestroy(c->stream);
@@ -194,6 +198,7 @@ int femo_vec_create(femo_ctx* ctx, int64_t n, femo_vec** out) {
   v->ctx = ctx; v->n = n; v->owned = true;
   FEMO_HIP_CHECK(hipMalloc(&v->d, (n + 2) * sizeof(double)));
   FEMO_HIP_CHECK(hipMemsetAsync(v->d, 0, (n + 2) * sizeof(double), ctx->stream));
+  femo_vec_register(v);
   *out = v;
   return 0;
 }
@@ -203,12 +208,14 @@ int femo_vec_wrap(femo_ctx* ctx, void* device_ptr, int64_t n, femo_vec** out) {
   FEMO_REQUIRE((reinterpret_cast<uintptr_t>(device_ptr) & 15) == 0, "wrapped pointer must be 16-byte aligned");
   femo_vec* v = new femo_vec();
   v->ctx = ctx; v->n = n; v->owned = false; v->d = static_cast<double*>(device_ptr);
+  femo_vec_register(v);
   *out = v;
   return 0;
 }
 
 int femo_vec_destroy(femo_vec* v) {
   if (!v) return 0;
+  femo_vec_unregister(v);
   if (v->owned && v->d) {
     hipStreamSynchronize(v->ctx->stream);
     hipFree(v->d);
@@ -220,25 +227,12 @@ int femo_vec_destroy(femo_vec* v) {
 int64_t femo_vec_size(const femo_vec* v) { return v ? v->n : -1; }
 void* femo_vec_device_ptr(femo_vec* v) { return v ? v->d : nullptr; }
 
-int femo_vec_set_host(femo_vec* v, const double* host, int64_t n) {
-  FEMO_REQUIRE(v && host, "null argument");
-  FEMO_REQUIRE(n == v->n, "size mismatch: vector has %lld entries, host array %lld", (long long)v->n, (long long)n);
-  FEMO_HIP_CHECK(hipMemcpyAsync(v->d, host, n * sizeof(double), hipMemcpyHostToDevice, v->ctx->stream));
-  FEMO_HIP_CHECK(hipStreamSynchronize(v->ctx->stream));
-  return 0;
-}
-
-int femo_vec_get_host(const femo_vec* v, double* host, int64_t n) {
-  FEMO_REQUIRE(v && host, "null argument");
-  FEMO_REQUIRE(n <= v->n, "size mismatch: vector has %lld entries, host array %lld", (long long)v->n, (long long)n);
-  FEMO_HIP_CHECK(hipMemcpyAsync(host, v->d, n * sizeof(double), hipMemcpyDeviceToHost, v->ctx->stream));
-  FEMO_HIP_CHECK(hipStreamSynchronize(v->ctx->stream));
-  return 0;
-}
+// femo_vec_set_host / femo_vec_get_host / femo_vec_add_to_host: hostmem.cpp
 
 int femo_vec_fill(femo_vec* v, double value) {
   FEMO_REQUIRE(v != nullptr, "null argument");
   if (v->n == 0) return 0;
+  femo_vec_touch(v);
   hipLaunchKernelGGL(k_fill, dim3(grid_for(v->n)), dim3(256), 0, v->ctx->stream, v->n, value, v->d);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
@@ -247,6 +241,7 @@ int femo_vec_fill(femo_vec* v, double value) {
 int femo_vec_copy(femo_vec* dst, const femo_vec* src) {
   FEMO_REQUIRE(dst && src, "null argument");
   FEMO_REQUIRE(dst->n == src->n, "size mismatch in vec_copy");
+  femo_vec_touch(dst);
   FEMO_HIP_CHECK(hipMemcpyAsync(dst->d, src->d, src->n * sizeof(double), hipMemcpyDeviceToDevice, dst->ctx->stream));
   return 0;
 }
@@ -255,6 +250,7 @@ int femo_vec_axpy(femo_vec* y, double a, const femo_vec* x) {
   FEMO_REQUIRE(y && x, "null argument");
   FEMO_REQUIRE(y->n == x->n, "size mismatch in vec_axpy");
   if (y->n == 0) return 0;
+  femo_vec_touch(y);
   hipLaunchKernelGGL(k_axpy, dim3(grid_for(y->n)), dim3(256), 0, y->ctx->stream, y->n, a, x->d, y->d);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
@@ -460,6 +456,7 @@ int femo_assemble_residual(femo_mesh* m, int pde, const double* params, const fe
   FEMO_REQUIRE(u->n >= m->n_vert && f->n >= m->n_cell && r->n >= m->n_rows, "vector size mismatch in assemble_residual");
   FEMO_REQUIRE(aux == nullptr || aux->n >= m->n_vert, "aux field shorter than n_vert");
   if (m->n_nbr > 0) FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(u)));
+  femo_vec_touch(r);
   return femo_launch_residual(m, pde, params, u->d, f->d, aux ? aux->d : nullptr, r->d);
 }
 
@@ -497,6 +494,7 @@ int femo_assemble_system(femo_mesh* m, int pde, const double* params, const femo
   }
   FEMO_REQUIRE(aux == nullptr || aux->n >= m->n_vert, "aux field shorter than n_vert");
   if (J_nobc) { J_nobc->valsT_valid = false; J_nobc->scaled_valid = false; J_nobc->s_valid = false; FEMO_TRY(note_pinned_vertices(J_nobc, pde, params, nullptr)); }
+  femo_vec_touch(rhs);
   if (A_bc) { A_bc->valsT_valid = false; A_bc->scaled_valid = false; A_bc->s_valid = false; FEMO_TRY(note_pinned_vertices(A_bc, pde, params, bc)); }
   return femo_launch_system(m, pde, params, u ? u->d : nullptr, f ? f->d : nullptr, aux ? aux->d : nullptr,
                             bc ? bc->d_mask : nullptr, bc ? bc->d_dense : nullptr,
@@ -509,6 +507,7 @@ int femo_bc_apply_rhs(const femo_bc* bc, const femo_vec* u, femo_vec* b) {
   FEMO_REQUIRE(bc && u && b, "null argument");
   femo_mesh* m = bc->mesh;
   FEMO_REQUIRE(u->n >= m->n_vert && b->n >= m->n_rows, "vector size mismatch in bc_apply_rhs");
+  femo_vec_touch(b);
   if (bc->n > 0) {
     hipLaunchKernelGGL(k_bc_set_rhs, dim3(grid_for(bc->n)), dim3(256), 0, m->ctx->stream, bc->n, m->n_rows, bc->d_dofs, bc->d_vals, u->d, b->d);
     FEMO_HIP_CHECK(hipGetLastError());
@@ -520,6 +519,7 @@ int femo_assemble_dRdf(femo_mesh* m, int pde, const double* params, const femo_v
                        const femo_vec* f, femo_vec* vals) {
   FEMO_REQUIRE(m && vals, "null argument");
   FEMO_REQUIRE(vals->n >= m->n_cell * (m->tdim + 1), "dRdf value buffer too small");
+  femo_vec_touch(vals);
   return femo_launch_dRdf(m, pde, params, u ? u->d : nullptr, f ? f->d : nullptr, vals->d);
 }
 
@@ -529,6 +529,7 @@ int femo_newton_rhs(const femo_mat* K, const femo_vec* F, const femo_vec* u, con
   femo_ctx* ctx = m->ctx;
   FEMO_REQUIRE(u->n >= m->n_vert && F->n >= m->n_rows && b->n >= m->n_rows, "vector size mismatch in newton_rhs");
   FEMO_REQUIRE(b->d != F->d, "newton_rhs cannot run in place");
+  femo_vec_touch(b);
   if (!m->d_scratch) FEMO_HIP_CHECK(hipMalloc(&m->d_scratch, (std::max<int64_t>(m->n_vert, 1) + 2) * sizeof(double)));
   double* w = m->d_scratch;  // w = (g - u) on the set, 0 elsewhere
   FEMO_HIP_CHECK(hipMemsetAsync(w, 0, (m->n_vert + 2) * sizeof(double), ctx->stream));
@@ -553,6 +554,7 @@ int femo_dRdf_apply(femo_mesh* m, const femo_vec* vals, int transpose, const fem
   } else {
     FEMO_REQUIRE(x->n >= m->n_cell && y->n >= m->n_rows, "vector size mismatch in dRdf apply");
   }
+  femo_vec_touch(y);
   return femo_launch_dRdf_apply(m, vals->d, transpose, x->d, y->d, accumulate);
 }
 
@@ -596,6 +598,7 @@ int femo_mat_export_csr(const femo_mat* A, int64_t* rowptr, int32_t* col, double
 int femo_mat_diagonal(const femo_mat* A, femo_vec* d) {
   FEMO_REQUIRE(A && d, "null argument");
   FEMO_REQUIRE(d->n >= A->mesh->n_rows, "vector too small");
+  femo_vec_touch(d);
   FEMO_HIP_CHECK(hipMemcpyAsync(d->d, A->d_diag, A->mesh->n_rows * sizeof(double), hipMemcpyDeviceToDevice, A->mesh->ctx->stream));
   return 0;
 }
@@ -614,6 +617,7 @@ int femo_functional_grad_u(femo_mesh* m, int kind, const double* params, const f
   FEMO_REQUIRE(m && u && u_d && g, "null argument");
   FEMO_REQUIRE(u->n >= m->n_vert && u_d->n >= m->n_vert && g->n >= m->n_rows, "vector size mismatch in functional grad_u");
   if (m->n_nbr > 0) FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(u)));
+  femo_vec_touch(g);
   return femo_launch_functional_grad_u(m, kind, params, u->d, f ? f->d : nullptr, u_d->d, g->d);
 }
 
@@ -621,6 +625,7 @@ int femo_functional_grad_f(femo_mesh* m, int kind, const double* params, const f
                            const femo_vec* f, const femo_vec* u_d, femo_vec* g) {
   FEMO_REQUIRE(m && f && g, "null argument");
   FEMO_REQUIRE(f->n >= m->n_cell && g->n >= m->n_cell, "vector size mismatch in functional grad_f");
+  femo_vec_touch(g);
   return femo_launch_functional_grad_f(m, kind, params, u ? u->d : nullptr, f->d, u_d ? u_d->d : nullptr, g->d);
 }
 
@@ -628,6 +633,7 @@ int femo_cell_expression(femo_mesh* m, int kind, const double* params, const fem
   FEMO_REQUIRE(m && in && out, "null argument");
   FEMO_REQUIRE(out->n >= m->n_cell && in->n >= (kind == 0 ? m->n_vert : m->n_cell), "vector size mismatch in cell_expression");
   if (kind == 0 && m->n_nbr > 0) FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(in)));
+  femo_vec_touch(out);
   return femo_launch_cell_expr(m, kind, params, in->d, out->d);
 }
 
@@ -635,6 +641,7 @@ int femo_vec_pointwise_divide(femo_vec* y, const femo_vec* x, const femo_vec* d,
   FEMO_REQUIRE(y && x && d, "null argument");
   FEMO_REQUIRE(n <= y->n && n <= x->n && n <= d->n, "length exceeds vector size");
   if (n == 0) return 0;
+  femo_vec_touch(y);
   hipLaunchKernelGGL(k_pdiv, dim3(grid_for(n)), dim3(256), 0, y->ctx->stream, n, x->d, d->d, y->d);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;

@@ -55,6 +55,7 @@ constexpr int FEMO_WAVE = 64;            // gfx950 wavefront
 constexpr int FEMO_BLOCK = 256;          // 4 waves = 4 SELL slices per workgroup
 constexpr int FEMO_MAX_PARTIALS = 2048;  // persistent reduction grids: 256 CUs x 8
 constexpr int FEMO_NSCAL = 16;           // device scalars of the CG recurrence
+constexpr int FEMO_STAGE_SLOTS = 4;      // pinned staging slots per context (8 MiB each)
 
 // SELL-64 with pair interleave: entry k of lane l in a slice starting at P:
 //   P + (k >> 1) * 128 + l * 2 + (k & 1)
@@ -105,6 +106,9 @@ struct femo_ctx {
   hipStream_t comm_stream = nullptr;          // halo exchange overlapped with interior rows
   hipEvent_t ev_main = nullptr, ev_comm = nullptr;
   int n_cu = 256;
+  // pinned staging ring for pageable host memory (hostmem.cpp), allocated on first use
+  double* stage[FEMO_STAGE_SLOTS] = {};
+  hipEvent_t stage_ev[FEMO_STAGE_SLOTS] = {};
   // CG workspace, grown on demand and reused across solves
   double *cg_r = nullptr, *cg_p = nullptr, *cg_q = nullptr, *cg_dinv = nullptr, *cg_s = nullptr;
   double *cg_t = nullptr, *cg_r0 = nullptr;
@@ -116,7 +120,13 @@ struct femo_vec {
   double* d = nullptr;
   int64_t n = 0;
   bool owned = true;
+  // provenance of host copies (hostmem.cpp): process-unique id (0 = wrapped memory, never trusted)
+  // and a generation that every entry point writing the vector bumps
+  uint64_t uid = 0, gen = 0;
 };
+inline void femo_vec_touch(femo_vec* v) { if (v) ++v->gen; }
+void femo_vec_register(femo_vec* v);     // after creation: assigns uid, enters the live table
+void femo_vec_unregister(femo_vec* v);   // before destruction
 
 struct femo_pc;   // auxiliary-lattice BPX hierarchy (bpx.hip)
 

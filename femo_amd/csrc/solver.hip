@@ -864,6 +864,7 @@ int femo_mesh_classify_slices(femo_mesh* m) {
 int femo_halo_exchange_on(femo_mesh* m, femo_vec* x, hipStream_t st) {
   FEMO_REQUIRE(m && x, "null argument");
   if (m->n_nbr == 0) return 0;
+  femo_vec_touch(x);                                  // ghost entries change
   femo_ctx* ctx = m->ctx;
   FEMO_REQUIRE(ctx->comm != nullptr || ctx->emu != nullptr, "halo exchange before femo_comm_init");
   FEMO_REQUIRE(x->n >= m->n_vert, "vector shorter than n_vert");
@@ -893,11 +894,13 @@ extern "C" int femo_mat_spmv(const femo_mat* A, int transpose, const femo_vec* x
   femo_mesh* m = A->mesh;
   FEMO_REQUIRE(x->n >= m->n_vert && y->n >= m->n_rows, "vector size mismatch in spmv");
   FEMO_REQUIRE(x->d != y->d, "spmv cannot run in place");
+  femo_vec_touch(y);
   const double* vals = A->d_vals;
   if (transpose) {
     FEMO_TRY(femo_mat_ensure_transpose(const_cast<femo_mat*>(A)));
     vals = A->d_valsT;
   }
+  if (m->n_nbr > 0) femo_vec_touch(const_cast<femo_vec*>(x));     // its ghost entries are refreshed
   if (m->n_nbr > 0 && m->d_slices_int != nullptr)
     return halo_spmv_overlapped(A, vals, x->d, y->d, nullptr, nullptr, false, false, nullptr, nullptr);
   if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, x->d));
@@ -920,6 +923,7 @@ extern "C" int femo_bench_spmv(const femo_mat* A, const femo_vec* x, femo_vec* y
   FEMO_REQUIRE(A && x && y && ms_per_launch && reps > 0, "bad argument");
   femo_ctx* ctx = A->mesh->ctx;
   FEMO_REQUIRE(x->n >= A->mesh->n_vert && y->n >= A->mesh->n_rows, "vector size mismatch");
+  femo_vec_touch(y);
   // the launch the CG loop issues: scaled operator, unit diagonal, fused p.Ap partials
   FEMO_TRY(ensure_scaled(const_cast<femo_mat*>(A), false));
   for (int i = 0; i < 3; ++i) FEMO_TRY(launch_spmv(A, A->d_valsS, x->d, y->d, ctx->d_partials + 3 * FEMO_MAX_PARTIALS, nullptr, true));
@@ -1174,6 +1178,7 @@ extern "C" int femo_mat_pc_apply(const femo_mat* A_, const femo_vec* r, femo_vec
   const int64_t n = m->n_rows;
   FEMO_REQUIRE(A->bpx_ok, "the BPX preconditioner needs an operator assembled from a Poisson-type form");
   FEMO_REQUIRE(r->n >= n && z->n >= n && r->d != z->d, "vector size mismatch in pc_apply");
+  femo_vec_touch(z);
   hipStream_t st = ctx->stream;
   FEMO_TRY(ensure_s(A));
   FEMO_TRY(femo_pc_build(m));
@@ -1201,6 +1206,7 @@ extern "C" int femo_solve_cg(const femo_mat* A_, int transpose, const femo_vec* 
   const int64_t n = m->n_rows;
   FEMO_REQUIRE(b->n >= n && x->n >= m->n_vert, "vector size mismatch in solve_cg");
   FEMO_REQUIRE(b->d != x->d, "solve_cg cannot run in place");
+  femo_vec_touch(x);
   memset(info, 0, sizeof *info);
   FEMO_REQUIRE(opts->pc == FEMO_PC_JACOBI || opts->pc == FEMO_PC_BPX, "unknown preconditioner %d", opts->pc);
   if (opts->pc == FEMO_PC_BPX) return solve_pcg_bpx(A, transpose, b, x, opts, info);
@@ -1365,6 +1371,7 @@ extern "C" int femo_solve_bicgstab(const femo_mat* A_, int transpose, const femo
   const int64_t n = m->n_rows;
   FEMO_REQUIRE(b->n >= n && x->n >= m->n_vert, "vector size mismatch in solve_bicgstab");
   FEMO_REQUIRE(b->d != x->d, "solve_bicgstab cannot run in place");
+  femo_vec_touch(x);
   memset(info, 0, sizeof *info);
   hipStream_t st = ctx->stream;
   FEMO_HIP_CHECK(hipEventRecord(ctx->ev0, st));

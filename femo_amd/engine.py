@@ -34,6 +34,87 @@ def _h(obj) -> Optional[H]:
     return None if obj is None else obj.handle
 
 
+# ------------------------------------------------------------------ host memory ----
+class _PinnedBlock:
+    """One block of ``femo_host_alloc``; NumPy arrays built on it keep it alive (``ndarray.base``),
+    the last reference returns it to the library's recycling list."""
+
+    __slots__ = ("ptr", "n", "__array_interface__", "__weakref__")
+
+    def __init__(self, n: int):
+        lib = _lib.load()
+        p = C.c_void_p()
+        check(lib.femo_host_alloc(max(int(n), 1) * 8, C.byref(p)))
+        self.ptr, self.n = p.value, int(n)
+        self.__array_interface__ = dict(shape=(self.n,), typestr="<f8", data=(self.ptr, False), version=3)
+
+    def __del__(self):
+        p, self.ptr = self.ptr, None
+        if p:
+            try:
+                _lib.load().femo_host_free(C.c_void_p(p))
+            except Exception:
+                pass
+
+
+def pinned_empty(n: int) -> np.ndarray:
+    """Writable fp64 array in pinned host memory (one DMA to / from the device).  The owner of such
+    an array calls ``host_touch`` after writing to it; arrays the library *returns* are read-only
+    views instead, so that it can trust them as exact copies of the device vector they came from."""
+    return np.asarray(_PinnedBlock(n))
+
+
+def pinned_array(values) -> np.ndarray:
+    """Read-only pinned copy of ``values`` (what bench.py / a driver hands to the operators)."""
+    a = _f64(values).ravel()
+    out = pinned_empty(a.size)
+    host_copy(out, a)
+    out.flags.writeable = False
+    return out
+
+
+def is_pinned(a: np.ndarray) -> bool:
+    return bool(_lib.load().femo_host_is_pinned(C.c_void_p(a.ctypes.data), a.nbytes))
+
+
+def host_touch(a: np.ndarray) -> None:
+    """Tell the library that ``a`` (pinned) was written on the host: it no longer mirrors a device vector."""
+    check(_lib.load().femo_host_touch(C.c_void_p(a.ctypes.data)))
+
+
+def writable(a: np.ndarray) -> np.ndarray:
+    """Writable alias of an array the library returned read-only.  For its new owner (a driver that
+    accumulates into a result in place); the block stops counting as a mirror of its device vector."""
+    if a.flags.writeable:
+        return a
+    base = a.base
+    if not isinstance(base, _PinnedBlock) or a.ctypes.data != base.ptr or a.size != base.n:
+        raise ValueError("writable(): not a whole array returned by the engine")
+    host_touch(a)
+    return np.asarray(base)
+
+
+def host_copy(dst: np.ndarray, src: np.ndarray) -> None:
+    """dst[:] = src on the library's host threads (both contiguous fp64)."""
+    assert dst.flags.c_contiguous and src.flags.c_contiguous and dst.dtype == src.dtype == np.float64 and dst.size == src.size
+    check(_lib.load().femo_host_copy(C.c_void_p(dst.ctypes.data), C.c_void_p(src.ctypes.data), dst.size))
+
+
+def host_axpby(a: float, x: np.ndarray, b: float, y: np.ndarray) -> None:
+    """y = a x + b y on the library's host threads."""
+    assert y.flags.c_contiguous and x.flags.c_contiguous and y.dtype == x.dtype == np.float64 and y.size == x.size
+    check(_lib.load().femo_host_axpby(y.size, float(a), C.c_void_p(x.ctypes.data), float(b), C.c_void_p(y.ctypes.data)))
+
+
+def host_stats(reset: bool = False) -> Dict[str, int]:
+    st = _lib.HostStats()
+    lib = _lib.load()
+    check(lib.femo_host_get_stats(C.byref(st)))
+    if reset:
+        check(lib.femo_host_reset_stats())
+    return {k: int(getattr(st, k)) for k, _ in _lib.HostStats._fields_}
+
+
 class EmuGroup:
     """In-process rank emulation (tests): ``nranks`` contexts on one GPU, one host thread each, whose
     collectives go through host memory and barriers instead of RCCL (include/femo_hip.h)."""
@@ -119,10 +200,27 @@ class Vec:
         check(self.lib.femo_vec_set_host(self.handle, _ptr(a), a.size))
         return self
 
-    def get(self, n: Optional[int] = None) -> np.ndarray:
-        out = np.empty(self.n if n is None else n, dtype=np.float64)
-        check(self.lib.femo_vec_get_host(self.handle, _ptr(out), out.size))
+    def get(self, n: Optional[int] = None, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """Host copy.  Without ``out`` the result lives in a pinned block (one DMA, no page faults of a
+        fresh allocation) and is READ-ONLY: the library remembers it as an exact copy of this vector,
+        so handing it back to ``set`` moves no PCIe bytes while the vector is unchanged
+        (include/femo_hip.h, "host memory").  ``engine.writable(a)`` gives its owner a writable alias."""
+        n = self.n if n is None else int(n)
+        if out is not None:
+            assert out.dtype == np.float64 and out.flags.c_contiguous and out.size == n
+            check(self.lib.femo_vec_get_host(self.handle, _ptr(out), n))
+            return out
+        out = pinned_empty(n)
+        check(self.lib.femo_vec_get_host(self.handle, _ptr(out), n))
+        out.flags.writeable = False
         return out
+
+    def add_to_host(self, host: np.ndarray, n: Optional[int] = None) -> np.ndarray:
+        """host[:n] += self[:n] in place (contiguous fp64 array)."""
+        n = self.n if n is None else int(n)
+        assert host.dtype == np.float64 and host.flags.c_contiguous and host.flags.writeable and host.size >= n
+        check(self.lib.femo_vec_add_to_host(self.handle, _ptr(host), n))
+        return host
 
     def fill(self, value: float) -> "Vec":
         check(self.lib.femo_vec_fill(self.handle, float(value)))

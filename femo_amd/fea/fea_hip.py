@@ -73,6 +73,7 @@ class FEA(object):
         # additions (not in the reference)
         self.consistent_bc_partials = False   # zero Dirichlet rows of dR/du, dR/df in the jac-vec products
         self.reference_fwd_bug = False        # reproduce solveLinearFwd's zeros (fea_dolfinx.py:192-206)
+        self.reload_in_jacvec = False         # re-send inputs/state in compute_jacvec_product (state_model.py:168-173)
 
     # ------------------------------------------------------------------ registration ----
     def _recorded(self, name, record, **fields):

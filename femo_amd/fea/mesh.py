@@ -45,6 +45,22 @@ class Mesh:
     def centroids(self) -> np.ndarray:
         return self.x[self.conn].mean(axis=1)
 
+    def permuted(self, seed: int = 0, cells: bool = False) -> "Mesh":
+        """The same mesh with a random vertex numbering (and, with ``cells``, a random cell order): what
+        an unstructured mesh generator without bandwidth reduction hands over.  No SELL slice is regular,
+        every gather is scattered.  ``vertex_perm[v]`` is the new index of old vertex v."""
+        rng = np.random.default_rng(seed)
+        p = rng.permutation(self.n_vert).astype(np.int32)
+        x = np.empty_like(self.x)
+        x[p] = self.x
+        conn = p[self.conn]
+        cp = rng.permutation(self.n_cell) if cells else None
+        if cp is not None:
+            conn = conn[cp]
+        m = Mesh(x, conn, self.n)
+        m.vertex_perm, m.cell_perm = p, cp
+        return m
+
     def lattice_occupancy(self) -> float:
         """Largest over mean number of vertices in the non-empty bins of the finest BPX lattice: a
         measure of mesh grading.  The lattice hierarchy has no levels between its finest spacing
@@ -61,17 +77,19 @@ class Mesh:
         i.e. it is an exterior facet (the `ds` measure of UFL [ext])."""
         if getattr(self, "_bfacets", None) is None:
             d1 = self.tdim + 1
-            base = np.int64(self.n_vert + 1)
-            keys = np.empty((d1, self.n_cell), dtype=np.int64)
-            for k in range(d1):
-                fv = np.sort(np.delete(self.conn, k, axis=1).astype(np.int64), axis=1)
-                key = fv[:, 0].copy()
-                for j in range(1, fv.shape[1]):
-                    key *= base
-                    key += fv[:, j]
-                keys[k] = key
-            _, inv, cnt = np.unique(keys.ravel(), return_inverse=True, return_counts=True)
-            once = (cnt[inv] == 1).reshape(d1, self.n_cell)
+            # all facets as sorted vertex tuples, (d1 * n_cell, tdim); equal tuples are found by a
+            # lexicographic sort and a comparison of neighbours (no packing of the tuple into one
+            # integer: (n_vert + 1) ** tdim overflows int64 beyond ~2 M vertices in 3-D)
+            fv = np.concatenate([np.sort(np.delete(self.conn, k, axis=1), axis=1) for k in range(d1)], axis=0)
+            order = np.lexsort(tuple(fv[:, j] for j in range(fv.shape[1] - 1, -1, -1)))
+            sf = fv[order]
+            same_next = np.zeros(len(sf), dtype=bool)
+            same_next[:-1] = np.all(sf[1:] == sf[:-1], axis=1)
+            shared = same_next.copy()
+            shared[1:] |= same_next[:-1]
+            once_flat = np.empty(len(sf), dtype=bool)
+            once_flat[order] = ~shared
+            once = once_flat.reshape(d1, self.n_cell)
             mask = np.zeros(self.n_cell, dtype=np.uint8)
             for k in range(d1):
                 mask |= once[k].astype(np.uint8) << np.uint8(k)

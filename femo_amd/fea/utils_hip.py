@@ -63,7 +63,8 @@ def set_context(ctx: Optional[Context], thread_local: bool = False) -> None:
 KSP_OPTIONS = dict(rtol=1e-14, atol=0.0, max_it=100000, check_every=32, pc='bpx')
 _BPX_KINDS = (_lib.PDE_POISSON, _lib.PDE_NL_POISSON)
 BPX_MAX_OCCUPANCY = 20.0      # Mesh.lattice_occupancy() above this: graded mesh, Jacobi does better
-LAST_KSP_INFO: List[dict] = []   # appended by every linear solve (iteration counts for reports)
+LAST_KSP_INFO: List[dict] = []   # appended by every linear solve (iteration counts for reports); callers
+KSP_INFO_CAP = 1 << 16           # that need a complete record clear it first (bench.py); oldest entries go beyond the cap
 
 
 # ------------------------------------------------------- array <-> function ----
@@ -465,6 +466,34 @@ def computeMatVecProductBwd(A, R: Function, device: bool = False):
     return DeviceArray(y, n) if device else y.get(n)
 
 
+def _add_product(target, A, x, transposed: bool):
+    """target += A x (or A^T x) with NumPy's in-place semantics: the ``d_residuals[u] += ...`` /
+    ``d_inputs[arg] += ...`` statements of state_model.py:176-200.  For a NumPy target the sum is
+    formed while the product is copied out of the device (no second pass over the host array)."""
+    y = A.new_col_vec() if transposed else A.new_row_vec()
+    (A.multTranspose if transposed else A.mult)(_as_vec(x), y)
+    n = A.getSizes()[1 if transposed else 0]
+    if isinstance(target, DeviceArray):
+        target += DeviceArray(y, n)
+        return target
+    if (isinstance(target, np.ndarray) and target.dtype == np.float64 and target.flags.c_contiguous
+            and target.flags.writeable and target.size == n):
+        y.add_to_host(target, n)
+        return target
+    target += y.get(n)
+    return target
+
+
+def addMatVecProductFwd(target, A, x):
+    """target += A x  (utils_dolfinx.py:256-264 followed by the caller's ``+=``)."""
+    return _add_product(target, A, x, False)
+
+
+def addMatVecProductBwd(target, A, R):
+    """target += A^T R  (utils_dolfinx.py:275-287 followed by the caller's ``+=``)."""
+    return _add_product(target, A, R, True)
+
+
 # ------------------------------------------------------------- linear solves ----
 class KSP:
     """A configured Jacobi-CG solve on a fixed operator (PETSc KSP stand-in).
@@ -496,7 +525,8 @@ class KSP:
                                   residual_norm=self.info.residual_norm, rhs_norm=self.info.rhs_norm,
                                   solve_ms=self.info.solve_ms, spmv_ms=self.info.spmv_ms,
                                   spmv_samples=self.info.spmv_samples))
-        del LAST_KSP_INFO[:-64]
+        if len(LAST_KSP_INFO) > KSP_INFO_CAP:
+            del LAST_KSP_INFO[:-KSP_INFO_CAP // 2]
         if self.info.converged != 1:
             raise RuntimeError(f"{'CG' if self.A.symmetric else 'BiCGSTAB'} did not converge: {self.info.iterations} iterations, "
                                f"||r|| = {self.info.residual_norm:.3e}, ||b|| = {self.info.rhs_norm:.3e}")

@@ -21,7 +21,8 @@
  *     and offsets int64.
  *   - host<->device copies are synchronous w.r.t. the host (they synchronise the
  *     context's stream); compute entry points are asynchronous unless they
- *     return a scalar to the host.
+ *     return a scalar to the host.  See "host memory" below for pinned blocks and
+ *     the provenance rule that elides repeated uploads.
  */
 #ifndef FEMO_HIP_H
 #define FEMO_HIP_H
@@ -116,10 +117,48 @@ int64_t femo_vec_size(const femo_vec* v);
 void*   femo_vec_device_ptr(femo_vec* v);
 int     femo_vec_set_host(femo_vec* v, const double* host, int64_t n);      /* setFuncArray */
 int     femo_vec_get_host(const femo_vec* v, double* host, int64_t n);      /* getFuncArray */
+/* host[0:n] += v[0:n]: the `d_inputs[name] += dRdf^T dR` of state_model.py:190-200 without a second
+ * pass over the host array (the add runs in the host threads that drain the staging slots).       */
+int     femo_vec_add_to_host(const femo_vec* v, double* host, int64_t n);
 int     femo_vec_fill(femo_vec* v, double value);                           /* Vec.set      */
 int     femo_vec_copy(femo_vec* dst, const femo_vec* src);
 int     femo_vec_axpy(femo_vec* y, double a, const femo_vec* x);            /* y += a x     */
 int     femo_vec_dot(const femo_vec* x, const femo_vec* y, int64_t n, double* out);
+
+/* ---- host memory of the array boundary (csrc/hostmem.cpp) -------------------------------------
+ * The CSDL operators exchange NumPy arrays with the FE layer in every method (state_model.py:81-84,
+ * 94-96, 123-124, 171-172; output_model.py:70-72, 78-80); here each exchange is a PCIe transfer.
+ *   - femo_host_alloc / femo_host_free: pinned blocks (recycled, kept pinned).  Transfers from / to
+ *     them are one DMA; from / to other (pageable) memory the library pipelines 8 MiB chunks through
+ *     pinned staging slots with a pool of host threads.
+ *   - femo_host_register / _unregister: pin a caller-owned range in place (e.g. a backend's state vector).
+ *   - provenance: a pinned block filled by femo_vec_get_host, or uploaded by femo_vec_set_host,
+ *     from its base address is remembered as an exact copy of that device vector.  Sending it again
+ *     (to the same or another vector) moves no PCIe bytes while the source vector is unchanged.
+ *     Whoever writes to such a block on the host MUST call femo_host_touch first/afterwards; the
+ *     library's own host writers do.  FEMO_HOST_VERIFY=1 (environment) checks every elided upload.
+ *   - femo_host_copy / femo_host_axpby: y = x, y = a x + b y on the library's host threads, for
+ *     drivers that keep their variables in pinned blocks (touch the destination themselves).   */
+typedef struct femo_host_stats {
+  int64_t h2d_pinned, h2d_pinned_bytes;     /* one DMA from a pinned block              */
+  int64_t h2d_staged, h2d_staged_bytes;     /* pageable source through the staging ring */
+  int64_t h2d_skipped, h2d_skipped_bytes;   /* elided: the vector already held the data */
+  int64_t h2d_as_d2d, h2d_as_d2d_bytes;     /* elided: copied from another device vector */
+  int64_t d2h_pinned, d2h_pinned_bytes;
+  int64_t d2h_staged, d2h_staged_bytes;     /* pageable destination, or accumulate      */
+} femo_host_stats;
+int femo_host_alloc(int64_t bytes, void** out);
+int femo_host_free(void* p);
+int femo_host_trim(void);                    /* release the recycled blocks            */
+int femo_host_register(void* p, int64_t bytes);
+int femo_host_unregister(void* p);
+int femo_host_touch(void* p);                /* the block containing p was written on the host */
+int femo_host_is_pinned(const void* p, int64_t bytes);
+int femo_host_threads(void);
+int femo_host_copy(double* dst, const double* src, int64_t n);
+int femo_host_axpby(int64_t n, double a, const double* x, double b, double* y);
+int femo_host_get_stats(femo_host_stats* out);
+int femo_host_reset_stats(void);
 
 /* ---- mesh -----------------------------------------------------------------
  * x: (n_vert, tdim) row-major; conn: (n_cell, tdim+1).  n_rows <= n_vert is

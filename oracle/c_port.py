@@ -152,11 +152,15 @@ def poisson_cycle(tdim: int, x: np.ndarray, conn: np.ndarray, f: np.ndarray, u_d
     else:
         solve = lambda A_, b_, atol_: pcg(rowptr, col, A_, b_, rtol, atol_, max_it)
 
-    t_cycle = time.perf_counter()
+    diag_at = _diag_index(rowptr, col)                      # set-up as well (pattern only)
+    NOISE_FACTOR = 64.0                                     # the engine's rule (utils_hip._NewtonBase): Newton
+    eps = np.finfo(np.float64).eps                          # corrections below the residual's rounding error
+    t_cycle = time.perf_counter()                           # are not solved for
     t0 = time.perf_counter()
     u = np.zeros(nv)
     its_newton = []
     atol = 0.0
+    z0 = None
     # Newton, always 3 iterations (utils_dolfinx.py:419-449); F assembled 4 times
     F = residual(tdim, x, conn, u, f)
     for k in range(3):
@@ -170,10 +174,11 @@ def poisson_cycle(tdim: int, x: np.ndarray, conn: np.ndarray, f: np.ndarray, u_d
         dx, it, res = solve(A, b, atol)
         if k == 0:
             T["cg_fwd"] = time.perf_counter() - t1
-            dinv = 1.0 / A[_diag_index(rowptr, col)]
-            atol = rtol * float(np.sqrt(b @ (dinv * b)))
+            dinv = 1.0 / A[diag_at]
+            z0 = float(np.sqrt(b @ (dinv * b)))
         its_newton.append(it)
         u -= dx
+        atol = max(rtol * z0, NOISE_FACTOR * eps * float(np.sqrt(u @ u)))
         F = residual(tdim, x, conn, u, f)
     T["newton_total"] = time.perf_counter() - t0
     t0 = time.perf_counter()

@@ -31,11 +31,54 @@ def test_cpu_baseline_leg_runs_the_same_preconditioner():
     import bench
 
     class Args:
-        cpu_n, n = 20, 215
+        cpu_n, n, jitter = 20, 215, 0.0
 
     for pc in ("bpx", "jacobi"):
         bench.PC = pc
         out = bench.cpu_baseline(Args, [42, 0, 0, 42], 10077696, 59630250, 150048286)
         assert out["kind"] == "port" and out["unit"] == "DOFs/s" and out["value"] > 0 and out["cores"] >= 1
-        assert pc.upper() in out["sample"]
+        assert pc.upper() in out["sample"] and "scaled to n=215" in out["sample"]
     bench.PC = "bpx"
+
+    class Same:                       # the default: the benchmark's own size, nothing extrapolated
+        cpu_n, n, jitter = 0, 16, 0.0
+
+    out = bench.cpu_baseline(Same, [30, 0, 0, 30], 17 ** 3, 6 * 16 ** 3, 1)
+    assert "nothing scaled" in out["sample"] and out["value"] > 0
+    # the port mirrors the engine's Newton noise-floor rule: solves 2 and 3 stop at once
+    assert "split_s" in out and out["sample"].count("[") >= 1
+
+
+def test_cpu_port_newton_noise_rule():
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from oracle import c_port
+    from oracle import femo_oracle as fo
+    m = fo.unit_cube_mesh(12)
+    f = np.ones(m.n_cell)
+    bd = fo.boundary_vertices_box(m.x)
+    out = c_port.poisson_cycle(3, m.x, m.conn, f, fo.u_target(m.x), bd, 1e-6, rtol=1e-14, pc="bpx")
+    assert out["it_fwd"][0] > 5 and out["it_fwd"][1] <= 2 and out["it_fwd"][2] <= 2
+    ref = fo.reference_cycle(m, f, fo.u_target(m.x), bd, np.zeros(len(bd)))
+    assert np.abs(out["u"] - ref["u"]).max() <= 1e-10 * np.abs(ref["u"]).max()
+    assert np.abs(out["grad"] - ref["grad"]).max() <= 1e-10 * np.abs(ref["grad"]).max()
+
+
+def test_multi_gpu_flag_without_launcher_starts_a_torchrun_job(monkeypatch):
+    """`python bench.py --gpus 2` must not quietly benchmark one GPU (it relaunches itself under torchrun)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    calls = []
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    import subprocess as sp
+
+    class R:
+        returncode = 7
+
+    monkeypatch.setattr(sp, "run", lambda cmd, **k: (calls.append(cmd), R())[1])
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 7
+    assert calls and "torch.distributed.run" in calls[0] and "--nproc-per-node=2" in calls[0]

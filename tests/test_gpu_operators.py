@@ -49,7 +49,7 @@ def build_poisson(mesh, alpha=1e-6):
     return fea, f_ex, u_ex
 
 
-def make_sim(mesh, device, alpha=1e-6):
+def make_sim(mesh, device, alpha=1e-6, pinned=True):
     from femo_amd.csdl_opt.fea_model import FEAModel
     from femo_amd.csdl_opt.simulator import Simulator
     fea, f_ex, u_ex = build_poisson(mesh, alpha)
@@ -59,7 +59,7 @@ def make_sim(mesh, device, alpha=1e-6):
     model.create_input('f', shape=n_f, val=0.1 * np.ones(n_f) * 0.86)
     model.add_design_variable('f')
     model.add_objective('l2_functional', scaler=1e5)
-    return Simulator(model, device=device), fea, f_ex, u_ex
+    return Simulator(model, device=device, pinned=pinned), fea, f_ex, u_ex
 
 
 def _rel(a, b):
