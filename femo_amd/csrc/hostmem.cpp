@@ -53,8 +53,10 @@ int usable_cores() {
 class HostPool {
  public:
   static HostPool& get() {
-    static HostPool p;
-    return p;
+    // never destroyed: the workers wait on its condition variable until the process ends, and destroying a
+    // condition variable with waiters blocks in glibc (an interpreter exiting would hang)
+    static HostPool* p = new HostPool();
+    return *p;
   }
   int threads() const { return nthreads_; }
   void run(int nparts, const std::function<void(int)>& fn) {

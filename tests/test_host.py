@@ -289,3 +289,23 @@ def test_abstract_fea_registry():
     assert f.name == 'f' and u.name == 'u' and fea.mesh == "m"
     assert fea.states_dict['u']['arguments'] == ('f', 'g') and fea.outputs_dict['J'] == {'form': 'form', 'arguments': ('u', 'f')}
     assert fea.bcs_list == ['bc0'] and set(fea.inputs_dict['f']) == {'function'}
+
+
+def test_host_thread_pool_runs_and_lets_the_process_exit():
+    """femo_host_copy / femo_host_axpby need no GPU; the pool's workers must not keep the interpreter
+    from exiting (a static pool destroyed at exit blocked on its waiting workers)."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np\n"
+        "from femo_amd import engine as E\n"
+        "x = np.random.default_rng(0).random(2_000_003); y = np.zeros_like(x)\n"
+        "for _ in range(20): E.host_axpby(2.0, x, 0.0, y)\n"
+        "z = np.full(x.size, np.nan); E.host_axpby(0.0, z, 0.0, z)\n"
+        "w = np.empty_like(x); E.host_copy(w, x)\n"
+        "assert np.array_equal(y, 2 * x) and not z.any() and np.array_equal(w, x)\n"
+        "print('ok')\n"
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, cwd=root)
+    assert p.returncode == 0 and p.stdout.strip() == "ok", p.stderr
