@@ -90,10 +90,10 @@ class Simulator:
             elif not a.flags.writeable and E.is_pinned(a):
                 value = a                                   # a result of the engine (or engine.pinned_array): adopt
             else:
-                own = self.__dict__.setdefault("_own", {})
-                w = own.get(name)
+                store = self.__dict__.setdefault("_storage", {})
+                w = store.get(name)
                 if w is None or w.size != a.size:
-                    w = own[name] = E.pinned_empty(a.size)
+                    w = store[name] = E.pinned_empty(a.size)
                 E.host_copy(w, a)                           # the driver's own storage; announces the write
                 value = _readonly(w)
         self.values[name] = value

@@ -67,7 +67,7 @@ def test_full_size_properties(ctx, n):
     ud = fo.u_target(mesh.x)
     UD, G, GF, LAM = E.Vec(ctx, N).set(ud), E.Vec(ctx, N), E.Vec(ctx, NC), E.Vec(ctx, N)
     E.functional_grad_u(dm, 0, [alpha], X, F, UD, G)
-    g = G.get()
+    g = np.array(G.get())                      # results are read-only (they mirror the device vector): copy to edit
     g[bd] = 0.0
     A.solve_cg(E.Vec(ctx, N).set(g), LAM, transpose=True, rtol=1e-14)
     DV, DT = E.Vec(ctx, NC * 4), E.Vec(ctx, NC)

@@ -64,10 +64,14 @@ def test_uploads_are_elided_only_while_exact(ctx):
     st = E.host_stats()
     assert st["h2d_as_d2d"] == 1 and st["h2d_pinned"] == 0
     assert np.array_equal(w.get(), a)
-    v.fill(2.0)                                         # v changed: h no longer mirrors it
+    v.fill(2.0)                                         # v changed: h no longer mirrors it, but it mirrors w now
     v.set(h)
     st = E.host_stats()
-    assert st["h2d_pinned"] == 1
+    assert st["h2d_as_d2d"] == 2 and st["h2d_pinned"] == 0
+    assert np.array_equal(v.get(), a)
+    w.fill(3.0); v.fill(2.0)                            # no device vector holds the content any more: real upload
+    v.set(h)
+    assert E.host_stats()["h2d_pinned"] == 1
     assert np.array_equal(v.get(), a)
     # after the upload the block mirrors v again
     v.set(h)
@@ -78,6 +82,7 @@ def test_uploads_are_elided_only_while_exact(ctx):
     v.set(hw)
     assert E.host_stats()["h2d_pinned"] == 2
     assert v.get()[0] == 123.0
+    w.set(a)
     # a destroyed source vector cannot serve as the source of a device-to-device copy
     h2 = w.get()
     del w
