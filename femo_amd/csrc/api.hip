@@ -47,6 +47,22 @@ __global__ void k_bc_mask(int64_t n, const int32_t* __restrict__ dofs, const dou
   }
 }
 
+// rowmask[row]: bit k = the row's k-th off-diagonal column is in the Dirichlet set, bit 63 = the row itself
+__global__ void k_bc_rowmask(int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ mptr, const int32_t* __restrict__ cols,
+                             const int32_t* __restrict__ rowlen, const uint8_t* __restrict__ mask, uint64_t* __restrict__ out) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n_slices * 64) return;
+  uint64_t bits = 0;
+  if (row < n_rows) {
+    const int64_t base = mptr[row >> 6];
+    const int lane = (int)(row & 63), len = rowlen[row];
+    for (int k = 0; k < len; ++k)
+      if (mask[cols[femo_sell_index(base, k, lane)]]) bits |= uint64_t(1) << k;
+    if (mask[row]) bits |= uint64_t(1) << 63;
+  }
+  out[row] = bits;
+}
+
 // w = (g - u) on the Dirichlet set, 0 elsewhere (w pre-zeroed)
 __global__ void k_bc_lift_vec(int64_t n, const int32_t* __restrict__ dofs, const double* __restrict__ g,
                               const double* __restrict__ u, double* __restrict__ w) {
@@ -302,7 +318,7 @@ int femo_mesh_destroy(femo_mesh* m) {
   hipFree(m->d_x); hipFree(m->d_conn); hipFree(m->d_vptr); hipFree(m->d_visit_cell);
   hipFree(m->d_visit_slots); hipFree(m->d_mptr); hipFree(m->d_cols); hipFree(m->d_rowlen);
   femo_pc_destroy(m);
-  hipFree(m->d_bvmask);
+  hipFree(m->d_bvmask); hipFree(m->d_visit_rec); hipFree(m->d_load);
   hipFree(m->d_sdelta); hipFree(m->d_bfacets); hipFree(m->d_tperm); hipFree(m->d_send_idx); hipFree(m->d_send_buf); hipFree(m->d_scratch); hipFree(m->d_slices_int); hipFree(m->d_slices_bnd);
   delete m;
   return 0;
@@ -392,6 +408,12 @@ int femo_bc_create(femo_mesh* m, int64_t n, const int32_t* dofs, const double* v
     hipLaunchKernelGGL(k_bc_mask, dim3(grid_for(n)), dim3(256), 0, st, n, b->d_dofs, b->d_vals, b->d_mask, b->d_dense);
     FEMO_HIP_CHECK(hipGetLastError());
   }
+  if (m->max_rowlen <= 62 && m->n_slices > 0) {
+    const int64_t nr = m->n_slices * FEMO_WAVE;
+    FEMO_HIP_CHECK(hipMalloc(&b->d_rowmask, nr * sizeof(uint64_t)));
+    hipLaunchKernelGGL(k_bc_rowmask, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, m->n_rows, m->n_slices, m->d_mptr, m->d_cols, m->d_rowlen, b->d_mask, b->d_rowmask);
+    FEMO_HIP_CHECK(hipGetLastError());
+  }
   FEMO_HIP_CHECK(hipStreamSynchronize(st));
   *out = b;
   return 0;
@@ -400,7 +422,7 @@ int femo_bc_create(femo_mesh* m, int64_t n, const int32_t* dofs, const double* v
 int femo_bc_destroy(femo_bc* b) {
   if (!b) return 0;
   hipStreamSynchronize(b->mesh->ctx->stream);
-  hipFree(b->d_dofs); hipFree(b->d_vals); hipFree(b->d_mask); hipFree(b->d_dense);
+  hipFree(b->d_dofs); hipFree(b->d_vals); hipFree(b->d_mask); hipFree(b->d_dense); hipFree(b->d_rowmask);
   delete b;
   return 0;
 }
@@ -457,7 +479,7 @@ int femo_assemble_residual(femo_mesh* m, int pde, const double* params, const fe
   FEMO_REQUIRE(aux == nullptr || aux->n >= m->n_vert, "aux field shorter than n_vert");
   if (m->n_nbr > 0) FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(u)));
   femo_vec_touch(r);
-  return femo_launch_residual(m, pde, params, u->d, f->d, aux ? aux->d : nullptr, r->d);
+  return femo_launch_residual(m, pde, params, u->d, f->d, aux ? aux->d : nullptr, r->d, f->uid, f->gen);
 }
 
 int femo_assemble_jacobian(femo_mesh* m, int pde, const double* params, const femo_vec* u,
@@ -472,7 +494,7 @@ int femo_assemble_jacobian(femo_mesh* m, int pde, const double* params, const fe
   FEMO_TRY(note_pinned_vertices(J, pde, params, bc));
   if (bc)
     return femo_launch_system(m, pde, params, u ? u->d : nullptr, f ? f->d : nullptr, ax, bc->d_mask, bc->d_dense,
-                              nullptr, nullptr, J->d_diag, J->d_vals, nullptr);
+                              nullptr, nullptr, J->d_diag, J->d_vals, nullptr, f ? f->uid : 0, f ? f->gen : 0, bc->d_rowmask);
   return femo_launch_system(m, pde, params, u ? u->d : nullptr, f ? f->d : nullptr, ax, nullptr, nullptr,
                             J->d_diag, J->d_vals, nullptr, nullptr, nullptr);
 }
@@ -500,7 +522,7 @@ int femo_assemble_system(femo_mesh* m, int pde, const double* params, const femo
                             bc ? bc->d_mask : nullptr, bc ? bc->d_dense : nullptr,
                             J_nobc ? J_nobc->d_diag : nullptr, J_nobc ? J_nobc->d_vals : nullptr,
                             A_bc ? A_bc->d_diag : nullptr, A_bc ? A_bc->d_vals : nullptr,
-                            rhs ? rhs->d : nullptr);
+                            rhs ? rhs->d : nullptr, f ? f->uid : 0, f ? f->gen : 0, bc ? bc->d_rowmask : nullptr);
 }
 
 int femo_bc_apply_rhs(const femo_bc* bc, const femo_vec* u, femo_vec* b) {

@@ -16,6 +16,8 @@
 //                utils_dolfinx.py:189-202 assembleSystem   (state_model.py:149)
 //   dRdf      -> state_model.py:141 assembleMatrix(computePartials(res, f))
 //   functional value / partials -> output_model.py:69-87
+#include <cstdlib>
+
 #include "femo_internal.h"
 
 namespace {
@@ -36,6 +38,14 @@ __device__ __forceinline__ void load_conn(const int32_t* __restrict__ conn, int6
   }
 }
 
+// Incidence word `slots`: byte j = off-diagonal slot (in the visiting row) of the j-th vertex of the cell OTHER
+// than the visiting one, in increasing local index (byte 3 unused for tetrahedra, bytes 2-3 for triangles).
+// Slot of canonical local vertex b != a:
+__device__ __forceinline__ int slot_of(uint32_t slots, int a, int b) {
+  const int j = b - (b > a ? 1 : 0);
+  return (int)((slots >> (8 * j)) & 0xFFu);
+}
+
 // The vertices of a visited cell without touching `conn`: local vertex a is the visiting row
 // itself, the others sit in the row's own column list at the positions the slot bytes name
 // (row + delta[pos] on regular slices).  `conn` rows of neighbouring lanes are 96 B apart (one
@@ -48,10 +58,7 @@ __device__ __forceinline__ void row_cell_vertices(int64_t row, int lane, int a, 
   // `regular` is uniform over the wave (a property of the slice)
   int pos[D + 1];
 #pragma unroll
-  for (int b = 0; b <= D; ++b) {
-    const int p = (slots >> (8 * b)) & 0xFF;
-    pos[b] = (b == a) ? 0 : p;
-  }
+  for (int b = 0; b <= D; ++b) pos[b] = (b == a) ? 0 : slot_of(slots, a, b);
   if (regular) {
 #pragma unroll
     for (int b = 0; b <= D; ++b) v[b] = (int32_t)row + dl[pos[b]];
@@ -285,6 +292,287 @@ __device__ __forceinline__ void beam_khat_row(double h, const double w[4], doubl
   for (int b = 0; b < 4; ++b) k[b] = (w[0] * r0[b] + w[1] * r1[b] + w[2] * r2[b] + w[3] * r3[b]) * i3;
 }
 
+// ------------------------------------------------ P1 Poisson: pair formulation ---
+// The linear-Poisson walks (BASELINE.json's benchmark form) do not build the gradient table of a cell.
+// For a visiting vertex a and another vertex b of the cell, with c < d the two remaining vertices in local
+// index order,
+//     K_ab = T_ab / (36 |T|),   T_ab = (e.u)(e.v) - (e.e)(u.v),   e = p_d - p_c, u = p_a - p_c, v = p_b - p_c
+// (Lagrange identity for the dot product of the two face normals; in 2-D K_ab = -(u.v) / (4 |T|) with the one
+// remaining vertex c).  With every product and sum rounded explicitly the expression is symmetric in a <-> b
+// bit for bit -- multiplication commutes and both rows subtract the same pairs of coordinates -- so K[i][j] ==
+// K[j][i] bitwise WITHOUT bringing the cell into a canonical vertex order first: the lane-varying selects that
+// made up a quarter of the old walk's instructions are gone, and so are the division and the 3x3 cofactors.
+// 1/(36|T|) and |T| come from a per-cell table written once per mesh (k_cell_weights; 16 B per cell, one
+// gather per visit).  K_aa = -sum_b K_ab (rows of the P1 stiffness matrix sum to zero).
+typedef double femo_d2 __attribute__((ext_vector_type(2)));
+
+// gathers off a wave-uniform base with a 32-bit byte offset: one global_load with scalar base + VGPR offset,
+// no 64-bit address arithmetic per lane (the launcher checks that every array stays below 4 GiB)
+template <class T>
+__device__ __forceinline__ T ldg32(const void* base, uint32_t byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+typedef double femo_d2u __attribute__((ext_vector_type(2), aligned(8)));   // 16-B load at an 8-B aligned address
+
+template <int D>
+__device__ __forceinline__ void ldg_point(const double* __restrict__ x, uint32_t vtx, double (&p)[D]) {
+  const uint32_t off = vtx * (uint32_t)(D * sizeof(double));
+  const femo_d2u q = ldg32<femo_d2u>(x, off);
+  p[0] = q.x; p[1] = q.y;
+  if constexpr (D == 3) p[2] = ldg32<double>(x, off + 16u);
+}
+
+// Explicitly rounded arithmetic for the pair formulation.  HIP's __dmul_rn / __dsub_rn are plain operators
+// compiled with contraction allowed, so the compiler would fuse ONE of the two products of a*b - c*d into the
+// subtraction -- and which one depends on how the expression is written: the three pair expressions would round
+// differently from their mirror images in the neighbouring rows.  Inside these functions contraction is off;
+// the only fused operations are the explicit fma calls of the dot product.
+template <int D>
+__device__ __forceinline__ void subD(const double (&p)[D], const double (&q)[D], double (&r)[D]) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int k = 0; k < D; ++k) r[k] = p[k] - q[k];
+}
+
+template <int D>
+__device__ __forceinline__ double dotP(const double (&p)[D], const double (&q)[D]) {
+#pragma clang fp contract(off)
+  double s = p[0] * q[0];
+#pragma unroll
+  for (int k = 1; k < D; ++k) s = __builtin_fma(p[k], q[k], s);
+  return s;
+}
+
+// a*b - c*d with both products rounded
+__device__ __forceinline__ double det2(double a, double b, double c, double d) {
+#pragma clang fp contract(off)
+  const double ab = a * b, cd = c * d;
+  return ab - cd;
+}
+
+__device__ __forceinline__ double mul_rn(double a, double b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+
+// k[j] = K_{a, other_j}: xo = coordinates of the visiting vertex, o[j] = the other vertices in increasing local index
+template <int D>
+__device__ __forceinline__ void poisson_pairs(const double (&xo)[D], const double (&o)[D][D], double w, double (&k)[D]) {
+  if constexpr (D == 3) {
+    double d0[3], d1[3], g01[3], g02[3], g12[3];
+    subD<3>(xo, o[0], d0);
+    subD<3>(xo, o[1], d1);
+    subD<3>(o[1], o[0], g01);
+    subD<3>(o[2], o[0], g02);
+    subD<3>(o[2], o[1], g12);
+    // pairs (a, o1) and (a, o2): remaining vertices (o0, o2) and (o0, o1), base o0
+    const double A = dotP<3>(g02, d0), B = dotP<3>(g02, g01), C = dotP<3>(g02, g02);
+    const double Dd = dotP<3>(d0, g01), E = dotP<3>(g01, g01);
+    const double T1 = det2(A, B, C, Dd);
+    const double T2 = det2(Dd, B, E, A);
+    // pair (a, o0): remaining (o1, o2), base o1: e = g12, u = d1, v = o0 - o1 = -g01 (exact negation)
+    const double P = dotP<3>(g12, d1), Q = dotP<3>(g12, g01), R = dotP<3>(g12, g12), S = dotP<3>(d1, g01);
+    const double T0 = det2(R, S, P, Q);
+    k[0] = mul_rn(T0, w); k[1] = mul_rn(T1, w); k[2] = mul_rn(T2, w);
+  } else {
+    double d0[2], d1[2], g01[2];
+    subD<2>(xo, o[0], d0);
+    subD<2>(xo, o[1], d1);
+    subD<2>(o[1], o[0], g01);
+    // pair (a, o0): c = o1, u = d1, v = -g01;  pair (a, o1): c = o0, u = d0, v = g01;  K = -(u.v) w
+    k[0] = mul_rn(dotP<2>(d1, g01), w);
+    k[1] = mul_rn(-dotP<2>(d0, g01), w);
+  }
+}
+
+// cw[c] = (1 / (36 |T|), |T|) for tetrahedra, (1 / (4 |T|), |T|) for triangles
+template <int D>
+__global__ __launch_bounds__(FEMO_BLOCK) void k_cell_weights(int64_t n_cell, const int32_t* __restrict__ conn,
+                                                             const double* __restrict__ x, femo_d2* __restrict__ cw) {
+  for (int64_t c = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; c < n_cell; c += (int64_t)gridDim.x * FEMO_BLOCK) {
+    int32_t v[D + 1];
+    load_conn<D>(conn, c, v);
+    CellGeom<D> G;
+    cell_geom<D>(x, v, G);
+    femo_d2 o;
+    o.x = 1.0 / ((D == 3 ? 36.0 : 4.0) * G.vol);
+    o.y = G.vol;
+    cw[c] = o;
+  }
+}
+
+// Incidence record of the pair-formulation walks, 16 B per visit in SELL-64 order (one dwordx4 load):
+//   ca  = cell << 2 | local index of the visiting vertex (-1: padding)
+//   sl  = byte j: off-diagonal slot of the j-th other vertex of the cell in the visiting row
+//   w   = 1/(36|T|) of the cell (1/(4|T|) for triangles), 0 for padding
+struct __attribute__((aligned(16))) P1Rec {
+  int32_t ca;
+  uint32_t sl;
+  double w;
+};
+
+// what a visit gathers: coordinates of the D other vertices, optionally the cell value of a DG0 field and up to
+// two nodal fields at the other vertices
+template <int D>
+struct P1Data {
+  double o[D][D];
+  double fc;
+  double ua[D], ub[D];
+};
+
+// The row walk of a SELL-64 slice, software pipelined: the incidence records of visits s+5 / s+6, the column
+// lookups of visit s+2, the coordinate / field gathers of visit s+1 and the arithmetic of visit s are in flight
+// together, so no load waits for a load issued in the same trip.  Two visits per trip with alternating gather sets.
+// Slice metadata is wave-uniform (scalar registers, scalar-base loads, 32-bit offsets).  Everything a visit
+// needs besides vertex data comes from the coalesced incidence stream -- the cell weight included: a
+// cell-indexed gather costs a 128-B line per lane (cells of neighbouring rows are 6 apart and a cell's four
+// visits are far apart in time): measured 22 GB of fetches per pass on the 10 M-DOF cube against 1.9 GB for the
+// same numbers in the stream.  Padded visits carry weight 0 and read the data of slot 0 instead of being
+// branched around.
+template <int D, bool NEED_X, int NFIELD, bool NEED_F>
+struct P1Walk {
+  const P1Rec* rec; const int32_t* dl; const int32_t* cols_slice;
+  bool regular; int nvis, lane; int32_t row;
+  const double* x; const double* fa; const double* fb; const double* f;
+
+  __device__ __forceinline__ P1Rec fetch(int s) const {
+    const int sc = s < nvis ? s : nvis - 1;                      // wave-uniform
+    typedef int femo_i4 __attribute__((ext_vector_type(4)));
+    const femo_i4 q = ldg32<femo_i4>(rec, (uint32_t)(sc * 64 + lane) * 16u);
+    const bool live = s < nvis && q.x >= 0;
+    P1Rec r;
+    r.ca = live ? q.x : -1;
+    r.sl = live ? (uint32_t)q.y : 0u;
+    r.w = live ? __hiloint2double(q.w, q.z) : 0.0;
+    return r;
+  }
+  __device__ __forceinline__ void lookup(const P1Rec& r, uint32_t (&vt)[D]) const {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const uint32_t pos = (r.sl >> (8 * j)) & 0xFFu;
+      if (regular) vt[j] = (uint32_t)(row + ldg32<int32_t>(dl, pos * 4u));
+      else vt[j] = (uint32_t)ldg32<int32_t>(cols_slice, ((pos >> 1) * 128u + (uint32_t)lane * 2u + (pos & 1u)) * 4u);
+    }
+  }
+  __device__ __forceinline__ void gather(const P1Rec& r, const uint32_t (&vt)[D], P1Data<D>& G) const {
+    if constexpr (NEED_F) G.fc = ldg32<double>(f, ((uint32_t)(r.ca < 0 ? 0 : r.ca) >> 2) * 8u);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      if constexpr (NEED_X) ldg_point<D>(x, vt[j], G.o[j]);
+      if constexpr (NFIELD >= 1) G.ua[j] = ldg32<double>(fa, vt[j] * 8u);
+      if constexpr (NFIELD >= 2) G.ub[j] = ldg32<double>(fb, vt[j] * 8u);
+    }
+  }
+  template <class Body>
+  __device__ __forceinline__ void run(Body&& body) const {
+    if (nvis <= 0) return;
+    // Loads of a wave return in issue order.  The incidence records come from HBM (they stream, nothing caches
+    // them), lookups and gathers mostly hit L2: a record fetch is therefore issued LAST in its trip, behind the
+    // gathers the next arithmetic waits for, and two visits further ahead than the lookup needs it.
+    P1Rec r0 = fetch(0), r1 = fetch(1), r2 = fetch(2), r3 = fetch(3), r4 = fetch(4);
+    uint32_t v0[D], v1[D];
+    lookup(r0, v0);
+    lookup(r1, v1);
+    P1Data<D> A, B;
+    gather(r0, v0, A);
+    for (int s = 0; s < nvis; s += 2) {
+      uint32_t v2[D], v3[D];
+      lookup(r2, v2);
+      gather(r1, v1, B);
+      body(r0, A);
+      const P1Rec r5 = fetch(s + 5);
+      lookup(r3, v3);
+      gather(r2, v2, A);
+      body(r1, B);
+      const P1Rec r6 = fetch(s + 6);
+      r0 = r2; r1 = r3; r2 = r4; r3 = r5; r4 = r6;
+#pragma unroll
+      for (int j = 0; j < D; ++j) v1[j] = v3[j];
+    }
+  }
+};
+
+// wave-uniform slice metadata of a row walk (the slice index comes through readfirstlane: scalar loads)
+template <int D, bool NEED_X, int NFIELD, bool NEED_F>
+__device__ __forceinline__ bool p1_walk_setup(P1Walk<D, NEED_X, NFIELD, NEED_F>& W, int64_t n_rows, int64_t n_blocks,
+                                              const int64_t* __restrict__ vptr, const P1Rec* __restrict__ visit_rec,
+                                              const int64_t* __restrict__ mptr,
+                                              const int32_t* __restrict__ cols, const int32_t* __restrict__ sdelta, int sdelta_stride,
+                                              int64_t& row_out, int64_t& slice_out) {
+  const int64_t blk = femo_xcd_block(blockIdx.x, n_blocks);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t slice = blk * (FEMO_BLOCK / 64) + wave;
+  W.lane = threadIdx.x & 63;
+  row_out = (slice << 6) + W.lane;
+  slice_out = slice;
+  if ((slice << 6) >= n_rows) return false;
+  const int64_t vb = vptr[slice];
+  W.nvis = (int)((vptr[slice + 1] - vb) >> 6);
+  W.rec = visit_rec + vb;
+  W.dl = sdelta + slice * sdelta_stride;
+  W.regular = W.dl[0] != INT32_MIN;
+  W.cols_slice = cols + mptr[slice];
+  W.row = (int32_t)row_out;
+  return true;
+}
+
+// Vector-valued Poisson walks without LDS strips:
+//   KIND 0  r_a = sum_cells sum_b K_ab (u_b - u_a)  - load_a                 evaluate_residuals (state_model.py:75-85)
+//   KIND 1  g_a = sum_cells |T| / ((D+1)(D+2)) (2 e_a + sum_b e_b), e = u - u_d  dJ/du of the tracking functional
+//   KIND 2  load_a = sum_cells f_c |T| / (D+1)                                 the u-independent part of the residual
+template <int D, int KIND>
+__global__ __launch_bounds__(FEMO_BLOCK) void k_p1_row_walk(
+    int64_t n_rows, int64_t n_blocks, const int64_t* __restrict__ vptr, const P1Rec* __restrict__ visit_rec,
+    const int64_t* __restrict__ mptr,
+    const int32_t* __restrict__ cols, const int32_t* __restrict__ sdelta, int sdelta_stride, const double* __restrict__ x,
+    const double* __restrict__ u, const double* __restrict__ second, double* __restrict__ out) {
+  P1Walk<D, KIND == 0, KIND == 0 ? 1 : (KIND == 1 ? 2 : 0), KIND == 2> W;
+  int64_t row, slice;
+  if (!p1_walk_setup(W, n_rows, n_blocks, vptr, visit_rec, mptr, cols, sdelta, sdelta_stride, row, slice)) return;
+  W.x = x; W.fa = u; W.fb = second; W.f = second;
+  const uint32_t r0 = (uint32_t)(row < n_rows ? row : 0);
+  double xo[D];
+  ldg_point<D>(x, r0, xo);
+  double uo = 0.0;
+  if constexpr (KIND == 0) uo = u[r0];
+  if constexpr (KIND == 1) uo = u[r0] - second[r0];
+  constexpr double VOLF = D == 3 ? 36.0 : 4.0;               // |T| = 1 / (VOLF w)
+  double acc = 0.0;
+  W.run([&](const P1Rec& R, const P1Data<D>& V) {
+    if constexpr (KIND == 0) {
+      double k[D];
+      poisson_pairs<D>(xo, V.o, R.w, k);
+#pragma unroll
+      for (int j = 0; j < D; ++j) acc += k[j] * (V.ua[j] - uo);
+    } else {
+      const double vol = R.w > 0.0 ? 1.0 / (VOLF * R.w) : 0.0;
+      if constexpr (KIND == 1) {
+        double es = uo + uo;
+#pragma unroll
+        for (int j = 0; j < D; ++j) es += V.ua[j] - V.ub[j];
+        acc += vol * (1.0 / ((D + 1) * (D + 2))) * es;
+      } else {
+        acc += V.fc * vol * (1.0 / (D + 1));
+      }
+    }
+  });
+  if constexpr (KIND == 0) acc -= second[r0];                // the load vector (KIND 2) of the current f
+  if (row < n_rows) out[row] = acc;
+}
+
+// rec[i] = (incidence words, weight of the cell) of incidence entry i: the one cell-indexed gather, once per mesh
+__global__ void k_visit_records(int64_t n, const int32_t* __restrict__ visit_cell, const uint32_t* __restrict__ visit_slots,
+                                const femo_d2* __restrict__ cw, P1Rec* __restrict__ rec) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    P1Rec r;
+    r.ca = visit_cell[i];
+    r.sl = r.ca >= 0 ? visit_slots[i] : 0u;
+    r.w = r.ca >= 0 ? cw[r.ca >> 2].x : 0.0;
+    rec[i] = r;
+  }
+}
+
 // ---------------------------------------------------------------- residual --
 template <int D, int PDE>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_residual(
@@ -368,12 +656,13 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
     const double* __restrict__ aux, const uint8_t* __restrict__ bfacets, double beta, double sgn,
     const uint8_t* __restrict__ bcmask, const double* __restrict__ bcval,
     double* __restrict__ diag0, double* __restrict__ vals0, double* __restrict__ diag1,
-    double* __restrict__ vals1, double* __restrict__ rhs) {
+    double* __restrict__ vals1, double* __restrict__ rhs, const P1Rec* __restrict__ visit_rec) {
   extern __shared__ double strip[];
   const int tid = threadIdx.x;
   const int64_t blk = femo_xcd_block(blockIdx.x, n_blocks);
   const int64_t row = blk * FEMO_BLOCK + tid;
-  const int64_t slice = row >> 6;
+  // wave-uniform by construction: through readfirstlane the slice metadata lives in scalar registers
+  const int64_t slice = blk * (FEMO_BLOCK / 64) + __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   if ((slice << 6) >= n_rows) return;
   const int len = rowlen[row];
@@ -391,7 +680,25 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
 #pragma unroll
     for (int k = 0; k < D; ++k) xo[k] = x[r0 * D + k];
   }
-  if constexpr (PDE != FEMO_PDE_EB_BEAM) {
+  if constexpr (PDE == FEMO_PDE_POISSON) {
+    // Pair formulation (see poisson_pairs): no canonical vertex order, no gradient table, no division.  The
+    // load vector (the u-independent part of the residual) comes in through `aux`, see femo_launch_system.
+    P1Walk<D, true, 0, false> W;
+    W.rec = visit_rec + vb; W.dl = dl; W.cols_slice = cols + mb;
+    W.regular = regular; W.nvis = nvis; W.lane = lane; W.row = (int32_t)row;
+    W.x = x; W.fa = nullptr; W.fb = nullptr; W.f = nullptr;
+    W.run([&](const P1Rec& R, const P1Data<D>& V) {
+      double k[D];
+      poisson_pairs<D>(xo, V.o, R.w, k);
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        dsum -= k[j];
+        const int pos = (int)((R.sl >> (8 * j)) & 0xFFu);
+        strip[pos * FEMO_BLOCK + tid] = __dadd_rn(strip[pos * FEMO_BLOCK + tid], k[j]);
+      }
+    });
+    if (want_rhs && row < n_rows) racc -= aux[row];
+  } else if constexpr (PDE != FEMO_PDE_EB_BEAM) {
     // Software-pipelined walk.  A visit is a chain of dependent loads (incidence words -> the
     // row's columns -> coordinates, state values); taken one visit at a time the wave sits in
     // s_waitcnt five times per cell.  Three stages in flight: incidence words of visit s+2, column
@@ -468,7 +775,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
           if (b == a) {
             dsum += krow[b];
           } else {
-            const int pos = (sl0 >> (8 * b)) & 0xFF;
+            const int pos = slot_of(sl0, a, b);
             strip[pos * FEMO_BLOCK + tid] = __dadd_rn(strip[pos * FEMO_BLOCK + tid], krow[b]);
           }
         }
@@ -542,7 +849,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
       if (b == a) {
         dsum += krow[b];
       } else {
-        const int pos = (slots >> (8 * b)) & 0xFF;
+        const int pos = slot_of(slots, a, b);
         strip[pos * FEMO_BLOCK + tid] = __dadd_rn(strip[pos * FEMO_BLOCK + tid], krow[b]);
       }
     }
@@ -585,6 +892,175 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
       if (row_bc || by) o.y = 0.0;
     }
     if (vals1) *reinterpret_cast<double2*>(vals1 + idx) = o;
+  }
+  if (want_rhs && valid) rhs[row] = row_bc ? (u[row] - bcval[row]) : (racc + lift);
+}
+
+// ------------------------------------ linear Poisson, row neighbourhood in LDS ---
+// The walk above gathers the coordinates of a visited cell's other vertices per visit: 24 visits x 3 vertices
+// per row although a row has only ~14 distinct neighbours, and with ~20 waves per CU the 32 KB vector L1 keeps
+// none of it (measured at C4: 25 GB of L1 -> L2 requests per pass, the waves parked in s_waitcnt 80 % of their
+// cycles, VALU 25 % busy, HBM 40 %).  Here one wave = one workgroup = one SELL slice keeps, per row,
+//     nx[k][d][lane]   coordinates of the row's k-th off-diagonal column      (gathered once, 14 x 24 B per row)
+//     strip[k][lane]   the off-diagonal entries being accumulated
+// in LDS (index depends on the lane only through `lane`: conflict-free), so a visit reads its three vertices
+// from LDS by the slot bytes of its incidence record and the only memory stream of the loop is the coalesced
+// 16-B record, prefetched a whole chunk of visits ahead into registers.  (NB+NB*D) x 512 B of LDS per wave:
+// 28 KB at 14 neighbours -> 5 waves per CU, which is enough because nothing in the loop waits on a gather.
+template <int D, int CH>
+__global__ __launch_bounds__(64) void k_poisson_system_lds(
+    int64_t n_rows, int64_t n_blocks, int nb, const int64_t* __restrict__ vptr, const P1Rec* __restrict__ visit_rec,
+    const int64_t* __restrict__ mptr, const int32_t* __restrict__ cols, const int32_t* __restrict__ sdelta, int sdelta_stride,
+    const int32_t* __restrict__ rowlen, const double* __restrict__ x, const double* __restrict__ u,
+    const double* __restrict__ load, const uint8_t* __restrict__ bcmask, const double* __restrict__ bcval,
+    double* __restrict__ diag0, double* __restrict__ vals0, double* __restrict__ diag1, double* __restrict__ vals1,
+    double* __restrict__ rhs, const uint64_t* __restrict__ bc_rowmask, int debug_skip) {
+  extern __shared__ double lds_row[];
+  double* strip = lds_row;                       // [nb][64]
+  double* nx = lds_row + nb * 64;                // [nb][D][64]
+  const int lane = threadIdx.x;
+  const int64_t slice = femo_xcd_block(blockIdx.x, n_blocks);
+  if ((slice << 6) >= n_rows) return;
+  const int64_t row = (slice << 6) + lane;
+  const bool valid = row < n_rows;
+  const int64_t vb = vptr[slice], mb = mptr[slice];
+  const int nvis = (debug_skip & 1) ? 0 : (int)((vptr[slice + 1] - vb) >> 6);
+  const int wm = (int)((mptr[slice + 1] - mb) >> 6);
+  const int32_t* dl = sdelta + slice * sdelta_stride;
+  const bool regular = dl[0] != INT32_MIN;
+  const int32_t* cols_slice = cols + mb;
+  const P1Rec* rec = visit_rec + vb;
+  const int len = rowlen[row];
+  const uint32_t r0 = (uint32_t)(valid ? row : 0);
+  double xo[D];
+  ldg_point<D>(x, r0, xo);
+  // neighbourhood: coordinates of the row's columns (padded entries point at the row itself).  All column
+  // indices of a chunk are loaded before the first coordinate gather and all gathers before the first LDS
+  // write: two memory round trips per 16 columns instead of two per column.
+  constexpr int PC = 16;
+  for (int k0 = 0; k0 < ((debug_skip & 2) ? 0 : wm); k0 += PC) {
+    uint32_t c[PC];
+#pragma unroll
+    for (int i = 0; i < PC; ++i) {
+      const int k = k0 + i < wm ? k0 + i : wm - 1;            // wave-uniform clamp
+      if (regular) c[i] = (uint32_t)((int32_t)row + dl[k]);
+      else c[i] = (uint32_t)ldg32<int32_t>(cols_slice, ((uint32_t)(k >> 1) * 128u + (uint32_t)lane * 2u + (uint32_t)(k & 1)) * 4u);
+    }
+    double p[PC][D];
+#pragma unroll
+    for (int i = 0; i < PC; ++i) ldg_point<D>(x, c[i], p[i]);
+#pragma unroll
+    for (int i = 0; i < PC; ++i) {
+      if (k0 + i < wm) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) nx[((k0 + i) * D + d) * 64 + lane] = p[i][d];
+        strip[(k0 + i) * 64 + lane] = 0.0;
+      }
+    }
+  }
+  typedef int femo_i4 __attribute__((ext_vector_type(4)));
+  auto fetch = [&](int s) -> femo_i4 {
+    const int sc = s < nvis ? s : nvis - 1;
+    return ldg32<femo_i4>(rec, (uint32_t)(sc * 64 + lane) * 16u);
+  };
+  double dsum = 0.0;
+  if (nvis > 0) {
+    femo_i4 cur[CH], nxt[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) cur[i] = fetch(i);
+    for (int base = 0; base < nvis; base += CH) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) nxt[i] = fetch(base + CH + i);
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        if (base + i < nvis) {                     // wave-uniform
+          const femo_i4 q = cur[i];
+          const bool live = q.x >= 0;
+          const uint32_t sl = live ? (uint32_t)q.y : 0u;
+          const double w = live ? __hiloint2double(q.w, q.z) : 0.0;
+          double o[D][D];
+          int pos[D];
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            pos[j] = (int)((sl >> (8 * j)) & 0xFFu);
+#pragma unroll
+            for (int d = 0; d < D; ++d) o[j][d] = nx[(pos[j] * D + d) * 64 + lane];
+          }
+          double k[D];
+          poisson_pairs<D>(xo, o, w, k);
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            dsum -= k[j];
+            strip[pos[j] * 64 + lane] = __dadd_rn(strip[pos[j] * 64 + lane], k[j]);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < CH; ++i) cur[i] = nxt[i];
+    }
+  }
+  // rows out: same treatment of Dirichlet rows / columns and of the Newton right-hand side as k_jacobian
+  const bool want_rhs = rhs != nullptr;
+  // Dirichlet columns of the row as one coalesced 8-B word instead of a byte gather per matrix entry
+  const uint64_t rmask = bc_rowmask != nullptr ? bc_rowmask[row] : 0;
+  const bool row_bc = bcmask != nullptr && valid && (bc_rowmask != nullptr ? (rmask >> 63) != 0 : bcmask[row] != 0);
+  if (diag0) diag0[row] = valid ? dsum : 1.0;
+  if (diag1) diag1[row] = (valid && !row_bc) ? dsum : 1.0;
+  double racc = 0.0, lift = 0.0;
+  if (want_rhs && valid) racc = dsum * u[row] - load[row];
+  const bool need_cols = (bcmask != nullptr && bc_rowmask == nullptr) || want_rhs;
+  for (int k0 = 0; k0 < wm; k0 += PC) {
+    // columns, then everything gathered through them, then the arithmetic and the stores: batched like the prologue
+    int2 cc[PC / 2];
+    double2 uu[PC / 2], gg[PC / 2];
+    bool bx[PC / 2], by[PC / 2];
+#pragma unroll
+    for (int i = 0; i < PC / 2; ++i) {
+      const int k = k0 + 2 * i < wm ? k0 + 2 * i : 0;
+      cc[i] = make_int2((int)r0, (int)r0);
+      if (need_cols) {
+        if (regular) cc[i] = make_int2((int32_t)row + dl[k], (int32_t)row + dl[k + 1]);
+        else cc[i] = ldg32<int2>(cols_slice, ((uint32_t)(k >> 1) * 128u + (uint32_t)lane * 2u) * 4u);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PC / 2; ++i) {
+      uu[i] = make_double2(0.0, 0.0); gg[i] = make_double2(0.0, 0.0); bx[i] = false; by[i] = false;
+      if (want_rhs) { uu[i].x = ldg32<double>(u, (uint32_t)cc[i].x * 8u); uu[i].y = ldg32<double>(u, (uint32_t)cc[i].y * 8u); }
+      if (bcmask != nullptr) {
+        const int k = k0 + 2 * i;
+        if (bc_rowmask != nullptr) {
+          bx[i] = ((rmask >> k) & 1) != 0; by[i] = ((rmask >> (k + 1)) & 1) != 0;
+        } else {
+          bx[i] = ldg32<uint8_t>(bcmask, (uint32_t)cc[i].x) != 0; by[i] = ldg32<uint8_t>(bcmask, (uint32_t)cc[i].y) != 0;
+        }
+        if (want_rhs) {                                   // prescribed values only where a column is in the set (rare)
+          if (bx[i]) gg[i].x = ldg32<double>(bcval, (uint32_t)cc[i].x * 8u);
+          if (by[i]) gg[i].y = ldg32<double>(bcval, (uint32_t)cc[i].y * 8u);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PC / 2; ++i) {
+      const int k = k0 + 2 * i;
+      if (k < wm) {                                        // wave-uniform (wm is even)
+        const int64_t idx = mb + (int64_t)(k >> 1) * 128 + lane * 2;
+        double2 o;
+        o.x = k < len ? strip[k * 64 + lane] : 0.0;
+        o.y = (k + 1) < len ? strip[(k + 1) * 64 + lane] : 0.0;
+        if (vals0) *reinterpret_cast<double2*>(vals0 + idx) = o;
+        if (want_rhs && valid) racc += o.x * uu[i].x + o.y * uu[i].y;
+        if (bcmask != nullptr) {
+          if (want_rhs && !row_bc) {
+            if (bx[i]) lift += o.x * (gg[i].x - uu[i].x);
+            if (by[i]) lift += o.y * (gg[i].y - uu[i].y);
+          }
+          if (row_bc || bx[i]) o.x = 0.0;
+          if (row_bc || by[i]) o.y = 0.0;
+        }
+        if (vals1) *reinterpret_cast<double2*>(vals1 + idx) = o;
+      }
+    }
   }
   if (want_rhs && valid) rhs[row] = row_bc ? (u[row] - bcval[row]) : (racc + lift);
 }
@@ -859,6 +1335,53 @@ inline int64_t row_blocks(const femo_mesh* m) { return (m->n_slices * FEMO_WAVE 
     else hipLaunchKernelGGL((KERNEL<2, P>), dim3(grid), dim3(FEMO_BLOCK), lds, st, __VA_ARGS__); \
   } while (0)
 
+// Cell weights of the pair-formulation walks, stored per incidence entry (see P1Walk); written once per mesh.
+// The walks address their arrays with 32-bit byte offsets: refuse meshes whose arrays reach 4 GiB
+// (178 M vertices in 3-D).
+static int ensure_visit_weights(femo_mesh* m) {
+  if (m->d_visit_rec) return 0;
+  const int64_t lim = int64_t(1) << 32;
+  FEMO_REQUIRE(m->n_vert * m->tdim * 8 < lim && m->n_cell * 8 < lim && m->sell_entries * 4 < lim,
+               "mesh too large for the 32-bit offsets of the Poisson walks (%lld vertices, %lld cells)", (long long)m->n_vert, (long long)m->n_cell);
+  hipStream_t st = m->ctx->stream;
+  femo_d2* cw = nullptr;
+  FEMO_HIP_CHECK(hipMalloc(&cw, std::max<int64_t>(m->n_cell, 1) * sizeof(femo_d2)));
+  FEMO_REQUIRE(m->visit_entries * 16 < (int64_t(1) << 40), "incidence too large");
+  FEMO_HIP_CHECK(hipMalloc(&m->d_visit_rec, std::max<int64_t>(m->visit_entries, 1) * sizeof(P1Rec) + 64));
+  if (m->n_cell > 0 && m->visit_entries > 0) {
+    const int g = cell_grid(m->n_cell);
+    if (m->tdim == 3) hipLaunchKernelGGL((k_cell_weights<3>), dim3(g), dim3(FEMO_BLOCK), 0, st, m->n_cell, m->d_conn, m->d_x, cw);
+    else hipLaunchKernelGGL((k_cell_weights<2>), dim3(g), dim3(FEMO_BLOCK), 0, st, m->n_cell, m->d_conn, m->d_x, cw);
+    hipLaunchKernelGGL(k_visit_records, dim3(2048), dim3(256), 0, st, m->visit_entries, m->d_visit_cell, m->d_visit_slots, cw, reinterpret_cast<P1Rec*>(m->d_visit_rec));
+    FEMO_HIP_CHECK(hipGetLastError());
+  }
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  FEMO_HIP_CHECK(hipFree(cw));
+  return 0;
+}
+
+#define FEMO_ROW_WALK(m, KIND, nb, st, u, second, out)                                                                   \
+  FEMO_LAUNCH_DP(m, k_p1_row_walk, KIND, nb, 0, st, (m)->n_rows, nb, (m)->d_vptr, reinterpret_cast<const P1Rec*>((m)->d_visit_rec), \
+                 (m)->d_mptr, (m)->d_cols, (m)->d_sdelta, (m)->sdelta_stride, (m)->d_x, u, second, out)
+
+// load_a = sum_cells f_c |T| / (D+1): the part of the Poisson residual that does not depend on u.  Newton
+// evaluates the residual four times per solve with the same f (utils_dolfinx.py:419-449); the vector is formed
+// once per content of f -- identified by the vector's (uid, generation), see hostmem.cpp -- instead of gathering
+// f cell by cell in every pass (f[c] is a cell-indexed gather: a 128-B line for 8 bytes).  uid 0 (wrapped
+// memory): recomputed every time.
+static int ensure_load_vector(femo_mesh* m, const double* f, uint64_t f_uid, uint64_t f_gen) {
+  if (m->d_load && f_uid != 0 && m->load_uid == f_uid && m->load_gen == f_gen) return 0;
+  FEMO_TRY(ensure_visit_weights(m));
+  if (!m->d_load) FEMO_HIP_CHECK(hipMalloc(&m->d_load, (std::max<int64_t>(m->n_slices * FEMO_WAVE, 1) + 2) * sizeof(double)));
+  const int64_t nb = row_blocks(m);
+  if (nb > 0) {
+    FEMO_ROW_WALK(m, 2, nb, m->ctx->stream, (const double*)nullptr, f, m->d_load);
+    FEMO_HIP_CHECK(hipGetLastError());
+  }
+  m->load_uid = f_uid; m->load_gen = f_gen;
+  return 0;
+}
+
 static int check_nl(femo_mesh* m, int pde, const double* u, const double* aux) {
   FEMO_REQUIRE(pde == FEMO_PDE_POISSON || pde == FEMO_PDE_NL_POISSON || pde == FEMO_PDE_MASS || pde == FEMO_PDE_EB_BEAM,
                "pde kind %d not implemented", pde);
@@ -874,7 +1397,7 @@ static int check_nl(femo_mesh* m, int pde, const double* u, const double* aux) {
 }
 
 int femo_launch_residual(femo_mesh* m, int pde, const double* params, const double* u,
-                         const double* f, const double* aux, double* r) {
+                         const double* f, const double* aux, double* r, uint64_t f_uid, uint64_t f_gen) {
   FEMO_TRY(check_nl(m, pde, u, aux));
   FEMO_REQUIRE(pde != FEMO_PDE_MASS, "the mass form has no residual");
   const int64_t nb = row_blocks(m);
@@ -886,8 +1409,10 @@ int femo_launch_residual(femo_mesh* m, int pde, const double* params, const doub
     hipLaunchKernelGGL((k_residual<3, FEMO_PDE_EB_BEAM>), dim3(nb), dim3(FEMO_BLOCK), 0, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_conn, m->d_x, u, f, aux, m->d_bfacets, params ? params[0] : 1.0, params ? params[1] : 1.0, r);
   else if (pde == FEMO_PDE_NL_POISSON)
     FEMO_LAUNCH_DP(m, k_residual, FEMO_PDE_NL_POISSON, nb, 0, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_conn, m->d_x, u, f, aux, m->d_bfacets, beta, sgn, r);
-  else
-    FEMO_LAUNCH_DP(m, k_residual, FEMO_PDE_POISSON, nb, 0, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_conn, m->d_x, u, f, aux, m->d_bfacets, beta, sgn, r);
+  else {
+    FEMO_TRY(ensure_load_vector(m, f, f_uid, f_gen));
+    FEMO_ROW_WALK(m, 0, nb, st, u, (const double*)m->d_load, r);
+  }
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -898,14 +1423,16 @@ static int launch_system_t(femo_mesh* m, int64_t nb, size_t lds, const double* u
                            double* diag1, double* vals1, double* rhs) {
   auto k = k_jacobian<D, PDE>;
   if (lds > 64 * 1024) FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k, dim3(nb), dim3(FEMO_BLOCK), lds, m->ctx->stream, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_visit_slots, m->d_mptr, m->d_cols, m->d_sdelta, m->sdelta_stride, m->d_rowlen, m->d_conn, m->d_x, u, f, aux, m->d_bfacets, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
+  if (PDE == FEMO_PDE_POISSON) FEMO_TRY(ensure_visit_weights(m));
+  hipLaunchKernelGGL(k, dim3(nb), dim3(FEMO_BLOCK), lds, m->ctx->stream, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_visit_slots, m->d_mptr, m->d_cols, m->d_sdelta, m->sdelta_stride, m->d_rowlen, m->d_conn, m->d_x, u, f, aux, m->d_bfacets, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs, reinterpret_cast<const P1Rec*>(m->d_visit_rec));
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 int femo_launch_system(femo_mesh* m, int pde, const double* params, const double* u, const double* f,
                        const double* aux, const uint8_t* bcmask, const double* bcval, double* diag0,
-                       double* vals0, double* diag1, double* vals1, double* rhs) {
+                       double* vals0, double* diag1, double* vals1, double* rhs, uint64_t f_uid, uint64_t f_gen,
+                       const uint64_t* bc_rowmask) {
   FEMO_TRY(check_nl(m, pde, u, aux));
   FEMO_REQUIRE(rhs == nullptr || (u != nullptr && f != nullptr), "the Newton right-hand side needs u and f");
   FEMO_REQUIRE((diag1 == nullptr && rhs == nullptr) || bcmask == nullptr || bcval != nullptr, "missing Dirichlet values");
@@ -929,10 +1456,37 @@ int femo_launch_system(femo_mesh* m, int pde, const double* params, const double
   }
   if (m->tdim == 3) {
     if (pde == FEMO_PDE_NL_POISSON) return launch_system_t<3, FEMO_PDE_NL_POISSON>(m, nb, lds, u, f, aux, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
-    return launch_system_t<3, FEMO_PDE_POISSON>(m, nb, lds, u, f, aux, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
+  } else if (pde == FEMO_PDE_NL_POISSON) {
+    return launch_system_t<2, FEMO_PDE_NL_POISSON>(m, nb, lds, u, f, aux, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
   }
-  if (pde == FEMO_PDE_NL_POISSON) return launch_system_t<2, FEMO_PDE_NL_POISSON>(m, nb, lds, u, f, aux, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
-  return launch_system_t<2, FEMO_PDE_POISSON>(m, nb, lds, u, f, aux, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
+  // linear Poisson: the kernel takes the load vector of f where the other forms take their aux field
+  const double* load = nullptr;
+  if (rhs) {
+    FEMO_TRY(ensure_load_vector(m, f, f_uid, f_gen));
+    load = m->d_load;
+  }
+  // rows with up to 64 neighbours: the row neighbourhood fits in LDS (one wave per workgroup)
+  const int nbr = (m->max_rowlen + 1) & ~1;
+  const size_t lds_row = (size_t)nbr * (m->tdim + 1) * 64 * sizeof(double);
+  if (lds_row <= 128 * 1024 && getenv("FEMO_ASSEMBLY_GATHER") == nullptr) {
+    FEMO_TRY(ensure_visit_weights(m));
+    const int64_t ns = m->n_slices;
+    const P1Rec* rec = reinterpret_cast<const P1Rec*>(m->d_visit_rec);
+    const int dbg = getenv("FEMO_DEBUG_SKIP") ? atoi(getenv("FEMO_DEBUG_SKIP")) : 0;     // timing experiments only
+#define FEMO_SYS_LDS(D)                                                                                                       \
+    do {                                                                                                                      \
+      auto k = k_poisson_system_lds<D, 12>;                                                                                   \
+      if (lds_row > 64 * 1024) FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row)); \
+      hipLaunchKernelGGL(k, dim3(ns), dim3(64), lds_row, m->ctx->stream, m->n_rows, ns, nbr, m->d_vptr, rec, m->d_mptr, m->d_cols,    \
+                         m->d_sdelta, m->sdelta_stride, m->d_rowlen, m->d_x, u, load, bcmask, bcval, diag0, vals0, diag1, vals1, rhs, bcmask ? bc_rowmask : nullptr, dbg); \
+    } while (0)
+    if (m->tdim == 3) FEMO_SYS_LDS(3); else FEMO_SYS_LDS(2);
+#undef FEMO_SYS_LDS
+    FEMO_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
+  if (m->tdim == 3) return launch_system_t<3, FEMO_PDE_POISSON>(m, nb, lds, u, f, load, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
+  return launch_system_t<2, FEMO_PDE_POISSON>(m, nb, lds, u, f, load, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
 }
 
 int femo_launch_dRdf(femo_mesh* m, int pde, const double* params, const double* u,
@@ -1008,7 +1562,8 @@ int femo_launch_functional_grad_u(femo_mesh* m, int kind, const double* params, 
   const int64_t nb = row_blocks(m);
   if (nb == 0) return 0;
   hipStream_t st = m->ctx->stream;
-  FEMO_LAUNCH_D(m, k_functional_grad_u, nb, 0, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_visit_slots, m->d_mptr, m->d_cols, m->d_sdelta, m->sdelta_stride, m->d_x, u, ud, gout);
+  FEMO_TRY(ensure_visit_weights(m));
+  FEMO_ROW_WALK(m, 1, nb, st, u, ud, gout);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -70,7 +70,7 @@ struct FemoTopology {
   // vertex -> cell incidence, SELL-64 (entry s of lane l: vptr[slice] + s*64 + l)
   std::vector<int64_t> vptr;
   std::vector<int32_t> visit_cell;    // (cell << 2) | local index, -1 = padding
-  std::vector<uint32_t> visit_slots;  // byte b = off-diagonal slot of conn[cell][b]
+  std::vector<uint32_t> visit_slots;  // byte j = off-diagonal slot of the j-th cell vertex other than the visiting one
   // off-diagonal sparsity pattern, SELL-64 pair-interleaved
   std::vector<int64_t> mptr;
   std::vector<int32_t> cols;          // padding entries carry the row's own index
@@ -167,6 +167,9 @@ struct femo_mesh {
   int32_t* d_sdelta = nullptr;   // per-slice column deltas (see FemoTopology::sdelta)
   int sdelta_stride = 0;
   int64_t n_regular = 0;
+  void* d_visit_rec = nullptr;   // per incidence entry, 16 B: (cell<<2|a, slots, 1/(36|T|)) for the Poisson walks, built on first use
+  double* d_load = nullptr;      // load vector of the Poisson residual for the f identified by (load_uid, load_gen)
+  uint64_t load_uid = 0, load_gen = 0;
   uint8_t* d_bfacets = nullptr;  // per cell: bit k = facet opposite local vertex k is on the boundary (optional)
   int32_t* d_tperm = nullptr;  // lazily built: SELL entry -> SELL entry of the transposed nonzero
   std::vector<int64_t> h_mptr;
@@ -195,6 +198,8 @@ struct femo_bc {
   double* d_vals = nullptr;
   uint8_t* d_mask = nullptr;  // n_vert
   double* d_dense = nullptr;  // n_vert: prescribed value on the set, 0 elsewhere
+  uint64_t* d_rowmask = nullptr;  // per row: bit k = its k-th off-diagonal column is in the set, bit 63 = the row itself
+                                  // (rows with at most 62 columns; saves the assembly one byte gather per matrix entry)
   uint64_t uid = 0;           // process-unique, never reused (keys cached preconditioner data)
 };
 
@@ -252,10 +257,11 @@ __device__ __forceinline__ int64_t femo_xcd_block(int64_t b, int64_t nb) {
 
 // kernel launchers implemented in the .hip files -------------------------------
 int femo_launch_residual(femo_mesh* m, int pde, const double* params, const double* u,
-                         const double* f, const double* aux, double* r);
+                         const double* f, const double* aux, double* r, uint64_t f_uid = 0, uint64_t f_gen = 0);
 int femo_launch_system(femo_mesh* m, int pde, const double* params, const double* u, const double* f,
                        const double* aux, const uint8_t* bcmask, const double* bcval, double* diag0, double* vals0,
-                       double* diag1, double* vals1, double* rhs);
+                       double* diag1, double* vals1, double* rhs, uint64_t f_uid = 0, uint64_t f_gen = 0,
+                       const uint64_t* bc_rowmask = nullptr);
 int femo_launch_cell_expr(femo_mesh* m, int kind, const double* params, const double* in, double* out);
 int femo_launch_dRdf(femo_mesh* m, int pde, const double* params, const double* u,
                      const double* f, double* vals);

@@ -171,13 +171,16 @@ int femo_build_topology(int tdim, int64_t n_vert, int64_t n_rows, int64_t n_cell
           for (int64_t e = off[v]; e < off[v + 1]; ++e) {
             const int64_t c = inc[e] >> 2;
             const int a = inc[e] & 3;
+            // byte j = slot (in this row) of the j-th vertex of the cell other than the visiting one
             uint32_t slots = 0xFFFFFFFFu;
+            int j = 0;
             for (int b = 0; b < nv; ++b) {
               if (b == a) continue;
               const int32_t nb = conn[c * nv + b];
               const int pos = (int)(std::lower_bound(w, w + len, nb) - w);
               const uint32_t byte = (pos < len && w[pos] == nb) ? (uint32_t)pos : 0xFFu;
-              slots = (slots & ~(0xFFu << (8 * b))) | (byte << (8 * b));
+              slots = (slots & ~(0xFFu << (8 * j))) | (byte << (8 * j));
+              ++j;
             }
             const int64_t idx = T.vptr[s] + (e - off[v]) * FEMO_WAVE + l;
             T.visit_cell[idx] = inc[e];
