@@ -32,12 +32,13 @@ J_L2_TRACKING = 0
 
 class SolverOpts(C.Structure):
     _fields_ = [("rtol", C.c_double), ("atol", C.c_double), ("max_it", C.c_int32),
-                ("zero_guess", C.c_int32), ("check_every", C.c_int32), ("pc", C.c_int32)]
+                ("zero_guess", C.c_int32), ("check_every", C.c_int32), ("pc", C.c_int32), ("atol_pc", C.c_double)]
 
 
 class SolveInfo(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32),
-                ("residual_norm", C.c_double), ("rhs_norm", C.c_double),
+                ("residual_norm", C.c_double), ("pc_residual_norm", C.c_double), ("pc_rhs_norm", C.c_double),
+                ("rhs_norm", C.c_double),
                 ("solve_ms", C.c_double), ("spmv_ms", C.c_double),
                 ("spmv_samples", C.c_int32), ("reserved", C.c_int32)]
 
@@ -147,7 +148,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.femo_abi_version() != 1:
+    if lib.femo_abi_version() != 2:
         raise FemoError("libfemo_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -445,15 +445,27 @@ int femo_mat_destroy(femo_mat* A) {
   if (!A) return 0;
   hipStreamSynchronize(A->mesh->ctx->stream);
   hipFree(A->d_diag); hipFree(A->d_vals); hipFree(A->d_valsT); hipFree(A->d_valsS); hipFree(A->d_s);
-  hipFree(A->d_pcmask);
+  hipFree(A->d_pcmask); hipFree(A->d_idrows);
   delete A;
   return 0;
 }
 
 // Records which vertices this assembly pins (strong Dirichlet set, Nitsche facets) for the BPX
-// preconditioner; the key identifies the combination so cached lattice data can be reused.
+// preconditioner; the key identifies the combination so cached lattice data can be reused.  Also keeps the
+// identity rows (the strong Dirichlet set the matrix was eliminated with) for the Krylov loops.
 static int note_pinned_vertices(femo_mat* A, int pde, const double* params, const femo_bc* bc) {
   femo_mesh* m = A->mesh;
+  if (bc != nullptr && bc->n > 0) {
+    if (A->idrows_uid != bc->uid) {
+      const int64_t nb = std::max<int64_t>(m->n_vert, 1) + 64;
+      if (!A->d_idrows) FEMO_HIP_CHECK(hipMalloc(&A->d_idrows, nb));
+      FEMO_HIP_CHECK(hipMemcpyAsync(A->d_idrows, bc->d_mask, nb, hipMemcpyDeviceToDevice, m->ctx->stream));
+      A->idrows_uid = bc->uid;
+    }
+    A->has_idrows = true;
+  } else {
+    A->has_idrows = false;
+  }
   A->bpx_ok = (pde == FEMO_PDE_POISSON || pde == FEMO_PDE_NL_POISSON);
   if (!A->bpx_ok) return 0;
   const bool nitsche = m->d_bvmask != nullptr && params != nullptr && params[0] != 0.0;

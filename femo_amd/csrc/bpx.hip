@@ -277,35 +277,82 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
 //   mode 0: out = zh
 //   mode 1: out = zh + beta out   (the next search direction; zh is never stored)
 //   mode 2: out = zh              (first direction)
-// In modes 1/2 gamma' = rh.zh = rho + g_L.e_L comes from the lattice (rho = rh.rh is already in
-// `rho`, the g.e partials of the finest k_lattice_prolong are folded here by every block in the
-// same order), beta = gamma'/gamma_cur, and gamma' is left in *gamma_nxt for the next alpha.
+// In modes 1/2 gamma' = rh.zh = rho + g_L.e_L comes from the lattice (rho = rh.rh is folded here from the
+// per-block partials of k_pcg_xr, or read from `rho` when it was reduced before; the g.e partials of the finest
+// k_lattice_prolong are folded here as well, by every block in the same order), beta = gamma'/gamma_cur, and
+// gamma' is left in *gamma_nxt for the next alpha.
+// Stopping test of the PCG loop (st != nullptr): gamma' = r^T M^-1 r is the squared residual in the norm of
+// the preconditioner, sqrt(gamma'/gamma_0) tracks the relative energy-norm error (measured: equal to within
+// 10 % from the third iteration on), independently of the mesh size -- unlike r^T D^-1 r, whose ratio to the
+// error grows like cond(D^-1 A) ~ n^2.  mode 2 stores tol^2 = rtol^2 * factor * gamma_0, mode 1 compares; every
+// block takes the same decision from the same numbers, block 0 publishes it.
+struct PcgStop {
+  double rtol2_factor;     // rtol^2 (x b.D^-1 b / r0.D^-1 r0 for a non-zero initial guess)
+  double atol_pc2;         // absolute threshold on gamma
+  double* tolg2;           // device scalar: rtol^2 * gamma_0
+  int32_t* flags;          // [0] stamp (it + 1) once converged, [1] iterations, [2] breakdown
+  int it;
+};
+
 template <int D>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat lat, const uint32_t* __restrict__ pk,
                                                              const double* __restrict__ rh, const double* __restrict__ s,
                                                              const uint8_t* __restrict__ mask, const double* __restrict__ e,
                                                              double* __restrict__ out, int mode, int nb_dot,
                                                              const double* __restrict__ dot_partials, const double* __restrict__ dot_global,
-                                                             const double* __restrict__ rho,
+                                                             int nb_rho, const double* __restrict__ rho_partials, double* __restrict__ rho,
                                                              const double* __restrict__ gamma_cur, double* __restrict__ gamma_nxt,
-                                                             const int32_t* __restrict__ done) {
+                                                             const int32_t* __restrict__ done, PcgStop st) {
   if (done != nullptr && *done) return;
-  __shared__ double lds[FEMO_BLOCK / 64];
+  __shared__ double lds[2 * (FEMO_BLOCK / 64)];
   double beta = 0.0;
   if (mode != 0) {
-    double a = 0.0;
+    double a = 0.0, b = 0.0;
     for (int i = threadIdx.x; i < nb_dot; i += FEMO_BLOCK) a += dot_partials[i];
+    for (int i = threadIdx.x; i < nb_rho; i += FEMO_BLOCK) b += rho_partials[i];
     a = femo_wave_sum(a);
+    b = femo_wave_sum(b);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) lds[w] = a;
+    if (lane == 0) { lds[w] = a; lds[FEMO_BLOCK / 64 + w] = b; }
     __syncthreads();
-    double ge = 0.0;
+    double ge = 0.0, rr = 0.0;
 #pragma unroll
-    for (int i = 0; i < FEMO_BLOCK / 64; ++i) ge += lds[i];
+    for (int i = 0; i < FEMO_BLOCK / 64; ++i) { ge += lds[i]; rr += lds[FEMO_BLOCK / 64 + i]; }
     if (dot_global != nullptr) ge = *dot_global;      // already folded and all-reduced (nb_dot == 0)
-    const double g1 = *rho + ge, g0 = *gamma_cur;
+    if (nb_rho == 0) rr = *rho;                       // reduced before (stopping test on r.D^-1 r, or several ranks)
+    const double g1 = rr + ge, g0 = *gamma_cur;
     if (mode == 1) beta = g0 != 0.0 ? g1 / g0 : 0.0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *gamma_nxt = g1;
+    const bool first = blockIdx.x == 0 && threadIdx.x == 0;
+    if (first) {
+      *gamma_nxt = g1;
+      if (nb_rho > 0) *rho = rr;
+    }
+    if (st.flags != nullptr) {
+      if (mode == 2) {
+        const double t2 = fmax(st.rtol2_factor * g1, st.atol_pc2);
+        if (first) {
+          *st.tolg2 = t2;
+          if (g1 <= t2) {                             // the initial residual is already below the absolute threshold
+            st.flags[1] = 0;
+            st.flags[2] = 0;
+            __threadfence();
+            st.flags[0] = 1;
+          }
+        }
+      } else {
+        const bool bad = !(g1 == g1);
+        if (g1 <= *st.tolg2 || bad) {                 // converged after st.it + 1 iterations: the direction is not needed
+          if (first) {
+            st.flags[1] = st.it + 1;
+            st.flags[2] = bad ? 1 : 0;
+            __threadfence();
+            st.flags[0] = st.it + 1;
+          }
+          return;
+        }
+        if (first) st.flags[1] = st.it + 1;
+      }
+    }
   }
   for (int64_t v = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; v < n_rows; v += (int64_t)gridDim.x * FEMO_BLOCK) {
     double z = rh[v];
@@ -701,7 +748,7 @@ static int pc_prepare(femo_mesh* m, const uint8_t* mask, uint64_t key) {
 // zh = M^-1 rh in scaled variables; partials[block] = rh.zh per block (gv blocks)
 int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const double* s, const double* rh, double* out,
                   int mode, double* rho, const double* gamma_cur, double* gamma_nxt, const int32_t* done, int gv,
-                  bool rho_is_partial) {
+                  bool rho_is_partial, const FemoPcgStop* stop, int nb_rho, const double* rho_partials) {
   femo_pc* pc = m->pc;
   femo_ctx* ctx = m->ctx;
   hipStream_t st = ctx->stream;
@@ -784,10 +831,16 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
     dot_global = pc->d_dot_scalar;
     nb_dot = 0;
   }
+  PcgStop ps;
+  ps.rtol2_factor = stop ? stop->rtol2_factor : 0.0;
+  ps.atol_pc2 = stop ? stop->atol_pc2 : 0.0;
+  ps.tolg2 = stop ? stop->tolg2 : nullptr;
+  ps.flags = stop ? stop->flags : nullptr;
+  ps.it = stop ? stop->it : 0;
   if (pc->dim == 3)
-    hipLaunchKernelGGL(k_prolong_mesh<3>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, s, mask, F.e, out, mode, nb_dot, pc->d_dot_partials, dot_global, rho, gamma_cur, gamma_nxt, done);
+    hipLaunchKernelGGL(k_prolong_mesh<3>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, s, mask, F.e, out, mode, nb_dot, pc->d_dot_partials, dot_global, nb_rho, rho_partials, rho, gamma_cur, gamma_nxt, done, ps);
   else
-    hipLaunchKernelGGL(k_prolong_mesh<2>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, s, mask, F.e, out, mode, nb_dot, pc->d_dot_partials, dot_global, rho, gamma_cur, gamma_nxt, done);
+    hipLaunchKernelGGL(k_prolong_mesh<2>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, s, mask, F.e, out, mode, nb_dot, pc->d_dot_partials, dot_global, nb_rho, rho_partials, rho, gamma_cur, gamma_nxt, done, ps);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -213,6 +213,10 @@ struct femo_mat {
   double* d_s = nullptr;      // S, n_vert entries (ghosts filled by halo exchange)
   bool scaled_valid = false, scaled_transposed = false;
   bool s_valid = false;       // d_s matches the current diagonal (set before the values are scaled)
+  // identity rows of the last assembly (strong Dirichlet set): the Krylov loops solve them up front
+  uint8_t* d_idrows = nullptr;  // n_vert bytes (own copy: the femo_bc may be destroyed before the matrix)
+  bool has_idrows = false;
+  uint64_t idrows_uid = 0;
   // BPX: which vertices the last assembly pinned (strong Dirichlet set and/or Nitsche facets)
   bool bpx_ok = false;          // assembled from a second-order scalar PDE on a geometric mesh
   uint8_t* d_pcmask = nullptr;  // n_vert bytes, valid when pc_key != 0 and pc_has_mask
@@ -286,9 +290,19 @@ int femo_pc_build(femo_mesh* m);
 void femo_pc_destroy(femo_mesh* m);
 // mode 0: out = M^-1 rh (scaled variables).  mode 1: out = M^-1 rh + beta out with beta = gamma'/(*gamma_cur),
 // gamma' = rh.M^-1 rh = *rho + g_L.e_L, written to *gamma_nxt.  mode 2: like 1 with beta = 0.
+// stopping test of the BPX-PCG loop, evaluated inside the preconditioner apply (see k_prolong_mesh)
+struct FemoPcgStop {
+  double rtol2_factor;
+  double atol_pc2;
+  double* tolg2;
+  int32_t* flags;
+  int it;
+};
+// nb_rho > 0: rho = rh.rh is folded from rho_partials[0:nb_rho] inside the apply (and stored to *rho)
 int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const double* s, const double* rh, double* out,
                   int mode, double* rho, const double* gamma_cur, double* gamma_nxt, const int32_t* done, int gv,
-                  bool rho_is_partial = false);
+                  bool rho_is_partial = false, const FemoPcgStop* stop = nullptr, int nb_rho = 0,
+                  const double* rho_partials = nullptr);
 bool femo_pc_can_piggyback(const femo_mesh* m);
 int femo_pc_begin(femo_mesh* m, const double* s, const uint8_t* mask);
 int femo_pc_levels(const femo_mesh* m, int* n_levels, int64_t* finest_nodes);

@@ -22,6 +22,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <fstream>
@@ -171,6 +172,17 @@ HostBlock* find_block(const void* p, size_t bytes) {     // g_mu held
 
 bool verify_enabled() { return getenv("FEMO_HOST_VERIFY") != nullptr; }
 
+// FEMO_HOST_TRACE=1: one line per host-side operation on stderr (what, MB, ms)
+struct Trace {
+  const char* what; int64_t bytes; std::chrono::steady_clock::time_point t0; bool on;
+  Trace(const char* w, int64_t b) : what(w), bytes(b), on(getenv("FEMO_HOST_TRACE") != nullptr) { if (on) t0 = std::chrono::steady_clock::now(); }
+  ~Trace() {
+    if (!on) return;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    fprintf(stderr, "[femo host] %-28s %9.2f MB %8.3f ms\n", what, bytes / 1e6, ms);
+  }
+};
+
 // staging ring of the context -------------------------------------------------------
 constexpr int64_t STAGE_DOUBLES = int64_t(1) << 20;     // 8 MiB per slot
 
@@ -274,6 +286,7 @@ int femo_host_alloc(int64_t bytes, void** out) {
     }
   }
   void* p = nullptr;
+  Trace tr("hipHostMalloc", (int64_t)need);
   FEMO_HIP_CHECK(hipHostMalloc(&p, need, hipHostMallocDefault));
   HostBlock b;
   b.base = static_cast<char*>(p); b.bytes = need; b.pooled = true;
@@ -356,6 +369,7 @@ int femo_host_threads(void) { return HostPool::get().threads(); }
 
 int femo_host_copy(double* dst, const double* src, int64_t n) {
   FEMO_REQUIRE((dst && src) || n == 0, "null argument");
+  Trace tr("host_copy", n * 8);
   par_stream(dst, src, n, 0);
   femo_host_touch(dst);
   return 0;
@@ -363,6 +377,7 @@ int femo_host_copy(double* dst, const double* src, int64_t n) {
 
 int femo_host_axpby(int64_t n, double a, const double* x, double b, double* y) {
   FEMO_REQUIRE((x && y) || n == 0, "null argument");
+  Trace tr("host_axpby", n * 8);
   par_stream(y, x, n, 2, a, b);
   femo_host_touch(y);
   return 0;
@@ -402,6 +417,7 @@ int femo_vec_set_host(femo_vec* v, const double* host, int64_t n) {
       }
     }
   }
+  Trace tr(src == v && src ? "set_host (skipped)" : (src ? "set_host (d2d)" : (pinned ? "set_host (pinned)" : "set_host (staged)")), n * 8);
   int elided = 0;
   if (src != nullptr && src == v) {
     elided = 1;                                          // v still holds exactly this content
@@ -447,7 +463,10 @@ static int get_host_impl(const femo_vec* v, double* host, int64_t n, int op) {
       b->src_uid = 0;                                    // being overwritten
     }
   }
-  FEMO_TRY(d2h(v, host, n, pinned, op));
+  {
+    Trace tr(op ? "add_to_host" : (pinned ? "get_host (pinned)" : "get_host (staged)"), n * 8);
+    FEMO_TRY(d2h(v, host, n, pinned, op));
+  }
   std::lock_guard<std::mutex> lk(g_mu);
   if (pinned && op == 0) { ++g_stats.d2h_pinned; g_stats.d2h_pinned_bytes += n * 8; }
   else { ++g_stats.d2h_staged; g_stats.d2h_staged_bytes += n * 8; }

@@ -311,16 +311,24 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_scale_sell(int64_t n_slices, con
   }
 }
 
-// rh = S (b - q) (q = A x0 or null); ph = rh; xh = 0; partials: slot 1 = rh.rh, slot 2 = (S b).(S b)
+// rh = S (b - q) (q = A x0 or null); ph = rh; xh = 0; partials: slot 1 = rh.rh, slot 2 = (S b).(S b).
+// Identity rows (idrow: the Dirichlet rows of the last assembly; their columns are eliminated too) are solved
+// here, xh = rh exactly, and take no part in the iteration or in either norm: with u = 1 as initial state the
+// lifted values on those rows are O(1) while the interior right-hand side is O(h^3), and a tolerance relative to
+// the whole vector would be no tolerance for the interior unknowns.
 __global__ __launch_bounds__(FEMO_BLOCK) void k_cg_init(int64_t n, const double* __restrict__ b, const double* __restrict__ q,
                                                         const double* __restrict__ s, double* __restrict__ r,
                                                         double* __restrict__ p, double* __restrict__ xh,
-                                                        double* __restrict__ partials) {
+                                                        double* __restrict__ partials, const uint8_t* __restrict__ idrow) {
   __shared__ double lds[FEMO_BLOCK / 64];
   double s0 = 0.0, s1 = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FEMO_BLOCK) {
     const double si = s[i], bi = si * b[i];
     const double ri = q ? si * (b[i] - q[i]) : bi;
+    if (idrow != nullptr && idrow[i]) {
+      r[i] = 0.0; p[i] = 0.0; xh[i] = ri;
+      continue;
+    }
     r[i] = ri; p[i] = ri; xh[i] = 0.0;
     s0 += ri * ri; s1 += bi * bi;
   }
@@ -422,6 +430,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_cg_update_xp(int64_t n, int cur,
 // scal: [0],[1] = gamma = rh.zh of even/odd iterations, [2] = delta = ph.Ah ph, [3] = tol^2,
 // [4] = rho = rh.rh (the natural-norm residual the stopping test uses, same as Jacobi-CG).
 constexpr int S_RHO = 4;
+constexpr int S_TOLG = 5;   // rtol^2 * gamma_0: the stopping threshold on gamma = rh.zh (set on the device by the first apply)
 
 // out[0] = sum of `nb` partials (+ `nb2` partials of the next slot pair, overlapped SpMV)
 __global__ __launch_bounds__(1024) void k_pcg_fold(int nb, const double* __restrict__ partials, int nb2,
@@ -1047,16 +1056,18 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
     FEMO_TRY(launch_spmv(A, A->d_vals, x->d, w.q, nullptr, nullptr));
     q0 = w.q;
   }
-  hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, b->d, q0, A->d_s, w.r, w.p, w.xh, P);
+  hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, b->d, q0, A->d_s, w.r, w.p, w.xh, P, A->has_idrows ? A->d_idrows : nullptr);
   hipLaunchKernelGGL(k_reduce_partials_at, dim3(1), dim3(1024), 0, st, gv, 2, P + FEMO_MAX_PARTIALS, S);
   FEMO_HIP_CHECK(hipGetLastError());
   if (multi) FEMO_TRY(femo_coll_allreduce(ctx, S, 2, st));
   FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, S, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
   FEMO_HIP_CHECK(hipStreamSynchronize(st));
   const double rho0 = ctx->h_scal[0], bb = ctx->h_scal[1];
+  // Stopping rule: relative in the norm of the preconditioner, sqrt(r^T M^-1 r) <= rtol sqrt(b^T M^-1 b)
+  // (tested inside femo_pc_apply, where gamma = r^T M^-1 r becomes known), absolute in the Jacobi norm,
+  // sqrt(r^T D^-1 r) <= atol (Newton's rounding-floor rule is stated in that norm; tested by k_pcg_check).
   const double bnorm = std::sqrt(bb);
-  double tol = opts->rtol * bnorm;
-  if (opts->atol > tol) tol = opts->atol;
+  const double tol = opts->atol;
   info->rhs_norm = bnorm;
   const int max_it = opts->max_it > 0 ? opts->max_it : 10000;
   auto finish = [&](int iters, int conv, double rho) -> int {
@@ -1074,8 +1085,7 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
     info->solve_ms = ms;
     return 0;
   };
-  if (!(std::sqrt(rho0) > tol)) return finish(0, rho0 == rho0 ? 1 : -1, rho0);
-  FEMO_TRY(ensure_scaled(A, false));
+  if (!(std::sqrt(rho0) > tol) || rho0 == 0.0) return finish(0, rho0 == rho0 ? 1 : -1, rho0);
 
   double hs[FEMO_NSCAL] = {0};
   hs[S_TOL2] = tol * tol;
@@ -1083,13 +1093,30 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
   memcpy(ctx->h_scal, hs, sizeof hs);
   FEMO_HIP_CHECK(hipMemcpyAsync(S, ctx->h_scal, sizeof hs, hipMemcpyHostToDevice, st));
   FEMO_HIP_CHECK(hipStreamSynchronize(st));
-  // ph0 = zh0 = M^-1 rh0, gamma0 = rh0.zh0 = rho0 + g_L.e_L (lattice dot: global on every rank, no all-reduce)
-  FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, w.p, 2, S + S_RHO, S + S_GAMMA + 1, S + S_GAMMA, ctx->d_flags, gv));
+  // ph0 = zh0 = M^-1 rh0, gamma0 = rh0.zh0 = rho0 + g_L.e_L (lattice dot: global on every rank, no all-reduce);
+  // the same launch stores the threshold max(rtol^2 gamma_0 bb/rho0, atol_pc^2) (relative to the right-hand
+  // side, not to r0) and tests gamma_0 against it
+  FemoPcgStop stop;
+  stop.rtol2_factor = opts->rtol * opts->rtol * (rho0 > 0.0 ? bb / rho0 : 1.0);
+  stop.atol_pc2 = opts->atol_pc * opts->atol_pc;
+  stop.tolg2 = S + S_TOLG;
+  stop.flags = ctx->d_flags;
+  stop.it = -1;
+  FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, w.p, 2, S + S_RHO, S + S_GAMMA + 1, S + S_GAMMA, ctx->d_flags, gv, false, &stop));
+  FEMO_HIP_CHECK(hipMemcpyAsync(h_flags, ctx->d_flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, S, FEMO_NSCAL * sizeof(double), hipMemcpyDeviceToHost, st));
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  const double gamma0 = ctx->h_scal[S_GAMMA];
+  info->pc_rhs_norm = std::sqrt(gamma0 * (rho0 > 0.0 ? bb / rho0 : 1.0));
+  info->pc_residual_norm = std::sqrt(gamma0);
+  if (h_flags[0]) return finish(0, gamma0 == gamma0 ? 1 : -1, rho0);      // below atol_pc before the first iteration
+  FEMO_TRY(ensure_scaled(A, false));   // the iteration's operator S A S (the apply above only needed S)
 
   const int n_sample = 4, sample_from = 2;
   int n_ev = 0;
   const bool local_scalars = !multi && m->n_nbr == 0;
   const bool piggyback = multi && femo_pc_can_piggyback(m);
+  const bool use_atol = opts->atol > 0.0;
   const int batch = opts->check_every > 0 ? std::min(opts->check_every, 8) : 8;
   int it = 0, polled = 0;
   bool done = false;
@@ -1111,12 +1138,18 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
       double* Pd = P + P_DELTA * FEMO_MAX_PARTIALS;
       double* Pr = P + 1 * FEMO_MAX_PARTIALS;
       double* Pg = P + 2 * FEMO_MAX_PARTIALS;   // boundary-slice partials of the overlapped SpMV
+      stop.it = it;
       if (local_scalars) {
         // single GPU: the consumers fold the per-block partials themselves
         hipLaunchKernelGGL(k_pcg_xr, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, g1, Pd, S, w.q, w.p, w.r, w.xh, Pr, ctx->d_flags);
-        hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(1024), 0, st, it, gv, Pr, S, ctx->d_flags);
-        // ph = M^-1 rh + beta ph in one pass: rh.zh = rho + g_L.e_L is known before the mesh prolongation
-        FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, w.p, 1, S + S_RHO, S + S_GAMMA + cur, S + S_GAMMA + nxt, ctx->d_flags, gv));
+        // ph = M^-1 rh + beta ph in one pass: rh.zh = rho + g_L.e_L is known before the mesh prolongation, and
+        // with it the stopping test.  The Jacobi-norm test runs only when an absolute tolerance is set.
+        if (use_atol) {
+          hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(1024), 0, st, it, gv, Pr, S, ctx->d_flags);
+          FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, w.p, 1, S + S_RHO, S + S_GAMMA + cur, S + S_GAMMA + nxt, ctx->d_flags, gv, false, &stop));
+        } else {
+          FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, w.p, 1, S + S_RHO, S + S_GAMMA + cur, S + S_GAMMA + nxt, ctx->d_flags, gv, false, &stop, gv, Pr));
+        }
       } else {
         hipLaunchKernelGGL(k_pcg_fold, dim3(1), dim3(1024), 0, st, g1, Pd, g2, Pg, S + S_DELTA, ctx->d_flags);
         FEMO_TRY(allreduce1(S + S_DELTA));
@@ -1125,12 +1158,12 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
         if (piggyback) {
           // the rank's part of rh.rh rides in the lattice all-reduce of the preconditioner; the stopping
           // test then runs after the apply (one wasted apply in the last iteration, one collective less in all)
-          FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, w.p, 1, S + S_RHO, S + S_GAMMA + cur, S + S_GAMMA + nxt, ctx->d_flags, gv, true));
-          hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(1024), 0, st, it, 0, Pr, S, ctx->d_flags);
+          FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, w.p, 1, S + S_RHO, S + S_GAMMA + cur, S + S_GAMMA + nxt, ctx->d_flags, gv, true, &stop));
+          if (use_atol) hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(1024), 0, st, it, 0, Pr, S, ctx->d_flags);
         } else {
           FEMO_TRY(allreduce1(S + S_RHO));
-          hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(1024), 0, st, it, 0, Pr, S, ctx->d_flags);
-          FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, w.p, 1, S + S_RHO, S + S_GAMMA + cur, S + S_GAMMA + nxt, ctx->d_flags, gv));
+          if (use_atol) hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(1024), 0, st, it, 0, Pr, S, ctx->d_flags);
+          FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, w.p, 1, S + S_RHO, S + S_GAMMA + cur, S + S_GAMMA + nxt, ctx->d_flags, gv, false, &stop));
         }
       }
     }
@@ -1165,6 +1198,7 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
   }
   info->spmv_ms = acc;
   info->spmv_samples = n_ev;
+  info->pc_residual_norm = std::sqrt(ctx->h_scal[S_GAMMA + (iters & 1)]);
   return finish(iters, conv, ctx->h_scal[S_RHO]);
 }
 
@@ -1190,7 +1224,7 @@ extern "C" int femo_mat_pc_apply(const femo_mat* A_, const femo_vec* r, femo_vec
   FEMO_HIP_CHECK(hipMemsetAsync(ctx->d_flags, 0, 4 * sizeof(int32_t), st));
   if (n == 0) return 0;
   // rh = S r, zh = Mh^-1 rh, z = S zh
-  hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, r->d, (const double*)nullptr, A->d_s, w.r, w.p, w.xh, ctx->d_partials);
+  hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, r->d, (const double*)nullptr, A->d_s, w.r, w.p, w.xh, ctx->d_partials, (const uint8_t*)nullptr);
   FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, w.sv, 0, nullptr, nullptr, nullptr, ctx->d_flags, gv));
   hipLaunchKernelGGL(k_unscale, dim3(2048), dim3(256), 0, st, n, 0, A->d_s, w.sv, z->d);
   FEMO_HIP_CHECK(hipGetLastError());
@@ -1235,7 +1269,7 @@ extern "C" int femo_solve_cg(const femo_mat* A_, int transpose, const femo_vec* 
     FEMO_TRY(launch_spmv(A, vals, x->d, w.q, nullptr, nullptr));
     q0 = w.q;
   }
-  hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, b->d, q0, A->d_s, w.r, w.p, w.xh, P);
+  hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, b->d, q0, A->d_s, w.r, w.p, w.xh, P, A->has_idrows ? A->d_idrows : nullptr);
   FEMO_HIP_CHECK(hipGetLastError());
   // gamma0 and ||S b||^2 (all-reduced when multi): partial slots 1 and 2
   hipLaunchKernelGGL(k_reduce_partials_at, dim3(1), dim3(1024), 0, st, gv, 2, P + FEMO_MAX_PARTIALS, ctx->d_scal);

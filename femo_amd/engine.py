@@ -88,6 +88,8 @@ def writable(a: np.ndarray) -> np.ndarray:
     if a.flags.writeable:
         return a
     base = a.base
+    while isinstance(base, np.ndarray):                  # views of the returned array (ravel(), [:]) keep it as their base
+        base = base.base
     if not isinstance(base, _PinnedBlock) or a.ctypes.data != base.ptr or a.size != base.n:
         raise ValueError("writable(): not a whole array returned by the engine")
     host_touch(a)
@@ -417,8 +419,11 @@ class Mat:
         return out
 
     def solve_cg(self, b: Vec, x: Vec, transpose: bool = False, rtol: float = 1e-12, atol: float = 0.0,
-                 max_it: int = 100000, zero_guess: bool = True, check_every: int = 32, pc: str = "jacobi") -> SolveInfo:
-        opts = SolverOpts(rtol, atol, max_it, int(zero_guess), check_every, PC_KINDS[pc])
+                 max_it: int = 100000, zero_guess: bool = True, check_every: int = 32, pc: str = "jacobi",
+                 atol_pc: float = 0.0) -> SolveInfo:
+        """Stopping rules: include/femo_hip.h, femo_solver_opts (rtol acts in the Jacobi norm for pc='jacobi',
+        in the norm of the preconditioner for pc='bpx')."""
+        opts = SolverOpts(rtol, atol, max_it, int(zero_guess), check_every, PC_KINDS[pc], atol_pc)
         info = SolveInfo()
         check(self.lib.femo_solve_cg(self.handle, int(transpose), b.handle, x.handle, C.byref(opts), C.byref(info)))
         return info
@@ -430,7 +435,7 @@ class Mat:
 
     def solve_bicgstab(self, b: Vec, x: Vec, transpose: bool = False, rtol: float = 1e-12, atol: float = 0.0,
                        max_it: int = 100000, zero_guess: bool = True, check_every: int = 32) -> SolveInfo:
-        opts = SolverOpts(rtol, atol, max_it, int(zero_guess), check_every, 0)
+        opts = SolverOpts(rtol, atol, max_it, int(zero_guess), check_every, 0, 0.0)
         info = SolveInfo()
         check(self.lib.femo_solve_bicgstab(self.handle, int(transpose), b.handle, x.handle, C.byref(opts), C.byref(info)))
         return info

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FEMO_ABI_VERSION 1
+#define FEMO_ABI_VERSION 2
 
 typedef struct femo_ctx  femo_ctx;   /* device + stream + reduction workspace (+ RCCL communicator) */
 typedef struct femo_vec  femo_vec;   /* fp64 device vector  (dolfinx Function.vector / PETSc Vec)     */
@@ -74,19 +74,28 @@ enum {
                         /*   operators assembled from FEMO_PDE_POISSON / FEMO_PDE_NL_POISSON only    */
 };
 
+/* Stopping rules.  D = diag(A), M = the preconditioner (rows / columns of the Dirichlet set the matrix was
+ * eliminated with are identity rows: they are solved exactly up front and take no part in any norm).
+ *   FEMO_PC_JACOBI:  sqrt(r^T D^-1 r) <= max(rtol sqrt(b^T D^-1 b), atol)
+ *   FEMO_PC_BPX:     sqrt(r^T M^-1 r) <= max(rtol sqrt(b^T M^-1 b), atol_pc)   or   sqrt(r^T D^-1 r) <= atol (if > 0)
+ *                    r^T M^-1 r is PCG's own gamma; sqrt(gamma / gamma_0) tracks the relative energy-norm error
+ *                    independently of the mesh size, which the Jacobi-norm ratio does not (its constant is cond(D^-1 A)). */
 typedef struct femo_solver_opts {
-  double rtol;          /* stop when sqrt(r^T D^-1 r) <= max(rtol*sqrt(b^T D^-1 b), atol), D = diag(A) */
-  double atol;
+  double rtol;
+  double atol;          /* absolute, Jacobi norm (both preconditioners)                 */
   int32_t max_it;
   int32_t zero_guess;   /* 1: x is taken as 0 on entry (skips the initial SpMV)         */
   int32_t check_every;  /* iterations enqueued between host convergence polls (0 = 32)  */
-  int32_t pc;           /* FEMO_PC_*; 0 keeps the round-1 behaviour                      */
+  int32_t pc;           /* FEMO_PC_*                                                     */
+  double atol_pc;       /* absolute, norm of the preconditioner (FEMO_PC_BPX only)      */
 } femo_solver_opts;
 
 typedef struct femo_solve_info {
   int32_t iterations;
   int32_t converged;    /* 1 converged, 0 hit max_it, -1 breakdown                      */
   double  residual_norm;/* sqrt(r^T D^-1 r) at exit (recurrence residual)               */
+  double  pc_residual_norm; /* sqrt(r^T M^-1 r) at exit and for the right-hand side     */
+  double  pc_rhs_norm;      /* (FEMO_PC_BPX; 0 otherwise)                                */
   double  rhs_norm;     /* sqrt(b^T D^-1 b)                                             */
   double  solve_ms;     /* device time of the solve (HIP events on the ctx stream)      */
   double  spmv_ms;      /* accumulated device time of sampled SpMV launches             */

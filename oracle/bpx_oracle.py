@@ -169,17 +169,18 @@ class BPX:
         return np.column_stack([self.apply(e) for e in np.eye(n)])
 
 
-def pcg(A: sp.csr_matrix, b: np.ndarray, M: BPX, rtol: float = 1e-12, atol: float = 0.0, max_it: int = 10000):
-    """PCG with the engine's stopping rule: sqrt(r^T D^-1 r) <= max(rtol sqrt(b^T D^-1 b), atol)."""
+def pcg(A: sp.csr_matrix, b: np.ndarray, M: BPX, rtol: float = 1e-11, atol: float = 0.0, max_it: int = 10000):
+    """PCG with the engine's stopping rule for BPX: relative in the norm of the preconditioner,
+    sqrt(r^T M^-1 r) <= rtol sqrt(b^T M^-1 b), absolute in the Jacobi norm, sqrt(r^T D^-1 r) <= atol."""
     dinv = M.dinv
     x = np.zeros_like(b)
     r = b.copy()
-    tol = max(rtol * math.sqrt(float(b @ (dinv * b))), atol)
-    if not math.sqrt(float(r @ (dinv * r))) > tol:
+    if not math.sqrt(float(r @ (dinv * r))) > atol:
         return x, 0
     z = M.apply(r)
     p = z.copy()
     rz = float(r @ z)
+    tol2 = rtol * rtol * rz
     it = 0
     while it < max_it:
         q = A @ p
@@ -187,10 +188,12 @@ def pcg(A: sp.csr_matrix, b: np.ndarray, M: BPX, rtol: float = 1e-12, atol: floa
         x += alpha * p
         r -= alpha * q
         it += 1
-        if math.sqrt(float(r @ (dinv * r))) <= tol:
+        if atol > 0.0 and math.sqrt(float(r @ (dinv * r))) <= atol:
             break
         z = M.apply(r)
         rz_new = float(r @ z)
+        if rz_new <= tol2:
+            break
         p = z + (rz_new / rz) * p
         rz = rz_new
     return x, it

@@ -115,17 +115,18 @@ class Bpx:
             _lib.oc_bpx_destroy(h)
 
 
-def pcg_bpx(B: Bpx, rowptr, col, val, b, rtol=1e-14, atol=0.0, max_it=100000):
+def pcg_bpx(B: Bpx, rowptr, col, val, b, rtol=1e-11, atol=0.0, max_it=100000, atol_pc=0.0):
     x = np.empty_like(b)
     res = C.c_double(0.0)
     it = lib().oc_pcg_bpx(B._h, _i64(len(b)), _p(rowptr), _p(col), _p(val), _p(b), _p(x), C.c_double(rtol),
-                          C.c_double(atol), int(max_it), C.byref(res))
+                          C.c_double(atol), int(max_it), C.byref(res), C.c_double(atol_pc))
     return x, it, res.value
 
 
 def poisson_cycle(tdim: int, x: np.ndarray, conn: np.ndarray, f: np.ndarray, u_d: np.ndarray,
                   bc_dofs: np.ndarray, alpha: float, rtol: float = 1e-14,
-                  cg_cap: Optional[int] = None, threads: Optional[int] = None, pc: str = "jacobi") -> Dict:
+                  cg_cap: Optional[int] = None, threads: Optional[int] = None, pc: str = "jacobi",
+                  rtol_bpx: float = 1e-11) -> Dict:
     """One assemble + forward solve + functional + linearise + adjoint solve + gradient
     cycle with homogeneous Dirichlet values, cold start u = 0 (the cycle bench.py times).
     ``cg_cap`` bounds the iterations of each CG solve (bounded baseline sample)."""
@@ -148,9 +149,9 @@ def poisson_cycle(tdim: int, x: np.ndarray, conn: np.ndarray, f: np.ndarray, u_d
         t0 = time.perf_counter()
         B = Bpx(x, isbc)
         T["bpx_setup"] = time.perf_counter() - t0           # per mesh, like the pattern
-        solve = lambda A_, b_, atol_: pcg_bpx(B, rowptr, col, A_, b_, rtol, atol_, max_it)
+        solve = lambda A_, b_, atol_, atol_pc_=0.0: pcg_bpx(B, rowptr, col, A_, b_, rtol_bpx, atol_, max_it, atol_pc_)   # engine: KSP_OPTIONS['rtol_bpx']
     else:
-        solve = lambda A_, b_, atol_: pcg(rowptr, col, A_, b_, rtol, atol_, max_it)
+        solve = lambda A_, b_, atol_, atol_pc_=0.0: pcg(rowptr, col, A_, b_, rtol, atol_, max_it)
 
     diag_at = _diag_index(rowptr, col)                      # set-up as well (pattern only)
     NOISE_FACTOR = 64.0                                     # the engine's rule (utils_hip._NewtonBase): Newton
@@ -160,6 +161,7 @@ def poisson_cycle(tdim: int, x: np.ndarray, conn: np.ndarray, f: np.ndarray, u_d
     u = np.zeros(nv)
     its_newton = []
     atol = 0.0
+    atol_pc = 0.0
     z0 = None
     # Newton, always 3 iterations (utils_dolfinx.py:419-449); F assembled 4 times
     F = residual(tdim, x, conn, u, f)
@@ -171,14 +173,16 @@ def poisson_cycle(tdim: int, x: np.ndarray, conn: np.ndarray, f: np.ndarray, u_d
         if k == 0:
             T["assembly_fwd"] = time.perf_counter() - t0
             t1 = time.perf_counter()
-        dx, it, res = solve(A, b, atol)
+        dx, it, res = solve(A, b, atol, atol_pc)
         if k == 0:
             T["cg_fwd"] = time.perf_counter() - t1
             dinv = 1.0 / A[diag_at]
             z0 = float(np.sqrt(b @ (dinv * b)))
         its_newton.append(it)
         u -= dx
-        atol = max(rtol * z0, NOISE_FACTOR * eps * float(np.sqrt(u @ u)))
+        atol = max(rtol * z0, NOISE_FACTOR * eps * float(np.sqrt(u @ u)))                # utils_hip._NewtonBase
+        if pc == "bpx":                       # later solves: energy-norm accuracy relative to the state (g = 0 here)
+            atol_pc = rtol_bpx * float(np.sqrt(max(u @ spmv(rowptr, col, A, u) - float(u[bc_dofs] @ u[bc_dofs]), 0.0)))
         F = residual(tdim, x, conn, u, f)
     T["newton_total"] = time.perf_counter() - t0
     t0 = time.perf_counter()

@@ -452,9 +452,10 @@ void oc_bpx_apply(oc_bpx* B, const double* dinv, const double* r, double* z) {
   }
 }
 
-/* BPX-PCG from x = 0, same stopping rule as oc_pcg_jacobi (natural norm of the Jacobi scaling). */
+/* BPX-PCG from x = 0 with the engine's stopping rule: relative in the norm of the preconditioner,
+ * sqrt(r^T M^-1 r) <= rtol sqrt(b^T M^-1 b); absolute in the Jacobi norm, sqrt(r^T D^-1 r) <= atol. */
 int oc_pcg_bpx(oc_bpx* B, int64_t n, const int64_t* rowptr, const int32_t* col, const double* val, const double* b,
-               double* x, double rtol, double atol, int max_it, double* res) {
+               double* x, double rtol, double atol, int max_it, double* res, double atol_pc) {
   double* r = (double*)malloc(n * sizeof(double));
   double* p = (double*)malloc(n * sizeof(double));
   double* q = (double*)malloc(n * sizeof(double));
@@ -471,15 +472,16 @@ int oc_pcg_bpx(oc_bpx* B, int64_t n, const int64_t* rowptr, const int32_t* col, 
     r[i] = b[i];
     bb += r[i] * dinv[i] * r[i];
   }
-  double tol = rtol * sqrt(bb), rho = bb;
-  if (atol > tol) tol = atol;
+  double rho = bb;
   int it = 0;
-  if (sqrt(rho) > tol) {
+  if (sqrt(rho) > atol && rho > 0.0) {
     oc_bpx_apply(B, dinv, r, z);
     double rz = 0.0;
 #pragma omp parallel for schedule(static) reduction(+ : rz)
     for (int64_t i = 0; i < n; ++i) { p[i] = z[i]; rz += r[i] * z[i]; }
-    while (it < max_it) {
+    double tol2 = rtol * rtol * rz;
+    if (atol_pc * atol_pc > tol2) tol2 = atol_pc * atol_pc;   /* sqrt(r^T M^-1 r) <= max(rtol sqrt(b^T M^-1 b), atol_pc) */
+    while (it < max_it && rz > tol2) {
       double pq = 0.0;
 #pragma omp parallel for schedule(static) reduction(+ : pq)
       for (int64_t i = 0; i < n; ++i) {
@@ -497,11 +499,12 @@ int oc_pcg_bpx(oc_bpx* B, int64_t n, const int64_t* rowptr, const int32_t* col, 
         rho += r[i] * dinv[i] * r[i];
       }
       ++it;
-      if (sqrt(rho) <= tol) break;
+      if (atol > 0.0 && sqrt(rho) <= atol) break;
       oc_bpx_apply(B, dinv, r, z);
       double rz1 = 0.0;
 #pragma omp parallel for schedule(static) reduction(+ : rz1)
       for (int64_t i = 0; i < n; ++i) rz1 += r[i] * z[i];
+      if (rz1 <= tol2) break;
       const double beta = rz != 0.0 ? rz1 / rz : 0.0;
       rz = rz1;
 #pragma omp parallel for schedule(static)
