@@ -234,7 +234,7 @@ def _run(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if world > 1 or os.environ.get("FEMO_BENCH_FORCE_DIST"):   # the env switch runs the N>1 code path on one rank (tests)
+    if world > 1 or os.environ.get("FEMO_BENCH_FORCE_DIST", "0") not in ("", "0"):   # the env switch runs the N>1 code path on one rank (tests)
         from femo_amd.dist import bench_distributed
         return bench_distributed(args, rank, world, local_rank)
 
@@ -265,8 +265,9 @@ def _run(args):
     def host_cycle(k):
         return one_cycle(sim, fea, f_pin[k % len(f_pin)], u0)
 
+    g = None
     for w in range(W):
-        host_cycle(w)
+        g = host_cycle(w)          # held across the next cycle like in the timed loop: the pinned pool reaches its steady size
     ctx.sync()
     del utils_hip.LAST_KSP_INFO[:]
     E.host_stats(reset=True)

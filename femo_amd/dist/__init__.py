@@ -24,13 +24,13 @@ from .partition import LocalMesh, build_local_mesh, rcb_partition
 class DistMesh(Mesh):
     """A rank's local piece of a partitioned mesh; drop-in for ``Mesh`` in the FEA stack."""
 
-    def __init__(self, local: LocalMesh, n_vert_global: int, n_cell_global: int, bbox=None):
+    def __init__(self, local: LocalMesh, n_vert_global: int, n_cell_global: int, bbox=None, box_domain: bool = False):
         super().__init__(local.x, local.conn)
         self.local = local
         self.n_vert_global = int(n_vert_global)
         self.n_cell_global = int(n_cell_global)
         self.bbox = bbox        # (lo, hi) of the whole mesh: every rank builds the same BPX lattice
-        self._global_mesh = None
+        self.box_domain = box_domain   # the whole mesh fills its bounding box (generated squares / cubes)
 
     @property
     def n_owned(self) -> int:
@@ -39,14 +39,17 @@ class DistMesh(Mesh):
     def boundary_facet_mask(self) -> np.ndarray:
         """Exterior facets are those of the WHOLE mesh: the cut faces of the partition are not a
         boundary (a facet seen once among the local cells may have its other cell on another rank).
-        Computed on first use from the global mesh -- only forms with facet terms (Nitsche) ask."""
+        Box-filling meshes decide from the coordinates; otherwise ``partition_mesh(..., facets=True)``
+        slices the whole mesh's mask at partition time (the whole mesh is not kept)."""
         if getattr(self, "_bfacets", None) is None:
-            g = getattr(self, "_global_mesh", None)
-            if g is None:
-                if self.local.nranks > 1:
-                    raise RuntimeError("DistMesh without its global mesh cannot tell exterior facets from partition cuts")
+            if self.box_domain:
+                from .structured import box_boundary_facets
+                lo, hi = self.bbox
+                self._bfacets = box_boundary_facets(self.x, self.conn, float(np.min(lo)), float(np.max(hi)))
+            elif self.local.nranks > 1:
+                raise RuntimeError("DistMesh: exterior facets were not prepared; partition the mesh with facets=True")
+            else:
                 return super().boundary_facet_mask()
-            self._bfacets = np.ascontiguousarray(g.boundary_facet_mask()[self.local.cell_global])
         return self._bfacets
 
     def device(self, ctx):
@@ -62,12 +65,28 @@ class DistMesh(Mesh):
         return self._device
 
 
-def partition_mesh(mesh: Mesh, rank: int, nranks: int) -> DistMesh:
+def partition_mesh(mesh: Mesh, rank: int, nranks: int, facets: bool = False) -> DistMesh:
+    """Rank ``rank``'s piece of a mesh that every rank holds whole (imported meshes).  Nothing of the whole
+    mesh is kept afterwards: ``facets=True`` slices its exterior-facet mask now (forms with facet terms need
+    it), and its lattice occupancy -- every rank must pick the same preconditioner -- is evaluated here."""
     part = rcb_partition(mesh.x, nranks)
     local = build_local_mesh(mesh.x, mesh.conn, part, rank, nranks)
     dm = DistMesh(local, mesh.n_vert, mesh.n_cell, bbox=(mesh.x.min(axis=0), mesh.x.max(axis=0)))
-    dm._occupancy = mesh.lattice_occupancy()      # of the WHOLE mesh: every rank must pick the same preconditioner
-    dm._global_mesh = mesh                        # for boundary_facet_mask(), computed only if a form needs facets
+    dm._occupancy = mesh.lattice_occupancy()
+    if facets or getattr(mesh, "_bfacets", None) is not None:
+        dm._bfacets = np.ascontiguousarray(mesh.boundary_facet_mask()[local.cell_global])
+    return dm
+
+
+def local_unit_mesh(n: int, dim: int, rank: int, nranks: int, jitter: float = 0.0, seed: int = 20240807) -> DistMesh:
+    """Rank ``rank``'s block of the n^dim unit square / cube, generated locally (dist/structured.py): host
+    memory and set-up time per rank scale like 1/nranks.  ``_occupancy`` is the LOCAL value; callers that run
+    several ranks take the maximum over ranks before the first solve (bench_distributed does)."""
+    from .structured import local_structured
+    local = local_structured(n, dim, rank, nranks, jitter, seed)
+    n1 = n + 1
+    dm = DistMesh(local, n1 ** dim, (2 if dim == 2 else 6) * n ** dim, bbox=(np.zeros(dim), np.ones(dim)), box_domain=True)
+    dm.n = n
     return dm
 
 
@@ -111,89 +130,197 @@ class _quiet_stdout:
         return False
 
 
+class TorchControl:
+    """Control plane of a multi-process run: torch.distributed over gloo (rendezvous, barriers, small host
+    reductions, the ncclUniqueId broadcast).  Never carries field data."""
+
+    def __init__(self, rank: int, world: int):
+        self.rank, self.world = rank, world
+        self.dist = init_process_group(rank, world)
+
+    def init_comm(self, ctx) -> None:
+        init_comm(ctx, self.rank, self.world)
+
+    def barrier(self) -> None:
+        self.dist.barrier()
+
+    def allreduce(self, values, op: str = "sum") -> np.ndarray:
+        import torch
+        t = torch.tensor(np.asarray(values, dtype=np.float64).ravel())
+        self.dist.all_reduce(t, op={"sum": self.dist.ReduceOp.SUM, "max": self.dist.ReduceOp.MAX}[op])
+        return t.numpy()
+
+    def gather(self, values) -> np.ndarray:
+        import torch
+        t = torch.tensor(np.asarray(values, dtype=np.float64).ravel())
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return np.stack([o.numpy() for o in out])
+
+
+class ThreadControl:
+    """The same interface for ranks that are host threads of one process (rank emulation on one GPU, tests)."""
+
+    class Shared:
+        def __init__(self, world: int):
+            import threading
+            self.world = world
+            self.barrier = threading.Barrier(world, timeout=300)
+            self.slots = [None] * world
+
+    def __init__(self, rank: int, shared: "ThreadControl.Shared", group):
+        self.rank, self.world, self._s, self._group = rank, shared.world, shared, group
+
+    def init_comm(self, ctx) -> None:
+        ctx.comm_emulate(self._group, self.rank)
+
+    def barrier(self) -> None:
+        self._s.barrier.wait()
+
+    def gather(self, values) -> np.ndarray:
+        self._s.slots[self.rank] = np.asarray(values, dtype=np.float64).ravel().copy()
+        self._s.barrier.wait()
+        out = np.stack(self._s.slots)
+        self._s.barrier.wait()
+        return out
+
+    def allreduce(self, values, op: str = "sum") -> np.ndarray:
+        g = self.gather(values)
+        return g.sum(axis=0) if op == "sum" else g.max(axis=0)
+
+
 def bench_distributed(args, rank: int, world: int, local_rank: int):
     """bench.py for N > 1: the 10 M-DOF mesh is partitioned over the ranks (strong scaling).
-    Returns the result line on rank 0 (None elsewhere); bench.py prints it."""
-    result = _bench_distributed(args, rank, world, local_rank)
-    import torch.distributed as dist
-    dist.barrier()
-    return result
-
-
-def _bench_distributed(args, rank: int, world: int, local_rank: int):
-    import bench as B
-    from ..engine import Context, DeviceArray, Vec
+    Returns the result line on rank 0 (None elsewhere); bench.py prints it.  A rank that fails takes the job
+    down instead of leaving the others in a barrier."""
+    from ..engine import Context
     from ..fea import utils_hip
-    from ..fea.mesh import createUnitCubeMesh
+    control = TorchControl(rank, world)
+    try:
+        ctx = Context(local_rank)
+        utils_hip.set_context(ctx)
+        control.init_comm(ctx)
+        result = run_distributed_bench(args, ctx, control)
+        control.barrier()
+        return result
+    except BaseException:                        # noqa: BLE001
+        import sys
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)                              # torchrun tears the other ranks down
 
-    dist = init_process_group(rank, world)
-    import torch
-    ctx = Context(local_rank)
-    utils_hip.set_context(ctx)
+
+def run_distributed_bench(args, ctx, control, cpu_baseline: bool = True):
+    """One rank's part of the N > 1 benchmark: rank-local mesh, the operator stack on it, the timed cycles,
+    the JSON line on rank 0.  ``ctx`` already has its communicator (RCCL or emulated)."""
+    import bench as B
+    from ..engine import Vec, pinned_array
+    from ..fea import utils_hip
+
+    rank, world = control.rank, control.world
     utils_hip.KSP_OPTIONS["pc"] = B.PC = getattr(args, "pc", "bpx")
-    init_comm(ctx, rank, world)
     t0 = time.perf_counter()
-    gmesh = createUnitCubeMesh(args.n, jitter=getattr(args, 'jitter', 0.0))
-    n_dof, n_cell_g = gmesh.n_vert, gmesh.n_cell
-    mesh = partition_mesh(gmesh, rank, world)
-    del gmesh
-    sim, fea = B.build_problem(mesh, device=True)
+    rss0 = _rss_mb()
+    mesh = local_unit_mesh(args.n, 3, rank, world, jitter=getattr(args, "jitter", 0.0))
+    mesh._occupancy = float(control.allreduce([mesh.lattice_occupancy()], "max")[0])    # one choice of preconditioner for all
+    n_dof, n_cell_g = mesh.n_vert_global, mesh.n_cell_global
+    # like N = 1: NumPy arrays at the operator boundary, every rank holding its own share of f, u and dJ/df in
+    # pinned host memory (a distributed driver; each GPU has its own PCIe link)
+    sim, fea = B.build_problem(mesh, device=False)
     dm = mesh.device(ctx)
     K, W = args.steps, args.warmup
-    f_host = B.source_fields(mesh, min(K + W, 4))
-    f_dev = [DeviceArray(Vec(ctx, mesh.n_cell).set(f)) for f in f_host]
+    f_host = [pinned_array(f) for f in B.source_fields(mesh, min(K + W, 4))]
+    u0 = pinned_array(np.zeros(mesh.n_vert))
     setup_s = time.perf_counter() - t0
+    rss_setup = _rss_mb() - rss0
 
+    g = None
     for w in range(W):
-        B.one_cycle(sim, fea, f_dev[w % len(f_dev)])
+        g = B.one_cycle(sim, fea, f_host[w % len(f_host)], u0)
     ctx.sync()
-    dist.barrier()
-    del utils_hip.LAST_KSP_INFO[:]
+    control.barrier()
+    if rank == 0:
+        del utils_hip.LAST_KSP_INFO[:]
+    control.barrier()
     t0 = time.perf_counter()
     for k in range(K):
-        B.one_cycle(sim, fea, f_dev[(W + k) % len(f_dev)])
+        g = B.one_cycle(sim, fea, f_host[(W + k) % len(f_host)], u0)   # the gradient is the caller's: held until replaced
     ctx.sync()
-    dist.barrier()
-    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    ms_per_step = float(elapsed[0]) / K * 1e3
+    control.barrier()
+    elapsed = float(control.allreduce([time.perf_counter() - t0], "max")[0])
+    ms_per_step = elapsed / max(K, 1) * 1e3
 
-    infos = list(utils_hip.LAST_KSP_INFO)
-    its_per_step = [i["iterations"] for i in infos[:len(infos) // K]] if K else []
+    import threading
+    me = threading.get_ident()                               # emulated ranks are threads sharing the module's log
+    infos = [i for i in utils_hip.LAST_KSP_INFO if i.get("thread") == me]
+    per = len(infos) // K if K else 0
+    its_per_step = [i["iterations"] for i in infos[:per]]
     cg_ms = sum(i["solve_ms"] for i in infos) / max(K, 1)
-    A_mat = [w[1] for k, w in utils_hip._WORK.items() if k[1] == "newton_A"][0].mat
+    A_mat = [w[1] for k, w in utils_hip._WORK.items() if k[1] == "newton_A" and w[0] is mesh][0].mat
     xv = Vec(ctx, mesh.n_vert).set(np.random.default_rng(rank).standard_normal(mesh.n_vert))
     yv = Vec(ctx, mesh.n_vert)
-    spmv_ms = min(A_mat.bench_spmv(xv, yv, 50) for _ in range(3))
+    control.barrier()
+    spmv_ms = min(A_mat.bench_spmv(xv, yv, 50) for _ in range(3))      # local rows only, no halo: the kernel's own rate
     local_nnz = dm.info["nnz"]
     B_A = B.spmv_algorithmic_bytes(local_nnz, mesh.n_owned)
     achieved = B_A / (spmv_ms * 1e-3) / 1e9
-    stats = torch.tensor([mesh.n_owned, mesh.n_vert - mesh.n_owned, len(mesh.local.nbr)], dtype=torch.float64)
-    gathered = [torch.zeros_like(stats) for _ in range(world)]
-    dist.all_gather(gathered, stats)
-    if rank == 0:
-        result = {
-            "metric": B.METRIC, "value": n_dof / (ms_per_step * 1e-3), "unit": "DOFs/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {
-                "workload": (f"3-D linear Poisson, P1 tets, unit cube n={args.n}: {n_dof} DOFs, {n_cell_g} cells, "
-                             f"RCB {world}-way vertex partition, ghost-DOF halo (ncclSend/Recv) + RCCL all-reduce "
-                             f"{B.PC.upper()}-CG; same cycle as N=1"),
-                "preconditioner": B.PC, "pc_lattice": dm.pc_info(),
-                "n": args.n, "n_dof": n_dof, "n_cell": n_cell_g, "parallelism": f"rcb{world}",
-                "owned_per_rank": [int(g[0]) for g in gathered], "ghosts_per_rank": [int(g[1]) for g in gathered],
-                "neighbours_per_rank": [int(g[2]) for g in gathered],
-                "cg_iterations_per_step": its_per_step, "cg_ms_per_step": cg_ms,
-                "non_cg_ms_per_step": ms_per_step - cg_ms, "setup_s": setup_s,
-            },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": B.HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / B.HBM_PEAK_GBS, "traffic": None,
-                "kernel": "k_spmv_sell<true,true> on rank 0's local rows (per GPU)",
-                "algorithmic_bytes_per_launch": B_A, "avg_launch_ms": spmv_ms, "launches_timed": 150,
-            },
-        }
-        return result
-    return None
+    L = mesh.local
+    lat = dm.pc_info()
+    # bytes a rank moves per CG iteration besides its HBM traffic: ghost values in and out, the lattice all-reduce
+    halo_out, halo_in = int(L.send_ptr[-1]) * 8, int(L.recv_ptr[-1]) * 8
+    stats = control.gather([mesh.n_owned, mesh.n_vert - mesh.n_owned, len(L.nbr), halo_out, halo_in, achieved, spmv_ms,
+                            B.stored_bytes(dm.info, mesh.n_owned), rss_setup, setup_s])
+    if rank != 0:
+        return None
+    result = {
+        "metric": B.METRIC, "value": n_dof / (ms_per_step * 1e-3), "unit": "DOFs/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": (f"3-D linear Poisson, P1 tets, unit cube n={args.n}: {n_dof} DOFs, {n_cell_g} cells, "
+                         f"{world}-way block partition {'x'.join(str(g) for g in _grid(world))} (rank-local mesh generation), "
+                         f"ghost-DOF halo (ncclSend/Recv) + RCCL all-reduce {B.PC.upper()}-CG; same cycle as N=1, every rank with "
+                         f"NumPy arrays of its share of f, u and dJ/df at the operator boundary"),
+            "boundary": "host (per rank: NumPy in pinned blocks; H2D + D2H inside the timed region)",
+            "preconditioner": B.PC, "pc_lattice": lat,
+            "n": args.n, "n_dof": n_dof, "n_cell": n_cell_g, "parallelism": f"block{world}",
+            "owned_per_rank": [int(s[0]) for s in stats], "ghosts_per_rank": [int(s[1]) for s in stats],
+            "neighbours_per_rank": [int(s[2]) for s in stats],
+            "halo_bytes_sent_per_exchange_per_rank": [int(s[3]) for s in stats],
+            "halo_bytes_received_per_exchange_per_rank": [int(s[4]) for s in stats],
+            "allreduce_per_cg_iteration": "1 lattice all-reduce (shared finest-level nodes + next level) + 2 scalar all-reduces",
+            "linear_solves_per_step": per, "cg_iterations_per_step": its_per_step, "cg_ms_per_step": cg_ms,
+            "non_cg_ms_per_step": ms_per_step - cg_ms,
+            "setup_s_per_rank": [float(s[9]) for s in stats], "setup_rss_mb_per_rank": [float(s[8]) for s in stats],
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": float(stats[0][5]), "peak": B.HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": float(stats[0][5]) / B.HBM_PEAK_GBS, "traffic": None,
+            "frac_physical": float(stats[0][7]) / (float(stats[0][6]) * 1e-3) / 1e9 / B.HBM_PEAK_GBS,
+            "physical_bytes_source": "stored bytes of the SELL format (no PMC pass at N > 1)",
+            "kernel": "k_spmv_sell<1,true> on rank 0's local rows (per GPU), 150 back-to-back launches",
+            "algorithmic_bytes_per_launch": B_A, "avg_launch_ms": float(stats[0][6]), "launches_timed": 150,
+            "achieved_per_rank": [float(s[5]) for s in stats],
+        },
+    }
+    if cpu_baseline and not getattr(args, "no_cpu_baseline", False):
+        counts = its_per_step if its_per_step else [0]
+        n = args.n
+        nnz = n_dof + 2 * (3 * n * (n + 1) ** 2 + 3 * n * n * (n + 1) + n ** 3)      # SURVEY.md section 8
+        result["cpu_baseline"] = B.cpu_baseline(args, counts, n_dof, n_cell_g, nnz)
+    return result
+
+
+def _grid(world: int):
+    from .structured import process_grid
+    return process_grid(world, 3)
+
+
+def _rss_mb() -> float:
+    try:
+        with open("/proc/self/statm") as fh:
+            return int(fh.read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 1e6
+    except Exception:
+        return 0.0

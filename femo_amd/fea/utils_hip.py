@@ -529,7 +529,7 @@ class KSP:
             self.info = self.A.mat.solve_cg(_as_vec(b), _as_vec(x), pc=pc, **kw)
         else:
             self.info = self.A.mat.solve_bicgstab(_as_vec(b), _as_vec(x), **kw)
-        LAST_KSP_INFO.append(dict(iterations=self.info.iterations, converged=self.info.converged,
+        LAST_KSP_INFO.append(dict(thread=threading.get_ident(), iterations=self.info.iterations, converged=self.info.converged,
                                   residual_norm=self.info.residual_norm, rhs_norm=self.info.rhs_norm,
                                   pc_residual_norm=self.info.pc_residual_norm, pc_rhs_norm=self.info.pc_rhs_norm,
                                   solve_ms=self.info.solve_ms, spmv_ms=self.info.spmv_ms,

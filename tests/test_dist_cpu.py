@@ -271,3 +271,26 @@ def test_two_process_gloo_bpx_pcg(tmp_path, d, n):
     pinned[bd] = True
     _, it_serial = bo.pcg(A, b, bo.BPX(m.x, A.diagonal(), pinned), rtol=1e-13)
     assert abs(its[0] - it_serial) <= 1
+
+
+@pytest.mark.parametrize("dim,n,nranks,jitter", [(3, 6, 8, 0.0), (3, 7, 4, 0.2), (3, 5, 2, 0.0), (2, 9, 4, 0.2), (2, 8, 3, 0.0), (3, 4, 1, 0.0)])
+def test_rank_local_generation_equals_partitioning_the_whole_mesh(dim, n, nranks, jitter):
+    """dist/structured.py builds a rank's block from local data only; it must be exactly what build_local_mesh
+    extracts from the whole mesh for the same owner map (numbering, coordinates incl. the seeded jitter, ghost
+    order, halo plan)."""
+    from femo_amd.dist.structured import BlockOwner, box_boundary_facets, local_structured, process_grid
+    from femo_amd.fea.mesh import createUnitCubeMesh, createUnitSquareMesh
+    g = createUnitSquareMesh(n, jitter=jitter) if dim == 2 else createUnitCubeMesh(n, jitter=jitter)
+    owner = BlockOwner(n, dim, nranks)
+    part = owner(np.arange(g.n_vert))
+    assert np.prod(process_grid(nranks, dim)) == nranks and np.bincount(part, minlength=nranks).min() > 0
+    for rank in range(nranks):
+        a = local_structured(n, dim, rank, nranks, jitter)
+        b = build_local_mesh(g.x, g.conn, part, rank, nranks)
+        for f in ("n_owned",):
+            assert getattr(a, f) == getattr(b, f)
+        for f in ("x", "conn", "vert_global", "cell_global", "cell_owned", "nbr", "send_ptr", "send_idx", "recv_ptr"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), (rank, f)
+        # exterior facets from the coordinates = the whole mesh's facet mask on the local cells
+        assert np.array_equal(box_boundary_facets(a.x, a.conn), g.boundary_facet_mask()[a.cell_global])
+    assert process_grid(8, 3) == (2, 2, 2) and process_grid(2, 3) == (1, 1, 2) and process_grid(4, 3) == (1, 2, 2)

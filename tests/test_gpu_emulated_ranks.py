@@ -260,7 +260,7 @@ def test_nitsche_facets_on_partitioned_meshes():
     x_ref = spla.spsolve(J_ref, r_ref)
 
     def rank_fn(rank, ctx):
-        mesh = partition_mesh(gmesh, rank, world)
+        mesh = partition_mesh(gmesh, rank, world, facets=True)
         L = mesh.local
         assert np.array_equal(mesh.boundary_facet_mask(), bm[L.cell_global])
         dm = mesh.device(ctx)
@@ -357,7 +357,7 @@ def test_bicgstab_on_emulated_ranks(world):
     x_ref = spla.splu(Jo.tocsc()).solve(rhs)
 
     def rank_fn(rank, ctx):
-        mesh = partition_mesh(gmesh, rank, world)
+        mesh = partition_mesh(gmesh, rank, world, facets=True)
         L = mesh.local
         dm = mesh.device(ctx)
         dm.set_boundary_facets(mesh.boundary_facet_mask())
@@ -425,3 +425,59 @@ def test_projection_on_two_emulated_ranks():
         for r in res:
             full[r["gid"]] = r[key]
         assert np.abs(full - ref).max() < 1e-9 * np.abs(ref).max(), key
+
+
+def test_distributed_bench_record_on_eight_emulated_ranks():
+    """`bench.py --gpus 8` end to end with the eight ranks emulated on one GPU (dist.run_distributed_bench with a
+    thread control plane instead of torch.distributed + RCCL): rank-local mesh generation under the 2 x 2 x 2
+    block partition, NumPy arrays at every rank's operator boundary, and a record whose counts are consistent."""
+    from argparse import Namespace
+    from femo_amd.dist import ThreadControl, run_distributed_bench
+    from femo_amd.engine import Context, EmuGroup
+    from femo_amd.fea import utils_hip
+    world, n = 8, 48
+    group = EmuGroup(world)
+    shared = ThreadControl.Shared(world)
+    args = Namespace(n=n, steps=2, warmup=1, pc="bpx", jitter=0.0, cpu_n=0, no_cpu_baseline=True)
+    out, err = [None] * world, [None] * world
+
+    def body(rank):
+        try:
+            ctx = Context(0)
+            control = ThreadControl(rank, shared, group)
+            control.init_comm(ctx)
+            utils_hip.set_context(ctx, thread_local=True)
+            try:
+                out[rank] = run_distributed_bench(args, ctx, control, cpu_baseline=False)
+                ctx.sync()
+            finally:
+                utils_hip.set_context(None, thread_local=True)
+        except BaseException as e:          # noqa: BLE001
+            err[rank] = e
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not any(t.is_alive() for t in threads), "a rank hung"
+    for e in err:
+        if e is not None:
+            raise e
+    assert all(o is None for o in out[1:])
+    r = out[0]
+    c = r["config"]
+    N = (n + 1) ** 3
+    assert r["n_gpus"] == 8 and r["scaling"] == "strong" and c["n_dof"] == N and c["parallelism"] == "block8"
+    assert abs(r["value"] - N / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
+    assert sum(c["owned_per_rank"]) == N and max(c["owned_per_rank"]) - min(c["owned_per_rank"]) <= 3 * (n + 1) ** 2
+    assert all(3 <= k <= 7 for k in c["neighbours_per_rank"])                  # 3 face + 3 edge + 1 corner blocks
+    assert all(b > 0 for b in c["halo_bytes_sent_per_exchange_per_rank"])
+    assert sum(c["halo_bytes_sent_per_exchange_per_rank"]) == sum(c["halo_bytes_received_per_exchange_per_rank"])
+    assert c["linear_solves_per_step"] == 4
+    its = c["cg_iterations_per_step"]
+    assert len(its) == 4 and 10 < its[0] <= 40 and 10 < its[3] <= 40 and its[1] <= 2 and its[2] <= 2
+    assert "host" in c["boundary"] and len(c["setup_rss_mb_per_rank"]) == 8
+    rf = r["roofline"]
+    assert rf["bound"] == "hbm" and rf["frac"] > 0 and len(rf["achieved_per_rank"]) == 8
