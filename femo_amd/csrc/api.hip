@@ -470,7 +470,10 @@ static int note_pinned_vertices(femo_mat* A, int pde, const double* params, cons
   if (!A->bpx_ok) return 0;
   const bool nitsche = m->d_bvmask != nullptr && params != nullptr && params[0] != 0.0;
   const bool strong = bc != nullptr && bc->n > 0;
-  const uint64_t key = 1 + (strong ? bc->uid << 20 : 0) + (nitsche ? (m->bfacets_version << 1) | 1 : 0);
+  // The key must change on every rank when the Dirichlet set is replaced, also on ranks whose block holds none
+  // of its vertices (bc->n == 0): the coefficient rebuild behind it runs all-reduces, and a rank that kept its old
+  // key would not enter them.  Ranks create their sets in the same order, so the process-local uid agrees.
+  const uint64_t key = 1 + (bc != nullptr ? bc->uid << 20 : 0) + (nitsche ? (m->bfacets_version << 1) | 1 : 0);
   if (A->pc_key == key) return 0;
   A->pc_has_mask = strong || nitsche;
   if (A->pc_has_mask) {

@@ -194,6 +194,37 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_spmv_sell(
   }
 }
 
+// y += A^T x by scatter (partitioned, structurally non-symmetric-valued operators): the transposed entry of a
+// ghost column lives in a row of another rank, so the explicit transposed values cannot be formed locally.
+// Row i adds a_ij x_i to y_j for all its entries, ghost columns included; the ghost tail of y then travels back
+// to the owners, who add it (femo_halo_reverse_add: SURVEY.md section 8(e) "reverse halo scatter-add").  Scattered
+// fp64 atomics are slow; this is the correctness path of the unsymmetric-Nitsche adjoint
+// on N > 1, not a benchmark path.  y[0:n_vert] must be zero on entry.
+template <bool UNIT>
+__global__ __launch_bounds__(FEMO_BLOCK) void k_spmv_sell_T_scatter(int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ mptr,
+                                                                    const int32_t* __restrict__ cols, const int32_t* __restrict__ rowlen,
+                                                                    const double* __restrict__ vals, const double* __restrict__ diag,
+                                                                    const double* __restrict__ x, double* __restrict__ y,
+                                                                    const int32_t* __restrict__ done) {
+  if (done != nullptr && *done) return;
+  const int64_t row = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x;
+  if (row >= n_rows) return;
+  const int64_t base = mptr[row >> 6];
+  const int lane = (int)(row & 63), len = rowlen[row];
+  const double xi = x[row];
+  unsafeAtomicAdd(&y[row], UNIT ? xi : diag[row] * xi);
+  for (int k = 0; k < len; ++k) {
+    const int64_t e = femo_sell_index(base, k, lane);
+    unsafeAtomicAdd(&y[cols[e]], vals[e] * xi);
+  }
+}
+
+// y[send_idx[i]] += buf[i]
+__global__ void k_unpack_add(int64_t n, const int32_t* __restrict__ idx, const double* __restrict__ buf, double* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    unsafeAtomicAdd(&y[idx[i]], buf[i]);       // a vertex can be sent to several neighbours
+}
+
 // ------------------------------------------------------------ transposition --
 __global__ void k_build_tperm(int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ mptr,
                               const int32_t* __restrict__ cols, const int32_t* __restrict__ rowlen,
@@ -897,6 +928,38 @@ static int halo_raw(femo_mesh* m, double* x) {
   return femo_halo_exchange(m, &v);
 }
 
+// ghost tail of y -> owners, who add it to their entries (the transpose of the ghost refresh)
+static int halo_reverse_add(femo_mesh* m, double* y, hipStream_t st) {
+  if (m->n_nbr == 0) return 0;
+  femo_ctx* ctx = m->ctx;
+  FEMO_REQUIRE(ctx->comm != nullptr || ctx->emu != nullptr, "halo exchange before femo_comm_init");
+  const int64_t ns = m->send_ptr[m->n_nbr];
+  // roles swapped: what this rank receives in a forward exchange (its ghost tail) is what it sends back
+  FEMO_TRY(femo_coll_neighbors(ctx, m->n_nbr, m->nbr.data(), m->recv_ptr.data(), y + m->n_rows, m->send_ptr.data(), m->d_send_buf, st));
+  if (ns > 0) {
+    hipLaunchKernelGGL(k_unpack_add, dim3((unsigned)std::min<int64_t>((ns + 255) / 256, 2048)), dim3(256), 0, st, ns, m->d_send_idx, m->d_send_buf, y);
+    FEMO_HIP_CHECK(hipGetLastError());
+  }
+  return 0;
+}
+
+// y = A^T x on a partitioned mesh, A given by its own (untransposed) values
+static int spmv_transposed_scatter(const femo_mat* A, const double* vals, bool unit, const double* x, double* y, const int32_t* done) {
+  femo_mesh* m = A->mesh;
+  hipStream_t st = m->ctx->stream;
+  FEMO_HIP_CHECK(hipMemsetAsync(y, 0, (size_t)m->n_vert * sizeof(double), st));
+  if (m->n_rows > 0) {
+    const unsigned g = (unsigned)((m->n_rows + FEMO_BLOCK - 1) / FEMO_BLOCK);
+    if (unit) hipLaunchKernelGGL((k_spmv_sell_T_scatter<true>), dim3(g), dim3(FEMO_BLOCK), 0, st, m->n_rows, m->n_slices, m->d_mptr, m->d_cols, m->d_rowlen, vals, A->d_diag, x, y, done);
+    else hipLaunchKernelGGL((k_spmv_sell_T_scatter<false>), dim3(g), dim3(FEMO_BLOCK), 0, st, m->n_rows, m->n_slices, m->d_mptr, m->d_cols, m->d_rowlen, vals, A->d_diag, x, y, done);
+    FEMO_HIP_CHECK(hipGetLastError());
+  }
+  return halo_reverse_add(m, y, st);
+}
+
+// can the explicit transposed values be formed on this rank?  (no on partitioned meshes: see k_build_tperm)
+static bool transpose_is_local(const femo_mesh* m) { return m->n_nbr == 0; }
+
 // ----------------------------------------------------------------- API ------
 extern "C" int femo_mat_spmv(const femo_mat* A, int transpose, const femo_vec* x, femo_vec* y) {
   FEMO_REQUIRE(A && x && y, "null argument");
@@ -905,6 +968,10 @@ extern "C" int femo_mat_spmv(const femo_mat* A, int transpose, const femo_vec* x
   FEMO_REQUIRE(x->d != y->d, "spmv cannot run in place");
   femo_vec_touch(y);
   const double* vals = A->d_vals;
+  if (transpose && !transpose_is_local(m)) {
+    FEMO_REQUIRE(y->n >= m->n_vert, "transposed product on a partitioned mesh: y needs room for the ghost contributions");
+    return spmv_transposed_scatter(A, A->d_vals, false, x->d, y->d, nullptr);
+  }
   if (transpose) {
     FEMO_TRY(femo_mat_ensure_transpose(const_cast<femo_mat*>(A)));
     vals = A->d_valsT;
@@ -1409,7 +1476,9 @@ extern "C" int femo_solve_bicgstab(const femo_mat* A_, int transpose, const femo
   memset(info, 0, sizeof *info);
   hipStream_t st = ctx->stream;
   FEMO_HIP_CHECK(hipEventRecord(ctx->ev0, st));
-  FEMO_TRY(ensure_scaled(A, transpose != 0));
+  // transposed operator of a partitioned mesh: applied by scatter + reverse halo add from the untransposed values
+  const bool scatter_T = transpose != 0 && !transpose_is_local(m);
+  FEMO_TRY(ensure_scaled(A, transpose != 0 && !scatter_T));
   CgWork w;
   FEMO_TRY(ensure_work(ctx, n, m->n_vert, w, 2));
   const bool multi = ctx->nranks > 1 || (ctx->comm != nullptr && getenv("FEMO_FORCE_MULTI") != nullptr);
@@ -1424,8 +1493,12 @@ extern "C" int femo_solve_bicgstab(const femo_mat* A_, int transpose, const femo
   if (opts->zero_guess) {
     FEMO_HIP_CHECK(hipMemsetAsync(x->d, 0, x->n * sizeof(double), st));
   } else {
-    if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, x->d));
-    FEMO_TRY(launch_spmv(A, transpose ? A->d_valsT : A->d_vals, x->d, w.q, nullptr, nullptr));
+    if (scatter_T) {
+      FEMO_TRY(spmv_transposed_scatter(A, A->d_vals, false, x->d, w.q, nullptr));
+    } else {
+      if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, x->d));
+      FEMO_TRY(launch_spmv(A, transpose ? A->d_valsT : A->d_vals, x->d, w.q, nullptr, nullptr));
+    }
     q0 = w.q;
   }
   hipLaunchKernelGGL(k_bi_init, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, b->d, q0, A->d_s, w.r, w.r0, w.p, w.q, w.xh, P);
@@ -1470,14 +1543,25 @@ extern "C" int femo_solve_bicgstab(const femo_mat* A_, int transpose, const femo
     for (; it < it_end; ++it) {
       hipLaunchKernelGGL(k_bi_check, dim3(1), dim3(1), 0, st, it, S, ctx->d_flags);
       hipLaunchKernelGGL(k_bi_p, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, it, S, w.r, w.q, w.p, ctx->d_flags);
-      if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, w.p));
-      FEMO_TRY(launch_spmv(A, A->d_valsS, w.p, w.q, P, ctx->d_flags, true, false, nullptr, 0, nullptr, w.r0));   // v, (r0, v)
-      hipLaunchKernelGGL(k_bi_fold, dim3(1), dim3(1024), 0, st, gs, 1, P, S + B_R0V, ctx->d_flags);
+      if (scatter_T) {
+        FEMO_TRY(spmv_transposed_scatter(A, A->d_valsS, true, w.p, w.q, ctx->d_flags));                       // v
+        hipLaunchKernelGGL(k_dot, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, w.r0, w.q, P);                            // (r0, v)
+      } else {
+        if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, w.p));
+        FEMO_TRY(launch_spmv(A, A->d_valsS, w.p, w.q, P, ctx->d_flags, true, false, nullptr, 0, nullptr, w.r0));   // v, (r0, v)
+      }
+      hipLaunchKernelGGL(k_bi_fold, dim3(1), dim3(1024), 0, st, scatter_T ? gv : gs, 1, P, S + B_R0V, ctx->d_flags);
       if (multi) FEMO_TRY(femo_coll_allreduce(ctx, S + B_R0V, 1, st));
       hipLaunchKernelGGL(k_bi_s, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, S, w.r, w.q, w.sv, ctx->d_flags);
-      if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, w.sv));
-      FEMO_TRY(launch_spmv(A, A->d_valsS, w.sv, w.t, P, ctx->d_flags, true, false, nullptr, 0, nullptr, nullptr, true));  // t, (s,t), (t,t)
-      hipLaunchKernelGGL(k_bi_fold, dim3(1), dim3(1024), 0, st, gs, 2, P, S + B_TS, ctx->d_flags);
+      if (scatter_T) {
+        FEMO_TRY(spmv_transposed_scatter(A, A->d_valsS, true, w.sv, w.t, ctx->d_flags));                      // t
+        hipLaunchKernelGGL(k_dot, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, w.sv, w.t, P);                            // (s, t)
+        hipLaunchKernelGGL(k_dot, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, w.t, w.t, P + FEMO_MAX_PARTIALS);         // (t, t)
+      } else {
+        if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, w.sv));
+        FEMO_TRY(launch_spmv(A, A->d_valsS, w.sv, w.t, P, ctx->d_flags, true, false, nullptr, 0, nullptr, nullptr, true));  // t, (s,t), (t,t)
+      }
+      hipLaunchKernelGGL(k_bi_fold, dim3(1), dim3(1024), 0, st, scatter_T ? gv : gs, 2, P, S + B_TS, ctx->d_flags);
       if (multi) FEMO_TRY(femo_coll_allreduce(ctx, S + B_TS, 2, st));
       hipLaunchKernelGGL(k_bi_xr, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, it, S, w.p, w.sv, w.t, w.r0, w.xh, w.r, P, ctx->d_flags);
       hipLaunchKernelGGL(k_bi_fold, dim3(1), dim3(1024), 0, st, gv, 2, P, S + 12, ctx->d_flags);

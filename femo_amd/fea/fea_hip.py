@@ -174,6 +174,9 @@ class FEA(object):
         """fea_dolfinx.py:228-234"""
         if not (record or self.record):
             return None
-        recorder = XDMFRecorder(os.path.join(self.recorder_path, "record_" + name + ".xdmf"))
+        # partitioned meshes: one file set per rank (every rank writes its own piece)
+        local = getattr(self.mesh, "local", None)
+        suffix = f"_rank{local.rank}" if local is not None and local.nranks > 1 else ""
+        recorder = XDMFRecorder(os.path.join(self.recorder_path, "record_" + name + suffix + ".xdmf"))
         recorder.write_mesh(self.mesh)
         return recorder

@@ -340,9 +340,9 @@ def test_nonlinear_cycle_on_two_emulated_ranks():
 @pytest.mark.parametrize("world", [2, 4])
 def test_bicgstab_on_emulated_ranks(world):
     """Non-symmetric operator (unsymmetric Nitsche) on a partitioned mesh: BiCGSTAB with halo exchanges
-    and all-reduced inner products against LU.  The explicit transpose of a row-partitioned operator
-    needs matrix entries owned by other ranks; the library refuses it loudly (a limit of the
-    partitioned path)."""
+    and all-reduced inner products against LU, for the operator AND its transpose.  The explicit transpose
+    of a row-partitioned operator needs matrix entries owned by other ranks, so the transposed product is
+    formed by scatter + the reverse halo add of SURVEY.md section 8(e) (round 1 refused it)."""
     from femo_amd import engine as E
     from femo_amd.dist import partition_mesh
     from femo_amd.fea.mesh import Mesh
@@ -355,6 +355,8 @@ def test_bicgstab_on_emulated_ranks(world):
     Jo = fo.nl_jacobian(om, u, bm, 0.0, -1.0)
     rhs = rng.standard_normal(om.n_vert)
     x_ref = spla.splu(Jo.tocsc()).solve(rhs)
+    xt_ref = spla.splu(Jo.T.tocsc()).solve(rhs)
+    assert np.abs(x_ref - xt_ref).max() > 1e-3 * np.abs(x_ref).max()          # genuinely non-symmetric
 
     def rank_fn(rank, ctx):
         mesh = partition_mesh(gmesh, rank, world, facets=True)
@@ -366,19 +368,25 @@ def test_bicgstab_on_emulated_ranks(world):
         U, F, UEX = E.Vec(ctx, nloc).set(ul), E.Vec(ctx, len(L.conn)).set(f[L.cell_global]), E.Vec(ctx, nloc).set(uex[L.vert_global])
         J = E.Mat(dm)
         E.assemble_jacobian(dm, 1, [0.0, -1.0], U, F, None, J, aux=UEX)
-        from femo_amd._lib import FemoError
         B, X, XT = E.Vec(ctx, L.n_owned).set(rhs[L.vert_global[:L.n_owned]]), E.Vec(ctx, nloc), E.Vec(ctx, nloc)
         i1 = J.solve_bicgstab(B, X, rtol=1e-13)
-        with pytest.raises(FemoError, match="owned by another rank"):
-            J.solve_bicgstab(B, XT, transpose=True, rtol=1e-13)
-        return dict(gid=L.vert_global[:L.n_owned], x=X.get(L.n_owned), conv=i1.converged)
+        i2 = J.solve_bicgstab(B, XT, transpose=True, rtol=1e-13)
+        # the transposed product itself: y = J^T v against the oracle
+        V, Y = E.Vec(ctx, nloc).set(np.concatenate([rhs[L.vert_global[:L.n_owned]], np.full(nloc - L.n_owned, 1e30)])), E.Vec(ctx, nloc)
+        J.mult(V, Y, transpose=True)
+        return dict(gid=L.vert_global[:L.n_owned], x=X.get(L.n_owned), xt=XT.get(L.n_owned), y=Y.get(L.n_owned),
+                    conv=(i1.converged, i2.converged))
 
     res = _run_ranks(world, rank_fn)
-    x = np.zeros(om.n_vert)
+    x, xt, y = np.zeros(om.n_vert), np.zeros(om.n_vert), np.zeros(om.n_vert)
     for r in res:
-        assert r["conv"] == 1
+        assert r["conv"] == (1, 1)
         x[r["gid"]] = r["x"]
+        xt[r["gid"]] = r["xt"]
+        y[r["gid"]] = r["y"]
     assert np.abs(x - x_ref).max() < 1e-9 * np.abs(x_ref).max()
+    assert np.abs(y - Jo.T @ rhs).max() < 1e-12 * np.abs(Jo.T @ rhs).max()
+    assert np.abs(xt - xt_ref).max() < 1e-9 * np.abs(xt_ref).max()
 
 
 def test_projection_on_two_emulated_ranks():

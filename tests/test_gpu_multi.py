@@ -1,0 +1,32 @@
+"""Two real ranks over RCCL (skipped on one-GPU boxes): `bench.py --gpus 2` under torchrun on a small cube --
+halo exchange on the comm stream overlapped with interior rows, the lattice and scalar all-reduces on the main
+stream, both over one ncclComm_t.  The emulated-rank tests cover the same library code with host-staged
+collectives; this is the only test that needs xGMI."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_bench_over_rccl():
+    from femo_amd import _lib
+    if _lib.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mesh-n", "40", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    c = r["config"]
+    assert r["n_gpus"] == 2 and c["n_dof"] == 41 ** 3 and sum(c["owned_per_rank"]) == 41 ** 3
+    assert c["linear_solves_per_step"] == 4 and c["neighbours_per_rank"] == [1, 1]
+    its = c["cg_iterations_per_step"]
+    assert 10 < its[0] <= 40 and its[1] <= 2 and its[2] <= 2 and 10 < its[3] <= 40
