@@ -20,6 +20,7 @@ from ..engine import Context, DeviceArray, Vec
 from .forms import (BeamResidual, DerivativeForm, FieldExpression, Form, FunctionExpr, GradientMagnitude,
                     L2TrackingFunctional, LinearFunctional, NonlinearPoissonResidual, PoissonResidual, PowerExpr, derivative)
 from .function import Function, FunctionSpace, _VectorView
+from .io import MeshTags, import_mesh, read_mesh, write_mesh_files
 from .mesh import (BeamMesh, Mesh, createIntervalMesh, createRectangleMesh, createUnitCubeMesh, createUnitSquareMesh,
                    findNodeIndices, meshSize,
                    locate_dofs_geometrical)

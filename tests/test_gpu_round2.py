@@ -199,3 +199,57 @@ def test_bpx_stopping_rule(ctx, d, n):
     # absolute threshold in the same norm: stops before the first iteration when the residual is already below it
     info = A.solve_cg(E.Vec(ctx, m.n_vert).set(b), X, rtol=1e-11, pc="bpx", atol_pc=1e30)
     assert info.iterations == 0 and info.converged == 1
+
+
+def test_imported_unstructured_mesh_cycle(ctx, tmp_path):
+    """A genuinely unstructured mesh entering through import_mesh (utils_dolfinx.py:69-123): L-shaped domain graded
+    towards the re-entrant corner, jittered, vertices and cells randomly numbered, Dirichlet data on the two tagged
+    boundary parts.  Assembly and the whole operator cycle against the oracle on the same arrays."""
+    from femo_amd import engine as E
+    from femo_amd.csdl_opt.fea_model import FEAModel
+    from femo_amd.csdl_opt.simulator import Simulator
+    from femo_amd.fea import utils_hip
+    from femo_amd.fea.fea_hip import FEA, Function, FunctionSpace, TestFunction, import_mesh, outputForm, pdeRes, write_mesh_files
+    from femo_amd.fea.mesh import Mesh
+    from tests.meshes import l_shape_mesh
+    utils_hip.set_context(ctx)
+    x, conn, edges, tags = l_shape_mesh(24)
+    write_mesh_files("lshape", Mesh(x, conn), edges, tags, {"outer": 1, "reentrant": 2}, directory=str(tmp_path))
+    mesh, bmf, table = import_mesh(prefix="lshape", dim=2, directory=str(tmp_path))
+    om = fo.OMesh(2, mesh.x, mesh.conn, 0)
+    dm = mesh.device(ctx)
+    assert dm.info["regular_slices"] == 0 and dm.info["max_rowlen"] >= 7
+    bd = np.union1d(bmf.vertices(table["outer"]), bmf.vertices(table["reentrant"]))
+    # kernels
+    rng = np.random.default_rng(2)
+    u, f = rng.standard_normal(mesh.n_vert), rng.standard_normal(mesh.n_cell)
+    K = E.Mat(dm)
+    E.assemble_jacobian(dm, 0, None, None, None, None, K)
+    Kr = fo.stiffness(om)
+    Kg = K.to_scipy()
+    assert np.array_equal(Kg.indices, Kr.indices) and _rel(Kg.data, Kr.data) < 1e-12 and abs(Kg - Kg.T).max() == 0.0
+    R = E.Vec(ctx, mesh.n_vert)
+    E.assemble_residual(dm, 0, None, E.Vec(ctx, mesh.n_vert).set(u), E.Vec(ctx, mesh.n_cell).set(f), R)
+    assert _rel(R.get(), fo.residual(om, u, f)) < 1e-12
+    # operator cycle: f -> u -> J -> dJ/df with Dirichlet values 0 on both tagged parts
+    fea = FEA(mesh)
+    fea.REPORT = False
+    Vf, Vu = FunctionSpace(mesh, ('DG', 0)), FunctionSpace(mesh, ('CG', 1))
+    f_fn, u_fn, ubc, ud = Function(Vf), Function(Vu), Function(Vu), Function(Vu)
+    ud_vals = np.sin(np.pi * mesh.x[:, 0]) * np.sin(np.pi * mesh.x[:, 1]) * 0.05
+    ud.vector[:] = ud_vals
+    ubc.vector.set(0.0)
+    fea.add_strong_bc(ubc, [bmf.vertices(table["outer"]), bmf.vertices(table["reentrant"])], Vu)
+    fea.add_input('f', f_fn)
+    fea.add_state(name='u', function=u_fn, residual_form=pdeRes(u_fn, TestFunction(Vu), f_fn), arguments=['f'])
+    fea.add_output(name='l2_functional', type='scalar', form=outputForm(u_fn, f_fn, ud, 1e-6), arguments=['f', 'u'])
+    model = FEAModel(fea=[fea])
+    model.create_input('f', shape=mesh.n_cell, val=1.0)
+    sim = Simulator(model, device=False)
+    fsrc = 1.0 + 0.5 * np.cos(3 * mesh.centroids()[:, 0])
+    sim['f'] = fsrc
+    sim.run()
+    g = np.asarray(sim.compute_totals('l2_functional', 'f'))
+    ref = fo.reference_cycle(om, fsrc, ud_vals, bd, np.zeros(len(bd)))
+    assert _rel(sim['u'], ref['u']) < 1e-10 and _rel(g, ref['grad']) < 1e-10
+    assert abs(sim['l2_functional'][0] - ref['J'][0]) < 1e-10 * abs(ref['J'][0])
