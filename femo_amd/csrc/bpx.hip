@@ -50,6 +50,11 @@ struct femo_pc {
   std::vector<LatticeLevel> L;
   uint64_t built_key = 0;   // identity of the Dirichlet mask the coef arrays were built for
   double* g_all = nullptr;  // the g arrays of all levels, coarsest first, contiguous
+  // The levels the brick kernel accumulates into (the finest n_fused + 1) exist twice; applies alternate between
+  // the two copies.  The fused prolongation reads the second-finest level from several workgroups, so it cannot
+  // clear it in place: it clears the OTHER copy, which the next restriction will accumulate into.
+  double* g_alt = nullptr;
+  int parity = 0;
   int n_fused = 0;          // coarser levels the brick kernel restricts to directly (besides the finest)
   bool coarse_lds_set = false;
   // owned vertices sorted by brick (BRICK^dim bins of the finest lattice), for the restriction
@@ -473,7 +478,8 @@ struct CoarseLevels {
   const double* coef[FEMO_PC_MAX_LEVELS];
   int64_t nodes[FEMO_PC_MAX_LEVELS];
   int64_t off[FEMO_PC_MAX_LEVELS];     // LDS offset (doubles) of level l: g at off, e at off + nodes
-};
+  int emit_top;                        // also e_top = coef_top g_top + I e_{top-1} (global), g_top cleared: the level the
+};                                     // brick kernel filled, so that no multi-block restriction / prolongation touches it
 
 __global__ __launch_bounds__(1024) void k_lattice_coarse(CoarseLevels L, int dim, const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
@@ -497,9 +503,130 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse(CoarseLevels L, int dim
       double v = L.coef[l][idx] * gl[idx];
       if (l > 0) v += lattice_interp_node(idx, L.n[l], L.n[l - 1], dim, ec);
       el[idx] = v;
-      if (l == top - 1) L.e[l][idx] = v;
+      if (l == top - 1 && !L.emit_top) L.e[l][idx] = v;
     }
     __syncthreads();
+  }
+  if (L.emit_top) {
+    const int64_t total = (int64_t)(L.n[top][0] + 1) * (L.n[top][1] + 1) * (L.n[top][2] + 1);
+    const double* ec = coarse_lds + L.off[top - 1] + L.nodes[top - 1];
+    for (int64_t idx = threadIdx.x; idx < total; idx += 1024) {
+      const double gi = L.g[top][idx];
+      L.g[top][idx] = 0.0;                          // every restriction read of it happened before the barriers above
+      L.e[top][idx] = L.coef[top][idx] * gi + lattice_interp_node(idx, L.n[top], L.n[top - 1], dim, ec);
+    }
+  }
+}
+
+// The three finest levels in one launch: a workgroup takes a tile of the finest lattice (8^3 or 16^2 nodes) and
+// builds in LDS the corrections of the two coarser levels on the tile's ancestors -- 3^3 / 5^2 nodes of level
+// L-2, then 5^3 / 9^2 nodes of level L-1 (recomputed by neighbouring tiles: 2.4x resp. 3.4x those levels' work,
+// which is 1/8 resp. 1/64 of the finest level's) -- and prolongs from there:
+//   e_c = coef_c g_c + I e_cc (global)     e_m = coef_m g_m + I e_c     e_f = coef_f g_f + I e_m     dot += g_f e_f (w)
+// g_f is cleared in place (one tile owns a node); g_m and g_c are read by several workgroups, so their OTHER
+// copies are cleared (see femo_pc::g_alt): the restriction after the next accumulates into those.
+struct FineLevels {
+  int ncc[3], nc[3], nm[3], nf[3];
+  const double *e_cc, *coef_c, *g_c, *coef_m, *g_m, *coef_f, *dot_weight;
+  double *g_c_other, *g_m_other, *g_f, *e_f, *dot_partials;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void k_lattice_prolong3(FineLevels P, const int32_t* __restrict__ done) {
+  if (done != nullptr && *done) return;
+  constexpr int TF = D == 3 ? 8 : 16, TM = TF / 2 + 1, TC = TF / 4 + 1;
+  constexpr int NC = D == 3 ? TC * TC * TC : TC * TC, NM = D == 3 ? TM * TM * TM : TM * TM, NT = D == 3 ? TF * TF * TF : TF * TF;
+  __shared__ double ec[NC];
+  __shared__ double em[NM];
+  __shared__ double red[256 / 64];
+  int tn[3] = {1, 1, 1};
+#pragma unroll
+  for (int k = 0; k < D; ++k) tn[k] = (P.nf[k] + TF) / TF;             // nodes 0 .. nf[k]
+  const int64_t n_tiles = (int64_t)tn[0] * tn[1] * tn[2];
+  // value of the patch `src` (side TS, origin slo) interpolated to node fi of the next finer level
+  auto from_patch = [](const double* src, int TS, const int (&fi)[3], const int (&slo)[3]) -> double {
+    int a[3], b[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { a[k] = (fi[k] >> 1) - slo[k]; b[k] = ((fi[k] + 1) >> 1) - slo[k]; }
+    if constexpr (D == 3) {
+      return 0.125 * (src[(a[2] * TS + a[1]) * TS + a[0]] + src[(a[2] * TS + a[1]) * TS + b[0]] + src[(a[2] * TS + b[1]) * TS + a[0]] +
+                      src[(a[2] * TS + b[1]) * TS + b[0]] + src[(b[2] * TS + a[1]) * TS + a[0]] + src[(b[2] * TS + a[1]) * TS + b[0]] +
+                      src[(b[2] * TS + b[1]) * TS + a[0]] + src[(b[2] * TS + b[1]) * TS + b[0]]);
+    } else {
+      return 0.25 * (src[a[1] * TS + a[0]] + src[a[1] * TS + b[0]] + src[b[1] * TS + a[0]] + src[b[1] * TS + b[0]]);
+    }
+  };
+  double dot = 0.0;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    int lo[3] = {0, 0, 0}, mlo[3] = {0, 0, 0}, clo[3] = {0, 0, 0};
+    {
+      int64_t t = tile;
+#pragma unroll
+      for (int k = 0; k < D; ++k) { lo[k] = (int)(t % tn[k]) * TF; t /= tn[k]; mlo[k] = lo[k] >> 1; clo[k] = lo[k] >> 2; }
+    }
+    for (int p = threadIdx.x; p < NC; p += 256) {
+      int ci[3] = {0, 0, 0};
+      int q = p;
+      bool inside = true, owned = true;
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const int pk = q % TC; q /= TC;
+        ci[k] = clo[k] + pk;
+        inside = inside && ci[k] <= P.nc[k];
+        owned = owned && pk < TF / 4;                                   // fine node 4 ci lies in this tile
+      }
+      double v = 0.0;
+      if (inside) {
+        const int64_t idx = node_index(P.nc, ci[0], ci[1], ci[2]);
+        v = P.coef_c[idx] * P.g_c[idx] + lattice_interp_node(idx, P.nc, P.ncc, D, P.e_cc);
+        if (owned) P.g_c_other[idx] = 0.0;
+      }
+      ec[p] = v;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < NM; p += 256) {
+      int mi[3] = {0, 0, 0};
+      int q = p;
+      bool inside = true, owned = true;
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const int pk = q % TM; q /= TM;
+        mi[k] = mlo[k] + pk;
+        inside = inside && mi[k] <= P.nm[k];
+        owned = owned && pk < TF / 2;                                   // fine node 2 mi lies in this tile
+      }
+      double v = 0.0;
+      if (inside) {
+        const int64_t idx = node_index(P.nm, mi[0], mi[1], mi[2]);
+        v = P.coef_m[idx] * P.g_m[idx] + from_patch(ec, TC, mi, clo);
+        if (owned) P.g_m_other[idx] = 0.0;
+      }
+      em[p] = v;
+    }
+    __syncthreads();
+    for (int q0 = threadIdx.x; q0 < NT; q0 += 256) {
+      int fi[3] = {0, 0, 0};
+      int q = q0;
+      bool inside = true;
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const int qk = q % TF; q /= TF;
+        fi[k] = lo[k] + qk;
+        inside = inside && fi[k] <= P.nf[k];
+      }
+      if (!inside) continue;
+      const int64_t idx = node_index(P.nf, fi[0], fi[1], fi[2]);
+      const double gi = P.g_f[idx];
+      P.g_f[idx] = 0.0;
+      const double v = P.coef_f[idx] * gi + from_patch(em, TM, fi, mlo);
+      P.e_f[idx] = v;
+      dot += P.dot_weight != nullptr ? gi * v * P.dot_weight[idx] : gi * v;
+    }
+    __syncthreads();
+  }
+  if (P.dot_partials != nullptr) {
+    const double t = femo_block_sum<256>(dot, red);
+    if (threadIdx.x == 0) P.dot_partials[blockIdx.x] = t;
   }
 }
 
@@ -571,8 +698,12 @@ int femo_pc_build(femo_mesh* m) {
     FEMO_HIP_CHECK(hipMalloc(&L.e, L.nodes * sizeof(double)));
     FEMO_HIP_CHECK(hipMalloc(&L.coef, L.nodes * sizeof(double)));
   }
-  FEMO_HIP_CHECK(hipMalloc(&pc->g_all, total * sizeof(double)));
-  FEMO_HIP_CHECK(hipMemset(pc->g_all, 0, total * sizeof(double)));
+  // every level once, then a second copy of the levels the brick kernel accumulates into (sized for the largest
+  // n_fused: the three / four finest levels), see femo_pc::g_alt
+  int64_t alt = 0;
+  for (int l = std::max(0, P.n_levels - 1 - (D == 3 ? 2 : 3)); l < P.n_levels; ++l) alt += pc->L[l].nodes;
+  FEMO_HIP_CHECK(hipMalloc(&pc->g_all, (total + alt) * sizeof(double)));
+  FEMO_HIP_CHECK(hipMemset(pc->g_all, 0, (total + alt) * sizeof(double)));
   {
     int64_t off = 0;
     for (auto& L : pc->L) { L.g = pc->g_all + off; off += L.nodes; }
@@ -581,8 +712,12 @@ int femo_pc_build(femo_mesh* m) {
   // (2-D) levels and running the lattice restrictions separately measure the same (72-75 ms per bench
   // cycle either way).  On partitioned meshes the bricks produce the finest level (exchanged sparsely,
   // pc_setup_shared) and the next one (summed densely); FEMO_BPX_FUSED overrides on one rank (tests, tuning).
-  pc->n_fused = ctx->nranks > 1 ? std::min(1, pc->n_levels - 1) : std::min(D == 3 ? 2 : 3, pc->n_levels - 1);
+  pc->n_fused = ctx->nranks > 1 ? std::min(2, pc->n_levels - 1) : std::min(D == 3 ? 2 : 3, pc->n_levels - 1);
   if (const char* e = getenv("FEMO_BPX_FUSED"); e != nullptr && ctx->nranks == 1) pc->n_fused = std::max(0, std::min(std::min(D == 3 ? 2 : 3, pc->n_levels - 1), atoi(e)));
+  {
+    // second copy of the fused levels: the same layout as the first, right behind all levels
+    pc->g_alt = pc->g_all + total;
+  }
   pc->n_bricks = P.n_bricks;
   auto upload = [&](auto** dst, const auto& src) -> int {
     using T = typename std::remove_reference<decltype(src)>::type::value_type;
@@ -690,7 +825,7 @@ static int pc_setup_shared(femo_mesh* m) {
     if (mine[(size_t)i] != 0.0) weight[(size_t)i] = 1.0 / cnt[(size_t)i];
   }
   pc->n_shared = (int64_t)shared.size();
-  const int64_t n_coarse = nl >= 2 ? pc->L[nl - 2].nodes : 0;
+  const int64_t n_coarse = F.g - pc->L[nl - 1 - pc->n_fused].g;      // the coarser fused levels travel whole
   FEMO_HIP_CHECK(hipMalloc(&pc->d_shared_idx, std::max<size_t>(shared.size(), 1) * sizeof(int32_t)));
   FEMO_HIP_CHECK(hipMalloc(&pc->d_dot_weight, F.nodes * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&pc->d_xbuf, (pc->n_shared + n_coarse + 1) * sizeof(double)));
@@ -754,75 +889,134 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
   hipStream_t st = ctx->stream;
   FEMO_TRY(pc_prepare(m, mask, mask_key));
   const int nl = pc->n_levels, nf = pc->n_fused;
+  const int T = nl - 1 - nf;                                   // coarsest level the brick kernel fills
   LatticeLevel& F = pc->L[nl - 1];
   const Lat lat = make_lat(pc, F);
-  // g of the finest nf+1 levels: zero on entry (femo_pc_begin, then k_lattice_prolong cleans up)
+  // accumulators of this apply / of the next one (levels >= T exist twice, see femo_pc::g_alt)
+  const int par = pc->parity;
+  auto G = [&](int l, int which) -> double* {
+    if (l < T || which == 0) return pc->L[l].g;
+    return pc->g_alt + (pc->L[l].g - pc->L[T].g);
+  };
+  double* gF = G(nl - 1, par);
+  // g of the finest nf+1 levels: zero on entry (femo_pc_begin, then the prolongation kernels clean up)
   if (pc->n_bricks > 0) {
     const unsigned gb = (unsigned)std::min<int64_t>(pc->n_bricks, 256 * 64);
     if (pc->dim == 3)
-      hipLaunchKernelGGL(k_restrict_bricks<3>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, rh, pc->d_w_sorted, F.g, nf, done);
+      hipLaunchKernelGGL(k_restrict_bricks<3>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, rh, pc->d_w_sorted, gF, nf, done);
     else
-      hipLaunchKernelGGL(k_restrict_bricks<2>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, rh, pc->d_w_sorted, F.g, nf, done);
+      hipLaunchKernelGGL(k_restrict_bricks<2>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, rh, pc->d_w_sorted, gF, nf, done);
   }
   const bool sparse = ctx->nranks > 1 && pc->shared_ready;
   if (sparse) {
-    // one all-reduce per apply: the finest-level nodes several ranks touch + the whole next level
-    double* gc = nf >= 1 ? pc->L[nl - 2].g : nullptr;
-    const int64_t n_coarse = nf >= 1 ? pc->L[nl - 2].nodes : 0;
+    // one all-reduce per apply: the finest-level nodes several ranks touch + the whole coarser fused levels
+    double* gc = nf >= 1 ? G(T, par) : nullptr;
+    const int64_t n_coarse = nf >= 1 ? gF - gc : 0;
     const int64_t count = pc->n_shared + n_coarse;
     // rho_is_partial: *rho holds this rank's part of rh.rh; it rides in the same all-reduce
     double* piggy = rho_is_partial ? rho : nullptr;
     if (count > 0 || piggy != nullptr) {
-      hipLaunchKernelGGL(k_pack_shared, dim3(lat_grid(std::max<int64_t>(count, 1))), dim3(256), 0, st, pc->n_shared, pc->d_shared_idx, F.g, n_coarse, gc, piggy, pc->d_xbuf, done);
+      hipLaunchKernelGGL(k_pack_shared, dim3(lat_grid(std::max<int64_t>(count, 1))), dim3(256), 0, st, pc->n_shared, pc->d_shared_idx, gF, n_coarse, gc, piggy, pc->d_xbuf, done);
       FEMO_TRY(femo_coll_allreduce(ctx, pc->d_xbuf, count + (piggy ? 1 : 0), st));
-      hipLaunchKernelGGL(k_unpack_shared, dim3(lat_grid(std::max<int64_t>(count, 1))), dim3(256), 0, st, pc->n_shared, pc->d_shared_idx, F.g, n_coarse, gc, piggy, pc->d_xbuf, done);
+      hipLaunchKernelGGL(k_unpack_shared, dim3(lat_grid(std::max<int64_t>(count, 1))), dim3(256), 0, st, pc->n_shared, pc->d_shared_idx, gF, n_coarse, gc, piggy, pc->d_xbuf, done);
     }
   } else if (rho_is_partial) {
     FEMO_REQUIRE(false, "femo_pc_apply: a partial rho needs the sparse exchange (femo_pc_can_piggyback)");
   } else if (ctx->nranks > 1) {   // dense: the contiguous accumulators of the finest nf+1 levels
-    double* first = pc->L[nl - 1 - nf].g;
-    const int64_t count = (F.g + F.nodes) - first;
+    double* first = G(T, par);
+    const int64_t count = (gF + F.nodes) - first;
     FEMO_TRY(femo_coll_allreduce(ctx, first, count, st));
   }
-  // levels with at most COARSE_NODES nodes (and below the brick-fused ones) go through the
-  // single-workgroup kernel; `cut` = first level handled by multi-block launches
-  // levels 0 .. cut-1 go through the single-workgroup kernel, which reads g of level `cut` from
-  // global memory: one CU gathers 27 values per coarse node, so that level must stay small (with
-  // 15.6 k nodes the phase alone took 25 us at C4)
-  constexpr int64_t COARSE_TOP_NODES = 4096;
-  int cut = 0;
-  int64_t coarse_total = 0;
-  while (cut < nl - 1 - nf && cut < FEMO_PC_MAX_LEVELS - 1 && pc->L[cut + 1].nodes <= COARSE_TOP_NODES) coarse_total += pc->L[cut++].nodes;
-  for (int l = nl - 2 - nf; l >= cut; --l) {
-    LatticeLevel& C = pc->L[l];
-    const LatticeLevel& Fi = pc->L[l + 1];
-    hipLaunchKernelGGL(k_lattice_restrict, dim3(lat_grid(C.nodes)), dim3(256), 0, st, C.n[0], C.n[1], C.n[2], Fi.n[0], Fi.n[1], Fi.n[2], pc->dim, Fi.g, C.g, done);
-  }
-  if (cut > 0) {
+  const double* dotw = sparse ? pc->d_dot_weight : nullptr;
+  int nb_dot = (int)lat_grid(F.nodes);
+  // Fused lattice cycle, 3 launches instead of 6 (3-D): the restriction from the coarsest level the bricks filled
+  // (multi-block: a single workgroup gathering 27 values per node of a 15 k-node level took 20 us), one workgroup
+  // for everything below it, and one launch for the three finest levels.
+  int64_t below = 0;
+  for (int l = 0; l + 1 < T; ++l) below += pc->L[l].nodes;
+  const bool fused_cycle = nf >= 2 && T >= 2 && T < FEMO_PC_MAX_LEVELS - 1 && below * 2 * (int64_t)sizeof(double) <= 144 * 1024 &&
+                           pc->L[T - 1].nodes <= 4096 && getenv("FEMO_BPX_UNFUSED_LATTICE") == nullptr;
+  if (fused_cycle) {
+    {
+      LatticeLevel& C = pc->L[T - 1];
+      const LatticeLevel& Fi = pc->L[T];
+      hipLaunchKernelGGL(k_lattice_restrict, dim3(lat_grid(C.nodes)), dim3(256), 0, st, C.n[0], C.n[1], C.n[2], Fi.n[0], Fi.n[1], Fi.n[2], pc->dim, G(T, par), C.g, done);
+    }
     CoarseLevels CL;
-    CL.n_levels = cut;
-    for (int l = 0; l <= cut; ++l) {
+    CL.n_levels = T - 1;                                           // levels 0 .. T-2 in LDS, e_{T-1} emitted
+    CL.emit_top = 1;
+    for (int l = 0; l <= T - 1; ++l) {
       for (int k = 0; k < 3; ++k) CL.n[l][k] = pc->L[l].n[k];
       CL.g[l] = pc->L[l].g; CL.e[l] = pc->L[l].e; CL.coef[l] = pc->L[l].coef;
       CL.nodes[l] = pc->L[l].nodes;
       CL.off[l] = l == 0 ? 0 : CL.off[l - 1] + 2 * CL.nodes[l - 1];
     }
-    const size_t lds = (size_t)coarse_total * 2 * sizeof(double);
+    const size_t lds = (size_t)below * 2 * sizeof(double);
     if (lds > 64 * 1024 && !pc->coarse_lds_set) {
       FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_coarse, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       pc->coarse_lds_set = true;
     }
     hipLaunchKernelGGL(k_lattice_coarse, dim3(1), dim3(1024), lds, st, CL, pc->dim, done);
+    for (int l = T; l <= nl - 4; ++l) {                         // 2-D only (three fused levels): the level in between
+      LatticeLevel& Fi = pc->L[l];
+      hipLaunchKernelGGL(k_lattice_prolong, dim3(lat_grid(Fi.nodes)), dim3(256), 0, st, Fi.n[0], Fi.n[1], Fi.n[2], pc->L[l - 1].n[0], pc->L[l - 1].n[1], pc->L[l - 1].n[2], pc->dim, pc->L[l - 1].e, Fi.coef, G(l, par), 1, Fi.e, (double*)nullptr, (const double*)nullptr, done);
+    }
+    FineLevels FL;
+    const LatticeLevel &Lcc = pc->L[nl - 4], &Lc = pc->L[nl - 3], &Lm = pc->L[nl - 2];
+    for (int k = 0; k < 3; ++k) { FL.ncc[k] = Lcc.n[k]; FL.nc[k] = Lc.n[k]; FL.nm[k] = Lm.n[k]; FL.nf[k] = F.n[k]; }
+    FL.e_cc = Lcc.e;
+    FL.coef_c = Lc.coef; FL.g_c = G(nl - 3, par); FL.g_c_other = G(nl - 3, par ^ 1);
+    FL.coef_m = Lm.coef; FL.g_m = G(nl - 2, par); FL.g_m_other = G(nl - 2, par ^ 1);
+    FL.coef_f = F.coef; FL.g_f = gF; FL.e_f = F.e;
+    FL.dot_partials = mode != 0 ? pc->d_dot_partials : nullptr;
+    FL.dot_weight = dotw;
+    const int TF = pc->dim == 3 ? 8 : 16;
+    int64_t tiles = 1;
+    for (int k = 0; k < pc->dim; ++k) tiles *= (F.n[k] + TF) / TF;
+    nb_dot = (int)std::min<int64_t>(tiles, 2048);
+    if (pc->dim == 3) hipLaunchKernelGGL(k_lattice_prolong3<3>, dim3(nb_dot), dim3(256), 0, st, FL, done);
+    else hipLaunchKernelGGL(k_lattice_prolong3<2>, dim3(nb_dot), dim3(256), 0, st, FL, done);
+    pc->parity ^= 1;
+  } else {
+    // levels with at most COARSE_NODES nodes (and below the brick-fused ones) go through the
+    // single-workgroup kernel; `cut` = first level handled by multi-block launches
+    // levels 0 .. cut-1 go through the single-workgroup kernel, which reads g of level `cut` from
+    // global memory: one CU gathers 27 values per coarse node, so that level must stay small (with
+    // 15.6 k nodes the phase alone took 25 us at C4)
+    constexpr int64_t COARSE_TOP_NODES = 4096;
+    int cut = 0;
+    int64_t coarse_total = 0;
+    while (cut < nl - 1 - nf && cut < FEMO_PC_MAX_LEVELS - 1 && pc->L[cut + 1].nodes <= COARSE_TOP_NODES) coarse_total += pc->L[cut++].nodes;
+    for (int l = nl - 2 - nf; l >= cut; --l) {
+      LatticeLevel& C = pc->L[l];
+      const LatticeLevel& Fi = pc->L[l + 1];
+      hipLaunchKernelGGL(k_lattice_restrict, dim3(lat_grid(C.nodes)), dim3(256), 0, st, C.n[0], C.n[1], C.n[2], Fi.n[0], Fi.n[1], Fi.n[2], pc->dim, G(l + 1, par), C.g, done);
+    }
+    if (cut > 0) {
+      CoarseLevels CL;
+      CL.n_levels = cut;
+      CL.emit_top = 0;
+      for (int l = 0; l <= cut; ++l) {
+        for (int k = 0; k < 3; ++k) CL.n[l][k] = pc->L[l].n[k];
+        CL.g[l] = G(l, par); CL.e[l] = pc->L[l].e; CL.coef[l] = pc->L[l].coef;
+        CL.nodes[l] = pc->L[l].nodes;
+        CL.off[l] = l == 0 ? 0 : CL.off[l - 1] + 2 * CL.nodes[l - 1];
+      }
+      const size_t lds = (size_t)coarse_total * 2 * sizeof(double);
+      if (lds > 64 * 1024 && !pc->coarse_lds_set) {
+        FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_coarse, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        pc->coarse_lds_set = true;
+      }
+      hipLaunchKernelGGL(k_lattice_coarse, dim3(1), dim3(1024), lds, st, CL, pc->dim, done);
+    }
+    for (int l = cut; l < nl; ++l) {
+      LatticeLevel& Fi = pc->L[l];
+      const double* ec = l > 0 ? pc->L[l - 1].e : nullptr;
+      const int* nc = l > 0 ? pc->L[l - 1].n : Fi.n;
+      double* dots = (l == nl - 1 && mode != 0) ? pc->d_dot_partials : nullptr;
+      hipLaunchKernelGGL(k_lattice_prolong, dim3(lat_grid(Fi.nodes)), dim3(256), 0, st, Fi.n[0], Fi.n[1], Fi.n[2], nc[0], nc[1], nc[2], pc->dim, ec, Fi.coef, G(l, par), l >= T ? 1 : 0, Fi.e, dots, l == nl - 1 ? dotw : (const double*)nullptr, done);
+    }
   }
-  for (int l = cut; l < nl; ++l) {
-    LatticeLevel& Fi = pc->L[l];
-    const double* ec = l > 0 ? pc->L[l - 1].e : nullptr;
-    const int* nc = l > 0 ? pc->L[l - 1].n : Fi.n;
-    double* dots = (l == nl - 1 && mode != 0) ? pc->d_dot_partials : nullptr;
-    const double* dotw = (l == nl - 1 && sparse) ? pc->d_dot_weight : nullptr;
-    hipLaunchKernelGGL(k_lattice_prolong, dim3(lat_grid(Fi.nodes)), dim3(256), 0, st, Fi.n[0], Fi.n[1], Fi.n[2], nc[0], nc[1], nc[2], pc->dim, ec, Fi.coef, Fi.g, l >= nl - 1 - nf ? 1 : 0, Fi.e, dots, dotw, done);
-  }
-  int nb_dot = (int)lat_grid(F.nodes);
   const double* dot_global = nullptr;
   if (sparse && mode != 0) {
     // each rank only holds the finest level on the nodes it touches: its weighted dot is a partial sum
@@ -857,6 +1051,8 @@ int femo_pc_begin(femo_mesh* m, const double* s, const uint8_t* mask) {
   double* first = pc->L[nl - 1 - pc->n_fused].g;
   const int64_t count = (pc->L[nl - 1].g + pc->L[nl - 1].nodes) - first;
   FEMO_HIP_CHECK(hipMemsetAsync(first, 0, count * sizeof(double), m->ctx->stream));
+  FEMO_HIP_CHECK(hipMemsetAsync(pc->g_alt, 0, count * sizeof(double), m->ctx->stream));
+  pc->parity = 0;
   return 0;
 }
 

@@ -13,13 +13,20 @@ from femo_amd.fea.mesh import createUnitCubeMesh
 n3 = int(sys.argv[1]) if len(sys.argv) > 1 else 215
 ctx = Context(0)
 mesh = createUnitCubeMesh(n3)
+if len(sys.argv) > 2 and sys.argv[2] == "permute":
+    mesh = mesh.permuted(seed=20240807)          # bench.py --permute
 dm = mesh.device(ctx)
 n = mesh.n_vert
 dofs = np.nonzero(np.any(np.isclose(mesh.x, 0.0) | np.isclose(mesh.x, 1.0), axis=1))[0]
 bc = E.DirichletSet(dm, dofs, np.zeros(len(dofs)))
 A, b = E.Mat(dm), Vec(ctx, n)
 f = Vec(ctx, mesh.n_cell).set(1.0 + np.random.default_rng(0).random(mesh.n_cell))
-E.assemble_system(dm, 0, None, Vec(ctx, n).fill(0.0), f, bc, None, A, b)
+u0 = Vec(ctx, n).fill(0.0)
+J, r, g = E.Mat(dm), Vec(ctx, n), Vec(ctx, n)
+E.assemble_system(dm, 0, None, u0, f, bc, None, A, b)          # A + Newton rhs (also builds the load vector of f)
+E.assemble_system(dm, 0, None, u0, f, bc, J, A, None)          # dR/du + A
+E.assemble_residual(dm, 0, None, u0, f, r)
+E.functional_grad_u(dm, 0, [1e-6], u0, f, Vec(ctx, n).fill(1.0), g)
 x = Vec(ctx, n)
 info = A.solve_cg(b, x, rtol=1e-14, max_it=3, pc="bpx", check_every=3)
 ctx.sync()
