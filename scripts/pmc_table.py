@@ -20,5 +20,5 @@ for d in dirs:
 with open(out, "w") as fh:
     fh.write("kernel,counter,mean_per_dispatch,dispatches\n")
     for (k, c), (s, n) in sorted(acc.items()):
-        fh.write(f"{k},{c},{s / n:.6g},{n}\n")
+        fh.write(f'"{k}",{c},{s / n:.6g},{n}\n')
 print(open(out).read())
