@@ -53,6 +53,8 @@ def parse():
     p.add_argument("--permute", action="store_true",
                    help="random vertex numbering: no regular SELL slices, scattered gathers (the unstructured-mesh rate)")
     p.add_argument("--no-pcie", action="store_true")
+    p.add_argument("--reorder", action="store_true",
+                   help="renumber the mesh along a Morton curve first (what import_mesh does to a mesh it reads)")
     p.add_argument("--pc", choices=("bpx", "jacobi"), default="bpx",
                    help="CG preconditioner: bpx = Jacobi + auxiliary-lattice multilevel correction (default)")
     return p.parse_args()
@@ -250,6 +252,8 @@ def _run(args):
     mesh = createUnitCubeMesh(args.n, jitter=args.jitter)
     if args.permute:
         mesh = mesh.permuted(seed=20240807)
+    if args.reorder:
+        mesh = mesh.reordered()
     sim, fea = build_problem(mesh, device=False)
     dm = mesh.device(ctx)
     n_dof, nnz = mesh.n_vert, dm.info["nnz"]
@@ -309,7 +313,7 @@ def _run(args):
         prof = os.path.join(ROOT, "profiles", name)
         if os.path.exists(prof):
             try:
-                traffic = json.load(open(prof)).get(f"spmv_n{args.n}" + ("_permuted" if args.permute else ""))
+                traffic = json.load(open(prof)).get(f"spmv_n{args.n}" + ("_permuted" if args.permute and not args.reorder else "")) if not (args.reorder and not args.permute) else None
             except Exception:
                 traffic = None
             if traffic is not None:
@@ -340,7 +344,7 @@ def _run(args):
                          f"dR/du, dR/df, A + transposed {PC.upper()}-CG + dR/df^T lambda; CG rtol 1e-14; cold start"),
             "boundary": "host (NumPy in pinned blocks of femo_host_alloc; H2D + D2H inside the timed region)",
             "preconditioner": PC, "pc_lattice": dm.pc_info(),
-            "n": args.n, "jitter": args.jitter, "permuted": bool(args.permute),
+            "n": args.n, "jitter": args.jitter, "permuted": bool(args.permute), "reordered": bool(args.reorder),
             "n_dof": n_dof, "n_cell": mesh.n_cell, "nnz": nnz,
             "sell_slices": dm.info["n_slices"], "regular_slices": dm.info["regular_slices"],
             "linear_solves_per_step": per, "cg_iterations_per_step": its_per_step, "cg_ms_per_step": cg_ms,

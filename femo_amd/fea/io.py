@@ -195,9 +195,11 @@ def write_mesh_files(prefix: str, mesh, facets: np.ndarray, facet_tags: np.ndarr
         fh.write("[ASSOCIATION TABLE]\n" + "".join(f"{k} = {int(v)}\n" for k, v in association_table.items()))
 
 
-def import_mesh(prefix="mesh", subdomains=False, dim=2, directory="."):
+def import_mesh(prefix="mesh", subdomains=False, dim=2, directory=".", reorder=True):
     """utils_dolfinx.py:69-123 -- same arguments, same return tuple:
-    (mesh, boundaries_mf, association_table) or (mesh, boundaries_mf, subdomains_mf, association_table)."""
+    (mesh, boundaries_mf, association_table) or (mesh, boundaries_mf, subdomains_mf, association_table).
+    Like dolfinx's reader the mesh comes back renumbered for locality (``reorder``; Mesh.reordered()): the tags
+    refer to the new numbering, ``mesh.original_vertex_index`` / ``mesh.original_cell_index`` to the file's."""
     from configparser import ConfigParser
     mesh, attrs = read_mesh(os.path.join(directory, f"{prefix}_domain.xdmf"))
     if mesh.tdim != dim:
@@ -207,13 +209,19 @@ def import_mesh(prefix="mesh", subdomains=False, dim=2, directory="."):
         raise ValueError(f"{prefix}_boundaries.xdmf: {fkind} entities are not the facets of a {dim}-D mesh")
     if "Grid" not in fattrs:
         raise ValueError(f"{prefix}_boundaries.xdmf: no 'Grid' tags")
+    cell_tags = attrs["Grid"][1] if "Grid" in attrs else None
+    if reorder:
+        mesh = mesh.reordered()
+        fcells = mesh.vertex_perm[fcells]
+        if cell_tags is not None:
+            cell_tags = cell_tags[mesh.original_cell_index]
     boundaries_mf = MeshTags(dim - 1, fcells, fattrs["Grid"][1])
     file_content = ConfigParser()
     file_content.read(os.path.join(directory, f"{prefix}_association_table.ini"))
     association_table = {k: int(v) for k, v in dict(file_content["ASSOCIATION TABLE"]).items()}
     if not subdomains:
         return mesh, boundaries_mf, association_table
-    if "Grid" not in attrs:
+    if cell_tags is None:
         raise ValueError(f"{prefix}_domain.xdmf: no 'Grid' subdomain tags")
-    subdomains_mf = MeshTags(dim, mesh.conn, attrs["Grid"][1])
+    subdomains_mf = MeshTags(dim, mesh.conn, cell_tags)
     return mesh, boundaries_mf, subdomains_mf, association_table

@@ -16,13 +16,21 @@ def test_import_mesh_round_trip(tmp_path, binary):
     cell_tags = (mesh.centroids()[:, 0] > 0).astype(np.int32) + 1
     table = {"outer": 1, "reentrant": 2, "left": 1, "right": 2}
     write_mesh_files("lshape", mesh, edges, tags, table, cell_tags=cell_tags, directory=str(tmp_path), binary=binary)
-    m2, bmf, smf, table2 = import_mesh(prefix="lshape", subdomains=True, dim=2, directory=str(tmp_path))
+    m2, bmf, smf, table2 = import_mesh(prefix="lshape", subdomains=True, dim=2, directory=str(tmp_path), reorder=False)
     assert np.array_equal(m2.x, x) and np.array_equal(m2.conn, conn)           # bit for bit, repr() / raw binary
     assert np.array_equal(bmf.entities, edges) and np.array_equal(bmf.values, tags) and bmf.dim == 1
     assert np.array_equal(smf.values, cell_tags) and smf.dim == 2
     assert table2 == table
-    m3, bmf3, table3 = import_mesh(prefix="lshape", dim=2, directory=str(tmp_path))
+    # default: renumbered for locality like dolfinx's reader; the same mesh and tags through the index maps
+    m3, bmf3, smf3, table3 = import_mesh(prefix="lshape", subdomains=True, dim=2, directory=str(tmp_path))
     assert m3.n_cell == mesh.n_cell and table3 == table
+    assert np.array_equal(m3.x, x[m3.original_vertex_index])
+    assert np.array_equal(m3.original_vertex_index[m3.conn], conn[m3.original_cell_index])
+    assert np.array_equal(smf3.values, cell_tags[m3.original_cell_index])
+    assert np.array_equal(np.sort(m3.original_vertex_index[bmf3.entities], axis=1), np.sort(edges, axis=1)) and np.array_equal(bmf3.values, tags)
+    # locality: the average index distance between a cell's vertices shrinks by an order of magnitude
+    spread = lambda c: np.abs(c.max(axis=1) - c.min(axis=1)).mean()
+    assert spread(m3.conn) < 0.3 * spread(conn)
     # tagged vertices = what locate_dofs_topological gives for CG1
     v2 = bmf.vertices(2)
     assert np.all((np.abs(x[v2, 0]) < 1e-12) | (np.abs(x[v2, 1]) < 1e-12)) and len(v2) == 2 * 6 + 1
