@@ -341,7 +341,9 @@ def _run(args):
             "workload": (f"3-D linear Poisson, P1 tets, unit cube n={args.n}: {n_dof} DOFs, {mesh.n_cell} cells, "
                          f"nnz {nnz}; per step, NumPy arrays at the operator boundary (f in; u, J, dJ/df out): "
                          f"Newton x3 (assemble R, dR/du, A; {PC.upper()}-CG) + J + dJ/du, dJ/df + "
-                         f"dR/du, dR/df, A + transposed {PC.upper()}-CG + dR/df^T lambda; CG rtol 1e-14; cold start"),
+                         f"dR/du, dR/df, A + transposed {PC.upper()}-CG + dR/df^T lambda; "
+                         + ("CG stops on sqrt(r.M^-1 r) <= 1e-11 sqrt(b.M^-1 b) (energy-equivalent norm)" if PC == "bpx" else
+                            "CG stops on sqrt(r.D^-1 r) <= 1e-14 sqrt(b.D^-1 b)") + "; cold start"),
             "boundary": "host (NumPy in pinned blocks of femo_host_alloc; H2D + D2H inside the timed region)",
             "preconditioner": PC, "pc_lattice": dm.pc_info(),
             "n": args.n, "jitter": args.jitter, "permuted": bool(args.permute), "reordered": bool(args.reorder),
