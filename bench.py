@@ -330,7 +330,8 @@ def _run(args):
     del probe, out
     nbytes = mesh.n_cell * 8
     h2d_bytes = (xfer["h2d_pinned_bytes"] + xfer["h2d_staged_bytes"]) / max(K, 1)
-    d2h_bytes = (xfer["d2h_pinned_bytes"] + xfer["d2h_staged_bytes"]) / max(K, 1)
+    d2h_bytes = (xfer["d2h_pinned_bytes"] + xfer["d2h_staged_bytes"] + xfer["d2h_async_bytes"]
+                 + xfer["d2h_device_sum_bytes"]) / max(K, 1)
 
     result = {
         "metric": METRIC, "value": n_dof / (ms_per_step * 1e-3), "unit": "DOFs/s",
@@ -354,9 +355,11 @@ def _run(args):
             # SURVEY.md section 8(d) split: Newton's linear solves / the transposed (adjoint) solve /
             # host<->device traffic and host-side passes / the rest (assembly, functional, dR/df^T lambda)
             "split_ms_per_step": {"forward_solves": fwd_ms, "adjoint_solve": adj_ms,
-                                  "h2d_d2h": ms_per_step - dev_ms,
+                                  "h2d_d2h": ms_per_step - dev_ms,       # the part of the transfers NOT hidden behind kernels
                                   "assembly_outputs": dev_ms - cg_ms},
             "pcie": {"h2d_bytes_per_step": h2d_bytes, "d2h_bytes_per_step": d2h_bytes,
+                     "d2h_async_bytes_per_step": xfer["d2h_async_bytes"] / max(K, 1),
+                     "d2h_device_sum_bytes_per_step": xfer["d2h_device_sum_bytes"] / max(K, 1),
                      "uploads_elided_per_step": (xfer["h2d_skipped"] + xfer["h2d_as_d2d"]) / max(K, 1),
                      "upload_bytes_elided_per_step": (xfer["h2d_skipped_bytes"] + xfer["h2d_as_d2d_bytes"]) / max(K, 1),
                      "h2d_pinned_GBs": nbytes / t_up / 1e9, "d2h_pinned_GBs": nbytes / t_dn / 1e9,

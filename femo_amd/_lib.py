@@ -46,7 +46,8 @@ class SolveInfo(C.Structure):
 class HostStats(C.Structure):
     _fields_ = [(k, C.c_int64) for k in ("h2d_pinned", "h2d_pinned_bytes", "h2d_staged", "h2d_staged_bytes",
                                          "h2d_skipped", "h2d_skipped_bytes", "h2d_as_d2d", "h2d_as_d2d_bytes",
-                                         "d2h_pinned", "d2h_pinned_bytes", "d2h_staged", "d2h_staged_bytes")]
+                                         "d2h_pinned", "d2h_pinned_bytes", "d2h_staged", "d2h_staged_bytes",
+                                         "d2h_async", "d2h_async_bytes", "d2h_device_sum", "d2h_device_sum_bytes")]
 
 
 # name -> (restype, argtypes); every symbol include/femo_hip.h declares
@@ -66,6 +67,9 @@ PROTOTYPES = {
     "femo_vec_set_host": (C.c_int, [H, C.c_void_p, c_i64]),
     "femo_vec_get_host": (C.c_int, [H, C.c_void_p, c_i64]),
     "femo_vec_add_to_host": (C.c_int, [H, C.c_void_p, c_i64]),
+    "femo_vec_get_host_async": (C.c_int, [H, C.c_void_p, c_i64]),
+    "femo_host_wait": (C.c_int, [C.c_void_p]),
+    "femo_host_sync": (C.c_int, []),
     "femo_host_alloc": (C.c_int, [c_i64, C.POINTER(C.c_void_p)]),
     "femo_host_free": (C.c_int, [C.c_void_p]),
     "femo_host_trim": (C.c_int, []),
@@ -148,7 +152,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.femo_abi_version() != 2:
+    if lib.femo_abi_version() != 3:
         raise FemoError("libfemo_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -10,6 +10,7 @@ import numpy as np
 
 from femo_amd.csdl_opt._common import declare_all, gather_arguments, push_functions, stays_on_device
 from femo_amd.csdl_opt._csdl_compat import CustomExplicitOperation, Model, custom
+from femo_amd.engine import lazy_results
 from femo_amd.fea.fea_hip import FEA
 from femo_amd.fea.utils_hip import assemble, computePartials, getFuncArray
 
@@ -57,9 +58,12 @@ class OutputOperation(_OutputOperationBase):
         push_functions(self.args_dict, inputs)
         dev = stays_on_device(inputs)
         form = self.output['form']
-        for name, entry in self.args_dict.items():
-            derivatives[self.output_name, name] = assemble(computePartials(form, entry['function']),
-                                                           dim=self.output_dim + 1, device=dev)
+        # smallest first: with asynchronous results the copies leave in this order, and the adjoint seed (dJ/du)
+        # is what the backend needs next
+        with lazy_results(self.fea.async_results):
+            for name, entry in sorted(self.args_dict.items(), key=lambda kv: kv[1]['shape']):
+                derivatives[self.output_name, name] = assemble(computePartials(form, entry['function']),
+                                                               dim=self.output_dim + 1, device=dev)
 
 
 class OutputFieldOperation(_OutputOperationBase):
@@ -72,7 +76,8 @@ class OutputFieldOperation(_OutputOperationBase):
         self.fea.projectFieldOutput(out['form'], out['func'])
         if out['record']:
             out['recorder'].write_function(out['func'], self.fea.opt_iter)
-        outputs[self.output_name] = getFuncArray(out['func'], device=stays_on_device(inputs))
+        with lazy_results(self.fea.async_results):
+            outputs[self.output_name] = getFuncArray(out['func'], device=stays_on_device(inputs))
 
 
 class _OutputModelBase(Model):

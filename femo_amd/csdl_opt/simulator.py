@@ -21,6 +21,12 @@ reference.  The engine can therefore tell that an array it is handed again is st
 device vector and moves it over PCIe once (include/femo_hip.h, "host memory").  The reverse sweep
 accumulates in place: the adjoint right-hand side is negated (one pass over a state-sized array), so that
 ``d_inputs[arg] += dRdf^T psi`` lands directly in the array that already holds the explicit partial.
+
+Asynchronous results (``async_results=True``, host mode with pinned storage): the driver tells the FEA objects that
+it honours the contract of ``engine.lazy_results`` -- arrays returned by operator methods may still be on their
+way down; it never reads them with NumPy before ``engine.host_wait`` (``sim[name]``) or ``engine.host_sync`` (end of
+``compute_totals``), and everything it does with them in between goes through library calls, which wait by
+themselves.  The 477 MB of dJ/df then travel while the adjoint system is assembled and solved.
 """
 from __future__ import annotations
 
@@ -43,10 +49,11 @@ def _readonly(a: np.ndarray) -> np.ndarray:
 
 
 class Simulator:
-    def __init__(self, model, device: bool = False, pinned: bool = True):
+    def __init__(self, model, device: bool = False, pinned: bool = True, async_results: bool = True):
         self.model = model
         self.device = device
         self.pinned = pinned          # host mode: variables in pinned engine blocks (False: plain pageable NumPy arrays)
+        self.async_results = bool(async_results) and pinned and not device
         self.values: Dict[str, object] = {}
         self.ops: List[Tuple[str, object]] = []          # (submodel name, operation)
         self._build(model)
@@ -64,6 +71,8 @@ class Simulator:
                     self._store(name, self._initial(var))
                 elif var.kind == "output" and var.op is not None:
                     self.ops.append((sub_name, var.op))
+                    if getattr(var.op, "fea", None) is not None:
+                        var.op.fea.async_results = self.async_results
                     for oname, meta in var.op.output_meta.items():
                         if oname not in self.values:
                             self._store(oname, np.full(meta["shape"], float(np.asarray(meta["val"]).ravel()[0])))
@@ -105,7 +114,7 @@ class Simulator:
     def __getitem__(self, name: str):
         """NumPy value of a variable.  Host mode returns the stored (read-only) array itself."""
         v = self.values[self._key(name)]
-        return v.numpy() if isinstance(v, DeviceArray) else v
+        return v.numpy() if isinstance(v, DeviceArray) else E.host_wait(v)
 
     def __setitem__(self, name: str, value) -> None:
         self._store(self._key(name), value)
@@ -159,13 +168,14 @@ class Simulator:
         return out
 
     @staticmethod
-    def _own(a: np.ndarray) -> np.ndarray:
+    def _own(a: np.ndarray, announce: bool = True) -> np.ndarray:
         """A writable array holding ``a``: the array itself, a writable alias of a result the engine
-        returned read-only (the sweep received it and is its only holder), or a copy."""
+        returned read-only (the sweep received it and is its only holder), or a copy.  ``announce=False``:
+        only library calls will write it until the sweep touches it (``engine.writable``)."""
         if a.flags.writeable:
             return a
         try:
-            return E.writable(a)
+            return E.writable(a, announce)
         except ValueError:
             w = E.pinned_empty(a.size)
             E.host_copy(w, np.ascontiguousarray(a))
@@ -234,13 +244,16 @@ class Simulator:
                         d_inputs = {}
                         for k in op.input_meta:
                             if k in adj:
-                                d_inputs[k] = self._own(adj[k])
+                                d_inputs[k] = self._own(adj[k], announce=False)
                             elif self.pinned:
                                 d_inputs[k] = E.pinned_empty(np.size(self.values[k]))
                                 E.host_axpby(0.0, d_inputs[k], 0.0, d_inputs[k])
                             else:
                                 d_inputs[k] = np.zeros(np.size(self.values[k]))
                         op.compute_jacvec_product(inputs, outputs, d_inputs, {}, d_residuals, 'rev')
+                        for v in d_inputs.values():
+                            if self.pinned:
+                                E.host_touch(v)           # whatever wrote it: it mirrors no device vector now
                         adj.update(d_inputs)
             if not seed_done:
                 raise KeyError(f"no operation produces {o!r}")
@@ -248,6 +261,8 @@ class Simulator:
                 w = self._key(w)
                 val = adj[w] if w in adj else self._zeros_like(w, 'adj')
                 result[(o, w)] = self._result((o, w), val)
+        if self.async_results:
+            E.host_sync()
         if single:
             return result[(self._key(of), self._key(wrt))]
         return result

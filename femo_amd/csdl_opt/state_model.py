@@ -15,6 +15,7 @@ import numpy as np
 from femo_amd.csdl_opt._common import (declare_all, gather_arguments, push_functions, stays_on_device,
                                        traced)
 from femo_amd.csdl_opt._csdl_compat import CustomImplicitOperation, Model, custom
+from femo_amd.engine import lazy_results
 from femo_amd.fea.fea_hip import FEA
 from femo_amd.fea.utils_hip import (DeviceArray, SparseMatrix, addMatVecProductBwd, addMatVecProductFwd,
                                     assembleMatrix, assembleSystem, assembleVector, computePartials,
@@ -86,7 +87,8 @@ class StateOperation(CustomImplicitOperation):
     def evaluate_residuals(self, inputs, outputs, residuals):
         """Residual vector without any Dirichlet treatment (state_model.py:75-85)."""
         self._load(inputs, outputs)
-        residuals[self.state_name] = assembleVector(self.state['residual_form'], device=stays_on_device(inputs))
+        with lazy_results(self.fea.async_results):
+            residuals[self.state_name] = assembleVector(self.state['residual_form'], device=stays_on_device(inputs))
 
     @traced()
     def solve_residual_equations(self, inputs, outputs):
@@ -99,7 +101,8 @@ class StateOperation(CustomImplicitOperation):
             if entry['record']:
                 entry['recorder'].write_function(entry['function'], fea.opt_iter)
         fea.solve(self.state['residual_form'], self.state['function'], self.bcs)
-        outputs[self.state_name] = getFuncArray(self.state['function'], device=stays_on_device(inputs))
+        with lazy_results(fea.async_results):
+            outputs[self.state_name] = getFuncArray(self.state['function'], device=stays_on_device(inputs))
         if fea.record:
             self.state['recorder'].write_function(self.state['function'], fea.opt_iter)
 

@@ -17,6 +17,11 @@ __global__ void k_axpy(int64_t n, double a, const double* __restrict__ x, double
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] += a * x[i];
 }
 
+__global__ void k_sum(int64_t n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = a[i] + b[i];
+}
+
 __global__ void k_pdiv(int64_t n, const double* __restrict__ x, const double* __restrict__ d, double* __restrict__ y) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = x[i] / d[i];
 }
@@ -124,6 +129,13 @@ int upload(T** dptr, const std::vector<T>& h, hipStream_t st) {
 
 }  // namespace
 
+int femo_launch_sum(double* out, const double* a, const double* b, int64_t n, hipStream_t st) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_sum, dim3(grid_for(n)), dim3(256), 0, st, n, a, b, out);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 extern "C" {
 
 int femo_abi_version(void) { return FEMO_ABI_VERSION; }
@@ -191,6 +203,9 @@ int femo_ctx_destroy(femo_ctx* c) {
     if (c->stage[k]) hipHostFree(c->stage[k]);
     if (c->stage_ev[k]) hipEventDestroy(c->stage_ev[k]);
   }
+  if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
+  if (c->ev_copy) hipEventDestroy(c->ev_copy);
+  hipFree(c->d_accum);
   hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
   for (auto& e : c->ev_pool) hipEventDestroy(e);
   if (c->own_stream) hipStreamDestroy(c->stream);
@@ -232,6 +247,10 @@ int femo_vec_wrap(femo_ctx* ctx, void* device_ptr, int64_t n, femo_vec** out) {
 int femo_vec_destroy(femo_vec* v) {
   if (!v) return 0;
   femo_vec_unregister(v);
+  if (v->d2h_ev) {
+    hipEventSynchronize(v->d2h_ev);                    // a copy-out may still be reading the vector
+    hipEventDestroy(v->d2h_ev);
+  }
   if (v->owned && v->d) {
     hipStreamSynchronize(v->ctx->stream);
     hipFree(v->d);

@@ -109,6 +109,12 @@ struct femo_ctx {
   // pinned staging ring for pageable host memory (hostmem.cpp), allocated on first use
   double* stage[FEMO_STAGE_SLOTS] = {};
   hipEvent_t stage_ev[FEMO_STAGE_SLOTS] = {};
+  // copy-out stream of the asynchronous result path (femo_vec_get_host_async) and the device scratch of
+  // accumulate-on-copy-out (hostmem.cpp), both created on first use
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_copy = nullptr;
+  double* d_accum = nullptr;
+  int64_t accum_n = 0;
   // CG workspace, grown on demand and reused across solves
   double *cg_r = nullptr, *cg_p = nullptr, *cg_q = nullptr, *cg_dinv = nullptr, *cg_s = nullptr;
   double *cg_t = nullptr, *cg_r0 = nullptr;
@@ -123,8 +129,19 @@ struct femo_vec {
   // provenance of host copies (hostmem.cpp): process-unique id (0 = wrapped memory, never trusted)
   // and a generation that every entry point writing the vector bumps
   uint64_t uid = 0, gen = 0;
+  // an asynchronous copy-out of this vector is (or was) in flight on the context's copy stream: the next writer
+  // makes the compute stream wait for it (every writing entry point calls femo_vec_touch BEFORE it launches)
+  hipEvent_t d2h_ev = nullptr;
+  bool d2h_pending = false;
 };
-inline void femo_vec_touch(femo_vec* v) { if (v) ++v->gen; }
+void femo_vec_wait_readers(femo_vec* v);   // hostmem.cpp
+inline void femo_vec_touch(femo_vec* v) {
+  if (!v) return;
+  ++v->gen;
+  if (v->d2h_pending) femo_vec_wait_readers(v);
+}
+// out = a + b on the stream (api.hip; the device half of femo_vec_add_to_host)
+int femo_launch_sum(double* out, const double* a, const double* b, int64_t n, hipStream_t st);
 void femo_vec_register(femo_vec* v);     // after creation: assigns uid, enters the live table
 void femo_vec_unregister(femo_vec* v);   // before destruction
 

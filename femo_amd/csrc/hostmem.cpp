@@ -18,6 +18,15 @@
 //     and stay exact: host-side writers must announce themselves (femo_host_touch), which is why
 //     the Python layer returns read-only arrays.  FEMO_HOST_VERIFY=1 checks every elision against
 //     a real comparison (tests).
+//  4. Asynchronous results (femo_vec_get_host_async).  The copy-out of a result runs on a second stream
+//     and the call returns at once; the block carries an event until the bytes have landed.  Every library
+//     entry that touches such a block waits first (or needs no bytes at all: an elided upload), a caller that
+//     reads it with its own code calls femo_host_wait / femo_host_sync.  The next kernel that writes the
+//     vector waits for the copy on the device (femo_vec_touch).  With it the 477 MB of dJ/df travel while the
+//     adjoint system is assembled and solved.
+//  5. Accumulate on the device.  femo_vec_add_to_host into a block that still mirrors a live vector G forms
+//     G + v in a scratch vector and copies the sum out at DMA rate, instead of adding on the host while the
+//     chunks arrive (same bits: one IEEE addition per entry either way).
 #include <sched.h>
 #include <unistd.h>
 
@@ -149,6 +158,9 @@ struct HostBlock {
   // provenance: the first src_n doubles are an exact copy of device vector src_uid at generation src_gen
   uint64_t src_uid = 0, src_gen = 0;
   int64_t src_n = 0;
+  // an asynchronous copy-out into the block is (or was) in flight: recorded on a copy stream after the DMA
+  hipEvent_t ready = nullptr;
+  bool pending = false;
 };
 
 std::mutex g_mu;
@@ -171,6 +183,39 @@ HostBlock* find_block(const void* p, size_t bytes) {     // g_mu held
 }
 
 bool verify_enabled() { return getenv("FEMO_HOST_VERIFY") != nullptr; }
+
+// events of blocks that left the registry, kept for the next block that needs one
+std::vector<hipEvent_t> g_ev_free;
+
+hipEvent_t take_event() {                                // g_mu held
+  if (!g_ev_free.empty()) { hipEvent_t e = g_ev_free.back(); g_ev_free.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+  return e;
+}
+
+// Wait until the asynchronous copy-out into the block containing p (if any) has landed.
+int wait_block(const void* p) {
+  hipEvent_t ev = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    HostBlock* b = p ? find_block(p, 1) : nullptr;
+    if (b == nullptr || !b->pending) return 0;
+    ev = b->ready;
+  }
+  FEMO_HIP_CHECK(hipEventSynchronize(ev));               // not under the lock: it can take milliseconds
+  std::lock_guard<std::mutex> lk(g_mu);
+  HostBlock* b = find_block(p, 1);
+  if (b != nullptr && b->ready == ev && hipEventQuery(ev) == hipSuccess) b->pending = false;
+  return 0;
+}
+
+int ensure_copy_stream(femo_ctx* c) {
+  if (c->copy_stream) return 0;
+  FEMO_HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  FEMO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
+  return 0;
+}
 
 // FEMO_HOST_TRACE=1: one line per host-side operation on stderr (what, MB, ms)
 struct Trace {
@@ -259,6 +304,12 @@ void femo_vec_register(femo_vec* v) {
   }
 }
 
+void femo_vec_wait_readers(femo_vec* v) {
+  // called by femo_vec_touch before a kernel that writes v is launched on the compute stream
+  if (v->d2h_ev != nullptr) (void)hipStreamWaitEvent(v->ctx->stream, v->d2h_ev, 0);
+  v->d2h_pending = false;
+}
+
 void femo_vec_unregister(femo_vec* v) {
   if (!v->uid) return;
   std::lock_guard<std::mutex> lk(g_mu);
@@ -305,6 +356,10 @@ int femo_host_free(void* p) {
     auto it = g_blocks.find(reinterpret_cast<uintptr_t>(p));
     FEMO_REQUIRE(it != g_blocks.end() && it->second.pooled, "femo_host_free: not a block of femo_host_alloc");
     bytes = it->second.bytes;
+    if (it->second.ready != nullptr) {
+      if (it->second.pending) (void)hipEventSynchronize(it->second.ready);   // the DMA still owns the block
+      g_ev_free.push_back(it->second.ready);
+    }
     g_blocks.erase(it);
     if (g_free_bytes + bytes <= FREE_CAP) {
       g_free.emplace(bytes, p);
@@ -347,6 +402,10 @@ int femo_host_unregister(void* p) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_blocks.find(reinterpret_cast<uintptr_t>(p));
     FEMO_REQUIRE(it != g_blocks.end() && !it->second.pooled, "femo_host_unregister: not a registered range");
+    if (it->second.ready != nullptr) {
+      if (it->second.pending) (void)hipEventSynchronize(it->second.ready);
+      g_ev_free.push_back(it->second.ready);
+    }
     g_blocks.erase(it);
   }
   FEMO_HIP_CHECK(hipHostUnregister(p));
@@ -355,6 +414,7 @@ int femo_host_unregister(void* p) {
 
 int femo_host_touch(void* p) {
   if (!p) return 0;
+  FEMO_TRY(wait_block(p));                               // the caller is about to write (or has read) the block
   std::lock_guard<std::mutex> lk(g_mu);
   if (HostBlock* b = find_block(p, 1)) b->src_uid = 0;
   return 0;
@@ -369,6 +429,8 @@ int femo_host_threads(void) { return HostPool::get().threads(); }
 
 int femo_host_copy(double* dst, const double* src, int64_t n) {
   FEMO_REQUIRE((dst && src) || n == 0, "null argument");
+  FEMO_TRY(wait_block(src));
+  FEMO_TRY(wait_block(dst));
   Trace tr("host_copy", n * 8);
   par_stream(dst, src, n, 0);
   femo_host_touch(dst);
@@ -377,6 +439,8 @@ int femo_host_copy(double* dst, const double* src, int64_t n) {
 
 int femo_host_axpby(int64_t n, double a, const double* x, double b, double* y) {
   FEMO_REQUIRE((x && y) || n == 0, "null argument");
+  FEMO_TRY(wait_block(x));
+  FEMO_TRY(wait_block(y));
   Trace tr("host_axpby", n * 8);
   par_stream(y, x, n, 2, a, b);
   femo_host_touch(y);
@@ -422,11 +486,12 @@ int femo_vec_set_host(femo_vec* v, const double* host, int64_t n) {
   if (src != nullptr && src == v) {
     elided = 1;                                          // v still holds exactly this content
   } else if (src != nullptr) {
+    femo_vec_touch(v);                                   // before the write: a copy-out of v may be in flight
     FEMO_HIP_CHECK(hipMemcpyAsync(v->d, src->d, n * sizeof(double), hipMemcpyDeviceToDevice, v->ctx->stream));
     if (src->ctx != v->ctx) FEMO_HIP_CHECK(hipStreamSynchronize(v->ctx->stream));
-    femo_vec_touch(v);
     elided = 2;
   }
+  if (!elided || verify_enabled()) FEMO_TRY(wait_block(host));   // the bytes themselves are needed
   if (elided && verify_enabled()) {
     std::vector<double> chk((size_t)n);
     FEMO_HIP_CHECK(hipMemcpy(chk.data(), v->d, n * sizeof(double), hipMemcpyDeviceToHost));
@@ -434,8 +499,8 @@ int femo_vec_set_host(femo_vec* v, const double* host, int64_t n) {
                  "FEMO_HOST_VERIFY: an elided upload (kind %d) would have changed the vector", elided);
   }
   if (!elided) {
-    FEMO_TRY(h2d(v, host, n, pinned));
     femo_vec_touch(v);
+    FEMO_TRY(h2d(v, host, n, pinned));
   }
   std::lock_guard<std::mutex> lk(g_mu);
   if (elided == 1) { ++g_stats.h2d_skipped; g_stats.h2d_skipped_bytes += n * 8; }
@@ -450,18 +515,77 @@ int femo_vec_set_host(femo_vec* v, const double* host, int64_t n) {
   return 0;
 }
 
-static int get_host_impl(const femo_vec* v, double* host, int64_t n, int op) {
+// op 0: host = v; op 1: host += v.  lazy: return before the bytes have landed (pinned blocks, op 0 only).
+static int get_host_impl(const femo_vec* v, double* host, int64_t n, int op, bool lazy) {
   FEMO_REQUIRE(v && host, "null argument");
   FEMO_REQUIRE(n <= v->n, "size mismatch: vector has %lld entries, host array %lld", (long long)v->n, (long long)n);
   if (n == 0) return 0;
-  FEMO_HIP_CHECK(hipSetDevice(v->ctx->device));
-  bool pinned = false;
+  femo_ctx* c = v->ctx;
+  FEMO_HIP_CHECK(hipSetDevice(c->device));
+  FEMO_TRY(wait_block(host));                            // an earlier copy-out into the block must not land after this one
+  bool pinned = false, exact_base = false;
+  femo_vec* mirror = nullptr;                            // live vector the block is an exact copy of (op 1)
   {
     std::lock_guard<std::mutex> lk(g_mu);
     if (HostBlock* b = find_block(host, (size_t)n * sizeof(double))) {
       pinned = true;
+      exact_base = reinterpret_cast<char*>(host) == b->base;
+      if (op == 1 && exact_base && b->src_uid != 0 && b->src_n >= n) {
+        auto it = g_live.find(b->src_uid);
+        if (it != g_live.end() && it->second->gen == b->src_gen && it->second->ctx == c) mirror = it->second;
+      }
       b->src_uid = 0;                                    // being overwritten
     }
+  }
+  if (op == 1 && mirror != nullptr) {
+    // host holds exactly mirror's content: host + v = mirror + v, formed on the device and copied out at DMA rate
+    Trace tr("add_to_host (device sum)", n * 8);
+    if (verify_enabled()) {
+      std::vector<double> chk((size_t)n);
+      FEMO_HIP_CHECK(hipMemcpy(chk.data(), mirror->d, n * sizeof(double), hipMemcpyDeviceToHost));
+      FEMO_REQUIRE(memcmp(chk.data(), host, (size_t)n * sizeof(double)) == 0,
+                   "FEMO_HOST_VERIFY: the block no longer holds the vector it is recorded to mirror");
+    }
+    if (c->accum_n < n) {
+      FEMO_HIP_CHECK(hipStreamSynchronize(c->stream));
+      if (c->d_accum) FEMO_HIP_CHECK(hipFree(c->d_accum));
+      c->d_accum = nullptr; c->accum_n = 0;
+      FEMO_HIP_CHECK(hipMalloc(&c->d_accum, (size_t)n * sizeof(double)));
+      c->accum_n = n;
+    }
+    FEMO_TRY(femo_launch_sum(c->d_accum, mirror->d, v->d, n, c->stream));
+    FEMO_HIP_CHECK(hipMemcpyAsync(host, c->d_accum, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    FEMO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    std::lock_guard<std::mutex> lk(g_mu);
+    ++g_stats.d2h_device_sum; g_stats.d2h_device_sum_bytes += n * 8;
+    return 0;
+  }
+  if (lazy && pinned && op == 0) {
+    Trace tr("get_host (async)", n * 8);
+    FEMO_TRY(ensure_copy_stream(c));
+    femo_vec* vv = const_cast<femo_vec*>(v);
+    if (vv->d2h_ev == nullptr) FEMO_HIP_CHECK(hipEventCreateWithFlags(&vv->d2h_ev, hipEventDisableTiming));
+    hipEvent_t ready = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(g_mu);
+      HostBlock* b = find_block(host, (size_t)n * sizeof(double));
+      if (b->ready == nullptr) b->ready = take_event();
+      ready = b->ready;
+    }
+    FEMO_REQUIRE(ready != nullptr, "could not create an event");
+    FEMO_HIP_CHECK(hipEventRecord(c->ev_copy, c->stream));           // everything enqueued so far produced v
+    FEMO_HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0));
+    FEMO_HIP_CHECK(hipMemcpyAsync(host, v->d, n * sizeof(double), hipMemcpyDeviceToHost, c->copy_stream));
+    FEMO_HIP_CHECK(hipEventRecord(ready, c->copy_stream));
+    FEMO_HIP_CHECK(hipEventRecord(vv->d2h_ev, c->copy_stream));
+    vv->d2h_pending = true;
+    std::lock_guard<std::mutex> lk(g_mu);
+    ++g_stats.d2h_async; g_stats.d2h_async_bytes += n * 8;
+    if (HostBlock* b = find_block(host, (size_t)n * sizeof(double))) {
+      b->pending = true;
+      if (exact_base && v->uid != 0) { b->src_uid = v->uid; b->src_gen = v->gen; b->src_n = n; }   // true once landed
+    }
+    return 0;
   }
   {
     Trace tr(op ? "add_to_host" : (pinned ? "get_host (pinned)" : "get_host (staged)"), n * 8);
@@ -478,8 +602,24 @@ static int get_host_impl(const femo_vec* v, double* host, int64_t n, int op) {
   return 0;
 }
 
-int femo_vec_get_host(const femo_vec* v, double* host, int64_t n) { return get_host_impl(v, host, n, 0); }
+int femo_vec_get_host(const femo_vec* v, double* host, int64_t n) { return get_host_impl(v, host, n, 0, false); }
 
-int femo_vec_add_to_host(const femo_vec* v, double* host, int64_t n) { return get_host_impl(v, host, n, 1); }
+int femo_vec_get_host_async(const femo_vec* v, double* host, int64_t n) { return get_host_impl(v, host, n, 0, true); }
+
+int femo_vec_add_to_host(const femo_vec* v, double* host, int64_t n) { return get_host_impl(v, host, n, 1, false); }
+
+int femo_host_wait(const void* p) { return wait_block(p); }
+
+int femo_host_sync(void) {
+  std::vector<hipEvent_t> evs;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& kv : g_blocks) if (kv.second.pending) evs.push_back(kv.second.ready);
+  }
+  for (hipEvent_t e : evs) FEMO_HIP_CHECK(hipEventSynchronize(e));
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& kv : g_blocks) if (kv.second.pending && hipEventQuery(kv.second.ready) == hipSuccess) kv.second.pending = false;
+  return 0;
+}
 
 }  // extern "C"

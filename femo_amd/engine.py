@@ -6,7 +6,9 @@ for are named per class.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import threading
 from typing import Dict, Optional, Sequence
 
 import numpy as np
@@ -82,9 +84,41 @@ def host_touch(a: np.ndarray) -> None:
     check(_lib.load().femo_host_touch(C.c_void_p(a.ctypes.data)))
 
 
-def writable(a: np.ndarray) -> np.ndarray:
+def host_wait(a: np.ndarray) -> np.ndarray:
+    """Block until an asynchronous copy-out into ``a`` (``Vec.get`` under ``lazy_results``) has landed.  No-op for
+    any other array.  Library calls that take ``a`` wait by themselves; NumPy code calls this first."""
+    check(_lib.load().femo_host_wait(C.c_void_p(a.ctypes.data)))
+    return a
+
+
+def host_sync() -> None:
+    """Wait for every asynchronous copy-out still in flight."""
+    check(_lib.load().femo_host_sync())
+
+
+_LAZY = threading.local()
+
+
+@contextlib.contextmanager
+def lazy_results(enabled: bool = True):
+    """Inside the block ``Vec.get()`` (without ``out``) returns its pinned array before the bytes have landed:
+    the copy runs on the context's copy stream while later kernels execute.  The caller promises that whoever
+    reads the array with code of its own calls ``host_wait`` / ``host_sync`` first (the operator classes hand
+    such arrays only to a backend that set ``fea.async_results``)."""
+    prev = getattr(_LAZY, "on", False)
+    _LAZY.on = bool(enabled) or prev
+    try:
+        yield
+    finally:
+        _LAZY.on = prev
+
+
+def writable(a: np.ndarray, announce: bool = True) -> np.ndarray:
     """Writable alias of an array the library returned read-only.  For its new owner (a driver that
-    accumulates into a result in place); the block stops counting as a mirror of its device vector."""
+    accumulates into a result in place); the block stops counting as a mirror of its device vector.
+    ``announce=False``: the alias will only be written by library calls (which keep the record straight
+    themselves, and can use it: ``Vec.add_to_host`` into a block that still mirrors a device vector adds on the
+    device); the owner calls ``host_touch`` before any write of its own."""
     if a.flags.writeable:
         return a
     base = a.base
@@ -92,7 +126,8 @@ def writable(a: np.ndarray) -> np.ndarray:
         base = base.base
     if not isinstance(base, _PinnedBlock) or a.ctypes.data != base.ptr or a.size != base.n:
         raise ValueError("writable(): not a whole array returned by the engine")
-    host_touch(a)
+    if announce:
+        host_touch(a)
     return np.asarray(base)
 
 
@@ -213,7 +248,10 @@ class Vec:
             check(self.lib.femo_vec_get_host(self.handle, _ptr(out), n))
             return out
         out = pinned_empty(n)
-        check(self.lib.femo_vec_get_host(self.handle, _ptr(out), n))
+        if getattr(_LAZY, "on", False):
+            check(self.lib.femo_vec_get_host_async(self.handle, _ptr(out), n))
+        else:
+            check(self.lib.femo_vec_get_host(self.handle, _ptr(out), n))
         out.flags.writeable = False
         return out
 

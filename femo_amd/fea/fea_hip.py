@@ -14,6 +14,7 @@ import os
 
 import numpy as np
 
+from .. import engine as E
 from .utils_hip import *          # noqa: F401,F403  re-export (the reference does the same, fea_dolfinx.py:5)
 from .utils_hip import (DeviceArray, DirichletBC, KSP, dirichletbc, getFuncArray, project, setFuncArray,
                         solveKSP_mumps, solveNonlinear, transpose)
@@ -74,6 +75,9 @@ class FEA(object):
         self.consistent_bc_partials = False   # zero Dirichlet rows of dR/du, dR/df in the jac-vec products
         self.reference_fwd_bug = False        # reproduce solveLinearFwd's zeros (fea_dolfinx.py:192-206)
         self.reload_in_jacvec = False         # re-send inputs/state in compute_jacvec_product (state_model.py:168-173)
+        # True: arrays the operator methods return may still be in flight (engine.lazy_results); the backend that
+        # sets it calls engine.host_wait / host_sync before reading them with code of its own (csdl_opt/simulator.py)
+        self.async_results = False
 
     # ------------------------------------------------------------------ registration ----
     def _recorded(self, name, record, **fields):
@@ -149,7 +153,8 @@ class FEA(object):
             solveKSP_mumps(operator, rhs_fn.vector, sol_fn.vector)
         else:
             ksp.solve(rhs_fn.vector, sol_fn.vector)
-        return getFuncArray(sol_fn, device=device)
+        with E.lazy_results(self.async_results):
+            return getFuncArray(sol_fn, device=device)
 
     def solveLinearFwd(self, du, A, dR, dR_array, ksp=None, device=False):
         """du = A^-1 dR.  The reference swaps right-hand side and solution and therefore returns

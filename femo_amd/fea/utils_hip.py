@@ -486,7 +486,9 @@ def _add_product(target, A, x, transposed: bool):
             and target.flags.writeable and target.size == n):
         y.add_to_host(target, n)
         return target
-    target += y.get(n)
+    if isinstance(target, np.ndarray) and E.is_pinned(target):
+        E.host_touch(target)                     # a NumPy write into a block that may be recorded as a mirror
+    target += E.host_wait(y.get(n))
     return target
 
 

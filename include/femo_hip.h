@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FEMO_ABI_VERSION 2
+#define FEMO_ABI_VERSION 3
 
 typedef struct femo_ctx  femo_ctx;   /* device + stream + reduction workspace (+ RCCL communicator) */
 typedef struct femo_vec  femo_vec;   /* fp64 device vector  (dolfinx Function.vector / PETSc Vec)     */
@@ -129,6 +129,7 @@ int     femo_vec_get_host(const femo_vec* v, double* host, int64_t n);      /* g
 /* host[0:n] += v[0:n]: the `d_inputs[name] += dRdf^T dR` of state_model.py:190-200 without a second
  * pass over the host array (the add runs in the host threads that drain the staging slots).       */
 int     femo_vec_add_to_host(const femo_vec* v, double* host, int64_t n);
+int     femo_vec_get_host_async(const femo_vec* v, double* host, int64_t n);   /* see "asynchronous results" below */
 int     femo_vec_fill(femo_vec* v, double value);                           /* Vec.set      */
 int     femo_vec_copy(femo_vec* dst, const femo_vec* src);
 int     femo_vec_axpy(femo_vec* y, double a, const femo_vec* x);            /* y += a x     */
@@ -155,6 +156,8 @@ typedef struct femo_host_stats {
   int64_t h2d_as_d2d, h2d_as_d2d_bytes;     /* elided: copied from another device vector */
   int64_t d2h_pinned, d2h_pinned_bytes;
   int64_t d2h_staged, d2h_staged_bytes;     /* pageable destination, or accumulate      */
+  int64_t d2h_async, d2h_async_bytes;       /* femo_vec_get_host_async                   */
+  int64_t d2h_device_sum, d2h_device_sum_bytes; /* accumulate formed on the device      */
 } femo_host_stats;
 int femo_host_alloc(int64_t bytes, void** out);
 int femo_host_free(void* p);
@@ -166,6 +169,11 @@ int femo_host_is_pinned(const void* p, int64_t bytes);
 int femo_host_threads(void);
 int femo_host_copy(double* dst, const double* src, int64_t n);
 int femo_host_axpby(int64_t n, double a, const double* x, double b, double* y);
+/* Asynchronous results: femo_vec_get_host_async returns before the bytes have landed when `host` lies in a
+ * pinned block (otherwise it is femo_vec_get_host).  Library entry points wait by themselves; code that reads the
+ * block on its own calls femo_host_wait(p) (one block) or femo_host_sync() (all) first.                       */
+int femo_host_wait(const void* p);
+int femo_host_sync(void);
 int femo_host_get_stats(femo_host_stats* out);
 int femo_host_reset_stats(void);
 

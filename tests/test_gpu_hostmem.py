@@ -201,7 +201,10 @@ def test_operator_cycle_moves_each_array_once(ctx):
     assert st["h2d_pinned_bytes"] + st["h2d_staged_bytes"] == nf + nu, st
     assert st["h2d_skipped"] + st["h2d_as_d2d"] == 8, st
     # down: u, dJ/df, dJ/du, psi, dR/df^T psi
-    assert st["d2h_pinned_bytes"] + st["d2h_staged_bytes"] == 2 * nf + 3 * nu, st
+    down = st["d2h_pinned_bytes"] + st["d2h_staged_bytes"] + st["d2h_async_bytes"] + st["d2h_device_sum_bytes"]
+    assert down == 2 * nf + 3 * nu, st
+    # u, dJ/du, dJ/df and psi leave asynchronously; dR/df^T psi is added to dJ/df on the device and leaves as the sum
+    assert st["d2h_async"] == 4 and st["d2h_device_sum"] == 1 and st["d2h_staged"] == 0, st
 
     def rel(a, b):
         return np.abs(np.asarray(a) - b).max() / np.abs(b).max()
@@ -214,6 +217,83 @@ def test_operator_cycle_moves_each_array_once(ctx):
     sim_p.run()
     gp = sim_p.compute_totals('l2_functional', 'f')
     assert rel(sim_p['u'], ref['u']) < 1e-10 and rel(gp, ref['grad']) < 1e-10
+
+
+def test_asynchronous_results(ctx):
+    """Vec.get under lazy_results returns before the bytes have landed: a later device-side write of the vector
+    must not leak into the copy, library calls on the array wait by themselves, a block is not recycled under a
+    running DMA."""
+    from femo_amd import engine as E
+    n = 6_000_011
+    a = np.random.default_rng(11).standard_normal(n)
+    v, w = E.Vec(ctx, n), E.Vec(ctx, n)
+    v.set(a)
+    E.host_stats(reset=True)
+    for trial in range(3):
+        with E.lazy_results():
+            h = v.get()
+        v.fill(-1.0)                                    # enqueued behind the copy (femo_vec_touch waits on the device)
+        v.axpy(2.0, v)
+        assert np.array_equal(E.host_wait(h), a), trial
+        v.set(h)                                        # h mirrors the OLD generation: a real upload
+        assert np.array_equal(v.get(), a)
+    st = E.host_stats()
+    assert st["d2h_async"] == 3 and st["h2d_pinned"] == 3, st
+    with E.lazy_results():
+        h = v.get()
+    v.set(h)                                            # skipped, without waiting for the bytes
+    w.set(h)                                            # elided (device to device); the block mirrors w from now on
+    st = E.host_stats()
+    assert st["h2d_as_d2d"] == 1 and st["h2d_skipped"] == 1, st
+    assert np.array_equal(w.get(), a)
+    out = np.empty(n)
+    E.host_copy(out, h)                                 # library call on a block in flight: waits
+    assert np.array_equal(out, a)
+    with E.lazy_results():
+        h2 = v.get()
+        p = h2.ctypes.data
+        del h2                                          # freed while the DMA may still run: the pool waits
+        gc.collect()
+        h3 = w.get()
+    assert np.array_equal(E.host_wait(h3), a)
+    E.host_sync()
+    with E.lazy_results(False):
+        assert np.array_equal(v.get(), a)               # not lazy: complete on return
+
+
+def test_accumulate_on_the_device(ctx):
+    """add_to_host into a block that still mirrors a live vector: the sum is formed on the device and is the
+    host sum bit for bit; the block mirrors nothing afterwards; any doubt falls back to the host path."""
+    from femo_amd import engine as E
+    n = 3_000_017
+    rng = np.random.default_rng(12)
+    a, b = rng.standard_normal(n), rng.standard_normal(n)
+    g, c = E.Vec(ctx, n).set(a), E.Vec(ctx, n).set(b)
+    E.host_stats(reset=True)
+    with E.lazy_results():
+        h = g.get()
+    hw = E.writable(h, announce=False)
+    c.add_to_host(hw)
+    st = E.host_stats()
+    assert st["d2h_device_sum"] == 1 and st["d2h_staged"] == 0, st
+    assert np.array_equal(hw, a + b)
+    g.set(hw)                                           # must be a real upload now
+    assert E.host_stats()["h2d_pinned"] == 1
+    assert np.array_equal(g.get(), a + b)
+    # announced write: host path
+    h = g.get()
+    hw = E.writable(h)
+    c.add_to_host(hw)
+    assert E.host_stats()["d2h_staged"] == 1
+    assert np.array_equal(hw, (a + b) + b)
+    # the mirrored vector changed in between: host path
+    g.set(a)
+    h = g.get()
+    hw = E.writable(h, announce=False)
+    g.fill(0.0)
+    c.add_to_host(hw)
+    assert E.host_stats()["d2h_staged"] == 2 and E.host_stats()["d2h_device_sum"] == 1
+    assert np.array_equal(hw, a + b)
 
 
 def test_two_outputs_do_not_alias_in_device_mode(ctx):
