@@ -166,6 +166,92 @@ __global__ void k_pc_weights(int64_t n, const int32_t* __restrict__ perm, const 
   }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's outstanding GLOBAL
+// operations (s_waitcnt vmcnt(0)): in the first version of this kernel every barrier after a batch of lattice
+// atomics waited a full round trip to L2 for them, and the loads prefetched for the next brick would be waited
+// for as well.  Nothing here communicates through global memory inside a workgroup.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Round 2: persistent workgroups, software-pipelined over bricks.  A brick's inputs are a chain of three
+// dependent loads (brick table -> permutation -> gathered residual); one brick at a time the workgroup
+// idled through each of them and, at every barrier, through the acknowledgement of its atomics, and then
+// through two 27-tap loops of dependent LDS reads on a handful of lanes (the fused coarser levels): 13 us per
+// brick, 118 us per launch at C4 with six workgroups per CU.  Now
+//  * the table of brick k+3, the permutation of brick k+2 and the values of brick k+1 are in flight (in
+//    registers) while brick k is reduced in LDS.  The number of atomics is data dependent, so every wait of the
+//    compiler for a vector-memory result is a full drain (vmcnt(0), returns are counted in order): all global
+//    traffic of an iteration -- the atomics of the PREVIOUS brick, flushed from a second copy of its node sums,
+//    and the three prefetch stages -- is issued in one burst right after the single drain;
+//  * the fused levels are separable 3-tap passes (x, y, z) with all taps of a pass issued together, run by wave 0
+//    while the other waves already stage the next brick.
+template <int D> struct BrickNodes {
+  // node sums of a brick on the finest lattice and the fused coarser ones: 5^3 + 3^3 + 2^3 (9^2 + 5^2 + 3^2 + 2^2)
+  static constexpr int NLEV = D == 3 ? 3 : 4;
+  static constexpr int TOTAL = D == 3 ? 125 + 27 + 8 : 81 + 25 + 9 + 4;
+  __host__ __device__ static constexpr int offset(int lev) {
+    return D == 3 ? (lev == 0 ? 0 : (lev == 1 ? 125 : 152)) : (lev == 0 ? 0 : (lev == 1 ? 81 : (lev == 2 ? 106 : 115)));
+  }
+};
+
+// value of lane (l ^ 1) [quad_perm 1,0,3,2 = 0xB1] or (l ^ 2) [2,3,0,1 = 0x4E]: DPP moves, no LDS crossbar
+template <int CTRL>
+__device__ __forceinline__ double quad_xor(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false),
+                          __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false));
+}
+
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// coarse = R fine for one brick, R = tensor product of [1/2 1 1/2]; fine has (NF+1)^D nodes, coarse (NF/2+1)^D.
+// One wave; tmpA / tmpB hold the intermediate passes.
+template <int D, int NF>
+__device__ __forceinline__ void brick_restrict_level(const double* fine, double* coarse, double* tmpA, double* tmpB, int lane) {
+  constexpr int F1 = NF + 1, C1 = NF / 2 + 1;
+  constexpr int NYZ = D == 3 ? F1 * F1 : F1;
+  for (int o = lane; o < NYZ * C1; o += 64) {                 // x
+    const int J = o % C1, yz = o / C1, x = 2 * J;
+    const double* row = fine + yz * F1;
+    const double a = row[x];
+    const double l = x > 0 ? row[x - 1] : 0.0, r = x < NF ? row[x + 1] : 0.0;
+    tmpA[o] = a + 0.5 * (l + r);
+  }
+  wave_lds_sync();
+  constexpr int NZ = D == 3 ? F1 : 1;
+  double* dstY = D == 3 ? tmpB : coarse;
+  for (int o = lane; o < NZ * C1 * C1; o += 64) {             // y
+    const int Jx = o % C1, Jy = (o / C1) % C1, z = o / (C1 * C1), y = 2 * Jy;
+    const int base = (z * F1 + y) * C1 + Jx;
+    const double a = tmpA[base];
+    const double l = y > 0 ? tmpA[base - C1] : 0.0, r = y < NF ? tmpA[base + C1] : 0.0;
+    dstY[o] = a + 0.5 * (l + r);
+  }
+  wave_lds_sync();
+  if constexpr (D == 3) {
+    for (int o = lane; o < C1 * C1 * C1; o += 64) {           // z
+      const int Jz = o / (C1 * C1), rem = o % (C1 * C1), z = 2 * Jz;
+      const int base = z * C1 * C1 + rem;
+      const double a = tmpB[base];
+      const double l = z > 0 ? tmpB[base - C1 * C1] : 0.0, r = z < NF ? tmpB[base + C1 * C1] : 0.0;
+      coarse[o] = a + 0.5 * (l + r);
+    }
+    wave_lds_sync();
+  }
+}
+
+// one global atomic per non-zero node sum of a finished brick on level LEV (NF = bins per axis of the brick there)
+template <int D, int NF>
+__device__ __forceinline__ void brick_flush_level(const double* src, double* gl, const int (&ln)[3], int b0, int b1, int b2, int tid) {
+  constexpr int C1 = NF + 1;
+  constexpr int NCL = D == 3 ? C1 * C1 * C1 : C1 * C1;
+  for (int j = tid; j < NCL; j += FEMO_BLOCK) {
+    const double a = src[j];
+    const int J0 = j % C1, J1 = (j / C1) % C1, J2 = D == 3 ? j / (C1 * C1) : 0;
+    const int i0 = b0 + J0, i1 = b1 + J1, i2 = D == 3 ? b2 + J2 : 0;
+    if (a != 0.0 && i0 <= ln[0] && i1 <= ln[1] && i2 <= ln[2]) atomicAdd(&gl[node_index(ln, i0, i1, i2)], a);
+  }
+}
+
 template <int D>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks, const int64_t* __restrict__ brick_ptr,
                                                                 const int32_t* __restrict__ brick_base, const uint32_t* __restrict__ bin_ptr,
@@ -174,108 +260,188 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
                                                                 const double* __restrict__ w_sorted,
                                                                 double* __restrict__ g, int n_fused, const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
+  const int debug = n_fused >> 8;                   // FEMO_DEBUG_BRICKS (timing experiments only)
+  n_fused &= 0xFF;
   constexpr int B = Brick<D>::B, N1 = Brick<D>::N1, NLOC = Brick<D>::NLOC, NC = Brick<D>::NC;
-  __shared__ double acc[NLOC];
-  __shared__ double acc2[NLOC];
+  constexpr int PF = BRICK_CHUNK / FEMO_BLOCK;      // staged entries per thread and pass
+  constexpr int NTOT = BrickNodes<D>::TOTAL;
+  __shared__ double nodes[2][NTOT];
+  __shared__ double tmpA[128], tmpB[64];
   __shared__ double sval[BRICK_CHUNK];
   __shared__ float st[D][BRICK_CHUNK];          // 20-bit fractions are exact in fp32
   __shared__ double binsum[NC][64];
-  const int bin = threadIdx.x >> 2, sub = threadIdx.x & 3;   // 4 adjacent lanes share a bin
-  for (int64_t brick = blockIdx.x; brick < n_bricks; brick += gridDim.x) {
-    int base[3] = {brick_base[brick * 3], brick_base[brick * 3 + 1], brick_base[brick * 3 + 2]};
-    const int64_t start = brick_ptr[brick], end = brick_ptr[brick + 1];
-    const uint32_t* bp = bin_ptr + brick * 65;
-    const int64_t bin_lo = start + bp[bin], bin_hi = start + bp[bin + 1];
+  const int tid = threadIdx.x;
+  const int bin = tid >> 2, sub = tid & 3;      // 4 adjacent lanes share a bin
+  struct Meta { int64_t start, end; int b0, b1, b2; uint32_t lo, hi; };
+  auto load_meta = [&](int64_t brick) -> Meta {
+    Meta M;
+    const bool ok = brick < n_bricks;
+    const int64_t bk = ok ? brick : 0;
+    M.start = brick_ptr[bk];
+    M.end = ok ? brick_ptr[bk + 1] : M.start;   // beyond the last brick: empty
+    M.b0 = brick_base[bk * 3]; M.b1 = brick_base[bk * 3 + 1]; M.b2 = brick_base[bk * 3 + 2];
+    const uint32_t* bp = bin_ptr + bk * 65;
+    M.lo = bp[bin]; M.hi = bp[bin + 1];
+    return M;
+  };
+  // entries beyond the end of a brick are clamped to its last one (index 0 for the empty bricks past the end of
+  // the list) and get weight 0: no divergent branches around the loads
+  auto entry = [&](const Meta& M, int q, bool& live) -> int64_t {
+    const int64_t i = M.start + tid + q * FEMO_BLOCK;
+    live = i < M.end;
+    const int64_t last = M.end > 0 ? M.end - 1 : 0;
+    return live ? i : last;
+  };
+  auto load_perm = [&](const Meta& M, int32_t (&p)[PF]) {
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      bool live;
+      p[q] = perm[entry(M, q, live)];
+    }
+  };
+  auto load_vals = [&](const Meta& M, const int32_t (&p)[PF], double (&v)[PF], double (&w)[PF], uint32_t (&k)[PF][D]) {
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      bool live;
+      const int64_t i = entry(M, q, live);
+      v[q] = val[(debug & 4) ? i : (int64_t)p[q]];
+      const double ws = w_sorted[i];
+      w[q] = live ? ws : 0.0;
+#pragma unroll
+      for (int d = 0; d < D; ++d) k[q][d] = pk[i * D + d];
+    }
+  };
+  auto flush = [&](const double* nd, int b0, int b1, int b2) {
+    if (debug & 1) return;
+    double* gl = g;
+    int ln[3] = {lat.n[0], lat.n[1], lat.n[2]};
+    auto coarser = [&]() {
+      ln[0] >>= 1; ln[1] >>= 1; ln[2] >>= 1;
+      gl -= (int64_t)(ln[0] + 1) * (ln[1] + 1) * (ln[2] + 1);       // levels are stored coarsest first, contiguously
+    };
+    brick_flush_level<D, B>(nd, gl, ln, b0, b1, b2, tid);
+    if (n_fused >= 1) { coarser(); brick_flush_level<D, B / 2>(nd + BrickNodes<D>::offset(1), gl, ln, b0 >> 1, b1 >> 1, b2 >> 1, tid); }
+    if (n_fused >= 2) { coarser(); brick_flush_level<D, B / 4>(nd + BrickNodes<D>::offset(2), gl, ln, b0 >> 2, b1 >> 2, b2 >> 2, tid); }
+    if constexpr (D == 2) {
+      if (n_fused >= 3) { coarser(); brick_flush_level<D, B / 8>(nd + BrickNodes<D>::offset(3), gl, ln, b0 >> 3, b1 >> 3, b2 >> 3, tid); }
+    }
+  };
+  const int64_t G = gridDim.x;
+  Meta M0 = load_meta(blockIdx.x), M1 = load_meta(blockIdx.x + G), M2 = load_meta(blockIdx.x + 2 * G);
+  int32_t p0[PF], p1[PF];
+  load_perm(M0, p0);
+  load_perm(M1, p1);
+  double v0[PF], w0[PF];
+  uint32_t k0[PF][D];
+  load_vals(M0, p0, v0, w0, k0);
+  int cur = 0;
+  bool have_prev = false;
+  int pb0 = 0, pb1 = 0, pb2 = 0;
+  for (int64_t brick = blockIdx.x; brick < n_bricks; brick += G) {
+    const int base[3] = {M0.b0, M0.b1, M0.b2};
+    const int64_t start = M0.start, end = M0.end;
+    const int64_t bin_lo = start + M0.lo, bin_hi = start + M0.hi;
     double c[NC];
 #pragma unroll
     for (int q = 0; q < NC; ++q) c[q] = 0.0;
+    // (1) the one drain of the iteration: the values of this brick (everything older has landed with them)
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int j = tid + q * FEMO_BLOCK;
+      sval[j] = v0[q] * w0[q];
+#pragma unroll
+      for (int d = 0; d < D; ++d) st[d][j] = (float)(k0[q][d] & PK_MASK) * (1.0f / (float)(1u << PK_BITS));
+    }
+    lds_barrier();            // staging visible; wave 0 has finished the fused levels of the previous brick
+    // (2) all global traffic of the iteration in one burst: the previous brick's atomics ...
+    if (have_prev) flush(nodes[cur ^ 1], pb0, pb1, pb2);
+    // ... and the three prefetch stages (consumed one, two and three bricks later)
+    const Meta M3 = load_meta(brick + 3 * G);
+    int32_t p2[PF];
+    load_perm(M2, p2);
+    double v1[PF], w1[PF];
+    uint32_t k1[PF][D];
+    load_vals(M1, p1, v1, w1, k1);
+    // (3) LDS phases
     for (int64_t chunk = start; chunk < end; chunk += BRICK_CHUNK) {
       const int64_t chunk_end = chunk + BRICK_CHUNK < end ? chunk + BRICK_CHUNK : end;
-      __syncthreads();
-      for (int64_t i = chunk + threadIdx.x; i < chunk_end; i += FEMO_BLOCK) {
-        sval[i - chunk] = val[perm[i]] * w_sorted[i];
+      if (chunk > start) {                        // bricks above BRICK_CHUNK vertices (rare): unpipelined passes
+        lds_barrier();
+        for (int64_t i = chunk + tid; i < chunk_end; i += FEMO_BLOCK) {
+          sval[i - chunk] = val[perm[i]] * w_sorted[i];
 #pragma unroll
-        for (int k = 0; k < D; ++k) st[k][i - chunk] = (float)(pk[i * D + k] & PK_MASK) * (1.0f / (float)(1u << PK_BITS));
+          for (int k = 0; k < D; ++k) st[k][i - chunk] = (float)(pk[i * D + k] & PK_MASK) * (1.0f / (float)(1u << PK_BITS));
+        }
+        lds_barrier();
       }
-      __syncthreads();
       for (int64_t j = bin_lo + sub; j < bin_hi; j += 4) {
-        if (j < chunk || j >= chunk_end) continue;      // only bricks above BRICK_CHUNK vertices take a second pass
+        if (j < chunk || j >= chunk_end || (debug & 8)) continue;
         const double r = sval[j - chunk];
         double t[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) t[k] = (double)st[k][j - chunk];
+        // corner weights r * prod_k (t_k or 1 - t_k), built axis by axis
+        double w[NC];
+        w[0] = r;
 #pragma unroll
-        for (int q = 0; q < NC; ++q) {
-          double w = r;
+        for (int k = 0; k < D; ++k) {
 #pragma unroll
-          for (int k = 0; k < D; ++k) w *= ((q >> k) & 1) ? t[k] : 1.0 - t[k];
-          c[q] += w;
+          for (int q = (1 << k) - 1; q >= 0; --q) {
+            const double hi = w[q] * t[k];
+            w[q | (1 << k)] = hi;
+            w[q] = w[q] - hi;
+          }
         }
+#pragma unroll
+        for (int q = 0; q < NC; ++q) c[q] += w[q];
       }
     }
 #pragma unroll
     for (int q = 0; q < NC; ++q) {
       double v = c[q];
-      v += __shfl_xor(v, 1, 64);
-      v += __shfl_xor(v, 2, 64);
+      v += quad_xor<0xB1>(v);                     // lanes 4b .. 4b+3 hold the partial sums of bin b
+      v += quad_xor<0x4E>(v);
       if (sub == 0) binsum[q][bin] = v;
     }
-    __syncthreads();
-    for (int j = threadIdx.x; j < NLOC; j += FEMO_BLOCK) {
+    lds_barrier();
+    double* nd = nodes[cur];
+    for (int j = tid; j < NLOC; j += FEMO_BLOCK) {
       const int J[3] = {j % N1, (j / N1) % N1, D == 3 ? j / (N1 * N1) : 0};
       double a = 0.0;
 #pragma unroll
       for (int q = 0; q < NC; ++q) {
         // the bin for which this node is corner q
         const int b0 = J[0] - (q & 1), b1 = J[1] - ((q >> 1) & 1), b2 = D == 3 ? J[2] - ((q >> 2) & 1) : 0;
-        if (b0 < 0 || b0 >= B || b1 < 0 || b1 >= B || b2 < 0 || (D == 3 && b2 >= B)) continue;
-        a += binsum[q][D == 3 ? (b2 * B + b1) * B + b0 : b1 * B + b0];
+        const bool in = !(b0 < 0 || b0 >= B || b1 < 0 || b1 >= B || b2 < 0 || (D == 3 && b2 >= B));
+        const double t = in ? binsum[q][D == 3 ? (b2 * B + b1) * B + b0 : b1 * B + b0] : 0.0;
+        a += t;
       }
-      acc[j] = a;
-      if (a != 0.0) {
-        const int i0 = base[0] + J[0], i1 = base[1] + J[1], i2 = D == 3 ? base[2] + J[2] : 0;
-        if (i0 <= lat.n[0] && i1 <= lat.n[1] && i2 <= lat.n[2]) atomicAdd(&g[node_index(lat.n, i0, i1, i2)], a);
+      nd[j] = a;
+    }
+    lds_barrier();
+    // the next n_fused coarser lattices straight from the LDS copy (the brick starts on a multiple of B bins, so
+    // its nodes' parents on those levels are its own corner/edge/face nodes): wave 0, the others move on
+    if (tid < 64 && !(debug & 2)) {
+      if (n_fused >= 1) brick_restrict_level<D, B>(nd, nd + BrickNodes<D>::offset(1), tmpA, tmpB, tid);
+      if (n_fused >= 2) brick_restrict_level<D, B / 2>(nd + BrickNodes<D>::offset(1), nd + BrickNodes<D>::offset(2), tmpA, tmpB, tid);
+      if constexpr (D == 2) {
+        if (n_fused >= 3) brick_restrict_level<D, B / 4>(nd + BrickNodes<D>::offset(2), nd + BrickNodes<D>::offset(3), tmpA, tmpB, tid);
       }
     }
-    // the next n_fused coarser lattices straight from the LDS copy: the brick starts on a multiple
-    // of B bins, so its nodes' parents on those levels are its own corner/edge/face nodes
-    double* fine = acc;
-    double* coarse = acc2;
-    double* gl = g;
-    int nfine = B, ln[3] = {lat.n[0], lat.n[1], lat.n[2]};
-    for (int lev = 1; lev <= n_fused; ++lev) {
-      const int nc = nfine >> 1, f1 = nfine + 1, c1 = nc + 1;
-      const int ncl = D == 3 ? c1 * c1 * c1 : c1 * c1;
-      int cn[3] = {ln[0] >> 1, ln[1] >> 1, ln[2] >> 1};
-      const int64_t coarse_nodes = (int64_t)(cn[0] + 1) * (cn[1] + 1) * (cn[2] + 1);
-      gl -= coarse_nodes;                       // levels are stored coarsest first, contiguously
-      __syncthreads();
-      for (int j = threadIdx.x; j < ncl; j += FEMO_BLOCK) {
-        const int J[3] = {j % c1, (j / c1) % c1, D == 3 ? j / (c1 * c1) : 0};
-        double a = 0.0;
-        for (int dz = (D == 3 ? -1 : 0); dz <= (D == 3 ? 1 : 0); ++dz) {
-          const int fz = D == 3 ? 2 * J[2] + dz : 0;
-          if (fz < 0 || fz > nfine) continue;
-          for (int dy = -1; dy <= 1; ++dy) {
-            const int fy = 2 * J[1] + dy;
-            if (fy < 0 || fy > nfine) continue;
-            for (int dx = -1; dx <= 1; ++dx) {
-              const int fx = 2 * J[0] + dx;
-              if (fx < 0 || fx > nfine) continue;
-              const double w = (dx ? 0.5 : 1.0) * (dy ? 0.5 : 1.0) * (dz ? 0.5 : 1.0);
-              a += w * fine[(D == 3 ? fz * f1 * f1 : 0) + fy * f1 + fx];
-            }
-          }
-        }
-        coarse[j] = a;
-        const int i0 = (base[0] >> lev) + J[0], i1 = (base[1] >> lev) + J[1], i2 = D == 3 ? (base[2] >> lev) + J[2] : 0;
-        if (a != 0.0 && i0 <= cn[0] && i1 <= cn[1] && i2 <= cn[2]) atomicAdd(&gl[node_index(cn, i0, i1, i2)], a);
-      }
-      double* t = fine; fine = coarse; coarse = t;
-      nfine = nc; ln[0] = cn[0]; ln[1] = cn[1]; ln[2] = cn[2];
+    // rotate the pipeline
+    have_prev = true; pb0 = base[0]; pb1 = base[1]; pb2 = base[2];
+    cur ^= 1;
+    M0 = M1; M1 = M2; M2 = M3;
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      p1[q] = p2[q];
+      v0[q] = v1[q]; w0[q] = w1[q];
+#pragma unroll
+      for (int d = 0; d < D; ++d) k0[q][d] = k1[q][d];
     }
-    __syncthreads();
   }
+  lds_barrier();
+  if (have_prev) flush(nodes[cur ^ 1], pb0, pb1, pb2);
 }
 
 // zh = rh + (1/s) P_L e_L, delivered as
@@ -784,6 +950,20 @@ __global__ __launch_bounds__(1024) void k_fold_partials(int nb, const double* __
   if (threadIdx.x == 0) out[0] = t;
 }
 
+// resident workgroups of the persistent brick kernel per CU (registers and LDS decide; asked once)
+static int bricks_per_cu(int dim) {
+  static int cached[2] = {0, 0};
+  int& c = cached[dim == 3 ? 1 : 0];
+  if (c == 0) {
+    int nb = 0;
+    hipError_t e = dim == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_restrict_bricks<3>, FEMO_BLOCK, 0)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_restrict_bricks<2>, FEMO_BLOCK, 0);
+    c = (e == hipSuccess && nb > 0) ? nb : 3;
+    if (const char* env = getenv("FEMO_BRICKS_PER_CU")) c = std::max(1, atoi(env));
+  }
+  return c;
+}
+
 // Which finest-lattice nodes do several ranks touch?  A rank's restriction only reaches the nodes
 // around its own vertices and its prolongation only reads those, so between ranks it is enough to
 // complete the sums on the nodes that more than one rank touches (the layers along the partition
@@ -804,7 +984,7 @@ static int pc_setup_shared(femo_mesh* m) {
   hipLaunchKernelGGL(k_fill_ones, dim3(lat_grid(m->n_rows)), dim3(256), 0, st, std::max<int64_t>(m->n_rows, 0), pc->d_w_sorted);
   FEMO_HIP_CHECK(hipMemsetAsync(F.g, 0, F.nodes * sizeof(double), st));
   if (pc->n_bricks > 0) {
-    const unsigned gb = (unsigned)std::min<int64_t>(pc->n_bricks, 256 * 64);
+    const unsigned gb = (unsigned)std::min<int64_t>(pc->n_bricks, (int64_t)ctx->n_cu * bricks_per_cu(pc->dim));
     if (pc->dim == 3)
       hipLaunchKernelGGL(k_restrict_bricks<3>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, ones, pc->d_w_sorted, F.g, 0, (const int32_t*)nullptr);
     else
@@ -901,11 +1081,12 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
   double* gF = G(nl - 1, par);
   // g of the finest nf+1 levels: zero on entry (femo_pc_begin, then the prolongation kernels clean up)
   if (pc->n_bricks > 0) {
-    const unsigned gb = (unsigned)std::min<int64_t>(pc->n_bricks, 256 * 64);
+    const unsigned gb = (unsigned)std::min<int64_t>(pc->n_bricks, (int64_t)ctx->n_cu * bricks_per_cu(pc->dim));
+    static const int dbg = getenv("FEMO_DEBUG_BRICKS") ? atoi(getenv("FEMO_DEBUG_BRICKS")) << 8 : 0;
     if (pc->dim == 3)
-      hipLaunchKernelGGL(k_restrict_bricks<3>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, rh, pc->d_w_sorted, gF, nf, done);
+      hipLaunchKernelGGL(k_restrict_bricks<3>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, rh, pc->d_w_sorted, gF, nf | dbg, done);
     else
-      hipLaunchKernelGGL(k_restrict_bricks<2>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, rh, pc->d_w_sorted, gF, nf, done);
+      hipLaunchKernelGGL(k_restrict_bricks<2>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, rh, pc->d_w_sorted, gF, nf | dbg, done);
   }
   const bool sparse = ctx->nranks > 1 && pc->shared_ready;
   if (sparse) {

@@ -28,6 +28,7 @@ E.assemble_system(dm, 0, None, u0, f, bc, J, A, None)          # dR/du + A
 E.assemble_residual(dm, 0, None, u0, f, r)
 E.functional_grad_u(dm, 0, [1e-6], u0, f, Vec(ctx, n).fill(1.0), g)
 x = Vec(ctx, n)
-info = A.solve_cg(b, x, rtol=1e-14, max_it=3, pc="bpx", check_every=3)
+MAX_IT = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+info = A.solve_cg(b, x, rtol=1e-14, max_it=MAX_IT, pc="bpx", check_every=MAX_IT)
 ctx.sync()
 print("iterations", info.iterations)
