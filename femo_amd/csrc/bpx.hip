@@ -557,23 +557,35 @@ __device__ __forceinline__ double lattice_restrict_node(int64_t idx, const int* 
   const int i = (int)(idx % (nc[0] + 1));
   const int j = (int)((idx / (nc[0] + 1)) % (nc[1] + 1));
   const int k = (int)(idx / ((int64_t)(nc[0] + 1) * (nc[1] + 1)));
+  // branch-free: out-of-range taps read a clamped node with weight 0, so all 9 / 27 reads are issued together
+  // (with `continue` around them they were a chain of dependent round trips)
   double acc = 0.0;
-  const int kz0 = dim == 3 ? -1 : 0, kz1 = dim == 3 ? 1 : 0;
-  for (int dz = kz0; dz <= kz1; ++dz) {
-    const int fk = dim == 3 ? 2 * k + dz : 0;
-    if (fk < 0 || fk > nf[2]) continue;
-    const double wz = dz == 0 ? 1.0 : 0.5;
-    for (int dy = -1; dy <= 1; ++dy) {
-      const int fj = 2 * j + dy;
-      if (fj < 0 || fj > nf[1]) continue;
-      const double wy = dy == 0 ? 1.0 : 0.5;
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int fi = 2 * i + dx;
-        if (fi < 0 || fi > nf[0]) continue;
-        const double wx = dx == 0 ? 1.0 : 0.5;
-        acc += wx * wy * wz * fine[node_index(nf, fi, fj, fk)];
-      }
+  if (dim == 3) {
+    double v[27], w[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      const int dx = t % 3 - 1, dy = (t / 3) % 3 - 1, dz = t / 9 - 1;
+      const int fi = 2 * i + dx, fj = 2 * j + dy, fk = 2 * k + dz;
+      const bool in = fi >= 0 && fi <= nf[0] && fj >= 0 && fj <= nf[1] && fk >= 0 && fk <= nf[2];
+      const int ci = min(max(fi, 0), nf[0]), cj = min(max(fj, 0), nf[1]), ck = min(max(fk, 0), nf[2]);
+      w[t] = in ? (dx ? 0.5 : 1.0) * (dy ? 0.5 : 1.0) * (dz ? 0.5 : 1.0) : 0.0;
+      v[t] = fine[node_index(nf, ci, cj, ck)];
     }
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc += w[t] * v[t];
+  } else {
+    double v[9], w[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int dx = t % 3 - 1, dy = t / 3 - 1;
+      const int fi = 2 * i + dx, fj = 2 * j + dy;
+      const bool in = fi >= 0 && fi <= nf[0] && fj >= 0 && fj <= nf[1];
+      const int ci = min(max(fi, 0), nf[0]), cj = min(max(fj, 0), nf[1]);
+      w[t] = in ? (dx ? 0.5 : 1.0) * (dy ? 0.5 : 1.0) : 0.0;
+      v[t] = fine[node_index(nf, ci, cj, 0)];
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc += w[t] * v[t];
   }
   return acc;
 }
@@ -645,41 +657,84 @@ struct CoarseLevels {
   int64_t nodes[FEMO_PC_MAX_LEVELS];
   int64_t off[FEMO_PC_MAX_LEVELS];     // LDS offset (doubles) of level l: g at off, e at off + nodes
   int emit_top;                        // also e_top = coef_top g_top + I e_{top-1} (global), g_top cleared: the level the
-};                                     // brick kernel filled, so that no multi-block restriction / prolongation touches it
+                                       // brick kernel filled, so that no multi-block restriction / prolongation touches it
+  int top_in_lds;                      // g_top is copied to LDS at off[top] first (<= 4096 nodes and room for it)
+};
 
 __global__ __launch_bounds__(1024) void k_lattice_coarse(CoarseLevels L, int dim, const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
   // g and e of the levels below `top` live in LDS for the whole launch (a few thousand nodes);
-  // only e_{top-1}, which the next prolongation reads, goes back to global memory
+  // only e_{top-1}, which the next prolongation reads, goes back to global memory.
+  // Round 2: every global read of the launch is issued before the first LDS phase -- g_top goes to LDS with
+  // coalesced loads (the 27-point restriction read it from global memory: 27 dependent L2 round trips per
+  // thread, most of the 15.7 us the launch took), the coefficients of all levels wait in registers -- and the
+  // barriers order LDS only, so no phase waits for the stores of the one before.
   extern __shared__ double coarse_lds[];
   const int top = L.n_levels;
+  const int tid = threadIdx.x;
+  constexpr int TOPR = 4;                           // g_top / coef_top entries per thread kept in registers
+  const int64_t n_top = L.nodes[top];
+  double* g_top_lds = coarse_lds + L.off[top];      // the host reserves nodes[top] doubles there when they fit
+  const bool top_in_lds = L.top_in_lds != 0;
+  double gt[TOPR], ct[TOPR];
+  if (top_in_lds) {
+#pragma unroll
+    for (int q = 0; q < TOPR; ++q) {
+      const int64_t idx = tid + q * 1024;
+      gt[q] = idx < n_top ? L.g[top][idx] : 0.0;
+      ct[q] = (L.emit_top && idx < n_top) ? L.coef[top][idx] : 0.0;
+    }
+  }
+  // coefficient of level l at node tid (levels with <= 1024 nodes), fetched one phase ahead
+  auto coef_of = [&](int l) -> double { return (l < top && L.nodes[l] <= 1024 && tid < L.nodes[l]) ? L.coef[l][tid] : 0.0; };
+  double c_cur = coef_of(0);
+  if (top_in_lds) {
+#pragma unroll
+    for (int q = 0; q < TOPR; ++q) {
+      const int64_t idx = tid + q * 1024;
+      if (idx < n_top) g_top_lds[idx] = gt[q];
+    }
+    lds_barrier();
+  }
   for (int l = top - 1; l >= 0; --l) {
-    const int64_t total = (int64_t)(L.n[l][0] + 1) * (L.n[l][1] + 1) * (L.n[l][2] + 1);
-    const double* fine = l + 1 == top ? L.g[top] : coarse_lds + L.off[l + 1];
+    const int64_t total = L.nodes[l];
+    const double* fine = l + 1 == top ? (top_in_lds ? g_top_lds : L.g[top]) : coarse_lds + L.off[l + 1];
     double* gl = coarse_lds + L.off[l];
-    for (int64_t idx = threadIdx.x; idx < total; idx += 1024) gl[idx] = lattice_restrict_node(idx, L.n[l], L.n[l + 1], dim, fine);
-    __syncthreads();
+    for (int64_t idx = tid; idx < total; idx += 1024) gl[idx] = lattice_restrict_node(idx, L.n[l], L.n[l + 1], dim, fine);
+    lds_barrier();
   }
   for (int l = 0; l < top; ++l) {
-    const int64_t total = (int64_t)(L.n[l][0] + 1) * (L.n[l][1] + 1) * (L.n[l][2] + 1);
+    const int64_t total = L.nodes[l];
     const double* gl = coarse_lds + L.off[l];
     double* el = coarse_lds + L.off[l] + L.nodes[l];
     const double* ec = l > 0 ? coarse_lds + L.off[l - 1] + L.nodes[l - 1] : nullptr;
-    for (int64_t idx = threadIdx.x; idx < total; idx += 1024) {
-      double v = L.coef[l][idx] * gl[idx];
+    const double c_nxt = coef_of(l + 1);
+    for (int64_t idx = tid; idx < total; idx += 1024) {
+      double v = (total <= 1024 ? c_cur : L.coef[l][idx]) * gl[idx];
       if (l > 0) v += lattice_interp_node(idx, L.n[l], L.n[l - 1], dim, ec);
       el[idx] = v;
       if (l == top - 1 && !L.emit_top) L.e[l][idx] = v;
     }
-    __syncthreads();
+    c_cur = c_nxt;
+    lds_barrier();
   }
   if (L.emit_top) {
-    const int64_t total = (int64_t)(L.n[top][0] + 1) * (L.n[top][1] + 1) * (L.n[top][2] + 1);
     const double* ec = coarse_lds + L.off[top - 1] + L.nodes[top - 1];
-    for (int64_t idx = threadIdx.x; idx < total; idx += 1024) {
-      const double gi = L.g[top][idx];
-      L.g[top][idx] = 0.0;                          // every restriction read of it happened before the barriers above
-      L.e[top][idx] = L.coef[top][idx] * gi + lattice_interp_node(idx, L.n[top], L.n[top - 1], dim, ec);
+    if (top_in_lds) {
+#pragma unroll
+      for (int q = 0; q < TOPR; ++q) {
+        const int64_t idx = tid + q * 1024;
+        if (idx < n_top) {
+          L.g[top][idx] = 0.0;                      // every restriction read of it came from the LDS copy
+          L.e[top][idx] = ct[q] * gt[q] + lattice_interp_node(idx, L.n[top], L.n[top - 1], dim, ec);
+        }
+      }
+    } else {
+      for (int64_t idx = tid; idx < n_top; idx += 1024) {
+        const double gi = L.g[top][idx];
+        L.g[top][idx] = 0.0;                        // every restriction read of it happened before the barriers above
+        L.e[top][idx] = L.coef[top][idx] * gi + lattice_interp_node(idx, L.n[top], L.n[top - 1], dim, ec);
+      }
     }
   }
 }
@@ -730,65 +785,99 @@ __global__ __launch_bounds__(256) void k_lattice_prolong3(FineLevels P, const in
 #pragma unroll
       for (int k = 0; k < D; ++k) { lo[k] = (int)(t % tn[k]) * TF; t /= tn[k]; mlo[k] = lo[k] >> 1; clo[k] = lo[k] >> 2; }
     }
-    for (int p = threadIdx.x; p < NC; p += 256) {
+    // Round 2: all global reads of the tile are issued before the first LDS phase and the barriers order LDS only
+    // (three dependent round trips and three store drains per tile before: 19 us per launch at C4).
+    static_assert(NC <= 256 && NM <= 256, "one patch node per thread");
+    constexpr int NQ = NT / 256;
+    const int p = threadIdx.x;
+    // level c (coarsest of the three): coef, g and the eight parents on level cc
+    bool c_in = false, c_own = true;
+    int64_t c_idx = 0;
+    double c_coef = 0.0, c_g = 0.0, c_par = 0.0;
+    if (p < NC) {
       int ci[3] = {0, 0, 0};
       int q = p;
-      bool inside = true, owned = true;
+      c_in = true;
 #pragma unroll
       for (int k = 0; k < D; ++k) {
         const int pk = q % TC; q /= TC;
         ci[k] = clo[k] + pk;
-        inside = inside && ci[k] <= P.nc[k];
-        owned = owned && pk < TF / 4;                                   // fine node 4 ci lies in this tile
+        c_in = c_in && ci[k] <= P.nc[k];
+        c_own = c_own && pk < TF / 4;                                   // fine node 4 ci lies in this tile
       }
-      double v = 0.0;
-      if (inside) {
-        const int64_t idx = node_index(P.nc, ci[0], ci[1], ci[2]);
-        v = P.coef_c[idx] * P.g_c[idx] + lattice_interp_node(idx, P.nc, P.ncc, D, P.e_cc);
-        if (owned) P.g_c_other[idx] = 0.0;
+      if (c_in) {
+        c_idx = node_index(P.nc, ci[0], ci[1], ci[2]);
+        c_coef = P.coef_c[c_idx];
+        c_g = P.g_c[c_idx];
+        c_par = lattice_interp_node(c_idx, P.nc, P.ncc, D, P.e_cc);
       }
-      ec[p] = v;
     }
-    __syncthreads();
-    for (int p = threadIdx.x; p < NM; p += 256) {
-      int mi[3] = {0, 0, 0};
+    // level m
+    bool m_in = false, m_own = true;
+    int64_t m_idx = 0;
+    int mi[3] = {0, 0, 0};
+    double m_coef = 0.0, m_g = 0.0;
+    if (p < NM) {
       int q = p;
-      bool inside = true, owned = true;
+      m_in = true;
 #pragma unroll
       for (int k = 0; k < D; ++k) {
         const int pk = q % TM; q /= TM;
         mi[k] = mlo[k] + pk;
-        inside = inside && mi[k] <= P.nm[k];
-        owned = owned && pk < TF / 2;                                   // fine node 2 mi lies in this tile
+        m_in = m_in && mi[k] <= P.nm[k];
+        m_own = m_own && pk < TF / 2;                                   // fine node 2 mi lies in this tile
       }
-      double v = 0.0;
-      if (inside) {
-        const int64_t idx = node_index(P.nm, mi[0], mi[1], mi[2]);
-        v = P.coef_m[idx] * P.g_m[idx] + from_patch(ec, TC, mi, clo);
-        if (owned) P.g_m_other[idx] = 0.0;
+      if (m_in) {
+        m_idx = node_index(P.nm, mi[0], mi[1], mi[2]);
+        m_coef = P.coef_m[m_idx];
+        m_g = P.g_m[m_idx];
       }
-      em[p] = v;
     }
-    __syncthreads();
-    for (int q0 = threadIdx.x; q0 < NT; q0 += 256) {
-      int fi[3] = {0, 0, 0};
-      int q = q0;
-      bool inside = true;
+    // finest level
+    bool f_in[NQ];
+    int64_t f_idx[NQ];
+    int fi[NQ][3];
+    double f_g[NQ], f_coef[NQ], f_w[NQ];
+#pragma unroll
+    for (int r = 0; r < NQ; ++r) {
+      int q = p + r * 256;
+      f_in[r] = true;
+      fi[r][0] = fi[r][1] = fi[r][2] = 0;
 #pragma unroll
       for (int k = 0; k < D; ++k) {
         const int qk = q % TF; q /= TF;
-        fi[k] = lo[k] + qk;
-        inside = inside && fi[k] <= P.nf[k];
+        fi[r][k] = lo[k] + qk;
+        f_in[r] = f_in[r] && fi[r][k] <= P.nf[k];
       }
-      if (!inside) continue;
-      const int64_t idx = node_index(P.nf, fi[0], fi[1], fi[2]);
-      const double gi = P.g_f[idx];
-      P.g_f[idx] = 0.0;
-      const double v = P.coef_f[idx] * gi + from_patch(em, TM, fi, mlo);
-      P.e_f[idx] = v;
-      dot += P.dot_weight != nullptr ? gi * v * P.dot_weight[idx] : gi * v;
+      f_idx[r] = 0; f_g[r] = 0.0; f_coef[r] = 0.0; f_w[r] = 1.0;
+      if (f_in[r]) {
+        f_idx[r] = node_index(P.nf, fi[r][0], fi[r][1], fi[r][2]);
+        f_g[r] = P.g_f[f_idx[r]];
+        f_coef[r] = P.coef_f[f_idx[r]];
+        if (P.dot_weight != nullptr) f_w[r] = P.dot_weight[f_idx[r]];
+      }
     }
-    __syncthreads();
+    // LDS phases
+    if (p < NC) {
+      ec[p] = c_in ? c_coef * c_g + c_par : 0.0;
+      if (c_in && c_own) P.g_c_other[c_idx] = 0.0;
+    }
+    lds_barrier();
+    if (p < NM) {
+      em[p] = m_in ? m_coef * m_g + from_patch(ec, TC, mi, clo) : 0.0;
+      if (m_in && m_own) P.g_m_other[m_idx] = 0.0;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < NQ; ++r) {
+      if (!f_in[r]) continue;
+      const double gi = f_g[r];
+      P.g_f[f_idx[r]] = 0.0;
+      const double v = f_coef[r] * gi + from_patch(em, TM, fi[r], mlo);
+      P.e_f[f_idx[r]] = v;
+      dot += P.dot_weight != nullptr ? gi * v * f_w[r] : gi * v;
+    }
+    lds_barrier();
   }
   if (P.dot_partials != nullptr) {
     const double t = femo_block_sum<256>(dot, red);
@@ -1132,7 +1221,9 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
       CL.nodes[l] = pc->L[l].nodes;
       CL.off[l] = l == 0 ? 0 : CL.off[l - 1] + 2 * CL.nodes[l - 1];
     }
-    const size_t lds = (size_t)below * 2 * sizeof(double);
+    size_t lds = (size_t)below * 2 * sizeof(double);
+    CL.top_in_lds = (CL.nodes[T - 1] <= 4096 && lds + (size_t)CL.nodes[T - 1] * sizeof(double) <= 150 * 1024) ? 1 : 0;
+    if (CL.top_in_lds) lds += (size_t)CL.nodes[T - 1] * sizeof(double);
     if (lds > 64 * 1024 && !pc->coarse_lds_set) {
       FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_coarse, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       pc->coarse_lds_set = true;
@@ -1183,7 +1274,9 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
         CL.nodes[l] = pc->L[l].nodes;
         CL.off[l] = l == 0 ? 0 : CL.off[l - 1] + 2 * CL.nodes[l - 1];
       }
-      const size_t lds = (size_t)coarse_total * 2 * sizeof(double);
+      size_t lds = (size_t)coarse_total * 2 * sizeof(double);
+      CL.top_in_lds = (CL.nodes[cut] <= 4096 && lds + (size_t)CL.nodes[cut] * sizeof(double) <= 150 * 1024) ? 1 : 0;
+      if (CL.top_in_lds) lds += (size_t)CL.nodes[cut] * sizeof(double);
       if (lds > 64 * 1024 && !pc->coarse_lds_set) {
         FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_coarse, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         pc->coarse_lds_set = true;
