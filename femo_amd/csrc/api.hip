@@ -337,7 +337,7 @@ int femo_mesh_destroy(femo_mesh* m) {
   hipFree(m->d_x); hipFree(m->d_conn); hipFree(m->d_vptr); hipFree(m->d_visit_cell);
   hipFree(m->d_visit_slots); hipFree(m->d_mptr); hipFree(m->d_cols); hipFree(m->d_rowlen);
   femo_pc_destroy(m);
-  hipFree(m->d_bvmask); hipFree(m->d_visit_rec); hipFree(m->d_load);
+  hipFree(m->d_bvmask); hipFree(m->d_visit_rec); hipFree(m->d_load); hipFree(m->d_pipe_dummy); hipFree(m->d_ubc);
   hipFree(m->d_sdelta); hipFree(m->d_bfacets); hipFree(m->d_tperm); hipFree(m->d_send_idx); hipFree(m->d_send_buf); hipFree(m->d_scratch); hipFree(m->d_slices_int); hipFree(m->d_slices_bnd);
   delete m;
   return 0;

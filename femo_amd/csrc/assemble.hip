@@ -1065,6 +1065,225 @@ __global__ __launch_bounds__(64) void k_poisson_system_lds(
   if (want_rhs && valid) rhs[row] = row_bc ? (u[row] - bcval[row]) : (racc + lift);
 }
 
+// ------------------------- linear Poisson, persistent waves pipelined over slices ---
+// k_poisson_system_lds spends a slice in three phases that nothing overlaps -- gather the neighbourhood (0.4 ms of
+// the 2.0-2.2 ms at C4), walk the incidence (0.85 ms), write the rows (0.9 ms, with 16 gathers of u per row for
+// the right-hand side) -- because 28-32 KB of LDS per wave leave ~one wave per SIMD, and a SIMD whose only wave
+// waits is idle.  Here a wave keeps its SIMD and walks a contiguous range of slices: the slice table of slice
+// s+3, the column indices of slice s+2 and the neighbourhood (coordinates, u) + row data of slice s+1 are in
+// flight in registers while slice s is walked.
+//
+// What shapes the loop is the wait counter: vector loads AND stores share vmcnt on gfx9, returns are counted in
+// order, and the compiler can only wait for "all but the N youngest" when N is known at compile time -- after a
+// data-dependent number of memory instructions every wait is a full drain, including stores issued a moment ago
+// and prefetches that were meant to fly.  Therefore (a) every vector-memory instruction of an iteration is
+// unconditional: columns are always read from the column array (not from the scalar deltas of regular slices),
+// the flags are template parameters, entries beyond the slice width and lanes beyond n_rows store into a dummy
+// line, and the Dirichlet lifting needs no conditional gather because the kernel reads u' = u with the prescribed
+// values imposed (K u' = K u + K[:,bc](g - u)); (b) the order within an iteration is
+//     drain (only the prefetch issued a whole walk ago is outstanding) -> neighbourhood of slice s to LDS
+//     -> first records of slice s -> rows of slice s-1 out (stores, never waited for) -> prefetch for s+1 -> walk s.
+// Off-diagonals are accumulated with ds_add_f64 (per-lane addresses: conflict-free, nothing to wait for).
+// Same arithmetic and order of accumulation as the other two kernels; the right-hand side sums K u' in one sum
+// instead of K u and the lifting separately (differs in the last bits).
+__global__ void k_impose_bc(int64_t n, const double* __restrict__ u, const uint8_t* __restrict__ bcmask,
+                            const double* __restrict__ bcval, double* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (bcmask != nullptr && bcmask[i]) ? bcval[i] : u[i];
+}
+
+template <int D, int NB, bool WANT_RHS, bool HAS_V0, bool HAS_V1, bool LDS_ATOMIC, bool HAVE_BC = true>
+__global__ __launch_bounds__(64) void k_poisson_system_pipe(
+    int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ vptr, const P1Rec* __restrict__ visit_rec,
+    const int64_t* __restrict__ mptr, const int32_t* __restrict__ cols, const int32_t* __restrict__ rowlen,
+    const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ ubc,
+    const double* __restrict__ load, const double* __restrict__ bcval,
+    double* __restrict__ diag0, double* __restrict__ vals0, double* __restrict__ diag1, double* __restrict__ vals1,
+    double* __restrict__ rhs, const uint64_t* __restrict__ bc_rowmask, double* __restrict__ dummy) {
+  constexpr int CH = 8;
+  extern __shared__ double lds_row[];
+  double* strip = lds_row;                       // [NB][64]
+  double* nx = lds_row + NB * 64;                // [NB][D][64]
+  const int lane = threadIdx.x;
+  const int64_t w = femo_xcd_block(blockIdx.x, gridDim.x);
+  const int64_t per = (n_slices + gridDim.x - 1) / gridDim.x;
+  const int64_t s_begin = w * per, s_end = s_begin + per < n_slices ? s_begin + per : n_slices;
+  if (s_begin >= s_end) return;
+  struct Meta { int64_t vb, mb; int nvis, wm; };
+  auto clamp_slice = [&](int64_t sl) -> int64_t { return sl < n_slices ? sl : n_slices - 1; };
+  auto load_meta = [&](int64_t sl) -> Meta {
+    const int64_t sc = clamp_slice(sl);
+    Meta M;
+    M.vb = vptr[sc]; M.nvis = (int)((vptr[sc + 1] - M.vb) >> 6);
+    M.mb = mptr[sc]; M.wm = (int)((mptr[sc + 1] - M.mb) >> 6);
+    return M;
+  };
+  auto load_cols = [&](const Meta& M, uint32_t (&c)[NB]) {
+    const int32_t* cs = cols + M.mb;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const int kk = k < M.wm ? k : M.wm - 1;                   // wave-uniform clamp
+      c[k] = (uint32_t)ldg32<int32_t>(cs, ((uint32_t)(kk >> 1) * 128u + (uint32_t)lane * 2u + (uint32_t)(kk & 1)) * 4u);
+    }
+  };
+  auto load_nbhd = [&](const uint32_t (&c)[NB], double (&px)[NB][D], double (&pu)[NB]) {
+#pragma unroll
+    for (int k = 0; k < NB; ++k) ldg_point<D>(x, c[k], px[k]);
+    if constexpr (WANT_RHS) {
+#pragma unroll
+      for (int k = 0; k < NB; ++k) pu[k] = ldg32<double>(ubc, c[k] * 8u);
+    }
+  };
+  struct RowData { double xo[D]; double ld, ur, gr; uint64_t rmask; int len; };
+  auto load_row = [&](int64_t sl) -> RowData {
+    const int64_t row = clamp_slice(sl) * 64 + lane;
+    const int64_t r0 = row < n_rows ? row : 0;
+    RowData R;
+    R.len = rowlen[row];
+    ldg_point<D>(x, (uint32_t)r0, R.xo);
+    R.rmask = 0;
+    if constexpr (HAVE_BC) R.rmask = bc_rowmask[row];
+    R.ld = 0.0; R.ur = 0.0; R.gr = 0.0;
+    if constexpr (WANT_RHS) { R.ld = load[r0]; R.ur = u[r0]; }
+    if constexpr (WANT_RHS && HAVE_BC) R.gr = bcval[r0];
+    return R;
+  };
+  typedef int femo_i4 __attribute__((ext_vector_type(4)));
+  auto fetch = [&](const Meta& M, int v) -> femo_i4 {
+    const int sc = v < M.nvis ? v : (M.nvis > 0 ? M.nvis - 1 : 0);
+    return ldg32<femo_i4>(visit_rec + M.vb, (uint32_t)(sc * 64 + lane) * 16u);
+  };
+  double* const my_dummy = dummy + lane * 2;
+
+  Meta M0 = load_meta(s_begin), M1 = load_meta(s_begin + 1), M2 = load_meta(s_begin + 2);
+  uint32_t c0[NB], c1[NB];
+  double px[NB][D], pu[NB];
+  load_cols(M0, c0);
+  load_cols(M1, c1);
+  load_nbhd(c0, px, pu);
+  RowData R0 = load_row(s_begin);
+  // state of the slice whose rows are still to be written (none before the first iteration)
+  bool have_prev = false;
+  int64_t prev_row = 0, prev_mb = 0;
+  int prev_wm = 0;
+  double prev_dsum = 0.0;
+  double cu_prev[NB];
+  RowData Rp = R0;
+#pragma unroll
+  for (int k = 0; k < NB; ++k) cu_prev[k] = 0.0;
+
+  auto rows_out = [&](int64_t row, int64_t mb, int wm, double dsum, const RowData& R, const double (&cu)[NB]) {
+    const bool valid = row < n_rows;
+    const bool row_bc = valid && (R.rmask >> 63) != 0;
+    if constexpr (HAS_V0) diag0[row] = valid ? dsum : 1.0;       // the diagonal arrays are padded to whole slices
+    if constexpr (HAS_V1) diag1[row] = (valid && !row_bc) ? dsum : 1.0;
+    double racc = 0.0;
+    if constexpr (WANT_RHS) racc = dsum * R.ur - R.ld;
+#pragma unroll
+    for (int k = 0; k < NB; k += 2) {
+      const bool in = k < wm;                                // wave-uniform (wm is even)
+      const int64_t idx = mb + (int64_t)(k >> 1) * 128 + lane * 2;
+      double2 o;
+      o.x = (in && k < R.len) ? strip[k * 64 + lane] : 0.0;
+      o.y = (in && (k + 1) < R.len) ? strip[(k + 1) * 64 + lane] : 0.0;
+      if constexpr (HAS_V0) *reinterpret_cast<double2*>(in ? vals0 + idx : my_dummy) = o;
+      if constexpr (WANT_RHS) racc += o.x * cu[k] + o.y * cu[k + 1];
+      const bool bx = ((R.rmask >> k) & 1) != 0, by = ((R.rmask >> (k + 1)) & 1) != 0;
+      if (row_bc || bx) o.x = 0.0;
+      if (row_bc || by) o.y = 0.0;
+      if constexpr (HAS_V1) *reinterpret_cast<double2*>(in ? vals1 + idx : my_dummy) = o;
+    }
+    if constexpr (WANT_RHS) {
+      double* const dst = valid ? rhs + row : my_dummy;
+      *dst = row_bc ? (R.ur - R.gr) : racc;
+    }
+  };
+
+  for (int64_t s = s_begin; s < s_end; ++s) {
+    // (1) drain: the prefetch issued before the previous walk.  Neighbourhood of this slice to LDS.
+    double cu[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      cu[k] = WANT_RHS ? pu[k] : 0.0;
+#pragma unroll
+      for (int d = 0; d < D; ++d) nx[(k * D + d) * 64 + lane] = px[k][d];
+    }
+    const RowData R = R0;
+    // (2) first records of this slice
+    femo_i4 cur[CH], nxt[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) cur[i] = fetch(M0, i);
+    // (3) rows of the previous slice out of the strip, then clear it
+    if (have_prev) rows_out(prev_row, prev_mb, prev_wm, prev_dsum, Rp, cu_prev);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) strip[k * 64 + lane] = 0.0;
+    // (4) prefetch: table of s+3, columns of s+2, neighbourhood and row data of s+1
+    const Meta M3 = load_meta(s + 3);
+    uint32_t c2[NB];
+    load_cols(M2, c2);
+    load_nbhd(c1, px, pu);
+    R0 = load_row(s + 1);
+    // (5) the walk.  Whole chunks of CH visits run as straight-line code (no per-visit branch), so the LDS reads
+    // of the next visits are scheduled under the arithmetic of the current one -- with one wave per SIMD nothing
+    // else hides LDS latency.
+    const int nvis = M0.nvis;
+    double dsum = 0.0;
+    struct Nbr { double o[D][D]; int pos[D]; double wt; };
+    auto gather = [&](const femo_i4 q) -> Nbr {                  // the visit's three (two) other vertices from LDS
+      Nbr V;
+      const bool live = q.x >= 0;
+      const uint32_t sl = live ? (uint32_t)q.y : 0u;
+      V.wt = live ? __hiloint2double(q.w, q.z) : 0.0;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        V.pos[j] = (int)((sl >> (8 * j)) & 0xFFu);
+#pragma unroll
+        for (int d = 0; d < D; ++d) V.o[j][d] = nx[(V.pos[j] * D + d) * 64 + lane];
+      }
+      return V;
+    };
+    auto accumulate = [&](const Nbr& V) {
+      double kk[D];
+      poisson_pairs<D>(R.xo, V.o, V.wt, kk);
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        dsum -= kk[j];
+        if constexpr (LDS_ATOMIC) (void)__hip_atomic_fetch_add(&strip[V.pos[j] * 64 + lane], kk[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        else strip[V.pos[j] * 64 + lane] = __dadd_rn(strip[V.pos[j] * 64 + lane], kk[j]);
+      }
+    };
+    int base = 0;
+    for (; base + CH <= nvis; base += CH) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) nxt[i] = fetch(M0, base + CH + i);
+      // the LDS reads of visit i+1 are issued before the arithmetic of visit i (the compiler keeps them behind
+      // the ds_add of the visit before otherwise)
+      Nbr V = gather(cur[0]);
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        Nbr W = V;
+        if (i + 1 < CH) W = gather(cur[i + 1]);
+        accumulate(V);
+        V = W;
+      }
+#pragma unroll
+      for (int i = 0; i < CH; ++i) cur[i] = nxt[i];
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      if (base + i < nvis) accumulate(gather(cur[i]));            // wave-uniform tail
+    }
+    // rotate
+    have_prev = true;
+    prev_row = (s << 6) + lane; prev_mb = M0.mb; prev_wm = M0.wm; prev_dsum = dsum;
+    Rp = R;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) { cu_prev[k] = cu[k]; c0[k] = c1[k]; c1[k] = c2[k]; }
+    M0 = M1; M1 = M2; M2 = M3;
+  }
+  rows_out(prev_row, prev_mb, prev_wm, prev_dsum, Rp, cu_prev);
+}
+
 // -------------------------------------------------------------------- dRdf --
 // dR/dt of the beam: column e = (E width t_e^2 / 4) * Khat u_e  (4 entries aligned with conn[e])
 __global__ __launch_bounds__(FEMO_BLOCK) void k_dRdt_beam(int64_t n_cell, double Ey, double width, const int32_t* __restrict__ conn,
@@ -1347,7 +1566,7 @@ static int ensure_visit_weights(femo_mesh* m) {
   femo_d2* cw = nullptr;
   FEMO_HIP_CHECK(hipMalloc(&cw, std::max<int64_t>(m->n_cell, 1) * sizeof(femo_d2)));
   FEMO_REQUIRE(m->visit_entries * 16 < (int64_t(1) << 40), "incidence too large");
-  FEMO_HIP_CHECK(hipMalloc(&m->d_visit_rec, std::max<int64_t>(m->visit_entries, 1) * sizeof(P1Rec) + 64));
+  FEMO_HIP_CHECK(hipMalloc(&m->d_visit_rec, (std::max<int64_t>(m->visit_entries, 1) + 64) * sizeof(P1Rec)));   // + one padded visit: slices without visits still fetch
   if (m->n_cell > 0 && m->visit_entries > 0) {
     const int g = cell_grid(m->n_cell);
     if (m->tdim == 3) hipLaunchKernelGGL((k_cell_weights<3>), dim3(g), dim3(FEMO_BLOCK), 0, st, m->n_cell, m->d_conn, m->d_x, cw);
@@ -1410,6 +1629,12 @@ int femo_launch_residual(femo_mesh* m, int pde, const double* params, const doub
   else if (pde == FEMO_PDE_NL_POISSON)
     FEMO_LAUNCH_DP(m, k_residual, FEMO_PDE_NL_POISSON, nb, 0, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_conn, m->d_x, u, f, aux, m->d_bfacets, beta, sgn, r);
   else {
+    // K u - L is the Newton right-hand side without a Dirichlet set: the pipelined system kernel in its
+    // rhs-only form (1.3 ms at C4 against 2.2 ms for the per-visit-gather walk below)
+    const int nbr = (m->max_rowlen + 1) & ~1;
+    static const bool walk = getenv("FEMO_RESIDUAL_WALK") != nullptr;
+    if (!walk && nbr <= (m->tdim == 3 ? 16 : 8))
+      return femo_launch_system(m, pde, params, u, f, aux, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, r, f_uid, f_gen, nullptr);
     FEMO_TRY(ensure_load_vector(m, f, f_uid, f_gen));
     FEMO_ROW_WALK(m, 0, nb, st, u, (const double*)m->d_load, r);
   }
@@ -1480,6 +1705,44 @@ int femo_launch_system(femo_mesh* m, int pde, const double* params, const double
       hipLaunchKernelGGL(k, dim3(ns), dim3(64), lds_row, m->ctx->stream, m->n_rows, ns, nbr, m->d_vptr, rec, m->d_mptr, m->d_cols,    \
                          m->d_sdelta, m->sdelta_stride, m->d_rowlen, m->d_x, u, load, bcmask, bcval, diag0, vals0, diag1, vals1, rhs, bcmask ? bc_rowmask : nullptr, dbg); \
     } while (0)
+    // persistent pipelined kernel: rows of up to 16 entries, a Dirichlet set with its row masks, and one of the
+    // three combinations the operators ask for: A + rhs, dR/du + A, rhs only
+    static const int pipe_mode = getenv("FEMO_ASSEMBLY_PIPE") ? atoi(getenv("FEMO_ASSEMBLY_PIPE")) : 1;
+    const int NBp = m->tdim == 3 ? (nbr <= 14 ? 14 : 16) : 8;
+    const bool combo_a = rhs && !vals0 && vals1, combo_b = !rhs && vals0 && vals1, combo_c = rhs && !vals0 && !vals1;
+    const bool no_bc_residual = combo_c && bcmask == nullptr;          // evaluate_residuals: K u - L, no Dirichlet treatment
+    if (pipe_mode != 0 && nbr <= NBp && ((bcmask != nullptr && bc_rowmask != nullptr && (combo_a || combo_b || combo_c)) || no_bc_residual)) {
+      hipStream_t st = m->ctx->stream;
+      if (!m->d_pipe_dummy) {
+        FEMO_HIP_CHECK(hipMalloc(&m->d_pipe_dummy, 64 * 2 * sizeof(double)));
+        FEMO_HIP_CHECK(hipMalloc(&m->d_ubc, (std::max<int64_t>(m->n_vert, 1) + 2) * sizeof(double)));
+      }
+      if (rhs && !no_bc_residual) hipLaunchKernelGGL(k_impose_bc, dim3(cell_grid(m->n_vert)), dim3(FEMO_BLOCK), 0, st, m->n_vert, u, bcmask, bcval, m->d_ubc);
+      const double* ubc = no_bc_residual ? u : m->d_ubc;
+      static const int waves_per_cu = getenv("FEMO_ASSEMBLY_WAVES") ? std::max(1, atoi(getenv("FEMO_ASSEMBLY_WAVES"))) : 4;
+      // one wave per SIMD: the LDS request is raised so that a fifth workgroup cannot land on a CU (it would share a
+      // SIMD with another persistent wave and both would take twice as long)
+      const size_t lds_need = (size_t)NBp * (m->tdim + 1) * 64 * sizeof(double);
+      const size_t lds_pipe = waves_per_cu <= 4 ? std::max<size_t>(lds_need, 34 * 1024) : lds_need;
+      const unsigned grid = (unsigned)std::min<int64_t>(ns, (int64_t)m->ctx->n_cu * waves_per_cu);
+#define FEMO_SYS_PIPE(D, NB, R, V0, V1, AT)                                                                                      \
+      hipLaunchKernelGGL((k_poisson_system_pipe<D, NB, R, V0, V1, AT>), dim3(grid), dim3(64), lds_pipe, st, m->n_rows, ns, m->d_vptr, rec, \
+                         m->d_mptr, m->d_cols, m->d_rowlen, m->d_x, u, ubc, load, bcval, diag0, vals0, diag1, vals1, rhs,        \
+                         bc_rowmask, m->d_pipe_dummy)
+#define FEMO_SYS_PIPE_COMBO(D, NB)                                                                                           \
+      do { if (no_bc_residual) hipLaunchKernelGGL((k_poisson_system_pipe<D, NB, true, false, false, true, false>), dim3(grid), dim3(64), lds_pipe, st, m->n_rows, ns, m->d_vptr, rec, \
+                         m->d_mptr, m->d_cols, m->d_rowlen, m->d_x, u, ubc, load, bcval, diag0, vals0, diag1, vals1, rhs, bc_rowmask, m->d_pipe_dummy); \
+           else if (pipe_mode == 2) { if (combo_a) FEMO_SYS_PIPE(D, NB, true, false, true, false); else if (combo_b) FEMO_SYS_PIPE(D, NB, false, true, true, false);  \
+           else FEMO_SYS_PIPE(D, NB, true, false, false, false); }                                                             \
+           else if (combo_a) FEMO_SYS_PIPE(D, NB, true, false, true, true); else if (combo_b) FEMO_SYS_PIPE(D, NB, false, true, true, true);  \
+           else FEMO_SYS_PIPE(D, NB, true, false, false, true); } while (0)
+      if (m->tdim == 3) { if (NBp == 14) FEMO_SYS_PIPE_COMBO(3, 14); else FEMO_SYS_PIPE_COMBO(3, 16); }
+      else FEMO_SYS_PIPE_COMBO(2, 8);
+#undef FEMO_SYS_PIPE_COMBO
+#undef FEMO_SYS_PIPE
+      FEMO_HIP_CHECK(hipGetLastError());
+      return 0;
+    }
     if (m->tdim == 3) FEMO_SYS_LDS(3); else FEMO_SYS_LDS(2);
 #undef FEMO_SYS_LDS
     FEMO_HIP_CHECK(hipGetLastError());
