@@ -187,6 +187,7 @@ struct femo_mesh {
   void* d_visit_rec = nullptr;   // per incidence entry, 16 B: (cell<<2|a, slots, 1/(36|T|)) for the Poisson walks, built on first use
   double* d_load = nullptr;      // load vector of the Poisson residual for the f identified by (load_uid, load_gen)
   uint64_t load_uid = 0, load_gen = 0;
+  int pcg_last_iters = 0, pcg_prev_iters = 0;   // iterations of the last two converged BPX-PCG solves on this mesh (size the first batch)
   double* d_pipe_dummy = nullptr; // k_poisson_system_pipe: a line that absorbs the stores of padded entries / lanes
   double* d_ubc = nullptr;        // ... and u with the prescribed values imposed
   uint8_t* d_bfacets = nullptr;  // per cell: bit k = facet opposite local vertex k is on the boundary (optional)
