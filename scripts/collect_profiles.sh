@@ -25,4 +25,5 @@ for V in "215" "215 permute"; do
   python3 scripts/pmc_table.py $O/pmc_kernels_n$T.csv $O/pmc_${T}_FETCH_SIZE $O/pmc_${T}_WRITE_SIZE $O/pmc_${T}_SQ_WAVES $O/pmc_${T}_GRBM_GUI_ACTIVE > /dev/null
   rm -rf $O/pmc_${T}_*
 done
+python3 scripts/pmc_traffic.py $O/pmc_traffic.json $O/pmc_kernels_n215.csv $O/pmc_kernels_n215_permute.csv > /dev/null
 ls -la $O

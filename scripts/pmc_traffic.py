@@ -1,0 +1,37 @@
+"""profiles/rNN_pmc_traffic.json from the hardware-counter tables of scripts/collect_profiles.sh.
+usage: pmc_traffic.py OUT.json TABLE_n215.csv [TABLE_n215_permute.csv]
+bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE / WRITE_SIZE are in KiB; the factor 2 is the gfx950
+correction for wide coalesced streaming reads (MI355X_MICROARCH.md, HBM section; checked in round 1 on k_cg_update_xp:
+counter / bytes = 0.501).  Kernels that gather (assembly, permuted SpMV) use access widths the guide calls
+uncalibrated: their figures are upper estimates."""
+import csv
+import json
+import sys
+
+
+def table(path):
+    t = {}
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            t.setdefault(r["kernel"], {})[r["counter"]] = float(r["mean_per_dispatch"])
+    return t
+
+
+def entry(c):
+    f, w = c.get("FETCH_SIZE", 0.0), c.get("WRITE_SIZE", 0.0)
+    return {"fetch_KiB": f, "write_KiB": w, "bytes_2F_plus_W": (2 * f + w) * 1024}
+
+
+out = {"note": __doc__.split("\n", 2)[2].strip()}
+for tag, path in zip(("n215", "n215_permute"), sys.argv[2:]):
+    t = table(path)
+    spmv = t.get("k_spmv_sell<1, true>", {})
+    key = "spmv_" + tag.replace("_permute", "_permuted")
+    e = entry(spmv)
+    out[key] = e["bytes_2F_plus_W"]
+    out[key + "_fetch_KiB"], out[key + "_write_KiB"] = e["fetch_KiB"], e["write_KiB"]
+    out["other_kernels_" + tag] = {k: entry(c) for k, c in t.items()
+                                   if k != "k_spmv_sell<1, true>" and ("FETCH_SIZE" in c) and
+                                   any(s in k for s in ("poisson_system", "p1_row_walk", "restrict_bricks", "prolong_mesh", "pcg_xr", "lattice_prolong3"))}
+json.dump(out, open(sys.argv[1], "w"), indent=1)
+print(json.dumps(out, indent=1)[:1500])
