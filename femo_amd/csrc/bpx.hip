@@ -258,8 +258,24 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
                                                                 const int32_t* __restrict__ perm, const uint32_t* __restrict__ pk,
                                                                 Lat lat, const double* __restrict__ val,
                                                                 const double* __restrict__ w_sorted,
-                                                                double* __restrict__ g, int n_fused, const int32_t* __restrict__ done) {
+                                                                double* __restrict__ g, int n_fused, const int32_t* __restrict__ done,
+                                                                FemoPcSide::Update upd) {
   if (done != nullptr && *done) return;
+  // upd.q != nullptr: the kernel runs BESIDE the PCG update (second stream) and restricts r - alpha q itself,
+  // alpha = gamma / (p.q) folded from the SpMV's partials exactly as k_pcg_xr folds them
+  double alpha = 0.0;
+  if (upd.q != nullptr) {
+    __shared__ double fold[FEMO_BLOCK / 64];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < upd.nb_d; i += FEMO_BLOCK) a += upd.partials_d[i];
+    a = femo_wave_sum(a);
+    if ((threadIdx.x & 63) == 0) fold[threadIdx.x >> 6] = a;
+    __syncthreads();
+    double delta = 0.0;
+#pragma unroll
+    for (int i = 0; i < FEMO_BLOCK / 64; ++i) delta += fold[i];
+    alpha = delta != 0.0 ? upd.scal[upd.gamma_index] / delta : 0.0;
+  }
   const int debug = n_fused >> 8;                   // FEMO_DEBUG_BRICKS (timing experiments only)
   n_fused &= 0xFF;
   constexpr int B = Brick<D>::B, N1 = Brick<D>::N1, NLOC = Brick<D>::NLOC, NC = Brick<D>::NC;
@@ -305,6 +321,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
       bool live;
       const int64_t i = entry(M, q, live);
       v[q] = val[(debug & 4) ? i : (int64_t)p[q]];
+      if (upd.q != nullptr) v[q] -= alpha * upd.q[p[q]];
       const double ws = w_sorted[i];
       w[q] = live ? ws : 0.0;
 #pragma unroll
@@ -368,7 +385,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
       if (chunk > start) {                        // bricks above BRICK_CHUNK vertices (rare): unpipelined passes
         lds_barrier();
         for (int64_t i = chunk + tid; i < chunk_end; i += FEMO_BLOCK) {
-          sval[i - chunk] = val[perm[i]] * w_sorted[i];
+          sval[i - chunk] = (upd.q != nullptr ? val[perm[i]] - alpha * upd.q[perm[i]] : val[perm[i]]) * w_sorted[i];
 #pragma unroll
           for (int k = 0; k < D; ++k) st[k][i - chunk] = (float)(pk[i * D + k] & PK_MASK) * (1.0f / (float)(1u << PK_BITS));
         }
@@ -1075,9 +1092,9 @@ static int pc_setup_shared(femo_mesh* m) {
   if (pc->n_bricks > 0) {
     const unsigned gb = (unsigned)std::min<int64_t>(pc->n_bricks, (int64_t)ctx->n_cu * bricks_per_cu(pc->dim));
     if (pc->dim == 3)
-      hipLaunchKernelGGL(k_restrict_bricks<3>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, ones, pc->d_w_sorted, F.g, 0, (const int32_t*)nullptr);
+      hipLaunchKernelGGL(k_restrict_bricks<3>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, ones, pc->d_w_sorted, F.g, 0, (const int32_t*)nullptr, FemoPcSide::Update{});
     else
-      hipLaunchKernelGGL(k_restrict_bricks<2>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, ones, pc->d_w_sorted, F.g, 0, (const int32_t*)nullptr);
+      hipLaunchKernelGGL(k_restrict_bricks<2>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, ones, pc->d_w_sorted, F.g, 0, (const int32_t*)nullptr, FemoPcSide::Update{});
   }
   hipLaunchKernelGGL(k_mark_touched, dim3(lat_grid(F.nodes)), dim3(256), 0, st, F.nodes, F.g, F.e);
   FEMO_HIP_CHECK(hipGetLastError());
@@ -1152,11 +1169,17 @@ static int pc_prepare(femo_mesh* m, const uint8_t* mask, uint64_t key) {
 // zh = M^-1 rh in scaled variables; partials[block] = rh.zh per block (gv blocks)
 int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const double* s, const double* rh, double* out,
                   int mode, double* rho, const double* gamma_cur, double* gamma_nxt, const int32_t* done, int gv,
-                  bool rho_is_partial, const FemoPcgStop* stop, int nb_rho, const double* rho_partials) {
+                  bool rho_is_partial, const FemoPcgStop* stop, int nb_rho, const double* rho_partials, const FemoPcSide* side) {
   femo_pc* pc = m->pc;
   femo_ctx* ctx = m->ctx;
-  hipStream_t st = ctx->stream;
   FEMO_TRY(pc_prepare(m, mask, mask_key));
+  // `st` carries the restriction and the lattice cycle: the main stream, or the side stream of an overlapped apply
+  const hipStream_t st_main = ctx->stream;
+  const bool overlapped = side != nullptr && side->stream != nullptr && ctx->nranks == 1;
+  hipStream_t st = overlapped ? side->stream : st_main;
+  const FemoPcSide::Update upd = overlapped ? side->upd : FemoPcSide::Update{};
+  const double* rsrc = overlapped ? side->restrict_src : rh;
+  if (overlapped) FEMO_HIP_CHECK(hipStreamWaitEvent(st, side->fork, 0));
   const int nl = pc->n_levels, nf = pc->n_fused;
   const int T = nl - 1 - nf;                                   // coarsest level the brick kernel fills
   LatticeLevel& F = pc->L[nl - 1];
@@ -1173,9 +1196,9 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
     const unsigned gb = (unsigned)std::min<int64_t>(pc->n_bricks, (int64_t)ctx->n_cu * bricks_per_cu(pc->dim));
     static const int dbg = getenv("FEMO_DEBUG_BRICKS") ? atoi(getenv("FEMO_DEBUG_BRICKS")) << 8 : 0;
     if (pc->dim == 3)
-      hipLaunchKernelGGL(k_restrict_bricks<3>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, rh, pc->d_w_sorted, gF, nf | dbg, done);
+      hipLaunchKernelGGL(k_restrict_bricks<3>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, rsrc, pc->d_w_sorted, gF, nf | dbg, done, upd);
     else
-      hipLaunchKernelGGL(k_restrict_bricks<2>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, rh, pc->d_w_sorted, gF, nf | dbg, done);
+      hipLaunchKernelGGL(k_restrict_bricks<2>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, rsrc, pc->d_w_sorted, gF, nf | dbg, done, upd);
   }
   const bool sparse = ctx->nranks > 1 && pc->shared_ready;
   if (sparse) {
@@ -1299,6 +1322,11 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
     dot_global = pc->d_dot_scalar;
     nb_dot = 0;
   }
+  if (overlapped) {
+    FEMO_HIP_CHECK(hipEventRecord(side->join, st));
+    FEMO_HIP_CHECK(hipStreamWaitEvent(st_main, side->join, 0));
+    st = st_main;
+  }
   PcgStop ps;
   ps.rtol2_factor = stop ? stop->rtol2_factor : 0.0;
   ps.atol_pc2 = stop ? stop->atol_pc2 : 0.0;
@@ -1331,6 +1359,8 @@ int femo_pc_begin(femo_mesh* m, const double* s, const uint8_t* mask) {
 }
 
 // can the PCG loop hand its partial rh.rh to femo_pc_apply instead of all-reducing it itself?
+bool femo_pc_can_overlap(const femo_mesh* m) { return m->pc != nullptr && m->ctx->nranks == 1 && m->pc->n_bricks > 0; }
+
 bool femo_pc_can_piggyback(const femo_mesh* m) { return m->pc != nullptr && m->ctx->nranks > 1 && m->pc->shared_ready; }
 
 int femo_pc_levels(const femo_mesh* m, int* n_levels, int64_t* finest_nodes) {

@@ -481,8 +481,10 @@ __global__ __launch_bounds__(1024) void k_pcg_fold(int nb, const double* __restr
 __global__ __launch_bounds__(FEMO_BLOCK) void k_pcg_xr(int64_t n, int cur, int nb_d, const double* __restrict__ partials_d,
                                                        double* __restrict__ scal,
                                                        const double* __restrict__ q, const double* __restrict__ p,
-                                                       double* __restrict__ r, double* __restrict__ xh,
+                                                       const double* r_in, double* r, double* __restrict__ xh,
                                                        double* __restrict__ partials, const int32_t* __restrict__ done) {
+  // r = r_in - alpha q: in place (r_in == r) or into the other residual buffer when the restriction of the
+  // preconditioner runs beside this kernel and still reads r_in (FemoPcSide)
   if (*done) return;
   __shared__ double lds[FEMO_BLOCK / 64];
   const double gamma = scal[S_GAMMA + cur];
@@ -494,10 +496,11 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_pcg_xr(int64_t n, int cur, int n
   const double2* q2 = reinterpret_cast<const double2*>(q);
   const double2* p2 = reinterpret_cast<const double2*>(p);
   double2* r2 = reinterpret_cast<double2*>(r);
+  const double2* r2_in = reinterpret_cast<const double2*>(r_in);
   double2* x2 = reinterpret_cast<double2*>(xh);
   for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n2; i += (int64_t)gridDim.x * FEMO_BLOCK) {
     const double2 qi = q2[i], pi = p2[i];
-    double2 ri = r2[i], xi = x2[i];
+    double2 ri = r2_in[i], xi = x2[i];
     xi.x += alpha * pi.x; xi.y += alpha * pi.y;
     ri.x -= alpha * qi.x; ri.y -= alpha * qi.y;
     x2[i] = xi; r2[i] = ri;
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_pcg_xr(int64_t n, int cur, int n
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
     xh[i] += alpha * p[i];
-    const double ri = r[i] - alpha * q[i];
+    const double ri = r_in[i] - alpha * q[i];
     r[i] = ri;
     s0 += ri * ri;
   }
@@ -1189,6 +1192,15 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
   // solve that converges at iteration 28 enqueued 40 (12 dead iterations, 0.4 ms).  Adaptive: the first batch runs
   // to the iteration count of earlier solves on this mesh (+1), the following ones are short.
   const int batch = opts->check_every > 0 ? std::min(opts->check_every, 8) : 8;
+  // Overlapped preconditioner apply (single GPU, FEMO_PCG_OVERLAP=1): x/r update on the main stream, restriction and
+  // lattice cycle beside it on a second stream with a second residual buffer.  Measured at C4 (A/B in one call):
+  // 19.7 ms per solve against 18.2 ms without -- the two event dependencies per iteration and the bandwidth the
+  // streaming update takes from the latency-bound brick kernel cost more than the 75 us the update could hide.  Off.
+  static const bool overlap_on = getenv("FEMO_PCG_OVERLAP") != nullptr;
+  const bool overlap = local_scalars && !use_atol && overlap_on && femo_pc_can_overlap(m) && w.sv != nullptr;
+  if (overlap && ctx->comm_stream == nullptr) FEMO_HIP_CHECK(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+  double* r_cur = w.r;
+  double* r_oth = overlap ? w.sv : w.r;
   // (the smaller of the last two counts: Newton's later solves need far fewer iterations than its first)
   const int last2 = std::min(m->pcg_last_iters, m->pcg_prev_iters);
   const int predicted = last2 > 0 ? last2 + 1 : 0;
@@ -1216,19 +1228,31 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
       stop.it = it;
       if (local_scalars) {
         // single GPU: the consumers fold the per-block partials themselves
-        hipLaunchKernelGGL(k_pcg_xr, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, g1, Pd, S, w.q, w.p, w.r, w.xh, Pr, ctx->d_flags);
         // ph = M^-1 rh + beta ph in one pass: rh.zh = rho + g_L.e_L is known before the mesh prolongation, and
         // with it the stopping test.  The Jacobi-norm test runs only when an absolute tolerance is set.
         if (use_atol) {
+          hipLaunchKernelGGL(k_pcg_xr, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, g1, Pd, S, w.q, w.p, (const double*)r_cur, r_cur, w.xh, Pr, ctx->d_flags);
           hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(1024), 0, st, it, gv, Pr, S, ctx->d_flags);
-          FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, w.p, 1, S + S_RHO, S + S_GAMMA + cur, S + S_GAMMA + nxt, ctx->d_flags, gv, false, &stop));
+          FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, r_cur, w.p, 1, S + S_RHO, S + S_GAMMA + cur, S + S_GAMMA + nxt, ctx->d_flags, gv, false, &stop));
+        } else if (overlap) {
+          // x, r update on the main stream; the restriction of r - alpha q (formed by the brick kernel from the old
+          // residual) and the lattice cycle beside it on the second stream; they meet before the mesh prolongation
+          FEMO_HIP_CHECK(hipEventRecord(ctx->ev_main, st));
+          hipLaunchKernelGGL(k_pcg_xr, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, g1, Pd, S, w.q, w.p, (const double*)r_cur, r_oth, w.xh, Pr, ctx->d_flags);
+          FemoPcSide side;
+          side.stream = ctx->comm_stream; side.fork = ctx->ev_main; side.join = ctx->ev_comm;
+          side.restrict_src = r_cur;
+          side.upd.q = w.q; side.upd.scal = S; side.upd.gamma_index = S_GAMMA + cur; side.upd.nb_d = g1; side.upd.partials_d = Pd;
+          FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, r_oth, w.p, 1, S + S_RHO, S + S_GAMMA + cur, S + S_GAMMA + nxt, ctx->d_flags, gv, false, &stop, gv, Pr, &side));
+          std::swap(r_cur, r_oth);
         } else {
-          FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, w.r, w.p, 1, S + S_RHO, S + S_GAMMA + cur, S + S_GAMMA + nxt, ctx->d_flags, gv, false, &stop, gv, Pr));
+          hipLaunchKernelGGL(k_pcg_xr, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, g1, Pd, S, w.q, w.p, (const double*)r_cur, r_cur, w.xh, Pr, ctx->d_flags);
+          FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, r_cur, w.p, 1, S + S_RHO, S + S_GAMMA + cur, S + S_GAMMA + nxt, ctx->d_flags, gv, false, &stop, gv, Pr));
         }
       } else {
         hipLaunchKernelGGL(k_pcg_fold, dim3(1), dim3(1024), 0, st, g1, Pd, g2, Pg, S + S_DELTA, ctx->d_flags);
         FEMO_TRY(allreduce1(S + S_DELTA));
-        hipLaunchKernelGGL(k_pcg_xr, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, 0, Pd, S, w.q, w.p, w.r, w.xh, Pr, ctx->d_flags);
+        hipLaunchKernelGGL(k_pcg_xr, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, 0, Pd, S, w.q, w.p, (const double*)w.r, w.r, w.xh, Pr, ctx->d_flags);
         hipLaunchKernelGGL(k_pcg_fold, dim3(1), dim3(1024), 0, st, gv, Pr, 0, (const double*)nullptr, S + S_RHO, ctx->d_flags);
         if (piggyback) {
           // the rank's part of rh.rh rides in the lattice all-reduce of the preconditioner; the stopping
