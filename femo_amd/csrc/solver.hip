@@ -1196,7 +1196,7 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
   // lattice cycle beside it on a second stream with a second residual buffer.  Measured at C4 (A/B in one call):
   // 19.7 ms per solve against 18.2 ms without -- the two event dependencies per iteration and the bandwidth the
   // streaming update takes from the latency-bound brick kernel cost more than the 75 us the update could hide.  Off.
-  static const bool overlap_on = getenv("FEMO_PCG_OVERLAP") != nullptr;
+  const bool overlap_on = getenv("FEMO_PCG_OVERLAP") != nullptr;
   const bool overlap = local_scalars && !use_atol && overlap_on && femo_pc_can_overlap(m) && w.sv != nullptr;
   if (overlap && ctx->comm_stream == nullptr) FEMO_HIP_CHECK(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
   double* r_cur = w.r;
