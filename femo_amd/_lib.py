@@ -95,6 +95,19 @@ PROTOTYPES = {
     "femo_emu_group_create": (C.c_int, [C.c_int, C.POINTER(H)]),
     "femo_emu_group_destroy": (C.c_int, [H]),
     "femo_comm_emulate": (C.c_int, [H, H, C.c_int]),
+    # Reissner-Mindlin shell
+    "femo_shell_create": (C.c_int, [H, c_i64, C.c_void_p, c_i64, C.c_void_p, c_i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(H)]),
+    "femo_shell_destroy": (C.c_int, [H]),
+    "femo_shell_ndof": (c_i64, [H]),
+    "femo_shell_nnz": (c_i64, [H]),
+    "femo_shell_assemble": (C.c_int, [H, C.c_double, C.c_double, H, H]),
+    "femo_shell_matvec": (C.c_int, [H, H, C.c_void_p, H, H]),
+    "femo_shell_load": (C.c_int, [H, H, C.c_double, C.c_int, H]),
+    "femo_shell_load_T": (C.c_int, [H, H, C.c_double, C.c_int, H]),
+    "femo_shell_dform_dh": (C.c_int, [H, C.c_double, C.c_double, H, H, H, C.c_int, H, C.POINTER(C.c_double)]),
+    "femo_shell_compliance": (C.c_int, [H, H, C.POINTER(C.c_double), C.c_int, H]),
+    "femo_shell_mass": (C.c_int, [H, C.c_double, H, C.POINTER(C.c_double), C.c_int, H]),
+    "femo_shell_solve": (C.c_int, [H, H, C.c_void_p, H, H, H, C.POINTER(SolverOpts), C.POINTER(SolveInfo)]),
     "femo_mesh_set_global": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int64]),
     "femo_mesh_pc_info": (C.c_int, [H, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "femo_mesh_pattern_csr": (C.c_int, [H, C.c_void_p, C.c_void_p]),

@@ -1,0 +1,798 @@
+// Reissner-Mindlin shell, CG2^3 x CG1^3 on flat triangular facets (BASELINE config 3;
+// replaces what examples/test_shell_m3l/shell_pde.py:219-332 obtains from shell_analysis_fenicsx + dolfinx + MUMPS).
+// The formulation is restated and pinned in oracle/shell_oracle.py (Scordelis-Lo, Kirchhoff plate, rigid modes);
+// the kernels here are checked against it entry by entry (tests/test_gpu_shell.py).
+//
+// First version, correctness before speed:
+//   * degrees of freedom and the CSR pattern of the 27 x 27 element couplings are built on the host (Python,
+//     femo_amd/fea/shell.py) and handed over as plain arrays, with the CSR position of every element entry;
+//   * assembly: one thread per (cell, element column) forms the column from the facet frame and the quadrature
+//     points in registers (B^T D B, nine strain rows) and adds its 27 entries with fp64 atomics -- about 1e8 atomics
+//     for the 136 k-triangle wing of the reference's aeroelastic example, ~10 ms, against a linear solve that takes
+//     seconds; an owner-computes variant like the Poisson path's is the obvious next step;
+//   * solve: Jacobi-preconditioned CG on the assembled CSR matrix with strongly imposed dofs (masked operator),
+//     scalars kept on the device (consumers fold the producers' per-block partials), host polls a flag.
+//     Shell stiffness matrices are ill conditioned (3,169 iterations on the 16 x 16 roof, 7,491 on 32 x 32): a
+//     multilevel preconditioner for this operator is future work, the reference uses a direct solver.
+//   * thickness sensitivity: (dR/dh)^T lambda evaluated element by element from the strains of w and lambda.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "femo_internal.h"
+
+struct femo_shell {
+  femo_ctx* ctx = nullptr;
+  int64_t n_vert = 0, n_cell = 0, n_edge = 0, n_unode = 0, n_dof = 0, nnz = 0;
+  double* d_x = nullptr;
+  int32_t *d_conn = nullptr, *d_cedge = nullptr, *d_cols = nullptr, *d_epos = nullptr;
+  int64_t* d_rowptr = nullptr;
+  // CG workspace
+  double *d_r = nullptr, *d_p = nullptr, *d_q = nullptr, *d_dinv = nullptr, *d_scal = nullptr, *d_part = nullptr;
+  int32_t* d_flag = nullptr;
+};
+
+// plain view of the device arrays for kernels
+struct femo_shell_view {
+  int64_t n_vert, n_cell, n_unode;
+  const double* x;
+  const int32_t *conn, *cedge;
+};
+
+namespace {
+
+constexpr int SH_BLOCK = 256;
+constexpr int SH_MAXPART = 1024;
+
+// quadrature rules of oracle/shell_oracle.py: Dunavant degree 4 (in-plane terms), degree 2 (shear)
+__constant__ double c_lam6[6][3] = {
+    {0.108103018168070, 0.445948490915965, 0.445948490915965}, {0.445948490915965, 0.108103018168070, 0.445948490915965},
+    {0.445948490915965, 0.445948490915965, 0.108103018168070}, {0.816847572980459, 0.091576213509771, 0.091576213509771},
+    {0.091576213509771, 0.816847572980459, 0.091576213509771}, {0.091576213509771, 0.091576213509771, 0.816847572980459}};
+__constant__ double c_w6[6] = {0.223381589678011, 0.223381589678011, 0.223381589678011,
+                               0.109951743655322, 0.109951743655322, 0.109951743655322};
+__constant__ double c_lam3[3][3] = {{2.0 / 3, 1.0 / 6, 1.0 / 6}, {1.0 / 6, 2.0 / 3, 1.0 / 6}, {1.0 / 6, 1.0 / 6, 2.0 / 3}};
+
+struct Facet {
+  double e1[3], e2[3], e3[3], area;
+  double gl[3][2];            // tangent gradients of the barycentric coordinates
+};
+
+__device__ __forceinline__ void facet_frame(const double* __restrict__ x, const int32_t* __restrict__ conn, int64_t c, Facet& F) {
+  double p[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[a][k] = x[(int64_t)conn[c * 3 + a] * 3 + k];
+  double t1[3], t2[3], n[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { t1[k] = p[1][k] - p[0][k]; t2[k] = p[2][k] - p[0][k]; }
+  n[0] = t1[1] * t2[2] - t1[2] * t2[1]; n[1] = t1[2] * t2[0] - t1[0] * t2[2]; n[2] = t1[0] * t2[1] - t1[1] * t2[0];
+  const double dbl = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+  const double l1 = sqrt(t1[0] * t1[0] + t1[1] * t1[1] + t1[2] * t1[2]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { F.e3[k] = n[k] / dbl; F.e1[k] = t1[k] / l1; }
+  F.e2[0] = F.e3[1] * F.e1[2] - F.e3[2] * F.e1[1];
+  F.e2[1] = F.e3[2] * F.e1[0] - F.e3[0] * F.e1[2];
+  F.e2[2] = F.e3[0] * F.e1[1] - F.e3[1] * F.e1[0];
+  F.area = 0.5 * dbl;
+  // tangent coordinates of the vertices: (0,0), (a,0), (b,c)
+  const double a = t1[0] * F.e1[0] + t1[1] * F.e1[1] + t1[2] * F.e1[2];
+  const double b = t2[0] * F.e1[0] + t2[1] * F.e1[1] + t2[2] * F.e1[2];
+  const double cc = t2[0] * F.e2[0] + t2[1] * F.e2[1] + t2[2] * F.e2[2];
+  const double X[3] = {0.0, a, b}, Y[3] = {0.0, 0.0, cc};
+  const double det = 2.0 * F.area;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int j = (i + 1) % 3, k = (i + 2) % 3;
+    F.gl[i][0] = (Y[j] - Y[k]) / det;
+    F.gl[i][1] = (X[k] - X[j]) / det;
+  }
+}
+
+// tangent gradient of P2 shape function a at barycentric point lam (vertices 0..2, then edges (0,1), (1,2), (2,0))
+__device__ __forceinline__ void p2_grad(const Facet& F, const double* lam, int a, double& g1, double& g2) {
+  if (a < 3) {
+    const double d = 4.0 * lam[a] - 1.0;
+    g1 = d * F.gl[a][0]; g2 = d * F.gl[a][1];
+  } else {
+    const int i = a - 3, j = (a - 2) % 3;
+    g1 = 4.0 * (lam[j] * F.gl[i][0] + lam[i] * F.gl[j][0]);
+    g2 = 4.0 * (lam[j] * F.gl[i][1] + lam[i] * F.gl[j][1]);
+  }
+}
+
+__device__ __forceinline__ double p2_value(const double* lam, int a) {
+  if (a < 3) return lam[a] * (2.0 * lam[a] - 1.0);
+  const int i = a - 3, j = (a - 2) % 3;
+  return 4.0 * lam[i] * lam[j];
+}
+
+// Column `col` (0..26) of the strain operator at one point: rows 0-2 membrane (Voigt, engineering shear), 3-5 bending,
+// 6-7 transverse shear, 8 drilling (oracle/shell_oracle.py::_strain_operators)
+__device__ __forceinline__ void strain_column(const Facet& F, const double* lam, int col, double (&b)[9]) {
+#pragma unroll
+  for (int r = 0; r < 9; ++r) b[r] = 0.0;
+  if (col < 18) {
+    const int a = col / 3, k = col % 3;
+    double g1, g2;
+    p2_grad(F, lam, a, g1, g2);
+    b[0] = F.e1[k] * g1;
+    b[1] = F.e2[k] * g2;
+    b[2] = F.e1[k] * g2 + F.e2[k] * g1;
+    b[6] = F.e3[k] * g1;
+    b[7] = F.e3[k] * g2;
+    b[8] = 0.5 * (F.e1[k] * g2 - F.e2[k] * g1);
+  } else {
+    const int v = (col - 18) / 3, k = (col - 18) % 3;
+    const double g1 = F.gl[v][0], g2 = F.gl[v][1], M = lam[v];
+    b[3] = -F.e2[k] * g1;
+    b[4] = F.e1[k] * g2;
+    b[5] = -F.e2[k] * g2 + F.e1[k] * g1;
+    b[6] = F.e2[k] * M;
+    b[7] = -F.e1[k] * M;
+    b[8] = F.e3[k] * M;
+  }
+}
+
+__device__ __forceinline__ int64_t shell_gdof(const femo_shell_view& S, int64_t c, int i) {
+  if (i < 18) {
+    const int a = i / 3, k = i % 3;
+    const int64_t node = a < 3 ? (int64_t)S.conn[c * 3 + a] : S.n_vert + S.cedge[c * 3 + a - 3];
+    return 3 * node + k;
+  }
+  const int v = (i - 18) / 3, k = (i - 18) % 3;
+  return 3 * S.n_unode + 3 * (int64_t)S.conn[c * 3 + v] + k;
+}
+
+struct Material { double c11, c12, c33, mu_s, E; };     // plane stress, shear modulus x 5/6, Young's modulus
+
+__device__ __forceinline__ Material material(double E, double nu) {
+  Material m;
+  const double f = E / (1.0 - nu * nu);
+  m.c11 = f; m.c12 = f * nu; m.c33 = f * 0.5 * (1.0 - nu);
+  m.mu_s = (5.0 / 6.0) * E / (2.0 * (1.0 + nu));
+  m.E = E;
+  return m;
+}
+
+// K_e[:, col] for every (cell, col): B^T D B over the two rules, added to the CSR values with atomics
+__global__ __launch_bounds__(SH_BLOCK) void k_shell_assemble(femo_shell_view S, double E, double nu, const double* __restrict__ h,
+                                                             const int32_t* __restrict__ epos, double* __restrict__ vals) {
+  const int64_t t = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x;
+  const int64_t c = t / 27;
+  const int col = (int)(t % 27);
+  if (c >= S.n_cell) return;
+  Facet F;
+  facet_frame(S.x, S.conn, c, F);
+  const Material m = material(E, nu);
+  const double hv[3] = {h[S.conn[c * 3]], h[S.conn[c * 3 + 1]], h[S.conn[c * 3 + 2]]};
+  double acc[27];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+  for (int q = 0; q < 6; ++q) {
+    const double* lam = c_lam6[q];
+    const double hq = hv[0] * lam[0] + hv[1] * lam[1] + hv[2] * lam[2];
+    const double w = c_w6[q] * F.area;
+    const double dm = w * hq, db = w * hq * hq * hq * (1.0 / 12.0), dd = w * m.E * hq * hq * hq;
+    double bj[9];
+    strain_column(F, lam, col, bj);
+    // D B[:, col]: membrane, bending, drilling
+    const double s0 = dm * (m.c11 * bj[0] + m.c12 * bj[1]), s1 = dm * (m.c12 * bj[0] + m.c11 * bj[1]), s2 = dm * m.c33 * bj[2];
+    const double s3 = db * (m.c11 * bj[3] + m.c12 * bj[4]), s4 = db * (m.c12 * bj[3] + m.c11 * bj[4]), s5 = db * m.c33 * bj[5];
+    const double s8 = dd * bj[8];
+    for (int i = 0; i < 27; ++i) {
+      double bi[9];
+      strain_column(F, lam, i, bi);
+      acc[i] += bi[0] * s0 + bi[1] * s1 + bi[2] * s2 + bi[3] * s3 + bi[4] * s4 + bi[5] * s5 + bi[8] * s8;
+    }
+  }
+  for (int q = 0; q < 3; ++q) {
+    const double* lam = c_lam3[q];
+    const double hq = hv[0] * lam[0] + hv[1] * lam[1] + hv[2] * lam[2];
+    const double ds = (1.0 / 3.0) * F.area * m.mu_s * hq;
+    double bj[9];
+    strain_column(F, lam, col, bj);
+    const double s6 = ds * bj[6], s7 = ds * bj[7];
+    for (int i = 0; i < 27; ++i) {
+      double bi[9];
+      strain_column(F, lam, i, bi);
+      acc[i] += bi[6] * s6 + bi[7] * s7;
+    }
+  }
+  const int32_t* ep = epos + c * 729;
+  for (int i = 0; i < 27; ++i) atomicAdd(&vals[ep[i * 27 + col]], acc[i]);
+}
+
+// strains B w_e (9 rows) of an element vector at one point
+__device__ __forceinline__ void element_strain(const Facet& F, const double* lam, const double (&we)[27], double (&s)[9]) {
+#pragma unroll
+  for (int r = 0; r < 9; ++r) s[r] = 0.0;
+  for (int i = 0; i < 27; ++i) {
+    double bi[9];
+    strain_column(F, lam, i, bi);
+#pragma unroll
+    for (int r = 0; r < 9; ++r) s[r] += bi[r] * we[i];
+  }
+}
+
+// out[b] += sum_e v_e^T (dK_e/dh_b) w_e  (one thread per cell): the thickness derivative of the bilinear form.
+// v == w gives 2 dEnergy/dh.  energy != nullptr: per-block partials of 1/2 v^T K w as well.
+__global__ __launch_bounds__(SH_BLOCK) void k_shell_dform_dh(femo_shell_view S, double E, double nu, const double* __restrict__ h,
+                                                             const double* __restrict__ v, const double* __restrict__ w,
+                                                             double* __restrict__ out, double* __restrict__ energy) {
+  __shared__ double lds[SH_BLOCK / 64];
+  const int64_t c = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x;
+  double en = 0.0;
+  if (c < S.n_cell) {
+    Facet F;
+    facet_frame(S.x, S.conn, c, F);
+    const Material m = material(E, nu);
+    const double hv[3] = {h[S.conn[c * 3]], h[S.conn[c * 3 + 1]], h[S.conn[c * 3 + 2]]};
+    double ve[27], we[27];
+    for (int i = 0; i < 27; ++i) {
+      const int64_t g = shell_gdof(S, c, i);
+      ve[i] = v[g]; we[i] = w[g];
+    }
+    double g[3] = {0.0, 0.0, 0.0};
+    for (int q = 0; q < 6; ++q) {
+      const double* lam = c_lam6[q];
+      const double hq = hv[0] * lam[0] + hv[1] * lam[1] + hv[2] * lam[2];
+      const double wq = c_w6[q] * F.area;
+      double sv[9], sw[9];
+      element_strain(F, lam, ve, sv);
+      element_strain(F, lam, we, sw);
+      const double mem = sv[0] * (m.c11 * sw[0] + m.c12 * sw[1]) + sv[1] * (m.c12 * sw[0] + m.c11 * sw[1]) + sv[2] * m.c33 * sw[2];
+      const double ben = sv[3] * (m.c11 * sw[3] + m.c12 * sw[4]) + sv[4] * (m.c12 * sw[3] + m.c11 * sw[4]) + sv[5] * m.c33 * sw[5];
+      const double dri = m.E * sv[8] * sw[8];
+      en += wq * (hq * mem + hq * hq * hq * (ben * (1.0 / 12.0) + dri));
+      const double d = wq * (mem + hq * hq * (0.25 * ben + 3.0 * dri));        // d/dh of h, h^3/12, h^3
+#pragma unroll
+      for (int b = 0; b < 3; ++b) g[b] += d * lam[b];
+    }
+    for (int q = 0; q < 3; ++q) {
+      const double* lam = c_lam3[q];
+      const double hq = hv[0] * lam[0] + hv[1] * lam[1] + hv[2] * lam[2];
+      const double wq = (1.0 / 3.0) * F.area;
+      double sv[9], sw[9];
+      element_strain(F, lam, ve, sv);
+      element_strain(F, lam, we, sw);
+      const double sh = m.mu_s * (sv[6] * sw[6] + sv[7] * sw[7]);
+      en += wq * hq * sh;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) g[b] += wq * sh * lam[b];
+    }
+    if (out != nullptr) {
+#pragma unroll
+      for (int b = 0; b < 3; ++b) atomicAdd(&out[S.conn[c * 3 + b]], g[b]);
+    }
+  }
+  if (energy != nullptr) {
+    const double t = femo_block_sum<SH_BLOCK>(0.5 * en, lds);
+    if (threadIdx.x == 0) energy[blockIdx.x] = t;
+  }
+}
+
+// F += int f . v  (f: CG1 vector field at the vertices, force per unit area), sign * that
+__global__ __launch_bounds__(SH_BLOCK) void k_shell_load(femo_shell_view S, const double* __restrict__ f, double sign, double* __restrict__ Fv) {
+  const int64_t c = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x;
+  if (c >= S.n_cell) return;
+  Facet F;
+  facet_frame(S.x, S.conn, c, F);
+  double fv[3][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) fv[b][k] = f[(int64_t)S.conn[c * 3 + b] * 3 + k];
+  double acc[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) acc[i] = 0.0;
+  for (int q = 0; q < 6; ++q) {
+    const double* lam = c_lam6[q];
+    const double wq = c_w6[q] * F.area;
+    double fq[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) fq[k] = lam[0] * fv[0][k] + lam[1] * fv[1][k] + lam[2] * fv[2][k];
+    for (int a = 0; a < 6; ++a) {
+      const double N = p2_value(lam, a) * wq;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acc[a * 3 + k] += N * fq[k];
+    }
+  }
+  for (int i = 0; i < 18; ++i) atomicAdd(&Fv[shell_gdof(S, c, i)], sign * acc[i]);
+}
+
+// out[vertex b, k] += sign * int phi_b (lambda_u)_k : transpose of the load map applied to a state-sized vector
+__global__ __launch_bounds__(SH_BLOCK) void k_shell_load_T(femo_shell_view S, const double* __restrict__ lam_state, double sign, double* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x;
+  if (c >= S.n_cell) return;
+  Facet F;
+  facet_frame(S.x, S.conn, c, F);
+  double le[18];
+  for (int i = 0; i < 18; ++i) le[i] = lam_state[shell_gdof(S, c, i)];
+  double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (int q = 0; q < 6; ++q) {
+    const double* lam = c_lam6[q];
+    const double wq = c_w6[q] * F.area;
+    double uq[3] = {0, 0, 0};
+    for (int a = 0; a < 6; ++a) {
+      const double N = p2_value(lam, a);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) uq[k] += N * le[a * 3 + k];
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acc[b][k] += wq * lam[b] * uq[k];
+  }
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) atomicAdd(&out[(int64_t)S.conn[c * 3 + b] * 3 + k], sign * acc[b][k]);
+}
+
+// compliance 1/2 int u.u (partials per block) and, if grad != nullptr, its gradient M_u w added to grad
+__global__ __launch_bounds__(SH_BLOCK) void k_shell_compliance(femo_shell_view S, const double* __restrict__ w, double* __restrict__ partials,
+                                                               double* __restrict__ grad) {
+  __shared__ double lds[SH_BLOCK / 64];
+  const int64_t c = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x;
+  double J = 0.0;
+  if (c < S.n_cell) {
+    Facet F;
+    facet_frame(S.x, S.conn, c, F);
+    double ue[18], ge[18];
+    for (int i = 0; i < 18; ++i) { ue[i] = w[shell_gdof(S, c, i)]; ge[i] = 0.0; }
+    for (int q = 0; q < 6; ++q) {
+      const double* lam = c_lam6[q];
+      const double wq = c_w6[q] * F.area;
+      double uq[3] = {0, 0, 0};
+      for (int a = 0; a < 6; ++a) {
+        const double N = p2_value(lam, a);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) uq[k] += N * ue[a * 3 + k];
+      }
+      J += 0.5 * wq * (uq[0] * uq[0] + uq[1] * uq[1] + uq[2] * uq[2]);
+      for (int a = 0; a < 6; ++a) {
+        const double N = p2_value(lam, a) * wq;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ge[a * 3 + k] += N * uq[k];
+      }
+    }
+    if (grad != nullptr)
+      for (int i = 0; i < 18; ++i) atomicAdd(&grad[shell_gdof(S, c, i)], ge[i]);
+  }
+  if (partials != nullptr) {
+    const double t = femo_block_sum<SH_BLOCK>(J, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  }
+}
+
+// int rho h (partials) and its gradient rho |T| / 3 per vertex
+__global__ __launch_bounds__(SH_BLOCK) void k_shell_mass(femo_shell_view S, double rho, const double* __restrict__ h, double* __restrict__ partials,
+                                                         double* __restrict__ grad) {
+  __shared__ double lds[SH_BLOCK / 64];
+  const int64_t c = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x;
+  double M = 0.0;
+  if (c < S.n_cell) {
+    Facet F;
+    facet_frame(S.x, S.conn, c, F);
+    const double a3 = rho * F.area * (1.0 / 3.0);
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      M += a3 * h[S.conn[c * 3 + b]];
+      if (grad != nullptr) atomicAdd(&grad[S.conn[c * 3 + b]], a3);
+    }
+  }
+  if (partials != nullptr) {
+    const double t = femo_block_sum<SH_BLOCK>(M, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  }
+}
+
+// ---------------------------------------------------------------- CSR operator ----
+// y = A x for rows [0, n), one wave per row; `fixed` != nullptr: the masked operator M A M + (I - M) (strongly imposed
+// dofs are identity rows and columns).  partials != nullptr: per-block partial of x.y.
+__global__ __launch_bounds__(SH_BLOCK) void k_csr_spmv(int64_t n, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                       const double* __restrict__ vals, const uint8_t* __restrict__ fixed,
+                                                       const double* __restrict__ x, double* __restrict__ y, double* __restrict__ partials,
+                                                       const int32_t* __restrict__ done) {
+  if (done != nullptr && *done) return;
+  __shared__ double lds[SH_BLOCK / 64];
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (int64_t)gridDim.x * (SH_BLOCK / 64);
+  double dot = 0.0;
+  for (int64_t row = (int64_t)blockIdx.x * (SH_BLOCK / 64) + (threadIdx.x >> 6); row < n; row += nw) {
+    double s = 0.0;
+    const bool rf = fixed != nullptr && fixed[row];
+    if (!rf) {
+      for (int64_t e = rowptr[row] + lane; e < rowptr[row + 1]; e += 64) {
+        const int32_t cidx = cols[e];
+        if (fixed == nullptr || !fixed[cidx]) s += vals[e] * x[cidx];
+      }
+    }
+    s = femo_wave_sum(s);
+    if (lane == 0) {
+      const double yi = rf ? x[row] : s;
+      y[row] = yi;
+      dot += x[row] * yi;
+    }
+  }
+  if (partials != nullptr) {
+    const double t = femo_block_sum<SH_BLOCK>(dot, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  }
+}
+
+__global__ void k_csr_diag_inv(int64_t n, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                               const double* __restrict__ vals, const uint8_t* __restrict__ fixed, double* __restrict__ dinv) {
+  for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < n; row += (int64_t)gridDim.x * blockDim.x) {
+    double d = 1.0;
+    if (fixed == nullptr || !fixed[row]) {
+      d = 0.0;
+      for (int64_t e = rowptr[row]; e < rowptr[row + 1]; ++e)
+        if (cols[e] == row) d += vals[e];
+    }
+    dinv[row] = d != 0.0 ? 1.0 / d : 1.0;
+  }
+}
+
+// sum of per-block partials, the same value in every thread of every block (fixed order: reproducible)
+__device__ __forceinline__ double fold(const double* __restrict__ partials, int nb, double* lds) {
+  double a = 0.0;
+  for (int i = threadIdx.x; i < nb; i += SH_BLOCK) a += partials[i];
+  a = femo_wave_sum(a);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) lds[w] = a;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < SH_BLOCK / 64; ++i) s += lds[i];
+  return s;
+}
+
+// scal: [0] gamma = r.z, [1] gamma0 (tolerance reference), [2] tol^2 factor
+// r = b - A x0 is prepared by the host code; z = dinv r; p = z; partial r.z
+__global__ __launch_bounds__(SH_BLOCK) void k_scg_init(int64_t n, const double* __restrict__ r, const double* __restrict__ dinv,
+                                                       double* __restrict__ p, double* __restrict__ partials) {
+  __shared__ double lds[SH_BLOCK / 64];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * SH_BLOCK) {
+    const double z = dinv[i] * r[i];
+    p[i] = z;
+    s += r[i] * z;
+  }
+  const double t = femo_block_sum<SH_BLOCK>(s, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(SH_BLOCK) void k_scg_gamma0(int nb, const double* __restrict__ partials, double rtol2, double atol2, double* __restrict__ scal,
+                                                         int32_t* __restrict__ flag) {
+  __shared__ double lds[SH_BLOCK / 64];
+  const double g = fold(partials, nb, lds);
+  if (threadIdx.x == 0) {
+    scal[0] = g; scal[1] = g;
+    scal[2] = fmax(rtol2 * g, atol2);
+    flag[0] = g <= scal[2] ? 1 : 0;
+    flag[1] = 0;
+  }
+}
+
+// x += alpha p; r -= alpha q; z = dinv r; partial r.z           alpha = gamma / (p.q), p.q folded here
+__global__ __launch_bounds__(SH_BLOCK) void k_scg_xr(int64_t n, int nb_pq, const double* __restrict__ part_pq, const double* __restrict__ scal,
+                                                     const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ dinv,
+                                                     double* __restrict__ x, double* __restrict__ r, double* __restrict__ part_rz,
+                                                     const int32_t* __restrict__ done) {
+  if (*done) return;
+  __shared__ double lds[SH_BLOCK / 64];
+  const double pq = fold(part_pq, nb_pq, lds);
+  const double alpha = pq != 0.0 ? scal[0] / pq : 0.0;
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * SH_BLOCK) {
+    x[i] += alpha * p[i];
+    const double ri = r[i] - alpha * q[i];
+    r[i] = ri;
+    s += ri * ri * dinv[i];
+  }
+  const double t = femo_block_sum<SH_BLOCK>(s, lds);
+  if (threadIdx.x == 0) part_rz[blockIdx.x] = t;
+}
+
+// gamma' folded; beta = gamma'/gamma; p = dinv r + beta p; stopping test; one extra block-0 duty: publish gamma'
+__global__ __launch_bounds__(SH_BLOCK) void k_scg_p(int64_t n, int it, int nb_rz, const double* __restrict__ part_rz, double* __restrict__ scal,
+                                                    const double* __restrict__ r, const double* __restrict__ dinv, double* __restrict__ p,
+                                                    int32_t* __restrict__ flag, double* __restrict__ gamma_out) {
+  if (flag[0]) return;
+  __shared__ double lds[SH_BLOCK / 64];
+  const double g1 = fold(part_rz, nb_rz, lds);
+  const double g0 = scal[0];
+  const bool conv = g1 <= scal[2] || !(g1 == g1);
+  const double beta = g0 != 0.0 ? g1 / g0 : 0.0;
+  if (!conv) {
+    for (int64_t i = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * SH_BLOCK)
+      p[i] = dinv[i] * r[i] + beta * p[i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    gamma_out[0] = g1;                   // read by the next iteration only after this kernel has finished
+    flag[1] = it + 1;
+    if (conv) { flag[2] = (g1 == g1) ? 0 : 1; __threadfence(); flag[0] = it + 1; }
+  }
+}
+
+__global__ void k_scg_commit(double* __restrict__ scal, const double* __restrict__ gamma_out, const int32_t* __restrict__ flag) {
+  if (flag[0]) return;
+  scal[0] = gamma_out[0];
+}
+
+// r = rhs on the free dofs, 0 on the strongly imposed ones (those are set exactly after the loop)
+__global__ void k_rhs_free(int64_t n, const double* __restrict__ rhs, const uint8_t* __restrict__ fixed, double* __restrict__ r) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    r[i] = (fixed != nullptr && fixed[i]) ? 0.0 : rhs[i];
+}
+
+__global__ void k_set_fixed(int64_t n, const uint8_t* __restrict__ fixed, const double* __restrict__ xfix, double* __restrict__ x) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (fixed[i]) x[i] = xfix != nullptr ? xfix[i] : 0.0;
+}
+
+// lifting: x holds the prescribed values on fixed dofs and 0 elsewhere on entry of the caller's choice; b' = b - A_fc x_c on free rows
+__global__ __launch_bounds__(SH_BLOCK) void k_csr_lift(int64_t n, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                       const double* __restrict__ vals, const uint8_t* __restrict__ fixed,
+                                                       const double* __restrict__ xfix, const double* __restrict__ b, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (int64_t)gridDim.x * (SH_BLOCK / 64);
+  for (int64_t row = (int64_t)blockIdx.x * (SH_BLOCK / 64) + (threadIdx.x >> 6); row < n; row += nw) {
+    double s = 0.0;
+    if (!fixed[row]) {
+      for (int64_t e = rowptr[row] + lane; e < rowptr[row + 1]; e += 64) {
+        const int32_t cidx = cols[e];
+        if (fixed[cidx]) s += vals[e] * xfix[cidx];
+      }
+    }
+    s = femo_wave_sum(s);
+    if (lane == 0) out[row] = fixed[row] ? xfix[row] : b[row] - s;
+  }
+}
+
+inline unsigned sgrid(int64_t n, int per = SH_BLOCK) {
+  int64_t g = (n + per - 1) / per;
+  if (g < 1) g = 1;
+  return (unsigned)std::min<int64_t>(g, 1 << 20);
+}
+
+femo_shell_view view(const femo_shell* s) {
+  femo_shell_view v;
+  v.n_vert = s->n_vert; v.n_cell = s->n_cell; v.n_unode = s->n_unode;
+  v.x = s->d_x; v.conn = s->d_conn; v.cedge = s->d_cedge;
+  return v;
+}
+
+template <class T>
+int to_device(T** d, const T* h, int64_t n, hipStream_t st) {
+  FEMO_HIP_CHECK(hipMalloc(d, std::max<int64_t>(n, 1) * sizeof(T)));
+  if (n > 0) FEMO_HIP_CHECK(hipMemcpyAsync(*d, h, n * sizeof(T), hipMemcpyHostToDevice, st));
+  return 0;
+}
+
+int reduce_partials(femo_ctx* ctx, const double* d_part, int nb, double* host) {
+  std::vector<double> h((size_t)nb);
+  FEMO_HIP_CHECK(hipMemcpyAsync(h.data(), d_part, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  FEMO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  double s = 0.0;
+  for (double v : h) s += v;
+  *host = s;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int femo_shell_create(femo_ctx* ctx, int64_t n_vert, const double* x, int64_t n_cell, const int32_t* conn, int64_t n_edge,
+                      const int32_t* cell_edges, const int64_t* rowptr, const int32_t* cols, const int32_t* elem_pos,
+                      femo_shell** out) {
+  FEMO_REQUIRE(ctx && x && conn && cell_edges && rowptr && cols && elem_pos && out, "null argument");
+  FEMO_REQUIRE(n_vert > 0 && n_cell > 0 && n_edge > 0, "empty shell mesh");
+  FEMO_HIP_CHECK(hipSetDevice(ctx->device));
+  femo_shell* s = new femo_shell();
+  s->ctx = ctx;
+  s->n_vert = n_vert; s->n_cell = n_cell; s->n_edge = n_edge;
+  s->n_unode = n_vert + n_edge;
+  s->n_dof = 3 * s->n_unode + 3 * n_vert;
+  s->nnz = rowptr[s->n_dof];
+  FEMO_REQUIRE(s->nnz > 0 && s->nnz < (int64_t)1 << 31, "pattern too large for 32-bit element positions");
+  hipStream_t st = ctx->stream;
+  FEMO_TRY(to_device(&s->d_x, x, n_vert * 3, st));
+  FEMO_TRY(to_device(&s->d_conn, conn, n_cell * 3, st));
+  FEMO_TRY(to_device(&s->d_cedge, cell_edges, n_cell * 3, st));
+  FEMO_TRY(to_device(&s->d_rowptr, rowptr, s->n_dof + 1, st));
+  FEMO_TRY(to_device(&s->d_cols, cols, s->nnz, st));
+  FEMO_TRY(to_device(&s->d_epos, elem_pos, n_cell * 729, st));
+  const int64_t n = s->n_dof;
+  FEMO_HIP_CHECK(hipMalloc(&s->d_r, n * sizeof(double)));
+  FEMO_HIP_CHECK(hipMalloc(&s->d_p, n * sizeof(double)));
+  FEMO_HIP_CHECK(hipMalloc(&s->d_q, n * sizeof(double)));
+  FEMO_HIP_CHECK(hipMalloc(&s->d_dinv, n * sizeof(double)));
+  FEMO_HIP_CHECK(hipMalloc(&s->d_scal, 8 * sizeof(double)));
+  FEMO_HIP_CHECK(hipMalloc(&s->d_part, 3 * SH_MAXPART * sizeof(double)));
+  FEMO_HIP_CHECK(hipMalloc(&s->d_flag, 4 * sizeof(int32_t)));
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  *out = s;
+  return 0;
+}
+
+int femo_shell_destroy(femo_shell* s) {
+  if (!s) return 0;
+  hipStreamSynchronize(s->ctx->stream);
+  hipFree(s->d_x); hipFree(s->d_conn); hipFree(s->d_cedge); hipFree(s->d_rowptr); hipFree(s->d_cols); hipFree(s->d_epos);
+  hipFree(s->d_r); hipFree(s->d_p); hipFree(s->d_q); hipFree(s->d_dinv); hipFree(s->d_scal); hipFree(s->d_part); hipFree(s->d_flag);
+  delete s;
+  return 0;
+}
+
+int64_t femo_shell_ndof(const femo_shell* s) { return s ? s->n_dof : -1; }
+int64_t femo_shell_nnz(const femo_shell* s) { return s ? s->nnz : -1; }
+
+int femo_shell_assemble(femo_shell* s, double E, double nu, const femo_vec* h, femo_vec* vals) {
+  FEMO_REQUIRE(s && h && vals, "null argument");
+  FEMO_REQUIRE(h->n >= s->n_vert && vals->n >= s->nnz, "vector size mismatch in shell_assemble");
+  FEMO_REQUIRE(E > 0.0 && nu > -1.0 && nu < 0.5, "bad material");
+  hipStream_t st = s->ctx->stream;
+  femo_vec_touch(vals);
+  FEMO_HIP_CHECK(hipMemsetAsync(vals->d, 0, s->nnz * sizeof(double), st));
+  hipLaunchKernelGGL(k_shell_assemble, dim3(sgrid(s->n_cell * 27)), dim3(SH_BLOCK), 0, st, view(s), E, nu, h->d, s->d_epos, vals->d);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int femo_shell_matvec(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_dev_or_null, const femo_vec* x, femo_vec* y) {
+  FEMO_REQUIRE(s && vals && x && y, "null argument");
+  FEMO_REQUIRE(vals->n >= s->nnz && x->n >= s->n_dof && y->n >= s->n_dof && x->d != y->d, "vector size mismatch in shell_matvec");
+  femo_vec_touch(y);
+  hipLaunchKernelGGL(k_csr_spmv, dim3(sgrid(s->n_dof, SH_BLOCK / 64)), dim3(SH_BLOCK), 0, s->ctx->stream, s->n_dof, s->d_rowptr, s->d_cols,
+                     vals->d, fixed_dev_or_null, x->d, y->d, (double*)nullptr, (const int32_t*)nullptr);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int femo_shell_load(femo_shell* s, const femo_vec* f, double sign, int accumulate, femo_vec* F) {
+  FEMO_REQUIRE(s && f && F, "null argument");
+  FEMO_REQUIRE(f->n >= 3 * s->n_vert && F->n >= s->n_dof, "vector size mismatch in shell_load");
+  hipStream_t st = s->ctx->stream;
+  femo_vec_touch(F);
+  if (!accumulate) FEMO_HIP_CHECK(hipMemsetAsync(F->d, 0, s->n_dof * sizeof(double), st));
+  hipLaunchKernelGGL(k_shell_load, dim3(sgrid(s->n_cell)), dim3(SH_BLOCK), 0, st, view(s), f->d, sign, F->d);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int femo_shell_load_T(femo_shell* s, const femo_vec* lam, double sign, int accumulate, femo_vec* out) {
+  FEMO_REQUIRE(s && lam && out, "null argument");
+  FEMO_REQUIRE(lam->n >= s->n_dof && out->n >= 3 * s->n_vert, "vector size mismatch in shell_load_T");
+  hipStream_t st = s->ctx->stream;
+  femo_vec_touch(out);
+  if (!accumulate) FEMO_HIP_CHECK(hipMemsetAsync(out->d, 0, 3 * s->n_vert * sizeof(double), st));
+  hipLaunchKernelGGL(k_shell_load_T, dim3(sgrid(s->n_cell)), dim3(SH_BLOCK), 0, st, view(s), lam->d, sign, out->d);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// out_b (+)= sign * v^T (dK/dh_b) w;  energy (optional) = 1/2 v^T K(h) w
+int femo_shell_dform_dh(femo_shell* s, double E, double nu, const femo_vec* h, const femo_vec* v, const femo_vec* w,
+                        int accumulate, femo_vec* out, double* energy) {
+  FEMO_REQUIRE(s && h && v && w, "null argument");
+  FEMO_REQUIRE(h->n >= s->n_vert && v->n >= s->n_dof && w->n >= s->n_dof, "vector size mismatch in shell_dform_dh");
+  FEMO_REQUIRE(out == nullptr || out->n >= s->n_vert, "output shorter than n_vert");
+  hipStream_t st = s->ctx->stream;
+  const unsigned g = sgrid(s->n_cell);
+  FEMO_REQUIRE(energy == nullptr || g <= 3 * SH_MAXPART, "mesh too large for the energy reduction buffer");
+  if (out) {
+    femo_vec_touch(out);
+    if (!accumulate) FEMO_HIP_CHECK(hipMemsetAsync(out->d, 0, s->n_vert * sizeof(double), st));
+  }
+  hipLaunchKernelGGL(k_shell_dform_dh, dim3(g), dim3(SH_BLOCK), 0, st, view(s), E, nu, h->d, v->d, w->d, out ? out->d : nullptr,
+                     energy ? s->d_part : nullptr);
+  FEMO_HIP_CHECK(hipGetLastError());
+  if (energy) FEMO_TRY(reduce_partials(s->ctx, s->d_part, (int)g, energy));
+  return 0;
+}
+
+int femo_shell_compliance(femo_shell* s, const femo_vec* w, double* value, int accumulate, femo_vec* grad) {
+  FEMO_REQUIRE(s && w, "null argument");
+  FEMO_REQUIRE(w->n >= s->n_dof && (grad == nullptr || grad->n >= s->n_dof), "vector size mismatch in shell_compliance");
+  hipStream_t st = s->ctx->stream;
+  const unsigned g = sgrid(s->n_cell);
+  FEMO_REQUIRE(value == nullptr || g <= 3 * SH_MAXPART, "mesh too large for the reduction buffer");
+  if (grad) {
+    femo_vec_touch(grad);
+    if (!accumulate) FEMO_HIP_CHECK(hipMemsetAsync(grad->d, 0, s->n_dof * sizeof(double), st));
+  }
+  hipLaunchKernelGGL(k_shell_compliance, dim3(g), dim3(SH_BLOCK), 0, st, view(s), w->d, value ? s->d_part : nullptr, grad ? grad->d : nullptr);
+  FEMO_HIP_CHECK(hipGetLastError());
+  if (value) FEMO_TRY(reduce_partials(s->ctx, s->d_part, (int)g, value));
+  return 0;
+}
+
+int femo_shell_mass(femo_shell* s, double rho, const femo_vec* h, double* value, int accumulate, femo_vec* grad) {
+  FEMO_REQUIRE(s && h, "null argument");
+  FEMO_REQUIRE(h->n >= s->n_vert && (grad == nullptr || grad->n >= s->n_vert), "vector size mismatch in shell_mass");
+  hipStream_t st = s->ctx->stream;
+  const unsigned g = sgrid(s->n_cell);
+  FEMO_REQUIRE(value == nullptr || g <= 3 * SH_MAXPART, "mesh too large for the reduction buffer");
+  if (grad) {
+    femo_vec_touch(grad);
+    if (!accumulate) FEMO_HIP_CHECK(hipMemsetAsync(grad->d, 0, s->n_vert * sizeof(double), st));
+  }
+  hipLaunchKernelGGL(k_shell_mass, dim3(g), dim3(SH_BLOCK), 0, st, view(s), rho, h->d, value ? s->d_part : nullptr, grad ? grad->d : nullptr);
+  FEMO_HIP_CHECK(hipGetLastError());
+  if (value) FEMO_TRY(reduce_partials(s->ctx, s->d_part, (int)g, value));
+  return 0;
+}
+
+// K_ff x_f = b_f - K_fc g_c with x_c = g_c on the dofs flagged in `fixed` (host array of n_dof bytes, values in xfix);
+// Jacobi-PCG, stops on sqrt(r.D^-1 r) <= max(rtol sqrt(r0.D^-1 r0), atol).  K symmetric: the same call serves
+// the adjoint (fea_dolfinx.py:208-222).
+int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_host, const femo_vec* xfix, const femo_vec* b,
+                     femo_vec* x, const femo_solver_opts* opts, femo_solve_info* info) {
+  FEMO_REQUIRE(s && vals && b && x && opts && info, "null argument");
+  const int64_t n = s->n_dof;
+  FEMO_REQUIRE(vals->n >= s->nnz && b->n >= n && x->n >= n && b->d != x->d, "vector size mismatch in shell_solve");
+  FEMO_REQUIRE(fixed_host == nullptr || xfix == nullptr || xfix->n >= n, "prescribed values shorter than n_dof");
+  femo_ctx* ctx = s->ctx;
+  hipStream_t st = ctx->stream;
+  memset(info, 0, sizeof *info);
+  femo_vec_touch(x);
+  uint8_t* d_fixed = nullptr;
+  if (fixed_host != nullptr) FEMO_TRY(to_device(&d_fixed, fixed_host, n, st));
+  const unsigned gv = std::min<unsigned>(sgrid(n), SH_MAXPART);
+  const unsigned gs = std::min<unsigned>(sgrid(n, SH_BLOCK / 64), SH_MAXPART);
+  double *Ppq = s->d_part, *Prz = s->d_part + SH_MAXPART, *gam = s->d_scal + 4;
+  FEMO_HIP_CHECK(hipEventRecord(ctx->ev0, st));
+  // right-hand side with lifting (into q); zero initial guess
+  FEMO_HIP_CHECK(hipMemsetAsync(x->d, 0, n * sizeof(double), st));
+  const double* rhs = b->d;
+  if (d_fixed != nullptr && xfix != nullptr) {
+    hipLaunchKernelGGL(k_csr_lift, dim3(gs), dim3(SH_BLOCK), 0, st, n, s->d_rowptr, s->d_cols, vals->d, d_fixed, xfix->d, b->d, s->d_q);
+    rhs = s->d_q;
+  }
+  hipLaunchKernelGGL(k_rhs_free, dim3(gv), dim3(256), 0, st, n, rhs, d_fixed, s->d_r);
+  hipLaunchKernelGGL(k_csr_diag_inv, dim3(gv), dim3(256), 0, st, n, s->d_rowptr, s->d_cols, vals->d, d_fixed, s->d_dinv);
+  hipLaunchKernelGGL(k_scg_init, dim3(gv), dim3(SH_BLOCK), 0, st, n, s->d_r, s->d_dinv, s->d_p, Prz);
+  hipLaunchKernelGGL(k_scg_gamma0, dim3(1), dim3(SH_BLOCK), 0, st, (int)gv, Prz, opts->rtol * opts->rtol, opts->atol * opts->atol, s->d_scal, s->d_flag);
+  FEMO_HIP_CHECK(hipGetLastError());
+  const int max_it = opts->max_it > 0 ? opts->max_it : 100000;
+  const int batch = opts->check_every > 0 ? opts->check_every : 64;
+  int32_t h_flag[4] = {0, 0, 0, 0};
+  double h_scal[8];
+  FEMO_HIP_CHECK(hipMemcpyAsync(h_flag, s->d_flag, sizeof h_flag, hipMemcpyDeviceToHost, st));
+  FEMO_HIP_CHECK(hipMemcpyAsync(h_scal, s->d_scal, sizeof h_scal, hipMemcpyDeviceToHost, st));
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  info->rhs_norm = std::sqrt(h_scal[1]);
+  int it = 0;
+  while (!h_flag[0] && it < max_it) {
+    const int it_end = std::min(it + batch, max_it);
+    for (; it < it_end; ++it) {
+      hipLaunchKernelGGL(k_csr_spmv, dim3(gs), dim3(SH_BLOCK), 0, st, n, s->d_rowptr, s->d_cols, vals->d, d_fixed, s->d_p, s->d_q, Ppq, s->d_flag);
+      hipLaunchKernelGGL(k_scg_xr, dim3(gv), dim3(SH_BLOCK), 0, st, n, (int)gs, Ppq, s->d_scal, s->d_p, s->d_q, s->d_dinv, x->d, s->d_r, Prz, s->d_flag);
+      hipLaunchKernelGGL(k_scg_p, dim3(gv), dim3(SH_BLOCK), 0, st, n, it, (int)gv, Prz, s->d_scal, s->d_r, s->d_dinv, s->d_p, s->d_flag, gam);
+      hipLaunchKernelGGL(k_scg_commit, dim3(1), dim3(1), 0, st, s->d_scal, gam, s->d_flag);
+    }
+    FEMO_HIP_CHECK(hipGetLastError());
+    FEMO_HIP_CHECK(hipMemcpyAsync(h_flag, s->d_flag, sizeof h_flag, hipMemcpyDeviceToHost, st));
+    FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  }
+  if (d_fixed != nullptr) hipLaunchKernelGGL(k_set_fixed, dim3(gv), dim3(256), 0, st, n, d_fixed, xfix ? xfix->d : nullptr, x->d);
+  FEMO_HIP_CHECK(hipMemcpyAsync(h_scal, s->d_scal, sizeof h_scal, hipMemcpyDeviceToHost, st));
+  FEMO_HIP_CHECK(hipEventRecord(ctx->ev1, st));
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  float ms = 0.f;
+  FEMO_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  info->solve_ms = ms;
+  info->iterations = h_flag[0] ? h_flag[1] : it;
+  info->converged = h_flag[0] ? (h_flag[2] ? -1 : 1) : 0;
+  info->residual_norm = std::sqrt(std::max(h_flag[0] && h_flag[1] > 0 ? h_scal[4] : h_scal[0], 0.0));
+  if (d_fixed) (void)hipFree(d_fixed);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,261 @@
+"""Reissner-Mindlin shell on the GPU engine: host side of `csrc/shell.hip`.
+
+Mirrors the surface of `examples/test_shell_m3l/shell_pde.py:219-332` (``ShellPDE``: function spaces W / VT / VF,
+``pdeRes``, ``compliance``, ``mass``, ``volume``, ``elastic_energy``) for the CG2^3 x CG1^3 element; the weak form the
+reference imports from ``shell_analysis_fenicsx`` is restated in `oracle/shell_oracle.py` and implemented by the
+kernels.  What is here: numbering of the P2 nodes, the CSR pattern of the 27 x 27 element couplings with the position
+of every element entry (the arrays `femo_shell_create` takes), and ``ShellProblem``: residual, stiffness, forward and
+adjoint solves, outputs and their partials -- the calls a StateOperation / OutputOperation makes
+(`state_model.py:75-218`, `output_model.py:69-87`), with NumPy arrays at the boundary.
+
+State layout (n_dof = 3 (n_vert + n_edge) + 3 n_vert): displacement of P2 node a, component k at 3 a + k (vertices first,
+then edge midpoints), rotation of vertex v at 3 (n_vert + n_edge) + 3 v + k.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from .. import _lib
+from .. import engine as E
+from ..engine import Context, Vec, check
+
+LOCAL_EDGES = ((0, 1), (1, 2), (2, 0))
+
+
+class ShellSpace:
+    """P2^3 x P1^3 degrees of freedom of a triangulated surface and the sparsity pattern of their couplings."""
+
+    def __init__(self, x: np.ndarray, conn: np.ndarray):
+        self.x = np.ascontiguousarray(x, dtype=np.float64)
+        self.conn = np.ascontiguousarray(conn, dtype=np.int32)
+        if self.x.ndim != 2 or self.x.shape[1] != 3 or self.conn.ndim != 2 or self.conn.shape[1] != 3:
+            raise ValueError("ShellSpace: x must be (n_vert, 3) and conn (n_cell, 3)")
+        nv = self.x.shape[0]
+        c64 = self.conn.astype(np.int64)
+        pairs = np.stack([np.sort(c64[:, list(e)], axis=1) for e in LOCAL_EDGES], axis=1)          # (nc, 3, 2)
+        key = pairs[..., 0] * nv + pairs[..., 1]
+        uniq, inv = np.unique(key.ravel(), return_inverse=True)
+        self.n_vert, self.n_cell, self.n_edge = nv, self.conn.shape[0], int(uniq.size)
+        self.edge_vertices = np.stack([uniq // nv, uniq % nv], axis=1)
+        self.cell_edges = np.ascontiguousarray(inv.reshape(-1, 3), dtype=np.int32)
+        self.n_unode = nv + self.n_edge
+        self.n_dof = 3 * self.n_unode + 3 * nv
+        unodes = np.concatenate([c64, nv + self.cell_edges.astype(np.int64)], axis=1)               # (nc, 6)
+        udofs = (3 * unodes[:, :, None] + np.arange(3)[None, None, :]).reshape(-1, 18)
+        tdofs = (3 * self.n_unode + 3 * c64[:, :, None] + np.arange(3)[None, None, :]).reshape(-1, 9)
+        self.cell_dofs = np.concatenate([udofs, tdofs], axis=1)                                     # (nc, 27)
+        self.unode_x = np.concatenate([self.x, 0.5 * (self.x[self.edge_vertices[:, 0]] + self.x[self.edge_vertices[:, 1]])])
+        self._pattern = None
+
+    def u_dof(self, node, comp):
+        return 3 * np.asarray(node, dtype=np.int64) + comp
+
+    def theta_dof(self, vertex, comp):
+        return 3 * self.n_unode + 3 * np.asarray(vertex, dtype=np.int64) + comp
+
+    def vertex_displacement(self, w: np.ndarray) -> np.ndarray:
+        return np.asarray(w)[: 3 * self.n_vert].reshape(-1, 3)
+
+    def pattern(self):
+        """(rowptr int64, cols int32, elem_pos int32 (n_cell, 729)): CSR pattern of all element couplings (rows
+        sorted by column) and the position of K_e[i][j] of every cell in it."""
+        if self._pattern is None:
+            cd = self.cell_dofs
+            rows = np.repeat(cd, 27, axis=1).ravel()
+            cols = np.tile(cd, (1, 27)).ravel()
+            key = rows * self.n_dof + cols
+            uniq, inv = np.unique(key, return_inverse=True)
+            if uniq.size >= 2 ** 31:
+                raise ValueError("shell pattern exceeds 32-bit element positions")
+            urow = uniq // self.n_dof
+            rowptr = np.zeros(self.n_dof + 1, dtype=np.int64)
+            np.add.at(rowptr, urow + 1, 1)
+            np.cumsum(rowptr, out=rowptr)
+            self._pattern = (rowptr, np.ascontiguousarray(uniq % self.n_dof, dtype=np.int32),
+                             np.ascontiguousarray(inv.reshape(-1, 729), dtype=np.int32))
+        return self._pattern
+
+
+class DeviceShell:
+    """`femo_shell` handle."""
+
+    def __init__(self, ctx: Context, space: ShellSpace):
+        self.ctx, self.space, self.lib = ctx, space, _lib.load()
+        rowptr, cols, epos = space.pattern()
+        self.handle = _lib.H()
+        p = lambda a: C.c_void_p(a.ctypes.data)
+        check(self.lib.femo_shell_create(ctx.handle, space.n_vert, p(space.x), space.n_cell, p(space.conn), space.n_edge,
+                                         p(space.cell_edges), p(rowptr), p(cols), p(epos), C.byref(self.handle)))
+        self.n_dof = int(self.lib.femo_shell_ndof(self.handle))
+        self.nnz = int(self.lib.femo_shell_nnz(self.handle))
+        assert self.n_dof == space.n_dof and self.nnz == cols.size
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.femo_shell_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # thin wrappers --------------------------------------------------------------------------------
+    def assemble(self, Ey: float, nu: float, h: Vec, vals: Vec) -> Vec:
+        check(self.lib.femo_shell_assemble(self.handle, float(Ey), float(nu), h.handle, vals.handle))
+        return vals
+
+    def matvec(self, vals: Vec, x: Vec, y: Vec) -> Vec:
+        check(self.lib.femo_shell_matvec(self.handle, vals.handle, None, x.handle, y.handle))
+        return y
+
+    def load(self, f: Vec, F: Vec, sign: float = 1.0, accumulate: bool = False) -> Vec:
+        check(self.lib.femo_shell_load(self.handle, f.handle, float(sign), int(accumulate), F.handle))
+        return F
+
+    def load_T(self, lam: Vec, out: Vec, sign: float = 1.0, accumulate: bool = False) -> Vec:
+        check(self.lib.femo_shell_load_T(self.handle, lam.handle, float(sign), int(accumulate), out.handle))
+        return out
+
+    def dform_dh(self, Ey, nu, h: Vec, v: Vec, w: Vec, out: Optional[Vec] = None, accumulate: bool = False, energy: bool = False):
+        en = C.c_double(0.0)
+        check(self.lib.femo_shell_dform_dh(self.handle, float(Ey), float(nu), h.handle, v.handle, w.handle, int(accumulate),
+                                           out.handle if out is not None else None, C.byref(en) if energy else None))
+        return en.value if energy else out
+
+    def compliance(self, w: Vec, grad: Optional[Vec] = None, value: bool = True, accumulate: bool = False):
+        val = C.c_double(0.0)
+        check(self.lib.femo_shell_compliance(self.handle, w.handle, C.byref(val) if value else None, int(accumulate),
+                                             grad.handle if grad is not None else None))
+        return val.value
+
+    def mass(self, rho: float, h: Vec, grad: Optional[Vec] = None, value: bool = True, accumulate: bool = False):
+        val = C.c_double(0.0)
+        check(self.lib.femo_shell_mass(self.handle, float(rho), h.handle, C.byref(val) if value else None, int(accumulate),
+                                       grad.handle if grad is not None else None))
+        return val.value
+
+    def solve(self, vals: Vec, b: Vec, x: Vec, fixed: Optional[np.ndarray] = None, xfix: Optional[Vec] = None,
+              rtol: float = 1e-12, atol: float = 0.0, max_it: int = 2_000_000, check_every: int = 64):
+        opts = _lib.SolverOpts(rtol=rtol, atol=atol, max_it=max_it, zero_guess=1, check_every=check_every, pc=0, atol_pc=0.0)
+        info = _lib.SolveInfo()
+        mask = None
+        if fixed is not None:
+            mask = np.ascontiguousarray(fixed, dtype=np.uint8)
+            assert mask.size == self.n_dof
+        check(self.lib.femo_shell_solve(self.handle, vals.handle, C.c_void_p(mask.ctypes.data) if mask is not None else None,
+                                        xfix.handle if xfix is not None else None, b.handle, x.handle, C.byref(opts), C.byref(info)))
+        if info.converged != 1:
+            raise E.FemoError(f"shell CG did not converge: {info.iterations} iterations, residual {info.residual_norm:.3e} "
+                              f"(rhs {info.rhs_norm:.3e})")
+        return info
+
+
+class ShellProblem:
+    """The linear shell state problem R(w; h, f) = K(h) w - F(f) = 0 with strongly imposed dofs, its adjoint and the
+    outputs of `shell_pde.py` -- what StateOperation / OutputOperation evaluate (`state_model.py:75-218`), NumPy at the
+    boundary.  ``fixed_dofs``: indices into the state vector (the reference imposes them strongly in
+    `run_shape_opt_roof.py:131-160` and by a penalty in `shell_pde.py:246-253`, whose limit this is)."""
+
+    def __init__(self, x, conn, E_young: float, nu: float, fixed_dofs: Sequence[int] = (), ctx: Optional[Context] = None):
+        from .utils_hip import get_context
+        self.ctx = ctx if ctx is not None else get_context()
+        self.space = ShellSpace(x, conn)
+        self.dev = DeviceShell(self.ctx, self.space)
+        self.E, self.nu = float(E_young), float(nu)
+        n, nv = self.space.n_dof, self.space.n_vert
+        self.fixed = np.zeros(n, dtype=np.uint8)
+        self.fixed[np.asarray(list(fixed_dofs), dtype=np.int64)] = 1
+        c = self.ctx
+        self.h, self.f = Vec(c, nv), Vec(c, 3 * nv)
+        self.w, self.F, self.tmp, self.lam = Vec(c, n), Vec(c, n), Vec(c, n), Vec(c, n)
+        self.vals = Vec(c, self.dev.nnz)
+        self.gh, self.gf = Vec(c, nv), Vec(c, 3 * nv)
+        self._K_for = None
+        self.last_info = None
+
+    # inputs ---------------------------------------------------------------------------------------
+    def set_thickness(self, h) -> None:
+        h = np.broadcast_to(np.asarray(h, dtype=np.float64), (self.space.n_vert,))
+        self.h.set(np.ascontiguousarray(h))
+        self._K_for = None
+
+    def set_load(self, f) -> None:
+        f = np.broadcast_to(np.asarray(f, dtype=np.float64).reshape(-1, 3) if np.ndim(f) > 1 else np.asarray(f, dtype=np.float64),
+                            (self.space.n_vert, 3))
+        self.f.set(np.ascontiguousarray(f).ravel())
+
+    def _stiffness(self) -> Vec:
+        if self._K_for is None:                     # reset by set_thickness
+            self.dev.assemble(self.E, self.nu, self.h, self.vals)
+            self._K_for = True
+        return self.vals
+
+    # state ----------------------------------------------------------------------------------------
+    def residual(self, w: np.ndarray) -> np.ndarray:
+        """K(h) w - F(f), no Dirichlet treatment (evaluate_residuals, state_model.py:75-85)."""
+        K = self._stiffness()
+        self.w.set(np.ascontiguousarray(w, dtype=np.float64))
+        self.dev.matvec(K, self.w, self.tmp)
+        self.dev.load(self.f, self.tmp, sign=-1.0, accumulate=True)
+        return np.array(self.tmp.get())
+
+    def solve(self, rtol: float = 1e-12) -> np.ndarray:
+        """solve_residual_equations (state_model.py:87-115): w with the strongly imposed dofs at zero."""
+        K = self._stiffness()
+        self.dev.load(self.f, self.F)
+        self.last_info = self.dev.solve(K, self.F, self.w, fixed=self.fixed, rtol=rtol)
+        return np.array(self.w.get())
+
+    def solve_adjoint(self, rhs: np.ndarray, rtol: float = 1e-12) -> np.ndarray:
+        """apply_inverse_jacobian 'rev' (state_model.py:202-218): K^-T rhs with the Dirichlet rows / columns eliminated
+        (K is symmetric); the entries of rhs on imposed dofs do not enter."""
+        K = self._stiffness()
+        self.tmp.set(np.ascontiguousarray(rhs, dtype=np.float64))
+        self.last_info = self.dev.solve(K, self.tmp, self.lam, fixed=self.fixed, rtol=rtol)
+        return np.array(self.lam.get())
+
+    # partials of the residual --------------------------------------------------------------------
+    def dRdh_T(self, lam: np.ndarray, w: Optional[np.ndarray] = None) -> np.ndarray:
+        """(dR/dh)^T lam = lam^T dK/dh w per thickness dof (compute_jacvec_product 'rev', state_model.py:190-200)."""
+        if w is not None:
+            self.w.set(np.ascontiguousarray(w, dtype=np.float64))
+        self.lam.set(np.ascontiguousarray(lam, dtype=np.float64))
+        self.dev.dform_dh(self.E, self.nu, self.h, self.lam, self.w, out=self.gh)
+        return np.array(self.gh.get())
+
+    def dRdf_T(self, lam: np.ndarray) -> np.ndarray:
+        """(dR/df)^T lam = -(dF/df)^T lam, shape (n_vert, 3)."""
+        self.lam.set(np.ascontiguousarray(lam, dtype=np.float64))
+        self.dev.load_T(self.lam, self.gf, sign=-1.0)
+        return np.array(self.gf.get()).reshape(-1, 3)
+
+    # outputs --------------------------------------------------------------------------------------
+    def compliance(self, w: Optional[np.ndarray] = None, grad: bool = False):
+        if w is not None:
+            self.w.set(np.ascontiguousarray(w, dtype=np.float64))
+        if grad:
+            J = self.dev.compliance(self.w, grad=self.tmp)
+            return J, np.array(self.tmp.get())
+        return self.dev.compliance(self.w)
+
+    def mass(self, rho: float = 1.0, grad: bool = False):
+        if grad:
+            M = self.dev.mass(rho, self.h, grad=self.gh)
+            return M, np.array(self.gh.get())
+        return self.dev.mass(rho, self.h)
+
+    def elastic_energy(self, w: Optional[np.ndarray] = None) -> float:
+        if w is not None:
+            self.w.set(np.ascontiguousarray(w, dtype=np.float64))
+        return self.dev.dform_dh(self.E, self.nu, self.h, self.w, self.w, energy=True)
+
+    # the adjoint cycle of BASELINE config 3 ----------------------------------------------------
+    def compliance_gradient(self):
+        """J(h) = 1/2 int |u_mid(h)|^2 and dJ/dh by the adjoint: K w = F, K lam = dJ/dw, dJ/dh = -lam^T dK/dh w."""
+        w = self.solve()
+        J, dJdw = self.compliance(grad=True)
+        dJdw[self.fixed.astype(bool)] = 0.0
+        lam = self.solve_adjoint(dJdw)
+        return J, -self.dRdh_T(lam), w

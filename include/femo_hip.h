@@ -41,6 +41,7 @@ typedef struct femo_mesh femo_mesh;  /* P1 simplex mesh + vertex->cell incidence
 typedef struct femo_bc   femo_bc;    /* strong Dirichlet set (fea_dolfinx.py:169-176 add_strong_bc)   */
 typedef struct femo_mat  femo_mat;   /* N x N sparse matrix on the mesh pattern (PETSc Mat)           */
 typedef struct femo_emu_group femo_emu_group;  /* in-process rank emulation, tests only (see below)  */
+typedef struct femo_shell femo_shell; /* Reissner-Mindlin shell space CG2^3 x CG1^3 on a triangulated surface (below) */
 
 /* closed catalogue of residual forms (UFL is not available) */
 enum femo_pde_kind {
@@ -334,6 +335,41 @@ int femo_allreduce_sum(femo_ctx* ctx, double* host_inout, int n);
 int femo_emu_group_create(int nranks, femo_emu_group** out);
 int femo_emu_group_destroy(femo_emu_group* group);
 int femo_comm_emulate(femo_ctx* ctx, femo_emu_group* group, int rank);
+
+/* ---- Reissner-Mindlin shell (examples/test_shell_m3l/shell_pde.py:219-332) ----------
+ * State w = (u_mid in CG2^3, theta in CG1^3) on flat triangular facets: 3 dofs per P2 node (vertices [0, n_vert), then
+ * edge midpoints), then 3 per vertex; thickness h and surface load f are CG1 fields at the vertices (shell_pde.py:
+ * 228-231).  Formulation: oracle/shell_oracle.py (membrane + bending + shear + drilling energies, ElasticModel of the
+ * un-vendored shell_analysis_fenicsx restated from its published source, pinned by the Scordelis-Lo roof).
+ * The host side (femo_amd/fea/shell.py) numbers the edges and builds the CSR pattern of the element couplings:
+ *   cell_edges[c][k] = edge of local edge k = (0,1), (1,2), (2,0);   rowptr / cols: pattern over the n_dof dofs;
+ *   elem_pos[c][27 i + j] = CSR position of the coupling of local dofs i, j (local order: 6 displacement nodes x 3
+ *   components, then 3 rotation nodes x 3).
+ * Matrices are plain value arrays (femo_vec of nnz entries) on that pattern.                                        */
+int femo_shell_create(femo_ctx* ctx, int64_t n_vert, const double* x, int64_t n_cell, const int32_t* conn, int64_t n_edge,
+                      const int32_t* cell_edges, const int64_t* rowptr, const int32_t* cols, const int32_t* elem_pos,
+                      femo_shell** out);
+int femo_shell_destroy(femo_shell* s);
+int64_t femo_shell_ndof(const femo_shell* s);
+int64_t femo_shell_nnz(const femo_shell* s);
+/* K(h): stiffness of the elastic energy (pdeRes / elasticEnergy, shell_pde.py:246-253); dR/dw of the linear residual */
+int femo_shell_assemble(femo_shell* s, double E, double nu, const femo_vec* h, femo_vec* vals);
+/* y = K x; fixed_dev != NULL (device array of n_dof bytes): the operator with strongly imposed dofs as identity rows/columns */
+int femo_shell_matvec(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_dev_or_null, const femo_vec* x, femo_vec* y);
+/* F (+)= sign * int f . v (weakFormResidual's load term) and its transpose: out (+)= sign * (dF/df)^T lambda */
+int femo_shell_load(femo_shell* s, const femo_vec* f, double sign, int accumulate, femo_vec* F);
+int femo_shell_load_T(femo_shell* s, const femo_vec* lam, double sign, int accumulate, femo_vec* out);
+/* out_b (+)= v^T (dK/dh_b) w -- (dR/dh)^T lambda for R = K(h) w - F with v = lambda; *energy = 1/2 v^T K w (shell_pde.py:299-302) */
+int femo_shell_dform_dh(femo_shell* s, double E, double nu, const femo_vec* h, const femo_vec* v, const femo_vec* w,
+                        int accumulate, femo_vec* out, double* energy);
+/* 1/2 int u_mid . u_mid (shell_pde.py:287-288) and its gradient; int rho h (shell_pde.py:293-294) and its gradient */
+int femo_shell_compliance(femo_shell* s, const femo_vec* w, double* value, int accumulate, femo_vec* grad);
+int femo_shell_mass(femo_shell* s, double rho, const femo_vec* h, double* value, int accumulate, femo_vec* grad);
+/* K x = b with x = xfix on the dofs flagged in fixed_host (n_dof bytes; NULL: none; xfix NULL: zero values).
+ * Jacobi-PCG, sqrt(r.D^-1 r) <= max(rtol sqrt(r0.D^-1 r0), atol); K is symmetric, so the adjoint solve
+ * (fea_dolfinx.py:208-222) is the same call.  The reference uses MUMPS (utils_dolfinx.py:476-512).              */
+int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_host, const femo_vec* xfix, const femo_vec* b,
+                     femo_vec* x, const femo_solver_opts* opts, femo_solve_info* info);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,291 @@
+"""TEST INFRASTRUCTURE (oracle): CPU restatement of the Reissner-Mindlin shell of BASELINE config 3
+(SURVEY.md section 8(f) row 3).  Only tests/ may import it; the product (femo_amd/) never does.
+
+**Parity unpinned.**  The reference takes the weak form from the package ``shell_analysis_fenicsx``
+(`examples/test_shell_m3l/shell_pde.py:5,246-253`: ``ShellElement``, ``MaterialModel``, ``ElasticModel.elasticEnergy``,
+``weakFormResidual``), which is not in the tree and not installable here.  What the tree fixes is the discretisation
+(`shell_pde.py:222-232`: element type "CG2CG1", separate measures ``dx_inplane`` / ``dx_shear``), the state
+w = (u_mid in CG2^3, theta in CG1^3) (`shell_module.py`, `shell_pde.py:228`), the CG1 thickness (`shell_pde.py:229`)
+and one known answer: the Scordelis-Lo roof, v_tip = -0.3024 (`examples/ongoing/shape_opt/run_shape_opt_roof.py:
+48-51,131-160,224`: E = 4.32e8, nu = 0, h = 0.25, f = (0, 0, -90) per unit area, quarter model with a diaphragm at
+x = 25 and two symmetry planes).  This file restates the published linear shell model that package is built on
+(J. Bleyer, "Numerical tours of computational mechanics with FEniCS", linear shell demo [ext]: local tangent frame
+per facet, membrane + bending + transverse shear + drilling energies, rotations as a global 3-vector) with the CG2/CG1
+pair and a separate, lower-degree rule for the shear energy, and is pinned by that known answer (-0.2992 on a
+16 x 16 mesh, -0.3010 on 32 x 32, converging from below), by a Kirchhoff plate solution and by rigid-body / patch
+properties (tests/test_oracle_shell.py).
+
+Kinematics on a flat facet with orthonormal tangent frame (e1, e2) and normal e3 (any tangent frame gives the same
+energy for the isotropic material), s_j = tangent coordinates:
+    eps_ij   = sym(e_i . du/ds_j)                                  membrane strain
+    beta     = e3 x theta,  kappa_ij = sym(e_i . dbeta/ds_j)       bending strain
+    gamma_j  = e3 . du/ds_j - e_j . beta                           transverse shear
+    omega    = (e1 . du/ds_2 - e2 . du/ds_1) / 2 + e3 . theta      drilling strain (zero for rigid rotations)
+Energy  1/2 int [ h eps:C:eps + h^3/12 kappa:C:kappa + E h^3 omega^2 ] dx_inplane + 1/2 int (5/6) mu h |gamma|^2 dx_shear,
+C = plane-stress elasticity.  Degrees of freedom: 3 per P2 node (vertices, then edge midpoints), then 3 per vertex.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+# Dunavant degree-4 rule (6 points): barycentric coordinates and weights (sum 1)
+_A1, _B1, _W1 = 0.445948490915965, 0.108103018168070, 0.223381589678011
+_A2, _B2, _W2 = 0.091576213509771, 0.816847572980459, 0.109951743655322
+QUAD_INPLANE = (np.array([[_B1, _A1, _A1], [_A1, _B1, _A1], [_A1, _A1, _B1],
+                          [_B2, _A2, _A2], [_A2, _B2, _A2], [_A2, _A2, _B2]]),
+                np.array([_W1, _W1, _W1, _W2, _W2, _W2]))
+# dx_shear: the degree-2 rule (3 points).  It is the lowest rule that keeps the CG2/CG1 pair rank sufficient -- with
+# the one-point rule the assembled roof problem is singular (tests/test_oracle_shell.py) -- and it is "reduced"
+# against dx_inplane (degree 4, needed for the CG1 thickness under the quadratic membrane terms).
+QUAD_SHEAR = (np.array([[2 / 3, 1 / 6, 1 / 6], [1 / 6, 2 / 3, 1 / 6], [1 / 6, 1 / 6, 2 / 3]]), np.array([1 / 3, 1 / 3, 1 / 3]))
+QUAD_ONE_POINT = (np.array([[1 / 3, 1 / 3, 1 / 3]]), np.array([1.0]))
+LOCAL_EDGES = ((0, 1), (1, 2), (2, 0))
+SHEAR_CORRECTION = 5.0 / 6.0
+
+
+class ShellSpace:
+    """P2^3 x P1^3 on a triangulated surface.  ``conn``: (n_cell, 3) vertex indices."""
+
+    def __init__(self, x: np.ndarray, conn: np.ndarray):
+        self.x = np.asarray(x, dtype=np.float64)
+        self.conn = np.asarray(conn, dtype=np.int64)
+        nv = self.x.shape[0]
+        pairs = np.stack([np.sort(self.conn[:, list(e)], axis=1) for e in LOCAL_EDGES], axis=1)      # (nc, 3, 2)
+        key = pairs[..., 0] * nv + pairs[..., 1]
+        uniq, inv = np.unique(key.ravel(), return_inverse=True)
+        self.n_vert, self.n_edge = nv, uniq.size
+        self.edge_vertices = np.stack([uniq // nv, uniq % nv], axis=1)
+        self.cell_edges = inv.reshape(-1, 3)
+        self.n_unode = nv + self.n_edge
+        self.n_dof = 3 * self.n_unode + 3 * nv
+        # element dof map: 6 displacement nodes x 3, then 3 rotation nodes x 3
+        unodes = np.concatenate([self.conn, nv + self.cell_edges], axis=1)                               # (nc, 6)
+        udofs = (3 * unodes[:, :, None] + np.arange(3)[None, None, :]).reshape(-1, 18)
+        tdofs = (3 * self.n_unode + 3 * self.conn[:, :, None] + np.arange(3)[None, None, :]).reshape(-1, 9)
+        self.cell_dofs = np.concatenate([udofs, tdofs], axis=1)                                          # (nc, 27)
+        self.unode_x = np.concatenate([self.x, 0.5 * (self.x[self.edge_vertices[:, 0]] + self.x[self.edge_vertices[:, 1]])])
+
+    # dof helpers ----------------------------------------------------------------------------------
+    def u_dof(self, node, comp):
+        return 3 * np.asarray(node) + comp
+
+    def theta_dof(self, vertex, comp):
+        return 3 * self.n_unode + 3 * np.asarray(vertex) + comp
+
+    def vertex_displacement(self, w: np.ndarray) -> np.ndarray:
+        return w[: 3 * self.n_vert].reshape(-1, 3)
+
+    # geometry -------------------------------------------------------------------------------------
+    def frames(self):
+        """Per cell: e1, e2, e3, area, grad_lambda (3 barycentric gradients in tangent coordinates)."""
+        p0, p1, p2 = (self.x[self.conn[:, k]] for k in range(3))
+        t1, t2 = p1 - p0, p2 - p0
+        n = np.cross(t1, t2)
+        dbl = np.linalg.norm(n, axis=1)
+        e3 = n / dbl[:, None]
+        e1 = t1 / np.linalg.norm(t1, axis=1)[:, None]
+        e2 = np.cross(e3, e1)
+        area = 0.5 * dbl
+        # tangent coordinates of the vertices: p0 = (0,0), p1 = (a,0), p2 = (b,c)
+        a = np.einsum("ci,ci->c", t1, e1)
+        b = np.einsum("ci,ci->c", t2, e1)
+        c = np.einsum("ci,ci->c", t2, e2)
+        X = np.stack([np.zeros_like(a), a, b], axis=1)
+        Y = np.stack([np.zeros_like(a), np.zeros_like(a), c], axis=1)
+        det = 2.0 * area
+        gl = np.empty((self.conn.shape[0], 3, 2))
+        for i in range(3):
+            j, k = (i + 1) % 3, (i + 2) % 3
+            gl[:, i, 0] = (Y[:, j] - Y[:, k]) / det
+            gl[:, i, 1] = (X[:, k] - X[:, j]) / det
+        return e1, e2, e3, area, gl
+
+
+def _p2(lam: np.ndarray, gl: np.ndarray):
+    """P2 shape functions (6,) and their tangent gradients (nc, 6, 2) at barycentric point lam."""
+    N = np.empty(6)
+    dN = np.zeros((6, 3))                                           # d N_a / d lambda_i
+    for i in range(3):
+        N[i] = lam[i] * (2 * lam[i] - 1)
+        dN[i, i] = 4 * lam[i] - 1
+    for k, (i, j) in enumerate(LOCAL_EDGES):
+        N[3 + k] = 4 * lam[i] * lam[j]
+        dN[3 + k, i] = 4 * lam[j]
+        dN[3 + k, j] = 4 * lam[i]
+    return N, np.einsum("ai,cij->caj", dN, gl)
+
+
+def _strain_operators(e1, e2, e3, gN, gM, M):
+    """B matrices (nc, rows, 27) at one point: membrane (3, Voigt with engineering shear), bending (3), shear (2),
+    drilling (1).  gN: (nc, 6, 2) P2 gradients, gM: (nc, 3, 2) P1 gradients, M: (3,) P1 values."""
+    nc = e1.shape[0]
+    Bm, Bb = np.zeros((nc, 3, 27)), np.zeros((nc, 3, 27))
+    Bs, Bd = np.zeros((nc, 2, 27)), np.zeros((nc, 1, 27))
+    for a in range(6):
+        cols = slice(3 * a, 3 * a + 3)
+        g1, g2 = gN[:, a, 0][:, None], gN[:, a, 1][:, None]
+        Bm[:, 0, cols] = e1 * g1
+        Bm[:, 1, cols] = e2 * g2
+        Bm[:, 2, cols] = e1 * g2 + e2 * g1
+        Bs[:, 0, cols] = e3 * g1
+        Bs[:, 1, cols] = e3 * g2
+        Bd[:, 0, cols] = 0.5 * (e1 * g2 - e2 * g1)
+    for b in range(3):
+        cols = slice(18 + 3 * b, 18 + 3 * b + 3)
+        g1, g2 = gM[:, b, 0][:, None], gM[:, b, 1][:, None]
+        # kappa_1j = -e2 . dtheta/ds_j,  kappa_2j = e1 . dtheta/ds_j
+        Bb[:, 0, cols] = -e2 * g1
+        Bb[:, 1, cols] = e1 * g2
+        Bb[:, 2, cols] = -e2 * g2 + e1 * g1
+        Bs[:, 0, cols] = e2 * M[b]
+        Bs[:, 1, cols] = -e1 * M[b]
+        Bd[:, 0, cols] = e3 * M[b]
+    return Bm, Bb, Bs, Bd
+
+
+def plane_stress(E: float, nu: float) -> np.ndarray:
+    return E / (1.0 - nu * nu) * np.array([[1.0, nu, 0.0], [nu, 1.0, 0.0], [0.0, 0.0, 0.5 * (1.0 - nu)]])
+
+
+def element_stiffness(V: ShellSpace, h_nodal: np.ndarray, E: float, nu: float, return_parts: bool = False,
+                      quad_shear=None):
+    """(n_cell, 27, 27) element matrices for the CG1 thickness ``h_nodal`` (n_vert,)."""
+    quad_shear = QUAD_SHEAR if quad_shear is None else quad_shear
+    e1, e2, e3, area, gl = V.frames()
+    C = plane_stress(E, nu)
+    mu = E / (2.0 * (1.0 + nu))
+    hc = np.asarray(h_nodal, dtype=np.float64)[V.conn]              # (nc, 3)
+    nc = V.conn.shape[0]
+    Km, Kb, Ks, Kd = (np.zeros((nc, 27, 27)) for _ in range(4))
+    for lam, wq in zip(*QUAD_INPLANE):
+        _, gN = _p2(lam, gl)
+        Bm, Bb, _, Bd = _strain_operators(e1, e2, e3, gN, gl, lam)
+        h = hc @ lam
+        w = wq * area
+        Km += np.einsum("c,cia,ij,cjb->cab", w * h, Bm, C, Bm)
+        Kb += np.einsum("c,cia,ij,cjb->cab", w * h ** 3 / 12.0, Bb, C, Bb)
+        Kd += np.einsum("c,cia,cib->cab", w * E * h ** 3, Bd, Bd)
+    for lam, wq in zip(*quad_shear):
+        _, gN = _p2(lam, gl)
+        _, _, Bs, _ = _strain_operators(e1, e2, e3, gN, gl, lam)
+        h = hc @ lam
+        Ks += np.einsum("c,cia,cib->cab", wq * area * SHEAR_CORRECTION * mu * h, Bs, Bs)
+    if return_parts:
+        return Km, Kb, Ks, Kd
+    return Km + Kb + Ks + Kd
+
+
+def assemble(V: ShellSpace, Ke: np.ndarray) -> sp.csr_matrix:
+    rows = np.repeat(V.cell_dofs, 27, axis=1).ravel()
+    cols = np.tile(V.cell_dofs, (1, 27)).ravel()
+    return sp.coo_matrix((Ke.ravel(), (rows, cols)), shape=(V.n_dof, V.n_dof)).tocsr()
+
+
+def load_vector(V: ShellSpace, f_nodal: np.ndarray) -> np.ndarray:
+    """int f . v with f a CG1 vector field given at the vertices (n_vert, 3) (force per unit area)."""
+    _, _, _, area, gl = V.frames()
+    F = np.zeros(V.n_dof)
+    fc = np.asarray(f_nodal, dtype=np.float64)[V.conn]              # (nc, 3, 3)
+    for lam, wq in zip(*QUAD_INPLANE):
+        N, _ = _p2(lam, gl)
+        fq = np.einsum("b,cbi->ci", lam, fc)
+        contrib = np.einsum("c,a,ci->cai", wq * area, N, fq).reshape(-1, 18)
+        np.add.at(F, V.cell_dofs[:, :18].ravel(), contrib.ravel())
+    return F
+
+
+def solve(K: sp.csr_matrix, F: np.ndarray, fixed: Sequence[int], values: Optional[np.ndarray] = None) -> np.ndarray:
+    """Static solve with strongly imposed dofs (the reference imposes them strongly in run_shape_opt_roof.py:131-160
+    and by penalty in shell_pde.py:246-253; the limit of the penalty form is this elimination)."""
+    n = K.shape[0]
+    fixed = np.unique(np.asarray(fixed, dtype=np.int64))
+    w = np.zeros(n)
+    if values is not None:
+        w[fixed] = values
+    free = np.setdiff1d(np.arange(n), fixed)
+    rhs = F[free] - K[free][:, fixed] @ w[fixed]
+    w[free] = spla.spsolve(K[free][:, free].tocsc(), rhs)
+    return w
+
+
+def energy_parts(V: ShellSpace, w: np.ndarray, h_nodal, E, nu) -> Dict[str, float]:
+    parts = element_stiffness(V, h_nodal, E, nu, return_parts=True)
+    we = w[V.cell_dofs]
+    return {k: 0.5 * float(np.einsum("ca,cab,cb->", we, P, we)) for k, P in zip(("membrane", "bending", "shear", "drilling"), parts)}
+
+
+def compliance(V: ShellSpace, w: np.ndarray) -> float:
+    """1/2 int u_mid . u_mid  (shell_pde.py:287-288 without the regularisation term), P2 mass matrix, degree-4 rule."""
+    _, _, _, area, gl = V.frames()
+    ue = w[V.cell_dofs[:, :18]].reshape(-1, 6, 3)
+    J = 0.0
+    for lam, wq in zip(*QUAD_INPLANE):
+        N, _ = _p2(lam, gl)
+        uq = np.einsum("a,cai->ci", N, ue)
+        J += 0.5 * float(np.einsum("c,ci,ci->", wq * area, uq, uq))
+    return J
+
+
+# ------------------------------------------------------------------------------ test problems ----
+def scordelis_lo_mesh(nx: int, nphi: int, R: float = 25.0, L: float = 25.0, phi_max: float = np.deg2rad(40.0)):
+    """Quarter of the Scordelis-Lo roof as in run_shape_opt_roof.py: axis along x in [0, L], y = R sin(phi),
+    z = R cos(phi), phi in [0, 40 deg]; each (x, phi) cell split into two triangles."""
+    xs = np.linspace(0.0, L, nx + 1)
+    ph = np.linspace(0.0, phi_max, nphi + 1)
+    X, P = np.meshgrid(xs, ph, indexing="ij")
+    pts = np.stack([X.ravel(), R * np.sin(P).ravel(), R * np.cos(P).ravel()], axis=1)
+    idx = np.arange((nx + 1) * (nphi + 1)).reshape(nx + 1, nphi + 1)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    conn = np.concatenate([np.stack([a, b, c], axis=1), np.stack([a, c, d], axis=1)])
+    return pts, conn
+
+
+def scordelis_lo(nx: int, nphi: int) -> Tuple[float, ShellSpace, np.ndarray]:
+    """Vertical displacement at the midpoint of the free edge (reference value -0.3024,
+    run_shape_opt_roof.py:224) with the boundary conditions of run_shape_opt_roof.py:131-160."""
+    E, nu, h, fz, L = 4.32e8, 0.0, 0.25, -90.0, 25.0
+    pts, conn = scordelis_lo_mesh(nx, nphi, L=L)
+    V = ShellSpace(pts, conn)
+    K = assemble(V, element_stiffness(V, np.full(V.n_vert, h), E, nu))
+    F = load_vector(V, np.tile([0.0, 0.0, fz], (V.n_vert, 1)))
+    ux, vx = V.unode_x, V.x
+    on = lambda arr, val: np.nonzero(np.isclose(arr, val, atol=1e-6))[0]
+    fixed = np.concatenate([
+        V.u_dof(on(ux[:, 0], L), 1), V.u_dof(on(ux[:, 0], L), 2),                       # diaphragm at x = L
+        V.u_dof(on(ux[:, 1], 0.0), 1), V.theta_dof(on(vx[:, 1], 0.0), 0), V.theta_dof(on(vx[:, 1], 0.0), 2),   # crown symmetry
+        V.u_dof(on(ux[:, 0], 0.0), 0), V.theta_dof(on(vx[:, 0], 0.0), 1), V.theta_dof(on(vx[:, 0], 0.0), 2),   # midspan symmetry
+    ])
+    w = solve(K, F, fixed)
+    tip = int(np.argmin(np.abs(vx[:, 0]) + np.abs(vx[:, 1] - vx[:, 1].max())))
+    return float(V.vertex_displacement(w)[tip, 2]), V, w
+
+
+def plate_mesh(n: int, a: float = 1.0):
+    """Flat square plate [0, a]^2 in the plane z = 0, n x n cells split into two triangles each."""
+    g = np.linspace(0.0, a, n + 1)
+    X, Y = np.meshgrid(g, g, indexing="ij")
+    pts = np.stack([X.ravel(), Y.ravel(), np.zeros(X.size)], axis=1)
+    idx = np.arange((n + 1) ** 2).reshape(n + 1, n + 1)
+    p, q, r, t = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    return pts, np.concatenate([np.stack([p, q, r], axis=1), np.stack([p, r, t], axis=1)])
+
+
+def simply_supported_plate(n: int, h: float = 0.01, E: float = 1.0e7, nu: float = 0.3, q: float = -1.0):
+    """Centre deflection of a simply supported square plate under uniform pressure; Kirchhoff series solution
+    w = 0.00406235 q a^4 / D, D = E h^3 / (12 (1 - nu^2)) (Timoshenko & Woinowsky-Krieger, table 8 [ext])."""
+    pts, conn = plate_mesh(n)
+    V = ShellSpace(pts, conn)
+    K = assemble(V, element_stiffness(V, np.full(V.n_vert, h), E, nu))
+    F = load_vector(V, np.tile([0.0, 0.0, q], (V.n_vert, 1)))
+    ux = V.unode_x
+    edge = np.nonzero(np.isclose(ux[:, 0], 0) | np.isclose(ux[:, 0], 1) | np.isclose(ux[:, 1], 0) | np.isclose(ux[:, 1], 1))[0]
+    fixed = np.concatenate([V.u_dof(edge, 2), V.u_dof(np.arange(V.n_unode), 0), V.u_dof(np.arange(V.n_unode), 1),
+                            V.theta_dof(np.arange(V.n_vert), 2)])      # membrane and drilling dofs are decoupled here
+    w = solve(K, F, fixed)
+    centre = int(np.argmin(np.abs(V.x[:, 0] - 0.5) + np.abs(V.x[:, 1] - 0.5)))
+    D = E * h ** 3 / (12.0 * (1.0 - nu * nu))
+    return float(V.vertex_displacement(w)[centre, 2]), 0.00406235 * q / D

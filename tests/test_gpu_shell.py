@@ -1,0 +1,159 @@
+"""Reissner-Mindlin shell kernels (csrc/shell.hip through femo_amd/fea/shell.py) against oracle/shell_oracle.py:
+element couplings, load, residual, forward / adjoint solves on the Scordelis-Lo roof, thickness sensitivities."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import shell_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+E_ROOF, NU_ROOF, H_ROOF, FZ, L = 4.32e8, 0.0, 0.25, -90.0, 25.0
+
+
+def roof_fixed(V):
+    ux, vx = V.unode_x, V.x
+    on = lambda arr, val: np.nonzero(np.isclose(arr, val, atol=1e-6))[0]
+    return np.unique(np.concatenate([
+        V.u_dof(on(ux[:, 0], L), 1), V.u_dof(on(ux[:, 0], L), 2),
+        V.u_dof(on(ux[:, 1], 0.0), 1), V.theta_dof(on(vx[:, 1], 0.0), 0), V.theta_dof(on(vx[:, 1], 0.0), 2),
+        V.u_dof(on(ux[:, 0], 0.0), 0), V.theta_dof(on(vx[:, 0], 0.0), 1), V.theta_dof(on(vx[:, 0], 0.0), 2)]))
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(b).max()
+
+
+@pytest.fixture(scope="module")
+def roof(ctx):
+    from femo_amd.fea.shell import ShellProblem
+    pts, conn = so.scordelis_lo_mesh(8, 8)
+    rng = np.random.default_rng(0)
+    pts = pts.copy()
+    V0 = so.ShellSpace(pts, conn)
+    prob = ShellProblem(pts, conn, E_ROOF, 0.3, fixed_dofs=roof_fixed(V0), ctx=ctx)
+    h = H_ROOF * (1.0 + 0.3 * rng.random(V0.n_vert))
+    f = np.tile([0.0, 0.0, FZ], (V0.n_vert, 1)) * (1.0 + 0.2 * rng.random((V0.n_vert, 1)))
+    prob.set_thickness(h)
+    prob.set_load(f)
+    return prob, V0, h, f
+
+
+def test_space_matches_the_oracle(roof):
+    prob, V0, _, _ = roof
+    S = prob.space
+    assert S.n_dof == V0.n_dof and np.array_equal(S.cell_dofs, V0.cell_dofs) and np.array_equal(S.cell_edges, V0.cell_edges)
+    rowptr, cols, epos = S.pattern()
+    assert rowptr[-1] == cols.size and epos.shape == (S.n_cell, 729)
+    # positions point at the right (row, col)
+    rows = np.repeat(np.arange(S.n_dof), np.diff(rowptr))
+    c = 5
+    assert np.array_equal(rows[epos[c]].reshape(27, 27), np.repeat(S.cell_dofs[c], 27).reshape(27, 27))
+    assert np.array_equal(cols[epos[c]].reshape(27, 27), np.tile(S.cell_dofs[c], 27).reshape(27, 27))
+
+
+def test_stiffness_load_and_residual(roof):
+    prob, V0, h, f = roof
+    S = prob.space
+    rowptr, cols, _ = S.pattern()
+    vals = np.array(prob._stiffness().get())
+    K = sp.csr_matrix((vals, cols, rowptr), shape=(S.n_dof, S.n_dof))
+    Kref = so.assemble(V0, so.element_stiffness(V0, h, E_ROOF, 0.3))
+    assert abs(K - Kref).max() <= 1e-12 * abs(Kref).max()
+    assert abs(K - K.T).max() <= 1e-12 * abs(Kref).max()
+    Fref = so.load_vector(V0, f)
+    prob.dev.load(prob.f, prob.F)
+    assert rel(prob.F.get(), Fref) <= 1e-13
+    w = np.random.default_rng(1).standard_normal(S.n_dof)
+    assert rel(prob.residual(w), Kref @ w - Fref) <= 1e-12
+
+
+def test_forward_and_adjoint_solves(roof):
+    prob, V0, h, f = roof
+    Kref = so.assemble(V0, so.element_stiffness(V0, h, E_ROOF, 0.3))
+    Fref = so.load_vector(V0, f)
+    fixed = np.nonzero(prob.fixed)[0]
+    wref = so.solve(Kref, Fref, fixed)
+    w = prob.solve()
+    assert prob.last_info.converged == 1 and prob.last_info.iterations > 100
+    assert rel(w, wref) <= 1e-8
+    assert np.all(w[fixed] == 0.0)
+    c = np.random.default_rng(2).standard_normal(V0.n_dof)
+    c[fixed] = 0.0
+    lam = prob.solve_adjoint(c)
+    assert rel(lam, so.solve(Kref, c, fixed)) <= 1e-8
+    # adjoint identity <K^-1 F, c> = <F, K^-T c> on the free dofs
+    Ff = Fref.copy(); Ff[fixed] = 0.0
+    assert abs(w @ c - Ff @ lam) <= 1e-9 * abs(w @ c)
+
+
+def test_outputs_and_their_partials(roof):
+    prob, V0, h, f = roof
+    w = np.random.default_rng(3).standard_normal(V0.n_dof) * 1e-3
+    J, g = prob.compliance(w, grad=True)
+    assert J == pytest.approx(so.compliance(V0, w), rel=1e-12)
+    d = np.random.default_rng(4).standard_normal(V0.n_dof) * 1e-3
+    fd = (so.compliance(V0, w + 1e-4 * d) - so.compliance(V0, w - 1e-4 * d)) / 2e-4
+    assert g @ d == pytest.approx(fd, rel=1e-8)
+    M, gm = prob.mass(2.5, grad=True)
+    _, _, _, area, _ = V0.frames()
+    assert M == pytest.approx(2.5 * float((area[:, None] / 3.0 * h[V0.conn]).sum()), rel=1e-13)
+    assert gm.sum() == pytest.approx(2.5 * area.sum(), rel=1e-13)
+    en = prob.elastic_energy(w)
+    assert en == pytest.approx(sum(so.energy_parts(V0, w, h, E_ROOF, 0.3).values()), rel=1e-11)
+
+
+def test_thickness_derivative_of_the_bilinear_form(roof):
+    prob, V0, h, f = roof
+    rng = np.random.default_rng(5)
+    w, lam = rng.standard_normal(V0.n_dof), rng.standard_normal(V0.n_dof)
+    g = prob.dRdh_T(lam, w)
+    dh = rng.standard_normal(V0.n_vert) * 0.01
+
+    def form(hh):
+        Ke = so.element_stiffness(V0, hh, E_ROOF, 0.3)
+        return float(np.einsum("ca,cab,cb->", lam[V0.cell_dofs], Ke, w[V0.cell_dofs]))
+
+    fd = (form(h + 1e-3 * dh) - form(h - 1e-3 * dh)) / 2e-3
+    assert g @ dh == pytest.approx(fd, rel=1e-6)
+    gf = prob.dRdf_T(lam)
+    df = rng.standard_normal((V0.n_vert, 3))
+    assert (gf * df).sum() == pytest.approx(-lam @ so.load_vector(V0, df), rel=1e-12)
+
+
+def test_compliance_gradient_by_the_adjoint(ctx):
+    """BASELINE config 3 in miniature: thickness sensitivity of an output through the adjoint of the shell solve,
+    against central differences of the oracle's direct solves."""
+    from femo_amd.fea.shell import ShellProblem
+    pts, conn = so.scordelis_lo_mesh(4, 4)
+    V0 = so.ShellSpace(pts, conn)
+    fixed = roof_fixed(V0)
+    prob = ShellProblem(pts, conn, E_ROOF, NU_ROOF, fixed_dofs=fixed, ctx=ctx)
+    rng = np.random.default_rng(6)
+    h = H_ROOF * (1.0 + 0.2 * rng.random(V0.n_vert))
+    f = np.tile([0.0, 0.0, FZ], (V0.n_vert, 1))
+    prob.set_thickness(h); prob.set_load(f)
+    J, g, w = prob.compliance_gradient()
+
+    def Jref(hh):
+        K = so.assemble(V0, so.element_stiffness(V0, hh, E_ROOF, NU_ROOF))
+        return so.compliance(V0, so.solve(K, so.load_vector(V0, f), fixed))
+
+    assert J == pytest.approx(Jref(h), rel=1e-7)
+    dh = rng.standard_normal(V0.n_vert) * 0.01
+    fd = (Jref(h + 1e-2 * dh) - Jref(h - 1e-2 * dh)) / 2e-2
+    assert g @ dh == pytest.approx(fd, rel=1e-4)
+
+
+def test_scordelis_lo_on_the_gpu(ctx):
+    from femo_amd.fea.shell import ShellProblem
+    pts, conn = so.scordelis_lo_mesh(16, 16)
+    V0 = so.ShellSpace(pts, conn)
+    prob = ShellProblem(pts, conn, E_ROOF, NU_ROOF, fixed_dofs=roof_fixed(V0), ctx=ctx)
+    prob.set_thickness(H_ROOF)
+    prob.set_load([0.0, 0.0, FZ])
+    w = prob.solve(rtol=1e-10)
+    tip = int(np.argmin(np.abs(V0.x[:, 0]) + np.abs(V0.x[:, 1] - V0.x[:, 1].max())))
+    ref, _, _ = so.scordelis_lo(16, 16)
+    assert V0.vertex_displacement(w)[tip, 2] == pytest.approx(ref, rel=1e-6)
+    assert V0.vertex_displacement(w)[tip, 2] == pytest.approx(-0.3024, rel=0.015)       # run_shape_opt_roof.py:224

@@ -1,0 +1,93 @@
+"""The Reissner-Mindlin shell oracle (oracle/shell_oracle.py): SURVEY.md section 8(f) row 3, BASELINE config 3.
+CPU only -- the HIP path of this element is not built yet; these tests pin the formulation the
+kernels will be checked against."""
+import numpy as np
+import pytest
+
+from oracle import shell_oracle as so
+
+
+def _roof_space(n=4, nu=0.3):
+    pts, conn = so.scordelis_lo_mesh(n, n)
+    V = so.ShellSpace(pts, conn)
+    return V, so.assemble(V, so.element_stiffness(V, np.full(V.n_vert, 0.25), 4.32e8, nu))
+
+
+def test_space_and_symmetry():
+    V, K = _roof_space()
+    assert V.n_vert == 25 and V.n_edge == 56 and V.n_dof == 3 * (25 + 56) + 3 * 25
+    assert abs(K - K.T).max() <= 1e-9 * abs(K).max()
+    # every element matrix is positive semi-definite
+    Ke = so.element_stiffness(V, np.full(V.n_vert, 0.25), 4.32e8, 0.3)
+    assert np.linalg.eigvalsh(Ke).min() >= -1e-9 * np.abs(Ke).max()
+
+
+def test_rigid_body_motions_carry_no_energy():
+    """Three translations and three rotations (u = om x x, theta = om) are in the null space: the drilling strain is
+    written so that it vanishes for a rigid rotation about the normal."""
+    V, K = _roof_space()
+    scale = abs(K).max()
+    for mode in range(6):
+        w = np.zeros(V.n_dof)
+        if mode < 3:
+            w[mode:3 * V.n_unode:3] = 1.0
+        else:
+            om = np.eye(3)[mode - 3]
+            w[:3 * V.n_unode] = np.cross(om, V.unode_x).ravel()
+            w[3 * V.n_unode:] = np.tile(om, V.n_vert)
+        assert np.abs(K @ w).max() <= 1e-12 * scale, mode
+    # and nothing else is: exactly six zero eigenvalues
+    ev = np.linalg.eigvalsh(K.toarray())
+    assert np.count_nonzero(ev < 1e-9 * ev.max()) == 6
+
+
+def test_one_point_shear_rule_is_rank_deficient():
+    """Why dx_shear is the 3-point rule: with one point per element the supported roof is singular."""
+    pts, conn = so.scordelis_lo_mesh(4, 4)
+    V = so.ShellSpace(pts, conn)
+    h = np.full(V.n_vert, 0.25)
+    ev3 = np.linalg.eigvalsh(so.assemble(V, so.element_stiffness(V, h, 4.32e8, 0.0)).toarray())
+    ev1 = np.linalg.eigvalsh(so.assemble(V, so.element_stiffness(V, h, 4.32e8, 0.0, quad_shear=so.QUAD_ONE_POINT)).toarray())
+    assert np.count_nonzero(ev3 < 1e-9 * ev3.max()) == 6
+    assert np.count_nonzero(ev1 < 1e-9 * ev1.max()) > 6
+
+
+def test_uniform_stretch_patch():
+    """u = eps x e_x on a flat plate: membrane energy 1/2 h E/(1-nu^2) eps^2 A, every other part zero."""
+    pts, conn = so.plate_mesh(3)
+    V = so.ShellSpace(pts, conn)
+    E, nu, h, eps = 2.0e5, 0.3, 0.02, 1e-3
+    w = np.zeros(V.n_dof)
+    w[0:3 * V.n_unode:3] = eps * V.unode_x[:, 0]
+    parts = so.energy_parts(V, w, np.full(V.n_vert, h), E, nu)
+    assert parts["membrane"] == pytest.approx(0.5 * h * E / (1 - nu ** 2) * eps ** 2, rel=1e-12)
+    assert max(parts["bending"], parts["shear"], parts["drilling"]) <= 1e-20
+
+
+def test_thickness_enters_as_h_and_h_cubed():
+    V, _ = _roof_space()
+    km, kb, ks, kd = so.element_stiffness(V, np.full(V.n_vert, 0.25), 4.32e8, 0.3, return_parts=True)
+    km2, kb2, ks2, kd2 = so.element_stiffness(V, np.full(V.n_vert, 0.5), 4.32e8, 0.3, return_parts=True)
+    assert np.allclose(km2, 2 * km) and np.allclose(ks2, 2 * ks) and np.allclose(kb2, 8 * kb) and np.allclose(kd2, 8 * kd)
+
+
+def test_simply_supported_plate_matches_kirchhoff():
+    # thin plate (h / a = 0.01): the CG2/CG1 pair locks on coarse meshes (0.29, 0.78 of the answer at n = 4, 8)
+    # and converges: 0.979 at n = 16, 1.0008 at n = 32 (the shear-deformable answer lies slightly above Kirchhoff's)
+    w16, ref = so.simply_supported_plate(16)
+    w32, _ = so.simply_supported_plate(32)
+    assert w16 == pytest.approx(ref, rel=0.03) and w32 == pytest.approx(ref, rel=0.003)
+    w8, _ = so.simply_supported_plate(8)
+    assert abs(w8 - ref) > abs(w16 - ref) > abs(w32 - ref)
+
+
+def test_scordelis_lo_roof():
+    """The one shell number the reference tree holds: v_tip = -0.3024 (run_shape_opt_roof.py:224), approached from
+    below like every displacement-based element."""
+    t8, _, _ = so.scordelis_lo(8, 8)
+    t16, V, w = so.scordelis_lo(16, 16)
+    assert -0.3024 < t16 < t8 < 0.0
+    assert t16 == pytest.approx(-0.3024, rel=0.015)
+    parts = so.energy_parts(V, w, np.full(V.n_vert, 0.25), 4.32e8, 0.0)
+    assert parts["shear"] < 0.01 * (parts["membrane"] + parts["bending"])      # thin: no shear locking
+    assert so.compliance(V, w) > 0.0
