@@ -114,8 +114,11 @@ class StateOperation(CustomImplicitOperation):
         state, res = self.state, self.state['residual_form']
         dR_du = state['dR_du'] if state['dR_du'] is not None else computePartials(res, state['function'])
         if getattr(self, 'dRdu', None) is None:
-            self.dRdu = SparseMatrix(state['function'].function_space.mesh,
-                                     symmetric=getattr(res, 'is_symmetric', False))
+            if hasattr(res, 'new_matrix'):                      # forms with a backend of their own (shell)
+                self.dRdu = res.new_matrix()
+            else:
+                self.dRdu = SparseMatrix(state['function'].function_space.mesh,
+                                         symmetric=getattr(res, 'is_symmetric', False))
         previous = getattr(self, 'dRdf_dict', {})
         self.dRdf_dict = {}
         for k, name in enumerate(state['arguments']):

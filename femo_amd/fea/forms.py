@@ -24,6 +24,16 @@ class Form:
         return ()
 
 
+class BackendForm(Form):
+    """A form that carries its own assembly and solves (the shell forms of fea/shell_forms.py): `utils_hip` hands
+    the work over instead of looking the form up in its catalogue.  Interface, by rank --
+      rank 0: assemble_scalar() -> float;  assemble_derivative(wrt, out) -> Vec (gradient w.r.t. a Function)
+      rank 1: assemble_vector(out) -> Vec;  partial_matrix(wrt, out) -> operator with mult / multTranspose / getSizes;
+              assemble_system(bcs, rhs, out, out_nobc) -> (A, b);  solve_state(func, bcs, report);  new_matrix()
+    and ``mesh``."""
+    mesh = None
+
+
 class PoissonResidual(Form):
     rank = 1
     pde_kind = _lib.PDE_POISSON

@@ -1,0 +1,368 @@
+"""Shell forms for the FEA / FEAModel operator stack: the objects `examples/test_shell_m3l/shell_pde.py:219-332`
+builds (``ShellPDE`` with its spaces W / VT / VF, ``pdeRes``, ``compliance``, ``mass``, ``volume``,
+``elastic_energy``) on the HIP shell kernels (`csrc/shell.hip`, host side `fea/shell.py`).
+
+They are ``BackendForm``s: `utils_hip.assemble*`, `solveNonlinear`, `KSP` hand them their own assembly and solves,
+so `FEA.add_input / add_state / add_output`, `StateOperation`, `OutputOperation` and `FEAModel` are used unchanged
+(`shell_module.py:20-120` registers exactly these: thickness and nodal force as inputs, ``disp_solid`` as state,
+compliance / mass / elastic energy as outputs).
+
+Not built (say so when asked): the forward-mode product with dR/dh (the reference's forward mode returns zeros,
+`fea_dolfinx.py:192-206`), the penalty form of the boundary conditions (imposed strongly here, its limit), the stress
+outputs (`shell_pde.py:304-332`) and the inertial residual.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import numpy as np
+
+from ..engine import Vec
+from .forms import BackendForm
+from .function import Function
+from .shell import DeviceShell, ShellSpace
+
+
+class ShellMesh:
+    """Triangulated surface in R^3 (dolfinx mesh of triangles with gdim 3, `shell_pde.py:220`)."""
+    tdim, gdim = 2, 3
+
+    def __init__(self, x, conn):
+        self.space = ShellSpace(x, conn)
+        self.x, self.conn = self.space.x, self.space.conn
+        self.n_vert, self.n_cell = self.space.n_vert, self.space.n_cell
+        self._dev = {}
+
+    def device(self, ctx) -> DeviceShell:
+        d = self._dev.get(id(ctx))
+        if d is None:
+            d = self._dev[id(ctx)] = DeviceShell(ctx, self.space)
+        return d
+
+    def centroids(self):
+        return self.x[self.conn].mean(axis=1)
+
+
+class ShellFunctionSpace:
+    """kind 'W': CG2^3 x CG1^3 (the state), 'VT': CG1 (thickness), 'VF': CG1^3 (nodal force) -- shell_pde.py:228-230."""
+
+    def __init__(self, mesh: ShellMesh, kind: str):
+        if kind not in ("W", "VT", "VF"):
+            raise ValueError(f"unknown shell space {kind!r}")
+        self.mesh, self.kind = mesh, kind
+        self.family = {"W": "SHELL", "VT": "CG", "VF": "CGV"}[kind]
+        self.degree = 2 if kind == "W" else 1
+        self.num_sub_spaces = {"W": 2, "VT": 0, "VF": 3}[kind]
+
+    @property
+    def dim(self) -> int:
+        S = self.mesh.space
+        return {"W": S.n_dof, "VT": S.n_vert, "VF": 3 * S.n_vert}[self.kind]
+
+    def tabulate_dof_coordinates(self):
+        S = self.mesh.space
+        if self.kind == "VT":
+            return S.x
+        if self.kind == "VF":
+            return np.repeat(S.x, 3, axis=0)
+        return np.concatenate([np.repeat(S.unode_x, 3, axis=0), np.repeat(S.x, 3, axis=0)])
+
+    def __eq__(self, other):
+        return isinstance(other, ShellFunctionSpace) and other.mesh is self.mesh and other.kind == self.kind
+
+    __hash__ = object.__hash__
+
+
+def locate_shell_dofs(W: ShellFunctionSpace, field: str, comp: int, marker) -> np.ndarray:
+    """State dofs of one component (field 'u' or 'theta', comp 0..2) at the nodes where ``marker(x)`` holds
+    (x: (3, n_nodes), like dolfinx.fem.locate_dofs_geometrical on W.sub(i).sub(comp), run_shape_opt_roof.py:131-146)."""
+    S = W.mesh.space
+    pts = S.unode_x if field == "u" else S.x
+    hit = np.nonzero(np.asarray(marker(pts.T), dtype=bool))[0]
+    return (S.u_dof(hit, comp) if field == "u" else S.theta_dof(hit, comp)).astype(np.int32)
+
+
+def _ctx():
+    from .utils_hip import get_context
+    return get_context()
+
+
+def _fixed_mask(space: ShellSpace, bcs) -> Optional[np.ndarray]:
+    if not bcs:
+        return None
+    mask = np.zeros(space.n_dof, dtype=np.uint8)
+    for bc in bcs:
+        mask[bc.dofs] = 1
+    return mask
+
+
+def _fixed_values(space: ShellSpace, bcs) -> Optional[np.ndarray]:
+    vals = np.zeros(space.n_dof)
+    any_nonzero = False
+    for bc in reversed(list(bcs)):                     # first bc wins on duplicates
+        v = np.asarray(bc.values(), dtype=np.float64)
+        vals[bc.dofs] = v
+        any_nonzero = any_nonzero or bool(np.any(v != 0.0))
+    return vals if any_nonzero else None
+
+
+class ShellMatrix:
+    """dR/dw = K(h) on the element-coupling pattern; with ``fixed`` the strongly imposed dofs are identity rows /
+    columns in every product and solve (the A of state_model.py:149)."""
+    symmetric = True
+    pde_kind = None
+
+    def __init__(self, form: "ShellResidual", fixed: Optional[np.ndarray] = None, xfix: Optional[np.ndarray] = None):
+        self.form, self.fixed, self.xfix = form, fixed, xfix
+        self.mesh = form.mesh
+        self._row = self._col = None
+        self.info = None
+
+    def getSizes(self):
+        n = self.mesh.space.n_dof
+        return (n, n)
+
+    size = property(getSizes)
+
+    def _masked(self, x: Vec) -> Vec:
+        return x
+
+    def mult(self, x: Vec, y: Vec) -> Vec:
+        dev = self.mesh.device(_ctx())
+        if self.fixed is None:
+            return dev.matvec(self.form.stiffness(), x, y)
+        # identity rows / columns: y = M K M x + (I - M) x through host masks (products with A are not on the hot path)
+        xm = np.array(x.get()); free = self.fixed == 0
+        tmp = Vec(_ctx(), xm.size).set(xm * free)
+        dev.matvec(self.form.stiffness(), tmp, y)
+        yh = np.array(y.get())
+        y.set(np.where(free, yh, xm))
+        return y
+
+    multTranspose = mult
+
+    def new_row_vec(self) -> Vec:
+        if self._row is None:
+            self._row = Vec(_ctx(), self.mesh.space.n_dof)
+        return self._row
+
+    def new_col_vec(self) -> Vec:
+        if self._col is None:
+            self._col = Vec(_ctx(), self.mesh.space.n_dof)
+        return self._col
+
+    def backend_solve(self, b: Vec, x: Vec, options: Optional[dict] = None) -> None:
+        dev = self.mesh.device(_ctx())
+        o = options or {}
+        xfix = Vec(_ctx(), self.mesh.space.n_dof).set(self.xfix) if self.xfix is not None else None
+        self.info = dev.solve(self.form.stiffness(), b, x, fixed=self.fixed, xfix=xfix,
+                              rtol=o.get("shell_rtol", 1e-12), max_it=o.get("shell_max_it", 2_000_000))
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        rowptr, cols, _ = self.mesh.space.pattern()
+        n = self.mesh.space.n_dof
+        return sp.csr_matrix((np.array(self.form.stiffness().get()), cols, rowptr), shape=(n, n))
+
+
+class _ShellPartial:
+    """dR/dh (n_dof x n_vert) or dR/df (n_dof x 3 n_vert) of the shell residual, matrix free."""
+
+    def __init__(self, form: "ShellResidual", wrt: str):
+        self.form, self.wrt, self.mesh = form, wrt, form.mesh
+        self._row = self._col = None
+
+    def getSizes(self):
+        S = self.mesh.space
+        return (S.n_dof, S.n_vert if self.wrt == "h" else 3 * S.n_vert)
+
+    def mult(self, x: Vec, y: Vec) -> Vec:
+        if self.wrt == "h":
+            raise NotImplementedError("forward-mode product with dR/dh of the shell is not built (reverse mode is)")
+        return self.mesh.device(_ctx()).load(x, y, sign=-1.0)
+
+    def multTranspose(self, x: Vec, y: Vec) -> Vec:
+        dev, F = self.mesh.device(_ctx()), self.form
+        if self.wrt == "h":
+            return dev.dform_dh(F.E, F.nu, F.h.vec, x, F.w.vec, out=y)
+        return dev.load_T(x, y, sign=-1.0)
+
+    def new_row_vec(self) -> Vec:
+        if self._row is None:
+            self._row = Vec(_ctx(), self.getSizes()[0])
+        return self._row
+
+    def new_col_vec(self) -> Vec:
+        if self._col is None:
+            self._col = Vec(_ctx(), self.getSizes()[1])
+        return self._col
+
+
+class ShellResidual(BackendForm):
+    """R(w; h, f) = dE_elastic(w; h)/dw - int f . v = K(h) w - F(f)   (pdeRes -> weakFormResidual, shell_pde.py:246-253)."""
+    rank = 1
+    is_linear = True
+    is_symmetric = True
+
+    def __init__(self, h: Function, w: Function, f: Function, E: float, nu: float):
+        self.h, self.w, self.f, self.E, self.nu = h, w, f, float(E), float(nu)
+        self.u = w
+        self.mesh = w.function_space.mesh
+        self._vals: Optional[Vec] = None
+        self._vals_ver = None
+        self._res: Optional[Vec] = None
+
+    def functions(self):
+        return (self.h, self.w, self.f)
+
+    def stiffness(self) -> Vec:
+        dev = self.mesh.device(_ctx())
+        if self._vals is None:
+            self._vals = Vec(_ctx(), dev.nnz)
+        if self._vals_ver != self.h.version:
+            dev.assemble(self.E, self.nu, self.h.vec, self._vals)
+            self._vals_ver = self.h.version
+        return self._vals
+
+    def new_matrix(self) -> ShellMatrix:
+        return ShellMatrix(self)
+
+    def assemble_vector(self, out: Optional[Vec] = None) -> Vec:
+        dev = self.mesh.device(_ctx())
+        if out is None:
+            if self._res is None:
+                self._res = Vec(_ctx(), self.mesh.space.n_dof)
+            out = self._res
+        dev.matvec(self.stiffness(), self.w.vec, out)
+        dev.load(self.f.vec, out, sign=-1.0, accumulate=True)
+        return out
+
+    def partial_matrix(self, wrt: Function, out=None):
+        if wrt is self.w:
+            return ShellMatrix(self)
+        if wrt is self.h:
+            return out if isinstance(out, _ShellPartial) and out.wrt == "h" else _ShellPartial(self, "h")
+        if wrt is self.f:
+            return out if isinstance(out, _ShellPartial) and out.wrt == "f" else _ShellPartial(self, "f")
+        raise ValueError("the shell residual does not depend on that Function")
+
+    def assemble_system(self, bcs, rhs: bool, out, out_nobc):
+        if rhs:
+            raise NotImplementedError("assembleSystem(rhs=True) for the shell form: use solveNonlinear / FEA.solve")
+        self.stiffness()
+        S = self.mesh.space
+        A = out if isinstance(out, ShellMatrix) else ShellMatrix(self)
+        A.form, A.fixed, A.xfix = self, _fixed_mask(S, bcs), None      # linearised solves: homogeneous values
+        if isinstance(out_nobc, ShellMatrix):
+            out_nobc.form, out_nobc.fixed = self, None
+        return A, None
+
+    def solve_state(self, func: Function, bcs, report: bool = False) -> None:
+        """K(h) w = F(f) with the imposed dofs (solveNonlinear -> NewtonSolver on a linear residual: one solve)."""
+        dev = self.mesh.device(_ctx())
+        S = self.mesh.space
+        F = dev.load(self.f.vec, Vec(_ctx(), S.n_dof))
+        vals = _fixed_values(S, bcs) if bcs else None
+        xfix = Vec(_ctx(), S.n_dof).set(vals) if vals is not None else None
+        info = dev.solve(self.stiffness(), F, func.vec, fixed=_fixed_mask(S, bcs), xfix=xfix)
+        func.version += 1
+        if report:
+            print(f"shell solve: {info.iterations} CG iterations, {info.solve_ms:.1f} ms")
+
+
+class _ShellScalar(BackendForm):
+    rank = 0
+
+    def assemble_derivative(self, wrt: Function, out: Optional[Vec] = None) -> Vec:
+        n = wrt.function_space.dim
+        if out is None:
+            cache = self.__dict__.setdefault("_grad_vecs", {})
+            out = cache.get(id(wrt))
+            if out is None or out.n != n:
+                out = cache[id(wrt)] = Vec(_ctx(), n)
+        if not any(wrt is fn for fn in self.functions()):
+            return out.fill(0.0)
+        return self._gradient(wrt, out)
+
+
+class ShellCompliance(_ShellScalar):
+    """1/2 int u_mid . u_mid dx  (shell_pde.py:287-288; the thickness regularisation there is switched off by default)."""
+
+    def __init__(self, w: Function):
+        self.w, self.mesh = w, w.function_space.mesh
+
+    def functions(self):
+        return (self.w,)
+
+    def assemble_scalar(self) -> float:
+        return self.mesh.device(_ctx()).compliance(self.w.vec)
+
+    def _gradient(self, wrt, out):
+        self.mesh.device(_ctx()).compliance(self.w.vec, grad=out, value=False)
+        return out
+
+
+class ShellMass(_ShellScalar):
+    """int rho h dx (shell_pde.py:293-294); rho = 1: the volume (:290-291)."""
+
+    def __init__(self, h: Function, rho: float = 1.0):
+        self.h, self.rho, self.mesh = h, float(rho), h.function_space.mesh
+
+    def functions(self):
+        return (self.h,)
+
+    def assemble_scalar(self) -> float:
+        return self.mesh.device(_ctx()).mass(self.rho, self.h.vec)
+
+    def _gradient(self, wrt, out):
+        self.mesh.device(_ctx()).mass(self.rho, self.h.vec, grad=out, value=False)
+        return out
+
+
+class ShellElasticEnergy(_ShellScalar):
+    """1/2 w^T K(h) w (shell_pde.py:296-299)."""
+
+    def __init__(self, w: Function, h: Function, E: float, nu: float):
+        self.w, self.h, self.E, self.nu, self.mesh = w, h, float(E), float(nu), w.function_space.mesh
+        self._res = ShellResidual(h, w, None, E, nu)
+
+    def functions(self):
+        return (self.w, self.h)
+
+    def assemble_scalar(self) -> float:
+        return self.mesh.device(_ctx()).dform_dh(self.E, self.nu, self.h.vec, self.w.vec, self.w.vec, energy=True)
+
+    def _gradient(self, wrt, out):
+        dev = self.mesh.device(_ctx())
+        if wrt is self.w:
+            return dev.matvec(self._res.stiffness(), self.w.vec, out)
+        dev.dform_dh(self.E, self.nu, self.h.vec, self.w.vec, self.w.vec, out=out)          # w^T dK/dh w
+        half = Vec(_ctx(), out.n).copy_from(out)
+        return out.axpy(-0.5, half)                                                         # ... times 1/2
+
+
+class ShellPDE:
+    """`shell_pde.py:219-302` on the HIP engine: spaces and form builders with the reference's names."""
+
+    def __init__(self, mesh: ShellMesh):
+        self.mesh = mesh
+        self.W = ShellFunctionSpace(mesh, "W")
+        self.VT = ShellFunctionSpace(mesh, "VT")
+        self.VF = ShellFunctionSpace(mesh, "VF")
+
+    def pdeRes(self, h, w, f, E, nu, penalty=False, dss=None, dSS=None, g=None) -> ShellResidual:
+        if penalty:
+            raise NotImplementedError("penalty boundary terms: impose the dofs strongly (FEA.add_strong_bc)")
+        return ShellResidual(h, w, f, E, nu)
+
+    def compliance(self, w, h=None, dxx=None) -> ShellCompliance:
+        return ShellCompliance(w)
+
+    def volume(self, h) -> ShellMass:
+        return ShellMass(h, 1.0)
+
+    def mass(self, h, rho) -> ShellMass:
+        return ShellMass(h, rho)
+
+    def elastic_energy(self, w, h, E, nu=0.0) -> ShellElasticEnergy:
+        return ShellElasticEnergy(w, h, E, nu)

@@ -17,7 +17,7 @@ import numpy as np
 from .. import _lib
 from .. import engine as E
 from ..engine import Context, DeviceArray, Vec
-from .forms import (BeamResidual, DerivativeForm, FieldExpression, Form, FunctionExpr, GradientMagnitude,
+from .forms import (BackendForm, BeamResidual, DerivativeForm, FieldExpression, Form, FunctionExpr, GradientMagnitude,
                     L2TrackingFunctional, LinearFunctional, NonlinearPoissonResidual, PoissonResidual, PowerExpr, derivative)
 from .function import Function, FunctionSpace, _VectorView
 from .io import MeshTags, import_mesh, read_mesh, write_mesh_files
@@ -298,6 +298,8 @@ def convertToDense(A) -> np.ndarray:
 # ------------------------------------------------------------------ assembly ----
 def _mesh_of(form: Form) -> Mesh:
     base = form.form if isinstance(form, DerivativeForm) else form
+    if isinstance(base, BackendForm):
+        return base.mesh
     return base.functions()[0].function_space.mesh
 
 
@@ -321,6 +323,8 @@ def _aux(res) -> Optional[Vec]:
 
 def assembleScalar(c: Form) -> float:
     """utils_dolfinx.py:169-173; local value (all-reduced over ranks inside the engine)."""
+    if isinstance(c, BackendForm):
+        return c.assemble_scalar()
     if isinstance(c, L2TrackingFunctional):
         dm = _mesh_of(c).device(get_context())
         return E.functional_value(dm, c.functional_kind, c.params, c.u.vec, c.f.vec, c.u_exact.vec)
@@ -333,6 +337,10 @@ def assembleScalar(c: Form) -> float:
 def _assemble_vector_dev(v: Form, out: Optional[Vec] = None) -> Vec:
     """Assembles into ``out`` or into a per-(mesh, form kind) buffer that the next
     assembly of the same kind overwrites (callers consume the result at once)."""
+    if isinstance(v, BackendForm):
+        return v.assemble_vector(out)
+    if isinstance(v, DerivativeForm) and isinstance(v.form, BackendForm):
+        return v.form.assemble_derivative(v.wrt, out)
     ctx = get_context()
     mesh = _mesh_of(v)
     dm = mesh.device(ctx)
@@ -365,6 +373,8 @@ def assembleVector(v: Form, device: bool = False):
 
 def assembleMatrix(M: Form, bcs: Sequence[DirichletBC] = (), out=None):
     """utils_dolfinx.py:181-187.  ``out`` lets callers re-use a matrix."""
+    if isinstance(M, DerivativeForm) and isinstance(M.form, BackendForm):
+        return M.form.partial_matrix(M.wrt, out)
     if not isinstance(M, DerivativeForm) or not isinstance(M.form, _RESIDUALS):
         raise NotImplementedError(f"assembleMatrix: {type(M).__name__} is not in the form catalogue")
     res = M.form
@@ -391,6 +401,8 @@ def assembleSystem(J: Form, F: Form, bcs: Sequence[DirichletBC] = (), rhs: bool 
     b = F - K[:,bc] g, b[bc] = g (apply_lifting + set_bc [ext]).  The operator
     layer passes ``rhs=False`` because it discards b (state_model.py:149), and
     ``out_nobc`` to get dR/du without BCs from the same pass over the mesh."""
+    if isinstance(J, DerivativeForm) and isinstance(J.form, BackendForm) and J.wrt is J.form.u:
+        return J.form.assemble_system(bcs, rhs, out, out_nobc)
     if not isinstance(J, DerivativeForm) or not isinstance(J.form, _RESIDUALS) or J.wrt is not J.form.u:
         raise NotImplementedError("assembleSystem: J must be derivative(residual, state)")
     res = J.form
@@ -517,6 +529,10 @@ class KSP:
 
     def solve(self, b, x) -> None:
         """Symmetric operators: Jacobi-CG; otherwise BiCGSTAB on A or its explicit transpose."""
+        if hasattr(self.A, "backend_solve"):               # operators of a BackendForm bring their own solver
+            self.A.backend_solve(_as_vec(b), _as_vec(x), self.options)
+            self.info = self.A.info
+            return
         o = self.options
         tr = self.transposed and not self.A.symmetric
         kw = dict(transpose=tr, rtol=o["rtol"], atol=o["atol"], max_it=o["max_it"], zero_guess=True,
@@ -684,7 +700,11 @@ def SNESSolver(F, w, bcs=[], abs_tol=1e-13, rel_tol=1e-13, max_it=100, report=Fa
 def solveNonlinear(res, func, bc, solver, report, initialize):
     """utils_dolfinx.py:319-333."""
     start = default_timer()
-    if solver == 'Newton':
+    if isinstance(res, BackendForm):
+        if initialize is True:
+            func.vector.set(0.1)                           # utils_dolfinx.py:433-435
+        res.solve_state(func, bc, report)
+    elif solver == 'Newton':
         newton_solver = NewtonSolver(res, func, bc, initialize=initialize, report=report)
         newton_solver.solve(func)
     elif solver == 'SNES':
