@@ -390,31 +390,43 @@ __global__ __launch_bounds__(SH_BLOCK) void k_shell_mass(femo_shell_view S, doub
 }
 
 // ---------------------------------------------------------------- CSR operator ----
-// y = A x for rows [0, n), one wave per row; `fixed` != nullptr: the masked operator M A M + (I - M) (strongly imposed
-// dofs are identity rows and columns).  partials != nullptr: per-block partial of x.y.
+// y = A x for rows [0, n), 16 lanes per row (the element-coupling pattern has ~50 entries per row: a whole wave per
+// row left three quarters of the lanes idle and a quarter of the rows in flight).  `fixed` != nullptr: the masked
+// operator M A M + (I - M) (strongly imposed dofs are identity rows and columns); mask_cols = 0 skips the column test
+// for callers whose x is zero on the imposed dofs anyway (the CG directions) -- a byte gather per matrix entry.
+// partials != nullptr: per-block partial of x.y.
 __global__ __launch_bounds__(SH_BLOCK) void k_csr_spmv(int64_t n, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
-                                                       const double* __restrict__ vals, const uint8_t* __restrict__ fixed,
+                                                       const double* __restrict__ vals, const uint8_t* __restrict__ fixed, int mask_cols,
                                                        const double* __restrict__ x, double* __restrict__ y, double* __restrict__ partials,
-                                                       const int32_t* __restrict__ done) {
+                                                       const int32_t* __restrict__ done, double* commit_dst = nullptr,
+                                                       const double* commit_src = nullptr) {
   if (done != nullptr && *done) return;
+  // the CG loop publishes gamma of the iteration here (every consumer of it runs after this launch, every block of
+  // the kernel that produced it has finished): saves a launch of its own
+  if (commit_dst != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *commit_dst = *commit_src;
   __shared__ double lds[SH_BLOCK / 64];
-  const int lane = threadIdx.x & 63;
-  const int64_t nw = (int64_t)gridDim.x * (SH_BLOCK / 64);
+  constexpr int SUB = 16;
+  const int sl = threadIdx.x & (SUB - 1);
+  const int64_t nsub = (int64_t)gridDim.x * (SH_BLOCK / SUB);
   double dot = 0.0;
-  for (int64_t row = (int64_t)blockIdx.x * (SH_BLOCK / 64) + (threadIdx.x >> 6); row < n; row += nw) {
+  for (int64_t row = (int64_t)blockIdx.x * (SH_BLOCK / SUB) + (threadIdx.x / SUB); row < n; row += nsub) {
     double s = 0.0;
     const bool rf = fixed != nullptr && fixed[row];
     if (!rf) {
-      for (int64_t e = rowptr[row] + lane; e < rowptr[row + 1]; e += 64) {
+      const int64_t e1 = rowptr[row + 1];
+      for (int64_t e = rowptr[row] + sl; e < e1; e += SUB) {
         const int32_t cidx = cols[e];
-        if (fixed == nullptr || !fixed[cidx]) s += vals[e] * x[cidx];
+        const double v = vals[e] * x[cidx];
+        s += (mask_cols && fixed != nullptr && fixed[cidx]) ? 0.0 : v;
       }
     }
-    s = femo_wave_sum(s);
-    if (lane == 0) {
-      const double yi = rf ? x[row] : s;
+#pragma unroll
+    for (int off = SUB / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (sl == 0) {
+      const double xr = x[row];
+      const double yi = rf ? xr : s;
       y[row] = yi;
-      dot += x[row] * yi;
+      dot += xr * yi;
     }
   }
   if (partials != nullptr) {
@@ -472,6 +484,7 @@ __global__ __launch_bounds__(SH_BLOCK) void k_scg_gamma0(int nb, const double* _
   const double g = fold(partials, nb, lds);
   if (threadIdx.x == 0) {
     scal[0] = g; scal[1] = g;
+    scal[4] = g;                           // gamma as published by the first SpMV of the loop
     scal[2] = fmax(rtol2 * g, atol2);
     flag[0] = g <= scal[2] ? 1 : 0;
     flag[1] = 0;
@@ -517,11 +530,6 @@ __global__ __launch_bounds__(SH_BLOCK) void k_scg_p(int64_t n, int it, int nb_rz
     flag[1] = it + 1;
     if (conv) { flag[2] = (g1 == g1) ? 0 : 1; __threadfence(); flag[0] = it + 1; }
   }
-}
-
-__global__ void k_scg_commit(double* __restrict__ scal, const double* __restrict__ gamma_out, const int32_t* __restrict__ flag) {
-  if (flag[0]) return;
-  scal[0] = gamma_out[0];
 }
 
 // r = rhs on the free dofs, 0 on the strongly imposed ones (those are set exactly after the loop)
@@ -649,8 +657,8 @@ int femo_shell_matvec(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_
   FEMO_REQUIRE(s && vals && x && y, "null argument");
   FEMO_REQUIRE(vals->n >= s->nnz && x->n >= s->n_dof && y->n >= s->n_dof && x->d != y->d, "vector size mismatch in shell_matvec");
   femo_vec_touch(y);
-  hipLaunchKernelGGL(k_csr_spmv, dim3(sgrid(s->n_dof, SH_BLOCK / 64)), dim3(SH_BLOCK), 0, s->ctx->stream, s->n_dof, s->d_rowptr, s->d_cols,
-                     vals->d, fixed_dev_or_null, x->d, y->d, (double*)nullptr, (const int32_t*)nullptr);
+  hipLaunchKernelGGL(k_csr_spmv, dim3(sgrid(s->n_dof, SH_BLOCK / 16)), dim3(SH_BLOCK), 0, s->ctx->stream, s->n_dof, s->d_rowptr, s->d_cols,
+                     vals->d, fixed_dev_or_null, 1, x->d, y->d, (double*)nullptr, (const int32_t*)nullptr);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -745,7 +753,7 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
   uint8_t* d_fixed = nullptr;
   if (fixed_host != nullptr) FEMO_TRY(to_device(&d_fixed, fixed_host, n, st));
   const unsigned gv = std::min<unsigned>(sgrid(n), SH_MAXPART);
-  const unsigned gs = std::min<unsigned>(sgrid(n, SH_BLOCK / 64), SH_MAXPART);
+  const unsigned gs = std::min<unsigned>(sgrid(n, SH_BLOCK / 16), SH_MAXPART);
   double *Ppq = s->d_part, *Prz = s->d_part + SH_MAXPART, *gam = s->d_scal + 4;
   FEMO_HIP_CHECK(hipEventRecord(ctx->ev0, st));
   // right-hand side with lifting (into q); zero initial guess
@@ -772,10 +780,10 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
   while (!h_flag[0] && it < max_it) {
     const int it_end = std::min(it + batch, max_it);
     for (; it < it_end; ++it) {
-      hipLaunchKernelGGL(k_csr_spmv, dim3(gs), dim3(SH_BLOCK), 0, st, n, s->d_rowptr, s->d_cols, vals->d, d_fixed, s->d_p, s->d_q, Ppq, s->d_flag);
+      // p is zero on the imposed dofs (r and the initial direction are): no column mask needed
+      hipLaunchKernelGGL(k_csr_spmv, dim3(gs), dim3(SH_BLOCK), 0, st, n, s->d_rowptr, s->d_cols, vals->d, d_fixed, 0, s->d_p, s->d_q, Ppq, s->d_flag, s->d_scal, gam);
       hipLaunchKernelGGL(k_scg_xr, dim3(gv), dim3(SH_BLOCK), 0, st, n, (int)gs, Ppq, s->d_scal, s->d_p, s->d_q, s->d_dinv, x->d, s->d_r, Prz, s->d_flag);
       hipLaunchKernelGGL(k_scg_p, dim3(gv), dim3(SH_BLOCK), 0, st, n, it, (int)gv, Prz, s->d_scal, s->d_r, s->d_dinv, s->d_p, s->d_flag, gam);
-      hipLaunchKernelGGL(k_scg_commit, dim3(1), dim3(1), 0, st, s->d_scal, gam, s->d_flag);
     }
     FEMO_HIP_CHECK(hipGetLastError());
     FEMO_HIP_CHECK(hipMemcpyAsync(h_flag, s->d_flag, sizeof h_flag, hipMemcpyDeviceToHost, st));

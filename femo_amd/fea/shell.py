@@ -94,10 +94,11 @@ class DeviceShell:
         assert self.n_dof == space.n_dof and self.nnz == cols.size
 
     def __del__(self):
+        # destroy only while the owning context is alive (interpreter shutdown tears objects down in arbitrary order)
         try:
-            if getattr(self, "handle", None):
-                self.lib.femo_shell_destroy(self.handle)
-                self.handle = None
+            h, self.handle = getattr(self, "handle", None), None
+            if h and getattr(self.ctx, "handle", None):
+                self.lib.femo_shell_destroy(h)
         except Exception:
             pass
 
