@@ -235,6 +235,11 @@ def run_distributed_bench(args, ctx, control, cpu_baseline: bool = True):
     setup_s = time.perf_counter() - t0
     rss_setup = _rss_mb() - rss0
 
+    # pinned pool sized during set-up (see bench.py: two generations of result blocks are alive at a time)
+    from ..engine import pinned_empty
+    n_f, n_u = int(np.size(sim['f'])), int(np.size(sim['u']))          # sizes of the arrays that cross the boundary
+    prime = [pinned_empty(n_f) for _ in range(4)] + [pinned_empty(n_u) for _ in range(8)]
+    del prime
     g = None
     for w in range(W):
         g = B.one_cycle(sim, fea, f_host[w % len(f_host)], u0)
