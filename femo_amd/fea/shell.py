@@ -79,6 +79,105 @@ class ShellSpace:
         return self._pattern
 
 
+def lattice_pc(space: ShellSpace, finest: Optional[int] = None):
+    """Arrays of the lattice preconditioner (`femo_shell_pc_create`): nested lattices of 2, 4, ..., m cells per axis
+    over the bounding cube, m = the power of two whose spacing is closest to the mean edge length.  Per level the
+    trilinear interpolation from the lattice nodes a dof node touches (compacted: a surface meets few nodes of a 3-D
+    lattice), for each of the six fields (3 displacement components on the P2 nodes, 3 rotation components on the
+    vertices).  Returns (width, n_lat, ell_idx (n_dof, width) int32, ell_w (n_dof, width), P^T as CSR)."""
+    import scipy.sparse as sp
+    pts = np.concatenate([space.unode_x, space.x])                    # displacement nodes, then rotation nodes
+    n_pts = pts.shape[0]
+    lo = pts.min(axis=0)
+    ext = float((pts.max(axis=0) - lo).max()) * (1.0 + 1e-9) + 1e-300
+    ev = space.edge_vertices
+    h_avg = float(np.linalg.norm(space.x[ev[:, 0]] - space.x[ev[:, 1]], axis=1).mean())
+    if finest is None:
+        finest = max(2, 2 ** int(round(np.log2(max(ext / h_avg, 2.0)))))
+    levels = []
+    m = 2
+    while m <= finest:
+        levels.append(m)
+        m *= 2
+    nl = len(levels)
+    width = 8 * nl
+    node_idx = np.zeros((n_pts, width), dtype=np.int64)
+    node_w = np.zeros((n_pts, width))
+    offsets, level_nodes = [], []
+    off = 0
+    for l, m in enumerate(levels):
+        t = (pts - lo) / ext * m
+        i0 = np.clip(np.floor(t).astype(np.int64), 0, m - 1)
+        fr = t - i0
+        gids = np.empty((n_pts, 8), dtype=np.int64)
+        for c in range(8):
+            w = np.ones(n_pts)
+            ii = []
+            for k in range(3):
+                bit = (c >> k) & 1
+                w = w * (fr[:, k] if bit else 1.0 - fr[:, k])
+                ii.append(i0[:, k] + bit)
+            gids[:, c] = (ii[2] * (m + 1) + ii[1]) * (m + 1) + ii[0]
+            node_w[:, l * 8 + c] = w
+        uniq, inv = np.unique(gids.ravel(), return_inverse=True)
+        node_idx[:, l * 8:(l + 1) * 8] = off + inv.reshape(-1, 8)
+        offsets.append(off)
+        level_nodes.append(uniq)
+        off += uniq.size
+    offsets.append(off)
+    n_nodes = off
+    n_lat = 6 * n_nodes
+    # dofs: field f of point p -> lattice unknown 6 * node + f
+    nu, nv = space.n_unode, space.n_vert
+    point_of = np.concatenate([np.repeat(np.arange(nu), 3), nu + np.repeat(np.arange(nv), 3)])
+    field_of = np.concatenate([np.tile(np.arange(3), nu), 3 + np.tile(np.arange(3), nv)])
+    ell_idx = (6 * node_idx[point_of] + field_of[:, None]).astype(np.int32)
+    ell_w = np.ascontiguousarray(node_w[point_of])
+    # finest level: P_L^T as CSR over all lattice unknowns (only the finest rows are non-empty)
+    fin = slice(width - 8, width)
+    rows = np.repeat(np.arange(space.n_dof), 8)
+    P = sp.csr_matrix((ell_w[:, fin].ravel(), (rows, ell_idx[:, fin].ravel())), shape=(space.n_dof, n_lat))
+    Pt = P.T.tocsr()
+    Pt.sort_indices()
+    # nested lattices: node-level transfer between consecutive levels (trilinear: even index -> one parent with
+    # weight 1, odd -> two parents with weight 1/2, per axis).  Every parent of a touched node is itself touched
+    # (it is a corner of the coarse cell that contains the point), so the compacted node sets are closed.
+    pr, pc, pw = [], [], []
+    for l in range(1, nl):
+        m, mc = levels[l], levels[l - 1]
+        g = level_nodes[l]                                        # global ids on the (m+1)^3 lattice, sorted
+        i = g % (m + 1); j = (g // (m + 1)) % (m + 1); k = g // ((m + 1) ** 2)
+        child = offsets[l] + np.arange(g.size)
+        for c in range(8):
+            w = np.ones(g.size)
+            par = []
+            for ax, q in enumerate((i, j, k)):
+                bit = (c >> ax) & 1
+                odd = (q & 1) == 1
+                p_ax = np.where(odd, (q - 1) // 2 + bit, q // 2)       # odd: lower / upper parent, even: the one parent
+                w = w * np.where(odd, 0.5, 1.0 if bit == 0 else 0.0)
+                par.append(p_ax)
+            keep = w > 0.0
+            gp = (par[2] * (mc + 1) + par[1]) * (mc + 1) + par[0]
+            pos = np.searchsorted(level_nodes[l - 1], gp[keep])
+            if not np.array_equal(level_nodes[l - 1][pos], gp[keep]):
+                raise RuntimeError("lattice levels are not nested")            # cannot happen, see above
+            pr.append(child[keep]); pc.append(offsets[l - 1] + pos); pw.append(w[keep])
+    if pr:
+        Tp = sp.csr_matrix((np.concatenate(pw), (np.concatenate(pr), np.concatenate(pc))), shape=(n_nodes, n_nodes))
+    else:
+        Tp = sp.csr_matrix((n_nodes, n_nodes))
+    Tp.sort_indices()
+    Tc = Tp.T.tocsr()
+    Tc.sort_indices()
+    i64, i32 = np.int64, np.int32
+    return dict(width=width, n_lat=int(n_lat), n_nodes=int(n_nodes), levels=levels, level_offsets=np.asarray(offsets, dtype=i64),
+                ell_idx=np.ascontiguousarray(ell_idx), ell_w=ell_w,
+                pt_rowptr=Pt.indptr.astype(i64), pt_cols=Pt.indices.astype(i32), pt_vals=np.ascontiguousarray(Pt.data),
+                par_rowptr=Tp.indptr.astype(i64), par_cols=Tp.indices.astype(i32), par_vals=np.ascontiguousarray(Tp.data),
+                chi_rowptr=Tc.indptr.astype(i64), chi_cols=Tc.indices.astype(i32), chi_vals=np.ascontiguousarray(Tc.data))
+
+
 class DeviceShell:
     """`femo_shell` handle."""
 
@@ -92,6 +191,19 @@ class DeviceShell:
         self.n_dof = int(self.lib.femo_shell_ndof(self.handle))
         self.nnz = int(self.lib.femo_shell_nnz(self.handle))
         assert self.n_dof == space.n_dof and self.nnz == cols.size
+        self.pc_levels = None
+
+    def enable_lattice_pc(self, finest: Optional[int] = None) -> None:
+        """Build and upload the lattice preconditioner once per mesh (used by ``solve(pc='lattice')``)."""
+        if self.pc_levels is not None:
+            return
+        L = lattice_pc(self.space, finest)
+        p = lambda a: C.c_void_p(a.ctypes.data)
+        check(self.lib.femo_shell_pc_create(self.handle, L["width"], L["n_nodes"], len(L["levels"]), p(L["level_offsets"]),
+                                            p(L["ell_idx"]), p(L["ell_w"]), p(L["pt_rowptr"]), p(L["pt_cols"]), p(L["pt_vals"]),
+                                            p(L["par_rowptr"]), p(L["par_cols"]), p(L["par_vals"]),
+                                            p(L["chi_rowptr"]), p(L["chi_cols"]), p(L["chi_vals"])))
+        self.pc_levels = L["levels"]
 
     def __del__(self):
         # destroy only while the owning context is alive (interpreter shutdown tears objects down in arbitrary order)
@@ -138,8 +250,13 @@ class DeviceShell:
         return val.value
 
     def solve(self, vals: Vec, b: Vec, x: Vec, fixed: Optional[np.ndarray] = None, xfix: Optional[Vec] = None,
-              rtol: float = 1e-12, atol: float = 0.0, max_it: int = 2_000_000, check_every: int = 64):
-        opts = _lib.SolverOpts(rtol=rtol, atol=atol, max_it=max_it, zero_guess=1, check_every=check_every, pc=0, atol_pc=0.0)
+              rtol: float = 1e-12, atol: float = 0.0, max_it: int = 2_000_000, check_every: int = 64, pc: str = "lattice"):
+        if pc == "lattice":
+            self.enable_lattice_pc()
+        elif pc != "jacobi":
+            raise ValueError(f"unknown shell preconditioner {pc!r}")
+        opts = _lib.SolverOpts(rtol=rtol, atol=atol, max_it=max_it, zero_guess=1, check_every=check_every,
+                               pc=1 if pc == "lattice" else 0, atol_pc=0.0)
         info = _lib.SolveInfo()
         mask = None
         if fixed is not None:
@@ -159,7 +276,8 @@ class ShellProblem:
     boundary.  ``fixed_dofs``: indices into the state vector (the reference imposes them strongly in
     `run_shape_opt_roof.py:131-160` and by a penalty in `shell_pde.py:246-253`, whose limit this is)."""
 
-    def __init__(self, x, conn, E_young: float, nu: float, fixed_dofs: Sequence[int] = (), ctx: Optional[Context] = None):
+    def __init__(self, x, conn, E_young: float, nu: float, fixed_dofs: Sequence[int] = (), ctx: Optional[Context] = None,
+                 pc: str = "lattice"):
         from .utils_hip import get_context
         self.ctx = ctx if ctx is not None else get_context()
         self.space = ShellSpace(x, conn)
@@ -175,6 +293,7 @@ class ShellProblem:
         self.gh, self.gf = Vec(c, nv), Vec(c, 3 * nv)
         self._K_for = None
         self.last_info = None
+        self.pc = pc
 
     # inputs ---------------------------------------------------------------------------------------
     def set_thickness(self, h) -> None:
@@ -206,7 +325,7 @@ class ShellProblem:
         """solve_residual_equations (state_model.py:87-115): w with the strongly imposed dofs at zero."""
         K = self._stiffness()
         self.dev.load(self.f, self.F)
-        self.last_info = self.dev.solve(K, self.F, self.w, fixed=self.fixed, rtol=rtol)
+        self.last_info = self.dev.solve(K, self.F, self.w, fixed=self.fixed, rtol=rtol, pc=self.pc)
         return np.array(self.w.get())
 
     def solve_adjoint(self, rhs: np.ndarray, rtol: float = 1e-12) -> np.ndarray:
@@ -214,7 +333,7 @@ class ShellProblem:
         (K is symmetric); the entries of rhs on imposed dofs do not enter."""
         K = self._stiffness()
         self.tmp.set(np.ascontiguousarray(rhs, dtype=np.float64))
-        self.last_info = self.dev.solve(K, self.tmp, self.lam, fixed=self.fixed, rtol=rtol)
+        self.last_info = self.dev.solve(K, self.tmp, self.lam, fixed=self.fixed, rtol=rtol, pc=self.pc)
         return np.array(self.lam.get())
 
     # partials of the residual --------------------------------------------------------------------

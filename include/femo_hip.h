@@ -365,9 +365,21 @@ int femo_shell_dform_dh(femo_shell* s, double E, double nu, const femo_vec* h, c
 /* 1/2 int u_mid . u_mid (shell_pde.py:287-288) and its gradient; int rho h (shell_pde.py:293-294) and its gradient */
 int femo_shell_compliance(femo_shell* s, const femo_vec* w, double* value, int accumulate, femo_vec* grad);
 int femo_shell_mass(femo_shell* s, double rho, const femo_vec* h, double* value, int accumulate, femo_vec* grad);
+/* Lattice preconditioner for femo_shell_solve (opts->pc = 1): M^-1 = D^-1 + sum_l P_l C_l P_l^T, P_l = trilinear
+ * interpolation from nested lattices over the bounding cube (2, 4, ... cells per axis) to the dof nodes, per component,
+ * C_l = 1 / diag(P_l^T K P_l) (recomputed on the device when K or the Dirichlet set change).  The host passes
+ *   ell_idx / ell_w   P of every level: 8 (lattice unknown, weight) pairs per level and dof (width = 8 n_levels);
+ *                     lattice unknown = 6 * node + field, nodes numbered level by level (level_offsets, n_levels + 1)
+ *   pt_*              the finest level's P^T as CSR over all 6 n_nodes unknowns
+ *   par_* / chi_*     node-level transfers between consecutive lattices: parents (<= 8) and children (<= 27) of a node. */
+int femo_shell_pc_create(femo_shell* s, int width, int64_t n_nodes, int n_levels, const int64_t* level_offsets,
+                         const int32_t* ell_idx, const double* ell_w,
+                         const int64_t* pt_rowptr, const int32_t* pt_cols, const double* pt_vals,
+                         const int64_t* par_rowptr, const int32_t* par_cols, const double* par_vals,
+                         const int64_t* chi_rowptr, const int32_t* chi_cols, const double* chi_vals);
 /* K x = b with x = xfix on the dofs flagged in fixed_host (n_dof bytes; NULL: none; xfix NULL: zero values).
- * Jacobi-PCG, sqrt(r.D^-1 r) <= max(rtol sqrt(r0.D^-1 r0), atol); K is symmetric, so the adjoint solve
- * (fea_dolfinx.py:208-222) is the same call.  The reference uses MUMPS (utils_dolfinx.py:476-512).              */
+ * PCG, sqrt(r.M^-1 r) <= max(rtol sqrt(r0.M^-1 r0), atol), opts->pc: 0 Jacobi, 1 lattice; K is symmetric, so the
+ * adjoint solve (fea_dolfinx.py:208-222) is the same call.  The reference uses MUMPS (utils_dolfinx.py:476-512).   */
 int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_host, const femo_vec* xfix, const femo_vec* b,
                      femo_vec* x, const femo_solver_opts* opts, femo_solve_info* info);
 

@@ -23,6 +23,7 @@ def roof_mesh(nx, nphi, R=25.0, L=25.0, phi_max=np.deg2rad(40.0)):
 
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+PC = sys.argv[2] if len(sys.argv) > 2 else "lattice"
 L = 25.0
 pts, conn = roof_mesh(n, n)
 t0 = time.perf_counter()
@@ -33,8 +34,12 @@ fixed = np.unique(np.concatenate([
     S.u_dof(on(ux[:, 0], L), 1), S.u_dof(on(ux[:, 0], L), 2), S.u_dof(on(ux[:, 1], 0.0), 1), S.theta_dof(on(vx[:, 1], 0.0), 0),
     S.theta_dof(on(vx[:, 1], 0.0), 2), S.u_dof(on(ux[:, 0], 0.0), 0), S.theta_dof(on(vx[:, 0], 0.0), 1), S.theta_dof(on(vx[:, 0], 0.0), 2)]))
 ctx = Context(0)
-prob = ShellProblem(pts, conn, 4.32e8, 0.0, fixed_dofs=fixed, ctx=ctx)
+prob = ShellProblem(pts, conn, 4.32e8, 0.0, fixed_dofs=fixed, ctx=ctx, pc=PC)
 setup_s = time.perf_counter() - t0
+t0 = time.perf_counter()
+if PC == "lattice":
+    prob.dev.enable_lattice_pc()
+pc_setup_s = time.perf_counter() - t0
 prob.set_thickness(0.25)
 prob.set_load([0.0, 0.0, -90.0])
 ctx.sync()
@@ -54,6 +59,7 @@ tip = int(np.argmin(np.abs(vx[:, 0]) + np.abs(vx[:, 1] - vx[:, 1].max())))
 print(json.dumps({
     "workload": f"Scordelis-Lo roof {n} x {n} x 2 triangles, CG2^3 x CG1^3 Reissner-Mindlin shell: assemble K(h), solve K w = F, "
                 "compliance, adjoint solve, dJ/dh (thickness sensitivity)",
+    "preconditioner": PC, "pc_levels": prob.dev.pc_levels, "pc_setup_s": pc_setup_s,
     "n_dof": int(S.n_dof), "n_cell": int(S.n_cell), "nnz": int(prob.dev.nnz), "setup_s": setup_s,
     "assemble_ms": t_asm * 1e3, "forward_solve_s": t_fwd, "forward_cg_iterations": int(it_fwd), "forward_solve_device_ms": ms_fwd,
     "adjoint_s": t_adj, "adjoint_cg_iterations": int(it_adj), "adjoint_solve_device_ms": ms_adj,
