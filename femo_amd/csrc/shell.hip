@@ -37,6 +37,8 @@ struct femo_shell {
   int32_t *d_ell_idx = nullptr, *d_pt_cols = nullptr, *d_par_cols = nullptr, *d_chi_cols = nullptr;
   double *d_ell_w = nullptr, *d_pt_vals = nullptr, *d_par_vals = nullptr, *d_chi_vals = nullptr;
   double *d_coarse = nullptr, *d_t = nullptr, *d_e = nullptr, *d_z = nullptr;
+  int32_t* d_fin_idx = nullptr;                         // the finest level's eight (unknown, weight) pairs per dof, contiguous
+  double* d_fin_w = nullptr;
   int64_t *d_pt_rowptr = nullptr, *d_par_rowptr = nullptr, *d_chi_rowptr = nullptr;
   uint64_t pc_vals_uid = 0, pc_vals_gen = 0, pc_mask_hash = 0;     // what d_coarse was computed for
 };
@@ -51,7 +53,7 @@ struct femo_shell_view {
 namespace {
 
 constexpr int SH_BLOCK = 256;
-constexpr int SH_MAXPART = 1024;
+constexpr int SH_MAXPART = 4096;
 
 // quadrature rules of oracle/shell_oracle.py: Dunavant degree 4 (in-plane terms), degree 2 (shear)
 __constant__ double c_lam6[6][3] = {
@@ -614,6 +616,40 @@ __global__ void k_pc_invert(int64_t n, double* __restrict__ d) {
     d[i] = d[i] > 0.0 ? 1.0 / d[i] : 0.0;
 }
 
+// The coarse end of the hierarchy in one single-workgroup launch: levels kc .. 0 down, then 0 .. kc up (a few
+// thousand nodes; as separate launches each costs its ~5 us launch floor).  The levels communicate through global
+// memory inside one workgroup: __syncthreads() drains the stores before the barrier.
+struct LatLevels { int kc; int64_t off[18]; };
+__global__ __launch_bounds__(1024) void k_lat_coarse_fused(LatLevels Lv, const int64_t* __restrict__ chi_rowptr, const int32_t* __restrict__ chi_cols,
+                                                           const double* __restrict__ chi_vals, const int64_t* __restrict__ par_rowptr,
+                                                           const int32_t* __restrict__ par_cols, const double* __restrict__ par_vals,
+                                                           const double* __restrict__ coarse, double* g, double* e, const int32_t* __restrict__ done) {
+  if (done != nullptr && *done) return;
+  for (int l = Lv.kc; l >= 0; --l) {
+    const int64_t n0 = Lv.off[l], cnt = (Lv.off[l + 1] - n0) * 6;
+    for (int64_t t = threadIdx.x; t < cnt; t += 1024) {
+      const int64_t node = n0 + t / 6;
+      const int f = (int)(t % 6);
+      double s = 0.0;
+      for (int64_t k = chi_rowptr[node]; k < chi_rowptr[node + 1]; ++k) s += chi_vals[k] * g[6 * (int64_t)chi_cols[k] + f];
+      g[6 * node + f] = s;
+    }
+    __syncthreads();
+  }
+  for (int l = 0; l <= Lv.kc; ++l) {
+    const int64_t n0 = Lv.off[l], cnt = (Lv.off[l + 1] - n0) * 6;
+    for (int64_t t = threadIdx.x; t < cnt; t += 1024) {
+      const int64_t node = n0 + t / 6;
+      const int f = (int)(t % 6);
+      const int64_t u = 6 * node + f;
+      double s = 0.0;
+      for (int64_t k = par_rowptr[node]; k < par_rowptr[node + 1]; ++k) s += par_vals[k] * e[6 * (int64_t)par_cols[k] + f];
+      e[u] = coarse[u] * g[u] + s;
+    }
+    __syncthreads();
+  }
+}
+
 // g = P_L^T r on the finest lattice's unknowns [row0, row1): CSR rows = lattice unknowns, 16 lanes per row
 __global__ __launch_bounds__(SH_BLOCK) void k_pc_restrict(int64_t row0, int64_t row1, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                                                           const double* __restrict__ vals, const double* __restrict__ r, double* __restrict__ g,
@@ -652,7 +688,7 @@ __global__ void k_lat_level(int64_t n0, int64_t n1, const int64_t* __restrict__ 
 }
 
 // z = D^-1 r + P_L e_L (8 lanes per row, one finest-level entry each) and the per-block partial of r.z; imposed dofs: z = 0
-__global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong(int64_t n, int width, const int32_t* __restrict__ ell_idx, const double* __restrict__ ell_w,
+__global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong(int64_t n, const int32_t* __restrict__ ell_idx, const double* __restrict__ ell_w,
                                                          const uint8_t* __restrict__ fixed, const double* __restrict__ dinv,
                                                          const double* __restrict__ r, const double* __restrict__ t, double* __restrict__ z,
                                                          double* __restrict__ partials, const int32_t* __restrict__ done) {
@@ -665,11 +701,7 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong(int64_t n, int width, c
   for (int64_t row = (int64_t)blockIdx.x * (SH_BLOCK / SUB) + (threadIdx.x / SUB); row < n; row += nsub) {
     const bool rf = fixed != nullptr && fixed[row];
     double s = 0.0;
-    if (!rf) {                                            // the finest level's eight entries are the last ones of the row
-      const int32_t* ir = ell_idx + row * width + (width - 8);
-      const double* wr = ell_w + row * width + (width - 8);
-      s = wr[sl] * t[ir[sl]];
-    }
+    if (!rf) s = ell_w[row * 8 + sl] * t[ell_idx[row * 8 + sl]];     // the finest level's eight entries of the dof
 #pragma unroll
     for (int off = SUB / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if (sl == 0) {
@@ -795,7 +827,7 @@ int femo_shell_destroy(femo_shell* s) {
   hipFree(s->d_r); hipFree(s->d_p); hipFree(s->d_q); hipFree(s->d_dinv); hipFree(s->d_scal); hipFree(s->d_part); hipFree(s->d_flag);
   hipFree(s->d_ell_idx); hipFree(s->d_ell_w); hipFree(s->d_pt_rowptr); hipFree(s->d_pt_cols); hipFree(s->d_pt_vals);
   hipFree(s->d_par_rowptr); hipFree(s->d_par_cols); hipFree(s->d_par_vals); hipFree(s->d_chi_rowptr); hipFree(s->d_chi_cols); hipFree(s->d_chi_vals);
-  hipFree(s->d_coarse); hipFree(s->d_t); hipFree(s->d_e); hipFree(s->d_z);
+  hipFree(s->d_coarse); hipFree(s->d_t); hipFree(s->d_e); hipFree(s->d_z); hipFree(s->d_fin_idx); hipFree(s->d_fin_w);
   delete s;
   return 0;
 }
@@ -825,6 +857,20 @@ int femo_shell_pc_create(femo_shell* s, int width, int64_t n_nodes, int n_levels
   FEMO_TRY(to_device(&s->d_chi_rowptr, chi_rowptr, n_nodes + 1, st));
   FEMO_TRY(to_device(&s->d_chi_cols, chi_cols, chi_rowptr[n_nodes], st));
   FEMO_TRY(to_device(&s->d_chi_vals, chi_vals, chi_rowptr[n_nodes], st));
+  {
+    // the prolongation runs every iteration: its eight entries per dof in arrays of their own (the full ELL rows are
+    // 12 x width bytes apart)
+    std::vector<int32_t> fi((size_t)s->n_dof * 8);
+    std::vector<double> fw((size_t)s->n_dof * 8);
+    for (int64_t i = 0; i < s->n_dof; ++i)
+      for (int a = 0; a < 8; ++a) {
+        fi[(size_t)i * 8 + a] = ell_idx[i * width + (width - 8) + a];
+        fw[(size_t)i * 8 + a] = ell_w[i * width + (width - 8) + a];
+      }
+    FEMO_TRY(to_device(&s->d_fin_idx, fi.data(), s->n_dof * 8, st));
+    FEMO_TRY(to_device(&s->d_fin_w, fw.data(), s->n_dof * 8, st));
+    FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  }
   FEMO_HIP_CHECK(hipMalloc(&s->d_coarse, n_lat * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&s->d_t, n_lat * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&s->d_e, n_lat * sizeof(double)));
@@ -842,17 +888,27 @@ static int shell_pc_apply(femo_shell* s, const uint8_t* d_fixed, double* Prz, un
   const int64_t f0 = 6 * s->level_off[L - 1], f1 = 6 * s->level_off[L];
   hipLaunchKernelGGL(k_pc_restrict, dim3(std::min<unsigned>(sgrid(f1 - f0, SH_BLOCK / 16), 1 << 16)), dim3(SH_BLOCK), 0, st, f0, f1,
                      s->d_pt_rowptr, s->d_pt_cols, s->d_pt_vals, s->d_r, s->d_t, done);
-  for (int l = L - 2; l >= 0; --l) {
+  // levels 0 .. kc (at most 256 nodes each, never the finest: with 4096 the one workgroup took 244 us, with 768 still 71) go through the fused single-workgroup kernel
+  int kc = -1;
+  while (kc + 1 < L - 1 && kc + 1 < 16 && s->level_off[kc + 2] - s->level_off[kc + 1] <= 256) ++kc;
+  for (int l = L - 2; l > kc; --l) {
     const int64_t n0 = s->level_off[l], n1 = s->level_off[l + 1];
     hipLaunchKernelGGL(k_lat_level, dim3(sgrid((n1 - n0) * 6, 256)), dim3(256), 0, st, n0, n1, s->d_chi_rowptr, s->d_chi_cols, s->d_chi_vals,
                        s->d_coarse, s->d_t, s->d_e, 0, done);
   }
-  for (int l = 0; l < L; ++l) {
+  if (kc >= 0) {
+    LatLevels Lv;
+    Lv.kc = kc;
+    for (int l = 0; l <= kc + 1; ++l) Lv.off[l] = s->level_off[l];
+    hipLaunchKernelGGL(k_lat_coarse_fused, dim3(1), dim3(1024), 0, st, Lv, s->d_chi_rowptr, s->d_chi_cols, s->d_chi_vals, s->d_par_rowptr,
+                       s->d_par_cols, s->d_par_vals, s->d_coarse, s->d_t, s->d_e, done);
+  }
+  for (int l = kc + 1; l < L; ++l) {
     const int64_t n0 = s->level_off[l], n1 = s->level_off[l + 1];
     hipLaunchKernelGGL(k_lat_level, dim3(sgrid((n1 - n0) * 6, 256)), dim3(256), 0, st, n0, n1, s->d_par_rowptr, s->d_par_cols, s->d_par_vals,
                        s->d_coarse, s->d_t, s->d_e, 1, done);
   }
-  hipLaunchKernelGGL(k_pc_prolong, dim3(gz), dim3(SH_BLOCK), 0, st, s->n_dof, s->pc_width, s->d_ell_idx, s->d_ell_w, d_fixed, s->d_dinv, s->d_r, s->d_e,
+  hipLaunchKernelGGL(k_pc_prolong, dim3(gz), dim3(SH_BLOCK), 0, st, s->n_dof, s->d_fin_idx, s->d_fin_w, d_fixed, s->d_dinv, s->d_r, s->d_e,
                      s->d_z, Prz, done);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
