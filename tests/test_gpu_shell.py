@@ -253,3 +253,42 @@ def test_lattice_preconditioner(ctx):
     assert res[(16, "lattice")][0] < 0.4 * res[(16, "jacobi")][0]           # 980 against 3171
     assert res[(16, "lattice")][0] < 1.4 * res[(8, "lattice")][0]           # 753 -> 980; Jacobi: 1151 -> 3171
     assert res[(16, "jacobi")][0] > 2.0 * res[(8, "jacobi")][0]
+
+
+def test_irregular_surface_mesh(ctx):
+    """Jittered vertices (moved along the cylinder), flipped and rotated cell numbering: kernels against the oracle,
+    the lattice-preconditioned solve against the direct one; and a flat plate, whose bounding box is degenerate."""
+    from femo_amd.fea.shell import ShellProblem
+    rng = np.random.default_rng(13)
+    pts, conn = so.scordelis_lo_mesh(10, 10)
+    X = pts[:, 0] + rng.uniform(-0.6, 0.6, len(pts)) * (pts[:, 0] > 1e-6) * (pts[:, 0] < L - 1e-6)
+    phi = np.arcsin(pts[:, 1] / 25.0)
+    inner = (phi > 1e-9) & (phi < phi.max() - 1e-9)
+    phi = phi + rng.uniform(-0.015, 0.015, len(pts)) * inner
+    pts = np.stack([X, 25.0 * np.sin(phi), 25.0 * np.cos(phi)], axis=1)
+    conn = conn.copy()
+    flip = rng.random(len(conn)) < 0.5
+    conn[flip] = conn[flip][:, [0, 2, 1]]
+    conn = np.stack([np.roll(c, r) for c, r in zip(conn, rng.integers(0, 3, len(conn)))])
+    V0 = so.ShellSpace(pts, conn)
+    fixed = roof_fixed(V0)
+    prob = ShellProblem(pts, conn, E_ROOF, 0.25, fixed_dofs=fixed, ctx=ctx)
+    h = H_ROOF * (1.0 + 0.3 * rng.random(V0.n_vert))
+    f = rng.standard_normal((V0.n_vert, 3)) * 50.0
+    prob.set_thickness(h); prob.set_load(f)
+    Kref = so.assemble(V0, so.element_stiffness(V0, h, E_ROOF, 0.25))
+    rowptr, cols, _ = prob.space.pattern()
+    K = sp.csr_matrix((np.array(prob._stiffness().get()), cols, rowptr), shape=Kref.shape)
+    assert abs(K - Kref).max() <= 1e-12 * abs(Kref).max()
+    wref = so.solve(Kref, so.load_vector(V0, f), fixed)
+    assert rel(prob.solve(rtol=1e-11), wref) <= 1e-7
+    # flat plate in the plane z = 0
+    ppts, pconn = so.plate_mesh(12)
+    P0 = so.ShellSpace(ppts, pconn)
+    edge = np.nonzero(np.isclose(P0.unode_x[:, 0], 0) | np.isclose(P0.unode_x[:, 0], 1))[0]
+    pfixed = np.unique(np.concatenate([P0.u_dof(edge, k) for k in range(3)] + [P0.theta_dof(np.nonzero(np.isclose(P0.x[:, 0], 0))[0], k) for k in range(3)]))
+    plate = ShellProblem(ppts, pconn, 1.0e7, 0.3, fixed_dofs=pfixed, ctx=ctx)
+    plate.set_thickness(0.02); plate.set_load([0.0, 0.0, -1.0])
+    Kp = so.assemble(P0, so.element_stiffness(P0, np.full(P0.n_vert, 0.02), 1.0e7, 0.3))
+    wp = so.solve(Kp, so.load_vector(P0, np.tile([0.0, 0.0, -1.0], (P0.n_vert, 1))), pfixed)
+    assert rel(plate.solve(rtol=1e-11), wp) <= 1e-6

@@ -91,3 +91,23 @@ def test_scordelis_lo_roof():
     parts = so.energy_parts(V, w, np.full(V.n_vert, 0.25), 4.32e8, 0.0)
     assert parts["shear"] < 0.01 * (parts["membrane"] + parts["bending"])      # thin: no shear locking
     assert so.compliance(V, w) > 0.0
+
+
+def test_energy_does_not_depend_on_cell_orientation_or_numbering():
+    """Flipping the vertex order of some triangles flips their normal and tangent frame; rotating the local numbering
+    changes the frame's first axis.  The assembled stiffness must not care (the material is isotropic, every strain
+    enters quadratically)."""
+    pts, conn = so.scordelis_lo_mesh(4, 4)
+    rng = np.random.default_rng(0)
+    V0 = so.ShellSpace(pts, conn)
+    h = 0.25 * (1 + 0.3 * rng.random(V0.n_vert))
+    K0 = so.assemble(V0, so.element_stiffness(V0, h, 4.32e8, 0.3))
+    conn2 = conn.copy()
+    flip = rng.random(len(conn)) < 0.5
+    conn2[flip] = conn2[flip][:, [0, 2, 1]]
+    rot = rng.integers(0, 3, len(conn))
+    conn2 = np.stack([np.roll(c, r) for c, r in zip(conn2, rot)])
+    V1 = so.ShellSpace(pts, conn2)
+    assert V1.n_dof == V0.n_dof and np.array_equal(V1.edge_vertices, V0.edge_vertices)      # same global numbering
+    K1 = so.assemble(V1, so.element_stiffness(V1, h, 4.32e8, 0.3))
+    assert abs(K1 - K0).max() <= 1e-10 * abs(K0).max()
