@@ -211,6 +211,11 @@ def main():
     PC = args.pc
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(_relaunch_multi_gpu(args))
+    # several ranks on one node share its cores (and the container's CPU quota): the library's host thread pool
+    # would otherwise start min(cores, 16) threads in EVERY rank
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    if local_world > 1 and "FEMO_HOST_THREADS" not in os.environ:
+        os.environ["FEMO_HOST_THREADS"] = str(max(1, min(16, usable_cores() // local_world)))
     from femo_amd.dist import _quiet_stdout
     with _quiet_stdout():                       # library banners go to stderr: stdout carries ONE JSON line
         result = _run(args)
