@@ -33,6 +33,25 @@ class ShellMesh:
         self.n_vert, self.n_cell = self.space.n_vert, self.space.n_cell
         self._dev = {}
 
+    @classmethod
+    def read(cls, path: str) -> "ShellMesh":
+        """Triangle grid with three coordinates per vertex from an XDMF file -- what the shell drivers do with
+        ``XDMFFile(...).read_mesh(name="Grid")`` (`run_shape_opt_roof.py:40-42`, `shell_pde.py` callers).  Heavy data as
+        XML or raw binary (fea/io.py); HDF5 is refused there with a message."""
+        from .io import read_xdmf_grid
+        x, cells, kind, _ = read_xdmf_grid(path)
+        if kind != "triangle":
+            raise NotImplementedError(f"{path}: shell meshes are triangle grids (got {kind!r})")
+        x = np.asarray(x, dtype=np.float64)
+        if x.shape[1] == 2:
+            x = np.concatenate([x, np.zeros((x.shape[0], 1))], axis=1)
+        return cls(x, cells)
+
+    def write(self, path: str, binary: bool = False) -> None:
+        """XDMF3 file of the surface mesh (same writer as the volume meshes')."""
+        from .io import _write_grid
+        _write_grid(path, "Triangle", self.x, self.conn, None, binary)
+
     def device(self, ctx) -> DeviceShell:
         d = self._dev.get(id(ctx))
         if d is None:

@@ -63,3 +63,17 @@ def test_l_shape_generator_is_a_valid_unstructured_mesh():
     assert area.min() > 0 and abs(area.sum() - 3.0) < 1e-12            # the L covers 3 of the 4 unit squares
     assert area.max() / area.min() > 20                                  # graded
     assert np.abs(np.diff(np.sort(conn.ravel()))).max() <= 1 and set(tags) == {1, 2}
+
+
+def test_shell_mesh_round_trip(tmp_path):
+    """Triangle grid with three coordinates per vertex (the roof meshes of run_shape_opt_roof.py:22-42), XML and raw."""
+    from oracle import shell_oracle as so
+    from femo_amd.fea.shell_forms import ShellMesh
+    pts, conn = so.scordelis_lo_mesh(5, 3)
+    mesh = ShellMesh(pts, conn)
+    for binary in (False, True):
+        path = str(tmp_path / f"roof_{int(binary)}.xdmf")
+        mesh.write(path, binary=binary)
+        back = ShellMesh.read(path)
+        assert np.array_equal(back.conn, mesh.conn) and np.array_equal(back.x, mesh.x)
+        assert back.space.n_dof == mesh.space.n_dof == 3 * (mesh.n_vert + mesh.space.n_edge) + 3 * mesh.n_vert
