@@ -22,6 +22,11 @@ __global__ void k_sum(int64_t n, const double* __restrict__ a, const double* __r
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = a[i] + b[i];
 }
 
+__global__ void k_scale(int64_t n, double a, const double* __restrict__ x, double* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = a * x[i];
+}
+
 __global__ void k_pdiv(int64_t n, const double* __restrict__ x, const double* __restrict__ d, double* __restrict__ y) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = x[i] / d[i];
 }
@@ -132,6 +137,13 @@ int upload(T** dptr, const std::vector<T>& h, hipStream_t st) {
 int femo_launch_sum(double* out, const double* a, const double* b, int64_t n, hipStream_t st) {
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_sum, dim3(grid_for(n)), dim3(256), 0, st, n, a, b, out);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int femo_launch_scale(double* out, double a, const double* x, int64_t n, hipStream_t st) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_scale, dim3(grid_for(n)), dim3(256), 0, st, n, a, x, out);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }

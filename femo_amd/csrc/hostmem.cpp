@@ -156,11 +156,16 @@ struct HostBlock {
   size_t bytes = 0;
   bool pooled = false;       // hipHostMalloc'ed by femo_host_alloc (else: hipHostRegister'ed user memory)
   // provenance: the first src_n doubles are an exact copy of device vector src_uid at generation src_gen
+  // times src_scale (1 unless the block was filled by femo_host_axpby(a, x, 0, y) from a block that mirrors a vector:
+  // the library then knows y = a * vector without looking at the bytes)
   uint64_t src_uid = 0, src_gen = 0;
   int64_t src_n = 0;
+  double src_scale = 1.0;
   // an asynchronous copy-out into the block is (or was) in flight: recorded on a copy stream after the DMA
+  // (pend_ctx: the context whose copy stream carries it -- deferred host work is queued behind it there)
   hipEvent_t ready = nullptr;
   bool pending = false;
+  femo_ctx* pend_ctx = nullptr;
 };
 
 std::mutex g_mu;
@@ -437,10 +442,70 @@ int femo_host_copy(double* dst, const double* src, int64_t n) {
   return 0;
 }
 
+namespace {
+struct DeferredScale { double* y; const double* x; int64_t n; double a; };
+void run_deferred_scale(void* p) {                       // hipLaunchHostFunc callback: host work only, no HIP calls
+  DeferredScale* d = static_cast<DeferredScale*>(p);
+  par_stream(d->y, d->x, d->n, 2, d->a, 0.0);
+  delete d;
+}
+}  // namespace
+
 int femo_host_axpby(int64_t n, double a, const double* x, double b, double* y) {
   FEMO_REQUIRE((x && y) || n == 0, "null argument");
-  FEMO_TRY(wait_block(x));
+  if (n == 0) return 0;
   FEMO_TRY(wait_block(y));
+  // y = a x with x a block that mirrors a device vector: y is then known to be a * that vector without its bytes
+  // (femo_vec_set_host from y becomes a device-side scale).  If x is still on its way down the host pass is queued
+  // behind the copy on the same stream instead of waiting for it here -- the reverse sweep negates dJ/du this way
+  // and goes on to enqueue the adjoint solve.
+  if (b == 0.0 && a != 0.0 && x != y) {
+    uint64_t uid = 0, gen = 0;
+    double scale = 1.0;
+    bool x_pending = false;
+    femo_ctx* pctx = nullptr;
+    hipEvent_t y_ready = nullptr, x_ready = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(g_mu);
+      HostBlock* bx = find_block(x, (size_t)n * sizeof(double));
+      HostBlock* by = find_block(y, (size_t)n * sizeof(double));
+      if (bx && by && reinterpret_cast<const char*>(x) == bx->base && reinterpret_cast<char*>(y) == by->base && bx->src_uid != 0 &&
+          bx->src_n >= n) {
+        auto it = g_live.find(bx->src_uid);
+        if (it != g_live.end() && it->second->gen == bx->src_gen) {
+          uid = bx->src_uid; gen = bx->src_gen; scale = bx->src_scale;
+          x_pending = bx->pending && bx->pend_ctx != nullptr && bx->pend_ctx->copy_stream != nullptr;
+          pctx = bx->pend_ctx;
+          if (x_pending) {
+            if (by->ready == nullptr) by->ready = take_event();
+            y_ready = by->ready;
+            x_ready = bx->ready;
+          }
+        }
+      }
+    }
+    if (uid != 0) {
+      if (x_pending && y_ready != nullptr) {
+        Trace tr("host_axpby (deferred)", n * 8);
+        FEMO_HIP_CHECK(hipSetDevice(pctx->device));
+        FEMO_HIP_CHECK(hipLaunchHostFunc(pctx->copy_stream, run_deferred_scale, new DeferredScale{y, x, n, a}));
+        FEMO_HIP_CHECK(hipEventRecord(y_ready, pctx->copy_stream));
+        // x stays "in flight" until the pass that reads it has run: freeing its block waits for this event
+        if (x_ready != nullptr) FEMO_HIP_CHECK(hipEventRecord(x_ready, pctx->copy_stream));
+      } else {
+        FEMO_TRY(wait_block(x));
+        Trace tr("host_axpby", n * 8);
+        par_stream(y, x, n, 2, a, 0.0);
+      }
+      std::lock_guard<std::mutex> lk(g_mu);
+      if (HostBlock* by = find_block(y, (size_t)n * sizeof(double))) {
+        by->src_uid = uid; by->src_gen = gen; by->src_n = n; by->src_scale = a * scale;
+        if (x_pending && y_ready != nullptr) { by->pending = true; by->pend_ctx = pctx; }
+      }
+      return 0;
+    }
+  }
+  FEMO_TRY(wait_block(x));
   Trace tr("host_axpby", n * 8);
   par_stream(y, x, n, 2, a, b);
   femo_host_touch(y);
@@ -468,6 +533,7 @@ int femo_vec_set_host(femo_vec* v, const double* host, int64_t n) {
   FEMO_HIP_CHECK(hipSetDevice(v->ctx->device));
   bool pinned = false, exact_base = false;
   uint64_t src_uid = 0, src_gen = 0;
+  double src_scale = 1.0;
   femo_vec* src = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -475,7 +541,7 @@ int femo_vec_set_host(femo_vec* v, const double* host, int64_t n) {
       pinned = true;
       exact_base = reinterpret_cast<const char*>(host) == b->base;
       if (exact_base && b->src_uid != 0 && b->src_n >= n) {
-        src_uid = b->src_uid; src_gen = b->src_gen;
+        src_uid = b->src_uid; src_gen = b->src_gen; src_scale = b->src_scale;
         auto it = g_live.find(src_uid);
         if (it != g_live.end() && it->second->gen == src_gen && it->second->ctx->device == v->ctx->device) src = it->second;
       }
@@ -483,8 +549,15 @@ int femo_vec_set_host(femo_vec* v, const double* host, int64_t n) {
   }
   Trace tr(src == v && src ? "set_host (skipped)" : (src ? "set_host (d2d)" : (pinned ? "set_host (pinned)" : "set_host (staged)")), n * 8);
   int elided = 0;
-  if (src != nullptr && src == v) {
+  if (src != nullptr && src == v && src_scale == 1.0) {
     elided = 1;                                          // v still holds exactly this content
+  } else if (src != nullptr && src == v) {
+    src = nullptr;                                       // a * v into v itself: not worth a special case, upload
+  } else if (src != nullptr && src_scale != 1.0) {
+    femo_vec_touch(v);
+    FEMO_TRY(femo_launch_scale(v->d, src_scale, src->d, n, v->ctx->stream));   // host = scale * src: the same product on the device
+    if (src->ctx != v->ctx) FEMO_HIP_CHECK(hipStreamSynchronize(v->ctx->stream));
+    elided = 2;
   } else if (src != nullptr) {
     femo_vec_touch(v);                                   // before the write: a copy-out of v may be in flight
     FEMO_HIP_CHECK(hipMemcpyAsync(v->d, src->d, n * sizeof(double), hipMemcpyDeviceToDevice, v->ctx->stream));
@@ -509,7 +582,7 @@ int femo_vec_set_host(femo_vec* v, const double* host, int64_t n) {
   else { ++g_stats.h2d_staged; g_stats.h2d_staged_bytes += n * 8; }
   if (exact_base && v->uid != 0) {                       // the block is now an exact copy of v
     if (HostBlock* b = find_block(host, (size_t)n * sizeof(double))) {
-      if (reinterpret_cast<const char*>(host) == b->base) { b->src_uid = v->uid; b->src_gen = v->gen; b->src_n = n; }
+      if (reinterpret_cast<const char*>(host) == b->base) { b->src_uid = v->uid; b->src_gen = v->gen; b->src_n = n; b->src_scale = 1.0; }
     }
   }
   return 0;
@@ -583,7 +656,8 @@ static int get_host_impl(const femo_vec* v, double* host, int64_t n, int op, boo
     ++g_stats.d2h_async; g_stats.d2h_async_bytes += n * 8;
     if (HostBlock* b = find_block(host, (size_t)n * sizeof(double))) {
       b->pending = true;
-      if (exact_base && v->uid != 0) { b->src_uid = v->uid; b->src_gen = v->gen; b->src_n = n; }   // true once landed
+      b->pend_ctx = c;
+      if (exact_base && v->uid != 0) { b->src_uid = v->uid; b->src_gen = v->gen; b->src_n = n; b->src_scale = 1.0; }   // true once landed
     }
     return 0;
   }
@@ -596,7 +670,7 @@ static int get_host_impl(const femo_vec* v, double* host, int64_t n, int op, boo
   else { ++g_stats.d2h_staged; g_stats.d2h_staged_bytes += n * 8; }
   if (pinned && op == 0 && v->uid != 0) {
     if (HostBlock* b = find_block(host, (size_t)n * sizeof(double))) {
-      if (reinterpret_cast<char*>(host) == b->base) { b->src_uid = v->uid; b->src_gen = v->gen; b->src_n = n; }
+      if (reinterpret_cast<char*>(host) == b->base) { b->src_uid = v->uid; b->src_gen = v->gen; b->src_n = n; b->src_scale = 1.0; }
     }
   }
   return 0;

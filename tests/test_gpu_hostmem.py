@@ -196,10 +196,11 @@ def test_operator_cycle_moves_each_array_once(ctx):
     st = E.host_stats()
     nf, nu = mesh.n_cell * 8, mesh.n_vert * 8
     assert isinstance(g, np.ndarray) and g.flags.writeable
-    # PCIe: f once and the adjoint seed; the initial guess is the state the previous run returned (still on
-    # the device), and f / u / psi come back to the later operator methods as the arrays already sent
-    assert st["h2d_pinned_bytes"] + st["h2d_staged_bytes"] == nf + nu, st
-    assert st["h2d_skipped"] + st["h2d_as_d2d"] == 8, st
+    # PCIe: f once; the initial guess is the state the previous run returned (still on the device), f / u / psi come
+    # back to the later operator methods as the arrays already sent, and the adjoint seed -dJ/du is known to be
+    # -1 x a device vector (femo_host_axpby from a block that mirrors it): formed on the device
+    assert st["h2d_pinned_bytes"] + st["h2d_staged_bytes"] == nf, st
+    assert st["h2d_skipped"] + st["h2d_as_d2d"] == 9, st
     # down: u, dJ/df, dJ/du, psi, dR/df^T psi
     down = st["d2h_pinned_bytes"] + st["d2h_staged_bytes"] + st["d2h_async_bytes"] + st["d2h_device_sum_bytes"]
     assert down == 2 * nf + 3 * nu, st
@@ -259,6 +260,42 @@ def test_asynchronous_results(ctx):
     E.host_sync()
     with E.lazy_results(False):
         assert np.array_equal(v.get(), a)               # not lazy: complete on return
+
+
+def test_scaled_copies_are_formed_on_the_device(ctx):
+    """y = a x on the host (femo_host_axpby) with x a block that mirrors a device vector: y is recorded as a x that
+    vector -- also while x is still on its way down, the host pass is then queued behind the copy -- and sending y
+    to a vector is a device-side scale.  Every elision checked byte for byte (FEMO_HOST_VERIFY)."""
+    from femo_amd import engine as E
+    n = 4_000_003
+    a = np.random.default_rng(21).standard_normal(n)
+    v, w = E.Vec(ctx, n).set(a), E.Vec(ctx, n)
+    for lazy in (False, True):
+        E.host_stats(reset=True)
+        with E.lazy_results(lazy):
+            h = v.get()
+        y = E.pinned_empty(n)
+        E.host_axpby(-2.5, h, 0.0, y)                   # returns at once in the lazy case
+        w.fill(0.0)
+        w.set(y)
+        st = E.host_stats()
+        assert st["h2d_as_d2d"] == 1 and st["h2d_pinned"] == 0, (lazy, st)
+        assert np.array_equal(w.get(), -2.5 * a)
+        assert np.array_equal(E.host_wait(y), -2.5 * a)
+        # chained: z = 2 y is -5 x the vector
+        z = E.pinned_empty(n)
+        E.host_axpby(2.0, y, 0.0, z)
+        w.set(z)
+        assert np.array_equal(w.get(), -5.0 * a) and np.array_equal(E.host_wait(z), -5.0 * a)
+        # the vector changes: y no longer describes it, a real upload follows
+        v.axpy(1.0, v)
+        E.host_axpby(3.0, h, 0.0, y)
+        w.set(y)
+        assert E.host_stats()["h2d_pinned"] >= 1
+        assert np.array_equal(w.get(), 3.0 * a)
+        v.set(a)
+        del h, y, z
+        gc.collect()
 
 
 def test_accumulate_on_the_device(ctx):
