@@ -149,7 +149,10 @@ int     femo_vec_dot(const femo_vec* x, const femo_vec* y, int64_t n, double* ou
  *     Whoever writes to such a block on the host MUST call femo_host_touch first/afterwards; the
  *     library's own host writers do.  FEMO_HOST_VERIFY=1 (environment) checks every elided upload.
  *   - femo_host_copy / femo_host_axpby: y = x, y = a x + b y on the library's host threads, for
- *     drivers that keep their variables in pinned blocks (touch the destination themselves).   */
+ *     drivers that keep their variables in pinned blocks (touch the destination themselves).
+ *     femo_host_axpby(a, x, 0, y) with x a block that mirrors a device vector records y as a times that
+ *     vector (femo_vec_set_host from y is then a device-side scale), and queues the host pass behind a
+ *     copy-out of x that is still in flight instead of waiting for it (y is then in flight itself).   */
 typedef struct femo_host_stats {
   int64_t h2d_pinned, h2d_pinned_bytes;     /* one DMA from a pinned block              */
   int64_t h2d_staged, h2d_staged_bytes;     /* pageable source through the staging ring */
