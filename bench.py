@@ -267,7 +267,7 @@ def _run(args):
     # inputs "already on host" (SURVEY.md section 8(d)): NumPy arrays in pinned memory, as a driver that
     # allocates its variables through femo_host_alloc holds them
     f_pin = [E.pinned_array(f) for f in f_host]
-    u0 = E.pinned_array(np.zeros(n_dof))
+    u0 = E.pinned_full(n_dof, 0.0)          # the cold-start state: a constant the library knows as such (device fill, no upload)
     setup_s = time.perf_counter() - t0
 
     # ---- headline: host arrays in, host arrays out ------------------------------------------------

@@ -76,6 +76,7 @@ PROTOTYPES = {
     "femo_host_register": (C.c_int, [C.c_void_p, c_i64]),
     "femo_host_unregister": (C.c_int, [C.c_void_p]),
     "femo_host_touch": (C.c_int, [C.c_void_p]),
+    "femo_host_fill": (C.c_int, [C.c_void_p, c_i64, C.c_double]),
     "femo_host_is_pinned": (C.c_int, [C.c_void_p, c_i64]),
     "femo_host_threads": (C.c_int, []),
     "femo_host_copy": (C.c_int, [C.c_void_p, C.c_void_p, c_i64]),

@@ -141,6 +141,13 @@ int femo_launch_sum(double* out, const double* a, const double* b, int64_t n, hi
   return 0;
 }
 
+int femo_launch_fill(double* out, double value, int64_t n, hipStream_t st) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_fill, dim3(grid_for(n)), dim3(256), 0, st, n, value, out);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int femo_launch_scale(double* out, double a, const double* x, int64_t n, hipStream_t st) {
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_scale, dim3(grid_for(n)), dim3(256), 0, st, n, a, x, out);

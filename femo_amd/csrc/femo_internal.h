@@ -144,6 +144,7 @@ inline void femo_vec_touch(femo_vec* v) {
 int femo_launch_sum(double* out, const double* a, const double* b, int64_t n, hipStream_t st);
 // out = a * x on the stream (api.hip; a host array known to be a * a device vector is "uploaded" this way)
 int femo_launch_scale(double* out, double a, const double* x, int64_t n, hipStream_t st);
+int femo_launch_fill(double* out, double value, int64_t n, hipStream_t st);
 void femo_vec_register(femo_vec* v);     // after creation: assigns uid, enters the live table
 void femo_vec_unregister(femo_vec* v);   // before destruction
 

@@ -161,6 +161,9 @@ struct HostBlock {
   uint64_t src_uid = 0, src_gen = 0;
   int64_t src_n = 0;
   double src_scale = 1.0;
+  // ... or every one of the first const_n doubles equals const_value (femo_host_fill): sending the block is a device fill
+  int64_t const_n = 0;
+  double const_value = 0.0;
   // an asynchronous copy-out into the block is (or was) in flight: recorded on a copy stream after the DMA
   // (pend_ctx: the context whose copy stream carries it -- deferred host work is queued behind it there)
   hipEvent_t ready = nullptr;
@@ -421,7 +424,7 @@ int femo_host_touch(void* p) {
   if (!p) return 0;
   FEMO_TRY(wait_block(p));                               // the caller is about to write (or has read) the block
   std::lock_guard<std::mutex> lk(g_mu);
-  if (HostBlock* b = find_block(p, 1)) b->src_uid = 0;
+  if (HostBlock* b = find_block(p, 1)) { b->src_uid = 0; b->const_n = 0; }
   return 0;
 }
 
@@ -431,6 +434,26 @@ int femo_host_is_pinned(const void* p, int64_t bytes) {
 }
 
 int femo_host_threads(void) { return HostPool::get().threads(); }
+
+int femo_host_fill(double* p, int64_t n, double value) {
+  FEMO_REQUIRE(p || n == 0, "null argument");
+  if (n == 0) return 0;
+  FEMO_TRY(wait_block(p));
+  Trace tr("host_fill", n * 8);
+  HostPool& P = HostPool::get();
+  const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(P.threads(), n >> 16));
+  P.run(parts, [&](int k) {
+    const int64_t lo = n * k / parts, hi = n * (k + 1) / parts;
+    for (int64_t i = lo; i < hi; ++i) p[i] = value;
+  });
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (HostBlock* b = find_block(p, (size_t)n * sizeof(double))) {
+    b->src_uid = 0;
+    if (reinterpret_cast<char*>(p) == b->base) { b->const_n = n; b->const_value = value; }
+    else b->const_n = 0;
+  }
+  return 0;
+}
 
 int femo_host_copy(double* dst, const double* src, int64_t n) {
   FEMO_REQUIRE((dst && src) || n == 0, "null argument");
@@ -499,7 +522,7 @@ int femo_host_axpby(int64_t n, double a, const double* x, double b, double* y) {
       }
       std::lock_guard<std::mutex> lk(g_mu);
       if (HostBlock* by = find_block(y, (size_t)n * sizeof(double))) {
-        by->src_uid = uid; by->src_gen = gen; by->src_n = n; by->src_scale = a * scale;
+        by->src_uid = uid; by->src_gen = gen; by->src_n = n; by->src_scale = a * scale; by->const_n = 0;
         if (x_pending && y_ready != nullptr) { by->pending = true; by->pend_ctx = pctx; }
       }
       return 0;
@@ -531,7 +554,8 @@ int femo_vec_set_host(femo_vec* v, const double* host, int64_t n) {
   FEMO_REQUIRE(n == v->n, "size mismatch: vector has %lld entries, host array %lld", (long long)v->n, (long long)n);
   if (n == 0) return 0;
   FEMO_HIP_CHECK(hipSetDevice(v->ctx->device));
-  bool pinned = false, exact_base = false;
+  bool pinned = false, exact_base = false, is_const = false;
+  double const_value = 0.0;
   uint64_t src_uid = 0, src_gen = 0;
   double src_scale = 1.0;
   femo_vec* src = nullptr;
@@ -540,6 +564,7 @@ int femo_vec_set_host(femo_vec* v, const double* host, int64_t n) {
     if (HostBlock* b = find_block(host, (size_t)n * sizeof(double))) {
       pinned = true;
       exact_base = reinterpret_cast<const char*>(host) == b->base;
+      if (exact_base && b->const_n >= n) { is_const = true; const_value = b->const_value; }
       if (exact_base && b->src_uid != 0 && b->src_n >= n) {
         src_uid = b->src_uid; src_gen = b->src_gen; src_scale = b->src_scale;
         auto it = g_live.find(src_uid);
@@ -551,6 +576,11 @@ int femo_vec_set_host(femo_vec* v, const double* host, int64_t n) {
   int elided = 0;
   if (src != nullptr && src == v && src_scale == 1.0) {
     elided = 1;                                          // v still holds exactly this content
+  } else if (is_const && (src == nullptr || src != v)) {
+    femo_vec_touch(v);
+    FEMO_TRY(femo_launch_fill(v->d, const_value, n, v->ctx->stream));   // the block is a constant: fill on the device
+    src = nullptr;
+    elided = 2;
   } else if (src != nullptr && src == v) {
     src = nullptr;                                       // a * v into v itself: not worth a special case, upload
   } else if (src != nullptr && src_scale != 1.0) {
@@ -608,6 +638,7 @@ static int get_host_impl(const femo_vec* v, double* host, int64_t n, int op, boo
         if (it != g_live.end() && it->second->gen == b->src_gen && it->second->ctx == c) mirror = it->second;
       }
       b->src_uid = 0;                                    // being overwritten
+      b->const_n = 0;
     }
   }
   if (op == 1 && mirror != nullptr) {

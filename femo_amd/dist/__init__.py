@@ -231,7 +231,8 @@ def run_distributed_bench(args, ctx, control, cpu_baseline: bool = True):
     dm = mesh.device(ctx)
     K, W = args.steps, args.warmup
     f_host = [pinned_array(f) for f in B.source_fields(mesh, min(K + W, 4))]
-    u0 = pinned_array(np.zeros(mesh.n_vert))
+    from ..engine import pinned_full
+    u0 = pinned_full(mesh.n_vert, 0.0)
     setup_s = time.perf_counter() - t0
     rss_setup = _rss_mb() - rss0
 

@@ -84,6 +84,15 @@ def host_touch(a: np.ndarray) -> None:
     check(_lib.load().femo_host_touch(C.c_void_p(a.ctypes.data)))
 
 
+def pinned_full(n: int, value: float) -> np.ndarray:
+    """READ-ONLY pinned array of n copies of ``value`` that the library remembers as that constant: sending it to a
+    device vector is a fill kernel, not a transfer (initial guesses and other constant fields of a driver)."""
+    a = pinned_empty(n)
+    check(_lib.load().femo_host_fill(C.c_void_p(a.ctypes.data), int(n), float(value)))
+    a.flags.writeable = False
+    return a
+
+
 def host_wait(a: np.ndarray) -> np.ndarray:
     """Block until an asynchronous copy-out into ``a`` (``Vec.get`` under ``lazy_results``) has landed.  No-op for
     any other array.  Library calls that take ``a`` wait by themselves; NumPy code calls this first."""

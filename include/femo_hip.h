@@ -171,6 +171,8 @@ int femo_host_unregister(void* p);
 int femo_host_touch(void* p);                /* the block containing p was written on the host */
 int femo_host_is_pinned(const void* p, int64_t bytes);
 int femo_host_threads(void);
+int femo_host_fill(double* p, int64_t n, double value);   /* p[:] = value; at the base of a pinned block the library remembers
+                                                            * it as that constant: sending it to a vector is a device-side fill */
 int femo_host_copy(double* dst, const double* src, int64_t n);
 int femo_host_axpby(int64_t n, double a, const double* x, double b, double* y);
 /* Asynchronous results: femo_vec_get_host_async returns before the bytes have landed when `host` lies in a

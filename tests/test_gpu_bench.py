@@ -35,8 +35,9 @@ def test_bench_record_with_twenty_steps():
     assert abs(sum(s.values()) - r["ms_per_step"]) < 1e-6 * r["ms_per_step"]
     assert "host" in c["boundary"]
     # the array boundary: f goes up once per step, repeated uploads are elided
-    # (f and the cold-start state; the adjoint seed -dJ/du is formed on the device from the vector it negates)
-    assert c["pcie"]["h2d_bytes_per_step"] == 8 * (c["n_cell"] + c["n_dof"])
+    # (f only: the cold-start state is a constant block, filled on the device; the adjoint seed -dJ/du is formed on
+    # the device from the vector it negates)
+    assert c["pcie"]["h2d_bytes_per_step"] == 8 * c["n_cell"]
     assert c["pcie"]["d2h_bytes_per_step"] == 8 * (2 * c["n_cell"] + 3 * c["n_dof"])
     assert c["pcie"]["uploads_elided_per_step"] >= 7
     rf = r["roofline"]

@@ -298,6 +298,28 @@ def test_scaled_copies_are_formed_on_the_device(ctx):
         gc.collect()
 
 
+def test_constant_blocks_are_filled_on_the_device(ctx):
+    from femo_amd import engine as E
+    n = 2_000_003
+    v = E.Vec(ctx, n).fill(7.0)
+    z = E.pinned_full(n, 0.25)
+    assert not z.flags.writeable and np.all(z == 0.25)
+    E.host_stats(reset=True)
+    v.set(z)
+    st = E.host_stats()
+    assert st["h2d_pinned"] == 0 and st["h2d_as_d2d"] == 1, st
+    assert np.all(v.get() == 0.25)
+    v.fill(1.0)
+    v.set(z)                                            # still the constant, whatever the vector holds
+    assert np.all(v.get() == 0.25) and E.host_stats()["h2d_pinned"] == 0
+    zw = E.writable(z)                                  # announced write: an ordinary block from now on
+    zw[5] = 3.0
+    v.set(zw)
+    assert E.host_stats()["h2d_pinned"] == 1
+    got = v.get()
+    assert got[5] == 3.0 and got[4] == 0.25
+
+
 def test_accumulate_on_the_device(ctx):
     """add_to_host into a block that still mirrors a live vector: the sum is formed on the device and is the
     host sum bit for bit; the block mirrors nothing afterwards; any doubt falls back to the host path."""
