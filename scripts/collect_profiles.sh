@@ -16,6 +16,7 @@ timeout 300 python scripts/run_nonlinear_c5.py > $O/config5_nonlinear_n2236.json
 python3 scripts/trace_summary.py $O/trace 5 k_spmv_sell 8 > $O/bench_kernel_stats.csv
 cp $(find $O/trace -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats_rocprofv3.csv 2>/dev/null
 rm -rf $O/trace
+if [ "${SKIP_PMC:-0}" = "1" ]; then ls -la $O; exit 0; fi
 for V in "215" "215 permute"; do
   T=$(echo $V | tr ' ' '_')
   for P in "FETCH_SIZE" "WRITE_SIZE L2CacheHit" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD" "GRBM_GUI_ACTIVE VALUBusy MemUnitBusy MemUnitStalled"; do
