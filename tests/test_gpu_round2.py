@@ -282,3 +282,35 @@ def test_overlapped_pcg_matches_the_sequential_one(ctx):
             os.environ.pop("FEMO_PCG_OVERLAP", None)
     assert res["0"][0] == res["1"][0] and res["0"][0] > 5
     assert np.abs(res["0"][1] - res["1"][1]).max() <= 1e-12 * np.abs(res["0"][1]).max()
+
+
+def test_poisson_opt_example_reaches_the_analytic_optimum(ctx):
+    """BASELINE config 1 / examples/poisson_opt end to end: the optimisation of run_poisson_opt.py (objective scaled by
+    1e5, start at f = 0.086, :168-176) driven by the GPU values and adjoint gradients converges to the analytic
+    optimal pair the example prints its errors against (Expression_f / Expression_u, :78-92) -- the one pin the
+    reference holds for this problem.  The control error is second order in h (8.2e-4 at n = 32, 2.1e-4 at n = 64)."""
+    import scipy.optimize as sopt
+    from femo_amd.fea import utils_hip
+    from femo_amd.fea.mesh import createUnitSquareMesh
+    from femo_amd.fea.utils_hip import errorNorm
+    from tests.test_gpu_operators import make_sim
+    utils_hip.set_context(ctx)
+    err = {}
+    for n in (32, 64):
+        mesh = createUnitSquareMesh(n)
+        sim, fea, f_ex, u_ex = make_sim(mesh, device=False)
+
+        def fun(f):
+            sim['f'] = f
+            sim.run()
+            return 1e5 * float(sim['l2_functional'][0]), 1e5 * np.array(sim.compute_totals('l2_functional', 'f'))
+
+        f0 = 0.086 * np.ones(fea.inputs_dict['f']['shape'])
+        J0 = fun(f0)[0]
+        res = sopt.minimize(fun, f0, jac=True, method="L-BFGS-B", options=dict(maxiter=300, ftol=1e-15, gtol=1e-12))
+        sim['f'] = res.x
+        sim.run()
+        err[n] = (errorNorm(f_ex, fea.inputs_dict['f']['function']), errorNorm(u_ex, fea.states_dict['u']['function']), res.fun, J0)
+    assert err[64][2] < 1e-3 * err[64][3]                          # 23.7 -> 0.0125
+    assert err[64][0] < 3e-4 and err[64][1] < 2e-5
+    assert 3.0 < err[32][0] / err[64][0] < 5.0                     # O(h^2)
