@@ -676,6 +676,11 @@ struct CoarseLevels {
   int emit_top;                        // also e_top = coef_top g_top + I e_{top-1} (global), g_top cleared: the level the
                                        // brick kernel filled, so that no multi-block restriction / prolongation touches it
   int top_in_lds;                      // g_top is copied to LDS at off[top] first (<= 4096 nodes and room for it)
+  // restrict_top: g_top is not read but formed here, g_top = R g_finer (27-point restriction from the level the
+  // brick kernel filled): the launch that did it (k_lattice_restrict, 5.6 us = one launch floor) is folded in
+  const double* finer_g;
+  int finer_n[3];
+  int restrict_top;
 };
 
 __global__ __launch_bounds__(1024) void k_lattice_coarse(CoarseLevels L, int dim, const int32_t* __restrict__ done) {
@@ -698,7 +703,8 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse(CoarseLevels L, int dim
 #pragma unroll
     for (int q = 0; q < TOPR; ++q) {
       const int64_t idx = tid + q * 1024;
-      gt[q] = idx < n_top ? L.g[top][idx] : 0.0;
+      if (L.restrict_top) gt[q] = idx < n_top ? lattice_restrict_node(idx, L.n[top], L.finer_n, dim, L.finer_g) : 0.0;
+      else gt[q] = idx < n_top ? L.g[top][idx] : 0.0;
       ct[q] = (L.emit_top && idx < n_top) ? L.coef[top][idx] : 0.0;
     }
   }
@@ -742,7 +748,7 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse(CoarseLevels L, int dim
       for (int q = 0; q < TOPR; ++q) {
         const int64_t idx = tid + q * 1024;
         if (idx < n_top) {
-          L.g[top][idx] = 0.0;                      // every restriction read of it came from the LDS copy
+          if (!L.restrict_top) L.g[top][idx] = 0.0;  // every restriction read of it came from the LDS copy
           L.e[top][idx] = ct[q] * gt[q] + lattice_interp_node(idx, L.n[top], L.n[top - 1], dim, ec);
         }
       }
@@ -1230,11 +1236,6 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
   const bool fused_cycle = nf >= 2 && T >= 2 && T < FEMO_PC_MAX_LEVELS - 1 && below * 2 * (int64_t)sizeof(double) <= 144 * 1024 &&
                            pc->L[T - 1].nodes <= 4096 && getenv("FEMO_BPX_UNFUSED_LATTICE") == nullptr;
   if (fused_cycle) {
-    {
-      LatticeLevel& C = pc->L[T - 1];
-      const LatticeLevel& Fi = pc->L[T];
-      hipLaunchKernelGGL(k_lattice_restrict, dim3(lat_grid(C.nodes)), dim3(256), 0, st, C.n[0], C.n[1], C.n[2], Fi.n[0], Fi.n[1], Fi.n[2], pc->dim, G(T, par), C.g, done);
-    }
     CoarseLevels CL;
     CL.n_levels = T - 1;                                           // levels 0 .. T-2 in LDS, e_{T-1} emitted
     CL.emit_top = 1;
@@ -1247,6 +1248,14 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
     size_t lds = (size_t)below * 2 * sizeof(double);
     CL.top_in_lds = (CL.nodes[T - 1] <= 4096 && lds + (size_t)CL.nodes[T - 1] * sizeof(double) <= 150 * 1024) ? 1 : 0;
     if (CL.top_in_lds) lds += (size_t)CL.nodes[T - 1] * sizeof(double);
+    CL.restrict_top = CL.top_in_lds;
+    CL.finer_g = G(T, par);
+    for (int k = 0; k < 3; ++k) CL.finer_n[k] = pc->L[T].n[k];
+    if (!CL.restrict_top) {                                     // no room for g_top in LDS: restrict it with a launch of its own
+      LatticeLevel& C = pc->L[T - 1];
+      const LatticeLevel& Fi = pc->L[T];
+      hipLaunchKernelGGL(k_lattice_restrict, dim3(lat_grid(C.nodes)), dim3(256), 0, st, C.n[0], C.n[1], C.n[2], Fi.n[0], Fi.n[1], Fi.n[2], pc->dim, G(T, par), C.g, done);
+    }
     if (lds > 64 * 1024 && !pc->coarse_lds_set) {
       FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_coarse, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       pc->coarse_lds_set = true;
@@ -1300,6 +1309,7 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
       size_t lds = (size_t)coarse_total * 2 * sizeof(double);
       CL.top_in_lds = (CL.nodes[cut] <= 4096 && lds + (size_t)CL.nodes[cut] * sizeof(double) <= 150 * 1024) ? 1 : 0;
       if (CL.top_in_lds) lds += (size_t)CL.nodes[cut] * sizeof(double);
+      CL.restrict_top = 0; CL.finer_g = nullptr; CL.finer_n[0] = CL.finer_n[1] = CL.finer_n[2] = 0;
       if (lds > 64 * 1024 && !pc->coarse_lds_set) {
         FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_coarse, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         pc->coarse_lds_set = true;
