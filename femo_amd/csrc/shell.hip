@@ -27,6 +27,11 @@ struct femo_shell {
   double* d_x = nullptr;
   int32_t *d_conn = nullptr, *d_cedge = nullptr, *d_cols = nullptr, *d_epos = nullptr;
   int64_t* d_rowptr = nullptr;
+  // node-block view of the pattern (dofs 3 b .. 3 b + 2 of a node share their columns, which come in runs of three):
+  // block-row offsets and the first scalar column of every 3 x 3 block; nullptr if the pattern is not of that shape
+  int64_t n_bnode = 0;
+  int64_t* d_brow = nullptr;
+  int32_t* d_bcols = nullptr;
   // CG workspace
   double *d_r = nullptr, *d_p = nullptr, *d_q = nullptr, *d_dinv = nullptr, *d_scal = nullptr, *d_part = nullptr;
   int32_t* d_flag = nullptr;
@@ -34,12 +39,15 @@ struct femo_shell {
   int pc_width = 0, pc_levels = 0;
   int64_t n_lat = 0, pc_nodes = 0;
   std::vector<int64_t> level_off;                       // node offsets of the levels (pc_levels + 1 entries)
-  int32_t *d_ell_idx = nullptr, *d_pt_cols = nullptr, *d_par_cols = nullptr, *d_chi_cols = nullptr;
-  double *d_ell_w = nullptr, *d_pt_vals = nullptr, *d_par_vals = nullptr, *d_chi_vals = nullptr;
+  int32_t *d_ell_idx = nullptr, *d_par_cols = nullptr, *d_chi_cols = nullptr;
+  double *d_ell_w = nullptr, *d_par_vals = nullptr, *d_chi_vals = nullptr;
   double *d_coarse = nullptr, *d_t = nullptr, *d_e = nullptr, *d_z = nullptr;
-  int32_t* d_fin_idx = nullptr;                         // the finest level's eight (unknown, weight) pairs per dof, contiguous
-  double* d_fin_w = nullptr;
-  int64_t *d_pt_rowptr = nullptr, *d_par_rowptr = nullptr, *d_chi_rowptr = nullptr;
+  int32_t* d_fin_idx = nullptr;                         // the finest level's eight (unknown, weight) pairs per POINT (a P2 node's
+  double* d_fin_w = nullptr;                            // three displacements / a vertex's three rotations share them)
+  int64_t* d_ptp_rowptr = nullptr;                      // P_L^T by (finest lattice node, field group): points and weights
+  int32_t* d_ptp_cols = nullptr;
+  double* d_ptp_vals = nullptr;
+  int64_t *d_par_rowptr = nullptr, *d_chi_rowptr = nullptr;
   uint64_t pc_vals_uid = 0, pc_vals_gen = 0, pc_mask_hash = 0;     // what d_coarse was computed for
 };
 
@@ -446,6 +454,64 @@ __global__ __launch_bounds__(SH_BLOCK) void k_csr_spmv(int64_t n, const int64_t*
   }
 }
 
+// The same product over the node-block view of the pattern: the three dofs of a node have the same columns and the
+// columns come in runs of three, so one column index serves nine entries (8.4 instead of 12 bytes per entry) and the
+// three x values of a block are loaded once for its three rows.  The value array is the scalar CSR one, untouched:
+// row 3 b + i of block row b is the run vals[9 k0 + 3 i nb ..), block k at offset 3 (k - k0).  16 lanes per block row
+// (13 blocks for an edge node, ~26 for a vertex node or a rotation).  Imposed dofs: identity rows; x must be zero on
+// the imposed columns (the CG directions are).
+__global__ __launch_bounds__(SH_BLOCK) void k_bcsr3_spmv(int64_t nb, const int64_t* __restrict__ brow, const int32_t* __restrict__ bcols,
+                                                         const double* __restrict__ vals, const uint8_t* __restrict__ fixed,
+                                                         const double* __restrict__ x, double* __restrict__ y, double* __restrict__ partials,
+                                                         const int32_t* __restrict__ done, double* commit_dst = nullptr,
+                                                         const double* commit_src = nullptr) {
+  if (done != nullptr && *done) return;
+  if (commit_dst != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *commit_dst = *commit_src;
+  __shared__ double lds[SH_BLOCK / 64];
+  constexpr int SUB = 16;
+  const int sl = threadIdx.x & (SUB - 1);
+  const int64_t nsub = (int64_t)gridDim.x * (SH_BLOCK / SUB);
+  double dot = 0.0;
+  for (int64_t b = (int64_t)blockIdx.x * (SH_BLOCK / SUB) + (threadIdx.x / SUB); b < nb; b += nsub) {
+    const int64_t k0 = brow[b], k1 = brow[b + 1];
+    const int64_t len = 3 * (k1 - k0);
+    const double* v0 = vals + 9 * k0;
+    const double* v1 = v0 + len;
+    const double* v2 = v1 + len;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int64_t k = k0 + sl; k < k1; k += SUB) {
+      const int32_t c = __builtin_nontemporal_load(bcols + k);
+      const int64_t o = 3 * (k - k0);
+      const double a00 = __builtin_nontemporal_load(v0 + o), a01 = __builtin_nontemporal_load(v0 + o + 1), a02 = __builtin_nontemporal_load(v0 + o + 2);
+      const double a10 = __builtin_nontemporal_load(v1 + o), a11 = __builtin_nontemporal_load(v1 + o + 1), a12 = __builtin_nontemporal_load(v1 + o + 2);
+      const double a20 = __builtin_nontemporal_load(v2 + o), a21 = __builtin_nontemporal_load(v2 + o + 1), a22 = __builtin_nontemporal_load(v2 + o + 2);
+      const double x0 = x[c], x1 = x[c + 1], x2 = x[c + 2];
+      s0 += a00 * x0 + a01 * x1 + a02 * x2;
+      s1 += a10 * x0 + a11 * x1 + a12 * x2;
+      s2 += a20 * x0 + a21 * x1 + a22 * x2;
+    }
+#pragma unroll
+    for (int off = SUB / 2; off > 0; off >>= 1) {
+      s0 += __shfl_xor(s0, off, 64);
+      s1 += __shfl_xor(s1, off, 64);
+      s2 += __shfl_xor(s2, off, 64);
+    }
+    if (sl < 3) {
+      const int64_t row = 3 * b + sl;
+      const double s = sl == 0 ? s0 : (sl == 1 ? s1 : s2);
+      const bool rf = fixed != nullptr && fixed[row];
+      const double xr = x[row];
+      const double yi = rf ? xr : s;
+      y[row] = yi;
+      dot += xr * yi;
+    }
+  }
+  if (partials != nullptr) {
+    const double t = femo_block_sum<SH_BLOCK>(dot, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  }
+}
+
 __global__ void k_csr_diag_inv(int64_t n, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                                const double* __restrict__ vals, const uint8_t* __restrict__ fixed, double* __restrict__ dinv) {
   for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < n; row += (int64_t)gridDim.x * blockDim.x) {
@@ -650,21 +716,33 @@ __global__ __launch_bounds__(1024) void k_lat_coarse_fused(LatLevels Lv, const i
   }
 }
 
-// g = P_L^T r on the finest lattice's unknowns [row0, row1): CSR rows = lattice unknowns, 16 lanes per row
-__global__ __launch_bounds__(SH_BLOCK) void k_pc_restrict(int64_t row0, int64_t row1, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+// g = P_L^T r on the finest lattice's nodes [m0, m1): one row per (node, field group) listing the points (first dof
+// 3 p) that touch the node and their weights, 16 lanes per row, three components at a time
+__global__ __launch_bounds__(SH_BLOCK) void k_pc_restrict(int64_t m0, int64_t m1, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                                                           const double* __restrict__ vals, const double* __restrict__ r, double* __restrict__ g,
                                                           const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
   constexpr int SUB = 16;
   const int sl = threadIdx.x & (SUB - 1);
   const int64_t nsub = (int64_t)gridDim.x * (SH_BLOCK / SUB);
-  for (int64_t row = row0 + (int64_t)blockIdx.x * (SH_BLOCK / SUB) + (threadIdx.x / SUB); row < row1; row += nsub) {
-    double s = 0.0;
+  const int64_t nrow = 2 * (m1 - m0);
+  for (int64_t row = (int64_t)blockIdx.x * (SH_BLOCK / SUB) + (threadIdx.x / SUB); row < nrow; row += nsub) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     const int64_t e1 = rowptr[row + 1];
-    for (int64_t e = rowptr[row] + sl; e < e1; e += SUB) s += vals[e] * r[cols[e]];
+    for (int64_t e = rowptr[row] + sl; e < e1; e += SUB) {
+      const int32_t c = cols[e];
+      const double w = vals[e];
+      s0 += w * r[c];
+      s1 += w * r[c + 1];
+      s2 += w * r[c + 2];
+    }
 #pragma unroll
-    for (int off = SUB / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (sl == 0) g[row] = s;
+    for (int off = SUB / 2; off > 0; off >>= 1) {
+      s0 += __shfl_xor(s0, off, 64);
+      s1 += __shfl_xor(s1, off, 64);
+      s2 += __shfl_xor(s2, off, 64);
+    }
+    if (sl < 3) g[6 * (m0 + (row >> 1)) + 3 * (row & 1) + sl] = sl == 0 ? s0 : (sl == 1 ? s1 : s2);
   }
 }
 
@@ -687,8 +765,9 @@ __global__ void k_lat_level(int64_t n0, int64_t n1, const int64_t* __restrict__ 
   else g[u] = s;
 }
 
-// z = D^-1 r + P_L e_L (8 lanes per row, one finest-level entry each) and the per-block partial of r.z; imposed dofs: z = 0
-__global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong(int64_t n, const int32_t* __restrict__ ell_idx, const double* __restrict__ ell_w,
+// z = D^-1 r + P_L e_L (8 lanes per point, one finest-level entry each, three components) and the per-block partial of
+// r.z; imposed dofs: z = 0
+__global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong(int64_t n_pts, const int32_t* __restrict__ fin_idx, const double* __restrict__ fin_w,
                                                          const uint8_t* __restrict__ fixed, const double* __restrict__ dinv,
                                                          const double* __restrict__ r, const double* __restrict__ t, double* __restrict__ z,
                                                          double* __restrict__ partials, const int32_t* __restrict__ done) {
@@ -698,15 +777,21 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong(int64_t n, const int32_
   const int sl = threadIdx.x & (SUB - 1);
   const int64_t nsub = (int64_t)gridDim.x * (SH_BLOCK / SUB);
   double dot = 0.0;
-  for (int64_t row = (int64_t)blockIdx.x * (SH_BLOCK / SUB) + (threadIdx.x / SUB); row < n; row += nsub) {
-    const bool rf = fixed != nullptr && fixed[row];
-    double s = 0.0;
-    if (!rf) s = ell_w[row * 8 + sl] * t[ell_idx[row * 8 + sl]];     // the finest level's eight entries of the dof
+  for (int64_t p = (int64_t)blockIdx.x * (SH_BLOCK / SUB) + (threadIdx.x / SUB); p < n_pts; p += nsub) {
+    const double w = fin_w[p * 8 + sl];
+    const double* tp = t + fin_idx[p * 8 + sl];
+    double s0 = w * tp[0], s1 = w * tp[1], s2 = w * tp[2];
 #pragma unroll
-    for (int off = SUB / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (sl == 0) {
+    for (int off = SUB / 2; off > 0; off >>= 1) {
+      s0 += __shfl_xor(s0, off, 64);
+      s1 += __shfl_xor(s1, off, 64);
+      s2 += __shfl_xor(s2, off, 64);
+    }
+    if (sl < 3) {
+      const int64_t row = 3 * p + sl;
+      const bool rf = fixed != nullptr && fixed[row];
       const double ri = r[row];
-      const double zi = rf ? 0.0 : dinv[row] * ri + s;
+      const double zi = rf ? 0.0 : dinv[row] * ri + (sl == 0 ? s0 : (sl == 1 ? s1 : s2));
       z[row] = zi;
       dot += ri * zi;
     }
@@ -807,6 +892,33 @@ int femo_shell_create(femo_ctx* ctx, int64_t n_vert, const double* x, int64_t n_
   FEMO_TRY(to_device(&s->d_rowptr, rowptr, s->n_dof + 1, st));
   FEMO_TRY(to_device(&s->d_cols, cols, s->nnz, st));
   FEMO_TRY(to_device(&s->d_epos, elem_pos, n_cell * 729, st));
+  {
+    // node-block view: valid when every node's three rows have the same columns in runs of three (fea/shell.py numbers
+    // the dofs 3 node + component, so the element-coupling pattern always is)
+    const int64_t nbn = s->n_dof / 3;
+    std::vector<int64_t> brow((size_t)nbn + 1, 0);
+    std::vector<int32_t> bcols;
+    bcols.reserve((size_t)(s->nnz / 9));
+    bool ok = s->n_dof % 3 == 0;
+    for (int64_t b = 0; ok && b < nbn; ++b) {
+      const int64_t r0 = rowptr[3 * b], len = rowptr[3 * b + 1] - r0;
+      ok = len % 3 == 0 && rowptr[3 * b + 2] - rowptr[3 * b + 1] == len && rowptr[3 * b + 3] - rowptr[3 * b + 2] == len &&
+           r0 == 9 * brow[(size_t)b];
+      for (int64_t j = 0; ok && j < len; j += 3) {
+        const int32_t c = cols[r0 + j];
+        ok = c % 3 == 0 && cols[r0 + j + 1] == c + 1 && cols[r0 + j + 2] == c + 2 && cols[r0 + len + j] == c &&
+             cols[r0 + 2 * len + j] == c;
+        bcols.push_back(c);
+      }
+      brow[(size_t)b + 1] = brow[(size_t)b] + len / 3;
+    }
+    if (ok) {
+      s->n_bnode = nbn;
+      FEMO_TRY(to_device(&s->d_brow, brow.data(), nbn + 1, st));
+      FEMO_TRY(to_device(&s->d_bcols, bcols.data(), (int64_t)bcols.size(), st));
+      FEMO_HIP_CHECK(hipStreamSynchronize(st));
+    }
+  }
   const int64_t n = s->n_dof;
   FEMO_HIP_CHECK(hipMalloc(&s->d_r, n * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&s->d_p, n * sizeof(double)));
@@ -823,9 +935,10 @@ int femo_shell_create(femo_ctx* ctx, int64_t n_vert, const double* x, int64_t n_
 int femo_shell_destroy(femo_shell* s) {
   if (!s) return 0;
   hipStreamSynchronize(s->ctx->stream);
-  hipFree(s->d_x); hipFree(s->d_conn); hipFree(s->d_cedge); hipFree(s->d_rowptr); hipFree(s->d_cols); hipFree(s->d_epos);
+  hipFree(s->d_x); hipFree(s->d_conn); hipFree(s->d_cedge); hipFree(s->d_rowptr); hipFree(s->d_cols); hipFree(s->d_epos); hipFree(s->d_brow); hipFree(s->d_bcols);
+  hipFree(s->d_ptp_rowptr); hipFree(s->d_ptp_cols); hipFree(s->d_ptp_vals);
   hipFree(s->d_r); hipFree(s->d_p); hipFree(s->d_q); hipFree(s->d_dinv); hipFree(s->d_scal); hipFree(s->d_part); hipFree(s->d_flag);
-  hipFree(s->d_ell_idx); hipFree(s->d_ell_w); hipFree(s->d_pt_rowptr); hipFree(s->d_pt_cols); hipFree(s->d_pt_vals);
+  hipFree(s->d_ell_idx); hipFree(s->d_ell_w);
   hipFree(s->d_par_rowptr); hipFree(s->d_par_cols); hipFree(s->d_par_vals); hipFree(s->d_chi_rowptr); hipFree(s->d_chi_cols); hipFree(s->d_chi_vals);
   hipFree(s->d_coarse); hipFree(s->d_t); hipFree(s->d_e); hipFree(s->d_z); hipFree(s->d_fin_idx); hipFree(s->d_fin_w);
   delete s;
@@ -848,9 +961,6 @@ int femo_shell_pc_create(femo_shell* s, int width, int64_t n_nodes, int n_levels
   const int64_t n_lat = 6 * n_nodes;
   FEMO_TRY(to_device(&s->d_ell_idx, ell_idx, s->n_dof * width, st));
   FEMO_TRY(to_device(&s->d_ell_w, ell_w, s->n_dof * width, st));
-  FEMO_TRY(to_device(&s->d_pt_rowptr, pt_rowptr, n_lat + 1, st));
-  FEMO_TRY(to_device(&s->d_pt_cols, pt_cols, pt_rowptr[n_lat], st));
-  FEMO_TRY(to_device(&s->d_pt_vals, pt_vals, pt_rowptr[n_lat], st));
   FEMO_TRY(to_device(&s->d_par_rowptr, par_rowptr, n_nodes + 1, st));
   FEMO_TRY(to_device(&s->d_par_cols, par_cols, par_rowptr[n_nodes], st));
   FEMO_TRY(to_device(&s->d_par_vals, par_vals, par_rowptr[n_nodes], st));
@@ -858,17 +968,46 @@ int femo_shell_pc_create(femo_shell* s, int width, int64_t n_nodes, int n_levels
   FEMO_TRY(to_device(&s->d_chi_cols, chi_cols, chi_rowptr[n_nodes], st));
   FEMO_TRY(to_device(&s->d_chi_vals, chi_vals, chi_rowptr[n_nodes], st));
   {
-    // the prolongation runs every iteration: its eight entries per dof in arrays of their own (the full ELL rows are
-    // 12 x width bytes apart)
-    std::vector<int32_t> fi((size_t)s->n_dof * 8);
-    std::vector<double> fw((size_t)s->n_dof * 8);
-    for (int64_t i = 0; i < s->n_dof; ++i)
+    // The finest level runs every iteration, in arrays of its own and per POINT (a P2 node with its three displacements,
+    // a vertex with its three rotations: dofs 3 p .. 3 p + 2): the three components share the eight lattice nodes and
+    // weights, so the prolongation reads 8 (index, weight) pairs per point instead of 24, and P_L^T has one row per
+    // (lattice node, field group) listing points instead of six rows listing dofs.
+    const int64_t n_pts = s->n_dof / 3;
+    FEMO_REQUIRE(s->n_dof % 3 == 0, "dofs are not numbered 3 point + component");
+    std::vector<int32_t> fi((size_t)n_pts * 8);
+    std::vector<double> fw((size_t)n_pts * 8);
+    for (int64_t p = 0; p < n_pts; ++p)
       for (int a = 0; a < 8; ++a) {
-        fi[(size_t)i * 8 + a] = ell_idx[i * width + (width - 8) + a];
-        fw[(size_t)i * 8 + a] = ell_w[i * width + (width - 8) + a];
+        const int64_t e0 = (3 * p) * width + (width - 8) + a;
+        fi[(size_t)p * 8 + a] = ell_idx[e0];                      // unknown of component 0; components 1, 2 follow it
+        fw[(size_t)p * 8 + a] = ell_w[e0];
+        for (int k = 1; k < 3; ++k) {
+          const int64_t ek = (3 * p + k) * width + (width - 8) + a;
+          FEMO_REQUIRE(ell_idx[ek] == ell_idx[e0] + k && ell_w[ek] == ell_w[e0], "components of a point do not share their lattice weights");
+        }
       }
-    FEMO_TRY(to_device(&s->d_fin_idx, fi.data(), s->n_dof * 8, st));
-    FEMO_TRY(to_device(&s->d_fin_w, fw.data(), s->n_dof * 8, st));
+    FEMO_TRY(to_device(&s->d_fin_idx, fi.data(), n_pts * 8, st));
+    FEMO_TRY(to_device(&s->d_fin_w, fw.data(), n_pts * 8, st));
+    // rows 6 m + 0 (displacement group) and 6 m + 3 (rotation group) of P^T for the finest level's nodes m
+    const int64_t m0 = level_offsets[n_levels - 1], m1 = level_offsets[n_levels];
+    std::vector<int64_t> rp((size_t)(2 * (m1 - m0) + 1), 0);
+    std::vector<int32_t> pc;
+    std::vector<double> pv;
+    for (int64_t m = m0; m < m1; ++m)
+      for (int g = 0; g < 2; ++g) {
+        const int64_t row = 6 * m + 3 * g;
+        for (int64_t e = pt_rowptr[row]; e < pt_rowptr[row + 1]; ++e) {
+          FEMO_REQUIRE(pt_cols[e] % 3 == 0, "P^T row of component 0 lists another component");
+          pc.push_back(pt_cols[e]);
+          pv.push_back(pt_vals[e]);
+        }
+        for (int k = 1; k < 3; ++k)
+          FEMO_REQUIRE(pt_rowptr[row + k + 1] - pt_rowptr[row + k] == pt_rowptr[row + 1] - pt_rowptr[row], "P^T rows of a field group differ");
+        rp[(size_t)(2 * (m - m0) + g + 1)] = (int64_t)pc.size();
+      }
+    FEMO_TRY(to_device(&s->d_ptp_rowptr, rp.data(), (int64_t)rp.size(), st));
+    FEMO_TRY(to_device(&s->d_ptp_cols, pc.data(), (int64_t)pc.size(), st));
+    FEMO_TRY(to_device(&s->d_ptp_vals, pv.data(), (int64_t)pv.size(), st));
     FEMO_HIP_CHECK(hipStreamSynchronize(st));
   }
   FEMO_HIP_CHECK(hipMalloc(&s->d_coarse, n_lat * sizeof(double)));
@@ -885,9 +1024,9 @@ int femo_shell_pc_create(femo_shell* s, int width, int64_t n_nodes, int n_levels
 static int shell_pc_apply(femo_shell* s, const uint8_t* d_fixed, double* Prz, unsigned gz, const int32_t* done) {
   hipStream_t st = s->ctx->stream;
   const int L = s->pc_levels;
-  const int64_t f0 = 6 * s->level_off[L - 1], f1 = 6 * s->level_off[L];
-  hipLaunchKernelGGL(k_pc_restrict, dim3(std::min<unsigned>(sgrid(f1 - f0, SH_BLOCK / 16), 1 << 16)), dim3(SH_BLOCK), 0, st, f0, f1,
-                     s->d_pt_rowptr, s->d_pt_cols, s->d_pt_vals, s->d_r, s->d_t, done);
+  const int64_t m0 = s->level_off[L - 1], m1 = s->level_off[L];
+  hipLaunchKernelGGL(k_pc_restrict, dim3(std::min<unsigned>(sgrid(2 * (m1 - m0), SH_BLOCK / 16), 1 << 16)), dim3(SH_BLOCK), 0, st, m0, m1,
+                     s->d_ptp_rowptr, s->d_ptp_cols, s->d_ptp_vals, s->d_r, s->d_t, done);
   // levels 0 .. kc (at most 256 nodes each, never the finest: with 4096 the one workgroup took 244 us, with 768 still 71) go through the fused single-workgroup kernel
   int kc = -1;
   while (kc + 1 < L - 1 && kc + 1 < 16 && s->level_off[kc + 2] - s->level_off[kc + 1] <= 256) ++kc;
@@ -908,7 +1047,7 @@ static int shell_pc_apply(femo_shell* s, const uint8_t* d_fixed, double* Prz, un
     hipLaunchKernelGGL(k_lat_level, dim3(sgrid((n1 - n0) * 6, 256)), dim3(256), 0, st, n0, n1, s->d_par_rowptr, s->d_par_cols, s->d_par_vals,
                        s->d_coarse, s->d_t, s->d_e, 1, done);
   }
-  hipLaunchKernelGGL(k_pc_prolong, dim3(gz), dim3(SH_BLOCK), 0, st, s->n_dof, s->d_fin_idx, s->d_fin_w, d_fixed, s->d_dinv, s->d_r, s->d_e,
+  hipLaunchKernelGGL(k_pc_prolong, dim3(gz), dim3(SH_BLOCK), 0, st, s->n_dof / 3, s->d_fin_idx, s->d_fin_w, d_fixed, s->d_dinv, s->d_r, s->d_e,
                      s->d_z, Prz, done);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
@@ -1029,7 +1168,9 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
   uint8_t* d_fixed = nullptr;
   if (fixed_host != nullptr) FEMO_TRY(to_device(&d_fixed, fixed_host, n, st));
   const unsigned gv = std::min<unsigned>(sgrid(n), SH_MAXPART);
-  const unsigned gs = std::min<unsigned>(sgrid(n, SH_BLOCK / 16), SH_MAXPART);
+  // workgroups of the operator product (their per-block partials of p.q are folded by k_scg_xr*): 16 rows, or 16
+  // node blocks of three rows, per workgroup pass
+  const unsigned gs = std::min<unsigned>(s->d_brow != nullptr ? sgrid(s->n_bnode, SH_BLOCK / 16) : sgrid(n, SH_BLOCK / 16), SH_MAXPART);
   double *Ppq = s->d_part, *Prz = s->d_part + SH_MAXPART, *gam = s->d_scal + 4;
   FEMO_HIP_CHECK(hipEventRecord(ctx->ev0, st));
   // right-hand side with lifting (into q); zero initial guess
@@ -1043,7 +1184,7 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
   hipLaunchKernelGGL(k_csr_diag_inv, dim3(gv), dim3(256), 0, st, n, s->d_rowptr, s->d_cols, vals->d, d_fixed, s->d_dinv);
   const bool lattice = opts->pc == 1;
   FEMO_REQUIRE(!lattice || s->pc_width > 0, "opts->pc = 1 needs femo_shell_pc_create");
-  const unsigned gz = std::min<unsigned>(sgrid(n, SH_BLOCK / 8), SH_MAXPART);
+  const unsigned gz = std::min<unsigned>(sgrid(n / 3, SH_BLOCK / 8), SH_MAXPART);     // k_pc_prolong: 8 lanes per point
   if (lattice) {
     // Galerkin diagonals of the current stiffness and Dirichlet set (kept while both stay the same)
     uint64_t mh = 1469598103934665603ull;
@@ -1077,7 +1218,10 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
     const int it_end = std::min(it + batch, max_it);
     for (; it < it_end; ++it) {
       // p is zero on the imposed dofs (r and the initial direction are): no column mask needed
-      hipLaunchKernelGGL(k_csr_spmv, dim3(gs), dim3(SH_BLOCK), 0, st, n, s->d_rowptr, s->d_cols, vals->d, d_fixed, 0, s->d_p, s->d_q, Ppq, s->d_flag, s->d_scal, gam);
+      if (s->d_brow != nullptr)
+        hipLaunchKernelGGL(k_bcsr3_spmv, dim3(gs), dim3(SH_BLOCK), 0, st, s->n_bnode, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_p, s->d_q, Ppq, s->d_flag, s->d_scal, gam);
+      else
+        hipLaunchKernelGGL(k_csr_spmv, dim3(gs), dim3(SH_BLOCK), 0, st, n, s->d_rowptr, s->d_cols, vals->d, d_fixed, 0, s->d_p, s->d_q, Ppq, s->d_flag, s->d_scal, gam);
       if (lattice) {
         hipLaunchKernelGGL(k_scg_xr_plain, dim3(gv), dim3(SH_BLOCK), 0, st, n, (int)gs, Ppq, s->d_scal, s->d_p, s->d_q, x->d, s->d_r, s->d_flag);
         FEMO_TRY(shell_pc_apply(s, d_fixed, Prz, gz, s->d_flag));
