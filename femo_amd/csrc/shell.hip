@@ -17,6 +17,7 @@
 //   * thickness sensitivity: (dR/dh)^T lambda evaluated element by element from the strains of w and lambda.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "femo_internal.h"
@@ -460,6 +461,7 @@ __global__ __launch_bounds__(SH_BLOCK) void k_csr_spmv(int64_t n, const int64_t*
 // row 3 b + i of block row b is the run vals[9 k0 + 3 i nb ..), block k at offset 3 (k - k0).  16 lanes per block row
 // (13 blocks for an edge node, ~26 for a vertex node or a rotation).  Imposed dofs: identity rows; x must be zero on
 // the imposed columns (the CG directions are).
+template <int SUB>
 __global__ __launch_bounds__(SH_BLOCK) void k_bcsr3_spmv(int64_t nb, const int64_t* __restrict__ brow, const int32_t* __restrict__ bcols,
                                                          const double* __restrict__ vals, const uint8_t* __restrict__ fixed,
                                                          const double* __restrict__ x, double* __restrict__ y, double* __restrict__ partials,
@@ -468,23 +470,39 @@ __global__ __launch_bounds__(SH_BLOCK) void k_bcsr3_spmv(int64_t nb, const int64
   if (done != nullptr && *done) return;
   if (commit_dst != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *commit_dst = *commit_src;
   __shared__ double lds[SH_BLOCK / 64];
-  constexpr int SUB = 16;
   const int sl = threadIdx.x & (SUB - 1);
   const int64_t nsub = (int64_t)gridDim.x * (SH_BLOCK / SUB);
   double dot = 0.0;
-  for (int64_t b = (int64_t)blockIdx.x * (SH_BLOCK / SUB) + (threadIdx.x / SUB); b < nb; b += nsub) {
-    const int64_t k0 = brow[b], k1 = brow[b + 1];
+  // Software pipeline over the group's block rows: the offsets of row b + 2 nsub and the first column index of row
+  // b + nsub are requested before row b is computed, so a row costs one memory latency (values and x together) instead
+  // of three in a chain (offsets -> column -> x).
+  int64_t b = (int64_t)blockIdx.x * (SH_BLOCK / SUB) + (threadIdx.x / SUB);
+  int64_t k0 = 0, k1 = 0, n0 = 0, n1 = 0;
+  int32_t c = 0;
+  if (b < nb) {
+    k0 = brow[b]; k1 = brow[b + 1];
+    if (k0 + sl < k1) c = bcols[k0 + sl];
+  }
+  if (b + nsub < nb) { n0 = brow[b + nsub]; n1 = brow[b + nsub + 1]; }
+  for (; b < nb; b += nsub) {
+    int64_t m0 = 0, m1 = 0;
+    int32_t cn = 0;
+    if (b + 2 * nsub < nb) { m0 = brow[b + 2 * nsub]; m1 = brow[b + 2 * nsub + 1]; }
+    if (n0 + sl < n1) cn = bcols[n0 + sl];
     const int64_t len = 3 * (k1 - k0);
     const double* v0 = vals + 9 * k0;
     const double* v1 = v0 + len;
     const double* v2 = v1 + len;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     for (int64_t k = k0 + sl; k < k1; k += SUB) {
-      const int32_t c = __builtin_nontemporal_load(bcols + k);
+      if (k >= k0 + SUB) c = bcols[k];
       const int64_t o = 3 * (k - k0);
-      const double a00 = __builtin_nontemporal_load(v0 + o), a01 = __builtin_nontemporal_load(v0 + o + 1), a02 = __builtin_nontemporal_load(v0 + o + 2);
-      const double a10 = __builtin_nontemporal_load(v1 + o), a11 = __builtin_nontemporal_load(v1 + o + 1), a12 = __builtin_nontemporal_load(v1 + o + 2);
-      const double a20 = __builtin_nontemporal_load(v2 + o), a21 = __builtin_nontemporal_load(v2 + o + 1), a22 = __builtin_nontemporal_load(v2 + o + 2);
+      // plain loads: a lane reads 8 bytes at a stride of 24, so a cache line serves three instructions -- with
+      // nontemporal loads the product took 135 us instead of 103 (988 k dofs).  Also slower: streaming the rows in
+      // storage order (lane = entry: 109-121 us), 8 or 4 lanes per block row
+      const double a00 = v0[o], a01 = v0[o + 1], a02 = v0[o + 2];
+      const double a10 = v1[o], a11 = v1[o + 1], a12 = v1[o + 2];
+      const double a20 = v2[o], a21 = v2[o + 1], a22 = v2[o + 2];
       const double x0 = x[c], x1 = x[c + 1], x2 = x[c + 2];
       s0 += a00 * x0 + a01 * x1 + a02 * x2;
       s1 += a10 * x0 + a11 * x1 + a12 * x2;
@@ -505,6 +523,8 @@ __global__ __launch_bounds__(SH_BLOCK) void k_bcsr3_spmv(int64_t nb, const int64
       y[row] = yi;
       dot += xr * yi;
     }
+    k0 = n0; k1 = n1; c = cn;
+    n0 = m0; n1 = m1;
   }
   if (partials != nullptr) {
     const double t = femo_block_sum<SH_BLOCK>(dot, lds);
@@ -1072,8 +1092,15 @@ int femo_shell_matvec(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_
   FEMO_REQUIRE(s && vals && x && y, "null argument");
   FEMO_REQUIRE(vals->n >= s->nnz && x->n >= s->n_dof && y->n >= s->n_dof && x->d != y->d, "vector size mismatch in shell_matvec");
   femo_vec_touch(y);
-  hipLaunchKernelGGL(k_csr_spmv, dim3(sgrid(s->n_dof, SH_BLOCK / 16)), dim3(SH_BLOCK), 0, s->ctx->stream, s->n_dof, s->d_rowptr, s->d_cols,
-                     vals->d, fixed_dev_or_null, 1, x->d, y->d, (double*)nullptr, (const int32_t*)nullptr);
+  hipStream_t st = s->ctx->stream;
+  if (s->d_brow != nullptr && fixed_dev_or_null == nullptr) {
+    hipLaunchKernelGGL(k_bcsr3_spmv<16>, dim3(std::min<unsigned>(sgrid(s->n_bnode, SH_BLOCK / 16), SH_MAXPART)), dim3(SH_BLOCK), 0, st, s->n_bnode,
+                       s->d_brow, s->d_bcols, vals->d, (const uint8_t*)nullptr, x->d, y->d, (double*)nullptr, (const int32_t*)nullptr,
+                       (double*)nullptr, (const double*)nullptr);
+  } else {
+    hipLaunchKernelGGL(k_csr_spmv, dim3(sgrid(s->n_dof, SH_BLOCK / 16)), dim3(SH_BLOCK), 0, st, s->n_dof, s->d_rowptr, s->d_cols,
+                       vals->d, fixed_dev_or_null, 1, x->d, y->d, (double*)nullptr, (const int32_t*)nullptr);
+  }
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -1219,7 +1246,7 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
     for (; it < it_end; ++it) {
       // p is zero on the imposed dofs (r and the initial direction are): no column mask needed
       if (s->d_brow != nullptr)
-        hipLaunchKernelGGL(k_bcsr3_spmv, dim3(gs), dim3(SH_BLOCK), 0, st, s->n_bnode, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_p, s->d_q, Ppq, s->d_flag, s->d_scal, gam);
+        hipLaunchKernelGGL(k_bcsr3_spmv<16>, dim3(gs), dim3(SH_BLOCK), 0, st, s->n_bnode, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_p, s->d_q, Ppq, s->d_flag, s->d_scal, gam);
       else
         hipLaunchKernelGGL(k_csr_spmv, dim3(gs), dim3(SH_BLOCK), 0, st, n, s->d_rowptr, s->d_cols, vals->d, d_fixed, 0, s->d_p, s->d_q, Ppq, s->d_flag, s->d_scal, gam);
       if (lattice) {
