@@ -38,7 +38,7 @@ prob = ShellProblem(pts, conn, 4.32e8, 0.0, fixed_dofs=fixed, ctx=ctx, pc=PC)
 setup_s = time.perf_counter() - t0
 t0 = time.perf_counter()
 if PC == "lattice":
-    prob.dev.enable_lattice_pc()
+    prob.dev.enable_lattice_pc(int(os.environ["FEMO_SHELL_FINEST"]) if "FEMO_SHELL_FINEST" in os.environ else None)
 pc_setup_s = time.perf_counter() - t0
 prob.set_thickness(0.25)
 prob.set_load([0.0, 0.0, -90.0])
