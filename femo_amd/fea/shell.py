@@ -178,10 +178,48 @@ def lattice_pc(space: ShellSpace, finest: Optional[int] = None):
     Tc.sort_indices()
     i64, i32 = np.int64, np.int32
     return dict(width=width, n_lat=int(n_lat), n_nodes=int(n_nodes), levels=levels, level_offsets=np.asarray(offsets, dtype=i64),
+                level_nodes=level_nodes, n_unode=int(space.n_unode),
                 ell_idx=np.ascontiguousarray(ell_idx), ell_w=ell_w,
                 pt_rowptr=Pt.indptr.astype(i64), pt_cols=Pt.indices.astype(i32), pt_vals=np.ascontiguousarray(Pt.data),
                 par_rowptr=Tp.indptr.astype(i64), par_cols=Tp.indices.astype(i32), par_vals=np.ascontiguousarray(Tp.data),
                 chi_rowptr=Tc.indptr.astype(i64), chi_cols=Tc.indices.astype(i32), chi_vals=np.ascontiguousarray(Tc.data))
+
+
+def coarse_solve_plan(L: dict, max_unknowns: int = 3200, chunk: int = 256):
+    """Arrays of `femo_shell_pc_coarse` for the lattice levels of ``lattice_pc``: the coarse-solve level is the finest
+    level (never the finest of the hierarchy) with at most ``max_unknowns`` unknowns; its points are grouped by (coarse
+    cell, field group) and cut into items of at most ``chunk`` points.  None if no level qualifies."""
+    levels, off = L["levels"], L["level_offsets"]
+    c = -1
+    for l in range(len(levels) - 1):
+        if 6 * (off[l + 1] - off[l]) <= max_unknowns:
+            c = l
+    if c < 0:
+        return None
+    m, g = levels[c], L["level_nodes"][c]
+    xyz = np.stack([g % (m + 1), (g // (m + 1)) % (m + 1), g // ((m + 1) ** 2)], axis=1).astype(np.int32)
+    node0 = L["ell_idx"][0::3, 8 * c].astype(np.int64) // 6 - off[c]          # corner (0, 0, 0) of every point's cell
+    n_pts = node0.size
+    key = 2 * node0 + (np.arange(n_pts) >= L["n_unode"])
+    order = np.argsort(key, kind="stable")
+    skey = key[order]
+    starts = np.flatnonzero(np.r_[True, skey[1:] != skey[:-1]])
+    ends = np.r_[starts[1:], skey.size]
+    cuts = np.concatenate([np.arange(a, b, chunk) for a, b in zip(starts, ends)])
+    item_ptr = np.r_[cuts, skey.size].astype(np.int64)
+    base = xyz[node0[order[cuts]]].astype(np.int64)                           # (n_items, 3)
+    nbr = np.full((cuts.size, 64), -1, dtype=np.int32)
+    for lz in range(4):
+        for ly in range(4):
+            for lx in range(4):
+                q = base + np.array([lx - 1, ly - 1, lz - 1])
+                ok = np.all((q >= 0) & (q <= m), axis=1)
+                gid = (q[:, 2] * (m + 1) + q[:, 1]) * (m + 1) + q[:, 0]
+                pos = np.minimum(np.searchsorted(g, gid), g.size - 1)
+                ok &= g[pos] == gid
+                nbr[ok, lz * 16 + ly * 4 + lx] = pos[ok]
+    return dict(level=int(c), node_xyz=np.ascontiguousarray(xyz), item_ptr=item_ptr,
+                item_pts=np.ascontiguousarray(order, dtype=np.int32), item_nbr=np.ascontiguousarray(nbr))
 
 
 class DeviceShell:
@@ -199,8 +237,13 @@ class DeviceShell:
         assert self.n_dof == space.n_dof and self.nnz == cols.size
         self.pc_levels = None
 
-    def enable_lattice_pc(self, finest: Optional[int] = None) -> None:
-        """Build and upload the lattice preconditioner once per mesh (used by ``solve(pc='lattice')``)."""
+    def enable_lattice_pc(self, finest: Optional[int] = None, coarse_unknowns: Optional[int] = None) -> None:
+        """Build and upload the lattice preconditioner once per mesh (used by ``solve(pc='lattice')``).
+        ``coarse_unknowns``: size limit of the level that gets an exact (dense) coarse solve, 0 = none; default 3200
+        (``FEMO_SHELL_COARSE`` overrides)."""
+        if coarse_unknowns is None:
+            import os
+            coarse_unknowns = int(os.environ.get("FEMO_SHELL_COARSE", "3200"))
         if self.pc_levels is not None:
             return
         L = lattice_pc(self.space, finest)
@@ -210,6 +253,23 @@ class DeviceShell:
                                             p(L["par_rowptr"]), p(L["par_cols"]), p(L["par_vals"]),
                                             p(L["chi_rowptr"]), p(L["chi_cols"]), p(L["chi_vals"])))
         self.pc_levels = L["levels"]
+        self.coarse_level = None
+        if coarse_unknowns > 0:
+            plan = coarse_solve_plan(L, coarse_unknowns)
+            if plan is not None:
+                check(self.lib.femo_shell_pc_coarse(self.handle, plan["level"], p(plan["node_xyz"]), plan["item_ptr"].size - 1,
+                                                    p(plan["item_ptr"]), p(plan["item_pts"]), p(plan["item_nbr"])))
+                self.coarse_level = plan["level"]
+
+    def coarse_matrix(self, vals: Vec, fixed: Optional[np.ndarray] = None, inverse: bool = False) -> np.ndarray:
+        """The dense Galerkin operator of the coarse-solve level (or its inverse) for ``vals``: for tests."""
+        n = C.c_int64(0)
+        mask = np.ascontiguousarray(fixed, dtype=np.uint8) if fixed is not None else None
+        mp = C.c_void_p(mask.ctypes.data) if mask is not None else None
+        check(self.lib.femo_shell_pc_coarse_matrix(self.handle, vals.handle, mp, int(inverse), None, C.byref(n)))
+        out = np.empty((n.value, n.value))
+        check(self.lib.femo_shell_pc_coarse_matrix(self.handle, vals.handle, mp, int(inverse), C.c_void_p(out.ctypes.data), C.byref(n)))
+        return out
 
     def __del__(self):
         # destroy only while the owning context is alive (interpreter shutdown tears objects down in arbitrary order)
@@ -270,7 +330,7 @@ class DeviceShell:
             assert mask.size == self.n_dof
         check(self.lib.femo_shell_solve(self.handle, vals.handle, C.c_void_p(mask.ctypes.data) if mask is not None else None,
                                         xfix.handle if xfix is not None else None, b.handle, x.handle, C.byref(opts), C.byref(info)))
-        if info.converged != 1:
+        if info.converged not in (1, 2):           # 2: stalled at the attainable accuracy, below 1e-9 relative (shell.hip)
             raise E.FemoError(f"shell CG did not converge: {info.iterations} iterations, residual {info.residual_norm:.3e} "
                               f"(rhs {info.rhs_norm:.3e})")
         return info

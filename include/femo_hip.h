@@ -382,9 +382,28 @@ int femo_shell_pc_create(femo_shell* s, int width, int64_t n_nodes, int n_levels
                          const int64_t* pt_rowptr, const int32_t* pt_cols, const double* pt_vals,
                          const int64_t* par_rowptr, const int32_t* par_cols, const double* par_vals,
                          const int64_t* chi_rowptr, const int32_t* chi_cols, const double* chi_vals);
+/* Exact coarse solve for the lattice preconditioner (optional, after femo_shell_pc_create): on lattice level `level`
+ * (not the finest; 6 x nodes <= 8192 unknowns) the Galerkin operator P^T K P is formed as a dense matrix on the device,
+ * factorised with rocSOLVER (potrf + trtri, loaded at run time) whenever the stiffness or the Dirichlet set change, and
+ * A^-1 = L^-T L^-1 applied in place
+ * of the diagonal levels 0 .. level: M^-1 = D^-1 + sum_{l > level} P_l C_l P_l^T + P_c (P_c^T K P_c)^-1 P_c^T.  What
+ * the reference's direct solver (MUMPS, utils_dolfinx.py:476-512) does for the whole matrix is done here for the
+ * ~3000 unknowns that carry the smooth, nearly inextensional modes a diagonal cannot see.
+ *   node_xyz   int32[3 x nodes]: lattice coordinates of the level's nodes (level-local numbering)
+ *   item_*     work items of the Galerkin kernel: points (first dof / 3) of one coarse cell and one field group, at most
+ *              a chunk each (item_ptr n_items + 1, item_pts), and the level-local numbers of the 4 x 4 x 4 nodes around
+ *              the cell (item_nbr 64 per item, x fastest, -1 where the surface does not touch the lattice)            */
+int femo_shell_pc_coarse(femo_shell* s, int level, const int32_t* node_xyz, int64_t n_items, const int64_t* item_ptr,
+                         const int32_t* item_pts, const int32_t* item_nbr);
+/* For tests: the dense coarse operator (inverse = 0) or the factors of its inverse (1: L^-T above, L^-1 below the
+ * diagonal) for `vals` and the mask, row-major n x n into `out` (host; NULL: only *n_out).                           */
+int femo_shell_pc_coarse_matrix(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_host, int inverse, double* out,
+                                int64_t* n_out);
 /* K x = b with x = xfix on the dofs flagged in fixed_host (n_dof bytes; NULL: none; xfix NULL: zero values).
  * PCG, sqrt(r.M^-1 r) <= max(rtol sqrt(r0.M^-1 r0), atol), opts->pc: 0 Jacobi, 1 lattice; K is symmetric, so the
- * adjoint solve (fea_dolfinx.py:208-222) is the same call.  The reference uses MUMPS (utils_dolfinx.py:476-512).   */
+ * adjoint solve (fea_dolfinx.py:208-222) is the same call.  The reference uses MUMPS (utils_dolfinx.py:476-512).
+ * info->converged: 1 tolerance met, 2 stalled at the attainable accuracy (residual below 1e-9 of the initial one in the
+ * preconditioner's norm and no progress over 8 batches of check_every iterations), 0 max_it, -1 breakdown (NaN).      */
 int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_host, const femo_vec* xfix, const femo_vec* b,
                      femo_vec* x, const femo_solver_opts* opts, femo_solve_info* info);
 

@@ -75,7 +75,7 @@ def test_forward_and_adjoint_solves(roof):
     fixed = np.nonzero(prob.fixed)[0]
     wref = so.solve(Kref, Fref, fixed)
     w = prob.solve()
-    assert prob.last_info.converged == 1 and prob.last_info.iterations > 100
+    assert prob.last_info.converged in (1, 2) and prob.last_info.iterations > 100
     assert rel(w, wref) <= 1e-8
     assert np.all(w[fixed] == 0.0)
     c = np.random.default_rng(2).standard_normal(V0.n_dof)
@@ -253,6 +253,50 @@ def test_lattice_preconditioner(ctx):
     assert res[(16, "lattice")][0] < 0.4 * res[(16, "jacobi")][0]           # 980 against 3171
     assert res[(16, "lattice")][0] < 1.4 * res[(8, "lattice")][0]           # 753 -> 980; Jacobi: 1151 -> 3171
     assert res[(16, "jacobi")][0] > 2.0 * res[(8, "jacobi")][0]
+
+
+def test_coarse_solve(ctx):
+    """Exact coarse solve of the lattice preconditioner: the dense Galerkin operator formed on the device is
+    P_c^T K_ff P_c of the oracle's stiffness, its inverse is one, the solution is unchanged and the iteration count
+    drops by more than half (983 -> 357 on the 16 x 16 roof with the NumPy restatement)."""
+    import scipy.sparse as sp
+    from femo_amd.fea.shell import ShellProblem, ShellSpace, coarse_solve_plan, lattice_pc
+    n = 16
+    pts, conn = so.scordelis_lo_mesh(n, n)
+    V0 = so.ShellSpace(pts, conn)
+    fixed = roof_fixed(V0)
+    res = {}
+    for coarse in (0, 3200):
+        prob = ShellProblem(pts, conn, E_ROOF, NU_ROOF, fixed_dofs=fixed, ctx=ctx, pc="lattice")
+        prob.dev.enable_lattice_pc(coarse_unknowns=coarse)
+        prob.set_thickness(H_ROOF)
+        prob.set_load([0.0, 0.0, FZ])
+        w = prob.solve(rtol=1e-10)
+        res[coarse] = (prob.last_info.iterations, w)
+    assert rel(res[3200][1], res[0][1]) <= 1e-7
+    assert res[3200][0] < 0.5 * res[0][0]
+    # the matrix itself
+    L = lattice_pc(ShellSpace(pts, conn))
+    plan = coarse_solve_plan(L)
+    c, off = plan["level"], L["level_offsets"]
+    assert prob.dev.coarse_level == c
+    K = so.assemble(V0, so.element_stiffness(V0, np.full(V0.n_vert, H_ROOF), E_ROOF, NU_ROOF)).tocsr()
+    free = np.ones(V0.n_dof, dtype=bool); free[fixed] = False
+    D = sp.diags(free.astype(float))
+    rows = np.repeat(np.arange(V0.n_dof), 8)
+    P = sp.csr_matrix((L["ell_w"][:, 8 * c:8 * c + 8].ravel(), (rows, L["ell_idx"][:, 8 * c:8 * c + 8].ravel())),
+                      shape=(V0.n_dof, L["n_lat"]))[:, 6 * off[c]:6 * off[c + 1]]
+    A_ref = (P.T @ (D @ K @ D) @ P).toarray()
+    mask = (~free).astype(np.uint8)
+    A = prob.dev.coarse_matrix(prob.vals, mask)
+    assert A.shape == A_ref.shape
+    assert np.abs(A - A_ref).max() <= 1e-11 * np.abs(A_ref).max()
+    W = prob.dev.coarse_matrix(prob.vals, mask, inverse=True)          # L^-T above, L^-1 below the diagonal
+    d = np.diag(A_ref).copy()
+    A_fix = A_ref + np.diag(np.where(d > 0, 1e-13 * d, 1.0))
+    assert np.array_equal(np.triu(W), np.tril(W).T)
+    Li = np.tril(W)
+    assert np.abs(Li @ A_fix @ Li.T - np.eye(A.shape[0])).max() <= 1e-6
 
 
 def test_irregular_surface_mesh(ctx):
