@@ -690,10 +690,12 @@ __global__ __launch_bounds__(SH_BLOCK) void k_csr_lift(int64_t n, const int64_t*
 __global__ __launch_bounds__(SH_BLOCK) void k_pc_galerkin_diag(int64_t n, int width, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                                                                const double* __restrict__ vals, const uint8_t* __restrict__ fixed,
                                                                const int32_t* __restrict__ ell_idx, const double* __restrict__ ell_w,
-                                                               double* __restrict__ diag) {
+                                                               double* __restrict__ diag, int first_slot) {
+  // slots first_slot .. width - 1 of every row (the levels below belong to the coarse solve when there is one)
+  const int wact = width - first_slot;
   const int64_t t = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x;
-  const int64_t i = t / width;
-  const int a = (int)(t % width);
+  const int64_t i = t / wact;
+  const int a = first_slot + (int)(t % wact);
   if (i >= n || (fixed != nullptr && fixed[i])) return;
   const double wi = ell_w[i * width + a];
   if (wi == 0.0) return;
@@ -1636,11 +1638,13 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
     if (fixed_host != nullptr)
       for (int64_t i = 0; i < n; ++i) mh = (mh ^ fixed_host[i]) * 1099511628211ull;
     if (s->pc_vals_uid != vals->uid || s->pc_vals_gen != vals->gen || s->pc_mask_hash != mh || vals->uid == 0) {
-      FEMO_HIP_CHECK(hipMemsetAsync(s->d_coarse, 0, s->n_lat * sizeof(double), st));
-      hipLaunchKernelGGL(k_pc_galerkin_diag, dim3(sgrid(n * s->pc_width)), dim3(SH_BLOCK), 0, st, n, s->pc_width, s->d_rowptr, s->d_cols,
-                         vals->d, d_fixed, s->d_ell_idx, s->d_ell_w, s->d_coarse);
-      hipLaunchKernelGGL(k_pc_invert, dim3(sgrid(s->n_lat)), dim3(256), 0, st, s->n_lat, s->d_coarse);
       FEMO_TRY(shell_pc_coarse_setup(s, vals, d_fixed));
+      // Galerkin diagonals of the levels the coarse solve does not replace
+      const int first_slot = s->cs_ready ? 8 * (s->cs_level + 1) : 0;
+      FEMO_HIP_CHECK(hipMemsetAsync(s->d_coarse, 0, s->n_lat * sizeof(double), st));
+      hipLaunchKernelGGL(k_pc_galerkin_diag, dim3(sgrid(n * (s->pc_width - first_slot))), dim3(SH_BLOCK), 0, st, n, s->pc_width, s->d_rowptr, s->d_cols,
+                         vals->d, d_fixed, s->d_ell_idx, s->d_ell_w, s->d_coarse, first_slot);
+      hipLaunchKernelGGL(k_pc_invert, dim3(sgrid(s->n_lat)), dim3(256), 0, st, s->n_lat, s->d_coarse);
       s->pc_vals_uid = vals->uid; s->pc_vals_gen = vals->gen; s->pc_mask_hash = mh;
     }
     FEMO_TRY(shell_pc_apply(s, d_fixed, Prz, gz, nullptr));

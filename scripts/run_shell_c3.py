@@ -59,7 +59,7 @@ tip = int(np.argmin(np.abs(vx[:, 0]) + np.abs(vx[:, 1] - vx[:, 1].max())))
 print(json.dumps({
     "workload": f"Scordelis-Lo roof {n} x {n} x 2 triangles, CG2^3 x CG1^3 Reissner-Mindlin shell: assemble K(h), solve K w = F, "
                 "compliance, adjoint solve, dJ/dh (thickness sensitivity)",
-    "preconditioner": PC, "pc_levels": prob.dev.pc_levels, "pc_setup_s": pc_setup_s,
+    "preconditioner": PC, "pc_levels": prob.dev.pc_levels, "pc_coarse_solve_level": getattr(prob.dev, "coarse_level", None), "pc_setup_s": pc_setup_s,
     "n_dof": int(S.n_dof), "n_cell": int(S.n_cell), "nnz": int(prob.dev.nnz), "setup_s": setup_s,
     "assemble_ms": t_asm * 1e3, "forward_solve_s": t_fwd, "forward_cg_iterations": int(it_fwd), "forward_solve_device_ms": ms_fwd,
     "adjoint_s": t_adj, "adjoint_cg_iterations": int(it_adj), "adjoint_solve_device_ms": ms_adj,
