@@ -169,7 +169,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.femo_abi_version() != 3:
+    if lib.femo_abi_version() != 4:
         raise FemoError("libfemo_hip.so ABI version mismatch")
     _lib = lib
     return lib

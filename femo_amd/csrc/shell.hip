@@ -58,7 +58,7 @@ struct femo_shell {
   int cs_level = -1;
   int64_t cs_n = 0, cs_N = 0, cs_items = 0;            // unknowns of the level (6 x nodes), padded to 64s, items of the Galerkin kernel
   bool cs_ready = false;                               // d_cs_A holds the factors of the inverse for the current stiffness and mask
-  int32_t *d_cs_xyz = nullptr, *d_cs_pts = nullptr, *d_cs_nbr = nullptr, *d_cs_info = nullptr;
+  int32_t *d_cs_xyz = nullptr, *d_cs_pts = nullptr, *d_cs_nbr = nullptr, *d_cs_info = nullptr, *d_cs_pcell = nullptr;
   int64_t* d_cs_ptr = nullptr;
   double *d_cs_A = nullptr, *d_cs_tmp = nullptr;       // L^-T above / L^-1 below the diagonal (row-major, N x N); L^-1 g
   double* d_cs_dinv = nullptr;                         // inverses of the diagonal tiles of L
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_galerkin_diag(int64_t n, int wi
 __global__ __launch_bounds__(256) void k_pc_coarse_galerkin(int c, int width, int64_t off_c, int64_t n_c, int64_t n_unode,
                                                             const int64_t* __restrict__ item_ptr, const int32_t* __restrict__ item_pts,
                                                             const int32_t* __restrict__ item_nbr, const int32_t* __restrict__ node_xyz,
-                                                            const int64_t* __restrict__ brow, const int32_t* __restrict__ bcols,
+                                                            const int32_t* __restrict__ pcell, const int64_t* __restrict__ brow, const int32_t* __restrict__ bcols,
                                                             const double* __restrict__ vals, const uint8_t* __restrict__ fixed,
                                                             const int32_t* __restrict__ ell_idx, const double* __restrict__ ell_w,
                                                             double* __restrict__ A, int32_t* __restrict__ info) {
@@ -752,12 +752,15 @@ __global__ __launch_bounds__(256) void k_pc_coarse_galerkin(int c, int width, in
     const bool fi0 = fixed != nullptr && fixed[3 * i], fi1 = fixed != nullptr && fixed[3 * i + 1], fi2 = fixed != nullptr && fixed[3 * i + 2];
     const int64_t k0 = brow[i], k1 = brow[i + 1], len = 3 * (k1 - k0);
     const double *v0 = vals + 9 * k0, *v1 = v0 + len, *v2 = v1 + len;
+    // column and coarse cell (pcell: lattice coordinates of the cell's corner, 10 bits each) one block ahead
+    int32_t cj_n = bcols[k0];
+    int32_t pk_n = pcell[cj_n / 3];
     for (int64_t k = k0; k < k1; ++k) {
-      const int32_t cj = bcols[k];
+      const int32_t cj = cj_n, pk = pk_n;
+      if (k + 1 < k1) { cj_n = bcols[k + 1]; pk_n = pcell[cj_n / 3]; }
       const int gj = cj >= 3 * n_unode ? 1 : 0;
       const int64_t ej = (int64_t)cj * width + 8 * c;
-      const int32_t ndj = ell_idx[ej] / 6 - (int32_t)off_c;
-      const int ox = node_xyz[3 * ndj] - bx + 1, oy = node_xyz[3 * ndj + 1] - by + 1, oz = node_xyz[3 * ndj + 2] - bz + 1;
+      const int ox = (pk & 1023) - bx + 1, oy = ((pk >> 10) & 1023) - by + 1, oz = (pk >> 20) - bz + 1;
       if ((unsigned)ox > 2u || (unsigned)oy > 2u || (unsigned)oz > 2u) { far = 1; continue; }
       const int64_t o = 3 * (k - k0);
       const bool fj0 = fixed != nullptr && fixed[cj], fj1 = fixed != nullptr && fixed[cj + 1], fj2 = fixed != nullptr && fixed[cj + 2];
@@ -800,6 +803,15 @@ __global__ __launch_bounds__(256) void k_pc_coarse_galerkin(int c, int width, in
       for (int f = 0; f < 6; ++f)
         if (acc[s][fa][f] != 0.0) atomicAdd(&A[(6 * na + 3 * gi + fa) * n_c + 6 * (int64_t)nb + f], acc[s][fa][f]);
   }
+}
+
+// packed lattice coordinates of the level-c cell of every point (its first ELL node is the cell's corner)
+__global__ void k_pc_coarse_cells(int64_t n_pts, int c, int width, int64_t off_c, const int32_t* __restrict__ ell_idx,
+                                  const int32_t* __restrict__ node_xyz, int32_t* __restrict__ pcell) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pts) return;
+  const int32_t nd = ell_idx[(3 * p) * width + 8 * c] / 6 - (int32_t)off_c;
+  pcell[p] = node_xyz[3 * nd] | (node_xyz[3 * nd + 1] << 10) | (node_xyz[3 * nd + 2] << 20);
 }
 
 // ---- dense factorisation of the coarse operator (N = n padded to a multiple of 64, row-major, leading dimension N) ----
@@ -980,19 +992,25 @@ __global__ void k_pc_coarse_mirror(int64_t N, double* __restrict__ A) {
   if (cidx < N && cidx / DT > r / DT) A[cidx * N + r] = A[r * N + cidx];
 }
 
-// one wave per row of the triangular factor: lower = 1: y = L^-1 x (entries 0 .. r of row r); 0: y = L^-T x (r .. n)
+// one workgroup per row of the triangular factor: lower = 1: y = L^-1 x (entries 0 .. r of row r); 0: y = L^-T x (r .. n).
+// (A wave per row took 25 us per pass at n = 3060: the long rows are 24 dependent rounds of loads for one wave.)
 __global__ __launch_bounds__(SH_BLOCK) void k_pc_coarse_apply(int64_t n, int64_t N, int lower, const double* __restrict__ W, const double* __restrict__ x,
                                                               double* __restrict__ y, const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
-  const int lane = threadIdx.x & 63;
-  const int64_t r = (int64_t)blockIdx.x * (SH_BLOCK / 64) + (threadIdx.x >> 6);
-  if (r >= n) return;
-  const double* row = W + r * N;
-  const int64_t k0 = lower ? 0 : r, k1 = lower ? r + 1 : n;
-  double s = 0.0;
-  for (int64_t k = k0 + lane; k < k1; k += 64) s += row[k] * x[k];
-  s = femo_wave_sum(s);
-  if (lane == 0) y[r] = s;
+  __shared__ double lds[SH_BLOCK / 64];
+  // rows are paired long with short (r and n - 1 - r take n + 1 entries together): even work per workgroup
+  const int64_t pair = blockIdx.x;
+  for (int h = 0; h < 2; ++h) {
+    const int64_t r = h == 0 ? pair : n - 1 - pair;
+    if (h == 1 && r <= pair) break;
+    const double* row = W + r * N;
+    const int64_t k0 = lower ? 0 : r, k1 = lower ? r + 1 : n;
+    double s = 0.0;
+    for (int64_t k = k0 + threadIdx.x; k < k1; k += SH_BLOCK) s += row[k] * x[k];
+    __syncthreads();
+    const double t = femo_block_sum<SH_BLOCK>(s, lds);
+    if (threadIdx.x == 0) y[r] = t;
+  }
 }
 
 __global__ void k_pc_invert(int64_t n, double* __restrict__ d) {
@@ -1255,7 +1273,7 @@ int femo_shell_destroy(femo_shell* s) {
   hipStreamSynchronize(s->ctx->stream);
   hipFree(s->d_x); hipFree(s->d_conn); hipFree(s->d_cedge); hipFree(s->d_rowptr); hipFree(s->d_cols); hipFree(s->d_epos); hipFree(s->d_brow); hipFree(s->d_bcols);
   hipFree(s->d_ptp_rowptr); hipFree(s->d_ptp_cols); hipFree(s->d_ptp_vals);
-  hipFree(s->d_cs_xyz); hipFree(s->d_cs_ptr); hipFree(s->d_cs_pts); hipFree(s->d_cs_nbr); hipFree(s->d_cs_A); hipFree(s->d_cs_tmp); hipFree(s->d_cs_dinv); hipFree(s->d_cs_info);
+  hipFree(s->d_cs_xyz); hipFree(s->d_cs_ptr); hipFree(s->d_cs_pts); hipFree(s->d_cs_nbr); hipFree(s->d_cs_A); hipFree(s->d_cs_tmp); hipFree(s->d_cs_dinv); hipFree(s->d_cs_info); hipFree(s->d_cs_pcell);
   hipFree(s->d_r); hipFree(s->d_p); hipFree(s->d_q); hipFree(s->d_dinv); hipFree(s->d_scal); hipFree(s->d_part); hipFree(s->d_flag);
   hipFree(s->d_ell_idx); hipFree(s->d_ell_w);
   hipFree(s->d_par_rowptr); hipFree(s->d_par_cols); hipFree(s->d_par_vals); hipFree(s->d_chi_rowptr); hipFree(s->d_chi_cols); hipFree(s->d_chi_vals);
@@ -1354,7 +1372,7 @@ static int shell_pc_coarse_setup(femo_shell* s, const femo_vec* vals, const uint
   FEMO_HIP_CHECK(hipMemsetAsync(s->d_cs_A, 0, N * N * sizeof(double), st));
   FEMO_HIP_CHECK(hipMemsetAsync(s->d_cs_info, 0, 4 * sizeof(int32_t), st));
   hipLaunchKernelGGL(k_pc_coarse_galerkin, dim3((unsigned)s->cs_items), dim3(256), 0, st, s->cs_level, s->pc_width, s->level_off[s->cs_level], N,
-                     s->n_unode, s->d_cs_ptr, s->d_cs_pts, s->d_cs_nbr, s->d_cs_xyz, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_ell_idx,
+                     s->n_unode, s->d_cs_ptr, s->d_cs_pts, s->d_cs_nbr, s->d_cs_xyz, s->d_cs_pcell, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_ell_idx,
                      s->d_ell_w, s->d_cs_A, s->d_cs_info);
   hipLaunchKernelGGL(k_pc_coarse_fix_diag, dim3(sgrid(N, 256)), dim3(256), 0, st, N, s->d_cs_A);
   FEMO_HIP_CHECK(hipGetLastError());
@@ -1400,9 +1418,10 @@ static int shell_pc_apply(femo_shell* s, const uint8_t* d_fixed, double* Prz, un
       hipLaunchKernelGGL(k_lat_level, dim3(sgrid((n1 - n0) * 6, 256)), dim3(256), 0, st, n0, n1, s->d_chi_rowptr, s->d_chi_cols, s->d_chi_vals,
                          s->d_coarse, s->d_t, s->d_e, 0, done);
     }
-    hipLaunchKernelGGL(k_pc_coarse_apply, dim3(sgrid(s->cs_n, SH_BLOCK / 64)), dim3(SH_BLOCK), 0, st, s->cs_n, s->cs_N, 1, s->d_cs_A,
+    const unsigned gp = (unsigned)((s->cs_n + 1) / 2);
+    hipLaunchKernelGGL(k_pc_coarse_apply, dim3(gp), dim3(SH_BLOCK), 0, st, s->cs_n, s->cs_N, 1, s->d_cs_A,
                        s->d_t + 6 * s->level_off[cs], s->d_cs_tmp, done);
-    hipLaunchKernelGGL(k_pc_coarse_apply, dim3(sgrid(s->cs_n, SH_BLOCK / 64)), dim3(SH_BLOCK), 0, st, s->cs_n, s->cs_N, 0, s->d_cs_A, s->d_cs_tmp,
+    hipLaunchKernelGGL(k_pc_coarse_apply, dim3(gp), dim3(SH_BLOCK), 0, st, s->cs_n, s->cs_N, 0, s->d_cs_A, s->d_cs_tmp,
                        s->d_e + 6 * s->level_off[cs], done);
     for (int l = cs + 1; l < L; ++l) {
       const int64_t n0 = s->level_off[l], n1 = s->level_off[l + 1];
@@ -1457,6 +1476,11 @@ int femo_shell_pc_coarse(femo_shell* s, int level, const int32_t* node_xyz, int6
   FEMO_HIP_CHECK(hipMalloc(&s->d_cs_tmp, N * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&s->d_cs_dinv, N * DT * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&s->d_cs_info, 4 * sizeof(int32_t)));
+  FEMO_REQUIRE(s->level_off[level + 1] - s->level_off[level] > 0 && (1 << 10) > (1 << (level + 1)), "lattice too fine for 10-bit coordinates");
+  FEMO_HIP_CHECK(hipMalloc(&s->d_cs_pcell, (s->n_dof / 3) * sizeof(int32_t)));
+  hipLaunchKernelGGL(k_pc_coarse_cells, dim3(sgrid(s->n_dof / 3, 256)), dim3(256), 0, st, s->n_dof / 3, level, s->pc_width, s->level_off[level],
+                     s->d_ell_idx, s->d_cs_xyz, s->d_cs_pcell);
+  FEMO_HIP_CHECK(hipGetLastError());
   FEMO_HIP_CHECK(hipStreamSynchronize(st));
   s->cs_level = level; s->cs_n = n; s->cs_N = N; s->cs_items = n_items;
   s->pc_vals_uid = 0; s->pc_vals_gen = 0;                 // next solve recomputes the preconditioner's numbers
@@ -1481,7 +1505,7 @@ int femo_shell_pc_coarse_matrix(femo_shell* s, const femo_vec* vals, const uint8
     FEMO_HIP_CHECK(hipMemsetAsync(s->d_cs_A, 0, N * N * sizeof(double), st));
     FEMO_HIP_CHECK(hipMemsetAsync(s->d_cs_info, 0, 4 * sizeof(int32_t), st));
     hipLaunchKernelGGL(k_pc_coarse_galerkin, dim3((unsigned)s->cs_items), dim3(256), 0, st, s->cs_level, s->pc_width, s->level_off[s->cs_level], N,
-                       s->n_unode, s->d_cs_ptr, s->d_cs_pts, s->d_cs_nbr, s->d_cs_xyz, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_ell_idx,
+                       s->n_unode, s->d_cs_ptr, s->d_cs_pts, s->d_cs_nbr, s->d_cs_xyz, s->d_cs_pcell, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_ell_idx,
                        s->d_ell_w, s->d_cs_A, s->d_cs_info);
     FEMO_HIP_CHECK(hipGetLastError());
     s->cs_ready = false;
