@@ -716,28 +716,39 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_galerkin_diag(int64_t n, int wi
 }
 
 // Dense Galerkin operator of one coarse lattice level c: A[a, b] = sum_{i, j free} P[i, a] K[i, j] P[j, b], 6 n_c x 6 n_c.
-// One workgroup per item = the points (<= a chunk) of one coarse cell and one field group (displacements of P2 nodes /
+// One workgroup per item = points (256 by default) of one coarse cell and one field group (displacements of P2 nodes /
 // rotations of vertices): they share the cell's eight nodes a, and the eight nodes of any j they couple to lie in the
 // 4 x 4 x 4 node neighbourhood of the cell (an element is smaller than a coarse cell).  Thread t keeps the 3 x 6 sums
 // of node a = t % 8 against the neighbourhood nodes t / 8 and t / 8 + 32 in registers over the whole item -- the sum
 // over the ~1e4 points of a cell never leaves the workgroup -- and adds them to the dense matrix once (item_nbr: the
 // neighbourhood's level-local node numbers, -1 where the surface does not touch the lattice).
-__global__ __launch_bounds__(256) void k_pc_coarse_galerkin(int c, int width, int64_t off_c, int64_t n_c, int64_t n_unode,
+// The item's 3 x 3 blocks are staged through LDS 256 at a time, one block per thread (values with the Dirichlet mask
+// applied, the column's eight weights, its cell offset), then every thread walks the staged blocks: the first version
+// had all threads follow the same block through global memory, one exposed latency per block (27 ms at 1.97 M dofs).
+constexpr int CG_MAXPTS = 256;
+__global__ __launch_bounds__(256) void k_pc_coarse_galerkin(int c, int width, int64_t off_c, int64_t lda, int64_t n_unode,
                                                             const int64_t* __restrict__ item_ptr, const int32_t* __restrict__ item_pts,
                                                             const int32_t* __restrict__ item_nbr, const int32_t* __restrict__ node_xyz,
-                                                            const int32_t* __restrict__ pcell, const int64_t* __restrict__ brow, const int32_t* __restrict__ bcols,
-                                                            const double* __restrict__ vals, const uint8_t* __restrict__ fixed,
-                                                            const int32_t* __restrict__ ell_idx, const double* __restrict__ ell_w,
-                                                            double* __restrict__ A, int32_t* __restrict__ info) {
+                                                            const int32_t* __restrict__ pcell, const int64_t* __restrict__ brow,
+                                                            const int32_t* __restrict__ bcols, const double* __restrict__ vals,
+                                                            const uint8_t* __restrict__ fixed, const int32_t* __restrict__ ell_idx,
+                                                            const double* __restrict__ ell_w, double* __restrict__ A, int32_t* __restrict__ info) {
+  __shared__ int32_t s_scan[CG_MAXPTS + 1];              // blocks before point q of the item
+  __shared__ int32_t s_k0[CG_MAXPTS];                    // first block of the point's block row
+  __shared__ int32_t s_fi[CG_MAXPTS];                    // Dirichlet bits of the point's three dofs
+  __shared__ double s_wpt[CG_MAXPTS][8];                 // the point's weights on the cell's eight nodes
+  __shared__ double s_val[256][9];
+  __shared__ double s_wb[256][8];
+  __shared__ int32_t s_meta[256];                        // ox | oy << 2 | oz << 4 | gj << 6 | q << 8, or -1
   const int64_t item = blockIdx.x;
   const int t = threadIdx.x, a = t & 7, blq = t >> 3;
   const int lx0 = blq & 3, ly0 = (blq >> 2) & 3, lz0 = blq >> 4;
-  const int64_t p0 = item_ptr[item], p1 = item_ptr[item + 1];
-  const int32_t pfirst = item_pts[p0];
+  const int64_t pbeg = item_ptr[item], pend = item_ptr[item + 1];
+  const int32_t pfirst = item_pts[pbeg];
   const int gi = pfirst >= n_unode ? 1 : 0;
   const int64_t e0 = (int64_t)(3 * pfirst) * width + 8 * c;
-  const int32_t nd0 = ell_idx[e0] / 6 - (int32_t)off_c;
-  const int bx = node_xyz[3 * nd0], by = node_xyz[3 * nd0 + 1], bz = node_xyz[3 * nd0 + 2];
+  const int32_t pk0 = pcell[pfirst];
+  const int bx = pk0 & 1023, by = (pk0 >> 10) & 1023, bz = pk0 >> 20;
   double acc[2][3][6];
 #pragma unroll
   for (int s = 0; s < 2; ++s)
@@ -746,50 +757,88 @@ __global__ __launch_bounds__(256) void k_pc_coarse_galerkin(int c, int width, in
 #pragma unroll
       for (int f = 0; f < 6; ++f) acc[s][fa][f] = 0.0;
   int far = 0;
-  for (int64_t q = p0; q < p1; ++q) {
-    const int32_t i = item_pts[q];
-    const double wa = ell_w[(int64_t)(3 * i) * width + 8 * c + a];
-    const bool fi0 = fixed != nullptr && fixed[3 * i], fi1 = fixed != nullptr && fixed[3 * i + 1], fi2 = fixed != nullptr && fixed[3 * i + 2];
-    const int64_t k0 = brow[i], k1 = brow[i + 1], len = 3 * (k1 - k0);
-    const double *v0 = vals + 9 * k0, *v1 = v0 + len, *v2 = v1 + len;
-    // column and coarse cell (pcell: lattice coordinates of the cell's corner, 10 bits each) one block ahead
-    int32_t cj_n = bcols[k0];
-    int32_t pk_n = pcell[cj_n / 3];
-    for (int64_t k = k0; k < k1; ++k) {
-      const int32_t cj = cj_n, pk = pk_n;
-      if (k + 1 < k1) { cj_n = bcols[k + 1]; pk_n = pcell[cj_n / 3]; }
-      const int gj = cj >= 3 * n_unode ? 1 : 0;
-      const int64_t ej = (int64_t)cj * width + 8 * c;
+  // the item's points 256 at a time, one flush of the register sums per item.  Measured at 1.97 M dofs: 17-20 ms for
+  // items of 64 .. 256 points (10 k .. 2.8 k workgroups), 24 with 512, 29 with 2048 (608 workgroups): neither the
+  // flush atomics nor the global latency of the first version (all threads following one block: 27 ms) is the limit;
+  // the walk over the staged blocks is (one in eight (thread, block) pairs does arithmetic)
+  for (int64_t p0 = pbeg; p0 < pend; p0 += CG_MAXPTS) {
+  const int npts = (int)min((int64_t)CG_MAXPTS, pend - p0);
+  __syncthreads();
+  if (t < npts) {
+    const int32_t i = item_pts[p0 + t];
+    const int64_t k0 = brow[i];
+    s_k0[t] = (int32_t)k0;
+    s_scan[t + 1] = (int32_t)(brow[i + 1] - k0);
+    s_fi[t] = fixed == nullptr ? 0 : (fixed[3 * i] ? 1 : 0) | (fixed[3 * i + 1] ? 2 : 0) | (fixed[3 * i + 2] ? 4 : 0);
+  }
+  for (int idx = t; idx < npts * 8; idx += 256) {
+    const int32_t i = item_pts[p0 + (idx >> 3)];
+    s_wpt[idx >> 3][idx & 7] = ell_w[(int64_t)(3 * i) * width + 8 * c + (idx & 7)];
+  }
+  __syncthreads();
+  if (t == 0) {
+    int32_t run = 0;
+    s_scan[0] = 0;
+    for (int q = 0; q < npts; ++q) { run += s_scan[q + 1]; s_scan[q + 1] = run; }
+  }
+  __syncthreads();
+  const int B = s_scan[npts];
+  for (int base = 0; base < B; base += 256) {
+    const int f = base + t;
+    if (f < B) {
+      int lo = 0, hi = npts - 1;                           // largest q with s_scan[q] <= f
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (s_scan[mid] <= f) lo = mid; else hi = mid - 1;
+      }
+      const int q = lo, lk = f - s_scan[q];
+      const int64_t k0 = s_k0[q];
+      const int64_t len = 3 * (int64_t)(s_scan[q + 1] - s_scan[q]);
+      const int32_t cj = bcols[k0 + lk];
+      const int32_t pk = pcell[cj / 3];
       const int ox = (pk & 1023) - bx + 1, oy = ((pk >> 10) & 1023) - by + 1, oz = (pk >> 20) - bz + 1;
-      if ((unsigned)ox > 2u || (unsigned)oy > 2u || (unsigned)oz > 2u) { far = 1; continue; }
-      const int64_t o = 3 * (k - k0);
-      const bool fj0 = fixed != nullptr && fixed[cj], fj1 = fixed != nullptr && fixed[cj + 1], fj2 = fixed != nullptr && fixed[cj + 2];
-      double m[3][3];
-      m[0][0] = v0[o]; m[0][1] = v0[o + 1]; m[0][2] = v0[o + 2];
-      m[1][0] = v1[o]; m[1][1] = v1[o + 1]; m[1][2] = v1[o + 2];
-      m[2][0] = v2[o]; m[2][1] = v2[o + 1]; m[2][2] = v2[o + 2];
-      if (fi0) m[0][0] = m[0][1] = m[0][2] = 0.0;
-      if (fi1) m[1][0] = m[1][1] = m[1][2] = 0.0;
-      if (fi2) m[2][0] = m[2][1] = m[2][2] = 0.0;
-      if (fj0) m[0][0] = m[1][0] = m[2][0] = 0.0;
-      if (fj1) m[0][1] = m[1][1] = m[2][1] = 0.0;
-      if (fj2) m[0][2] = m[1][2] = m[2][2] = 0.0;
-      const int dx = lx0 - ox, dy = ly0 - oy;
+      if ((unsigned)ox > 2u || (unsigned)oy > 2u || (unsigned)oz > 2u) {
+        far = 1;
+        s_meta[t] = -1;
+      } else {
+        s_meta[t] = ox | (oy << 2) | (oz << 4) | ((cj >= 3 * n_unode ? 1 : 0) << 6) | (q << 8);
+        const double* v = vals + 9 * k0 + 3 * lk;
+        const int fi = s_fi[q];
+        const int fj = fixed == nullptr ? 0 : (fixed[cj] ? 1 : 0) | (fixed[cj + 1] ? 2 : 0) | (fixed[cj + 2] ? 4 : 0);
+#pragma unroll
+        for (int fa = 0; fa < 3; ++fa)
+#pragma unroll
+          for (int fb = 0; fb < 3; ++fb) s_val[t][3 * fa + fb] = ((fi >> fa) & 1) || ((fj >> fb) & 1) ? 0.0 : v[fa * len + fb];
+        const double* wj = ell_w + (int64_t)cj * width + 8 * c;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) s_wb[t][b] = wj[b];
+      }
+    }
+    __syncthreads();
+    const int cnt = min(256, B - base);
+    for (int e = 0; e < cnt; ++e) {
+      const int32_t m = s_meta[e];
+      if (m < 0) continue;
+      const int dx = lx0 - (m & 3), dy = ly0 - ((m >> 2) & 3);
       if ((unsigned)dx > 1u || (unsigned)dy > 1u) continue;
+      const int oz = (m >> 4) & 3, gj = (m >> 6) & 1, q = m >> 8;
+      const double wa = s_wpt[q][a];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int dz = lz0 + 2 * s - oz;
         if ((unsigned)dz > 1u) continue;
-        const double ww = wa * ell_w[ej + dx + 2 * dy + 4 * dz];
+        const double ww = wa * s_wb[e][dx + 2 * dy + 4 * dz];
 #pragma unroll
         for (int fa = 0; fa < 3; ++fa)
 #pragma unroll
           for (int fb = 0; fb < 3; ++fb) {
-            if (gj) acc[s][fa][3 + fb] += ww * m[fa][fb];
-            else acc[s][fa][fb] += ww * m[fa][fb];
+            if (gj) acc[s][fa][3 + fb] += ww * s_val[e][3 * fa + fb];
+            else acc[s][fa][fb] += ww * s_val[e][3 * fa + fb];
           }
       }
     }
+    __syncthreads();
+  }
   }
   if (far && info != nullptr) atomicOr(&info[1], 1);
   const int64_t na = ell_idx[e0 + a] / 6 - off_c;
@@ -801,7 +850,7 @@ __global__ __launch_bounds__(256) void k_pc_coarse_galerkin(int c, int width, in
     for (int fa = 0; fa < 3; ++fa)
 #pragma unroll
       for (int f = 0; f < 6; ++f)
-        if (acc[s][fa][f] != 0.0) atomicAdd(&A[(6 * na + 3 * gi + fa) * n_c + 6 * (int64_t)nb + f], acc[s][fa][f]);
+        if (acc[s][fa][f] != 0.0) atomicAdd(&A[(6 * na + 3 * gi + fa) * lda + 6 * (int64_t)nb + f], acc[s][fa][f]);
   }
 }
 
@@ -1467,6 +1516,7 @@ int femo_shell_pc_coarse(femo_shell* s, int level, const int32_t* node_xyz, int6
   const int64_t nodes = s->level_off[level + 1] - s->level_off[level];
   const int64_t n = 6 * nodes;
   FEMO_REQUIRE(n <= 8192, "coarse-solve level too large for a dense inverse");
+  for (int64_t it = 0; it < n_items; ++it) FEMO_REQUIRE(item_ptr[it + 1] > item_ptr[it], "empty Galerkin item");
   FEMO_TRY(to_device(&s->d_cs_xyz, node_xyz, 3 * nodes, st));
   FEMO_TRY(to_device(&s->d_cs_ptr, item_ptr, n_items + 1, st));
   FEMO_TRY(to_device(&s->d_cs_pts, item_pts, item_ptr[n_items], st));

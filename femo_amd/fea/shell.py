@@ -189,6 +189,8 @@ def coarse_solve_plan(L: dict, max_unknowns: int = 3200, chunk: int = 256):
     """Arrays of `femo_shell_pc_coarse` for the lattice levels of ``lattice_pc``: the coarse-solve level is the finest
     level (never the finest of the hierarchy) with at most ``max_unknowns`` unknowns; its points are grouped by (coarse
     cell, field group) and cut into items of at most ``chunk`` points.  None if no level qualifies."""
+    import os
+    chunk = int(os.environ.get("FEMO_SHELL_CG_CHUNK", chunk))
     levels, off = L["levels"], L["level_offsets"]
     c = -1
     for l in range(len(levels) - 1):

@@ -390,8 +390,8 @@ int femo_shell_pc_create(femo_shell* s, int width, int64_t n_nodes, int n_levels
  * the reference's direct solver (MUMPS, utils_dolfinx.py:476-512) does for the whole matrix is done here for the
  * ~3000 unknowns that carry the smooth, nearly inextensional modes a diagonal cannot see.
  *   node_xyz   int32[3 x nodes]: lattice coordinates of the level's nodes (level-local numbering)
- *   item_*     work items of the Galerkin kernel: points (first dof / 3) of one coarse cell and one field group, at most
- *              a chunk each (item_ptr n_items + 1, item_pts), and the level-local numbers of the 4 x 4 x 4 nodes around
+ *   item_*     work items of the Galerkin kernel: points (first dof / 3) of one coarse cell and one field group, any
+ *              number each, 256 by default (item_ptr n_items + 1, item_pts), and the level-local numbers of the 4 x 4 x 4 nodes around
  *              the cell (item_nbr 64 per item, x fastest, -1 where the surface does not touch the lattice)            */
 int femo_shell_pc_coarse(femo_shell* s, int level, const int32_t* node_xyz, int64_t n_items, const int64_t* item_ptr,
                          const int32_t* item_pts, const int32_t* item_nbr);
