@@ -996,9 +996,10 @@ __global__ __launch_bounds__(256) void k_chol_diag(int64_t N, int kb, double* __
     if (threadIdx.x == 0) a[p][p] = sd;
     else if (threadIdx.x > p && threadIdx.x < DT) a[threadIdx.x][p] /= sd;
     __syncthreads();
-    for (int idx = threadIdx.x; idx < DT * DT; idx += 256) {
-      const int r = idx / DT, c = idx % DT;
-      if (c > p && r >= c) a[r][c] -= a[r][p] * a[c][p];
+    const int m = DT - 1 - p;                              // trailing block (p, DT) x (p, DT), lower part
+    for (int idx = threadIdx.x; idx < m * m; idx += 256) {
+      const int r = p + 1 + idx / m, c = p + 1 + idx % m;
+      if (r >= c) a[r][c] -= a[r][p] * a[c][p];
     }
     __syncthreads();
   }
