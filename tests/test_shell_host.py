@@ -1,0 +1,57 @@
+"""Host side of the shell's lattice preconditioner (femo_amd/fea/shell.py): the nested lattices and the plan of the
+exact coarse solve (`femo_shell_pc_coarse`) -- no GPU."""
+import numpy as np
+import scipy.sparse as sp
+
+from femo_amd.fea.shell import ShellSpace, coarse_solve_plan, lattice_pc
+from oracle import shell_oracle as so
+
+
+def test_lattice_levels_are_nested_partitions_of_unity():
+    pts, conn = so.scordelis_lo_mesh(8, 8)
+    S = ShellSpace(pts, conn)
+    L = lattice_pc(S)
+    assert L["levels"] == [2, 4, 8] and L["width"] == 24
+    w = L["ell_w"].reshape(S.n_dof, len(L["levels"]), 8)
+    assert np.allclose(w.sum(axis=2), 1.0) and w.min() >= 0.0
+    # P_l = P_{l+1} T_l: the coarser level's interpolation is the finer one's composed with the node transfer
+    off = L["level_offsets"]
+    Tp = sp.csr_matrix((L["par_vals"], L["par_cols"], L["par_rowptr"]), shape=(L["n_nodes"], L["n_nodes"]))
+    rows = np.repeat(np.arange(S.n_dof), 8)
+    for l in range(len(L["levels"]) - 1):
+        P = [sp.csr_matrix((L["ell_w"][:, 8 * k:8 * k + 8].ravel(), (rows, L["ell_idx"][:, 8 * k:8 * k + 8].ravel() // 6)),
+                           shape=(S.n_dof, L["n_nodes"])) for k in (l, l + 1)]
+        assert abs(P[0] - P[1] @ Tp).max() < 1e-14
+
+
+def test_coarse_solve_plan():
+    pts, conn = so.scordelis_lo_mesh(16, 16)
+    S = ShellSpace(pts, conn)
+    L = lattice_pc(S)
+    plan = coarse_solve_plan(L, chunk=64)
+    c, off = plan["level"], L["level_offsets"]
+    assert L["levels"][c] == 8 and 6 * (off[c + 1] - off[c]) <= 3200          # never the finest level (16)
+    assert coarse_solve_plan(L, max_unknowns=10) is None
+    n_pts = S.n_dof // 3
+    ptr, ipts, nbr, xyz = plan["item_ptr"], plan["item_pts"], plan["item_nbr"], plan["node_xyz"]
+    assert np.array_equal(np.sort(ipts), np.arange(n_pts))                    # every point in exactly one item
+    assert np.all(np.diff(ptr) > 0) and np.diff(ptr).max() <= 64
+    node = L["ell_idx"][0::3, 8 * c:8 * c + 8].astype(np.int64) // 6 - off[c]   # (n_pts, 8) level-local nodes of a point
+    rowptr, cols, _ = S.pattern()
+    for it in range(ptr.size - 1):
+        p = ipts[ptr[it]:ptr[it + 1]]
+        assert np.all(node[p, 0] == node[p[0], 0])                           # one coarse cell ...
+        assert np.all((p >= S.n_unode) == (p[0] >= S.n_unode))               # ... and one field group per item
+        base = xyz[node[p[0], 0]]
+        # corner k of the cell sits at local (1 + k & 1, 1 + (k >> 1) & 1, 1 + (k >> 2) & 1) of the 4 x 4 x 4 table
+        for k in range(8):
+            loc = (1 + (k & 1)) + 4 * (1 + ((k >> 1) & 1)) + 16 * (1 + ((k >> 2) & 1))
+            assert nbr[it, loc] == node[p[0], k]
+        # every point any of the item's points couples to has its cell within one cell of the item's, and the
+        # table holds its nodes where the kernel will look for them
+        j = np.unique(np.concatenate([cols[rowptr[3 * i]:rowptr[3 * i + 1]:3] // 3 for i in p[:8]]))
+        o = xyz[node[j, 0]] - base + 1
+        assert o.min() >= 0 and o.max() <= 2
+        for k in range(8):
+            loc = (o[:, 0] + (k & 1)) + 4 * (o[:, 1] + ((k >> 1) & 1)) + 16 * (o[:, 2] + ((k >> 2) & 1))
+            assert np.array_equal(nbr[it, loc], node[j, k])
