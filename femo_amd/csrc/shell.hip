@@ -54,6 +54,8 @@ struct femo_shell {
   double *d_coarse = nullptr, *d_t = nullptr, *d_e = nullptr, *d_z = nullptr;
   double* d_cblk = nullptr;                             // 6 x 6 inverse Galerkin blocks of the nodes above the coarse-solve level
   bool blk_ready = false;
+  double* d_dinv3 = nullptr;                            // 3 x 3 inverse diagonal blocks of the points (finest-level smoother)
+  bool dinv3_ready = false;
   int32_t* d_fin_idx = nullptr;                         // the finest level's eight (unknown, weight) pairs per POINT (a P2 node's
   double* d_fin_w = nullptr;                            // three displacements / a vertex's three rotations share them)
   int64_t* d_ptp_rowptr = nullptr;                      // P_L^T by (finest lattice node, field group): points and weights
@@ -1300,6 +1302,46 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_galerkin_blocks(int64_t n_pts, 
   }
 }
 
+// inverse of the 3 x 3 diagonal block of every point (imposed dofs: unit row and column), the smoother of the finest
+// level in place of 1 / diag: it sees the coupling of a node's three displacement (rotation) components
+__global__ void k_pt_block_inv(int64_t n_pts, const int64_t* __restrict__ brow, const int32_t* __restrict__ bcols,
+                               const double* __restrict__ vals, const uint8_t* __restrict__ fixed, double* __restrict__ dinv3) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pts) return;
+  const int64_t k0 = brow[p], k1 = brow[p + 1], len = 3 * (k1 - k0);
+  double a[3][3] = {{1.0, 0.0, 0.0}, {0.0, 1.0, 0.0}, {0.0, 0.0, 1.0}};
+  for (int64_t k = k0; k < k1; ++k)
+    if (bcols[k] == 3 * p) {
+      const double* v = vals + 9 * k0 + 3 * (k - k0);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a[i][j] = v[i * len + j];
+      break;
+    }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if ((fixed != nullptr && fixed[3 * p + i]) || !(a[i][i] > 0.0)) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { a[i][j] = 0.0; a[j][i] = 0.0; }
+      a[i][i] = 1.0;
+    }
+  // symmetric 3 x 3 inverse by cofactors
+  const double s01 = 0.5 * (a[0][1] + a[1][0]), s02 = 0.5 * (a[0][2] + a[2][0]), s12 = 0.5 * (a[1][2] + a[2][1]);
+  const double c00 = a[1][1] * a[2][2] - s12 * s12, c01 = s02 * s12 - s01 * a[2][2], c02 = s01 * s12 - s02 * a[1][1];
+  const double c11 = a[0][0] * a[2][2] - s02 * s02, c12 = s01 * s02 - a[0][0] * s12, c22 = a[0][0] * a[1][1] - s01 * s01;
+  const double det = a[0][0] * c00 + s01 * c01 + s02 * c02;
+  double* B = dinv3 + 9 * p;
+  if (det > 0.0 && c00 > 0.0 && c22 > 0.0) {
+    const double id = 1.0 / det;
+    B[0] = c00 * id; B[1] = c01 * id; B[2] = c02 * id;
+    B[3] = c01 * id; B[4] = c11 * id; B[5] = c12 * id;
+    B[6] = c02 * id; B[7] = c12 * id; B[8] = c22 * id;
+  } else {                                                 // not positive definite in floating point: plain Jacobi for this point
+    B[0] = 1.0 / a[0][0]; B[1] = 0.0; B[2] = 0.0; B[3] = 0.0; B[4] = 1.0 / a[1][1]; B[5] = 0.0; B[6] = 0.0; B[7] = 0.0; B[8] = 1.0 / a[2][2];
+  }
+}
+
 // in-place inverse of every node's 6 x 6 block (symmetric positive definite on the fields that have free dofs; a field
 // without any gets a zero row and column): Gauss-Jordan without pivoting on the symmetrised block
 __global__ void k_pc_invert_blocks(int64_t node0, int64_t node1, double* __restrict__ blk) {
@@ -1347,7 +1389,8 @@ __global__ void k_pc_invert_blocks(int64_t node0, int64_t node1, double* __restr
 __global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong(int64_t n_pts, const int32_t* __restrict__ fin_idx, const double* __restrict__ fin_w,
                                                          const uint8_t* __restrict__ fixed, const double* __restrict__ dinv,
                                                          const double* __restrict__ r, const double* __restrict__ t, double* __restrict__ z,
-                                                         double* __restrict__ partials, const int32_t* __restrict__ done) {
+                                                         double* __restrict__ partials, const int32_t* __restrict__ done,
+                                                         const double* __restrict__ dinv3 = nullptr) {
   if (done != nullptr && *done) return;
   __shared__ double lds[SH_BLOCK / 64];
   constexpr int SUB = 8;
@@ -1368,7 +1411,14 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong(int64_t n_pts, const in
       const int64_t row = 3 * p + sl;
       const bool rf = fixed != nullptr && fixed[row];
       const double ri = r[row];
-      const double zi = rf ? 0.0 : dinv[row] * ri + (sl == 0 ? s0 : (sl == 1 ? s1 : s2));
+      double sm;                                           // the smoother: point-block (3 x 3) or plain Jacobi
+      if (dinv3 != nullptr) {
+        const double* B = dinv3 + 9 * p + 3 * sl;
+        sm = B[0] * r[3 * p] + B[1] * r[3 * p + 1] + B[2] * r[3 * p + 2];
+      } else {
+        sm = dinv[row] * ri;
+      }
+      const double zi = rf ? 0.0 : sm + (sl == 0 ? s0 : (sl == 1 ? s1 : s2));
       z[row] = zi;
       dot += ri * zi;
     }
@@ -1530,7 +1580,7 @@ int femo_shell_destroy(femo_shell* s) {
   hipFree(s->d_r); hipFree(s->d_p); hipFree(s->d_q); hipFree(s->d_dinv); hipFree(s->d_scal); hipFree(s->d_part); hipFree(s->d_flag);
   hipFree(s->d_ell_idx); hipFree(s->d_ell_w);
   hipFree(s->d_par_rowptr); hipFree(s->d_par_cols); hipFree(s->d_par_vals); hipFree(s->d_chi_rowptr); hipFree(s->d_chi_cols); hipFree(s->d_chi_vals);
-  hipFree(s->d_coarse); hipFree(s->d_cblk); hipFree(s->d_t); hipFree(s->d_e); hipFree(s->d_z); hipFree(s->d_fin_idx); hipFree(s->d_fin_w);
+  hipFree(s->d_coarse); hipFree(s->d_cblk); hipFree(s->d_dinv3); hipFree(s->d_t); hipFree(s->d_e); hipFree(s->d_z); hipFree(s->d_fin_idx); hipFree(s->d_fin_w);
   delete s;
   return 0;
 }
@@ -1602,6 +1652,7 @@ int femo_shell_pc_create(femo_shell* s, int width, int64_t n_nodes, int n_levels
   }
   FEMO_HIP_CHECK(hipMalloc(&s->d_coarse, n_lat * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&s->d_cblk, n_nodes * 36 * sizeof(double)));
+  FEMO_HIP_CHECK(hipMalloc(&s->d_dinv3, (s->n_dof / 3) * 9 * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&s->d_t, n_lat * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&s->d_e, n_lat * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&s->d_z, s->n_dof * sizeof(double)));
@@ -1705,7 +1756,7 @@ static int shell_pc_apply(femo_shell* s, const uint8_t* d_fixed, double* Prz, un
     }
   }
   hipLaunchKernelGGL(k_pc_prolong, dim3(gz), dim3(SH_BLOCK), 0, st, s->n_dof / 3, s->d_fin_idx, s->d_fin_w, d_fixed, s->d_dinv, s->d_r, s->d_e,
-                     s->d_z, Prz, done);
+                     s->d_z, Prz, done, s->dinv3_ready ? s->d_dinv3 : (const double*)nullptr);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -1944,6 +1995,11 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
         hipLaunchKernelGGL(k_pc_galerkin_diag, dim3(sgrid(n * (s->pc_width - first_slot))), dim3(SH_BLOCK), 0, st, n, s->pc_width, s->d_rowptr, s->d_cols,
                            vals->d, d_fixed, s->d_ell_idx, s->d_ell_w, s->d_coarse, first_slot);
         hipLaunchKernelGGL(k_pc_invert, dim3(sgrid(s->n_lat)), dim3(256), 0, st, s->n_lat, s->d_coarse);
+      }
+      s->dinv3_ready = false;
+      if (s->d_brow != nullptr && getenv("FEMO_SHELL_NO_POINT_BLOCKS") == nullptr) {
+        hipLaunchKernelGGL(k_pt_block_inv, dim3(sgrid(n / 3, 256)), dim3(256), 0, st, n / 3, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_dinv3);
+        s->dinv3_ready = true;
       }
       s->pc_vals_uid = vals->uid; s->pc_vals_gen = vals->gen; s->pc_mask_hash = mh;
     }
