@@ -969,19 +969,46 @@ __device__ __forceinline__ void tile_load(double (*s)[DP], const double* __restr
   }
 }
 
-// acc[a][b] += sum_k sa[4 ty + a][k] sb[4 tx + b][k]   (C = A B^T with both operands stored [row][k])
-__device__ __forceinline__ void tile_mma(double (&acc)[4][4], const double (*sa)[DP], const double (*sb)[DP]) {
-  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-#pragma unroll 8
-  for (int k = 0; k < DT; ++k) {
-    double a[4], b[4];
+// C += A B^T for 64 x 64 tiles with both operands in LDS as [row][k], on the fp64 matrix cores: wave w owns the
+// 32 x 32 quadrant (w >> 1, w & 1) as 2 x 2 tiles of v_mfma_f64_16x16x4_f64; per k-step of 4 a lane supplies
+// A[l & 15][l >> 4] and B[l >> 4][l & 15] and holds D[(l >> 4) + 4 i][l & 15] in register i (the f64 map, not the
+// f32 one).  16 k-steps x 4 MFMAs per wave and tile product (the scalar version: 1024 FMAs per thread, ~4 us).
+typedef double v4d __attribute__((ext_vector_type(4)));
+struct TileAcc {
+  v4d v[2][2];
+  __device__ TileAcc() {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { a[q] = sa[4 * ty + q][k]; b[q] = sb[4 * tx + q][k]; }
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int w = 0; w < 4; ++w) acc[q][w] += a[q] * b[w];
+      for (int b = 0; b < 2; ++b) v[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
   }
+};
+
+__device__ __forceinline__ void tile_mma(TileAcc& acc, const double (*sa)[DP], const double (*sb)[DP]) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r0 = 32 * (w >> 1), c0 = 32 * (w & 1), li = lane & 15, lk = lane >> 4;
+#pragma unroll 4
+  for (int k0 = 0; k0 < DT; k0 += 4) {
+    const double a0 = sa[r0 + li][k0 + lk], a1 = sa[r0 + 16 + li][k0 + lk];
+    const double b0 = sb[c0 + li][k0 + lk], b1 = sb[c0 + 16 + li][k0 + lk];
+    acc.v[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc.v[0][0], 0, 0, 0);
+    acc.v[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc.v[0][1], 0, 0, 0);
+    acc.v[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc.v[1][0], 0, 0, 0);
+    acc.v[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc.v[1][1], 0, 0, 0);
+  }
+}
+
+// f(row, col, value) for the 16 elements of the tile this lane holds
+template <class F>
+__device__ __forceinline__ void tile_foreach(const TileAcc& acc, F f) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r0 = 32 * (w >> 1) + (lane >> 4), c0 = 32 * (w & 1) + (lane & 15);
+#pragma unroll
+  for (int sr = 0; sr < 2; ++sr)
+#pragma unroll
+    for (int sc = 0; sc < 2; ++sc)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f(r0 + 16 * sr + 4 * i, c0 + 16 * sc, acc.v[sr][sc][i]);
 }
 
 // diagonal tile kb: unblocked Cholesky in LDS, L_kk written back (lower part), its inverse (lower triangular, full
@@ -992,6 +1019,9 @@ __global__ __launch_bounds__(256) void k_chol_diag(int64_t N, int kb, double* __
   double* g = A + ((int64_t)kb * DT) * N + (int64_t)kb * DT;
   tile_load(a, g, N, false);
   __syncthreads();
+  // (Measured alternatives for this tile: one wave working on the LDS copy without workgroup barriers, 11.5 instead of
+  // 10.1 ms for the whole factorisation -- dependent LDS read-modify-writes; the row in registers with both loops
+  // unrolled -- 2 k spilled registers.)
   for (int p = 0; p < DT; ++p) {
     const double d = a[p][p];
     __syncthreads();
@@ -1038,13 +1068,9 @@ __global__ __launch_bounds__(256) void k_chol_panel(int64_t N, int kb, double* _
   tile_load(sa, g, N, false);
   tile_load(sb, dinv + (int64_t)kb * DT * DT, DT, false);
   __syncthreads();
-  double acc[4][4] = {};
+  TileAcc acc;
   tile_mma(acc, sa, sb);
-  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int w = 0; w < 4; ++w) g[(int64_t)(4 * ty + q) * N + 4 * tx + w] = acc[q][w];
+  tile_foreach(acc, [&](int r, int c, double v) { g[(int64_t)r * N + c] = v; });
 }
 
 // trailing update: A_ij -= L_ik L_jk^T for kb < j <= i; blockIdx.x enumerates the pairs (i, j) of the trailing triangle
@@ -1060,14 +1086,10 @@ __global__ __launch_bounds__(256) void k_chol_update(int64_t N, int kb, double* 
   tile_load(sa, A + ((int64_t)i * DT) * N + (int64_t)kb * DT, N, false);
   tile_load(sb, A + ((int64_t)j * DT) * N + (int64_t)kb * DT, N, false);
   __syncthreads();
-  double acc[4][4] = {};
+  TileAcc acc;
   tile_mma(acc, sa, sb);
   double* g = A + ((int64_t)i * DT) * N + (int64_t)j * DT;
-  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int w = 0; w < 4; ++w) g[(int64_t)(4 * ty + q) * N + 4 * tx + w] -= acc[q][w];
+  tile_foreach(acc, [&](int r, int c, double v) { g[(int64_t)r * N + c] -= v; });
 }
 
 // row of tiles i of W = L^-1: W_ij = -dinv_i sum_{k = j}^{i - 1} L_ik W_kj for j = blockIdx.x < i, with W_jj = dinv_j and
@@ -1077,31 +1099,43 @@ __global__ __launch_bounds__(256) void k_trinv_row(int64_t N, int i, double* __r
   __shared__ double sa[DT][DP];
   __shared__ double sb[DT][DP];
   const int j = blockIdx.x;
-  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-  double acc[4][4] = {};
+  TileAcc acc;
+  // the two tiles of step k + 1 travel from global memory to registers while step k multiplies
+  double ra[16], rb[16];
+  auto fetch = [&](int k) {
+    const double* ga = A + ((int64_t)i * DT) * N + (int64_t)k * DT;                              // L_ik [r][m]
+    const double* gb = k == j ? dinv + (int64_t)j * DT * DT : A + ((int64_t)j * DT) * N + (int64_t)k * DT;
+    const int64_t ldb = k == j ? DT : N;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int idx = threadIdx.x + 256 * q, r = idx / DT, c = idx % DT;
+      ra[q] = ga[(int64_t)r * N + c];
+      rb[q] = gb[(int64_t)r * ldb + c];
+    }
+  };
+  fetch(j);
   for (int k = j; k < i; ++k) {
     __syncthreads();
-    tile_load(sa, A + ((int64_t)i * DT) * N + (int64_t)k * DT, N, false);                       // L_ik [r][m]
-    if (k == j) tile_load(sb, dinv + (int64_t)j * DT * DT, DT, true);                            // sb[c][m] = W_jj[m][c]
-    else tile_load(sb, A + ((int64_t)j * DT) * N + (int64_t)k * DT, N, false);                   // tile (j, k)[c][m] = W_kj[m][c]
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int idx = threadIdx.x + 256 * q, r = idx / DT, c = idx % DT;
+      sa[r][c] = ra[q];
+      if (k == j) sb[c][r] = rb[q];                        // sb[c][m] = W_jj[m][c]: the diagonal tile is stored untransposed
+      else sb[r][c] = rb[q];                               // tile (j, k)[c][m] = W_kj[m][c]
+    }
     __syncthreads();
+    if (k + 1 < i) fetch(k + 1);
     tile_mma(acc, sa, sb);
   }
   __syncthreads();
   // S (in acc) transposed into sb: sb[c][m] = S[m][c]; then W_ij[r][c] = -sum_m dinv_i[r][m] S[m][c]
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int w = 0; w < 4; ++w) sb[4 * tx + w][4 * ty + q] = acc[q][w];
+  tile_foreach(acc, [&](int r, int c, double v) { sb[c][r] = v; });
   tile_load(sa, dinv + (int64_t)i * DT * DT, DT, false);
   __syncthreads();
-  double out[4][4] = {};
+  TileAcc out;
   tile_mma(out, sa, sb);
   double* g = A + ((int64_t)j * DT) * N + (int64_t)i * DT;                                       // tile (j, i), transposed store
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int w = 0; w < 4; ++w) g[(int64_t)(4 * tx + w) * N + 4 * ty + q] = -out[q][w];
+  tile_foreach(out, [&](int r, int c, double v) { g[(int64_t)c * N + r] = -v; });
 }
 
 // diagonal tiles of the result: L_kk^-T above, L_kk^-1 below the diagonal
