@@ -1274,65 +1274,66 @@ __global__ void k_lat_level(int64_t n0, int64_t n1, const int64_t* __restrict__ 
 }
 
 // 6 x 6 Galerkin blocks of the lattice nodes, levels first_slot / 8 and up: blk[node][f][f'] = sum over free dofs i of
-// field f and k of field f' that both touch the node of P[i, node] K[i, k] P[k, node].  One thread per (point, ELL
-// slot) over the node-block view of the matrix: the point's three dofs share node and weight, a 3 x 3 block of K is
-// matched against the column point's eight nodes once (the first version, a thread per (dof, slot) over the scalar
-// rows, took longer than the iterations it saved).  The diagonal of a block is the scalar Galerkin diagonal.
+// field f and k of field f' that both touch the node of P[i, node] K[i, k] P[k, node].  One thread per (point, level,
+// component fa of the point) over the node-block view of the matrix: it keeps the row's sums against the point's eight
+// nodes of the level (8 x 6 registers), reads a column point's eight (node, weight) pairs of the level once per block
+// and matches them against its own eight.  (A thread per (dof, slot) over the scalar rows took longer than the
+// iterations the blocks save; a thread per (point, slot) re-read the column's pairs for every slot: 18 ms at 1.97 M
+// dofs.)  The diagonal of a block is the scalar Galerkin diagonal.
 __global__ __launch_bounds__(SH_BLOCK) void k_pc_galerkin_blocks(int64_t n_pts, int width, int64_t n_unode, const int64_t* __restrict__ brow,
                                                                  const int32_t* __restrict__ bcols, const double* __restrict__ vals,
                                                                  const uint8_t* __restrict__ fixed, const int32_t* __restrict__ ell_idx,
                                                                  const double* __restrict__ ell_w, double* __restrict__ blk, int first_slot) {
-  const int wact = width - first_slot;
+  const int nlev = (width - first_slot) >> 3;
   const int64_t t = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x;
-  const int64_t p = t / wact;
-  const int a = first_slot + (int)(t % wact);
-  if (p >= n_pts) return;
-  const double wi = ell_w[(3 * p) * width + a];
-  if (wi == 0.0) return;
-  const int32_t node = ell_idx[(3 * p) * width + a] / 6;
+  const int fa = (int)(t % 3);
+  const int64_t pl = t / 3;
+  const int64_t p = pl / nlev;
+  const int lev8 = first_slot + 8 * (int)(pl % nlev);
+  if (p >= n_pts || (fixed != nullptr && fixed[3 * p + fa])) return;
+  int32_t nd[8];
+  double wi[8], acc[8][6];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    nd[a] = ell_idx[(3 * p) * width + lev8 + a] / 6;
+    wi[a] = ell_w[(3 * p) * width + lev8 + a];
+    if (wi[a] == 0.0) nd[a] = -1;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) acc[a][q] = 0.0;
+  }
   const int gi = p >= n_unode ? 1 : 0;
-  const int lev8 = (a >> 3) << 3;
-  const bool fi0 = fixed != nullptr && fixed[3 * p], fi1 = fixed != nullptr && fixed[3 * p + 1], fi2 = fixed != nullptr && fixed[3 * p + 2];
-  double acc[3][6];
-#pragma unroll
-  for (int fa = 0; fa < 3; ++fa)
-#pragma unroll
-    for (int q = 0; q < 6; ++q) acc[fa][q] = 0.0;
   const int64_t k0 = brow[p], k1 = brow[p + 1], len = 3 * (k1 - k0);
-  const double *v0 = vals + 9 * k0, *v1 = v0 + len, *v2 = v1 + len;
+  const double* v = vals + 9 * k0 + fa * len;
   for (int64_t k = k0; k < k1; ++k) {
     const int32_t cj = bcols[k];
     const int32_t* ik = ell_idx + (int64_t)cj * width + lev8;
     const double* wk = ell_w + (int64_t)cj * width + lev8;
-    double pk = 0.0;
-#pragma unroll
-    for (int b = 0; b < 8; ++b) pk += ik[b] / 6 == node ? wk[b] : 0.0;
-    if (pk == 0.0) continue;
     const int64_t o = 3 * (k - k0);
-    const bool fj0 = fixed != nullptr && fixed[cj], fj1 = fixed != nullptr && fixed[cj + 1], fj2 = fixed != nullptr && fixed[cj + 2];
-    double m[3][3];
-    m[0][0] = v0[o]; m[0][1] = v0[o + 1]; m[0][2] = v0[o + 2];
-    m[1][0] = v1[o]; m[1][1] = v1[o + 1]; m[1][2] = v1[o + 2];
-    m[2][0] = v2[o]; m[2][1] = v2[o + 1]; m[2][2] = v2[o + 2];
-    if (fj0) m[0][0] = m[1][0] = m[2][0] = 0.0;
-    if (fj1) m[0][1] = m[1][1] = m[2][1] = 0.0;
-    if (fj2) m[0][2] = m[1][2] = m[2][2] = 0.0;
+    double m0 = v[o], m1 = v[o + 1], m2 = v[o + 2];
+    if (fixed != nullptr) {
+      if (fixed[cj]) m0 = 0.0;
+      if (fixed[cj + 1]) m1 = 0.0;
+      if (fixed[cj + 2]) m2 = 0.0;
+    }
     const bool gj = cj >= 3 * n_unode;
 #pragma unroll
-    for (int fa = 0; fa < 3; ++fa)
+    for (int b = 0; b < 8; ++b) {
+      const int32_t nb = ik[b] / 6;
+      const double wb = wk[b];
 #pragma unroll
-      for (int fb = 0; fb < 3; ++fb) {
-        if (gj) acc[fa][3 + fb] += pk * m[fa][fb];
-        else acc[fa][fb] += pk * m[fa][fb];
+      for (int a = 0; a < 8; ++a) {
+        const double ww = nb == nd[a] ? wb : 0.0;
+        if (gj) { acc[a][3] += ww * m0; acc[a][4] += ww * m1; acc[a][5] += ww * m2; }
+        else { acc[a][0] += ww * m0; acc[a][1] += ww * m1; acc[a][2] += ww * m2; }
       }
+    }
   }
-  const bool fi[3] = {fi0, fi1, fi2};
 #pragma unroll
-  for (int fa = 0; fa < 3; ++fa) {
-    if (fi[fa]) continue;
+  for (int a = 0; a < 8; ++a) {
+    if (nd[a] < 0) continue;
 #pragma unroll
     for (int q = 0; q < 6; ++q)
-      if (acc[fa][q] != 0.0) atomicAdd(&blk[36 * (int64_t)node + 6 * (3 * gi + fa) + q], wi * acc[fa][q]);
+      if (acc[a][q] != 0.0) atomicAdd(&blk[36 * (int64_t)nd[a] + 6 * (3 * gi + fa) + q], wi[a] * acc[a][q]);
   }
 }
 
@@ -2020,7 +2021,7 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
       if (s->cs_ready && getenv("FEMO_SHELL_NO_BLOCKS") == nullptr) {
         const int64_t nd0 = s->level_off[s->cs_level + 1], nd1 = s->level_off[s->pc_levels];
         FEMO_HIP_CHECK(hipMemsetAsync(s->d_cblk + 36 * nd0, 0, (nd1 - nd0) * 36 * sizeof(double), st));
-        hipLaunchKernelGGL(k_pc_galerkin_blocks, dim3(sgrid((n / 3) * (s->pc_width - first_slot))), dim3(SH_BLOCK), 0, st, n / 3, s->pc_width,
+        hipLaunchKernelGGL(k_pc_galerkin_blocks, dim3(sgrid((n / 3) * 3 * ((s->pc_width - first_slot) / 8))), dim3(SH_BLOCK), 0, st, n / 3, s->pc_width,
                            s->n_unode, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_ell_idx, s->d_ell_w, s->d_cblk, first_slot);
         hipLaunchKernelGGL(k_pc_invert_blocks, dim3(sgrid(nd1 - nd0, 256)), dim3(256), 0, st, nd0, nd1, s->d_cblk);
         s->blk_ready = true;
