@@ -797,14 +797,19 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_galerkin_diag(int64_t n, int wi
 // Dense Galerkin operator of one coarse lattice level c: A[a, b] = sum_{i, j free} P[i, a] K[i, j] P[j, b], 6 n_c x 6 n_c.
 // One workgroup per item = points (256 by default) of one coarse cell and one field group (displacements of P2 nodes /
 // rotations of vertices): they share the cell's eight nodes a, and the eight nodes of any j they couple to lie in the
-// 4 x 4 x 4 node neighbourhood of the cell (an element is smaller than a coarse cell).  Thread t keeps the 3 x 6 sums
-// of node a = t % 8 against the neighbourhood nodes t / 8 and t / 8 + 32 in registers over the whole item -- the sum
-// over the ~1e4 points of a cell never leaves the workgroup -- and adds them to the dense matrix once (item_nbr: the
-// neighbourhood's level-local node numbers, -1 where the surface does not touch the lattice).
-// The item's 3 x 3 blocks are staged through LDS 256 at a time, one block per thread (values with the Dirichlet mask
-// applied, the column's eight weights, its cell offset), then every thread walks the staged blocks: the first version
-// had all threads follow the same block through global memory, one exposed latency per block (27 ms at 1.97 M dofs).
+// 4 x 4 x 4 node neighbourhood of the cell (an element is smaller than a coarse cell; info[1] reports otherwise).  The
+// sums over the item never leave the workgroup: table[3 x 6 components][64 neighbourhood nodes][8 a] in LDS (72 KB),
+// flushed to the dense matrix once (item_nbr: the neighbourhood's level-local node numbers, -1 where the surface does
+// not touch the lattice).  The item's 3 x 3 blocks are staged through LDS 256 at a time, one block per thread (values
+// with the Dirichlet mask applied, the column's eight weights, its cell offset); then a wave takes one staged block
+// per step, its 64 lanes being the 8 x 8 pairs (cell node a, corner k' of the column's cell), and adds the nine
+// products with ds_add_f64.  History at 1.97 M dofs (12 M blocks): all threads following one block through global
+// memory, sums in registers of the thread that owns (a, neighbourhood node): 27 ms; blocks staged through LDS, same
+// ownership (one (thread, block) pair in eight has work): 20 ms whatever the item size; LDS table with a 16-way bank
+// conflict: 16.4 ms; this layout: 8.1 ms.
 constexpr int CG_MAXPTS = 256;
+constexpr int CG_TABLE = 8 * 64 * 18;                     // doubles
+constexpr size_t CG_LDS = (size_t)CG_TABLE * 8 + 256 * 9 * 8 + 256 * 8 * 8 + CG_MAXPTS * 8 * 8 + 256 * 4 + (CG_MAXPTS + 1) * 4 + CG_MAXPTS * 4 * 2;
 __global__ __launch_bounds__(256) void k_pc_coarse_galerkin(int c, int width, int64_t off_c, int64_t lda, int64_t n_unode,
                                                             const int64_t* __restrict__ item_ptr, const int32_t* __restrict__ item_pts,
                                                             const int32_t* __restrict__ item_nbr, const int32_t* __restrict__ node_xyz,
@@ -812,124 +817,120 @@ __global__ __launch_bounds__(256) void k_pc_coarse_galerkin(int c, int width, in
                                                             const int32_t* __restrict__ bcols, const double* __restrict__ vals,
                                                             const uint8_t* __restrict__ fixed, const int32_t* __restrict__ ell_idx,
                                                             const double* __restrict__ ell_w, double* __restrict__ A, int32_t* __restrict__ info) {
-  __shared__ int32_t s_scan[CG_MAXPTS + 1];              // blocks before point q of the item
-  __shared__ int32_t s_k0[CG_MAXPTS];                    // first block of the point's block row
-  __shared__ int32_t s_fi[CG_MAXPTS];                    // Dirichlet bits of the point's three dofs
-  __shared__ double s_wpt[CG_MAXPTS][8];                 // the point's weights on the cell's eight nodes
-  __shared__ double s_val[256][9];
-  __shared__ double s_wb[256][8];
-  __shared__ int32_t s_meta[256];                        // ox | oy << 2 | oz << 4 | gj << 6 | q << 8, or -1
+  extern __shared__ double cg_lds[];
+  double* table = cg_lds;                                                  // [3 fa][6][64 bl][8 a]
+  double (*s_val)[9] = reinterpret_cast<double (*)[9]>(table + CG_TABLE);  // staged 3 x 3 blocks, Dirichlet mask applied
+  double (*s_wb)[8] = reinterpret_cast<double (*)[8]>(s_val + 256);        // the column's weights on its cell's nodes
+  double (*s_wpt)[8] = reinterpret_cast<double (*)[8]>(s_wb + 256);        // the item's points: weights on the cell's nodes
+  int32_t* s_meta = reinterpret_cast<int32_t*>(s_wpt + CG_MAXPTS);         // ox | oy << 2 | oz << 4 | gj << 6 | q << 8, or -1
+  int32_t* s_scan = s_meta + 256;                                          // blocks before point q of the chunk
+  int32_t* s_k0 = s_scan + CG_MAXPTS + 1;
+  int32_t* s_fi = s_k0 + CG_MAXPTS;
   const int64_t item = blockIdx.x;
-  const int t = threadIdx.x, a = t & 7, blq = t >> 3;
-  const int lx0 = blq & 3, ly0 = (blq >> 2) & 3, lz0 = blq >> 4;
+  const int t = threadIdx.x;
   const int64_t pbeg = item_ptr[item], pend = item_ptr[item + 1];
   const int32_t pfirst = item_pts[pbeg];
   const int gi = pfirst >= n_unode ? 1 : 0;
   const int64_t e0 = (int64_t)(3 * pfirst) * width + 8 * c;
   const int32_t pk0 = pcell[pfirst];
   const int bx = pk0 & 1023, by = (pk0 >> 10) & 1023, bz = pk0 >> 20;
-  double acc[2][3][6];
-#pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int fa = 0; fa < 3; ++fa)
-#pragma unroll
-      for (int f = 0; f < 6; ++f) acc[s][fa][f] = 0.0;
+  for (int idx = t; idx < CG_TABLE; idx += 256) table[idx] = 0.0;
   int far = 0;
-  // the item's points 256 at a time, one flush of the register sums per item.  Measured at 1.97 M dofs: 17-20 ms for
-  // items of 64 .. 256 points (10 k .. 2.8 k workgroups), 24 with 512, 29 with 2048 (608 workgroups): neither the
-  // flush atomics nor the global latency of the first version (all threads following one block: 27 ms) is the limit;
-  // the walk over the staged blocks is (one in eight (thread, block) pairs does arithmetic)
+  const int wv = t >> 6, la = t & 7, lk = (t >> 3) & 7;                     // wave, cell node a, corner k' of the column's cell
   for (int64_t p0 = pbeg; p0 < pend; p0 += CG_MAXPTS) {
-  const int npts = (int)min((int64_t)CG_MAXPTS, pend - p0);
-  __syncthreads();
-  if (t < npts) {
-    const int32_t i = item_pts[p0 + t];
-    const int64_t k0 = brow[i];
-    s_k0[t] = (int32_t)k0;
-    s_scan[t + 1] = (int32_t)(brow[i + 1] - k0);
-    s_fi[t] = fixed == nullptr ? 0 : (fixed[3 * i] ? 1 : 0) | (fixed[3 * i + 1] ? 2 : 0) | (fixed[3 * i + 2] ? 4 : 0);
-  }
-  for (int idx = t; idx < npts * 8; idx += 256) {
-    const int32_t i = item_pts[p0 + (idx >> 3)];
-    s_wpt[idx >> 3][idx & 7] = ell_w[(int64_t)(3 * i) * width + 8 * c + (idx & 7)];
-  }
-  __syncthreads();
-  if (t == 0) {
-    int32_t run = 0;
-    s_scan[0] = 0;
-    for (int q = 0; q < npts; ++q) { run += s_scan[q + 1]; s_scan[q + 1] = run; }
-  }
-  __syncthreads();
-  const int B = s_scan[npts];
-  for (int base = 0; base < B; base += 256) {
-    const int f = base + t;
-    if (f < B) {
-      int lo = 0, hi = npts - 1;                           // largest q with s_scan[q] <= f
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (s_scan[mid] <= f) lo = mid; else hi = mid - 1;
+    const int npts = (int)min((int64_t)CG_MAXPTS, pend - p0);
+    __syncthreads();
+    if (t < npts) {
+      const int32_t i = item_pts[p0 + t];
+      const int64_t k0 = brow[i];
+      s_k0[t] = (int32_t)k0;
+      s_scan[t + 1] = (int32_t)(brow[i + 1] - k0);
+      s_fi[t] = fixed == nullptr ? 0 : (fixed[3 * i] ? 1 : 0) | (fixed[3 * i + 1] ? 2 : 0) | (fixed[3 * i + 2] ? 4 : 0);
+    }
+    for (int idx = t; idx < npts * 8; idx += 256) {
+      const int32_t i = item_pts[p0 + (idx >> 3)];
+      s_wpt[idx >> 3][idx & 7] = ell_w[(int64_t)(3 * i) * width + 8 * c + (idx & 7)];
+    }
+    __syncthreads();
+    if (t == 0) {
+      int32_t run = 0;
+      s_scan[0] = 0;
+      for (int q = 0; q < npts; ++q) { run += s_scan[q + 1]; s_scan[q + 1] = run; }
+    }
+    __syncthreads();
+    const int B = s_scan[npts];
+    for (int base = 0; base < B; base += 256) {
+      const int f = base + t;
+      if (f < B) {
+        int lo = 0, hi = npts - 1;                         // largest q with s_scan[q] <= f
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (s_scan[mid] <= f) lo = mid; else hi = mid - 1;
+        }
+        const int q = lo, lkk = f - s_scan[q];
+        const int64_t k0 = s_k0[q];
+        const int64_t len = 3 * (int64_t)(s_scan[q + 1] - s_scan[q]);
+        const int32_t cj = bcols[k0 + lkk];
+        const int32_t pk = pcell[cj / 3];
+        const int ox = (pk & 1023) - bx + 1, oy = ((pk >> 10) & 1023) - by + 1, oz = (pk >> 20) - bz + 1;
+        if ((unsigned)ox > 2u || (unsigned)oy > 2u || (unsigned)oz > 2u) {
+          far = 1;
+          s_meta[t] = -1;
+        } else {
+          s_meta[t] = ox | (oy << 2) | (oz << 4) | ((cj >= 3 * n_unode ? 1 : 0) << 6) | (q << 8);
+          const double* v = vals + 9 * k0 + 3 * lkk;
+          const int fi = s_fi[q];
+          const int fj = fixed == nullptr ? 0 : (fixed[cj] ? 1 : 0) | (fixed[cj + 1] ? 2 : 0) | (fixed[cj + 2] ? 4 : 0);
+#pragma unroll
+          for (int fa = 0; fa < 3; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < 3; ++fb) s_val[t][3 * fa + fb] = ((fi >> fa) & 1) || ((fj >> fb) & 1) ? 0.0 : v[fa * len + fb];
+          const double* wj = ell_w + (int64_t)cj * width + 8 * c;
+#pragma unroll
+          for (int b = 0; b < 8; ++b) s_wb[t][b] = wj[b];
+        }
       }
-      const int q = lo, lk = f - s_scan[q];
-      const int64_t k0 = s_k0[q];
-      const int64_t len = 3 * (int64_t)(s_scan[q + 1] - s_scan[q]);
-      const int32_t cj = bcols[k0 + lk];
-      const int32_t pk = pcell[cj / 3];
-      const int ox = (pk & 1023) - bx + 1, oy = ((pk >> 10) & 1023) - by + 1, oz = (pk >> 20) - bz + 1;
-      if ((unsigned)ox > 2u || (unsigned)oy > 2u || (unsigned)oz > 2u) {
-        far = 1;
-        s_meta[t] = -1;
-      } else {
-        s_meta[t] = ox | (oy << 2) | (oz << 4) | ((cj >= 3 * n_unode ? 1 : 0) << 6) | (q << 8);
-        const double* v = vals + 9 * k0 + 3 * lk;
-        const int fi = s_fi[q];
-        const int fj = fixed == nullptr ? 0 : (fixed[cj] ? 1 : 0) | (fixed[cj + 1] ? 2 : 0) | (fixed[cj + 2] ? 4 : 0);
+      __syncthreads();
+      const int cnt = min(256, B - base);
+      for (int e = wv; e < cnt; e += 4) {                  // one staged block per wave and step
+        const int32_t m = s_meta[e];
+        if (m < 0) continue;
+        const int ox = m & 3, oy = (m >> 2) & 3, oz = (m >> 4) & 3, gj = (m >> 6) & 1, q = m >> 8;
+        const double ww = s_wpt[q][la] * s_wb[e][lk];
+        const int bl = (ox + (lk & 1)) + 4 * (oy + ((lk >> 1) & 1)) + 16 * (oz + (lk >> 2));
+        // table[component][bl][a], a fastest: the 64 lanes of an update spread over all banks (4 lanes per 8-byte
+        // bank pair, the minimum); with [a][bl][component] the eight a and the two z corners shared a bank, a 16-way
+        // conflict on every ds_add_f64 (16.4 ms at 1.97 M dofs)
+        double* dst = table + ((3 * gj) * 64 + bl) * 8 + la;
 #pragma unroll
         for (int fa = 0; fa < 3; ++fa)
 #pragma unroll
-          for (int fb = 0; fb < 3; ++fb) s_val[t][3 * fa + fb] = ((fi >> fa) & 1) || ((fj >> fb) & 1) ? 0.0 : v[fa * len + fb];
-        const double* wj = ell_w + (int64_t)cj * width + 8 * c;
-#pragma unroll
-        for (int b = 0; b < 8; ++b) s_wb[t][b] = wj[b];
+          for (int fb = 0; fb < 3; ++fb)
+            __hip_atomic_fetch_add(dst + (6 * fa + fb) * 512, ww * s_val[e][3 * fa + fb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
+      __syncthreads();
     }
-    __syncthreads();
-    const int cnt = min(256, B - base);
-    for (int e = 0; e < cnt; ++e) {
-      const int32_t m = s_meta[e];
-      if (m < 0) continue;
-      const int dx = lx0 - (m & 3), dy = ly0 - ((m >> 2) & 3);
-      if ((unsigned)dx > 1u || (unsigned)dy > 1u) continue;
-      const int oz = (m >> 4) & 3, gj = (m >> 6) & 1, q = m >> 8;
-      const double wa = s_wpt[q][a];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int dz = lz0 + 2 * s - oz;
-        if ((unsigned)dz > 1u) continue;
-        const double ww = wa * s_wb[e][dx + 2 * dy + 4 * dz];
-#pragma unroll
-        for (int fa = 0; fa < 3; ++fa)
-#pragma unroll
-          for (int fb = 0; fb < 3; ++fb) {
-            if (gj) acc[s][fa][3 + fb] += ww * s_val[e][3 * fa + fb];
-            else acc[s][fa][fb] += ww * s_val[e][3 * fa + fb];
-          }
-      }
-    }
-    __syncthreads();
-  }
   }
   if (far && info != nullptr) atomicOr(&info[1], 1);
-  const int64_t na = ell_idx[e0 + a] / 6 - off_c;
+  __syncthreads();
+  // flush: thread t owns node a = t & 7 against neighbourhood nodes t >> 3 and (t >> 3) + 32
+  {
+    const int a = t & 7, blq = t >> 3;
+    const int64_t na = ell_idx[e0 + a] / 6 - off_c;
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int32_t nb = item_nbr[item * 64 + blq + 32 * s];
-    if (nb < 0) continue;
+    for (int s = 0; s < 2; ++s) {
+      const int bl = blq + 32 * s;
+      const int32_t nb = item_nbr[item * 64 + bl];
+      if (nb < 0) continue;
+      const double* src = table + bl * 8 + a;
 #pragma unroll
-    for (int fa = 0; fa < 3; ++fa)
+      for (int fa = 0; fa < 3; ++fa)
 #pragma unroll
-      for (int f = 0; f < 6; ++f)
-        if (acc[s][fa][f] != 0.0) atomicAdd(&A[(6 * na + 3 * gi + fa) * lda + 6 * (int64_t)nb + f], acc[s][fa][f]);
+        for (int f = 0; f < 6; ++f) {
+          const double v = src[(6 * fa + f) * 512];
+          if (v != 0.0) atomicAdd(&A[(6 * na + 3 * gi + fa) * lda + 6 * (int64_t)nb + f], v);
+        }
+    }
   }
 }
 
@@ -1711,7 +1712,7 @@ static int shell_pc_coarse_setup(femo_shell* s, const femo_vec* vals, const uint
   auto t0 = now();
   FEMO_HIP_CHECK(hipMemsetAsync(s->d_cs_A, 0, N * N * sizeof(double), st));
   FEMO_HIP_CHECK(hipMemsetAsync(s->d_cs_info, 0, 4 * sizeof(int32_t), st));
-  hipLaunchKernelGGL(k_pc_coarse_galerkin, dim3((unsigned)s->cs_items), dim3(256), 0, st, s->cs_level, s->pc_width, s->level_off[s->cs_level], N,
+  hipLaunchKernelGGL(k_pc_coarse_galerkin, dim3((unsigned)s->cs_items), dim3(256), CG_LDS, st, s->cs_level, s->pc_width, s->level_off[s->cs_level], N,
                      s->n_unode, s->d_cs_ptr, s->d_cs_pts, s->d_cs_nbr, s->d_cs_xyz, s->d_cs_pcell, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_ell_idx,
                      s->d_ell_w, s->d_cs_A, s->d_cs_info);
   hipLaunchKernelGGL(k_pc_coarse_fix_diag, dim3(sgrid(N, 256)), dim3(256), 0, st, N, s->d_cs_A);
@@ -1823,6 +1824,7 @@ int femo_shell_pc_coarse(femo_shell* s, int level, const int32_t* node_xyz, int6
                      s->d_ell_idx, s->d_cs_xyz, s->d_cs_pcell);
   FEMO_HIP_CHECK(hipGetLastError());
   FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  FEMO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pc_coarse_galerkin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CG_LDS));
   s->cs_level = level; s->cs_n = n; s->cs_N = N; s->cs_items = n_items;
   s->pc_vals_uid = 0; s->pc_vals_gen = 0;                 // next solve recomputes the preconditioner's numbers
   return 0;
@@ -1845,7 +1847,7 @@ int femo_shell_pc_coarse_matrix(femo_shell* s, const femo_vec* vals, const uint8
   } else {
     FEMO_HIP_CHECK(hipMemsetAsync(s->d_cs_A, 0, N * N * sizeof(double), st));
     FEMO_HIP_CHECK(hipMemsetAsync(s->d_cs_info, 0, 4 * sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_pc_coarse_galerkin, dim3((unsigned)s->cs_items), dim3(256), 0, st, s->cs_level, s->pc_width, s->level_off[s->cs_level], N,
+    hipLaunchKernelGGL(k_pc_coarse_galerkin, dim3((unsigned)s->cs_items), dim3(256), CG_LDS, st, s->cs_level, s->pc_width, s->level_off[s->cs_level], N,
                        s->n_unode, s->d_cs_ptr, s->d_cs_pts, s->d_cs_nbr, s->d_cs_xyz, s->d_cs_pcell, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_ell_idx,
                        s->d_ell_w, s->d_cs_A, s->d_cs_info);
     FEMO_HIP_CHECK(hipGetLastError());
