@@ -61,22 +61,50 @@ class ShellSpace:
 
     def pattern(self):
         """(rowptr int64, cols int32, elem_pos int32 (n_cell, 729)): CSR pattern of all element couplings (rows
-        sorted by column) and the position of K_e[i][j] of every cell in it."""
+        sorted by column) and the position of K_e[i][j] of every cell in it.  Built on the node blocks (a cell has 9:
+        six P2 nodes and three rotation nodes, three dofs each): 81 instead of 729 sort keys per cell, the scalar
+        pattern follows by arithmetic (`pattern_scalar_reference` is the direct construction the tests compare with)."""
         if self._pattern is None:
-            cd = self.cell_dofs
-            rows = np.repeat(cd, 27, axis=1).ravel()
-            cols = np.tile(cd, (1, 27)).ravel()
-            key = rows * self.n_dof + cols
+            nc, nbn = self.n_cell, self.n_dof // 3
+            bn = self.cell_dofs[:, 0::3] // 3                                      # (nc, 9) block nodes of a cell
+            key = (np.repeat(bn, 9, axis=1) * nbn + np.tile(bn, (1, 9))).ravel()
             uniq, inv = np.unique(key, return_inverse=True)
-            if uniq.size >= 2 ** 31:
+            if 9 * uniq.size >= 2 ** 31:
                 raise ValueError("shell pattern exceeds 32-bit element positions")
-            urow = uniq // self.n_dof
-            rowptr = np.zeros(self.n_dof + 1, dtype=np.int64)
-            np.add.at(rowptr, urow + 1, 1)
-            np.cumsum(rowptr, out=rowptr)
-            self._pattern = (rowptr, np.ascontiguousarray(uniq % self.n_dof, dtype=np.int32),
-                             np.ascontiguousarray(inv.reshape(-1, 729), dtype=np.int32))
+            brow_of, bcol_of = uniq // nbn, uniq % nbn
+            nb = np.bincount(brow_of, minlength=nbn)                               # blocks per block row
+            brow = np.concatenate([[0], np.cumsum(nb)])
+            slot = np.arange(uniq.size) - brow[brow_of]
+            # scalar row 3 b + i starts at 9 brow[b] + 3 i nb[b]; block `slot` occupies 3 entries of it
+            rowptr = np.empty(self.n_dof + 1, dtype=np.int64)
+            rowptr[:-1] = (9 * brow[:-1][:, None] + 3 * nb[:, None] * np.arange(3)[None, :]).ravel()
+            rowptr[-1] = 9 * uniq.size
+            base = 9 * brow[brow_of] + 3 * slot                                    # entry (i = 0, j = 0) of every block
+            stride = 3 * nb[brow_of]                                               # distance between its rows
+            cols = np.empty(9 * uniq.size, dtype=np.int32)
+            for i in range(3):
+                for j in range(3):
+                    cols[base + i * stride + j] = 3 * bcol_of + j
+            inv = inv.reshape(nc, 9, 9)
+            b32, s32 = base.astype(np.int32)[inv], stride.astype(np.int32)[inv]
+            epos = np.empty((nc, 9, 3, 9, 3), dtype=np.int32)                       # (cell, ln, i, lm, j)
+            for i in range(3):
+                for j in range(3):
+                    epos[:, :, i, :, j] = b32 + (i * s32 + j)
+            self._pattern = (rowptr, cols, epos.reshape(nc, 729))
         return self._pattern
+
+    def pattern_scalar_reference(self):
+        """The same triple built directly from the 27 x 27 dof pairs of every cell (729 sort keys per cell)."""
+        cd = self.cell_dofs
+        rows = np.repeat(cd, 27, axis=1).ravel()
+        cols = np.tile(cd, (1, 27)).ravel()
+        uniq, inv = np.unique(rows * self.n_dof + cols, return_inverse=True)
+        rowptr = np.zeros(self.n_dof + 1, dtype=np.int64)
+        np.add.at(rowptr, uniq // self.n_dof + 1, 1)
+        np.cumsum(rowptr, out=rowptr)
+        return (rowptr, np.ascontiguousarray(uniq % self.n_dof, dtype=np.int32),
+                np.ascontiguousarray(inv.reshape(-1, 729), dtype=np.int32))
 
 
 def lattice_pc(space: ShellSpace, finest: Optional[int] = None):

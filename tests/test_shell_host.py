@@ -24,6 +24,16 @@ def test_lattice_levels_are_nested_partitions_of_unity():
         assert abs(P[0] - P[1] @ Tp).max() < 1e-14
 
 
+def test_pattern_from_node_blocks_is_the_scalar_pattern():
+    rng = np.random.default_rng(3)
+    pts, conn = so.scordelis_lo_mesh(6, 5)
+    conn = conn[rng.permutation(conn.shape[0])]
+    conn = np.stack([np.roll(c, rng.integers(3)) for c in conn])              # any cell order, any rotation
+    S = ShellSpace(pts, conn)
+    for got, want in zip(S.pattern(), S.pattern_scalar_reference()):
+        assert got.dtype == want.dtype and np.array_equal(got, want)
+
+
 def test_coarse_solve_plan():
     pts, conn = so.scordelis_lo_mesh(16, 16)
     S = ShellSpace(pts, conn)
