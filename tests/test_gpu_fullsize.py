@@ -88,3 +88,50 @@ def test_full_size_properties(ctx, n):
     fd = (J_of(f + eps * dirn) - J_of(f - eps * dirn)) / (2 * eps)        # J is quadratic in f: exact up to round-off
     an = float(grad @ dirn)
     assert abs(fd - an) < 1e-7 * abs(an)
+
+
+def test_config3_shell_at_full_size(ctx):
+    """BASELINE config 3 as written -- Reissner-Mindlin shell, ~2 M dofs (362 x 362 roof: 1.97 M), thickness
+    sensitivity through the adjoint -- by properties that need no direct solve: the Scordelis-Lo reference value the
+    tree holds (run_shape_opt_roof.py:224), the residual of the computed state, the adjoint identity, the thickness
+    gradient against a directional difference of the compliance, and the iteration count of the preconditioned CG."""
+    from femo_amd.fea.shell import ShellProblem, ShellSpace
+    from oracle import shell_oracle as so
+    n, L = 362, 25.0
+    pts, conn = so.scordelis_lo_mesh(n, n, L=L)
+    S = ShellSpace(pts, conn)
+    assert 1.9e6 < S.n_dof < 2.1e6
+    on = lambda arr, val: np.nonzero(np.isclose(arr, val, atol=1e-6))[0]
+    ux, vx = S.unode_x, S.x
+    fixed = np.unique(np.concatenate([
+        S.u_dof(on(ux[:, 0], L), 1), S.u_dof(on(ux[:, 0], L), 2), S.u_dof(on(ux[:, 1], 0.0), 1), S.theta_dof(on(vx[:, 1], 0.0), 0),
+        S.theta_dof(on(vx[:, 1], 0.0), 2), S.u_dof(on(ux[:, 0], 0.0), 0), S.theta_dof(on(vx[:, 0], 0.0), 1), S.theta_dof(on(vx[:, 0], 0.0), 2)]))
+    prob = ShellProblem(pts, conn, 4.32e8, 0.0, fixed_dofs=fixed, ctx=ctx)
+    rng = np.random.default_rng(362)
+    h = 0.25 * (1.0 + 0.02 * np.cos(2 * np.pi * vx[:, 0] / L))
+    prob.set_thickness(h)
+    prob.set_load([0.0, 0.0, -90.0])
+    w = prob.solve(rtol=1e-10)
+    assert prob.last_info.converged == 1 and prob.last_info.iterations < 400        # 1.3 k with diagonal levels only
+    free = ~prob.fixed.astype(bool)
+    r = prob.residual(w)
+    Fn = np.abs(r[~free]).max()                                                     # reactions: the scale of the forces
+    assert np.abs(r[free]).max() <= 1e-7 * Fn
+    tip = int(np.argmin(np.abs(vx[:, 0]) + np.abs(vx[:, 1] - vx[:, 1].max())))
+    assert S.vertex_displacement(w)[tip, 2] == pytest.approx(-0.3024, rel=0.01)     # thickness varies by 2 %
+    # adjoint identity and the thickness sensitivity of the compliance
+    J, dJdw = prob.compliance(grad=True)
+    dJdw[~free] = 0.0
+    lam = prob.solve_adjoint(dJdw, rtol=1e-10)
+    c = rng.standard_normal(S.n_dof); c[~free] = 0.0
+    mu = prob.solve_adjoint(c, rtol=1e-10)
+    F = np.array(prob.F.get()); F[~free] = 0.0
+    assert abs(w @ c - F @ mu) <= 1e-7 * abs(w @ c)
+    g = -prob.dRdh_T(lam, w)
+    dh = 1e-3 * 0.25 * np.sin(2 * np.pi * vx[:, 1] / vx[:, 1].max())
+    Js = []
+    for sgn in (1.0, -1.0):
+        prob.set_thickness(h + sgn * dh)
+        prob.solve(rtol=1e-10)
+        Js.append(prob.compliance())
+    assert g @ dh == pytest.approx((Js[0] - Js[1]) / 2.0, rel=1e-4)
