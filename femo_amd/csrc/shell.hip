@@ -69,6 +69,9 @@ struct femo_shell {
   int cs_level = -1;
   int64_t cs_n = 0, cs_N = 0, cs_items = 0;            // unknowns of the level (6 x nodes), padded to 64s, items of the Galerkin kernel
   bool cs_ready = false;                               // d_cs_A holds the factors of the inverse for the current stiffness and mask
+  int64_t* d_cd_rowptr = nullptr;                      // composite restriction finest lattice -> levels cs_level .. L - 2
+  int32_t* d_cd_cols = nullptr;
+  double* d_cd_vals = nullptr;
   int32_t *d_cs_xyz = nullptr, *d_cs_pts = nullptr, *d_cs_nbr = nullptr, *d_cs_info = nullptr, *d_cs_pcell = nullptr;
   int64_t* d_cs_ptr = nullptr;
   double *d_cs_A = nullptr, *d_cs_tmp = nullptr;       // L^-T above / L^-1 below the diagonal (row-major, N x N); L^-1 g
@@ -1420,6 +1423,31 @@ __global__ void k_pc_invert_blocks(int64_t node0, int64_t node1, double* __restr
     for (int c = 0; c < 6; ++c) B[6 * r + c] = (dead[r] || dead[c]) ? 0.0 : 0.5 * (inv[r][c] + inv[c][r]);
 }
 
+// all levels between the coarse-solve level and the finest lattice at once: g[node] = sum over the finest lattice's
+// nodes of the composite child transfer (T_l^T ... T_{F-1}^T, built on the host), one wave per node, six fields per lane
+__global__ __launch_bounds__(SH_BLOCK) void k_lat_down_composite(int64_t row0, int64_t n_rows, const int64_t* __restrict__ rowptr,
+                                                                 const int32_t* __restrict__ cols, const double* __restrict__ vals,
+                                                                 double* __restrict__ g, const int32_t* __restrict__ done) {
+  if (done != nullptr && *done) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (SH_BLOCK / 64) + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int64_t k = rowptr[row] + lane; k < rowptr[row + 1]; k += 64) {
+    const double w = vals[k];
+    const double* src = g + 6 * (int64_t)cols[k];
+#pragma unroll
+    for (int f = 0; f < 6; ++f) s[f] += w * src[f];
+  }
+#pragma unroll
+  for (int f = 0; f < 6; ++f) s[f] = femo_wave_sum(s[f]);
+  if (lane == 0) {
+    double* dst = g + 6 * (row0 + row);
+#pragma unroll
+    for (int f = 0; f < 6; ++f) dst[f] = s[f];
+  }
+}
+
 // z = D^-1 r + P_L e_L (8 lanes per point, one finest-level entry each, three components) and the per-block partial of
 // r.z; imposed dofs: z = 0
 __global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong(int64_t n_pts, const int32_t* __restrict__ fin_idx, const double* __restrict__ fin_w,
@@ -1613,6 +1641,7 @@ int femo_shell_destroy(femo_shell* s) {
   hipFree(s->d_x); hipFree(s->d_conn); hipFree(s->d_cedge); hipFree(s->d_rowptr); hipFree(s->d_cols); hipFree(s->d_epos); hipFree(s->d_brow); hipFree(s->d_bcols); hipFree(s->d_bs_off); hipFree(s->d_bs_cols); hipFree(s->d_bs_vals);
   hipFree(s->d_ptp_rowptr); hipFree(s->d_ptp_cols); hipFree(s->d_ptp_vals);
   hipFree(s->d_cs_xyz); hipFree(s->d_cs_ptr); hipFree(s->d_cs_pts); hipFree(s->d_cs_nbr); hipFree(s->d_cs_A); hipFree(s->d_cs_tmp); hipFree(s->d_cs_dinv); hipFree(s->d_cs_info); hipFree(s->d_cs_pcell);
+  hipFree(s->d_cd_rowptr); hipFree(s->d_cd_cols); hipFree(s->d_cd_vals);
   hipFree(s->d_r); hipFree(s->d_p); hipFree(s->d_q); hipFree(s->d_dinv); hipFree(s->d_scal); hipFree(s->d_part); hipFree(s->d_flag);
   hipFree(s->d_ell_idx); hipFree(s->d_ell_w);
   hipFree(s->d_par_rowptr); hipFree(s->d_par_cols); hipFree(s->d_par_vals); hipFree(s->d_chi_rowptr); hipFree(s->d_chi_cols); hipFree(s->d_chi_vals);
@@ -1754,10 +1783,16 @@ static int shell_pc_apply(femo_shell* s, const uint8_t* d_fixed, double* Prz, un
   if (s->cs_ready) {
     // levels above the coarse-solve level as before; on it the dense inverse replaces the diagonal levels 0 .. cs
     const int cs = s->cs_level;
-    for (int l = L - 2; l >= cs; --l) {
-      const int64_t n0 = s->level_off[l], n1 = s->level_off[l + 1];
-      hipLaunchKernelGGL(k_lat_level, dim3(sgrid((n1 - n0) * 6, 256)), dim3(256), 0, st, n0, n1, s->d_chi_rowptr, s->d_chi_cols, s->d_chi_vals,
-                         s->d_coarse, s->d_t, s->d_e, 0, done);
+    if (s->d_cd_rowptr != nullptr && L - 1 > cs) {
+      const int64_t rows = s->level_off[L - 1] - s->level_off[cs];
+      hipLaunchKernelGGL(k_lat_down_composite, dim3(sgrid(rows, SH_BLOCK / 64)), dim3(SH_BLOCK), 0, st, s->level_off[cs], rows, s->d_cd_rowptr,
+                         s->d_cd_cols, s->d_cd_vals, s->d_t, done);
+    } else {
+      for (int l = L - 2; l >= cs; --l) {
+        const int64_t n0 = s->level_off[l], n1 = s->level_off[l + 1];
+        hipLaunchKernelGGL(k_lat_level, dim3(sgrid((n1 - n0) * 6, 256)), dim3(256), 0, st, n0, n1, s->d_chi_rowptr, s->d_chi_cols, s->d_chi_vals,
+                           s->d_coarse, s->d_t, s->d_e, 0, done);
+      }
     }
     const unsigned gp = (unsigned)((s->cs_n + 1) / 2);
     hipLaunchKernelGGL(k_pc_coarse_apply, dim3(gp), dim3(SH_BLOCK), 0, st, s->cs_n, s->cs_N, 1, s->d_cs_A,
@@ -1798,7 +1833,8 @@ static int shell_pc_apply(femo_shell* s, const uint8_t* d_fixed, double* Prz, un
 }
 
 int femo_shell_pc_coarse(femo_shell* s, int level, const int32_t* node_xyz, int64_t n_items, const int64_t* item_ptr,
-                         const int32_t* item_pts, const int32_t* item_nbr) {
+                         const int32_t* item_pts, const int32_t* item_nbr, const int64_t* down_rowptr, const int32_t* down_cols,
+                         const double* down_vals) {
   FEMO_REQUIRE(s && node_xyz && item_ptr && item_pts && item_nbr, "null argument");
   FEMO_REQUIRE(s->pc_width > 0, "femo_shell_pc_coarse needs femo_shell_pc_create first");
   FEMO_REQUIRE(level >= 0 && level < s->pc_levels - 1 && n_items > 0 && s->cs_level < 0, "bad coarse-solve level");
@@ -1824,6 +1860,14 @@ int femo_shell_pc_coarse(femo_shell* s, int level, const int32_t* node_xyz, int6
                      s->d_ell_idx, s->d_cs_xyz, s->d_cs_pcell);
   FEMO_HIP_CHECK(hipGetLastError());
   FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  if (down_rowptr != nullptr && down_cols != nullptr && down_vals != nullptr) {
+    // rows: the nodes of levels `level` .. L - 2 in their global order, columns: global node numbers of the finest lattice
+    const int64_t rows = s->level_off[s->pc_levels - 1] - s->level_off[level];
+    FEMO_TRY(to_device(&s->d_cd_rowptr, down_rowptr, rows + 1, st));
+    FEMO_TRY(to_device(&s->d_cd_cols, down_cols, down_rowptr[rows], st));
+    FEMO_TRY(to_device(&s->d_cd_vals, down_vals, down_rowptr[rows], st));
+    FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  }
   FEMO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pc_coarse_galerkin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CG_LDS));
   s->cs_level = level; s->cs_n = n; s->cs_N = N; s->cs_items = n_items;
   s->pc_vals_uid = 0; s->pc_vals_gen = 0;                 // next solve recomputes the preconditioner's numbers

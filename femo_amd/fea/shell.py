@@ -248,8 +248,24 @@ def coarse_solve_plan(L: dict, max_unknowns: int = 3200, chunk: int = 256):
                 pos = np.minimum(np.searchsorted(g, gid), g.size - 1)
                 ok &= g[pos] == gid
                 nbr[ok, lz * 16 + ly * 4 + lx] = pos[ok]
+    # composite restriction from the finest lattice to every level c .. F - 1 (g_l = T_l^T g_{l+1} chained on the host):
+    # one launch per iteration instead of F - c
+    import scipy.sparse as sp
+    nn, F = int(L["n_nodes"]), len(levels) - 1
+    Tc = sp.csr_matrix((L["chi_vals"], L["chi_cols"], L["chi_rowptr"]), shape=(nn, nn))
+    comp, R = [], None
+    for l in range(F - 1, c - 1, -1):
+        rows = Tc[off[l]:off[l + 1]]                          # level l from level l + 1 (global column numbers)
+        R = rows if R is None else (rows[:, off[l + 1]:off[l + 2]] @ R).tocsr()
+        comp.append(R)
+    down = sp.vstack(comp[::-1]).tocsr() if comp else None   # rows: levels c, c + 1, ..., F - 1 in node order
+    if down is not None:
+        down.sort_indices()
     return dict(level=int(c), node_xyz=np.ascontiguousarray(xyz), item_ptr=item_ptr,
-                item_pts=np.ascontiguousarray(order, dtype=np.int32), item_nbr=np.ascontiguousarray(nbr))
+                item_pts=np.ascontiguousarray(order, dtype=np.int32), item_nbr=np.ascontiguousarray(nbr),
+                down_rowptr=None if down is None else down.indptr.astype(np.int64),
+                down_cols=None if down is None else down.indices.astype(np.int32),
+                down_vals=None if down is None else np.ascontiguousarray(down.data, dtype=np.float64))
 
 
 class DeviceShell:
@@ -287,8 +303,10 @@ class DeviceShell:
         if coarse_unknowns > 0:
             plan = coarse_solve_plan(L, coarse_unknowns)
             if plan is not None:
+                q = lambda a: None if a is None else C.c_void_p(a.ctypes.data)
                 check(self.lib.femo_shell_pc_coarse(self.handle, plan["level"], p(plan["node_xyz"]), plan["item_ptr"].size - 1,
-                                                    p(plan["item_ptr"]), p(plan["item_pts"]), p(plan["item_nbr"])))
+                                                    p(plan["item_ptr"]), p(plan["item_pts"]), p(plan["item_nbr"]),
+                                                    q(plan["down_rowptr"]), q(plan["down_cols"]), q(plan["down_vals"])))
                 self.coarse_level = plan["level"]
 
     def coarse_matrix(self, vals: Vec, fixed: Optional[np.ndarray] = None, inverse: bool = False) -> np.ndarray:

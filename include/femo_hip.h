@@ -392,9 +392,13 @@ int femo_shell_pc_create(femo_shell* s, int width, int64_t n_nodes, int n_levels
  *   node_xyz   int32[3 x nodes]: lattice coordinates of the level's nodes (level-local numbering)
  *   item_*     work items of the Galerkin kernel: points (first dof / 3) of one coarse cell and one field group, any
  *              number each, 256 by default (item_ptr n_items + 1, item_pts), and the level-local numbers of the 4 x 4 x 4 nodes around
- *              the cell (item_nbr 64 per item, x fastest, -1 where the surface does not touch the lattice)            */
+ *              the cell (item_nbr 64 per item, x fastest, -1 where the surface does not touch the lattice)
+ *   down_*     optional (NULL: level by level): composite restriction from the finest lattice's nodes to the nodes of
+ *              levels `level` .. n_levels - 2 as CSR (rows in node order, columns = node numbers on the finest lattice):
+ *              one launch per iteration in place of n_levels - 1 - level                                             */
 int femo_shell_pc_coarse(femo_shell* s, int level, const int32_t* node_xyz, int64_t n_items, const int64_t* item_ptr,
-                         const int32_t* item_pts, const int32_t* item_nbr);
+                         const int32_t* item_pts, const int32_t* item_nbr, const int64_t* down_rowptr, const int32_t* down_cols,
+                         const double* down_vals);
 /* For tests: the dense coarse operator (inverse = 0) or the factors of its inverse (1: L^-T above, L^-1 below the
  * diagonal) for `vals` and the mask, row-major n x n into `out` (host; NULL: only *n_out).                           */
 int femo_shell_pc_coarse_matrix(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_host, int inverse, double* out,
