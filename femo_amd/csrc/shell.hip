@@ -1235,9 +1235,10 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_restrict(int64_t m0, int64_t m1
     for (int64_t e = rowptr[row] + sl; e < e1; e += SUB) {
       const int32_t c = cols[e];
       const double w = vals[e];
-      s0 += w * r[c];
-      s1 += w * r[c + 1];
-      s2 += w * r[c + 2];
+      const Triple rc = *reinterpret_cast<const Triple*>(r + c);
+      s0 += w * rc.a;
+      s1 += w * rc.b;
+      s2 += w * rc.c;
     }
 #pragma unroll
     for (int off = SUB / 2; off > 0; off >>= 1) {
@@ -1463,8 +1464,8 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong(int64_t n_pts, const in
   double dot = 0.0;
   for (int64_t p = (int64_t)blockIdx.x * (SH_BLOCK / SUB) + (threadIdx.x / SUB); p < n_pts; p += nsub) {
     const double w = fin_w[p * 8 + sl];
-    const double* tp = t + fin_idx[p * 8 + sl];
-    double s0 = w * tp[0], s1 = w * tp[1], s2 = w * tp[2];
+    const Triple tp = *reinterpret_cast<const Triple*>(t + fin_idx[p * 8 + sl]);
+    double s0 = w * tp.a, s1 = w * tp.b, s2 = w * tp.c;
 #pragma unroll
     for (int off = SUB / 2; off > 0; off >>= 1) {
       s0 += __shfl_xor(s0, off, 64);
@@ -1477,8 +1478,8 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong(int64_t n_pts, const in
       const double ri = r[row];
       double sm;                                           // the smoother: point-block (3 x 3) or plain Jacobi
       if (dinv3 != nullptr) {
-        const double* B = dinv3 + 9 * p + 3 * sl;
-        sm = B[0] * r[3 * p] + B[1] * r[3 * p + 1] + B[2] * r[3 * p + 2];
+        const Triple B = *reinterpret_cast<const Triple*>(dinv3 + 9 * p + 3 * sl), rp = *reinterpret_cast<const Triple*>(r + 3 * p);
+        sm = B.a * rp.a + B.b * rp.b + B.c * rp.c;
       } else {
         sm = dinv[row] * ri;
       }
