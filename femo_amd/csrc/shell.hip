@@ -1023,37 +1023,57 @@ __global__ __launch_bounds__(256) void k_chol_diag(int64_t N, int kb, double* __
   double* g = A + ((int64_t)kb * DT) * N + (int64_t)kb * DT;
   tile_load(a, g, N, false);
   __syncthreads();
-  // (Measured alternatives for this tile: one wave working on the LDS copy without workgroup barriers, 11.5 instead of
-  // 10.1 ms for the whole factorisation -- dependent LDS read-modify-writes; the row in registers with both loops
-  // unrolled -- 2 k spilled registers.)
-  for (int p = 0; p < DT; ++p) {
-    const double d = a[p][p];
-    __syncthreads();
-    if (!(d > 0.0)) { if (threadIdx.x == 0) atomicOr(&info[2], 1); return; }
-    const double sd = sqrt(d);
-    if (threadIdx.x == 0) a[p][p] = sd;
-    else if (threadIdx.x > p && threadIdx.x < DT) a[threadIdx.x][p] /= sd;
-    __syncthreads();
-    const int m = DT - 1 - p;                              // trailing block (p, DT) x (p, DT), lower part
-    for (int idx = threadIdx.x; idx < m * m; idx += 256) {
-      const int r = p + 1 + idx / m, c = p + 1 + idx % m;
-      if (r >= c) a[r][c] -= a[r][p] * a[c][p];
+  // One wave factorises the tile column by column, lane r holding row r in registers (static indices: both loops
+  // unrolled); the finished entries live in LDS as well, where the other lanes read row c as broadcasts:
+  //   L[r][c] = (A[r][c] - sum_{k < c} L[r][k] L[c][k]) / L[c][c].
+  // LDS operations of one wave execute in program order; the fences pin the compiler.  (History of this tile: three
+  // workgroup barriers per column and the inverse through LDS 169 us, 8 of the factorisation's 10 ms; a wave working on
+  // the LDS copy in place was slower (dependent read-modify-writes); a right-looking register version spilled 2 k
+  // registers.)
+#define FEMO_WAVE_SYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier()
+  if (threadIdx.x < DT) {
+    const int r = threadIdx.x;
+    double row[DT];
+#pragma unroll
+    for (int c = 0; c < DT; ++c) row[c] = a[r][c];
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < DT; ++c) {
+      double sum = 0.0;
+#pragma unroll
+      for (int k = 0; k < c; ++k) sum += row[k] * a[c][k];
+      const double v = row[c] - sum;
+      if (r == c) {
+        if (!(v > 0.0)) bad = true;
+        row[c] = sqrt(v > 0.0 ? v : 1.0);
+        a[c][c] = row[c];
+      }
+      FEMO_WAVE_SYNC();
+      if (r > c) {
+        row[c] = v / a[c][c];
+        a[r][c] = row[c];
+      }
+      FEMO_WAVE_SYNC();
     }
-    __syncthreads();
+    if (bad) atomicOr(&info[2], 1);
   }
-  // inverse: thread c solves L x = e_c
+#undef FEMO_WAVE_SYNC
+  __syncthreads();
+  // inverse: thread c solves L x = e_c with its column in registers; the loops are uniform (entries above the
+  // diagonal of the column are zeros), so every read of L is an LDS broadcast and the unrolled code has static
+  // register indices
   if (threadIdx.x < DT) {
     const int c = threadIdx.x;
+    double x[DT];
+#pragma unroll
     for (int r = 0; r < DT; ++r) {
       double v = r == c ? 1.0 : 0.0;
-      if (r >= c) {
-        for (int k = c; k < r; ++k) v -= a[r][k] * w[k][c];
-        v /= a[r][r];
-      } else {
-        v = 0.0;
-      }
-      w[r][c] = v;
+#pragma unroll
+      for (int k = 0; k < r; ++k) v -= a[r][k] * x[k];
+      x[r] = r >= c ? v / a[r][r] : 0.0;
     }
+#pragma unroll
+    for (int r = 0; r < DT; ++r) w[r][c] = x[r];
   }
   __syncthreads();
   for (int idx = threadIdx.x; idx < DT * DT; idx += 256) {
