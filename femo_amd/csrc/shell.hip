@@ -1356,9 +1356,11 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_galerkin_blocks(int64_t n_pts, 
 #pragma unroll
   for (int a = 0; a < 8; ++a) {
     if (nd[a] < 0) continue;
+    // upper triangle only (the block is symmetric; k_pc_invert_blocks mirrors it): the atomics are three quarters of
+    // this kernel's time (7.4 ms with, 1.75 ms without them at 988 k dofs)
 #pragma unroll
     for (int q = 0; q < 6; ++q)
-      if (acc[a][q] != 0.0) atomicAdd(&blk[36 * (int64_t)nd[a] + 6 * (3 * gi + fa) + q], wi[a] * acc[a][q]);
+      if (q >= 3 * gi + fa && acc[a][q] != 0.0) atomicAdd(&blk[36 * (int64_t)nd[a] + 6 * (3 * gi + fa) + q], wi[a] * acc[a][q]);
   }
 }
 
@@ -1413,7 +1415,7 @@ __global__ void k_pc_invert_blocks(int64_t node0, int64_t node1, double* __restr
 #pragma unroll
   for (int r = 0; r < 6; ++r)
 #pragma unroll
-    for (int c = 0; c < 6; ++c) { a[r][c] = 0.5 * (B[6 * r + c] + B[6 * c + r]); inv[r][c] = r == c ? 1.0 : 0.0; }
+    for (int c = 0; c < 6; ++c) { a[r][c] = r <= c ? B[6 * r + c] : B[6 * c + r]; inv[r][c] = r == c ? 1.0 : 0.0; }    // upper triangle holds the sums
 #pragma unroll
   for (int r = 0; r < 6; ++r) dead[r] = !(a[r][r] > 0.0);
 #pragma unroll
