@@ -1309,58 +1309,93 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_galerkin_blocks(int64_t n_pts, 
                                                                  const int32_t* __restrict__ bcols, const double* __restrict__ vals,
                                                                  const uint8_t* __restrict__ fixed, const int32_t* __restrict__ ell_idx,
                                                                  const double* __restrict__ ell_w, double* __restrict__ blk, int first_slot) {
-  const int nlev = (width - first_slot) >> 3;
-  const int64_t t = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x;
-  const int fa = (int)(t % 3);
-  const int64_t pl = t / 3;
-  const int64_t p = pl / nlev;
-  const int lev8 = first_slot + 8 * (int)(pl % nlev);
-  if (p >= n_pts || (fixed != nullptr && fixed[3 * p + fa])) return;
-  int32_t nd[8];
-  double wi[8], acc[8][6];
+  // A workgroup = 256 consecutive points, one level, one component (blockIdx.y = 3 level + fa): neighbouring points
+  // touch the same few dozen lattice nodes, so their sums are combined in an LDS hash table (key = node and field
+  // group) and leave the workgroup as one global atomic per entry -- the global atomics were three quarters of this
+  // kernel's time (7.4 ms with, 1.75 without them at 988 k dofs).
+  constexpr int HS = 512;
+  __shared__ int32_t h_key[HS];
+  __shared__ double h_val[HS][6];
+  for (int i = threadIdx.x; i < HS; i += SH_BLOCK) {
+    h_key[i] = -1;
 #pragma unroll
-  for (int a = 0; a < 8; ++a) {
-    nd[a] = ell_idx[(3 * p) * width + lev8 + a] / 6;
-    wi[a] = ell_w[(3 * p) * width + lev8 + a];
-    if (wi[a] == 0.0) nd[a] = -1;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) acc[a][q] = 0.0;
+    for (int q = 0; q < 6; ++q) h_val[i][q] = 0.0;
   }
-  const int gi = p >= n_unode ? 1 : 0;
-  const int64_t k0 = brow[p], k1 = brow[p + 1], len = 3 * (k1 - k0);
-  const double* v = vals + 9 * k0 + fa * len;
-  for (int64_t k = k0; k < k1; ++k) {
-    const int32_t cj = bcols[k];
-    const int32_t* ik = ell_idx + (int64_t)cj * width + lev8;
-    const double* wk = ell_w + (int64_t)cj * width + lev8;
-    const int64_t o = 3 * (k - k0);
-    double m0 = v[o], m1 = v[o + 1], m2 = v[o + 2];
-    if (fixed != nullptr) {
-      if (fixed[cj]) m0 = 0.0;
-      if (fixed[cj + 1]) m1 = 0.0;
-      if (fixed[cj + 2]) m2 = 0.0;
+  __syncthreads();
+  const int fa = (int)(blockIdx.y % 3);
+  const int lev8 = first_slot + 8 * (int)(blockIdx.y / 3);
+  const int64_t p = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x;
+  const bool active = p < n_pts && !(fixed != nullptr && fixed[3 * p + fa]);
+  if (active) {
+    int32_t nd[8];
+    double wi[8], acc[8][6];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      nd[a] = ell_idx[(3 * p) * width + lev8 + a] / 6;
+      wi[a] = ell_w[(3 * p) * width + lev8 + a];
+      if (wi[a] == 0.0) nd[a] = -1;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) acc[a][q] = 0.0;
     }
-    const bool gj = cj >= 3 * n_unode;
+    const int gi = p >= n_unode ? 1 : 0;
+    const int64_t k0 = brow[p], k1 = brow[p + 1], len = 3 * (k1 - k0);
+    const double* v = vals + 9 * k0 + fa * len;
+    for (int64_t k = k0; k < k1; ++k) {
+      const int32_t cj = bcols[k];
+      const int32_t* ik = ell_idx + (int64_t)cj * width + lev8;
+      const double* wk = ell_w + (int64_t)cj * width + lev8;
+      const int64_t o = 3 * (k - k0);
+      double m0 = v[o], m1 = v[o + 1], m2 = v[o + 2];
+      if (fixed != nullptr) {
+        if (fixed[cj]) m0 = 0.0;
+        if (fixed[cj + 1]) m1 = 0.0;
+        if (fixed[cj + 2]) m2 = 0.0;
+      }
+      const bool gj = cj >= 3 * n_unode;
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const int32_t nb = ik[b] / 6;
-      const double wb = wk[b];
+      for (int b = 0; b < 8; ++b) {
+        const int32_t nb = ik[b] / 6;
+        const double wb = wk[b];
 #pragma unroll
-      for (int a = 0; a < 8; ++a) {
-        const double ww = nb == nd[a] ? wb : 0.0;
-        if (gj) { acc[a][3] += ww * m0; acc[a][4] += ww * m1; acc[a][5] += ww * m2; }
-        else { acc[a][0] += ww * m0; acc[a][1] += ww * m1; acc[a][2] += ww * m2; }
+        for (int a = 0; a < 8; ++a) {
+          const double ww = nb == nd[a] ? wb : 0.0;
+          if (gj) { acc[a][3] += ww * m0; acc[a][4] += ww * m1; acc[a][5] += ww * m2; }
+          else { acc[a][0] += ww * m0; acc[a][1] += ww * m1; acc[a][2] += ww * m2; }
+        }
+      }
+    }
+    // upper triangle only (the block is symmetric; k_pc_invert_blocks mirrors it)
+    const int fi = 3 * gi + fa;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      if (nd[a] < 0) continue;
+      const int32_t key = 2 * nd[a] + gi;
+      int h = (int)(((uint32_t)key * 2654435761u) >> 23) & (HS - 1);
+      int slot = -1;
+      for (int probe = 0; probe < 16; ++probe) {
+        const int32_t seen = atomicCAS(&h_key[h], -1, key);
+        if (seen == -1 || seen == key) { slot = h; break; }
+        h = (h + 1) & (HS - 1);
+      }
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        if (q < fi || acc[a][q] == 0.0) continue;
+        const double val = wi[a] * acc[a][q];
+        if (slot >= 0) __hip_atomic_fetch_add(&h_val[slot][q], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else atomicAdd(&blk[36 * (int64_t)nd[a] + 6 * fi + q], val);          // table full around this key: straight to memory
       }
     }
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < HS; i += SH_BLOCK) {
+    const int32_t key = h_key[i];
+    if (key < 0) continue;
+    const int fi = 3 * (key & 1) + fa;
 #pragma unroll
-  for (int a = 0; a < 8; ++a) {
-    if (nd[a] < 0) continue;
-    // upper triangle only (the block is symmetric; k_pc_invert_blocks mirrors it): the atomics are three quarters of
-    // this kernel's time (7.4 ms with, 1.75 ms without them at 988 k dofs)
-#pragma unroll
-    for (int q = 0; q < 6; ++q)
-      if (q >= 3 * gi + fa && acc[a][q] != 0.0) atomicAdd(&blk[36 * (int64_t)nd[a] + 6 * (3 * gi + fa) + q], wi[a] * acc[a][q]);
+    for (int q = 0; q < 6; ++q) {
+      const double val = h_val[i][q];
+      if (q >= fi && val != 0.0) atomicAdd(&blk[36 * (int64_t)(key >> 1) + 6 * fi + q], val);
+    }
   }
 }
 
@@ -2090,7 +2125,7 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
       if (s->cs_ready && getenv("FEMO_SHELL_NO_BLOCKS") == nullptr) {
         const int64_t nd0 = s->level_off[s->cs_level + 1], nd1 = s->level_off[s->pc_levels];
         FEMO_HIP_CHECK(hipMemsetAsync(s->d_cblk + 36 * nd0, 0, (nd1 - nd0) * 36 * sizeof(double), st));
-        hipLaunchKernelGGL(k_pc_galerkin_blocks, dim3(sgrid((n / 3) * 3 * ((s->pc_width - first_slot) / 8))), dim3(SH_BLOCK), 0, st, n / 3, s->pc_width,
+        hipLaunchKernelGGL(k_pc_galerkin_blocks, dim3(sgrid(n / 3), 3 * ((s->pc_width - first_slot) / 8)), dim3(SH_BLOCK), 0, st, n / 3, s->pc_width,
                            s->n_unode, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_ell_idx, s->d_ell_w, s->d_cblk, first_slot);
         hipLaunchKernelGGL(k_pc_invert_blocks, dim3(sgrid(nd1 - nd0, 256)), dim3(256), 0, st, nd0, nd1, s->d_cblk);
         s->blk_ready = true;
