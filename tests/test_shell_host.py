@@ -65,3 +65,20 @@ def test_coarse_solve_plan():
         for k in range(8):
             loc = (o[:, 0] + (k & 1)) + 4 * (o[:, 1] + ((k >> 1) & 1)) + 16 * (o[:, 2] + ((k >> 2) & 1))
             assert np.array_equal(nbr[it, loc], node[j, k])
+
+
+def test_composite_restriction_is_the_chain_of_node_transfers():
+    pts, conn = so.scordelis_lo_mesh(64, 64)
+    L = lattice_pc(ShellSpace(pts, conn))
+    plan = coarse_solve_plan(L)
+    off, c, F, nn = L["level_offsets"], plan["level"], len(L["levels"]) - 1, L["n_nodes"]
+    assert F - c >= 1
+    Tc = sp.csr_matrix((L["chi_vals"], L["chi_cols"], L["chi_rowptr"]), shape=(nn, nn))
+    g = np.zeros(nn)
+    g[off[F]:off[F + 1]] = np.random.default_rng(0).standard_normal(off[F + 1] - off[F])
+    chain = g.copy()
+    for l in range(F - 1, c - 1, -1):
+        chain[off[l]:off[l + 1]] = (Tc @ chain)[off[l]:off[l + 1]]
+    D = sp.csr_matrix((plan["down_vals"], plan["down_cols"], plan["down_rowptr"]), shape=(off[F] - off[c], nn))
+    assert plan["down_cols"].min() >= off[F]                                  # reads the finest lattice only
+    assert np.abs(D @ g - chain[off[c]:off[F]]).max() <= 1e-14 * np.abs(g).max()
