@@ -562,28 +562,29 @@ __global__ __launch_bounds__(SH_BLOCK) void k_bcsr3_spmv(int64_t nb, const int64
   }
 }
 
-// ---- block-SELL-16 ----
-// copy of the CSR values into the slice layout: group g = bs_off[slice] + slot holds block `slot` of the slice's 16
-// block rows: cols[16 g + lane], vals[(9 g + comp) 16 + lane]; rows with fewer blocks are padded (column = own, 0)
+// ---- block-SELL ----
+constexpr int BSW = 32;                                  // block rows per slice (16 / 32 / 64: 0.355 / 0.347 / 0.355 ms per iteration at 1.97 M dofs)
+// copy of the CSR values into the slice layout: group g = bs_off[slice] + slot holds block `slot` of the slice's BSW
+// block rows: cols[BSW g + lane], vals[(9 g + comp) BSW + lane]; rows with fewer blocks are padded (column = own, 0)
 __global__ __launch_bounds__(256) void k_bsell_fill(int64_t nb, const int64_t* __restrict__ brow, const int32_t* __restrict__ bcols,
                                                     const double* __restrict__ vals, const int64_t* __restrict__ bs_off,
                                                     int32_t* __restrict__ cols, double* __restrict__ out) {
   const int64_t slice = blockIdx.x;
-  const int lane = threadIdx.x & 15, sub = threadIdx.x >> 4;          // 16 slots in flight per pass
-  const int64_t b = slice * 16 + lane;
+  const int lane = threadIdx.x & (BSW - 1), sub = threadIdx.x / BSW;   // 256 / BSW slots in flight per pass
+  const int64_t b = slice * BSW + lane;
   const int64_t g0 = bs_off[slice], nslot = bs_off[slice + 1] - g0;
   int64_t k0 = 0, k1 = 0;
   if (b < nb) { k0 = brow[b]; k1 = brow[b + 1]; }
   const int64_t len = 3 * (k1 - k0);
-  for (int64_t sl = sub; sl < nslot; sl += 16) {
+  for (int64_t sl = sub; sl < nslot; sl += 256 / BSW) {
     const int64_t g = g0 + sl;
     const bool have = k0 + sl < k1;
-    cols[16 * g + lane] = have ? bcols[k0 + sl] : (int32_t)(b < nb ? 3 * b : 0);
+    cols[BSW * g + lane] = have ? bcols[k0 + sl] : (int32_t)(b < nb ? 3 * b : 0);
     const double* v = vals + 9 * k0 + 3 * sl;
 #pragma unroll
     for (int fa = 0; fa < 3; ++fa)
 #pragma unroll
-      for (int fb = 0; fb < 3; ++fb) out[(9 * g + 3 * fa + fb) * 16 + lane] = have ? v[fa * len + fb] : 0.0;
+      for (int fb = 0; fb < 3; ++fb) out[(9 * g + 3 * fa + fb) * BSW + lane] = have ? v[fa * len + fb] : 0.0;
   }
 }
 
@@ -597,25 +598,25 @@ __global__ __launch_bounds__(SH_BLOCK) void k_bsell_spmv(int64_t nb, int64_t n_s
   if (done != nullptr && *done) return;
   if (commit_dst != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *commit_dst = *commit_src;
   __shared__ double lds[SH_BLOCK / 64];
-  const int lane = threadIdx.x & 15;
-  const int64_t nsub = (int64_t)gridDim.x * (SH_BLOCK / 16);
+  const int lane = threadIdx.x & (BSW - 1);
+  const int64_t nsub = (int64_t)gridDim.x * (SH_BLOCK / BSW);
   double dot = 0.0;
-  for (int64_t slice = (int64_t)blockIdx.x * (SH_BLOCK / 16) + (threadIdx.x >> 4); slice < n_slice; slice += nsub) {
+  for (int64_t slice = (int64_t)blockIdx.x * (SH_BLOCK / BSW) + (threadIdx.x / BSW); slice < n_slice; slice += nsub) {
     const int64_t g0 = bs_off[slice], g1 = bs_off[slice + 1];
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     for (int64_t g = g0; g < g1; ++g) {
-      const double* v = vals + (9 * g) * 16 + lane;
+      const double* v = vals + (9 * g) * BSW + lane;
       // nontemporal: every line is used by exactly one instruction here (plain loads: 0.401 against 0.390 ms per iteration)
-      const int32_t c = __builtin_nontemporal_load(cols + 16 * g + lane);
-      const double a00 = __builtin_nontemporal_load(v), a01 = __builtin_nontemporal_load(v + 16), a02 = __builtin_nontemporal_load(v + 32);
-      const double a10 = __builtin_nontemporal_load(v + 48), a11 = __builtin_nontemporal_load(v + 64), a12 = __builtin_nontemporal_load(v + 80);
-      const double a20 = __builtin_nontemporal_load(v + 96), a21 = __builtin_nontemporal_load(v + 112), a22 = __builtin_nontemporal_load(v + 128);
+      const int32_t c = __builtin_nontemporal_load(cols + BSW * g + lane);
+      const double a00 = __builtin_nontemporal_load(v), a01 = __builtin_nontemporal_load(v + 1 * BSW), a02 = __builtin_nontemporal_load(v + 2 * BSW);
+      const double a10 = __builtin_nontemporal_load(v + 3 * BSW), a11 = __builtin_nontemporal_load(v + 4 * BSW), a12 = __builtin_nontemporal_load(v + 5 * BSW);
+      const double a20 = __builtin_nontemporal_load(v + 6 * BSW), a21 = __builtin_nontemporal_load(v + 7 * BSW), a22 = __builtin_nontemporal_load(v + 8 * BSW);
       const Triple xc = *reinterpret_cast<const Triple*>(x + c);
       s0 += a00 * xc.a + a01 * xc.b + a02 * xc.c;
       s1 += a10 * xc.a + a11 * xc.b + a12 * xc.c;
       s2 += a20 * xc.a + a21 * xc.b + a22 * xc.c;
     }
-    const int64_t b = slice * 16 + lane;
+    const int64_t b = slice * BSW + lane;
     if (b < nb) {
       const Triple xr = *reinterpret_cast<const Triple*>(x + 3 * b);
       const bool f0 = fixed != nullptr && fixed[3 * b], f1 = fixed != nullptr && fixed[3 * b + 1], f2 = fixed != nullptr && fixed[3 * b + 2];
@@ -1665,18 +1666,18 @@ int femo_shell_create(femo_ctx* ctx, int64_t n_vert, const double* x, int64_t n_
       s->n_bnode = nbn;
       FEMO_TRY(to_device(&s->d_brow, brow.data(), nbn + 1, st));
       FEMO_TRY(to_device(&s->d_bcols, bcols.data(), (int64_t)bcols.size(), st));
-      // block-SELL-16: slots per slice = the longest of its 16 block rows
-      const int64_t nsl = (nbn + 15) / 16;
+      // block-SELL: slots per slice = the longest of its BSW block rows
+      const int64_t nsl = (nbn + BSW - 1) / BSW;
       std::vector<int64_t> off((size_t)nsl + 1, 0);
       for (int64_t sl = 0; sl < nsl; ++sl) {
         int64_t mx = 0;
-        for (int64_t b = 16 * sl; b < std::min<int64_t>(16 * sl + 16, nbn); ++b) mx = std::max(mx, brow[(size_t)b + 1] - brow[(size_t)b]);
+        for (int64_t b = BSW * sl; b < std::min<int64_t>(BSW * sl + BSW, nbn); ++b) mx = std::max(mx, brow[(size_t)b + 1] - brow[(size_t)b]);
         off[(size_t)sl + 1] = off[(size_t)sl] + mx;
       }
       s->n_bslice = nsl; s->bsell_blocks = off[(size_t)nsl];
       FEMO_TRY(to_device(&s->d_bs_off, off.data(), nsl + 1, st));
-      FEMO_HIP_CHECK(hipMalloc(&s->d_bs_cols, std::max<int64_t>(s->bsell_blocks, 1) * 16 * sizeof(int32_t)));
-      FEMO_HIP_CHECK(hipMalloc(&s->d_bs_vals, std::max<int64_t>(s->bsell_blocks, 1) * 144 * sizeof(double)));
+      FEMO_HIP_CHECK(hipMalloc(&s->d_bs_cols, std::max<int64_t>(s->bsell_blocks, 1) * BSW * sizeof(int32_t)));
+      FEMO_HIP_CHECK(hipMalloc(&s->d_bs_vals, std::max<int64_t>(s->bsell_blocks, 1) * 9 * BSW * sizeof(double)));
       FEMO_HIP_CHECK(hipStreamSynchronize(st));
     }
   }
@@ -2090,7 +2091,7 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
   const bool bsell = s->d_bs_vals != nullptr && getenv("FEMO_SHELL_NO_BSELL") == nullptr;
   // block-SELL: 16 slices per workgroup pass, at most 2048 workgroups (0.376 ms per iteration at 1.97 M dofs against
   // 0.390 with one pass per workgroup: fewer partial sums for the consumers to fold)
-  const unsigned gs = bsell ? std::min<unsigned>(sgrid(s->n_bslice, SH_BLOCK / 16), 2048u)
+  const unsigned gs = bsell ? std::min<unsigned>(sgrid(s->n_bslice, SH_BLOCK / BSW), 2048u)
                             : std::min<unsigned>(s->d_brow != nullptr ? sgrid(s->n_bnode, SH_BLOCK / 16) : sgrid(n, SH_BLOCK / 16), SH_MAXPART);
   double *Ppq = s->d_part, *Prz = s->d_part + SH_MAXPART, *gam = s->d_scal + 4;
   FEMO_HIP_CHECK(hipEventRecord(ctx->ev0, st));
