@@ -414,6 +414,65 @@ __global__ __launch_bounds__(SH_BLOCK) void k_shell_compliance(femo_shell_view S
 }
 
 // int rho h (partials) and its gradient rho |T| / 3 per vertex
+// J = 1 / alpha int (m sigma_vm)^rho dx, sigma_vm the von Mises stress of the in-plane stress C (eps + z kappa) at
+// z = surface * h / 2 (oracle/shell_oracle.py::pnorm_stress; shell_pde.py:297-313), degree-4 rule; partials: per-block
+// sums of the value, grad_w += dJ/dw (n_dof), grad_h += dJ/dh (n_vert).  One thread per cell.
+__global__ __launch_bounds__(SH_BLOCK) void k_shell_pnorm_stress(femo_shell_view S, double E, double nu, const double* __restrict__ h,
+                                                                 const double* __restrict__ w, double mscale, double rho, double inv_alpha,
+                                                                 double surface, double* __restrict__ partials, double* __restrict__ grad_w,
+                                                                 double* __restrict__ grad_h) {
+  __shared__ double lds[SH_BLOCK / 64];
+  const int64_t c = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x;
+  double val = 0.0;
+  if (c < S.n_cell) {
+    Facet F;
+    facet_frame(S.x, S.conn, c, F);
+    const Material mt = material(E, nu);
+    const double hv[3] = {h[S.conn[c * 3]], h[S.conn[c * 3 + 1]], h[S.conn[c * 3 + 2]]};
+    double we[27], gw[27];
+    for (int i = 0; i < 27; ++i) { we[i] = w[shell_gdof(S, c, i)]; gw[i] = 0.0; }
+    double gh[3] = {0.0, 0.0, 0.0};
+    for (int q = 0; q < 6; ++q) {
+      const double* lam = c_lam6[q];
+      const double z = 0.5 * surface * (hv[0] * lam[0] + hv[1] * lam[1] + hv[2] * lam[2]);
+      const double wq = c_w6[q] * F.area;
+      double sw[9];
+      element_strain(F, lam, we, sw);
+      const double e0 = sw[0] + z * sw[3], e1 = sw[1] + z * sw[4], e2 = sw[2] + z * sw[5];
+      const double s0 = mt.c11 * e0 + mt.c12 * e1, s1 = mt.c12 * e0 + mt.c11 * e1, s2 = mt.c33 * e2;
+      const double vm = sqrt(s0 * s0 - s0 * s1 + s1 * s1 + 3.0 * s2 * s2);
+      if (!(vm > 0.0)) continue;
+      const double pw = pow(mscale * vm, rho - 1.0);
+      val += wq * pw * mscale * vm * inv_alpha;
+      if (grad_w == nullptr && grad_h == nullptr) continue;
+      const double fac = wq * rho * mscale * pw * inv_alpha / (2.0 * vm);             // dJ/dvm / (2 vm)
+      const double d0 = fac * (2.0 * s0 - s1), d1 = fac * (2.0 * s1 - s0), d2 = fac * 6.0 * s2;   // dJ / d sigma
+      const double t0 = mt.c11 * d0 + mt.c12 * d1, t1 = mt.c12 * d0 + mt.c11 * d1, t2 = mt.c33 * d2;   // dJ / d (eps + z kappa)
+      const double dk = 0.5 * surface * (t0 * sw[3] + t1 * sw[4] + t2 * sw[5]);
+#pragma unroll
+      for (int b = 0; b < 3; ++b) gh[b] += dk * lam[b];
+      if (grad_w != nullptr) {
+        for (int col = 0; col < 27; ++col) {
+          double bc[9];
+          strain_column(F, lam, col, bc);
+          gw[col] += t0 * (bc[0] + z * bc[3]) + t1 * (bc[1] + z * bc[4]) + t2 * (bc[2] + z * bc[5]);
+        }
+      }
+    }
+    if (grad_w != nullptr)
+      for (int i = 0; i < 27; ++i)
+        if (gw[i] != 0.0) atomicAdd(&grad_w[shell_gdof(S, c, i)], gw[i]);
+    if (grad_h != nullptr) {
+#pragma unroll
+      for (int b = 0; b < 3; ++b) atomicAdd(&grad_h[S.conn[c * 3 + b]], gh[b]);
+    }
+  }
+  if (partials != nullptr) {
+    const double t = femo_block_sum<SH_BLOCK>(val, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  }
+}
+
 __global__ __launch_bounds__(SH_BLOCK) void k_shell_mass(femo_shell_view S, double rho, const double* __restrict__ h, double* __restrict__ partials,
                                                          double* __restrict__ grad) {
   __shared__ double lds[SH_BLOCK / 64];
@@ -2049,6 +2108,30 @@ int femo_shell_compliance(femo_shell* s, const femo_vec* w, double* value, int a
     if (!accumulate) FEMO_HIP_CHECK(hipMemsetAsync(grad->d, 0, s->n_dof * sizeof(double), st));
   }
   hipLaunchKernelGGL(k_shell_compliance, dim3(g), dim3(SH_BLOCK), 0, st, view(s), w->d, value ? s->d_part : nullptr, grad ? grad->d : nullptr);
+  FEMO_HIP_CHECK(hipGetLastError());
+  if (value) FEMO_TRY(reduce_partials(s->ctx, s->d_part, (int)g, value));
+  return 0;
+}
+
+int femo_shell_pnorm_stress(femo_shell* s, double E, double nu, const femo_vec* h, const femo_vec* w, double m, double rho, double alpha,
+                            double surface, double* value, int accumulate, femo_vec* grad_w, femo_vec* grad_h) {
+  FEMO_REQUIRE(s && h && w, "null argument");
+  FEMO_REQUIRE(h->n >= s->n_vert && w->n >= s->n_dof && (grad_w == nullptr || grad_w->n >= s->n_dof) &&
+               (grad_h == nullptr || grad_h->n >= s->n_vert), "vector size mismatch in shell_pnorm_stress");
+  FEMO_REQUIRE(E > 0.0 && nu > -1.0 && nu < 0.5 && m > 0.0 && rho >= 1.0 && alpha > 0.0, "bad parameters of the stress aggregate");
+  hipStream_t st = s->ctx->stream;
+  const unsigned g = sgrid(s->n_cell);
+  FEMO_REQUIRE(value == nullptr || g <= 3 * SH_MAXPART, "mesh too large for the reduction buffer");
+  if (grad_w) {
+    femo_vec_touch(grad_w);
+    if (!accumulate) FEMO_HIP_CHECK(hipMemsetAsync(grad_w->d, 0, s->n_dof * sizeof(double), st));
+  }
+  if (grad_h) {
+    femo_vec_touch(grad_h);
+    if (!accumulate) FEMO_HIP_CHECK(hipMemsetAsync(grad_h->d, 0, s->n_vert * sizeof(double), st));
+  }
+  hipLaunchKernelGGL(k_shell_pnorm_stress, dim3(g), dim3(SH_BLOCK), 0, st, view(s), E, nu, h->d, w->d, m, rho, 1.0 / alpha, surface,
+                     value ? s->d_part : nullptr, grad_w ? grad_w->d : nullptr, grad_h ? grad_h->d : nullptr);
   FEMO_HIP_CHECK(hipGetLastError());
   if (value) FEMO_TRY(reduce_partials(s->ctx, s->d_part, (int)g, value));
   return 0;

@@ -363,6 +363,15 @@ class DeviceShell:
                                        grad.handle if grad is not None else None))
         return val.value
 
+    def pnorm_stress(self, Ey: float, nu: float, h: Vec, w: Vec, m: float, rho: float, alpha: float, surface: float = 1.0,
+                     grad_w: Optional[Vec] = None, grad_h: Optional[Vec] = None, value: bool = True, accumulate: bool = False):
+        val = C.c_double(0.0)
+        check(self.lib.femo_shell_pnorm_stress(self.handle, float(Ey), float(nu), h.handle, w.handle, float(m), float(rho), float(alpha),
+                                               float(surface), C.byref(val) if value else None, int(accumulate),
+                                               grad_w.handle if grad_w is not None else None,
+                                               grad_h.handle if grad_h is not None else None))
+        return val.value
+
     def solve(self, vals: Vec, b: Vec, x: Vec, fixed: Optional[np.ndarray] = None, xfix: Optional[Vec] = None,
               rtol: float = 1e-12, atol: float = 0.0, max_it: int = 2_000_000, check_every: int = 64, pc: str = "lattice"):
         if pc == "lattice":
@@ -479,6 +488,23 @@ class ShellProblem:
             M = self.dev.mass(rho, self.h, grad=self.gh)
             return M, np.array(self.gh.get())
         return self.dev.mass(rho, self.h)
+
+    def surface_area(self) -> float:
+        x, c = self.space.x, self.space.conn
+        return float(0.5 * np.linalg.norm(np.cross(x[c[:, 1]] - x[c[:, 0]], x[c[:, 2]] - x[c[:, 0]]), axis=1).sum())
+
+    def pnorm_stress(self, w: Optional[np.ndarray] = None, m: float = 1e-6, rho: float = 100.0, alpha: Optional[float] = None,
+                     surface: float = 1.0, grad: bool = False):
+        """`ShellPDE.pnorm_stress` (shell_pde.py:297-313): 1 / alpha int (m sigma_vm)^rho dx on the top (surface = +1), mid (0) or
+        bottom (-1) surface, alpha = surface area by default.  grad: also (dJ/dw, dJ/dh)."""
+        if w is not None:
+            self.w.set(np.ascontiguousarray(w, dtype=np.float64))
+        if alpha is None:
+            alpha = self.surface_area()
+        if grad:
+            J = self.dev.pnorm_stress(self.E, self.nu, self.h, self.w, m, rho, alpha, surface, grad_w=self.tmp, grad_h=self.gh)
+            return J, np.array(self.tmp.get()), np.array(self.gh.get())
+        return self.dev.pnorm_stress(self.E, self.nu, self.h, self.w, m, rho, alpha, surface)
 
     def elastic_energy(self, w: Optional[np.ndarray] = None) -> float:
         if w is not None:

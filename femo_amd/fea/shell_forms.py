@@ -360,8 +360,34 @@ class ShellElasticEnergy(_ShellScalar):
         return out.axpy(-0.5, half)                                                         # ... times 1/2
 
 
+class ShellPnormStress(_ShellScalar):
+    """1 / alpha int (m sigma_vm)^rho dx (shell_pde.py:297-313): the aggregated von Mises stress on the top (surface = +1),
+    mid (0) or bottom (-1) surface; alpha = surface area unless given."""
+
+    def __init__(self, w: Function, h: Function, E: float, nu: float, m: float = 1e-6, rho: float = 100.0,
+                 alpha: Optional[float] = None, surface: float = 1.0):
+        self.w, self.h, self.E, self.nu, self.mesh = w, h, float(E), float(nu), w.function_space.mesh
+        self.m, self.rho, self.surface = float(m), float(rho), float(surface)
+        if alpha is None:
+            x, c = self.mesh.x, self.mesh.conn
+            alpha = float(0.5 * np.linalg.norm(np.cross(x[c[:, 1]] - x[c[:, 0]], x[c[:, 2]] - x[c[:, 0]]), axis=1).sum())
+        self.alpha = float(alpha)
+
+    def functions(self):
+        return (self.w, self.h)
+
+    def assemble_scalar(self) -> float:
+        return self.mesh.device(_ctx()).pnorm_stress(self.E, self.nu, self.h.vec, self.w.vec, self.m, self.rho, self.alpha, self.surface)
+
+    def _gradient(self, wrt, out):
+        dev = self.mesh.device(_ctx())
+        kw = dict(grad_w=out) if wrt is self.w else dict(grad_h=out)
+        dev.pnorm_stress(self.E, self.nu, self.h.vec, self.w.vec, self.m, self.rho, self.alpha, self.surface, value=False, **kw)
+        return out
+
+
 class ShellPDE:
-    """`shell_pde.py:219-302` on the HIP engine: spaces and form builders with the reference's names."""
+    """`shell_pde.py:219-313` on the HIP engine: spaces and form builders with the reference's names."""
 
     def __init__(self, mesh: ShellMesh):
         self.mesh = mesh
@@ -385,3 +411,9 @@ class ShellPDE:
 
     def elastic_energy(self, w, h, E, nu=0.0) -> ShellElasticEnergy:
         return ShellElasticEnergy(w, h, E, nu)
+
+    def pnorm_stress(self, w, h, E, nu, dx=None, m=1e-6, rho=100, alpha=None, regularization=False, surface='Top') -> ShellPnormStress:
+        """shell_pde.py:297-313 (stress on the top surface there; 'Mid' / 'Bot' as in von_Mises_stress, :315-328)."""
+        if regularization:
+            raise NotImplementedError("pnorm_stress(regularization=True): add the thickness term as an output of its own")
+        return ShellPnormStress(w, h, E, nu, m=m, rho=rho, alpha=alpha, surface={'Top': 1.0, 'Mid': 0.0, 'Bot': -1.0}[surface])

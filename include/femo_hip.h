@@ -370,6 +370,11 @@ int femo_shell_dform_dh(femo_shell* s, double E, double nu, const femo_vec* h, c
 /* 1/2 int u_mid . u_mid (shell_pde.py:287-288) and its gradient; int rho h (shell_pde.py:293-294) and its gradient */
 int femo_shell_compliance(femo_shell* s, const femo_vec* w, double* value, int accumulate, femo_vec* grad);
 int femo_shell_mass(femo_shell* s, double rho, const femo_vec* h, double* value, int accumulate, femo_vec* grad);
+/* J = 1 / alpha int (m sigma_vm)^rho dx: the aggregated von Mises stress of the shell drivers (shell_pde.py:297-313,
+ * `pnorm_stress`; sigma(z) = C (eps + z kappa) at z = surface * h / 2, surface = +1 top, 0 mid, -1 bottom as in
+ * shell_pde.py:315-328).  value and/or partials: grad_w (+)= dJ/dw (n_dof), grad_h (+)= dJ/dh (n_vert).             */
+int femo_shell_pnorm_stress(femo_shell* s, double E, double nu, const femo_vec* h, const femo_vec* w, double m, double rho, double alpha,
+                            double surface, double* value, int accumulate, femo_vec* grad_w, femo_vec* grad_h);
 /* Lattice preconditioner for femo_shell_solve (opts->pc = 1): M^-1 = D^-1 + sum_l P_l C_l P_l^T, P_l = trilinear
  * interpolation from nested lattices over the bounding cube (2, 4, ... cells per axis) to the dof nodes, per component,
  * C_l = 1 / diag(P_l^T K P_l) (recomputed on the device when K or the Dirichlet set change).  The host passes

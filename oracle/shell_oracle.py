@@ -231,6 +231,54 @@ def compliance(V: ShellSpace, w: np.ndarray) -> float:
 
 
 # ------------------------------------------------------------------------------ test problems ----
+def von_mises_stress(V: ShellSpace, w: np.ndarray, h_nodal, E: float, nu: float, surface: float = 1.0) -> np.ndarray:
+    """von Mises stress of the in-plane stress sigma(z) = C (eps + z kappa) at z = surface * h / 2 ('Top' = +1, 'Mid' = 0,
+    'Bot' = -1; shell_pde.py:315-328, whose ShellStressRM is in the absent shell_analysis_fenicsx: the standard
+    Reissner-Mindlin recovery, transverse shear vanishing at the faces), at the six in-plane quadrature points: (nc, 6)."""
+    e1, e2, e3, area, gl = V.frames()
+    C = plane_stress(E, nu)
+    hc = np.asarray(h_nodal, dtype=np.float64)[V.conn]
+    we = np.asarray(w, dtype=np.float64)[V.cell_dofs]
+    out = np.empty((V.conn.shape[0], len(QUAD_INPLANE[1])))
+    for q, lam in enumerate(QUAD_INPLANE[0]):
+        _, gN = _p2(lam, gl)
+        Bm, Bb, _, _ = _strain_operators(e1, e2, e3, gN, gl, lam)
+        z = 0.5 * surface * (hc @ lam)
+        sig = np.einsum("ij,cj->ci", C, np.einsum("cia,ca->ci", Bm, we) + z[:, None] * np.einsum("cia,ca->ci", Bb, we))
+        out[:, q] = np.sqrt(sig[:, 0] ** 2 - sig[:, 0] * sig[:, 1] + sig[:, 1] ** 2 + 3.0 * sig[:, 2] ** 2)
+    return out
+
+
+def pnorm_stress(V: ShellSpace, w: np.ndarray, h_nodal, E: float, nu: float, m: float = 1e-6, rho: float = 100.0,
+                 alpha: Optional[float] = None, surface: float = 1.0, grad: bool = False):
+    """1 / alpha int (m sigma_vm)^rho dx (shell_pde.py:297-313: the aggregated stress constraint of the shell drivers;
+    alpha defaults to the surface area).  grad: also dJ/dw (n_dof,) and dJ/dh (n_vert,)."""
+    e1, e2, e3, area, gl = V.frames()
+    C = plane_stress(E, nu)
+    hc = np.asarray(h_nodal, dtype=np.float64)[V.conn]
+    we = np.asarray(w, dtype=np.float64)[V.cell_dofs]
+    if alpha is None:
+        alpha = float(area.sum())
+    J = 0.0
+    gw, gh = np.zeros(V.n_dof), np.zeros(V.n_vert)
+    for lam, wq in zip(*QUAD_INPLANE):
+        _, gN = _p2(lam, gl)
+        Bm, Bb, _, _ = _strain_operators(e1, e2, e3, gN, gl, lam)
+        z = 0.5 * surface * (hc @ lam)
+        kap = np.einsum("cia,ca->ci", Bb, we)
+        sig = np.einsum("ij,cj->ci", C, np.einsum("cia,ca->ci", Bm, we) + z[:, None] * kap)
+        vm = np.sqrt(sig[:, 0] ** 2 - sig[:, 0] * sig[:, 1] + sig[:, 1] ** 2 + 3.0 * sig[:, 2] ** 2)
+        J += float(np.sum(wq * area * (m * vm) ** rho)) / alpha
+        if grad:
+            safe = np.where(vm > 0.0, vm, 1.0)
+            dvm = np.stack([2 * sig[:, 0] - sig[:, 1], 2 * sig[:, 1] - sig[:, 0], 6 * sig[:, 2]], axis=1) / (2.0 * safe[:, None])
+            fac = np.where(vm > 0.0, wq * area * rho * m * (m * safe) ** (rho - 1.0) / alpha, 0.0)      # dJ / d vm
+            ds = fac[:, None] * np.einsum("ci,ij->cj", dvm, C)                                          # dJ / d (eps + z kappa)
+            np.add.at(gw, V.cell_dofs.ravel(), (np.einsum("ci,cia->ca", ds, Bm) + z[:, None] * np.einsum("ci,cia->ca", ds, Bb)).ravel())
+            np.add.at(gh, V.conn.ravel(), (0.5 * surface * np.einsum("ci,ci->c", ds, kap)[:, None] * lam[None, :]).ravel())
+    return (J, gw, gh) if grad else J
+
+
 def scordelis_lo_mesh(nx: int, nphi: int, R: float = 25.0, L: float = 25.0, phi_max: float = np.deg2rad(40.0)):
     """Quarter of the Scordelis-Lo roof as in run_shape_opt_roof.py: axis along x in [0, L], y = R sin(phi),
     z = R cos(phi), phi in [0, 40 deg]; each (x, phi) cell split into two triangles."""

@@ -103,6 +103,37 @@ def test_outputs_and_their_partials(roof):
     assert en == pytest.approx(sum(so.energy_parts(V0, w, h, E_ROOF, 0.3).values()), rel=1e-11)
 
 
+def test_pnorm_stress_and_its_partials(roof):
+    """`pnorm_stress` (shell_pde.py:297-313) against the oracle: value, dJ/dw, dJ/dh on the three surfaces; and its total
+    derivative w.r.t. the thickness through the adjoint against differences of the oracle's direct solves."""
+    prob, V0, h, f = roof
+    rng = np.random.default_rng(21)
+    w = 1e-3 * rng.standard_normal(V0.n_dof)
+    for surface, m, rho in ((1.0, 2e-6, 6.0), (-1.0, 2e-6, 6.0), (0.0, 1e-5, 3.0), (1.0, 1e-6, 100.0)):
+        J, gw, gh = prob.pnorm_stress(w, m=m, rho=rho, surface=surface, grad=True)
+        Jr, gwr, ghr = so.pnorm_stress(V0, w, h, E_ROOF, 0.3, m=m, rho=rho, surface=surface, grad=True)
+        assert J == pytest.approx(Jr, rel=1e-11)
+        assert np.abs(gw - gwr).max() <= 1e-10 * np.abs(gwr).max()
+        assert np.abs(gh - ghr).max() <= 1e-10 * np.abs(ghr).max()
+        assert prob.pnorm_stress(w, m=m, rho=rho, surface=surface) == pytest.approx(Jr, rel=1e-11)
+    # total derivative dJ/dh = partial - lam^T dK/dh w with K lam = dJ/dw
+    m, rho = 2e-6, 4.0
+    fixed = np.nonzero(prob.fixed)[0]
+    wsol = prob.solve(rtol=1e-12)
+    J, gw, gh = prob.pnorm_stress(m=m, rho=rho, grad=True)
+    gw[fixed] = 0.0
+    lam = prob.solve_adjoint(gw, rtol=1e-12)
+    total = gh - prob.dRdh_T(lam, wsol)
+
+    def Jref(hh):
+        K = so.assemble(V0, so.element_stiffness(V0, hh, E_ROOF, 0.3))
+        return so.pnorm_stress(V0, so.solve(K, so.load_vector(V0, f), fixed), hh, E_ROOF, 0.3, m=m, rho=rho)
+
+    dh = 0.01 * rng.standard_normal(V0.n_vert)
+    assert total @ dh == pytest.approx((Jref(h + 1e-2 * dh) - Jref(h - 1e-2 * dh)) / 2e-2, rel=1e-4)
+    prob.set_thickness(h)
+
+
 def test_thickness_derivative_of_the_bilinear_form(roof):
     prob, V0, h, f = roof
     rng = np.random.default_rng(5)
@@ -185,6 +216,8 @@ def test_shell_through_the_operator_stack(ctx):
     fea.add_output(name='mass', type='scalar', form=pde.mass(h_fn, 2.0), arguments=['thickness'])
     fea.add_output(name='elastic_energy', type='scalar', form=pde.elastic_energy(w_fn, h_fn, E_ROOF, NU_ROOF),
                    arguments=['disp_solid', 'thickness'])
+    fea.add_output(name='pnorm_stress', type='scalar', form=pde.pnorm_stress(w_fn, h_fn, E_ROOF, NU_ROOF, m=2e-6, rho=4),
+                   arguments=['disp_solid', 'thickness'])
     at = lambda k, v: (lambda x: np.isclose(x[k], v, atol=1e-6))
     ubc = Function(pde.W)
     ubc.vector.set(0.0)
@@ -231,6 +264,11 @@ def test_shell_through_the_operator_stack(ctx):
     Eref = lambda hh: sum(so.energy_parts(V0, solve_ref(hh), hh, E_ROOF, NU_ROOF).values())
     fde = (Eref(h + 1e-2 * dh) - Eref(h - 1e-2 * dh)) / 2e-2
     assert ge @ dh == pytest.approx(fde, rel=1e-4)
+    # the aggregated stress constraint of the shell drivers (shell_pde.py:297-313): value and total derivative
+    Sref = lambda hh: so.pnorm_stress(V0, solve_ref(hh), hh, E_ROOF, NU_ROOF, m=2e-6, rho=4.0)
+    assert sim['pnorm_stress'][0] == pytest.approx(Sref(h), rel=1e-7)
+    gs = np.asarray(sim.compute_totals('pnorm_stress', 'thickness'))
+    assert gs @ dh == pytest.approx((Sref(h + 1e-2 * dh) - Sref(h - 1e-2 * dh)) / 2e-2, rel=1e-4)
 
 
 def test_lattice_preconditioner(ctx):

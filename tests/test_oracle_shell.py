@@ -111,3 +111,48 @@ def test_energy_does_not_depend_on_cell_orientation_or_numbering():
     assert V1.n_dof == V0.n_dof and np.array_equal(V1.edge_vertices, V0.edge_vertices)      # same global numbering
     K1 = so.assemble(V1, so.element_stiffness(V1, h, 4.32e8, 0.3))
     assert abs(K1 - K0).max() <= 1e-10 * abs(K0).max()
+
+
+def test_plate_bending_stress_matches_the_series_solution():
+    """Surface stress at the centre of a simply supported square plate under uniform pressure: sigma_max =
+    6 M / h^2 with M = 0.0479 q a^2 for nu = 0.3 (Timoshenko & Woinowsky-Krieger, table 8 [ext]); there sigma_11 =
+    sigma_22 and sigma_12 = 0, so the von Mises stress is sigma_max.  Pins `von_mises_stress` (shell_pde.py:315-328)."""
+    n, h, E, nu, q = 16, 0.01, 1.0e7, 0.3, -1.0
+    pts, conn = so.plate_mesh(n)
+    V = so.ShellSpace(pts, conn)
+    K = so.assemble(V, so.element_stiffness(V, np.full(V.n_vert, h), E, nu))
+    F = so.load_vector(V, np.tile([0.0, 0.0, q], (V.n_vert, 1)))
+    ux = V.unode_x
+    edge = np.nonzero(np.isclose(ux[:, 0], 0) | np.isclose(ux[:, 0], 1) | np.isclose(ux[:, 1], 0) | np.isclose(ux[:, 1], 1))[0]
+    fixed = np.concatenate([V.u_dof(edge, 2), V.u_dof(np.arange(V.n_unode), 0), V.u_dof(np.arange(V.n_unode), 1),
+                            V.theta_dof(np.arange(V.n_vert), 2)])
+    w = so.solve(K, F, fixed)
+    hn = np.full(V.n_vert, h)
+    top, mid, bot = (so.von_mises_stress(V, w, hn, E, nu, s) for s in (1.0, 0.0, -1.0))
+    cells = np.nonzero(np.all(np.abs(V.x[V.conn][:, :, :2] - 0.5).max(axis=2) <= 1.5 / n, axis=1))[0]    # around the centre
+    ref = 6.0 * 0.0479 * abs(q) / h ** 2
+    assert top[cells].max() == pytest.approx(ref, rel=0.02)
+    assert np.allclose(top, bot, rtol=1e-9, atol=1e-9 * ref)          # pure bending: symmetric about the mid-surface
+    assert mid.max() <= 1e-6 * ref                                    # no membrane stress
+
+
+def test_pnorm_stress_partials():
+    """dJ/dw and dJ/dh of the aggregated stress (shell_pde.py:297-313) against central differences."""
+    pts, conn = so.scordelis_lo_mesh(4, 3)
+    V = so.ShellSpace(pts, conn)
+    rng = np.random.default_rng(11)
+    w = 1e-3 * rng.standard_normal(V.n_dof)
+    h = 0.25 * (1.0 + 0.2 * rng.random(V.n_vert))
+    E, nu, m, rho = 4.32e8, 0.3, 2e-6, 6.0
+    for surface in (1.0, -1.0, 0.0):
+        J, gw, gh = so.pnorm_stress(V, w, h, E, nu, m=m, rho=rho, surface=surface, grad=True)
+        assert J > 0.0
+        dw, dh = 1e-3 * rng.standard_normal(V.n_dof), 0.25 * rng.standard_normal(V.n_vert)
+        f = lambda t, s: so.pnorm_stress(V, w + t * dw, h + s * dh, E, nu, m=m, rho=rho, surface=surface)
+        assert gw @ dw == pytest.approx((f(1e-4, 0) - f(-1e-4, 0)) / 2e-4, rel=1e-6)
+        assert gh @ dh == pytest.approx((f(0, 1e-5) - f(0, -1e-5)) / 2e-5, rel=1e-6, abs=1e-12 * abs(J))
+    # alpha defaults to the area; rho = 1, m = 1: the mean von Mises stress
+    _, _, _, area, _ = V.frames()
+    vm = so.von_mises_stress(V, w, h, E, nu, 1.0)
+    wq = np.asarray(so.QUAD_INPLANE[1])
+    assert so.pnorm_stress(V, w, h, E, nu, m=1.0, rho=1.0) == pytest.approx(float((area[:, None] * wq[None, :] * vm).sum() / area.sum()), rel=1e-13)
