@@ -104,6 +104,8 @@ PROTOTYPES = {
     "femo_shell_pc_coarse_matrix": (C.c_int, [H, H, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(c_i64)]),
     "femo_shell_pnorm_stress": (C.c_int, [H, C.c_double, C.c_double, H, H, C.c_double, C.c_double, C.c_double, C.c_double,
                                           C.POINTER(C.c_double), C.c_int, H, H]),
+    "femo_shell_vm_rhs": (C.c_int, [H, C.c_double, C.c_double, H, H, C.c_double, H, H]),
+    "femo_shell_p1_mass": (C.c_int, [H, H, H]),
     "femo_shell_ndof": (c_i64, [H]),
     "femo_shell_nnz": (c_i64, [H]),
     "femo_shell_assemble": (C.c_int, [H, C.c_double, C.c_double, H, H]),

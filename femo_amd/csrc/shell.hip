@@ -473,6 +473,51 @@ __global__ __launch_bounds__(SH_BLOCK) void k_shell_pnorm_stress(femo_shell_view
   }
 }
 
+// right-hand side of the L2 projection of the von Mises stress onto CG1 (shell_pde.py:330-332): b_i += int sigma_vm phi_i,
+// and the row sums of the P1 mass matrix, lumped_i += |T| / 3.  One thread per cell.
+__global__ __launch_bounds__(SH_BLOCK) void k_shell_vm_rhs(femo_shell_view S, double E, double nu, const double* __restrict__ h,
+                                                           const double* __restrict__ w, double surface, double* __restrict__ rhs,
+                                                           double* __restrict__ lumped) {
+  const int64_t c = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x;
+  if (c >= S.n_cell) return;
+  Facet F;
+  facet_frame(S.x, S.conn, c, F);
+  const Material mt = material(E, nu);
+  const double hv[3] = {h[S.conn[c * 3]], h[S.conn[c * 3 + 1]], h[S.conn[c * 3 + 2]]};
+  double we[27];
+  for (int i = 0; i < 27; ++i) we[i] = w[shell_gdof(S, c, i)];
+  double b[3] = {0.0, 0.0, 0.0};
+  for (int q = 0; q < 6; ++q) {
+    const double* lam = c_lam6[q];
+    const double z = 0.5 * surface * (hv[0] * lam[0] + hv[1] * lam[1] + hv[2] * lam[2]);
+    double sw[9];
+    element_strain(F, lam, we, sw);
+    const double e0 = sw[0] + z * sw[3], e1 = sw[1] + z * sw[4], e2 = sw[2] + z * sw[5];
+    const double s0 = mt.c11 * e0 + mt.c12 * e1, s1 = mt.c12 * e0 + mt.c11 * e1, s2 = mt.c33 * e2;
+    const double vm = sqrt(s0 * s0 - s0 * s1 + s1 * s1 + 3.0 * s2 * s2);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) b[a] += c_w6[q] * F.area * vm * lam[a];
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    atomicAdd(&rhs[S.conn[c * 3 + a]], b[a]);
+    if (lumped != nullptr) atomicAdd(&lumped[S.conn[c * 3 + a]], F.area * (1.0 / 3.0));
+  }
+}
+
+// y += M x with the P1 mass matrix of the surface, element by element: M_e = |T| / 12 (1 + delta)
+__global__ __launch_bounds__(SH_BLOCK) void k_shell_p1_mass(femo_shell_view S, const double* __restrict__ x, double* __restrict__ y) {
+  const int64_t c = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x;
+  if (c >= S.n_cell) return;
+  Facet F;
+  facet_frame(S.x, S.conn, c, F);
+  const int32_t v0 = S.conn[c * 3], v1 = S.conn[c * 3 + 1], v2 = S.conn[c * 3 + 2];
+  const double x0 = x[v0], x1 = x[v1], x2 = x[v2], sum = x0 + x1 + x2, k = F.area * (1.0 / 12.0);
+  atomicAdd(&y[v0], k * (sum + x0));
+  atomicAdd(&y[v1], k * (sum + x1));
+  atomicAdd(&y[v2], k * (sum + x2));
+}
+
 __global__ __launch_bounds__(SH_BLOCK) void k_shell_mass(femo_shell_view S, double rho, const double* __restrict__ h, double* __restrict__ partials,
                                                          double* __restrict__ grad) {
   __shared__ double lds[SH_BLOCK / 64];
@@ -2134,6 +2179,36 @@ int femo_shell_pnorm_stress(femo_shell* s, double E, double nu, const femo_vec* 
                      value ? s->d_part : nullptr, grad_w ? grad_w->d : nullptr, grad_h ? grad_h->d : nullptr);
   FEMO_HIP_CHECK(hipGetLastError());
   if (value) FEMO_TRY(reduce_partials(s->ctx, s->d_part, (int)g, value));
+  return 0;
+}
+
+int femo_shell_vm_rhs(femo_shell* s, double E, double nu, const femo_vec* h, const femo_vec* w, double surface, femo_vec* rhs,
+                      femo_vec* lumped) {
+  FEMO_REQUIRE(s && h && w && rhs, "null argument");
+  FEMO_REQUIRE(h->n >= s->n_vert && w->n >= s->n_dof && rhs->n >= s->n_vert && (lumped == nullptr || lumped->n >= s->n_vert),
+               "vector size mismatch in shell_vm_rhs");
+  FEMO_REQUIRE(E > 0.0 && nu > -1.0 && nu < 0.5, "bad material");
+  hipStream_t st = s->ctx->stream;
+  femo_vec_touch(rhs);
+  FEMO_HIP_CHECK(hipMemsetAsync(rhs->d, 0, s->n_vert * sizeof(double), st));
+  if (lumped) {
+    femo_vec_touch(lumped);
+    FEMO_HIP_CHECK(hipMemsetAsync(lumped->d, 0, s->n_vert * sizeof(double), st));
+  }
+  hipLaunchKernelGGL(k_shell_vm_rhs, dim3(sgrid(s->n_cell)), dim3(SH_BLOCK), 0, st, view(s), E, nu, h->d, w->d, surface, rhs->d,
+                     lumped ? lumped->d : nullptr);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int femo_shell_p1_mass(femo_shell* s, const femo_vec* x, femo_vec* y) {
+  FEMO_REQUIRE(s && x && y, "null argument");
+  FEMO_REQUIRE(x->n >= s->n_vert && y->n >= s->n_vert && x->d != y->d, "vector size mismatch in shell_p1_mass");
+  hipStream_t st = s->ctx->stream;
+  femo_vec_touch(y);
+  FEMO_HIP_CHECK(hipMemsetAsync(y->d, 0, s->n_vert * sizeof(double), st));
+  hipLaunchKernelGGL(k_shell_p1_mass, dim3(sgrid(s->n_cell)), dim3(SH_BLOCK), 0, st, view(s), x->d, y->d);
+  FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
 

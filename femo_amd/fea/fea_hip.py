@@ -123,7 +123,8 @@ class FEA(object):
 
     def add_field_output(self, name, form, arguments, record=False):
         """CG1 field obtained by L2 projection of ``form`` (fea_dolfinx.py:148-161)."""
-        func = Function(FunctionSpace(self.mesh, ("CG", 1)))
+        space = self.mesh.field_space() if hasattr(self.mesh, "field_space") else FunctionSpace(self.mesh, ("CG", 1))
+        func = Function(space)
         self.outputs_field_dict[name] = self._recorded(name, record, form=form, func=func,
                                                        shape=len(getFuncArray(func)), arguments=arguments,
                                                        partials=[])

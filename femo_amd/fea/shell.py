@@ -372,6 +372,46 @@ class DeviceShell:
                                                grad_h.handle if grad_h is not None else None))
         return val.value
 
+    def vm_rhs(self, Ey: float, nu: float, h: Vec, w: Vec, surface: float, rhs: Vec, lumped: Optional[Vec] = None) -> Vec:
+        check(self.lib.femo_shell_vm_rhs(self.handle, float(Ey), float(nu), h.handle, w.handle, float(surface), rhs.handle,
+                                         lumped.handle if lumped is not None else None))
+        return rhs
+
+    def p1_mass(self, x: Vec, y: Vec) -> Vec:
+        check(self.lib.femo_shell_p1_mass(self.handle, x.handle, y.handle))
+        return y
+
+    def project_von_mises(self, Ey: float, nu: float, h: Vec, w: Vec, surface: float, out: Vec, lump_mass: bool = False,
+                          rtol: float = 1e-12, max_it: int = 500) -> Vec:
+        """L2 projection of the von Mises stress onto CG1 (`projected_von_Mises_stress`, shell_pde.py:330-332): lumped, or
+        M x = b by CG preconditioned with the lumped mass (the P1 mass matrix: ~20 iterations whatever the mesh)."""
+        nv, ctx = self.space.n_vert, self.ctx
+        wk = self.__dict__.setdefault("_proj_work", None)
+        if wk is None:
+            wk = self._proj_work = [Vec(ctx, nv) for _ in range(6)]
+        b, ml, r, z, p, q = wk
+        self.vm_rhs(Ey, nu, h, w, surface, b, ml)
+        if lump_mass:
+            return E.pointwise_divide(out, b, ml, nv)
+        out.fill(0.0)
+        r.copy_from(b)
+        E.pointwise_divide(z, r, ml, nv)
+        p.copy_from(z)
+        g = g0 = r.dot(z, nv)
+        for _ in range(max_it):
+            if g <= (rtol * rtol) * g0 or g0 == 0.0:
+                return out
+            self.p1_mass(p, q)
+            a = g / p.dot(q, nv)
+            out.axpy(a, p)
+            r.axpy(-a, q)
+            E.pointwise_divide(z, r, ml, nv)
+            g1 = r.dot(z, nv)
+            z.axpy(g1 / g, p)                    # z <- z + beta p, then p <- z
+            p.copy_from(z)
+            g = g1
+        raise E.FemoError("the projection of the von Mises stress did not converge")
+
     def solve(self, vals: Vec, b: Vec, x: Vec, fixed: Optional[np.ndarray] = None, xfix: Optional[Vec] = None,
               rtol: float = 1e-12, atol: float = 0.0, max_it: int = 2_000_000, check_every: int = 64, pc: str = "lattice"):
         if pc == "lattice":
@@ -505,6 +545,13 @@ class ShellProblem:
             J = self.dev.pnorm_stress(self.E, self.nu, self.h, self.w, m, rho, alpha, surface, grad_w=self.tmp, grad_h=self.gh)
             return J, np.array(self.tmp.get()), np.array(self.gh.get())
         return self.dev.pnorm_stress(self.E, self.nu, self.h, self.w, m, rho, alpha, surface)
+
+    def von_mises_field(self, w: Optional[np.ndarray] = None, surface: float = 1.0, lump_mass: bool = False) -> np.ndarray:
+        """The von Mises stress on the top / mid / bottom surface projected onto the vertices (shell_pde.py:315-332)."""
+        if w is not None:
+            self.w.set(np.ascontiguousarray(w, dtype=np.float64))
+        self.dev.project_von_mises(self.E, self.nu, self.h, self.w, surface, self.gh, lump_mass=lump_mass)
+        return np.array(self.gh.get())
 
     def elastic_energy(self, w: Optional[np.ndarray] = None) -> float:
         if w is not None:

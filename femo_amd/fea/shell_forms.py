@@ -7,9 +7,10 @@ so `FEA.add_input / add_state / add_output`, `StateOperation`, `OutputOperation`
 (`shell_module.py:20-120` registers exactly these: thickness and nodal force as inputs, ``disp_solid`` as state,
 compliance / mass / elastic energy as outputs).
 
-Not built (say so when asked): the forward-mode product with dR/dh (the reference's forward mode returns zeros,
-`fea_dolfinx.py:192-206`), the penalty form of the boundary conditions (imposed strongly here, its limit), the stress
-outputs (`shell_pde.py:304-332`) and the inertial residual.
+Stress outputs (`shell_pde.py:297-332`): ``pnorm_stress`` (scalar, with partials) and ``von_Mises_stress`` /
+``projected_von_Mises_stress`` (field).  Not built (say so when asked): the forward-mode product with dR/dh (the
+reference's forward mode returns zeros, `fea_dolfinx.py:192-206`), the penalty form of the boundary conditions (imposed
+strongly here, its limit) and the inertial residual.
 """
 from __future__ import annotations
 
@@ -57,6 +58,10 @@ class ShellMesh:
         if d is None:
             d = self._dev[id(ctx)] = DeviceShell(ctx, self.space)
         return d
+
+    def field_space(self) -> "ShellFunctionSpace":
+        """The CG1 space field outputs are projected onto (FEA.add_field_output)."""
+        return ShellFunctionSpace(self, "VT")
 
     def centroids(self):
         return self.x[self.conn].mean(axis=1)
@@ -386,8 +391,27 @@ class ShellPnormStress(_ShellScalar):
         return out
 
 
+class ShellVonMises(BackendForm):
+    """The von Mises stress on the top / mid / bottom surface as a field expression (shell_pde.py:315-328); `project`
+    (and with it `FEA.add_field_output`, fea_dolfinx.py:148-161) hands the L2 projection onto CG1 over to it."""
+    rank = 0
+
+    def __init__(self, w: Function, h: Function, E: float, nu: float, surface: float):
+        self.w, self.h, self.E, self.nu, self.surface = w, h, float(E), float(nu), float(surface)
+        self.mesh = w.function_space.mesh
+
+    def functions(self):
+        return (self.w, self.h)
+
+    def project_field(self, target: Function, lump_mass: bool = False) -> Function:
+        if target.function_space.dim != self.mesh.space.n_vert:
+            raise NotImplementedError("the von Mises stress is projected onto the CG1 space of the shell mesh (pde.VT)")
+        self.mesh.device(_ctx()).project_von_mises(self.E, self.nu, self.h.vec, self.w.vec, self.surface, target.vec, lump_mass=lump_mass)
+        return target
+
+
 class ShellPDE:
-    """`shell_pde.py:219-313` on the HIP engine: spaces and form builders with the reference's names."""
+    """`shell_pde.py:219-332` on the HIP engine: spaces and form builders with the reference's names."""
 
     def __init__(self, mesh: ShellMesh):
         self.mesh = mesh
@@ -417,3 +441,13 @@ class ShellPDE:
         if regularization:
             raise NotImplementedError("pnorm_stress(regularization=True): add the thickness term as an output of its own")
         return ShellPnormStress(w, h, E, nu, m=m, rho=rho, alpha=alpha, surface={'Top': 1.0, 'Mid': 0.0, 'Bot': -1.0}[surface])
+
+    def von_Mises_stress(self, w, h, E, nu, surface='Top') -> ShellVonMises:
+        """shell_pde.py:315-328"""
+        if surface not in ('Top', 'Mid', 'Bot'):
+            raise TypeError("Unsupported surface type for stress computation.")
+        return ShellVonMises(w, h, E, nu, {'Top': 1.0, 'Mid': 0.0, 'Bot': -1.0}[surface])
+
+    def projected_von_Mises_stress(self, vm_stress: ShellVonMises) -> Function:
+        """shell_pde.py:330-332: the consistent L2 projection onto VT."""
+        return vm_stress.project_field(Function(self.VT), lump_mass=False)

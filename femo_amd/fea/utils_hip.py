@@ -738,6 +738,10 @@ def project(v, target_func: Function, bcs=[], lump_mass=False):
     """utils_dolfinx.py:549-583: L2 projection onto the (CG1) space of ``target_func``.
     b_i = int v phi_i; lump_mass: x = b / (M 1); else solve M x = b (the reference uses PETSc's
     default KSP, rtol 1e-5 [ext]; here Jacobi-CG at the KSP_OPTIONS tolerance)."""
+    if isinstance(v, BackendForm) and hasattr(v, "project_field"):
+        if bcs:
+            raise NotImplementedError("project with Dirichlet conditions")
+        return v.project_field(target_func, lump_mass)
     if isinstance(v, Function):
         v = FunctionExpr(v)
     if not isinstance(v, FieldExpression):

@@ -370,6 +370,12 @@ int femo_shell_dform_dh(femo_shell* s, double E, double nu, const femo_vec* h, c
 /* 1/2 int u_mid . u_mid (shell_pde.py:287-288) and its gradient; int rho h (shell_pde.py:293-294) and its gradient */
 int femo_shell_compliance(femo_shell* s, const femo_vec* w, double* value, int accumulate, femo_vec* grad);
 int femo_shell_mass(femo_shell* s, double rho, const femo_vec* h, double* value, int accumulate, femo_vec* grad);
+/* L2 projection of the von Mises stress onto CG1 (shell_pde.py:315-332; the field output of the shell drivers,
+ * shell_dynamic_pde.py:82-83,129): rhs_i = int sigma_vm phi_i, lumped_i = row sum of the P1 mass matrix (may be NULL);
+ * femo_shell_p1_mass: y = M x with that mass matrix (the host side runs Jacobi-CG with it, utils_dolfinx.py:549-583). */
+int femo_shell_vm_rhs(femo_shell* s, double E, double nu, const femo_vec* h, const femo_vec* w, double surface, femo_vec* rhs,
+                      femo_vec* lumped);
+int femo_shell_p1_mass(femo_shell* s, const femo_vec* x, femo_vec* y);
 /* J = 1 / alpha int (m sigma_vm)^rho dx: the aggregated von Mises stress of the shell drivers (shell_pde.py:297-313,
  * `pnorm_stress`; sigma(z) = C (eps + z kappa) at z = surface * h / 2, surface = +1 top, 0 mid, -1 bottom as in
  * shell_pde.py:315-328).  value and/or partials: grad_w (+)= dJ/dw (n_dof), grad_h (+)= dJ/dh (n_vert).             */

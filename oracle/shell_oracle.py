@@ -249,6 +249,25 @@ def von_mises_stress(V: ShellSpace, w: np.ndarray, h_nodal, E: float, nu: float,
     return out
 
 
+def project_von_mises(V: ShellSpace, w: np.ndarray, h_nodal, E: float, nu: float, surface: float = 1.0,
+                      lump_mass: bool = False) -> np.ndarray:
+    """L2 projection of the von Mises stress onto CG1 (shell_pde.py:330-332 `projected_von_Mises_stress`; the field
+    output of the shell drivers, shell_dynamic_pde.py:82-83,129): M x = b, b_i = int sigma_vm phi_i (degree-4 rule),
+    M the P1 mass matrix of the surface, or its row sums with ``lump_mass``."""
+    _, _, _, area, _ = V.frames()
+    vm = von_mises_stress(V, w, h_nodal, E, nu, surface)                  # (nc, 6)
+    lam, wq = np.asarray(QUAD_INPLANE[0]), np.asarray(QUAD_INPLANE[1])
+    be = np.einsum("c,q,cq,qi->ci", area, wq, vm, lam)
+    b = np.zeros(V.n_vert)
+    np.add.at(b, V.conn.ravel(), be.ravel())
+    Me = area[:, None, None] / 12.0 * (np.ones((3, 3)) + np.eye(3))[None]
+    M = sp.coo_matrix((Me.ravel(), (np.repeat(V.conn, 3, axis=1).ravel(), np.tile(V.conn, (1, 3)).ravel())),
+                      shape=(V.n_vert, V.n_vert)).tocsc()
+    if lump_mass:
+        return b / np.asarray(M.sum(axis=1)).ravel()
+    return spla.spsolve(M, b)
+
+
 def pnorm_stress(V: ShellSpace, w: np.ndarray, h_nodal, E: float, nu: float, m: float = 1e-6, rho: float = 100.0,
                  alpha: Optional[float] = None, surface: float = 1.0, grad: bool = False):
     """1 / alpha int (m sigma_vm)^rho dx (shell_pde.py:297-313: the aggregated stress constraint of the shell drivers;

@@ -134,6 +134,18 @@ def test_pnorm_stress_and_its_partials(roof):
     prob.set_thickness(h)
 
 
+def test_von_mises_field(roof):
+    """`von_Mises_stress` + `projected_von_Mises_stress` (shell_pde.py:315-332): consistent and lumped L2 projection onto
+    the vertices against the oracle, on the three surfaces."""
+    prob, V0, h, f = roof
+    w = 1e-3 * np.random.default_rng(31).standard_normal(V0.n_dof)
+    for surface in (1.0, 0.0, -1.0):
+        for lump in (False, True):
+            got = prob.von_mises_field(w, surface=surface, lump_mass=lump)
+            ref = so.project_von_mises(V0, w, h, E_ROOF, 0.3, surface, lump_mass=lump)
+            assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max()
+
+
 def test_thickness_derivative_of_the_bilinear_form(roof):
     prob, V0, h, f = roof
     rng = np.random.default_rng(5)
@@ -218,6 +230,8 @@ def test_shell_through_the_operator_stack(ctx):
                    arguments=['disp_solid', 'thickness'])
     fea.add_output(name='pnorm_stress', type='scalar', form=pde.pnorm_stress(w_fn, h_fn, E_ROOF, NU_ROOF, m=2e-6, rho=4),
                    arguments=['disp_solid', 'thickness'])
+    fea.add_field_output(name='von_Mises_stress', form=pde.von_Mises_stress(w_fn, h_fn, E_ROOF, NU_ROOF, surface='Top'),
+                         arguments=['disp_solid', 'thickness'])                         # shell_dynamic_pde.py:82-83,129
     at = lambda k, v: (lambda x: np.isclose(x[k], v, atol=1e-6))
     ubc = Function(pde.W)
     ubc.vector.set(0.0)
@@ -267,6 +281,10 @@ def test_shell_through_the_operator_stack(ctx):
     # the aggregated stress constraint of the shell drivers (shell_pde.py:297-313): value and total derivative
     Sref = lambda hh: so.pnorm_stress(V0, solve_ref(hh), hh, E_ROOF, NU_ROOF, m=2e-6, rho=4.0)
     assert sim['pnorm_stress'][0] == pytest.approx(Sref(h), rel=1e-7)
+    vm = np.asarray(sim['von_Mises_stress'])
+    vref = so.project_von_mises(V0, wref, h, E_ROOF, NU_ROOF, 1.0)
+    assert vm.shape == (V0.n_vert,) and np.abs(vm - vref).max() <= 1e-7 * np.abs(vref).max()
+    assert np.array_equal(pde.projected_von_Mises_stress(pde.von_Mises_stress(w_fn, h_fn, E_ROOF, NU_ROOF)).vec.get(), vm)
     gs = np.asarray(sim.compute_totals('pnorm_stress', 'thickness'))
     assert gs @ dh == pytest.approx((Sref(h + 1e-2 * dh) - Sref(h - 1e-2 * dh)) / 2e-2, rel=1e-4)
 

@@ -156,3 +156,30 @@ def test_pnorm_stress_partials():
     vm = so.von_mises_stress(V, w, h, E, nu, 1.0)
     wq = np.asarray(so.QUAD_INPLANE[1])
     assert so.pnorm_stress(V, w, h, E, nu, m=1.0, rho=1.0) == pytest.approx(float((area[:, None] * wq[None, :] * vm).sum() / area.sum()), rel=1e-13)
+
+
+def test_projection_of_the_von_mises_stress():
+    """`project_von_mises` (shell_pde.py:330-332): the consistent projection reproduces a stress field that is P1 on the
+    mesh -- pure bending of the plate with a linearly varying thickness gives sigma_vm = c h(x) -- and the lumped one keeps
+    its integral."""
+    pts, conn = so.plate_mesh(6)
+    V = so.ShellSpace(pts, conn)
+    E, nu = 1.0e7, 0.3
+    # rotation field theta = (0, kappa x, 0): curvature kappa_11 constant, no membrane strain -> sigma = C (z kappa)
+    w = np.zeros(V.n_dof)
+    kap = 1e-3
+    w[V.theta_dof(np.arange(V.n_vert), 1)] = kap * V.x[:, 0]
+    h = 0.01 * (1.0 + 0.5 * V.x[:, 0] + 0.25 * V.x[:, 1])
+    vm_q = so.von_mises_stress(V, w, h, E, nu, 1.0)
+    C = so.plane_stress(E, nu)
+    s = C @ np.array([kap, 0.0, 0.0])
+    c = float(np.sqrt(s[0] ** 2 - s[0] * s[1] + s[1] ** 2)) / 2.0          # sigma_vm = c h
+    lamq = np.asarray(so.QUAD_INPLANE[0])
+    assert np.allclose(vm_q, c * np.einsum("cv,qv->cq", h[V.conn], lamq), rtol=1e-10)
+    x = so.project_von_mises(V, w, h, E, nu, 1.0)
+    assert np.allclose(x, c * h, rtol=1e-10)
+    xl = so.project_von_mises(V, w, h, E, nu, 1.0, lump_mass=True)
+    _, _, _, area, _ = V.frames()
+    nodal = np.zeros(V.n_vert); np.add.at(nodal, V.conn.ravel(), np.repeat(area / 3.0, 3))
+    assert float(nodal @ xl) == pytest.approx(float(nodal @ x), rel=1e-12)
+    assert not np.allclose(xl, x, rtol=1e-4)
