@@ -3,18 +3,19 @@
 // The formulation is restated and pinned in oracle/shell_oracle.py (Scordelis-Lo, Kirchhoff plate, rigid modes);
 // the kernels here are checked against it entry by entry (tests/test_gpu_shell.py).
 //
-// First version, correctness before speed:
+// What is here (DESIGN.md section 8 has the measurements and the versions that came before):
 //   * degrees of freedom and the CSR pattern of the 27 x 27 element couplings are built on the host (Python,
 //     femo_amd/fea/shell.py) and handed over as plain arrays, with the CSR position of every element entry;
 //   * assembly: one thread per (cell, element column) forms the column from the facet frame and the quadrature
-//     points in registers (B^T D B, nine strain rows) and adds its 27 entries with fp64 atomics -- about 1e8 atomics
-//     for the 136 k-triangle wing of the reference's aeroelastic example, ~10 ms, against a linear solve that takes
-//     seconds; an owner-computes variant like the Poisson path's is the obvious next step;
-//   * solve: Jacobi-preconditioned CG on the assembled CSR matrix with strongly imposed dofs (masked operator),
-//     scalars kept on the device (consumers fold the producers' per-block partials), host polls a flag.
-//     Shell stiffness matrices are ill conditioned (3,169 iterations on the 16 x 16 roof, 7,491 on 32 x 32): a
-//     multilevel preconditioner for this operator is future work, the reference uses a direct solver.
-//   * thickness sensitivity: (dR/dh)^T lambda evaluated element by element from the strains of w and lambda.
+//     points in registers (B^T D B, nine strain rows) and adds its 27 entries with fp64 atomics;
+//   * operator: the three dofs of a node share their columns, so the matrix is read as 3 x 3 blocks -- straight from
+//     the CSR values (k_bcsr3_spmv) or, in the CG loop, from a block-SELL copy (k_bsell_spmv);
+//   * solve: CG with device-side scalars (consumers fold the producers' per-block partials, the host polls a flag)
+//     and a nested-lattice preconditioner: 3 x 3 point blocks of K as the smoother, 6 x 6 Galerkin node blocks on the
+//     lattice levels, an exact dense solve (Galerkin operator formed on the device, blocked Cholesky on the fp64 matrix
+//     cores) on the coarsest level kept -- 252 iterations at 1.97 M dofs where Jacobi needs ~1e5;
+//   * partials and outputs: (dR/dh)^T lambda element by element from the strains of w and lambda, load and its
+//     transpose, compliance, mass, elastic energy, the aggregated von Mises stress and its projection onto the vertices.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
