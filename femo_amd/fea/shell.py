@@ -272,6 +272,8 @@ class DeviceShell:
     """`femo_shell` handle."""
 
     def __init__(self, ctx: Context, space: ShellSpace):
+        if getattr(ctx, "nranks", 1) > 1:
+            raise NotImplementedError("the shell path runs on one GPU (no partitioned shell meshes yet)")
         self.ctx, self.space, self.lib = ctx, space, _lib.load()
         rowptr, cols, epos = space.pattern()
         self.handle = _lib.H()
