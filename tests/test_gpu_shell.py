@@ -378,7 +378,7 @@ def test_preconditioner_variants_agree(ctx, monkeypatch):
         assert rel(res[name][1], res["full"][1]) <= 1e-7, name
     assert res["full"][0] < res["no node blocks"][0]
     assert res["full"][0] < res["no point blocks"][0]
-    assert abs(res["csr view"][0] - res["full"][0]) <= 3          # same operator, another summation order
+    assert abs(res["csr view"][0] - res["full"][0]) <= 10         # same operator, another summation order
 
 
 def test_irregular_surface_mesh(ctx):
