@@ -54,6 +54,10 @@ struct femo_shell {
   double *d_ell_w = nullptr, *d_par_vals = nullptr, *d_chi_vals = nullptr;
   double *d_coarse = nullptr, *d_t = nullptr, *d_e = nullptr, *d_z = nullptr;
   double* d_cblk = nullptr;                             // 6 x 6 inverse Galerkin blocks of the nodes above the coarse-solve level
+  int32_t* d_lvl_node = nullptr;                        // levels above the coarse solve, per level and POINT: the eight lattice
+  double* d_lvl_w = nullptr;                            // nodes and weights, contiguous ([level][point][8]; the ELL rows interleave
+                                                        // all levels of a dof: 3 cache lines per access, 52 GB fetched by the
+                                                        // node-block kernel at 1.97 M dofs)
   bool blk_ready = false;
   double* d_dinv3 = nullptr;                            // 3 x 3 inverse diagonal blocks of the points (finest-level smoother)
   bool dinv3_ready = false;
@@ -1404,6 +1408,20 @@ __global__ void k_lat_level(int64_t n0, int64_t n1, const int64_t* __restrict__ 
   }
 }
 
+// per-point copies of the ELL entries of the levels first_slot / 8 and up (node = unknown / 6): [level][point][8]
+__global__ void k_compact_levels(int64_t n_pts, int width, int first_slot, const int32_t* __restrict__ ell_idx,
+                                 const double* __restrict__ ell_w, int32_t* __restrict__ node, double* __restrict__ w) {
+  const int nlev = (width - first_slot) >> 3;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_pts * nlev * 8) return;
+  const int a = (int)(t & 7);
+  const int64_t p = (t >> 3) % n_pts;
+  const int lv = (int)((t >> 3) / n_pts);
+  const int64_t e = (3 * p) * width + first_slot + 8 * lv + a;
+  node[t] = ell_idx[e] / 6;
+  w[t] = ell_w[e];
+}
+
 // 6 x 6 Galerkin blocks of the lattice nodes, levels first_slot / 8 and up: blk[node][f][f'] = sum over free dofs i of
 // field f and k of field f' that both touch the node of P[i, node] K[i, k] P[k, node].  One thread per (point, level,
 // component fa of the point) over the node-block view of the matrix: it keeps the row's sums against the point's eight
@@ -1413,8 +1431,8 @@ __global__ void k_lat_level(int64_t n0, int64_t n1, const int64_t* __restrict__ 
 // dofs.)  The diagonal of a block is the scalar Galerkin diagonal.
 __global__ __launch_bounds__(SH_BLOCK) void k_pc_galerkin_blocks(int64_t n_pts, int width, int64_t n_unode, const int64_t* __restrict__ brow,
                                                                  const int32_t* __restrict__ bcols, const double* __restrict__ vals,
-                                                                 const uint8_t* __restrict__ fixed, const int32_t* __restrict__ ell_idx,
-                                                                 const double* __restrict__ ell_w, double* __restrict__ blk, int first_slot) {
+                                                                 const uint8_t* __restrict__ fixed, const int32_t* __restrict__ lvl_node,
+                                                                 const double* __restrict__ lvl_w, double* __restrict__ blk, int first_slot) {
   // A workgroup = 256 consecutive points, one level, one component (blockIdx.y = 3 level + fa): neighbouring points
   // touch the same few dozen lattice nodes, so their sums are combined in an LDS hash table (key = node and field
   // group) and leave the workgroup as one global atomic per entry -- the global atomics were three quarters of this
@@ -1429,7 +1447,8 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_galerkin_blocks(int64_t n_pts, 
   }
   __syncthreads();
   const int fa = (int)(blockIdx.y % 3);
-  const int lev8 = first_slot + 8 * (int)(blockIdx.y / 3);
+  const int32_t* ln = lvl_node + (int64_t)(blockIdx.y / 3) * n_pts * 8;          // this level's [point][8] tables
+  const double* lw = lvl_w + (int64_t)(blockIdx.y / 3) * n_pts * 8;
   const int64_t p = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x;
   const bool active = p < n_pts && !(fixed != nullptr && fixed[3 * p + fa]);
   if (active) {
@@ -1437,8 +1456,8 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_galerkin_blocks(int64_t n_pts, 
     double wi[8], acc[8][6];
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
-      nd[a] = ell_idx[(3 * p) * width + lev8 + a] / 6;
-      wi[a] = ell_w[(3 * p) * width + lev8 + a];
+      nd[a] = ln[p * 8 + a];
+      wi[a] = lw[p * 8 + a];
       if (wi[a] == 0.0) nd[a] = -1;
 #pragma unroll
       for (int q = 0; q < 6; ++q) acc[a][q] = 0.0;
@@ -1448,8 +1467,8 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_galerkin_blocks(int64_t n_pts, 
     const double* v = vals + 9 * k0 + fa * len;
     for (int64_t k = k0; k < k1; ++k) {
       const int32_t cj = bcols[k];
-      const int32_t* ik = ell_idx + (int64_t)cj * width + lev8;
-      const double* wk = ell_w + (int64_t)cj * width + lev8;
+      const int32_t* ik = ln + (int64_t)(cj / 3) * 8;
+      const double* wk = lw + (int64_t)(cj / 3) * 8;
       const int64_t o = 3 * (k - k0);
       double m0 = v[o], m1 = v[o + 1], m2 = v[o + 2];
       if (fixed != nullptr) {
@@ -1460,7 +1479,7 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_galerkin_blocks(int64_t n_pts, 
       const bool gj = cj >= 3 * n_unode;
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
-        const int32_t nb = ik[b] / 6;
+        const int32_t nb = ik[b];
         const double wb = wk[b];
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
@@ -1809,7 +1828,7 @@ int femo_shell_destroy(femo_shell* s) {
   hipFree(s->d_r); hipFree(s->d_p); hipFree(s->d_q); hipFree(s->d_dinv); hipFree(s->d_scal); hipFree(s->d_part); hipFree(s->d_flag);
   hipFree(s->d_ell_idx); hipFree(s->d_ell_w);
   hipFree(s->d_par_rowptr); hipFree(s->d_par_cols); hipFree(s->d_par_vals); hipFree(s->d_chi_rowptr); hipFree(s->d_chi_cols); hipFree(s->d_chi_vals);
-  hipFree(s->d_coarse); hipFree(s->d_cblk); hipFree(s->d_dinv3); hipFree(s->d_t); hipFree(s->d_e); hipFree(s->d_z); hipFree(s->d_fin_idx); hipFree(s->d_fin_w);
+  hipFree(s->d_coarse); hipFree(s->d_cblk); hipFree(s->d_lvl_node); hipFree(s->d_lvl_w); hipFree(s->d_dinv3); hipFree(s->d_t); hipFree(s->d_e); hipFree(s->d_z); hipFree(s->d_fin_idx); hipFree(s->d_fin_w);
   delete s;
   return 0;
 }
@@ -2032,6 +2051,17 @@ int femo_shell_pc_coarse(femo_shell* s, int level, const int32_t* node_xyz, int6
     FEMO_TRY(to_device(&s->d_cd_cols, down_cols, down_rowptr[rows], st));
     FEMO_TRY(to_device(&s->d_cd_vals, down_vals, down_rowptr[rows], st));
     FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  }
+  {
+    const int first_slot = 8 * (level + 1);
+    const int64_t n_pts = s->n_dof / 3, cnt = n_pts * ((s->pc_width - first_slot) / 8) * 8;
+    if (cnt > 0) {
+      FEMO_HIP_CHECK(hipMalloc(&s->d_lvl_node, cnt * sizeof(int32_t)));
+      FEMO_HIP_CHECK(hipMalloc(&s->d_lvl_w, cnt * sizeof(double)));
+      hipLaunchKernelGGL(k_compact_levels, dim3(sgrid(cnt, 256)), dim3(256), 0, st, n_pts, s->pc_width, first_slot, s->d_ell_idx, s->d_ell_w,
+                         s->d_lvl_node, s->d_lvl_w);
+      FEMO_HIP_CHECK(hipGetLastError());
+    }
   }
   FEMO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pc_coarse_galerkin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CG_LDS));
   s->cs_level = level; s->cs_n = n; s->cs_N = N; s->cs_items = n_items;
@@ -2283,11 +2313,11 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
       // the Galerkin diagonals when there is no coarse solve
       const int first_slot = s->cs_ready ? 8 * (s->cs_level + 1) : 0;
       s->blk_ready = false;
-      if (s->cs_ready && getenv("FEMO_SHELL_NO_BLOCKS") == nullptr) {
+      if (s->cs_ready && s->d_lvl_node != nullptr && getenv("FEMO_SHELL_NO_BLOCKS") == nullptr) {
         const int64_t nd0 = s->level_off[s->cs_level + 1], nd1 = s->level_off[s->pc_levels];
         FEMO_HIP_CHECK(hipMemsetAsync(s->d_cblk + 36 * nd0, 0, (nd1 - nd0) * 36 * sizeof(double), st));
         hipLaunchKernelGGL(k_pc_galerkin_blocks, dim3(sgrid(n / 3), 3 * ((s->pc_width - first_slot) / 8)), dim3(SH_BLOCK), 0, st, n / 3, s->pc_width,
-                           s->n_unode, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_ell_idx, s->d_ell_w, s->d_cblk, first_slot);
+                           s->n_unode, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_lvl_node, s->d_lvl_w, s->d_cblk, first_slot);
         hipLaunchKernelGGL(k_pc_invert_blocks, dim3(sgrid(nd1 - nd0, 256)), dim3(256), 0, st, nd0, nd1, s->d_cblk);
         s->blk_ready = true;
       } else {
