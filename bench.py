@@ -53,6 +53,7 @@ def parse():
     p.add_argument("--permute", action="store_true",
                    help="random vertex numbering: no regular SELL slices, scattered gathers (the unstructured-mesh rate)")
     p.add_argument("--no-pcie", action="store_true")
+    p.add_argument("--no-check", action="store_true", help="skip the self-check of the timed configuration against the DST-exact cycle")
     p.add_argument("--reorder", action="store_true",
                    help="renumber the mesh along a Morton curve first (what import_mesh does to a mesh it reads)")
     p.add_argument("--pc", choices=("bpx", "jacobi"), default="bpx",
@@ -150,6 +151,19 @@ def usable_cores() -> int:
     return n
 
 
+_CANON: dict = {}
+
+
+def _canonical_mesh(n: int, jitter: float):
+    """The oracle's own mesh generator (lexicographic numbering), shared by the checker and the CPU baseline."""
+    from oracle import femo_oracle as fo
+    key = (n, jitter)
+    if key not in _CANON:
+        _CANON.clear()
+        _CANON[key] = fo.unit_cube_mesh(n, jitter=jitter)
+    return _CANON[key]
+
+
 def cpu_baseline(args, gpu_counts, n_dof_gpu, n_cell_gpu, nnz_gpu):
     """The same cycle on the host cores with the C/OpenMP oracle port: ONE cycle at the benchmark's own
     size by default (about 10 s of CPU work with BPX-CG), so nothing is extrapolated.  ``--cpu-n`` selects a
@@ -157,7 +171,7 @@ def cpu_baseline(args, gpu_counts, n_dof_gpu, n_cell_gpu, nnz_gpu):
     from oracle import c_port
     from oracle import femo_oracle as fo
     n = args.cpu_n if args.cpu_n else args.n
-    m = fo.unit_cube_mesh(n, jitter=args.jitter)
+    m = _canonical_mesh(n, args.jitter)
     f = source_fields(_Centroid(m), 1)[0]
     bd = fo.boundary_vertices_box(m.x)
     threads = usable_cores()
@@ -182,6 +196,57 @@ def cpu_baseline(args, gpu_counts, n_dof_gpu, n_cell_gpu, nnz_gpu):
     t_scaled = t_other * (n_cell_gpu / m.n_cell) + per_it_per_nnz * nnz_gpu * it_scaled
     return {"value": n_dof_gpu / t_scaled, "unit": "DOFs/s", "cores": int(out["threads"]), "kind": "port",
             "sample": head + f"; scaled to n={args.n} by cell count (assembly, {t_other:.2f} s) and nnz x {it_scaled:.0f} iterations"}
+
+
+def self_check(args, mesh, f, u, J, grad):
+    """The checker of the timed configuration (outside the timed region; part of the CPU leg like ``cpu_baseline``, the
+    only other place that touches ``oracle/``): state, functional and total gradient of one more cycle of the SAME
+    operator stack -- BPX-CG at KSP_OPTIONS['rtol_bpx'], Newton's noise rule, pinned host arrays -- against values
+    that involve no iterative solver.  Structured cube: both solves by the type-I sine transform
+    (oracle/c_port.py::poisson_cycle_dst, exact to round-off at any size); the vertex / cell numbering of permuted or
+    reordered meshes is mapped back through the coordinates.  Jittered cube: no closed form exists, the C port's
+    cycle with a 100x tighter CG tolerance stands in and ``kind`` says so.
+    Reference algebra: femo/csdl_opt/state_model.py:87-115, 202-218."""
+    from oracle import c_port
+    from oracle import femo_oracle as fo
+    n, d = args.n, mesh.tdim
+    t0 = time.perf_counter()
+    canon = _canonical_mesh(n, args.jitter)
+    bd = fo.boundary_vertices_box(canon.x)
+    # canonical (lexicographic) index of every vertex / cell of the benchmark's mesh, from the un-jittered lattice
+    # position (jitter moves interior vertices by < h/2, so rounding recovers it) and the cell's vertex set
+    if not (args.permute or args.reorder):
+        vmap, cmap = None, None                      # generated in canonical numbering
+    else:
+        iv = np.rint(mesh.x * n).astype(np.int64)
+        vmap = (iv[:, 2] * (n + 1) + iv[:, 1]) * (n + 1) + iv[:, 0]
+        def cell_keys(conn, vm):
+            s = np.sort(vm[conn] if vm is not None else conn.astype(np.int64), axis=1)
+            order = np.lexsort((s[:, 3], s[:, 2], s[:, 1], s[:, 0]))
+            return order
+        oc, ob = cell_keys(canon.conn, None), cell_keys(mesh.conn, vmap)
+        cmap = np.empty(mesh.n_cell, np.int64)
+        cmap[ob] = oc                                # cell c of the benchmark mesh = canonical cell cmap[c]
+    f_c = np.empty(canon.n_cell)
+    if cmap is None:
+        f_c[:] = f
+    else:
+        f_c[cmap] = f
+    if args.jitter:
+        ref = c_port.poisson_cycle(d, canon.x, canon.conn, f_c, fo.u_target(canon.x), bd, ALPHA, threads=usable_cores(),
+                                   pc="bpx", rtol_bpx=1e-13)
+        kind = "C port of the same cycle with BPX-CG at rtol 1e-13 (jittered mesh: no exact discrete solution)"
+    else:
+        ref = c_port.poisson_cycle_dst(n, d, canon.x, canon.conn, f_c, fo.u_target(canon.x), bd, ALPHA,
+                                       threads=usable_cores())
+        kind = "DST-exact discrete state and multiplier (oracle/c_port.py::poisson_cycle_dst), no iterative solve"
+    u_ref = ref["u"] if vmap is None else ref["u"][vmap]
+    g_ref = ref["grad"] if cmap is None else ref["grad"][cmap]
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
+    return {"u_rel_err": rel(np.asarray(u), u_ref), "grad_rel_err": rel(np.asarray(grad), g_ref),
+            "J_rel_err": float(abs(float(J) - float(ref["J"])) / abs(float(ref["J"]))),
+            "tolerance": 1e-10, "norm": "max-norm relative to the largest entry", "against": kind,
+            "seconds": time.perf_counter() - t0}
 
 
 class _Centroid:
@@ -404,6 +469,13 @@ def _run(args):
                                        "note": "pageable NumPy arrays owned by the driver on both sides of every operator call "
                                                "(staged through pinned slots by host threads; no upload can be elided)"}
         del sim_p, fea_p
+    if not args.no_check:
+        # one more cycle of the timed stack, outside the timed region, compared with solver-free values
+        kc = (W + K) % len(f_pin)
+        g_chk = np.array(E.host_wait(host_cycle(kc)), copy=True)
+        result["check"] = self_check(args, mesh, f_host[kc], np.array(sim['u'], copy=True),
+                                     float(np.asarray(sim['l2_functional']).ravel()[0]), g_chk)
+        del g_chk
     if not args.no_cpu_baseline:
         counts = its_per_step if its_per_step else [0]
         result["cpu_baseline"] = cpu_baseline(args, counts, n_dof, mesh.n_cell, nnz)

@@ -64,6 +64,7 @@ PROTOTYPES = {
     "femo_vec_destroy": (C.c_int, [H]),
     "femo_vec_size": (c_i64, [H]),
     "femo_vec_device_ptr": (C.c_void_p, [H]),
+    "femo_vec_device_ptr_const": (C.c_void_p, [H]),
     "femo_vec_set_host": (C.c_int, [H, C.c_void_p, c_i64]),
     "femo_vec_get_host": (C.c_int, [H, C.c_void_p, c_i64]),
     "femo_vec_add_to_host": (C.c_int, [H, C.c_void_p, c_i64]),

@@ -15,7 +15,7 @@ import numpy as np
 from femo_amd.csdl_opt._common import (declare_all, gather_arguments, push_functions, stays_on_device,
                                        traced)
 from femo_amd.csdl_opt._csdl_compat import CustomImplicitOperation, Model, custom
-from femo_amd.engine import lazy_results
+from femo_amd.engine import host_wait, lazy_results
 from femo_amd.fea.fea_hip import FEA
 from femo_amd.fea.utils_hip import (DeviceArray, SparseMatrix, addMatVecProductBwd, addMatVecProductFwd,
                                     assembleMatrix, assembleSystem, assembleVector, computePartials,
@@ -75,6 +75,8 @@ class StateOperation(CustomImplicitOperation):
         if not (self.fea.consistent_bc_partials and self.bcs):
             return values
         dofs = np.unique(np.concatenate([bc.dofs for bc in self.bcs]))
+        if isinstance(values, np.ndarray):
+            host_wait(values)          # apply_inverse_jacobian may have returned it while its copy-out is in flight
         host = np.array(values, dtype=np.float64, copy=True)
         host[dofs] = 0.0
         if isinstance(values, DeviceArray):

@@ -279,7 +279,14 @@ int femo_vec_destroy(femo_vec* v) {
 }
 
 int64_t femo_vec_size(const femo_vec* v) { return v ? v->n : -1; }
-void* femo_vec_device_ptr(femo_vec* v) { return v ? v->d : nullptr; }
+// A mutable pointer leaves the library: assume the caller writes through it (the generation moves, so no host block
+// keeps counting as a mirror of v and per-content caches keyed by (uid, generation) are rebuilt).
+void* femo_vec_device_ptr(femo_vec* v) {
+  if (!v) return nullptr;
+  femo_vec_touch(v);
+  return v->d;
+}
+const void* femo_vec_device_ptr_const(const femo_vec* v) { return v ? v->d : nullptr; }
 
 // femo_vec_set_host / femo_vec_get_host / femo_vec_add_to_host: hostmem.cpp
 
@@ -357,6 +364,8 @@ int femo_mesh_destroy(femo_mesh* m) {
   hipFree(m->d_visit_slots); hipFree(m->d_mptr); hipFree(m->d_cols); hipFree(m->d_rowlen);
   femo_pc_destroy(m);
   hipFree(m->d_bvmask); hipFree(m->d_visit_rec); hipFree(m->d_load); hipFree(m->d_pipe_dummy); hipFree(m->d_ubc);
+  if (m->mass) { femo_mat_destroy(m->mass); m->mass = nullptr; }
+  hipFree(m->d_mass_e);
   hipFree(m->d_sdelta); hipFree(m->d_bfacets); hipFree(m->d_tperm); hipFree(m->d_send_idx); hipFree(m->d_send_buf); hipFree(m->d_scratch); hipFree(m->d_slices_int); hipFree(m->d_slices_bnd);
   delete m;
   return 0;

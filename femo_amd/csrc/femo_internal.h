@@ -191,6 +191,8 @@ struct femo_mesh {
   double* d_load = nullptr;      // load vector of the Poisson residual for the f identified by (load_uid, load_gen)
   uint64_t load_uid = 0, load_gen = 0;
   int pcg_last_iters = 0, pcg_prev_iters = 0;   // iterations of the last two converged BPX-PCG solves on this mesh (size the first batch)
+  struct femo_mat* mass = nullptr;  // P1 mass matrix on the operator pattern (geometry only; built on first use): dJ/du = M (u - u_d)
+  double* d_mass_e = nullptr;       // n_vert: the difference the mass product is applied to
   double* d_pipe_dummy = nullptr; // k_poisson_system_pipe: a line that absorbs the stores of padded entries / lanes
   double* d_ubc = nullptr;        // ... and u with the prescribed values imposed
   uint8_t* d_bfacets = nullptr;  // per cell: bit k = facet opposite local vertex k is on the boundary (optional)

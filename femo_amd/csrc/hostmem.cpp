@@ -37,6 +37,7 @@
 #include <fstream>
 #include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -59,7 +60,10 @@ int usable_cores() {
   return n;
 }
 
-// fork-join pool: run(nparts, fn) calls fn(part) for part in [0, nparts) on the workers and the caller
+// fork-join pool: run(nparts, fn) calls fn(part) for part in [0, nparts) on the workers and the caller.
+// Every job has its own state object (function, part count, counters): a worker that is preempted between taking a
+// part index and reading the job can never see the fields of the NEXT job, and the caller's wait is
+// tied to its own job object.
 class HostPool {
  public:
   static HostPool& get() {
@@ -75,34 +79,40 @@ class HostPool {
       return;
     }
     std::lock_guard<std::mutex> serial(run_mu_);      // one job at a time (contexts on several host threads)
+    auto job = std::make_shared<Job>();
+    job->fn = &fn;
+    job->nparts = nparts;
+    job->left.store(nparts);
     {
       std::lock_guard<std::mutex> lk(mu_);
-      fn_ = &fn;
-      nparts_ = nparts;
-      next_.store(0);
-      left_.store(nparts);
+      cur_ = job;
       ++job_;
     }
     cv_.notify_all();
-    work();
+    work(*job);
     std::unique_lock<std::mutex> lk(mu_);
-    done_cv_.wait(lk, [&] { return left_.load() == 0; });
-    fn_ = nullptr;
+    done_cv_.wait(lk, [&] { return job->left.load() == 0; });   // every part of THIS job has returned: fn may go
+    cur_.reset();
   }
 
  private:
+  struct Job {
+    const std::function<void(int)>* fn = nullptr;
+    int nparts = 0;
+    std::atomic<int> next{0}, left{0};
+  };
   HostPool() {
     nthreads_ = std::min(usable_cores(), 16);
     if (const char* e = getenv("FEMO_HOST_THREADS")) nthreads_ = std::max(1, atoi(e));
     for (int i = 1; i < nthreads_; ++i) workers_.emplace_back([this] { loop(); });
     for (auto& t : workers_) t.detach();              // live until the process exits
   }
-  void work() {
+  void work(Job& j) {
     for (;;) {
-      const int i = next_.fetch_add(1);
-      if (i >= nparts_) return;
-      (*fn_)(i);
-      if (left_.fetch_sub(1) == 1) {
+      const int i = j.next.fetch_add(1);
+      if (i >= j.nparts) return;
+      (*j.fn)(i);                                      // fn outlives the job: run() waits for left == 0
+      if (j.left.fetch_sub(1) == 1) {
         std::lock_guard<std::mutex> lk(mu_);
         done_cv_.notify_all();
       }
@@ -111,21 +121,21 @@ class HostPool {
   void loop() {
     uint64_t seen = 0;
     for (;;) {
+      std::shared_ptr<Job> j;
       {
         std::unique_lock<std::mutex> lk(mu_);
         cv_.wait(lk, [&] { return job_ != seen; });
         seen = job_;
+        j = cur_;                                      // may already be finished and reset: nothing to do then
       }
-      work();
+      if (j) work(*j);
     }
   }
   int nthreads_ = 1;
   std::vector<std::thread> workers_;
   std::mutex mu_, run_mu_;
   std::condition_variable cv_, done_cv_;
-  const std::function<void(int)>* fn_ = nullptr;
-  int nparts_ = 0;
-  std::atomic<int> next_{0}, left_{0};
+  std::shared_ptr<Job> cur_;
   uint64_t job_ = 0;
 };
 
@@ -633,7 +643,8 @@ static int get_host_impl(const femo_vec* v, double* host, int64_t n, int op, boo
     if (HostBlock* b = find_block(host, (size_t)n * sizeof(double))) {
       pinned = true;
       exact_base = reinterpret_cast<char*>(host) == b->base;
-      if (op == 1 && exact_base && b->src_uid != 0 && b->src_n >= n) {
+      // only an UNSCALED mirror: a block recorded as a * vector (femo_host_axpby) holds a * mirror, not mirror
+      if (op == 1 && exact_base && b->src_uid != 0 && b->src_n >= n && b->src_scale == 1.0) {
         auto it = g_live.find(b->src_uid);
         if (it != g_live.end() && it->second->gen == b->src_gen && it->second->ctx == c) mirror = it->second;
       }

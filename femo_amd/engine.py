@@ -290,7 +290,12 @@ class Vec:
 
     @property
     def device_ptr(self) -> int:
+        """Mutable device address: the library assumes the holder writes through it (include/femo_hip.h)."""
         return int(self.lib.femo_vec_device_ptr(self.handle) or 0)
+
+    @property
+    def device_ptr_const(self) -> int:
+        return int(self.lib.femo_vec_device_ptr_const(self.handle) or 0)
 
     def __del__(self):
         # destroy only while the owning context is alive (interpreter shutdown tears

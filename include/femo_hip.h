@@ -124,7 +124,10 @@ int     femo_vec_create(femo_ctx* ctx, int64_t n, femo_vec** out);          /* z
 int     femo_vec_wrap(femo_ctx* ctx, void* device_ptr, int64_t n, femo_vec** out); /* borrow */
 int     femo_vec_destroy(femo_vec* v);
 int64_t femo_vec_size(const femo_vec* v);
-void*   femo_vec_device_ptr(femo_vec* v);
+void*   femo_vec_device_ptr(femo_vec* v);         /* mutable: counts as a write to v (provenance records and per-content
+                                                     caches of v are dropped; a pending copy-out of v is waited for
+                                                     on the device before the next kernel on the context's stream) */
+const void* femo_vec_device_ptr_const(const femo_vec* v);   /* read-only access, no side effect */
 int     femo_vec_set_host(femo_vec* v, const double* host, int64_t n);      /* setFuncArray */
 int     femo_vec_get_host(const femo_vec* v, double* host, int64_t n);      /* getFuncArray */
 /* host[0:n] += v[0:n]: the `d_inputs[name] += dRdf^T dR` of state_model.py:190-200 without a second

@@ -208,6 +208,39 @@ def poisson_cycle(tdim: int, x: np.ndarray, conn: np.ndarray, f: np.ndarray, u_d
                 threads=L.oc_num_threads(), nnz=int(rowptr[-1]), pc=pc)
 
 
+def poisson_cycle_dst(n: int, tdim: int, x: np.ndarray, conn: np.ndarray, f: np.ndarray, u_d: np.ndarray,
+                      bc_dofs: np.ndarray, alpha: float, threads: Optional[int] = None) -> Dict:
+    """The cycle of ``poisson_cycle`` with BOTH linear solves done exactly: on the un-jittered, lexicographically
+    numbered n^d grid with homogeneous Dirichlet values on the whole box boundary the eliminated operator's interior
+    block is diagonalised by the type-I sine transform (femo_oracle.dst_solve), so state, multiplier and gradient are
+    known to round-off at any size -- the full-size checker of bench.py and tests/test_gpu_fullsize.py (no iterative
+    solver, no tolerance).  Same algebra as the reference's sweep (state_model.py:87-115, 202-218): three Newton
+    steps on a linear problem from u = 0 give A^-1 b; lam = A^-T dJ/du with identity rows on the Dirichlet set
+    (lam_bc = dJ/du_bc: the reference keeps those rows in dR/df^T lam); grad = alpha f |T| - dR/df^T lam."""
+    from . import femo_oracle as fo
+    L = lib()
+    if threads:
+        L.oc_set_num_threads(int(threads))
+    x = np.ascontiguousarray(x, np.float64)
+    conn = np.ascontiguousarray(conn, np.int32)
+    f = np.ascontiguousarray(f, np.float64)
+    u_d = np.ascontiguousarray(u_d, np.float64)
+    nv, nc = x.shape[0], conn.shape[0]
+    om = fo.OMesh(tdim, x, conn, n)
+    load = -residual(tdim, x, conn, np.zeros(nv), f)
+    load[bc_dofs] = 0.0
+    u = fo.dst_solve(om, load)
+    J = L.oc_functional(tdim, _p(x), _i64(nc), _p(conn), _p(u), _p(f), _p(u_d), C.c_double(alpha))
+    dJdu = np.empty(nv)
+    L.oc_functional_du(tdim, _i64(nv), _p(x), _i64(nc), _p(conn), _p(u), _p(u_d), _p(dJdu))
+    dJdf = np.empty(nc)
+    L.oc_functional_df(tdim, _p(x), _i64(nc), _p(conn), _p(f), C.c_double(alpha), _p(dJdf))
+    lam = fo.dst_solve(om, dJdu)               # identity rows: lam_bc = dJdu_bc; columns eliminated: no coupling
+    g = np.empty(nc)
+    L.oc_dRdfT_apply(tdim, _p(x), _i64(nc), _p(conn), _p(lam), _p(g))
+    return dict(u=u, J=J, grad=dJdf - g, lam=lam, dJdu=dJdu)
+
+
 _DIAG_CACHE: dict = {}
 
 

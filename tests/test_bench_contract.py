@@ -82,3 +82,53 @@ def test_multi_gpu_flag_without_launcher_starts_a_torchrun_job(monkeypatch):
     except SystemExit as e:
         assert e.code == 7
     assert calls and "torch.distributed.run" in calls[0] and "--nproc-per-node=2" in calls[0]
+
+
+def test_dst_exact_cycle_matches_the_lu_reference():
+    """The full-size checker (oracle/c_port.py::poisson_cycle_dst) = the LU reference cycle to round-off."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from oracle import c_port
+    from oracle import femo_oracle as fo
+    for d, n in ((3, 10), (2, 24)):
+        m = fo.unit_cube_mesh(n) if d == 3 else fo.unit_square_mesh(n)
+        xc = fo.centroids(m)
+        f = np.prod(np.sin(np.pi * xc), axis=1) * (1.0 + 0.3 * xc[:, 0]) + 0.05
+        bd = fo.boundary_vertices_box(m.x)
+        ref = fo.reference_cycle(m, f, fo.u_target(m.x), bd, np.zeros(len(bd)))
+        out = c_port.poisson_cycle_dst(n, d, m.x, m.conn, f, fo.u_target(m.x), bd, fo.ALPHA_POISSON)
+        assert np.abs(out["u"] - ref["u"]).max() <= 1e-13 * np.abs(ref["u"]).max()
+        assert np.abs(out["grad"] - ref["grad"]).max() <= 1e-13 * np.abs(ref["grad"]).max()
+        assert abs(out["J"] - ref["J"][0]) <= 1e-13 * abs(ref["J"][0])
+
+
+def test_self_check_maps_renumbered_meshes_back():
+    """bench.self_check on a permuted + Morton-reordered cube: the canonical numbering is recovered from the
+    coordinates, so exact values in the benchmark's numbering give round-off errors and a wrong entry shows."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import bench
+    from femo_amd.fea.mesh import createUnitCubeMesh
+    from oracle import femo_oracle as fo
+    n = 6
+    canon = createUnitCubeMesh(n)
+    mesh = canon.permuted(seed=3, cells=True).reordered()
+    f = bench.source_fields(mesh, 1)[0]
+    om = fo.OMesh(3, mesh.x, mesh.conn, n)
+    bd = fo.boundary_vertices_box(mesh.x)
+    ref = fo.reference_cycle(om, f, fo.u_target(mesh.x), bd, np.zeros(len(bd)))       # LU in the benchmark's own numbering
+
+    class A:
+        pass
+    a = A()
+    a.n, a.jitter, a.permute, a.reorder = n, 0.0, True, True
+    chk = bench.self_check(a, mesh, f, ref["u"], ref["J"][0], ref["grad"])
+    assert chk["u_rel_err"] < 1e-12 and chk["grad_rel_err"] < 1e-12 and chk["J_rel_err"] < 1e-12
+    bad = ref["grad"].copy()
+    bad[5] *= 1.0 + 1e-6
+    assert bench.self_check(a, mesh, f, ref["u"], ref["J"][0], bad)["grad_rel_err"] > 1e-9
+    a.permute = a.reorder = False
+    f0 = bench.source_fields(canon, 1)[0]
+    ref0 = fo.reference_cycle(fo.OMesh(3, canon.x, canon.conn, n), f0, fo.u_target(canon.x), fo.boundary_vertices_box(canon.x), np.zeros(len(bd)))
+    chk0 = bench.self_check(a, canon, f0, ref0["u"], ref0["J"][0], ref0["grad"])
+    assert max(chk0["u_rel_err"], chk0["grad_rel_err"], chk0["J_rel_err"]) < 1e-12

@@ -13,10 +13,16 @@ from oracle import femo_oracle as fo
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("pc", ["jacobi", "bpx"])
 @pytest.mark.parametrize("n", [100, 215])
-def test_full_size_properties(ctx, n):
+def test_full_size_properties(ctx, n, pc):
+    """``pc='bpx'`` is the configuration bench.py times: BPX-CG stopping on sqrt(r.M^-1 r) <= rtol_bpx sqrt(b.M^-1 b)
+    with rtol_bpx = KSP_OPTIONS['rtol_bpx'] (1e-11); ``pc='jacobi'`` the Jacobi-CG of BASELINE.json config 2."""
     from femo_amd import engine as E
     from femo_amd.fea.mesh import createUnitCubeMesh
+    from femo_amd.fea.utils_hip import KSP_OPTIONS
+    kw = dict(pc="bpx", rtol=KSP_OPTIONS["rtol_bpx"]) if pc == "bpx" else dict(pc="jacobi", rtol=KSP_OPTIONS["rtol"])
+    tr = pc != "bpx"          # A is symmetric; the BPX solver takes it as such (utils_hip.KSP passes transpose only for unsymmetric operators)
     mesh = createUnitCubeMesh(n)
     N, NC = mesh.n_vert, mesh.n_cell
     dm = E.DeviceMesh(ctx, mesh.x, mesh.conn)
@@ -37,7 +43,7 @@ def test_full_size_properties(ctx, n):
     u_exact = fo.dst_solve(om, load)
     X = E.Vec(ctx, N)
     Bpos = E.Vec(ctx, N).fill(0.0).axpy(-1.0, B)
-    info = A.solve_cg(Bpos, X, rtol=1e-14)
+    info = A.solve_cg(Bpos, X, **kw)
     u = X.get()
     assert info.converged == 1
     assert np.abs(u - u_exact).max() < 1e-10 * np.abs(u_exact).max()
@@ -45,11 +51,11 @@ def test_full_size_properties(ctx, n):
     c = rng.standard_normal(N)
     c[bd] = 0.0
     C, Y = E.Vec(ctx, N).set(c), E.Vec(ctx, N)
-    A.solve_cg(C, Y, transpose=True, rtol=1e-14)
+    A.solve_cg(C, Y, transpose=tr, **kw)
     lhs, rhs = float(u @ c), float(load @ Y.get())
     assert abs(lhs - rhs) < 1e-10 * max(abs(lhs), abs(rhs))
     S, Z = E.Vec(ctx, N).set(load + 0.5 * c), E.Vec(ctx, N)
-    A.solve_cg(S, Z, rtol=1e-14)
+    A.solve_cg(S, Z, **kw)
     expect = u + 0.5 * Y.get()
     assert np.abs(Z.get() - expect).max() < 1e-10 * np.abs(expect).max()
     # (3) SpMV vs residual: R(u; 0) = K u, and A = K off the Dirichlet set
@@ -69,7 +75,7 @@ def test_full_size_properties(ctx, n):
     E.functional_grad_u(dm, 0, [alpha], X, F, UD, G)
     g = np.array(G.get())                      # results are read-only (they mirror the device vector): copy to edit
     g[bd] = 0.0
-    A.solve_cg(E.Vec(ctx, N).set(g), LAM, transpose=True, rtol=1e-14)
+    A.solve_cg(E.Vec(ctx, N).set(g), LAM, transpose=tr, **kw)
     DV, DT = E.Vec(ctx, NC * 4), E.Vec(ctx, NC)
     E.assemble_dRdf(dm, 0, None, X, F, DV)
     E.dRdf_apply(dm, DV, LAM, DT, transpose=True)
@@ -82,12 +88,54 @@ def test_full_size_properties(ctx, n):
         Fv = E.Vec(ctx, NC).set(ff)
         Bv, Xv = E.Vec(ctx, N), E.Vec(ctx, N)
         E.assemble_system(dm, 0, None, U0, Fv, bc, None, None, Bv)
-        A.solve_cg(E.Vec(ctx, N).fill(0.0).axpy(-1.0, Bv), Xv, rtol=1e-14)
+        A.solve_cg(E.Vec(ctx, N).fill(0.0).axpy(-1.0, Bv), Xv, **kw)
         return E.functional_value(dm, 0, [alpha], Xv, Fv, UD)
 
     fd = (J_of(f + eps * dirn) - J_of(f - eps * dirn)) / (2 * eps)        # J is quadratic in f: exact up to round-off
     an = float(grad @ dirn)
     assert abs(fd - an) < 1e-7 * abs(an)
+
+
+@pytest.mark.parametrize("n", [100, 215])
+def test_operator_cycle_full_size(ctx, n):
+    """The cycle bench.py times, at the sizes it is quoted on, through the operator stack exactly as bench.py drives
+    it (``bench.build_problem`` / ``one_cycle``: FEAModel -> StateOperation / OutputOperation, NumPy arrays in pinned
+    blocks at the boundary, default KSP options = BPX-CG at rtol_bpx 1e-11, Newton x3 with the noise rule, asynchronous
+    results) against the DST-exact state, functional and total gradient (oracle/c_port.py::poisson_cycle_dst: no
+    iterative solve on the checker's side).  Reference: state_model.py:87-115, 202-218; BASELINE.json: 1e-10."""
+    import bench
+    from femo_amd import engine as E
+    from femo_amd.fea import utils_hip
+    from femo_amd.fea.mesh import createUnitCubeMesh
+    prev = utils_hip._CTX
+    utils_hip.set_context(ctx)
+    try:
+        mesh = createUnitCubeMesh(n)
+        sim, fea = bench.build_problem(mesh, device=False)
+        f = bench.source_fields(mesh, 2)[1]
+        u0 = E.pinned_full(mesh.n_vert, 0.0)
+        for f_k in (bench.source_fields(mesh, 1)[0], f):          # the second cycle runs on warm workspaces, like a timed one
+            g = bench.one_cycle(sim, fea, E.pinned_array(f_k), u0)
+        g = np.array(E.host_wait(g), copy=True)
+        u = np.array(sim['u'], copy=True)
+        J = float(np.asarray(sim['l2_functional']).ravel()[0])
+        its = [i["iterations"] for i in utils_hip.LAST_KSP_INFO[-4:]]
+        bd = fo.boundary_vertices_box(mesh.x)
+        ref = c_port.poisson_cycle_dst(n, 3, mesh.x, mesh.conn, f, fo.u_target(mesh.x), bd, bench.ALPHA)
+        assert np.abs(u - ref["u"]).max() < 1e-10 * np.abs(ref["u"]).max()
+        assert np.abs(g - ref["grad"]).max() < 1e-10 * np.abs(ref["grad"]).max()
+        assert abs(J - ref["J"]) < 1e-10 * abs(ref["J"])
+        assert u[bd].max() == 0.0 and u[bd].min() == 0.0          # identity rows are exact
+        assert its[0] > 0 and its[3] > 0 and max(its) < 60        # mesh-independent counts (28 at C4)
+        # the same check as bench.py emits in its JSON line
+        class A:
+            pass
+        a = A(); a.n, a.jitter, a.permute, a.reorder = n, 0.0, False, False
+        chk = bench.self_check(a, mesh, f, u, J, g)
+        assert chk["u_rel_err"] < 1e-10 and chk["grad_rel_err"] < 1e-10 and chk["J_rel_err"] < 1e-10
+    finally:
+        utils_hip.clear_workspaces()
+        utils_hip.set_context(prev)
 
 
 def test_config3_shell_at_full_size(ctx):

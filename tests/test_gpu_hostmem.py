@@ -355,6 +355,30 @@ def test_accumulate_on_the_device(ctx):
     assert np.array_equal(hw, a + b)
 
 
+def test_accumulate_into_a_scaled_block(ctx):
+    """A block filled by host_axpby(a != 1, x, 0, y) is recorded as a * vector; adding into it must give a * vector + v
+    (the device-sum path used the unscaled mirror)."""
+    from femo_amd import engine as E
+    n = 2_000_011
+    rng = np.random.default_rng(33)
+    a, b = rng.standard_normal(n), rng.standard_normal(n)
+    g, c = E.Vec(ctx, n).set(a), E.Vec(ctx, n).set(b)
+    os.environ.pop("FEMO_HOST_VERIFY", None)            # the defect was silent only without the verifier
+    try:
+        for lazy in (False, True):
+            with E.lazy_results(lazy):
+                h = g.get()
+            y = E.pinned_empty(n)
+            E.host_axpby(-2.5, h, 0.0, y)
+            E.host_stats(reset=True)
+            c.add_to_host(y)
+            assert E.host_stats()["d2h_device_sum"] == 0
+            assert np.array_equal(y, -2.5 * a + b)
+            del h, y
+    finally:
+        os.environ["FEMO_HOST_VERIFY"] = "1"
+
+
 def test_two_outputs_do_not_alias_in_device_mode(ctx):
     """compute_totals(of=[a, b]) on the device returns distinct buffers, and a result kept from an earlier
     call survives the next one (pooled work arrays were handed out)."""
