@@ -2357,11 +2357,16 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
   FEMO_HIP_CHECK(hipStreamSynchronize(st));
   info->rhs_norm = std::sqrt(h_scal[1]);
   int it = 0, since_mark = 0;
+  const int n_sample = 4;
+  int n_ev = 0;
   bool stalled = false;
   double best = HUGE_VAL, best_mark = HUGE_VAL;
   while (!h_flag[0] && it < max_it) {
     const int it_end = std::min(it + batch, max_it);
     for (; it < it_end; ++it) {
+      // HIP events around four of the operator products (iterations 4 .. 7) for the roofline record of bench.py
+      const bool sample = it >= 4 && it < 4 + n_sample;
+      if (sample) FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev], st));
       // p is zero on the imposed dofs (r and the initial direction are): no column mask needed
       if (bsell)
         hipLaunchKernelGGL(k_bsell_spmv, dim3(gs), dim3(SH_BLOCK), 0, st, s->n_bnode, s->n_bslice, s->d_bs_off, s->d_bs_cols, s->d_bs_vals, d_fixed, s->d_p, s->d_q, Ppq, s->d_flag, s->d_scal, gam);
@@ -2369,6 +2374,7 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
         hipLaunchKernelGGL(k_bcsr3_spmv<16>, dim3(gs), dim3(SH_BLOCK), 0, st, s->n_bnode, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_p, s->d_q, Ppq, s->d_flag, s->d_scal, gam);
       else
         hipLaunchKernelGGL(k_csr_spmv, dim3(gs), dim3(SH_BLOCK), 0, st, n, s->d_rowptr, s->d_cols, vals->d, d_fixed, 0, s->d_p, s->d_q, Ppq, s->d_flag, s->d_scal, gam);
+      if (sample) { FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev + 1], st)); ++n_ev; }
       if (lattice) {
         hipLaunchKernelGGL(k_scg_xr_plain, dim3(gv), dim3(SH_BLOCK), 0, st, n, (int)gs, Ppq, s->d_scal, s->d_p, s->d_q, x->d, s->d_r, s->d_flag);
         FEMO_TRY(shell_pc_apply(s, d_fixed, Prz, gz, s->d_flag));
@@ -2403,6 +2409,19 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
   float ms = 0.f;
   FEMO_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   info->solve_ms = ms;
+  {
+    const int iters_run = h_flag[0] ? h_flag[1] : it;
+    double acc = 0.0;
+    int used = 0;
+    for (int i = 0; i < n_ev; ++i) {
+      if (4 + i >= iters_run) break;                     // a launch behind the converged iteration returned at once
+      float t = 0.f;
+      FEMO_HIP_CHECK(hipEventElapsedTime(&t, ctx->ev_pool[2 * i], ctx->ev_pool[2 * i + 1]));
+      acc += t; ++used;
+    }
+    info->spmv_ms = acc;
+    info->spmv_samples = used;
+  }
   info->iterations = h_flag[0] ? h_flag[1] : it;
   info->converged = h_flag[0] ? (h_flag[2] ? -1 : 1) : (stalled ? 2 : 0);
   info->residual_norm = std::sqrt(std::max(h_flag[0] && h_flag[1] > 0 ? h_scal[4] : h_scal[0], 0.0));
