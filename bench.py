@@ -53,6 +53,7 @@ def parse():
     p.add_argument("--permute", action="store_true",
                    help="random vertex numbering: no regular SELL slices, scattered gathers (the unstructured-mesh rate)")
     p.add_argument("--no-pcie", action="store_true")
+    p.add_argument("--no-configs", action="store_true", help="skip the legs for BASELINE configs 2, 5 and 3 (reported under 'configs')")
     p.add_argument("--no-check", action="store_true", help="skip the self-check of the timed configuration against the DST-exact cycle")
     p.add_argument("--reorder", action="store_true",
                    help="renumber the mesh along a Morton curve first (what import_mesh does to a mesh it reads)")
@@ -255,6 +256,210 @@ class _Centroid:
 
     def centroids(self):
         return self._m.x[self._m.conn].mean(axis=1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The other single-GPU configurations of BASELINE.json, timed after the headline leg and reported under "configs"
+# (configs 2, 3 and 5 had builder-run numbers only).  Each record: ms_per_cycle, dofs_per_s,
+# iteration counts, the roofline of its dominant kernel (HIP events inside its own loop) and a CPU baseline at a
+# stated size (nothing scaled).
+# ---------------------------------------------------------------------------------------------------------------
+def _roofline(kernel: str, bytes_per_launch: int, ms: float, samples: int, note: str = "") -> dict:
+    ach = bytes_per_launch / (ms * 1e-3) / 1e9 if ms and ms == ms and ms > 0 else None
+    return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": None, "algorithmic_bytes_per_launch": int(bytes_per_launch),
+            "avg_launch_ms": ms, "launches_timed": samples,
+            "timed": "single launches inside the timed solver loops (HIP events on the library's stream)" + (("; " + note) if note else "")}
+
+
+def _spmv_in_loop(infos):
+    solves = [i for i in infos if i["spmv_samples"] > 0]
+    n = sum(i["spmv_samples"] for i in solves)
+    return (sum(i["spmv_ms"] for i in solves) / n if n else float("nan")), n
+
+
+def bench_config2(ctx, steps: int) -> dict:
+    """BASELINE config 2: 3-D linear Poisson, n = 100 cube (1,030,301 DOFs), the same operator cycle as the headline."""
+    from femo_amd import engine as E
+    from femo_amd.fea import utils_hip
+    from femo_amd.fea.mesh import createUnitCubeMesh
+    n = 100
+    mesh = createUnitCubeMesh(n)
+    sim, fea = build_problem(mesh, device=False)
+    dm = mesh.device(ctx)
+    fs = [E.pinned_array(f) for f in source_fields(mesh, 3)]
+    u0 = E.pinned_full(mesh.n_vert, 0.0)
+    g = None
+    for k in range(2):
+        g = one_cycle(sim, fea, fs[k], u0)
+    ctx.sync()
+    del utils_hip.LAST_KSP_INFO[:]
+    ms, g = _timed_cycles(ctx, lambda k: one_cycle(sim, fea, fs[k % 3], u0), steps, 0)
+    infos = list(utils_hip.LAST_KSP_INFO)
+    per = len(infos) // steps
+    spmv_ms, ns = _spmv_in_loop(infos)
+    nnz = dm.info["nnz"]
+    from oracle import c_port
+    from oracle import femo_oracle as fo
+    om = _canonical_mesh(n, 0.0)
+    bd = fo.boundary_vertices_box(om.x)
+    f0 = source_fields(mesh, 1)[0]
+    cpu = c_port.poisson_cycle(3, om.x, om.conn, f0, fo.u_target(om.x), bd, ALPHA, threads=usable_cores(), pc="bpx")
+    ref = c_port.poisson_cycle_dst(n, 3, om.x, om.conn, np.asarray(fs[(steps - 1) % 3]), fo.u_target(om.x), bd, ALPHA)
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
+    rec = {"workload": f"3-D linear Poisson, unit cube n={n}: {mesh.n_vert} DOFs, nnz {nnz}; the headline's operator cycle (host boundary, BPX-CG)",
+           "n_dof": mesh.n_vert, "steps": steps, "ms_per_cycle": ms, "dofs_per_s": mesh.n_vert / (ms * 1e-3),
+           "cg_iterations_per_cycle": [i["iterations"] for i in infos[:per]],
+           "roofline": _roofline("k_spmv_sell<1,true>", spmv_algorithmic_bytes(nnz, mesh.n_vert), spmv_ms, ns),
+           "check": {"u_rel_err": rel(np.asarray(sim['u']), ref["u"]), "grad_rel_err": rel(np.asarray(E.host_wait(g)), ref["grad"]),
+                     "against": "DST-exact cycle (oracle/c_port.py::poisson_cycle_dst)", "tolerance": 1e-10},
+           "cpu_baseline": {"value": om.n_vert / cpu["times"]["cycle"], "unit": "DOFs/s", "cores": int(cpu["threads"]), "kind": "port",
+                            "sample": f"oracle/femo_oracle_c.c, one whole cycle at n={n} (this configuration's own size), "
+                                      f"{cpu['times']['cycle']:.2f} s, CG its {cpu['it_fwd']}+{cpu['it_adj']}; nothing scaled"}}
+    utils_hip.clear_workspaces()
+    return rec
+
+
+def build_problem_nl(mesh, device: bool = False):
+    """examples/nonlinear_poisson_opt/run_nonlinear_poisson_opt.py:147-232 on the HIP mirror (symmetric Nitsche, SNES)."""
+    from femo_amd.csdl_opt.fea_model import FEAModel
+    from femo_amd.csdl_opt.simulator import Simulator
+    from femo_amd.fea.fea_hip import FEA, Function, FunctionSpace, TestFunction
+    from femo_amd.fea.nonlinear_poisson import outputForm as outputFormNL, pdeRes as pdeResNL
+    fea = FEA(mesh)
+    fea.REPORT = False
+    Vf, Vu = FunctionSpace(mesh, ('DG', 0)), FunctionSpace(mesh, ('CG', 1))
+    f_fn, u_fn = Function(Vf), Function(Vu)
+    u_ex = Function(Vu)
+    u_ex.interpolate(lambda x: np.sin(2 * np.pi * x[0]) * np.sin(np.pi * x[1]))
+    fea.add_input('f', f_fn)
+    fea.add_state(name='u', function=u_fn, residual_form=pdeResNL(u_fn, TestFunction(Vu), f_fn, u_exact=u_ex, weak_bc=True, sym=True),
+                  arguments=['f'])
+    fea.add_output(name='l2_functional', type='scalar', form=outputFormNL(u_fn, f_fn, u_ex), arguments=['f', 'u'])
+    fea.PDE_SOLVER = 'SNES'
+    model = FEAModel(fea=[fea])
+    model.create_input('f', shape=fea.inputs_dict['f']['shape'], val=0.1)
+    return Simulator(model, device=device), fea
+
+
+def bench_config5(ctx, steps: int, n: int = 2236, cpu_n: int = 384) -> dict:
+    """BASELINE config 5 on one GPU: -div grad u + u^3 = f with symmetric Nitsche terms on the n x n square
+    (n = 2236: 5,004,169 DOFs), SNES (Jacobian reassembled every Newton iteration) + adjoint-of-Newton gradient, NumPy
+    arrays at the operator boundary, cold start from CSDL's default state u = 1 in every cycle."""
+    from femo_amd import engine as E
+    from femo_amd.fea import utils_hip
+    from femo_amd.fea.mesh import createUnitSquareMesh
+    mesh = createUnitSquareMesh(n)
+    sim, fea = build_problem_nl(mesh)
+    dm = mesh.device(ctx)
+    xc = mesh.centroids()
+    fs = [E.pinned_array(0.1 * (1.0 + 0.2 * np.sin(np.pi * (k + 1) * xc[:, 0]) * xc[:, 1])) for k in range(3)]   # run_nonlinear...:230-232: f = 0.1
+    u1 = E.pinned_full(mesh.n_vert, 1.0)
+    ufn = fea.states_dict['u']['function']
+
+    def cycle(k):
+        sim['f'] = fs[k % 3]
+        ufn.vector.set(1.0)
+        sim['u'] = u1
+        sim.run()
+        return sim.compute_totals('l2_functional', 'f')
+
+    for k in range(2):
+        cycle(k)
+    ctx.sync()
+    del utils_hip.LAST_KSP_INFO[:]
+    ms, g = _timed_cycles(ctx, cycle, steps, 0)
+    infos = list(utils_hip.LAST_KSP_INFO)
+    per = len(infos) // steps
+    spmv_ms, ns = _spmv_in_loop(infos)
+    nnz = dm.info["nnz"]
+    J = float(np.asarray(sim['l2_functional']).ravel()[0])
+    # CPU: the NumPy/SciPy oracle's cycle (SuperLU stands where the reference has MUMPS) at a bounded size
+    from oracle import femo_oracle as fo
+    om = fo.unit_square_mesh(cpu_n)
+    t0 = time.perf_counter()
+    out = fo.nl_reference_cycle(om, np.full(om.n_cell, 0.1), fo.u_exact_nl(om.x), fo.boundary_facets(om))
+    t_cpu = time.perf_counter() - t0
+    rec = {"workload": f"nonlinear Poisson + symmetric Nitsche, unit square n={n}: {mesh.n_vert} DOFs, nnz {nnz}; SNES from u = 1, "
+                       "J, dJ/du, dJ/df, dR/du, dR/df, A, transposed solve, dR/df^T lambda; host boundary",
+           "n_dof": mesh.n_vert, "steps": steps, "ms_per_cycle": ms, "dofs_per_s": mesh.n_vert / (ms * 1e-3),
+           "newton_linear_solves_per_cycle": per - 1, "cg_iterations_per_cycle": [i["iterations"] for i in infos[:per]],
+           "J": J, "roofline": _roofline("k_spmv_sell<1,true>", spmv_algorithmic_bytes(nnz, mesh.n_vert), spmv_ms, ns),
+           "cpu_baseline": {"value": om.n_vert / t_cpu, "unit": "DOFs/s", "cores": 1, "kind": "port",
+                            "sample": f"oracle/femo_oracle.py::nl_reference_cycle (NumPy assembly + SciPy SuperLU per Newton step and for the "
+                                      f"adjoint, as the reference uses LU) on the n={cpu_n} square, {om.n_vert} DOFs, {out['newton_its']} Newton "
+                                      f"steps, {t_cpu:.1f} s; measured at that size, nothing scaled"}}
+    utils_hip.clear_workspaces()
+    return rec
+
+
+def bench_config3(ctx, steps: int, n: int = 362, cpu_n: int = 48) -> dict:
+    """BASELINE config 3: Reissner-Mindlin shell (CG2^3 x CG1^3), Scordelis-Lo roof n x n x 2 triangles (n = 362:
+    1.97 M dofs): assemble K(h), solve K w = F, compliance + dJ/dw, adjoint solve, thickness sensitivity dJ/dh."""
+    from femo_amd.fea.shell import ShellProblem
+    from oracle import shell_oracle as so
+    Lr = 25.0
+
+    def roof_fixed(S):
+        on = lambda arr, val: np.nonzero(np.isclose(arr, val, atol=1e-6))[0]
+        ux, vx = S.unode_x, S.x
+        return np.unique(np.concatenate([
+            S.u_dof(on(ux[:, 0], Lr), 1), S.u_dof(on(ux[:, 0], Lr), 2), S.u_dof(on(ux[:, 1], 0.0), 1), S.theta_dof(on(vx[:, 1], 0.0), 0),
+            S.theta_dof(on(vx[:, 1], 0.0), 2), S.u_dof(on(ux[:, 0], 0.0), 0), S.theta_dof(on(vx[:, 0], 0.0), 1), S.theta_dof(on(vx[:, 0], 0.0), 2)]))
+
+    pts, conn = so.scordelis_lo_mesh(n, n, L=Lr)
+    t0 = time.perf_counter()
+    from femo_amd.fea.shell import ShellSpace
+    S = ShellSpace(pts, conn)
+    prob = ShellProblem(pts, conn, 4.32e8, 0.0, fixed_dofs=roof_fixed(S), ctx=ctx)
+    prob.dev.enable_lattice_pc()
+    setup_s = time.perf_counter() - t0
+    vx = S.x
+    prob.set_load([0.0, 0.0, -90.0])
+    free = ~prob.fixed.astype(bool)
+    its, spmv_ms, spmv_n = [], 0.0, 0
+
+    def cycle(k):
+        nonlocal spmv_ms, spmv_n
+        prob.set_thickness(0.25 * (1.0 + 0.02 * np.cos(2 * np.pi * (k + 1) * vx[:, 0] / Lr)))     # a new K every cycle
+        w = prob.solve(rtol=1e-10)
+        i1 = prob.last_info
+        J, dJdw = prob.compliance(grad=True)
+        dJdw[~free] = 0.0
+        lam = prob.solve_adjoint(dJdw, rtol=1e-10)
+        i2 = prob.last_info
+        g = -prob.dRdh_T(lam)
+        its.append([int(i1.iterations), int(i2.iterations)])
+        spmv_ms += i1.spmv_ms + i2.spmv_ms
+        spmv_n += i1.spmv_samples + i2.spmv_samples
+        return w, J, g
+
+    cycle(0)
+    ctx.sync()
+    its.clear(); spmv_ms = 0.0; spmv_n = 0
+    t0 = time.perf_counter()
+    for k in range(steps):
+        w, J, g = cycle(k + 1)
+    ctx.sync()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    tip = int(np.argmin(np.abs(vx[:, 0]) + np.abs(vx[:, 1] - vx[:, 1].max())))
+    # block-SELL bytes of the operator product: 9 values + 1 column index per 3 x 3 block, x and y once
+    nblk = int(prob.dev.nnz) // 9
+    b_spmv = nblk * (72 + 4) + 2 * 8 * int(S.n_dof)
+    # CPU: the oracle's direct-solver cycle (the reference factorises: 3 Newton steps + 1 adjoint factorisation)
+    t0 = time.perf_counter()
+    cpu = so.reference_cycle(cpu_n)
+    t_cpu = time.perf_counter() - t0
+    return {"workload": f"Reissner-Mindlin shell, Scordelis-Lo roof {n} x {n} x 2 triangles: {S.n_dof} dofs, nnz {int(prob.dev.nnz)}; assemble K(h), "
+                        "PCG solve, compliance + dJ/dw, adjoint PCG solve, dJ/dh; NumPy arrays in and out",
+            "n_dof": int(S.n_dof), "steps": steps, "ms_per_cycle": ms, "dofs_per_s": S.n_dof / (ms * 1e-3), "setup_s": setup_s,
+            "cg_iterations_per_cycle": its[-1], "tip_deflection": float(S.vertex_displacement(w)[tip, 2]), "tip_reference": -0.3024,
+            "roofline": _roofline("k_bsell_spmv", b_spmv, spmv_ms / max(spmv_n, 1), spmv_n,
+                                  "bytes in the block-SELL format the kernel reads (8.44 B per scalar entry), not scalar-CSR bytes"),
+            "cpu_baseline": {"value": cpu["n_dof"] / t_cpu, "unit": "DOFs/s", "cores": 1, "kind": "port",
+                             "sample": f"oracle/shell_oracle.py::reference_cycle (NumPy assembly, SciPy SuperLU: 3 Newton factorisations + 1 for the "
+                                       f"adjoint, as the reference's MUMPS path does) on the {cpu_n} x {cpu_n} roof, {cpu['n_dof']} dofs, {t_cpu:.1f} s; "
+                                       "measured at that size, nothing scaled"}}
 
 
 def _relaunch_multi_gpu(args) -> int:
@@ -476,6 +681,10 @@ def _run(args):
         result["check"] = self_check(args, mesh, f_host[kc], np.array(sim['u'], copy=True),
                                      float(np.asarray(sim['l2_functional']).ravel()[0]), g_chk)
         del g_chk
+    if not args.no_configs and not (args.permute or args.reorder or args.jitter) and args.n == 215:
+        sim = fea = f_pin = u0 = g = None           # release the 10 M-DOF problem before the other meshes are built
+        utils_hip.clear_workspaces()
+        result["configs"] = {"c2": bench_config2(ctx, 20), "c5_nl": bench_config5(ctx, 5), "c3_shell": bench_config3(ctx, 3)}
     if not args.no_cpu_baseline:
         counts = its_per_step if its_per_step else [0]
         result["cpu_baseline"] = cpu_baseline(args, counts, n_dof, mesh.n_cell, nnz)

@@ -218,19 +218,6 @@ def energy_parts(V: ShellSpace, w: np.ndarray, h_nodal, E, nu) -> Dict[str, floa
     return {k: 0.5 * float(np.einsum("ca,cab,cb->", we, P, we)) for k, P in zip(("membrane", "bending", "shear", "drilling"), parts)}
 
 
-def compliance(V: ShellSpace, w: np.ndarray) -> float:
-    """1/2 int u_mid . u_mid  (shell_pde.py:287-288 without the regularisation term), P2 mass matrix, degree-4 rule."""
-    _, _, _, area, gl = V.frames()
-    ue = w[V.cell_dofs[:, :18]].reshape(-1, 6, 3)
-    J = 0.0
-    for lam, wq in zip(*QUAD_INPLANE):
-        N, _ = _p2(lam, gl)
-        uq = np.einsum("a,cai->ci", N, ue)
-        J += 0.5 * float(np.einsum("c,ci,ci->", wq * area, uq, uq))
-    return J
-
-
-# ------------------------------------------------------------------------------ test problems ----
 def von_mises_stress(V: ShellSpace, w: np.ndarray, h_nodal, E: float, nu: float, surface: float = 1.0) -> np.ndarray:
     """von Mises stress of the in-plane stress sigma(z) = C (eps + z kappa) at z = surface * h / 2 ('Top' = +1, 'Mid' = 0,
     'Bot' = -1; shell_pde.py:315-328, whose ShellStressRM is in the absent shell_analysis_fenicsx: the standard
@@ -296,6 +283,191 @@ def pnorm_stress(V: ShellSpace, w: np.ndarray, h_nodal, E: float, nu: float, m: 
             np.add.at(gw, V.cell_dofs.ravel(), (np.einsum("ci,cia->ca", ds, Bm) + z[:, None] * np.einsum("ci,cia->ca", ds, Bb)).ravel())
             np.add.at(gh, V.conn.ravel(), (0.5 * surface * np.einsum("ci,ci->c", ds, kap)[:, None] * lam[None, :]).ravel())
     return (J, gw, gh) if grad else J
+
+
+# ----------------------------------------------------------------------------------------------
+# exact partials, boundary penalty, inertia, regularisation (round 3)
+# ----------------------------------------------------------------------------------------------
+def dform_dh(V: ShellSpace, h_nodal: np.ndarray, E: float, nu: float, v: np.ndarray, w: np.ndarray) -> np.ndarray:
+    """g_b = v^T (dK/dh_b) w for the CG1 thickness, differentiated exactly: the thickness enters the quadrature-point
+    factors h (membrane, shear) and h^3 (bending, drilling) through h_q = sum_b lam_b h_b.  This is (dR/dh)^T of
+    compute_jacvec_product 'rev' (state_model.py:190-200) for the residual K(h) w - F."""
+    e1, e2, e3, area, gl = V.frames()
+    C = plane_stress(E, nu)
+    mu = E / (2.0 * (1.0 + nu))
+    hc = np.asarray(h_nodal, dtype=np.float64)[V.conn]
+    ve, we = v[V.cell_dofs], w[V.cell_dofs]
+    g = np.zeros(V.n_vert)
+    for lam, wq in zip(*QUAD_INPLANE):
+        _, gN = _p2(lam, gl)
+        Bm, Bb, _, Bd = _strain_operators(e1, e2, e3, gN, gl, lam)
+        h = hc @ lam
+        mem = np.einsum("cia,ca,ij,cjb,cb->c", Bm, ve, C, Bm, we)
+        ben = np.einsum("cia,ca,ij,cjb,cb->c", Bb, ve, C, Bb, we)
+        dri = E * np.einsum("cia,ca,cib,cb->c", Bd, ve, Bd, we)
+        d = wq * area * (mem + h * h * (0.25 * ben + 3.0 * dri))
+        np.add.at(g, V.conn.ravel(), (d[:, None] * lam[None, :]).ravel())
+    for lam, wq in zip(*QUAD_SHEAR):
+        _, gN = _p2(lam, gl)
+        _, _, Bs, _ = _strain_operators(e1, e2, e3, gN, gl, lam)
+        sh = SHEAR_CORRECTION * mu * np.einsum("cia,ca,cib,cb->c", Bs, ve, Bs, we)
+        np.add.at(g, V.conn.ravel(), ((wq * area * sh)[:, None] * lam[None, :]).ravel())
+    return g
+
+
+def p2_mass_apply(V: ShellSpace, coeff_nodal: Optional[np.ndarray], a: np.ndarray, cells: Optional[np.ndarray] = None,
+                  power: int = 1) -> np.ndarray:
+    """y = M a on the displacement dofs, M_ab = int c(x)^power N_a N_b (c CG1, given at the vertices; None: 1), degree-4
+    rule; ``cells``: integrate over that subset only (a `dx(tag)` measure).  y has the length of the state vector."""
+    _, _, _, area, gl = V.frames()
+    y = np.zeros(V.n_dof)
+    ue = a[V.cell_dofs[:, :18]].reshape(-1, 6, 3)
+    sel = np.ones(V.conn.shape[0], bool) if cells is None else np.isin(np.arange(V.conn.shape[0]), cells)
+    cc = None if coeff_nodal is None else np.asarray(coeff_nodal, dtype=np.float64)[V.conn]
+    for lam, wq in zip(*QUAD_INPLANE):
+        N, _ = _p2(lam, gl)
+        c = 1.0 if cc is None else (cc @ lam) ** power
+        uq = np.einsum("a,cai->ci", N, ue)
+        contrib = np.einsum("c,a,ci->cai", wq * area * c * sel, N, uq).reshape(-1, 18)
+        np.add.at(y, V.cell_dofs[:, :18].ravel(), contrib.ravel())
+    return y
+
+
+def compliance(V: ShellSpace, w: np.ndarray, cells: Optional[np.ndarray] = None) -> float:
+    """1/2 int_dxx u_mid . u_mid (shell_pde.py:284-285 without the regularisation term), P2 mass matrix, degree-4 rule;
+    ``cells``: the cells of the `dxx` measure the reference passes (`shell_pde.py:66`: dx_2(10), a tagged subset)."""
+    return 0.5 * float(w @ p2_mass_apply(V, None, w, cells))
+
+
+def compliance_du(V: ShellSpace, w: np.ndarray, cells: Optional[np.ndarray] = None) -> np.ndarray:
+    """d compliance / d w = M_P2 u (zero on the rotations)."""
+    return p2_mass_apply(V, None, w, cells)
+
+
+def cell_diameter(V: ShellSpace) -> np.ndarray:
+    """UFL CellDiameter [ext]: the largest vertex distance of the cell."""
+    p = V.x[V.conn]
+    return np.max(np.stack([np.linalg.norm(p[:, i] - p[:, j], axis=1) for i, j in LOCAL_EDGES], axis=1), axis=1)
+
+
+def regularization(V: ShellSpace, h_nodal: np.ndarray, kind: Optional[str] = None, grad: bool = False):
+    """`ShellPDE.regularization(h, type)` (shell_pde.py:262-282), alpha1 = 1e3, alpha2 = 1:
+        'H1'   1/2 alpha1 int |grad h|^2          'L2'  1/2 alpha1 int h^2
+        'L2H1' 1/2 alpha1 int h^2 + 1/2 alpha2 int h_mesh^2 |grad h|^2        None: 0
+    for the CG1 thickness on the flat facets (tangential gradient).  grad: also d/dh (n_vert,)."""
+    h = np.asarray(h_nodal, dtype=np.float64)
+    _, _, _, area, gl = V.frames()
+    hc = h[V.conn]
+    a1, a2 = 1e3, 1.0
+    val, g = 0.0, np.zeros(V.n_vert)
+    if kind is None:
+        return (0.0, g) if grad else 0.0
+    if kind not in ("H1", "L2H1", "L2"):
+        raise ValueError(f"unknown regularisation {kind!r}")
+    if kind in ("L2", "L2H1"):
+        Me = area[:, None, None] / 12.0 * (np.ones((3, 3)) + np.eye(3))[None]          # P1 mass matrix
+        Mh = np.einsum("cab,cb->ca", Me, hc)
+        val += 0.5 * a1 * float((hc * Mh).sum())
+        np.add.at(g, V.conn.ravel(), (a1 * Mh).ravel())
+    if kind in ("H1", "L2H1"):
+        gh = np.einsum("cbj,cb->cj", gl, hc)                                             # grad h per cell (tangent coordinates)
+        coef = a1 * area if kind == "H1" else a2 * cell_diameter(V) ** 2 * area
+        val += 0.5 * float((coef * (gh * gh).sum(axis=1)).sum())
+        np.add.at(g, V.conn.ravel(), (coef[:, None] * np.einsum("cbj,cj->cb", gl, gh)).ravel())
+    return (val, g) if grad else val
+
+
+def tagged_edges(V: ShellSpace, marker) -> Tuple[np.ndarray, np.ndarray]:
+    """Edges all of whose vertices satisfy ``marker(x)`` (x: (3, n) like dolfinx's locate_entities [ext]): (exterior edge
+    ids, interior edge ids) -- the facets of the `ds(tag)` / `dS(tag)` measures of
+    run_aeroelasticity_static_wo_feedback.py:110-124."""
+    hit = np.asarray(marker(V.x.T), dtype=bool)
+    on = hit[V.edge_vertices[:, 0]] & hit[V.edge_vertices[:, 1]]
+    count = np.bincount(V.cell_edges.ravel(), minlength=V.n_edge)
+    return np.nonzero(on & (count == 1))[0], np.nonzero(on & (count == 2))[0]
+
+
+def penalty_matrix(V: ShellSpace, ext_edges: np.ndarray, int_edges: np.ndarray, beta: float) -> sp.csr_matrix:
+    """Boundary penalty of `weakFormResidual(..., penalty=True, dss, dSS, g)` (shell_pde.py:246-253; the form itself is in
+    the absent shell_analysis_fenicsx): restated in the idiom of the tree's other penalty terms
+    (run_poisson_opt.py:60, motor_pde.py:177-178)
+        beta / h_E (w - g) . dw  on ds,      [beta / h_E]('+') + [beta / h_E]('-') on dS,
+    all six fields of w = (u_mid, theta), h_E = CellDiameter of the adjacent cell(s).  Edge mass matrices: P2 (two
+    vertices + midpoint) for u, P1 for theta; exact (the reference integrates with degree 4).  Returns K_pen; the
+    residual contribution is K_pen (w - g)."""
+    hE = cell_diameter(V)
+    inv_h = np.zeros(V.n_edge)
+    np.add.at(inv_h, V.cell_edges.ravel(), np.repeat(1.0 / hE, 3))          # exterior: one cell; interior: both sides
+    edges = np.concatenate([np.asarray(ext_edges, dtype=np.int64), np.asarray(int_edges, dtype=np.int64)])
+    if edges.size == 0:
+        return sp.csr_matrix((V.n_dof, V.n_dof))
+    v0, v1 = V.edge_vertices[edges, 0], V.edge_vertices[edges, 1]
+    length = np.linalg.norm(V.x[v1] - V.x[v0], axis=1)
+    coef = beta * inv_h[edges] * length
+    M2 = np.array([[4.0, -1.0, 2.0], [-1.0, 4.0, 2.0], [2.0, 2.0, 16.0]]) / 30.0      # P2 on [0, 1]: (v0, v1, midpoint)
+    M1 = np.array([[2.0, 1.0], [1.0, 2.0]]) / 6.0
+    un = np.stack([v0, v1, V.n_vert + edges], axis=1)                                   # displacement nodes of the edge
+    rows, cols, vals = [], [], []
+    for k in range(3):
+        r = 3 * un + k
+        rows.append(np.repeat(r, 3, axis=1).ravel()); cols.append(np.tile(r, (1, 3)).ravel())
+        vals.append((coef[:, None, None] * M2[None]).ravel())
+        t = 3 * V.n_unode + 3 * np.stack([v0, v1], axis=1) + k
+        rows.append(np.repeat(t, 2, axis=1).ravel()); cols.append(np.tile(t, (1, 2)).ravel())
+        vals.append((coef[:, None, None] * M1[None]).ravel())
+    K = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(V.n_dof, V.n_dof)).tocsr()
+    K.sum_duplicates()
+    return K
+
+
+def inertia_apply(V: ShellSpace, h_nodal: np.ndarray, rho: float, acc: np.ndarray) -> np.ndarray:
+    """Inertial residual of `kinetic_residual(rho, h)` (shell_pde.py:255-256 -> ElasticModel.inertialResidual [ext, absent]):
+    the Reissner-Mindlin kinetic terms  int rho h  uddot . du  +  int rho h^3/12  thetaddot . dtheta  (consistent mass,
+    degree-4 rule, CG1 thickness) applied to the acceleration vector ``acc`` = (uddot, thetaddot) in state layout."""
+    _, _, _, area, _ = V.frames()
+    h = np.asarray(h_nodal, dtype=np.float64)
+    y = rho * p2_mass_apply(V, h, acc)
+    hc = h[V.conn]
+    te = acc[V.cell_dofs[:, 18:]].reshape(-1, 3, 3)
+    for lam, wq in zip(*QUAD_INPLANE):
+        hq = hc @ lam
+        tq = np.einsum("b,cbi->ci", lam, te)
+        contrib = np.einsum("c,b,ci->cbi", wq * area * rho * hq ** 3 / 12.0, lam, tq).reshape(-1, 9)
+        np.add.at(y, V.cell_dofs[:, 18:].ravel(), contrib.ravel())
+    return y
+
+
+def reference_cycle(n: int, E: float = 4.32e8, nu: float = 0.0, h0: float = 0.25) -> Dict:
+    """The cycle of BASELINE config 3 the way the reference runs it, on the n x n roof (bench.py's CPU leg): Newton with
+    always three iterations, each assembling K and factorising it afresh (utils_dolfinx.py:419-449), compliance and
+    dJ/dw, one more factorisation for the adjoint (state_model.py:157-158 with linear_problem = True), the transposed
+    solve and dJ/dh = -lam^T dK/dh w."""
+    pts, conn = scordelis_lo_mesh(n, n)
+    V = ShellSpace(pts, conn)
+    L = 25.0
+    ux, vx = V.unode_x, V.x
+    on = lambda arr, val: np.nonzero(np.isclose(arr, val, atol=1e-6))[0]
+    fixed = np.unique(np.concatenate([
+        V.u_dof(on(ux[:, 0], L), 1), V.u_dof(on(ux[:, 0], L), 2), V.u_dof(on(ux[:, 1], 0.0), 1), V.theta_dof(on(vx[:, 1], 0.0), 0),
+        V.theta_dof(on(vx[:, 1], 0.0), 2), V.u_dof(on(ux[:, 0], 0.0), 0), V.theta_dof(on(vx[:, 0], 0.0), 1), V.theta_dof(on(vx[:, 0], 0.0), 2)]))
+    free = np.setdiff1d(np.arange(V.n_dof), fixed)
+    h = np.full(V.n_vert, h0)
+    F = load_vector(V, np.tile([0.0, 0.0, -90.0], (V.n_vert, 1)))
+    w = np.zeros(V.n_dof)
+    for _ in range(3):
+        K = assemble(V, element_stiffness(V, h, E, nu))
+        r = K @ w - F
+        lu = spla.splu(K[free][:, free].tocsc())
+        w[free] -= lu.solve(r[free])
+    J = compliance(V, w)
+    dJdw = compliance_du(V, w)
+    K = assemble(V, element_stiffness(V, h, E, nu))
+    lu = spla.splu(K[free][:, free].tocsc())
+    lam = np.zeros(V.n_dof)
+    lam[free] = lu.solve(dJdw[free])
+    grad = -dform_dh(V, h, E, nu, lam, w)
+    tip = int(np.argmin(np.abs(vx[:, 0]) + np.abs(vx[:, 1] - vx[:, 1].max())))
+    return dict(n_dof=int(V.n_dof), w=w, J=J, grad=grad, tip=float(V.vertex_displacement(w)[tip, 2]))
 
 
 def scordelis_lo_mesh(nx: int, nphi: int, R: float = 25.0, L: float = 25.0, phi_max: float = np.deg2rad(40.0)):

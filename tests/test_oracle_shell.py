@@ -183,3 +183,118 @@ def test_projection_of_the_von_mises_stress():
     nodal = np.zeros(V.n_vert); np.add.at(nodal, V.conn.ravel(), np.repeat(area / 3.0, 3))
     assert float(nodal @ xl) == pytest.approx(float(nodal @ x), rel=1e-12)
     assert not np.allclose(xl, x, rtol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------- round 3
+def _small_roof():
+    pts, conn = so.scordelis_lo_mesh(6, 6)
+    V = so.ShellSpace(pts, conn)
+    rng = np.random.default_rng(0)
+    return V, rng, 0.25 * (1.0 + 0.3 * rng.random(V.n_vert))
+
+
+def test_exact_thickness_derivative_of_the_bilinear_form():
+    V, rng, h = _small_roof()
+    v, w = rng.standard_normal(V.n_dof), rng.standard_normal(V.n_dof)
+    E, nu = 4.32e8, 0.3
+    g = so.dform_dh(V, h, E, nu, v, w)
+    dh = 0.01 * rng.standard_normal(V.n_vert)
+    form = lambda hh: float(np.einsum("ca,cab,cb->", v[V.cell_dofs], so.element_stiffness(V, hh, E, nu), w[V.cell_dofs]))
+    # K is cubic in h: Richardson-extrapolated central differences are exact up to round-off
+    d1 = (form(h + 1e-2 * dh) - form(h - 1e-2 * dh)) / 2e-2
+    d2 = (form(h + 2e-2 * dh) - form(h - 2e-2 * dh)) / 4e-2
+    assert g @ dh == pytest.approx((4 * d1 - d2) / 3, rel=1e-10)
+    # homogeneity: h d/dh of (membrane + shear) + (bending + drilling) parts = 1 x and 3 x the parts
+    parts = so.element_stiffness(V, h, E, nu, return_parts=True)
+    val = [float(np.einsum("ca,cab,cb->", v[V.cell_dofs], P, w[V.cell_dofs])) for P in parts]
+    assert g @ h == pytest.approx(val[0] + 3 * val[1] + val[2] + 3 * val[3], rel=1e-11)
+
+
+def test_compliance_on_a_tagged_subset_and_its_gradient():
+    V, rng, _ = _small_roof()
+    w, d = rng.standard_normal(V.n_dof), rng.standard_normal(V.n_dof)
+    cells = np.arange(0, V.conn.shape[0], 3)
+    rest = np.setdiff1d(np.arange(V.conn.shape[0]), cells)
+    assert so.compliance(V, w) == pytest.approx(so.compliance(V, w, cells) + so.compliance(V, w, rest), rel=1e-13)
+    g = so.compliance_du(V, w, cells)
+    assert np.all(g[3 * V.n_unode:] == 0.0)
+    assert g @ d == pytest.approx((so.compliance(V, w + d, cells) - so.compliance(V, w - d, cells)) / 2.0, rel=1e-12)   # quadratic: exact
+    one = np.zeros(V.n_dof); one[0:3 * V.n_unode:3] = 1.0
+    _, _, _, area, _ = V.frames()
+    assert 2.0 * so.compliance(V, one) == pytest.approx(area.sum(), rel=1e-13)
+
+
+def test_regularisation_terms():
+    """shell_pde.py:262-282: values on fields with closed forms, gradients against differences."""
+    pts, conn = so.plate_mesh(6, a=2.0)
+    V = so.ShellSpace(pts, conn)
+    hlin = 0.1 + 0.3 * V.x[:, 0] - 0.2 * V.x[:, 1]                      # |grad h|^2 = 0.13 on an area of 4
+    assert so.regularization(V, hlin, "H1") == pytest.approx(0.5 * 1e3 * 0.13 * 4.0, rel=1e-12)
+    assert so.regularization(V, np.full(V.n_vert, 0.5), "L2") == pytest.approx(0.5 * 1e3 * 0.25 * 4.0, rel=1e-12)
+    hE = so.cell_diameter(V)
+    assert np.allclose(hE, np.sqrt(2.0) * 2.0 / 6)
+    assert so.regularization(V, hlin, "L2H1") == pytest.approx(so.regularization(V, hlin, "L2") + 0.5 * hE[0] ** 2 * 0.13 * 4.0, rel=1e-12)
+    assert so.regularization(V, hlin, None) == 0.0
+    rng = np.random.default_rng(3)
+    h, dh = 0.2 + 0.1 * rng.random(V.n_vert), rng.standard_normal(V.n_vert)
+    for kind in ("H1", "L2", "L2H1"):
+        _, g = so.regularization(V, h, kind, grad=True)
+        assert g @ dh == pytest.approx((so.regularization(V, h + dh, kind) - so.regularization(V, h - dh, kind)) / 2.0, rel=1e-11)
+    with pytest.raises(ValueError):
+        so.regularization(V, h, "H2")
+
+
+def test_penalty_boundary_terms_reach_the_strong_limit():
+    """The penalty form of `pdeRes(..., penalty=True, dss, dSS, g)`: symmetric positive semi-definite, acts on the tagged
+    edges only, and beta -> 1e15 (the value the reference's recorded runs name) reproduces the strongly clamped solution."""
+    import scipy.sparse.linalg as spla
+    pp, cc = so.plate_mesh(8)
+    P = so.ShellSpace(pp, cc)
+    ext, inte = so.tagged_edges(P, lambda x: x[0] <= 1e-9)
+    assert len(ext) == 8 and len(inte) == 0
+    ext2, int2 = so.tagged_edges(P, lambda x: x[0] <= 0.25 + 1e-9)          # a clamped REGION: interior facets too (dS)
+    assert len(ext2) == 8 + 2 * 2 and len(int2) > 0
+    K = so.assemble(P, so.element_stiffness(P, np.full(P.n_vert, 0.05), 1e7, 0.3))
+    F = so.load_vector(P, np.tile([0.0, 0.0, -1.0], (P.n_vert, 1)))
+    un, vn = np.nonzero(P.unode_x[:, 0] <= 1e-9)[0], np.nonzero(P.x[:, 0] <= 1e-9)[0]
+    fixed = np.concatenate([P.u_dof(un, k) for k in range(3)] + [P.theta_dof(vn, k) for k in range(3)])
+    ws = so.solve(K, F, fixed)
+    err = {}
+    for beta in (1e6, 1e10, 1e15):
+        Kp = so.penalty_matrix(P, ext, inte, beta)
+        assert abs(Kp - Kp.T).max() == 0.0
+        touched = np.unique(Kp.nonzero()[0])
+        assert np.array_equal(touched, np.sort(fixed))
+        err[beta] = np.abs(spla.spsolve((K + Kp).tocsc(), F) - ws).max() / np.abs(ws).max()
+    assert err[1e6] > err[1e10] > err[1e15] and err[1e15] < 1e-9 and err[1e10] < 1e-5
+    # edge mass matrices integrate constants exactly: 1^T K_pen 1 over one field = beta sum(len / h_E)
+    Kp = so.penalty_matrix(P, ext, inte, 2.0)
+    one = np.zeros(P.n_dof); one[0:3 * P.n_unode:3] = 1.0
+    assert one @ (Kp @ one) == pytest.approx(2.0 * 8 * (1.0 / 8) / so.cell_diameter(P)[0], rel=1e-12)
+    # inhomogeneous data: residual K_pen (w - g) vanishes at w = g
+    g = np.random.default_rng(1).standard_normal(P.n_dof)
+    assert np.abs(Kp @ (g - g)).max() == 0.0
+
+
+def test_inertial_residual():
+    """kinetic_residual (shell_pde.py:255-256): symmetric, total mass and rotary inertia of a uniform plate."""
+    pts, conn = so.plate_mesh(4, a=2.0)
+    V = so.ShellSpace(pts, conn)
+    h, rho = np.full(V.n_vert, 0.1), 3.0
+    rng = np.random.default_rng(2)
+    a, b = rng.standard_normal(V.n_dof), rng.standard_normal(V.n_dof)
+    assert a @ so.inertia_apply(V, h, rho, b) == pytest.approx(b @ so.inertia_apply(V, h, rho, a), rel=1e-12)
+    tz = np.zeros(V.n_dof); tz[2:3 * V.n_unode:3] = 1.0                     # unit acceleration in z
+    assert tz @ so.inertia_apply(V, h, rho, tz) == pytest.approx(rho * 0.1 * 4.0, rel=1e-12)
+    rx = np.zeros(V.n_dof); rx[3 * V.n_unode::3] = 1.0                      # unit angular acceleration about x
+    assert rx @ so.inertia_apply(V, h, rho, rx) == pytest.approx(rho * 0.1 ** 3 / 12.0 * 4.0, rel=1e-12)
+    hv = 0.1 * (1.0 + V.x[:, 0])                                            # linear thickness: int rho h = rho 0.1 (4 + 4)
+    assert tz @ so.inertia_apply(V, hv, rho, tz) == pytest.approx(rho * 0.1 * 8.0, rel=1e-12)
+
+
+def test_reference_cycle_of_the_roof():
+    out = so.reference_cycle(8)
+    assert out["tip"] == pytest.approx(so.scordelis_lo(8, 8)[0], rel=1e-9)          # three Newton steps on a linear problem = one solve
+    V = so.ShellSpace(*so.scordelis_lo_mesh(8, 8))
+    assert out["J"] == pytest.approx(so.compliance(V, out["w"]), rel=1e-13)
+    assert out["grad"].shape == (V.n_vert,) and np.all(np.isfinite(out["grad"]))
