@@ -116,6 +116,14 @@ PROTOTYPES = {
     "femo_shell_dform_dh": (C.c_int, [H, C.c_double, C.c_double, H, H, H, C.c_int, H, C.POINTER(C.c_double)]),
     "femo_shell_compliance": (C.c_int, [H, H, C.POINTER(C.c_double), C.c_int, H]),
     "femo_shell_mass": (C.c_int, [H, C.c_double, H, C.POINTER(C.c_double), C.c_int, H]),
+    "femo_shell_compliance_dx": (C.c_int, [H, H, H, C.POINTER(C.c_double), C.c_int, H]),
+    "femo_shell_regularization": (C.c_int, [H, C.c_int, H, C.POINTER(C.c_double), C.c_int, H]),
+    "femo_shell_hpower": (C.c_int, [H, C.c_double, C.c_double, H, C.POINTER(C.c_double), C.c_int, H]),
+    "femo_shell_set_penalty": (C.c_int, [H, c_i64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "femo_shell_penalty_add": (C.c_int, [H, H]),
+    "femo_shell_penalty_apply": (C.c_int, [H, H, H, C.c_int, H]),
+    "femo_shell_inertia_apply": (C.c_int, [H, C.c_double, H, H, C.c_int, H]),
+    "femo_shell_inertia_dh": (C.c_int, [H, C.c_double, H, H, H, C.c_int, H]),
     "femo_shell_solve": (C.c_int, [H, H, C.c_void_p, H, H, H, C.POINTER(SolverOpts), C.POINTER(SolveInfo)]),
     "femo_mesh_set_global": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int64]),
     "femo_mesh_pc_info": (C.c_int, [H, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),

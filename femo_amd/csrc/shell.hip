@@ -81,6 +81,10 @@ struct femo_shell {
   int64_t* d_cs_ptr = nullptr;
   double *d_cs_A = nullptr, *d_cs_tmp = nullptr;       // L^-T above / L^-1 below the diagonal (row-major, N x N); L^-1 g
   double* d_cs_dinv = nullptr;                         // inverses of the diagonal tiles of L
+  // penalty boundary terms (femo_shell_set_penalty): tagged edges, their coefficient and the CSR positions of their entries
+  int64_t pen_n = 0;
+  int32_t *d_pen_nodes = nullptr, *d_pen_pos = nullptr;
+  double* d_pen_coef = nullptr;
 };
 
 // plain view of the device arrays for kernels
@@ -383,14 +387,18 @@ __global__ __launch_bounds__(SH_BLOCK) void k_shell_load_T(femo_shell_view S, co
 }
 
 // compliance 1/2 int u.u (partials per block) and, if grad != nullptr, its gradient M_u w added to grad
-__global__ __launch_bounds__(SH_BLOCK) void k_shell_compliance(femo_shell_view S, const double* __restrict__ w, double* __restrict__ partials,
-                                                               double* __restrict__ grad) {
+// cellw (optional, one weight per cell): the `dxx` measure of shell_pde.py:66,284 -- dx_2(10), a tagged subset of cells --
+// as a DG0 indicator; cells of weight 0 are skipped
+__global__ __launch_bounds__(SH_BLOCK) void k_shell_compliance(femo_shell_view S, const double* __restrict__ w, const double* __restrict__ cellw,
+                                                               double* __restrict__ partials, double* __restrict__ grad) {
   __shared__ double lds[SH_BLOCK / 64];
   const int64_t c = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x;
   double J = 0.0;
-  if (c < S.n_cell) {
+  const double chi = (c < S.n_cell && cellw != nullptr) ? cellw[c] : 1.0;
+  if (c < S.n_cell && chi != 0.0) {
     Facet F;
     facet_frame(S.x, S.conn, c, F);
+    F.area *= chi;
     double ue[18], ge[18];
     for (int i = 0; i < 18; ++i) { ue[i] = w[shell_gdof(S, c, i)]; ge[i] = 0.0; }
     for (int q = 0; q < 6; ++q) {
@@ -540,6 +548,192 @@ __global__ __launch_bounds__(SH_BLOCK) void k_shell_mass(femo_shell_view S, doub
   }
   if (partials != nullptr) {
     const double t = femo_block_sum<SH_BLOCK>(M, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  }
+}
+
+// ------------------------------------------------- penalty boundary terms, inertia, regularisation (round 3) ----
+// Edge mass matrices on [0, 1] x length: P2 (end vertices, midpoint) and P1
+__constant__ double c_m2[3][3] = {{4.0 / 30, -1.0 / 30, 2.0 / 30}, {-1.0 / 30, 4.0 / 30, 2.0 / 30}, {2.0 / 30, 2.0 / 30, 16.0 / 30}};
+__constant__ double c_m1[2][2] = {{2.0 / 6, 1.0 / 6}, {1.0 / 6, 2.0 / 6}};
+
+// vals += K_pen: per tagged edge and component 9 + 4 entries at the CSR positions the host looked up (pos: 39 per edge,
+// component-major: 9 displacement pairs row-major over (v0, v1, mid), then 4 rotation pairs over (v0, v1)); coef =
+// beta (sum over adjacent cells of 1 / h_E) |edge|  (oracle/shell_oracle.py::penalty_matrix)
+__global__ void k_shell_penalty_add(int64_t n_e, const int32_t* __restrict__ pos, const double* __restrict__ coef, double* __restrict__ vals) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_e * 39) return;
+  const int64_t e = t / 39;
+  const int r = (int)(t % 39) % 13;
+  const double m = r < 9 ? c_m2[r / 3][r % 3] : c_m1[(r - 9) / 2][(r - 9) % 2];
+  atomicAdd(&vals[pos[t]], coef[e] * m);
+}
+
+// y += K_pen (x - g)   (g == nullptr: homogeneous data)
+__global__ void k_shell_penalty_apply(int64_t n_e, const int32_t* __restrict__ nodes, const double* __restrict__ coef, int64_t n_unode,
+                                      const double* __restrict__ x, const double* __restrict__ g, double* __restrict__ y) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_e) return;
+  const int64_t un[3] = {nodes[3 * e], nodes[3 * e + 1], nodes[3 * e + 2]};
+  const double cf = coef[e];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    double d[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const int64_t dof = 3 * un[i] + k; d[i] = x[dof] - (g ? g[dof] : 0.0); }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) atomicAdd(&y[3 * un[i] + k], cf * (c_m2[i][0] * d[0] + c_m2[i][1] * d[1] + c_m2[i][2] * d[2]));
+    double t2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int64_t dof = 3 * n_unode + 3 * un[i] + k; t2[i] = x[dof] - (g ? g[dof] : 0.0); }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) atomicAdd(&y[3 * n_unode + 3 * un[i] + k], cf * (c_m1[i][0] * t2[0] + c_m1[i][1] * t2[1]));
+  }
+}
+
+// Inertial residual (shell_pde.py:255-256 kinetic_residual -> inertialResidual [ext]):
+//   y += M(h) a,  M = int rho h  N_a N_b (displacements, P2) + int rho h^3 / 12  phi_a phi_b (rotations, P1), degree-4 rule;
+//   out_h[b] += lam^T (dM/dh_b) a   when lam != nullptr (y is not written then).  One thread per cell.
+__global__ __launch_bounds__(SH_BLOCK) void k_shell_inertia(femo_shell_view S, double rho, const double* __restrict__ h, const double* __restrict__ a,
+                                                            const double* __restrict__ lam_state, double* __restrict__ y, double* __restrict__ out_h) {
+  const int64_t c = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x;
+  if (c >= S.n_cell) return;
+  Facet F;
+  facet_frame(S.x, S.conn, c, F);
+  const double hv[3] = {h[S.conn[c * 3]], h[S.conn[c * 3 + 1]], h[S.conn[c * 3 + 2]]};
+  double ae[27], le[27], acc[27];
+  for (int i = 0; i < 27; ++i) {
+    const int64_t gd = shell_gdof(S, c, i);
+    ae[i] = a[gd];
+    le[i] = lam_state ? lam_state[gd] : 0.0;
+    acc[i] = 0.0;
+  }
+  double gh[3] = {0.0, 0.0, 0.0};
+  for (int q = 0; q < 6; ++q) {
+    const double* lam = c_lam6[q];
+    const double hq = hv[0] * lam[0] + hv[1] * lam[1] + hv[2] * lam[2];
+    const double wq = c_w6[q] * F.area * rho;
+    double uq[3] = {0, 0, 0}, tq[3] = {0, 0, 0}, lu[3] = {0, 0, 0}, lt[3] = {0, 0, 0};
+    for (int n = 0; n < 6; ++n) {
+      const double N = p2_value(lam, n);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { uq[k] += N * ae[3 * n + k]; lu[k] += N * le[3 * n + k]; }
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { tq[k] += lam[b] * ae[18 + 3 * b + k]; lt[k] += lam[b] * le[18 + 3 * b + k]; }
+    if (lam_state == nullptr) {
+      const double cu = wq * hq, ct = wq * hq * hq * hq * (1.0 / 12.0);
+      for (int n = 0; n < 6; ++n) {
+        const double N = p2_value(lam, n) * cu;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[3 * n + k] += N * uq[k];
+      }
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[18 + 3 * b + k] += ct * lam[b] * tq[k];
+    } else {
+      const double d = wq * ((lu[0] * uq[0] + lu[1] * uq[1] + lu[2] * uq[2]) + 0.25 * hq * hq * (lt[0] * tq[0] + lt[1] * tq[1] + lt[2] * tq[2]));
+#pragma unroll
+      for (int b = 0; b < 3; ++b) gh[b] += d * lam[b];
+    }
+  }
+  if (lam_state == nullptr) {
+    for (int i = 0; i < 27; ++i) atomicAdd(&y[shell_gdof(S, c, i)], acc[i]);
+  } else {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) atomicAdd(&out_h[S.conn[c * 3 + b]], gh[b]);
+  }
+}
+
+// `ShellPDE.regularization(h, type)` (shell_pde.py:262-282), alpha1 = 1e3, alpha2 = 1, CG1 thickness on flat facets:
+//   kind 1 'H1':  1/2 alpha1 int |grad h|^2     kind 2 'L2H1': 1/2 alpha1 int h^2 + 1/2 alpha2 int h_mesh^2 |grad h|^2
+//   kind 3 'L2':  1/2 alpha1 int h^2            h_mesh = CellDiameter = the largest vertex distance of the cell [ext]
+// partials: per-block sums of the value; grad += d/dh.  One thread per cell.
+__global__ __launch_bounds__(SH_BLOCK) void k_shell_regularization(femo_shell_view S, int kind, const double* __restrict__ h,
+                                                                   double* __restrict__ partials, double* __restrict__ grad) {
+  __shared__ double lds[SH_BLOCK / 64];
+  const int64_t c = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x;
+  double val = 0.0;
+  if (c < S.n_cell) {
+    Facet F;
+    facet_frame(S.x, S.conn, c, F);
+    const double a1 = 1e3, a2 = 1.0;
+    const double hv[3] = {h[S.conn[c * 3]], h[S.conn[c * 3 + 1]], h[S.conn[c * 3 + 2]]};
+    double g[3] = {0.0, 0.0, 0.0};
+    if (kind == 2 || kind == 3) {
+      const double k12 = F.area * (1.0 / 12.0), sum = hv[0] + hv[1] + hv[2];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const double Mh = k12 * (sum + hv[b]);
+        val += 0.5 * a1 * hv[b] * Mh;
+        g[b] += a1 * Mh;
+      }
+    }
+    if (kind == 1 || kind == 2) {
+      double coef = a1 * F.area;
+      if (kind == 2) {
+        double d2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int j = (i + 1) % 3;
+          double l2 = 0.0;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const double dx = S.x[(int64_t)S.conn[c * 3 + i] * 3 + k] - S.x[(int64_t)S.conn[c * 3 + j] * 3 + k];
+            l2 += dx * dx;
+          }
+          d2 = fmax(d2, l2);
+        }
+        coef = a2 * d2 * F.area;
+      }
+      const double g1 = F.gl[0][0] * hv[0] + F.gl[1][0] * hv[1] + F.gl[2][0] * hv[2];
+      const double g2 = F.gl[0][1] * hv[0] + F.gl[1][1] * hv[1] + F.gl[2][1] * hv[2];
+      val += 0.5 * coef * (g1 * g1 + g2 * g2);
+#pragma unroll
+      for (int b = 0; b < 3; ++b) g[b] += coef * (F.gl[b][0] * g1 + F.gl[b][1] * g2);
+    }
+    if (grad != nullptr) {
+#pragma unroll
+      for (int b = 0; b < 3; ++b) atomicAdd(&grad[S.conn[c * 3 + b]], g[b]);
+    }
+  }
+  if (partials != nullptr) {
+    const double t = femo_block_sum<SH_BLOCK>(val, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  }
+}
+
+// int coef h^p dx with the degree-4 rule (the thickness term of pnorm_stress(regularization=True), shell_pde.py:307-309:
+// 0.5 * 1e3 * h**rho * dx) and its gradient.  One thread per cell.
+__global__ __launch_bounds__(SH_BLOCK) void k_shell_hpower(femo_shell_view S, double coef, double p, const double* __restrict__ h,
+                                                           double* __restrict__ partials, double* __restrict__ grad) {
+  __shared__ double lds[SH_BLOCK / 64];
+  const int64_t c = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x;
+  double val = 0.0;
+  if (c < S.n_cell) {
+    Facet F;
+    facet_frame(S.x, S.conn, c, F);
+    const double hv[3] = {h[S.conn[c * 3]], h[S.conn[c * 3 + 1]], h[S.conn[c * 3 + 2]]};
+    double g[3] = {0.0, 0.0, 0.0};
+    for (int q = 0; q < 6; ++q) {
+      const double* lam = c_lam6[q];
+      const double hq = hv[0] * lam[0] + hv[1] * lam[1] + hv[2] * lam[2];
+      const double wq = c_w6[q] * F.area * coef;
+      const double pm1 = pow(hq, p - 1.0);
+      val += wq * pm1 * hq;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) g[b] += wq * p * pm1 * lam[b];
+    }
+    if (grad != nullptr) {
+#pragma unroll
+      for (int b = 0; b < 3; ++b) atomicAdd(&grad[S.conn[c * 3 + b]], g[b]);
+    }
+  }
+  if (partials != nullptr) {
+    const double t = femo_block_sum<SH_BLOCK>(val, lds);
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
   }
 }
@@ -1829,6 +2023,7 @@ int femo_shell_destroy(femo_shell* s) {
   hipFree(s->d_ptp_rowptr); hipFree(s->d_ptp_cols); hipFree(s->d_ptp_vals);
   hipFree(s->d_cs_xyz); hipFree(s->d_cs_ptr); hipFree(s->d_cs_pts); hipFree(s->d_cs_nbr); hipFree(s->d_cs_A); hipFree(s->d_cs_tmp); hipFree(s->d_cs_dinv); hipFree(s->d_cs_info); hipFree(s->d_cs_pcell);
   hipFree(s->d_cd_rowptr); hipFree(s->d_cd_cols); hipFree(s->d_cd_vals);
+  hipFree(s->d_pen_nodes); hipFree(s->d_pen_pos); hipFree(s->d_pen_coef);
   hipFree(s->d_r); hipFree(s->d_p); hipFree(s->d_q); hipFree(s->d_dinv); hipFree(s->d_scal); hipFree(s->d_part); hipFree(s->d_flag);
   hipFree(s->d_ell_idx); hipFree(s->d_ell_w);
   hipFree(s->d_par_rowptr); hipFree(s->d_par_cols); hipFree(s->d_par_vals); hipFree(s->d_chi_rowptr); hipFree(s->d_chi_cols); hipFree(s->d_chi_vals);
@@ -2178,8 +2373,13 @@ int femo_shell_dform_dh(femo_shell* s, double E, double nu, const femo_vec* h, c
 }
 
 int femo_shell_compliance(femo_shell* s, const femo_vec* w, double* value, int accumulate, femo_vec* grad) {
+  return femo_shell_compliance_dx(s, w, nullptr, value, accumulate, grad);
+}
+
+int femo_shell_compliance_dx(femo_shell* s, const femo_vec* w, const femo_vec* cell_weight, double* value, int accumulate, femo_vec* grad) {
   FEMO_REQUIRE(s && w, "null argument");
   FEMO_REQUIRE(w->n >= s->n_dof && (grad == nullptr || grad->n >= s->n_dof), "vector size mismatch in shell_compliance");
+  FEMO_REQUIRE(cell_weight == nullptr || cell_weight->n >= s->n_cell, "cell weights shorter than n_cell");
   hipStream_t st = s->ctx->stream;
   const unsigned g = sgrid(s->n_cell);
   FEMO_REQUIRE(value == nullptr || g <= 3 * SH_MAXPART, "mesh too large for the reduction buffer");
@@ -2187,7 +2387,8 @@ int femo_shell_compliance(femo_shell* s, const femo_vec* w, double* value, int a
     femo_vec_touch(grad);
     if (!accumulate) FEMO_HIP_CHECK(hipMemsetAsync(grad->d, 0, s->n_dof * sizeof(double), st));
   }
-  hipLaunchKernelGGL(k_shell_compliance, dim3(g), dim3(SH_BLOCK), 0, st, view(s), w->d, value ? s->d_part : nullptr, grad ? grad->d : nullptr);
+  hipLaunchKernelGGL(k_shell_compliance, dim3(g), dim3(SH_BLOCK), 0, st, view(s), w->d, cell_weight ? cell_weight->d : (const double*)nullptr,
+                     value ? s->d_part : nullptr, grad ? grad->d : nullptr);
   FEMO_HIP_CHECK(hipGetLastError());
   if (value) FEMO_TRY(reduce_partials(s->ctx, s->d_part, (int)g, value));
   return 0;
@@ -2258,6 +2459,111 @@ int femo_shell_mass(femo_shell* s, double rho, const femo_vec* h, double* value,
     if (!accumulate) FEMO_HIP_CHECK(hipMemsetAsync(grad->d, 0, s->n_vert * sizeof(double), st));
   }
   hipLaunchKernelGGL(k_shell_mass, dim3(g), dim3(SH_BLOCK), 0, st, view(s), rho, h->d, value ? s->d_part : nullptr, grad ? grad->d : nullptr);
+  FEMO_HIP_CHECK(hipGetLastError());
+  if (value) FEMO_TRY(reduce_partials(s->ctx, s->d_part, (int)g, value));
+  return 0;
+}
+
+// ---- penalty boundary terms: K_pen = sum over tagged edges of coef_e x (edge mass matrices), all six fields ----
+int femo_shell_set_penalty(femo_shell* s, int64_t n_edges, const int32_t* edge_nodes, const double* coef, const int32_t* pos) {
+  FEMO_REQUIRE(s != nullptr && n_edges >= 0, "bad argument");
+  FEMO_REQUIRE(n_edges == 0 || (edge_nodes && coef && pos), "null argument");
+  hipStream_t st = s->ctx->stream;
+  FEMO_HIP_CHECK(hipSetDevice(s->ctx->device));
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  hipFree(s->d_pen_nodes); hipFree(s->d_pen_pos); hipFree(s->d_pen_coef);
+  s->d_pen_nodes = s->d_pen_pos = nullptr; s->d_pen_coef = nullptr; s->pen_n = 0;
+  if (n_edges == 0) return 0;
+  for (int64_t e = 0; e < n_edges; ++e) {
+    FEMO_REQUIRE(edge_nodes[3 * e] >= 0 && edge_nodes[3 * e] < s->n_vert && edge_nodes[3 * e + 1] >= 0 && edge_nodes[3 * e + 1] < s->n_vert &&
+                 edge_nodes[3 * e + 2] >= s->n_vert && edge_nodes[3 * e + 2] < s->n_unode, "penalty edge %lld: bad node numbers", (long long)e);
+    for (int k = 0; k < 39; ++k) FEMO_REQUIRE(pos[39 * e + k] >= 0 && pos[39 * e + k] < s->nnz, "penalty edge %lld: position outside the pattern", (long long)e);
+  }
+  FEMO_TRY(to_device(&s->d_pen_nodes, edge_nodes, 3 * n_edges, st));
+  FEMO_TRY(to_device(&s->d_pen_pos, pos, 39 * n_edges, st));
+  FEMO_TRY(to_device(&s->d_pen_coef, coef, n_edges, st));
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  s->pen_n = n_edges;
+  return 0;
+}
+
+int femo_shell_penalty_add(femo_shell* s, femo_vec* vals) {
+  FEMO_REQUIRE(s && vals, "null argument");
+  FEMO_REQUIRE(vals->n >= s->nnz, "vector size mismatch in shell_penalty_add");
+  if (s->pen_n == 0) return 0;
+  femo_vec_touch(vals);
+  hipLaunchKernelGGL(k_shell_penalty_add, dim3(sgrid(s->pen_n * 39, 256)), dim3(256), 0, s->ctx->stream, s->pen_n, s->d_pen_pos, s->d_pen_coef, vals->d);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int femo_shell_penalty_apply(femo_shell* s, const femo_vec* x, const femo_vec* g, int accumulate, femo_vec* y) {
+  FEMO_REQUIRE(s && x && y, "null argument");
+  FEMO_REQUIRE(x->n >= s->n_dof && y->n >= s->n_dof && (g == nullptr || g->n >= s->n_dof) && x->d != y->d, "vector size mismatch in shell_penalty_apply");
+  hipStream_t st = s->ctx->stream;
+  femo_vec_touch(y);
+  if (!accumulate) FEMO_HIP_CHECK(hipMemsetAsync(y->d, 0, s->n_dof * sizeof(double), st));
+  if (s->pen_n == 0) return 0;
+  hipLaunchKernelGGL(k_shell_penalty_apply, dim3(sgrid(s->pen_n, 256)), dim3(256), 0, st, s->pen_n, s->d_pen_nodes, s->d_pen_coef, s->n_unode, x->d,
+                     g ? g->d : (const double*)nullptr, y->d);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// y (+)= M(h) acc: the inertial residual for the accelerations `acc` in state layout
+int femo_shell_inertia_apply(femo_shell* s, double rho, const femo_vec* h, const femo_vec* acc, int accumulate, femo_vec* y) {
+  FEMO_REQUIRE(s && h && acc && y, "null argument");
+  FEMO_REQUIRE(h->n >= s->n_vert && acc->n >= s->n_dof && y->n >= s->n_dof && acc->d != y->d, "vector size mismatch in shell_inertia_apply");
+  hipStream_t st = s->ctx->stream;
+  femo_vec_touch(y);
+  if (!accumulate) FEMO_HIP_CHECK(hipMemsetAsync(y->d, 0, s->n_dof * sizeof(double), st));
+  hipLaunchKernelGGL(k_shell_inertia, dim3(sgrid(s->n_cell)), dim3(SH_BLOCK), 0, st, view(s), rho, h->d, acc->d, (const double*)nullptr, y->d, (double*)nullptr);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// out_b (+)= lam^T (dM/dh_b) acc: the thickness partial of the inertial residual, transposed
+int femo_shell_inertia_dh(femo_shell* s, double rho, const femo_vec* h, const femo_vec* lam, const femo_vec* acc, int accumulate, femo_vec* out) {
+  FEMO_REQUIRE(s && h && lam && acc && out, "null argument");
+  FEMO_REQUIRE(h->n >= s->n_vert && lam->n >= s->n_dof && acc->n >= s->n_dof && out->n >= s->n_vert, "vector size mismatch in shell_inertia_dh");
+  hipStream_t st = s->ctx->stream;
+  femo_vec_touch(out);
+  if (!accumulate) FEMO_HIP_CHECK(hipMemsetAsync(out->d, 0, s->n_vert * sizeof(double), st));
+  hipLaunchKernelGGL(k_shell_inertia, dim3(sgrid(s->n_cell)), dim3(SH_BLOCK), 0, st, view(s), rho, h->d, acc->d, lam->d, (double*)nullptr, out->d);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// kind 1 'H1', 2 'L2H1', 3 'L2' (shell_pde.py:262-282); value and / or gradient w.r.t. the thickness
+int femo_shell_regularization(femo_shell* s, int kind, const femo_vec* h, double* value, int accumulate, femo_vec* grad) {
+  FEMO_REQUIRE(s && h, "null argument");
+  FEMO_REQUIRE(kind >= 1 && kind <= 3, "unknown regularisation kind %d", kind);
+  FEMO_REQUIRE(h->n >= s->n_vert && (grad == nullptr || grad->n >= s->n_vert), "vector size mismatch in shell_regularization");
+  hipStream_t st = s->ctx->stream;
+  const unsigned g = sgrid(s->n_cell);
+  FEMO_REQUIRE(value == nullptr || g <= 3 * SH_MAXPART, "mesh too large for the reduction buffer");
+  if (grad) {
+    femo_vec_touch(grad);
+    if (!accumulate) FEMO_HIP_CHECK(hipMemsetAsync(grad->d, 0, s->n_vert * sizeof(double), st));
+  }
+  hipLaunchKernelGGL(k_shell_regularization, dim3(g), dim3(SH_BLOCK), 0, st, view(s), kind, h->d, value ? s->d_part : nullptr, grad ? grad->d : nullptr);
+  FEMO_HIP_CHECK(hipGetLastError());
+  if (value) FEMO_TRY(reduce_partials(s->ctx, s->d_part, (int)g, value));
+  return 0;
+}
+
+// int coef h^p dx and its thickness gradient
+int femo_shell_hpower(femo_shell* s, double coef, double p, const femo_vec* h, double* value, int accumulate, femo_vec* grad) {
+  FEMO_REQUIRE(s && h, "null argument");
+  FEMO_REQUIRE(h->n >= s->n_vert && (grad == nullptr || grad->n >= s->n_vert), "vector size mismatch in shell_hpower");
+  hipStream_t st = s->ctx->stream;
+  const unsigned g = sgrid(s->n_cell);
+  FEMO_REQUIRE(value == nullptr || g <= 3 * SH_MAXPART, "mesh too large for the reduction buffer");
+  if (grad) {
+    femo_vec_touch(grad);
+    if (!accumulate) FEMO_HIP_CHECK(hipMemsetAsync(grad->d, 0, s->n_vert * sizeof(double), st));
+  }
+  hipLaunchKernelGGL(k_shell_hpower, dim3(g), dim3(SH_BLOCK), 0, st, view(s), coef, p, h->d, value ? s->d_part : nullptr, grad ? grad->d : nullptr);
   FEMO_HIP_CHECK(hipGetLastError());
   if (value) FEMO_TRY(reduce_partials(s->ctx, s->d_part, (int)g, value));
   return 0;

@@ -92,7 +92,52 @@ class ShellSpace:
                 for j in range(3):
                     epos[:, :, i, :, j] = b32 + (i * s32 + j)
             self._pattern = (rowptr, cols, epos.reshape(nc, 729))
+            self._block_lookup = (uniq, brow, nb, nbn)
         return self._pattern
+
+    def positions(self, rows, cols) -> np.ndarray:
+        """CSR positions of the couplings (rows[i], cols[i]) in the pattern (int32); every pair must be one."""
+        self.pattern()
+        uniq, brow, nb, nbn = self._block_lookup
+        rows, cols = np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)
+        br, bc = rows // 3, cols // 3
+        b = np.searchsorted(uniq, br * nbn + bc)
+        if np.any(b >= uniq.size) or np.any(uniq[np.minimum(b, uniq.size - 1)] != br * nbn + bc):
+            raise ValueError("ShellSpace.positions: a pair is not in the element-coupling pattern")
+        slot = b - brow[br]
+        return (9 * brow[br] + 3 * (rows % 3) * nb[br] + 3 * slot + cols % 3).astype(np.int32)
+
+    def cell_diameter(self) -> np.ndarray:
+        """UFL CellDiameter [ext]: the largest vertex distance of each cell."""
+        p = self.x[self.conn]
+        return np.max(np.stack([np.linalg.norm(p[:, i] - p[:, j], axis=1) for i, j in LOCAL_EDGES], axis=1), axis=1)
+
+    def tagged_edges(self, marker):
+        """(exterior edge ids, interior edge ids) of the edges all of whose vertices satisfy ``marker(x)`` (x: (3, n) as
+        in dolfinx's locate_entities / locate_entities_boundary [ext]) -- the facets of the reference's `ds_1(100)` /
+        `dS_1(100)` measures (run_aeroelasticity_static_wo_feedback.py:110-124)."""
+        hit = np.asarray(marker(self.x.T), dtype=bool)
+        on = hit[self.edge_vertices[:, 0]] & hit[self.edge_vertices[:, 1]]
+        count = np.bincount(self.cell_edges.ravel(), minlength=self.n_edge)
+        return np.nonzero(on & (count == 1))[0], np.nonzero(on & (count == 2))[0]
+
+    def penalty_data(self, edges, beta: float):
+        """What `femo_shell_set_penalty` takes for the tagged ``edges`` (ids, exterior and interior alike): per edge its
+        three displacement nodes, coef = beta (sum over the adjacent cells of 1 / h_E) |edge| and the 39 CSR positions."""
+        edges = np.asarray(edges, dtype=np.int64)
+        inv_h = np.zeros(self.n_edge)
+        np.add.at(inv_h, self.cell_edges.ravel(), np.repeat(1.0 / self.cell_diameter(), 3))
+        v0, v1 = self.edge_vertices[edges, 0], self.edge_vertices[edges, 1]
+        length = np.linalg.norm(self.x[v1] - self.x[v0], axis=1)
+        coef = np.ascontiguousarray(beta * inv_h[edges] * length)
+        un = np.stack([v0, v1, self.n_vert + edges], axis=1)                                  # (ne, 3)
+        pos = np.empty((edges.size, 3, 13), dtype=np.int32)
+        for k in range(3):
+            r = 3 * un + k                                                                     # displacement dofs of the edge
+            pos[:, k, :9] = self.positions(np.repeat(r, 3, axis=1).ravel(), np.tile(r, (1, 3)).ravel()).reshape(-1, 9)
+            t = 3 * self.n_unode + 3 * un[:, :2] + k
+            pos[:, k, 9:] = self.positions(np.repeat(t, 2, axis=1).ravel(), np.tile(t, (1, 2)).ravel()).reshape(-1, 4)
+        return np.ascontiguousarray(un, dtype=np.int32), coef, np.ascontiguousarray(pos.reshape(-1, 39))
 
     def pattern_scalar_reference(self):
         """The same triple built directly from the 27 x 27 dof pairs of every cell (729 sort keys per cell)."""
@@ -358,6 +403,52 @@ class DeviceShell:
         check(self.lib.femo_shell_compliance(self.handle, w.handle, C.byref(val) if value else None, int(accumulate),
                                              grad.handle if grad is not None else None))
         return val.value
+
+    def compliance_dx(self, w: Vec, cell_weight: Optional[Vec], grad: Optional[Vec] = None, value: bool = True, accumulate: bool = False):
+        val = C.c_double(0.0)
+        check(self.lib.femo_shell_compliance_dx(self.handle, w.handle, cell_weight.handle if cell_weight is not None else None,
+                                                C.byref(val) if value else None, int(accumulate), grad.handle if grad is not None else None))
+        return val.value
+
+    REGULARIZATION_KINDS = {"H1": 1, "L2H1": 2, "L2": 3}
+
+    def regularization(self, kind: str, h: Vec, grad: Optional[Vec] = None, value: bool = True, accumulate: bool = False) -> float:
+        val = C.c_double(0.0)
+        check(self.lib.femo_shell_regularization(self.handle, self.REGULARIZATION_KINDS[kind], h.handle, C.byref(val) if value else None,
+                                                 int(accumulate), grad.handle if grad is not None else None))
+        return val.value
+
+    def hpower(self, coef: float, p: float, h: Vec, grad: Optional[Vec] = None, value: bool = True, accumulate: bool = False) -> float:
+        val = C.c_double(0.0)
+        check(self.lib.femo_shell_hpower(self.handle, float(coef), float(p), h.handle, C.byref(val) if value else None, int(accumulate),
+                                         grad.handle if grad is not None else None))
+        return val.value
+
+    def set_penalty(self, edges, beta: float) -> None:
+        """Tagged edges (ids) and penalty parameter of the boundary terms; ``edges`` empty: none."""
+        edges = np.asarray(edges, dtype=np.int64)
+        if edges.size == 0:
+            check(self.lib.femo_shell_set_penalty(self.handle, 0, None, None, None))
+            return
+        un, coef, pos = self.space.penalty_data(edges, beta)
+        p = lambda a: C.c_void_p(a.ctypes.data)
+        check(self.lib.femo_shell_set_penalty(self.handle, edges.size, p(un), p(coef), p(pos)))
+
+    def penalty_add(self, vals: Vec) -> Vec:
+        check(self.lib.femo_shell_penalty_add(self.handle, vals.handle))
+        return vals
+
+    def penalty_apply(self, x: Vec, y: Vec, g: Optional[Vec] = None, accumulate: bool = False) -> Vec:
+        check(self.lib.femo_shell_penalty_apply(self.handle, x.handle, g.handle if g is not None else None, int(accumulate), y.handle))
+        return y
+
+    def inertia_apply(self, rho: float, h: Vec, acc: Vec, y: Vec, accumulate: bool = False) -> Vec:
+        check(self.lib.femo_shell_inertia_apply(self.handle, float(rho), h.handle, acc.handle, int(accumulate), y.handle))
+        return y
+
+    def inertia_dh(self, rho: float, h: Vec, lam: Vec, acc: Vec, out: Vec, accumulate: bool = False) -> Vec:
+        check(self.lib.femo_shell_inertia_dh(self.handle, float(rho), h.handle, lam.handle, acc.handle, int(accumulate), out.handle))
+        return out
 
     def mass(self, rho: float, h: Vec, grad: Optional[Vec] = None, value: bool = True, accumulate: bool = False):
         val = C.c_double(0.0)

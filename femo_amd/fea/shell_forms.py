@@ -8,9 +8,11 @@ so `FEA.add_input / add_state / add_output`, `StateOperation`, `OutputOperation`
 compliance / mass / elastic energy as outputs).
 
 Stress outputs (`shell_pde.py:297-332`): ``pnorm_stress`` (scalar, with partials) and ``von_Mises_stress`` /
-``projected_von_Mises_stress`` (field).  Not built (say so when asked): the forward-mode product with dR/dh (the
-reference's forward mode returns zeros, `fea_dolfinx.py:192-206`), the penalty form of the boundary conditions (imposed
-strongly here, its limit) and the inertial residual.
+``projected_von_Mises_stress`` (field).  Round 3: the boundary conditions as the reference's driver configures them --
+``pdeRes(..., penalty=True, dss, dSS, g)`` with ``ShellMeasure`` objects standing for the tagged `ds` / `dS` / `dx`
+measures (`shell_pde.py:34,59-61`, `run_pav_shell.py:128-131`) --, ``kinetic_residual`` / ``elastic_residual``
+(`shell_pde.py:255-260`), the regularisation options of ``compliance`` (`:262-285`) and its `dxx` subset.  Not built (say so
+when asked): the forward-mode product with dR/dh (the reference's forward mode returns zeros, `fea_dolfinx.py:192-206`).
 """
 from __future__ import annotations
 
@@ -130,6 +132,52 @@ def _fixed_values(space: ShellSpace, bcs) -> Optional[np.ndarray]:
     return vals if any_nonzero else None
 
 
+class ShellMeasure:
+    """A UFL measure with subdomain data, as far as the shell forms use it: ``kind`` 'ds' (exterior facets = boundary
+    edges), 'dS' (interior facets) or 'dx' (cells), and the entities carrying ``tag``.  ``m(tag)`` selects, like
+    ``ds_1(100)`` in `run_aeroelasticity_static_wo_feedback.py:180` / `run_pav_shell.py:144-146`."""
+
+    def __init__(self, mesh: ShellMesh, kind: str, entities, tag: int = 0, selected: bool = False):
+        if kind not in ("ds", "dS", "dx"):
+            raise ValueError(f"unknown measure {kind!r}")
+        self.mesh, self.kind, self.tag, self.selected = mesh, kind, int(tag), selected
+        self.entities = np.unique(np.asarray(entities, dtype=np.int64))
+
+    def __call__(self, tag: int) -> "ShellMeasure":
+        ents = self.entities if int(tag) == self.tag else np.zeros(0, np.int64)
+        return ShellMeasure(self.mesh, self.kind, ents, tag, selected=True)
+
+    def cell_weight(self) -> np.ndarray:
+        """DG0 indicator of a 'dx' measure."""
+        if self.kind != "dx":
+            raise ValueError("cell_weight: not a dx measure")
+        w = np.zeros(self.mesh.n_cell)
+        w[self.entities] = 1.0
+        return w
+
+
+def createCustomMeasure(mesh: ShellMesh, dim: int, marker, measure: str = "ds", tag: int = 100) -> ShellMeasure:
+    """`createCustomMeasure(mesh, fdim, locator, measure='ds' | 'dS' | 'dx', tag=...)` of the shell drivers
+    (`run_pav_shell.py:128-131`): the entities of dimension ``dim`` all of whose vertices satisfy ``marker(x)`` (x: (3, n));
+    'ds' keeps the boundary edges among them, 'dS' the interior ones (locate_entities_boundary / locate_entities [ext],
+    `run_aeroelasticity_static_wo_feedback.py:110-124`)."""
+    S = mesh.space
+    if measure in ("ds", "dS"):
+        if dim != 1:
+            raise ValueError("facets of a surface mesh have dimension 1")
+        ext, inte = S.tagged_edges(marker)
+        return ShellMeasure(mesh, measure, ext if measure == "ds" else inte, tag)
+    if measure == "dx":
+        if dim != 2:
+            raise ValueError("cells of a surface mesh have dimension 2")
+        hit = np.asarray(marker(S.x.T), dtype=bool)
+        return ShellMeasure(mesh, "dx", np.nonzero(hit[S.conn].all(axis=1))[0], tag)
+    raise ValueError(f"unknown measure {measure!r}")
+
+
+PENALTY_BETA = 1e15        # the value the reference's recorded penalty runs name (run_aeroelasticity_static_wo_feedback.py:466,499)
+
+
 class ShellMatrix:
     """dR/dw = K(h) on the element-coupling pattern; with ``fixed`` the strongly imposed dofs are identity rows /
     columns in every product and solve (the A of state_model.py:149)."""
@@ -228,25 +276,58 @@ class ShellResidual(BackendForm):
     is_linear = True
     is_symmetric = True
 
-    def __init__(self, h: Function, w: Function, f: Function, E: float, nu: float):
+    def __init__(self, h: Function, w: Function, f: Optional[Function], E: float, nu: float, penalty_edges=None,
+                 g: Optional[Function] = None, beta: float = PENALTY_BETA, with_load: bool = True):
+        """``penalty_edges``: ids of the edges of the `dss` / `dSS` measures -- the penalty form of the boundary conditions,
+        K_pen (w - g) added to the residual and K_pen to dR/dw (oracle/shell_oracle.py::penalty_matrix); ``with_load=False``:
+        the elastic force alone (`elastic_residual`, shell_pde.py:258-260)."""
         self.h, self.w, self.f, self.E, self.nu = h, w, f, float(E), float(nu)
         self.u = w
         self.mesh = w.function_space.mesh
         self._vals: Optional[Vec] = None
         self._vals_ver = None
         self._res: Optional[Vec] = None
+        self.penalty_edges = None if penalty_edges is None else np.unique(np.asarray(penalty_edges, dtype=np.int64))
+        self.g, self.beta, self.with_load = g, float(beta), bool(with_load)
+
+    @property
+    def has_penalty(self) -> bool:
+        return self.penalty_edges is not None and self.penalty_edges.size > 0
 
     def functions(self):
-        return (self.h, self.w, self.f)
+        return tuple(fn for fn in (self.h, self.w, self.f, self.g) if fn is not None)
+
+    def _bind_penalty(self, dev: DeviceShell) -> None:
+        """The device handle holds one set of tagged edges: (re)load this form's when another form's is there."""
+        key = (id(self), self.beta)
+        if getattr(dev, "_penalty_owner", None) != key:
+            dev.set_penalty(self.penalty_edges if self.has_penalty else np.zeros(0, np.int64), self.beta)
+            dev._penalty_owner = key
 
     def stiffness(self) -> Vec:
+        """dR/dw = K(h) (+ K_pen): reassembled when the thickness changed."""
         dev = self.mesh.device(_ctx())
         if self._vals is None:
             self._vals = Vec(_ctx(), dev.nnz)
         if self._vals_ver != self.h.version:
             dev.assemble(self.E, self.nu, self.h.vec, self._vals)
+            if self.has_penalty:
+                self._bind_penalty(dev)
+                dev.penalty_add(self._vals)
             self._vals_ver = self.h.version
         return self._vals
+
+    def _rhs(self, out: Vec) -> Vec:
+        """F(f) + K_pen g: what the state equation K_total w = rhs has on its right."""
+        dev = self.mesh.device(_ctx())
+        if self.with_load and self.f is not None:
+            dev.load(self.f.vec, out)
+        else:
+            out.fill(0.0)
+        if self.has_penalty and self.g is not None:
+            self._bind_penalty(dev)
+            dev.penalty_apply(self.g.vec, out, accumulate=True)   # + K_pen g
+        return out
 
     def new_matrix(self) -> ShellMatrix:
         return ShellMatrix(self)
@@ -257,8 +338,14 @@ class ShellResidual(BackendForm):
             if self._res is None:
                 self._res = Vec(_ctx(), self.mesh.space.n_dof)
             out = self._res
-        dev.matvec(self.stiffness(), self.w.vec, out)
-        dev.load(self.f.vec, out, sign=-1.0, accumulate=True)
+        dev.matvec(self.stiffness(), self.w.vec, out)              # (K + K_pen) w
+        if self.with_load and self.f is not None:
+            dev.load(self.f.vec, out, sign=-1.0, accumulate=True)
+        if self.has_penalty and self.g is not None:
+            self._bind_penalty(dev)
+            tmp = Vec(_ctx(), self.mesh.space.n_dof)
+            dev.penalty_apply(self.g.vec, tmp)                     # K_pen g
+            out.axpy(-1.0, tmp)
         return out
 
     def partial_matrix(self, wrt: Function, out=None):
@@ -266,7 +353,9 @@ class ShellResidual(BackendForm):
             return ShellMatrix(self)
         if wrt is self.h:
             return out if isinstance(out, _ShellPartial) and out.wrt == "h" else _ShellPartial(self, "h")
-        if wrt is self.f:
+        if self.f is not None and wrt is self.f:
+            if not self.with_load:
+                raise ValueError("the elastic residual does not depend on the load")
             return out if isinstance(out, _ShellPartial) and out.wrt == "f" else _ShellPartial(self, "f")
         raise ValueError("the shell residual does not depend on that Function")
 
@@ -285,7 +374,7 @@ class ShellResidual(BackendForm):
         """K(h) w = F(f) with the imposed dofs (solveNonlinear -> NewtonSolver on a linear residual: one solve)."""
         dev = self.mesh.device(_ctx())
         S = self.mesh.space
-        F = dev.load(self.f.vec, Vec(_ctx(), S.n_dof))
+        F = self._rhs(Vec(_ctx(), S.n_dof))
         vals = _fixed_values(S, bcs) if bcs else None
         xfix = Vec(_ctx(), S.n_dof).set(vals) if vals is not None else None
         info = dev.solve(self.stiffness(), F, func.vec, fixed=_fixed_mask(S, bcs), xfix=xfix)
@@ -310,19 +399,130 @@ class _ShellScalar(BackendForm):
 
 
 class ShellCompliance(_ShellScalar):
-    """1/2 int u_mid . u_mid dx  (shell_pde.py:287-288; the thickness regularisation there is switched off by default)."""
+    """1/2 int_dxx u_mid . u_mid + regularization(h, type)  (shell_pde.py:262-285): ``dxx`` a tagged 'dx' measure (None: the
+    whole surface), ``regularization`` None (the reference's default), 'H1', 'L2H1' or 'L2'."""
 
-    def __init__(self, w: Function):
-        self.w, self.mesh = w, w.function_space.mesh
+    def __init__(self, w: Function, h: Optional[Function] = None, dxx: Optional[ShellMeasure] = None,
+                 regularization: Optional[str] = None):
+        self.w, self.h, self.mesh = w, h, w.function_space.mesh
+        if regularization is not None and regularization not in DeviceShell.REGULARIZATION_KINDS:
+            raise ValueError(f"unknown regularisation {regularization!r}")
+        if regularization is not None and h is None:
+            raise ValueError("the regularisation term needs the thickness")
+        self.regularization = regularization
+        if dxx is not None and (not isinstance(dxx, ShellMeasure) or dxx.kind != "dx"):
+            raise TypeError("compliance: dxx must be a ShellMeasure of kind 'dx'")
+        self._cw_host = None if dxx is None else dxx.cell_weight()
+        self._cw: Optional[Vec] = None
 
     def functions(self):
-        return (self.w,)
+        return (self.w,) if self.regularization is None else (self.w, self.h)
+
+    def _weight(self) -> Optional[Vec]:
+        if self._cw_host is None:
+            return None
+        if self._cw is None:
+            self._cw = Vec(_ctx(), self.mesh.n_cell).set(self._cw_host)
+        return self._cw
 
     def assemble_scalar(self) -> float:
-        return self.mesh.device(_ctx()).compliance(self.w.vec)
+        dev = self.mesh.device(_ctx())
+        J = dev.compliance_dx(self.w.vec, self._weight())
+        if self.regularization is not None:
+            J += dev.regularization(self.regularization, self.h.vec)
+        return J
 
     def _gradient(self, wrt, out):
-        self.mesh.device(_ctx()).compliance(self.w.vec, grad=out, value=False)
+        dev = self.mesh.device(_ctx())
+        if wrt is self.w:
+            dev.compliance_dx(self.w.vec, self._weight(), grad=out, value=False)
+        else:
+            dev.regularization(self.regularization, self.h.vec, grad=out, value=False)
+        return out
+
+
+class ShellInertialResidual(BackendForm):
+    """`kinetic_residual(rho, h)` (shell_pde.py:255-256 -> inertialResidual): M(h) a for the accelerations ``acc`` (a Function
+    on W: uddot on the displacement dofs, thetaddot on the rotations; the reference's dynamic driver passes them
+    explicitly, run_aeroelasticity_dynamic.py:93).  Partials: w.r.t. ``acc`` the (symmetric) mass operator, w.r.t. the
+    thickness lam^T dM/dh a."""
+    rank = 1
+    is_linear = True
+    is_symmetric = True
+
+    def __init__(self, rho: float, h: Function, acc: Function):
+        self.rho, self.h, self.acc = float(rho), h, acc
+        self.u = acc
+        self.mesh = acc.function_space.mesh
+        self._res: Optional[Vec] = None
+
+    def functions(self):
+        return (self.h, self.acc)
+
+    def assemble_vector(self, out: Optional[Vec] = None) -> Vec:
+        if out is None:
+            if self._res is None:
+                self._res = Vec(_ctx(), self.mesh.space.n_dof)
+            out = self._res
+        return self.mesh.device(_ctx()).inertia_apply(self.rho, self.h.vec, self.acc.vec, out)
+
+    def partial_matrix(self, wrt: Function, out=None):
+        if wrt is self.acc:
+            return _InertiaOperator(self, "a")
+        if wrt is self.h:
+            return _InertiaOperator(self, "h")
+        raise ValueError("the inertial residual does not depend on that Function")
+
+
+class _InertiaOperator:
+    def __init__(self, form: ShellInertialResidual, wrt: str):
+        self.form, self.wrt, self.mesh = form, wrt, form.mesh
+        self._row = self._col = None
+
+    def getSizes(self):
+        S = self.mesh.space
+        return (S.n_dof, S.n_dof if self.wrt == "a" else S.n_vert)
+
+    def mult(self, x: Vec, y: Vec) -> Vec:
+        if self.wrt == "h":
+            raise NotImplementedError("forward-mode product with dM/dh is not built (reverse mode is)")
+        F = self.form
+        return self.mesh.device(_ctx()).inertia_apply(F.rho, F.h.vec, x, y)
+
+    def multTranspose(self, x: Vec, y: Vec) -> Vec:
+        F = self.form
+        dev = self.mesh.device(_ctx())
+        if self.wrt == "a":
+            return dev.inertia_apply(F.rho, F.h.vec, x, y)
+        return dev.inertia_dh(F.rho, F.h.vec, x, F.acc.vec, y)
+
+    def new_row_vec(self) -> Vec:
+        if self._row is None:
+            self._row = Vec(_ctx(), self.getSizes()[0])
+        return self._row
+
+    def new_col_vec(self) -> Vec:
+        if self._col is None:
+            self._col = Vec(_ctx(), self.getSizes()[1])
+        return self._col
+
+
+class ShellRegularization(_ShellScalar):
+    """`ShellPDE.regularization(h, type)` (shell_pde.py:262-282) as a scalar form: 'H1', 'L2H1' or 'L2'."""
+
+    def __init__(self, h: Function, kind: str):
+        if kind not in DeviceShell.REGULARIZATION_KINDS:
+            raise ValueError(f"unknown regularisation {kind!r}")
+        self.h, self.kind, self.mesh = h, kind, h.function_space.mesh
+
+    def functions(self):
+        return (self.h,)
+
+    def assemble_scalar(self) -> float:
+        return self.mesh.device(_ctx()).regularization(self.kind, self.h.vec)
+
+    def _gradient(self, wrt, out):
+        self.mesh.device(_ctx()).regularization(self.kind, self.h.vec, grad=out, value=False)
         return out
 
 
@@ -346,9 +546,12 @@ class ShellMass(_ShellScalar):
 class ShellElasticEnergy(_ShellScalar):
     """1/2 w^T K(h) w (shell_pde.py:296-299)."""
 
-    def __init__(self, w: Function, h: Function, E: float, nu: float):
+    def __init__(self, w: Function, h: Function, E: float, nu: float, residual: Optional["ShellResidual"] = None):
         self.w, self.h, self.E, self.nu, self.mesh = w, h, float(E), float(nu), w.function_space.mesh
-        self._res = ShellResidual(h, w, None, E, nu)
+        # dE/dw = K(h) w needs the stiffness WITHOUT penalty terms: share the residual form's value array when it has
+        # none (ADVICE round 2: a second nnz-sized copy, ~1 GB at 2 M dofs), else keep a form of its own
+        share = residual is not None and not residual.has_penalty and residual.h is h and residual.E == self.E and residual.nu == self.nu
+        self._res = residual if share else ShellResidual(h, w, None, E, nu)
 
     def functions(self):
         return (self.w, self.h)
@@ -370,9 +573,10 @@ class ShellPnormStress(_ShellScalar):
     mid (0) or bottom (-1) surface; alpha = surface area unless given."""
 
     def __init__(self, w: Function, h: Function, E: float, nu: float, m: float = 1e-6, rho: float = 100.0,
-                 alpha: Optional[float] = None, surface: float = 1.0):
+                 alpha: Optional[float] = None, surface: float = 1.0, regularization: bool = False):
         self.w, self.h, self.E, self.nu, self.mesh = w, h, float(E), float(nu), w.function_space.mesh
         self.m, self.rho, self.surface = float(m), float(rho), float(surface)
+        self.regularization = bool(regularization)          # + 1/alpha int 0.5 * 1e3 * h**rho dx (shell_pde.py:307-309)
         if alpha is None:
             x, c = self.mesh.x, self.mesh.conn
             alpha = float(0.5 * np.linalg.norm(np.cross(x[c[:, 1]] - x[c[:, 0]], x[c[:, 2]] - x[c[:, 0]]), axis=1).sum())
@@ -382,12 +586,18 @@ class ShellPnormStress(_ShellScalar):
         return (self.w, self.h)
 
     def assemble_scalar(self) -> float:
-        return self.mesh.device(_ctx()).pnorm_stress(self.E, self.nu, self.h.vec, self.w.vec, self.m, self.rho, self.alpha, self.surface)
+        dev = self.mesh.device(_ctx())
+        J = dev.pnorm_stress(self.E, self.nu, self.h.vec, self.w.vec, self.m, self.rho, self.alpha, self.surface)
+        if self.regularization:
+            J += dev.hpower(0.5e3 / self.alpha, self.rho, self.h.vec)
+        return J
 
     def _gradient(self, wrt, out):
         dev = self.mesh.device(_ctx())
         kw = dict(grad_w=out) if wrt is self.w else dict(grad_h=out)
         dev.pnorm_stress(self.E, self.nu, self.h.vec, self.w.vec, self.m, self.rho, self.alpha, self.surface, value=False, **kw)
+        if self.regularization and wrt is self.h:
+            dev.hpower(0.5e3 / self.alpha, self.rho, self.h.vec, grad=out, value=False, accumulate=True)
         return out
 
 
@@ -419,13 +629,46 @@ class ShellPDE:
         self.VT = ShellFunctionSpace(mesh, "VT")
         self.VF = ShellFunctionSpace(mesh, "VF")
 
-    def pdeRes(self, h, w, f, E, nu, penalty=False, dss=None, dSS=None, g=None) -> ShellResidual:
+    def pdeRes(self, h, w, f, E, nu, penalty=False, dss=None, dSS=None, g=None, beta: float = PENALTY_BETA) -> ShellResidual:
+        """shell_pde.py:246-253.  ``penalty=True``: the boundary conditions w = g as penalty terms on the tagged exterior
+        (``dss``) and interior (``dSS``) facets, as the reference's drivers configure the shell (shell_pde.py:34,59-61);
+        the measures are ``ShellMeasure`` objects (``createCustomMeasure``); untagged `ufl.ds` / `ufl.dS` defaults of the
+        reference correspond to passing every boundary / interior edge.  ``beta``: the penalty parameter (the form itself
+        is in the absent shell_analysis_fenicsx; the recorded runs name 1e15)."""
+        edges = None
         if penalty:
-            raise NotImplementedError("penalty boundary terms: impose the dofs strongly (FEA.add_strong_bc)")
-        return ShellResidual(h, w, f, E, nu)
+            parts = []
+            for m, kind in ((dss, "ds"), (dSS, "dS")):
+                if m is None:
+                    continue
+                if not isinstance(m, ShellMeasure) or m.kind != kind:
+                    raise TypeError(f"pdeRes: {kind} must be a ShellMeasure of kind {kind!r}")
+                parts.append(m.entities)
+            if not parts:
+                raise ValueError("pdeRes(penalty=True) needs the tagged measures dss and / or dSS")
+            edges = np.concatenate(parts)
+        self.elastic_model = res = ShellResidual(h, w, f, E, nu, penalty_edges=edges, g=g, beta=beta)
+        return res
 
-    def compliance(self, w, h=None, dxx=None) -> ShellCompliance:
-        return ShellCompliance(w)
+    def kinetic_residual(self, rho, h, acc: Optional[Function] = None) -> "ShellInertialResidual":
+        """shell_pde.py:255-256.  ``acc``: the accelerations (uddot, thetaddot) as a Function on W; a new zero Function by
+        default (the reference's method takes them from the elastic model it built in pdeRes)."""
+        return ShellInertialResidual(rho, h, acc if acc is not None else Function(self.W))
+
+    def elastic_residual(self, h, w, f, E, nu, penalty=False, dss=None, dSS=None, g=None) -> ShellResidual:
+        """shell_pde.py:258-260: pdeRes without penalty terms plus int f . du_mid, i.e. the elastic force K(h) w alone."""
+        return ShellResidual(h, w, f, E, nu, with_load=False)
+
+    def regularization(self, h, type=None):
+        """shell_pde.py:262-282 as a scalar form of its own (0.0 for ``type=None``, like the reference)."""
+        if type is None:
+            return 0.0
+        return ShellRegularization(h, type)
+
+    def compliance(self, u_mid, h=None, dxx=None, regularization=None) -> ShellCompliance:
+        """shell_pde.py:284-285: 1/2 int_dxx u_mid . u_mid + regularization(h) (the reference's default type is None).
+        ``u_mid``: the state Function (its displacement part is what enters, like `ufl.split(w)[0]`)."""
+        return ShellCompliance(u_mid, h, dxx, regularization)
 
     def volume(self, h) -> ShellMass:
         return ShellMass(h, 1.0)
@@ -433,14 +676,18 @@ class ShellPDE:
     def mass(self, h, rho) -> ShellMass:
         return ShellMass(h, rho)
 
-    def elastic_energy(self, w, h, E, nu=0.0) -> ShellElasticEnergy:
-        return ShellElasticEnergy(w, h, E, nu)
+    def elastic_energy(self, w, h, E, nu=None) -> ShellElasticEnergy:
+        """shell_pde.py:296-299: the elastic model of the last ``pdeRes`` supplies the Poisson ratio, as in the reference
+        (where ``elastic_energy(w, h, E)`` reuses ``self.elastic_model``); without one nu defaults to 0."""
+        em = getattr(self, "elastic_model", None)
+        if nu is None:
+            nu = em.nu if em is not None else 0.0
+        return ShellElasticEnergy(w, h, E, nu, residual=em if em is not None and em.w is w else None)
 
     def pnorm_stress(self, w, h, E, nu, dx=None, m=1e-6, rho=100, alpha=None, regularization=False, surface='Top') -> ShellPnormStress:
         """shell_pde.py:297-313 (stress on the top surface there; 'Mid' / 'Bot' as in von_Mises_stress, :315-328)."""
-        if regularization:
-            raise NotImplementedError("pnorm_stress(regularization=True): add the thickness term as an output of its own")
-        return ShellPnormStress(w, h, E, nu, m=m, rho=rho, alpha=alpha, surface={'Top': 1.0, 'Mid': 0.0, 'Bot': -1.0}[surface])
+        return ShellPnormStress(w, h, E, nu, m=m, rho=rho, alpha=alpha, surface={'Top': 1.0, 'Mid': 0.0, 'Bot': -1.0}[surface],
+                                regularization=bool(regularization))
 
     def von_Mises_stress(self, w, h, E, nu, surface='Top') -> ShellVonMises:
         """shell_pde.py:315-328"""

@@ -373,6 +373,31 @@ int femo_shell_dform_dh(femo_shell* s, double E, double nu, const femo_vec* h, c
 /* 1/2 int u_mid . u_mid (shell_pde.py:287-288) and its gradient; int rho h (shell_pde.py:293-294) and its gradient */
 int femo_shell_compliance(femo_shell* s, const femo_vec* w, double* value, int accumulate, femo_vec* grad);
 int femo_shell_mass(femo_shell* s, double rho, const femo_vec* h, double* value, int accumulate, femo_vec* grad);
+/* The compliance over a tagged subset of cells -- the `dxx` measure the shell drivers pass (shell_pde.py:66,284-285:
+ * dx_2(10)): cell_weight is a DG0 indicator (n_cell doubles; NULL: the whole surface).                                 */
+int femo_shell_compliance_dx(femo_shell* s, const femo_vec* w, const femo_vec* cell_weight, double* value, int accumulate, femo_vec* grad);
+/* Thickness regularisation of `compliance` (shell_pde.py:262-282, ShellPDE.regularization): kind 1 'H1', 2 'L2H1',
+ * 3 'L2' (alpha1 = 1e3, alpha2 = 1, h_mesh = CellDiameter); value and/or grad (+)= d/dh.  femo_shell_hpower: int coef h^p dx
+ * with the degree-4 rule -- the thickness term of pnorm_stress(regularization=True), shell_pde.py:307-309.              */
+int femo_shell_regularization(femo_shell* s, int kind, const femo_vec* h, double* value, int accumulate, femo_vec* grad);
+int femo_shell_hpower(femo_shell* s, double coef, double p, const femo_vec* h, double* value, int accumulate, femo_vec* grad);
+/* Penalty form of the boundary conditions, `pdeRes(..., penalty=True, dss, dSS, g)` (shell_pde.py:34,59-61,246-253 ->
+ * ElasticModel.weakFormResidual of the un-vendored shell_analysis_fenicsx; restated in oracle/shell_oracle.py::
+ * penalty_matrix in the idiom of the tree's other penalty terms, run_poisson_opt.py:60, motor_pde.py:177-178):
+ *     R_pen(dw) = sum over tagged edges of coef_e int_e (w - g) . dw,    coef_e = beta (1/h_E('+') + 1/h_E('-')),
+ * all six fields of w, exterior (ds) and interior (dS) facets alike.  The host passes per tagged edge its three
+ * displacement nodes (end vertices, midpoint node), coef_e |e| and the CSR positions of its 3 x (9 + 4) entries
+ * (component-major; 9 displacement pairs row-major over (v0, v1, mid), then 4 rotation pairs over (v0, v1)).
+ * femo_shell_penalty_add: vals += K_pen (after femo_shell_assemble);  femo_shell_penalty_apply: y (+)= K_pen (x - g).   */
+int femo_shell_set_penalty(femo_shell* s, int64_t n_edges, const int32_t* edge_nodes, const double* coef, const int32_t* pos);
+int femo_shell_penalty_add(femo_shell* s, femo_vec* vals);
+int femo_shell_penalty_apply(femo_shell* s, const femo_vec* x, const femo_vec* g, int accumulate, femo_vec* y);
+/* Inertial residual, `kinetic_residual(rho, h)` (shell_pde.py:255-256 -> ElasticModel.inertialResidual [absent package];
+ * its use with accelerations: run_aeroelasticity_dynamic.py:93): y (+)= M(h) acc with
+ * M = int rho h N_a N_b (displacements) + int rho h^3/12 phi_a phi_b (rotations), consistent, degree-4 rule;
+ * femo_shell_inertia_dh: out_b (+)= lam^T (dM/dh_b) acc, its thickness partial transposed.                             */
+int femo_shell_inertia_apply(femo_shell* s, double rho, const femo_vec* h, const femo_vec* acc, int accumulate, femo_vec* y);
+int femo_shell_inertia_dh(femo_shell* s, double rho, const femo_vec* h, const femo_vec* lam, const femo_vec* acc, int accumulate, femo_vec* out);
 /* L2 projection of the von Mises stress onto CG1 (shell_pde.py:315-332; the field output of the shell drivers,
  * shell_dynamic_pde.py:82-83,129): rhs_i = int sigma_vm phi_i, lumped_i = row sum of the P1 mass matrix (may be NULL);
  * femo_shell_p1_mass: y = M x with that mass matrix (the host side runs Jacobi-CG with it, utils_dolfinx.py:549-583). */
@@ -398,8 +423,8 @@ int femo_shell_pc_create(femo_shell* s, int width, int64_t n_nodes, int n_levels
                          const int64_t* chi_rowptr, const int32_t* chi_cols, const double* chi_vals);
 /* Exact coarse solve for the lattice preconditioner (optional, after femo_shell_pc_create): on lattice level `level`
  * (not the finest; 6 x nodes <= 8192 unknowns) the Galerkin operator P^T K P is formed as a dense matrix on the device,
- * factorised with rocSOLVER (potrf + trtri, loaded at run time) whenever the stiffness or the Dirichlet set change, and
- * A^-1 = L^-T L^-1 applied in place
+ * factorised by the library's own blocked Cholesky + triangular inverse on the fp64 matrix cores (shell.hip) whenever
+ * the stiffness or the Dirichlet set change, and A^-1 = L^-T L^-1 applied in place
  * of the diagonal levels 0 .. level: M^-1 = D^-1 + sum_{l > level} P_l C_l P_l^T + P_c (P_c^T K P_c)^-1 P_c^T.  What
  * the reference's direct solver (MUMPS, utils_dolfinx.py:476-512) does for the whole matrix is done here for the
  * ~3000 unknowns that carry the smooth, nearly inextensional modes a diagonal cannot see.
