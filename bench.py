@@ -663,17 +663,33 @@ def _run(args):
 
     if not args.no_pcie:
         # a backend that keeps every array in its own pageable memory (copies results out, hands pageable inputs in)
+        # ... with persistent storage, like a backend that preallocates its variable vectors: the engine pins such an
+        # array in place the second time it sees it (engine._note_caller_array), so from the third cycle on every
+        # transfer is one DMA; nothing is ever elided (the owner may write its arrays at any time).  The driver's
+        # input array is its own too: f is copied into it at the start of every cycle.
         sim_p, fea_p = build_problem(mesh, device=False, pinned=False)
-        one_cycle(sim_p, fea_p, f_host[0])
+        f_own = np.empty(mesh.n_cell)
+        u0_own = np.zeros(n_dof)
+        for w in range(3):
+            np.copyto(f_own, f_host[w % len(f_host)])
+            one_cycle(sim_p, fea_p, f_own, u0_own)
         ctx.sync()
+        E.host_stats(reset=True)
+        Kp = 3
         t0 = time.perf_counter()
-        one_cycle(sim_p, fea_p, f_host[1 % len(f_host)])
+        for k in range(Kp):
+            E.host_copy(f_own, f_host[(k + 1) % len(f_host)])
+            one_cycle(sim_p, fea_p, f_own, u0_own)
         ctx.sync()
-        t_h = time.perf_counter() - t0
-        result["pageable_boundary"] = {"value": n_dof / t_h, "unit": "DOFs/s", "ms_per_step": t_h * 1e3, "steps": 1,
-                                       "note": "pageable NumPy arrays owned by the driver on both sides of every operator call "
-                                               "(staged through pinned slots by host threads; no upload can be elided)"}
-        del sim_p, fea_p
+        t_h = (time.perf_counter() - t0) / Kp
+        xp = E.host_stats()
+        result["pageable_boundary"] = {"value": n_dof / t_h, "unit": "DOFs/s", "ms_per_step": t_h * 1e3, "steps": Kp,
+                                       "h2d_pinned_per_step": xp["h2d_pinned"] / Kp, "h2d_staged_per_step": xp["h2d_staged"] / Kp,
+                                       "h2d_elided_per_step": (xp["h2d_skipped"] + xp["h2d_as_d2d"]) / Kp,
+                                       "note": "pageable NumPy arrays owned by the driver (preallocated variable storage) on both sides of "
+                                               "every operator call; pinned in place by the engine on second sight, so transfers are DMAs; "
+                                               "no upload is elided for caller-owned memory"}
+        del sim_p, fea_p, f_own, u0_own
     if not args.no_check:
         # one more cycle of the timed stack, outside the timed region, compared with solver-free values
         kc = (W + K) % len(f_pin)

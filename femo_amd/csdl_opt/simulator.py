@@ -95,7 +95,16 @@ class Simulator:
                 value = value.numpy()
             a = np.ascontiguousarray(value, dtype=np.float64).ravel()
             if not self.pinned:
-                value = np.array(a, copy=True)              # a driver with pageable storage of its own
+                # a driver with pageable storage of its own: one persistent array per variable, written in place (what a
+                # backend that preallocates its variable vectors does); the engine pins such an array in place the
+                # second time it is handed over (engine._note_caller_array)
+                store = self.__dict__.setdefault("_storage", {})
+                w = store.get(name)
+                if w is None or w.size != a.size:
+                    w = store[name] = np.empty(a.size)
+                if w is not a and not np.shares_memory(w, a):
+                    E.host_copy(w, np.ascontiguousarray(E.host_wait(a)))
+                value = w
             elif not a.flags.writeable and E.is_pinned(a):
                 value = a                                   # a result of the engine (or engine.pinned_array): adopt
             else:
@@ -208,7 +217,13 @@ class Simulator:
                         else:
                             val = np.ascontiguousarray(val, dtype=np.float64).ravel()
                             if not self.pinned:
-                                val = np.array(val, copy=True)
+                                # the driver's own (persistent, pageable) adjoint storage for this argument
+                                pool = self.__dict__.setdefault("_adj_storage", {})
+                                w = pool.get((o, arg, len(adj)))
+                                if w is None or w.size != val.size:
+                                    w = pool[(o, arg, len(adj))] = np.empty(val.size)
+                                E.host_copy(w, E.host_wait(val))
+                                val = w
                             if arg not in adj:
                                 adj[arg] = val                      # by reference: no pass over the array
                             else:

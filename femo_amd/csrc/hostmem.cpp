@@ -17,7 +17,9 @@
 //     ("might be redundant", state_model.py:168-173); with provenance those re-sends cost nothing
 //     and stay exact: host-side writers must announce themselves (femo_host_touch), which is why
 //     the Python layer returns read-only arrays.  FEMO_HOST_VERIFY=1 checks every elision against
-//     a real comparison (tests).
+//     a real comparison (tests).  Only blocks of femo_host_alloc are ever recorded: caller memory pinned in place
+//     (femo_host_register, which the Python layer does by itself for arrays it is handed repeatedly) can be written by
+//     its owner at any time and is never trusted as a mirror.
 //  4. Asynchronous results (femo_vec_get_host_async).  The copy-out of a result runs on a second stream
 //     and the call returns at once; the block carries an event until the bytes have landed.  Every library
 //     entry that touches such a block waits first (or needs no bytes at all: an elided upload), a caller that
@@ -459,7 +461,7 @@ int femo_host_fill(double* p, int64_t n, double value) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (HostBlock* b = find_block(p, (size_t)n * sizeof(double))) {
     b->src_uid = 0;
-    if (reinterpret_cast<char*>(p) == b->base) { b->const_n = n; b->const_value = value; }
+    if (reinterpret_cast<char*>(p) == b->base && b->pooled) { b->const_n = n; b->const_value = value; }
     else b->const_n = 0;
   }
   return 0;
@@ -502,7 +504,7 @@ int femo_host_axpby(int64_t n, double a, const double* x, double b, double* y) {
       std::lock_guard<std::mutex> lk(g_mu);
       HostBlock* bx = find_block(x, (size_t)n * sizeof(double));
       HostBlock* by = find_block(y, (size_t)n * sizeof(double));
-      if (bx && by && reinterpret_cast<const char*>(x) == bx->base && reinterpret_cast<char*>(y) == by->base && bx->src_uid != 0 &&
+      if (bx && by && by->pooled && reinterpret_cast<const char*>(x) == bx->base && reinterpret_cast<char*>(y) == by->base && bx->src_uid != 0 &&
           bx->src_n >= n) {
         auto it = g_live.find(bx->src_uid);
         if (it != g_live.end() && it->second->gen == bx->src_gen) {
@@ -622,7 +624,7 @@ int femo_vec_set_host(femo_vec* v, const double* host, int64_t n) {
   else { ++g_stats.h2d_staged; g_stats.h2d_staged_bytes += n * 8; }
   if (exact_base && v->uid != 0) {                       // the block is now an exact copy of v
     if (HostBlock* b = find_block(host, (size_t)n * sizeof(double))) {
-      if (reinterpret_cast<const char*>(host) == b->base) { b->src_uid = v->uid; b->src_gen = v->gen; b->src_n = n; b->src_scale = 1.0; }
+      if (reinterpret_cast<const char*>(host) == b->base && b->pooled) { b->src_uid = v->uid; b->src_gen = v->gen; b->src_n = n; b->src_scale = 1.0; }
     }
   }
   return 0;
@@ -699,7 +701,7 @@ static int get_host_impl(const femo_vec* v, double* host, int64_t n, int op, boo
     if (HostBlock* b = find_block(host, (size_t)n * sizeof(double))) {
       b->pending = true;
       b->pend_ctx = c;
-      if (exact_base && v->uid != 0) { b->src_uid = v->uid; b->src_gen = v->gen; b->src_n = n; b->src_scale = 1.0; }   // true once landed
+      if (exact_base && v->uid != 0 && b->pooled) { b->src_uid = v->uid; b->src_gen = v->gen; b->src_n = n; b->src_scale = 1.0; }   // true once landed
     }
     return 0;
   }
@@ -712,7 +714,7 @@ static int get_host_impl(const femo_vec* v, double* host, int64_t n, int op, boo
   else { ++g_stats.d2h_staged; g_stats.d2h_staged_bytes += n * 8; }
   if (pinned && op == 0 && v->uid != 0) {
     if (HostBlock* b = find_block(host, (size_t)n * sizeof(double))) {
-      if (reinterpret_cast<char*>(host) == b->base) { b->src_uid = v->uid; b->src_gen = v->gen; b->src_n = n; b->src_scale = 1.0; }
+      if (reinterpret_cast<char*>(host) == b->base && b->pooled) { b->src_uid = v->uid; b->src_gen = v->gen; b->src_n = n; b->src_scale = 1.0; }
     }
   }
   return 0;

@@ -105,6 +105,63 @@ def host_sync() -> None:
     check(_lib.load().femo_host_sync())
 
 
+# ---- caller arrays in pageable memory: pinned in place on second sight ---------------------------------------
+# A backend that keeps its variables in NumPy arrays of its own hands the same arrays over in every operator call
+# (utils_dolfinx.py:155-167, 300-311 copy from / into them).  The first transfer of such an array takes the staged
+# path; when the same array (same owner object, address and size) shows up again it is pinned in place with
+# femo_host_register, so every later transfer is one DMA at PCIe rate, and unpinned when NumPy releases the array
+# (a weak-reference callback on the owning ndarray runs before its memory is freed).  No provenance is ever recorded
+# for such memory (hostmem.cpp): its owner may write it at any time.  Arrays handed over once -- temporaries -- are
+# never pinned: hipHostRegister of 0.5 GB costs more than ten staged transfers.
+AUTO_REGISTER_MIN_BYTES = 1 << 20
+_SEEN: Dict[int, tuple] = {}         # id(owner) -> (address, nbytes): seen once
+_REGISTERED: Dict[int, tuple] = {}   # id(owner) -> (address, nbytes): pinned
+_AUTO_REGISTER = True
+
+
+def auto_register(enabled: bool) -> None:
+    """Switch the pinning of repeatedly used caller arrays on / off (on by default)."""
+    global _AUTO_REGISTER
+    _AUTO_REGISTER = bool(enabled)
+
+
+def _forget_owner(key: int) -> None:
+    _SEEN.pop(key, None)
+    rec = _REGISTERED.pop(key, None)
+    if rec is not None:
+        try:
+            _lib.load().femo_host_unregister(C.c_void_p(rec[0]))
+        except Exception:
+            pass
+
+
+def _note_caller_array(a: np.ndarray) -> None:
+    """Called with every caller-owned array a transfer entry point is handed (``Vec.set`` / ``get(out=)`` / ``add_to_host``)."""
+    if not _AUTO_REGISTER or a.nbytes < AUTO_REGISTER_MIN_BYTES:
+        return
+    owner = a
+    while isinstance(owner.base, np.ndarray):
+        owner = owner.base
+    if owner.base is not None or not owner.flags.owndata:
+        return                                   # memory of another object (buffer, mmap, a pinned block): lifetime unknown / not ours
+    key, addr, nb = id(owner), owner.ctypes.data, owner.nbytes
+    rec = _REGISTERED.get(key)
+    if rec is not None:
+        if rec == (addr, nb):
+            return
+        _forget_owner(key)                       # resized in place: the old range is gone
+    if _SEEN.get(key) != (addr, nb):
+        if key not in _SEEN:
+            import weakref
+            weakref.finalize(owner, _forget_owner, key)
+        _SEEN[key] = (addr, nb)
+        return                                   # first sight: staged path
+    if _lib.load().femo_host_register(C.c_void_p(addr), nb) == 0:
+        _REGISTERED[key] = (addr, nb)
+    else:
+        _SEEN.pop(key, None)                     # could not pin (limits, overlap): stay on the staged path
+
+
 _LAZY = threading.local()
 
 
@@ -243,6 +300,7 @@ class Vec:
 
     def set(self, a) -> "Vec":
         a = _f64(a)
+        _note_caller_array(a)
         check(self.lib.femo_vec_set_host(self.handle, _ptr(a), a.size))
         return self
 
@@ -254,6 +312,7 @@ class Vec:
         n = self.n if n is None else int(n)
         if out is not None:
             assert out.dtype == np.float64 and out.flags.c_contiguous and out.size == n
+            _note_caller_array(out)
             check(self.lib.femo_vec_get_host(self.handle, _ptr(out), n))
             return out
         out = pinned_empty(n)
@@ -268,6 +327,7 @@ class Vec:
         """host[:n] += self[:n] in place (contiguous fp64 array)."""
         n = self.n if n is None else int(n)
         assert host.dtype == np.float64 and host.flags.c_contiguous and host.flags.writeable and host.size >= n
+        _note_caller_array(host)
         check(self.lib.femo_vec_add_to_host(self.handle, _ptr(host), n))
         return host
 

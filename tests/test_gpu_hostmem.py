@@ -379,6 +379,60 @@ def test_accumulate_into_a_scaled_block(ctx):
         os.environ["FEMO_HOST_VERIFY"] = "1"
 
 
+def test_caller_arrays_are_pinned_on_second_sight(ctx):
+    """A pageable NumPy array handed over repeatedly (a backend's own variable storage, utils_dolfinx.py:155-167,
+    300-311): first transfer staged, pinned in place at the second, DMA from then on; never trusted as a mirror (its
+    owner may write it); unpinned when NumPy frees it; temporaries are never pinned."""
+    from femo_amd import engine as E
+    n = 1_500_003
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal(n)                      # pageable, owns its memory
+    v = E.Vec(ctx, n)
+    E.host_stats(reset=True)
+    v.set(a)
+    st = E.host_stats()
+    assert st["h2d_staged"] == 1 and st["h2d_pinned"] == 0 and not E.is_pinned(a)
+    v.set(a)                                        # second sight: registered, this transfer already is a DMA
+    st = E.host_stats()
+    assert E.is_pinned(a) and st["h2d_pinned"] == 1 and st["h2d_staged"] == 1
+    a[7] = 42.0                                     # the owner writes without telling anyone ...
+    v.set(a)                                        # ... and the bytes still go over: no elision for caller memory
+    st = E.host_stats()
+    assert st["h2d_pinned"] == 2 and st["h2d_skipped"] == 0 and st["h2d_as_d2d"] == 0
+    assert v.get()[7] == 42.0 and np.array_equal(v.get(), a)
+    # results into the caller's array and accumulation take the pinned path as well
+    out = np.empty(n)
+    v.get(out=out); v.get(out=out)
+    assert E.is_pinned(out) and np.array_equal(out, a)
+    acc = np.ones(n)
+    v.add_to_host(acc); v.add_to_host(acc)
+    assert E.is_pinned(acc) and np.array_equal(acc, (1.0 + a) + a)
+    # views of the same owner count as the owner; small arrays and one-off temporaries are left alone
+    E.host_stats(reset=True)
+    v2 = E.Vec(ctx, n - 3)
+    v2.set(a[3:]); v2.set(a[:-3])
+    assert E.host_stats()["h2d_pinned"] == 2
+    small = np.zeros(1000)
+    s = E.Vec(ctx, 1000)
+    s.set(small); s.set(small)
+    assert not E.is_pinned(small)
+    for _ in range(3):
+        v.set(rng.standard_normal(n))
+    # freeing the array unpins it (the address may be handed out again by the allocator)
+    addr, nb = a.ctypes.data, a.nbytes
+    del a, out, acc
+    gc.collect()
+    lib = E._lib.load()
+    assert not lib.femo_host_is_pinned(addr, nb)
+    E.auto_register(False)
+    try:
+        b = rng.standard_normal(n)
+        v.set(b); v.set(b)
+        assert not E.is_pinned(b)
+    finally:
+        E.auto_register(True)
+
+
 def test_two_outputs_do_not_alias_in_device_mode(ctx):
     """compute_totals(of=[a, b]) on the device returns distinct buffers, and a result kept from an earlier
     call survives the next one (pooled work arrays were handed out)."""
