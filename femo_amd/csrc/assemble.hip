@@ -1637,7 +1637,7 @@ int femo_launch_residual(femo_mesh* m, int pde, const double* params, const doub
     // K u - L is the Newton right-hand side without a Dirichlet set: the pipelined system kernel in its
     // rhs-only form (1.3 ms at C4 against 2.2 ms for the per-visit-gather walk below)
     const int nbr = (m->max_rowlen + 1) & ~1;
-    static const bool walk = getenv("FEMO_RESIDUAL_WALK") != nullptr;
+    static const bool walk = FEMO_TUNE_ENV("FEMO_RESIDUAL_WALK") != nullptr;
     if (!walk && nbr <= (m->tdim == 3 ? 16 : 8))
       return femo_launch_system(m, pde, params, u, f, aux, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, r, f_uid, f_gen, nullptr);
     FEMO_TRY(ensure_load_vector(m, f, f_uid, f_gen));
@@ -1698,11 +1698,12 @@ int femo_launch_system(femo_mesh* m, int pde, const double* params, const double
   // rows with up to 64 neighbours: the row neighbourhood fits in LDS (one wave per workgroup)
   const int nbr = (m->max_rowlen + 1) & ~1;
   const size_t lds_row = (size_t)nbr * (m->tdim + 1) * 64 * sizeof(double);
-  if (lds_row <= 128 * 1024 && getenv("FEMO_ASSEMBLY_GATHER") == nullptr) {
+  static const bool gather_only = FEMO_TUNE_ENV("FEMO_ASSEMBLY_GATHER") != nullptr;
+  if (lds_row <= 128 * 1024 && !gather_only) {
     FEMO_TRY(ensure_visit_weights(m));
     const int64_t ns = m->n_slices;
     const P1Rec* rec = reinterpret_cast<const P1Rec*>(m->d_visit_rec);
-    const int dbg = getenv("FEMO_DEBUG_SKIP") ? atoi(getenv("FEMO_DEBUG_SKIP")) : 0;     // timing experiments only
+    static const int dbg = FEMO_TUNE_ENV("FEMO_DEBUG_SKIP") ? atoi(FEMO_TUNE_ENV("FEMO_DEBUG_SKIP")) : 0;     // timing experiments (FEMO_TUNING builds)
 #define FEMO_SYS_LDS(D)                                                                                                       \
     do {                                                                                                                      \
       auto k = k_poisson_system_lds<D, 12>;                                                                                   \
@@ -1712,7 +1713,7 @@ int femo_launch_system(femo_mesh* m, int pde, const double* params, const double
     } while (0)
     // persistent pipelined kernel: rows of up to 16 entries, a Dirichlet set with its row masks, and one of the
     // three combinations the operators ask for: A + rhs, dR/du + A, rhs only
-    static const int pipe_mode = getenv("FEMO_ASSEMBLY_PIPE") ? atoi(getenv("FEMO_ASSEMBLY_PIPE")) : 1;
+    static const int pipe_mode = FEMO_TUNE_ENV("FEMO_ASSEMBLY_PIPE") ? atoi(FEMO_TUNE_ENV("FEMO_ASSEMBLY_PIPE")) : 1;
     const int NBp = m->tdim == 3 ? (nbr <= 14 ? 14 : 16) : 8;
     const bool combo_a = rhs && !vals0 && vals1, combo_b = !rhs && vals0 && vals1, combo_c = rhs && !vals0 && !vals1;
     const bool no_bc_residual = combo_c && bcmask == nullptr;          // evaluate_residuals: K u - L, no Dirichlet treatment
@@ -1724,7 +1725,7 @@ int femo_launch_system(femo_mesh* m, int pde, const double* params, const double
       }
       if (rhs && !no_bc_residual) hipLaunchKernelGGL(k_impose_bc, dim3(cell_grid(m->n_vert)), dim3(FEMO_BLOCK), 0, st, m->n_vert, u, bcmask, bcval, m->d_ubc);
       const double* ubc = no_bc_residual ? u : m->d_ubc;
-      static const int waves_per_cu = getenv("FEMO_ASSEMBLY_WAVES") ? std::max(1, atoi(getenv("FEMO_ASSEMBLY_WAVES"))) : 4;
+      static const int waves_per_cu = FEMO_TUNE_ENV("FEMO_ASSEMBLY_WAVES") ? std::max(1, atoi(FEMO_TUNE_ENV("FEMO_ASSEMBLY_WAVES"))) : 4;
       // one wave per SIMD: the LDS request is raised so that a fifth workgroup cannot land on a CU (it would share a
       // SIMD with another persistent wave and both would take twice as long)
       const size_t lds_need = (size_t)NBp * (m->tdim + 1) * 64 * sizeof(double);

@@ -258,26 +258,8 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
                                                                 const int32_t* __restrict__ perm, const uint32_t* __restrict__ pk,
                                                                 Lat lat, const double* __restrict__ val,
                                                                 const double* __restrict__ w_sorted,
-                                                                double* __restrict__ g, int n_fused, const int32_t* __restrict__ done,
-                                                                FemoPcSide::Update upd) {
+                                                                double* __restrict__ g, int n_fused, const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
-  // upd.q != nullptr: the kernel runs BESIDE the PCG update (second stream) and restricts r - alpha q itself,
-  // alpha = gamma / (p.q) folded from the SpMV's partials exactly as k_pcg_xr folds them
-  double alpha = 0.0;
-  if (upd.q != nullptr) {
-    __shared__ double fold[FEMO_BLOCK / 64];
-    double a = 0.0;
-    for (int i = threadIdx.x; i < upd.nb_d; i += FEMO_BLOCK) a += upd.partials_d[i];
-    a = femo_wave_sum(a);
-    if ((threadIdx.x & 63) == 0) fold[threadIdx.x >> 6] = a;
-    __syncthreads();
-    double delta = 0.0;
-#pragma unroll
-    for (int i = 0; i < FEMO_BLOCK / 64; ++i) delta += fold[i];
-    alpha = delta != 0.0 ? upd.scal[upd.gamma_index] / delta : 0.0;
-  }
-  const int debug = n_fused >> 8;                   // FEMO_DEBUG_BRICKS (timing experiments only)
-  n_fused &= 0xFF;
   constexpr int B = Brick<D>::B, N1 = Brick<D>::N1, NLOC = Brick<D>::NLOC, NC = Brick<D>::NC;
   constexpr int PF = BRICK_CHUNK / FEMO_BLOCK;      // staged entries per thread and pass
   constexpr int NTOT = BrickNodes<D>::TOTAL;
@@ -320,8 +302,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
     for (int q = 0; q < PF; ++q) {
       bool live;
       const int64_t i = entry(M, q, live);
-      v[q] = val[(debug & 4) ? i : (int64_t)p[q]];
-      if (upd.q != nullptr) v[q] -= alpha * upd.q[p[q]];
+      v[q] = val[(int64_t)p[q]];
       const double ws = w_sorted[i];
       w[q] = live ? ws : 0.0;
 #pragma unroll
@@ -329,7 +310,6 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
     }
   };
   auto flush = [&](const double* nd, int b0, int b1, int b2) {
-    if (debug & 1) return;
     double* gl = g;
     int ln[3] = {lat.n[0], lat.n[1], lat.n[2]};
     auto coarser = [&]() {
@@ -385,14 +365,14 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
       if (chunk > start) {                        // bricks above BRICK_CHUNK vertices (rare): unpipelined passes
         lds_barrier();
         for (int64_t i = chunk + tid; i < chunk_end; i += FEMO_BLOCK) {
-          sval[i - chunk] = (upd.q != nullptr ? val[perm[i]] - alpha * upd.q[perm[i]] : val[perm[i]]) * w_sorted[i];
+          sval[i - chunk] = val[perm[i]] * w_sorted[i];
 #pragma unroll
           for (int k = 0; k < D; ++k) st[k][i - chunk] = (float)(pk[i * D + k] & PK_MASK) * (1.0f / (float)(1u << PK_BITS));
         }
         lds_barrier();
       }
       for (int64_t j = bin_lo + sub; j < bin_hi; j += 4) {
-        if (j < chunk || j >= chunk_end || (debug & 8)) continue;
+        if (j < chunk || j >= chunk_end) continue;
         const double r = sval[j - chunk];
         double t[D];
 #pragma unroll
@@ -438,7 +418,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
     lds_barrier();
     // the next n_fused coarser lattices straight from the LDS copy (the brick starts on a multiple of B bins, so
     // its nodes' parents on those levels are its own corner/edge/face nodes): wave 0, the others move on
-    if (tid < 64 && !(debug & 2)) {
+    if (tid < 64) {
       if (n_fused >= 1) brick_restrict_level<D, B>(nd, nd + BrickNodes<D>::offset(1), tmpA, tmpB, tid);
       if (n_fused >= 2) brick_restrict_level<D, B / 2>(nd + BrickNodes<D>::offset(1), nd + BrickNodes<D>::offset(2), tmpA, tmpB, tid);
       if constexpr (D == 2) {
@@ -1071,7 +1051,7 @@ static int bricks_per_cu(int dim) {
     hipError_t e = dim == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_restrict_bricks<3>, FEMO_BLOCK, 0)
                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_restrict_bricks<2>, FEMO_BLOCK, 0);
     c = (e == hipSuccess && nb > 0) ? nb : 3;
-    if (const char* env = getenv("FEMO_BRICKS_PER_CU")) c = std::max(1, atoi(env));
+    if (const char* env = FEMO_TUNE_ENV("FEMO_BRICKS_PER_CU")) c = std::max(1, atoi(env));
   }
   return c;
 }
@@ -1098,9 +1078,9 @@ static int pc_setup_shared(femo_mesh* m) {
   if (pc->n_bricks > 0) {
     const unsigned gb = (unsigned)std::min<int64_t>(pc->n_bricks, (int64_t)ctx->n_cu * bricks_per_cu(pc->dim));
     if (pc->dim == 3)
-      hipLaunchKernelGGL(k_restrict_bricks<3>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, ones, pc->d_w_sorted, F.g, 0, (const int32_t*)nullptr, FemoPcSide::Update{});
+      hipLaunchKernelGGL(k_restrict_bricks<3>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, ones, pc->d_w_sorted, F.g, 0, (const int32_t*)nullptr);
     else
-      hipLaunchKernelGGL(k_restrict_bricks<2>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, ones, pc->d_w_sorted, F.g, 0, (const int32_t*)nullptr, FemoPcSide::Update{});
+      hipLaunchKernelGGL(k_restrict_bricks<2>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, ones, pc->d_w_sorted, F.g, 0, (const int32_t*)nullptr);
   }
   hipLaunchKernelGGL(k_mark_touched, dim3(lat_grid(F.nodes)), dim3(256), 0, st, F.nodes, F.g, F.e);
   FEMO_HIP_CHECK(hipGetLastError());
@@ -1175,17 +1155,12 @@ static int pc_prepare(femo_mesh* m, const uint8_t* mask, uint64_t key) {
 // zh = M^-1 rh in scaled variables; partials[block] = rh.zh per block (gv blocks)
 int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const double* s, const double* rh, double* out,
                   int mode, double* rho, const double* gamma_cur, double* gamma_nxt, const int32_t* done, int gv,
-                  bool rho_is_partial, const FemoPcgStop* stop, int nb_rho, const double* rho_partials, const FemoPcSide* side) {
+                  bool rho_is_partial, const FemoPcgStop* stop, int nb_rho, const double* rho_partials) {
   femo_pc* pc = m->pc;
   femo_ctx* ctx = m->ctx;
   FEMO_TRY(pc_prepare(m, mask, mask_key));
-  // `st` carries the restriction and the lattice cycle: the main stream, or the side stream of an overlapped apply
-  const hipStream_t st_main = ctx->stream;
-  const bool overlapped = side != nullptr && side->stream != nullptr && ctx->nranks == 1;
-  hipStream_t st = overlapped ? side->stream : st_main;
-  const FemoPcSide::Update upd = overlapped ? side->upd : FemoPcSide::Update{};
-  const double* rsrc = overlapped ? side->restrict_src : rh;
-  if (overlapped) FEMO_HIP_CHECK(hipStreamWaitEvent(st, side->fork, 0));
+  const hipStream_t st = ctx->stream;
+  const double* rsrc = rh;
   const int nl = pc->n_levels, nf = pc->n_fused;
   const int T = nl - 1 - nf;                                   // coarsest level the brick kernel fills
   LatticeLevel& F = pc->L[nl - 1];
@@ -1200,11 +1175,10 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
   // g of the finest nf+1 levels: zero on entry (femo_pc_begin, then the prolongation kernels clean up)
   if (pc->n_bricks > 0) {
     const unsigned gb = (unsigned)std::min<int64_t>(pc->n_bricks, (int64_t)ctx->n_cu * bricks_per_cu(pc->dim));
-    static const int dbg = getenv("FEMO_DEBUG_BRICKS") ? atoi(getenv("FEMO_DEBUG_BRICKS")) << 8 : 0;
     if (pc->dim == 3)
-      hipLaunchKernelGGL(k_restrict_bricks<3>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, rsrc, pc->d_w_sorted, gF, nf | dbg, done, upd);
+      hipLaunchKernelGGL(k_restrict_bricks<3>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, rsrc, pc->d_w_sorted, gF, nf, done);
     else
-      hipLaunchKernelGGL(k_restrict_bricks<2>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, rsrc, pc->d_w_sorted, gF, nf | dbg, done, upd);
+      hipLaunchKernelGGL(k_restrict_bricks<2>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, rsrc, pc->d_w_sorted, gF, nf, done);
   }
   const bool sparse = ctx->nranks > 1 && pc->shared_ready;
   if (sparse) {
@@ -1234,7 +1208,7 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
   int64_t below = 0;
   for (int l = 0; l + 1 < T; ++l) below += pc->L[l].nodes;
   const bool fused_cycle = nf >= 2 && T >= 2 && T < FEMO_PC_MAX_LEVELS - 1 && below * 2 * (int64_t)sizeof(double) <= 144 * 1024 &&
-                           pc->L[T - 1].nodes <= 4096 && getenv("FEMO_BPX_UNFUSED_LATTICE") == nullptr;
+                           pc->L[T - 1].nodes <= 4096 && FEMO_TUNE_ENV("FEMO_BPX_UNFUSED_LATTICE") == nullptr;
   if (fused_cycle) {
     CoarseLevels CL;
     CL.n_levels = T - 1;                                           // levels 0 .. T-2 in LDS, e_{T-1} emitted
@@ -1332,11 +1306,6 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
     dot_global = pc->d_dot_scalar;
     nb_dot = 0;
   }
-  if (overlapped) {
-    FEMO_HIP_CHECK(hipEventRecord(side->join, st));
-    FEMO_HIP_CHECK(hipStreamWaitEvent(st_main, side->join, 0));
-    st = st_main;
-  }
   PcgStop ps;
   ps.rtol2_factor = stop ? stop->rtol2_factor : 0.0;
   ps.atol_pc2 = stop ? stop->atol_pc2 : 0.0;
@@ -1369,7 +1338,6 @@ int femo_pc_begin(femo_mesh* m, const double* s, const uint8_t* mask) {
 }
 
 // can the PCG loop hand its partial rh.rh to femo_pc_apply instead of all-reducing it itself?
-bool femo_pc_can_overlap(const femo_mesh* m) { return m->pc != nullptr && m->ctx->nranks == 1 && m->pc->n_bricks > 0; }
 
 bool femo_pc_can_piggyback(const femo_mesh* m) { return m->pc != nullptr && m->ctx->nranks > 1 && m->pc->shared_ready; }
 

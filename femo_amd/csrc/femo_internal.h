@@ -6,6 +6,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -49,6 +50,16 @@ void femo_set_error(const char* fmt, ...);
     int rc__ = (expr);                                                              \
     if (rc__ != 0) return rc__;                                                     \
   } while (0)
+
+// Tuning / timing switches read from the environment exist only in builds with -DFEMO_TUNING (make TUNING=1): the
+// product library never calls getenv on a launch path.  Functional options that tests select
+// (FEMO_FORCE_MULTI, FEMO_HOST_VERIFY, FEMO_BPX_DENSE_ALLREDUCE, FEMO_BPX_FUSED, FEMO_SHELL_NO_*) are read once.
+#if defined(FEMO_TUNING)
+#define FEMO_TUNE_ENV(name) getenv(name)
+#else
+#define FEMO_TUNE_ENV(name) (static_cast<const char*>(nullptr))
+#endif
+inline bool femo_env_flag(const char* name) { return getenv(name) != nullptr; }
 
 // ------------------------------------------------------------- constants ----
 constexpr int FEMO_WAVE = 64;            // gfx950 wavefront
@@ -323,29 +334,12 @@ struct FemoPcgStop {
   int32_t* flags;
   int it;
 };
-// The restriction half of the apply (mesh -> lattice and the lattice cycle) on a second stream, beside the PCG
-// update x += alpha p, r' = r - alpha q that produces the vector it restricts: the brick kernel then forms
-// r - alpha q itself from the OLD residual (`restrict_src`), so both only depend on the SpMV (solver.hip).
-struct FemoPcSide {
-  struct Update {                 // what the brick kernel needs to form alpha = gamma / (p.q)
-    const double* q = nullptr;    // nullptr: restrict the source as it is
-    const double* scal = nullptr; // device scalars; gamma at scal[gamma_index]
-    int gamma_index = 0;
-    int nb_d = 0;                 // SpMV partials of p.q to fold
-    const double* partials_d = nullptr;
-  } upd;
-  hipStream_t stream = nullptr;   // the second stream
-  hipEvent_t fork = nullptr;      // recorded by the caller on the main stream after the SpMV
-  hipEvent_t join = nullptr;      // recorded here on the second stream; the main stream waits for it
-  const double* restrict_src = nullptr;
-};
 // nb_rho > 0: rho = rh.rh is folded from rho_partials[0:nb_rho] inside the apply (and stored to *rho)
 int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const double* s, const double* rh, double* out,
                   int mode, double* rho, const double* gamma_cur, double* gamma_nxt, const int32_t* done, int gv,
                   bool rho_is_partial = false, const FemoPcgStop* stop = nullptr, int nb_rho = 0,
-                  const double* rho_partials = nullptr, const FemoPcSide* side = nullptr);
+                  const double* rho_partials = nullptr);
 bool femo_pc_can_piggyback(const femo_mesh* m);
-bool femo_pc_can_overlap(const femo_mesh* m);      // single rank, brick restriction: FemoPcSide is honoured
 int femo_pc_begin(femo_mesh* m, const double* s, const uint8_t* mask);
 int femo_pc_levels(const femo_mesh* m, int* n_levels, int64_t* finest_nodes);
 int femo_reduce_to_host(femo_ctx* ctx, int nblocks, int nsums, double* host_out);

@@ -240,7 +240,7 @@ int ensure_copy_stream(femo_ctx* c) {
 // FEMO_HOST_TRACE=1: one line per host-side operation on stderr (what, MB, ms)
 struct Trace {
   const char* what; int64_t bytes; std::chrono::steady_clock::time_point t0; bool on;
-  Trace(const char* w, int64_t b) : what(w), bytes(b), on(getenv("FEMO_HOST_TRACE") != nullptr) { if (on) t0 = std::chrono::steady_clock::now(); }
+  Trace(const char* w, int64_t b) : what(w), bytes(b), on(FEMO_TUNE_ENV("FEMO_HOST_TRACE") != nullptr) { if (on) t0 = std::chrono::steady_clock::now(); }
   ~Trace() {
     if (!on) return;
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

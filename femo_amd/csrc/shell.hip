@@ -2118,7 +2118,7 @@ static int shell_pc_coarse_setup(femo_shell* s, const femo_vec* vals, const uint
   hipStream_t st = s->ctx->stream;
   const int64_t n = s->cs_n, N = s->cs_N;
   const int nblk = (int)(N / DT);
-  const bool dbg = getenv("FEMO_DEBUG_COARSE") != nullptr;
+  static const bool dbg = FEMO_TUNE_ENV("FEMO_DEBUG_COARSE") != nullptr;
   auto now = [&] { if (dbg) (void)hipStreamSynchronize(st); return std::chrono::steady_clock::now(); };
   auto t0 = now();
   FEMO_HIP_CHECK(hipMemsetAsync(s->d_cs_A, 0, N * N * sizeof(double), st));

@@ -484,7 +484,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_pcg_xr(int64_t n, int cur, int n
                                                        const double* r_in, double* r, double* __restrict__ xh,
                                                        double* __restrict__ partials, const int32_t* __restrict__ done) {
   // r = r_in - alpha q: in place (r_in == r) or into the other residual buffer when the restriction of the
-  // preconditioner runs beside this kernel and still reads r_in (FemoPcSide)
+  // caller keeps the old residual
   if (*done) return;
   __shared__ double lds[FEMO_BLOCK / 64];
   const double gamma = scal[S_GAMMA + cur];
@@ -1103,7 +1103,7 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
   FEMO_TRY(ensure_s(A));
   FEMO_TRY(femo_pc_build(m));
   CgWork w;
-  const bool multi = ctx->nranks > 1 || (ctx->comm != nullptr && getenv("FEMO_FORCE_MULTI") != nullptr);
+  const bool multi = ctx->nranks > 1 || (ctx->comm != nullptr && femo_env_flag("FEMO_FORCE_MULTI"));
   FEMO_TRY(ensure_work(ctx, n, m->n_vert, w, 1));
   const int gv = vec_grid(ctx, n);
   const int gs = femo_spmv_grid(m);
@@ -1187,28 +1187,24 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
   const bool local_scalars = !multi && m->n_nbr == 0;
   const bool piggyback = multi && femo_pc_can_piggyback(m);
   const bool use_atol = opts->atol > 0.0;
-  // Iterations are enqueued in batches and the host polls the "done" stamp two batches deep; launches behind the
-  // converged iteration return at once but still cost ~5 us each (7 per iteration).  With a fixed batch of 8 a
-  // solve that converges at iteration 28 enqueued 40 (12 dead iterations, 0.4 ms).  Adaptive: the first batch runs
-  // to the iteration count of earlier solves on this mesh (+1), the following ones are short.
+  // Iterations are enqueued in batches and the host polls the "done" stamp; launches behind the converged iteration
+  // return at once but still cost ~5 us each (6 per iteration).  Round 1: fixed batches of 8, polled two deep -- a
+  // solve that converges at iteration 28 enqueued 40 (12 dead iterations).  Round 2: first batch = the count of
+  // earlier solves on this mesh + 1, then batches of 3, still two deep: 4 dead iterations per solve (12 % of the
+  // SpMV launches in the kernel trace were early exits).  Round 3: with a prediction the first batch is exactly the
+  // earlier count (BPX counts repeat from solve to solve: 28, 28, 28 ...) and the host waits for its stamp before it
+  // enqueues anything else; beyond the prediction two iterations at a time (a host round trip of ~30 us per pair,
+  // at most one dead iteration).  Without a prediction: batches of 8, two deep, as before.
   const int batch = opts->check_every > 0 ? std::min(opts->check_every, 8) : 8;
-  // Overlapped preconditioner apply (single GPU, FEMO_PCG_OVERLAP=1): x/r update on the main stream, restriction and
-  // lattice cycle beside it on a second stream with a second residual buffer.  Measured at C4 (A/B in one call):
-  // 19.7 ms per solve against 18.2 ms without -- the two event dependencies per iteration and the bandwidth the
-  // streaming update takes from the latency-bound brick kernel cost more than the 75 us the update could hide.  Off.
-  const bool overlap_on = getenv("FEMO_PCG_OVERLAP") != nullptr;
-  const bool overlap = local_scalars && !use_atol && overlap_on && femo_pc_can_overlap(m) && w.sv != nullptr;
-  if (overlap && ctx->comm_stream == nullptr) FEMO_HIP_CHECK(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
   double* r_cur = w.r;
-  double* r_oth = overlap ? w.sv : w.r;
   // (the smaller of the last two counts: Newton's later solves need far fewer iterations than its first)
   const int last2 = std::min(m->pcg_last_iters, m->pcg_prev_iters);
-  const int predicted = last2 > 0 ? last2 + 1 : 0;
+  const int predicted = last2 > 0 ? last2 : 0;
   int it = 0, polled = 0;
   bool done = false;
   int pending[2] = {-1, -1};
   while (!done) {
-    const int this_batch = predicted > 0 ? (it == 0 ? predicted : 3) : batch;
+    const int this_batch = predicted > 0 ? (it == 0 ? predicted : 2) : batch;
     const int it_end = it + this_batch < max_it ? it + this_batch : max_it;
     for (; it < it_end; ++it) {
       const int cur = it & 1, nxt = cur ^ 1;
@@ -1234,17 +1230,6 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
           hipLaunchKernelGGL(k_pcg_xr, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, g1, Pd, S, w.q, w.p, (const double*)r_cur, r_cur, w.xh, Pr, ctx->d_flags);
           hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(1024), 0, st, it, gv, Pr, S, ctx->d_flags);
           FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, r_cur, w.p, 1, S + S_RHO, S + S_GAMMA + cur, S + S_GAMMA + nxt, ctx->d_flags, gv, false, &stop));
-        } else if (overlap) {
-          // x, r update on the main stream; the restriction of r - alpha q (formed by the brick kernel from the old
-          // residual) and the lattice cycle beside it on the second stream; they meet before the mesh prolongation
-          FEMO_HIP_CHECK(hipEventRecord(ctx->ev_main, st));
-          hipLaunchKernelGGL(k_pcg_xr, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, g1, Pd, S, w.q, w.p, (const double*)r_cur, r_oth, w.xh, Pr, ctx->d_flags);
-          FemoPcSide side;
-          side.stream = ctx->comm_stream; side.fork = ctx->ev_main; side.join = ctx->ev_comm;
-          side.restrict_src = r_cur;
-          side.upd.q = w.q; side.upd.scal = S; side.upd.gamma_index = S_GAMMA + cur; side.upd.nb_d = g1; side.upd.partials_d = Pd;
-          FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, r_oth, w.p, 1, S + S_RHO, S + S_GAMMA + cur, S + S_GAMMA + nxt, ctx->d_flags, gv, false, &stop, gv, Pr, &side));
-          std::swap(r_cur, r_oth);
         } else {
           hipLaunchKernelGGL(k_pcg_xr, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, g1, Pd, S, w.q, w.p, (const double*)r_cur, r_cur, w.xh, Pr, ctx->d_flags);
           FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, r_cur, w.p, 1, S + S_RHO, S + S_GAMMA + cur, S + S_GAMMA + nxt, ctx->d_flags, gv, false, &stop, gv, Pr));
@@ -1274,6 +1259,12 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
     ++polled;
     const int prev = polled & 1;
     const bool last = it >= max_it;
+    if (predicted > 0) {                                  // synchronous poll of the batch just enqueued
+      FEMO_HIP_CHECK(hipEventSynchronize(ctx->ev_pool[2 * n_sample + slot]));
+      if (h_flags[4 * slot] || last) done = true;
+      pending[slot] = -1;
+      continue;
+    }
     if (pending[prev] >= 0) {
       FEMO_HIP_CHECK(hipEventSynchronize(ctx->ev_pool[2 * n_sample + prev]));
       if (h_flags[4 * prev]) done = true;
@@ -1350,7 +1341,7 @@ extern "C" int femo_solve_cg(const femo_mat* A_, int transpose, const femo_vec* 
   if (transpose && !opts->zero_guess) FEMO_TRY(femo_mat_ensure_transpose(A));
   CgWork w;
   // FEMO_FORCE_MULTI=1 runs the all-reduce code path on a 1-rank communicator (tests)
-  const bool multi = ctx->nranks > 1 || (ctx->comm != nullptr && getenv("FEMO_FORCE_MULTI") != nullptr);
+  const bool multi = ctx->nranks > 1 || (ctx->comm != nullptr && femo_env_flag("FEMO_FORCE_MULTI"));
   FEMO_TRY(ensure_work(ctx, n, m->n_vert, w, multi ? 1 : 0));
   const int gv = vec_grid(ctx, n);
   const int gs = femo_spmv_grid(m);
@@ -1514,7 +1505,7 @@ extern "C" int femo_solve_bicgstab(const femo_mat* A_, int transpose, const femo
   FEMO_TRY(ensure_scaled(A, transpose != 0 && !scatter_T));
   CgWork w;
   FEMO_TRY(ensure_work(ctx, n, m->n_vert, w, 2));
-  const bool multi = ctx->nranks > 1 || (ctx->comm != nullptr && getenv("FEMO_FORCE_MULTI") != nullptr);
+  const bool multi = ctx->nranks > 1 || (ctx->comm != nullptr && femo_env_flag("FEMO_FORCE_MULTI"));
   const int gv = vec_grid(ctx, n);
   const int gs = femo_spmv_grid(m);
   double* P = ctx->d_partials;

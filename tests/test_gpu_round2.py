@@ -255,35 +255,6 @@ def test_imported_unstructured_mesh_cycle(ctx, tmp_path):
     assert abs(sim['l2_functional'][0] - ref['J'][0]) < 1e-10 * abs(ref['J'][0])
 
 
-def test_overlapped_pcg_matches_the_sequential_one(ctx):
-    """FEMO_PCG_OVERLAP=1: update and restriction on two streams, the brick kernel forms r - alpha q itself from the
-    old residual (second residual buffer).  Same iteration count, same solution to rounding."""
-    import os
-    from femo_amd import engine as E
-    from femo_amd.fea.mesh import createUnitCubeMesh
-    mesh = createUnitCubeMesh(24, jitter=0.15)
-    dm = mesh.device(ctx)
-    n = mesh.n_vert
-    bd = fo.boundary_vertices_box(mesh.x)
-    ds = E.DirichletSet(dm, bd, np.zeros(len(bd)))
-    A, b = E.Mat(dm), E.Vec(ctx, n)
-    u0 = E.Vec(ctx, n).fill(0.0)
-    f = E.Vec(ctx, mesh.n_cell).set(1.0 + np.random.default_rng(3).random(mesh.n_cell))
-    E.assemble_system(dm, 0, None, u0, f, ds, None, A, b)
-    res = {}
-    for mode in ("0", "1"):
-        if mode == "1":
-            os.environ["FEMO_PCG_OVERLAP"] = "1"
-        try:
-            x = E.Vec(ctx, n)
-            info = A.solve_cg(b, x, rtol=1e-11, pc="bpx")
-            res[mode] = (info.iterations, np.array(x.get()))
-        finally:
-            os.environ.pop("FEMO_PCG_OVERLAP", None)
-    assert res["0"][0] == res["1"][0] and res["0"][0] > 5
-    assert np.abs(res["0"][1] - res["1"][1]).max() <= 1e-12 * np.abs(res["0"][1]).max()
-
-
 def test_poisson_opt_example_reaches_the_analytic_optimum(ctx):
     """BASELINE config 1 / examples/poisson_opt end to end: the optimisation of run_poisson_opt.py (objective scaled by
     1e5, start at f = 0.086, :168-176) driven by the GPU values and adjoint gradients converges to the analytic
