@@ -95,8 +95,9 @@ __global__ void k_bc_set_rhs(int64_t n, int64_t n_rows, const int32_t* __restric
   }
 }
 
+// structural zeros of completed regular slices (FemoTopology::real) are not part of the exported pattern
 __global__ void k_export_rows(int64_t n_rows, const int64_t* __restrict__ mptr, const int32_t* __restrict__ cols,
-                              const int32_t* __restrict__ rowlen, const double* __restrict__ diag,
+                              const int32_t* __restrict__ rowlen, const uint32_t* __restrict__ rowreal, const double* __restrict__ diag,
                               const double* __restrict__ vals, const int64_t* __restrict__ rowptr,
                               int32_t* __restrict__ ocol, double* __restrict__ oval) {
   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -106,7 +107,9 @@ __global__ void k_export_rows(int64_t n_rows, const int64_t* __restrict__ mptr, 
   const int len = rowlen[row];
   int64_t o = rowptr[row];
   bool placed = false;
+  const uint32_t real = rowreal[row];
   for (int k = 0; k < len; ++k) {
+    if (k < 32 && !((real >> k) & 1u)) continue;
     const int64_t e = femo_sell_index(base, k, lane);
     const int32_t c = cols[e];
     if (!placed && c > row) {
@@ -350,6 +353,7 @@ int femo_mesh_create(femo_ctx* ctx, int tdim, int64_t n_vert, int64_t n_rows, co
   FEMO_TRY(upload(&m->d_mptr, T.mptr, st));
   FEMO_TRY(upload(&m->d_cols, T.cols, st));
   FEMO_TRY(upload(&m->d_rowlen, T.rowlen, st));
+  FEMO_TRY(upload(&m->d_rowreal, T.real, st));
   FEMO_TRY(upload(&m->d_sdelta, T.sdelta, st));
   m->sdelta_stride = T.sdelta_stride; m->n_regular = T.n_regular;
   FEMO_HIP_CHECK(hipStreamSynchronize(st));  // T's host buffers die with this scope
@@ -361,7 +365,7 @@ int femo_mesh_destroy(femo_mesh* m) {
   if (!m) return 0;
   hipStreamSynchronize(m->ctx->stream);
   hipFree(m->d_x); hipFree(m->d_conn); hipFree(m->d_vptr); hipFree(m->d_visit_cell);
-  hipFree(m->d_visit_slots); hipFree(m->d_mptr); hipFree(m->d_cols); hipFree(m->d_rowlen);
+  hipFree(m->d_visit_slots); hipFree(m->d_mptr); hipFree(m->d_cols); hipFree(m->d_rowlen); hipFree(m->d_rowreal);
   femo_pc_destroy(m);
   hipFree(m->d_bvmask); hipFree(m->d_visit_rec); hipFree(m->d_load); hipFree(m->d_pipe_dummy); hipFree(m->d_ubc);
   if (m->mass) { femo_mat_destroy(m->mass); m->mass = nullptr; }
@@ -425,12 +429,18 @@ int femo_mesh_set_global(femo_mesh* m, const double* lo, const double* hi, int64
 
 static int pattern_rowptr(const femo_mesh* m, std::vector<int64_t>& rowptr) {
   std::vector<int32_t> rl(m->n_slices * FEMO_WAVE);
+  std::vector<uint32_t> real(m->n_slices * FEMO_WAVE);
   if (!rl.empty()) {
     FEMO_HIP_CHECK(hipMemcpyAsync(rl.data(), m->d_rowlen, rl.size() * sizeof(int32_t), hipMemcpyDeviceToHost, m->ctx->stream));
+    FEMO_HIP_CHECK(hipMemcpyAsync(real.data(), m->d_rowreal, real.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, m->ctx->stream));
     FEMO_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
   }
   rowptr.assign(m->n_rows + 1, 0);
-  for (int64_t v = 0; v < m->n_rows; ++v) rowptr[v + 1] = rowptr[v] + rl[v] + 1;
+  for (int64_t v = 0; v < m->n_rows; ++v) {
+    int n = 0;                                             // true couplings only (structural zeros are not exported)
+    for (int k = 0; k < rl[v]; ++k) n += (k >= 32 || ((real[v] >> k) & 1u)) ? 1 : 0;
+    rowptr[v + 1] = rowptr[v] + n + 1;
+  }
   return 0;
 }
 
@@ -670,7 +680,7 @@ int femo_mat_export_csr(const femo_mat* A, int64_t* rowptr, int32_t* col, double
   FEMO_HIP_CHECK(hipMalloc(&d_col, m->nnz * sizeof(int32_t)));
   FEMO_HIP_CHECK(hipMalloc(&d_val, m->nnz * sizeof(double)));
   FEMO_HIP_CHECK(hipMemcpyAsync(d_rp, rp.data(), rp.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_export_rows, dim3((unsigned)((m->n_rows + 255) / 256)), dim3(256), 0, st, m->n_rows, m->d_mptr, m->d_cols, m->d_rowlen, A->d_diag, A->d_vals, d_rp, d_col, d_val);
+  hipLaunchKernelGGL(k_export_rows, dim3((unsigned)((m->n_rows + 255) / 256)), dim3(256), 0, st, m->n_rows, m->d_mptr, m->d_cols, m->d_rowlen, m->d_rowreal, A->d_diag, A->d_vals, d_rp, d_col, d_val);
   FEMO_HIP_CHECK(hipGetLastError());
   FEMO_HIP_CHECK(hipMemcpyAsync(col, d_col, m->nnz * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   FEMO_HIP_CHECK(hipMemcpyAsync(val, d_val, m->nnz * sizeof(double), hipMemcpyDeviceToHost, st));

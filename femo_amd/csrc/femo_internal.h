@@ -85,9 +85,11 @@ struct FemoTopology {
   // off-diagonal sparsity pattern, SELL-64 pair-interleaved
   std::vector<int64_t> mptr;
   std::vector<int32_t> cols;          // padding entries carry the row's own index
-  std::vector<int32_t> rowlen;        // off-diagonal entries per row (n_slices*64)
-  // Slices whose 64 rows all have cols[k] = row + delta[k] (locally regular numbering)
-  // carry their deltas here; SpMV then needs no column indices for them.
+  std::vector<int32_t> rowlen;        // off-diagonal entries STORED per row (n_slices*64): true couplings + structural zeros
+  std::vector<uint32_t> real;         // bit k: entry k of the row is a true coupling (all ones outside completed regular slices)
+  // Slices whose 64 rows all have cols[k] = row + delta[k] (locally regular numbering; rows that lack a delta of the
+  // slice's set carry a structural zero there, topology.cpp) carry their deltas here; SpMV then needs no column
+  // indices for them.
   std::vector<int32_t> sdelta;        // n_slices * sdelta_stride, sdelta[s*stride] = INT32_MIN if irregular
   int sdelta_stride = 0;              // = padded max row length
   int64_t n_regular = 0;
@@ -195,6 +197,7 @@ struct femo_mesh {
   int64_t* d_mptr = nullptr;
   int32_t* d_cols = nullptr;
   int32_t* d_rowlen = nullptr;
+  uint32_t* d_rowreal = nullptr;  // FemoTopology::real
   int32_t* d_sdelta = nullptr;   // per-slice column deltas (see FemoTopology::sdelta)
   int sdelta_stride = 0;
   int64_t n_regular = 0;

@@ -227,7 +227,7 @@ __global__ void k_unpack_add(int64_t n, const int32_t* __restrict__ idx, const d
 
 // ------------------------------------------------------------ transposition --
 __global__ void k_build_tperm(int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ mptr,
-                              const int32_t* __restrict__ cols, const int32_t* __restrict__ rowlen,
+                              const int32_t* __restrict__ cols, const int32_t* __restrict__ rowlen, const uint32_t* __restrict__ rowreal,
                               int32_t* __restrict__ tperm, int32_t* __restrict__ err) {
   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n_slices * 64) return;
@@ -238,8 +238,8 @@ __global__ void k_build_tperm(int64_t n_rows, int64_t n_slices, const int64_t* _
   const int len = rowlen[row];
   for (int k = 0; k < wm; ++k) {
     const int64_t e = femo_sell_index(base, k, lane);
-    int32_t t = (int32_t)e;  // padding maps to itself (value 0)
-    if (k < len) {
+    int32_t t = (int32_t)e;  // padding and structural zeros (completed regular slices) map to themselves (value 0)
+    if (k < len && (k >= 32 || ((rowreal[row] >> k) & 1u))) {
       const int64_t j = cols[e];
       if (j >= n_rows) {
         atomicExch(err, 1);  // transposed entry lives on another rank
@@ -845,7 +845,7 @@ int femo_mat_ensure_transpose(femo_mat* A) {
     FEMO_HIP_CHECK(hipMalloc(&m->d_tperm, m->sell_entries * sizeof(int32_t)));
     FEMO_HIP_CHECK(hipMemsetAsync(ctx->d_flags + 3, 0, sizeof(int32_t), ctx->stream));
     const int64_t nr = m->n_slices * 64;
-    hipLaunchKernelGGL(k_build_tperm, dim3((nr + 255) / 256), dim3(256), 0, ctx->stream, m->n_rows, m->n_slices, m->d_mptr, m->d_cols, m->d_rowlen, m->d_tperm, ctx->d_flags + 3);
+    hipLaunchKernelGGL(k_build_tperm, dim3((nr + 255) / 256), dim3(256), 0, ctx->stream, m->n_rows, m->n_slices, m->d_mptr, m->d_cols, m->d_rowlen, m->d_rowreal, m->d_tperm, ctx->d_flags + 3);
     FEMO_HIP_CHECK(hipGetLastError());
     int32_t err = 0;
     FEMO_HIP_CHECK(hipMemcpyAsync(&err, ctx->d_flags + 3, sizeof err, hipMemcpyDeviceToHost, ctx->stream));

@@ -143,6 +143,55 @@ int femo_build_topology(int tdim, int64_t n_vert, int64_t n_rows, int64_t n_cell
                  max_len);
     T.nnz = noff[n_pad] + n_rows;
 
+    // 3.5 regular slices, completed.  A slice is "regular" when every lane's k-th column is row + delta[k]: the SpMV
+    // then fetches no column indices and reads x as 64 consecutive doubles per k.  Round 1-2 required the 64 rows to
+    // have identical delta lists, which on the lexicographically numbered cube fails for every slice that contains a
+    // vertex of the domain boundary (fewer neighbours): 35 % of the slices at n = 215.  Round 3: the slice's delta
+    // set is the UNION of its rows' deltas; a row that lacks one of them gets a structural zero there (column
+    // row + delta, value 0: no cell couples the two vertices, the assembly leaves the slot at zero).  Accepted when
+    // the union is no larger than the longest row of the mesh (so no kernel capacity changes, and unstructured
+    // numberings, whose union explodes, are rejected after a few rows) and every row + delta is a valid vertex.
+    // T.real marks the true couplings (bit k of row v); the CSR exports skip the structural zeros.
+    T.sdelta_stride = (T.max_rowlen + 1) & ~1;
+    if (T.sdelta_stride < 2) T.sdelta_stride = 2;
+    T.sdelta.assign((size_t)T.n_slices * T.sdelta_stride, INT32_MIN);
+    std::vector<int32_t> slen(T.n_slices, -1);               // |delta set| of the regular slices, -1: irregular
+    const int dcap = std::min(T.max_rowlen, 32);             // T.real is a 32-bit mask
+    {
+      std::atomic<int64_t> nreg{0};
+      parallel_for(T.n_slices, [&](int64_t lo, int64_t hi) {
+        int64_t local = 0;
+        std::vector<int64_t> D;
+        for (int64_t s = lo; s < hi; ++s) {
+          if ((s + 1) * FEMO_WAVE > n_rows || dcap < 1) continue;       // partial last slice: general path
+          D.clear();
+          bool ok = true;
+          for (int l = 0; l < FEMO_WAVE && ok; ++l) {
+            const int64_t v = s * FEMO_WAVE + l;
+            const int32_t* w = tmp.data() + uoff[v];
+            for (int k = 0; k < T.rowlen[v]; ++k) {
+              const int64_t d = (int64_t)w[k] - v;
+              auto it = std::lower_bound(D.begin(), D.end(), d);
+              if (it == D.end() || *it != d) {
+                if ((int)D.size() >= dcap) { ok = false; break; }
+                D.insert(it, d);
+              }
+            }
+          }
+          if (!ok || D.empty()) continue;
+          const int64_t v0 = s * FEMO_WAVE, v1 = v0 + FEMO_WAVE - 1;
+          if (v0 + D.front() < 0 || v1 + D.back() >= n_vert) continue;  // a completed column would leave [0, n_vert)
+          for (size_t k = 0; k < D.size(); ++k) T.sdelta[s * T.sdelta_stride + k] = (int32_t)D[k];
+          for (int k = (int)D.size(); k < T.sdelta_stride; ++k) T.sdelta[s * T.sdelta_stride + k] = 0;   // padding slot: own row, value 0
+          slen[s] = (int)D.size();
+          ++local;
+        }
+        nreg += local;
+      });
+      T.n_regular = nreg.load();
+    }
+    T.real.assign(n_pad, 0xFFFFFFFFu);
+
     // 4. SELL layouts
     T.vptr.assign(T.n_slices + 1, 0);
     T.mptr.assign(T.n_slices + 1, 0);
@@ -152,6 +201,7 @@ int femo_build_topology(int tdim, int64_t n_vert, int64_t n_rows, int64_t n_cell
         wv = std::max(wv, deg[s * FEMO_WAVE + l]);
         wm = std::max(wm, T.rowlen[s * FEMO_WAVE + l]);
       }
+      if (slen[s] >= 0) wm = slen[s];
       wm = (wm + 1) & ~1;
       T.vptr[s + 1] = T.vptr[s] + (int64_t)wv * FEMO_WAVE;
       T.mptr[s + 1] = T.mptr[s] + (int64_t)wm * FEMO_WAVE;
@@ -162,13 +212,26 @@ int femo_build_topology(int tdim, int64_t n_vert, int64_t n_rows, int64_t n_cell
     parallel_for(T.n_slices, [&](int64_t lo, int64_t hi) {
       for (int64_t s = lo; s < hi; ++s) {
         const int wm = (int)((T.mptr[s + 1] - T.mptr[s]) / FEMO_WAVE);
+        const bool reg = slen[s] >= 0;
+        const int32_t* dl = T.sdelta.data() + s * T.sdelta_stride;
         for (int l = 0; l < FEMO_WAVE; ++l) {
           const int64_t v = s * FEMO_WAVE + l;
           const int32_t* w = tmp.data() + uoff[v];
-          const int len = T.rowlen[v];
+          const int len_true = T.rowlen[v];
+          const int len = reg ? slen[s] : len_true;
           const int32_t self = (int32_t)std::min<int64_t>(v, n_vert - 1);
-          for (int k = 0; k < wm; ++k)
-            T.cols[femo_sell_index(T.mptr[s], k, l)] = k < len ? w[k] : self;
+          if (reg) {
+            uint32_t real = 0;
+            for (int k = 0; k < wm; ++k) {
+              const int32_t c = k < len ? (int32_t)(v + dl[k]) : self;
+              T.cols[femo_sell_index(T.mptr[s], k, l)] = c;
+              if (k < len && std::binary_search(w, w + len_true, c)) real |= 1u << k;
+            }
+            T.real[v] = real;
+          } else {
+            for (int k = 0; k < wm; ++k)
+              T.cols[femo_sell_index(T.mptr[s], k, l)] = k < len ? w[k] : self;
+          }
           for (int64_t e = off[v]; e < off[v + 1]; ++e) {
             const int64_t c = inc[e] >> 2;
             const int a = inc[e] & 3;
@@ -178,8 +241,15 @@ int femo_build_topology(int tdim, int64_t n_vert, int64_t n_rows, int64_t n_cell
             for (int b = 0; b < nv; ++b) {
               if (b == a) continue;
               const int32_t nb = conn[c * nv + b];
-              const int pos = (int)(std::lower_bound(w, w + len, nb) - w);
-              const uint32_t byte = (pos < len && w[pos] == nb) ? (uint32_t)pos : 0xFFu;
+              uint32_t byte = 0xFFu;
+              if (reg) {
+                const int32_t d = (int32_t)((int64_t)nb - v);
+                const int pos = (int)(std::lower_bound(dl, dl + len, d) - dl);
+                if (pos < len && dl[pos] == d && nb != v) byte = (uint32_t)pos;
+              } else {
+                const int pos = (int)(std::lower_bound(w, w + len, nb) - w);
+                if (pos < len && w[pos] == nb) byte = (uint32_t)pos;
+              }
               slots = (slots & ~(0xFFu << (8 * j))) | (byte << (8 * j));
               ++j;
             }
@@ -187,44 +257,21 @@ int femo_build_topology(int tdim, int64_t n_vert, int64_t n_rows, int64_t n_cell
             T.visit_cell[idx] = inc[e];
             T.visit_slots[idx] = slots;
           }
+          if (reg) T.rowlen[v] = len;                         // stored entries of the row (structural zeros included)
         }
       }
     });
-    // 5. regular slices: every lane's k-th column is row + delta[k]
-    T.sdelta_stride = (T.max_rowlen + 1) & ~1;
-    if (T.sdelta_stride < 2) T.sdelta_stride = 2;
-    T.sdelta.assign((size_t)T.n_slices * T.sdelta_stride, INT32_MIN);
-    std::atomic<int64_t> nreg{0};
-    parallel_for(T.n_slices, [&](int64_t lo, int64_t hi) {
-      int64_t local = 0;
-      for (int64_t s = lo; s < hi; ++s) {
-        if ((s + 1) * FEMO_WAVE > n_rows) continue;          // partial last slice: general path
-        const int wm = (int)((T.mptr[s + 1] - T.mptr[s]) / FEMO_WAVE);
-        bool regular = wm > 0;
-        const int len0 = T.rowlen[s * FEMO_WAVE];
-        if (len0 != wm) regular = false;                      // padding would break the delta form
-        for (int l = 1; l < FEMO_WAVE && regular; ++l)
-          if (T.rowlen[s * FEMO_WAVE + l] != len0) regular = false;
-        for (int k = 0; k < wm && regular; ++k) {
-          const int64_t d0 = (int64_t)T.cols[femo_sell_index(T.mptr[s], k, 0)] - s * FEMO_WAVE;
-          for (int l = 1; l < FEMO_WAVE; ++l)
-            if ((int64_t)T.cols[femo_sell_index(T.mptr[s], k, l)] - (s * FEMO_WAVE + l) != d0) { regular = false; break; }
-        }
-        if (!regular) continue;
-        for (int k = 0; k < wm; ++k)
-          T.sdelta[s * T.sdelta_stride + k] = (int32_t)((int64_t)T.cols[femo_sell_index(T.mptr[s], k, 0)] - s * FEMO_WAVE);
-        ++local;
-      }
-      nreg += local;
-    });
-    T.n_regular = nreg.load();
   }
   return 0;
 }
 
 void femo_topology_csr(const FemoTopology& T, int64_t* rowptr, int32_t* col) {
   rowptr[0] = 0;
-  for (int64_t v = 0; v < T.n_rows; ++v) rowptr[v + 1] = rowptr[v] + T.rowlen[v] + 1;
+  for (int64_t v = 0; v < T.n_rows; ++v) {
+    int n = 0;
+    for (int k = 0; k < T.rowlen[v]; ++k) n += (k >= 32 || ((T.real[v] >> k) & 1u)) ? 1 : 0;
+    rowptr[v + 1] = rowptr[v] + n + 1;
+  }
   if (!col) return;
   parallel_for(T.n_rows, [&](int64_t lo, int64_t hi) {
     for (int64_t v = lo; v < hi; ++v) {
@@ -234,6 +281,7 @@ void femo_topology_csr(const FemoTopology& T, int64_t* rowptr, int32_t* col) {
       bool placed = false;
       int n = 0;
       for (int k = 0; k < T.rowlen[v]; ++k) {
+        if (k < 32 && !((T.real[v] >> k) & 1u)) continue;     // structural zero of a completed regular slice
         const int32_t c = T.cols[femo_sell_index(T.mptr[s], k, l)];
         if (!placed && c > v) {
           out[n++] = (int32_t)v;

@@ -17,7 +17,7 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
-# the last two have slices with regular column offsets (delta-compressed SpMV path)
+# all but the smallest have slices with regular column offsets (delta-compressed SpMV path)
 CASES = [(2, 5, 0.0), (2, 33, 0.2), (3, 4, 0.0), (3, 13, 0.2), (2, 64, 0.0), (2, 200, 0.2), (3, 70, 0.0)]
 
 
@@ -30,7 +30,9 @@ def test_assembly_parity(ctx, d, n, jit):
     f = rng.standard_normal(m.n_cell)
     ud = rng.standard_normal(m.n_vert)
     dm = E.DeviceMesh(ctx, m.x, m.conn)
-    assert (dm.info['regular_slices'] > 0) == (n >= 70)
+    # structured numbering: every full slice away from the first / last rows is regular (boundary rows are completed with
+    # structural zeros, topology.cpp); meshes below one full slice have none
+    assert (dm.info['regular_slices'] > 0) == (m.n_vert >= 256)
     K = fo.stiffness(m)
     rowptr, col = dm.pattern_csr()
     assert np.array_equal(rowptr, K.indptr) and np.array_equal(col, K.indices)

@@ -309,3 +309,24 @@ def test_host_thread_pool_runs_and_lets_the_process_exit():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, cwd=root)
     assert p.returncode == 0 and p.stdout.strip() == "ok", p.stderr
+
+
+def test_regular_slices_are_completed_with_structural_zeros():
+    """topology.cpp step 3.5: on a structured numbering every full slice whose completed columns stay inside [0, n_vert) is
+    regular -- rows of boundary vertices get structural zeros at the deltas they lack -- while the exported CSR pattern
+    stays the true one (the other topology tests compare it with the oracle's); a random numbering has none."""
+    from femo_amd.engine import topology_host
+    m = fo.unit_cube_mesh(20)
+    info, rowptr, col = topology_host(3, m.n_vert, m.n_vert, m.conn)
+    K = fo.stiffness(m)
+    assert info["nnz"] == K.nnz and np.array_equal(rowptr, K.indptr) and np.array_equal(col, K.indices)
+    n_full = m.n_vert // 64
+    assert info["regular_slices"] >= n_full - 8 and info["max_rowlen"] == 14
+    assert info["sell_entries"] <= 1.02 * 14 * 64 * info["n_slices"]
+    perm = np.random.default_rng(0).permutation(m.n_vert)
+    info2, _, _ = topology_host(3, m.n_vert, m.n_vert, perm[m.conn].astype(np.int32))
+    assert info2["regular_slices"] == 0
+    m2 = fo.unit_square_mesh(40)
+    info3, rp3, col3 = topology_host(2, m2.n_vert, m2.n_vert, m2.conn)
+    K2 = fo.stiffness(m2)
+    assert np.array_equal(rp3, K2.indptr) and np.array_equal(col3, K2.indices) and info3["regular_slices"] >= m2.n_vert // 64 - 4
