@@ -56,7 +56,8 @@ def parse():
     p.add_argument("--no-configs", action="store_true", help="skip the legs for BASELINE configs 2, 5 and 3 (reported under 'configs')")
     p.add_argument("--no-check", action="store_true", help="skip the self-check of the timed configuration against the DST-exact cycle")
     p.add_argument("--reorder", action="store_true",
-                   help="renumber the mesh along a Morton curve first (what import_mesh does to a mesh it reads)")
+                   help="Mesh.reordered(): what import_mesh does to a mesh it reads (Morton curve unless the numbering is already structured)")
+    p.add_argument("--force-morton", action="store_true", help="with --reorder: renumber along the Morton curve regardless")
     p.add_argument("--pc", choices=("bpx", "jacobi"), default="bpx",
                    help="CG preconditioner: bpx = Jacobi + auxiliary-lattice multilevel correction (default)")
     return p.parse_args()
@@ -528,7 +529,7 @@ def _run(args):
     if args.permute:
         mesh = mesh.permuted(seed=20240807)
     if args.reorder:
-        mesh = mesh.reordered()
+        mesh = mesh.reordered(force=args.force_morton)
     sim, fea = build_problem(mesh, device=False)
     dm = mesh.device(ctx)
     n_dof, nnz = mesh.n_vert, dm.info["nnz"]

@@ -19,6 +19,7 @@ c_i64p = C.POINTER(C.c_int64)
 c_f64p = C.POINTER(C.c_double)
 H = C.c_void_p  # opaque handle
 
+ABI_VERSION = 5            # include/femo_hip.h FEMO_ABI_VERSION
 MESH_INFO_COUNT = 11
 MESH_INFO_KEYS = ("tdim", "n_vert", "n_rows", "n_cell", "nnz", "sell_entries", "max_rowlen",
                   "max_valence", "n_slices", "visit_entries", "regular_slices")
@@ -182,7 +183,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.femo_abi_version() != 4:
+    if lib.femo_abi_version() != ABI_VERSION:
         raise FemoError("libfemo_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -1578,27 +1578,38 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_restrict(int64_t m0, int64_t m1
 //   down: g[u] = sum over the node's children c of w g[6 c + f]                       (T^T, <= 27 children)
 //   up:   e[u] = C[u] g[u] + sum over the node's parents p of w e[6 p + f]           (T, <= 8 parents; none on level 0)
 //   blocks != nullptr (up only): C is the node's 6 x 6 block (row f of blocks[36 node ..]) instead of the diagonal
-__global__ void k_lat_level(int64_t n0, int64_t n1, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+__global__ __launch_bounds__(256) void k_lat_level(int64_t n0, int64_t n1, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                             const double* __restrict__ vals, const double* __restrict__ coarse, double* __restrict__ g,
-                            double* __restrict__ e, int up, const int32_t* __restrict__ done, const double* __restrict__ blocks = nullptr) {
+                            double* __restrict__ e, int up, const int32_t* __restrict__ done, const double* __restrict__ blocks = nullptr,
+                            double* __restrict__ dot_partials = nullptr) {
   if (done != nullptr && *done) return;
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t node = n0 + t / 6;
-  const int f = (int)(t % 6);
-  if (node >= n1) return;
-  const int64_t u = 6 * node + f;
-  const double* src = up ? e : g;
-  double s = 0.0;
-  for (int64_t k = rowptr[node]; k < rowptr[node + 1]; ++k) s += vals[k] * src[6 * (int64_t)cols[k] + f];
-  if (!up) { g[u] = s; return; }
-  if (blocks != nullptr) {
-    const double* B = blocks + 36 * node + 6 * f;
-    const double* gn = g + 6 * node;
+  // dot_partials (up, finest level only): per-block partial of e . g over the level -- with r . (B r) from the update
+  // kernel it gives r . z before z exists (r . P e = (P^T r) . e), so the direction update is fused into the prolongation
+  __shared__ double lds[256 / 64];
+  double dot = 0.0;
+  const int64_t total = (n1 - n0) * 6;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t node = n0 + t / 6;
+    const int f = (int)(t % 6);
+    const int64_t u = 6 * node + f;
+    const double* src = up ? e : g;
+    double s = 0.0;
+    for (int64_t k = rowptr[node]; k < rowptr[node + 1]; ++k) s += vals[k] * src[6 * (int64_t)cols[k] + f];
+    if (!up) { g[u] = s; continue; }
+    if (blocks != nullptr) {
+      const double* B = blocks + 36 * node + 6 * f;
+      const double* gn = g + 6 * node;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) s += B[q] * gn[q];
+      for (int q = 0; q < 6; ++q) s += B[q] * gn[q];
+    } else {
+      s += coarse[u] * g[u];
+    }
     e[u] = s;
-  } else {
-    e[u] = coarse[u] * g[u] + s;
+    dot += s * g[u];
+  }
+  if (dot_partials != nullptr) {
+    const double tsum = femo_block_sum<256>(dot, lds);
+    if (threadIdx.x == 0) dot_partials[blockIdx.x] = tsum;
   }
 }
 
@@ -1910,6 +1921,88 @@ __global__ __launch_bounds__(SH_BLOCK) void k_scg_p_z(int64_t n, int it, int nb_
   }
 }
 
+// x += alpha p; r -= alpha q per POINT (three dofs), and the per-block partial of r . (B r), B = the point's 3 x 3
+// smoother block (or 1 / diag): the first half of r . z = r . B r + (P^T r) . e  (see k_lat_level, k_pc_prolong_fused)
+__global__ __launch_bounds__(SH_BLOCK) void k_scg_xr_pt(int64_t n_pts, int nb_pq, const double* __restrict__ part_pq, const double* __restrict__ scal,
+                                                        const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ dinv,
+                                                        const double* __restrict__ dinv3, double* __restrict__ x, double* __restrict__ r,
+                                                        double* __restrict__ part_rB, const int32_t* __restrict__ done) {
+  if (*done) return;
+  __shared__ double lds[SH_BLOCK / 64];
+  const double pq = fold(part_pq, nb_pq, lds);
+  const double alpha = pq != 0.0 ? scal[0] / pq : 0.0;
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x; i < n_pts; i += (int64_t)gridDim.x * SH_BLOCK) {
+    const Triple pp = *reinterpret_cast<const Triple*>(p + 3 * i), qq = *reinterpret_cast<const Triple*>(q + 3 * i);
+    Triple xx = *reinterpret_cast<const Triple*>(x + 3 * i), rr = *reinterpret_cast<const Triple*>(r + 3 * i);
+    xx.a += alpha * pp.a; xx.b += alpha * pp.b; xx.c += alpha * pp.c;
+    rr.a -= alpha * qq.a; rr.b -= alpha * qq.b; rr.c -= alpha * qq.c;
+    *reinterpret_cast<Triple*>(x + 3 * i) = xx;
+    *reinterpret_cast<Triple*>(r + 3 * i) = rr;
+    if (dinv3 != nullptr) {
+      const double* B = dinv3 + 9 * i;
+      s += rr.a * (B[0] * rr.a + B[1] * rr.b + B[2] * rr.c) + rr.b * (B[3] * rr.a + B[4] * rr.b + B[5] * rr.c) +
+           rr.c * (B[6] * rr.a + B[7] * rr.b + B[8] * rr.c);
+    } else {
+      s += rr.a * rr.a * dinv[3 * i] + rr.b * rr.b * dinv[3 * i + 1] + rr.c * rr.c * dinv[3 * i + 2];
+    }
+  }
+  const double t = femo_block_sum<SH_BLOCK>(s, lds);
+  if (threadIdx.x == 0) part_rB[blockIdx.x] = t;
+}
+
+// The prolongation with the direction update fused in: gamma' = r . z is known before z is formed (partials of
+// r . B r from k_scg_xr_pt, of (P^T r) . e from the finest k_lat_level), so beta and the stopping test are, and the pass
+// writes p = z + beta p directly -- z = B r + P_L e_L is never stored, k_scg_p_z and its three vector streams are gone.
+__global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong_fused(int64_t n_pts, int it, int nb_rB, const double* __restrict__ part_rB, int nb_te,
+                                                               const double* __restrict__ part_te, double* __restrict__ scal,
+                                                               const int32_t* __restrict__ fin_idx, const double* __restrict__ fin_w,
+                                                               const uint8_t* __restrict__ fixed, const double* __restrict__ dinv,
+                                                               const double* __restrict__ dinv3, const double* __restrict__ r,
+                                                               const double* __restrict__ t, double* __restrict__ p,
+                                                               int32_t* __restrict__ flag, double* __restrict__ gamma_out) {
+  if (flag[0]) return;
+  __shared__ double lds[SH_BLOCK / 64];
+  const double g1 = fold(part_rB, nb_rB, lds) + fold(part_te, nb_te, lds);
+  const double g0 = scal[0];
+  const bool conv = g1 <= scal[2] || !(g1 == g1);
+  const double beta = g0 != 0.0 ? g1 / g0 : 0.0;
+  if (!conv) {
+    constexpr int SUB = 8;
+    const int sl = threadIdx.x & (SUB - 1);
+    const int64_t nsub = (int64_t)gridDim.x * (SH_BLOCK / SUB);
+    for (int64_t pt = (int64_t)blockIdx.x * (SH_BLOCK / SUB) + (threadIdx.x / SUB); pt < n_pts; pt += nsub) {
+      const double w = fin_w[pt * 8 + sl];
+      const Triple tp = *reinterpret_cast<const Triple*>(t + fin_idx[pt * 8 + sl]);
+      double s0 = w * tp.a, s1 = w * tp.b, s2 = w * tp.c;
+#pragma unroll
+      for (int off = SUB / 2; off > 0; off >>= 1) {
+        s0 += __shfl_xor(s0, off, 64);
+        s1 += __shfl_xor(s1, off, 64);
+        s2 += __shfl_xor(s2, off, 64);
+      }
+      if (sl < 3) {
+        const int64_t row = 3 * pt + sl;
+        const bool rf = fixed != nullptr && fixed[row];
+        double sm;
+        if (dinv3 != nullptr) {
+          const Triple B = *reinterpret_cast<const Triple*>(dinv3 + 9 * pt + 3 * sl), rp = *reinterpret_cast<const Triple*>(r + 3 * pt);
+          sm = B.a * rp.a + B.b * rp.b + B.c * rp.c;
+        } else {
+          sm = dinv[row] * r[row];
+        }
+        const double zi = rf ? 0.0 : sm + (sl == 0 ? s0 : (sl == 1 ? s1 : s2));
+        p[row] = zi + beta * p[row];
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    gamma_out[0] = g1;
+    flag[1] = it + 1;
+    if (conv) { flag[2] = (g1 == g1) ? 0 : 1; __threadfence(); flag[0] = it + 1; }
+  }
+}
+
 inline unsigned sgrid(int64_t n, int per = SH_BLOCK) {
   int64_t g = (n + per - 1) / per;
   if (g < 1) g = 1;
@@ -2156,9 +2249,20 @@ static int shell_pc_coarse_setup(femo_shell* s, const femo_vec* vals, const uint
 }
 
 // z = M^-1 r (lattice preconditioner) and the per-block partials of r.z; enqueues 2 L + 1 launches
-static int shell_pc_apply(femo_shell* s, const uint8_t* d_fixed, double* Prz, unsigned gz, const int32_t* done) {
+// Pte != nullptr: the fused form -- the finest level's up kernel also emits the partials of e . g into Pte (*nb_te blocks)
+// and the prolongation is left to the caller (k_pc_prolong_fused).
+static int shell_pc_apply(femo_shell* s, const uint8_t* d_fixed, double* Prz, unsigned gz, const int32_t* done,
+                          double* Pte = nullptr, int* nb_te = nullptr) {
   hipStream_t st = s->ctx->stream;
   const int L = s->pc_levels;
+  auto level_up = [&](int l, const double* blocks) {
+    const int64_t n0 = s->level_off[l], n1 = s->level_off[l + 1];
+    const bool last = l == L - 1 && Pte != nullptr;
+    const unsigned g = last ? std::min<unsigned>(sgrid((n1 - n0) * 6, 256), 1024u) : sgrid((n1 - n0) * 6, 256);   // few partials: every block of the prolongation folds them
+    if (last && nb_te) *nb_te = (int)g;
+    hipLaunchKernelGGL(k_lat_level, dim3(g), dim3(256), 0, st, n0, n1, s->d_par_rowptr, s->d_par_cols, s->d_par_vals,
+                       s->d_coarse, s->d_t, s->d_e, 1, done, blocks, last ? Pte : (double*)nullptr);
+  };
   const int64_t m0 = s->level_off[L - 1], m1 = s->level_off[L];
   // 32 lanes per row (rows hold ~100 points; 8 / 16 / 32 / 64 lanes: 0.362 / 0.355 / 0.351 / 0.351 ms per iteration)
   hipLaunchKernelGGL(k_pc_restrict<32>, dim3(std::min<unsigned>(sgrid(2 * (m1 - m0), SH_BLOCK / 32), 1 << 16)), dim3(SH_BLOCK), 0, st, m0, m1,
@@ -2182,11 +2286,7 @@ static int shell_pc_apply(femo_shell* s, const uint8_t* d_fixed, double* Prz, un
                        s->d_t + 6 * s->level_off[cs], s->d_cs_tmp, done);
     hipLaunchKernelGGL(k_pc_coarse_apply, dim3(gp), dim3(SH_BLOCK), 0, st, s->cs_n, s->cs_N, 0, s->d_cs_A, s->d_cs_tmp,
                        s->d_e + 6 * s->level_off[cs], done);
-    for (int l = cs + 1; l < L; ++l) {
-      const int64_t n0 = s->level_off[l], n1 = s->level_off[l + 1];
-      hipLaunchKernelGGL(k_lat_level, dim3(sgrid((n1 - n0) * 6, 256)), dim3(256), 0, st, n0, n1, s->d_par_rowptr, s->d_par_cols, s->d_par_vals,
-                         s->d_coarse, s->d_t, s->d_e, 1, done, s->blk_ready ? s->d_cblk : (const double*)nullptr);
-    }
+    for (int l = cs + 1; l < L; ++l) level_up(l, s->blk_ready ? s->d_cblk : (const double*)nullptr);
   } else {
   // levels 0 .. kc (at most 256 nodes each, never the finest: with 4096 the one workgroup took 244 us, with 768 still 71) go through the fused single-workgroup kernel
     int kc = -1;
@@ -2203,12 +2303,9 @@ static int shell_pc_apply(femo_shell* s, const uint8_t* d_fixed, double* Prz, un
       hipLaunchKernelGGL(k_lat_coarse_fused, dim3(1), dim3(1024), 0, st, Lv, s->d_chi_rowptr, s->d_chi_cols, s->d_chi_vals, s->d_par_rowptr,
                          s->d_par_cols, s->d_par_vals, s->d_coarse, s->d_t, s->d_e, done);
     }
-    for (int l = kc + 1; l < L; ++l) {
-      const int64_t n0 = s->level_off[l], n1 = s->level_off[l + 1];
-      hipLaunchKernelGGL(k_lat_level, dim3(sgrid((n1 - n0) * 6, 256)), dim3(256), 0, st, n0, n1, s->d_par_rowptr, s->d_par_cols, s->d_par_vals,
-                         s->d_coarse, s->d_t, s->d_e, 1, done);
-    }
+    for (int l = kc + 1; l < L; ++l) level_up(l, (const double*)nullptr);
   }
+  if (Pte != nullptr) { FEMO_HIP_CHECK(hipGetLastError()); return 0; }
   hipLaunchKernelGGL(k_pc_prolong, dim3(gz), dim3(SH_BLOCK), 0, st, s->n_dof / 3, s->d_fin_idx, s->d_fin_w, d_fixed, s->d_dinv, s->d_r, s->d_e,
                      s->d_z, Prz, done, s->dinv3_ready ? s->d_dinv3 : (const double*)nullptr);
   FEMO_HIP_CHECK(hipGetLastError());
@@ -2614,6 +2711,10 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
     s->bs_vals_uid = vals->uid; s->bs_vals_gen = vals->gen;
   }
   const unsigned gz = std::min<unsigned>(sgrid(n / 3, SH_BLOCK / 8), SH_MAXPART);     // k_pc_prolong: 8 lanes per point
+  const unsigned gx = std::min<unsigned>(sgrid(n / 3), 1024u);                        // k_scg_xr_pt: a thread per point, few partials
+  double* Pte = s->d_part + 2 * SH_MAXPART;
+  // direction update fused into the prolongation (dofs numbered 3 point + component: every shell pattern of fea/shell.py)
+  const bool fused = opts->pc == 1 && n % 3 == 0 && !femo_env_flag("FEMO_SHELL_UNFUSED");
   if (lattice) {
     // Galerkin diagonals of the current stiffness and Dirichlet set (kept while both stay the same)
     uint64_t mh = 1469598103934665603ull;
@@ -2681,7 +2782,17 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
       else
         hipLaunchKernelGGL(k_csr_spmv, dim3(gs), dim3(SH_BLOCK), 0, st, n, s->d_rowptr, s->d_cols, vals->d, d_fixed, 0, s->d_p, s->d_q, Ppq, s->d_flag, s->d_scal, gam);
       if (sample) { FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev + 1], st)); ++n_ev; }
-      if (lattice) {
+      if (lattice && fused) {
+        // r . z = r . B r + (P^T r) . e is known before z is: the update emits the first part, the finest lattice level
+        // the second, and the prolongation writes p = z + beta p at once (9 launches and 3 vector streams fewer
+        // per iteration than the unfused form below)
+        int nb_te = 0;
+        hipLaunchKernelGGL(k_scg_xr_pt, dim3(gx), dim3(SH_BLOCK), 0, st, n / 3, (int)gs, Ppq, s->d_scal, s->d_p, s->d_q, s->d_dinv,
+                           s->dinv3_ready ? s->d_dinv3 : (const double*)nullptr, x->d, s->d_r, Prz, s->d_flag);
+        FEMO_TRY(shell_pc_apply(s, d_fixed, Prz, gz, s->d_flag, Pte, &nb_te));
+        hipLaunchKernelGGL(k_pc_prolong_fused, dim3(gz), dim3(SH_BLOCK), 0, st, n / 3, it, (int)gx, Prz, nb_te, Pte, s->d_scal, s->d_fin_idx, s->d_fin_w,
+                           d_fixed, s->d_dinv, s->dinv3_ready ? s->d_dinv3 : (const double*)nullptr, s->d_r, s->d_e, s->d_p, s->d_flag, gam);
+      } else if (lattice) {
         hipLaunchKernelGGL(k_scg_xr_plain, dim3(gv), dim3(SH_BLOCK), 0, st, n, (int)gs, Ppq, s->d_scal, s->d_p, s->d_q, x->d, s->d_r, s->d_flag);
         FEMO_TRY(shell_pc_apply(s, d_fixed, Prz, gz, s->d_flag));
         hipLaunchKernelGGL(k_scg_p_z, dim3(gv), dim3(SH_BLOCK), 0, st, n, it, (int)gz, Prz, s->d_scal, s->d_z, s->d_p, s->d_flag, gam);

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FEMO_ABI_VERSION 4
+#define FEMO_ABI_VERSION 5
 
 typedef struct femo_ctx  femo_ctx;   /* device + stream + reduction workspace (+ RCCL communicator) */
 typedef struct femo_vec  femo_vec;   /* fp64 device vector  (dolfinx Function.vector / PETSc Vec)     */

@@ -286,3 +286,60 @@ for fac in (0.66, 1.0, 1.33):
         z = z + PtF @ vc(PtF.T @ (r - Kf @ z), nl - 1)
         return z + w * (Spt @ (r - Kf @ z))
     it, _ = pcg(pc_sa_v); print(f"smoothed P (omega={fac:.2f}/lmax), V-cycle: {it} its (5 K-applies per it)", flush=True)
+
+# ---- deflation with Ritz vectors harvested from the forward solve (recycling for the adjoint right-hand side)
+print("--- deflation / recycling", flush=True)
+def pcg_store(apply_pc, rhs, rtol=1e-10, maxit=3000):
+    x = np.zeros(nd); r = rhs.copy(); z = apply_pc(r); p = z.copy(); g = r @ z; g0 = g
+    Z, al, be = [z / np.sqrt(g)], [], []
+    for it in range(1, maxit + 1):
+        q = Kf @ p
+        a = g / (p @ q)
+        x += a * p; r -= a * q
+        z = apply_pc(r); g1 = r @ z
+        al.append(a)
+        if g1 <= rtol ** 2 * g0:
+            return it, x, Z, al, be
+        be.append(g1 / g)
+        Z.append(z / np.sqrt(g1) * (-1) ** it)
+        p = z + (g1 / g) * p; g = g1
+    return maxit, x, Z, al, be
+
+it, x, Z, al, be = pcg_store(pc_current, b)
+m = len(al)
+T = np.zeros((m, m))
+for j in range(m):
+    T[j, j] = 1.0 / al[j] + (be[j - 1] / al[j - 1] if j > 0 else 0.0)
+    if j + 1 < m:
+        T[j, j + 1] = T[j + 1, j] = np.sqrt(be[j]) / al[j]
+ev, V = np.linalg.eigh(T)
+print("forward solve", it, "its; extreme Ritz values of M^-1 K:", ev[:6], "...", ev[-3:], " cond ~", ev[-1] / ev[0])
+Zm = np.stack(Z[:m], axis=1)
+w0 = spla.splu(Kf.tocsc()).solve(b)
+rhs2 = so.compliance_du(V_ := V, w0) if False else so.compliance_du(so.ShellSpace(pts, conn), w0) * mask
+it_plain, _ = pcg(pc_current) if False else (None, None)
+def pcg_rhs(apply_pc, rhs, rtol=1e-10, maxit=3000, W=None):
+    if W is not None:
+        KW = Kf @ W
+        E = W.T @ KW
+        Einv = np.linalg.inv(E)
+        x = W @ (Einv @ (W.T @ rhs))
+        r = rhs - Kf @ x
+    else:
+        x = np.zeros(nd); r = rhs.copy()
+    def proj(v):                       # v - W E^-1 (KW)^T v : K-orthogonal to W
+        return v - W @ (Einv @ (KW.T @ v)) if W is not None else v
+    z = proj(apply_pc(r)); p = z.copy(); g = r @ z; g0 = rhs @ apply_pc(rhs)
+    for it in range(1, maxit + 1):
+        q = Kf @ p
+        a = g / (p @ q)
+        x += a * p; r -= a * q
+        z = proj(apply_pc(r)); g1 = r @ z
+        if g1 <= rtol ** 2 * g0:
+            return it
+        p = z + (g1 / g) * p; g = g1
+    return maxit
+print("adjoint rhs, no deflation:", pcg_rhs(pc_current, rhs2), "its")
+for k in (4, 8, 16, 32):
+    W = Zm @ V[:, :k]                  # Ritz vectors of the k smallest Ritz values
+    print(f"adjoint rhs, deflating {k} Ritz vectors: {pcg_rhs(pc_current, rhs2, W=W)} its")

@@ -113,6 +113,8 @@ def test_self_check_maps_renumbered_meshes_back():
     n = 6
     canon = createUnitCubeMesh(n)
     mesh = canon.permuted(seed=3, cells=True).reordered()
+    assert canon.reordered() is not canon and np.array_equal(canon.reordered().conn, canon.conn)      # structured numbering: kept
+    assert not np.array_equal(canon.reordered(force=True).conn, canon.conn)
     f = bench.source_fields(mesh, 1)[0]
     om = fo.OMesh(3, mesh.x, mesh.conn, n)
     bd = fo.boundary_vertices_box(mesh.x)
