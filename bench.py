@@ -71,8 +71,10 @@ def spmv_algorithmic_bytes(nnz: int, n: int) -> int:
 def stored_bytes(info: dict, n: int) -> int:
     """Bytes the SELL SpMV actually has to move: values of every padded entry, column
     indices of the irregular slices only, per-slice deltas, diagonal, x and y."""
-    frac_irregular = 1.0 - info["regular_slices"] / max(info["n_slices"], 1)
-    return int(info["sell_entries"] * 8 + info["sell_entries"] * 4 * frac_irregular
+    ns = max(info["n_slices"], 1)
+    frac_short = info.get("short_slices", 0) / ns                       # 16-bit column deltas
+    frac_general = 1.0 - info["regular_slices"] / ns - frac_short       # 32-bit column indices
+    return int(info["sell_entries"] * 8 + info["sell_entries"] * (4 * frac_general + 2 * frac_short)
                + info["n_slices"] * (8 + 4 * info["max_rowlen"]) + 3 * n * 8)
 
 
@@ -590,7 +592,7 @@ def _run(args):
     B_A = spmv_algorithmic_bytes(nnz, n_dof)
     achieved = B_A / (spmv_avg_ms * 1e-3) / 1e9
     traffic = None
-    for name in ("r02_pmc_traffic.json", "pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
         prof = os.path.join(ROOT, "profiles", name)
         if os.path.exists(prof):
             try:
@@ -630,7 +632,7 @@ def _run(args):
             "preconditioner": PC, "pc_lattice": dm.pc_info(),
             "n": args.n, "jitter": args.jitter, "permuted": bool(args.permute), "reordered": bool(args.reorder),
             "n_dof": n_dof, "n_cell": mesh.n_cell, "nnz": nnz,
-            "sell_slices": dm.info["n_slices"], "regular_slices": dm.info["regular_slices"],
+            "sell_slices": dm.info["n_slices"], "regular_slices": dm.info["regular_slices"], "short_slices": dm.info.get("short_slices", 0),
             "linear_solves_per_step": per, "cg_iterations_per_step": its_per_step, "cg_ms_per_step": cg_ms,
             "non_cg_ms_per_step": ms_per_step - cg_ms, "setup_s": setup_s,
             # SURVEY.md section 8(d) split: Newton's linear solves / the transposed (adjoint) solve /

@@ -20,9 +20,9 @@ c_f64p = C.POINTER(C.c_double)
 H = C.c_void_p  # opaque handle
 
 ABI_VERSION = 5            # include/femo_hip.h FEMO_ABI_VERSION
-MESH_INFO_COUNT = 11
+MESH_INFO_COUNT = 12
 MESH_INFO_KEYS = ("tdim", "n_vert", "n_rows", "n_cell", "nnz", "sell_entries", "max_rowlen",
-                  "max_valence", "n_slices", "visit_entries", "regular_slices")
+                  "max_valence", "n_slices", "visit_entries", "regular_slices", "short_slices")
 
 PDE_POISSON = 0
 PDE_NL_POISSON = 1

@@ -355,7 +355,8 @@ int femo_mesh_create(femo_ctx* ctx, int tdim, int64_t n_vert, int64_t n_rows, co
   FEMO_TRY(upload(&m->d_rowlen, T.rowlen, st));
   FEMO_TRY(upload(&m->d_rowreal, T.real, st));
   FEMO_TRY(upload(&m->d_sdelta, T.sdelta, st));
-  m->sdelta_stride = T.sdelta_stride; m->n_regular = T.n_regular;
+  m->sdelta_stride = T.sdelta_stride; m->n_regular = T.n_regular; m->n_short = T.n_short;
+  FEMO_TRY(upload(&m->d_cols16, T.cols16, st));
   FEMO_HIP_CHECK(hipStreamSynchronize(st));  // T's host buffers die with this scope
   *out = m;
   return 0;
@@ -370,7 +371,7 @@ int femo_mesh_destroy(femo_mesh* m) {
   hipFree(m->d_bvmask); hipFree(m->d_visit_rec); hipFree(m->d_load); hipFree(m->d_pipe_dummy); hipFree(m->d_ubc);
   if (m->mass) { femo_mat_destroy(m->mass); m->mass = nullptr; }
   hipFree(m->d_mass_e);
-  hipFree(m->d_sdelta); hipFree(m->d_bfacets); hipFree(m->d_tperm); hipFree(m->d_send_idx); hipFree(m->d_send_buf); hipFree(m->d_scratch); hipFree(m->d_slices_int); hipFree(m->d_slices_bnd);
+  hipFree(m->d_sdelta); hipFree(m->d_cols16); hipFree(m->d_bfacets); hipFree(m->d_tperm); hipFree(m->d_send_idx); hipFree(m->d_send_buf); hipFree(m->d_scratch); hipFree(m->d_slices_int); hipFree(m->d_slices_bnd);
   delete m;
   return 0;
 }
@@ -388,6 +389,7 @@ int femo_mesh_info(const femo_mesh* m, int64_t info[FEMO_MESH_INFO_COUNT]) {
   info[FEMO_MESH_N_SLICES] = m->n_slices;
   info[FEMO_MESH_VISIT_ENTRIES] = m->visit_entries;
   info[FEMO_MESH_REGULAR_SLICES] = m->n_regular;
+  info[FEMO_MESH_SHORT_SLICES] = m->n_short;
   return 0;
 }
 

@@ -93,6 +93,10 @@ struct FemoTopology {
   std::vector<int32_t> sdelta;        // n_slices * sdelta_stride, sdelta[s*stride] = INT32_MIN if irregular
   int sdelta_stride = 0;              // = padded max row length
   int64_t n_regular = 0;
+  // irregular slices whose columns all lie within +-32767 of their row: 16-bit deltas, same layout as `cols`
+  // (flag: sdelta[s*stride + 1] == 1); the SpMV reads these instead of the 32-bit indices
+  std::vector<int16_t> cols16;
+  int64_t n_short = 0;
   int64_t nnz = 0;                    // true nonzeros incl. diagonal
   int max_rowlen = 0, max_valence = 0;
 };
@@ -200,7 +204,8 @@ struct femo_mesh {
   uint32_t* d_rowreal = nullptr;  // FemoTopology::real
   int32_t* d_sdelta = nullptr;   // per-slice column deltas (see FemoTopology::sdelta)
   int sdelta_stride = 0;
-  int64_t n_regular = 0;
+  int64_t n_regular = 0, n_short = 0;
+  int16_t* d_cols16 = nullptr;   // FemoTopology::cols16
   void* d_visit_rec = nullptr;   // per incidence entry, 16 B: (cell<<2|a, slots, 1/(36|T|)) for the Poisson walks, built on first use
   double* d_load = nullptr;      // load vector of the Poisson residual for the f identified by (load_uid, load_gen)
   uint64_t load_uid = 0, load_gen = 0;

@@ -94,6 +94,51 @@ __device__ __forceinline__ double row_sum(int npair, const double2* __restrict__
   }
 }
 
+// Short slice: the columns as 16-bit deltas from the row, two per 4-byte word (one global_load_dword per pair and lane
+// instead of a dwordx2)
+template <int NP>
+__device__ __forceinline__ double row_pairs_short(const double2* __restrict__ v2, const int* __restrict__ c16,
+                                                  const double* __restrict__ xrow, double acc) {
+  double2 a[NP];
+  int j[NP];
+#pragma unroll
+  for (int m = 0; m < NP; ++m) {
+    a[m] = nt_load2(&v2[m * 64]);
+    j[m] = __builtin_nontemporal_load(&c16[m * 64]);
+  }
+  double xv[2 * NP];
+#pragma unroll
+  for (int m = 0; m < NP; ++m) {
+    xv[2 * m] = xrow[(int)(short)(j[m] & 0xFFFF)];
+    xv[2 * m + 1] = xrow[j[m] >> 16];
+  }
+#pragma unroll
+  for (int m = 0; m < NP; ++m) {
+    acc += a[m].x * xv[2 * m];
+    acc += a[m].y * xv[2 * m + 1];
+  }
+  return acc;
+}
+
+__device__ __forceinline__ double row_sum_short(int npair, const double2* __restrict__ v2, const int* __restrict__ c16,
+                                                const double* __restrict__ xrow, double acc) {
+  while (npair > 8) {
+    acc = row_pairs_short<8>(v2, c16, xrow, acc);
+    v2 += 8 * 64; c16 += 8 * 64; npair -= 8;
+  }
+  switch (npair) {  // wave-uniform
+    case 8: return row_pairs_short<8>(v2, c16, xrow, acc);
+    case 7: return row_pairs_short<7>(v2, c16, xrow, acc);
+    case 6: return row_pairs_short<6>(v2, c16, xrow, acc);
+    case 5: return row_pairs_short<5>(v2, c16, xrow, acc);
+    case 4: return row_pairs_short<4>(v2, c16, xrow, acc);
+    case 3: return row_pairs_short<3>(v2, c16, xrow, acc);
+    case 2: return row_pairs_short<2>(v2, c16, xrow, acc);
+    case 1: return row_pairs_short<1>(v2, c16, xrow, acc);
+    default: return acc;
+  }
+}
+
 // Regular slice: column k of lane l is row + delta[k]; x is read as 64 consecutive
 // doubles per k (one coalesced 512-B load), no column indices are fetched.
 template <int NP>
@@ -142,7 +187,7 @@ __device__ __forceinline__ double row_sum_regular(int npair, const double2* __re
 template <int DOT, bool UNIT>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_spmv_sell(
     int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ mptr,
-    const int32_t* __restrict__ cols, const int32_t* __restrict__ sdelta, int sdelta_stride,
+    const int32_t* __restrict__ cols, const int16_t* __restrict__ cols16, const int32_t* __restrict__ sdelta, int sdelta_stride,
     const double* __restrict__ vals, const double* __restrict__ diag, const double* __restrict__ x,
     double* __restrict__ y, double* __restrict__ partials, const int32_t* __restrict__ done,
     const int32_t* __restrict__ slice_list, int64_t n_list, const double* __restrict__ dvec) {
@@ -173,6 +218,9 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_spmv_sell(
     const int32_t* __restrict__ dl = sdelta + slice * sdelta_stride;
     if (dl[0] != INT32_MIN) {  // wave-uniform (scalar load)
       acc = row_sum_regular(npair, v2, dl, x + row, acc);
+    } else if (dl[1] == 1) {   // 16-bit column deltas (the clamped row of a lane beyond n_rows still addresses valid entries)
+      const int* __restrict__ c16 = reinterpret_cast<const int*>(cols16) + (base >> 1) + lane;
+      acc = row_sum_short(npair, v2, c16, x + row, acc);
     } else {
       const int2* __restrict__ c2 = reinterpret_cast<const int2*>(cols + base) + lane;
       acc = row_sum<true>(npair, v2, c2, x, acc);
@@ -788,7 +836,7 @@ static int launch_spmv(const femo_mat* A, const double* vals, const double* x, d
     g = std::min<int64_t>(g, std::max<int64_t>(8, ((n_walk + 3) / 4 + 7) & ~int64_t(7)));
   }
   hipStream_t st = stream ? stream : m->ctx->stream;
-#define FEMO_SPMV_ARGS m->n_rows, m->n_slices, m->d_mptr, m->d_cols, m->d_sdelta, m->sdelta_stride, vals, A->d_diag, x, y, partials, done, slice_list, n_list, dvec
+#define FEMO_SPMV_ARGS m->n_rows, m->n_slices, m->d_mptr, m->d_cols, m->d_cols16, m->d_sdelta, m->sdelta_stride, vals, A->d_diag, x, y, partials, done, slice_list, n_list, dvec
   if (partials && unit && dot_yy) hipLaunchKernelGGL((k_spmv_sell<3, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
   else if (partials && unit && dot2) hipLaunchKernelGGL((k_spmv_sell<2, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
   else if (partials && unit) hipLaunchKernelGGL((k_spmv_sell<1, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);

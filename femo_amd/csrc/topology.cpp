@@ -261,6 +261,40 @@ int femo_build_topology(int tdim, int64_t n_vert, int64_t n_rows, int64_t n_cell
         }
       }
     });
+    // 6. short slices: irregular slices all of whose stored columns lie within +-32767 of their row keep a second copy of
+    // the column indices as 16-bit deltas (pair-interleaved like `cols`): the SpMV then fetches 2 instead of 4 bytes per
+    // entry for them.  A bandwidth-reducing numbering (Morton curve: ~2/3 of the slices at 10 M vertices; any banded
+    // numbering of a smaller mesh: all of them) qualifies, a random one does not.  Flag: sdelta[s * stride + 1] = 1.
+    T.cols16.assign(T.cols.size(), 0);
+    std::atomic<int64_t> nshort{0};
+    parallel_for(T.n_slices, [&](int64_t lo, int64_t hi) {
+      int64_t local = 0;
+      for (int64_t s = lo; s < hi; ++s) {
+        if (slen[s] >= 0) continue;
+        const int wm = (int)((T.mptr[s + 1] - T.mptr[s]) / FEMO_WAVE);
+        if (wm == 0) continue;
+        bool ok = true;
+        for (int l = 0; l < FEMO_WAVE && ok; ++l) {
+          const int64_t v = s * FEMO_WAVE + l;
+          for (int k = 0; k < wm; ++k) {
+            const int64_t d = (int64_t)T.cols[femo_sell_index(T.mptr[s], k, l)] - v;
+            if (d < -32767 || d > 32767) { ok = false; break; }
+          }
+        }
+        if (!ok) continue;
+        for (int l = 0; l < FEMO_WAVE; ++l) {
+          const int64_t v = s * FEMO_WAVE + l;
+          for (int k = 0; k < wm; ++k) {
+            const int64_t e = femo_sell_index(T.mptr[s], k, l);
+            T.cols16[e] = (int16_t)((int64_t)T.cols[e] - v);
+          }
+        }
+        T.sdelta[s * T.sdelta_stride + 1] = 1;
+        ++local;
+      }
+      nshort += local;
+    });
+    T.n_short = nshort.load();
   }
   return 0;
 }
@@ -311,6 +345,7 @@ extern "C" int femo_topology_build_host(int tdim, int64_t n_vert, int64_t n_rows
   info[FEMO_MESH_N_SLICES] = T.n_slices;
   info[FEMO_MESH_VISIT_ENTRIES] = T.vptr[T.n_slices];
   info[FEMO_MESH_REGULAR_SLICES] = T.n_regular;
+  info[FEMO_MESH_SHORT_SLICES] = T.n_short;
   if (rowptr) femo_topology_csr(T, rowptr, col);
   return 0;
 }

@@ -65,7 +65,8 @@ enum femo_mesh_info_key {
   FEMO_MESH_MAX_ROWLEN = 6, FEMO_MESH_MAX_VALENCE = 7, FEMO_MESH_N_SLICES = 8,
   FEMO_MESH_VISIT_ENTRIES = 9,
   FEMO_MESH_REGULAR_SLICES = 10, /* slices whose column indices are row + per-slice deltas */
-  FEMO_MESH_INFO_COUNT = 11
+  FEMO_MESH_SHORT_SLICES = 11,   /* irregular slices with 16-bit column deltas (SpMV reads 2 B per entry) */
+  FEMO_MESH_INFO_COUNT = 12
 };
 
 /* preconditioner of femo_solve_cg (femo_solver_opts.pc) */
