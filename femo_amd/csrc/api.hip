@@ -370,7 +370,7 @@ int femo_mesh_destroy(femo_mesh* m) {
   femo_pc_destroy(m);
   hipFree(m->d_bvmask); hipFree(m->d_visit_rec); hipFree(m->d_load); hipFree(m->d_pipe_dummy); hipFree(m->d_ubc);
   if (m->mass) { femo_mat_destroy(m->mass); m->mass = nullptr; }
-  hipFree(m->d_mass_e);
+  hipFree(m->d_mass_e); hipFree(m->d_mass_g); hipFree(m->d_cellvol); hipFree(m->d_cellvol_own); hipFree(m->d_cell_t);
   hipFree(m->d_sdelta); hipFree(m->d_cols16); hipFree(m->d_bfacets); hipFree(m->d_tperm); hipFree(m->d_send_idx); hipFree(m->d_send_buf); hipFree(m->d_scratch); hipFree(m->d_slices_int); hipFree(m->d_slices_bnd);
   delete m;
   return 0;
@@ -705,7 +705,8 @@ int femo_functional_value(femo_mesh* m, int kind, const double* params, const fe
   FEMO_REQUIRE(m && u && f && u_d && value, "null argument");
   FEMO_REQUIRE(u->n >= m->n_vert && u_d->n >= m->n_vert && f->n >= m->n_cell, "vector size mismatch in functional");
   if (m->n_nbr > 0) FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(u)));
-  return femo_launch_functional_value(m, kind, params, u->d, f->d, u_d->d, value);
+  const uint64_t key[4] = {u->uid, u->gen, u_d->uid, u_d->gen};
+  return femo_launch_functional_value(m, kind, params, u->d, f->d, u_d->d, value, key);
 }
 
 int femo_functional_grad_u(femo_mesh* m, int kind, const double* params, const femo_vec* u,
@@ -713,8 +714,9 @@ int femo_functional_grad_u(femo_mesh* m, int kind, const double* params, const f
   FEMO_REQUIRE(m && u && u_d && g, "null argument");
   FEMO_REQUIRE(u->n >= m->n_vert && u_d->n >= m->n_vert && g->n >= m->n_rows, "vector size mismatch in functional grad_u");
   if (m->n_nbr > 0) FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(u)));
+  const uint64_t key[4] = {u->uid, u->gen, u_d->uid, u_d->gen};      // before the touch: g may alias neither
   femo_vec_touch(g);
-  return femo_launch_functional_grad_u(m, kind, params, u->d, f ? f->d : nullptr, u_d->d, g->d);
+  return femo_launch_functional_grad_u(m, kind, params, u->d, f ? f->d : nullptr, u_d->d, g->d, key);
 }
 
 int femo_functional_grad_f(femo_mesh* m, int kind, const double* params, const femo_vec* u,

@@ -212,6 +212,11 @@ struct femo_mesh {
   int pcg_last_iters = 0, pcg_prev_iters = 0;   // iterations of the last two converged BPX-PCG solves on this mesh (size the first batch)
   struct femo_mat* mass = nullptr;  // P1 mass matrix on the operator pattern (geometry only; built on first use): dJ/du = M (u - u_d)
   double* d_mass_e = nullptr;       // n_vert: the difference the mass product is applied to
+  double* d_mass_g = nullptr;       // n_rows: M (u - u_d) of the vectors identified by mass_key (functional value -> grad_u)
+  uint64_t mass_key[4] = {0, 0, 0, 0};   // (u uid, u gen, u_d uid, u_d gen); uid 0 = unknown: never matches
+  double* d_cellvol = nullptr;      // |T_c| per cell, and the same with 0 for cells owned by another rank (first vertex
+  double* d_cellvol_own = nullptr;  // a ghost): geometry + partition only, built on first use
+  double* d_cell_t = nullptr;       // n_cell scratch: f_c |T_c| / (D+1) for the load-vector walk
   double* d_pipe_dummy = nullptr; // k_poisson_system_pipe: a line that absorbs the stores of padded entries / lanes
   double* d_ubc = nullptr;        // ... and u with the prescribed values imposed
   uint8_t* d_bfacets = nullptr;  // per cell: bit k = facet opposite local vertex k is on the boundary (optional)
@@ -315,10 +320,11 @@ int femo_launch_dRdf(femo_mesh* m, int pde, const double* params, const double* 
                      const double* f, double* vals);
 int femo_launch_dRdf_apply(femo_mesh* m, const double* vals, int transpose, const double* x,
                            double* y, int accumulate);
+// key (optional): uid / generation of u and u_d -- M (u - u_d) formed for the value is kept for the gradient
 int femo_launch_functional_value(femo_mesh* m, int kind, const double* params, const double* u,
-                                 const double* f, const double* ud, double* host_value);
+                                 const double* f, const double* ud, double* host_value, const uint64_t* key = nullptr);
 int femo_launch_functional_grad_u(femo_mesh* m, int kind, const double* params, const double* u,
-                                  const double* f, const double* ud, double* g);
+                                  const double* f, const double* ud, double* g, const uint64_t* key = nullptr);
 int femo_launch_functional_grad_f(femo_mesh* m, int kind, const double* params, const double* u,
                                   const double* f, const double* ud, double* g);
 int femo_launch_spmv(const femo_mat* A, const double* vals, const double* x, double* y,
