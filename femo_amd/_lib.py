@@ -142,6 +142,8 @@ PROTOTYPES = {
     "femo_newton_rhs": (C.c_int, [H, H, H, H, H]),
     "femo_mat_spmv": (C.c_int, [H, C.c_int, H, H]),
     "femo_dRdf_apply": (C.c_int, [H, H, C.c_int, H, H, C.c_int]),
+    "femo_assemble_dRdf_cell": (C.c_int, [H, C.c_int, C.c_void_p, H]),
+    "femo_dRdf_cell_apply": (C.c_int, [H, H, C.c_int, H, H, C.c_int]),
     "femo_mat_export_csr": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "femo_mat_diagonal": (C.c_int, [H, H]),
     "femo_solve_cg": (C.c_int, [H, C.c_int, H, H, C.POINTER(SolverOpts), C.POINTER(SolveInfo)]),

@@ -619,6 +619,27 @@ int femo_assemble_dRdf(femo_mesh* m, int pde, const double* params, const femo_v
   return femo_launch_dRdf(m, pde, params, u ? u->d : nullptr, f ? f->d : nullptr, vals->d);
 }
 
+int femo_assemble_dRdf_cell(femo_mesh* m, int pde, const double* params, femo_vec* cvals) {
+  FEMO_REQUIRE(m && cvals, "null argument");
+  FEMO_REQUIRE(pde == FEMO_PDE_POISSON || pde == FEMO_PDE_NL_POISSON, "dR/df has one value per cell only for the Poisson-type forms (pde kind %d)", pde);
+  FEMO_REQUIRE(cvals->n >= m->n_cell, "dRdf value buffer too small");
+  femo_vec_touch(cvals);
+  return femo_launch_dRdf_cell(m, cvals->d);
+}
+
+int femo_dRdf_cell_apply(femo_mesh* m, const femo_vec* cvals, int transpose, const femo_vec* x, femo_vec* y, int accumulate) {
+  FEMO_REQUIRE(m && cvals && x && y, "null argument");
+  FEMO_REQUIRE(cvals->n >= m->n_cell, "dRdf value buffer too small");
+  if (transpose) {
+    FEMO_REQUIRE(x->n >= m->n_vert && y->n >= m->n_cell, "vector size mismatch in dRdf^T apply");
+    if (m->n_nbr > 0) FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(x)));
+  } else {
+    FEMO_REQUIRE(x->n >= m->n_cell && y->n >= m->n_rows, "vector size mismatch in dRdf apply");
+  }
+  femo_vec_touch(y);
+  return femo_launch_dRdf_cell_apply(m, cvals->d, transpose, x->d, y->d, accumulate);
+}
+
 int femo_newton_rhs(const femo_mat* K, const femo_vec* F, const femo_vec* u, const femo_bc* bc, femo_vec* b) {
   FEMO_REQUIRE(K && F && u && bc && b, "null argument");
   femo_mesh* m = K->mesh;

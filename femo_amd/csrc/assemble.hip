@@ -1761,6 +1761,64 @@ int femo_launch_dRdf_apply(femo_mesh* m, const double* vals, int transpose, cons
   return 0;
 }
 
+// compact dR/df of the Poisson-type forms: one value per cell
+template <int D>
+__global__ __launch_bounds__(FEMO_BLOCK) void k_dRdf_cell_apply_T(int64_t n_cell, const int32_t* __restrict__ conn, const double* __restrict__ cv,
+                                                                  const double* __restrict__ xin, double* __restrict__ y, int accumulate) {
+  for (int64_t c = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; c < n_cell; c += (int64_t)gridDim.x * FEMO_BLOCK) {
+    int32_t v[D + 1];
+    load_conn<D>(conn, c, v);
+    double s = 0.0;
+#pragma unroll
+    for (int a = 0; a <= D; ++a) s += xin[v[a]];
+    s *= cv[c];
+    y[c] = accumulate ? y[c] + s : s;
+  }
+}
+
+__global__ void k_scale_copy(int64_t n, double a, const double* __restrict__ x, double* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = a * x[i];
+}
+
+__global__ void k_mul_into(int64_t n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = a[i] * b[i];
+}
+
+__global__ void k_add_rows(int64_t n, const double* __restrict__ a, double* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] += a[i];
+}
+
+int femo_launch_dRdf_cell(femo_mesh* m, double* cvals) {
+  if (m->n_cell == 0) return 0;
+  FEMO_TRY(ensure_cell_volumes(m));
+  hipLaunchKernelGGL(k_scale_copy, dim3(cell_grid(m->n_cell)), dim3(FEMO_BLOCK), 0, m->ctx->stream, m->n_cell, -1.0 / (m->tdim + 1), m->d_cellvol, cvals);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int femo_launch_dRdf_cell_apply(femo_mesh* m, const double* cvals, int transpose, const double* x, double* y, int accumulate) {
+  hipStream_t st = m->ctx->stream;
+  if (transpose) {
+    if (m->n_cell == 0) return 0;
+    FEMO_LAUNCH_D(m, k_dRdf_cell_apply_T, cell_grid(m->n_cell), 0, st, m->n_cell, m->d_conn, cvals, x, y, accumulate);
+  } else {
+    // y_i (+)= sum over the cells around vertex i of cvals_c x_c: the load-vector walk on t = cvals .* x
+    const int64_t nb = row_blocks(m);
+    if (nb == 0) return 0;
+    FEMO_TRY(ensure_cell_volumes(m));
+    hipLaunchKernelGGL(k_mul_into, dim3(cell_grid(m->n_cell)), dim3(FEMO_BLOCK), 0, st, m->n_cell, cvals, x, m->d_cell_t);
+    if (accumulate) {
+      if (!m->d_scratch) FEMO_HIP_CHECK(hipMalloc(&m->d_scratch, (std::max<int64_t>(m->n_vert, 1) + 2) * sizeof(double)));
+      hipLaunchKernelGGL(k_load_walk, dim3(nb), dim3(FEMO_BLOCK), 0, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_cell_t, m->d_scratch);
+      hipLaunchKernelGGL(k_add_rows, dim3(cell_grid(m->n_rows)), dim3(FEMO_BLOCK), 0, st, m->n_rows, m->d_scratch, y);
+    } else {
+      hipLaunchKernelGGL(k_load_walk, dim3(nb), dim3(FEMO_BLOCK), 0, st, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_cell_t, y);
+    }
+  }
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int femo_launch_cell_expr(femo_mesh* m, int kind, const double* params, const double* in, double* out) {
   FEMO_REQUIRE(kind == 0 || kind == 1, "cell expression kind %d not implemented", kind);
   if (m->n_cell == 0) return 0;

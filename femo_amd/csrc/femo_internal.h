@@ -320,6 +320,8 @@ int femo_launch_dRdf(femo_mesh* m, int pde, const double* params, const double* 
                      const double* f, double* vals);
 int femo_launch_dRdf_apply(femo_mesh* m, const double* vals, int transpose, const double* x,
                            double* y, int accumulate);
+int femo_launch_dRdf_cell(femo_mesh* m, double* cvals);
+int femo_launch_dRdf_cell_apply(femo_mesh* m, const double* cvals, int transpose, const double* x, double* y, int accumulate);
 // key (optional): uid / generation of u and u_d -- M (u - u_d) formed for the value is kept for the gradient
 int femo_launch_functional_value(femo_mesh* m, int kind, const double* params, const double* u,
                                  const double* f, const double* ud, double* host_value, const uint64_t* key = nullptr);

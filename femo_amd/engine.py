@@ -603,6 +603,17 @@ def assemble_dRdf(mesh: DeviceMesh, pde: int, params, u: Optional[Vec], f: Optio
     return vals
 
 
+def assemble_dRdf_cell(mesh: DeviceMesh, pde: int, params, cvals: Vec) -> Vec:
+    """dR/df of a Poisson-type form in its compact shape: one value per cell (include/femo_hip.h)."""
+    check(mesh.lib.femo_assemble_dRdf_cell(mesh.handle, pde, _ptr(_params(params)), cvals.handle))
+    return cvals
+
+
+def dRdf_cell_apply(mesh: DeviceMesh, cvals: Vec, x: Vec, y: Vec, transpose: bool, accumulate: bool = False) -> Vec:
+    check(mesh.lib.femo_dRdf_cell_apply(mesh.handle, cvals.handle, int(transpose), x.handle, y.handle, int(accumulate)))
+    return y
+
+
 def newton_rhs(K: Mat, F: Vec, u: Vec, bc: DirichletSet, b: Vec) -> Vec:
     check(K.lib.femo_newton_rhs(K.handle, F.handle, u.handle, bc.handle, b.handle))
     return b

@@ -252,6 +252,12 @@ int femo_assemble_jacobian(femo_mesh* mesh, int pde, const double* params,
                            const femo_bc* bc, femo_mat* J);
 int femo_assemble_dRdf(femo_mesh* mesh, int pde, const double* params,
                        const femo_vec* u, const femo_vec* f, femo_vec* vals);
+/* The same matrix for the forms whose column c has ONE value on all its rows (Poisson-type residuals with a DG0 source:
+ * dR_i/df_c = -int_c phi_i = -|T_c|/(d+1), state_model.py:136-146): cvals holds n_cell values instead of
+ * (d+1) n_cell, and femo_dRdf_cell_apply is femo_dRdf_apply on that compact form (a quarter of the bytes).          */
+int femo_assemble_dRdf_cell(femo_mesh* mesh, int pde, const double* params, femo_vec* cvals);
+int femo_dRdf_cell_apply(femo_mesh* mesh, const femo_vec* cvals, int transpose,
+                         const femo_vec* x, femo_vec* y, int accumulate);
 /* One pass over the mesh for any subset of: J_nobc (state_model.py:132), A_bc
  * (state_model.py:149) and the Newton right-hand side  rhs = F + K[:,bc](g-u),
  * rhs[bc] = u-g  (dolfinx NonlinearProblem.F/J [ext], utils_dolfinx.py:431).

