@@ -157,6 +157,13 @@ class TorchControl:
         self.dist.all_gather(out, t)
         return np.stack([o.numpy() for o in out])
 
+    def broadcast(self, values, n: int, src: int = 0) -> np.ndarray:
+        """``values`` (length n, rank ``src`` only; None elsewhere) to every rank: checker data, outside any timed region."""
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(values, dtype=np.float64).ravel().copy()) if self.rank == src else torch.empty(int(n), dtype=torch.float64)
+        self.dist.broadcast(t, src=src)
+        return t.numpy()
+
 
 class ThreadControl:
     """The same interface for ranks that are host threads of one process (rank emulation on one GPU, tests)."""
@@ -188,6 +195,14 @@ class ThreadControl:
         g = self.gather(values)
         return g.sum(axis=0) if op == "sum" else g.max(axis=0)
 
+    def broadcast(self, values, n: int, src: int = 0) -> np.ndarray:
+        if self.rank == src:
+            self._s.slots[src] = np.ascontiguousarray(values, dtype=np.float64).ravel()
+        self._s.barrier.wait()
+        out = self._s.slots[src]
+        self._s.barrier.wait()
+        return out
+
 
 def bench_distributed(args, rank: int, world: int, local_rank: int):
     """bench.py for N > 1: the 10 M-DOF mesh is partitioned over the ranks (strong scaling).
@@ -215,7 +230,7 @@ def run_distributed_bench(args, ctx, control, cpu_baseline: bool = True):
     """One rank's part of the N > 1 benchmark: rank-local mesh, the operator stack on it, the timed cycles,
     the JSON line on rank 0.  ``ctx`` already has its communicator (RCCL or emulated)."""
     import bench as B
-    from ..engine import Vec, pinned_array
+    from ..engine import Vec, host_wait as E_host_wait, pinned_array
     from ..fea import utils_hip
 
     rank, world = control.rank, control.world
@@ -277,6 +292,34 @@ def run_distributed_bench(args, ctx, control, cpu_baseline: bool = True):
     halo_out, halo_in = int(L.send_ptr[-1]) * 8, int(L.recv_ptr[-1]) * 8
     stats = control.gather([mesh.n_owned, mesh.n_vert - mesh.n_owned, len(L.nbr), halo_out, halo_in, achieved, spmv_ms,
                             B.stored_bytes(dm.info, mesh.n_owned), rss_setup, setup_s])
+    # ---- self-check of the partitioned run (outside the timed region): one more cycle; rank 0 computes the DST-exact
+    # cycle of the WHOLE mesh (oracle/c_port.py::poisson_cycle_dst, no iterative solve), every rank compares the entries
+    # it owns, the largest error over the ranks goes into the record.  Structured cube only.
+    check = None
+    if not getattr(args, "no_check", False) and not getattr(args, "jitter", 0.0):
+        kc = (W + K) % len(f_host)
+        g_chk = np.array(E_host_wait(B.one_cycle(sim, fea, f_host[kc], u0)), copy=True)
+        u_chk = np.array(sim['u'], copy=True)
+        n_cell_g = mesh.n_cell_global
+        ref_u = ref_g = None
+        if rank == 0:
+            from oracle import c_port
+            from oracle import femo_oracle as fo
+            canon = B._canonical_mesh(args.n, 0.0)
+            fg = B.source_fields(B._Centroid(canon), min(K + W, 4))[kc]
+            bd = fo.boundary_vertices_box(canon.x)
+            ref = c_port.poisson_cycle_dst(args.n, 3, canon.x, canon.conn, fg, fo.u_target(canon.x), bd, B.ALPHA, threads=B.usable_cores())
+            ref_u, ref_g = ref["u"], ref["grad"]
+        ref_u = control.broadcast(ref_u, n_dof)
+        ref_g = control.broadcast(ref_g, n_cell_g)
+        own_v, own_c = L.vert_global[:L.n_owned], L.cell_global[L.cell_owned]
+        eu = float(np.abs(u_chk[:L.n_owned] - ref_u[own_v]).max()) if L.n_owned else 0.0
+        eg = float(np.abs(g_chk[L.cell_owned] - ref_g[own_c]).max()) if own_c.size else 0.0
+        errs = control.allreduce([eu, eg], "max")
+        check = {"u_rel_err": float(errs[0] / np.abs(ref_u).max()), "grad_rel_err": float(errs[1] / np.abs(ref_g).max()),
+                 "tolerance": 1e-10, "norm": "max over all ranks' owned entries, relative to the largest entry",
+                 "against": "DST-exact cycle of the whole mesh on rank 0 (oracle/c_port.py::poisson_cycle_dst)"}
+        del ref_u, ref_g
     if rank != 0:
         return None
     result = {
@@ -311,6 +354,8 @@ def run_distributed_bench(args, ctx, control, cpu_baseline: bool = True):
             "achieved_per_rank": [float(s[5]) for s in stats],
         },
     }
+    if check is not None:
+        result["check"] = check
     if cpu_baseline and not getattr(args, "no_cpu_baseline", False):
         counts = its_per_step if its_per_step else [0]
         n = args.n

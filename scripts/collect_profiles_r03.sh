@@ -41,6 +41,6 @@ for P in "FETCH_SIZE" "WRITE_SIZE L2CacheHit" "GRBM_GUI_ACTIVE VALUBusy MemUnitB
   D=$O/pmc_shell_$(echo $P | cut -d" " -f1)
   (cd /tmp && FEMO_SHELL_PMC_ITS=4 timeout 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $D -- python3 $R/scripts/pmc_shell_kernels.py 362 > $D.log 2>&1)
 done
-python3 scripts/pmc_table.py $O/pmc_shell_kernels_n362.csv $O/pmc_shell_FETCH_SIZE $O/pmc_shell_WRITE_SIZE $O/pmc_shell_GRBM_GUI_ACTIVE > /dev/null
+python3 scripts/pmc_table.py $O/shell_pmc_kernels_n362.csv $O/pmc_shell_FETCH_SIZE $O/pmc_shell_WRITE_SIZE $O/pmc_shell_GRBM_GUI_ACTIVE > /dev/null
 rm -rf $O/pmc_shell_*
 ls -la $O

@@ -294,3 +294,29 @@ def test_rank_local_generation_equals_partitioning_the_whole_mesh(dim, n, nranks
         # exterior facets from the coordinates = the whole mesh's facet mask on the local cells
         assert np.array_equal(box_boundary_facets(a.x, a.conn), g.boundary_facet_mask()[a.cell_global])
     assert process_grid(8, 3) == (2, 2, 2) and process_grid(2, 3) == (1, 1, 2) and process_grid(4, 3) == (1, 2, 2)
+
+
+def _control_worker(rank, world, port, out_dir):
+    """TorchControl over gloo: barrier, all-reduce, gather and the broadcast the distributed self-check of bench.py uses."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from femo_amd.dist import TorchControl
+    c = TorchControl(rank, world)
+    ref = np.arange(1000, dtype=np.float64) ** 0.5
+    got = c.broadcast(ref if rank == 0 else None, ref.size)
+    s = c.allreduce([float(rank + 1), 2.0])
+    mx = c.allreduce([float(rank)], "max")
+    g = c.gather([rank, 10 * rank])
+    c.barrier()
+    np.savez(os.path.join(out_dir, f"ctl{rank}.npz"), got=got, s=s, mx=mx, g=g)
+    c.dist.destroy_process_group()
+
+
+def test_two_process_control_plane(tmp_path):
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_control_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ref = np.arange(1000, dtype=np.float64) ** 0.5
+    for r in range(world):
+        z = np.load(tmp_path / f"ctl{r}.npz")
+        assert np.array_equal(z["got"], ref) and z["s"].tolist() == [3.0, 4.0] and z["mx"].tolist() == [1.0]
+        assert z["g"].tolist() == [[0.0, 0.0], [1.0, 10.0]]

@@ -483,6 +483,8 @@ def test_distributed_bench_record_on_eight_emulated_ranks():
     assert all(3 <= k <= 7 for k in c["neighbours_per_rank"])                  # 3 face + 3 edge + 1 corner blocks
     assert all(b > 0 for b in c["halo_bytes_sent_per_exchange_per_rank"])
     assert sum(c["halo_bytes_sent_per_exchange_per_rank"]) == sum(c["halo_bytes_received_per_exchange_per_rank"])
+    # the partitioned run checks itself against the DST-exact cycle of the whole mesh (rank 0 computes, every rank compares)
+    assert r["check"]["u_rel_err"] < 1e-10 and r["check"]["grad_rel_err"] < 1e-10
     assert c["linear_solves_per_step"] == 4
     its = c["cg_iterations_per_step"]
     assert len(its) == 4 and 10 < its[0] <= 40 and 10 < its[3] <= 40 and its[1] <= 2 and its[2] <= 2
