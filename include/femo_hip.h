@@ -94,7 +94,9 @@ typedef struct femo_solver_opts {
 
 typedef struct femo_solve_info {
   int32_t iterations;
-  int32_t converged;    /* 1 converged, 0 hit max_it, -1 breakdown                      */
+  int32_t converged;    /* 1 converged, 0 hit max_it, -1 breakdown (NaN); femo_shell_solve only: 2 = stalled at the
+                           attainable accuracy (below 1e-9 of the initial residual in the preconditioner's norm, no
+                           progress over 8 polls)                                          */
   double  residual_norm;/* sqrt(r^T D^-1 r) at exit (recurrence residual)               */
   double  pc_residual_norm; /* sqrt(r^T M^-1 r) at exit and for the right-hand side     */
   double  pc_rhs_norm;      /* (FEMO_PC_BPX; 0 otherwise)                                */
