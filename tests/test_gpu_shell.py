@@ -76,12 +76,20 @@ def test_forward_and_adjoint_solves(roof):
     wref = so.solve(Kref, Fref, fixed)
     w = prob.solve()
     assert prob.last_info.converged in (1, 2) and prob.last_info.iterations > 100
-    assert rel(w, wref) <= 1e-8
+    # the attainable bound: eps * cond(K_ff) limits what ANY fp64 solver delivers in the solution -- the oracle's SuperLU
+    # included -- so two correct solutions agree to a small multiple of it (cond = 2.3e6 on this 8 x 8 roof: bound 5e-10)
+    free = np.setdiff1d(np.arange(V0.n_dof), fixed)
+    ev = np.linalg.eigvalsh(Kref[free][:, free].toarray())
+    bound = np.finfo(float).eps * ev[-1] / ev[0]
+    assert 1e-10 < bound < 1e-8
+    print(f"shell solve: error {rel(w, wref):.2e}, eps*cond {bound:.2e}")
+    assert rel(w, wref) <= bound                                     # measured: 1.5e-11
     assert np.all(w[fixed] == 0.0)
     c = np.random.default_rng(2).standard_normal(V0.n_dof)
     c[fixed] = 0.0
     lam = prob.solve_adjoint(c)
-    assert rel(lam, so.solve(Kref, c, fixed)) <= 1e-8
+    print(f"shell adjoint solve: error {rel(lam, so.solve(Kref, c, fixed)):.2e}")
+    assert rel(lam, so.solve(Kref, c, fixed)) <= bound
     # adjoint identity <K^-1 F, c> = <F, K^-T c> on the free dofs
     Ff = Fref.copy(); Ff[fixed] = 0.0
     assert abs(w @ c - Ff @ lam) <= 1e-9 * abs(w @ c)
@@ -256,7 +264,7 @@ def test_shell_through_the_operator_stack(ctx):
         return so.solve(K, so.load_vector(V0, ff.reshape(-1, 3)), fixed)
 
     wref = solve_ref(h)
-    assert rel(sim['disp_solid'], wref) <= 1e-8
+    assert rel(sim['disp_solid'], wref) <= 1e-9                      # eps * cond(K_ff) of this roof, see test_forward_and_adjoint_solves
     assert sim['compliance'][0] == pytest.approx(so.compliance(V0, wref), rel=1e-8)
     assert sim['elastic_energy'][0] == pytest.approx(sum(so.energy_parts(V0, wref, h, E_ROOF, NU_ROOF).values()), rel=1e-8)
     _, _, _, area, _ = V0.frames()
