@@ -1172,19 +1172,19 @@ __global__ __launch_bounds__(64) void k_poisson_system_pipe(
   bool have_prev = false;
   int64_t prev_row = 0, prev_mb = 0;
   int prev_wm = 0;
-  double prev_dsum = 0.0;
   double cu_prev[NB];
   RowData Rp = R0;
 #pragma unroll
   for (int k = 0; k < NB; ++k) cu_prev[k] = 0.0;
 
-  auto rows_out = [&](int64_t row, int64_t mb, int wm, double dsum, const RowData& R, const double (&cu)[NB]) {
+  // K_aa = -sum_b K_ab (rows of the P1 stiffness matrix sum to zero): formed here from the strip entries the row
+  // writes anyway (round 3; rounds 1-2 subtracted every pair term from a running diagonal inside the walk: 3 of the
+  // 57 fp64 instructions of a visit)
+  auto rows_out = [&](int64_t row, int64_t mb, int wm, const RowData& R, const double (&cu)[NB]) {
     const bool valid = row < n_rows;
     const bool row_bc = valid && (R.rmask >> 63) != 0;
-    if constexpr (HAS_V0) diag0[row] = valid ? dsum : 1.0;       // the diagonal arrays are padded to whole slices
-    if constexpr (HAS_V1) diag1[row] = (valid && !row_bc) ? dsum : 1.0;
-    double racc = 0.0;
-    if constexpr (WANT_RHS) racc = dsum * R.ur - R.ld;
+    double racc = 0.0, osum = 0.0;
+    if constexpr (WANT_RHS) racc = -R.ld;
 #pragma unroll
     for (int k = 0; k < NB; k += 2) {
       const bool in = k < wm;                                // wave-uniform (wm is even)
@@ -1192,6 +1192,7 @@ __global__ __launch_bounds__(64) void k_poisson_system_pipe(
       double2 o;
       o.x = (in && k < R.len) ? strip[k * 64 + lane] : 0.0;
       o.y = (in && (k + 1) < R.len) ? strip[(k + 1) * 64 + lane] : 0.0;
+      osum += o.x; osum += o.y;
       if constexpr (HAS_V0) *reinterpret_cast<double2*>(in ? vals0 + idx : my_dummy) = o;
       if constexpr (WANT_RHS) racc += o.x * cu[k] + o.y * cu[k + 1];
       const bool bx = ((R.rmask >> k) & 1) != 0, by = ((R.rmask >> (k + 1)) & 1) != 0;
@@ -1199,7 +1200,11 @@ __global__ __launch_bounds__(64) void k_poisson_system_pipe(
       if (row_bc || by) o.y = 0.0;
       if constexpr (HAS_V1) *reinterpret_cast<double2*>(in ? vals1 + idx : my_dummy) = o;
     }
+    const double dsum = -osum;
+    if constexpr (HAS_V0) diag0[row] = valid ? dsum : 1.0;       // the diagonal arrays are padded to whole slices
+    if constexpr (HAS_V1) diag1[row] = (valid && !row_bc) ? dsum : 1.0;
     if constexpr (WANT_RHS) {
+      racc += dsum * R.ur;
       double* const dst = valid ? rhs + row : my_dummy;
       *dst = row_bc ? (R.ur - R.gr) : racc;
     }
@@ -1220,7 +1225,7 @@ __global__ __launch_bounds__(64) void k_poisson_system_pipe(
 #pragma unroll
     for (int i = 0; i < CH; ++i) cur[i] = fetch(M0, i);
     // (3) rows of the previous slice out of the strip, then clear it
-    if (have_prev) rows_out(prev_row, prev_mb, prev_wm, prev_dsum, Rp, cu_prev);
+    if (have_prev) rows_out(prev_row, prev_mb, prev_wm, Rp, cu_prev);
 #pragma unroll
     for (int k = 0; k < NB; ++k) strip[k * 64 + lane] = 0.0;
     // (4) prefetch: table of s+3, columns of s+2, neighbourhood and row data of s+1
@@ -1233,7 +1238,6 @@ __global__ __launch_bounds__(64) void k_poisson_system_pipe(
     // of the next visits are scheduled under the arithmetic of the current one -- with one wave per SIMD nothing
     // else hides LDS latency.
     const int nvis = M0.nvis;
-    double dsum = 0.0;
     struct Nbr { double o[D][D]; int pos[D]; double wt; };
     auto gather = [&](const femo_i4 q) -> Nbr {                  // the visit's three (two) other vertices from LDS
       Nbr V;
@@ -1253,7 +1257,6 @@ __global__ __launch_bounds__(64) void k_poisson_system_pipe(
       poisson_pairs<D>(R.xo, V.o, V.wt, kk);
 #pragma unroll
       for (int j = 0; j < D; ++j) {
-        dsum -= kk[j];
         if constexpr (LDS_ATOMIC) (void)__hip_atomic_fetch_add(&strip[V.pos[j] * 64 + lane], kk[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         else strip[V.pos[j] * 64 + lane] = __dadd_rn(strip[V.pos[j] * 64 + lane], kk[j]);
       }
@@ -1281,13 +1284,13 @@ __global__ __launch_bounds__(64) void k_poisson_system_pipe(
     }
     // rotate
     have_prev = true;
-    prev_row = (s << 6) + lane; prev_mb = M0.mb; prev_wm = M0.wm; prev_dsum = dsum;
+    prev_row = (s << 6) + lane; prev_mb = M0.mb; prev_wm = M0.wm;
     Rp = R;
 #pragma unroll
     for (int k = 0; k < NB; ++k) { cu_prev[k] = cu[k]; c0[k] = c1[k]; c1[k] = c2[k]; }
     M0 = M1; M1 = M2; M2 = M3;
   }
-  rows_out(prev_row, prev_mb, prev_wm, prev_dsum, Rp, cu_prev);
+  rows_out(prev_row, prev_mb, prev_wm, Rp, cu_prev);
 }
 
 // -------------------------------------------------------------------- dRdf --
