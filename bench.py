@@ -222,6 +222,19 @@ def cpu_baseline(args, gpu_counts, n_dof_gpu, n_cell_gpu, nnz_gpu):
             "sample": head + f"; scaled to n={args.n} by cell count (assembly, {t_other:.2f} s) and nnz x {it_scaled:.0f} iterations"}
 
 
+def dst_reference_cycle(n: int, k: int, count: int):
+    """(u, dJ/df) of the structured n-cube for source field ``k`` of ``source_fields(..., count)``, both solves by the sine
+    transform (oracle/c_port.py::poisson_cycle_dst): the checker of the N > 1 run, computed on rank 0 outside the timed region
+    (`femo_amd/dist` calls back into the harness for it: the package itself never touches ``oracle/``)."""
+    from oracle import c_port
+    from oracle import femo_oracle as fo
+    canon = _canonical_mesh(n, 0.0)
+    fg = source_fields(_Centroid(canon), count)[k]
+    ref = c_port.poisson_cycle_dst(n, 3, canon.x, canon.conn, fg, fo.u_target(canon.x), fo.boundary_vertices_box(canon.x), ALPHA,
+                                   threads=usable_cores())
+    return ref["u"], ref["grad"]
+
+
 def self_check(args, mesh, f, u, J, grad):
     """The checker of the timed configuration (outside the timed region; part of the CPU leg like ``cpu_baseline``, the
     only other place that touches ``oracle/``): state, functional and total gradient of one more cycle of the SAME

@@ -19,7 +19,7 @@ c_i64p = C.POINTER(C.c_int64)
 c_f64p = C.POINTER(C.c_double)
 H = C.c_void_p  # opaque handle
 
-ABI_VERSION = 5            # include/femo_hip.h FEMO_ABI_VERSION
+ABI_VERSION = 6            # include/femo_hip.h FEMO_ABI_VERSION
 MESH_INFO_COUNT = 12
 MESH_INFO_KEYS = ("tdim", "n_vert", "n_rows", "n_cell", "nnz", "sell_entries", "max_rowlen",
                   "max_valence", "n_slices", "visit_entries", "regular_slices", "short_slices")
@@ -126,6 +126,9 @@ PROTOTYPES = {
     "femo_shell_inertia_apply": (C.c_int, [H, C.c_double, H, H, C.c_int, H]),
     "femo_shell_inertia_dh": (C.c_int, [H, C.c_double, H, H, H, C.c_int, H]),
     "femo_shell_solve": (C.c_int, [H, H, C.c_void_p, H, H, H, C.POINTER(SolverOpts), C.POINTER(SolveInfo)]),
+    "femo_shell_set_partition": (C.c_int, [H, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "femo_shell_halo": (C.c_int, [H, H]),
+    "femo_shell_mask_unowned": (C.c_int, [H, H]),
     "femo_mesh_set_global": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int64]),
     "femo_mesh_pc_info": (C.c_int, [H, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "femo_mesh_pattern_csr": (C.c_int, [H, C.c_void_p, C.c_void_p]),

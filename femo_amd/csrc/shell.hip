@@ -85,6 +85,16 @@ struct femo_shell {
   int64_t pen_n = 0;
   int32_t *d_pen_nodes = nullptr, *d_pen_pos = nullptr;
   double* d_pen_coef = nullptr;
+  // partition (femo_shell_set_partition): this handle holds the cells that touch a point the rank
+  // owns.  d_owned flags the owned points (dofs 3 p .. 3 p + 2); the rows of the others are zeroed after assembly, so
+  // that K, right-hand sides and residuals are the rank's share and sums over the ranks are the global objects.  The
+  // halo plan refreshes the entries of the points owned elsewhere.
+  uint8_t* d_owned = nullptr;
+  int n_nbr = 0;
+  std::vector<int32_t> nbr;
+  std::vector<int64_t> send_ptr, recv_ptr;
+  int32_t *d_send_idx = nullptr, *d_recv_idx = nullptr;
+  double *d_send_buf = nullptr, *d_recv_buf = nullptr;
 };
 
 // plain view of the device arrays for kernels
@@ -2016,6 +2026,37 @@ femo_shell_view view(const femo_shell* s) {
   return v;
 }
 
+// ---- partitioned shells (several ranks): rows of points owned elsewhere, halo, all-reduced scalars ----------------------
+// the scalar rows of block row p are the 9 (brow[p+1] - brow[p]) values from 9 brow[p] on
+__global__ void k_zero_unowned_rows(int64_t n_pts, const uint8_t* __restrict__ owned, const int64_t* __restrict__ brow, double* __restrict__ vals) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); p < n_pts; p += (int64_t)gridDim.x * (blockDim.x >> 6)) {
+    if (owned[p]) continue;
+    for (int64_t k = 9 * brow[p] + lane; k < 9 * brow[p + 1]; k += 64) vals[k] = 0.0;
+  }
+}
+
+__global__ void k_mask_unowned(int64_t n_pts, const uint8_t* __restrict__ owned, double* __restrict__ v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * n_pts; i += (int64_t)gridDim.x * blockDim.x)
+    if (!owned[i / 3]) v[i] = 0.0;
+}
+
+__global__ void k_halo_pack(int64_t n, const int32_t* __restrict__ idx, const double* __restrict__ v, double* __restrict__ buf) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) buf[i] = v[idx[i]];
+}
+
+__global__ void k_halo_unpack(int64_t n, const int32_t* __restrict__ idx, const double* __restrict__ buf, double* __restrict__ v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v[idx[i]] = buf[i];
+}
+
+// out[0] = sum of the partials (one workgroup): what the all-reduce between a producer and its consumer works on
+__global__ __launch_bounds__(SH_BLOCK) void k_fold1(int nb, const double* __restrict__ partials, double* __restrict__ out, const int32_t* __restrict__ done) {
+  if (done != nullptr && *done) return;
+  __shared__ double lds[SH_BLOCK / 64];
+  const double g = fold(partials, nb, lds);
+  if (threadIdx.x == 0) out[0] = g;
+}
+
 template <class T>
 int to_device(T** d, const T* h, int64_t n, hipStream_t st) {
   FEMO_HIP_CHECK(hipMalloc(d, std::max<int64_t>(n, 1) * sizeof(T)));
@@ -2029,7 +2070,42 @@ int reduce_partials(femo_ctx* ctx, const double* d_part, int nb, double* host) {
   FEMO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   double s = 0.0;
   for (double v : h) s += v;
+  if (ctx->nranks > 1) {
+    // a shell on several ranks is partitioned: the caller integrates over the cells it owns (cell weights) and the
+    // value is the sum over the ranks
+    FEMO_HIP_CHECK(hipMemcpyAsync(ctx->d_scal, &s, sizeof s, hipMemcpyHostToDevice, ctx->stream));
+    FEMO_TRY(femo_coll_allreduce(ctx, ctx->d_scal, 1, ctx->stream));
+    FEMO_HIP_CHECK(hipMemcpyAsync(&s, ctx->d_scal, sizeof s, hipMemcpyDeviceToHost, ctx->stream));
+    FEMO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  }
   *host = s;
+  return 0;
+}
+
+// entries of the points owned by other ranks <- their owners' values (v: a state-sized device vector)
+int shell_halo(femo_shell* s, double* v, hipStream_t st) {
+  if (s->d_owned == nullptr || s->ctx->nranks == 1 || s->n_nbr == 0) return 0;
+  const int64_t ns = s->send_ptr[(size_t)s->n_nbr], nr = s->recv_ptr[(size_t)s->n_nbr];
+  if (ns > 0) hipLaunchKernelGGL(k_halo_pack, dim3(sgrid(ns, 256)), dim3(256), 0, st, ns, s->d_send_idx, v, s->d_send_buf);
+  FEMO_HIP_CHECK(hipGetLastError());
+  FEMO_TRY(femo_coll_neighbors(s->ctx, s->n_nbr, s->nbr.data(), s->send_ptr.data(), s->d_send_buf, s->recv_ptr.data(), s->d_recv_buf, st));
+  if (nr > 0) hipLaunchKernelGGL(k_halo_unpack, dim3(sgrid(nr, 256)), dim3(256), 0, st, nr, s->d_recv_idx, s->d_recv_buf, v);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// sum over the ranks of a device array (no-op on one rank)
+int shell_allreduce(femo_shell* s, double* d, int64_t n, hipStream_t st) {
+  if (s->d_owned == nullptr || s->ctx->nranks == 1) return 0;
+  return femo_coll_allreduce(s->ctx, d, n, st);
+}
+
+// the rank's share of an assembled matrix: rows of the points owned elsewhere are zero
+int shell_zero_unowned_rows(femo_shell* s, double* vals, hipStream_t st) {
+  if (s->d_owned == nullptr) return 0;
+  FEMO_REQUIRE(s->d_brow != nullptr, "a partitioned shell needs the node-block view of the pattern");
+  hipLaunchKernelGGL(k_zero_unowned_rows, dim3(sgrid(s->n_bnode, 4)), dim3(256), 0, st, s->n_bnode, s->d_owned, s->d_brow, vals);
+  FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
@@ -2117,6 +2193,7 @@ int femo_shell_destroy(femo_shell* s) {
   hipFree(s->d_cs_xyz); hipFree(s->d_cs_ptr); hipFree(s->d_cs_pts); hipFree(s->d_cs_nbr); hipFree(s->d_cs_A); hipFree(s->d_cs_tmp); hipFree(s->d_cs_dinv); hipFree(s->d_cs_info); hipFree(s->d_cs_pcell);
   hipFree(s->d_cd_rowptr); hipFree(s->d_cd_cols); hipFree(s->d_cd_vals);
   hipFree(s->d_pen_nodes); hipFree(s->d_pen_pos); hipFree(s->d_pen_coef);
+  hipFree(s->d_owned); hipFree(s->d_send_idx); hipFree(s->d_recv_idx); hipFree(s->d_send_buf); hipFree(s->d_recv_buf);
   hipFree(s->d_r); hipFree(s->d_p); hipFree(s->d_q); hipFree(s->d_dinv); hipFree(s->d_scal); hipFree(s->d_part); hipFree(s->d_flag);
   hipFree(s->d_ell_idx); hipFree(s->d_ell_w);
   hipFree(s->d_par_rowptr); hipFree(s->d_par_cols); hipFree(s->d_par_vals); hipFree(s->d_chi_rowptr); hipFree(s->d_chi_cols); hipFree(s->d_chi_vals);
@@ -2219,6 +2296,8 @@ static int shell_pc_coarse_setup(femo_shell* s, const femo_vec* vals, const uint
   hipLaunchKernelGGL(k_pc_coarse_galerkin, dim3((unsigned)s->cs_items), dim3(256), CG_LDS, st, s->cs_level, s->pc_width, s->level_off[s->cs_level], N,
                      s->n_unode, s->d_cs_ptr, s->d_cs_pts, s->d_cs_nbr, s->d_cs_xyz, s->d_cs_pcell, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_ell_idx,
                      s->d_ell_w, s->d_cs_A, s->d_cs_info);
+  FEMO_HIP_CHECK(hipGetLastError());
+  FEMO_TRY(shell_allreduce(s, s->d_cs_A, N * N, st));      // partitioned: every rank formed P^T (its rows of K) P
   hipLaunchKernelGGL(k_pc_coarse_fix_diag, dim3(sgrid(N, 256)), dim3(256), 0, st, N, s->d_cs_A);
   FEMO_HIP_CHECK(hipGetLastError());
   auto t1 = now();
@@ -2239,6 +2318,17 @@ static int shell_pc_coarse_setup(femo_shell* s, const femo_vec* vals, const uint
   FEMO_HIP_CHECK(hipMemcpyAsync(info, s->d_cs_info, sizeof info, hipMemcpyDeviceToHost, st));
   FEMO_HIP_CHECK(hipStreamSynchronize(st));
   s->cs_ready = info[1] == 0 && info[2] == 0;
+  if (s->d_owned != nullptr && s->ctx->nranks > 1) {
+    // the ranks must take the same branch (the collectives of the iteration depend on it): the coarse solve is used only
+    // if no rank saw a failure (the factorisation is replicated, `far` is a property of the rank's cells)
+    const double bad = s->cs_ready ? 0.0 : 1.0;
+    double all = 0.0;
+    FEMO_HIP_CHECK(hipMemcpyAsync(s->d_cs_tmp, &bad, sizeof bad, hipMemcpyHostToDevice, st));
+    FEMO_TRY(shell_allreduce(s, s->d_cs_tmp, 1, st));
+    FEMO_HIP_CHECK(hipMemcpyAsync(&all, s->d_cs_tmp, sizeof all, hipMemcpyDeviceToHost, st));
+    FEMO_HIP_CHECK(hipStreamSynchronize(st));
+    s->cs_ready = all == 0.0;
+  }
   if (dbg) {
     auto t3 = now();
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -2267,6 +2357,12 @@ static int shell_pc_apply(femo_shell* s, const uint8_t* d_fixed, double* Prz, un
   // 32 lanes per row (rows hold ~100 points; 8 / 16 / 32 / 64 lanes: 0.362 / 0.355 / 0.351 / 0.351 ms per iteration)
   hipLaunchKernelGGL(k_pc_restrict<32>, dim3(std::min<unsigned>(sgrid(2 * (m1 - m0), SH_BLOCK / 32), 1 << 16)), dim3(SH_BLOCK), 0, st, m0, m1,
                      s->d_ptp_rowptr, s->d_ptp_cols, s->d_ptp_vals, s->d_r, s->d_t, done);
+  if (s->d_owned != nullptr && s->ctx->nranks > 1) {
+    // partitioned: r is zero on the points owned elsewhere, so the sum over the ranks is P^T r; the lattice levels below
+    // are replicated (same arithmetic on every rank)
+    FEMO_HIP_CHECK(hipGetLastError());
+    FEMO_TRY(shell_allreduce(s, s->d_t + 6 * m0, 6 * (m1 - m0), st));
+  }
   if (s->cs_ready) {
     // levels above the coarse-solve level as before; on it the dense inverse replaces the diagonal levels 0 .. cs
     const int cs = s->cs_level;
@@ -2407,6 +2503,7 @@ int femo_shell_assemble(femo_shell* s, double E, double nu, const femo_vec* h, f
   FEMO_HIP_CHECK(hipMemsetAsync(vals->d, 0, s->nnz * sizeof(double), st));
   hipLaunchKernelGGL(k_shell_assemble, dim3(sgrid(s->n_cell * 27)), dim3(SH_BLOCK), 0, st, view(s), E, nu, h->d, s->d_epos, vals->d);
   FEMO_HIP_CHECK(hipGetLastError());
+  FEMO_TRY(shell_zero_unowned_rows(s, vals->d, st));       // partitioned: the rank's share of K (its points' rows are complete)
   return 0;
 }
 
@@ -2591,6 +2688,63 @@ int femo_shell_penalty_add(femo_shell* s, femo_vec* vals) {
   femo_vec_touch(vals);
   hipLaunchKernelGGL(k_shell_penalty_add, dim3(sgrid(s->pen_n * 39, 256)), dim3(256), 0, s->ctx->stream, s->pen_n, s->d_pen_pos, s->d_pen_coef, vals->d);
   FEMO_HIP_CHECK(hipGetLastError());
+  FEMO_TRY(shell_zero_unowned_rows(s, vals->d, s->ctx->stream));
+  return 0;
+}
+
+// Partition of a shell over the ranks of the context.  The handle was created on the rank's cells: all
+// cells that touch a point it owns (points: P2 nodes and rotation vertices, dofs 3 p .. 3 p + 2).  owned_points flags
+// them (n_dof / 3 bytes); segment k of send_dofs lists the dofs whose values rank nbr[k] needs, segment k of recv_dofs the
+// dofs that receive rank nbr[k]'s values in the same order.
+int femo_shell_set_partition(femo_shell* s, const uint8_t* owned_points, int n_nbr, const int32_t* nbr, const int64_t* send_ptr,
+                             const int32_t* send_dofs, const int64_t* recv_ptr, const int32_t* recv_dofs) {
+  FEMO_REQUIRE(s && owned_points, "null argument");
+  FEMO_REQUIRE(n_nbr >= 0 && (n_nbr == 0 || (nbr && send_ptr && send_dofs && recv_ptr && recv_dofs)), "bad halo plan");
+  FEMO_REQUIRE(s->d_owned == nullptr, "the shell already has a partition");
+  FEMO_REQUIRE(s->d_brow != nullptr && s->n_dof % 3 == 0, "a partitioned shell needs the node-block view of the pattern");
+  hipStream_t st = s->ctx->stream;
+  FEMO_HIP_CHECK(hipSetDevice(s->ctx->device));
+  const int64_t n_pts = s->n_dof / 3;
+  for (int k = 0; k < n_nbr; ++k) {
+    FEMO_REQUIRE(nbr[k] >= 0 && nbr[k] < s->ctx->nranks && nbr[k] != s->ctx->rank, "bad neighbour rank %d", nbr[k]);
+    FEMO_REQUIRE(send_ptr[k + 1] >= send_ptr[k] && recv_ptr[k + 1] >= recv_ptr[k], "halo segments not ordered");
+  }
+  const int64_t ns = n_nbr ? send_ptr[n_nbr] : 0, nr = n_nbr ? recv_ptr[n_nbr] : 0;
+  for (int64_t i = 0; i < ns; ++i) FEMO_REQUIRE(send_dofs[i] >= 0 && send_dofs[i] < s->n_dof && owned_points[send_dofs[i] / 3], "a rank sends a dof it does not own");
+  for (int64_t i = 0; i < nr; ++i) FEMO_REQUIRE(recv_dofs[i] >= 0 && recv_dofs[i] < s->n_dof && !owned_points[recv_dofs[i] / 3], "a rank receives a dof it owns");
+  FEMO_TRY(to_device(&s->d_owned, owned_points, n_pts, st));
+  s->n_nbr = n_nbr;
+  if (n_nbr > 0) {
+    s->nbr.assign(nbr, nbr + n_nbr);
+    s->send_ptr.assign(send_ptr, send_ptr + n_nbr + 1);
+    s->recv_ptr.assign(recv_ptr, recv_ptr + n_nbr + 1);
+    FEMO_TRY(to_device(&s->d_send_idx, send_dofs, ns, st));
+    FEMO_TRY(to_device(&s->d_recv_idx, recv_dofs, nr, st));
+    FEMO_HIP_CHECK(hipMalloc(&s->d_send_buf, std::max<int64_t>(ns, 1) * sizeof(double)));
+    FEMO_HIP_CHECK(hipMalloc(&s->d_recv_buf, std::max<int64_t>(nr, 1) * sizeof(double)));
+  }
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  s->pc_vals_uid = 0; s->pc_vals_gen = 0; s->bs_vals_uid = 0; s->bs_vals_gen = 0;
+  return 0;
+}
+
+// x on the points owned by other ranks <- the owners' values (collective over the ranks of the partition)
+int femo_shell_halo(femo_shell* s, femo_vec* x) {
+  FEMO_REQUIRE(s && x, "null argument");
+  FEMO_REQUIRE(x->n >= s->n_dof, "vector size mismatch in shell_halo");
+  FEMO_REQUIRE(s->d_owned != nullptr, "femo_shell_halo needs femo_shell_set_partition");
+  femo_vec_touch(x);
+  return shell_halo(s, x->d, s->ctx->stream);
+}
+
+// x <- 0 on the points owned by other ranks: the rank's share of a vector assembled over its cells
+int femo_shell_mask_unowned(femo_shell* s, femo_vec* x) {
+  FEMO_REQUIRE(s && x, "null argument");
+  FEMO_REQUIRE(x->n >= s->n_dof, "vector size mismatch in shell_mask_unowned");
+  if (s->d_owned == nullptr) return 0;
+  femo_vec_touch(x);
+  hipLaunchKernelGGL(k_mask_unowned, dim3(sgrid(s->n_dof, 256)), dim3(256), 0, s->ctx->stream, s->n_dof / 3, s->d_owned, x->d);
+  FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
@@ -2699,6 +2853,16 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
     rhs = s->d_q;
   }
   hipLaunchKernelGGL(k_rhs_free, dim3(gv), dim3(256), 0, st, n, rhs, d_fixed, s->d_r);
+  // Partitioned shell (femo_shell_set_partition): the rows of K and the entries of r on points owned elsewhere are zero, so
+  // every dot product below is the rank's share and P^T r, P^T K P sum over the ranks to the global objects; the producers'
+  // partials are folded into one number, all-reduced, and handed to the unfused consumers as a single "partial".  The
+  // direction p is refreshed on the halo before every product (x follows: it is updated with the refreshed p).
+  const bool multi = s->d_owned != nullptr;
+  if (multi) {
+    FEMO_REQUIRE(n % 3 == 0, "a partitioned shell numbers its dofs 3 point + component");
+    hipLaunchKernelGGL(k_mask_unowned, dim3(gv), dim3(256), 0, st, n / 3, s->d_owned, s->d_r);
+  }
+  double *one_pq = s->d_scal + 6, *one_rz = s->d_scal + 7;   // the all-reduced p.q and r.z
   const bool lattice = opts->pc == 1;
   // 1 / diag: with the lattice preconditioner and its point blocks it comes out of k_pt_block_inv (below, and only when
   // the stiffness or the mask changed)
@@ -2714,7 +2878,7 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
   const unsigned gx = std::min<unsigned>(sgrid(n / 3), 1024u);                        // k_scg_xr_pt: a thread per point, few partials
   double* Pte = s->d_part + 2 * SH_MAXPART;
   // direction update fused into the prolongation (dofs numbered 3 point + component: every shell pattern of fea/shell.py)
-  const bool fused = opts->pc == 1 && n % 3 == 0 && !femo_env_flag("FEMO_SHELL_UNFUSED");
+  const bool fused = opts->pc == 1 && n % 3 == 0 && !multi && !femo_env_flag("FEMO_SHELL_UNFUSED");
   if (lattice) {
     // Galerkin diagonals of the current stiffness and Dirichlet set (kept while both stay the same)
     uint64_t mh = 1469598103934665603ull;
@@ -2732,12 +2896,16 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
         FEMO_HIP_CHECK(hipMemsetAsync(s->d_cblk + 36 * nd0, 0, (nd1 - nd0) * 36 * sizeof(double), st));
         hipLaunchKernelGGL(k_pc_galerkin_blocks, dim3(sgrid(n / 3), 3 * ((s->pc_width - first_slot) / 8)), dim3(SH_BLOCK), 0, st, n / 3, s->pc_width,
                            s->n_unode, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_lvl_node, s->d_lvl_w, s->d_cblk, first_slot);
+        FEMO_HIP_CHECK(hipGetLastError());
+        FEMO_TRY(shell_allreduce(s, s->d_cblk + 36 * nd0, (nd1 - nd0) * 36, st));
         hipLaunchKernelGGL(k_pc_invert_blocks, dim3(sgrid(nd1 - nd0, 256)), dim3(256), 0, st, nd0, nd1, s->d_cblk);
         s->blk_ready = true;
       } else {
         FEMO_HIP_CHECK(hipMemsetAsync(s->d_coarse, 0, s->n_lat * sizeof(double), st));
         hipLaunchKernelGGL(k_pc_galerkin_diag, dim3(sgrid(n * (s->pc_width - first_slot))), dim3(SH_BLOCK), 0, st, n, s->pc_width, s->d_rowptr, s->d_cols,
                            vals->d, d_fixed, s->d_ell_idx, s->d_ell_w, s->d_coarse, first_slot);
+        FEMO_HIP_CHECK(hipGetLastError());
+        FEMO_TRY(shell_allreduce(s, s->d_coarse, s->n_lat, st));
         hipLaunchKernelGGL(k_pc_invert, dim3(sgrid(s->n_lat)), dim3(256), 0, st, s->n_lat, s->d_coarse);
       }
       s->dinv3_ready = false;
@@ -2753,7 +2921,14 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
     hipLaunchKernelGGL(k_scg_init, dim3(gv), dim3(SH_BLOCK), 0, st, n, s->d_r, s->d_dinv, s->d_p, Prz);
   }
   const int nb_rz0 = lattice ? (int)gz : (int)gv;
-  hipLaunchKernelGGL(k_scg_gamma0, dim3(1), dim3(SH_BLOCK), 0, st, nb_rz0, Prz, opts->rtol * opts->rtol, opts->atol * opts->atol, s->d_scal, s->d_flag);
+  if (multi) {
+    hipLaunchKernelGGL(k_fold1, dim3(1), dim3(SH_BLOCK), 0, st, nb_rz0, Prz, one_rz, (const int32_t*)nullptr);
+    FEMO_HIP_CHECK(hipGetLastError());
+    FEMO_TRY(shell_allreduce(s, one_rz, 1, st));
+    hipLaunchKernelGGL(k_scg_gamma0, dim3(1), dim3(SH_BLOCK), 0, st, 1, one_rz, opts->rtol * opts->rtol, opts->atol * opts->atol, s->d_scal, s->d_flag);
+  } else {
+    hipLaunchKernelGGL(k_scg_gamma0, dim3(1), dim3(SH_BLOCK), 0, st, nb_rz0, Prz, opts->rtol * opts->rtol, opts->atol * opts->atol, s->d_scal, s->d_flag);
+  }
   FEMO_HIP_CHECK(hipGetLastError());
   const int max_it = opts->max_it > 0 ? opts->max_it : 100000;
   const int batch = opts->check_every > 0 ? opts->check_every : 64;
@@ -2775,6 +2950,7 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
       const bool sample = it >= 4 && it < 4 + n_sample;
       if (sample) FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev], st));
       // p is zero on the imposed dofs (r and the initial direction are): no column mask needed
+      if (multi) FEMO_TRY(shell_halo(s, s->d_p, st));
       if (bsell)
         hipLaunchKernelGGL(k_bsell_spmv, dim3(gs), dim3(SH_BLOCK), 0, st, s->n_bnode, s->n_bslice, s->d_bs_off, s->d_bs_cols, s->d_bs_vals, d_fixed, s->d_p, s->d_q, Ppq, s->d_flag, s->d_scal, gam);
       else if (s->d_brow != nullptr)
@@ -2782,7 +2958,25 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
       else
         hipLaunchKernelGGL(k_csr_spmv, dim3(gs), dim3(SH_BLOCK), 0, st, n, s->d_rowptr, s->d_cols, vals->d, d_fixed, 0, s->d_p, s->d_q, Ppq, s->d_flag, s->d_scal, gam);
       if (sample) { FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev + 1], st)); ++n_ev; }
-      if (lattice && fused) {
+      if (multi) {
+        hipLaunchKernelGGL(k_fold1, dim3(1), dim3(SH_BLOCK), 0, st, (int)gs, Ppq, one_pq, s->d_flag);
+        FEMO_HIP_CHECK(hipGetLastError());
+        FEMO_TRY(shell_allreduce(s, one_pq, 1, st));
+        if (lattice) {
+          hipLaunchKernelGGL(k_scg_xr_plain, dim3(gv), dim3(SH_BLOCK), 0, st, n, 1, one_pq, s->d_scal, s->d_p, s->d_q, x->d, s->d_r, s->d_flag);
+          FEMO_TRY(shell_pc_apply(s, d_fixed, Prz, gz, s->d_flag));
+          hipLaunchKernelGGL(k_fold1, dim3(1), dim3(SH_BLOCK), 0, st, (int)gz, Prz, one_rz, s->d_flag);
+          FEMO_HIP_CHECK(hipGetLastError());
+          FEMO_TRY(shell_allreduce(s, one_rz, 1, st));
+          hipLaunchKernelGGL(k_scg_p_z, dim3(gv), dim3(SH_BLOCK), 0, st, n, it, 1, one_rz, s->d_scal, s->d_z, s->d_p, s->d_flag, gam);
+        } else {
+          hipLaunchKernelGGL(k_scg_xr, dim3(gv), dim3(SH_BLOCK), 0, st, n, 1, one_pq, s->d_scal, s->d_p, s->d_q, s->d_dinv, x->d, s->d_r, Prz, s->d_flag);
+          hipLaunchKernelGGL(k_fold1, dim3(1), dim3(SH_BLOCK), 0, st, (int)gv, Prz, one_rz, s->d_flag);
+          FEMO_HIP_CHECK(hipGetLastError());
+          FEMO_TRY(shell_allreduce(s, one_rz, 1, st));
+          hipLaunchKernelGGL(k_scg_p, dim3(gv), dim3(SH_BLOCK), 0, st, n, it, 1, one_rz, s->d_scal, s->d_r, s->d_dinv, s->d_p, s->d_flag, gam);
+        }
+      } else if (lattice && fused) {
         // r . z = r . B r + (P^T r) . e is known before z is: the update emits the first part, the finest lattice level
         // the second, and the prolongation writes p = z + beta p at once (9 launches and 3 vector streams fewer
         // per iteration than the unfused form below)
@@ -2820,6 +3014,7 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
     }
   }
   if (d_fixed != nullptr) hipLaunchKernelGGL(k_set_fixed, dim3(gv), dim3(256), 0, st, n, d_fixed, xfix ? xfix->d : nullptr, x->d);
+  if (multi) FEMO_TRY(shell_halo(s, x->d, st));          // the caller reads a consistent state on all its points
   FEMO_HIP_CHECK(hipMemcpyAsync(h_scal, s->d_scal, sizeof h_scal, hipMemcpyDeviceToHost, st));
   FEMO_HIP_CHECK(hipEventRecord(ctx->ev1, st));
   FEMO_HIP_CHECK(hipStreamSynchronize(st));

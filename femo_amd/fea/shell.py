@@ -316,10 +316,14 @@ def coarse_solve_plan(L: dict, max_unknowns: int = 3200, chunk: int = 256):
 class DeviceShell:
     """`femo_shell` handle."""
 
-    def __init__(self, ctx: Context, space: ShellSpace):
-        if getattr(ctx, "nranks", 1) > 1:
-            raise NotImplementedError("the shell path runs on one GPU (no partitioned shell meshes yet)")
-        self.ctx, self.space, self.lib = ctx, space, _lib.load()
+    def __init__(self, ctx: Context, space: ShellSpace, partition=None):
+        """``partition``: a `dist.shell.ShellPartition` whose ``space`` is ``space`` -- the handle then holds one rank's part
+        (`femo_shell_set_partition`); a context with several ranks takes nothing else."""
+        if getattr(ctx, "nranks", 1) > 1 and partition is None:
+            raise ValueError("a shell on a multi-rank context needs its partition (femo_amd.dist.shell.ShellPartition)")
+        if partition is not None and partition.space is not space:
+            raise ValueError("DeviceShell: the partition belongs to another space")
+        self.ctx, self.space, self.lib, self.partition = ctx, space, _lib.load(), partition
         rowptr, cols, epos = space.pattern()
         self.handle = _lib.H()
         p = lambda a: C.c_void_p(a.ctypes.data)
@@ -329,6 +333,11 @@ class DeviceShell:
         self.nnz = int(self.lib.femo_shell_nnz(self.handle))
         assert self.n_dof == space.n_dof and self.nnz == cols.size
         self.pc_levels = None
+        if partition is not None:
+            P = partition
+            q = lambda a: C.c_void_p(a.ctypes.data) if a.size else None
+            check(self.lib.femo_shell_set_partition(self.handle, p(P.owned_points), int(P.nbr.size), q(P.nbr), p(P.send_ptr),
+                                                    q(P.send_dofs), p(P.recv_ptr), q(P.recv_dofs)))
 
     def enable_lattice_pc(self, finest: Optional[int] = None, coarse_unknowns: Optional[int] = None) -> None:
         """Build and upload the lattice preconditioner once per mesh (used by ``solve(pc='lattice')``).
@@ -339,7 +348,8 @@ class DeviceShell:
             coarse_unknowns = int(os.environ.get("FEMO_SHELL_COARSE", "3200"))
         if self.pc_levels is not None:
             return
-        L = lattice_pc(self.space, finest)
+        # partitioned: the global lattice (same nodes on every rank) with the rows of the local dofs
+        L = lattice_pc(self.space, finest) if self.partition is None else self.partition.lattice(finest)
         p = lambda a: C.c_void_p(a.ctypes.data)
         check(self.lib.femo_shell_pc_create(self.handle, L["width"], L["n_nodes"], len(L["levels"]), p(L["level_offsets"]),
                                             p(L["ell_idx"]), p(L["ell_w"]), p(L["pt_rowptr"]), p(L["pt_cols"]), p(L["pt_vals"]),
@@ -379,6 +389,16 @@ class DeviceShell:
     def assemble(self, Ey: float, nu: float, h: Vec, vals: Vec) -> Vec:
         check(self.lib.femo_shell_assemble(self.handle, float(Ey), float(nu), h.handle, vals.handle))
         return vals
+
+    def halo(self, x: Vec) -> Vec:
+        """x on the points owned by other ranks <- the owners' values (collective)."""
+        check(self.lib.femo_shell_halo(self.handle, x.handle))
+        return x
+
+    def mask_unowned(self, x: Vec) -> Vec:
+        """x <- 0 on the points owned by other ranks (no-op without a partition)."""
+        check(self.lib.femo_shell_mask_unowned(self.handle, x.handle))
+        return x
 
     def matvec(self, vals: Vec, x: Vec, y: Vec) -> Vec:
         check(self.lib.femo_shell_matvec(self.handle, vals.handle, None, x.handle, y.handle))
@@ -533,15 +553,33 @@ class ShellProblem:
     `run_shape_opt_roof.py:131-160` and by a penalty in `shell_pde.py:246-253`, whose limit this is)."""
 
     def __init__(self, x, conn, E_young: float, nu: float, fixed_dofs: Sequence[int] = (), ctx: Optional[Context] = None,
-                 pc: str = "lattice"):
+                 pc: str = "lattice", partition=None):
+        """``partition`` (a `dist.shell.ShellPartition` of the space of ``x, conn``): this rank's part of the problem.  Inputs
+        (thickness, load, fixed dofs) stay in GLOBAL numbering -- every rank passes the same arrays --, states and
+        gradients come back on the rank's local points (`partition.dof_global / vert_global` map them; complete on the
+        owned ones), scalar outputs are summed over the ranks."""
         from .utils_hip import get_context
         self.ctx = ctx if ctx is not None else get_context()
-        self.space = ShellSpace(x, conn)
-        self.dev = DeviceShell(self.ctx, self.space)
+        self.partition = partition
+        if partition is None:
+            self.space = ShellSpace(x, conn)
+        else:
+            g = partition.global_space
+            if g.x.shape != np.shape(x) or g.conn.shape != np.shape(conn):
+                raise ValueError("ShellProblem: the partition was made for another mesh")
+            self.space = partition.space
+        self.dev = DeviceShell(self.ctx, self.space, partition)
         self.E, self.nu = float(E_young), float(nu)
         n, nv = self.space.n_dof, self.space.n_vert
         self.fixed = np.zeros(n, dtype=np.uint8)
-        self.fixed[np.asarray(list(fixed_dofs), dtype=np.int64)] = 1
+        fd = np.asarray(list(fixed_dofs), dtype=np.int64)
+        if partition is None:
+            self.fixed[fd] = 1
+        else:
+            gfix = np.zeros(partition.global_space.n_dof, dtype=np.uint8)
+            gfix[fd] = 1
+            self.fixed[:] = gfix[partition.dof_global]
+            self._cell_owned = Vec(self.ctx, self.space.n_cell).set(np.ascontiguousarray(partition.cell_owned, dtype=np.float64))
         c = self.ctx
         self.h, self.f = Vec(c, nv), Vec(c, 3 * nv)
         self.w, self.F, self.tmp, self.lam = Vec(c, n), Vec(c, n), Vec(c, n), Vec(c, n)
@@ -553,14 +591,16 @@ class ShellProblem:
 
     # inputs ---------------------------------------------------------------------------------------
     def set_thickness(self, h) -> None:
-        h = np.broadcast_to(np.asarray(h, dtype=np.float64), (self.space.n_vert,))
-        self.h.set(np.ascontiguousarray(h))
+        P = self.partition
+        h = np.broadcast_to(np.asarray(h, dtype=np.float64), (self.space.n_vert if P is None else P.global_space.n_vert,))
+        self.h.set(np.ascontiguousarray(h if P is None else h[P.vert_global]))
         self._K_for = None
 
     def set_load(self, f) -> None:
+        P = self.partition
         f = np.broadcast_to(np.asarray(f, dtype=np.float64).reshape(-1, 3) if np.ndim(f) > 1 else np.asarray(f, dtype=np.float64),
-                            (self.space.n_vert, 3))
-        self.f.set(np.ascontiguousarray(f).ravel())
+                            (self.space.n_vert if P is None else P.global_space.n_vert, 3))
+        self.f.set(np.ascontiguousarray(f if P is None else f[P.vert_global]).ravel())
 
     def _stiffness(self) -> Vec:
         if self._K_for is None:                     # reset by set_thickness
@@ -575,6 +615,7 @@ class ShellProblem:
         self.w.set(np.ascontiguousarray(w, dtype=np.float64))
         self.dev.matvec(K, self.w, self.tmp)
         self.dev.load(self.f, self.tmp, sign=-1.0, accumulate=True)
+        self.dev.mask_unowned(self.tmp)                        # partitioned: the rank's share (rows of its points)
         return np.array(self.tmp.get())
 
     def solve(self, rtol: float = 1e-12) -> np.ndarray:
@@ -608,15 +649,28 @@ class ShellProblem:
         return np.array(self.gf.get()).reshape(-1, 3)
 
     # outputs --------------------------------------------------------------------------------------
+    def _serial_only(self, what: str) -> None:
+        if self.partition is not None:
+            raise NotImplementedError(f"ShellProblem.{what} on a partitioned shell: its kernel integrates over all local cells "
+                                      "(ghost cells would count twice); the partitioned outputs are compliance and its gradient")
+
     def compliance(self, w: Optional[np.ndarray] = None, grad: bool = False):
         if w is not None:
             self.w.set(np.ascontiguousarray(w, dtype=np.float64))
+        if self.partition is not None:
+            # value: the cells this rank owns, summed over the ranks; gradient: all local cells (complete on owned points)
+            J = self.dev.compliance_dx(self.w, self._cell_owned)
+            if grad:
+                self.dev.compliance(self.w, grad=self.tmp, value=False)
+                return J, np.array(self.tmp.get())
+            return J
         if grad:
             J = self.dev.compliance(self.w, grad=self.tmp)
             return J, np.array(self.tmp.get())
         return self.dev.compliance(self.w)
 
     def mass(self, rho: float = 1.0, grad: bool = False):
+        self._serial_only("mass")
         if grad:
             M = self.dev.mass(rho, self.h, grad=self.gh)
             return M, np.array(self.gh.get())
@@ -630,6 +684,7 @@ class ShellProblem:
                      surface: float = 1.0, grad: bool = False):
         """`ShellPDE.pnorm_stress` (shell_pde.py:297-313): 1 / alpha int (m sigma_vm)^rho dx on the top (surface = +1), mid (0) or
         bottom (-1) surface, alpha = surface area by default.  grad: also (dJ/dw, dJ/dh)."""
+        self._serial_only("pnorm_stress")
         if w is not None:
             self.w.set(np.ascontiguousarray(w, dtype=np.float64))
         if alpha is None:
@@ -641,12 +696,14 @@ class ShellProblem:
 
     def von_mises_field(self, w: Optional[np.ndarray] = None, surface: float = 1.0, lump_mass: bool = False) -> np.ndarray:
         """The von Mises stress on the top / mid / bottom surface projected onto the vertices (shell_pde.py:315-332)."""
+        self._serial_only("von_mises_field")
         if w is not None:
             self.w.set(np.ascontiguousarray(w, dtype=np.float64))
         self.dev.project_von_mises(self.E, self.nu, self.h, self.w, surface, self.gh, lump_mass=lump_mass)
         return np.array(self.gh.get())
 
     def elastic_energy(self, w: Optional[np.ndarray] = None) -> float:
+        self._serial_only("elastic_energy")
         if w is not None:
             self.w.set(np.ascontiguousarray(w, dtype=np.float64))
         return self.dev.dform_dh(self.E, self.nu, self.h, self.w, self.w, energy=True)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FEMO_ABI_VERSION 5
+#define FEMO_ABI_VERSION 6
 
 typedef struct femo_ctx  femo_ctx;   /* device + stream + reduction workspace (+ RCCL communicator) */
 typedef struct femo_vec  femo_vec;   /* fp64 device vector  (dolfinx Function.vector / PETSc Vec)     */
@@ -458,6 +458,26 @@ int femo_shell_pc_coarse_matrix(femo_shell* s, const femo_vec* vals, const uint8
  * preconditioner's norm and no progress over 8 batches of check_every iterations), 0 max_it, -1 breakdown (NaN).      */
 int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_host, const femo_vec* xfix, const femo_vec* b,
                      femo_vec* x, const femo_solver_opts* opts, femo_solve_info* info);
+/* The shell on the N ranks of a context (femo_comm_init; the reference is single-rank, SURVEY.md section 0.3 -- the
+ * partitioning of section 8(e) applied to the shell).  Each rank creates its handle on the cells that touch a point it
+ * owns (a point: a P2 node with its three displacements or a vertex with its three rotations, dofs 3 p .. 3 p + 2),
+ * builds the lattice arrays of femo_shell_pc_create / _pc_coarse on the GLOBAL lattice (same nodes on every rank, the
+ * rows of its own points), then declares the partition:
+ *   owned_points  uint8[n_dof / 3]: 1 for the points this rank owns
+ *   nbr           the ranks it exchanges with; segment k of send_dofs (send_ptr) lists the owned dofs rank nbr[k] holds
+ *                 copies of, segment k of recv_dofs (recv_ptr) the local dofs of the points rank nbr[k] owns, in the order
+ *                 that rank sends them.
+ * From then on femo_shell_assemble / _penalty_add leave the rows of points owned elsewhere zero (the rank's share of K:
+ * owned rows are complete because every cell around an owned point is local), femo_shell_solve masks the right-hand
+ * side the same way, refreshes the search direction on the halo before every product, all-reduces its two scalars, the
+ * restricted residual on the finest lattice and -- per stiffness -- the Galerkin blocks and the dense coarse operator,
+ * and returns x consistent on all local points.  Values of outputs are all-reduced: integrate over owned cells only
+ * (femo_shell_compliance_dx with the ownership indicator as cell weight).
+ * femo_shell_halo: x on the points owned elsewhere <- the owners' values.  femo_shell_mask_unowned: x <- 0 there.        */
+int femo_shell_set_partition(femo_shell* s, const uint8_t* owned_points, int n_nbr, const int32_t* nbr, const int64_t* send_ptr,
+                             const int32_t* send_dofs, const int64_t* recv_ptr, const int32_t* recv_dofs);
+int femo_shell_halo(femo_shell* s, femo_vec* x);
+int femo_shell_mask_unowned(femo_shell* s, femo_vec* x);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,7 @@
 """Two real ranks over RCCL (skipped on one-GPU boxes): `bench.py --gpus 2` under torchrun on a small cube --
 halo exchange on the comm stream overlapped with interior rows, the lattice and scalar all-reduces on the main
 stream, both over one ncclComm_t.  The emulated-rank tests cover the same library code with host-staged
-collectives; this is the only test that needs xGMI."""
+collectives; these are the only tests that need xGMI.  Round 3: the partitioned shell over the same communicator."""
 import json
 import os
 import subprocess
@@ -30,3 +30,17 @@ def test_two_rank_bench_over_rccl():
     assert c["linear_solves_per_step"] == 4 and c["neighbours_per_rank"] == [1, 1]
     its = c["cg_iterations_per_step"]
     assert 10 < its[0] <= 40 and its[1] <= 2 and its[2] <= 2 and 10 < its[3] <= 40
+
+
+def test_two_rank_shell_over_rccl():
+    """The partitioned shell (femo_shell_set_partition) with real ncclSend/ncclRecv + ncclAllReduce: tests/_shell_rccl_worker.py
+    on two GPUs against the oracle's direct solve and exact adjoint gradient."""
+    from femo_amd import _lib
+    if _lib.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "tests", "_shell_rccl_worker.py")],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    assert "shell over RCCL on 2 ranks" in p.stdout

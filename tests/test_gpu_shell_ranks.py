@@ -1,0 +1,173 @@
+"""The shell on N ranks (missing #4): N contexts on ONE GPU joined in an emulated group
+(csrc/comm.cpp: the collectives staged through the host, everything else the code a torchrun job runs), each holding its
+`ShellPartition` of the roof.  Checked against the oracle's direct solves and against the single-rank run."""
+import numpy as np
+import pytest
+
+from oracle import shell_oracle as so
+from test_gpu_emulated_ranks import _run_ranks
+from test_gpu_shell import E_ROOF, FZ, H_ROOF, rel, roof_fixed
+
+pytestmark = pytest.mark.gpu
+
+
+def _roof(nx, nphi, seed=0):
+    pts, conn = so.scordelis_lo_mesh(nx, nphi)
+    V = so.ShellSpace(pts, conn)
+    rng = np.random.default_rng(seed)
+    h = H_ROOF * (1.0 + 0.3 * rng.random(V.n_vert))
+    f = np.tile([0.0, 0.0, FZ], (V.n_vert, 1)) * (1.0 + 0.2 * rng.random((V.n_vert, 1)))
+    return pts, conn, V, h, f, roof_fixed(V)
+
+
+def _gather(parts, locals_, n):
+    out = np.full(n, np.nan)
+    for P, w in zip(parts, locals_):
+        P.scatter_owned(w, out)
+    assert not np.isnan(out).any()
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rank_shares_of_the_stiffness(world):
+    """Owned rows of every rank's assembled matrix are the global rows, the rows of points owned elsewhere are zero."""
+    import scipy.sparse as sp
+    from femo_amd.dist.shell import ShellPartition
+    from femo_amd.fea.shell import ShellProblem, ShellSpace
+    pts, conn, V, h, f, fixed = _roof(8, 6)
+    G = ShellSpace(pts, conn)
+    K = so.assemble(V, so.element_stiffness(V, h, E_ROOF, 0.3)).tocsr()
+    w = np.random.default_rng(3).standard_normal(V.n_dof)
+    Fref = so.load_vector(V, f)
+
+    def rank_fn(rank, ctx):
+        P = ShellPartition(G, rank, world)
+        prob = ShellProblem(pts, conn, E_ROOF, 0.3, fixed_dofs=fixed, ctx=ctx, partition=P)
+        prob.set_thickness(h)
+        prob.set_load(f)
+        rowptr, cols, _ = P.space.pattern()
+        vals = np.array(prob._stiffness().get())
+        Kl = sp.csr_matrix((vals, cols, rowptr), shape=(P.space.n_dof, P.space.n_dof))
+        return P, Kl, prob.residual(P.local_state(w))
+
+    res = _run_ranks(world, rank_fn)
+    scale = abs(K).max()
+    R = np.zeros(V.n_dof)
+    for P, Kl, Rl in res:
+        own = np.nonzero(P.owned_dofs)[0]
+        ghost = np.nonzero(~P.owned_dofs)[0]
+        assert abs(Kl[ghost]).max() == 0.0 and np.all(Rl[ghost] == 0.0)
+        Kg = K[P.dof_global[own]][:, P.dof_global]                   # global rows of the owned dofs in local columns
+        assert abs(Kl[own] - Kg).max() <= 1e-12 * scale
+        R[P.dof_global] += Rl
+    assert rel(R, K @ w - Fref) <= 1e-12
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partitioned_solves_match_the_oracle_and_one_rank(world):
+    from femo_amd.dist.shell import ShellPartition
+    from femo_amd.fea.shell import ShellProblem, ShellSpace
+    pts, conn, V, h, f, fixed = _roof(16, 12)
+    G = ShellSpace(pts, conn)
+    K = so.assemble(V, so.element_stiffness(V, h, E_ROOF, 0.3))
+    wref = so.solve(K, so.load_vector(V, f), fixed)
+    c = np.random.default_rng(2).standard_normal(V.n_dof)
+    c[fixed] = 0.0
+    lref = so.solve(K, c, fixed)
+
+    def rank_fn(rank, ctx, nranks=world):
+        P = ShellPartition(G, rank, nranks)
+        prob = ShellProblem(pts, conn, E_ROOF, 0.3, fixed_dofs=fixed, ctx=ctx, partition=P)
+        prob.set_thickness(h)
+        prob.set_load(f)
+        wl = prob.solve()
+        it_f = prob.last_info.iterations
+        assert prob.last_info.converged in (1, 2)
+        lam = prob.solve_adjoint(P.local_state(c))
+        return dict(P=P, w=wl, lam=lam, it=(it_f, prob.last_info.iterations), coarse=prob.dev.coarse_level)
+
+    res = _run_ranks(world, rank_fn)
+    one = _run_ranks(1, lambda rank, ctx: rank_fn(rank, ctx, 1))[0]
+    parts = [r["P"] for r in res]
+    w = _gather(parts, [r["w"] for r in res], V.n_dof)
+    lam = _gather(parts, [r["lam"] for r in res], V.n_dof)
+    print(f"shell on {world} ranks: state {rel(w, wref):.2e}, adjoint {rel(lam, lref):.2e}, iterations {res[0]['it']} (one rank {one['it']})")
+    assert rel(w, wref) <= 1e-9 and rel(lam, lref) <= 1e-9           # measured 5e-12 .. 1.4e-11; eps * cond(K) of such a roof is ~2e-9
+    assert np.all(w[fixed] == 0.0)
+    for r in res:
+        assert r["it"] == res[0]["it"] and r["coarse"] == res[0]["coarse"]      # the ranks stop together
+        # and the copies a rank holds of its neighbours' points carry the owners' values
+        assert np.abs(r["w"] - w[r["P"].dof_global]).max() <= 1e-13 * np.abs(w).max()
+    # the partitioned preconditioner IS the serial one (global lattice, all-reduced Galerkin operators): same counts up to rounding
+    for a, b in zip(res[0]["it"], one["it"]):
+        assert abs(a - b) <= max(3, 0.03 * b)
+
+
+def test_compliance_gradient_on_three_ranks():
+    """The adjoint cycle of BASELINE config 3 (K w = F, J = 1/2 int |u|^2, K lam = dJ/dw, dJ/dh = -lam^T dK/dh w) on 3 ranks
+    against the oracle's exact adjoint gradient."""
+    from femo_amd.dist.shell import ShellPartition
+    from femo_amd.fea.shell import ShellProblem, ShellSpace
+    pts, conn, V, h, f, fixed = _roof(12, 10, seed=5)
+    G = ShellSpace(pts, conn)
+    K = so.assemble(V, so.element_stiffness(V, h, E_ROOF, 0.3))
+    wref = so.solve(K, so.load_vector(V, f), fixed)
+    Jref = so.compliance(V, wref)
+    dJdw = so.compliance_du(V, wref)
+    dJdw[fixed] = 0.0
+    lref = so.solve(K, dJdw, fixed)
+    gref = -so.dform_dh(V, h, E_ROOF, 0.3, lref, wref)
+    world = 3
+
+    def rank_fn(rank, ctx):
+        P = ShellPartition(G, rank, world)
+        prob = ShellProblem(pts, conn, E_ROOF, 0.3, fixed_dofs=fixed, ctx=ctx, partition=P)
+        prob.set_thickness(h)
+        prob.set_load(f)
+        J, g, w = prob.compliance_gradient()
+        with pytest.raises(NotImplementedError):
+            prob.mass()
+        return P, J, g
+
+    res = _run_ranks(world, rank_fn)
+    grad = np.full(V.n_vert, np.nan)
+    for P, J, g in res:
+        assert abs(J - Jref) <= 1e-8 * abs(Jref)                     # every rank holds the all-reduced value
+        ov = P.owned_vertices()
+        grad[P.vert_global[ov]] = g[ov]
+    assert not np.isnan(grad).any()
+    print(f"compliance gradient on 3 ranks: {rel(grad, gref):.2e}")
+    assert rel(grad, gref) <= 1e-7
+
+
+def test_jacobi_cg_on_two_ranks():
+    from femo_amd.dist.shell import ShellPartition
+    from femo_amd.fea.shell import ShellProblem, ShellSpace
+    pts, conn, V, h, f, fixed = _roof(4, 4)
+    G = ShellSpace(pts, conn)
+    K = so.assemble(V, so.element_stiffness(V, h, E_ROOF, 0.3))
+    wref = so.solve(K, so.load_vector(V, f), fixed)
+
+    def rank_fn(rank, ctx):
+        P = ShellPartition(G, rank, 2)
+        prob = ShellProblem(pts, conn, E_ROOF, 0.3, fixed_dofs=fixed, ctx=ctx, pc="jacobi", partition=P)
+        prob.set_thickness(h)
+        prob.set_load(f)
+        return P, prob.solve(rtol=1e-11), prob.last_info.iterations
+
+    res = _run_ranks(2, rank_fn)
+    w = _gather([r[0] for r in res], [r[1] for r in res], V.n_dof)
+    assert res[0][2] == res[1][2]
+    assert rel(w, wref) <= 1e-7
+
+
+def test_a_multi_rank_context_needs_a_partition():
+    from femo_amd.fea.shell import DeviceShell, ShellSpace
+    pts, conn = so.scordelis_lo_mesh(2, 2)
+
+    def rank_fn(rank, ctx):
+        with pytest.raises(ValueError, match="partition"):
+            DeviceShell(ctx, ShellSpace(pts, conn))
+        return True
+
+    assert all(_run_ranks(2, rank_fn))
