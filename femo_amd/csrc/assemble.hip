@@ -402,15 +402,25 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_cell_weights(int64_t n_cell, con
   }
 }
 
-// Incidence record of the pair-formulation walks, 16 B per visit in SELL-64 order (one dwordx4 load):
-//   ca  = cell << 2 | local index of the visiting vertex (-1: padding)
-//   sl  = byte j: off-diagonal slot of the j-th other vertex of the cell in the visiting row
-//   w   = 1/(36|T|) of the cell (1/(4|T|) for triangles), 0 for padding
-struct __attribute__((aligned(16))) P1Rec {
-  int32_t ca;
+// Incidence record of the pair-formulation walks, 12 B per visit in SELL-64 order (one dwordx3 load; round 3 -- rounds 1-2
+// carried the cell id as a fourth word, which no walk reads any more: 3.8 -> 2.9 GB per pass at C4):
+//   sl  = byte j: off-diagonal slot of the j-th other vertex of the cell in the visiting row (0 for padding)
+//   w   = 1/(36|T|) of the cell (1/(4|T|) for triangles), 0 for padding: a padded visit adds zeros to slot 0
+struct __attribute__((packed, aligned(4))) P1Rec12 {
+  uint32_t sl, wlo, whi;
+};
+// the record as the walks use it
+struct P1Rec {
   uint32_t sl;
   double w;
 };
+__device__ __forceinline__ P1Rec p1_fetch(const P1Rec12* rec, uint32_t index, bool live) {
+  const P1Rec12 q = ldg32<P1Rec12>(rec, index * 12u);
+  P1Rec r;
+  r.sl = live ? q.sl : 0u;
+  r.w = live ? __hiloint2double((int)q.whi, (int)q.wlo) : 0.0;
+  return r;
+}
 
 // what a visit gathers: coordinates of the D other vertices, optionally the cell value of a DG0 field and up to
 // two nodal fields at the other vertices
@@ -430,22 +440,15 @@ struct P1Data {
 // visits are far apart in time): measured 22 GB of fetches per pass on the 10 M-DOF cube against 1.9 GB for the
 // same numbers in the stream.  Padded visits carry weight 0 and read the data of slot 0 instead of being
 // branched around.
-template <int D, bool NEED_X, int NFIELD, bool NEED_F>
+template <int D, bool NEED_X, int NFIELD>
 struct P1Walk {
-  const P1Rec* rec; const int32_t* dl; const int32_t* cols_slice;
+  const P1Rec12* rec; const int32_t* dl; const int32_t* cols_slice;
   bool regular; int nvis, lane; int32_t row;
-  const double* x; const double* fa; const double* fb; const double* f;
+  const double* x; const double* fa; const double* fb;
 
   __device__ __forceinline__ P1Rec fetch(int s) const {
     const int sc = s < nvis ? s : nvis - 1;                      // wave-uniform
-    typedef int femo_i4 __attribute__((ext_vector_type(4)));
-    const femo_i4 q = ldg32<femo_i4>(rec, (uint32_t)(sc * 64 + lane) * 16u);
-    const bool live = s < nvis && q.x >= 0;
-    P1Rec r;
-    r.ca = live ? q.x : -1;
-    r.sl = live ? (uint32_t)q.y : 0u;
-    r.w = live ? __hiloint2double(q.w, q.z) : 0.0;
-    return r;
+    return p1_fetch(rec, (uint32_t)(sc * 64 + lane), s < nvis);
   }
   __device__ __forceinline__ void lookup(const P1Rec& r, uint32_t (&vt)[D]) const {
 #pragma unroll
@@ -456,7 +459,6 @@ struct P1Walk {
     }
   }
   __device__ __forceinline__ void gather(const P1Rec& r, const uint32_t (&vt)[D], P1Data<D>& G) const {
-    if constexpr (NEED_F) G.fc = ldg32<double>(f, ((uint32_t)(r.ca < 0 ? 0 : r.ca) >> 2) * 8u);
 #pragma unroll
     for (int j = 0; j < D; ++j) {
       if constexpr (NEED_X) ldg_point<D>(x, vt[j], G.o[j]);
@@ -494,9 +496,9 @@ struct P1Walk {
 };
 
 // wave-uniform slice metadata of a row walk (the slice index comes through readfirstlane: scalar loads)
-template <int D, bool NEED_X, int NFIELD, bool NEED_F>
-__device__ __forceinline__ bool p1_walk_setup(P1Walk<D, NEED_X, NFIELD, NEED_F>& W, int64_t n_rows, int64_t n_blocks,
-                                              const int64_t* __restrict__ vptr, const P1Rec* __restrict__ visit_rec,
+template <int D, bool NEED_X, int NFIELD>
+__device__ __forceinline__ bool p1_walk_setup(P1Walk<D, NEED_X, NFIELD>& W, int64_t n_rows, int64_t n_blocks,
+                                              const int64_t* __restrict__ vptr, const P1Rec12* __restrict__ visit_rec,
                                               const int64_t* __restrict__ mptr,
                                               const int32_t* __restrict__ cols, const int32_t* __restrict__ sdelta, int sdelta_stride,
                                               int64_t& row_out, int64_t& slice_out) {
@@ -518,58 +520,45 @@ __device__ __forceinline__ bool p1_walk_setup(P1Walk<D, NEED_X, NFIELD, NEED_F>&
 }
 
 // Vector-valued Poisson walk without LDS strips (the fallback of evaluate_residuals for rows the pipelined kernel does
-// not take):
-//   KIND 0  r_a = sum_cells sum_b K_ab (u_b - u_a)  - load_a                 evaluate_residuals (state_model.py:75-85)
-// (KIND 1, dJ/du, became a mass-matrix SpMV and KIND 2, the load vector, a cell stream + k_load_walk in round 3; their
-// bodies are kept below for the record of what the counters in profiles/r02_* measured)
+// not take):   r_a = sum_cells sum_b K_ab (u_b - u_a) - load_a                 evaluate_residuals (state_model.py:75-85)
+// (Rounds 1-2 had two more walks of this shape: dJ/du, now a mass-matrix SpMV, and the load vector, now a cell stream +
+// k_load_walk; profiles/r02_* hold their counters.)
 template <int D, int KIND>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_p1_row_walk(
-    int64_t n_rows, int64_t n_blocks, const int64_t* __restrict__ vptr, const P1Rec* __restrict__ visit_rec,
+    int64_t n_rows, int64_t n_blocks, const int64_t* __restrict__ vptr, const P1Rec12* __restrict__ visit_rec,
     const int64_t* __restrict__ mptr,
     const int32_t* __restrict__ cols, const int32_t* __restrict__ sdelta, int sdelta_stride, const double* __restrict__ x,
     const double* __restrict__ u, const double* __restrict__ second, double* __restrict__ out) {
-  P1Walk<D, KIND == 0, KIND == 0 ? 1 : (KIND == 1 ? 2 : 0), KIND == 2> W;
+  static_assert(KIND == 0, "only the residual walk is left");
+  P1Walk<D, true, 1> W;
   int64_t row, slice;
   if (!p1_walk_setup(W, n_rows, n_blocks, vptr, visit_rec, mptr, cols, sdelta, sdelta_stride, row, slice)) return;
-  W.x = x; W.fa = u; W.fb = second; W.f = second;
+  W.x = x; W.fa = u; W.fb = second;
   const uint32_t r0 = (uint32_t)(row < n_rows ? row : 0);
   double xo[D];
   ldg_point<D>(x, r0, xo);
-  double uo = 0.0;
-  if constexpr (KIND == 0) uo = u[r0];
-  if constexpr (KIND == 1) uo = u[r0] - second[r0];
-  constexpr double VOLF = D == 3 ? 36.0 : 4.0;               // |T| = 1 / (VOLF w)
+  const double uo = u[r0];
   double acc = 0.0;
   W.run([&](const P1Rec& R, const P1Data<D>& V) {
-    if constexpr (KIND == 0) {
-      double k[D];
-      poisson_pairs<D>(xo, V.o, R.w, k);
+    double k[D];
+    poisson_pairs<D>(xo, V.o, R.w, k);
 #pragma unroll
-      for (int j = 0; j < D; ++j) acc += k[j] * (V.ua[j] - uo);
-    } else {
-      const double vol = R.w > 0.0 ? 1.0 / (VOLF * R.w) : 0.0;
-      if constexpr (KIND == 1) {
-        double es = uo + uo;
-#pragma unroll
-        for (int j = 0; j < D; ++j) es += V.ua[j] - V.ub[j];
-        acc += vol * (1.0 / ((D + 1) * (D + 2))) * es;
-      } else {
-        acc += V.fc * vol * (1.0 / (D + 1));
-      }
-    }
+    for (int j = 0; j < D; ++j) acc += k[j] * (V.ua[j] - uo);
   });
-  if constexpr (KIND == 0) acc -= second[r0];                // the load vector (KIND 2) of the current f
+  acc -= second[r0];                                         // the load vector of the current f
   if (row < n_rows) out[row] = acc;
 }
 
 // rec[i] = (incidence words, weight of the cell) of incidence entry i: the one cell-indexed gather, once per mesh
 __global__ void k_visit_records(int64_t n, const int32_t* __restrict__ visit_cell, const uint32_t* __restrict__ visit_slots,
-                                const femo_d2* __restrict__ cw, P1Rec* __restrict__ rec) {
+                                const femo_d2* __restrict__ cw, P1Rec12* __restrict__ rec) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    P1Rec r;
-    r.ca = visit_cell[i];
-    r.sl = r.ca >= 0 ? visit_slots[i] : 0u;
-    r.w = r.ca >= 0 ? cw[r.ca >> 2].x : 0.0;
+    const int32_t ca = visit_cell[i];                        // cell << 2 | local vertex, -1: padding
+    const double w = ca >= 0 ? cw[ca >> 2].x : 0.0;
+    P1Rec12 r;
+    r.sl = ca >= 0 ? visit_slots[i] : 0u;
+    r.wlo = (uint32_t)__double2loint(w);
+    r.whi = (uint32_t)__double2hiint(w);
     rec[i] = r;
   }
 }
@@ -657,7 +646,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
     const double* __restrict__ aux, const uint8_t* __restrict__ bfacets, double beta, double sgn,
     const uint8_t* __restrict__ bcmask, const double* __restrict__ bcval,
     double* __restrict__ diag0, double* __restrict__ vals0, double* __restrict__ diag1,
-    double* __restrict__ vals1, double* __restrict__ rhs, const P1Rec* __restrict__ visit_rec) {
+    double* __restrict__ vals1, double* __restrict__ rhs, const P1Rec12* __restrict__ visit_rec) {
   extern __shared__ double strip[];
   const int tid = threadIdx.x;
   const int64_t blk = femo_xcd_block(blockIdx.x, n_blocks);
@@ -684,10 +673,10 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
   if constexpr (PDE == FEMO_PDE_POISSON) {
     // Pair formulation (see poisson_pairs): no canonical vertex order, no gradient table, no division.  The
     // load vector (the u-independent part of the residual) comes in through `aux`, see femo_launch_system.
-    P1Walk<D, true, 0, false> W;
+    P1Walk<D, true, 0> W;
     W.rec = visit_rec + vb; W.dl = dl; W.cols_slice = cols + mb;
     W.regular = regular; W.nvis = nvis; W.lane = lane; W.row = (int32_t)row;
-    W.x = x; W.fa = nullptr; W.fb = nullptr; W.f = nullptr;
+    W.x = x; W.fa = nullptr; W.fb = nullptr;
     W.run([&](const P1Rec& R, const P1Data<D>& V) {
       double k[D];
       poisson_pairs<D>(xo, V.o, R.w, k);
@@ -910,7 +899,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_jacobian(
 // 28 KB at 14 neighbours -> 5 waves per CU, which is enough because nothing in the loop waits on a gather.
 template <int D, int CH>
 __global__ __launch_bounds__(64) void k_poisson_system_lds(
-    int64_t n_rows, int64_t n_blocks, int nb, const int64_t* __restrict__ vptr, const P1Rec* __restrict__ visit_rec,
+    int64_t n_rows, int64_t n_blocks, int nb, const int64_t* __restrict__ vptr, const P1Rec12* __restrict__ visit_rec,
     const int64_t* __restrict__ mptr, const int32_t* __restrict__ cols, const int32_t* __restrict__ sdelta, int sdelta_stride,
     const int32_t* __restrict__ rowlen, const double* __restrict__ x, const double* __restrict__ u,
     const double* __restrict__ load, const uint8_t* __restrict__ bcmask, const double* __restrict__ bcval,
@@ -930,7 +919,7 @@ __global__ __launch_bounds__(64) void k_poisson_system_lds(
   const int32_t* dl = sdelta + slice * sdelta_stride;
   const bool regular = dl[0] != INT32_MIN;
   const int32_t* cols_slice = cols + mb;
-  const P1Rec* rec = visit_rec + vb;
+  const P1Rec12* rec = visit_rec + vb;
   const int len = rowlen[row];
   const uint32_t r0 = (uint32_t)(valid ? row : 0);
   double xo[D];
@@ -959,14 +948,13 @@ __global__ __launch_bounds__(64) void k_poisson_system_lds(
       }
     }
   }
-  typedef int femo_i4 __attribute__((ext_vector_type(4)));
-  auto fetch = [&](int s) -> femo_i4 {
+  auto fetch = [&](int s) -> P1Rec12 {
     const int sc = s < nvis ? s : nvis - 1;
-    return ldg32<femo_i4>(rec, (uint32_t)(sc * 64 + lane) * 16u);
+    return ldg32<P1Rec12>(rec, (uint32_t)(sc * 64 + lane) * 12u);
   };
   double dsum = 0.0;
   if (nvis > 0) {
-    femo_i4 cur[CH], nxt[CH];
+    P1Rec12 cur[CH], nxt[CH];
 #pragma unroll
     for (int i = 0; i < CH; ++i) cur[i] = fetch(i);
     for (int base = 0; base < nvis; base += CH) {
@@ -975,10 +963,9 @@ __global__ __launch_bounds__(64) void k_poisson_system_lds(
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
         if (base + i < nvis) {                     // wave-uniform
-          const femo_i4 q = cur[i];
-          const bool live = q.x >= 0;
-          const uint32_t sl = live ? (uint32_t)q.y : 0u;
-          const double w = live ? __hiloint2double(q.w, q.z) : 0.0;
+          const P1Rec12 q = cur[i];                 // padded visits carry slot word 0 and weight 0
+          const uint32_t sl = q.sl;
+          const double w = __hiloint2double((int)q.whi, (int)q.wlo);
           double o[D][D];
           int pos[D];
 #pragma unroll
@@ -1095,7 +1082,7 @@ __global__ void k_impose_bc(int64_t n, const double* __restrict__ u, const uint8
 
 template <int D, int NB, bool WANT_RHS, bool HAS_V0, bool HAS_V1, bool LDS_ATOMIC, bool HAVE_BC = true>
 __global__ __launch_bounds__(64) void k_poisson_system_pipe(
-    int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ vptr, const P1Rec* __restrict__ visit_rec,
+    int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ vptr, const P1Rec12* __restrict__ visit_rec,
     const int64_t* __restrict__ mptr, const int32_t* __restrict__ cols, const int32_t* __restrict__ rowlen,
     const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ ubc,
     const double* __restrict__ load, const double* __restrict__ bcval,
@@ -1154,10 +1141,9 @@ __global__ __launch_bounds__(64) void k_poisson_system_pipe(
     if constexpr (WANT_RHS && HAVE_BC) R.gr = bcval[r0];
     return R;
   };
-  typedef int femo_i4 __attribute__((ext_vector_type(4)));
-  auto fetch = [&](const Meta& M, int v) -> femo_i4 {
+  auto fetch = [&](const Meta& M, int v) -> P1Rec12 {
     const int sc = v < M.nvis ? v : (M.nvis > 0 ? M.nvis - 1 : 0);
-    return ldg32<femo_i4>(visit_rec + M.vb, (uint32_t)(sc * 64 + lane) * 16u);
+    return ldg32<P1Rec12>(visit_rec + M.vb, (uint32_t)(sc * 64 + lane) * 12u);
   };
   double* const my_dummy = dummy + lane * 2;
 
@@ -1221,7 +1207,7 @@ __global__ __launch_bounds__(64) void k_poisson_system_pipe(
     }
     const RowData R = R0;
     // (2) first records of this slice
-    femo_i4 cur[CH], nxt[CH];
+    P1Rec12 cur[CH], nxt[CH];
 #pragma unroll
     for (int i = 0; i < CH; ++i) cur[i] = fetch(M0, i);
     // (3) rows of the previous slice out of the strip, then clear it
@@ -1239,11 +1225,10 @@ __global__ __launch_bounds__(64) void k_poisson_system_pipe(
     // else hides LDS latency.
     const int nvis = M0.nvis;
     struct Nbr { double o[D][D]; int pos[D]; double wt; };
-    auto gather = [&](const femo_i4 q) -> Nbr {                  // the visit's three (two) other vertices from LDS
+    auto gather = [&](const P1Rec12 q) -> Nbr {                  // the visit's three (two) other vertices from LDS
       Nbr V;
-      const bool live = q.x >= 0;
-      const uint32_t sl = live ? (uint32_t)q.y : 0u;
-      V.wt = live ? __hiloint2double(q.w, q.z) : 0.0;
+      const uint32_t sl = q.sl;                                  // padded visits: slot word 0, weight 0
+      V.wt = __hiloint2double((int)q.whi, (int)q.wlo);
 #pragma unroll
       for (int j = 0; j < D; ++j) {
         V.pos[j] = (int)((sl >> (8 * j)) & 0xFFu);
@@ -1527,12 +1512,12 @@ static int ensure_visit_weights(femo_mesh* m) {
   femo_d2* cw = nullptr;
   FEMO_HIP_CHECK(hipMalloc(&cw, std::max<int64_t>(m->n_cell, 1) * sizeof(femo_d2)));
   FEMO_REQUIRE(m->visit_entries * 16 < (int64_t(1) << 40), "incidence too large");
-  FEMO_HIP_CHECK(hipMalloc(&m->d_visit_rec, (std::max<int64_t>(m->visit_entries, 1) + 64) * sizeof(P1Rec)));   // + one padded visit: slices without visits still fetch
+  FEMO_HIP_CHECK(hipMalloc(&m->d_visit_rec, (std::max<int64_t>(m->visit_entries, 1) + 64) * sizeof(P1Rec12) + 16));   // + one padded visit: slices without visits still fetch
   if (m->n_cell > 0 && m->visit_entries > 0) {
     const int g = cell_grid(m->n_cell);
     if (m->tdim == 3) hipLaunchKernelGGL((k_cell_weights<3>), dim3(g), dim3(FEMO_BLOCK), 0, st, m->n_cell, m->d_conn, m->d_x, cw);
     else hipLaunchKernelGGL((k_cell_weights<2>), dim3(g), dim3(FEMO_BLOCK), 0, st, m->n_cell, m->d_conn, m->d_x, cw);
-    hipLaunchKernelGGL(k_visit_records, dim3(2048), dim3(256), 0, st, m->visit_entries, m->d_visit_cell, m->d_visit_slots, cw, reinterpret_cast<P1Rec*>(m->d_visit_rec));
+    hipLaunchKernelGGL(k_visit_records, dim3(2048), dim3(256), 0, st, m->visit_entries, m->d_visit_cell, m->d_visit_slots, cw, reinterpret_cast<P1Rec12*>(m->d_visit_rec));
     FEMO_HIP_CHECK(hipGetLastError());
   }
   FEMO_HIP_CHECK(hipStreamSynchronize(st));
@@ -1541,7 +1526,7 @@ static int ensure_visit_weights(femo_mesh* m) {
 }
 
 #define FEMO_ROW_WALK(m, KIND, nb, st, u, second, out)                                                                   \
-  FEMO_LAUNCH_DP(m, k_p1_row_walk, KIND, nb, 0, st, (m)->n_rows, nb, (m)->d_vptr, reinterpret_cast<const P1Rec*>((m)->d_visit_rec), \
+  FEMO_LAUNCH_DP(m, k_p1_row_walk, KIND, nb, 0, st, (m)->n_rows, nb, (m)->d_vptr, reinterpret_cast<const P1Rec12*>((m)->d_visit_rec), \
                  (m)->d_mptr, (m)->d_cols, (m)->d_sdelta, (m)->sdelta_stride, (m)->d_x, u, second, out)
 
 // load_a = sum_cells f_c |T| / (D+1): the part of the Poisson residual that does not depend on u.  Newton
@@ -1627,7 +1612,7 @@ static int launch_system_t(femo_mesh* m, int64_t nb, size_t lds, const double* u
   auto k = k_jacobian<D, PDE>;
   if (lds > 64 * 1024) FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (PDE == FEMO_PDE_POISSON) FEMO_TRY(ensure_visit_weights(m));
-  hipLaunchKernelGGL(k, dim3(nb), dim3(FEMO_BLOCK), lds, m->ctx->stream, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_visit_slots, m->d_mptr, m->d_cols, m->d_sdelta, m->sdelta_stride, m->d_rowlen, m->d_conn, m->d_x, u, f, aux, m->d_bfacets, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs, reinterpret_cast<const P1Rec*>(m->d_visit_rec));
+  hipLaunchKernelGGL(k, dim3(nb), dim3(FEMO_BLOCK), lds, m->ctx->stream, m->n_rows, nb, m->d_vptr, m->d_visit_cell, m->d_visit_slots, m->d_mptr, m->d_cols, m->d_sdelta, m->sdelta_stride, m->d_rowlen, m->d_conn, m->d_x, u, f, aux, m->d_bfacets, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs, reinterpret_cast<const P1Rec12*>(m->d_visit_rec));
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -1675,7 +1660,7 @@ int femo_launch_system(femo_mesh* m, int pde, const double* params, const double
   if (lds_row <= 128 * 1024 && !gather_only) {
     FEMO_TRY(ensure_visit_weights(m));
     const int64_t ns = m->n_slices;
-    const P1Rec* rec = reinterpret_cast<const P1Rec*>(m->d_visit_rec);
+    const P1Rec12* rec = reinterpret_cast<const P1Rec12*>(m->d_visit_rec);
     static const int dbg = FEMO_TUNE_ENV("FEMO_DEBUG_SKIP") ? atoi(FEMO_TUNE_ENV("FEMO_DEBUG_SKIP")) : 0;     // timing experiments (FEMO_TUNING builds)
 #define FEMO_SYS_LDS(D)                                                                                                       \
     do {                                                                                                                      \

@@ -206,7 +206,7 @@ struct femo_mesh {
   int sdelta_stride = 0;
   int64_t n_regular = 0, n_short = 0;
   int16_t* d_cols16 = nullptr;   // FemoTopology::cols16
-  void* d_visit_rec = nullptr;   // per incidence entry, 16 B: (cell<<2|a, slots, 1/(36|T|)) for the Poisson walks, built on first use
+  void* d_visit_rec = nullptr;   // per incidence entry, 12 B: (slots, 1/(36|T|)) for the Poisson walks, built on first use
   double* d_load = nullptr;      // load vector of the Poisson residual for the f identified by (load_uid, load_gen)
   uint64_t load_uid = 0, load_gen = 0;
   int pcg_last_iters = 0, pcg_prev_iters = 0;   // iterations of the last two converged BPX-PCG solves on this mesh (size the first batch)
