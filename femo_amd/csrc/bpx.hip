@@ -154,7 +154,9 @@ __device__ __forceinline__ void unpack_coord(uint32_t w, int& bin, double& t) {
 // The first version accumulated with ds_add_f64 per vertex and corner and was bound by same-address
 // LDS atomics (~11 vertices per bin): 101-150 us at C4 against ~65 us for this one.
 template <int D> struct Brick { static constexpr int B = D == 3 ? 4 : 8; static constexpr int N1 = B + 1; static constexpr int NLOC = D == 3 ? N1 * N1 * N1 : N1 * N1; static constexpr int NBIN = 64; static constexpr int NC = 1 << D; };
-constexpr int BRICK_CHUNK = 1024;   // vertices staged per pass (bricks with more loop)
+// vertices staged per pass (bricks with more loop): a 3-D brick of 4^3 bins holds ~700 vertices, a 2-D brick of 8^2 bins
+// ~310 -- with 1024 slots three quarters of the 2-D staging loads fetched the clamped last entry (round 3: 512)
+template <int D> constexpr int BRICK_CHUNK = D == 3 ? 1024 : 512;
 
 // w_sorted[i] = 1/s of the i-th sorted vertex, 0 for pinned vertices (once per solve: s changes with
 // every assembly).  Leaves one gather (the residual) in the restriction's staging loop.
@@ -261,12 +263,12 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
                                                                 double* __restrict__ g, int n_fused, const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
   constexpr int B = Brick<D>::B, N1 = Brick<D>::N1, NLOC = Brick<D>::NLOC, NC = Brick<D>::NC;
-  constexpr int PF = BRICK_CHUNK / FEMO_BLOCK;      // staged entries per thread and pass
+  constexpr int PF = BRICK_CHUNK<D> / FEMO_BLOCK;      // staged entries per thread and pass
   constexpr int NTOT = BrickNodes<D>::TOTAL;
   __shared__ double nodes[2][NTOT];
   __shared__ double tmpA[128], tmpB[64];
-  __shared__ double sval[BRICK_CHUNK];
-  __shared__ float st[D][BRICK_CHUNK];          // 20-bit fractions are exact in fp32
+  __shared__ double sval[BRICK_CHUNK<D>];
+  __shared__ float st[D][BRICK_CHUNK<D>];          // 20-bit fractions are exact in fp32
   __shared__ double binsum[NC][64];
   const int tid = threadIdx.x;
   const int bin = tid >> 2, sub = tid & 3;      // 4 adjacent lanes share a bin
@@ -360,9 +362,9 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
     uint32_t k1[PF][D];
     load_vals(M1, p1, v1, w1, k1);
     // (3) LDS phases
-    for (int64_t chunk = start; chunk < end; chunk += BRICK_CHUNK) {
-      const int64_t chunk_end = chunk + BRICK_CHUNK < end ? chunk + BRICK_CHUNK : end;
-      if (chunk > start) {                        // bricks above BRICK_CHUNK vertices (rare): unpipelined passes
+    for (int64_t chunk = start; chunk < end; chunk += BRICK_CHUNK<D>) {
+      const int64_t chunk_end = chunk + BRICK_CHUNK<D> < end ? chunk + BRICK_CHUNK<D> : end;
+      if (chunk > start) {                        // bricks above BRICK_CHUNK<D> vertices (rare): unpipelined passes
         lds_barrier();
         for (int64_t i = chunk + tid; i < chunk_end; i += FEMO_BLOCK) {
           sval[i - chunk] = val[perm[i]] * w_sorted[i];
