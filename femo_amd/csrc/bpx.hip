@@ -56,6 +56,7 @@ struct femo_pc {
   double* g_alt = nullptr;
   int parity = 0;
   int n_fused = 0;          // coarser levels the brick kernel restricts to directly (besides the finest)
+  int brick_pf = 4;         // staging depth of the brick kernel: smallest of 2..4 with 256 x brick_pf >= the fullest brick
   bool coarse_lds_set = false;
   // owned vertices sorted by brick (BRICK^dim bins of the finest lattice), for the restriction
   int64_t n_bricks = 0;
@@ -154,9 +155,10 @@ __device__ __forceinline__ void unpack_coord(uint32_t w, int& bin, double& t) {
 // The first version accumulated with ds_add_f64 per vertex and corner and was bound by same-address
 // LDS atomics (~11 vertices per bin): 101-150 us at C4 against ~65 us for this one.
 template <int D> struct Brick { static constexpr int B = D == 3 ? 4 : 8; static constexpr int N1 = B + 1; static constexpr int NLOC = D == 3 ? N1 * N1 * N1 : N1 * N1; static constexpr int NBIN = 64; static constexpr int NC = 1 << D; };
-// vertices staged per pass (bricks with more loop): a 3-D brick of 4^3 bins holds ~700 vertices, a 2-D brick of 8^2 bins
-// ~310 -- with 1024 slots three quarters of the 2-D staging loads fetched the clamped last entry (round 3: 512)
-template <int D> constexpr int BRICK_CHUNK = D == 3 ? 1024 : 512;
+// Vertices staged per pass = PF x 256, PF = entries per thread (bricks with more loop, unpipelined).  A 3-D brick of 4^3
+// bins holds ~700 vertices (exactly 729 on the benchmark cube), a 2-D brick of 8^2 bins ~310; rounds 1-2 always staged 1024,
+// so a quarter (3-D) to three quarters (2-D) of the staging loads fetched the clamped last entry.  Round 3: the launcher
+// picks the smallest PF in 2..4 that holds the mesh's fullest brick (femo_pc::brick_pf).
 
 // w_sorted[i] = 1/s of the i-th sorted vertex, 0 for pinned vertices (once per solve: s changes with
 // every assembly).  Leaves one gather (the residual) in the restriction's staging loop.
@@ -254,7 +256,7 @@ __device__ __forceinline__ void brick_flush_level(const double* src, double* gl,
   }
 }
 
-template <int D>
+template <int D, int PF>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks, const int64_t* __restrict__ brick_ptr,
                                                                 const int32_t* __restrict__ brick_base, const uint32_t* __restrict__ bin_ptr,
                                                                 const int32_t* __restrict__ perm, const uint32_t* __restrict__ pk,
@@ -263,12 +265,12 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
                                                                 double* __restrict__ g, int n_fused, const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
   constexpr int B = Brick<D>::B, N1 = Brick<D>::N1, NLOC = Brick<D>::NLOC, NC = Brick<D>::NC;
-  constexpr int PF = BRICK_CHUNK<D> / FEMO_BLOCK;      // staged entries per thread and pass
+  constexpr int BRICK_CHUNK = PF * FEMO_BLOCK;         // staged entries per pass
   constexpr int NTOT = BrickNodes<D>::TOTAL;
   __shared__ double nodes[2][NTOT];
   __shared__ double tmpA[128], tmpB[64];
-  __shared__ double sval[BRICK_CHUNK<D>];
-  __shared__ float st[D][BRICK_CHUNK<D>];          // 20-bit fractions are exact in fp32
+  __shared__ double sval[BRICK_CHUNK];
+  __shared__ float st[D][BRICK_CHUNK];          // 20-bit fractions are exact in fp32
   __shared__ double binsum[NC][64];
   const int tid = threadIdx.x;
   const int bin = tid >> 2, sub = tid & 3;      // 4 adjacent lanes share a bin
@@ -362,9 +364,9 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
     uint32_t k1[PF][D];
     load_vals(M1, p1, v1, w1, k1);
     // (3) LDS phases
-    for (int64_t chunk = start; chunk < end; chunk += BRICK_CHUNK<D>) {
-      const int64_t chunk_end = chunk + BRICK_CHUNK<D> < end ? chunk + BRICK_CHUNK<D> : end;
-      if (chunk > start) {                        // bricks above BRICK_CHUNK<D> vertices (rare): unpipelined passes
+    for (int64_t chunk = start; chunk < end; chunk += BRICK_CHUNK) {
+      const int64_t chunk_end = chunk + BRICK_CHUNK < end ? chunk + BRICK_CHUNK : end;
+      if (chunk > start) {                        // bricks above BRICK_CHUNK vertices (rare): unpipelined passes
         lds_barrier();
         for (int64_t i = chunk + tid; i < chunk_end; i += FEMO_BLOCK) {
           sval[i - chunk] = val[perm[i]] * w_sorted[i];
@@ -989,6 +991,12 @@ int femo_pc_build(femo_mesh* m) {
   FEMO_TRY(upload(&pc->d_pk, P.pk));
   FEMO_TRY(upload(&pc->d_pk_sorted, P.pk_sorted));
   FEMO_TRY(upload(&pc->d_brick_ptr, P.brick_ptr));
+  {
+    int64_t fullest = 0;
+    for (size_t b = 0; b + 1 < P.brick_ptr.size(); ++b) fullest = std::max<int64_t>(fullest, P.brick_ptr[b + 1] - P.brick_ptr[b]);
+    pc->brick_pf = fullest <= 2 * FEMO_BLOCK ? 2 : (fullest <= 3 * FEMO_BLOCK ? 3 : 4);
+    if (const char* env = FEMO_TUNE_ENV("FEMO_BRICK_PF")) pc->brick_pf = std::min(4, std::max(2, atoi(env)));
+  }
   FEMO_TRY(upload(&pc->d_bin_ptr, P.bin_ptr));
   FEMO_TRY(upload(&pc->d_brick_base, P.brick_base));
   FEMO_HIP_CHECK(hipMalloc(&pc->d_w_sorted, std::max<size_t>(P.perm.size(), 1) * sizeof(double)));
@@ -1045,18 +1053,37 @@ __global__ __launch_bounds__(1024) void k_fold_partials(int nb, const double* __
 }
 
 // resident workgroups of the persistent brick kernel per CU (registers and LDS decide; asked once)
-static int bricks_per_cu(int dim) {
-  static int cached[2] = {0, 0};
-  int& c = cached[dim == 3 ? 1 : 0];
+template <int D, int PF>
+static int bricks_per_cu_of() {
+  int nb = 0;
+  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_restrict_bricks<D, PF>, FEMO_BLOCK, 0);
+  return (e == hipSuccess && nb > 0) ? nb : 3;
+}
+
+static int bricks_per_cu(int dim, int pf) {
+  static int cached[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
+  int& c = cached[dim == 3 ? 1 : 0][pf];
   if (c == 0) {
-    int nb = 0;
-    hipError_t e = dim == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_restrict_bricks<3>, FEMO_BLOCK, 0)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_restrict_bricks<2>, FEMO_BLOCK, 0);
-    c = (e == hipSuccess && nb > 0) ? nb : 3;
+    if (dim == 3) c = pf == 2 ? bricks_per_cu_of<3, 2>() : (pf == 3 ? bricks_per_cu_of<3, 3>() : bricks_per_cu_of<3, 4>());
+    else c = pf == 2 ? bricks_per_cu_of<2, 2>() : (pf == 3 ? bricks_per_cu_of<2, 3>() : bricks_per_cu_of<2, 4>());
     if (const char* env = FEMO_TUNE_ENV("FEMO_BRICKS_PER_CU")) c = std::max(1, atoi(env));
   }
   return c;
 }
+
+// the brick restriction for the mesh's dimension and staging depth
+#define FEMO_LAUNCH_BRICKS(pc, gb, st, ...)                                                                                        \
+  do {                                                                                                                             \
+    if ((pc)->dim == 3) {                                                                                                          \
+      if ((pc)->brick_pf == 2) hipLaunchKernelGGL((k_restrict_bricks<3, 2>), dim3(gb), dim3(FEMO_BLOCK), 0, st, __VA_ARGS__);      \
+      else if ((pc)->brick_pf == 3) hipLaunchKernelGGL((k_restrict_bricks<3, 3>), dim3(gb), dim3(FEMO_BLOCK), 0, st, __VA_ARGS__); \
+      else hipLaunchKernelGGL((k_restrict_bricks<3, 4>), dim3(gb), dim3(FEMO_BLOCK), 0, st, __VA_ARGS__);                          \
+    } else {                                                                                                                       \
+      if ((pc)->brick_pf == 2) hipLaunchKernelGGL((k_restrict_bricks<2, 2>), dim3(gb), dim3(FEMO_BLOCK), 0, st, __VA_ARGS__);      \
+      else if ((pc)->brick_pf == 3) hipLaunchKernelGGL((k_restrict_bricks<2, 3>), dim3(gb), dim3(FEMO_BLOCK), 0, st, __VA_ARGS__); \
+      else hipLaunchKernelGGL((k_restrict_bricks<2, 4>), dim3(gb), dim3(FEMO_BLOCK), 0, st, __VA_ARGS__);                          \
+    }                                                                                                                              \
+  } while (0)
 
 // Which finest-lattice nodes do several ranks touch?  A rank's restriction only reaches the nodes
 // around its own vertices and its prolongation only reads those, so between ranks it is enough to
@@ -1078,11 +1105,8 @@ static int pc_setup_shared(femo_mesh* m) {
   hipLaunchKernelGGL(k_fill_ones, dim3(lat_grid(m->n_rows)), dim3(256), 0, st, std::max<int64_t>(m->n_rows, 0), pc->d_w_sorted);
   FEMO_HIP_CHECK(hipMemsetAsync(F.g, 0, F.nodes * sizeof(double), st));
   if (pc->n_bricks > 0) {
-    const unsigned gb = (unsigned)std::min<int64_t>(pc->n_bricks, (int64_t)ctx->n_cu * bricks_per_cu(pc->dim));
-    if (pc->dim == 3)
-      hipLaunchKernelGGL(k_restrict_bricks<3>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, ones, pc->d_w_sorted, F.g, 0, (const int32_t*)nullptr);
-    else
-      hipLaunchKernelGGL(k_restrict_bricks<2>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, ones, pc->d_w_sorted, F.g, 0, (const int32_t*)nullptr);
+    const unsigned gb = (unsigned)std::min<int64_t>(pc->n_bricks, (int64_t)ctx->n_cu * bricks_per_cu(pc->dim, pc->brick_pf));
+    FEMO_LAUNCH_BRICKS(pc, gb, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, ones, pc->d_w_sorted, F.g, 0, (const int32_t*)nullptr);
   }
   hipLaunchKernelGGL(k_mark_touched, dim3(lat_grid(F.nodes)), dim3(256), 0, st, F.nodes, F.g, F.e);
   FEMO_HIP_CHECK(hipGetLastError());
@@ -1176,11 +1200,8 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
   double* gF = G(nl - 1, par);
   // g of the finest nf+1 levels: zero on entry (femo_pc_begin, then the prolongation kernels clean up)
   if (pc->n_bricks > 0) {
-    const unsigned gb = (unsigned)std::min<int64_t>(pc->n_bricks, (int64_t)ctx->n_cu * bricks_per_cu(pc->dim));
-    if (pc->dim == 3)
-      hipLaunchKernelGGL(k_restrict_bricks<3>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, rsrc, pc->d_w_sorted, gF, nf, done);
-    else
-      hipLaunchKernelGGL(k_restrict_bricks<2>, dim3(gb), dim3(FEMO_BLOCK), 0, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, rsrc, pc->d_w_sorted, gF, nf, done);
+    const unsigned gb = (unsigned)std::min<int64_t>(pc->n_bricks, (int64_t)ctx->n_cu * bricks_per_cu(pc->dim, pc->brick_pf));
+    FEMO_LAUNCH_BRICKS(pc, gb, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, rsrc, pc->d_w_sorted, gF, nf, done);
   }
   const bool sparse = ctx->nranks > 1 && pc->shared_ready;
   if (sparse) {
