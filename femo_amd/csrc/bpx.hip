@@ -57,6 +57,7 @@ struct femo_pc {
   int parity = 0;
   int n_fused = 0;          // coarser levels the brick kernel restricts to directly (besides the finest)
   int brick_pf = 4;         // staging depth of the brick kernel: smallest of 2..4 with 256 x brick_pf >= the fullest brick
+  bool fused_cycle_seen = false;   // the last apply ran the fused lattice cycle (femo_pc_carries_xupdate)
   bool coarse_lds_set = false;
   // owned vertices sorted by brick (BRICK^dim bins of the finest lattice), for the restriction
   int64_t n_bricks = 0;
@@ -667,8 +668,25 @@ struct CoarseLevels {
   int restrict_top;
 };
 
-__global__ __launch_bounds__(1024) void k_lattice_coarse(CoarseLevels L, int dim, const int32_t* __restrict__ done) {
+__global__ __launch_bounds__(1024) void k_lattice_coarse(CoarseLevels L, int dim, const int32_t* __restrict__ done, FemoXUpdate xu) {
   if (done != nullptr && *done) return;
+  if (blockIdx.x > 0) {
+    // workgroups 1 .. gridDim.x - 1 exist only to carry the solver's x += alpha p (FemoXUpdate) on the compute units the
+    // lattice work of workgroup 0 leaves idle
+    const double alpha = *xu.alpha;
+    const int64_t n2 = xu.n >> 1;
+    double2* x2 = reinterpret_cast<double2*>(xu.x);
+    const double2* p2 = reinterpret_cast<const double2*>(xu.p);
+    const int64_t stride = (int64_t)(gridDim.x - 1) * 1024;
+    for (int64_t i = (int64_t)(blockIdx.x - 1) * 1024 + threadIdx.x; i < n2; i += stride) {
+      double2 xi = x2[i];
+      const double2 pi = p2[i];
+      xi.x += alpha * pi.x; xi.y += alpha * pi.y;
+      x2[i] = xi;
+    }
+    if ((xu.n & 1) && blockIdx.x == 1 && threadIdx.x == 0) xu.x[xu.n - 1] += alpha * xu.p[xu.n - 1];
+    return;
+  }
   // g and e of the levels below `top` live in LDS for the whole launch (a few thousand nodes);
   // only e_{top-1}, which the next prolongation reads, goes back to global memory.
   // Round 2: every global read of the launch is issued before the first LDS phase -- g_top goes to LDS with
@@ -1181,7 +1199,7 @@ static int pc_prepare(femo_mesh* m, const uint8_t* mask, uint64_t key) {
 // zh = M^-1 rh in scaled variables; partials[block] = rh.zh per block (gv blocks)
 int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const double* s, const double* rh, double* out,
                   int mode, double* rho, const double* gamma_cur, double* gamma_nxt, const int32_t* done, int gv,
-                  bool rho_is_partial, const FemoPcgStop* stop, int nb_rho, const double* rho_partials) {
+                  bool rho_is_partial, const FemoPcgStop* stop, int nb_rho, const double* rho_partials, const FemoXUpdate* xupdate) {
   femo_pc* pc = m->pc;
   femo_ctx* ctx = m->ctx;
   FEMO_TRY(pc_prepare(m, mask, mask_key));
@@ -1232,6 +1250,8 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
   for (int l = 0; l + 1 < T; ++l) below += pc->L[l].nodes;
   const bool fused_cycle = nf >= 2 && T >= 2 && T < FEMO_PC_MAX_LEVELS - 1 && below * 2 * (int64_t)sizeof(double) <= 144 * 1024 &&
                            pc->L[T - 1].nodes <= 4096 && FEMO_TUNE_ENV("FEMO_BPX_UNFUSED_LATTICE") == nullptr;
+  pc->fused_cycle_seen = fused_cycle;
+  FEMO_REQUIRE(xupdate == nullptr || fused_cycle, "femo_pc_apply: the x update rides in the fused lattice cycle only");
   if (fused_cycle) {
     CoarseLevels CL;
     CL.n_levels = T - 1;                                           // levels 0 .. T-2 in LDS, e_{T-1} emitted
@@ -1257,7 +1277,13 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
       FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_coarse, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       pc->coarse_lds_set = true;
     }
-    hipLaunchKernelGGL(k_lattice_coarse, dim3(1), dim3(1024), lds, st, CL, pc->dim, done);
+    {
+      // one workgroup does the lattice work; with an x update to carry, one more per remaining compute unit
+      FemoXUpdate xu = {nullptr, nullptr, nullptr, 0};
+      unsigned grid = 1;
+      if (xupdate != nullptr && xupdate->n > 0) { xu = *xupdate; grid = (unsigned)std::max(2, ctx->n_cu); }
+      hipLaunchKernelGGL(k_lattice_coarse, dim3(grid), dim3(1024), lds, st, CL, pc->dim, done, xu);
+    }
     for (int l = T; l <= nl - 4; ++l) {                         // 2-D only (three fused levels): the level in between
       LatticeLevel& Fi = pc->L[l];
       hipLaunchKernelGGL(k_lattice_prolong, dim3(lat_grid(Fi.nodes)), dim3(256), 0, st, Fi.n[0], Fi.n[1], Fi.n[2], pc->L[l - 1].n[0], pc->L[l - 1].n[1], pc->L[l - 1].n[2], pc->dim, pc->L[l - 1].e, Fi.coef, G(l, par), 1, Fi.e, (double*)nullptr, (const double*)nullptr, done);
@@ -1311,7 +1337,7 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
         FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_coarse, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         pc->coarse_lds_set = true;
       }
-      hipLaunchKernelGGL(k_lattice_coarse, dim3(1), dim3(1024), lds, st, CL, pc->dim, done);
+      hipLaunchKernelGGL(k_lattice_coarse, dim3(1), dim3(1024), lds, st, CL, pc->dim, done, FemoXUpdate{nullptr, nullptr, nullptr, 0});
     }
     for (int l = cut; l < nl; ++l) {
       LatticeLevel& Fi = pc->L[l];
@@ -1361,6 +1387,11 @@ int femo_pc_begin(femo_mesh* m, const double* s, const uint8_t* mask) {
 }
 
 // can the PCG loop hand its partial rh.rh to femo_pc_apply instead of all-reducing it itself?
+
+bool femo_pc_carries_xupdate(const femo_mesh* m) {
+  static const bool off = femo_env_flag("FEMO_PCG_NO_XCARRY");
+  return !off && m->pc != nullptr && m->pc->fused_cycle_seen && m->ctx->nranks == 1;
+}
 
 bool femo_pc_can_piggyback(const femo_mesh* m) { return m->pc != nullptr && m->ctx->nranks > 1 && m->pc->shared_ready; }
 

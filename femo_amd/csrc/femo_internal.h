@@ -350,11 +350,21 @@ struct FemoPcgStop {
   int32_t* flags;
   int it;
 };
+// The solver's x += alpha p, carried by the idle compute units of the single-workgroup coarse-lattice kernel (round 3): the
+// update depends on nothing the preconditioner computes and nothing in the iteration waits for it, while k_lattice_coarse
+// keeps one CU busy for ~24 us at C4.  alpha: device scalar written by k_pcg_xr.  Taken only when femo_pc_carries_xupdate().
+struct FemoXUpdate {
+  double* x;
+  const double* p;
+  const double* alpha;
+  int64_t n;
+};
 // nb_rho > 0: rho = rh.rh is folded from rho_partials[0:nb_rho] inside the apply (and stored to *rho)
 int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const double* s, const double* rh, double* out,
                   int mode, double* rho, const double* gamma_cur, double* gamma_nxt, const int32_t* done, int gv,
                   bool rho_is_partial = false, const FemoPcgStop* stop = nullptr, int nb_rho = 0,
-                  const double* rho_partials = nullptr);
+                  const double* rho_partials = nullptr, const FemoXUpdate* xupdate = nullptr);
+bool femo_pc_carries_xupdate(const femo_mesh* m);   // after the first apply on the mesh: the fused lattice cycle runs
 bool femo_pc_can_piggyback(const femo_mesh* m);
 int femo_pc_begin(femo_mesh* m, const double* s, const uint8_t* mask);
 int femo_pc_levels(const femo_mesh* m, int* n_levels, int64_t* finest_nodes);

@@ -509,6 +509,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_cg_update_xp(int64_t n, int cur,
 // scal: [0],[1] = gamma = rh.zh of even/odd iterations, [2] = delta = ph.Ah ph, [3] = tol^2,
 // [4] = rho = rh.rh (the natural-norm residual the stopping test uses, same as Jacobi-CG).
 constexpr int S_RHO = 4;
+constexpr int S_ALPHA = 8;  // alpha of the current iteration (k_pcg_xr with carry_x: the x update runs inside the preconditioner)
 constexpr int S_TOLG = 5;   // rtol^2 * gamma_0: the stopping threshold on gamma = rh.zh (set on the device by the first apply)
 
 // out[0] = sum of `nb` partials (+ `nb2` partials of the next slot pair, overlapped SpMV)
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_pcg_xr(int64_t n, int cur, int n
                                                        double* __restrict__ scal,
                                                        const double* __restrict__ q, const double* __restrict__ p,
                                                        const double* r_in, double* r, double* __restrict__ xh,
-                                                       double* __restrict__ partials, const int32_t* __restrict__ done) {
+                                                       double* __restrict__ partials, const int32_t* __restrict__ done, int carry_x = 0) {
   // r = r_in - alpha q: in place (r_in == r) or into the other residual buffer when the restriction of the
   // caller keeps the old residual
   if (*done) return;
@@ -546,6 +547,25 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_pcg_xr(int64_t n, int cur, int n
   double2* r2 = reinterpret_cast<double2*>(r);
   const double2* r2_in = reinterpret_cast<const double2*>(r_in);
   double2* x2 = reinterpret_cast<double2*>(xh);
+  if (carry_x) {
+    // the residual only (3 of the 6 vector streams); x += alpha p is carried by the preconditioner's coarse-lattice launch
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[S_ALPHA] = alpha;
+    for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n2; i += (int64_t)gridDim.x * FEMO_BLOCK) {
+      const double2 qi = q2[i];
+      double2 ri = r2_in[i];
+      ri.x -= alpha * qi.x; ri.y -= alpha * qi.y;
+      r2[i] = ri;
+      s0 += ri.x * ri.x + ri.y * ri.y;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+      const double ri = r_in[n - 1] - alpha * q[n - 1];
+      r[n - 1] = ri;
+      s0 += ri * ri;
+    }
+    const double t = femo_block_sum<FEMO_BLOCK>(s0, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n2; i += (int64_t)gridDim.x * FEMO_BLOCK) {
     const double2 qi = q2[i], pi = p2[i];
     double2 ri = r2_in[i], xi = x2[i];
@@ -1234,6 +1254,9 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
   int n_ev = 0;
   const bool local_scalars = !multi && m->n_nbr == 0;
   const bool piggyback = multi && femo_pc_can_piggyback(m);
+  // x += alpha p inside the preconditioner's single-workgroup launch (the first apply, above, has settled whether the
+  // fused lattice cycle runs on this mesh)
+  const bool carry_x = local_scalars && femo_pc_carries_xupdate(m);
   const bool use_atol = opts->atol > 0.0;
   // Iterations are enqueued in batches and the host polls the "done" stamp; launches behind the converged iteration
   // return at once but still cost ~5 us each (6 per iteration).  Round 1: fixed batches of 8, polled two deep -- a
@@ -1278,6 +1301,10 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
           hipLaunchKernelGGL(k_pcg_xr, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, g1, Pd, S, w.q, w.p, (const double*)r_cur, r_cur, w.xh, Pr, ctx->d_flags);
           hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(1024), 0, st, it, gv, Pr, S, ctx->d_flags);
           FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, r_cur, w.p, 1, S + S_RHO, S + S_GAMMA + cur, S + S_GAMMA + nxt, ctx->d_flags, gv, false, &stop));
+        } else if (carry_x) {
+          hipLaunchKernelGGL(k_pcg_xr, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, g1, Pd, S, w.q, w.p, (const double*)r_cur, r_cur, w.xh, Pr, ctx->d_flags, 1);
+          const FemoXUpdate xu = {w.xh, w.p, S + S_ALPHA, n};
+          FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, r_cur, w.p, 1, S + S_RHO, S + S_GAMMA + cur, S + S_GAMMA + nxt, ctx->d_flags, gv, false, &stop, gv, Pr, &xu));
         } else {
           hipLaunchKernelGGL(k_pcg_xr, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, cur, g1, Pd, S, w.q, w.p, (const double*)r_cur, r_cur, w.xh, Pr, ctx->d_flags);
           FEMO_TRY(femo_pc_apply(m, mask, A->pc_key, A->d_s, r_cur, w.p, 1, S + S_RHO, S + S_GAMMA + cur, S + S_GAMMA + nxt, ctx->d_flags, gv, false, &stop, gv, Pr));
