@@ -65,6 +65,7 @@ struct femo_pc {
   uint32_t* d_pk = nullptr;         // packed lattice coordinates, dim words per owned vertex (vertex order)
   uint32_t* d_pk_sorted = nullptr;  // the same in sorted order
   double* d_w_sorted = nullptr;     // 1/s (0 on pinned vertices) in sorted order, refreshed per solve
+  double* d_sinv = nullptr;         // 1/s in mesh order (same reciprocals), refreshed per solve
   double* d_dot_partials = nullptr; // per-block partials of g_L.e_L (2048)
   // partitioned meshes: only the finest-lattice nodes that several ranks touch are exchanged
   bool shared_ready = false;
@@ -163,11 +164,15 @@ template <int D> struct Brick { static constexpr int B = D == 3 ? 4 : 8; static 
 
 // w_sorted[i] = 1/s of the i-th sorted vertex, 0 for pinned vertices (once per solve: s changes with
 // every assembly).  Leaves one gather (the residual) in the restriction's staging loop.
+// sinv[v] = 1/s of vertex v in mesh order: the mesh prolongation multiplies with the same rounded reciprocal (round 3: it
+// divided per vertex and iteration, ~12 of its ~100 instructions)
 __global__ void k_pc_weights(int64_t n, const int32_t* __restrict__ perm, const double* __restrict__ s,
-                             const uint8_t* __restrict__ mask, double* __restrict__ w) {
+                             const uint8_t* __restrict__ mask, double* __restrict__ w, double* __restrict__ sinv) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int32_t v = perm[i];
-    w[i] = (mask != nullptr && mask[v]) ? 0.0 : 1.0 / s[v];
+    const double r = 1.0 / s[v];
+    w[i] = (mask != nullptr && mask[v]) ? 0.0 : r;
+    sinv[v] = r;
   }
 }
 
@@ -469,7 +474,7 @@ struct PcgStop {
 
 template <int D>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat lat, const uint32_t* __restrict__ pk,
-                                                             const double* __restrict__ rh, const double* __restrict__ s,
+                                                             const double* __restrict__ rh, const double* __restrict__ sinv,
                                                              const uint8_t* __restrict__ mask, const double* __restrict__ e,
                                                              double* __restrict__ out, int mode, int nb_dot,
                                                              const double* __restrict__ dot_partials, const double* __restrict__ dot_global,
@@ -547,7 +552,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat
         }
         sum += w * e[node_index(lat.n, ijk[0], ijk[1], ijk[2])];
       }
-      z += sum * (1.0 / s[v]);     // the same rounded 1/s the restriction multiplies with
+      z += sum * sinv[v];          // the same rounded 1/s the restriction multiplies with (k_pc_weights)
     }
     out[v] = mode == 1 ? z + beta * out[v] : z;
   }
@@ -1018,6 +1023,7 @@ int femo_pc_build(femo_mesh* m) {
   FEMO_TRY(upload(&pc->d_bin_ptr, P.bin_ptr));
   FEMO_TRY(upload(&pc->d_brick_base, P.brick_base));
   FEMO_HIP_CHECK(hipMalloc(&pc->d_w_sorted, std::max<size_t>(P.perm.size(), 1) * sizeof(double)));
+  FEMO_HIP_CHECK(hipMalloc(&pc->d_sinv, std::max<size_t>(P.perm.size(), 1) * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&pc->d_dot_partials, 2048 * sizeof(double)));
   m->pc = pc;
   return 0;
@@ -1027,7 +1033,7 @@ void femo_pc_destroy(femo_mesh* m) {
   if (!m->pc) return;
   for (auto& L : m->pc->L) { (void)hipFree(L.e); (void)hipFree(L.coef); }
   (void)hipFree(m->pc->g_all);
-  (void)hipFree(m->pc->d_perm); (void)hipFree(m->pc->d_pk); (void)hipFree(m->pc->d_pk_sorted); (void)hipFree(m->pc->d_w_sorted); (void)hipFree(m->pc->d_dot_partials);
+  (void)hipFree(m->pc->d_perm); (void)hipFree(m->pc->d_pk); (void)hipFree(m->pc->d_pk_sorted); (void)hipFree(m->pc->d_w_sorted); (void)hipFree(m->pc->d_sinv); (void)hipFree(m->pc->d_dot_partials);
   (void)hipFree(m->pc->d_shared_idx); (void)hipFree(m->pc->d_dot_weight); (void)hipFree(m->pc->d_xbuf); (void)hipFree(m->pc->d_dot_scalar);
   (void)hipFree(m->pc->d_brick_ptr); (void)hipFree(m->pc->d_bin_ptr); (void)hipFree(m->pc->d_brick_base);
   delete m->pc;
@@ -1362,9 +1368,9 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
   ps.flags = stop ? stop->flags : nullptr;
   ps.it = stop ? stop->it : 0;
   if (pc->dim == 3)
-    hipLaunchKernelGGL(k_prolong_mesh<3>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, s, mask, F.e, out, mode, nb_dot, pc->d_dot_partials, dot_global, nb_rho, rho_partials, rho, gamma_cur, gamma_nxt, done, ps);
+    hipLaunchKernelGGL(k_prolong_mesh<3>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, pc->d_sinv, mask, F.e, out, mode, nb_dot, pc->d_dot_partials, dot_global, nb_rho, rho_partials, rho, gamma_cur, gamma_nxt, done, ps);
   else
-    hipLaunchKernelGGL(k_prolong_mesh<2>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, s, mask, F.e, out, mode, nb_dot, pc->d_dot_partials, dot_global, nb_rho, rho_partials, rho, gamma_cur, gamma_nxt, done, ps);
+    hipLaunchKernelGGL(k_prolong_mesh<2>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, pc->d_sinv, mask, F.e, out, mode, nb_dot, pc->d_dot_partials, dot_global, nb_rho, rho_partials, rho, gamma_cur, gamma_nxt, done, ps);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -1374,7 +1380,7 @@ int femo_pc_begin(femo_mesh* m, const double* s, const uint8_t* mask) {
   femo_pc* pc = m->pc;
   if (m->ctx->nranks > 1 && getenv("FEMO_BPX_DENSE_ALLREDUCE") == nullptr) FEMO_TRY(pc_setup_shared(m));   // once; uses d_w_sorted as scratch
   if (m->n_rows > 0) {
-    hipLaunchKernelGGL(k_pc_weights, dim3(lat_grid(m->n_rows)), dim3(256), 0, m->ctx->stream, m->n_rows, pc->d_perm, s, mask, pc->d_w_sorted);
+    hipLaunchKernelGGL(k_pc_weights, dim3(lat_grid(m->n_rows)), dim3(256), 0, m->ctx->stream, m->n_rows, pc->d_perm, s, mask, pc->d_w_sorted, pc->d_sinv);
     FEMO_HIP_CHECK(hipGetLastError());
   }
   const int nl = pc->n_levels;
