@@ -116,3 +116,129 @@ def test_one_rank_partition_is_the_whole_mesh():
     P = ShellPartition(G, 0, 1)
     assert P.owned_points.all() and P.nbr.size == 0 and P.send_dofs.size == 0
     assert np.array_equal(P.dof_global, np.arange(G.n_dof)) and np.array_equal(P.space.conn, G.conn)
+
+
+# ---- two real processes over gloo: the partitioned solver's algorithm in NumPy on the partition's plans ----------------
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shell_worker(rank, world, port, out_dir):
+    """What femo_shell_solve does on a partitioned handle, restated with SciPy: zeroed foreign rows, masked right-hand side,
+    halo refresh of the direction (isend / irecv on the plan's dof lists), all-reduced scalars, and the lattice
+    preconditioner with the restricted residual and the Galerkin operators summed over the ranks."""
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pts, conn = so.scordelis_lo_mesh(8, 6)
+    G = ShellSpace(pts, conn)
+    P = ShellPartition(G, rank, world)
+    Vl = so.ShellSpace(P.space.x, P.space.conn)
+    Vg = so.ShellSpace(pts, conn)
+    rng = np.random.default_rng(0)
+    h = 0.25 * (1.0 + 0.3 * rng.random(Vg.n_vert))
+    f = np.tile([0.0, 0.0, -90.0], (Vg.n_vert, 1))
+    nd = P.dof_global.size
+    own = P.owned_dofs
+    fixed_g = np.zeros(Vg.n_dof, dtype=bool)
+    fixed_g[_roof_fixed(Vg)] = True
+    fixed = fixed_g[P.dof_global]
+    free = sp.diags((~fixed).astype(float))
+    K = so.assemble(Vl, so.element_stiffness(Vl, h[P.vert_global], 4.32e8, 0.3)).tolil()
+    K[np.nonzero(~own)[0], :] = 0.0
+    K = (free @ K.tocsr() @ free).tocsr()                           # the rank's share, imposed rows / columns eliminated
+    b = so.load_vector(Vl, f[P.vert_global]) * own * (~fixed)
+
+    def allsum(a):
+        t = torch.from_numpy(np.ascontiguousarray(np.atleast_1d(np.asarray(a, dtype=np.float64))).copy())
+        dist.all_reduce(t)
+        return t.numpy()
+
+    def halo(v):
+        reqs, recv = [], []
+        for k, q in enumerate(P.nbr):
+            sb = torch.from_numpy(np.ascontiguousarray(v[P.send_dofs[P.send_ptr[k]:P.send_ptr[k + 1]]]))
+            rb = torch.zeros(int(P.recv_ptr[k + 1] - P.recv_ptr[k]), dtype=torch.float64)
+            reqs += [dist.isend(sb, int(q)), dist.irecv(rb, int(q))]
+            recv.append((k, rb, sb))
+        for r_ in reqs:
+            r_.wait()
+        for k, rb, _ in recv:
+            v[P.recv_dofs[P.recv_ptr[k]:P.recv_ptr[k + 1]]] = rb.numpy()
+
+    # preconditioner: Jacobi on the own rows + the global lattice levels with all-reduced Galerkin diagonals
+    L = P.lattice()
+    n_lat = L["n_lat"]
+    rows = np.repeat(np.arange(nd), L["width"])
+    Pl = (free @ sp.csr_matrix((L["ell_w"].ravel(), (rows, L["ell_idx"].ravel())), shape=(nd, n_lat))).tocsr()
+    gdiag = allsum((Pl.T @ K @ Pl).diagonal())
+    cinv = np.where(gdiag > 0.0, 1.0 / np.where(gdiag > 0.0, gdiag, 1.0), 0.0)
+    kd = K.diagonal()
+    dinv = np.where(kd > 0.0, 1.0 / np.where(kd > 0.0, kd, 1.0), 0.0)
+
+    def apply_pc(r):
+        return dinv * r + Pl @ (cinv * allsum(Pl.T @ r))            # the second term is consistent on every local point
+
+    x = np.zeros(nd)
+    r = b.copy()
+    z = apply_pc(r)
+    p = z.copy()
+    g = float(allsum(r @ z)[0])
+    g0, its = g, 0
+    while g > 1e-22 * g0 and its < 20000:
+        halo(p)
+        q = K @ p
+        a = g / float(allsum(p @ q)[0])
+        x += a * p
+        r -= a * q
+        z = apply_pc(r)
+        g1 = float(allsum(r @ z)[0])
+        p = z + (g1 / g) * p
+        g = g1
+        its += 1
+    halo(x)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=x, dofs=P.dof_global, own=own, its=its)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _roof_fixed(V):
+    ux, vx, L = V.unode_x, V.x, 25.0
+    on = lambda arr, val: np.nonzero(np.isclose(arr, val, atol=1e-6))[0]
+    return np.unique(np.concatenate([
+        V.u_dof(on(ux[:, 0], L), 1), V.u_dof(on(ux[:, 0], L), 2),
+        V.u_dof(on(ux[:, 1], 0.0), 1), V.theta_dof(on(vx[:, 1], 0.0), 0), V.theta_dof(on(vx[:, 1], 0.0), 2),
+        V.u_dof(on(ux[:, 0], 0.0), 0), V.theta_dof(on(vx[:, 0], 0.0), 1), V.theta_dof(on(vx[:, 0], 0.0), 2)]))
+
+
+def test_two_process_gloo_shell_solve(tmp_path):
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_shell_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    pts, conn = so.scordelis_lo_mesh(8, 6)
+    V = so.ShellSpace(pts, conn)
+    rng = np.random.default_rng(0)
+    h = 0.25 * (1.0 + 0.3 * rng.random(V.n_vert))
+    K = so.assemble(V, so.element_stiffness(V, h, 4.32e8, 0.3))
+    wref = so.solve(K, so.load_vector(V, np.tile([0.0, 0.0, -90.0], (V.n_vert, 1))), _roof_fixed(V))
+    w = np.full(V.n_dof, np.nan)
+    its = set()
+    for r in range(world):
+        d = np.load(tmp_path / f"rank{r}.npz")
+        w[d["dofs"][d["own"]]] = d["x"][d["own"]]
+        its.add(int(d["its"]))
+        # ghost copies were refreshed from their owners
+    assert not np.isnan(w).any() and len(its) == 1 and 10 < its.pop() < 20000
+    for r in range(world):
+        d = np.load(tmp_path / f"rank{r}.npz")
+        assert np.abs(d["x"] - w[d["dofs"]]).max() <= 1e-13 * np.abs(w).max()
+    assert np.abs(w - wref).max() <= 1e-8 * np.abs(wref).max()
