@@ -171,3 +171,41 @@ def test_a_multi_rank_context_needs_a_partition():
         return True
 
     assert all(_run_ranks(2, rank_fn))
+
+
+def test_warped_plate_on_four_ranks():
+    """An irregular surface (warped, jittered plate, clamped rim) on four ranks: a rank in the middle of the cut has several
+    neighbours, ghost points of three owners meet in its cells."""
+    from femo_amd.dist.shell import ShellPartition
+    from femo_amd.fea.shell import ShellProblem, ShellSpace
+    pts, conn = so.plate_mesh(14)
+    rng = np.random.default_rng(4)
+    interior = (pts[:, 0] > 1e-9) & (pts[:, 0] < 1 - 1e-9) & (pts[:, 1] > 1e-9) & (pts[:, 1] < 1 - 1e-9)
+    pts = pts.copy()
+    pts[interior, :2] += 0.015 * rng.standard_normal((int(interior.sum()), 2))
+    pts[:, 2] = 0.05 * np.sin(3 * pts[:, 0]) * np.cos(2 * pts[:, 1])
+    V = so.ShellSpace(pts, conn)
+    G = ShellSpace(pts, conn)
+    rim_u = np.nonzero(np.isclose(V.unode_x[:, 0], 0) | np.isclose(V.unode_x[:, 0], 1) | np.isclose(V.unode_x[:, 1], 0) | np.isclose(V.unode_x[:, 1], 1))[0]
+    rim_v = np.nonzero(~interior)[0]
+    fixed = np.unique(np.concatenate([V.u_dof(rim_u, k) for k in range(3)] + [V.theta_dof(rim_v, k) for k in range(3)]))
+    h = 0.02 * (1.0 + 0.2 * rng.random(V.n_vert))
+    f = np.tile([0.0, 0.0, -1.0], (V.n_vert, 1)) * (1.0 + 0.3 * rng.random((V.n_vert, 1)))
+    Ey, nu = 1.0e7, 0.3
+    K = so.assemble(V, so.element_stiffness(V, h, Ey, nu))
+    wref = so.solve(K, so.load_vector(V, f), fixed)
+    world = 4
+
+    def rank_fn(rank, ctx):
+        P = ShellPartition(G, rank, world)
+        prob = ShellProblem(pts, conn, Ey, nu, fixed_dofs=fixed, ctx=ctx, partition=P)
+        prob.set_thickness(h)
+        prob.set_load(f)
+        w = prob.solve()
+        return P, w, prob.last_info.iterations, len(P.nbr)
+
+    res = _run_ranks(world, rank_fn)
+    w = _gather([r[0] for r in res], [r[1] for r in res], V.n_dof)
+    assert len({r[2] for r in res}) == 1 and max(r[3] for r in res) >= 2
+    print(f"warped plate on 4 ranks: {rel(w, wref):.2e}, {res[0][2]} iterations, neighbours {[r[3] for r in res]}")
+    assert rel(w, wref) <= 1e-8
