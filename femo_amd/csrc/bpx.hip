@@ -1395,7 +1395,7 @@ int femo_pc_begin(femo_mesh* m, const double* s, const uint8_t* mask) {
 // can the PCG loop hand its partial rh.rh to femo_pc_apply instead of all-reducing it itself?
 
 bool femo_pc_carries_xupdate(const femo_mesh* m) {
-  static const bool off = femo_env_flag("FEMO_PCG_NO_XCARRY");
+  const bool off = femo_env_flag("FEMO_PCG_NO_XCARRY");        // read per solve (a test switches it), never per launch
   return !off && m->pc != nullptr && m->pc->fused_cycle_seen && m->ctx->nranks == 1;
 }
 

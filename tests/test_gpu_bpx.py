@@ -110,6 +110,27 @@ def test_bpx_refuses_other_operators(ctx):
     assert M.solve_cg(b, x, pc="jacobi").converged == 1
 
 
+@pytest.mark.parametrize("d,n", [(3, 40), (2, 160), (3, 15)])
+def test_carried_x_update_is_the_old_loop(ctx, monkeypatch, d, n):
+    """Round 3: x += alpha p rides in the coarse-lattice launch of the preconditioner when the fused lattice cycle runs (the
+    two larger meshes; on the small one the loop is the old one either way).  Same arithmetic on the same numbers: iteration
+    count and solution are those of the loop with the update in k_pcg_xr (FEMO_PCG_NO_XCARRY)."""
+    from femo_amd import engine as E
+    m = fo.unit_square_mesh(n, 0.1) if d == 2 else fo.unit_cube_mesh(n, 0.1)
+    dm, bc, A, b = _poisson_system(ctx, m, seed=4)
+    x0, x1 = E.Vec(ctx, m.n_vert), E.Vec(ctx, m.n_vert)
+    monkeypatch.delenv("FEMO_PCG_NO_XCARRY", raising=False)
+    i0 = A.solve_cg(b, x0, rtol=1e-11, pc="bpx")
+    monkeypatch.setenv("FEMO_PCG_NO_XCARRY", "1")
+    i1 = A.solve_cg(b, x1, rtol=1e-11, pc="bpx")
+    monkeypatch.delenv("FEMO_PCG_NO_XCARRY")
+    assert i0.converged == 1 and i1.converged == 1 and i0.iterations == i1.iterations > 5
+    # (not bit for bit: the brick restriction flushes its node sums with atomics, so two runs of ONE loop differ in the last bits too)
+    assert _rel(x0.get(), x1.get()) < 1e-12
+    x_ref = spla.spsolve(A.to_scipy().tocsc(), b.get())
+    assert _rel(x0.get(), x_ref) < 1e-9
+
+
 def test_bpx_allreduce_path_on_one_rank(monkeypatch):
     """FEMO_FORCE_MULTI routes the lattice and scalar all-reduces through a 1-rank communicator,
     and the self-halo mesh of test_gpu_dist exercises the overlapped SpMV inside the BPX loop."""
