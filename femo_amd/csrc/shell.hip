@@ -80,6 +80,7 @@ struct femo_shell {
   int32_t *d_cs_xyz = nullptr, *d_cs_pts = nullptr, *d_cs_nbr = nullptr, *d_cs_info = nullptr, *d_cs_pcell = nullptr;
   int64_t* d_cs_ptr = nullptr;
   double *d_cs_A = nullptr, *d_cs_tmp = nullptr;       // L^-T above / L^-1 below the diagonal (row-major, N x N); L^-1 g
+  float* d_cs_Af = nullptr;                            // the same factors in single precision: what the iteration applies
   double* d_cs_dinv = nullptr;                         // inverses of the diagonal tiles of L
   // penalty boundary terms (femo_shell_set_penalty): tagged edges, their coefficient and the CSR positions of their entries
   int64_t pen_n = 0;
@@ -1493,9 +1494,17 @@ __global__ void k_pc_coarse_mirror(int64_t N, double* __restrict__ A) {
   if (cidx < N && cidx / DT > r / DT) A[cidx * N + r] = A[r * N + cidx];
 }
 
+// the factors of the coarse inverse as the iteration reads them: single precision (round 3).  M_c^-1 = B^T B with B = fl32(L^-1)
+// is symmetric positive semi-definite whatever the rounding did, a relative 6e-8 away from the fp64 one -- nothing an
+// iteration count sees --, and the two triangular products per iteration stream half the bytes (products and sums in fp64).
+__global__ void k_pc_coarse_to_float(int64_t count, const double* __restrict__ A, float* __restrict__ Af) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) Af[i] = (float)A[i];
+}
+
 // one workgroup per row of the triangular factor: lower = 1: y = L^-1 x (entries 0 .. r of row r); 0: y = L^-T x (r .. n).
 // (A wave per row took 25 us per pass at n = 3060: the long rows are 24 dependent rounds of loads for one wave.)
-__global__ __launch_bounds__(SH_BLOCK) void k_pc_coarse_apply(int64_t n, int64_t N, int lower, const double* __restrict__ W, const double* __restrict__ x,
+template <class T>
+__global__ __launch_bounds__(SH_BLOCK) void k_pc_coarse_apply(int64_t n, int64_t N, int lower, const T* __restrict__ W, const double* __restrict__ x,
                                                               double* __restrict__ y, const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
   __shared__ double lds[SH_BLOCK / 64];
@@ -1504,10 +1513,10 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_coarse_apply(int64_t n, int64_t
   for (int h = 0; h < 2; ++h) {
     const int64_t r = h == 0 ? pair : n - 1 - pair;
     if (h == 1 && r <= pair) break;
-    const double* row = W + r * N;
+    const T* row = W + r * N;
     const int64_t k0 = lower ? 0 : r, k1 = lower ? r + 1 : n;
     double s = 0.0;
-    for (int64_t k = k0 + threadIdx.x; k < k1; k += SH_BLOCK) s += row[k] * x[k];
+    for (int64_t k = k0 + threadIdx.x; k < k1; k += SH_BLOCK) s += (double)row[k] * x[k];
     __syncthreads();
     const double t = femo_block_sum<SH_BLOCK>(s, lds);
     if (threadIdx.x == 0) y[r] = t;
@@ -2190,7 +2199,7 @@ int femo_shell_destroy(femo_shell* s) {
   hipStreamSynchronize(s->ctx->stream);
   hipFree(s->d_x); hipFree(s->d_conn); hipFree(s->d_cedge); hipFree(s->d_rowptr); hipFree(s->d_cols); hipFree(s->d_epos); hipFree(s->d_brow); hipFree(s->d_bcols); hipFree(s->d_bs_off); hipFree(s->d_bs_cols); hipFree(s->d_bs_vals);
   hipFree(s->d_ptp_rowptr); hipFree(s->d_ptp_cols); hipFree(s->d_ptp_vals);
-  hipFree(s->d_cs_xyz); hipFree(s->d_cs_ptr); hipFree(s->d_cs_pts); hipFree(s->d_cs_nbr); hipFree(s->d_cs_A); hipFree(s->d_cs_tmp); hipFree(s->d_cs_dinv); hipFree(s->d_cs_info); hipFree(s->d_cs_pcell);
+  hipFree(s->d_cs_xyz); hipFree(s->d_cs_ptr); hipFree(s->d_cs_pts); hipFree(s->d_cs_nbr); hipFree(s->d_cs_A); hipFree(s->d_cs_Af); hipFree(s->d_cs_tmp); hipFree(s->d_cs_dinv); hipFree(s->d_cs_info); hipFree(s->d_cs_pcell);
   hipFree(s->d_cd_rowptr); hipFree(s->d_cd_cols); hipFree(s->d_cd_vals);
   hipFree(s->d_pen_nodes); hipFree(s->d_pen_pos); hipFree(s->d_pen_coef);
   hipFree(s->d_owned); hipFree(s->d_send_idx); hipFree(s->d_recv_idx); hipFree(s->d_send_buf); hipFree(s->d_recv_buf);
@@ -2313,6 +2322,7 @@ static int shell_pc_coarse_setup(femo_shell* s, const femo_vec* vals, const uint
   for (int i = 1; i < nblk; ++i) hipLaunchKernelGGL(k_trinv_row, dim3(i), dim3(256), 0, st, N, i, s->d_cs_A, s->d_cs_dinv);
   hipLaunchKernelGGL(k_trinv_diag, dim3(nblk), dim3(256), 0, st, N, s->d_cs_A, s->d_cs_dinv);
   hipLaunchKernelGGL(k_pc_coarse_mirror, dim3(sgrid(N, 256), (unsigned)N), dim3(256), 0, st, N, s->d_cs_A);
+  if (s->d_cs_Af != nullptr) hipLaunchKernelGGL(k_pc_coarse_to_float, dim3(2048), dim3(256), 0, st, N * N, s->d_cs_A, s->d_cs_Af);
   FEMO_HIP_CHECK(hipGetLastError());
   int32_t info[4] = {0, 0, 0, 0};
   FEMO_HIP_CHECK(hipMemcpyAsync(info, s->d_cs_info, sizeof info, hipMemcpyDeviceToHost, st));
@@ -2378,10 +2388,17 @@ static int shell_pc_apply(femo_shell* s, const uint8_t* d_fixed, double* Prz, un
       }
     }
     const unsigned gp = (unsigned)((s->cs_n + 1) / 2);
-    hipLaunchKernelGGL(k_pc_coarse_apply, dim3(gp), dim3(SH_BLOCK), 0, st, s->cs_n, s->cs_N, 1, s->d_cs_A,
-                       s->d_t + 6 * s->level_off[cs], s->d_cs_tmp, done);
-    hipLaunchKernelGGL(k_pc_coarse_apply, dim3(gp), dim3(SH_BLOCK), 0, st, s->cs_n, s->cs_N, 0, s->d_cs_A, s->d_cs_tmp,
-                       s->d_e + 6 * s->level_off[cs], done);
+    if (s->d_cs_Af != nullptr) {
+      hipLaunchKernelGGL(k_pc_coarse_apply<float>, dim3(gp), dim3(SH_BLOCK), 0, st, s->cs_n, s->cs_N, 1, (const float*)s->d_cs_Af,
+                         s->d_t + 6 * s->level_off[cs], s->d_cs_tmp, done);
+      hipLaunchKernelGGL(k_pc_coarse_apply<float>, dim3(gp), dim3(SH_BLOCK), 0, st, s->cs_n, s->cs_N, 0, (const float*)s->d_cs_Af, s->d_cs_tmp,
+                         s->d_e + 6 * s->level_off[cs], done);
+    } else {
+      hipLaunchKernelGGL(k_pc_coarse_apply<double>, dim3(gp), dim3(SH_BLOCK), 0, st, s->cs_n, s->cs_N, 1, (const double*)s->d_cs_A,
+                         s->d_t + 6 * s->level_off[cs], s->d_cs_tmp, done);
+      hipLaunchKernelGGL(k_pc_coarse_apply<double>, dim3(gp), dim3(SH_BLOCK), 0, st, s->cs_n, s->cs_N, 0, (const double*)s->d_cs_A, s->d_cs_tmp,
+                         s->d_e + 6 * s->level_off[cs], done);
+    }
     for (int l = cs + 1; l < L; ++l) level_up(l, s->blk_ready ? s->d_cblk : (const double*)nullptr);
   } else {
   // levels 0 .. kc (at most 256 nodes each, never the finest: with 4096 the one workgroup took 244 us, with 768 still 71) go through the fused single-workgroup kernel
@@ -2427,6 +2444,7 @@ int femo_shell_pc_coarse(femo_shell* s, int level, const int32_t* node_xyz, int6
   FEMO_TRY(to_device(&s->d_cs_nbr, item_nbr, n_items * 64, st));
   const int64_t N = (n + DT - 1) / DT * DT;
   FEMO_HIP_CHECK(hipMalloc(&s->d_cs_A, N * N * sizeof(double)));
+  if (!femo_env_flag("FEMO_SHELL_COARSE_FP64")) FEMO_HIP_CHECK(hipMalloc(&s->d_cs_Af, N * N * sizeof(float)));
   FEMO_HIP_CHECK(hipMalloc(&s->d_cs_tmp, N * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&s->d_cs_dinv, N * DT * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&s->d_cs_info, 4 * sizeof(int32_t)));
