@@ -59,7 +59,9 @@ struct femo_shell {
                                                         // all levels of a dof: 3 cache lines per access, 52 GB fetched by the
                                                         // node-block kernel at 1.97 M dofs)
   bool blk_ready = false;
-  double* d_dinv3 = nullptr;                            // 3 x 3 inverse diagonal blocks of the points (finest-level smoother)
+  float* d_dinv3 = nullptr;                             // 3 x 3 inverse diagonal blocks of the points (finest-level smoother), single
+                                                        // precision: a smoother rounded at 6e-8 is as good a smoother, products and sums stay fp64
+                                                        // (round 3: 72 -> 36 bytes per point in both kernels that read it, every iteration)
   bool dinv3_ready = false;
   int32_t* d_fin_idx = nullptr;                         // the finest level's eight (unknown, weight) pairs per POINT (a P2 node's
   double* d_fin_w = nullptr;                            // three displacements / a vertex's three rotations share them)
@@ -1751,7 +1753,7 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_galerkin_blocks(int64_t n_pts, 
 // inverse of the 3 x 3 diagonal block of every point (imposed dofs: unit row and column), the smoother of the finest
 // level in place of 1 / diag: it sees the coupling of a node's three displacement (rotation) components
 __global__ void k_pt_block_inv(int64_t n_pts, const int64_t* __restrict__ brow, const int32_t* __restrict__ bcols,
-                               const double* __restrict__ vals, const uint8_t* __restrict__ fixed, double* __restrict__ dinv3,
+                               const double* __restrict__ vals, const uint8_t* __restrict__ fixed, float* __restrict__ dinv3,
                                double* __restrict__ dinv) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_pts) return;
@@ -1781,14 +1783,14 @@ __global__ void k_pt_block_inv(int64_t n_pts, const int64_t* __restrict__ brow, 
   const double c00 = a[1][1] * a[2][2] - s12 * s12, c01 = s02 * s12 - s01 * a[2][2], c02 = s01 * s12 - s02 * a[1][1];
   const double c11 = a[0][0] * a[2][2] - s02 * s02, c12 = s01 * s02 - a[0][0] * s12, c22 = a[0][0] * a[1][1] - s01 * s01;
   const double det = a[0][0] * c00 + s01 * c01 + s02 * c02;
-  double* B = dinv3 + 9 * p;
+  float* B = dinv3 + 9 * p;
   if (det > 0.0 && c00 > 0.0 && c22 > 0.0) {
     const double id = 1.0 / det;
-    B[0] = c00 * id; B[1] = c01 * id; B[2] = c02 * id;
-    B[3] = c01 * id; B[4] = c11 * id; B[5] = c12 * id;
-    B[6] = c02 * id; B[7] = c12 * id; B[8] = c22 * id;
+    B[0] = (float)(c00 * id); B[1] = (float)(c01 * id); B[2] = (float)(c02 * id);
+    B[3] = (float)(c01 * id); B[4] = (float)(c11 * id); B[5] = (float)(c12 * id);
+    B[6] = (float)(c02 * id); B[7] = (float)(c12 * id); B[8] = (float)(c22 * id);
   } else {                                                 // not positive definite in floating point: plain Jacobi for this point
-    B[0] = 1.0 / a[0][0]; B[1] = 0.0; B[2] = 0.0; B[3] = 0.0; B[4] = 1.0 / a[1][1]; B[5] = 0.0; B[6] = 0.0; B[7] = 0.0; B[8] = 1.0 / a[2][2];
+    B[0] = (float)(1.0 / a[0][0]); B[1] = 0.f; B[2] = 0.f; B[3] = 0.f; B[4] = (float)(1.0 / a[1][1]); B[5] = 0.f; B[6] = 0.f; B[7] = 0.f; B[8] = (float)(1.0 / a[2][2]);
   }
 }
 
@@ -1865,7 +1867,7 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong(int64_t n_pts, const in
                                                          const uint8_t* __restrict__ fixed, const double* __restrict__ dinv,
                                                          const double* __restrict__ r, const double* __restrict__ t, double* __restrict__ z,
                                                          double* __restrict__ partials, const int32_t* __restrict__ done,
-                                                         const double* __restrict__ dinv3 = nullptr) {
+                                                         const float* __restrict__ dinv3 = nullptr) {
   if (done != nullptr && *done) return;
   __shared__ double lds[SH_BLOCK / 64];
   constexpr int SUB = 8;
@@ -1888,8 +1890,9 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong(int64_t n_pts, const in
       const double ri = r[row];
       double sm;                                           // the smoother: point-block (3 x 3) or plain Jacobi
       if (dinv3 != nullptr) {
-        const Triple B = *reinterpret_cast<const Triple*>(dinv3 + 9 * p + 3 * sl), rp = *reinterpret_cast<const Triple*>(r + 3 * p);
-        sm = B.a * rp.a + B.b * rp.b + B.c * rp.c;
+        const float* B = dinv3 + 9 * p + 3 * sl;
+        const Triple rp = *reinterpret_cast<const Triple*>(r + 3 * p);
+        sm = (double)B[0] * rp.a + (double)B[1] * rp.b + (double)B[2] * rp.c;
       } else {
         sm = dinv[row] * ri;
       }
@@ -1944,7 +1947,7 @@ __global__ __launch_bounds__(SH_BLOCK) void k_scg_p_z(int64_t n, int it, int nb_
 // smoother block (or 1 / diag): the first half of r . z = r . B r + (P^T r) . e  (see k_lat_level, k_pc_prolong_fused)
 __global__ __launch_bounds__(SH_BLOCK) void k_scg_xr_pt(int64_t n_pts, int nb_pq, const double* __restrict__ part_pq, const double* __restrict__ scal,
                                                         const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ dinv,
-                                                        const double* __restrict__ dinv3, double* __restrict__ x, double* __restrict__ r,
+                                                        const float* __restrict__ dinv3, double* __restrict__ x, double* __restrict__ r,
                                                         double* __restrict__ part_rB, const int32_t* __restrict__ done) {
   if (*done) return;
   __shared__ double lds[SH_BLOCK / 64];
@@ -1959,9 +1962,9 @@ __global__ __launch_bounds__(SH_BLOCK) void k_scg_xr_pt(int64_t n_pts, int nb_pq
     *reinterpret_cast<Triple*>(x + 3 * i) = xx;
     *reinterpret_cast<Triple*>(r + 3 * i) = rr;
     if (dinv3 != nullptr) {
-      const double* B = dinv3 + 9 * i;
-      s += rr.a * (B[0] * rr.a + B[1] * rr.b + B[2] * rr.c) + rr.b * (B[3] * rr.a + B[4] * rr.b + B[5] * rr.c) +
-           rr.c * (B[6] * rr.a + B[7] * rr.b + B[8] * rr.c);
+      const float* B = dinv3 + 9 * i;
+      s += rr.a * ((double)B[0] * rr.a + (double)B[1] * rr.b + (double)B[2] * rr.c) + rr.b * ((double)B[3] * rr.a + (double)B[4] * rr.b + (double)B[5] * rr.c) +
+           rr.c * ((double)B[6] * rr.a + (double)B[7] * rr.b + (double)B[8] * rr.c);
     } else {
       s += rr.a * rr.a * dinv[3 * i] + rr.b * rr.b * dinv[3 * i + 1] + rr.c * rr.c * dinv[3 * i + 2];
     }
@@ -1977,7 +1980,7 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong_fused(int64_t n_pts, in
                                                                const double* __restrict__ part_te, double* __restrict__ scal,
                                                                const int32_t* __restrict__ fin_idx, const double* __restrict__ fin_w,
                                                                const uint8_t* __restrict__ fixed, const double* __restrict__ dinv,
-                                                               const double* __restrict__ dinv3, const double* __restrict__ r,
+                                                               const float* __restrict__ dinv3, const double* __restrict__ r,
                                                                const double* __restrict__ t, double* __restrict__ p,
                                                                int32_t* __restrict__ flag, double* __restrict__ gamma_out) {
   if (flag[0]) return;
@@ -2005,8 +2008,9 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong_fused(int64_t n_pts, in
         const bool rf = fixed != nullptr && fixed[row];
         double sm;
         if (dinv3 != nullptr) {
-          const Triple B = *reinterpret_cast<const Triple*>(dinv3 + 9 * pt + 3 * sl), rp = *reinterpret_cast<const Triple*>(r + 3 * pt);
-          sm = B.a * rp.a + B.b * rp.b + B.c * rp.c;
+          const float* B = dinv3 + 9 * pt + 3 * sl;
+          const Triple rp = *reinterpret_cast<const Triple*>(r + 3 * pt);
+          sm = (double)B[0] * rp.a + (double)B[1] * rp.b + (double)B[2] * rp.c;
         } else {
           sm = dinv[row] * r[row];
         }
@@ -2278,7 +2282,7 @@ int femo_shell_pc_create(femo_shell* s, int width, int64_t n_nodes, int n_levels
   }
   FEMO_HIP_CHECK(hipMalloc(&s->d_coarse, n_lat * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&s->d_cblk, n_nodes * 36 * sizeof(double)));
-  FEMO_HIP_CHECK(hipMalloc(&s->d_dinv3, (s->n_dof / 3) * 9 * sizeof(double)));
+  FEMO_HIP_CHECK(hipMalloc(&s->d_dinv3, (s->n_dof / 3) * 9 * sizeof(float)));
   FEMO_HIP_CHECK(hipMalloc(&s->d_t, n_lat * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&s->d_e, n_lat * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&s->d_z, s->n_dof * sizeof(double)));
@@ -2420,7 +2424,7 @@ static int shell_pc_apply(femo_shell* s, const uint8_t* d_fixed, double* Prz, un
   }
   if (Pte != nullptr) { FEMO_HIP_CHECK(hipGetLastError()); return 0; }
   hipLaunchKernelGGL(k_pc_prolong, dim3(gz), dim3(SH_BLOCK), 0, st, s->n_dof / 3, s->d_fin_idx, s->d_fin_w, d_fixed, s->d_dinv, s->d_r, s->d_e,
-                     s->d_z, Prz, done, s->dinv3_ready ? s->d_dinv3 : (const double*)nullptr);
+                     s->d_z, Prz, done, s->dinv3_ready ? s->d_dinv3 : (const float*)nullptr);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -3000,10 +3004,10 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
         // per iteration than the unfused form below)
         int nb_te = 0;
         hipLaunchKernelGGL(k_scg_xr_pt, dim3(gx), dim3(SH_BLOCK), 0, st, n / 3, (int)gs, Ppq, s->d_scal, s->d_p, s->d_q, s->d_dinv,
-                           s->dinv3_ready ? s->d_dinv3 : (const double*)nullptr, x->d, s->d_r, Prz, s->d_flag);
+                           s->dinv3_ready ? s->d_dinv3 : (const float*)nullptr, x->d, s->d_r, Prz, s->d_flag);
         FEMO_TRY(shell_pc_apply(s, d_fixed, Prz, gz, s->d_flag, Pte, &nb_te));
         hipLaunchKernelGGL(k_pc_prolong_fused, dim3(gz), dim3(SH_BLOCK), 0, st, n / 3, it, (int)gx, Prz, nb_te, Pte, s->d_scal, s->d_fin_idx, s->d_fin_w,
-                           d_fixed, s->d_dinv, s->dinv3_ready ? s->d_dinv3 : (const double*)nullptr, s->d_r, s->d_e, s->d_p, s->d_flag, gam);
+                           d_fixed, s->d_dinv, s->dinv3_ready ? s->d_dinv3 : (const float*)nullptr, s->d_r, s->d_e, s->d_p, s->d_flag, gam);
       } else if (lattice) {
         hipLaunchKernelGGL(k_scg_xr_plain, dim3(gv), dim3(SH_BLOCK), 0, st, n, (int)gs, Ppq, s->d_scal, s->d_p, s->d_q, x->d, s->d_r, s->d_flag);
         FEMO_TRY(shell_pc_apply(s, d_fixed, Prz, gz, s->d_flag));
