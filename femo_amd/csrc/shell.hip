@@ -64,10 +64,11 @@ struct femo_shell {
                                                         // (round 3: 72 -> 36 bytes per point in both kernels that read it, every iteration)
   bool dinv3_ready = false;
   int32_t* d_fin_idx = nullptr;                         // the finest level's eight (unknown, weight) pairs per POINT (a P2 node's
-  double* d_fin_w = nullptr;                            // three displacements / a vertex's three rotations share them)
+  float* d_fin_w = nullptr;                             // three displacements / a vertex's three rotations share them); single
+                                                        // precision like d_ptp_vals -- the same rounded numbers in both directions, so M^-1 stays symmetric
   int64_t* d_ptp_rowptr = nullptr;                      // P_L^T by (finest lattice node, field group): points and weights
   int32_t* d_ptp_cols = nullptr;
-  double* d_ptp_vals = nullptr;
+  float* d_ptp_vals = nullptr;
   int64_t *d_par_rowptr = nullptr, *d_chi_rowptr = nullptr;
   uint64_t pc_vals_uid = 0, pc_vals_gen = 0, pc_mask_hash = 0;     // what d_coarse was computed for
   // exact coarse solve (femo_shell_pc_coarse): on level cs_level the Galerkin operator P^T K P is formed as a dense
@@ -1568,7 +1569,7 @@ __global__ __launch_bounds__(1024) void k_lat_coarse_fused(LatLevels Lv, const i
 // 3 p) that touch the node and their weights, SUB lanes per row, three components at a time
 template <int SUB>
 __global__ __launch_bounds__(SH_BLOCK) void k_pc_restrict(int64_t m0, int64_t m1, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
-                                                          const double* __restrict__ vals, const double* __restrict__ r, double* __restrict__ g,
+                                                          const float* __restrict__ vals, const double* __restrict__ r, double* __restrict__ g,
                                                           const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
   const int sl = threadIdx.x & (SUB - 1);
@@ -1579,7 +1580,7 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_restrict(int64_t m0, int64_t m1
     const int64_t e1 = rowptr[row + 1];
     for (int64_t e = rowptr[row] + sl; e < e1; e += SUB) {
       const int32_t c = cols[e];
-      const double w = vals[e];
+      const double w = (double)vals[e];
       const Triple rc = *reinterpret_cast<const Triple*>(r + c);
       s0 += w * rc.a;
       s1 += w * rc.b;
@@ -1863,7 +1864,7 @@ __global__ __launch_bounds__(SH_BLOCK) void k_lat_down_composite(int64_t row0, i
 
 // z = D^-1 r + P_L e_L (8 lanes per point, one finest-level entry each, three components) and the per-block partial of
 // r.z; imposed dofs: z = 0
-__global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong(int64_t n_pts, const int32_t* __restrict__ fin_idx, const double* __restrict__ fin_w,
+__global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong(int64_t n_pts, const int32_t* __restrict__ fin_idx, const float* __restrict__ fin_w,
                                                          const uint8_t* __restrict__ fixed, const double* __restrict__ dinv,
                                                          const double* __restrict__ r, const double* __restrict__ t, double* __restrict__ z,
                                                          double* __restrict__ partials, const int32_t* __restrict__ done,
@@ -1875,7 +1876,7 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong(int64_t n_pts, const in
   const int64_t nsub = (int64_t)gridDim.x * (SH_BLOCK / SUB);
   double dot = 0.0;
   for (int64_t p = (int64_t)blockIdx.x * (SH_BLOCK / SUB) + (threadIdx.x / SUB); p < n_pts; p += nsub) {
-    const double w = fin_w[p * 8 + sl];
+    const double w = (double)fin_w[p * 8 + sl];
     const Triple tp = *reinterpret_cast<const Triple*>(t + fin_idx[p * 8 + sl]);
     double s0 = w * tp.a, s1 = w * tp.b, s2 = w * tp.c;
 #pragma unroll
@@ -1978,7 +1979,7 @@ __global__ __launch_bounds__(SH_BLOCK) void k_scg_xr_pt(int64_t n_pts, int nb_pq
 // writes p = z + beta p directly -- z = B r + P_L e_L is never stored, k_scg_p_z and its three vector streams are gone.
 __global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong_fused(int64_t n_pts, int it, int nb_rB, const double* __restrict__ part_rB, int nb_te,
                                                                const double* __restrict__ part_te, double* __restrict__ scal,
-                                                               const int32_t* __restrict__ fin_idx, const double* __restrict__ fin_w,
+                                                               const int32_t* __restrict__ fin_idx, const float* __restrict__ fin_w,
                                                                const uint8_t* __restrict__ fixed, const double* __restrict__ dinv,
                                                                const float* __restrict__ dinv3, const double* __restrict__ r,
                                                                const double* __restrict__ t, double* __restrict__ p,
@@ -1994,7 +1995,7 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong_fused(int64_t n_pts, in
     const int sl = threadIdx.x & (SUB - 1);
     const int64_t nsub = (int64_t)gridDim.x * (SH_BLOCK / SUB);
     for (int64_t pt = (int64_t)blockIdx.x * (SH_BLOCK / SUB) + (threadIdx.x / SUB); pt < n_pts; pt += nsub) {
-      const double w = fin_w[pt * 8 + sl];
+      const double w = (double)fin_w[pt * 8 + sl];
       const Triple tp = *reinterpret_cast<const Triple*>(t + fin_idx[pt * 8 + sl]);
       double s0 = w * tp.a, s1 = w * tp.b, s2 = w * tp.c;
 #pragma unroll
@@ -2245,12 +2246,12 @@ int femo_shell_pc_create(femo_shell* s, int width, int64_t n_nodes, int n_levels
     const int64_t n_pts = s->n_dof / 3;
     FEMO_REQUIRE(s->n_dof % 3 == 0, "dofs are not numbered 3 point + component");
     std::vector<int32_t> fi((size_t)n_pts * 8);
-    std::vector<double> fw((size_t)n_pts * 8);
+    std::vector<float> fw((size_t)n_pts * 8);
     for (int64_t p = 0; p < n_pts; ++p)
       for (int a = 0; a < 8; ++a) {
         const int64_t e0 = (3 * p) * width + (width - 8) + a;
         fi[(size_t)p * 8 + a] = ell_idx[e0];                      // unknown of component 0; components 1, 2 follow it
-        fw[(size_t)p * 8 + a] = ell_w[e0];
+        fw[(size_t)p * 8 + a] = (float)ell_w[e0];
         for (int k = 1; k < 3; ++k) {
           const int64_t ek = (3 * p + k) * width + (width - 8) + a;
           FEMO_REQUIRE(ell_idx[ek] == ell_idx[e0] + k && ell_w[ek] == ell_w[e0], "components of a point do not share their lattice weights");
@@ -2262,14 +2263,14 @@ int femo_shell_pc_create(femo_shell* s, int width, int64_t n_nodes, int n_levels
     const int64_t m0 = level_offsets[n_levels - 1], m1 = level_offsets[n_levels];
     std::vector<int64_t> rp((size_t)(2 * (m1 - m0) + 1), 0);
     std::vector<int32_t> pc;
-    std::vector<double> pv;
+    std::vector<float> pv;
     for (int64_t m = m0; m < m1; ++m)
       for (int g = 0; g < 2; ++g) {
         const int64_t row = 6 * m + 3 * g;
         for (int64_t e = pt_rowptr[row]; e < pt_rowptr[row + 1]; ++e) {
           FEMO_REQUIRE(pt_cols[e] % 3 == 0, "P^T row of component 0 lists another component");
           pc.push_back(pt_cols[e]);
-          pv.push_back(pt_vals[e]);
+          pv.push_back((float)pt_vals[e]);
         }
         for (int k = 1; k < 3; ++k)
           FEMO_REQUIRE(pt_rowptr[row + k + 1] - pt_rowptr[row + k] == pt_rowptr[row + 1] - pt_rowptr[row], "P^T rows of a field group differ");
