@@ -1506,10 +1506,27 @@ __global__ void k_pc_coarse_to_float(int64_t count, const double* __restrict__ A
 
 // one workgroup per row of the triangular factor: lower = 1: y = L^-1 x (entries 0 .. r of row r); 0: y = L^-T x (r .. n).
 // (A wave per row took 25 us per pass at n = 3060: the long rows are 24 dependent rounds of loads for one wave.)
+// The solver's x += alpha p carried by extra workgroups of the first coarse product (round 3, see FemoXUpdate in bpx.hip for
+// the Poisson twin): the lattice kernels between the restriction and the prolongation are launch- and latency-bound, the
+// update depends on nothing they compute, and it must only be done before the prolongation overwrites p.
+struct ShellXCarry {
+  double* x;
+  const double* p;
+  const double* alpha;
+  int64_t n;
+  int row_blocks;        // workgroups [0, row_blocks) do the product, the rest carry
+};
+
 template <class T>
 __global__ __launch_bounds__(SH_BLOCK) void k_pc_coarse_apply(int64_t n, int64_t N, int lower, const T* __restrict__ W, const double* __restrict__ x,
-                                                              double* __restrict__ y, const int32_t* __restrict__ done) {
+                                                              double* __restrict__ y, const int32_t* __restrict__ done, ShellXCarry xc = {nullptr, nullptr, nullptr, 0, 0}) {
   if (done != nullptr && *done) return;
+  if (xc.x != nullptr && (int)blockIdx.x >= xc.row_blocks) {
+    const double alpha = *xc.alpha;
+    const int64_t stride = (int64_t)(gridDim.x - xc.row_blocks) * SH_BLOCK;
+    for (int64_t i = (int64_t)(blockIdx.x - xc.row_blocks) * SH_BLOCK + threadIdx.x; i < xc.n; i += stride) xc.x[i] += alpha * xc.p[i];
+    return;
+  }
   __shared__ double lds[SH_BLOCK / 64];
   // rows are paired long with short (r and n - 1 - r take n + 1 entries together): even work per workgroup
   const int64_t pair = blockIdx.x;
@@ -1949,18 +1966,26 @@ __global__ __launch_bounds__(SH_BLOCK) void k_scg_p_z(int64_t n, int it, int nb_
 __global__ __launch_bounds__(SH_BLOCK) void k_scg_xr_pt(int64_t n_pts, int nb_pq, const double* __restrict__ part_pq, const double* __restrict__ scal,
                                                         const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ dinv,
                                                         const float* __restrict__ dinv3, double* __restrict__ x, double* __restrict__ r,
-                                                        double* __restrict__ part_rB, const int32_t* __restrict__ done) {
+                                                        double* __restrict__ part_rB, const int32_t* __restrict__ done, double* __restrict__ alpha_out = nullptr) {
   if (*done) return;
   __shared__ double lds[SH_BLOCK / 64];
   const double pq = fold(part_pq, nb_pq, lds);
   const double alpha = pq != 0.0 ? scal[0] / pq : 0.0;
+  // alpha_out != nullptr: x += alpha p is carried by the preconditioner's first coarse product (ShellXCarry); this kernel
+  // then streams q, r and the smoother blocks only
+  const bool carry = alpha_out != nullptr;
+  if (carry && blockIdx.x == 0 && threadIdx.x == 0) *alpha_out = alpha;
   double s = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x; i < n_pts; i += (int64_t)gridDim.x * SH_BLOCK) {
-    const Triple pp = *reinterpret_cast<const Triple*>(p + 3 * i), qq = *reinterpret_cast<const Triple*>(q + 3 * i);
-    Triple xx = *reinterpret_cast<const Triple*>(x + 3 * i), rr = *reinterpret_cast<const Triple*>(r + 3 * i);
-    xx.a += alpha * pp.a; xx.b += alpha * pp.b; xx.c += alpha * pp.c;
+    const Triple qq = *reinterpret_cast<const Triple*>(q + 3 * i);
+    Triple rr = *reinterpret_cast<const Triple*>(r + 3 * i);
+    if (!carry) {
+      const Triple pp = *reinterpret_cast<const Triple*>(p + 3 * i);
+      Triple xx = *reinterpret_cast<const Triple*>(x + 3 * i);
+      xx.a += alpha * pp.a; xx.b += alpha * pp.b; xx.c += alpha * pp.c;
+      *reinterpret_cast<Triple*>(x + 3 * i) = xx;
+    }
     rr.a -= alpha * qq.a; rr.b -= alpha * qq.b; rr.c -= alpha * qq.c;
-    *reinterpret_cast<Triple*>(x + 3 * i) = xx;
     *reinterpret_cast<Triple*>(r + 3 * i) = rr;
     if (dinv3 != nullptr) {
       const float* B = dinv3 + 9 * i;
@@ -2357,7 +2382,7 @@ static int shell_pc_coarse_setup(femo_shell* s, const femo_vec* vals, const uint
 // Pte != nullptr: the fused form -- the finest level's up kernel also emits the partials of e . g into Pte (*nb_te blocks)
 // and the prolongation is left to the caller (k_pc_prolong_fused).
 static int shell_pc_apply(femo_shell* s, const uint8_t* d_fixed, double* Prz, unsigned gz, const int32_t* done,
-                          double* Pte = nullptr, int* nb_te = nullptr) {
+                          double* Pte = nullptr, int* nb_te = nullptr, const ShellXCarry* carry = nullptr) {
   hipStream_t st = s->ctx->stream;
   const int L = s->pc_levels;
   auto level_up = [&](int l, const double* blocks) {
@@ -2393,9 +2418,13 @@ static int shell_pc_apply(femo_shell* s, const uint8_t* d_fixed, double* Prz, un
       }
     }
     const unsigned gp = (unsigned)((s->cs_n + 1) / 2);
+    FEMO_REQUIRE(carry == nullptr || s->d_cs_Af != nullptr, "the carried x update rides in the single-precision coarse product");
     if (s->d_cs_Af != nullptr) {
-      hipLaunchKernelGGL(k_pc_coarse_apply<float>, dim3(gp), dim3(SH_BLOCK), 0, st, s->cs_n, s->cs_N, 1, (const float*)s->d_cs_Af,
-                         s->d_t + 6 * s->level_off[cs], s->d_cs_tmp, done);
+      ShellXCarry xc = {nullptr, nullptr, nullptr, 0, 0};
+      unsigned g1 = gp;
+      if (carry != nullptr) { xc = *carry; xc.row_blocks = (int)gp; g1 = gp + 1024u; }
+      hipLaunchKernelGGL(k_pc_coarse_apply<float>, dim3(g1), dim3(SH_BLOCK), 0, st, s->cs_n, s->cs_N, 1, (const float*)s->d_cs_Af,
+                         s->d_t + 6 * s->level_off[cs], s->d_cs_tmp, done, xc);
       hipLaunchKernelGGL(k_pc_coarse_apply<float>, dim3(gp), dim3(SH_BLOCK), 0, st, s->cs_n, s->cs_N, 0, (const float*)s->d_cs_Af, s->d_cs_tmp,
                          s->d_e + 6 * s->level_off[cs], done);
     } else {
@@ -2943,6 +2972,8 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
   } else {
     hipLaunchKernelGGL(k_scg_init, dim3(gv), dim3(SH_BLOCK), 0, st, n, s->d_r, s->d_dinv, s->d_p, Prz);
   }
+  // x += alpha p inside the preconditioner's first coarse product (fused loop, one rank, coarse solve in single precision)
+  const bool carry_x = fused && s->cs_ready && s->d_cs_Af != nullptr && !femo_env_flag("FEMO_SHELL_NO_XCARRY");
   const int nb_rz0 = lattice ? (int)gz : (int)gv;
   if (multi) {
     hipLaunchKernelGGL(k_fold1, dim3(1), dim3(SH_BLOCK), 0, st, nb_rz0, Prz, one_rz, (const int32_t*)nullptr);
@@ -3004,9 +3035,16 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
         // the second, and the prolongation writes p = z + beta p at once (9 launches and 3 vector streams fewer
         // per iteration than the unfused form below)
         int nb_te = 0;
-        hipLaunchKernelGGL(k_scg_xr_pt, dim3(gx), dim3(SH_BLOCK), 0, st, n / 3, (int)gs, Ppq, s->d_scal, s->d_p, s->d_q, s->d_dinv,
-                           s->dinv3_ready ? s->d_dinv3 : (const float*)nullptr, x->d, s->d_r, Prz, s->d_flag);
-        FEMO_TRY(shell_pc_apply(s, d_fixed, Prz, gz, s->d_flag, Pte, &nb_te));
+        if (carry_x) {
+          const ShellXCarry xc = {x->d, s->d_p, s->d_scal + 5, n, 0};
+          hipLaunchKernelGGL(k_scg_xr_pt, dim3(gx), dim3(SH_BLOCK), 0, st, n / 3, (int)gs, Ppq, s->d_scal, s->d_p, s->d_q, s->d_dinv,
+                             s->dinv3_ready ? s->d_dinv3 : (const float*)nullptr, x->d, s->d_r, Prz, s->d_flag, s->d_scal + 5);
+          FEMO_TRY(shell_pc_apply(s, d_fixed, Prz, gz, s->d_flag, Pte, &nb_te, &xc));
+        } else {
+          hipLaunchKernelGGL(k_scg_xr_pt, dim3(gx), dim3(SH_BLOCK), 0, st, n / 3, (int)gs, Ppq, s->d_scal, s->d_p, s->d_q, s->d_dinv,
+                             s->dinv3_ready ? s->d_dinv3 : (const float*)nullptr, x->d, s->d_r, Prz, s->d_flag);
+          FEMO_TRY(shell_pc_apply(s, d_fixed, Prz, gz, s->d_flag, Pte, &nb_te));
+        }
         hipLaunchKernelGGL(k_pc_prolong_fused, dim3(gz), dim3(SH_BLOCK), 0, st, n / 3, it, (int)gx, Prz, nb_te, Pte, s->d_scal, s->d_fin_idx, s->d_fin_w,
                            d_fixed, s->d_dinv, s->dinv3_ready ? s->d_dinv3 : (const float*)nullptr, s->d_r, s->d_e, s->d_p, s->d_flag, gam);
       } else if (lattice) {
