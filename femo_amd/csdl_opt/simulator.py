@@ -218,10 +218,16 @@ class Simulator:
                             val = np.ascontiguousarray(val, dtype=np.float64).ravel()
                             if not self.pinned:
                                 # the driver's own (persistent, pageable) adjoint storage for this argument
-                                pool = self.__dict__.setdefault("_adj_storage", {})
-                                w = pool.get((o, arg, len(adj)))
-                                if w is None or w.size != val.size:
-                                    w = pool[(o, arg, len(adj))] = np.empty(val.size)
+                                # (a small ring per slot: an array handed out by an earlier compute_totals that its
+                                # caller still holds is never written again -- ADVICE round 3; arrays that come back
+                                # into rotation keep their in-place pinning, engine._note_caller_array)
+                                ring = self.__dict__.setdefault("_adj_storage", {}).setdefault((o, arg, len(adj)), [])
+                                ring[:] = [a for a in ring if a.size == val.size]
+                                w = next((a for a in ring if sys.getrefcount(a) <= 3), None)   # ring + generator variable + argument
+                                if w is None:
+                                    w = np.empty(val.size)
+                                    if len(ring) < 4:
+                                        ring.append(w)
                                 E.host_copy(w, E.host_wait(val))
                                 val = w
                             if arg not in adj:

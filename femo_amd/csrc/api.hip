@@ -193,7 +193,7 @@ int femo_ctx_create(int device_id, void* stream, femo_ctx** out) {
   hipDeviceProp_t prop;
   FEMO_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
   c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  FEMO_HIP_CHECK(hipMalloc(&c->d_partials, 4 * FEMO_MAX_PARTIALS * sizeof(double)));
+  FEMO_HIP_CHECK(hipMalloc(&c->d_partials, FEMO_PARTIAL_SLOTS * FEMO_MAX_PARTIALS * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&c->d_scal, FEMO_NSCAL * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&c->d_flags, 8 * sizeof(int32_t)));
   FEMO_HIP_CHECK(hipMemsetAsync(c->d_flags, 0, 8 * sizeof(int32_t), c->stream));

@@ -78,6 +78,17 @@ struct femo_pc {
   uint32_t* d_bin_ptr = nullptr;    // 65 per brick: start of each of its 64 bins, relative to the brick
   int32_t* d_brick_base = nullptr;  // 3 per brick: first bin of the brick along each axis
   bool coef_valid = false;
+  // merged BPX-PCG (femo_internal.h): the restricted residual of levels T-1 .. L as state, [T-1 | T | L-1 | L] like g_all
+  double* gs = nullptr;
+  int64_t gs_n = 0;
+  double* d_lat_partials = nullptr;   // per carrier workgroup of k_lattice_coarse_m: sum C g^2 over its part of levels T, L-1
+  double* d_rr_partials = nullptr;    // ... and r.r of its part of the updated residual
+  // N > 1: what the single all-reduce needs besides the shared nodes
+  int64_t n_int = 0;
+  int32_t* d_int_idx = nullptr;       // finest-lattice nodes that only this rank touches
+  double* d_dot_w = nullptr;          // 1 on the finest nodes several ranks touch (their sums are replicated), else 0
+  double* d_pack_scratch = nullptr;   // [3][PACK_GRID] per-block partials of the single-rank sums
+  uint32_t* d_ticket = nullptr;
 };
 
 namespace {
@@ -471,6 +482,14 @@ struct PcgStop {
   int32_t* flags;          // [0] stamp (it + 1) once converged, [1] iterations, [2] breakdown
   int it;
 };
+// merged BPX-PCG: where gamma' = r.r + sum_l C g^2 comes from (S == nullptr: the classic apply)
+struct MergedScal {
+  const double* S;
+  int multi, init;
+  int nb_lat; const double* lat_partials;   // carriers of k_lattice_coarse_m: levels T, L-1
+  int nb_rr; const double* rr_partials;     // ... and r.r of the updated residual (one rank)
+  double atol2;                             // absolute threshold on r.r (0: none)
+};
 
 template <int D>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat lat, const uint32_t* __restrict__ pk,
@@ -480,7 +499,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat
                                                              const double* __restrict__ dot_partials, const double* __restrict__ dot_global,
                                                              int nb_rho, const double* __restrict__ rho_partials, double* __restrict__ rho,
                                                              const double* __restrict__ gamma_cur, double* __restrict__ gamma_nxt,
-                                                             const int32_t* __restrict__ done, PcgStop st) {
+                                                             const int32_t* __restrict__ done, PcgStop st, MergedScal ms) {
   if (done != nullptr && *done) return;
   __shared__ double lds[2 * (FEMO_BLOCK / 64)];
   double beta = 0.0;
@@ -488,6 +507,10 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat
     double a = 0.0, b = 0.0;
     for (int i = threadIdx.x; i < nb_dot; i += FEMO_BLOCK) a += dot_partials[i];
     for (int i = threadIdx.x; i < nb_rho; i += FEMO_BLOCK) b += rho_partials[i];
+    if (ms.S != nullptr) {
+      for (int i = threadIdx.x; i < ms.nb_lat; i += FEMO_BLOCK) a += ms.lat_partials[i];
+      for (int i = threadIdx.x; i < ms.nb_rr; i += FEMO_BLOCK) b += ms.rr_partials[i];
+    }
     a = femo_wave_sum(a);
     b = femo_wave_sum(b);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -497,17 +520,32 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat
 #pragma unroll
     for (int i = 0; i < FEMO_BLOCK / 64; ++i) { ge += lds[i]; rr += lds[FEMO_BLOCK / 64 + i]; }
     if (dot_global != nullptr) ge = *dot_global;      // already folded and all-reduced (nb_dot == 0)
-    if (nb_rho == 0) rr = *rho;                       // reduced before (stopping test on r.D^-1 r, or several ranks)
+    if (nb_rho == 0 && ms.S == nullptr) rr = *rho;    // reduced before (stopping test on r.D^-1 r, or several ranks)
+    if (ms.S != nullptr) {
+      // merged loop: the lattice dot is sum_l C g^2 -- the finest level's partials and the carriers' partials folded above,
+      // the LDS-resident coarse levels from workgroup 0 of k_lattice_coarse_m; on N ranks the finest nodes a single rank
+      // touches and r.r of the updated residual follow from the reduced scalars of this iteration's all-reduce
+      const double alpha = ms.init ? -1.0 : ms.S[MS_ALPHA];
+      ge += ms.S[MS_DOTC];
+      if (ms.multi) {
+        const double* R = ms.S + MS_RED;
+        ge += R[4] - 2.0 * alpha * R[5] + alpha * alpha * R[6];
+        rr = ms.init ? ms.S[MS_RR] : R[3] - 2.0 * alpha * R[1] + alpha * alpha * R[2];
+      } else if (ms.init) {
+        rr = ms.S[MS_RR];
+      }
+      if (rr < 0.0) rr = 0.0;
+    }
     const double g1 = rr + ge, g0 = *gamma_cur;
     if (mode == 1) beta = g0 != 0.0 ? g1 / g0 : 0.0;
     const bool first = blockIdx.x == 0 && threadIdx.x == 0;
     if (first) {
       *gamma_nxt = g1;
-      if (nb_rho > 0) *rho = rr;
+      if (nb_rho > 0 || ms.S != nullptr) *rho = rr;
     }
     if (st.flags != nullptr) {
       if (mode == 2) {
-        const double t2 = fmax(st.rtol2_factor * g1, st.atol_pc2);
+        const double t2 = fmax((ms.S != nullptr ? ms.S[MS_FACTOR] : st.rtol2_factor) * g1, st.atol_pc2);
         if (first) {
           *st.tolg2 = t2;
           if (g1 <= t2) {                             // the initial residual is already below the absolute threshold
@@ -519,7 +557,8 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat
         }
       } else {
         const bool bad = !(g1 == g1);
-        if (g1 <= *st.tolg2 || bad) {                 // converged after st.it + 1 iterations: the direction is not needed
+        const bool below_atol = ms.S != nullptr && ms.atol2 > 0.0 && rr <= ms.atol2;      // absolute test in the Jacobi norm
+        if (g1 <= *st.tolg2 || below_atol || bad) {   // converged after st.it + 1 iterations: the direction is not needed
           if (first) {
             st.flags[1] = st.it + 1;
             st.flags[2] = bad ? 1 : 0;
@@ -915,6 +954,361 @@ __global__ __launch_bounds__(256) void k_lattice_prolong3(FineLevels P, const in
   }
 }
 
+// ---- merged BPX-PCG: the lattice part of one iteration with the restricted residual as state ---------------------------
+// (femo_internal.h "merged BPX-PCG").  h = this apply's brick accumulators = P^T(q/s) (P^T(r0/s) in
+// the first apply), gs = the state.  Three launches:
+//   k_lattice_coarse_m   workgroup 0: alpha; gs_{T-1} -= alpha R h_T; levels 0 .. T-1 in LDS, e_{T-1} out, sum C g^2 -> S[MS_DOTC]
+//                        the other workgroups: x += alpha p, r -= alpha q (+ partial r.r), gs -= alpha h on levels T and L-1
+//   k_lattice_prolong3_m gs_L -= alpha h_L in place (one tile owns a node), e of the three finest levels, partial sum C g^2
+//   k_prolong_mesh       gamma' = r.r + sum_l C g^2, beta, p = z + beta p, stopping test
+struct MergedCarry {
+  double* S;
+  int cur, multi, init;
+  int nb_pq, nb_pq2;
+  const double *pq_partials, *pq_partials2;
+  double *x, *r;
+  const double *p, *q;
+  int64_t n;
+  double* rr_partials;
+  double* gs_lvl[2];          // state of levels T and L-1
+  const double* h_lvl[2];     // this apply's accumulators of those levels
+  const double* coef_lvl[2];
+  int64_t n_lvl[2];
+  double* lat_partials;
+  double* gs_top;             // state of level T-1
+};
+
+__global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int dim, const int32_t* __restrict__ done, MergedCarry mc) {
+  if (done != nullptr && *done) return;
+  __shared__ double red[1024 / 64];
+  double alpha = -1.0, pq = 0.0;
+  if (!mc.init) {
+    if (mc.multi) {
+      pq = mc.S[MS_RED];
+    } else {
+      double a = 0.0;
+      for (int i = threadIdx.x; i < mc.nb_pq; i += 1024) a += mc.pq_partials[i];
+      for (int i = threadIdx.x; i < mc.nb_pq2; i += 1024) a += mc.pq_partials2[i];
+      pq = femo_block_sum_all<1024>(a, red);
+    }
+    const double gamma = mc.S[MS_GAMMA + mc.cur];
+    alpha = pq != 0.0 ? gamma / pq : 0.0;
+  }
+  if (blockIdx.x > 0) {
+    const int nc = gridDim.x - 1, b = blockIdx.x - 1;
+    double rr = 0.0, lat = 0.0;
+    if (!mc.init) {
+      const int64_t n2 = mc.n >> 1;
+      double2* x2 = reinterpret_cast<double2*>(mc.x);
+      double2* r2 = reinterpret_cast<double2*>(mc.r);
+      const double2* p2 = reinterpret_cast<const double2*>(mc.p);
+      const double2* q2 = reinterpret_cast<const double2*>(mc.q);
+      for (int64_t i = (int64_t)b * 1024 + threadIdx.x; i < n2; i += (int64_t)nc * 1024) {
+        double2 xi = x2[i], ri = r2[i];
+        const double2 pi = p2[i], qi = q2[i];
+        xi.x += alpha * pi.x; xi.y += alpha * pi.y;
+        ri.x -= alpha * qi.x; ri.y -= alpha * qi.y;
+        x2[i] = xi; r2[i] = ri;
+        rr += ri.x * ri.x + ri.y * ri.y;
+      }
+      if ((mc.n & 1) && b == 0 && threadIdx.x == 0) {
+        const int64_t i = mc.n - 1;
+        mc.x[i] += alpha * mc.p[i];
+        const double ri = mc.r[i] - alpha * mc.q[i];
+        mc.r[i] = ri;
+        rr += ri * ri;
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      double* gs = mc.gs_lvl[l];
+      const double* h = mc.h_lvl[l];
+      const double* cf = mc.coef_lvl[l];
+      for (int64_t i = (int64_t)b * 1024 + threadIdx.x; i < mc.n_lvl[l]; i += (int64_t)nc * 1024) {
+        const double g = gs[i] - alpha * h[i];
+        gs[i] = g;
+        lat += cf[i] * g * g;
+      }
+    }
+    const double t0 = femo_block_sum<1024>(rr, red);
+    if (threadIdx.x == 0) mc.rr_partials[b] = t0;
+    const double t1 = femo_block_sum<1024>(lat, red);
+    if (threadIdx.x == 0) mc.lat_partials[b] = t1;
+    return;
+  }
+  if (threadIdx.x == 0) { mc.S[MS_ALPHA] = alpha; mc.S[MS_PQ] = pq; }
+  // workgroup 0: the LDS-resident coarse end, as k_lattice_coarse with restrict_top and emit_top, on the updated state
+  extern __shared__ double coarse_lds[];
+  const int top = L.n_levels;
+  const int tid = threadIdx.x;
+  constexpr int TOPR = 4;
+  const int64_t n_top = L.nodes[top];
+  double* g_top_lds = coarse_lds + L.off[top];
+  double gt[TOPR], ct[TOPR];
+  double dot = 0.0;
+#pragma unroll
+  for (int q = 0; q < TOPR; ++q) {
+    const int64_t idx = tid + q * 1024;
+    const bool in = idx < n_top;
+    const double hres = in ? lattice_restrict_node(idx, L.n[top], L.finer_n, dim, L.finer_g) : 0.0;
+    const double g0 = in ? mc.gs_top[idx] : 0.0;
+    ct[q] = in ? L.coef[top][idx] : 0.0;
+    gt[q] = g0 - alpha * hres;
+    dot += ct[q] * gt[q] * gt[q];
+  }
+  auto coef_of = [&](int l) -> double { return (l < top && L.nodes[l] <= 1024 && tid < L.nodes[l]) ? L.coef[l][tid] : 0.0; };
+  double c_cur = coef_of(0);
+#pragma unroll
+  for (int q = 0; q < TOPR; ++q) {
+    const int64_t idx = tid + q * 1024;
+    if (idx < n_top) { g_top_lds[idx] = gt[q]; mc.gs_top[idx] = gt[q]; }
+  }
+  lds_barrier();
+  for (int l = top - 1; l >= 0; --l) {
+    const int64_t total = L.nodes[l];
+    const double* fine = l + 1 == top ? g_top_lds : coarse_lds + L.off[l + 1];
+    double* gl = coarse_lds + L.off[l];
+    for (int64_t idx = tid; idx < total; idx += 1024) gl[idx] = lattice_restrict_node(idx, L.n[l], L.n[l + 1], dim, fine);
+    lds_barrier();
+  }
+  for (int l = 0; l < top; ++l) {
+    const int64_t total = L.nodes[l];
+    const double* gl = coarse_lds + L.off[l];
+    double* el = coarse_lds + L.off[l] + L.nodes[l];
+    const double* ec = l > 0 ? coarse_lds + L.off[l - 1] + L.nodes[l - 1] : nullptr;
+    const double c_nxt = coef_of(l + 1);
+    for (int64_t idx = tid; idx < total; idx += 1024) {
+      const double c = total <= 1024 ? c_cur : L.coef[l][idx];
+      const double g = gl[idx];
+      double v = c * g;
+      dot += v * g;
+      if (l > 0) v += lattice_interp_node(idx, L.n[l], L.n[l - 1], dim, ec);
+      el[idx] = v;
+    }
+    c_cur = c_nxt;
+    lds_barrier();
+  }
+  {
+    const double* ec = coarse_lds + L.off[top - 1] + L.nodes[top - 1];
+#pragma unroll
+    for (int q = 0; q < TOPR; ++q) {
+      const int64_t idx = tid + q * 1024;
+      if (idx < n_top) L.e[top][idx] = ct[q] * gt[q] + lattice_interp_node(idx, L.n[top], L.n[top - 1], dim, ec);
+    }
+  }
+  const double t = femo_block_sum<1024>(dot, red);
+  if (tid == 0) mc.S[MS_DOTC] = t;
+}
+
+// FineLevels of the merged variant: g_c / g_m are the STATE of levels T and L-1 (already updated by the carriers of
+// k_lattice_coarse_m), g_f the state of the finest level (updated here), h_f its accumulator (cleared here);
+// g_c_other / g_m_other: the other parity's accumulators of levels T and L-1, cleared for the restriction after the next.
+template <int D>
+__global__ __launch_bounds__(256) void k_lattice_prolong3_m(FineLevels P, double* __restrict__ h_f, const double* __restrict__ S, int init,
+                                                            const int32_t* __restrict__ done) {
+  if (done != nullptr && *done) return;
+  constexpr int TF = D == 3 ? 8 : 16, TM = TF / 2 + 1, TC = TF / 4 + 1;
+  constexpr int NC = D == 3 ? TC * TC * TC : TC * TC, NM = D == 3 ? TM * TM * TM : TM * TM, NT = D == 3 ? TF * TF * TF : TF * TF;
+  __shared__ double ec[NC];
+  __shared__ double em[NM];
+  __shared__ double red[256 / 64];
+  const double alpha = init ? -1.0 : S[MS_ALPHA];
+  int tn[3] = {1, 1, 1};
+#pragma unroll
+  for (int k = 0; k < D; ++k) tn[k] = (P.nf[k] + TF) / TF;
+  const int64_t n_tiles = (int64_t)tn[0] * tn[1] * tn[2];
+  auto from_patch = [](const double* src, int TS, const int (&fi)[3], const int (&slo)[3]) -> double {
+    int a[3], b[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { a[k] = (fi[k] >> 1) - slo[k]; b[k] = ((fi[k] + 1) >> 1) - slo[k]; }
+    if constexpr (D == 3) {
+      return 0.125 * (src[(a[2] * TS + a[1]) * TS + a[0]] + src[(a[2] * TS + a[1]) * TS + b[0]] + src[(a[2] * TS + b[1]) * TS + a[0]] +
+                      src[(a[2] * TS + b[1]) * TS + b[0]] + src[(b[2] * TS + a[1]) * TS + a[0]] + src[(b[2] * TS + a[1]) * TS + b[0]] +
+                      src[(b[2] * TS + b[1]) * TS + a[0]] + src[(b[2] * TS + b[1]) * TS + b[0]]);
+    } else {
+      return 0.25 * (src[a[1] * TS + a[0]] + src[a[1] * TS + b[0]] + src[b[1] * TS + a[0]] + src[b[1] * TS + b[0]]);
+    }
+  };
+  double dot = 0.0;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    int lo[3] = {0, 0, 0}, mlo[3] = {0, 0, 0}, clo[3] = {0, 0, 0};
+    {
+      int64_t t = tile;
+#pragma unroll
+      for (int k = 0; k < D; ++k) { lo[k] = (int)(t % tn[k]) * TF; t /= tn[k]; mlo[k] = lo[k] >> 1; clo[k] = lo[k] >> 2; }
+    }
+    static_assert(NC <= 256 && NM <= 256, "one patch node per thread");
+    constexpr int NQ = NT / 256;
+    const int p = threadIdx.x;
+    bool c_in = false, c_own = true;
+    int64_t c_idx = 0;
+    double c_coef = 0.0, c_g = 0.0, c_par = 0.0;
+    if (p < NC) {
+      int ci[3] = {0, 0, 0};
+      int q = p;
+      c_in = true;
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const int pk = q % TC; q /= TC;
+        ci[k] = clo[k] + pk;
+        c_in = c_in && ci[k] <= P.nc[k];
+        c_own = c_own && pk < TF / 4;
+      }
+      if (c_in) {
+        c_idx = node_index(P.nc, ci[0], ci[1], ci[2]);
+        c_coef = P.coef_c[c_idx];
+        c_g = P.g_c[c_idx];
+        c_par = lattice_interp_node(c_idx, P.nc, P.ncc, D, P.e_cc);
+      }
+    }
+    bool m_in = false, m_own = true;
+    int64_t m_idx = 0;
+    int mi[3] = {0, 0, 0};
+    double m_coef = 0.0, m_g = 0.0;
+    if (p < NM) {
+      int q = p;
+      m_in = true;
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const int pk = q % TM; q /= TM;
+        mi[k] = mlo[k] + pk;
+        m_in = m_in && mi[k] <= P.nm[k];
+        m_own = m_own && pk < TF / 2;
+      }
+      if (m_in) {
+        m_idx = node_index(P.nm, mi[0], mi[1], mi[2]);
+        m_coef = P.coef_m[m_idx];
+        m_g = P.g_m[m_idx];
+      }
+    }
+    bool f_in[NQ];
+    int64_t f_idx[NQ];
+    int fi[NQ][3];
+    double f_g[NQ], f_coef[NQ], f_w[NQ];
+#pragma unroll
+    for (int r = 0; r < NQ; ++r) {
+      int q = p + r * 256;
+      f_in[r] = true;
+      fi[r][0] = fi[r][1] = fi[r][2] = 0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const int qk = q % TF; q /= TF;
+        fi[r][k] = lo[k] + qk;
+        f_in[r] = f_in[r] && fi[r][k] <= P.nf[k];
+      }
+      f_idx[r] = 0; f_g[r] = 0.0; f_coef[r] = 0.0; f_w[r] = 1.0;
+      if (f_in[r]) {
+        f_idx[r] = node_index(P.nf, fi[r][0], fi[r][1], fi[r][2]);
+        f_g[r] = P.g_f[f_idx[r]] - alpha * h_f[f_idx[r]];
+        f_coef[r] = P.coef_f[f_idx[r]];
+        if (P.dot_weight != nullptr) f_w[r] = P.dot_weight[f_idx[r]];
+      }
+    }
+    if (p < NC) {
+      ec[p] = c_in ? c_coef * c_g + c_par : 0.0;
+      if (c_in && c_own) P.g_c_other[c_idx] = 0.0;
+    }
+    lds_barrier();
+    if (p < NM) {
+      em[p] = m_in ? m_coef * m_g + from_patch(ec, TC, mi, clo) : 0.0;
+      if (m_in && m_own) P.g_m_other[m_idx] = 0.0;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < NQ; ++r) {
+      if (!f_in[r]) continue;
+      const double gi = f_g[r];
+      P.g_f[f_idx[r]] = gi;
+      h_f[f_idx[r]] = 0.0;
+      const double cg = f_coef[r] * gi;
+      P.e_f[f_idx[r]] = cg + from_patch(em, TM, fi[r], mlo);
+      dot += cg * gi * f_w[r];
+    }
+    lds_barrier();
+  }
+  if (P.dot_partials != nullptr) {
+    const double t = femo_block_sum<256>(dot, red);
+    if (threadIdx.x == 0) P.dot_partials[blockIdx.x] = t;
+  }
+}
+
+// N > 1: what the single all-reduce of an iteration carries -- [h_L on the shared nodes | h_T, h_{L-1} whole | 7 scalars].
+// The scalars: p.q, r.q, q.q (partials of the SpMV launches), r.r (partials of the previous iteration's carriers) and,
+// over the finest-lattice nodes only this rank touches, sum C g g, C g h, C h h.  The last workgroup to finish (ticket)
+// folds every per-block partial in a fixed order.
+constexpr int PACK_GRID = 256;
+struct PackArgs {
+  int64_t n_shared; const int32_t* shared_idx; const double* h_f;
+  int64_t n_dense; const double* h_dense;
+  int64_t n_int; const int32_t* int_idx; const double* gs_f; const double* coef_f;
+  int nb_q[2]; const double* Pq[2];
+  int nb_rr; const double* Prr;
+  double* buf; double* scratch; uint32_t* ticket;
+};
+__global__ __launch_bounds__(256) void k_pack_merged(PackArgs a, const int32_t* __restrict__ done) {
+  if (done != nullptr && *done) return;
+  __shared__ double red[256 / 64];
+  __shared__ uint32_t s_last;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (int64_t i = t0; i < a.n_shared + a.n_dense; i += stride) a.buf[i] = i < a.n_shared ? a.h_f[a.shared_idx[i]] : a.h_dense[i - a.n_shared];
+  double gg = 0.0, gh = 0.0, hh = 0.0;
+  for (int64_t i = t0; i < a.n_int; i += stride) {
+    const int32_t j = a.int_idx[i];
+    const double c = a.coef_f[j], g = a.gs_f[j], h = a.h_f[j];
+    gg += c * g * g; gh += c * g * h; hh += c * h * h;
+  }
+  double t;
+  t = femo_block_sum<256>(gg, red); if (threadIdx.x == 0) a.scratch[blockIdx.x] = t;
+  t = femo_block_sum<256>(gh, red); if (threadIdx.x == 0) a.scratch[PACK_GRID + blockIdx.x] = t;
+  t = femo_block_sum<256>(hh, red); if (threadIdx.x == 0) a.scratch[2 * PACK_GRID + blockIdx.x] = t;
+  __threadfence();
+  if (threadIdx.x == 0) s_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  double* tail = a.buf + a.n_shared + a.n_dense;
+  // p.q, q.q, r.q: slots 0, 1, 2 of each SpMV launch's triple; tail order p.q, r.q, q.q, r.r, gg, gh, hh
+  const int slot_of[3] = {0, 2, 1};
+  for (int k = 0; k < 3; ++k) {
+    double acc = 0.0;
+    for (int l = 0; l < 2; ++l)
+      for (int i = threadIdx.x; i < a.nb_q[l]; i += 256) acc += a.Pq[l][(int64_t)slot_of[k] * FEMO_MAX_PARTIALS + i];
+    t = femo_block_sum<256>(acc, red);
+    if (threadIdx.x == 0) tail[k] = t;
+  }
+  {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < a.nb_rr; i += 256) acc += a.Prr[i];
+    t = femo_block_sum<256>(acc, red);
+    if (threadIdx.x == 0) tail[3] = t;
+  }
+  for (int k = 0; k < 3; ++k) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) acc += a.scratch[k * PACK_GRID + i];
+    t = femo_block_sum<256>(acc, red);
+    if (threadIdx.x == 0) tail[4 + k] = t;
+  }
+  if (threadIdx.x == 0) *a.ticket = 0u;
+}
+__global__ void k_unpack_merged(int64_t n_shared, const int32_t* __restrict__ idx, double* __restrict__ h_f, int64_t n_dense,
+                                double* __restrict__ h_dense, const double* __restrict__ buf, double* __restrict__ S,
+                                const int32_t* __restrict__ done) {
+  if (done != nullptr && *done) return;
+  if (blockIdx.x == 0 && threadIdx.x < MS_NRED) S[MS_RED + threadIdx.x] = buf[n_shared + n_dense + threadIdx.x];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_shared + n_dense; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < n_shared) h_f[idx[i]] = buf[i];
+    else h_dense[i - n_shared] = buf[i];
+  }
+}
+
+// several regions cleared by one launch (a solve's set-up issued a dozen 5 us fills one after the other)
+struct ZeroRegions { double* p[8]; int64_t n[8]; int count; };
+__global__ void k_zero_regions(ZeroRegions z) {
+  for (int r = 0; r < z.count; ++r)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < z.n[r]; i += (int64_t)gridDim.x * blockDim.x) z.p[r][i] = 0.0;
+}
+
 // finest level: coef = C where the hat function is not dominated by Dirichlet vertices, else 0
 __global__ void k_lattice_coef(int64_t nodes, double c, const double* __restrict__ w_free, const double* __restrict__ w_dir,
                                double* __restrict__ coef) {
@@ -1036,6 +1430,8 @@ void femo_pc_destroy(femo_mesh* m) {
   (void)hipFree(m->pc->d_perm); (void)hipFree(m->pc->d_pk); (void)hipFree(m->pc->d_pk_sorted); (void)hipFree(m->pc->d_w_sorted); (void)hipFree(m->pc->d_sinv); (void)hipFree(m->pc->d_dot_partials);
   (void)hipFree(m->pc->d_shared_idx); (void)hipFree(m->pc->d_dot_weight); (void)hipFree(m->pc->d_xbuf); (void)hipFree(m->pc->d_dot_scalar);
   (void)hipFree(m->pc->d_brick_ptr); (void)hipFree(m->pc->d_bin_ptr); (void)hipFree(m->pc->d_brick_base);
+  (void)hipFree(m->pc->gs); (void)hipFree(m->pc->d_lat_partials); (void)hipFree(m->pc->d_rr_partials);
+  (void)hipFree(m->pc->d_int_idx); (void)hipFree(m->pc->d_dot_w); (void)hipFree(m->pc->d_pack_scratch); (void)hipFree(m->pc->d_ticket);
   delete m->pc;
   m->pc = nullptr;
 }
@@ -1147,10 +1543,25 @@ static int pc_setup_shared(femo_mesh* m) {
     if (mine[(size_t)i] != 0.0) weight[(size_t)i] = 1.0 / cnt[(size_t)i];
   }
   pc->n_shared = (int64_t)shared.size();
+  {
+    // merged loop: the nodes only this rank touches (their part of the lattice dot travels as three scalars) and the
+    // indicator of the shared ones (whose sums every rank holds after the exchange)
+    std::vector<int32_t> interior;
+    std::vector<double> wrep((size_t)F.nodes, 0.0);
+    for (int64_t i = 0; i < F.nodes; ++i) {
+      if (cnt[(size_t)i] >= 1.5) wrep[(size_t)i] = 1.0;
+      else if (mine[(size_t)i] != 0.0) interior.push_back((int32_t)i);
+    }
+    pc->n_int = (int64_t)interior.size();
+    FEMO_HIP_CHECK(hipMalloc(&pc->d_int_idx, std::max<size_t>(interior.size(), 1) * sizeof(int32_t)));
+    if (!interior.empty()) FEMO_HIP_CHECK(hipMemcpy(pc->d_int_idx, interior.data(), interior.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    FEMO_HIP_CHECK(hipMalloc(&pc->d_dot_w, F.nodes * sizeof(double)));
+    FEMO_HIP_CHECK(hipMemcpy(pc->d_dot_w, wrep.data(), F.nodes * sizeof(double), hipMemcpyHostToDevice));
+  }
   const int64_t n_coarse = F.g - pc->L[nl - 1 - pc->n_fused].g;      // the coarser fused levels travel whole
   FEMO_HIP_CHECK(hipMalloc(&pc->d_shared_idx, std::max<size_t>(shared.size(), 1) * sizeof(int32_t)));
   FEMO_HIP_CHECK(hipMalloc(&pc->d_dot_weight, F.nodes * sizeof(double)));
-  FEMO_HIP_CHECK(hipMalloc(&pc->d_xbuf, (pc->n_shared + n_coarse + 1) * sizeof(double)));
+  FEMO_HIP_CHECK(hipMalloc(&pc->d_xbuf, (pc->n_shared + n_coarse + 1 + MS_NRED) * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&pc->d_dot_scalar, sizeof(double)));
   if (!shared.empty()) FEMO_HIP_CHECK(hipMemcpy(pc->d_shared_idx, shared.data(), shared.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   FEMO_HIP_CHECK(hipMemcpy(pc->d_dot_weight, weight.data(), F.nodes * sizeof(double), hipMemcpyHostToDevice));
@@ -1368,9 +1779,9 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
   ps.flags = stop ? stop->flags : nullptr;
   ps.it = stop ? stop->it : 0;
   if (pc->dim == 3)
-    hipLaunchKernelGGL(k_prolong_mesh<3>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, pc->d_sinv, mask, F.e, out, mode, nb_dot, pc->d_dot_partials, dot_global, nb_rho, rho_partials, rho, gamma_cur, gamma_nxt, done, ps);
+    hipLaunchKernelGGL(k_prolong_mesh<3>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, pc->d_sinv, mask, F.e, out, mode, nb_dot, pc->d_dot_partials, dot_global, nb_rho, rho_partials, rho, gamma_cur, gamma_nxt, done, ps, MergedScal{});
   else
-    hipLaunchKernelGGL(k_prolong_mesh<2>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, pc->d_sinv, mask, F.e, out, mode, nb_dot, pc->d_dot_partials, dot_global, nb_rho, rho_partials, rho, gamma_cur, gamma_nxt, done, ps);
+    hipLaunchKernelGGL(k_prolong_mesh<2>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, pc->d_sinv, mask, F.e, out, mode, nb_dot, pc->d_dot_partials, dot_global, nb_rho, rho_partials, rho, gamma_cur, gamma_nxt, done, ps, MergedScal{});
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -1389,6 +1800,170 @@ int femo_pc_begin(femo_mesh* m, const double* s, const uint8_t* mask) {
   FEMO_HIP_CHECK(hipMemsetAsync(first, 0, count * sizeof(double), m->ctx->stream));
   FEMO_HIP_CHECK(hipMemsetAsync(pc->g_alt, 0, count * sizeof(double), m->ctx->stream));
   pc->parity = 0;
+  return 0;
+}
+
+
+// ---- merged BPX-PCG: host side ---------------------------------------------------------------------------------------
+// the shape the merged kernels are written for: two brick-fused levels, everything below level T-1 (and g_{T-1}) in LDS
+static bool merged_shape_ok(const femo_pc* pc) {
+  const int nl = pc->n_levels, nf = pc->n_fused;
+  const int T = nl - 1 - nf;
+  if (nf != 2 || T < 2 || T >= FEMO_PC_MAX_LEVELS - 1) return false;
+  int64_t below = 0;
+  for (int l = 0; l + 1 < T; ++l) below += pc->L[l].nodes;
+  const int64_t lds = below * 2 * (int64_t)sizeof(double) + pc->L[T - 1].nodes * (int64_t)sizeof(double);
+  return pc->L[T - 1].nodes <= 4096 && below * 2 * (int64_t)sizeof(double) <= 144 * 1024 && lds <= 150 * 1024;
+}
+
+bool femo_pc_merged_ok(femo_mesh* m) {
+  // FEMO_PCG_CLASSIC: A/B switch and the tests of the classic loop (read per solve, never per launch)
+  if (femo_env_flag("FEMO_PCG_CLASSIC") || femo_env_flag("FEMO_BPX_DENSE_ALLREDUCE") || femo_env_flag("FEMO_BPX_UNFUSED_LATTICE")) return false;
+  if (femo_pc_build(m) != 0) return false;
+  return merged_shape_ok(m->pc);
+}
+
+int femo_pc_merged_collectives(const femo_mesh* m) { return m->ctx->nranks > 1 ? 1 : 0; }
+
+// start of a solve with the merged loop: weights of the current operator, clean accumulators, zero state
+int femo_pc_merged_begin(femo_mesh* m, const double* s, const uint8_t* mask) {
+  femo_pc* pc = m->pc;
+  femo_ctx* ctx = m->ctx;
+  const hipStream_t st = ctx->stream;
+  if (ctx->nranks > 1) FEMO_TRY(pc_setup_shared(m));   // once; collective
+  const int nl = pc->n_levels, T = nl - 1 - pc->n_fused;
+  if (!pc->gs) {
+    pc->gs_n = (pc->L[nl - 1].g + pc->L[nl - 1].nodes) - pc->L[T - 1].g;
+    FEMO_HIP_CHECK(hipMalloc(&pc->gs, pc->gs_n * sizeof(double)));
+    FEMO_HIP_CHECK(hipMalloc(&pc->d_lat_partials, FEMO_MAX_PARTIALS * sizeof(double)));
+    FEMO_HIP_CHECK(hipMalloc(&pc->d_rr_partials, FEMO_MAX_PARTIALS * sizeof(double)));
+    FEMO_HIP_CHECK(hipMalloc(&pc->d_pack_scratch, 3 * PACK_GRID * sizeof(double)));
+    FEMO_HIP_CHECK(hipMalloc(&pc->d_ticket, sizeof(uint32_t)));
+    FEMO_HIP_CHECK(hipMemsetAsync(pc->d_ticket, 0, sizeof(uint32_t), st));
+  }
+  if (m->n_rows > 0) hipLaunchKernelGGL(k_pc_weights, dim3(lat_grid(m->n_rows)), dim3(256), 0, st, m->n_rows, pc->d_perm, s, mask, pc->d_w_sorted, pc->d_sinv);
+  double* first = pc->L[T].g;
+  const int64_t count = (pc->L[nl - 1].g + pc->L[nl - 1].nodes) - first;
+  ZeroRegions z;
+  z.count = 3;
+  z.p[0] = first; z.n[0] = count;
+  z.p[1] = pc->g_alt; z.n[1] = count;
+  z.p[2] = pc->gs; z.n[2] = pc->gs_n;
+  hipLaunchKernelGGL(k_zero_regions, dim3(lat_grid(std::max(count, pc->gs_n))), dim3(256), 0, st, z);
+  FEMO_HIP_CHECK(hipGetLastError());
+  pc->parity = 0;
+  return 0;
+}
+
+// One preconditioner application of the merged loop (see the kernels above).  V.q == nullptr: the first one.
+int femo_pc_merged_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const FemoMergedVecs& V, double* S,
+                         const int32_t* done, const FemoPcgStop* stop) {
+  femo_pc* pc = m->pc;
+  femo_ctx* ctx = m->ctx;
+  FEMO_TRY(pc_prepare(m, mask, mask_key));
+  const hipStream_t st = ctx->stream;
+  const int nl = pc->n_levels, nf = pc->n_fused;
+  const int T = nl - 1 - nf;
+  FEMO_REQUIRE(merged_shape_ok(pc) && pc->gs != nullptr, "femo_pc_merged_apply: lattice shape not supported / begin not called");
+  LatticeLevel& F = pc->L[nl - 1];
+  const Lat lat = make_lat(pc, F);
+  const int par = pc->parity;
+  auto H = [&](int l, int which) -> double* { return which == 0 ? pc->L[l].g : pc->g_alt + (pc->L[l].g - pc->L[T].g); };
+  auto GS = [&](int l) -> double* { return pc->gs + (pc->L[l].g - pc->L[T - 1].g); };
+  const bool init = V.q == nullptr;
+  const bool multi = ctx->nranks > 1;
+  double* hF = H(nl - 1, par);
+  if (pc->n_bricks > 0) {
+    const unsigned gb = (unsigned)std::min<int64_t>(pc->n_bricks, (int64_t)ctx->n_cu * bricks_per_cu(pc->dim, pc->brick_pf));
+    FEMO_LAUNCH_BRICKS(pc, gb, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, init ? (const double*)V.r : V.q, pc->d_w_sorted, hF, nf, done);
+  }
+  if (multi) {
+    FEMO_REQUIRE(pc->shared_ready, "femo_pc_merged_apply: the sparse lattice exchange is not set up");
+    PackArgs a;
+    a.n_shared = pc->n_shared; a.shared_idx = pc->d_shared_idx; a.h_f = hF;
+    a.h_dense = H(T, par); a.n_dense = hF - H(T, par);
+    a.n_int = pc->n_int; a.int_idx = pc->d_int_idx; a.gs_f = GS(nl - 1); a.coef_f = F.coef;
+    for (int l = 0; l < 2; ++l) { a.nb_q[l] = init ? 0 : V.nb_q[l]; a.Pq[l] = V.Pq[l]; }
+    a.nb_rr = init ? 0 : std::max(1, ctx->n_cu - 1); a.Prr = pc->d_rr_partials;
+    a.buf = pc->d_xbuf; a.scratch = pc->d_pack_scratch; a.ticket = pc->d_ticket;
+    const int64_t count = a.n_shared + a.n_dense;
+    const unsigned gp = (unsigned)std::min<int64_t>(PACK_GRID, std::max<int64_t>(1, (std::max(count, a.n_int) + 255) / 256));
+    hipLaunchKernelGGL(k_pack_merged, dim3(gp), dim3(256), 0, st, a, done);
+    FEMO_TRY(femo_coll_allreduce(ctx, pc->d_xbuf, count + MS_NRED, st));
+    hipLaunchKernelGGL(k_unpack_merged, dim3(lat_grid(std::max<int64_t>(count, 1))), dim3(256), 0, st, a.n_shared, pc->d_shared_idx, hF, a.n_dense, H(T, par), pc->d_xbuf, S, done);
+  }
+  // workgroup 0: the LDS-resident levels; the others: vector and lattice updates
+  CoarseLevels CL;
+  CL.n_levels = T - 1;
+  CL.emit_top = 1;
+  int64_t below = 0;
+  for (int l = 0; l <= T - 1; ++l) {
+    for (int k = 0; k < 3; ++k) CL.n[l][k] = pc->L[l].n[k];
+    CL.g[l] = pc->L[l].g; CL.e[l] = pc->L[l].e; CL.coef[l] = pc->L[l].coef;
+    CL.nodes[l] = pc->L[l].nodes;
+    CL.off[l] = l == 0 ? 0 : CL.off[l - 1] + 2 * CL.nodes[l - 1];
+    if (l + 1 < T) below += pc->L[l].nodes;
+  }
+  const size_t lds = (size_t)below * 2 * sizeof(double) + (size_t)CL.nodes[T - 1] * sizeof(double);
+  CL.top_in_lds = 1; CL.restrict_top = 1;
+  CL.finer_g = H(T, par);
+  for (int k = 0; k < 3; ++k) CL.finer_n[k] = pc->L[T].n[k];
+  if (lds > 64 * 1024 && !pc->coarse_lds_set) {
+    FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_coarse, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    pc->coarse_lds_set = true;
+  }
+  static bool merged_lds_set = false;
+  if (lds > 64 * 1024 && !merged_lds_set) {
+    FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_coarse_m, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    merged_lds_set = true;
+  }
+  const int n_carry = std::max(1, ctx->n_cu - 1);
+  MergedCarry mc;
+  mc.S = S; mc.cur = V.cur; mc.multi = multi ? 1 : 0; mc.init = init ? 1 : 0;
+  mc.nb_pq = V.nb_q[0]; mc.nb_pq2 = V.nb_q[1]; mc.pq_partials = V.Pq[0]; mc.pq_partials2 = V.Pq[1];
+  mc.x = V.x; mc.r = V.r; mc.p = V.p; mc.q = V.q; mc.n = V.n;
+  mc.rr_partials = pc->d_rr_partials; mc.lat_partials = pc->d_lat_partials;
+  for (int l = 0; l < 2; ++l) {
+    const int lev = T + l;
+    mc.gs_lvl[l] = GS(lev); mc.h_lvl[l] = H(lev, par); mc.coef_lvl[l] = pc->L[lev].coef; mc.n_lvl[l] = pc->L[lev].nodes;
+  }
+  mc.gs_top = GS(T - 1);
+  hipLaunchKernelGGL(k_lattice_coarse_m, dim3(1 + n_carry), dim3(1024), lds, st, CL, pc->dim, done, mc);
+  FineLevels FL;
+  const LatticeLevel &Lcc = pc->L[nl - 4], &Lc = pc->L[nl - 3], &Lm = pc->L[nl - 2];
+  for (int k = 0; k < 3; ++k) { FL.ncc[k] = Lcc.n[k]; FL.nc[k] = Lc.n[k]; FL.nm[k] = Lm.n[k]; FL.nf[k] = F.n[k]; }
+  FL.e_cc = Lcc.e;
+  FL.coef_c = Lc.coef; FL.g_c = GS(nl - 3); FL.g_c_other = H(nl - 3, par ^ 1);
+  FL.coef_m = Lm.coef; FL.g_m = GS(nl - 2); FL.g_m_other = H(nl - 2, par ^ 1);
+  FL.coef_f = F.coef; FL.g_f = GS(nl - 1); FL.e_f = F.e;
+  FL.dot_partials = pc->d_dot_partials;
+  FL.dot_weight = multi ? pc->d_dot_w : nullptr;
+  const int TF = pc->dim == 3 ? 8 : 16;
+  int64_t tiles = 1;
+  for (int k = 0; k < pc->dim; ++k) tiles *= (F.n[k] + TF) / TF;
+  const int nb_dot = (int)std::min<int64_t>(tiles, 2048);
+  if (pc->dim == 3) hipLaunchKernelGGL(k_lattice_prolong3_m<3>, dim3(nb_dot), dim3(256), 0, st, FL, hF, (const double*)S, init ? 1 : 0, done);
+  else hipLaunchKernelGGL(k_lattice_prolong3_m<2>, dim3(nb_dot), dim3(256), 0, st, FL, hF, (const double*)S, init ? 1 : 0, done);
+  pc->parity ^= 1;
+  PcgStop ps;
+  ps.rtol2_factor = stop ? stop->rtol2_factor : 0.0;
+  ps.atol_pc2 = stop ? stop->atol_pc2 : 0.0;
+  ps.tolg2 = stop ? stop->tolg2 : nullptr;
+  ps.flags = stop ? stop->flags : nullptr;
+  ps.it = stop ? stop->it : 0;
+  MergedScal ms;
+  ms.S = S; ms.multi = multi ? 1 : 0; ms.init = init ? 1 : 0;
+  ms.nb_lat = n_carry; ms.lat_partials = pc->d_lat_partials;
+  ms.nb_rr = (multi || init) ? 0 : n_carry; ms.rr_partials = pc->d_rr_partials;
+  ms.atol2 = V.atol2;
+  const int mode = init ? 2 : 1;
+  double* gamma_cur = S + MS_GAMMA + V.cur;
+  double* gamma_nxt = init ? S + MS_GAMMA + V.cur : S + MS_GAMMA + (V.cur ^ 1);
+  if (pc->dim == 3)
+    hipLaunchKernelGGL(k_prolong_mesh<3>, dim3(V.gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, (const double*)V.r, pc->d_sinv, mask, F.e, V.p, mode, nb_dot, pc->d_dot_partials, (const double*)nullptr, 0, (const double*)nullptr, S + MS_RR, (const double*)gamma_cur, gamma_nxt, done, ps, ms);
+  else
+    hipLaunchKernelGGL(k_prolong_mesh<2>, dim3(V.gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, (const double*)V.r, pc->d_sinv, mask, F.e, V.p, mode, nb_dot, pc->d_dot_partials, (const double*)nullptr, 0, (const double*)nullptr, S + MS_RR, (const double*)gamma_cur, gamma_nxt, done, ps, ms);
+  FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
 

@@ -65,7 +65,8 @@ inline bool femo_env_flag(const char* name) { return getenv(name) != nullptr; }
 constexpr int FEMO_WAVE = 64;            // gfx950 wavefront
 constexpr int FEMO_BLOCK = 256;          // 4 waves = 4 SELL slices per workgroup
 constexpr int FEMO_MAX_PARTIALS = 2048;  // persistent reduction grids: 256 CUs x 8
-constexpr int FEMO_NSCAL = 16;           // device scalars of the CG recurrence
+constexpr int FEMO_NSCAL = 32;           // device scalars of the CG recurrence
+constexpr int FEMO_PARTIAL_SLOTS = 12;   // slots of FEMO_MAX_PARTIALS per-block partials each (femo_ctx::d_partials)
 constexpr int FEMO_STAGE_SLOTS = 4;      // pinned staging slots per context (8 MiB each)
 
 // SELL-64 with pair interleave: entry k of lane l in a slice starting at P:
@@ -111,7 +112,7 @@ struct femo_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  double* d_partials = nullptr;  // [4][FEMO_MAX_PARTIALS]
+  double* d_partials = nullptr;  // [FEMO_PARTIAL_SLOTS][FEMO_MAX_PARTIALS]
   double* d_scal = nullptr;      // [FEMO_NSCAL]
   int32_t* d_flags = nullptr;    // [4]: done, iterations, breakdown, spare
   double* h_scal = nullptr;      // pinned mirror: FEMO_NSCAL doubles + 4 int32
@@ -297,6 +298,20 @@ __device__ __forceinline__ double femo_block_sum(double v, double* lds /* NT/64 
   return s;
 }
 
+// the same sum delivered to every thread of the block
+template <int NT>
+__device__ __forceinline__ double femo_block_sum_all(double v, double* lds /* NT/64 */) {
+  v = femo_wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) lds[w] = v;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) s += lds[i];
+  return s;
+}
+
 // Blocks are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD
 // group); give each XCD one contiguous range of logical blocks so that its L2
 // sees one contiguous slab of rows.  Speed only, never correctness.
@@ -359,6 +374,36 @@ struct FemoXUpdate {
   const double* alpha;
   int64_t n;
 };
+// ---- merged BPX-PCG (round 4): ONE all-reduce and one halo exchange per iteration on N ranks ------------------
+// The restricted residual of the finest levels is kept as STATE and updated by linearity, g <- g - alpha P^T(q/s)
+// with q = A p: the restriction no longer waits for alpha, so p.q travels in the same all-reduce as the lattice
+// sums; r.r of the updated residual and the lattice dot g_L.e_L = sum_l sum_i C_l,i g_l,i^2 (e_l = C_l g_l + I e_l-1,
+// g_l-1 = I^T g_l) follow from reduced scalars, r'.r' = r.r - 2 alpha r.q + alpha^2 q.q and likewise for the nodes a
+// single rank touches.  Device scalars (femo_ctx::d_scal):
+constexpr int MS_GAMMA = 0;    // [0], [1]: gamma = r.M^-1 r of even / odd iterations
+constexpr int MS_PQ = 2;       // p.Ap of the current iteration (breakdown test)
+constexpr int MS_TOL2 = 3;     // atol^2 (Jacobi norm)
+constexpr int MS_RR = 4;       // r.r (global)
+constexpr int MS_TOLG = 5;     // stopping threshold on gamma
+constexpr int MS_FACTOR = 6;   // rtol^2 * b.b / r0.r0
+constexpr int MS_BB = 7;       // b.D^-1 b
+constexpr int MS_ALPHA = 8;
+constexpr int MS_DOTC = 9;     // sum over the LDS-resident coarse levels of C g^2
+constexpr int MS_RED = 10;     // N > 1: the seven reduced scalars p.q, r.q, q.q, r.r, and over single-rank finest nodes C g g, C g h, C h h
+constexpr int MS_NRED = 7;
+struct FemoMergedVecs {
+  double* x; double* r; double* p; const double* q;   // q == nullptr: the first apply (g = P^T(r/s), alpha = -1, no updates)
+  int64_t n;
+  int cur;                                             // parity of the current gamma
+  int nb_q[2]; const double* Pq[2];                    // SpMV partial triples [p.q | q.q | r.q] (one or two launches), FEMO_MAX_PARTIALS apart
+  int gv;                                              // grid of the mesh-sized kernels
+  double atol2;                                        // absolute threshold on r.r (0: none)
+};
+bool femo_pc_merged_ok(femo_mesh* m);                 // the fused lattice cycle with two brick-fused levels runs on this mesh
+int femo_pc_merged_begin(femo_mesh* m, const double* s, const uint8_t* mask);
+int femo_pc_merged_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const FemoMergedVecs& V, double* S,
+                         const int32_t* done, const struct FemoPcgStop* stop);
+int femo_pc_merged_collectives(const femo_mesh* m);   // all-reduces per iteration of the merged loop on this mesh (0 on one rank)
 // nb_rho > 0: rho = rh.rh is folded from rho_partials[0:nb_rho] inside the apply (and stored to *rho)
 int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const double* s, const double* rh, double* out,
                   int mode, double* rho, const double* gamma_cur, double* gamma_nxt, const int32_t* done, int gv,

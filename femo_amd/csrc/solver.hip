@@ -183,7 +183,8 @@ __device__ __forceinline__ double row_sum_regular(int npair, const double2* __re
 }
 
 // DOT: 0 none; 1 partial d.Ax into partials[block] (d = dvec or x); 2 additionally partial x.x,
-// 3 additionally partial Ax.Ax, into the next slot
+// 3 additionally partial Ax.Ax, into the next slot; 4 (merged BPX-PCG): x.Ax, Ax.Ax and dvec.Ax into three
+// consecutive slots (p.q, q.q, r.q: everything the single all-reduce of an iteration carries besides the lattice)
 template <int DOT, bool UNIT>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_spmv_sell(
     int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ mptr,
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_spmv_sell(
   // slice_list != null: walk that subset (interior or boundary slices of a partitioned mesh)
   const int64_t n_walk = slice_list ? n_list : n_slices;
   const int64_t s_lo = n_walk * xcd / 8, s_hi = n_walk * (xcd + 1) / 8;
-  double dot = 0.0, dot2 = 0.0;
+  double dot = 0.0, dot2 = 0.0, dot3 = 0.0;
   for (int64_t si = s_lo + blk_in_xcd * (FEMO_BLOCK / 64) + wave; si < s_hi; si += waves_per_xcd) {
     const int64_t slice = slice_list ? (int64_t)slice_list[si] : si;
     const int64_t base = mptr[slice];
@@ -227,9 +228,15 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_spmv_sell(
     }
     if (row < n_rows) {
       y[row] = acc;
-      if (DOT) dot += acc * (dvec ? dvec[row] : xr);
-      if (DOT == 2) dot2 += xr * xr;
-      if (DOT == 3) dot2 += acc * acc;
+      if (DOT == 4) {
+        dot += acc * xr;
+        dot2 += acc * acc;
+        dot3 += acc * dvec[row];
+      } else {
+        if (DOT) dot += acc * (dvec ? dvec[row] : xr);
+        if (DOT == 2) dot2 += xr * xr;
+        if (DOT == 3) dot2 += acc * acc;
+      }
     }
   }
   if (DOT) {
@@ -239,6 +246,10 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_spmv_sell(
   if (DOT >= 2) {
     const double s = femo_block_sum<FEMO_BLOCK>(dot2, lds);
     if (threadIdx.x == 0) partials[FEMO_MAX_PARTIALS + blockIdx.x] = s;
+  }
+  if (DOT == 4) {
+    const double s = femo_block_sum<FEMO_BLOCK>(dot3, lds);
+    if (threadIdx.x == 0) partials[2 * FEMO_MAX_PARTIALS + blockIdx.x] = s;
   }
 }
 
@@ -847,7 +858,7 @@ int femo_spmv_grid(const femo_mesh* m) {
 static int launch_spmv(const femo_mat* A, const double* vals, const double* x, double* y,
                        double* partials, const int32_t* done, bool unit = false, bool dot2 = false,
                        const int32_t* slice_list = nullptr, int64_t n_list = 0, hipStream_t stream = nullptr,
-                       const double* dvec = nullptr, bool dot_yy = false) {
+                       const double* dvec = nullptr, bool dot_yy = false, bool dot3 = false) {
   const femo_mesh* m = A->mesh;
   const int64_t n_walk = slice_list ? n_list : m->n_slices;
   if (n_walk == 0 && !partials) return 0;
@@ -857,7 +868,8 @@ static int launch_spmv(const femo_mat* A, const double* vals, const double* x, d
   }
   hipStream_t st = stream ? stream : m->ctx->stream;
 #define FEMO_SPMV_ARGS m->n_rows, m->n_slices, m->d_mptr, m->d_cols, m->d_cols16, m->d_sdelta, m->sdelta_stride, vals, A->d_diag, x, y, partials, done, slice_list, n_list, dvec
-  if (partials && unit && dot_yy) hipLaunchKernelGGL((k_spmv_sell<3, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
+  if (partials && unit && dot3) hipLaunchKernelGGL((k_spmv_sell<4, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
+  else if (partials && unit && dot_yy) hipLaunchKernelGGL((k_spmv_sell<3, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
   else if (partials && unit && dot2) hipLaunchKernelGGL((k_spmv_sell<2, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
   else if (partials && unit) hipLaunchKernelGGL((k_spmv_sell<1, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
   else if (partials) hipLaunchKernelGGL((k_spmv_sell<1, false>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
@@ -875,7 +887,8 @@ static int launch_spmv(const femo_mat* A, const double* vals, const double* x, d
 // Partials (if requested) land in slot pairs: interior at `partials`, boundary at
 // `partials + 2*FEMO_MAX_PARTIALS`; *g_int / *g_bnd return the block counts to fold.
 static int halo_spmv_overlapped(const femo_mat* A, const double* vals, double* x, double* y, double* partials,
-                                const int32_t* done, bool unit, bool dot2, int* g_int, int* g_bnd) {
+                                const int32_t* done, bool unit, bool dot2, int* g_int, int* g_bnd,
+                                const double* dvec = nullptr, int n_slots = 2) {
   femo_mesh* m = A->mesh;
   femo_ctx* ctx = m->ctx;
   hipStream_t st = ctx->stream, cs = ctx->comm_stream;
@@ -892,10 +905,12 @@ static int halo_spmv_overlapped(const femo_mat* A, const double* vals, double* x
   };
   if (g_int) *g_int = grid_of(m->n_int);
   if (g_bnd) *g_bnd = grid_of(m->n_bnd);
-  FEMO_TRY(launch_spmv(A, vals, x, y, partials, done, unit, dot2, m->d_slices_int, m->n_int, st));
+  // n_slots == 3: the merged PCG's triple [x.Ax | Ax.Ax | dvec.Ax], boundary launch three slots further on
+  const bool dot3 = n_slots == 3;
+  FEMO_TRY(launch_spmv(A, vals, x, y, partials, done, unit, dot2, m->d_slices_int, m->n_int, st, dvec, false, dot3));
   FEMO_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_comm, 0));
-  FEMO_TRY(launch_spmv(A, vals, x, y, partials ? partials + 2 * FEMO_MAX_PARTIALS : nullptr, done, unit, dot2,
-                       m->d_slices_bnd, m->n_bnd, st));
+  FEMO_TRY(launch_spmv(A, vals, x, y, partials ? partials + n_slots * FEMO_MAX_PARTIALS : nullptr, done, unit, dot2,
+                       m->d_slices_bnd, m->n_bnd, st, dvec, false, dot3));
   return 0;
 }
 
@@ -1090,7 +1105,7 @@ struct CgWork {
 };
 
 // need: 0 = standard CG, 1 = single-reduction CG (+sv), 2 = BiCGSTAB (+sv, t, r0)
-int ensure_work(femo_ctx* ctx, int64_t n_rows, int64_t n_vert, CgWork& w, int need) {
+int ensure_work(femo_ctx* ctx, int64_t n_rows, int64_t n_vert, CgWork& w, int need, bool zero = true) {
   const int64_t len = std::max(n_rows, n_vert) + 2;
   if (ctx->cg_n < len) {
     hipFree(ctx->cg_r); hipFree(ctx->cg_p); hipFree(ctx->cg_q); hipFree(ctx->cg_dinv); hipFree(ctx->cg_s);
@@ -1106,9 +1121,12 @@ int ensure_work(femo_ctx* ctx, int64_t n_rows, int64_t n_vert, CgWork& w, int ne
   if (need >= 1 && !ctx->cg_s) FEMO_HIP_CHECK(hipMalloc(&ctx->cg_s, ctx->cg_n * sizeof(double)));
   if (need >= 2 && !ctx->cg_t) FEMO_HIP_CHECK(hipMalloc(&ctx->cg_t, ctx->cg_n * sizeof(double)));
   if (need >= 2 && !ctx->cg_r0) FEMO_HIP_CHECK(hipMalloc(&ctx->cg_r0, ctx->cg_n * sizeof(double)));
-  FEMO_HIP_CHECK(hipMemsetAsync(ctx->cg_p, 0, ctx->cg_n * sizeof(double), ctx->stream));
-  FEMO_HIP_CHECK(hipMemsetAsync(ctx->cg_r, 0, ctx->cg_n * sizeof(double), ctx->stream));
-  if (need >= 1) FEMO_HIP_CHECK(hipMemsetAsync(ctx->cg_s, 0, ctx->cg_n * sizeof(double), ctx->stream));
+  // (zero == false: the caller's init kernel writes every entry it will read -- no ghost tail)
+  if (zero) {
+    FEMO_HIP_CHECK(hipMemsetAsync(ctx->cg_p, 0, ctx->cg_n * sizeof(double), ctx->stream));
+    FEMO_HIP_CHECK(hipMemsetAsync(ctx->cg_r, 0, ctx->cg_n * sizeof(double), ctx->stream));
+    if (need >= 1) FEMO_HIP_CHECK(hipMemsetAsync(ctx->cg_s, 0, ctx->cg_n * sizeof(double), ctx->stream));
+  }
   w.r = ctx->cg_r; w.p = ctx->cg_p; w.q = ctx->cg_q; w.xh = ctx->cg_dinv; w.sv = ctx->cg_s;
   w.t = ctx->cg_t; w.r0 = ctx->cg_r0;
   return 0;
@@ -1156,6 +1174,190 @@ static int ensure_scaled(femo_mat* A, bool transpose) {
   return 0;
 }
 
+// ---- merged BPX-PCG (round 4) ---------------------------------------------------------------------------------------
+// One all-reduce + one halo exchange per iteration on N ranks, five launches per iteration on one (SpMV, brick
+// restriction of q = A p, coarse lattice + vector updates, fine lattice, mesh prolongation + direction update), one
+// host synchronisation before the loop and one after it.  See femo_internal.h "merged BPX-PCG" and DESIGN.md section 4.
+// Set-up on the device: rho0 = r0.r0 and bb = b.D^-1 b (folded here on one rank, reduced before on several), the
+// thresholds, and the decision not to iterate at all when the initial residual is below the absolute tolerance.
+__global__ __launch_bounds__(1024) void k_pcg_setup(int nb, const double* __restrict__ partials, double* __restrict__ S,
+                                                    double rtol2, double atol2, int32_t* __restrict__ flags) {
+  __shared__ double lds[1024 / 64];
+  double rho0, bb;
+  if (nb > 0) {
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 1024) { a += partials[i]; b += partials[FEMO_MAX_PARTIALS + i]; }
+    rho0 = femo_block_sum_all<1024>(a, lds);
+    bb = femo_block_sum_all<1024>(b, lds);
+  } else {
+    rho0 = S[MS_RED]; bb = S[MS_RED + 1];
+  }
+  if (threadIdx.x != 0) return;
+  S[MS_GAMMA] = 0.0; S[MS_GAMMA + 1] = 0.0; S[MS_PQ] = 0.0; S[MS_ALPHA] = 0.0; S[MS_DOTC] = 0.0; S[MS_TOLG] = 0.0;
+  S[MS_TOL2] = atol2;
+  S[MS_RR] = rho0;
+  S[MS_BB] = bb;
+  S[MS_FACTOR] = rtol2 * (rho0 > 0.0 ? bb / rho0 : 1.0);
+  flags[1] = 0; flags[2] = 0; flags[3] = 0;
+  const bool bad = !(rho0 == rho0);
+  if (!(rho0 > atol2) || rho0 == 0.0) {          // nothing to iterate on (or NaN): every later launch returns at once
+    flags[2] = bad ? 1 : 0;
+    __threadfence();
+    flags[0] = 1;
+  } else {
+    flags[0] = 0;
+  }
+}
+
+static int solve_pcg_bpx_merged(femo_mat* A, const femo_vec* b, femo_vec* x, const femo_solver_opts* opts, femo_solve_info* info) {
+  femo_mesh* m = A->mesh;
+  femo_ctx* ctx = m->ctx;
+  const int64_t n = m->n_rows;
+  hipStream_t st = ctx->stream;
+  FEMO_HIP_CHECK(hipEventRecord(ctx->ev0, st));
+  FEMO_TRY(ensure_s(A));
+  CgWork w;
+  const bool multi = ctx->nranks > 1;
+  FEMO_TRY(ensure_work(ctx, n, m->n_vert, w, 0, /*zero=*/m->n_vert > n));
+  const int gv = vec_grid(ctx, n);
+  const int gs = femo_spmv_grid(m);
+  int32_t* h_flags = reinterpret_cast<int32_t*>(ctx->h_scal + FEMO_NSCAL);
+  double* P = ctx->d_partials;
+  double* S = ctx->d_scal;
+  const uint8_t* mask = A->pc_has_mask ? A->d_pcmask : nullptr;
+  FEMO_TRY(femo_pc_merged_begin(m, A->d_s, mask));
+  const double* q0 = nullptr;
+  if (!opts->zero_guess) {
+    if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, x->d));
+    FEMO_TRY(launch_spmv(A, A->d_vals, x->d, w.q, nullptr, nullptr));
+    q0 = w.q;
+  } else if (x->n > n) {
+    FEMO_HIP_CHECK(hipMemsetAsync(x->d + n, 0, (x->n - n) * sizeof(double), st));     // ghost tail of the solution, as the classic loop leaves it
+  }
+  hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, b->d, q0, A->d_s, w.r, w.p, w.xh, P, A->has_idrows ? A->d_idrows : nullptr);
+  const double atol2 = opts->atol * opts->atol;
+  if (multi) {
+    hipLaunchKernelGGL(k_reduce_partials_at, dim3(1), dim3(1024), 0, st, gv, 2, P + FEMO_MAX_PARTIALS, S + MS_RED);
+    FEMO_TRY(femo_coll_allreduce(ctx, S + MS_RED, 2, st));
+    hipLaunchKernelGGL(k_pcg_setup, dim3(1), dim3(1024), 0, st, 0, P + FEMO_MAX_PARTIALS, S, opts->rtol * opts->rtol, atol2, ctx->d_flags);
+  } else {
+    hipLaunchKernelGGL(k_pcg_setup, dim3(1), dim3(1024), 0, st, gv, P + FEMO_MAX_PARTIALS, S, opts->rtol * opts->rtol, atol2, ctx->d_flags);
+  }
+  FemoPcgStop stop;
+  stop.rtol2_factor = 0.0;                       // read from S[MS_FACTOR] on the device
+  stop.atol_pc2 = opts->atol_pc * opts->atol_pc;
+  stop.tolg2 = S + MS_TOLG;
+  stop.flags = ctx->d_flags;
+  stop.it = -1;
+  FemoMergedVecs V;
+  V.x = w.xh; V.r = w.r; V.p = w.p; V.q = nullptr; V.n = n; V.cur = 0; V.gv = gv; V.atol2 = 0.0;
+  V.nb_q[0] = V.nb_q[1] = 0; V.Pq[0] = V.Pq[1] = nullptr;
+  FEMO_TRY(femo_pc_merged_apply(m, mask, A->pc_key, V, S, ctx->d_flags, &stop));
+  FEMO_HIP_CHECK(hipGetLastError());
+  // the one synchronisation before the loop: rho0, bb, gamma0 and the flag
+  FEMO_HIP_CHECK(hipMemcpyAsync(h_flags, ctx->d_flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, S, FEMO_NSCAL * sizeof(double), hipMemcpyDeviceToHost, st));
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  const double rho0 = ctx->h_scal[MS_RR], bb = ctx->h_scal[MS_BB], gamma0 = ctx->h_scal[MS_GAMMA];
+  info->rhs_norm = std::sqrt(bb);
+  const int max_it = opts->max_it > 0 ? opts->max_it : 10000;
+  auto finish = [&](int iters, int conv, double rho) -> int {
+    if (n > 0) {
+      hipLaunchKernelGGL(k_unscale, dim3(2048), dim3(256), 0, st, n, opts->zero_guess ? 0 : 1, A->d_s, w.xh, x->d);
+      FEMO_HIP_CHECK(hipGetLastError());
+    }
+    FEMO_HIP_CHECK(hipEventRecord(ctx->ev1, st));
+    FEMO_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    FEMO_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    info->iterations = iters;
+    info->converged = conv;
+    info->residual_norm = std::sqrt(rho);
+    info->solve_ms = ms;
+    return 0;
+  };
+  info->spmv_ms = 0.0; info->spmv_samples = 0;
+  if (h_flags[0]) {                               // below the absolute tolerance (k_pcg_setup) or below atol_pc (first apply)
+    info->pc_rhs_norm = std::sqrt(gamma0 * (rho0 > 0.0 ? bb / rho0 : 1.0));
+    info->pc_residual_norm = std::sqrt(gamma0);
+    return finish(0, (h_flags[2] || !(rho0 == rho0)) ? -1 : 1, rho0);
+  }
+  info->pc_rhs_norm = std::sqrt(gamma0 * (rho0 > 0.0 ? bb / rho0 : 1.0));
+  FEMO_TRY(ensure_scaled(A, false));
+
+  const int n_sample = 4, sample_from = 2;
+  int n_ev = 0;
+  // Batches: with a prediction (the smaller of the last two counts on this mesh) exactly that many iterations first, then
+  // 2, 3, 4, 6, 8, 8 ... -- each batch polled synchronously (a solve that follows a short one paid a
+  // blocking poll every second iteration).  Without a prediction: 8 at a time.
+  const int batch = opts->check_every > 0 ? std::min(opts->check_every, 8) : 8;
+  const int last2 = std::min(m->pcg_last_iters, m->pcg_prev_iters);
+  const int predicted = last2 > 0 ? last2 : 0;
+  int it = 0, grow = 2;
+  bool done = false;
+  double* Pq_int = P + 4 * FEMO_MAX_PARTIALS;     // triples [p.q | q.q | r.q]: interior / only launch, boundary launch
+  double* Pq_bnd = P + 7 * FEMO_MAX_PARTIALS;
+  V.q = w.q; V.atol2 = atol2;
+  while (!done) {
+    int this_batch = batch;
+    if (predicted > 0) {
+      if (it == 0) this_batch = predicted;
+      else { this_batch = grow; grow = std::min(8, grow + (grow + 1) / 2); }
+    }
+    const int it_end = it + this_batch < max_it ? it + this_batch : max_it;
+    for (; it < it_end; ++it) {
+      const bool sample = it >= sample_from && it < sample_from + n_sample;
+      if (sample) FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev], st));
+      int g1 = gs, g2 = 0;
+      if (multi) {
+        if (m->n_nbr > 0 && m->d_slices_int != nullptr) {
+          FEMO_TRY(halo_spmv_overlapped(A, A->d_valsS, w.p, w.q, Pq_int, ctx->d_flags, true, false, &g1, &g2, w.r, 3));
+        } else {
+          if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, w.p));
+          FEMO_TRY(launch_spmv(A, A->d_valsS, w.p, w.q, Pq_int, ctx->d_flags, true, false, nullptr, 0, nullptr, w.r, false, true));
+        }
+      } else {
+        FEMO_TRY(launch_spmv(A, A->d_valsS, w.p, w.q, Pq_int, ctx->d_flags, true));
+      }
+      if (sample) { FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev + 1], st)); ++n_ev; }
+      stop.it = it;
+      V.cur = it & 1;
+      V.nb_q[0] = g1; V.nb_q[1] = g2; V.Pq[0] = Pq_int; V.Pq[1] = Pq_bnd;
+      FEMO_TRY(femo_pc_merged_apply(m, mask, A->pc_key, V, S, ctx->d_flags, &stop));
+    }
+    FEMO_HIP_CHECK(hipGetLastError());
+    FEMO_HIP_CHECK(hipMemcpyAsync(h_flags, ctx->d_flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_sample], st));
+    FEMO_HIP_CHECK(hipEventSynchronize(ctx->ev_pool[2 * n_sample]));
+    if (h_flags[0] || it >= max_it) done = true;
+  }
+  // x, the final scalars and the time with one more synchronisation
+  if (n > 0) hipLaunchKernelGGL(k_unscale, dim3(2048), dim3(256), 0, st, n, opts->zero_guess ? 0 : 1, A->d_s, w.xh, x->d);
+  FEMO_HIP_CHECK(hipMemcpyAsync(h_flags, ctx->d_flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, S, FEMO_NSCAL * sizeof(double), hipMemcpyDeviceToHost, st));
+  FEMO_HIP_CHECK(hipEventRecord(ctx->ev1, st));
+  FEMO_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  FEMO_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  const int iters = h_flags[1];
+  const int conv = h_flags[0] ? (h_flags[2] ? -1 : 1) : 0;
+  if (conv == 1 && iters > 0) { m->pcg_prev_iters = m->pcg_last_iters; m->pcg_last_iters = iters; }
+  double acc = 0.0;
+  for (int i = 0; i < n_ev; ++i) {
+    float t = 0.f;
+    FEMO_HIP_CHECK(hipEventElapsedTime(&t, ctx->ev_pool[2 * i], ctx->ev_pool[2 * i + 1]));
+    acc += t;
+  }
+  info->spmv_ms = acc;
+  info->spmv_samples = n_ev;
+  info->pc_residual_norm = std::sqrt(ctx->h_scal[MS_GAMMA + (iters & 1)]);
+  info->iterations = iters;
+  info->converged = conv;
+  info->residual_norm = std::sqrt(ctx->h_scal[MS_RR]);
+  info->solve_ms = ms;
+  return 0;
+}
+
 // CG with the auxiliary-lattice BPX preconditioner.  Same scaled system, same stopping norm
 // (sqrt(rh.rh) = sqrt(r^T D^-1 r)) as the Jacobi path; scalars live on the device and are
 // all-reduced there when the mesh is partitioned.
@@ -1167,6 +1369,8 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
   FEMO_REQUIRE(A->bpx_ok, "the BPX preconditioner needs an operator assembled from a Poisson-type form");
   FEMO_REQUIRE(!transpose, "the BPX preconditioner is for symmetric operators");
   hipStream_t st = ctx->stream;
+  if (!(ctx->comm != nullptr && ctx->nranks == 1 && femo_env_flag("FEMO_FORCE_MULTI")) && femo_pc_merged_ok(m))
+    return solve_pcg_bpx_merged(A, b, x, opts, info);
   FEMO_HIP_CHECK(hipEventRecord(ctx->ev0, st));
   FEMO_TRY(ensure_s(A));
   FEMO_TRY(femo_pc_build(m));

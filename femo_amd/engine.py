@@ -125,41 +125,79 @@ def auto_register(enabled: bool) -> None:
     _AUTO_REGISTER = bool(enabled)
 
 
+_REG_LOCK = threading.RLock()       # emulated ranks are threads of one process: the two tables and the register call are one critical section
+
+
 def _forget_owner(key: int) -> None:
-    _SEEN.pop(key, None)
-    rec = _REGISTERED.pop(key, None)
-    if rec is not None:
-        try:
-            _lib.load().femo_host_unregister(C.c_void_p(rec[0]))
-        except Exception:
-            pass
+    with _REG_LOCK:
+        _SEEN.pop(key, None)
+        rec = _REGISTERED.pop(key, None)
+        if rec is not None:
+            try:
+                _lib.load().femo_host_unregister(C.c_void_p(rec[0]))     # by the RECORDED address: the owner may have moved
+            except Exception:
+                pass
 
 
-def _note_caller_array(a: np.ndarray) -> None:
-    """Called with every caller-owned array a transfer entry point is handed (``Vec.set`` / ``get(out=)`` / ``add_to_host``)."""
-    if not _AUTO_REGISTER or a.nbytes < AUTO_REGISTER_MIN_BYTES:
-        return
+def _owner_of(a: np.ndarray):
     owner = a
     while isinstance(owner.base, np.ndarray):
         owner = owner.base
     if owner.base is not None or not owner.flags.owndata:
-        return                                   # memory of another object (buffer, mmap, a pinned block): lifetime unknown / not ours
+        return None                              # memory of another object (buffer, mmap, a pinned block): lifetime unknown / not ours
+    return owner
+
+
+def _note_caller_array(a: np.ndarray) -> None:
+    """Called with every caller-owned array a transfer entry point is handed (``Vec.set`` / ``get(out=)`` / ``add_to_host``).
+    ``ndarray.resize`` (an in-place realloc) of an array that was handed over is not supported: the old range would stay
+    pinned until the array is seen again."""
+    if not _AUTO_REGISTER or a.nbytes < AUTO_REGISTER_MIN_BYTES:
+        return
+    owner = _owner_of(a)
+    if owner is None:
+        return
     key, addr, nb = id(owner), owner.ctypes.data, owner.nbytes
-    rec = _REGISTERED.get(key)
-    if rec is not None:
+    with _REG_LOCK:
+        rec = _REGISTERED.get(key)
+        if rec is not None:
+            if rec == (addr, nb):
+                return
+            _forget_owner(key)                   # resized in place: unpin the old range (by its recorded address) first
+        if _SEEN.get(key) != (addr, nb):
+            if key not in _SEEN:
+                import weakref
+                weakref.finalize(owner, _forget_owner, key)
+            _SEEN[key] = (addr, nb)
+            return                               # first sight: staged path
+        if _lib.load().femo_host_register(C.c_void_p(addr), nb) == 0:
+            _REGISTERED[key] = (addr, nb)
+        else:
+            _SEEN.pop(key, None)                 # could not pin (limits, overlap): stay on the staged path
+
+
+def register(a: np.ndarray) -> bool:
+    """Pin a caller-owned array in place now (a driver that knows its variable storage up front need not wait for the
+    second sight, and keeps hipHostRegister out of its first timed transfer).  Unpinned when NumPy frees the array.
+    Returns False when the array cannot be pinned (not the owner of its memory, or the runtime refused)."""
+    owner = _owner_of(a)
+    if owner is None:
+        return False
+    key, addr, nb = id(owner), owner.ctypes.data, owner.nbytes
+    with _REG_LOCK:
+        rec = _REGISTERED.get(key)
         if rec == (addr, nb):
-            return
-        _forget_owner(key)                       # resized in place: the old range is gone
-    if _SEEN.get(key) != (addr, nb):
+            return True
+        if rec is not None:
+            _forget_owner(key)
         if key not in _SEEN:
             import weakref
             weakref.finalize(owner, _forget_owner, key)
         _SEEN[key] = (addr, nb)
-        return                                   # first sight: staged path
-    if _lib.load().femo_host_register(C.c_void_p(addr), nb) == 0:
-        _REGISTERED[key] = (addr, nb)
-    else:
-        _SEEN.pop(key, None)                     # could not pin (limits, overlap): stay on the staged path
+        if _lib.load().femo_host_register(C.c_void_p(addr), nb) == 0:
+            _REGISTERED[key] = (addr, nb)
+            return True
+        return False
 
 
 _LAZY = threading.local()

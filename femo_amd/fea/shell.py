@@ -447,6 +447,7 @@ class DeviceShell:
     def set_penalty(self, edges, beta: float) -> None:
         """Tagged edges (ids) and penalty parameter of the boundary terms; ``edges`` empty: none."""
         edges = np.asarray(edges, dtype=np.int64)
+        self._penalty_owner = None          # a direct call invalidates whatever form bound its edges last (shell_forms._bind_penalty)
         if edges.size == 0:
             check(self.lib.femo_shell_set_penalty(self.handle, 0, None, None, None))
             return

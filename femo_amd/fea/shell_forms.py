@@ -299,9 +299,11 @@ class ShellResidual(BackendForm):
 
     def _bind_penalty(self, dev: DeviceShell) -> None:
         """The device handle holds one set of tagged edges: (re)load this form's when another form's is there."""
-        key = (id(self), self.beta)
+        # keyed on content, not on id(self): CPython reuses addresses, and the handle outlives the forms (ADVICE round 3)
+        edges = self.penalty_edges if self.has_penalty else np.zeros(0, np.int64)
+        key = (self.beta, int(edges.size), hash(edges.tobytes()))
         if getattr(dev, "_penalty_owner", None) != key:
-            dev.set_penalty(self.penalty_edges if self.has_penalty else np.zeros(0, np.int64), self.beta)
+            dev.set_penalty(edges, self.beta)
             dev._penalty_owner = key
 
     def stiffness(self) -> Vec:

@@ -454,3 +454,32 @@ def test_two_outputs_do_not_alias_in_device_mode(ctx):
         res[device] = (keep, np.array(g2, copy=True))
     assert np.allclose(res[False][0], res[True][0], rtol=1e-9, atol=1e-18)
     assert np.allclose(res[False][1], res[True][1], rtol=1e-9, atol=1e-18)
+
+
+def test_pageable_driver_results_are_not_overwritten(ctx):
+    """Simulator(pinned=False) keeps persistent pageable adjoint storage; a total handed out by one compute_totals
+    must survive the next one while its caller holds it (the storage array itself was returned and
+    rewritten), and the storage must come back into rotation once released (no fresh 0.5 GB array per cycle)."""
+    from femo_amd.fea.mesh import createUnitSquareMesh
+    from tests.test_gpu_operators import make_sim
+    mesh = createUnitSquareMesh(12)
+    sim, fea, f_ex, _ = make_sim(mesh, device=False, pinned=False)
+    f0 = np.asarray(f_ex.vector.getArray())
+    held, copies = [], []
+    for k in range(3):
+        sim['f'] = (1.0 - 0.25 * k) * f0
+        sim.run()
+        g = sim.compute_totals('l2_functional', 'f')
+        held.append(g)
+        copies.append(np.array(g, copy=True))
+        for a, c in zip(held, copies):
+            assert np.array_equal(np.asarray(a), c)
+    assert len({id(a) for a in held}) == 3
+    assert not np.array_equal(copies[0], copies[1])
+    first = id(held[0])
+    del held[:], g, a
+    sim['f'] = 0.3 * f0
+    sim.run()
+    g = sim.compute_totals('l2_functional', 'f')
+    rings = [r for r in sim._adj_storage.values() if any(g is a for a in r)]
+    assert len(rings) == 1 and len(rings[0]) <= 4 and first in {id(a) for a in rings[0]}
