@@ -19,7 +19,7 @@ c_i64p = C.POINTER(C.c_int64)
 c_f64p = C.POINTER(C.c_double)
 H = C.c_void_p  # opaque handle
 
-ABI_VERSION = 6            # include/femo_hip.h FEMO_ABI_VERSION
+ABI_VERSION = 7            # include/femo_hip.h FEMO_ABI_VERSION
 MESH_INFO_COUNT = 12
 MESH_INFO_KEYS = ("tdim", "n_vert", "n_rows", "n_cell", "nnz", "sell_entries", "max_rowlen",
                   "max_valence", "n_slices", "visit_entries", "regular_slices", "short_slices")
@@ -48,7 +48,8 @@ class HostStats(C.Structure):
     _fields_ = [(k, C.c_int64) for k in ("h2d_pinned", "h2d_pinned_bytes", "h2d_staged", "h2d_staged_bytes",
                                          "h2d_skipped", "h2d_skipped_bytes", "h2d_as_d2d", "h2d_as_d2d_bytes",
                                          "d2h_pinned", "d2h_pinned_bytes", "d2h_staged", "d2h_staged_bytes",
-                                         "d2h_async", "d2h_async_bytes", "d2h_device_sum", "d2h_device_sum_bytes")]
+                                         "d2h_async", "d2h_async_bytes", "d2h_device_sum", "d2h_device_sum_bytes",
+                                         "h2d_deferred", "h2d_deferred_bytes")]
 
 
 # name -> (restype, argtypes); every symbol include/femo_hip.h declares
@@ -70,6 +71,8 @@ PROTOTYPES = {
     "femo_vec_get_host": (C.c_int, [H, C.c_void_p, c_i64]),
     "femo_vec_add_to_host": (C.c_int, [H, C.c_void_p, c_i64]),
     "femo_vec_get_host_async": (C.c_int, [H, C.c_void_p, c_i64]),
+    "femo_vec_set_host_deferred": (C.c_int, [H, C.c_void_p, c_i64]),
+    "femo_vec_await_upload": (C.c_int, [H]),
     "femo_host_wait": (C.c_int, [C.c_void_p]),
     "femo_host_sync": (C.c_int, []),
     "femo_host_alloc": (C.c_int, [c_i64, C.POINTER(C.c_void_p)]),
@@ -89,6 +92,7 @@ PROTOTYPES = {
     "femo_vec_copy": (C.c_int, [H, H]),
     "femo_vec_axpy": (C.c_int, [H, C.c_double, H]),
     "femo_vec_dot": (C.c_int, [H, H, c_i64, c_f64p]),
+    "femo_vec_dots": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), c_i64, c_f64p]),
     "femo_mesh_create": (C.c_int, [H, C.c_int, c_i64, c_i64, C.c_void_p, c_i64, C.c_void_p, C.POINTER(H)]),
     "femo_mesh_destroy": (C.c_int, [H]),
     "femo_mesh_info": (C.c_int, [H, c_i64p]),
@@ -98,6 +102,7 @@ PROTOTYPES = {
     "femo_emu_group_create": (C.c_int, [C.c_int, C.POINTER(H)]),
     "femo_emu_group_destroy": (C.c_int, [H]),
     "femo_comm_emulate": (C.c_int, [H, H, C.c_int]),
+    "femo_comm_stats": (C.c_int, [H, C.POINTER(C.c_int64), C.c_int]),
     # Reissner-Mindlin shell
     "femo_shell_create": (C.c_int, [H, c_i64, C.c_void_p, c_i64, C.c_void_p, c_i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(H)]),
     "femo_shell_destroy": (C.c_int, [H]),

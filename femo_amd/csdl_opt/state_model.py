@@ -15,8 +15,9 @@ import numpy as np
 from femo_amd.csdl_opt._common import (declare_all, gather_arguments, push_functions, stays_on_device,
                                        traced)
 from femo_amd.csdl_opt._csdl_compat import CustomImplicitOperation, Model, custom
-from femo_amd.engine import host_wait, lazy_results
+from femo_amd.engine import deferred_uploads, host_wait, lazy_results
 from femo_amd.fea.fea_hip import FEA
+from femo_amd.fea.forms import BackendForm
 from femo_amd.fea.utils_hip import (DeviceArray, SparseMatrix, addMatVecProductBwd, addMatVecProductFwd,
                                     assembleMatrix, assembleSystem, assembleVector, computePartials,
                                     createFunction, getFuncArray, setUpKSP_MUMPS, update)
@@ -97,12 +98,22 @@ class StateOperation(CustomImplicitOperation):
         """Nonlinear solve from the incoming state as initial guess (state_model.py:87-115)."""
         fea = self.fea
         fea.opt_iter += 1
-        self._load(inputs, outputs)
-        for name in inputs:
-            entry = self.args_dict[name]
-            if entry['record']:
-                entry['recorder'].write_function(entry['function'], fea.opt_iter)
-        fea.solve(self.state['residual_form'], self.state['function'], self.bcs)
+        res = self.state['residual_form']
+        # The state first, then the inputs as DEFERRED uploads (engine.deferred_uploads): for the catalogue forms the first
+        # assembly pass orders its input-independent half -- matrix, K u', S A S -- in front of the wait for f, so that work
+        # runs under the transfer.  Forms with a backend of their own (shell) and recorders read the inputs through other
+        # entry points: they keep the synchronous upload.
+        recording = any(self.args_dict[name]['record'] for name in inputs)
+        defer = (fea.async_results and not isinstance(res, BackendForm) and not recording
+                 and fea.custom_solve is None)
+        update(self.state['function'], outputs[self.state_name])
+        with deferred_uploads(defer):
+            push_functions(self.args_dict, inputs)
+            for name in inputs:
+                entry = self.args_dict[name]
+                if entry['record']:
+                    entry['recorder'].write_function(entry['function'], fea.opt_iter)
+            fea.solve(res, self.state['function'], self.bcs)
         with lazy_results(fea.async_results):
             outputs[self.state_name] = getFuncArray(self.state['function'], device=stays_on_device(inputs))
         if fea.record:

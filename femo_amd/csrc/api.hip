@@ -368,7 +368,7 @@ int femo_mesh_destroy(femo_mesh* m) {
   hipFree(m->d_x); hipFree(m->d_conn); hipFree(m->d_vptr); hipFree(m->d_visit_cell);
   hipFree(m->d_visit_slots); hipFree(m->d_mptr); hipFree(m->d_cols); hipFree(m->d_rowlen); hipFree(m->d_rowreal);
   femo_pc_destroy(m);
-  hipFree(m->d_bvmask); hipFree(m->d_visit_rec); hipFree(m->d_load); hipFree(m->d_pipe_dummy); hipFree(m->d_ubc);
+  hipFree(m->d_bvmask); hipFree(m->d_visit_rec); hipFree(m->d_load); hipFree(m->d_zero_load); hipFree(m->d_pipe_dummy); hipFree(m->d_ubc);
   if (m->mass) { femo_mat_destroy(m->mass); m->mass = nullptr; }
   hipFree(m->d_mass_e); hipFree(m->d_mass_g); hipFree(m->d_cellvol); hipFree(m->d_cellvol_own); hipFree(m->d_cell_t);
   hipFree(m->d_sdelta); hipFree(m->d_cols16); hipFree(m->d_bfacets); hipFree(m->d_tperm); hipFree(m->d_send_idx); hipFree(m->d_send_buf); hipFree(m->d_scratch); hipFree(m->d_slices_int); hipFree(m->d_slices_bnd);
@@ -589,6 +589,8 @@ int femo_assemble_system(femo_mesh* m, int pde, const double* params, const femo
     FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(u)));
   }
   FEMO_REQUIRE(aux == nullptr || aux->n >= m->n_vert, "aux field shorter than n_vert");
+  FEMO_TRY(femo_vec_await(u));
+  FEMO_TRY(femo_vec_await(aux));
   if (J_nobc) { J_nobc->valsT_valid = false; J_nobc->scaled_valid = false; J_nobc->s_valid = false; FEMO_TRY(note_pinned_vertices(J_nobc, pde, params, nullptr)); }
   femo_vec_touch(rhs);
   if (A_bc) { A_bc->valsT_valid = false; A_bc->scaled_valid = false; A_bc->s_valid = false; FEMO_TRY(note_pinned_vertices(A_bc, pde, params, bc)); }
@@ -596,7 +598,8 @@ int femo_assemble_system(femo_mesh* m, int pde, const double* params, const femo
                             bc ? bc->d_mask : nullptr, bc ? bc->d_dense : nullptr,
                             J_nobc ? J_nobc->d_diag : nullptr, J_nobc ? J_nobc->d_vals : nullptr,
                             A_bc ? A_bc->d_diag : nullptr, A_bc ? A_bc->d_vals : nullptr,
-                            rhs ? rhs->d : nullptr, f ? f->uid : 0, f ? f->gen : 0, bc ? bc->d_rowmask : nullptr);
+                            rhs ? rhs->d : nullptr, f ? f->uid : 0, f ? f->gen : 0, bc ? bc->d_rowmask : nullptr, f,
+                            (rhs && A_bc && !J_nobc) ? A_bc : nullptr);
 }
 
 int femo_bc_apply_rhs(const femo_bc* bc, const femo_vec* u, femo_vec* b) {

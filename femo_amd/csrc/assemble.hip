@@ -1617,11 +1617,22 @@ static int launch_system_t(femo_mesh* m, int64_t nb, size_t lds, const double* u
   return 0;
 }
 
+// rhs -= L on the rows outside the Dirichlet set (deferred-upload path: the pass ran with a zero load vector)
+__global__ void k_rhs_sub_load(int64_t n_rows, const double* __restrict__ load, const uint8_t* __restrict__ bcmask, double* __restrict__ rhs) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += (int64_t)gridDim.x * blockDim.x)
+    if (!(bcmask != nullptr && bcmask[i])) rhs[i] -= load[i];
+}
+
 int femo_launch_system(femo_mesh* m, int pde, const double* params, const double* u, const double* f,
                        const double* aux, const uint8_t* bcmask, const double* bcval, double* diag0,
                        double* vals0, double* diag1, double* vals1, double* rhs, uint64_t f_uid, uint64_t f_gen,
-                       const uint64_t* bc_rowmask) {
+                       const uint64_t* bc_rowmask, const femo_vec* f_vec, femo_mat* A_solve) {
   FEMO_TRY(check_nl(m, pde, u, aux));
+  // An upload of f still in flight (femo_vec_set_host_deferred): only the linear-Poisson pass with a right-hand side can
+  // do useful work before it needs f; every other combination waits here.
+  const bool defer = f_vec != nullptr && f_vec->h2d_pending && pde == FEMO_PDE_POISSON && rhs != nullptr && vals1 != nullptr &&
+                     vals0 == nullptr && m->d_load != nullptr;
+  if (f_vec != nullptr && !defer) FEMO_TRY(femo_vec_await(f_vec));
   FEMO_REQUIRE(rhs == nullptr || (u != nullptr && f != nullptr), "the Newton right-hand side needs u and f");
   FEMO_REQUIRE((diag1 == nullptr && rhs == nullptr) || bcmask == nullptr || bcval != nullptr, "missing Dirichlet values");
   const int64_t nb = row_blocks(m);
@@ -1649,10 +1660,27 @@ int femo_launch_system(femo_mesh* m, int pde, const double* params, const double
   }
   // linear Poisson: the kernel takes the load vector of f where the other forms take their aux field
   const double* load = nullptr;
-  if (rhs) {
+  if (rhs && defer) {
+    // (K u' first, against a zero load vector; the load vector is subtracted once f has arrived, below)
+    if (!m->d_zero_load) {
+      const size_t nz = (size_t)(std::max<int64_t>(m->n_slices * FEMO_WAVE, 1) + 2);
+      FEMO_HIP_CHECK(hipMalloc(&m->d_zero_load, nz * sizeof(double)));
+      FEMO_HIP_CHECK(hipMemsetAsync(m->d_zero_load, 0, nz * sizeof(double), m->ctx->stream));
+    }
+    load = m->d_zero_load;
+  } else if (rhs) {
     FEMO_TRY(ensure_load_vector(m, f, f_uid, f_gen));
     load = m->d_load;
   }
+  auto finish_deferred = [&]() -> int {
+    if (!defer) return 0;
+    if (A_solve != nullptr) FEMO_TRY(femo_mat_prescale(A_solve));      // S, S A S: what the solve with this matrix starts with
+    FEMO_TRY(femo_vec_await(f_vec));
+    FEMO_TRY(ensure_load_vector(m, f, f_uid, f_gen));
+    hipLaunchKernelGGL(k_rhs_sub_load, dim3(cell_grid(m->n_rows)), dim3(FEMO_BLOCK), 0, m->ctx->stream, m->n_rows, m->d_load, bcmask, rhs);
+    FEMO_HIP_CHECK(hipGetLastError());
+    return 0;
+  };
   // rows with up to 64 neighbours: the row neighbourhood fits in LDS (one wave per workgroup)
   const int nbr = (m->max_rowlen + 1) & ~1;
   const size_t lds_row = (size_t)nbr * (m->tdim + 1) * 64 * sizeof(double);
@@ -1705,15 +1733,16 @@ int femo_launch_system(femo_mesh* m, int pde, const double* params, const double
 #undef FEMO_SYS_PIPE_COMBO
 #undef FEMO_SYS_PIPE
       FEMO_HIP_CHECK(hipGetLastError());
-      return 0;
+      return finish_deferred();
     }
     if (m->tdim == 3) FEMO_SYS_LDS(3); else FEMO_SYS_LDS(2);
 #undef FEMO_SYS_LDS
     FEMO_HIP_CHECK(hipGetLastError());
-    return 0;
+    return finish_deferred();
   }
-  if (m->tdim == 3) return launch_system_t<3, FEMO_PDE_POISSON>(m, nb, lds, u, f, load, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
-  return launch_system_t<2, FEMO_PDE_POISSON>(m, nb, lds, u, f, load, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs);
+  if (m->tdim == 3) FEMO_TRY((launch_system_t<3, FEMO_PDE_POISSON>(m, nb, lds, u, f, load, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs)));
+  else FEMO_TRY((launch_system_t<2, FEMO_PDE_POISSON>(m, nb, lds, u, f, load, beta, sgn, bcmask, bcval, diag0, vals0, diag1, vals1, rhs)));
+  return finish_deferred();
 }
 
 int femo_launch_dRdf(femo_mesh* m, int pde, const double* params, const double* u,

@@ -997,7 +997,10 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
   if (blockIdx.x > 0) {
     const int nc = gridDim.x - 1, b = blockIdx.x - 1;
     double rr = 0.0, lat = 0.0;
-    if (!mc.init) {
+    if (mc.init) {
+      // first apply: nothing to update, but r.r of the initial residual is what the next iteration's all-reduce carries
+      for (int64_t i = (int64_t)b * 1024 + threadIdx.x; i < mc.n; i += (int64_t)nc * 1024) rr += mc.r[i] * mc.r[i];
+    } else {
       const int64_t n2 = mc.n >> 1;
       double2* x2 = reinterpret_cast<double2*>(mc.x);
       double2* r2 = reinterpret_cast<double2*>(mc.r);
@@ -1088,12 +1091,18 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
     c_cur = c_nxt;
     lds_barrier();
   }
-  {
+  if (top > 0) {
     const double* ec = coarse_lds + L.off[top - 1] + L.nodes[top - 1];
 #pragma unroll
     for (int q = 0; q < TOPR; ++q) {
       const int64_t idx = tid + q * 1024;
       if (idx < n_top) L.e[top][idx] = ct[q] * gt[q] + lattice_interp_node(idx, L.n[top], L.n[top - 1], dim, ec);
+    }
+  } else {                                          // level T-1 is the coarsest lattice: nothing below it
+#pragma unroll
+    for (int q = 0; q < TOPR; ++q) {
+      const int64_t idx = tid + q * 1024;
+      if (idx < n_top) L.e[top][idx] = ct[q] * gt[q];
     }
   }
   const double t = femo_block_sum<1024>(dot, red);
@@ -1809,7 +1818,7 @@ int femo_pc_begin(femo_mesh* m, const double* s, const uint8_t* mask) {
 static bool merged_shape_ok(const femo_pc* pc) {
   const int nl = pc->n_levels, nf = pc->n_fused;
   const int T = nl - 1 - nf;
-  if (nf != 2 || T < 2 || T >= FEMO_PC_MAX_LEVELS - 1) return false;
+  if (nf != 2 || T < 1 || T >= FEMO_PC_MAX_LEVELS - 1) return false;
   int64_t below = 0;
   for (int l = 0; l + 1 < T; ++l) below += pc->L[l].nodes;
   const int64_t lds = below * 2 * (int64_t)sizeof(double) + pc->L[T - 1].nodes * (int64_t)sizeof(double);

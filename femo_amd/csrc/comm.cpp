@@ -104,6 +104,7 @@ int emu_neighbors(femo_ctx* ctx, int n_nbr, const int32_t* nbr, const int64_t* s
 // d[0..count) <- sum over the ranks, in place, ordered on `st`
 int femo_coll_allreduce(femo_ctx* ctx, double* d, int64_t count, hipStream_t st) {
   if (count <= 0) return 0;
+  ++ctx->n_allreduce; ctx->allreduce_doubles += count;
   if (ctx->emu != nullptr) return emu_allreduce(ctx, d, count, st);
   FEMO_REQUIRE(ctx->comm != nullptr, "collective before femo_comm_init");
   FEMO_NCCL_CHECK(ncclAllReduce(d, d, (size_t)count, ncclDouble, ncclSum, ctx->comm, st));
@@ -114,6 +115,7 @@ int femo_coll_allreduce(femo_ctx* ctx, double* d, int64_t count, hipStream_t st)
 int femo_coll_neighbors(femo_ctx* ctx, int n_nbr, const int32_t* nbr, const int64_t* send_ptr, const double* d_send,
                         const int64_t* recv_ptr, double* d_recv, hipStream_t st) {
   if (n_nbr == 0) return 0;
+  ++ctx->n_neighbor; ctx->neighbor_doubles += send_ptr[n_nbr];
   if (ctx->emu != nullptr) return emu_neighbors(ctx, n_nbr, nbr, send_ptr, d_send, recv_ptr, d_recv, st);
   FEMO_REQUIRE(ctx->comm != nullptr, "halo exchange before femo_comm_init");
   FEMO_NCCL_CHECK(ncclGroupStart());
@@ -128,6 +130,13 @@ int femo_coll_neighbors(femo_ctx* ctx, int n_nbr, const int32_t* nbr, const int6
 }
 
 extern "C" {
+
+int femo_comm_stats(femo_ctx* ctx, int64_t out[4], int reset) {
+  FEMO_REQUIRE(ctx && out, "null argument");
+  out[0] = ctx->n_allreduce; out[1] = ctx->allreduce_doubles; out[2] = ctx->n_neighbor; out[3] = ctx->neighbor_doubles;
+  if (reset) ctx->n_allreduce = ctx->allreduce_doubles = ctx->n_neighbor = ctx->neighbor_doubles = 0;
+  return 0;
+}
 
 int femo_emu_group_create(int nranks, femo_emu_group** out) {
   FEMO_REQUIRE(out != nullptr && nranks >= 1 && nranks <= 64, "bad argument");

@@ -121,6 +121,9 @@ struct femo_ctx {
   ncclComm_t comm = nullptr;
   struct femo_emu_group* emu = nullptr;      // in-process rank emulation (tests; comm.cpp)
   int rank = 0, nranks = 1;
+  // collectives issued through femo_coll_allreduce / femo_coll_neighbors since the last femo_comm_stats(reset):
+  // calls and doubles moved (per rank) -- the bench's scaling record and the tests count them per CG iteration
+  int64_t n_allreduce = 0, allreduce_doubles = 0, n_neighbor = 0, neighbor_doubles = 0;
   hipStream_t comm_stream = nullptr;          // halo exchange overlapped with interior rows
   hipEvent_t ev_main = nullptr, ev_comm = nullptr;
   int n_cu = 256;
@@ -151,12 +154,19 @@ struct femo_vec {
   // makes the compute stream wait for it (every writing entry point calls femo_vec_touch BEFORE it launches)
   hipEvent_t d2h_ev = nullptr;
   bool d2h_pending = false;
+  // a deferred upload of this vector (femo_vec_set_host_deferred) is (or was) in flight on the copy stream: the first
+  // reader or writer on the compute stream waits for it (femo_vec_await; round 4: the f-independent half of the first
+  // assembly pass, S A S and the preconditioner weights run under the upload of f)
+  hipEvent_t h2d_ev = nullptr;
+  bool h2d_pending = false;
 };
 void femo_vec_wait_readers(femo_vec* v);   // hostmem.cpp
+extern "C" int femo_vec_await(const femo_vec* v);     // hostmem.cpp: compute stream waits for a deferred upload of v (no-op otherwise)
 inline void femo_vec_touch(femo_vec* v) {
   if (!v) return;
   ++v->gen;
   if (v->d2h_pending) femo_vec_wait_readers(v);
+  if (v->h2d_pending) femo_vec_await(v);
 }
 // out = a + b on the stream (api.hip; the device half of femo_vec_add_to_host)
 int femo_launch_sum(double* out, const double* a, const double* b, int64_t n, hipStream_t st);
@@ -209,6 +219,7 @@ struct femo_mesh {
   int16_t* d_cols16 = nullptr;   // FemoTopology::cols16
   void* d_visit_rec = nullptr;   // per incidence entry, 12 B: (slots, 1/(36|T|)) for the Poisson walks, built on first use
   double* d_load = nullptr;      // load vector of the Poisson residual for the f identified by (load_uid, load_gen)
+  double* d_zero_load = nullptr; // zeros of the same length (deferred-upload path of femo_launch_system)
   uint64_t load_uid = 0, load_gen = 0;
   int pcg_last_iters = 0, pcg_prev_iters = 0;   // iterations of the last two converged BPX-PCG solves on this mesh (size the first batch)
   struct femo_mat* mass = nullptr;  // P1 mass matrix on the operator pattern (geometry only; built on first use): dJ/du = M (u - u_d)
@@ -326,10 +337,14 @@ __device__ __forceinline__ int64_t femo_xcd_block(int64_t b, int64_t nb) {
 // kernel launchers implemented in the .hip files -------------------------------
 int femo_launch_residual(femo_mesh* m, int pde, const double* params, const double* u,
                          const double* f, const double* aux, double* r, uint64_t f_uid = 0, uint64_t f_gen = 0);
+// f_vec / A_solve (optional): the input vector behind `f` and the matrix behind (diag1, vals1).  When an upload of f is
+// still in flight the linear-Poisson pass assembles the matrix and K u' first, scales A_solve for the Krylov loop, and
+// only then waits for f, builds the load vector and completes the right-hand side.
 int femo_launch_system(femo_mesh* m, int pde, const double* params, const double* u, const double* f,
                        const double* aux, const uint8_t* bcmask, const double* bcval, double* diag0, double* vals0,
                        double* diag1, double* vals1, double* rhs, uint64_t f_uid = 0, uint64_t f_gen = 0,
-                       const uint64_t* bc_rowmask = nullptr);
+                       const uint64_t* bc_rowmask = nullptr, const femo_vec* f_vec = nullptr, femo_mat* A_solve = nullptr);
+int femo_mat_prescale(femo_mat* A);        // solver.hip: S = diag^-1/2 and S A S now (what the first solve with A would do)
 int femo_launch_cell_expr(femo_mesh* m, int kind, const double* params, const double* in, double* out);
 int femo_launch_dRdf(femo_mesh* m, int pde, const double* params, const double* u,
                      const double* f, double* vals);

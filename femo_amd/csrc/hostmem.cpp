@@ -609,6 +609,7 @@ int femo_vec_set_host(femo_vec* v, const double* host, int64_t n) {
   if (!elided || verify_enabled()) FEMO_TRY(wait_block(host));   // the bytes themselves are needed
   if (elided && verify_enabled()) {
     std::vector<double> chk((size_t)n);
+    FEMO_HIP_CHECK(hipStreamSynchronize(v->ctx->stream));   // the fill / scale / copy above runs on a non-blocking stream
     FEMO_HIP_CHECK(hipMemcpy(chk.data(), v->d, n * sizeof(double), hipMemcpyDeviceToHost));
     FEMO_REQUIRE(memcmp(chk.data(), host, (size_t)n * sizeof(double)) == 0,
                  "FEMO_HOST_VERIFY: an elided upload (kind %d) would have changed the vector", elided);
@@ -628,6 +629,72 @@ int femo_vec_set_host(femo_vec* v, const double* host, int64_t n) {
     }
   }
   return 0;
+}
+
+// Deferred upload: the copy runs on the context's copy stream and the call returns at once.  Only from a whole pooled
+// block of femo_host_alloc (its writers announce themselves, and femo_host_touch / femo_host_free wait for the copy);
+// every other case -- elisions, caller-owned memory, pageable memory -- is the synchronous femo_vec_set_host.  The compute
+// stream waits in femo_vec_await, which every writer of v calls through femo_vec_touch and which the assembly entry points
+// call for their inputs; a driver that defers uploads awaits them before anything else reads the vector
+// (engine.deferred_uploads).  Replaces the same copy of utils_dolfinx.py:300-311.
+int femo_vec_set_host_deferred(femo_vec* v, const double* host, int64_t n) {
+  FEMO_REQUIRE(v && host, "null argument");
+  FEMO_REQUIRE(n == v->n, "size mismatch: vector has %lld entries, host array %lld", (long long)v->n, (long long)n);
+  bool ok = false;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (HostBlock* b = find_block(host, (size_t)n * sizeof(double))) {
+      const bool exact = reinterpret_cast<const char*>(host) == b->base;
+      bool mirrors_live = false;
+      if (exact && b->src_uid != 0 && b->src_n >= n) {
+        auto it = g_live.find(b->src_uid);
+        mirrors_live = it != g_live.end() && it->second->gen == b->src_gen;
+      }
+      ok = exact && b->pooled && !b->pending && b->const_n < n && !mirrors_live && n * (int64_t)sizeof(double) >= (8 << 20);
+    }
+  }
+  if (!ok || verify_enabled()) return femo_vec_set_host(v, host, n);
+  femo_ctx* c = v->ctx;
+  FEMO_HIP_CHECK(hipSetDevice(c->device));
+  FEMO_TRY(ensure_copy_stream(c));
+  femo_vec_touch(v);                                     // earlier copy-outs / uploads of v first; new generation
+  if (v->h2d_ev == nullptr) FEMO_HIP_CHECK(hipEventCreateWithFlags(&v->h2d_ev, hipEventDisableTiming));
+  Trace tr("set_host (deferred)", n * 8);
+  hipEvent_t ready = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    HostBlock* b = find_block(host, (size_t)n * sizeof(double));
+    if (b->ready == nullptr) b->ready = take_event();
+    ready = b->ready;
+  }
+  FEMO_REQUIRE(ready != nullptr, "could not create an event");
+  FEMO_HIP_CHECK(hipEventRecord(c->ev_copy, c->stream));           // kernels enqueued so far may still read v
+  FEMO_HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0));
+  FEMO_HIP_CHECK(hipMemcpyAsync(v->d, host, n * sizeof(double), hipMemcpyHostToDevice, c->copy_stream));
+  FEMO_HIP_CHECK(hipEventRecord(ready, c->copy_stream));
+  FEMO_HIP_CHECK(hipEventRecord(v->h2d_ev, c->copy_stream));
+  v->h2d_pending = true;
+  std::lock_guard<std::mutex> lk(g_mu);
+  ++g_stats.h2d_pinned; g_stats.h2d_pinned_bytes += n * 8;
+  ++g_stats.h2d_deferred; g_stats.h2d_deferred_bytes += n * 8;
+  if (HostBlock* b = find_block(host, (size_t)n * sizeof(double))) {
+    b->pending = true; b->pend_ctx = c;
+    if (v->uid != 0) { b->src_uid = v->uid; b->src_gen = v->gen; b->src_n = n; b->src_scale = 1.0; }
+  }
+  return 0;
+}
+
+int femo_vec_await(const femo_vec* v_) {
+  femo_vec* v = const_cast<femo_vec*>(v_);
+  if (!v || !v->h2d_pending) return 0;
+  v->h2d_pending = false;
+  FEMO_HIP_CHECK(hipStreamWaitEvent(v->ctx->stream, v->h2d_ev, 0));
+  return 0;
+}
+
+int femo_vec_await_upload(const femo_vec* v) {
+  FEMO_REQUIRE(v != nullptr, "null argument");
+  return femo_vec_await(v);
 }
 
 // op 0: host = v; op 1: host += v.  lazy: return before the bytes have landed (pinned blocks, op 0 only).
@@ -659,6 +726,7 @@ static int get_host_impl(const femo_vec* v, double* host, int64_t n, int op, boo
     Trace tr("add_to_host (device sum)", n * 8);
     if (verify_enabled()) {
       std::vector<double> chk((size_t)n);
+      FEMO_HIP_CHECK(hipStreamSynchronize(c->stream));
       FEMO_HIP_CHECK(hipMemcpy(chk.data(), mirror->d, n * sizeof(double), hipMemcpyDeviceToHost));
       FEMO_REQUIRE(memcmp(chk.data(), host, (size_t)n * sizeof(double)) == 0,
                    "FEMO_HOST_VERIFY: the block no longer holds the vector it is recorded to mirror");

@@ -1079,6 +1079,42 @@ extern "C" int femo_vec_dot(const femo_vec* x, const femo_vec* y, int64_t n, dou
   return femo_reduce_to_host(ctx, g, 1, out);
 }
 
+namespace {
+struct DotPairs { const double* a[4]; const double* b[4]; int k; };
+__global__ __launch_bounds__(FEMO_BLOCK) void k_dots(int64_t n, DotPairs d, double* __restrict__ partials) {
+  __shared__ double lds[FEMO_BLOCK / 64];
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FEMO_BLOCK) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < d.k) s[j] += d.a[j][i] * d.b[j][i];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (j < d.k) {
+      const double t = femo_block_sum<FEMO_BLOCK>(s[j], lds);
+      if (threadIdx.x == 0) partials[(int64_t)j * FEMO_MAX_PARTIALS + blockIdx.x] = t;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int femo_vec_dots(int k, const femo_vec* const* x, const femo_vec* const* y, int64_t n, double* out) {
+  FEMO_REQUIRE(x && y && out && k >= 1 && k <= 4, "femo_vec_dots: 1..4 pairs");
+  DotPairs d;
+  d.k = k;
+  for (int j = 0; j < 4; ++j) {
+    const int jj = j < k ? j : 0;
+    FEMO_REQUIRE(x[jj] && y[jj] && n <= x[jj]->n && n <= y[jj]->n, "dot length exceeds vector size");
+    d.a[j] = x[jj]->d; d.b[j] = y[jj]->d;
+  }
+  femo_ctx* ctx = x[0]->ctx;
+  const int g = vec_grid(ctx, n);
+  hipLaunchKernelGGL(k_dots, dim3(g), dim3(FEMO_BLOCK), 0, ctx->stream, n, d, ctx->d_partials);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return femo_reduce_to_host(ctx, g, k, out);
+}
+
 static int ensure_scaled(femo_mat* A, bool transpose);
 
 extern "C" int femo_bench_spmv(const femo_mat* A, const femo_vec* x, femo_vec* y, int reps, double* ms_per_launch) {
@@ -1254,35 +1290,35 @@ static int solve_pcg_bpx_merged(femo_mat* A, const femo_vec* b, femo_vec* x, con
   V.nb_q[0] = V.nb_q[1] = 0; V.Pq[0] = V.Pq[1] = nullptr;
   FEMO_TRY(femo_pc_merged_apply(m, mask, A->pc_key, V, S, ctx->d_flags, &stop));
   FEMO_HIP_CHECK(hipGetLastError());
-  // the one synchronisation before the loop: rho0, bb, gamma0 and the flag
+  // The one synchronisation before the loop: rho0, bb, gamma0 and the flag.  x of a solve that does not iterate (the
+  // identity rows, solved by k_cg_init) is written speculatively in front of it -- 6 us that save such a solve (Newton's
+  // later passes) a second stream drain; an iterating solve overwrites it at the end.
+  const bool spec_x = n > 0 && opts->zero_guess;
+  if (spec_x) hipLaunchKernelGGL(k_unscale, dim3(2048), dim3(256), 0, st, n, 0, A->d_s, w.xh, x->d);
   FEMO_HIP_CHECK(hipMemcpyAsync(h_flags, ctx->d_flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, S, FEMO_NSCAL * sizeof(double), hipMemcpyDeviceToHost, st));
-  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  FEMO_HIP_CHECK(hipEventRecord(ctx->ev1, st));
+  FEMO_HIP_CHECK(hipEventSynchronize(ctx->ev1));
   const double rho0 = ctx->h_scal[MS_RR], bb = ctx->h_scal[MS_BB], gamma0 = ctx->h_scal[MS_GAMMA];
   info->rhs_norm = std::sqrt(bb);
   const int max_it = opts->max_it > 0 ? opts->max_it : 10000;
-  auto finish = [&](int iters, int conv, double rho) -> int {
-    if (n > 0) {
-      hipLaunchKernelGGL(k_unscale, dim3(2048), dim3(256), 0, st, n, opts->zero_guess ? 0 : 1, A->d_s, w.xh, x->d);
-      FEMO_HIP_CHECK(hipGetLastError());
-    }
-    FEMO_HIP_CHECK(hipEventRecord(ctx->ev1, st));
-    FEMO_HIP_CHECK(hipEventSynchronize(ctx->ev1));
-    float ms = 0.f;
-    FEMO_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    info->iterations = iters;
-    info->converged = conv;
-    info->residual_norm = std::sqrt(rho);
-    info->solve_ms = ms;
-    return 0;
-  };
   info->spmv_ms = 0.0; info->spmv_samples = 0;
-  if (h_flags[0]) {                               // below the absolute tolerance (k_pcg_setup) or below atol_pc (first apply)
-    info->pc_rhs_norm = std::sqrt(gamma0 * (rho0 > 0.0 ? bb / rho0 : 1.0));
-    info->pc_residual_norm = std::sqrt(gamma0);
-    return finish(0, (h_flags[2] || !(rho0 == rho0)) ? -1 : 1, rho0);
-  }
   info->pc_rhs_norm = std::sqrt(gamma0 * (rho0 > 0.0 ? bb / rho0 : 1.0));
+  if (h_flags[0]) {                               // below the absolute tolerance (k_pcg_setup) or below atol_pc (first apply)
+    info->pc_residual_norm = std::sqrt(gamma0);
+    if (!spec_x && n > 0) {
+      hipLaunchKernelGGL(k_unscale, dim3(2048), dim3(256), 0, st, n, 1, A->d_s, w.xh, x->d);
+      FEMO_HIP_CHECK(hipEventRecord(ctx->ev1, st));
+      FEMO_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    }
+    float ms0 = 0.f;
+    FEMO_HIP_CHECK(hipEventElapsedTime(&ms0, ctx->ev0, ctx->ev1));
+    info->iterations = 0;
+    info->converged = (h_flags[2] || !(rho0 == rho0)) ? -1 : 1;
+    info->residual_norm = std::sqrt(rho0);
+    info->solve_ms = ms0;
+    return 0;
+  }
   FEMO_TRY(ensure_scaled(A, false));
 
   const int n_sample = 4, sample_from = 2;
@@ -1357,6 +1393,8 @@ static int solve_pcg_bpx_merged(femo_mat* A, const femo_vec* b, femo_vec* x, con
   info->solve_ms = ms;
   return 0;
 }
+
+int femo_mat_prescale(femo_mat* A) { return ensure_scaled(A, false); }
 
 // CG with the auxiliary-lattice BPX preconditioner.  Same scaled system, same stopping norm
 // (sqrt(rh.rh) = sqrt(r^T D^-1 r)) as the Jacobi path; scalars live on the device and are

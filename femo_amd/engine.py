@@ -9,7 +9,7 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import threading
-from typing import Dict, Optional, Sequence
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
@@ -217,6 +217,28 @@ def lazy_results(enabled: bool = True):
         _LAZY.on = prev
 
 
+_DEFER = threading.local()
+
+
+@contextlib.contextmanager
+def deferred_uploads(enabled: bool = True):
+    """Inside the block ``Vec.set`` from a pinned library block returns before the bytes have reached the device
+    (femo_vec_set_host_deferred): the assembly entry points order their input-independent work in front of the wait, so
+    the matrix of the first Newton pass, its scaling and the preconditioner weights run under the upload of the inputs
+    (state_model.py:94-103).  On leaving the block the compute stream waits for every upload started in it, so code
+    outside never sees a vector in flight."""
+    if not enabled or getattr(_DEFER, "vecs", None) is not None:
+        yield
+        return
+    _DEFER.vecs = []
+    try:
+        yield
+    finally:
+        vecs, _DEFER.vecs = _DEFER.vecs, None
+        for v in vecs:
+            v.await_upload()
+
+
 def writable(a: np.ndarray, announce: bool = True) -> np.ndarray:
     """Writable alias of an array the library returned read-only.  For its new owner (a driver that
     accumulates into a result in place); the block stops counting as a mirror of its device vector.
@@ -307,6 +329,12 @@ class Context:
         check(_lib.load().femo_comm_unique_id(buf))
         return buf.raw
 
+    def comm_stats(self, reset: bool = False) -> Dict[str, int]:
+        """Collectives this context issued since the last reset (femo_comm_stats)."""
+        out = (C.c_int64 * 4)()
+        check(self.lib.femo_comm_stats(self.handle, out, int(reset)))
+        return dict(allreduce_calls=int(out[0]), allreduce_doubles=int(out[1]), neighbor_calls=int(out[2]), neighbor_doubles=int(out[3]))
+
     def allreduce_sum(self, values: Sequence[float]) -> np.ndarray:
         a = _f64(values).copy()
         check(self.lib.femo_allreduce_sum(self.handle, a.ctypes.data_as(_lib.c_f64p), a.size))
@@ -339,7 +367,17 @@ class Vec:
     def set(self, a) -> "Vec":
         a = _f64(a)
         _note_caller_array(a)
-        check(self.lib.femo_vec_set_host(self.handle, _ptr(a), a.size))
+        pending = getattr(_DEFER, "vecs", None)
+        if pending is not None:
+            # inside engine.deferred_uploads(): the copy may still be in flight when this returns (pinned library blocks only)
+            check(self.lib.femo_vec_set_host_deferred(self.handle, _ptr(a), a.size))
+            pending.append(self)
+        else:
+            check(self.lib.femo_vec_set_host(self.handle, _ptr(a), a.size))
+        return self
+
+    def await_upload(self) -> "Vec":
+        check(self.lib.femo_vec_await_upload(self.handle))
         return self
 
     def get(self, n: Optional[int] = None, out: Optional[np.ndarray] = None) -> np.ndarray:
@@ -385,6 +423,17 @@ class Vec:
         out = C.c_double(0.0)
         check(self.lib.femo_vec_dot(self.handle, other.handle, self.n if n is None else n, C.byref(out)))
         return out.value
+
+    @staticmethod
+    def dots(pairs, n: int) -> List[float]:
+        """[x . y for (x, y) in pairs] over the first ``n`` entries, at most four pairs: one kernel, one reduction
+        and one host synchronisation for all of them (femo_vec_dots)."""
+        k = len(pairs)
+        xs = (C.c_void_p * k)(*[p[0].handle for p in pairs])
+        ys = (C.c_void_p * k)(*[p[1].handle for p in pairs])
+        out = (C.c_double * k)()
+        check(pairs[0][0].lib.femo_vec_dots(k, xs, ys, int(n), out))
+        return [float(v) for v in out]
 
     @property
     def device_ptr(self) -> int:

@@ -631,11 +631,16 @@ class _NewtonBase:
         z0 = None
         energy_scale = None
         eps = np.finfo(np.float64).eps
+        bpx_energy = opts.get("pc") == "bpx" and A.pde_kind in _BPX_KINDS
+        # Every scalar a Newton step looks at -- ||F||, ||u|| (noise floor of the next solve), ||dx|| (SNES step test),
+        # u.Au (energy scale of the next solve's threshold) -- comes from ONE reduction and one host synchronisation
+        # after the assembly pass (Vec.dots); rounds 1-3 drained the stream for each of them.
+        unorm = uAu = None
+        g2 = None
         while not converged and it < self.max_it:
             if it > 0:
-                unorm = float(np.sqrt(func.vec.dot(func.vec, n_own)))
                 opts["atol"] = max(KSP_OPTIONS["atol"], KSP_OPTIONS["rtol"] * z0, self.NOISE_FACTOR * eps * unorm)
-                if opts.get("pc") == "bpx" and A.pde_kind in _BPX_KINDS:
+                if bpx_energy:
                     # Later corrections are solved to the accuracy the first solve aims at, measured against the
                     # STATE: sqrt(r^T M^-1 r) ~ energy norm of the error, threshold rtol_bpx * sqrt(u^T A u) (interior
                     # rows).  From a good initial state (u = 0 in bench.py) the first solve already is that accurate
@@ -644,17 +649,16 @@ class _NewtonBase:
                     # The threshold is a scale, not a result: when the correction just applied did not iterate (it was
                     # below the previous threshold, i.e. below rtol_bpx of the state in the energy norm) the state's
                     # energy is unchanged to that accuracy and the product A u (0.28 ms at C4) is not repeated.
-                    if energy_scale is None or self.ksp_iterations[-1] > 0:
-                        Au = _work(mesh, "newton_Au", lambda: Vec(ctx, n))
-                        A.mult(func.vec, Au)
-                        g2 = 0.0
-                        if ds is not None:
-                            own = ds.vals[ds.dofs < n_own]                      # identity rows: (A u)_i = u_i = g_i
-                            g2 = float(np.square(own).sum())    # not np.dot: the first BLAS call starts a pool of spinning
-                            #                                     threads (one per core) that eats the process's CPU quota
-                            if ctx.nranks > 1:
-                                g2 = float(ctx.allreduce_sum([g2])[0])           # every rank must use the same threshold
-                        energy_scale = float(np.sqrt(max(func.vec.dot(Au, n_own) - g2, 0.0)))
+                    if uAu is not None:
+                        if g2 is None:
+                            g2 = 0.0
+                            if ds is not None:
+                                own = ds.vals[ds.dofs < n_own]                      # identity rows: (A u)_i = u_i = g_i
+                                g2 = float(np.square(own).sum())    # not np.dot: the first BLAS call starts a pool of spinning
+                                #                                     threads (one per core) that eats the process's CPU quota
+                                if ctx.nranks > 1:
+                                    g2 = float(ctx.allreduce_sum([g2])[0])           # every rank must use the same threshold
+                        energy_scale = float(np.sqrt(max(uAu - g2, 0.0)))
                     opts["atol_pc"] = opts.get("rtol_bpx", 1e-11) * energy_scale
             ksp = KSP(A, opts)
             ksp.solve(b, dx)
@@ -663,15 +667,27 @@ class _NewtonBase:
             self.ksp_iterations.append(ksp.info.iterations)
             func.vec.axpy(-1.0, dx)
             it += 1
-            step_small = False
-            if self.stol > 0.0:
-                step_small = dx.dot(dx, n_own) < (self.stol ** 2) * func.vec.dot(func.vec, n_own)
             # next pass: residual for the convergence test and, in the same launch, the Jacobian the
             # next iteration will use.  After the last allowed iteration nothing consumes a Jacobian
             # (the reference assembles J only when it iterates again), so that pass is residual-only.
             E.assemble_system(dm, F.pde_kind, F.params, F.u.vec, F.f.vec, ds, None,
                               A.mat if it < self.max_it else None, b, aux=aux)
-            r = float(np.sqrt(b.dot(b, n_own)))
+            pairs = [(b, b)]
+            more = it < self.max_it
+            want_energy = more and bpx_energy and (energy_scale is None or self.ksp_iterations[-1] > 0)
+            if more or self.stol > 0.0:
+                pairs.append((func.vec, func.vec))
+            if self.stol > 0.0:
+                pairs.append((dx, dx))
+            if want_energy:
+                Au = _work(mesh, "newton_Au", lambda: Vec(ctx, n))
+                A.mult(func.vec, Au)
+                pairs.append((func.vec, Au))
+            vals = Vec.dots(pairs, n_own)
+            r = float(np.sqrt(vals[0]))
+            unorm = float(np.sqrt(vals[1])) if len(vals) > 1 else None
+            step_small = self.stol > 0.0 and vals[2] < (self.stol ** 2) * vals[1]
+            uAu = vals[-1] if want_energy else None
             self.residual_norms.append(r)
             converged = r < self.atol or (r0 > 0 and r / r0 < self.rtol) or step_small
             if self.report:

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FEMO_ABI_VERSION 6
+#define FEMO_ABI_VERSION 7
 
 typedef struct femo_ctx  femo_ctx;   /* device + stream + reduction workspace (+ RCCL communicator) */
 typedef struct femo_vec  femo_vec;   /* fp64 device vector  (dolfinx Function.vector / PETSc Vec)     */
@@ -137,10 +137,22 @@ int     femo_vec_get_host(const femo_vec* v, double* host, int64_t n);      /* g
  * pass over the host array (the add runs in the host threads that drain the staging slots).       */
 int     femo_vec_add_to_host(const femo_vec* v, double* host, int64_t n);
 int     femo_vec_get_host_async(const femo_vec* v, double* host, int64_t n);   /* see "asynchronous results" below */
+/* Deferred upload (round 4): like femo_vec_set_host, but from a whole block of femo_host_alloc the copy runs on the
+ * context's copy stream and the call returns at once; the matrix half of the next assembly pass, its scaling and the
+ * preconditioner weights -- none of which depend on the input -- then run under the transfer (state_model.py:94-103
+ * sends the inputs before it solves).  Writers of v and the assembly entry points wait by themselves; before any
+ * OTHER entry point reads v the caller says femo_vec_await_upload (engine.deferred_uploads does it on leaving the
+ * scope).  Everything else (caller-owned or pageable memory, elided uploads) is femo_vec_set_host.              */
+int     femo_vec_set_host_deferred(femo_vec* v, const double* host, int64_t n);
+int     femo_vec_await_upload(const femo_vec* v);
 int     femo_vec_fill(femo_vec* v, double value);                           /* Vec.set      */
 int     femo_vec_copy(femo_vec* dst, const femo_vec* src);
 int     femo_vec_axpy(femo_vec* y, double a, const femo_vec* x);            /* y += a x     */
 int     femo_vec_dot(const femo_vec* x, const femo_vec* y, int64_t n, double* out);
+/* out[j] = x[j][0:n] . y[j][0:n] for j < k <= 4: one pass, one reduction (all-reduced over the ranks) and ONE
+ * host synchronisation for all of them -- the norms a Newton step of utils_dolfinx.py:419-449 looks at
+ * (||F||, ||u||, u.Au) used to cost a stream drain each.                                                    */
+int     femo_vec_dots(int k, const femo_vec* const* x, const femo_vec* const* y, int64_t n, double* out);
 
 /* ---- host memory of the array boundary (csrc/hostmem.cpp) -------------------------------------
  * The CSDL operators exchange NumPy arrays with the FE layer in every method (state_model.py:81-84,
@@ -168,6 +180,7 @@ typedef struct femo_host_stats {
   int64_t d2h_staged, d2h_staged_bytes;     /* pageable destination, or accumulate      */
   int64_t d2h_async, d2h_async_bytes;       /* femo_vec_get_host_async                   */
   int64_t d2h_device_sum, d2h_device_sum_bytes; /* accumulate formed on the device      */
+  int64_t h2d_deferred, h2d_deferred_bytes; /* of the h2d_pinned ones: femo_vec_set_host_deferred, on the copy stream */
 } femo_host_stats;
 int femo_host_alloc(int64_t bytes, void** out);
 int femo_host_free(void* p);
@@ -352,6 +365,10 @@ int femo_allreduce_sum(femo_ctx* ctx, double* host_inout, int n);
 int femo_emu_group_create(int nranks, femo_emu_group** out);
 int femo_emu_group_destroy(femo_emu_group* group);
 int femo_comm_emulate(femo_ctx* ctx, femo_emu_group* group, int rank);
+/* Collectives issued on this context since the last reset: out = {all-reduce calls, doubles all-reduced, neighbour
+ * exchanges, doubles sent}.  What `bench.py`'s scaling record and the tests divide by the CG iteration count (the
+ * reference's only collective is the ghost update of utils_dolfinx.py:32,236).                                    */
+int femo_comm_stats(femo_ctx* ctx, int64_t out[4], int reset);
 
 /* ---- Reissner-Mindlin shell (examples/test_shell_m3l/shell_pde.py:219-332) ----------
  * State w = (u_mid in CG2^3, theta in CG1^3) on flat triangular facets: 3 dofs per P2 node (vertices [0, n_vert), then

@@ -491,3 +491,59 @@ def test_distributed_bench_record_on_eight_emulated_ranks():
     assert "host" in c["boundary"] and len(c["setup_rss_mb_per_rank"]) == 8
     rf = r["roofline"]
     assert rf["bound"] == "hbm" and rf["frac"] > 0 and len(rf["achieved_per_rank"]) == 8
+
+
+def test_merged_pcg_one_allreduce_per_iteration_on_emulated_ranks(monkeypatch):
+    """Round 4: the merged BPX-PCG keeps the restricted residual as lattice state (g -= alpha P^T q), so that p.q travels
+    with the lattice sums and r.r / the lattice dot follow from reduced scalars: ONE all-reduce and one halo exchange per
+    iteration.  On a mesh whose lattice has the depth the merged kernels need (n = 48: 4 levels), with 2, 4 and 8 emulated
+    ranks: every rank stops in the same iteration, the count is the single-rank count (merged and classic) to within one,
+    the solution is the single-rank classic solution, and the collectives are COUNTED (femo_comm_stats)."""
+    from femo_amd import engine as E
+    m = fo.unit_cube_mesh(48, 0.2)
+    ref = {}
+
+    def solve(world, classic):
+        if classic:
+            monkeypatch.setenv("FEMO_PCG_CLASSIC", "1")
+        else:
+            monkeypatch.delenv("FEMO_PCG_CLASSIC", raising=False)
+        part = rcb_partition(m.x, world)
+
+        def rank_fn(rank, ctx):
+            L, dm, A, b, _, _ = _local_problem(ctx, m, part, rank, world, seed=3)
+            x = E.Vec(ctx, len(L.x))
+            A.solve_cg(b, x, rtol=1e-11, pc="bpx")                     # first solve: lattice plan, shared-node set-up
+            ctx.sync()
+            ctx.comm_stats(reset=True)
+            info = A.solve_cg(b, x, rtol=1e-11, pc="bpx")
+            st = ctx.comm_stats()
+            return dict(gid=L.vert_global[:L.n_owned], x=x.get(L.n_owned), its=info.iterations, conv=info.converged,
+                        levels=dm.pc_info()["levels"], st=st)
+
+        res = _run_ranks(world, rank_fn)
+        x = np.zeros(m.n_vert)
+        for r in res:
+            assert r["conv"] == 1 and r["levels"] >= 4
+            x[r["gid"]] = r["x"]
+        assert len({r["its"] for r in res}) == 1
+        return x, res[0]["its"], [r["st"] for r in res]
+
+    x_classic, its_classic, _ = solve(1, True)
+    x_merged, its_merged, _ = solve(1, False)
+    assert abs(its_merged - its_classic) <= 1
+    scale = np.abs(x_classic).max()
+    assert np.abs(x_merged - x_classic).max() < 1e-9 * scale
+    for world in (2, 4, 8):
+        x, its, stats = solve(world, False)
+        assert abs(its - its_merged) <= 1, (world, its, its_merged)
+        assert np.abs(x - x_classic).max() < 1e-9 * scale
+        for st in stats:
+            # per solve: the set-up reduction of (r0.r0, b.b) and the first preconditioner application, then ONE
+            # all-reduce and ONE halo exchange per enqueued iteration (the host enqueues in batches: up to a batch
+            # of iterations behind the converged one is enqueued and returns at once on the device)
+            enqueued = st["neighbor_calls"]
+            assert its <= enqueued < its + 8, (world, st, its)
+            assert st["allreduce_calls"] == enqueued + 2, (world, st, its)
+        _, its_c, stats_c = solve(world, True)
+        assert stats_c[0]["allreduce_calls"] >= 3 * its_c        # what the classic loop issues: three per iteration

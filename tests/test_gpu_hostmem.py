@@ -483,3 +483,40 @@ def test_pageable_driver_results_are_not_overwritten(ctx):
     g = sim.compute_totals('l2_functional', 'f')
     rings = [r for r in sim._adj_storage.values() if any(g is a for a in r)]
     assert len(rings) == 1 and len(rings[0]) <= 4 and first in {id(a) for a in rings[0]}
+
+
+def test_deferred_upload_of_f_matches_the_synchronous_cycle(ctx):
+    """The inputs of solve_residual_equations travel as deferred uploads (femo_vec_set_host_deferred): the first Newton
+    pass assembles A and K u' against a zero load vector, scales A, and only then waits for f.  Same state, functional
+    and gradient as the synchronous path (rounding of one subtraction), the upload is counted as deferred, and a host
+    write announced right after the cycle (femo_host_touch waits for the copy) cannot race it."""
+    from bench import build_problem, one_cycle, source_fields
+    from femo_amd import engine as E
+    from femo_amd.fea import utils_hip
+    from femo_amd.fea.mesh import createUnitCubeMesh
+    utils_hip.set_context(ctx)
+    mesh = createUnitCubeMesh(56)                       # 1.05 M cells: f is 8.4 MB, above the deferral threshold
+    fs = source_fields(mesh, 2)
+    out = {}
+    os.environ.pop("FEMO_HOST_VERIFY", None)            # the verifier makes every upload synchronous (it compares bytes)
+    for mode in ("deferred", "sync"):
+        sim, fea = build_problem(mesh, device=False)
+        if mode == "sync":
+            fea.async_results = False
+            sim.async_results = False
+        one_cycle(sim, fea, E.pinned_array(fs[0]), E.pinned_full(mesh.n_vert, 0.0))      # builds the load vector storage
+        E.host_stats(reset=True)
+        fpin = E.pinned_array(fs[1])
+        g = one_cycle(sim, fea, fpin, E.pinned_full(mesh.n_vert, 0.0))
+        st = E.host_stats()
+        out[mode] = (np.array(E.host_wait(sim['u']), copy=True), np.array(E.host_wait(g), copy=True),
+                     float(np.asarray(sim['l2_functional']).ravel()[0]), st["h2d_deferred"])
+        w = E.writable(fpin)                             # announces the write: waits for anything in flight on the block
+        w[:] = 0.0
+        utils_hip.clear_workspaces()
+    os.environ["FEMO_HOST_VERIFY"] = "1"
+    assert out["deferred"][3] >= 1 and out["sync"][3] == 0
+    rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
+    assert rel(out["deferred"][0], out["sync"][0]) < 1e-11
+    assert rel(out["deferred"][1], out["sync"][1]) < 1e-11
+    assert abs(out["deferred"][2] - out["sync"][2]) < 1e-12 * abs(out["sync"][2])
