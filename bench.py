@@ -53,7 +53,8 @@ def parse():
     p.add_argument("--permute", action="store_true",
                    help="random vertex numbering: no regular SELL slices, scattered gathers (the unstructured-mesh rate)")
     p.add_argument("--no-pcie", action="store_true")
-    p.add_argument("--no-configs", action="store_true", help="skip the legs for BASELINE configs 2, 5 and 3 (reported under 'configs')")
+    p.add_argument("--no-configs", action="store_true", help="skip the legs for BASELINE configs 2, 5 and 3 (reported under 'configs') and the scaling model")
+    p.add_argument("--scaling-model", action="store_true", help="only with --no-configs: still run the 8-rank block leg ('scaling_model')")
     p.add_argument("--no-check", action="store_true", help="skip the self-check of the timed configuration against the DST-exact cycle")
     p.add_argument("--reorder", action="store_true",
                    help="Mesh.reordered(): what import_mesh does to a mesh it reads (Morton curve unless the numbering is already structured)")
@@ -354,6 +355,67 @@ def bench_config2(ctx, steps: int) -> dict:
                                       f"{cpu['times']['cycle']:.2f} s, CG its {cpu['it_fwd']}+{cpu['it_adj']}; nothing scaled"}}
     utils_hip.clear_workspaces()
     return rec
+
+
+def bench_scaling_model(ctx, n_global: int, steps: int, headline_ms: float, headline_split: dict) -> dict:
+    """What one rank of the 8-GPU run does, measured on THIS GPU ("prove the budget on one GPU"): the block
+    of the 2 x 2 x 2 partition -- an (n/2)^3 cube in one octant of the unit cube, 1.26 M DOFs at n = 215 -- with the
+    preconditioner lattice of the WHOLE mesh (femo_mesh_set_global), so the replicated coarse-lattice work has its 8-GPU
+    size.  Timed: the same operator cycle as the headline on that block (host boundary).  Not in it: the pack / unpack
+    launches around the all-reduce and the collectives themselves -- counted, not timed (no multi-GPU box): one all-reduce
+    (shared finest-lattice nodes + two whole levels + 7 scalars) and one halo exchange per CG iteration, both COUNTED by
+    femo_comm_stats in the emulated-rank tests and in the N > 1 record of this script.  The projection adds an assumed
+    latency per collective and says so."""
+    from femo_amd import engine as E
+    from femo_amd.fea import utils_hip
+    from femo_amd.fea.mesh import createUnitCubeMesh
+    nb = (n_global + 1) // 2
+    mesh = createUnitCubeMesh(nb)
+    mesh.x *= nb / n_global                                           # the block [0, nb h]^3 of the n-cube
+    if hasattr(mesh, "n"):
+        mesh.n = 0                                                    # source_fields: evaluate point by point
+    sim, fea = build_problem(mesh, device=False)
+    dm = mesh.device(ctx)
+    dm.set_global(np.zeros(3), np.ones(3), (n_global + 1) ** 3)
+    fs = [E.pinned_array(f) for f in source_fields(mesh, 3)]
+    u0 = E.pinned_full(mesh.n_vert, 0.0)
+    for k in range(2):
+        one_cycle(sim, fea, fs[k], u0)
+    ctx.sync()
+    del utils_hip.LAST_KSP_INFO[:]
+    ms, _ = _timed_cycles(ctx, lambda k: one_cycle(sim, fea, fs[k % 3], u0), steps, 0)
+    infos = list(utils_hip.LAST_KSP_INFO)
+    per = len(infos) // steps
+    its = [i["iterations"] for i in infos[:per]]
+    solves = [i for i in infos if i["iterations"] > 0]
+    us_per_it = 1e3 * sum(i["solve_ms"] for i in solves) / max(sum(i["iterations"] for i in solves), 1)
+    spmv_ms, ns = _spmv_in_loop(infos)
+    cg_ms = sum(i["solve_ms"] for i in infos) / steps
+    lat = dm.pc_info()
+    utils_hip.clear_workspaces()
+    its_total = sum(its)
+    n_dof_global = (n_global + 1) ** 3
+    # lattice all-reduce payload at 8 blocks: the interface layers of the finest lattice (3 planes x 3 layers) + levels L-1, L-2
+    m = round(lat["finest_nodes"] ** (1 / 3)) - 1
+    ar_doubles = 3 * 3 * (m + 1) ** 2 + (m // 2 + 1) ** 3 + (m // 4 + 1) ** 3 + 7
+    proj = {}
+    for lat_us in (15.0, 30.0, 60.0):
+        t_it = us_per_it + 10.0 + lat_us + 10.0          # + pack / unpack launches + one all-reduce + the exposed part of one halo exchange
+        cyc = ms + its_total * (t_it - us_per_it) * 1e-3
+        proj[f"allreduce_{int(lat_us)}us"] = {"us_per_iteration": t_it, "ms_per_cycle": cyc, "speedup_vs_1gpu": headline_ms / cyc}
+    return {"what": "one rank's block of the 2x2x2 partition of the headline mesh, run alone on this GPU with the whole mesh's lattice",
+            "block": f"{nb}^3 cells, {mesh.n_vert} DOFs (1/8 of {n_dof_global} + interface)", "pc_lattice": lat,
+            "ms_per_cycle_block": ms, "cg_iterations_per_cycle": its, "cg_ms_per_cycle": cg_ms, "non_cg_ms_per_cycle": ms - cg_ms,
+            "us_per_cg_iteration_wall": us_per_it, "spmv_us": spmv_ms * 1e3 if ns else None,
+            "launches_per_cg_iteration": {"one_rank": 5, "n_ranks": 7, "kernels": "SpMV (interior + boundary slices on N ranks), brick restriction of q, [pack, unpack,] coarse lattice + vector updates, fine lattice (own tiles), mesh prolongation + direction update"},
+            "collectives_per_cg_iteration": {"allreduce": 1, "halo_exchange": 1, "allreduce_doubles_8_ranks": int(ar_doubles),
+                                             "counted_by": "femo_comm_stats (tests/test_gpu_emulated_ranks.py, bench.py --gpus N record)"},
+            "headline_1gpu_ms": headline_ms,
+            "ideal_speedup_without_communication": headline_ms / ms,
+            "projection": proj,
+            "assumptions": "each rank has its own PCIe link (block's transfers are inside ms_per_cycle_block); per iteration +10 us for the pack / "
+                           "unpack launches, the stated all-reduce latency, +10 us of halo exchange not hidden behind the interior SpMV; "
+                           "no multi-GPU box was available: RCCL latencies are assumptions, everything else is measured"}
 
 
 def build_problem_nl(mesh, device: bool = False):
@@ -761,7 +823,12 @@ def _run(args):
     if not args.no_configs and not (args.permute or args.reorder or args.jitter) and args.n == 215:
         sim = fea = f_pin = u0 = g = None           # release the 10 M-DOF problem before the other meshes are built
         utils_hip.clear_workspaces()
+        result["scaling_model"] = bench_scaling_model(ctx, args.n, 10, ms_per_step, result["config"]["split_ms_per_step"])
         result["configs"] = {"c2": bench_config2(ctx, 20), "c5_nl": bench_config5(ctx, 5), "c3_shell": bench_config3(ctx, 3)}
+    if args.no_configs and args.scaling_model:
+        sim = fea = f_pin = u0 = g = None
+        utils_hip.clear_workspaces()
+        result["scaling_model"] = bench_scaling_model(ctx, args.n, 10, ms_per_step, result["config"]["split_ms_per_step"])
     if not args.no_cpu_baseline:
         counts = its_per_step if its_per_step else [0]
         result["cpu_baseline"] = cpu_baseline(args, counts, n_dof, mesh.n_cell, nnz)

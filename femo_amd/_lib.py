@@ -41,7 +41,7 @@ class SolveInfo(C.Structure):
                 ("residual_norm", C.c_double), ("pc_residual_norm", C.c_double), ("pc_rhs_norm", C.c_double),
                 ("rhs_norm", C.c_double),
                 ("solve_ms", C.c_double), ("spmv_ms", C.c_double),
-                ("spmv_samples", C.c_int32), ("reserved", C.c_int32)]
+                ("spmv_samples", C.c_int32), ("loop_allreduces", C.c_int32)]
 
 
 class HostStats(C.Structure):

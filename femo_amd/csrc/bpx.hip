@@ -86,9 +86,15 @@ struct femo_pc {
   // N > 1: what the single all-reduce needs besides the shared nodes
   int64_t n_int = 0;
   int32_t* d_int_idx = nullptr;       // finest-lattice nodes that only this rank touches
-  double* d_dot_w = nullptr;          // 1 on the finest nodes several ranks touch (their sums are replicated), else 0
   double* d_pack_scratch = nullptr;   // [3][PACK_GRID] per-block partials of the single-rank sums
   uint32_t* d_ticket = nullptr;
+  // ... and the part of the finest three levels this rank needs: the 8^3 (16^2) tiles of k_lattice_prolong3_m that hold a
+  // node it touches (1/N of the lattice plus the interface layers); the shared nodes outside them are kept current
+  // by the carriers of k_lattice_coarse_m (d_shared_out = 1 there)
+  int64_t n_my_tiles = 0;
+  int32_t* d_my_tiles = nullptr;
+  std::vector<uint8_t> tile_mine;     // host copy of the tile mask (from the brick list: every node a local vertex touches lies in one of them)
+  uint8_t* d_shared_out = nullptr;    // per shared node: 1 = not inside one of this rank's tiles
 };
 
 namespace {
@@ -651,6 +657,60 @@ __device__ __forceinline__ double lattice_interp_node(int64_t idx, const int* nf
   return 0.125 * acc;   // even index: both parents coincide (2 x 1/2); odd: the two neighbours at 1/2 each
 }
 
+// 32-bit index arithmetic for the LDS-resident coarse levels (a few thousand nodes): the 64-bit divisions and products of
+// the general helpers above are ~10x the instructions, and workgroup 0 of k_lattice_coarse_m is the critical path of an
+// iteration on a partitioned mesh
+__device__ __forceinline__ int node_index32(const int* n, int i, int j, int k) { return (k * (n[1] + 1) + j) * (n[0] + 1) + i; }
+__device__ __forceinline__ double lattice_restrict_node32(int idx, const int* nc, const int* nf, int dim, const double* __restrict__ fine) {
+  const int n0 = nc[0] + 1, n1 = nc[1] + 1;
+  const int i = idx % n0, jk = idx / n0;
+  const int j = jk % n1, k = jk / n1;
+  double acc = 0.0;
+  if (dim == 3) {
+    double v[27], w[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      const int dx = t % 3 - 1, dy = (t / 3) % 3 - 1, dz = t / 9 - 1;
+      const int fi = 2 * i + dx, fj = 2 * j + dy, fk = 2 * k + dz;
+      const bool in = fi >= 0 && fi <= nf[0] && fj >= 0 && fj <= nf[1] && fk >= 0 && fk <= nf[2];
+      const int ci = min(max(fi, 0), nf[0]), cj = min(max(fj, 0), nf[1]), ck = min(max(fk, 0), nf[2]);
+      w[t] = in ? (dx ? 0.5 : 1.0) * (dy ? 0.5 : 1.0) * (dz ? 0.5 : 1.0) : 0.0;
+      v[t] = fine[node_index32(nf, ci, cj, ck)];
+    }
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc += w[t] * v[t];
+  } else {
+    double v[9], w[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int dx = t % 3 - 1, dy = t / 3 - 1;
+      const int fi = 2 * i + dx, fj = 2 * j + dy;
+      const bool in = fi >= 0 && fi <= nf[0] && fj >= 0 && fj <= nf[1];
+      const int ci = min(max(fi, 0), nf[0]), cj = min(max(fj, 0), nf[1]);
+      w[t] = in ? (dx ? 0.5 : 1.0) * (dy ? 0.5 : 1.0) : 0.0;
+      v[t] = fine[node_index32(nf, ci, cj, 0)];
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc += w[t] * v[t];
+  }
+  return acc;
+}
+__device__ __forceinline__ double lattice_interp_node32(int idx, const int* nf, const int* nc, int dim, const double* __restrict__ ec) {
+  const int n0 = nf[0] + 1, n1 = nf[1] + 1;
+  const int i = idx % n0, jk = idx / n0;
+  const int j = jk % n1, k = jk / n1;
+  const int ci[2] = {i >> 1, (i + 1) >> 1}, cj[2] = {j >> 1, (j + 1) >> 1};
+  const int ck[2] = {dim == 3 ? k >> 1 : 0, dim == 3 ? (k + 1) >> 1 : 0};
+  double acc = 0.0;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) acc += ec[node_index32(nc, ci[a], cj[b], ck[c])];
+  return 0.125 * acc;
+}
+
 __global__ void k_lattice_restrict(int nc0, int nc1, int nc2, int nf0, int nf1, int nf2, int dim,
                                    const double* __restrict__ fine, double* __restrict__ coarse, const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
@@ -972,10 +1032,21 @@ struct MergedCarry {
   double* rr_partials;
   double* gs_lvl[2];          // state of levels T and L-1
   const double* h_lvl[2];     // this apply's accumulators of those levels
+  double* h_other[2];         // the other parity's accumulators of those levels: cleared here for the restriction after the next
   const double* coef_lvl[2];
   int64_t n_lvl[2];
   double* lat_partials;
   double* gs_top;             // state of level T-1
+  // N > 1: the finest-level nodes several ranks touch -- every rank holds their sums after the exchange and adds their
+  // part of the lattice dot itself; those outside this rank's tiles are also updated here (k_lattice_prolong3_m
+  // only visits the rank's own tiles)
+  int64_t n_shared; const int32_t* shared_idx; const uint8_t* shared_out;
+  double* gs_f; double* h_f; const double* coef_f;
+  int dbg;                          // timing experiments (FEMO_TUNING builds): 1 = workgroup 0 returns early, 2 = the carriers do
+  // R h_T (level T-1) formed before this launch by a multi-workgroup kernel (k_lattice_restrict on one rank, the unpack
+  // kernel on several): the 27-point restriction of 2197 nodes is ~14 us of index arithmetic on ONE compute unit, the
+  // critical path of an iteration when the mesh-sized streams of the carriers are short (partitioned / small meshes)
+  const double* hres;
 };
 
 __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int dim, const int32_t* __restrict__ done, MergedCarry mc) {
@@ -995,6 +1066,7 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
     alpha = pq != 0.0 ? gamma / pq : 0.0;
   }
   if (blockIdx.x > 0) {
+    if (mc.dbg == 2) return;
     const int nc = gridDim.x - 1, b = blockIdx.x - 1;
     double rr = 0.0, lat = 0.0;
     if (mc.init) {
@@ -1030,8 +1102,15 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
       for (int64_t i = (int64_t)b * 1024 + threadIdx.x; i < mc.n_lvl[l]; i += (int64_t)nc * 1024) {
         const double g = gs[i] - alpha * h[i];
         gs[i] = g;
+        mc.h_other[l][i] = 0.0;
         lat += cf[i] * g * g;
       }
+    }
+    for (int64_t i = (int64_t)b * 1024 + threadIdx.x; i < mc.n_shared; i += (int64_t)nc * 1024) {
+      const int32_t j = mc.shared_idx[i];
+      const double g = mc.gs_f[j] - alpha * mc.h_f[j];
+      if (mc.shared_out[i]) { mc.gs_f[j] = g; mc.h_f[j] = 0.0; }
+      lat += mc.coef_f[j] * g * g;
     }
     const double t0 = femo_block_sum<1024>(rr, red);
     if (threadIdx.x == 0) mc.rr_partials[b] = t0;
@@ -1040,6 +1119,7 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
     return;
   }
   if (threadIdx.x == 0) { mc.S[MS_ALPHA] = alpha; mc.S[MS_PQ] = pq; }
+  if (mc.dbg == 1) return;
   // workgroup 0: the LDS-resident coarse end, as k_lattice_coarse with restrict_top and emit_top, on the updated state
   extern __shared__ double coarse_lds[];
   const int top = L.n_levels;
@@ -1049,11 +1129,16 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
   double* g_top_lds = coarse_lds + L.off[top];
   double gt[TOPR], ct[TOPR];
   double dot = 0.0;
+  // The 27-point restriction of h_T to level T-1 is ~14 us of index arithmetic when ONE compute unit does all 2197 nodes
+  // of the 96^3 lattice's level (measured with the carriers switched off: 32 us for this workgroup, 21 without the
+  // restriction; staging h_T in LDS first changed nothing -- it is instruction issue, not the gathers).  On N ranks the
+  // unpack kernel forms it (mc.hres); on one rank the carriers' mesh-sized streams hide this workgroup at the sizes where
+  // the lattice is that large.
 #pragma unroll
   for (int q = 0; q < TOPR; ++q) {
     const int64_t idx = tid + q * 1024;
     const bool in = idx < n_top;
-    const double hres = in ? lattice_restrict_node(idx, L.n[top], L.finer_n, dim, L.finer_g) : 0.0;
+    const double hres = !in ? 0.0 : (mc.hres != nullptr ? mc.hres[idx] : lattice_restrict_node32((int)idx, L.n[top], L.finer_n, dim, L.finer_g));
     const double g0 = in ? mc.gs_top[idx] : 0.0;
     ct[q] = in ? L.coef[top][idx] : 0.0;
     gt[q] = g0 - alpha * hres;
@@ -1071,7 +1156,7 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
     const int64_t total = L.nodes[l];
     const double* fine = l + 1 == top ? g_top_lds : coarse_lds + L.off[l + 1];
     double* gl = coarse_lds + L.off[l];
-    for (int64_t idx = tid; idx < total; idx += 1024) gl[idx] = lattice_restrict_node(idx, L.n[l], L.n[l + 1], dim, fine);
+    for (int64_t idx = tid; idx < total; idx += 1024) gl[idx] = lattice_restrict_node32((int)idx, L.n[l], L.n[l + 1], dim, fine);
     lds_barrier();
   }
   for (int l = 0; l < top; ++l) {
@@ -1085,7 +1170,7 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
       const double g = gl[idx];
       double v = c * g;
       dot += v * g;
-      if (l > 0) v += lattice_interp_node(idx, L.n[l], L.n[l - 1], dim, ec);
+      if (l > 0) v += lattice_interp_node32((int)idx, L.n[l], L.n[l - 1], dim, ec);
       el[idx] = v;
     }
     c_cur = c_nxt;
@@ -1096,7 +1181,7 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
 #pragma unroll
     for (int q = 0; q < TOPR; ++q) {
       const int64_t idx = tid + q * 1024;
-      if (idx < n_top) L.e[top][idx] = ct[q] * gt[q] + lattice_interp_node(idx, L.n[top], L.n[top - 1], dim, ec);
+      if (idx < n_top) L.e[top][idx] = ct[q] * gt[q] + lattice_interp_node32((int)idx, L.n[top], L.n[top - 1], dim, ec);
     }
   } else {                                          // level T-1 is the coarsest lattice: nothing below it
 #pragma unroll
@@ -1110,10 +1195,11 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
 }
 
 // FineLevels of the merged variant: g_c / g_m are the STATE of levels T and L-1 (already updated by the carriers of
-// k_lattice_coarse_m), g_f the state of the finest level (updated here), h_f its accumulator (cleared here);
-// g_c_other / g_m_other: the other parity's accumulators of levels T and L-1, cleared for the restriction after the next.
+// k_lattice_coarse_m), g_f the state of the finest level (updated here), h_f its accumulator (cleared here).  The other
+// parity's accumulators of levels T and L-1 are cleared by the carriers (g_c_other / g_m_other are not used here).
 template <int D>
 __global__ __launch_bounds__(256) void k_lattice_prolong3_m(FineLevels P, double* __restrict__ h_f, const double* __restrict__ S, int init,
+                                                            const int32_t* __restrict__ tile_list, int64_t n_list,
                                                             const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
   constexpr int TF = D == 3 ? 8 : 16, TM = TF / 2 + 1, TC = TF / 4 + 1;
@@ -1139,7 +1225,10 @@ __global__ __launch_bounds__(256) void k_lattice_prolong3_m(FineLevels P, double
     }
   };
   double dot = 0.0;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  // tile_list (N > 1): only the tiles that hold a node this rank touches
+  const int64_t n_walk = tile_list != nullptr ? n_list : n_tiles;
+  for (int64_t ti = blockIdx.x; ti < n_walk; ti += gridDim.x) {
+    const int64_t tile = tile_list != nullptr ? (int64_t)tile_list[ti] : ti;
     int lo[3] = {0, 0, 0}, mlo[3] = {0, 0, 0}, clo[3] = {0, 0, 0};
     {
       int64_t t = tile;
@@ -1215,12 +1304,10 @@ __global__ __launch_bounds__(256) void k_lattice_prolong3_m(FineLevels P, double
     }
     if (p < NC) {
       ec[p] = c_in ? c_coef * c_g + c_par : 0.0;
-      if (c_in && c_own) P.g_c_other[c_idx] = 0.0;
     }
     lds_barrier();
     if (p < NM) {
       em[p] = m_in ? m_coef * m_g + from_patch(ec, TC, mi, clo) : 0.0;
-      if (m_in && m_own) P.g_m_other[m_idx] = 0.0;
     }
     lds_barrier();
 #pragma unroll
@@ -1300,11 +1387,15 @@ __global__ __launch_bounds__(256) void k_pack_merged(PackArgs a, const int32_t* 
   }
   if (threadIdx.x == 0) *a.ticket = 0u;
 }
+struct TopRestrict { int nc[3], nf[3], dim; int64_t n_top; double* hres; };
 __global__ void k_unpack_merged(int64_t n_shared, const int32_t* __restrict__ idx, double* __restrict__ h_f, int64_t n_dense,
                                 double* __restrict__ h_dense, const double* __restrict__ buf, double* __restrict__ S,
-                                const int32_t* __restrict__ done) {
+                                TopRestrict tr, const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
   if (blockIdx.x == 0 && threadIdx.x < MS_NRED) S[MS_RED + threadIdx.x] = buf[n_shared + n_dense + threadIdx.x];
+  // R h_T for the coarse-lattice workgroup of the next launch, straight from the reduced buffer (level T leads the dense part)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tr.n_top; i += (int64_t)gridDim.x * blockDim.x)
+    tr.hres[i] = lattice_restrict_node32((int)i, tr.nc, tr.nf, tr.dim, buf + n_shared);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_shared + n_dense; i += (int64_t)gridDim.x * blockDim.x) {
     if (i < n_shared) h_f[idx[i]] = buf[i];
     else h_dense[i - n_shared] = buf[i];
@@ -1425,6 +1516,31 @@ int femo_pc_build(femo_mesh* m) {
   }
   FEMO_TRY(upload(&pc->d_bin_ptr, P.bin_ptr));
   FEMO_TRY(upload(&pc->d_brick_base, P.brick_base));
+  {
+    // tiles of the fine-lattice kernel (8^3 / 16^2 finest nodes) that hold a node of one of this mesh's bricks: all of
+    // them on one GPU with the mesh's own lattice, the rank's corner of the lattice on a partitioned mesh
+    const LatticeLevel& Fl = pc->L[P.n_levels - 1];
+    const int TF = D == 3 ? 8 : 16, BB = D == 3 ? 4 : 8;
+    int tn[3] = {1, 1, 1};
+    for (int k = 0; k < D; ++k) tn[k] = (Fl.n[k] + TF) / TF;
+    pc->tile_mine.assign((size_t)tn[0] * tn[1] * tn[2], 0);
+    for (int64_t b = 0; b < P.n_bricks; ++b) {
+      int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+      for (int k = 0; k < D; ++k) {
+        const int b0 = P.brick_base[(size_t)b * 3 + k];
+        lo[k] = b0 / TF;
+        hi[k] = std::min(b0 + BB, Fl.n[k]) / TF;
+      }
+      for (int z = lo[2]; z <= hi[2]; ++z)
+        for (int y = lo[1]; y <= hi[1]; ++y)
+          for (int x = lo[0]; x <= hi[0]; ++x) pc->tile_mine[((size_t)z * tn[1] + y) * tn[0] + x] = 1;
+    }
+    std::vector<int32_t> tiles;
+    for (size_t t = 0; t < pc->tile_mine.size(); ++t)
+      if (pc->tile_mine[t]) tiles.push_back((int32_t)t);
+    pc->n_my_tiles = (int64_t)tiles.size();
+    FEMO_TRY(upload(&pc->d_my_tiles, tiles));
+  }
   FEMO_HIP_CHECK(hipMalloc(&pc->d_w_sorted, std::max<size_t>(P.perm.size(), 1) * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&pc->d_sinv, std::max<size_t>(P.perm.size(), 1) * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&pc->d_dot_partials, 2048 * sizeof(double)));
@@ -1440,7 +1556,8 @@ void femo_pc_destroy(femo_mesh* m) {
   (void)hipFree(m->pc->d_shared_idx); (void)hipFree(m->pc->d_dot_weight); (void)hipFree(m->pc->d_xbuf); (void)hipFree(m->pc->d_dot_scalar);
   (void)hipFree(m->pc->d_brick_ptr); (void)hipFree(m->pc->d_bin_ptr); (void)hipFree(m->pc->d_brick_base);
   (void)hipFree(m->pc->gs); (void)hipFree(m->pc->d_lat_partials); (void)hipFree(m->pc->d_rr_partials);
-  (void)hipFree(m->pc->d_int_idx); (void)hipFree(m->pc->d_dot_w); (void)hipFree(m->pc->d_pack_scratch); (void)hipFree(m->pc->d_ticket);
+  (void)hipFree(m->pc->d_my_tiles); (void)hipFree(m->pc->d_shared_out);
+  (void)hipFree(m->pc->d_int_idx); (void)hipFree(m->pc->d_pack_scratch); (void)hipFree(m->pc->d_ticket);
   delete m->pc;
   m->pc = nullptr;
 }
@@ -1553,19 +1670,27 @@ static int pc_setup_shared(femo_mesh* m) {
   }
   pc->n_shared = (int64_t)shared.size();
   {
-    // merged loop: the nodes only this rank touches (their part of the lattice dot travels as three scalars) and the
-    // indicator of the shared ones (whose sums every rank holds after the exchange)
+    // merged loop: the nodes only this rank touches (their part of the lattice dot travels as three scalars)
     std::vector<int32_t> interior;
-    std::vector<double> wrep((size_t)F.nodes, 0.0);
-    for (int64_t i = 0; i < F.nodes; ++i) {
-      if (cnt[(size_t)i] >= 1.5) wrep[(size_t)i] = 1.0;
-      else if (mine[(size_t)i] != 0.0) interior.push_back((int32_t)i);
-    }
+    for (int64_t i = 0; i < F.nodes; ++i)
+      if (cnt[(size_t)i] < 1.5 && mine[(size_t)i] != 0.0) interior.push_back((int32_t)i);
     pc->n_int = (int64_t)interior.size();
     FEMO_HIP_CHECK(hipMalloc(&pc->d_int_idx, std::max<size_t>(interior.size(), 1) * sizeof(int32_t)));
     if (!interior.empty()) FEMO_HIP_CHECK(hipMemcpy(pc->d_int_idx, interior.data(), interior.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    FEMO_HIP_CHECK(hipMalloc(&pc->d_dot_w, F.nodes * sizeof(double)));
-    FEMO_HIP_CHECK(hipMemcpy(pc->d_dot_w, wrep.data(), F.nodes * sizeof(double), hipMemcpyHostToDevice));
+    // the shared nodes outside this rank's tiles (femo_pc_build) are kept current by the carriers of k_lattice_coarse_m
+    const int TF = pc->dim == 3 ? 8 : 16;
+    int tn[3] = {1, 1, 1};
+    for (int k = 0; k < pc->dim; ++k) tn[k] = (F.n[k] + TF) / TF;
+    const std::vector<uint8_t>& tile_mine = pc->tile_mine;
+    const int64_t n0 = F.n[0] + 1, n1 = F.n[1] + 1;
+    auto tile_of = [&](int64_t i) -> int64_t {
+      const int64_t ix = i % n0, iy = (i / n0) % n1, iz = i / (n0 * n1);
+      return ((iz / TF) * tn[1] + iy / TF) * tn[0] + ix / TF;
+    };
+    std::vector<uint8_t> sh_out(std::max<size_t>(shared.size(), 1), 0);
+    for (size_t q = 0; q < shared.size(); ++q) sh_out[q] = tile_mine[(size_t)tile_of(shared[q])] ? 0 : 1;
+    FEMO_HIP_CHECK(hipMalloc(&pc->d_shared_out, sh_out.size()));
+    FEMO_HIP_CHECK(hipMemcpy(pc->d_shared_out, sh_out.data(), sh_out.size(), hipMemcpyHostToDevice));
   }
   const int64_t n_coarse = F.g - pc->L[nl - 1 - pc->n_fused].g;      // the coarser fused levels travel whole
   FEMO_HIP_CHECK(hipMalloc(&pc->d_shared_idx, std::max<size_t>(shared.size(), 1) * sizeof(int32_t)));
@@ -1899,7 +2024,10 @@ int femo_pc_merged_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, c
     const unsigned gp = (unsigned)std::min<int64_t>(PACK_GRID, std::max<int64_t>(1, (std::max(count, a.n_int) + 255) / 256));
     hipLaunchKernelGGL(k_pack_merged, dim3(gp), dim3(256), 0, st, a, done);
     FEMO_TRY(femo_coll_allreduce(ctx, pc->d_xbuf, count + MS_NRED, st));
-    hipLaunchKernelGGL(k_unpack_merged, dim3(lat_grid(std::max<int64_t>(count, 1))), dim3(256), 0, st, a.n_shared, pc->d_shared_idx, hF, a.n_dense, H(T, par), pc->d_xbuf, S, done);
+    TopRestrict tr;
+    for (int k = 0; k < 3; ++k) { tr.nc[k] = pc->L[T - 1].n[k]; tr.nf[k] = pc->L[T].n[k]; }
+    tr.dim = pc->dim; tr.n_top = pc->L[T - 1].nodes; tr.hres = pc->L[T - 1].g;
+    hipLaunchKernelGGL(k_unpack_merged, dim3(lat_grid(std::max<int64_t>(std::max(count, tr.n_top), 1))), dim3(256), 0, st, a.n_shared, pc->d_shared_idx, hF, a.n_dense, H(T, par), pc->d_xbuf, S, tr, done);
   }
   // workgroup 0: the LDS-resident levels; the others: vector and lattice updates
   CoarseLevels CL;
@@ -1923,7 +2051,7 @@ int femo_pc_merged_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, c
   }
   static bool merged_lds_set = false;
   if (lds > 64 * 1024 && !merged_lds_set) {
-    FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_coarse_m, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_coarse_m, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
     merged_lds_set = true;
   }
   const int n_carry = std::max(1, ctx->n_cu - 1);
@@ -1935,8 +2063,14 @@ int femo_pc_merged_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, c
   for (int l = 0; l < 2; ++l) {
     const int lev = T + l;
     mc.gs_lvl[l] = GS(lev); mc.h_lvl[l] = H(lev, par); mc.coef_lvl[l] = pc->L[lev].coef; mc.n_lvl[l] = pc->L[lev].nodes;
+    mc.h_other[l] = H(lev, par ^ 1);
   }
   mc.gs_top = GS(T - 1);
+  mc.n_shared = multi ? pc->n_shared : 0; mc.shared_idx = pc->d_shared_idx; mc.shared_out = pc->d_shared_out;
+  mc.gs_f = GS(nl - 1); mc.h_f = hF; mc.coef_f = F.coef;
+  static const int dbg_coarse = FEMO_TUNE_ENV("FEMO_DEBUG_COARSE") ? atoi(FEMO_TUNE_ENV("FEMO_DEBUG_COARSE")) : 0;
+  mc.dbg = dbg_coarse;
+  mc.hres = multi ? pc->L[T - 1].g : nullptr;
   hipLaunchKernelGGL(k_lattice_coarse_m, dim3(1 + n_carry), dim3(1024), lds, st, CL, pc->dim, done, mc);
   FineLevels FL;
   const LatticeLevel &Lcc = pc->L[nl - 4], &Lc = pc->L[nl - 3], &Lm = pc->L[nl - 2];
@@ -1945,14 +2079,19 @@ int femo_pc_merged_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, c
   FL.coef_c = Lc.coef; FL.g_c = GS(nl - 3); FL.g_c_other = H(nl - 3, par ^ 1);
   FL.coef_m = Lm.coef; FL.g_m = GS(nl - 2); FL.g_m_other = H(nl - 2, par ^ 1);
   FL.coef_f = F.coef; FL.g_f = GS(nl - 1); FL.e_f = F.e;
-  FL.dot_partials = pc->d_dot_partials;
-  FL.dot_weight = multi ? pc->d_dot_w : nullptr;
+  // N > 1: the shared nodes' part of the dot comes from the carriers (replicated), the single-rank nodes' part from the
+  // reduced scalars; this launch adds nothing and walks the rank's own tiles only
+  FL.dot_partials = multi ? nullptr : pc->d_dot_partials;
+  FL.dot_weight = nullptr;
   const int TF = pc->dim == 3 ? 8 : 16;
   int64_t tiles = 1;
   for (int k = 0; k < pc->dim; ++k) tiles *= (F.n[k] + TF) / TF;
-  const int nb_dot = (int)std::min<int64_t>(tiles, 2048);
-  if (pc->dim == 3) hipLaunchKernelGGL(k_lattice_prolong3_m<3>, dim3(nb_dot), dim3(256), 0, st, FL, hF, (const double*)S, init ? 1 : 0, done);
-  else hipLaunchKernelGGL(k_lattice_prolong3_m<2>, dim3(nb_dot), dim3(256), 0, st, FL, hF, (const double*)S, init ? 1 : 0, done);
+  const int32_t* tile_list = pc->n_my_tiles < tiles ? pc->d_my_tiles : nullptr;      // all of them: walk the plain range
+  if (tile_list != nullptr) tiles = pc->n_my_tiles;
+  const int grid3 = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, 2048));
+  const int nb_dot = multi ? 0 : grid3;
+  if (pc->dim == 3) hipLaunchKernelGGL(k_lattice_prolong3_m<3>, dim3(grid3), dim3(256), 0, st, FL, hF, (const double*)S, init ? 1 : 0, tile_list, tiles, done);
+  else hipLaunchKernelGGL(k_lattice_prolong3_m<2>, dim3(grid3), dim3(256), 0, st, FL, hF, (const double*)S, init ? 1 : 0, tile_list, tiles, done);
   pc->parity ^= 1;
   PcgStop ps;
   ps.rtol2_factor = stop ? stop->rtol2_factor : 0.0;

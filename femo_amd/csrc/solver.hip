@@ -1331,6 +1331,7 @@ static int solve_pcg_bpx_merged(femo_mat* A, const femo_vec* b, femo_vec* x, con
   const int predicted = last2 > 0 ? last2 : 0;
   int it = 0, grow = 2;
   bool done = false;
+  const int64_t ar0 = ctx->n_allreduce;
   double* Pq_int = P + 4 * FEMO_MAX_PARTIALS;     // triples [p.q | q.q | r.q]: interior / only launch, boundary launch
   double* Pq_bnd = P + 7 * FEMO_MAX_PARTIALS;
   V.q = w.q; V.atol2 = atol2;
@@ -1367,6 +1368,7 @@ static int solve_pcg_bpx_merged(femo_mat* A, const femo_vec* b, femo_vec* x, con
     FEMO_HIP_CHECK(hipEventSynchronize(ctx->ev_pool[2 * n_sample]));
     if (h_flags[0] || it >= max_it) done = true;
   }
+  info->loop_allreduces = (int32_t)(ctx->n_allreduce - ar0);
   // x, the final scalars and the time with one more synchronisation
   if (n > 0) hipLaunchKernelGGL(k_unscale, dim3(2048), dim3(256), 0, st, n, opts->zero_guess ? 0 : 1, A->d_s, w.xh, x->d);
   FEMO_HIP_CHECK(hipMemcpyAsync(h_flags, ctx->d_flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -1516,6 +1518,7 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
   int it = 0, polled = 0;
   bool done = false;
   int pending[2] = {-1, -1};
+  const int64_t ar0 = ctx->n_allreduce;
   while (!done) {
     const int this_batch = predicted > 0 ? (it == 0 ? predicted : 2) : batch;
     const int it_end = it + this_batch < max_it ? it + this_batch : max_it;
@@ -1592,6 +1595,7 @@ static int solve_pcg_bpx(femo_mat* A, int transpose, const femo_vec* b, femo_vec
       done = true;
     }
   }
+  info->loop_allreduces = (int32_t)(ctx->n_allreduce - ar0);
   FEMO_HIP_CHECK(hipMemcpyAsync(h_flags, ctx->d_flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, S, FEMO_NSCAL * sizeof(double), hipMemcpyDeviceToHost, st));
   FEMO_HIP_CHECK(hipStreamSynchronize(st));

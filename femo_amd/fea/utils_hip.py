@@ -565,7 +565,7 @@ class KSP:
                                   residual_norm=self.info.residual_norm, rhs_norm=self.info.rhs_norm,
                                   pc_residual_norm=self.info.pc_residual_norm, pc_rhs_norm=self.info.pc_rhs_norm,
                                   solve_ms=self.info.solve_ms, spmv_ms=self.info.spmv_ms,
-                                  spmv_samples=self.info.spmv_samples))
+                                  spmv_samples=self.info.spmv_samples, loop_allreduces=getattr(self.info, "loop_allreduces", 0)))
         if len(LAST_KSP_INFO) > KSP_INFO_CAP:
             del LAST_KSP_INFO[:-KSP_INFO_CAP // 2]
         if self.info.converged != 1:

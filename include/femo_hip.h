@@ -104,7 +104,7 @@ typedef struct femo_solve_info {
   double  solve_ms;     /* device time of the solve (HIP events on the ctx stream)      */
   double  spmv_ms;      /* accumulated device time of sampled SpMV launches             */
   int32_t spmv_samples; /* number of SpMV launches that were individually timed         */
-  int32_t reserved;
+  int32_t loop_allreduces;   /* all-reduce calls issued inside the iteration loop (0 on one rank): the merged BPX-PCG issues one per iteration */
 } femo_solve_info;
 
 /* ---- errors / probing ---------------------------------------------------- */

@@ -519,12 +519,14 @@ def test_merged_pcg_one_allreduce_per_iteration_on_emulated_ranks(monkeypatch):
             info = A.solve_cg(b, x, rtol=1e-11, pc="bpx")
             st = ctx.comm_stats()
             return dict(gid=L.vert_global[:L.n_owned], x=x.get(L.n_owned), its=info.iterations, conv=info.converged,
-                        levels=dm.pc_info()["levels"], st=st)
+                        levels=dm.pc_info()["levels"], st=st, loop_ar=info.loop_allreduces)
 
         res = _run_ranks(world, rank_fn)
         x = np.zeros(m.n_vert)
         for r in res:
             assert r["conv"] == 1 and r["levels"] >= 4
+            if world > 1:
+                assert r["loop_ar"] == (r["st"]["neighbor_calls"] if not classic else r["loop_ar"])      # merged: one per enqueued iteration
             x[r["gid"]] = r["x"]
         assert len({r["its"] for r in res}) == 1
         return x, res[0]["its"], [r["st"] for r in res]
