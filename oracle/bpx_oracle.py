@@ -197,3 +197,105 @@ def pcg(A: sp.csr_matrix, b: np.ndarray, M: BPX, rtol: float = 1e-11, atol: floa
         p = z + (rz_new / rz) * p
         rz = rz_new
     return x, it
+
+
+def merged_pcg(A_owned: sp.csr_matrix, b: np.ndarray, M: BPX, n_local: int, halo=None, allreduce=None,
+               rtol: float = 1e-11, max_it: int = 10000):
+    """The merged BPX-PCG of femo_amd/csrc/solver.hip::solve_pcg_bpx_merged, one rank's view, in NumPy (round 4).
+
+    ``A_owned``: the rank's owned rows (columns: owned + ghost entries, ``n_local`` of them); ``M``: the rank's BPX over
+    its owned vertices with ``reduce`` = identity (nothing is reduced inside it here); ``halo(v)`` refreshes the ghost
+    tail of a local vector; ``allreduce(a)`` sums an array over the ranks and is called ONCE per iteration.
+
+    The restricted residual is kept as lattice state and updated by linearity, g <- g - alpha P^T q with q = A p, so that
+    the restriction no longer waits for alpha and p.q travels with the lattice sums.  r.r of the updated residual and the
+    lattice dot g_L.e_L = sum_l sum_i C_l,i g_l,i^2 (because e_l = C_l g_l + I e_l-1 and g_l-1 = I^T g_l) follow from the
+    reduced scalars: r'.r' = r.r - 2 alpha r.q + alpha^2 q.q, and the same expansion for the finest-lattice nodes a single
+    rank touches.  What travels: h = P^T q on the finest-lattice nodes several ranks touch, the whole next level, and
+    seven scalars.  Returns (x_owned, iterations, number of all-reduce calls)."""
+    halo = halo if halo is not None else (lambda v: None)
+    calls = [0]
+
+    def reduce(a):
+        calls[0] += 1
+        return allreduce(np.ascontiguousarray(a, dtype=np.float64)) if allreduce is not None else np.array(a, dtype=np.float64)
+
+    no = len(b)
+    dinv = M.dinv
+    L = M.levels - 1
+    P, I, coef = M.P, M.I, M.coef
+    # set-up (once per mesh in the engine): which finest nodes several ranks touch
+    mine = (np.abs(P).T @ np.ones(no)) != 0.0
+    cnt = reduce(mine.astype(np.float64))
+    shared = np.nonzero(cnt >= 1.5)[0]
+    interior = np.nonzero(mine & (cnt < 1.5))[0]
+    ns, nm = len(shared), (I[L - 1].shape[1] if L >= 1 else 0)
+
+    def exchange(hL, scal):
+        """ONE all-reduce: [h_L on shared nodes | h_{L-1} whole | scalars]; returns the completed pieces."""
+        hm = I[L - 1].T @ hL if L >= 1 else np.zeros(0)
+        buf = reduce(np.concatenate([hL[shared], hm, scal]))
+        hL = hL.copy()
+        hL[shared] = buf[:ns]
+        return hL, buf[ns:ns + nm], buf[ns + nm:]
+
+    def cycle(gL, gm):
+        """e_L and the replicated part of sum_l C g^2 (levels below L, shared nodes of L) from the state."""
+        g = [None] * (L + 1)
+        g[L] = gL
+        if L >= 1:
+            g[L - 1] = gm
+            for l in range(L - 2, -1, -1):
+                g[l] = I[l].T @ g[l + 1]
+        e = coef[0] * g[0]
+        dot = float(coef[0] @ (g[0] * g[0])) if L >= 1 else 0.0
+        for l in range(1, L + 1):
+            e = I[l - 1] @ e + coef[l] * g[l]
+            if l < L:
+                dot += float(coef[l] @ (g[l] * g[l]))
+        dot += float(coef[L][shared] @ (gL[shared] * gL[shared]))
+        return e, dot
+
+    x = np.zeros(no)
+    r = b.copy()
+    # first application: g = sum_ranks P^T r0 (the same exchange with alpha = -1 and g = 0)
+    hL = P.T @ r
+    cL = coef[L]
+    loc = np.array([float(r @ (dinv * r)), float(cL[interior] @ (hL[interior] ** 2))])
+    gL, gm, red = exchange(hL, loc)
+    rr, dint = red[0], red[1]
+    e, dot = cycle(gL, gm)
+    z = dinv * r + P @ e
+    gamma = rr + dot + dint
+    tol2 = rtol * rtol * gamma
+    p = np.zeros(n_local)
+    p[:no] = z
+    sq = np.sqrt(dinv)
+    it = 0
+    while it < max_it:
+        halo(p)
+        q = A_owned @ p
+        hL = P.T @ q
+        # scalars of this rank: p.q, r.q, q.q in the D^-1 inner product of the scaled system the engine iterates on
+        # (r^ = S r, q^ = S q: r^.q^ = r.D^-1 q), r.r of the current residual, and the single-rank lattice sums
+        loc = np.array([float(p[:no] @ q), float(r @ (dinv * q)), float(q @ (dinv * q)), float(r @ (dinv * r)),
+                        float(cL[interior] @ (gL[interior] ** 2)), float(cL[interior] @ (gL[interior] * hL[interior])),
+                        float(cL[interior] @ (hL[interior] ** 2))])
+        hL, hm, red = exchange(hL, loc)
+        pq, rq, qq, rr, gg, gh, hh = red
+        alpha = gamma / pq
+        x += alpha * p[:no]
+        r -= alpha * q
+        gL = gL - alpha * hL
+        gm = gm - alpha * hm
+        it += 1
+        rr_new = rr - 2.0 * alpha * rq + alpha * alpha * qq
+        e, dot = cycle(gL, gm)
+        gamma_new = rr_new + dot + (gg - 2.0 * alpha * gh + alpha * alpha * hh)
+        if gamma_new <= tol2:
+            break
+        z = dinv * r + P @ e
+        p[:no] = z + (gamma_new / gamma) * p[:no]
+        gamma = gamma_new
+    del sq
+    return x, it, calls[0]

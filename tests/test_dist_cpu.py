@@ -273,6 +273,86 @@ def test_two_process_gloo_bpx_pcg(tmp_path, d, n):
     assert abs(its[0] - it_serial) <= 1
 
 
+def _merged_worker(rank, world, port, d, n, out_dir):
+    """The MERGED BPX-PCG (round 4; oracle/bpx_oracle.py::merged_pcg restates solver.hip::solve_pcg_bpx_merged) on two real
+    processes over gloo: owned rows, one isend / irecv halo refresh of p and ONE all-reduce per iteration (lattice sums on
+    the shared nodes + the next level + seven scalars)."""
+    import torch
+    import torch.distributed as dist
+    from oracle import bpx_oracle as bo
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = fo.unit_square_mesh(n, 0.2) if d == 2 else fo.unit_cube_mesh(n, 0.2)
+    part = rcb_partition(m.x, world)
+    l = build_local_mesh(m.x, m.conn, part, rank, world)
+    lm = fo.OMesh(d, l.x, l.conn)
+    bd = fo.boundary_vertices_box(l.x)
+    no = l.n_owned
+    A = fo.eliminate_bc(fo.stiffness(lm), bd)[:no].tocsr()
+    b = fo.load_vector(lm, 1.0 + np.cos(3.0 * fo.centroids(lm)[:, 0]))
+    b[bd] = 0.25
+    b = b[:no]
+    pinned = np.zeros(len(l.x), bool)
+    pinned[bd] = True
+
+    def allreduce(a):
+        t = torch.from_numpy(a.copy())
+        dist.all_reduce(t)
+        return t.numpy()
+
+    def halo(v):
+        reqs, bufs = [], []
+        for k, q in enumerate(l.nbr):
+            sb = torch.from_numpy(np.ascontiguousarray(v[l.send_idx[l.send_ptr[k]:l.send_ptr[k + 1]]]))
+            rb = torch.zeros(int(l.recv_ptr[k + 1] - l.recv_ptr[k]), dtype=torch.float64)
+            reqs += [dist.isend(sb, int(q)), dist.irecv(rb, int(q))]
+            bufs.append((k, rb, sb))
+        for r_ in reqs:
+            r_.wait()
+        for k, rb, _ in bufs:
+            v[no + l.recv_ptr[k]: no + l.recv_ptr[k + 1]] = rb.numpy()
+
+    # the keep rule of the lattice coefficients needs the global hat-function masses: that set-up reduction stays inside BPX
+    M = bo.BPX(l.x[:no], A.diagonal(), pinned[:no], lo=m.x.min(axis=0), hi=m.x.max(axis=0), n_vert_global=m.n_vert,
+               reduce=allreduce)
+    M.reduce = lambda a: a                                   # nothing inside the operator is reduced from here on
+    x, its, calls = bo.merged_pcg(A, b, M, len(l.x), halo=halo, allreduce=allreduce, rtol=1e-13)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=x, gid=l.vert_global[:no], its=its, calls=calls, levels=M.levels)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("d,n", [(2, 24), (3, 8)])
+def test_two_process_gloo_merged_bpx_pcg_one_allreduce_per_iteration(tmp_path, d, n):
+    import scipy.sparse.linalg as spla
+    import torch.multiprocessing as mp
+    from oracle import bpx_oracle as bo
+    world, port = 2, _free_port()
+    mp.spawn(_merged_worker, args=(world, port, d, n, str(tmp_path)), nprocs=world, join=True)
+    m = fo.unit_square_mesh(n, 0.2) if d == 2 else fo.unit_cube_mesh(n, 0.2)
+    bd = fo.boundary_vertices_box(m.x)
+    A = fo.eliminate_bc(fo.stiffness(m), bd).tocsr()
+    b = fo.load_vector(m, 1.0 + np.cos(3.0 * fo.centroids(m)[:, 0]))
+    b[bd] = 0.25
+    x_ref = spla.spsolve(A.tocsc(), b)
+    x = np.zeros(m.n_vert)
+    its = []
+    for rank in range(world):
+        z = np.load(tmp_path / f"rank{rank}.npz")
+        x[z["gid"]] = z["x"]
+        its.append(int(z["its"]))
+        assert int(z["calls"]) == int(z["its"]) + 2         # touch counts (once per mesh) + first application + ONE per iteration
+    assert its[0] == its[1]
+    assert np.abs(x - x_ref).max() < 1e-10 * np.abs(x_ref).max()
+    pinned = np.zeros(m.n_vert, bool)
+    pinned[bd] = True
+    Ms = bo.BPX(m.x, A.diagonal(), pinned)
+    _, it_serial = bo.pcg(A, b, Ms, rtol=1e-13)
+    _, it_merged, _ = bo.merged_pcg(A, b, Ms, m.n_vert, rtol=1e-13)
+    assert abs(its[0] - it_serial) <= 1 and abs(it_merged - it_serial) <= 1
+
+
 @pytest.mark.parametrize("dim,n,nranks,jitter", [(3, 6, 8, 0.0), (3, 7, 4, 0.2), (3, 5, 2, 0.0), (2, 9, 4, 0.2), (2, 8, 3, 0.0), (3, 4, 1, 0.0)])
 def test_rank_local_generation_equals_partitioning_the_whole_mesh(dim, n, nranks, jitter):
     """dist/structured.py builds a rank's block from local data only; it must be exactly what build_local_mesh
