@@ -85,6 +85,20 @@ struct femo_shell {
   double *d_cs_A = nullptr, *d_cs_tmp = nullptr;       // L^-T above / L^-1 below the diagonal (row-major, N x N); L^-1 g
   float* d_cs_Af = nullptr;                            // the same factors in single precision: what the iteration applies
   double* d_cs_dinv = nullptr;                         // inverses of the diagonal tiles of L
+  // Hermite-type lattice spaces (femo_shell_pc_hermite; used when the coarse solve and the node blocks are ready, else the
+  // trilinear data above takes over): finest transfer weights per (point, corner), P_L^T rows per finest node (displacement
+  // points, then rotation points), (a, b, c) of the node-level transfers, composed weights of the levels above the
+  // coarse solve ([level][point][8], finest included) and of the coarse-solve level, composite restriction
+  bool hermite = false, hermite_on = false;             // uploaded / in use for the current stiffness
+  float4* d_fin_w4 = nullptr;
+  int64_t* d_hp_rowptr = nullptr;
+  int32_t* d_hp_cols = nullptr;
+  float4* d_hp_w4 = nullptr;
+  double *d_par_w5 = nullptr, *d_chi_w5 = nullptr;
+  float4 *d_lvl_w4 = nullptr, *d_cs_w4 = nullptr;
+  int64_t* d_hd_rowptr = nullptr;
+  int32_t* d_hd_cols = nullptr;
+  double* d_hd_w5 = nullptr;
   // penalty boundary terms (femo_shell_set_penalty): tagged edges, their coefficient and the CSR positions of their entries
   int64_t pen_n = 0;
   int32_t *d_pen_nodes = nullptr, *d_pen_pos = nullptr;
@@ -1255,6 +1269,307 @@ __global__ __launch_bounds__(256) void k_pc_coarse_galerkin(int c, int width, in
   }
 }
 
+
+// ---- Galerkin set-up for the Hermite-type lattice spaces ------------------------------------------------------------------
+// W_p,n = [alpha I, -[sigma]x] (3 x 6) for a displacement point, [0, w I] for a rotation point: blk[n] = sum over the pairs
+// of points (p, q) that both touch node n of W_p,n^T K_pq W_q,n.  Same organisation as k_pc_galerkin_blocks (a thread per
+// (point, level, component fa), the row's sums against the point's eight nodes in registers), but a row dof of a
+// displacement point now feeds three rows of the block (U_fa with alpha, two Theta rows with -+sigma), so the LDS table is
+// keyed by node and holds whole 6 x 6 blocks (upper triangle used).
+__global__ __launch_bounds__(SH_BLOCK) void k_pc_galerkin_blocks_h(int64_t n_pts, int64_t n_unode, const int64_t* __restrict__ brow,
+                                                                   const int32_t* __restrict__ bcols, const double* __restrict__ vals,
+                                                                   const uint8_t* __restrict__ fixed, const int32_t* __restrict__ lvl_node,
+                                                                   const float4* __restrict__ lvl_w4, double* __restrict__ blk) {
+  constexpr int HS = 256;
+  __shared__ int32_t h_key[HS];
+  __shared__ double h_val[HS][36];
+  for (int i = threadIdx.x; i < HS; i += SH_BLOCK) h_key[i] = -1;
+  for (int i = threadIdx.x; i < HS * 36; i += SH_BLOCK) (&h_val[0][0])[i] = 0.0;
+  __syncthreads();
+  const int fa = (int)(blockIdx.y % 3);
+  const int32_t* ln = lvl_node + (int64_t)(blockIdx.y / 3) * n_pts * 8;
+  const float4* lw = lvl_w4 + (int64_t)(blockIdx.y / 3) * n_pts * 8;
+  const int64_t p = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x;
+  const bool active = p < n_pts && !(fixed != nullptr && fixed[3 * p + fa]);
+  if (active) {
+    int32_t nd[8];
+    float4 wi[8];
+    double acc[8][6];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      nd[a] = ln[p * 8 + a];
+      wi[a] = lw[p * 8 + a];
+      if (wi[a].x == 0.f && wi[a].y == 0.f && wi[a].z == 0.f && wi[a].w == 0.f) nd[a] = -1;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) acc[a][q] = 0.0;
+    }
+    const bool pu = p < n_unode;
+    const int64_t k0 = brow[p], k1 = brow[p + 1], len = 3 * (k1 - k0);
+    const double* v = vals + 9 * k0 + fa * len;
+    for (int64_t k = k0; k < k1; ++k) {
+      const int32_t cj = bcols[k];
+      const int32_t* ik = ln + (int64_t)(cj / 3) * 8;
+      const float4* wk = lw + (int64_t)(cj / 3) * 8;
+      const int64_t o = 3 * (k - k0);
+      double m0 = v[o], m1 = v[o + 1], m2 = v[o + 2];
+      if (fixed != nullptr) {
+        if (fixed[cj]) m0 = 0.0;
+        if (fixed[cj + 1]) m1 = 0.0;
+        if (fixed[cj + 2]) m2 = 0.0;
+      }
+      const bool qu = cj < 3 * n_unode;
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const int32_t nb = ik[b];
+        const float4 w = wk[b];
+        // the row vector m (1 x 3) times W_q,b: [alpha m, sigma x m] for a displacement column, [0, w m] for a rotation column
+        double c0, c1, c2, c3, c4, c5;
+        if (qu) {
+          c0 = (double)w.x * m0; c1 = (double)w.x * m1; c2 = (double)w.x * m2;
+          c3 = (double)w.z * m2 - (double)w.w * m1; c4 = (double)w.w * m0 - (double)w.y * m2; c5 = (double)w.y * m1 - (double)w.z * m0;
+        } else {
+          c0 = c1 = c2 = 0.0;
+          c3 = (double)w.x * m0; c4 = (double)w.x * m1; c5 = (double)w.x * m2;
+        }
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+          const double on = nb == nd[a] ? 1.0 : 0.0;
+          acc[a][0] += on * c0; acc[a][1] += on * c1; acc[a][2] += on * c2;
+          acc[a][3] += on * c3; acc[a][4] += on * c4; acc[a][5] += on * c5;
+        }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      if (nd[a] < 0) continue;
+      const int32_t key = nd[a];
+      int h = (int)(((uint32_t)key * 2654435761u) >> 24) & (HS - 1);
+      int slot = -1;
+      for (int probe = 0; probe < 16; ++probe) {
+        const int32_t seen = atomicCAS(&h_key[h], -1, key);
+        if (seen == -1 || seen == key) { slot = h; break; }
+        h = (h + 1) & (HS - 1);
+      }
+      // rows of the block this dof feeds: (row, coefficient)
+      int rw[3];
+      double cf[3];
+      int nrow;
+      if (pu) {
+        const double sg[3] = {(double)wi[a].y, (double)wi[a].z, (double)wi[a].w};
+        const int k1i = (fa + 1) % 3, k2i = (fa + 2) % 3;          // (Theta x sigma)_fa = Theta_k1 sigma_k2 - Theta_k2 sigma_k1
+        rw[0] = fa; cf[0] = (double)wi[a].x;
+        rw[1] = 3 + k1i; cf[1] = sg[k2i];
+        rw[2] = 3 + k2i; cf[2] = -sg[k1i];
+        nrow = 3;
+      } else {
+        rw[0] = 3 + fa; cf[0] = (double)wi[a].x;
+        nrow = 1;
+      }
+      for (int rI = 0; rI < nrow; ++rI) {
+        if (cf[rI] == 0.0) continue;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          if (q < rw[rI] || acc[a][q] == 0.0) continue;
+          const double val = cf[rI] * acc[a][q];
+          if (slot >= 0) __hip_atomic_fetch_add(&h_val[slot][6 * rw[rI] + q], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          else atomicAdd(&blk[36 * (int64_t)key + 6 * rw[rI] + q], val);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < HS * 36; i += SH_BLOCK) {
+    const int32_t key = h_key[i / 36];
+    if (key < 0) continue;
+    const double val = (&h_val[0][0])[i];
+    if (val != 0.0) atomicAdd(&blk[36 * (int64_t)key + (i % 36)], val);
+  }
+}
+
+// Dense Galerkin operator of the coarse-solve level for the Hermite-type spaces: A[6 a + f, 6 b + f'] with the composed
+// (alpha, sigma) of that level.  Organisation of k_pc_coarse_galerkin (items = points of one coarse cell and one field
+// group; the item's 3 x 3 blocks staged through LDS; a wave per staged block, lanes = (cell node a, corner k' of the
+// column's cell); sums in an LDS table, flushed once).  pass 0: rows U of the displacement items against all six columns,
+// T[fa][f] += alpha_p (K W_q)[fa][f]; pass 1: rows Theta against the Theta columns only -- [sigma_p]x K W_q^Theta for a
+// displacement item, w_p K W_q^Theta for a rotation item; the (Theta, U) quadrant is the transpose of (U, Theta)
+// (k_pc_coarse_mirror_tu): 27 LDS atomics per (block, a, k') in place of 36.
+constexpr int CGH_CHUNK = 128;
+constexpr size_t CGH_LDS = (size_t)CG_TABLE * 8 + CGH_CHUNK * 9 * 8 + CGH_CHUNK * 8 * 16 + CGH_CHUNK * 8 * 16 + CGH_CHUNK * 4 + (CGH_CHUNK + 1) * 4 + CGH_CHUNK * 4 * 2;
+__global__ __launch_bounds__(256) void k_pc_coarse_galerkin_h(int pass, int c, int width, int64_t off_c, int64_t lda, int64_t n_unode,
+                                                              const int64_t* __restrict__ item_ptr, const int32_t* __restrict__ item_pts,
+                                                              const int32_t* __restrict__ item_nbr, const int32_t* __restrict__ pcell,
+                                                              const int64_t* __restrict__ brow, const int32_t* __restrict__ bcols,
+                                                              const double* __restrict__ vals, const uint8_t* __restrict__ fixed,
+                                                              const int32_t* __restrict__ ell_idx, const float4* __restrict__ cs_w4,
+                                                              double* __restrict__ A, int32_t* __restrict__ info) {
+  extern __shared__ double cg_lds[];
+  double* table = cg_lds;                                                  // [3 rows][6 cols][64 bl][8 a]
+  double (*s_val)[9] = reinterpret_cast<double (*)[9]>(table + CG_TABLE);
+  float4 (*s_wb)[8] = reinterpret_cast<float4 (*)[8]>(s_val + CGH_CHUNK);
+  float4 (*s_wpt)[8] = reinterpret_cast<float4 (*)[8]>(s_wb + CGH_CHUNK);
+  int32_t* s_meta = reinterpret_cast<int32_t*>(s_wpt + CGH_CHUNK);
+  int32_t* s_scan = s_meta + CGH_CHUNK;
+  int32_t* s_k0 = s_scan + CGH_CHUNK + 1;
+  int32_t* s_fi = s_k0 + CGH_CHUNK;
+  const int64_t item = blockIdx.x;
+  const int t = threadIdx.x;
+  const int64_t pbeg = item_ptr[item], pend = item_ptr[item + 1];
+  const int32_t pfirst = item_pts[pbeg];
+  const int gi = pfirst >= n_unode ? 1 : 0;
+  if (pass == 0 && gi == 1) return;                                        // rotation points have no U rows
+  const int64_t e0 = (int64_t)(3 * pfirst) * width + 8 * c;
+  const int32_t pk0 = pcell[pfirst];
+  const int bx = pk0 & 1023, by = (pk0 >> 10) & 1023, bz = pk0 >> 20;
+  for (int idx = t; idx < CG_TABLE; idx += 256) table[idx] = 0.0;
+  int far = 0;
+  const int wv = t >> 6, la = t & 7, lk = (t >> 3) & 7;
+  for (int64_t p0 = pbeg; p0 < pend; p0 += CGH_CHUNK) {
+    const int npts = (int)min((int64_t)CGH_CHUNK, pend - p0);
+    __syncthreads();
+    if (t < npts) {
+      const int32_t i = item_pts[p0 + t];
+      const int64_t k0 = brow[i];
+      s_k0[t] = (int32_t)k0;
+      s_scan[t + 1] = (int32_t)(brow[i + 1] - k0);
+      s_fi[t] = fixed == nullptr ? 0 : (fixed[3 * i] ? 1 : 0) | (fixed[3 * i + 1] ? 2 : 0) | (fixed[3 * i + 2] ? 4 : 0);
+    }
+    for (int idx = t; idx < npts * 8; idx += 256) {
+      const int32_t i = item_pts[p0 + (idx >> 3)];
+      s_wpt[idx >> 3][idx & 7] = cs_w4[(int64_t)i * 8 + (idx & 7)];
+    }
+    __syncthreads();
+    if (t == 0) {
+      int32_t run = 0;
+      s_scan[0] = 0;
+      for (int q = 0; q < npts; ++q) { run += s_scan[q + 1]; s_scan[q + 1] = run; }
+    }
+    __syncthreads();
+    const int B = s_scan[npts];
+    for (int base = 0; base < B; base += CGH_CHUNK) {
+      const int f = base + t;
+      if (t < CGH_CHUNK && f < B) {
+        int lo = 0, hi = npts - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (s_scan[mid] <= f) lo = mid; else hi = mid - 1;
+        }
+        const int q = lo, lkk = f - s_scan[q];
+        const int64_t k0 = s_k0[q];
+        const int64_t len = 3 * (int64_t)(s_scan[q + 1] - s_scan[q]);
+        const int32_t cj = bcols[k0 + lkk];
+        const int32_t pk = pcell[cj / 3];
+        const int ox = (pk & 1023) - bx + 1, oy = ((pk >> 10) & 1023) - by + 1, oz = (pk >> 20) - bz + 1;
+        if ((unsigned)ox > 2u || (unsigned)oy > 2u || (unsigned)oz > 2u) {
+          far = 1;
+          s_meta[t] = -1;
+        } else {
+          s_meta[t] = ox | (oy << 2) | (oz << 4) | ((cj >= 3 * n_unode ? 1 : 0) << 6) | (q << 8);
+          const double* v = vals + 9 * k0 + 3 * lkk;
+          const int fi = s_fi[q];
+          const int fj = fixed == nullptr ? 0 : (fixed[cj] ? 1 : 0) | (fixed[cj + 1] ? 2 : 0) | (fixed[cj + 2] ? 4 : 0);
+#pragma unroll
+          for (int fa = 0; fa < 3; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < 3; ++fb) s_val[t][3 * fa + fb] = ((fi >> fa) & 1) || ((fj >> fb) & 1) ? 0.0 : v[fa * len + fb];
+          const float4* wj = cs_w4 + (int64_t)(cj / 3) * 8;
+#pragma unroll
+          for (int b = 0; b < 8; ++b) s_wb[t][b] = wj[b];
+        }
+      }
+      __syncthreads();
+      const int cnt = min(CGH_CHUNK, B - base);
+      for (int e = wv; e < cnt; e += 4) {
+        const int32_t m = s_meta[e];
+        if (m < 0) continue;
+        const int ox = m & 3, oy = (m >> 2) & 3, oz = (m >> 4) & 3, gj = (m >> 6) & 1, q = m >> 8;
+        const float4 wp = s_wpt[q][la], wq = s_wb[e][lk];
+        const int bl = (ox + (lk & 1)) + 4 * (oy + ((lk >> 1) & 1)) + 16 * (oz + (lk >> 2));
+        const double* K = s_val[e];
+        // M = K W_q (3 x 6): U columns alpha_q K (displacement column), Theta columns -K [sigma_q]x or w_q K
+        double MU[3][3], MT[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const double k0v = K[3 * i], k1v = K[3 * i + 1], k2v = K[3 * i + 2];
+          if (gj == 0) {
+            MU[i][0] = (double)wq.x * k0v; MU[i][1] = (double)wq.x * k1v; MU[i][2] = (double)wq.x * k2v;
+            // -(K [s]x)[i][.]:  (K[s]x)[i][0] = k1 s2 - k2 s1, [i][1] = k2 s0 - k0 s2, [i][2] = k0 s1 - k1 s0
+            MT[i][0] = -(k1v * (double)wq.w - k2v * (double)wq.z);
+            MT[i][1] = -(k2v * (double)wq.y - k0v * (double)wq.w);
+            MT[i][2] = -(k0v * (double)wq.z - k1v * (double)wq.y);
+          } else {
+            MU[i][0] = MU[i][1] = MU[i][2] = 0.0;
+            MT[i][0] = (double)wq.x * k0v; MT[i][1] = (double)wq.x * k1v; MT[i][2] = (double)wq.x * k2v;
+          }
+        }
+        double* dst = table + bl * 8 + la;
+        if (pass == 0) {
+          const double ap = (double)wp.x;
+#pragma unroll
+          for (int fa = 0; fa < 3; ++fa) {
+#pragma unroll
+            for (int fb = 0; fb < 3; ++fb) {
+              if (gj == 0) __hip_atomic_fetch_add(dst + (6 * fa + fb) * 512, ap * MU[fa][fb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_fetch_add(dst + (6 * fa + 3 + fb) * 512, ap * MT[fa][fb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          }
+        } else {
+          // Theta rows against the Theta columns: R = [sigma_p]x MT (displacement item) or w_p MT (rotation item)
+          double R[3][3];
+          if (gi == 0) {
+            const double s0 = (double)wp.y, s1 = (double)wp.z, s2 = (double)wp.w;
+#pragma unroll
+            for (int fb = 0; fb < 3; ++fb) {
+              R[0][fb] = -s2 * MT[1][fb] + s1 * MT[2][fb];
+              R[1][fb] = s2 * MT[0][fb] - s0 * MT[2][fb];
+              R[2][fb] = -s1 * MT[0][fb] + s0 * MT[1][fb];
+            }
+          } else {
+#pragma unroll
+            for (int fa = 0; fa < 3; ++fa)
+#pragma unroll
+              for (int fb = 0; fb < 3; ++fb) R[fa][fb] = (double)wp.x * MT[fa][fb];
+          }
+#pragma unroll
+          for (int fa = 0; fa < 3; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < 3; ++fb)
+              __hip_atomic_fetch_add(dst + (6 * fa + 3 + fb) * 512, R[fa][fb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (far && info != nullptr) atomicOr(&info[1], 1);
+  __syncthreads();
+  {
+    const int a = t & 7, blq = t >> 3;
+    const int64_t na = ell_idx[e0 + a] / 6 - off_c;
+    const int row0 = pass == 0 ? 0 : 3;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int bl = blq + 32 * s;
+      const int32_t nb = item_nbr[item * 64 + bl];
+      if (nb < 0) continue;
+      const double* src = table + bl * 8 + a;
+#pragma unroll
+      for (int fa = 0; fa < 3; ++fa)
+#pragma unroll
+        for (int f = (pass == 0 ? 0 : 3); f < 6; ++f) {
+          const double v = src[(6 * fa + f) * 512];
+          if (v != 0.0) atomicAdd(&A[(6 * na + row0 + fa) * lda + 6 * (int64_t)nb + f], v);
+        }
+    }
+  }
+}
+
+// the (Theta, U) quadrant of every node pair = transpose of (U, Theta): A[6 a + 3 + i, 6 b + j] = A[6 b + j, 6 a + 3 + i]
+__global__ void k_pc_coarse_mirror_tu(int64_t n, int64_t lda, double* __restrict__ A) {
+  const int64_t r = blockIdx.y;
+  if (r >= n || (r % 6) < 3) return;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (int64_t)gridDim.x * blockDim.x)
+    if ((c % 6) < 3) A[r * lda + c] = A[c * lda + r];
+}
+
 // packed lattice coordinates of the level-c cell of every point (its first ELL node is the cell's corner)
 __global__ void k_pc_coarse_cells(int64_t n_pts, int c, int width, int64_t off_c, const int32_t* __restrict__ ell_idx,
                                   const int32_t* __restrict__ node_xyz, int32_t* __restrict__ pcell) {
@@ -1879,13 +2194,165 @@ __global__ __launch_bounds__(SH_BLOCK) void k_lat_down_composite(int64_t row0, i
   }
 }
 
+
+// ---- Hermite-type lattice spaces (round 4; fea/shell.py::hermite_lattice, oracle/shell_oracle.py::LatticePreconditioner) --
+// The nodal rotations of a lattice are the slopes of its displacement interpolation:
+//   displacement point:  u = sum_n [ alpha_n U_n + Theta_n x sigma_n ]        (w4 = (alpha, sigma), 8 nodes)
+//   rotation point:      theta = sum_n w_n Theta_n                            (w4 = (w, 0, 0, 0))
+//   lattice to lattice:  U_c = a U_p + Theta_p x b,   Theta_c = c Theta_p     (w5 = (a, b, c) per (child, parent))
+// and the transposes  g_U[n] += alpha r,  g_Theta[n] += sigma x r  /  g_U[p] += a g_U[c],  g_Theta[p] += c g_Theta[c] + b x g_U[c].
+// A bending mode (w quadratic, theta = grad w) is then reproduced by lattices far coarser than the shell is thick, where
+// the trilinear spaces of rounds 2-3 lock: 253 -> ~130 iterations on the 362 x 362 roof at the same cost per iteration.
+struct V3 { double x, y, z; };
+__device__ __forceinline__ V3 cross3(const V3& a, const V3& b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+
+// g = P_L^T r on the finest lattice's nodes [m0, m1): per node a row of displacement points (first dof 3 p, w4) and a row
+// of rotation points; SUB lanes per node
+template <int SUB>
+__global__ __launch_bounds__(SH_BLOCK) void k_pc_restrict_h(int64_t m0, int64_t m1, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                            const float4* __restrict__ w4, const double* __restrict__ r, double* __restrict__ g,
+                                                            const int32_t* __restrict__ done) {
+  if (done != nullptr && *done) return;
+  const int sl = threadIdx.x & (SUB - 1);
+  const int64_t nsub = (int64_t)gridDim.x * (SH_BLOCK / SUB);
+  for (int64_t k = (int64_t)blockIdx.x * (SH_BLOCK / SUB) + (threadIdx.x / SUB); k < m1 - m0; k += nsub) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, t0 = 0.0, t1 = 0.0, t2 = 0.0;
+    const int64_t e0 = rowptr[2 * k], e1 = rowptr[2 * k + 1], e2 = rowptr[2 * k + 2];
+    for (int64_t e = e0 + sl; e < e1; e += SUB) {
+      const float4 w = w4[e];
+      const Triple rc = *reinterpret_cast<const Triple*>(r + cols[e]);
+      s0 += (double)w.x * rc.a; s1 += (double)w.x * rc.b; s2 += (double)w.x * rc.c;
+      // sigma x r
+      t0 += (double)w.z * rc.c - (double)w.w * rc.b;
+      t1 += (double)w.w * rc.a - (double)w.y * rc.c;
+      t2 += (double)w.y * rc.b - (double)w.z * rc.a;
+    }
+    for (int64_t e = e1 + sl; e < e2; e += SUB) {
+      const double w = (double)w4[e].x;
+      const Triple rc = *reinterpret_cast<const Triple*>(r + cols[e]);
+      t0 += w * rc.a; t1 += w * rc.b; t2 += w * rc.c;
+    }
+#pragma unroll
+    for (int off = SUB / 2; off > 0; off >>= 1) {
+      s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64);
+      t0 += __shfl_xor(t0, off, 64); t1 += __shfl_xor(t1, off, 64); t2 += __shfl_xor(t2, off, 64);
+    }
+    if (sl < 6) {
+      const double v = sl == 0 ? s0 : (sl == 1 ? s1 : (sl == 2 ? s2 : (sl == 3 ? t0 : (sl == 4 ? t1 : t2))));
+      g[6 * (m0 + k) + sl] = v;
+    }
+  }
+}
+
+// one lattice level, nodes [n0, n1), a thread per (node, field group):
+//   down: g[p] from the node's children (chi rows), up: e[c] = B_c g_c + (transfer of the parents' e) with the node's
+//   6 x 6 block B; w5 = (a, bx, by, bz, c) per entry.  dot_partials (up, finest level): per-block partial of e . g.
+__global__ __launch_bounds__(256) void k_lat_level_h(int64_t n0, int64_t n1, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                     const double* __restrict__ w5, double* __restrict__ g, double* __restrict__ e, int up,
+                                                     const int32_t* __restrict__ done, const double* __restrict__ blocks,
+                                                     double* __restrict__ dot_partials) {
+  if (done != nullptr && *done) return;
+  __shared__ double lds[256 / 64];
+  double dot = 0.0;
+  const int64_t total = (n1 - n0) * 2;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t node = n0 + (t >> 1);
+    const int grp = (int)(t & 1);
+    const double* src = up ? e : g;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int64_t k = rowptr[node]; k < rowptr[node + 1]; ++k) {
+      const double* w = w5 + 5 * k;
+      const double* sv = src + 6 * (int64_t)cols[k];
+      if (up) {
+        if (grp == 0) {                     // U_c = a U_p + Theta_p x b
+          const V3 th = {sv[3], sv[4], sv[5]}, b = {w[1], w[2], w[3]};
+          const V3 cb = cross3(th, b);
+          s0 += w[0] * sv[0] + cb.x; s1 += w[0] * sv[1] + cb.y; s2 += w[0] * sv[2] + cb.z;
+        } else {                            // Theta_c = c Theta_p
+          s0 += w[4] * sv[3]; s1 += w[4] * sv[4]; s2 += w[4] * sv[5];
+        }
+      } else {
+        if (grp == 0) {                     // g_U[p] += a g_U[c]
+          s0 += w[0] * sv[0]; s1 += w[0] * sv[1]; s2 += w[0] * sv[2];
+        } else {                            // g_Theta[p] += c g_Theta[c] + b x g_U[c]
+          const V3 gu = {sv[0], sv[1], sv[2]}, b = {w[1], w[2], w[3]};
+          const V3 cb = cross3(b, gu);
+          s0 += w[4] * sv[3] + cb.x; s1 += w[4] * sv[4] + cb.y; s2 += w[4] * sv[5] + cb.z;
+        }
+      }
+    }
+    double* out = (up ? e : g) + 6 * node + 3 * grp;
+    if (!up) { out[0] = s0; out[1] = s1; out[2] = s2; continue; }
+    const double* B = blocks + 36 * node + 18 * grp;
+    const double* gn = g + 6 * node;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { s0 += B[q] * gn[q]; s1 += B[6 + q] * gn[q]; s2 += B[12 + q] * gn[q]; }
+    out[0] = s0; out[1] = s1; out[2] = s2;
+    dot += s0 * gn[3 * grp] + s1 * gn[3 * grp + 1] + s2 * gn[3 * grp + 2];
+  }
+  if (dot_partials != nullptr) {
+    const double tsum = femo_block_sum<256>(dot, lds);
+    if (threadIdx.x == 0) dot_partials[blockIdx.x] = tsum;
+  }
+}
+
+// all levels between the coarse-solve level and the finest lattice at once (composite of the child transfers, built on
+// the host in the same (A, B, C) form): one wave per node
+__global__ __launch_bounds__(SH_BLOCK) void k_lat_down_composite_h(int64_t row0, int64_t n_rows, const int64_t* __restrict__ rowptr,
+                                                                   const int32_t* __restrict__ cols, const double* __restrict__ w5,
+                                                                   double* __restrict__ g, const int32_t* __restrict__ done) {
+  if (done != nullptr && *done) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (SH_BLOCK / 64) + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int64_t k = rowptr[row] + lane; k < rowptr[row + 1]; k += 64) {
+    const double* w = w5 + 5 * k;
+    const double* sv = g + 6 * (int64_t)cols[k];
+    const V3 gu = {sv[0], sv[1], sv[2]}, b = {w[1], w[2], w[3]};
+    const V3 cb = cross3(b, gu);
+    s[0] += w[0] * gu.x; s[1] += w[0] * gu.y; s[2] += w[0] * gu.z;
+    s[3] += w[4] * sv[3] + cb.x; s[4] += w[4] * sv[4] + cb.y; s[5] += w[4] * sv[5] + cb.z;
+  }
+#pragma unroll
+  for (int f = 0; f < 6; ++f) s[f] = femo_wave_sum(s[f]);
+  if (lane == 0) {
+    double* dst = g + 6 * (row0 + row);
+#pragma unroll
+    for (int f = 0; f < 6; ++f) dst[f] = s[f];
+  }
+}
+
+// (P_L e_L) of one point, 8 lanes per point (lane sl = corner): the three components, valid in all 8 lanes
+__device__ __forceinline__ void prolong_point_h(int64_t p, int sl, int64_t n_unode, const int32_t* __restrict__ fin_idx, const float4* __restrict__ fin_w4,
+                                                const double* __restrict__ t, double& s0, double& s1, double& s2) {
+  const float4 w = fin_w4[p * 8 + sl];
+  const int32_t idx = fin_idx[p * 8 + sl];
+  if (p < n_unode) {
+    const double* tn = t + idx;                              // idx = 6 node
+    const V3 th = {tn[3], tn[4], tn[5]}, sg = {(double)w.y, (double)w.z, (double)w.w};
+    const V3 cb = cross3(th, sg);
+    s0 = (double)w.x * tn[0] + cb.x; s1 = (double)w.x * tn[1] + cb.y; s2 = (double)w.x * tn[2] + cb.z;
+  } else {
+    const Triple tp = *reinterpret_cast<const Triple*>(t + idx);     // idx = 6 node + 3
+    s0 = (double)w.x * tp.a; s1 = (double)w.x * tp.b; s2 = (double)w.x * tp.c;
+  }
+#pragma unroll
+  for (int off = 4; off > 0; off >>= 1) {
+    s0 += __shfl_xor(s0, off, 64);
+    s1 += __shfl_xor(s1, off, 64);
+    s2 += __shfl_xor(s2, off, 64);
+  }
+}
+
 // z = D^-1 r + P_L e_L (8 lanes per point, one finest-level entry each, three components) and the per-block partial of
 // r.z; imposed dofs: z = 0
 __global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong(int64_t n_pts, const int32_t* __restrict__ fin_idx, const float* __restrict__ fin_w,
                                                          const uint8_t* __restrict__ fixed, const double* __restrict__ dinv,
                                                          const double* __restrict__ r, const double* __restrict__ t, double* __restrict__ z,
                                                          double* __restrict__ partials, const int32_t* __restrict__ done,
-                                                         const float* __restrict__ dinv3 = nullptr) {
+                                                         const float* __restrict__ dinv3 = nullptr, const float4* __restrict__ fin_w4 = nullptr,
+                                                         int64_t n_unode = 0) {
   if (done != nullptr && *done) return;
   __shared__ double lds[SH_BLOCK / 64];
   constexpr int SUB = 8;
@@ -1893,14 +2360,19 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong(int64_t n_pts, const in
   const int64_t nsub = (int64_t)gridDim.x * (SH_BLOCK / SUB);
   double dot = 0.0;
   for (int64_t p = (int64_t)blockIdx.x * (SH_BLOCK / SUB) + (threadIdx.x / SUB); p < n_pts; p += nsub) {
-    const double w = (double)fin_w[p * 8 + sl];
-    const Triple tp = *reinterpret_cast<const Triple*>(t + fin_idx[p * 8 + sl]);
-    double s0 = w * tp.a, s1 = w * tp.b, s2 = w * tp.c;
+    double s0, s1, s2;
+    if (fin_w4 != nullptr) {                                 // Hermite-type finest transfer
+      prolong_point_h(p, sl, n_unode, fin_idx, fin_w4, t, s0, s1, s2);
+    } else {
+      const double w = (double)fin_w[p * 8 + sl];
+      const Triple tp = *reinterpret_cast<const Triple*>(t + fin_idx[p * 8 + sl]);
+      s0 = w * tp.a; s1 = w * tp.b; s2 = w * tp.c;
 #pragma unroll
-    for (int off = SUB / 2; off > 0; off >>= 1) {
-      s0 += __shfl_xor(s0, off, 64);
-      s1 += __shfl_xor(s1, off, 64);
-      s2 += __shfl_xor(s2, off, 64);
+      for (int off = SUB / 2; off > 0; off >>= 1) {
+        s0 += __shfl_xor(s0, off, 64);
+        s1 += __shfl_xor(s1, off, 64);
+        s2 += __shfl_xor(s2, off, 64);
+      }
     }
     if (sl < 3) {
       const int64_t row = 3 * p + sl;
@@ -2008,7 +2480,8 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong_fused(int64_t n_pts, in
                                                                const uint8_t* __restrict__ fixed, const double* __restrict__ dinv,
                                                                const float* __restrict__ dinv3, const double* __restrict__ r,
                                                                const double* __restrict__ t, double* __restrict__ p,
-                                                               int32_t* __restrict__ flag, double* __restrict__ gamma_out) {
+                                                               int32_t* __restrict__ flag, double* __restrict__ gamma_out,
+                                                               const float4* __restrict__ fin_w4 = nullptr, int64_t n_unode = 0) {
   if (flag[0]) return;
   __shared__ double lds[SH_BLOCK / 64];
   const double g1 = fold(part_rB, nb_rB, lds) + fold(part_te, nb_te, lds);
@@ -2020,14 +2493,19 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_prolong_fused(int64_t n_pts, in
     const int sl = threadIdx.x & (SUB - 1);
     const int64_t nsub = (int64_t)gridDim.x * (SH_BLOCK / SUB);
     for (int64_t pt = (int64_t)blockIdx.x * (SH_BLOCK / SUB) + (threadIdx.x / SUB); pt < n_pts; pt += nsub) {
-      const double w = (double)fin_w[pt * 8 + sl];
-      const Triple tp = *reinterpret_cast<const Triple*>(t + fin_idx[pt * 8 + sl]);
-      double s0 = w * tp.a, s1 = w * tp.b, s2 = w * tp.c;
+      double s0, s1, s2;
+      if (fin_w4 != nullptr) {
+        prolong_point_h(pt, sl, n_unode, fin_idx, fin_w4, t, s0, s1, s2);
+      } else {
+        const double w = (double)fin_w[pt * 8 + sl];
+        const Triple tp = *reinterpret_cast<const Triple*>(t + fin_idx[pt * 8 + sl]);
+        s0 = w * tp.a; s1 = w * tp.b; s2 = w * tp.c;
 #pragma unroll
-      for (int off = SUB / 2; off > 0; off >>= 1) {
-        s0 += __shfl_xor(s0, off, 64);
-        s1 += __shfl_xor(s1, off, 64);
-        s2 += __shfl_xor(s2, off, 64);
+        for (int off = SUB / 2; off > 0; off >>= 1) {
+          s0 += __shfl_xor(s0, off, 64);
+          s1 += __shfl_xor(s1, off, 64);
+          s2 += __shfl_xor(s2, off, 64);
+        }
       }
       if (sl < 3) {
         const int64_t row = 3 * pt + sl;
@@ -2231,6 +2709,8 @@ int femo_shell_destroy(femo_shell* s) {
   hipFree(s->d_ptp_rowptr); hipFree(s->d_ptp_cols); hipFree(s->d_ptp_vals);
   hipFree(s->d_cs_xyz); hipFree(s->d_cs_ptr); hipFree(s->d_cs_pts); hipFree(s->d_cs_nbr); hipFree(s->d_cs_A); hipFree(s->d_cs_Af); hipFree(s->d_cs_tmp); hipFree(s->d_cs_dinv); hipFree(s->d_cs_info); hipFree(s->d_cs_pcell);
   hipFree(s->d_cd_rowptr); hipFree(s->d_cd_cols); hipFree(s->d_cd_vals);
+  hipFree(s->d_fin_w4); hipFree(s->d_hp_rowptr); hipFree(s->d_hp_cols); hipFree(s->d_hp_w4); hipFree(s->d_par_w5); hipFree(s->d_chi_w5);
+  hipFree(s->d_lvl_w4); hipFree(s->d_cs_w4); hipFree(s->d_hd_rowptr); hipFree(s->d_hd_cols); hipFree(s->d_hd_w5);
   hipFree(s->d_pen_nodes); hipFree(s->d_pen_pos); hipFree(s->d_pen_coef);
   hipFree(s->d_owned); hipFree(s->d_send_idx); hipFree(s->d_recv_idx); hipFree(s->d_send_buf); hipFree(s->d_recv_buf);
   hipFree(s->d_r); hipFree(s->d_p); hipFree(s->d_q); hipFree(s->d_dinv); hipFree(s->d_scal); hipFree(s->d_part); hipFree(s->d_flag);
@@ -2323,6 +2803,7 @@ int femo_shell_pc_create(femo_shell* s, int width, int64_t n_nodes, int n_levels
 // diagonal levels take over: the preconditioner changes, the solution does not.
 static int shell_pc_coarse_setup(femo_shell* s, const femo_vec* vals, const uint8_t* d_fixed) {
   s->cs_ready = false;
+  s->hermite_on = false;
   if (s->cs_level < 0 || s->d_brow == nullptr) return 0;
   hipStream_t st = s->ctx->stream;
   const int64_t n = s->cs_n, N = s->cs_N;
@@ -2332,9 +2813,19 @@ static int shell_pc_coarse_setup(femo_shell* s, const femo_vec* vals, const uint
   auto t0 = now();
   FEMO_HIP_CHECK(hipMemsetAsync(s->d_cs_A, 0, N * N * sizeof(double), st));
   FEMO_HIP_CHECK(hipMemsetAsync(s->d_cs_info, 0, 4 * sizeof(int32_t), st));
-  hipLaunchKernelGGL(k_pc_coarse_galerkin, dim3((unsigned)s->cs_items), dim3(256), CG_LDS, st, s->cs_level, s->pc_width, s->level_off[s->cs_level], N,
-                     s->n_unode, s->d_cs_ptr, s->d_cs_pts, s->d_cs_nbr, s->d_cs_xyz, s->d_cs_pcell, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_ell_idx,
-                     s->d_ell_w, s->d_cs_A, s->d_cs_info);
+  if (s->hermite && s->d_lvl_node != nullptr && !femo_env_flag("FEMO_SHELL_TRILINEAR") && !femo_env_flag("FEMO_SHELL_NO_BLOCKS")) {
+    for (int pass = 0; pass < 2; ++pass)
+      hipLaunchKernelGGL(k_pc_coarse_galerkin_h, dim3((unsigned)s->cs_items), dim3(256), CGH_LDS, st, pass, s->cs_level, s->pc_width, s->level_off[s->cs_level], N,
+                         s->n_unode, s->d_cs_ptr, s->d_cs_pts, s->d_cs_nbr, s->d_cs_pcell, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_ell_idx,
+                         s->d_cs_w4, s->d_cs_A, s->d_cs_info);
+    hipLaunchKernelGGL(k_pc_coarse_mirror_tu, dim3(sgrid(n, 256), (unsigned)n), dim3(256), 0, st, n, N, s->d_cs_A);
+    s->hermite_on = true;
+  } else {
+    hipLaunchKernelGGL(k_pc_coarse_galerkin, dim3((unsigned)s->cs_items), dim3(256), CG_LDS, st, s->cs_level, s->pc_width, s->level_off[s->cs_level], N,
+                       s->n_unode, s->d_cs_ptr, s->d_cs_pts, s->d_cs_nbr, s->d_cs_xyz, s->d_cs_pcell, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_ell_idx,
+                       s->d_ell_w, s->d_cs_A, s->d_cs_info);
+    s->hermite_on = false;
+  }
   FEMO_HIP_CHECK(hipGetLastError());
   FEMO_TRY(shell_allreduce(s, s->d_cs_A, N * N, st));      // partitioned: every rank formed P^T (its rows of K) P
   hipLaunchKernelGGL(k_pc_coarse_fix_diag, dim3(sgrid(N, 256)), dim3(256), 0, st, N, s->d_cs_A);
@@ -2369,6 +2860,12 @@ static int shell_pc_coarse_setup(femo_shell* s, const femo_vec* vals, const uint
     FEMO_HIP_CHECK(hipStreamSynchronize(st));
     s->cs_ready = all == 0.0;
   }
+  if (s->hermite_on && !s->cs_ready) {
+    // the Hermite-type transfers need their own (composed) coarse operator: without it the trilinear hierarchy takes over,
+    // whose dense operator is formed now (the preconditioner changes, the solution does not)
+    s->hermite = false;
+    return shell_pc_coarse_setup(s, vals, d_fixed);
+  }
   if (dbg) {
     auto t3 = now();
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -2385,15 +2882,27 @@ static int shell_pc_apply(femo_shell* s, const uint8_t* d_fixed, double* Prz, un
                           double* Pte = nullptr, int* nb_te = nullptr, const ShellXCarry* carry = nullptr) {
   hipStream_t st = s->ctx->stream;
   const int L = s->pc_levels;
+  const bool herm = s->hermite_on && s->cs_ready && s->blk_ready;
   auto level_up = [&](int l, const double* blocks) {
     const int64_t n0 = s->level_off[l], n1 = s->level_off[l + 1];
     const bool last = l == L - 1 && Pte != nullptr;
+    if (herm) {
+      const unsigned g = last ? std::min<unsigned>(sgrid((n1 - n0) * 2, 256), 1024u) : sgrid((n1 - n0) * 2, 256);
+      if (last && nb_te) *nb_te = (int)g;
+      hipLaunchKernelGGL(k_lat_level_h, dim3(g), dim3(256), 0, st, n0, n1, s->d_par_rowptr, s->d_par_cols, s->d_par_w5, s->d_t, s->d_e, 1, done, blocks,
+                         last ? Pte : (double*)nullptr);
+      return;
+    }
     const unsigned g = last ? std::min<unsigned>(sgrid((n1 - n0) * 6, 256), 1024u) : sgrid((n1 - n0) * 6, 256);   // few partials: every block of the prolongation folds them
     if (last && nb_te) *nb_te = (int)g;
     hipLaunchKernelGGL(k_lat_level, dim3(g), dim3(256), 0, st, n0, n1, s->d_par_rowptr, s->d_par_cols, s->d_par_vals,
                        s->d_coarse, s->d_t, s->d_e, 1, done, blocks, last ? Pte : (double*)nullptr);
   };
   const int64_t m0 = s->level_off[L - 1], m1 = s->level_off[L];
+  if (herm)
+    hipLaunchKernelGGL(k_pc_restrict_h<32>, dim3(std::min<unsigned>(sgrid(m1 - m0, SH_BLOCK / 32), 1 << 16)), dim3(SH_BLOCK), 0, st, m0, m1,
+                       s->d_hp_rowptr, s->d_hp_cols, s->d_hp_w4, s->d_r, s->d_t, done);
+  else
   // 32 lanes per row (rows hold ~100 points; 8 / 16 / 32 / 64 lanes: 0.362 / 0.355 / 0.351 / 0.351 ms per iteration)
   hipLaunchKernelGGL(k_pc_restrict<32>, dim3(std::min<unsigned>(sgrid(2 * (m1 - m0), SH_BLOCK / 32), 1 << 16)), dim3(SH_BLOCK), 0, st, m0, m1,
                      s->d_ptp_rowptr, s->d_ptp_cols, s->d_ptp_vals, s->d_r, s->d_t, done);
@@ -2406,7 +2915,17 @@ static int shell_pc_apply(femo_shell* s, const uint8_t* d_fixed, double* Prz, un
   if (s->cs_ready) {
     // levels above the coarse-solve level as before; on it the dense inverse replaces the diagonal levels 0 .. cs
     const int cs = s->cs_level;
-    if (s->d_cd_rowptr != nullptr && L - 1 > cs) {
+    if (herm && s->d_hd_rowptr != nullptr && L - 1 > cs) {
+      const int64_t rows = s->level_off[L - 1] - s->level_off[cs];
+      hipLaunchKernelGGL(k_lat_down_composite_h, dim3(sgrid(rows, SH_BLOCK / 64)), dim3(SH_BLOCK), 0, st, s->level_off[cs], rows, s->d_hd_rowptr,
+                         s->d_hd_cols, s->d_hd_w5, s->d_t, done);
+    } else if (herm) {
+      for (int l = L - 2; l >= cs; --l) {
+        const int64_t n0 = s->level_off[l], n1 = s->level_off[l + 1];
+        hipLaunchKernelGGL(k_lat_level_h, dim3(sgrid((n1 - n0) * 2, 256)), dim3(256), 0, st, n0, n1, s->d_chi_rowptr, s->d_chi_cols, s->d_chi_w5, s->d_t, s->d_e, 0,
+                           done, (const double*)nullptr, (double*)nullptr);
+      }
+    } else if (s->d_cd_rowptr != nullptr && L - 1 > cs) {
       const int64_t rows = s->level_off[L - 1] - s->level_off[cs];
       hipLaunchKernelGGL(k_lat_down_composite, dim3(sgrid(rows, SH_BLOCK / 64)), dim3(SH_BLOCK), 0, st, s->level_off[cs], rows, s->d_cd_rowptr,
                          s->d_cd_cols, s->d_cd_vals, s->d_t, done);
@@ -2454,7 +2973,7 @@ static int shell_pc_apply(femo_shell* s, const uint8_t* d_fixed, double* Prz, un
   }
   if (Pte != nullptr) { FEMO_HIP_CHECK(hipGetLastError()); return 0; }
   hipLaunchKernelGGL(k_pc_prolong, dim3(gz), dim3(SH_BLOCK), 0, st, s->n_dof / 3, s->d_fin_idx, s->d_fin_w, d_fixed, s->d_dinv, s->d_r, s->d_e,
-                     s->d_z, Prz, done, s->dinv3_ready ? s->d_dinv3 : (const float*)nullptr);
+                     s->d_z, Prz, done, s->dinv3_ready ? s->d_dinv3 : (const float*)nullptr, herm ? s->d_fin_w4 : (const float4*)nullptr, s->n_unode);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -2513,6 +3032,44 @@ int femo_shell_pc_coarse(femo_shell* s, int level, const int32_t* node_xyz, int6
   return 0;
 }
 
+// Hermite-type lattice spaces on the hierarchy of femo_shell_pc_create / femo_shell_pc_coarse (fea/shell.py::hermite_lattice).
+int femo_shell_pc_hermite(femo_shell* s, const float* fin_w4, const int64_t* hp_rowptr, const int32_t* hp_cols, const float* hp_w4,
+                          const double* par_w5, const double* chi_w5, const float* lvl_w4, const float* cs_w4,
+                          const int64_t* down_rowptr, const int32_t* down_cols, const double* down_w5) {
+  FEMO_REQUIRE(s && fin_w4 && hp_rowptr && hp_cols && hp_w4 && par_w5 && chi_w5 && lvl_w4 && cs_w4, "null argument");
+  FEMO_REQUIRE(s->pc_width > 0 && s->cs_level >= 0, "femo_shell_pc_hermite needs femo_shell_pc_create and femo_shell_pc_coarse first");
+  FEMO_REQUIRE(!s->hermite, "the shell already has its Hermite-type lattice data");
+  FEMO_REQUIRE(s->d_owned == nullptr, "Hermite-type lattice spaces are not available on a partitioned shell");
+  hipStream_t st = s->ctx->stream;
+  FEMO_HIP_CHECK(hipSetDevice(s->ctx->device));
+  const int64_t n_pts = s->n_dof / 3;
+  const int L = s->pc_levels;
+  const int64_t m0 = s->level_off[L - 1], m1 = s->level_off[L];
+  std::vector<int64_t> h_par((size_t)s->pc_nodes + 1), h_chi((size_t)s->pc_nodes + 1);
+  FEMO_HIP_CHECK(hipMemcpy(h_par.data(), s->d_par_rowptr, (s->pc_nodes + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+  FEMO_HIP_CHECK(hipMemcpy(h_chi.data(), s->d_chi_rowptr, (s->pc_nodes + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+  FEMO_TRY(to_device(&s->d_fin_w4, reinterpret_cast<const float4*>(fin_w4), n_pts * 8, st));
+  FEMO_TRY(to_device(&s->d_hp_rowptr, hp_rowptr, 2 * (m1 - m0) + 1, st));
+  FEMO_TRY(to_device(&s->d_hp_cols, hp_cols, hp_rowptr[2 * (m1 - m0)], st));
+  FEMO_TRY(to_device(&s->d_hp_w4, reinterpret_cast<const float4*>(hp_w4), hp_rowptr[2 * (m1 - m0)], st));
+  FEMO_TRY(to_device(&s->d_par_w5, par_w5, 5 * h_par[(size_t)s->pc_nodes], st));
+  FEMO_TRY(to_device(&s->d_chi_w5, chi_w5, 5 * h_chi[(size_t)s->pc_nodes], st));
+  const int n_above = L - 1 - s->cs_level;                      // levels cs + 1 .. L - 1
+  FEMO_TRY(to_device(&s->d_lvl_w4, reinterpret_cast<const float4*>(lvl_w4), (int64_t)n_above * n_pts * 8, st));
+  FEMO_TRY(to_device(&s->d_cs_w4, reinterpret_cast<const float4*>(cs_w4), n_pts * 8, st));
+  if (down_rowptr != nullptr && down_cols != nullptr && down_w5 != nullptr) {
+    const int64_t rows = s->level_off[L - 1] - s->level_off[s->cs_level];
+    FEMO_TRY(to_device(&s->d_hd_rowptr, down_rowptr, rows + 1, st));
+    FEMO_TRY(to_device(&s->d_hd_cols, down_cols, down_rowptr[rows], st));
+    FEMO_TRY(to_device(&s->d_hd_w5, down_w5, 5 * down_rowptr[rows], st));
+  }
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  FEMO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pc_coarse_galerkin_h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CGH_LDS));
+  s->hermite = true;
+  s->pc_vals_uid = 0; s->pc_vals_gen = 0;
+  return 0;
+}
+
 // For tests: the dense coarse operator (inverse = 0) or the factors of its inverse (1: L^-T above, L^-1 below the
 // diagonal) for `vals` and the mask, row-major n x n on the host; the unknown count through *n_out.
 int femo_shell_pc_coarse_matrix(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_host, int inverse, double* out, int64_t* n_out) {
@@ -2530,9 +3087,17 @@ int femo_shell_pc_coarse_matrix(femo_shell* s, const femo_vec* vals, const uint8
   } else {
     FEMO_HIP_CHECK(hipMemsetAsync(s->d_cs_A, 0, N * N * sizeof(double), st));
     FEMO_HIP_CHECK(hipMemsetAsync(s->d_cs_info, 0, 4 * sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_pc_coarse_galerkin, dim3((unsigned)s->cs_items), dim3(256), CG_LDS, st, s->cs_level, s->pc_width, s->level_off[s->cs_level], N,
-                       s->n_unode, s->d_cs_ptr, s->d_cs_pts, s->d_cs_nbr, s->d_cs_xyz, s->d_cs_pcell, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_ell_idx,
-                       s->d_ell_w, s->d_cs_A, s->d_cs_info);
+    if (s->hermite && !femo_env_flag("FEMO_SHELL_TRILINEAR")) {
+      for (int pass = 0; pass < 2; ++pass)
+        hipLaunchKernelGGL(k_pc_coarse_galerkin_h, dim3((unsigned)s->cs_items), dim3(256), CGH_LDS, st, pass, s->cs_level, s->pc_width, s->level_off[s->cs_level], N,
+                           s->n_unode, s->d_cs_ptr, s->d_cs_pts, s->d_cs_nbr, s->d_cs_pcell, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_ell_idx,
+                           s->d_cs_w4, s->d_cs_A, s->d_cs_info);
+      hipLaunchKernelGGL(k_pc_coarse_mirror_tu, dim3(sgrid(n, 256), (unsigned)n), dim3(256), 0, st, n, N, s->d_cs_A);
+    } else {
+      hipLaunchKernelGGL(k_pc_coarse_galerkin, dim3((unsigned)s->cs_items), dim3(256), CG_LDS, st, s->cs_level, s->pc_width, s->level_off[s->cs_level], N,
+                         s->n_unode, s->d_cs_ptr, s->d_cs_pts, s->d_cs_nbr, s->d_cs_xyz, s->d_cs_pcell, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_ell_idx,
+                         s->d_ell_w, s->d_cs_A, s->d_cs_info);
+    }
     FEMO_HIP_CHECK(hipGetLastError());
     s->cs_ready = false;
   }
@@ -2875,6 +3440,76 @@ int femo_shell_hpower(femo_shell* s, double coef, double p, const femo_vec* h, d
 // K_ff x_f = b_f - K_fc g_c with x_c = g_c on the dofs flagged in `fixed` (host array of n_dof bytes, values in xfix);
 // PCG, stops on sqrt(r.M^-1 r) <= max(rtol sqrt(r0.M^-1 r0), atol); opts->pc = 0: M = D (Jacobi), 1: the lattice
 // preconditioner of femo_shell_pc_create.  K symmetric: the same call serves the adjoint (fea_dolfinx.py:208-222).
+// The preconditioner's numbers for the current stiffness and Dirichlet set (kept while both stay the same): dense coarse
+// operator and its factors, node blocks (or Galerkin diagonals), point blocks.
+static int shell_pc_setup(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_host, const uint8_t* d_fixed) {
+  hipStream_t st = s->ctx->stream;
+  const int64_t n = s->n_dof;
+  // Galerkin diagonals of the current stiffness and Dirichlet set (kept while both stay the same)
+  uint64_t mh = 1469598103934665603ull;
+  if (fixed_host != nullptr)
+    for (int64_t i = 0; i < n; ++i) mh = (mh ^ fixed_host[i]) * 1099511628211ull;
+  if (s->pc_vals_uid != vals->uid || s->pc_vals_gen != vals->gen || s->pc_mask_hash != mh || vals->uid == 0) {
+    FEMO_TRY(shell_pc_coarse_setup(s, vals, d_fixed));
+    // levels the coarse solve does not replace: 6 x 6 node blocks (they see the coupling of the displacement
+    // components and rotations at a node: 238 -> 203 iterations on the 128 x 128 roof, 412 -> 376 on 362 x 362), or
+    // the Galerkin diagonals when there is no coarse solve
+    const int first_slot = s->cs_ready ? 8 * (s->cs_level + 1) : 0;
+    s->blk_ready = false;
+    if (s->cs_ready && s->d_lvl_node != nullptr && getenv("FEMO_SHELL_NO_BLOCKS") == nullptr) {
+      const int64_t nd0 = s->level_off[s->cs_level + 1], nd1 = s->level_off[s->pc_levels];
+      FEMO_HIP_CHECK(hipMemsetAsync(s->d_cblk + 36 * nd0, 0, (nd1 - nd0) * 36 * sizeof(double), st));
+      if (s->hermite_on)
+        hipLaunchKernelGGL(k_pc_galerkin_blocks_h, dim3(sgrid(n / 3), 3 * ((s->pc_width - first_slot) / 8)), dim3(SH_BLOCK), 0, st, n / 3, s->n_unode,
+                           s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_lvl_node, s->d_lvl_w4, s->d_cblk);
+      else
+        hipLaunchKernelGGL(k_pc_galerkin_blocks, dim3(sgrid(n / 3), 3 * ((s->pc_width - first_slot) / 8)), dim3(SH_BLOCK), 0, st, n / 3, s->pc_width,
+                           s->n_unode, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_lvl_node, s->d_lvl_w, s->d_cblk, first_slot);
+      FEMO_HIP_CHECK(hipGetLastError());
+      FEMO_TRY(shell_allreduce(s, s->d_cblk + 36 * nd0, (nd1 - nd0) * 36, st));
+      hipLaunchKernelGGL(k_pc_invert_blocks, dim3(sgrid(nd1 - nd0, 256)), dim3(256), 0, st, nd0, nd1, s->d_cblk);
+      s->blk_ready = true;
+    } else {
+      FEMO_HIP_CHECK(hipMemsetAsync(s->d_coarse, 0, s->n_lat * sizeof(double), st));
+      hipLaunchKernelGGL(k_pc_galerkin_diag, dim3(sgrid(n * (s->pc_width - first_slot))), dim3(SH_BLOCK), 0, st, n, s->pc_width, s->d_rowptr, s->d_cols,
+                         vals->d, d_fixed, s->d_ell_idx, s->d_ell_w, s->d_coarse, first_slot);
+      FEMO_HIP_CHECK(hipGetLastError());
+      FEMO_TRY(shell_allreduce(s, s->d_coarse, s->n_lat, st));
+      hipLaunchKernelGGL(k_pc_invert, dim3(sgrid(s->n_lat)), dim3(256), 0, st, s->n_lat, s->d_coarse);
+    }
+    s->dinv3_ready = false;
+    if (s->d_brow != nullptr && getenv("FEMO_SHELL_NO_POINT_BLOCKS") == nullptr) {
+      hipLaunchKernelGGL(k_pt_block_inv, dim3(sgrid(n / 3, 256)), dim3(256), 0, st, n / 3, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_dinv3, s->d_dinv);
+      s->dinv3_ready = true;
+    }
+    s->pc_vals_uid = vals->uid; s->pc_vals_gen = vals->gen; s->pc_mask_hash = mh;
+  }
+  return 0;
+}
+
+// z = M^-1 r of the lattice preconditioner for `vals` and the mask (tests compare it with oracle/shell_oracle.py::
+// LatticePreconditioner.apply); entries of r on imposed dofs are ignored, z is zero there.
+int femo_shell_pc_apply(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_host, const femo_vec* r, femo_vec* z) {
+  FEMO_REQUIRE(s && vals && r && z, "null argument");
+  const int64_t n = s->n_dof;
+  FEMO_REQUIRE(s->pc_width > 0, "femo_shell_pc_apply needs femo_shell_pc_create");
+  FEMO_REQUIRE(vals->n >= s->nnz && r->n >= n && z->n >= n && n % 3 == 0, "vector size mismatch in shell_pc_apply");
+  FEMO_REQUIRE(s->d_owned == nullptr, "femo_shell_pc_apply: one rank only");
+  hipStream_t st = s->ctx->stream;
+  femo_vec_touch(z);
+  uint8_t* d_fixed = nullptr;
+  if (fixed_host != nullptr) FEMO_TRY(to_device(&d_fixed, fixed_host, n, st));
+  const unsigned gv = std::min<unsigned>(sgrid(n), SH_MAXPART);
+  hipLaunchKernelGGL(k_rhs_free, dim3(gv), dim3(256), 0, st, n, r->d, d_fixed, s->d_r);
+  FEMO_TRY(shell_pc_setup(s, vals, fixed_host, d_fixed));
+  const unsigned gz = std::min<unsigned>(sgrid(n / 3, SH_BLOCK / 8), SH_MAXPART);
+  FEMO_TRY(shell_pc_apply(s, d_fixed, s->d_part + SH_MAXPART, gz, nullptr));
+  FEMO_HIP_CHECK(hipMemcpyAsync(z->d, s->d_z, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  if (d_fixed) (void)hipFree(d_fixed);
+  return 0;
+}
+
 int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_host, const femo_vec* xfix, const femo_vec* b,
                      femo_vec* x, const femo_solver_opts* opts, femo_solve_info* info) {
   FEMO_REQUIRE(s && vals && b && x && opts && info, "null argument");
@@ -2932,41 +3567,7 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
   // direction update fused into the prolongation (dofs numbered 3 point + component: every shell pattern of fea/shell.py)
   const bool fused = opts->pc == 1 && n % 3 == 0 && !multi && !femo_env_flag("FEMO_SHELL_UNFUSED");
   if (lattice) {
-    // Galerkin diagonals of the current stiffness and Dirichlet set (kept while both stay the same)
-    uint64_t mh = 1469598103934665603ull;
-    if (fixed_host != nullptr)
-      for (int64_t i = 0; i < n; ++i) mh = (mh ^ fixed_host[i]) * 1099511628211ull;
-    if (s->pc_vals_uid != vals->uid || s->pc_vals_gen != vals->gen || s->pc_mask_hash != mh || vals->uid == 0) {
-      FEMO_TRY(shell_pc_coarse_setup(s, vals, d_fixed));
-      // levels the coarse solve does not replace: 6 x 6 node blocks (they see the coupling of the displacement
-      // components and rotations at a node: 238 -> 203 iterations on the 128 x 128 roof, 412 -> 376 on 362 x 362), or
-      // the Galerkin diagonals when there is no coarse solve
-      const int first_slot = s->cs_ready ? 8 * (s->cs_level + 1) : 0;
-      s->blk_ready = false;
-      if (s->cs_ready && s->d_lvl_node != nullptr && getenv("FEMO_SHELL_NO_BLOCKS") == nullptr) {
-        const int64_t nd0 = s->level_off[s->cs_level + 1], nd1 = s->level_off[s->pc_levels];
-        FEMO_HIP_CHECK(hipMemsetAsync(s->d_cblk + 36 * nd0, 0, (nd1 - nd0) * 36 * sizeof(double), st));
-        hipLaunchKernelGGL(k_pc_galerkin_blocks, dim3(sgrid(n / 3), 3 * ((s->pc_width - first_slot) / 8)), dim3(SH_BLOCK), 0, st, n / 3, s->pc_width,
-                           s->n_unode, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_lvl_node, s->d_lvl_w, s->d_cblk, first_slot);
-        FEMO_HIP_CHECK(hipGetLastError());
-        FEMO_TRY(shell_allreduce(s, s->d_cblk + 36 * nd0, (nd1 - nd0) * 36, st));
-        hipLaunchKernelGGL(k_pc_invert_blocks, dim3(sgrid(nd1 - nd0, 256)), dim3(256), 0, st, nd0, nd1, s->d_cblk);
-        s->blk_ready = true;
-      } else {
-        FEMO_HIP_CHECK(hipMemsetAsync(s->d_coarse, 0, s->n_lat * sizeof(double), st));
-        hipLaunchKernelGGL(k_pc_galerkin_diag, dim3(sgrid(n * (s->pc_width - first_slot))), dim3(SH_BLOCK), 0, st, n, s->pc_width, s->d_rowptr, s->d_cols,
-                           vals->d, d_fixed, s->d_ell_idx, s->d_ell_w, s->d_coarse, first_slot);
-        FEMO_HIP_CHECK(hipGetLastError());
-        FEMO_TRY(shell_allreduce(s, s->d_coarse, s->n_lat, st));
-        hipLaunchKernelGGL(k_pc_invert, dim3(sgrid(s->n_lat)), dim3(256), 0, st, s->n_lat, s->d_coarse);
-      }
-      s->dinv3_ready = false;
-      if (s->d_brow != nullptr && getenv("FEMO_SHELL_NO_POINT_BLOCKS") == nullptr) {
-        hipLaunchKernelGGL(k_pt_block_inv, dim3(sgrid(n / 3, 256)), dim3(256), 0, st, n / 3, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_dinv3, s->d_dinv);
-        s->dinv3_ready = true;
-      }
-      s->pc_vals_uid = vals->uid; s->pc_vals_gen = vals->gen; s->pc_mask_hash = mh;
-    }
+    FEMO_TRY(shell_pc_setup(s, vals, fixed_host, d_fixed));
     FEMO_TRY(shell_pc_apply(s, d_fixed, Prz, gz, nullptr));
     hipLaunchKernelGGL(k_copy, dim3(gv), dim3(256), 0, st, n, s->d_z, s->d_p);
   } else {
@@ -3046,7 +3647,8 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
           FEMO_TRY(shell_pc_apply(s, d_fixed, Prz, gz, s->d_flag, Pte, &nb_te));
         }
         hipLaunchKernelGGL(k_pc_prolong_fused, dim3(gz), dim3(SH_BLOCK), 0, st, n / 3, it, (int)gx, Prz, nb_te, Pte, s->d_scal, s->d_fin_idx, s->d_fin_w,
-                           d_fixed, s->d_dinv, s->dinv3_ready ? s->d_dinv3 : (const float*)nullptr, s->d_r, s->d_e, s->d_p, s->d_flag, gam);
+                           d_fixed, s->d_dinv, s->dinv3_ready ? s->d_dinv3 : (const float*)nullptr, s->d_r, s->d_e, s->d_p, s->d_flag, gam,
+                           (s->hermite_on && s->cs_ready && s->blk_ready) ? s->d_fin_w4 : (const float4*)nullptr, s->n_unode);
       } else if (lattice) {
         hipLaunchKernelGGL(k_scg_xr_plain, dim3(gv), dim3(SH_BLOCK), 0, st, n, (int)gs, Ppq, s->d_scal, s->d_p, s->d_q, x->d, s->d_r, s->d_flag);
         FEMO_TRY(shell_pc_apply(s, d_fixed, Prz, gz, s->d_flag));

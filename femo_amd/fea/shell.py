@@ -251,11 +251,232 @@ def lattice_pc(space: ShellSpace, finest: Optional[int] = None):
     Tc.sort_indices()
     i64, i32 = np.int64, np.int32
     return dict(width=width, n_lat=int(n_lat), n_nodes=int(n_nodes), levels=levels, level_offsets=np.asarray(offsets, dtype=i64),
-                level_nodes=level_nodes, n_unode=int(space.n_unode),
+                level_nodes=level_nodes, n_unode=int(space.n_unode), lo=lo, ext=ext,
                 ell_idx=np.ascontiguousarray(ell_idx), ell_w=ell_w,
                 pt_rowptr=Pt.indptr.astype(i64), pt_cols=Pt.indices.astype(i32), pt_vals=np.ascontiguousarray(Pt.data),
                 par_rowptr=Tp.indptr.astype(i64), par_cols=Tp.indices.astype(i32), par_vals=np.ascontiguousarray(Tp.data),
                 chi_rowptr=Tc.indptr.astype(i64), chi_cols=Tc.indices.astype(i32), chi_vals=np.ascontiguousarray(Tc.data))
+
+
+_CORNER_BITS = np.array([[(c >> k) & 1 for k in range(3)] for c in range(8)], dtype=np.int64)      # corner c of a cell: bit k = offset along axis k
+
+
+def _hermite_1d(fr, H):
+    """Per-axis shape values at fraction ``fr`` of a cell of size ``H``, for corner bit 0 / 1: the cubic Hermite value
+    shapes h0, the slope shapes h1 (derivative 1 at their node, value 0 at both; the offset they multiply is signed) and
+    the linear pair."""
+    h0 = np.stack([1.0 - 3.0 * fr ** 2 + 2.0 * fr ** 3, 3.0 * fr ** 2 - 2.0 * fr ** 3], axis=-1)
+    h1 = np.stack([fr * (1.0 - fr) ** 2 * H, -(1.0 - fr) * fr ** 2 * H], axis=-1)
+    lin = np.stack([1.0 - fr, fr], axis=-1)
+    return h0, h1, lin
+
+
+def _hermite_corner_weights(h0, h1):
+    """(alpha, sigma) of the eight corners from per-axis shapes h0, h1 of shape (n, 3, 2): alpha = prod_k h0_k,
+    sigma_j = h1_j prod_{k != j} h0_k -- the interpolated displacement is u = sum_n [alpha_n U_n + Theta_n x sigma_n]."""
+    n = h0.shape[0]
+    alpha = np.empty((n, 8))
+    sigma = np.empty((n, 8, 3))
+    for c in range(8):
+        b = _CORNER_BITS[c]
+        a = [h0[:, k, b[k]] for k in range(3)]
+        alpha[:, c] = a[0] * a[1] * a[2]
+        sigma[:, c, 0] = h1[:, 0, b[0]] * a[1] * a[2]
+        sigma[:, c, 1] = a[0] * h1[:, 1, b[1]] * a[2]
+        sigma[:, c, 2] = a[0] * a[1] * h1[:, 2, b[2]]
+    return alpha, sigma
+
+
+def hermite_lattice(space: ShellSpace, L: dict, first_level: int = 0):
+    """Hermite-type lattice spaces on the hierarchy of ``lattice_pc`` (round 4; DESIGN.md section 8 "the lead for round 4",
+    prototype scripts/probe_shell_hermite.py): the nodal ROTATIONS of a lattice act as the slopes of its displacement
+    interpolation,
+
+        u(x) = sum_n [ alpha_n(x) U_n + Theta_n x sigma_n(x) ],   theta(x) = sum_n w_n(x) Theta_n  (trilinear),
+
+    alpha = prod_k h0(t_k), sigma_j = h1(t_j) prod_{k != j} h0(t_k) with the cubic Hermite pair h0, h1 per axis, so that an
+    inextensional bending mode (w quadratic, theta = grad w) is reproduced by coarse lattices whose spacing is far above
+    the shell thickness -- where trilinear spaces lock.  Nested: only the finest lattice is interpolated from the mesh,
+    level l + 1 from level l by the same shapes evaluated at the finer lattice's nodes (U_c = a U_p + Theta_p x b,
+    Theta_c = c Theta_p).  The composition of such maps is again of the (alpha, sigma) form on the eight corners of the
+    point's cell of the coarser level, so every level's COMPOSED prolongation costs four numbers per (displacement point,
+    corner): what the Galerkin set-up kernels need (the level operators must be those of the transfers that are applied;
+    the direct interpolation of a coarse level is NOT its composed one, scripts/probe_shell_hermite.py).
+
+    Returns a dict: ``fin_w4`` (n_pts, 8, 4) float32 -- (alpha, sigma) of the displacement points on the finest lattice,
+    (w, 0, 0, 0) for the rotation points; ``lvl_w4`` {level: (n_pts, 8, 4) float32} composed weights of the levels
+    ``first_level`` .. finest - 1; ``par_w5`` / ``chi_w5`` (nnz, 5) -- (a, b, c) per entry of the node-level parent / child
+    CSR of ``lattice_pc``; plus what `DeviceShell` derives from them."""
+    import scipy.sparse as sp
+    levels, off = L["levels"], L["level_offsets"]
+    nl = len(levels)
+    pts = np.concatenate([space.unode_x, space.x])
+    n_pts, nu = pts.shape[0], space.n_unode
+    lo, ext = L["lo"], L["ext"]
+
+    def locate(m):
+        t = (pts - lo) / ext * m
+        i0 = np.clip(np.floor(t).astype(np.int64), 0, m - 1)
+        return i0, t - i0
+
+    # finest level: direct interpolation from the mesh
+    mF = levels[-1]
+    i0F, frF = locate(mF)
+    h0, h1, lin = _hermite_1d(frF[:nu], ext / mF)
+    alpha, sigma = _hermite_corner_weights(h0, h1)
+    w_theta = L["ell_w"][3 * nu::3, 8 * (nl - 1):8 * nl]                 # rotation points: the trilinear weights as they are
+    lvl = {nl - 1: (alpha, sigma)}
+    i0_child = i0F[:nu]
+    for l in range(nl - 2, first_level - 1, -1):
+        m, Hl = levels[l], ext / levels[l]
+        i0 = locate(m)[0][:nu]
+        a_ch, s_ch = lvl[l + 1]
+        alpha = np.zeros((nu, 8))
+        sigma = np.zeros((nu, 8, 3))
+        rows8 = np.arange(nu) * 8
+        for c in range(8):
+            cc = i0_child + _CORNER_BITS[c]                                   # lattice coordinates of the child node (level l + 1)
+            t = cc / 2.0
+            p0 = np.clip(np.floor(t).astype(np.int64), 0, m - 1)
+            h0, h1, lin = _hermite_1d(t - p0, Hl)                             # fractions are 0, 1/2 or (clipped top face) 1
+            for P in range(8):
+                b = _CORNER_BITS[P]
+                a1 = [h0[:, k, b[k]] for k in range(3)]
+                a = a1[0] * a1[1] * a1[2]
+                bv = np.stack([h1[:, 0, b[0]] * a1[1] * a1[2], a1[0] * h1[:, 1, b[1]] * a1[2], a1[0] * a1[1] * h1[:, 2, b[2]]], axis=1)
+                cw = lin[:, 0, b[0]] * lin[:, 1, b[1]] * lin[:, 2, b[2]]
+                sb = p0 + b - i0                                              # which corner of the POINT's cell of level l the parent is
+                ok = np.all((sb >= 0) & (sb <= 1), axis=1)                    # (outside: only with zero weights)
+                slot = np.clip(sb, 0, 1) @ np.array([1, 2, 4])
+                idx = rows8 + slot
+                wa = np.where(ok, a_ch[:, c] * a, 0.0)
+                alpha += np.bincount(idx, weights=wa, minlength=nu * 8).reshape(nu, 8)
+                for j in range(3):
+                    ws = np.where(ok, a_ch[:, c] * bv[:, j] + cw * s_ch[:, c, j], 0.0)
+                    sigma[:, :, j] += np.bincount(idx, weights=ws, minlength=nu * 8).reshape(nu, 8)
+        lvl[l] = (alpha, sigma)
+        i0_child = i0
+
+    def pack(l):
+        out = np.zeros((n_pts, 8, 4), dtype=np.float32)
+        a, sg = lvl[l]
+        out[:nu, :, 0] = a
+        out[:nu, :, 1:] = sg
+        out[nu:, :, 0] = L["ell_w"][3 * nu::3, 8 * l:8 * l + 8]
+        return out
+
+    fin_w4 = pack(nl - 1)
+    lvl_w4 = {l: pack(l) for l in range(first_level, nl - 1)}
+    # node-level transfers: (a, b, c) on the pattern of the trilinear parent CSR (same sparsity: h0(1/2) = 1/2, and the
+    # slope shapes vanish wherever the trilinear weight does)
+    nn = int(L["n_nodes"])
+    comp = [[], [], [], [], []]
+    pr, pc_ = [], []
+    for l in range(1, nl):
+        m, mc = levels[l], levels[l - 1]
+        g = L["level_nodes"][l]
+        ijk = np.stack([g % (m + 1), (g // (m + 1)) % (m + 1), g // ((m + 1) ** 2)], axis=1)
+        t = ijk / 2.0
+        p0 = np.clip(np.floor(t).astype(np.int64), 0, mc - 1)
+        h0, h1, lin = _hermite_1d(t - p0, ext / mc)
+        child = off[l] + np.arange(g.size)
+        for P in range(8):
+            b = _CORNER_BITS[P]
+            a1 = [h0[:, k, b[k]] for k in range(3)]
+            wl = lin[:, 0, b[0]] * lin[:, 1, b[1]] * lin[:, 2, b[2]]
+            keep = wl > 0.0                                                    # the trilinear pattern
+            par = p0 + b
+            gp = (par[:, 2] * (mc + 1) + par[:, 1]) * (mc + 1) + par[:, 0]
+            pos = np.searchsorted(L["level_nodes"][l - 1], gp[keep])
+            pr.append(child[keep]); pc_.append(off[l - 1] + pos)
+            comp[0].append((a1[0] * a1[1] * a1[2])[keep])
+            comp[1].append((h1[:, 0, b[0]] * a1[1] * a1[2])[keep])
+            comp[2].append((a1[0] * h1[:, 1, b[1]] * a1[2])[keep])
+            comp[3].append((a1[0] * a1[1] * h1[:, 2, b[2]])[keep])
+            comp[4].append(wl[keep])
+    rows = np.concatenate(pr) if pr else np.zeros(0, np.int64)
+    cols = np.concatenate(pc_) if pc_ else np.zeros(0, np.int64)
+    # one CSR per component on identical index arrays (a marker matrix fixes the order scipy gives the entries)
+    order = sp.csr_matrix((np.arange(1, rows.size + 1, dtype=np.float64), (rows, cols)), shape=(nn, nn))
+    order.sort_indices()
+    assert np.array_equal(order.indptr, L["par_rowptr"]) and np.array_equal(order.indices, L["par_cols"]), "Hermite transfers: pattern differs from the trilinear one"
+    perm = order.data.astype(np.int64) - 1
+    par_w5 = np.stack([np.concatenate(cp)[perm] for cp in comp], axis=1) if rows.size else np.zeros((0, 5))
+    order_t = order.T.tocsr()
+    order_t.sort_indices()
+    assert np.array_equal(order_t.indptr, L["chi_rowptr"]) and np.array_equal(order_t.indices, L["chi_cols"])
+    perm_t = order_t.data.astype(np.int64) - 1
+    chi_w5 = np.stack([np.concatenate(cp)[perm_t] for cp in comp], axis=1) if rows.size else np.zeros((0, 5))
+    return dict(fin_w4=fin_w4, lvl_w4=lvl_w4, par_w5=np.ascontiguousarray(par_w5), chi_w5=np.ascontiguousarray(chi_w5), w_theta=w_theta)
+
+
+def hermite_transfer_matrix(L: dict, H: dict, l: int):
+    """The node-level transfer T_l of ``hermite_lattice`` as a scalar sparse matrix over the 6 n unknowns (rows: unknowns of
+    level l + 1, columns: of level l; global node numbering of ``lattice_pc``): U_c = a U_p + Theta_p x b, Theta_c = c Theta_p."""
+    import scipy.sparse as sp
+    nn = int(L["n_nodes"])
+    rp, cols, w5 = L["par_rowptr"], L["par_cols"].astype(np.int64), H["par_w5"]
+    rows = np.repeat(np.arange(nn), np.diff(rp))
+    sel = (rows >= L["level_offsets"][l + 1]) & (rows < L["level_offsets"][l + 2])
+    r, c, w = rows[sel], cols[sel], w5[sel]
+    R, C, V = [], [], []
+    for i in range(3):
+        R.append(6 * r + i); C.append(6 * c + i); V.append(w[:, 0])
+        R.append(6 * r + 3 + i); C.append(6 * c + 3 + i); V.append(w[:, 4])
+    # (Theta x b)_0 = Th1 b2 - Th2 b1, (.)_1 = Th2 b0 - Th0 b2, (.)_2 = Th0 b1 - Th1 b0
+    for (i, k, j, sg) in ((0, 1, 2, 1.0), (0, 2, 1, -1.0), (1, 2, 0, 1.0), (1, 0, 2, -1.0), (2, 0, 1, 1.0), (2, 1, 0, -1.0)):
+        R.append(6 * r + i); C.append(6 * c + 3 + k); V.append(sg * w[:, 1 + j])
+    return sp.csr_matrix((np.concatenate(V), (np.concatenate(R), np.concatenate(C))), shape=(6 * nn, 6 * nn))
+
+
+def hermite_device_arrays(space: ShellSpace, L: dict, cs_level: int) -> dict:
+    """Everything `femo_shell_pc_hermite` takes, from ``hermite_lattice``: the finest level's P^T rows by lattice node, the
+    composed weights of the levels above the coarse solve and of the coarse-solve level, the composite restriction from the
+    finest lattice to the levels cs .. L - 2 in (A, B, C) form."""
+    import scipy.sparse as sp
+    H = hermite_lattice(space, L, first_level=cs_level)
+    levels, off = L["levels"], L["level_offsets"]
+    nl = len(levels)
+    nu = space.n_unode
+    n_pts = nu + space.n_vert
+    fin_w4 = H["fin_w4"]
+    # P_L^T: per finest node a row of displacement points and a row of rotation points
+    node = (L["ell_idx"][0::3, 8 * (nl - 1):8 * nl].astype(np.int64) // 6) - off[nl - 1]          # (n_pts, 8) level-local node
+    grp = (np.arange(n_pts) >= nu).astype(np.int64)
+    key = (2 * node + grp[:, None]).ravel()
+    pt = np.repeat(np.arange(n_pts), 8)
+    w4 = fin_w4.reshape(-1, 4)
+    keep = np.any(w4 != 0.0, axis=1)
+    key, pt, w4 = key[keep], pt[keep], w4[keep]
+    order = np.argsort(key, kind="stable")
+    n_fin = int(off[nl] - off[nl - 1])
+    hp_rowptr = np.zeros(2 * n_fin + 1, dtype=np.int64)
+    np.add.at(hp_rowptr, key + 1, 1)
+    hp_rowptr = np.cumsum(hp_rowptr)
+    hp_cols = (3 * pt[order]).astype(np.int32)
+    hp_w4 = np.ascontiguousarray(w4[order], dtype=np.float32)
+    lvl_w4 = np.ascontiguousarray(np.stack([H["lvl_w4"][l] for l in range(cs_level + 1, nl - 1)] + [fin_w4]), dtype=np.float32)
+    cs_w4 = np.ascontiguousarray(H["lvl_w4"][cs_level], dtype=np.float32)
+    # composite restriction: R_l = (T_l ... T_{F-1})^T as 6 x 6 block rows, levels cs .. F - 1 stacked in node order
+    F = nl - 1
+    down = None
+    if F > cs_level:
+        nn = int(L["n_nodes"])
+        comp, R = [], None
+        for l in range(F - 1, cs_level - 1, -1):
+            Tt = hermite_transfer_matrix(L, H, l).T.tocsr()                   # unknowns of level l + 1 -> level l (all node numbers global)
+            rows = Tt[6 * off[l]:6 * off[l + 1]]
+            R = rows if R is None else (rows[:, 6 * off[l + 1]:6 * off[l + 2]] @ R).tocsr()
+            comp.append(R)                                                     # rows: level l's unknowns, columns: global (finest level's)
+        stacked = sp.vstack(comp[::-1]).tocsr()
+        B = sp.bsr_matrix(stacked, blocksize=(6, 6))
+        B.sort_indices()
+        d = B.data
+        # block (parent rows, child columns): [UU] = A I, [TT] = C I, [TU] = [B]x = [[0, -B2, B1], [B2, 0, -B0], [-B1, B0, 0]]
+        w5 = np.stack([d[:, 0, 0], d[:, 5, 1], d[:, 3, 2], d[:, 4, 0], d[:, 3, 3]], axis=1)
+        down = dict(rowptr=B.indptr.astype(np.int64), cols=B.indices.astype(np.int32), w5=np.ascontiguousarray(w5))
+    return dict(fin_w4=np.ascontiguousarray(fin_w4), hp_rowptr=hp_rowptr, hp_cols=hp_cols, hp_w4=hp_w4,
+                par_w5=H["par_w5"], chi_w5=H["chi_w5"], lvl_w4=lvl_w4, cs_w4=cs_w4, down=down)
 
 
 def coarse_solve_plan(L: dict, max_unknowns: int = 3200, chunk: int = 256):
@@ -339,12 +560,15 @@ class DeviceShell:
             check(self.lib.femo_shell_set_partition(self.handle, p(P.owned_points), int(P.nbr.size), q(P.nbr), p(P.send_ptr),
                                                     q(P.send_dofs), p(P.recv_ptr), q(P.recv_dofs)))
 
-    def enable_lattice_pc(self, finest: Optional[int] = None, coarse_unknowns: Optional[int] = None) -> None:
+    def enable_lattice_pc(self, finest: Optional[int] = None, coarse_unknowns: Optional[int] = None, hermite: Optional[bool] = None) -> None:
         """Build and upload the lattice preconditioner once per mesh (used by ``solve(pc='lattice')``).
         ``coarse_unknowns``: size limit of the level that gets an exact (dense) coarse solve, 0 = none; default 3200
-        (``FEMO_SHELL_COARSE`` overrides)."""
+        (``FEMO_SHELL_COARSE`` overrides).  ``hermite`` (default on, one rank, needs the coarse solve; ``FEMO_SHELL_TRILINEAR``
+        switches it off): Hermite-type lattice spaces -- the rotations of a lattice as the slopes of its displacements."""
+        import os
+        if hermite is None:
+            hermite = "FEMO_SHELL_TRILINEAR" not in os.environ
         if coarse_unknowns is None:
-            import os
             coarse_unknowns = int(os.environ.get("FEMO_SHELL_COARSE", "3200"))
         if self.pc_levels is not None:
             return
@@ -365,6 +589,20 @@ class DeviceShell:
                                                     p(plan["item_ptr"]), p(plan["item_pts"]), p(plan["item_nbr"]),
                                                     q(plan["down_rowptr"]), q(plan["down_cols"]), q(plan["down_vals"])))
                 self.coarse_level = plan["level"]
+        self.hermite = False
+        if hermite and self.coarse_level is not None and self.partition is None:
+            A = hermite_device_arrays(self.space, L, self.coarse_level)
+            q = lambda a: None if a is None else C.c_void_p(a.ctypes.data)
+            dn = A["down"] or {}
+            check(self.lib.femo_shell_pc_hermite(self.handle, q(A["fin_w4"]), q(A["hp_rowptr"]), q(A["hp_cols"]), q(A["hp_w4"]), q(A["par_w5"]),
+                                                 q(A["chi_w5"]), q(A["lvl_w4"]), q(A["cs_w4"]), q(dn.get("rowptr")), q(dn.get("cols")), q(dn.get("w5"))))
+            self.hermite = True
+
+    def pc_apply(self, vals: Vec, r: Vec, z: Vec, fixed: Optional[np.ndarray] = None) -> Vec:
+        """z = M^-1 r of the lattice preconditioner for ``vals`` and the mask (`femo_shell_pc_apply`): for tests."""
+        mask = np.ascontiguousarray(fixed, dtype=np.uint8) if fixed is not None else None
+        check(self.lib.femo_shell_pc_apply(self.handle, vals.handle, C.c_void_p(mask.ctypes.data) if mask is not None else None, r.handle, z.handle))
+        return z
 
     def coarse_matrix(self, vals: Vec, fixed: Optional[np.ndarray] = None, inverse: bool = False) -> np.ndarray:
         """The dense Galerkin operator of the coarse-solve level (or its inverse) for ``vals``: for tests."""

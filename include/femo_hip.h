@@ -466,6 +466,20 @@ int femo_shell_pc_coarse(femo_shell* s, int level, const int32_t* node_xyz, int6
                          const double* down_vals);
 /* For tests: the dense coarse operator (inverse = 0) or the factors of its inverse (1: L^-T above, L^-1 below the
  * diagonal) for `vals` and the mask, row-major n x n into `out` (host; NULL: only *n_out).                           */
+/* Hermite-type lattice spaces on the hierarchy of femo_shell_pc_create / femo_shell_pc_coarse (round 4): the nodal rotations
+ * of a lattice act as the slopes of its displacement interpolation, u = sum_n [alpha_n U_n + Theta_n x sigma_n], so coarse
+ * lattices reproduce bending modes instead of locking on them (the solve that stands where the reference factorises with
+ * MUMPS, shell_pde.py:246-253, needs about half the iterations).  fin_w4: (alpha, sigma) per (point, corner) of the finest
+ * lattice ((w, 0, 0, 0) for rotation points); hp_*: P_L^T by finest node -- row 2 k lists the displacement points of node k
+ * (first dof, w4), row 2 k + 1 its rotation points; par_w5 / chi_w5: (a, b, c) per entry of the parent / child CSR;
+ * lvl_w4: composed weights of the levels above the coarse solve, [level][point][8][4]; cs_w4: of the coarse-solve level;
+ * down_*: composite restriction finest lattice -> levels cs .. L - 2 in (A, B, C) form (optional).  One rank only.        */
+int femo_shell_pc_hermite(femo_shell* s, const float* fin_w4, const int64_t* hp_rowptr, const int32_t* hp_cols, const float* hp_w4,
+                          const double* par_w5, const double* chi_w5, const float* lvl_w4, const float* cs_w4,
+                          const int64_t* down_rowptr, const int32_t* down_cols, const double* down_w5);
+/* z = M^-1 r of the lattice preconditioner for the stiffness `vals` and the mask (set up if needed): what the parity tests
+ * compare with the oracle's operator.  One rank.                                                                      */
+int femo_shell_pc_apply(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_host, const femo_vec* r, femo_vec* z);
 int femo_shell_pc_coarse_matrix(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_host, int inverse, double* out,
                                 int64_t* n_out);
 /* K x = b with x = xfix on the dofs flagged in fixed_host (n_dof bytes; NULL: none; xfix NULL: zero values).

@@ -528,3 +528,220 @@ def simply_supported_plate(n: int, h: float = 0.01, E: float = 1.0e7, nu: float 
     centre = int(np.argmin(np.abs(V.x[:, 0] - 0.5) + np.abs(V.x[:, 1] - 0.5)))
     D = E * h ** 3 / (12.0 * (1.0 - nu * nu))
     return float(V.vertex_displacement(w)[centre, 2]), 0.00406235 * q / D
+
+
+# ---- the lattice preconditioner of the shell's CG solves, restated in SciPy (round 4) -------------------------------------
+# The preconditioner is this repository's own design (the reference factorises with MUMPS, shell_pde.py:246-253 through
+# femo/fea/utils_dolfinx.py:476-512), so there is nothing in /root/reference to pin it against.  What the tests check: the
+# HIP kernels apply exactly the operator written down here (transfers, Galerkin node blocks, dense coarse operator), the
+# operator is symmetric positive definite, and the iteration counts below are pinned (tests/test_oracle_shell.py).
+#   M^-1 = B_pt^-1 + sum_{l > c} P_l B_l^-1 P_l^T + P_c (P_c^T K P_c)^-1 P_c^T
+# B_pt: 3 x 3 point blocks of K; B_l: 6 x 6 node blocks of P_l^T K P_l; P_l = P_L T_{L-1} ... T_l (nested lattices of
+# 2, 4, ..., m cells per axis over the bounding cube).  hermite = True: the nodal rotations of a lattice are the slopes of
+# its displacement interpolation (u = sum_n [alpha_n U_n + Theta_n x sigma_n], cubic Hermite shapes per axis), both from the
+# mesh to the finest lattice and between the lattices; hermite = False: trilinear everywhere (rounds 2-3).
+def lattice_levels(V: ShellSpace, finest: Optional[int] = None):
+    pts = np.concatenate([V.unode_x, V.x])
+    lo = pts.min(axis=0)
+    ext = float((pts.max(axis=0) - lo).max()) * (1.0 + 1e-9) + 1e-300
+    ev = V.edge_vertices
+    h_avg = float(np.linalg.norm(V.x[ev[:, 0]] - V.x[ev[:, 1]], axis=1).mean())
+    if finest is None:
+        lg = np.log2(max(ext / h_avg, 2.0))
+        finest = max(2, 2 ** int(np.floor(lg - 1.0 + 1e-9)), min(2 ** int(round(lg)), 32))
+    levels, m = [], 2
+    while m <= finest:
+        levels.append(m)
+        m *= 2
+    return levels, lo, ext
+
+
+def _lat_shapes(fr, H, hermite):
+    lin = [1.0 - fr, fr]
+    if not hermite:
+        return lin, lin, [0.0 * fr, 0.0 * fr]
+    return lin, [1.0 - 3 * fr ** 2 + 2 * fr ** 3, 3 * fr ** 2 - 2 * fr ** 3], [fr * (1.0 - fr) ** 2 * H, -(1.0 - fr) * fr ** 2 * H]
+
+
+_EPS3 = (((0, 1, 2), 1.0), ((1, 2, 0), 1.0), ((2, 0, 1), 1.0), ((0, 2, 1), -1.0), ((2, 1, 0), -1.0), ((1, 0, 2), -1.0))
+
+
+def lattice_node_sets(V: ShellSpace, levels, lo, ext):
+    out = []
+    for m in levels:
+        ids = []
+        for pts in (V.unode_x, V.x):
+            t = (pts - lo) / ext * m
+            i0 = np.clip(np.floor(t).astype(np.int64), 0, m - 1)
+            for c in range(8):
+                b = [(c >> k) & 1 for k in range(3)]
+                ids.append(((i0[:, 2] + b[2]) * (m + 1) + i0[:, 1] + b[1]) * (m + 1) + i0[:, 0] + b[0])
+        out.append(np.unique(np.concatenate(ids)))
+    return out
+
+
+def lattice_mesh_prolongation(V: ShellSpace, m: int, nodes: np.ndarray, lo, ext, hermite: bool) -> sp.csr_matrix:
+    """P: unknowns (6 per lattice node of the compacted set ``nodes``) -> dofs, from the coordinates."""
+    nu, nv, nd = V.n_unode, V.n_vert, V.n_dof
+    rows, cols, vals = [], [], []
+    H = ext / m
+
+    def corner(points):
+        t = (points - lo) / ext * m
+        i0 = np.clip(np.floor(t).astype(np.int64), 0, m - 1)
+        return i0, t - i0
+
+    i0u, fu = corner(V.unode_x)
+    i0t, ft = corner(V.x)
+    su = [_lat_shapes(fu[:, k], H, hermite) for k in range(3)]
+    st = [_lat_shapes(ft[:, k], H, False) for k in range(3)]
+    pu, pt = np.arange(nu), np.arange(nv)
+    for c in range(8):
+        b = [(c >> k) & 1 for k in range(3)]
+        gu = np.searchsorted(nodes, ((i0u[:, 2] + b[2]) * (m + 1) + i0u[:, 1] + b[1]) * (m + 1) + i0u[:, 0] + b[0])
+        gt = np.searchsorted(nodes, ((i0t[:, 2] + b[2]) * (m + 1) + i0t[:, 1] + b[1]) * (m + 1) + i0t[:, 0] + b[0])
+        w0 = su[0][1][b[0]] * su[1][1][b[1]] * su[2][1][b[2]]
+        wt = st[0][0][b[0]] * st[1][0][b[1]] * st[2][0][b[2]]
+        for i in range(3):
+            rows.append(3 * pu + i); cols.append(6 * gu + i); vals.append(w0)
+            rows.append(3 * nu + 3 * pt + i); cols.append(6 * gt + 3 + i); vals.append(wt)
+        if hermite:
+            for j in range(3):
+                w1 = su[j][2][b[j]]
+                for k in range(3):
+                    if k != j:
+                        w1 = w1 * su[k][1][b[k]]
+                for (i, kk, jj), sgn in _EPS3:                                  # u_i += (Theta x e_j)_i w1 = eps_{i kk j} Theta_kk w1
+                    if jj == j:
+                        rows.append(3 * pu + i); cols.append(6 * gu + 3 + kk); vals.append(sgn * w1)
+    P = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nd, 6 * nodes.size))
+    P.sum_duplicates()
+    return P
+
+
+def lattice_transfer(levels, sets, l: int, ext, hermite: bool) -> sp.csr_matrix:
+    """T_l: unknowns of level l -> unknowns of level l + 1 (the coarse fields evaluated at the finer lattice's nodes)."""
+    mc, mf = levels[l], levels[l + 1]
+    g = sets[l + 1]
+    ijk = np.stack([g % (mf + 1), (g // (mf + 1)) % (mf + 1), g // ((mf + 1) ** 2)], axis=1)
+    t = ijk / 2.0
+    i0 = np.clip(np.floor(t).astype(np.int64), 0, mc - 1)
+    fr = t - i0
+    sh = [_lat_shapes(fr[:, k], ext / mc, hermite) for k in range(3)]
+    rows, cols, vals = [], [], []
+    child = np.arange(g.size)
+    for c in range(8):
+        b = [(c >> k) & 1 for k in range(3)]
+        gid = ((i0[:, 2] + b[2]) * (mc + 1) + i0[:, 1] + b[1]) * (mc + 1) + i0[:, 0] + b[0]
+        w0 = sh[0][1][b[0]] * sh[1][1][b[1]] * sh[2][1][b[2]]
+        wl = sh[0][0][b[0]] * sh[1][0][b[1]] * sh[2][0][b[2]]
+        keep = wl > 0.0
+        pos = np.searchsorted(sets[l], gid[keep])
+        assert np.array_equal(sets[l][pos], gid[keep]), "lattice levels are not nested"
+        kk = np.nonzero(keep)[0]
+        for i in range(3):
+            rows.append(6 * child[kk] + i); cols.append(6 * pos + i); vals.append(w0[kk])
+            rows.append(6 * child[kk] + 3 + i); cols.append(6 * pos + 3 + i); vals.append(wl[kk])
+        if hermite:
+            for j in range(3):
+                w1 = sh[j][2][b[j]]
+                for k in range(3):
+                    if k != j:
+                        w1 = w1 * sh[k][1][b[k]]
+                for (i, k2, jj), sgn in _EPS3:
+                    if jj == j:
+                        rows.append(6 * child[kk] + i); cols.append(6 * pos + 3 + k2); vals.append(sgn * w1[kk])
+    T = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(6 * g.size, 6 * sets[l].size))
+    T.sum_duplicates()
+    return T
+
+
+def _block_diag_pinv(A: sp.csr_matrix, bs: int) -> sp.csr_matrix:
+    nb = A.shape[0] // bs
+    blocks = np.zeros((nb, bs, bs))
+    coo = A.tocoo()
+    sel = (coo.row // bs) == (coo.col // bs)
+    np.add.at(blocks, (coo.row[sel] // bs, coo.row[sel] % bs, coo.col[sel] % bs), coo.data[sel])
+    return blocks
+
+
+class LatticePreconditioner:
+    """z = M^-1 r as written above for the free-dof operator ``Kf`` (identity rows on the fixed dofs).  ``coarse_max``:
+    unknowns of the exact-solve level (the finest level below the top with at most that many)."""
+
+    def __init__(self, V: ShellSpace, K: sp.csr_matrix, fixed: Sequence[int], hermite: bool = True, finest: Optional[int] = None,
+                 coarse_max: int = 3200, ridge: float = 1e-12):
+        import scipy.sparse.linalg as spla
+        nd = V.n_dof
+        mask = np.ones(nd)
+        mask[np.asarray(fixed, dtype=np.int64)] = 0.0
+        Dm = sp.diags(mask)
+        self.mask = mask
+        self.Kf = (Dm @ K @ Dm + sp.diags(1.0 - mask)).tocsr()
+        self.levels, lo, ext = lattice_levels(V, finest)
+        self.sets = lattice_node_sets(V, self.levels, lo, ext)
+        nl = len(self.levels)
+        self.T = [lattice_transfer(self.levels, self.sets, l, ext, hermite) for l in range(nl - 1)]
+        P = [None] * nl
+        P[-1] = (Dm @ lattice_mesh_prolongation(V, self.levels[-1], self.sets[-1], lo, ext, hermite)).tocsr()
+        for l in range(nl - 2, -1, -1):
+            P[l] = (P[l + 1] @ self.T[l]).tocsr()
+        self.P = P
+        c = -1
+        for l in range(nl - 1):
+            if 6 * self.sets[l].size <= coarse_max:
+                c = l
+        self.c = c
+        # point blocks (3 x 3) of the free-dof operator
+        pb = _block_diag_pinv(self.Kf, 3)
+        self.Bpt = np.linalg.inv(pb)
+        # node blocks of the levels above c: symmetric 6 x 6, rows / columns no free dof reaches dropped
+        self.Bl = {}
+        for l in range(max(c, -1) + 1, nl):
+            A = (P[l].T @ self.Kf @ P[l]).tocsr()
+            blk = _block_diag_pinv(A, 6)
+            inv = np.zeros_like(blk)
+            for i in range(blk.shape[0]):
+                d = np.diag(blk[i]) > 0.0
+                if d.any():
+                    sub = blk[i][np.ix_(d, d)] * (1.0 + 0.0) + np.diag(np.diag(blk[i])[d]) * ridge
+                    inv[i][np.ix_(d, d)] = np.linalg.inv(sub)
+            self.Bl[l] = inv
+        self.Ac = None
+        if c >= 0:
+            Ac = (P[c].T @ self.Kf @ P[c]).toarray()
+            d = np.diag(Ac).copy()
+            Ac[np.diag_indices_from(Ac)] = np.where(d > 0.0, d * (1.0 + 1e-13), 1.0)
+            self.Ac = Ac
+            self.Ac_inv = np.linalg.inv(Ac)
+
+    def apply(self, r: np.ndarray) -> np.ndarray:
+        r = r * self.mask
+        z = np.einsum("pij,pj->pi", self.Bpt, r.reshape(-1, 3)).ravel() * self.mask
+        if self.c >= 0:
+            z += self.P[self.c] @ (self.Ac_inv @ (self.P[self.c].T @ r))
+        for l, B in self.Bl.items():
+            g = (self.P[l].T @ r).reshape(-1, 6)
+            z += self.P[l] @ np.einsum("nij,nj->ni", B, g).ravel()
+        return z
+
+    def pcg(self, b: np.ndarray, rtol: float = 1e-10, max_it: int = 5000):
+        """PCG on the free-dof operator with the engine's stopping rule sqrt(r.z) <= rtol sqrt(r0.z0); returns (x, iterations)."""
+        b = b * self.mask
+        x = np.zeros_like(b)
+        r = b.copy()
+        z = self.apply(r)
+        p = z.copy()
+        g0 = g = float(r @ z)
+        for it in range(1, max_it + 1):
+            q = self.Kf @ p
+            a = g / float(p @ q)
+            x += a * p
+            r -= a * q
+            z = self.apply(r)
+            g1 = float(r @ z)
+            if not g1 > 0.0 or g1 <= rtol * rtol * g0:
+                return x, it
+            p = z + (g1 / g) * p
+            g = g1
+        return x, max_it

@@ -286,6 +286,48 @@ for hm, hl, name in ((False, False, "nested, trilinear everywhere (= what runs)"
     print(f"{name}: {its} iterations, error {err:.1e} ({time.time()-t0:.1f}s)", flush=True)
 
 
+
+# ---- nested Hermite transfers for the APPLICATION, level operators from the DIRECT Hermite interpolation of each level
+# (8 nodes per point and level: what the existing Galerkin set-up kernels can form with W = [alpha I, -[sigma]x]) ----------
+def build_nested_direct_ops(exact_consistent):
+    sets = node_sets()
+    PN = [None] * len(levels)
+    PN[-1] = prolongation(levels[-1], True)
+    for l in range(len(levels) - 2, -1, -1):
+        PN[l] = (PN[l + 1] @ lattice_transfer(l, sets, True)).tocsr()
+    PD = [prolongation(m, True) for m in levels]
+    A = []
+    for Pl in PD:
+        Al = (Pl.T @ Kf @ Pl).tocsr()
+        d = Al.diagonal()
+        A.append((Al + sp.diags(np.where(d > 0.0, RIDGE * d, 1.0))).tocsr())
+    c = 0
+    for l in range(len(levels) - 1):
+        if A[l].shape[0] <= cmax:
+            c = l
+    if exact_consistent:       # coarse operator from the composed prolongation (what a consistent coarse solve needs)
+        Ac = (PN[c].T @ Kf @ PN[c]).tocsr(); d = Ac.diagonal()
+        lu = spla.splu((Ac + sp.diags(np.where(d > 0.0, RIDGE * d, 1.0))).tocsc())
+    else:
+        lu = spla.splu(A[c].tocsc())
+    Binv = [block_diag_inv(A[l], 6) if l > c else None for l in range(len(levels))]
+
+    def apply(r):
+        z = Spt @ r + PN[c] @ lu.solve(PN[c].T @ r)
+        for l in range(c + 1, len(levels)):
+            z += PN[l] @ (Binv[l] @ (PN[l].T @ r))
+        return z
+    return apply
+
+
+for ec in (False, True):
+    t0 = time.time()
+    its, err = pcg(build_nested_direct_ops(ec))
+    print(f"nested Hermite transfers, level operators from the DIRECT Hermite interpolation (coarse operator {'composed' if ec else 'direct'}): {its} iterations, error {err:.1e} ({time.time()-t0:.1f}s)", flush=True)
+
+
+# ---- non-nested application with direct Hermite P_l on the levels above the coarse solve, nested below? (reference) -------
+
 # ---- what if only the TRANSFERS are Hermite and the level operators stay the trilinear Galerkin ones (no new Galerkin
 # kernels on the GPU)?  M^-1 = S + sum_l P_l^H B_l^tri P_l^H^T is still symmetric positive definite -------------------------
 def build_mixed():

@@ -1,0 +1,75 @@
+"""Hermite-type lattice spaces in the shell's preconditioner (round 4): csrc/shell.hip (k_pc_restrict_h, k_lat_level_h,
+k_lat_down_composite_h, the Hermite branch of the prolongations, k_pc_galerkin_blocks_h, k_pc_coarse_galerkin_h) through
+femo_amd/fea/shell.py against oracle/shell_oracle.py::LatticePreconditioner -- the dense coarse operator entry by entry,
+M^-1 r, the iteration counts, and the solution against the direct solve."""
+import numpy as np
+import pytest
+
+from oracle import shell_oracle as so
+from tests.test_gpu_shell import E_ROOF, FZ, H_ROOF, NU_ROOF, rel, roof_fixed
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(ctx, n, hermite=True, coarse=None):
+    from femo_amd.fea.shell import ShellProblem
+    pts, conn = so.scordelis_lo_mesh(n, n)
+    V0 = so.ShellSpace(pts, conn)
+    fixed = roof_fixed(V0)
+    prob = ShellProblem(pts, conn, E_ROOF, NU_ROOF, fixed_dofs=fixed, ctx=ctx, pc="lattice")
+    prob.dev.enable_lattice_pc(hermite=hermite, coarse_unknowns=coarse)
+    prob.set_thickness(H_ROOF)
+    prob.set_load([0.0, 0.0, FZ])
+    return prob, V0, fixed
+
+
+@pytest.mark.parametrize("n,coarse", [(16, None), (16, 300), (24, None)])
+def test_hermite_operator_matches_the_oracle(ctx, n, coarse):
+    """The dense Galerkin operator of the coarse-solve level (composed Hermite prolongation) and M^-1 r as a whole: the
+    kernels apply the operator the oracle writes down.  coarse = 300 puts two levels of node blocks and the composite
+    restriction between the finest lattice and the coarse solve."""
+    from femo_amd.engine import Vec
+    prob, V0, fixed = _problem(ctx, n, coarse=coarse)
+    assert prob.dev.hermite
+    K = so.assemble(V0, so.element_stiffness(V0, np.full(V0.n_vert, H_ROOF), E_ROOF, NU_ROOF)).tocsr()
+    M = so.LatticePreconditioner(V0, K, fixed, hermite=True, coarse_max=coarse or 3200)
+    assert M.c == prob.dev.coarse_level and M.levels == prob.dev.pc_levels
+    mask = np.zeros(V0.n_dof, dtype=np.uint8)
+    mask[fixed] = 1
+    vals = prob._stiffness()
+    A = prob.dev.coarse_matrix(vals, mask)
+    A_ref = (M.P[M.c].T @ M.Kf @ M.P[M.c]).toarray()
+    # (the oracle's P has zero rows on the fixed dofs, so the identity rows of Kf do not enter)
+    assert A.shape == A_ref.shape
+    assert np.abs(A - A_ref).max() <= 2e-6 * np.abs(A_ref).max()          # transfer weights are single precision on the device
+    assert np.abs(A - A.T).max() <= 1e-12 * np.abs(A).max()
+    rng = np.random.default_rng(3)
+    r = rng.standard_normal(V0.n_dof)
+    z = prob.dev.pc_apply(vals, Vec(ctx, V0.n_dof).set(r), Vec(ctx, V0.n_dof), mask).get()
+    z_ref = M.apply(r)
+    assert np.abs(z - z_ref).max() <= 2e-5 * np.abs(z_ref).max()
+    # symmetric positive definite: <r1, M^-1 r2> = <M^-1 r1, r2>, <r, M^-1 r> > 0
+    r2 = rng.standard_normal(V0.n_dof)
+    z2 = prob.dev.pc_apply(vals, Vec(ctx, V0.n_dof).set(r2), Vec(ctx, V0.n_dof), mask).get()
+    free = mask == 0
+    assert abs(r[free] @ z2[free] - z[free] @ r2[free]) <= 1e-6 * abs(r[free] @ z2[free])
+    assert r[free] @ z[free] > 0.0
+
+
+def test_hermite_iteration_counts(ctx):
+    """The counts of the oracle's PCG with the same operator are reproduced (16 x 16: 156, 32 x 32: 89 -- pinned in
+    tests/test_oracle_shell.py), they are well below the trilinear hierarchy's (269 / 168), and the solution is the direct one."""
+    res = {}
+    for n in (16, 32):
+        for herm in (False, True):
+            prob, V0, fixed = _problem(ctx, n, hermite=herm)
+            w = prob.solve(rtol=1e-10)
+            res[(n, herm)] = (prob.last_info.iterations, prob.last_info.converged, w)
+        K = so.assemble(V0, so.element_stiffness(V0, np.full(V0.n_vert, H_ROOF), E_ROOF, NU_ROOF)).tocsr()
+        F = so.load_vector(V0, np.tile([0.0, 0.0, FZ], (V0.n_vert, 1)))
+        w_ref = so.solve(K, F, fixed)
+        for herm in (False, True):
+            assert res[(n, herm)][1] == 1
+            assert rel(res[(n, herm)][2], w_ref) <= 1e-7
+    assert abs(res[(16, True)][0] - 156) <= 6 and abs(res[(32, True)][0] - 89) <= 4
+    assert res[(16, True)][0] < 0.7 * res[(16, False)][0] and res[(32, True)][0] < 0.6 * res[(32, False)][0]
