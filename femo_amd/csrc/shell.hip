@@ -1591,11 +1591,11 @@ constexpr int DP = DT + 1;                               // LDS row pitch
 
 // unknowns no free dof touches have an empty row and column, and so have the padding rows: unit diagonal (their
 // restricted residual is zero); a relative 1e-13 on the others keeps the factorisation away from round-off rank deficiency
-__global__ void k_pc_coarse_fix_diag(int64_t N, double* __restrict__ A) {
+__global__ void k_pc_coarse_fix_diag(int64_t N, double* __restrict__ A, double ridge) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= N) return;
   const double d = A[r * N + r];
-  A[r * N + r] = d > 0.0 ? d * (1.0 + 1e-13) : 1.0;
+  A[r * N + r] = d > 0.0 ? d * (1.0 + ridge) : 1.0;
 }
 
 __device__ __forceinline__ void tile_load(double (*s)[DP], const double* __restrict__ g, int64_t ld, bool transpose) {
@@ -2828,7 +2828,11 @@ static int shell_pc_coarse_setup(femo_shell* s, const femo_vec* vals, const uint
   }
   FEMO_HIP_CHECK(hipGetLastError());
   FEMO_TRY(shell_allreduce(s, s->d_cs_A, N * N, st));      // partitioned: every rank formed P^T (its rows of K) P
-  hipLaunchKernelGGL(k_pc_coarse_fix_diag, dim3(sgrid(N, 256)), dim3(256), 0, st, N, s->d_cs_A);
+  // Hermite-type spaces: the six unknowns of a node the surface barely touches are nearly dependent (a rotation about the
+  // line through the few points that see the node moves nothing), the operator is semi-definite there up to rounding and
+  // the order of the atomic sums decided whether a pivot came out positive -- a relative 1e-9 on the diagonal settles it
+  // (the prototype used 1e-8; the iteration counts do not move)
+  hipLaunchKernelGGL(k_pc_coarse_fix_diag, dim3(sgrid(N, 256)), dim3(256), 0, st, N, s->d_cs_A, s->hermite_on ? 1e-9 : 1e-13);
   FEMO_HIP_CHECK(hipGetLastError());
   auto t1 = now();
   for (int kb = 0; kb < nblk; ++kb) {
@@ -2861,6 +2865,7 @@ static int shell_pc_coarse_setup(femo_shell* s, const femo_vec* vals, const uint
     s->cs_ready = all == 0.0;
   }
   if (s->hermite_on && !s->cs_ready) {
+    if (dbg) fprintf(stderr, "[femo] coarse solve: the Hermite-type operator could not be factorised (far %d, pivot %d): trilinear hierarchy\n", info[1], info[2]);
     // the Hermite-type transfers need their own (composed) coarse operator: without it the trilinear hierarchy takes over,
     // whose dense operator is formed now (the preconditioner changes, the solution does not)
     s->hermite = false;

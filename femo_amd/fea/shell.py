@@ -328,32 +328,41 @@ def hermite_lattice(space: ShellSpace, L: dict, first_level: int = 0):
     lvl = {nl - 1: (alpha, sigma)}
     i0_child = i0F[:nu]
     for l in range(nl - 2, first_level - 1, -1):
+        # The transfer from level l to the corners of the point's cell of level l + 1 is a tensor product over the axes:
+        # along axis k the fine cell is the lower or the upper half of the coarse one (half_k), its two nodes sit at
+        # fractions (0, 1/2) or (1/2, 1) of the coarse cell, and a node's 1-D weights on the two coarse corners are the
+        # shapes h0 / h1 / linear there.  alpha' = sum_child alpha prod_k A_k;  sigma'_j = sum_child [alpha B_j prod_{k != j} A_k
+        # + sigma_j prod_k C_k]: separable contractions (einsum), 2 x 2 per axis.
         m, Hl = levels[l], ext / levels[l]
         i0 = locate(m)[0][:nu]
+        half = i0_child - 2 * i0                                               # (nu, 3) in {0, 1}
+        fr = np.stack([0.5 * half, 0.5 * half + 0.5], axis=-1)                 # (nu, 3, child bit): fraction inside the coarse cell
+        h0, h1, lin = _hermite_1d(fr, Hl)                                      # (nu, 3, child bit, coarse corner bit)
         a_ch, s_ch = lvl[l + 1]
-        alpha = np.zeros((nu, 8))
-        sigma = np.zeros((nu, 8, 3))
-        rows8 = np.arange(nu) * 8
-        for c in range(8):
-            cc = i0_child + _CORNER_BITS[c]                                   # lattice coordinates of the child node (level l + 1)
-            t = cc / 2.0
-            p0 = np.clip(np.floor(t).astype(np.int64), 0, m - 1)
-            h0, h1, lin = _hermite_1d(t - p0, Hl)                             # fractions are 0, 1/2 or (clipped top face) 1
-            for P in range(8):
-                b = _CORNER_BITS[P]
-                a1 = [h0[:, k, b[k]] for k in range(3)]
-                a = a1[0] * a1[1] * a1[2]
-                bv = np.stack([h1[:, 0, b[0]] * a1[1] * a1[2], a1[0] * h1[:, 1, b[1]] * a1[2], a1[0] * a1[1] * h1[:, 2, b[2]]], axis=1)
-                cw = lin[:, 0, b[0]] * lin[:, 1, b[1]] * lin[:, 2, b[2]]
-                sb = p0 + b - i0                                              # which corner of the POINT's cell of level l the parent is
-                ok = np.all((sb >= 0) & (sb <= 1), axis=1)                    # (outside: only with zero weights)
-                slot = np.clip(sb, 0, 1) @ np.array([1, 2, 4])
-                idx = rows8 + slot
-                wa = np.where(ok, a_ch[:, c] * a, 0.0)
-                alpha += np.bincount(idx, weights=wa, minlength=nu * 8).reshape(nu, 8)
-                for j in range(3):
-                    ws = np.where(ok, a_ch[:, c] * bv[:, j] + cw * s_ch[:, c, j], 0.0)
-                    sigma[:, :, j] += np.bincount(idx, weights=ws, minlength=nu * 8).reshape(nu, 8)
+        A3 = a_ch.reshape(nu, 2, 2, 2)                                         # [bit of axis 2][axis 1][axis 0]
+        S3 = s_ch.reshape(nu, 2, 2, 2, 3)
+
+        def axis(T, M, ax):
+            """Contract the child-bit axis ``ax`` (1, 2 or 3 of T[n, c2, c1, c0]: axis 3 is coordinate 0) with M[n, child bit, slot bit]."""
+            idx0 = [slice(None)] * 4; idx1 = [slice(None)] * 4
+            idx0[ax] = 0; idx1[ax] = 1
+            t0, t1 = T[tuple(idx0)], T[tuple(idx1)]
+            sh = (nu, 1, 1)
+            return np.stack([t0 * M[:, 0, 0].reshape(sh) + t1 * M[:, 1, 0].reshape(sh),
+                             t0 * M[:, 0, 1].reshape(sh) + t1 * M[:, 1, 1].reshape(sh)], axis=ax)
+
+        Ak = [np.ascontiguousarray(h0[:, k]) for k in range(3)]
+        Bk = [np.ascontiguousarray(h1[:, k]) for k in range(3)]
+        Ck = [np.ascontiguousarray(lin[:, k]) for k in range(3)]
+        # coordinate 0 first (array axis 3), shared partial products: A0, B0 -> A0A1, A0B1, B0A1 -> alpha and the three alpha-parts of sigma
+        TA0, TB0 = axis(A3, Ak[0], 3), axis(A3, Bk[0], 3)
+        TA0A1, TA0B1, TB0A1 = axis(TA0, Ak[1], 2), axis(TA0, Bk[1], 2), axis(TB0, Ak[1], 2)
+        alpha = axis(TA0A1, Ak[2], 1).reshape(nu, 8)
+        part = [axis(TB0A1, Ak[2], 1), axis(TA0B1, Ak[2], 1), axis(TA0A1, Bk[2], 1)]
+        sigma = np.empty((nu, 8, 3))
+        for j in range(3):
+            Sj = np.ascontiguousarray(S3[..., j])
+            sigma[:, :, j] = (part[j] + axis(axis(axis(Sj, Ck[0], 3), Ck[1], 2), Ck[2], 1)).reshape(nu, 8)
         lvl[l] = (alpha, sigma)
         i0_child = i0
 

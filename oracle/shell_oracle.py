@@ -670,7 +670,7 @@ class LatticePreconditioner:
     unknowns of the exact-solve level (the finest level below the top with at most that many)."""
 
     def __init__(self, V: ShellSpace, K: sp.csr_matrix, fixed: Sequence[int], hermite: bool = True, finest: Optional[int] = None,
-                 coarse_max: int = 3200, ridge: float = 1e-12):
+                 coarse_max: int = 3200, ridge: float = 1e-12, hermite_mesh: Optional[bool] = None):
         import scipy.sparse.linalg as spla
         nd = V.n_dof
         mask = np.ones(nd)
@@ -683,7 +683,8 @@ class LatticePreconditioner:
         nl = len(self.levels)
         self.T = [lattice_transfer(self.levels, self.sets, l, ext, hermite) for l in range(nl - 1)]
         P = [None] * nl
-        P[-1] = (Dm @ lattice_mesh_prolongation(V, self.levels[-1], self.sets[-1], lo, ext, hermite)).tocsr()
+        # hermite_mesh: the mesh <-> finest-lattice transfer on its own (experiments; default: like the lattice transfers)
+        P[-1] = (Dm @ lattice_mesh_prolongation(V, self.levels[-1], self.sets[-1], lo, ext, hermite if hermite_mesh is None else hermite_mesh)).tocsr()
         for l in range(nl - 2, -1, -1):
             P[l] = (P[l + 1] @ self.T[l]).tocsr()
         self.P = P
@@ -711,7 +712,9 @@ class LatticePreconditioner:
         if c >= 0:
             Ac = (P[c].T @ self.Kf @ P[c]).toarray()
             d = np.diag(Ac).copy()
-            Ac[np.diag_indices_from(Ac)] = np.where(d > 0.0, d * (1.0 + 1e-13), 1.0)
+            # relative ridge as on the device (k_pc_coarse_fix_diag): the Hermite-type operator is semi-definite up to rounding
+            # where the surface barely touches a node (its six unknowns are nearly dependent)
+            Ac[np.diag_indices_from(Ac)] = np.where(d > 0.0, d * (1.0 + (1e-9 if hermite else 1e-13)), 1.0)
             self.Ac = Ac
             self.Ac_inv = np.linalg.inv(Ac)
 

@@ -333,7 +333,7 @@ def test_coarse_solve(ctx):
     res = {}
     for coarse in (0, 3200):
         prob = ShellProblem(pts, conn, E_ROOF, NU_ROOF, fixed_dofs=fixed, ctx=ctx, pc="lattice")
-        prob.dev.enable_lattice_pc(coarse_unknowns=coarse)
+        prob.dev.enable_lattice_pc(coarse_unknowns=coarse, hermite=False)      # the trilinear hierarchy (its Hermite-type successor: test_gpu_shell_hermite.py)
         prob.set_thickness(H_ROOF)
         prob.set_load([0.0, 0.0, FZ])
         w = prob.solve(rtol=1e-10)
