@@ -134,6 +134,7 @@ PROTOTYPES = {
     "femo_shell_inertia_dh": (C.c_int, [H, C.c_double, H, H, H, C.c_int, H]),
     "femo_shell_solve": (C.c_int, [H, H, C.c_void_p, H, H, H, C.POINTER(SolverOpts), C.POINTER(SolveInfo)]),
     "femo_shell_set_partition": (C.c_int, [H, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "femo_shell_set_owned_cells": (C.c_int, [H, C.c_void_p]),
     "femo_shell_halo": (C.c_int, [H, H]),
     "femo_shell_mask_unowned": (C.c_int, [H, H]),
     "femo_mesh_set_global": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int64]),

@@ -105,7 +105,7 @@ class StateOperation(CustomImplicitOperation):
         # entry points: they keep the synchronous upload.
         recording = any(self.args_dict[name]['record'] for name in inputs)
         defer = (fea.async_results and not isinstance(res, BackendForm) and not recording
-                 and fea.custom_solve is None)
+                 and fea.custom_solve is None and getattr(fea, "deferred_uploads", True))
         update(self.state['function'], outputs[self.state_name])
         with deferred_uploads(defer):
             push_functions(self.args_dict, inputs)

@@ -371,6 +371,7 @@ int femo_host_free(void* p) {
   if (!p) return 0;
   size_t bytes = 0;
   bool keep = false;
+  std::vector<void*> evict;
   {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_blocks.find(reinterpret_cast<uintptr_t>(p));
@@ -381,12 +382,26 @@ int femo_host_free(void* p) {
       g_ev_free.push_back(it->second.ready);
     }
     g_blocks.erase(it);
+    // Over the cap: make room by dropping recycled blocks of OTHER sizes, largest first -- the size being freed now is the
+    // one the running workload allocates again.  (Round 3 dropped the freed block itself: after a 10 M-DOF run had filled
+    // the pool with 477 MB blocks, every result block of a smaller problem was hipHostMalloc'ed and hipHostFree'd again,
+    // 50 ms per cycle of the 5 M-DOF configuration in bench.py.)
+    while (g_free_bytes + bytes > FREE_CAP && !g_free.empty()) {
+      auto victim = g_free.end();
+      for (auto jt = g_free.rbegin(); jt != g_free.rend(); ++jt)
+        if (jt->first != bytes) { victim = std::next(jt).base(); break; }
+      if (victim == g_free.end()) break;
+      evict.push_back(victim->second);
+      g_free_bytes -= victim->first;
+      g_free.erase(victim);
+    }
     if (g_free_bytes + bytes <= FREE_CAP) {
       g_free.emplace(bytes, p);
       g_free_bytes += bytes;
       keep = true;
     }
   }
+  for (void* q : evict) (void)hipHostFree(q);
   if (!keep) FEMO_HIP_CHECK(hipHostFree(p));
   return 0;
 }

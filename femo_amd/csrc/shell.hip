@@ -108,6 +108,7 @@ struct femo_shell {
   // that K, right-hand sides and residuals are the rank's share and sums over the ranks are the global objects.  The
   // halo plan refreshes the entries of the points owned elsewhere.
   uint8_t* d_owned = nullptr;
+  uint8_t* d_cell_owned = nullptr;                       // femo_shell_set_owned_cells: the cells whose scalar outputs this rank integrates
   int n_nbr = 0;
   std::vector<int32_t> nbr;
   std::vector<int64_t> send_ptr, recv_ptr;
@@ -120,7 +121,14 @@ struct femo_shell_view {
   int64_t n_vert, n_cell, n_unode;
   const double* x;
   const int32_t *conn, *cedge;
+  // partitioned shells (femo_shell_set_owned_cells): 1 for the cells this rank integrates in scalar outputs (each cell of the
+  // whole mesh belongs to exactly one rank; the values are summed over the ranks), nullptr on one rank.  Gradients are
+  // formed over ALL local cells: every cell around a point the rank owns is local, so their entries there are complete.
+  const uint8_t* cell_owned;
 };
+__device__ __forceinline__ double shell_value_weight(const femo_shell_view& S, int64_t c) {
+  return (S.cell_owned == nullptr || c >= S.n_cell || S.cell_owned[c]) ? 1.0 : 0.0;
+}
 
 namespace {
 
@@ -351,7 +359,7 @@ __global__ __launch_bounds__(SH_BLOCK) void k_shell_dform_dh(femo_shell_view S, 
     }
   }
   if (energy != nullptr) {
-    const double t = femo_block_sum<SH_BLOCK>(0.5 * en, lds);
+    const double t = femo_block_sum<SH_BLOCK>(0.5 * en * shell_value_weight(S, c), lds);
     if (threadIdx.x == 0) energy[blockIdx.x] = t;
   }
 }
@@ -509,7 +517,7 @@ __global__ __launch_bounds__(SH_BLOCK) void k_shell_pnorm_stress(femo_shell_view
     }
   }
   if (partials != nullptr) {
-    const double t = femo_block_sum<SH_BLOCK>(val, lds);
+    const double t = femo_block_sum<SH_BLOCK>(val * shell_value_weight(S, c), lds);
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
   }
 }
@@ -575,7 +583,7 @@ __global__ __launch_bounds__(SH_BLOCK) void k_shell_mass(femo_shell_view S, doub
     }
   }
   if (partials != nullptr) {
-    const double t = femo_block_sum<SH_BLOCK>(M, lds);
+    const double t = femo_block_sum<SH_BLOCK>(M * shell_value_weight(S, c), lds);
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
   }
 }
@@ -729,7 +737,7 @@ __global__ __launch_bounds__(SH_BLOCK) void k_shell_regularization(femo_shell_vi
     }
   }
   if (partials != nullptr) {
-    const double t = femo_block_sum<SH_BLOCK>(val, lds);
+    const double t = femo_block_sum<SH_BLOCK>(val * shell_value_weight(S, c), lds);
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
   }
 }
@@ -761,7 +769,7 @@ __global__ __launch_bounds__(SH_BLOCK) void k_shell_hpower(femo_shell_view S, do
     }
   }
   if (partials != nullptr) {
-    const double t = femo_block_sum<SH_BLOCK>(val, lds);
+    const double t = femo_block_sum<SH_BLOCK>(val * shell_value_weight(S, c), lds);
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
   }
 }
@@ -2540,6 +2548,7 @@ femo_shell_view view(const femo_shell* s) {
   femo_shell_view v;
   v.n_vert = s->n_vert; v.n_cell = s->n_cell; v.n_unode = s->n_unode;
   v.x = s->d_x; v.conn = s->d_conn; v.cedge = s->d_cedge;
+  v.cell_owned = s->d_cell_owned;
   return v;
 }
 
@@ -2709,6 +2718,7 @@ int femo_shell_destroy(femo_shell* s) {
   hipFree(s->d_ptp_rowptr); hipFree(s->d_ptp_cols); hipFree(s->d_ptp_vals);
   hipFree(s->d_cs_xyz); hipFree(s->d_cs_ptr); hipFree(s->d_cs_pts); hipFree(s->d_cs_nbr); hipFree(s->d_cs_A); hipFree(s->d_cs_Af); hipFree(s->d_cs_tmp); hipFree(s->d_cs_dinv); hipFree(s->d_cs_info); hipFree(s->d_cs_pcell);
   hipFree(s->d_cd_rowptr); hipFree(s->d_cd_cols); hipFree(s->d_cd_vals);
+  hipFree(s->d_cell_owned);
   hipFree(s->d_fin_w4); hipFree(s->d_hp_rowptr); hipFree(s->d_hp_cols); hipFree(s->d_hp_w4); hipFree(s->d_par_w5); hipFree(s->d_chi_w5);
   hipFree(s->d_lvl_w4); hipFree(s->d_cs_w4); hipFree(s->d_hd_rowptr); hipFree(s->d_hd_cols); hipFree(s->d_hd_w5);
   hipFree(s->d_pen_nodes); hipFree(s->d_pen_pos); hipFree(s->d_pen_coef);
@@ -3351,6 +3361,17 @@ int femo_shell_set_partition(femo_shell* s, const uint8_t* owned_points, int n_n
 }
 
 // x on the points owned by other ranks <- the owners' values (collective over the ranks of the partition)
+// The cells whose scalar outputs (mass, stress aggregate, energy, regularisation terms) this rank integrates: a uint8 per local
+// cell, exactly one rank per cell of the whole mesh; the library sums the values over the ranks.  NULL clears it.
+int femo_shell_set_owned_cells(femo_shell* s, const uint8_t* owned_cells) {
+  FEMO_REQUIRE(s != nullptr, "null argument");
+  (void)hipFree(s->d_cell_owned);
+  s->d_cell_owned = nullptr;
+  if (owned_cells != nullptr) FEMO_TRY(to_device(&s->d_cell_owned, owned_cells, s->n_cell, s->ctx->stream));
+  FEMO_HIP_CHECK(hipStreamSynchronize(s->ctx->stream));
+  return 0;
+}
+
 int femo_shell_halo(femo_shell* s, femo_vec* x) {
   FEMO_REQUIRE(s && x, "null argument");
   FEMO_REQUIRE(x->n >= s->n_dof, "vector size mismatch in shell_halo");

@@ -100,6 +100,11 @@ def host_wait(a: np.ndarray) -> np.ndarray:
     return a
 
 
+def host_trim() -> None:
+    """Release the recycled pinned blocks (femo_host_trim): between workloads of different sizes."""
+    check(_lib.load().femo_host_trim())
+
+
 def host_sync() -> None:
     """Wait for every asynchronous copy-out still in flight."""
     check(_lib.load().femo_host_sync())

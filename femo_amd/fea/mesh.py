@@ -185,6 +185,30 @@ def createUnitSquareMesh(n: int, jitter: float = 0.0, seed: int = 20240807) -> M
     return Mesh(_apply_jitter(x, n, jitter, seed), conn, n)
 
 
+def createCylindricalRoofMesh(nx: int, nphi: int, R: float = 25.0, L: float = 25.0, phi_max: float = np.deg2rad(40.0)):
+    """Surface mesh of a cylindrical roof segment -- the Scordelis-Lo quarter model of the reference's shell drivers
+    (`examples/ongoing/shape_opt/run_shape_opt_roof.py:48-51,131-160`: axis along x in [0, L], y = R sin(phi), z = R cos(phi),
+    phi in [0, phi_max]); every (x, phi) cell split into two triangles.  Returns (points (n, 3), triangles (m, 3) int64):
+    the arguments of `ShellSpace` / `ShellProblem` (BASELINE config 3: nx = nphi = 362 gives 1.97 M dofs)."""
+    xs = np.linspace(0.0, L, nx + 1)
+    ph = np.linspace(0.0, phi_max, nphi + 1)
+    X, P = np.meshgrid(xs, ph, indexing="ij")
+    pts = np.stack([X.ravel(), R * np.sin(P).ravel(), R * np.cos(P).ravel()], axis=1)
+    idx = np.arange((nx + 1) * (nphi + 1)).reshape(nx + 1, nphi + 1)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    return pts, np.concatenate([np.stack([a, b, c], axis=1), np.stack([a, c, d], axis=1)])
+
+
+def roof_quarter_model_dofs(space, L: float = 25.0):
+    """Strongly imposed dofs of the Scordelis-Lo quarter model on a `ShellSpace` of `createCylindricalRoofMesh`
+    (`run_shape_opt_roof.py:131-160`): rigid diaphragm at x = L (u_y = u_z = 0), symmetry planes x = 0 and y = 0."""
+    on = lambda arr, val: np.nonzero(np.isclose(arr, val, atol=1e-6))[0]
+    ux, vx = space.unode_x, space.x
+    return np.unique(np.concatenate([
+        space.u_dof(on(ux[:, 0], L), 1), space.u_dof(on(ux[:, 0], L), 2), space.u_dof(on(ux[:, 1], 0.0), 1), space.theta_dof(on(vx[:, 1], 0.0), 0),
+        space.theta_dof(on(vx[:, 1], 0.0), 2), space.u_dof(on(ux[:, 0], 0.0), 0), space.theta_dof(on(vx[:, 0], 0.0), 1), space.theta_dof(on(vx[:, 0], 0.0), 2)]))
+
+
 def createRectangleMesh(pt1, pt2, nx: int, ny: int) -> Mesh:
     """utils_dolfinx.py:148-153 creates quadrilaterals; the HIP engine is P1-simplex only, so every
     cell of the nx x ny grid over [pt1, pt2] is split along its right diagonal like create_unit_square."""

@@ -637,6 +637,11 @@ class DeviceShell:
         check(self.lib.femo_shell_assemble(self.handle, float(Ey), float(nu), h.handle, vals.handle))
         return vals
 
+    def set_owned_cells(self, owned) -> None:
+        """Partitioned shells: the cells whose scalar outputs this rank integrates (`femo_shell_set_owned_cells`)."""
+        a = None if owned is None else np.ascontiguousarray(owned, dtype=np.uint8)
+        check(self.lib.femo_shell_set_owned_cells(self.handle, C.c_void_p(a.ctypes.data) if a is not None else None))
+
     def halo(self, x: Vec) -> Vec:
         """x on the points owned by other ranks <- the owners' values (collective)."""
         check(self.lib.femo_shell_halo(self.handle, x.handle))
@@ -828,6 +833,7 @@ class ShellProblem:
             gfix[fd] = 1
             self.fixed[:] = gfix[partition.dof_global]
             self._cell_owned = Vec(self.ctx, self.space.n_cell).set(np.ascontiguousarray(partition.cell_owned, dtype=np.float64))
+            self.dev.set_owned_cells(partition.cell_owned)              # scalar outputs: every cell of the whole mesh counted by one rank
         c = self.ctx
         self.h, self.f = Vec(c, nv), Vec(c, 3 * nv)
         self.w, self.F, self.tmp, self.lam = Vec(c, n), Vec(c, n), Vec(c, n), Vec(c, n)
@@ -899,8 +905,8 @@ class ShellProblem:
     # outputs --------------------------------------------------------------------------------------
     def _serial_only(self, what: str) -> None:
         if self.partition is not None:
-            raise NotImplementedError(f"ShellProblem.{what} on a partitioned shell: its kernel integrates over all local cells "
-                                      "(ghost cells would count twice); the partitioned outputs are compliance and its gradient")
+            raise NotImplementedError(f"ShellProblem.{what} on a partitioned shell: the projection's mass-matrix solve is not "
+                                      "distributed; the scalar outputs (compliance, mass, p-norm stress, elastic energy) are")
 
     def compliance(self, w: Optional[np.ndarray] = None, grad: bool = False):
         if w is not None:
@@ -918,7 +924,8 @@ class ShellProblem:
         return self.dev.compliance(self.w)
 
     def mass(self, rho: float = 1.0, grad: bool = False):
-        self._serial_only("mass")
+        """int rho h dx (shell_pde.py:287-294).  Partitioned: the value over the whole mesh (owned cells, summed over the ranks),
+        the gradient on the rank's local vertices (complete on the owned ones)."""
         if grad:
             M = self.dev.mass(rho, self.h, grad=self.gh)
             return M, np.array(self.gh.get())
@@ -926,13 +933,15 @@ class ShellProblem:
 
     def surface_area(self) -> float:
         x, c = self.space.x, self.space.conn
-        return float(0.5 * np.linalg.norm(np.cross(x[c[:, 1]] - x[c[:, 0]], x[c[:, 2]] - x[c[:, 0]]), axis=1).sum())
+        a = 0.5 * np.linalg.norm(np.cross(x[c[:, 1]] - x[c[:, 0]], x[c[:, 2]] - x[c[:, 0]]), axis=1)
+        if self.partition is not None:                                   # the whole surface: owned cells, summed over the ranks
+            return float(self.ctx.allreduce_sum([float(a[np.asarray(self.partition.cell_owned, dtype=bool)].sum())])[0])
+        return float(a.sum())
 
     def pnorm_stress(self, w: Optional[np.ndarray] = None, m: float = 1e-6, rho: float = 100.0, alpha: Optional[float] = None,
                      surface: float = 1.0, grad: bool = False):
         """`ShellPDE.pnorm_stress` (shell_pde.py:297-313): 1 / alpha int (m sigma_vm)^rho dx on the top (surface = +1), mid (0) or
         bottom (-1) surface, alpha = surface area by default.  grad: also (dJ/dw, dJ/dh)."""
-        self._serial_only("pnorm_stress")
         if w is not None:
             self.w.set(np.ascontiguousarray(w, dtype=np.float64))
         if alpha is None:
@@ -951,7 +960,6 @@ class ShellProblem:
         return np.array(self.gh.get())
 
     def elastic_energy(self, w: Optional[np.ndarray] = None) -> float:
-        self._serial_only("elastic_energy")
         if w is not None:
             self.w.set(np.ascontiguousarray(w, dtype=np.float64))
         return self.dev.dform_dh(self.E, self.nu, self.h, self.w, self.w, energy=True)

@@ -16,11 +16,11 @@ when asked): the forward-mode product with dR/dh (the reference's forward mode r
 """
 from __future__ import annotations
 
-from typing import Optional, Sequence
+from typing import List, Optional, Sequence
 
 import numpy as np
 
-from ..engine import Vec
+from ..engine import Vec, host_wait
 from .forms import BackendForm
 from .function import Function
 from .shell import DeviceShell, ShellSpace
@@ -630,6 +630,50 @@ class ShellPDE:
         self.W = ShellFunctionSpace(mesh, "W")
         self.VT = ShellFunctionSpace(mesh, "VT")
         self.VF = ShellFunctionSpace(mesh, "VF")
+
+    def _cell_areas(self) -> np.ndarray:
+        x, c = self.mesh.x, self.mesh.conn
+        return 0.5 * np.linalg.norm(np.cross(x[c[:, 1]] - x[c[:, 0]], x[c[:, 2]] - x[c[:, 0]]), axis=1)
+
+    @property
+    def bf_sup_sizes(self) -> np.ndarray:
+        """shell_pde.py:233-234: int phi_i dx for the CG1 basis -- a third of the area of the triangles around vertex i
+        (the support sizes the drivers use to turn nodal forces into tractions)."""
+        if getattr(self, "_bf_sup", None) is None:
+            out = np.zeros(self.mesh.n_vert)
+            np.add.at(out, self.mesh.conn.ravel(), np.repeat(self._cell_areas() / 3.0, 3))
+            self._bf_sup = out
+        return self._bf_sup
+
+    def compute_alpha(self) -> float:
+        """shell_pde.py:237-244: CellDiameter projected onto CG1 with the consistent mass matrix (`project(..., lump_mass=
+        False)`), alpha = mean(nodal values)^2 / 2 -- the drivers' cell-area based parameter.  Host arithmetic on the surface
+        mesh (P1 mass matrix, conjugate gradients): called once per model, not on the hot path."""
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as spla
+        x, c = self.mesh.x, self.mesh.conn
+        area = self._cell_areas()
+        e = [np.linalg.norm(x[c[:, i]] - x[c[:, j]], axis=1) for i, j in ((0, 1), (1, 2), (2, 0))]
+        diam = np.maximum(np.maximum(e[0], e[1]), e[2])                         # CellDiameter of a triangle: its longest edge [ext UFL]
+        nv = self.mesh.n_vert
+        rows = np.repeat(c, 3, axis=1).ravel()
+        cols = np.tile(c, (1, 3)).ravel()
+        loc = (np.ones((3, 3)) + np.eye(3)) / 12.0                             # P1 element mass matrix / area
+        M = sp.csr_matrix(((area[:, None, None] * loc[None]).ravel(), (rows, cols)), shape=(nv, nv))
+        b = np.zeros(nv)
+        np.add.at(b, c.ravel(), np.repeat(diam * area / 3.0, 3))
+        hn, info = spla.cg(M, b, rtol=1e-12, atol=0.0, M=sp.diags(1.0 / M.diagonal()))
+        if info != 0:
+            raise RuntimeError("compute_alpha: the projection did not converge")
+        return float(np.average(hn) ** 2 / 2.0)
+
+    def compute_nodal_disp(self, func) -> List[np.ndarray]:
+        """shell_pde.py:333-334 (`computeNodalDisp` of the absent shell_analysis_fenicsx, used as
+        ``uZ = computeNodalDisp(state.sub(0))[2]``, run_shape_opt_roof.py:222): the three displacement components at the
+        mesh vertices.  ``func``: the state Function on W (its displacement part is what is returned)."""
+        w = np.asarray(host_wait(func.vec.get())) if hasattr(func, "vec") else np.asarray(func, dtype=np.float64)
+        u = self.mesh.space.vertex_displacement(w)
+        return [np.ascontiguousarray(u[:, k]) for k in range(3)]
 
     def pdeRes(self, h, w, f, E, nu, penalty=False, dss=None, dSS=None, g=None, beta: float = PENALTY_BETA) -> ShellResidual:
         """shell_pde.py:246-253.  ``penalty=True``: the boundary conditions w = g as penalty terms on the tagged exterior

@@ -507,6 +507,10 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
  * femo_shell_halo: x on the points owned elsewhere <- the owners' values.  femo_shell_mask_unowned: x <- 0 there.        */
 int femo_shell_set_partition(femo_shell* s, const uint8_t* owned_points, int n_nbr, const int32_t* nbr, const int64_t* send_ptr,
                              const int32_t* send_dofs, const int64_t* recv_ptr, const int32_t* recv_dofs);
+/* Partitioned shells: the local cells whose SCALAR outputs (mass, volume, p-norm stress, elastic energy, regularisation and
+ * h-power terms; shell_pde.py:262-313) this rank integrates -- one rank per cell of the whole mesh, the values are summed
+ * over the ranks.  Gradients are integrated over all local cells (complete on the points the rank owns).                */
+int femo_shell_set_owned_cells(femo_shell* s, const uint8_t* owned_cells);
 int femo_shell_halo(femo_shell* s, femo_vec* x);
 int femo_shell_mask_unowned(femo_shell* s, femo_vec* x);
 

@@ -126,7 +126,7 @@ def test_compliance_gradient_on_three_ranks():
         prob.set_load(f)
         J, g, w = prob.compliance_gradient()
         with pytest.raises(NotImplementedError):
-            prob.mass()
+            prob.von_mises_field()                                   # the projection's mass solve is not distributed
         return P, J, g
 
     res = _run_ranks(world, rank_fn)
@@ -209,3 +209,50 @@ def test_warped_plate_on_four_ranks():
     assert len({r[2] for r in res}) == 1 and max(r[3] for r in res) >= 2
     print(f"warped plate on 4 ranks: {rel(w, wref):.2e}, {res[0][2]} iterations, neighbours {[r[3] for r in res]}")
     assert rel(w, wref) <= 1e-8
+
+
+def test_scalar_outputs_on_three_ranks():
+    """VERDICT round 3, missing #2: mass, the aggregated von Mises stress and the elastic energy on a partitioned shell
+    (shell_pde.py:281-313) -- every cell of the whole mesh is integrated by exactly one rank (`femo_shell_set_owned_cells`),
+    the values are the oracle's, every rank holds them, and the gradients are the oracle's on the points a rank owns."""
+    from femo_amd.dist.shell import ShellPartition
+    from femo_amd.fea.shell import ShellProblem, ShellSpace
+    pts, conn, V, h, f, fixed = _roof(10, 9, seed=2)
+    G = ShellSpace(pts, conn)
+    nu = 0.3
+    K = so.assemble(V, so.element_stiffness(V, h, E_ROOF, nu))
+    wref = so.solve(K, so.load_vector(V, f), fixed)
+    area = 0.5 * np.linalg.norm(np.cross(pts[conn[:, 1]] - pts[conn[:, 0]], pts[conn[:, 2]] - pts[conn[:, 0]]), axis=1)
+    m_ref = float((area[:, None] / 3.0 * h[conn]).sum() * 2.5)
+    dm_ref = np.zeros(V.n_vert)
+    np.add.at(dm_ref, conn.ravel(), np.repeat(2.5 * area / 3.0, 3))
+    e_ref = 0.5 * float(wref @ (K @ wref))
+    p_ref, dpw_ref, dph_ref = so.pnorm_stress(V, wref, h, E_ROOF, nu, m=1e-6, rho=8.0, alpha=float(area.sum()), surface=1.0, grad=True)
+    world = 3
+
+    def rank_fn(rank, ctx):
+        P = ShellPartition(G, rank, world)
+        prob = ShellProblem(pts, conn, E_ROOF, nu, fixed_dofs=fixed, ctx=ctx, partition=P)
+        prob.set_thickness(h)
+        prob.set_load(f)
+        w = prob.solve(rtol=1e-11)
+        m, dm = prob.mass(2.5, grad=True)
+        en = prob.elastic_energy()
+        pn, dpw, dph = prob.pnorm_stress(m=1e-6, rho=8.0, grad=True)
+        return P, m, dm, en, pn, dpw, dph, prob.surface_area()
+
+    res = _run_ranks(world, rank_fn)
+    gm, gph = np.full(V.n_vert, np.nan), np.full(V.n_vert, np.nan)
+    gpw = np.full(V.n_dof, np.nan)
+    for P, m, dm, en, pn, dpw, dph, ar in res:
+        assert abs(ar - area.sum()) <= 1e-12 * area.sum()
+        assert abs(m - m_ref) <= 1e-12 * abs(m_ref)
+        assert abs(en - e_ref) <= 1e-7 * abs(e_ref)
+        assert abs(pn - p_ref) <= 1e-7 * abs(p_ref)
+        ov = P.owned_vertices()
+        gm[P.vert_global[ov]] = dm[ov]
+        gph[P.vert_global[ov]] = dph[ov]
+        P.scatter_owned(dpw, gpw)
+    assert rel(gm, dm_ref) <= 1e-12
+    assert rel(gph, dph_ref) <= 1e-6
+    assert rel(gpw, dpw_ref) <= 1e-6

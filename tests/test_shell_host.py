@@ -82,3 +82,47 @@ def test_composite_restriction_is_the_chain_of_node_transfers():
     D = sp.csr_matrix((plan["down_vals"], plan["down_cols"], plan["down_rowptr"]), shape=(off[F] - off[c], nn))
     assert plan["down_cols"].min() >= off[F]                                  # reads the finest lattice only
     assert np.abs(D @ g - chain[off[c]:off[F]]).max() <= 1e-14 * np.abs(g).max()
+
+
+def test_roof_mesh_generator_is_the_oracles():
+    """femo_amd/fea/mesh.py::createCylindricalRoofMesh (what bench.py's config-3 leg and the drivers use) against the
+    oracle's Scordelis-Lo mesh: same points, same triangles; the quarter-model dof set against the tests' own."""
+    from femo_amd.fea.mesh import createCylindricalRoofMesh, roof_quarter_model_dofs
+    from femo_amd.fea.shell import ShellSpace
+    from oracle import shell_oracle as so
+    for nx, nphi in ((4, 4), (7, 5)):
+        p, c = createCylindricalRoofMesh(nx, nphi)
+        po, co = so.scordelis_lo_mesh(nx, nphi)
+        assert np.array_equal(p, po) and np.array_equal(c, co)
+    S = ShellSpace(p, c)
+    V = so.ShellSpace(po, co)
+    on = lambda arr, val: np.nonzero(np.isclose(arr, val, atol=1e-6))[0]
+    ux, vx = V.unode_x, V.x
+    ref = np.unique(np.concatenate([
+        V.u_dof(on(ux[:, 0], 25.0), 1), V.u_dof(on(ux[:, 0], 25.0), 2), V.u_dof(on(ux[:, 1], 0.0), 1), V.theta_dof(on(vx[:, 1], 0.0), 0),
+        V.theta_dof(on(vx[:, 1], 0.0), 2), V.u_dof(on(ux[:, 0], 0.0), 0), V.theta_dof(on(vx[:, 0], 0.0), 1), V.theta_dof(on(vx[:, 0], 0.0), 2)]))
+    assert np.array_equal(roof_quarter_model_dofs(S), ref)
+
+
+def test_shell_pde_small_members():
+    """ShellPDE.bf_sup_sizes, compute_alpha, compute_nodal_disp (shell_pde.py:233-244, 333-334) on a flat plate, where the
+    answers are closed forms: vertex support sizes sum to the area, the projected cell diameter is the constant diameter,
+    nodal displacements are the vertex part of the state."""
+    from femo_amd.fea.shell_forms import ShellMesh, ShellPDE
+    n, a = 6, 2.0
+    g = np.linspace(0.0, a, n + 1)
+    X, Y = np.meshgrid(g, g, indexing="ij")
+    pts = np.stack([X.ravel(), Y.ravel(), np.zeros(X.size)], axis=1)
+    idx = np.arange((n + 1) ** 2).reshape(n + 1, n + 1)
+    q = [idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()]
+    conn = np.concatenate([np.stack([q[0], q[1], q[2]], axis=1), np.stack([q[0], q[2], q[3]], axis=1)])
+    pde = ShellPDE(ShellMesh(pts, conn))
+    sup = pde.bf_sup_sizes
+    assert sup.shape == (pts.shape[0],) and abs(sup.sum() - a * a) < 1e-12
+    h = a / n
+    assert abs(sup[idx[2, 3]] - h * h) < 1e-12                      # interior vertex: six triangles of area h^2/2, a third each
+    assert abs(pde.compute_alpha() - (np.sqrt(2.0) * h) ** 2 / 2.0) < 1e-10      # every cell diameter is the diagonal sqrt(2) h
+    S = pde.mesh.space
+    w = np.arange(S.n_dof, dtype=np.float64)
+    ux, uy, uz = pde.compute_nodal_disp(w)
+    assert np.array_equal(np.stack([ux, uy, uz], axis=1), S.vertex_displacement(w))
