@@ -764,7 +764,7 @@ def _run(args):
     B_A = spmv_algorithmic_bytes(nnz, n_dof)
     achieved = B_A / (spmv_avg_ms * 1e-3) / 1e9
     traffic = None
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
         prof = os.path.join(ROOT, "profiles", name)
         if os.path.exists(prof):
             try:

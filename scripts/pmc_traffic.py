@@ -32,6 +32,6 @@ for tag, path in zip(("n215", "n215_permute"), sys.argv[2:]):
     out[key + "_fetch_KiB"], out[key + "_write_KiB"] = e["fetch_KiB"], e["write_KiB"]
     out["other_kernels_" + tag] = {k: entry(c) for k, c in t.items()
                                    if k != "k_spmv_sell<1, true>" and ("FETCH_SIZE" in c) and
-                                   any(s in k for s in ("poisson_system", "p1_row_walk", "restrict_bricks", "prolong_mesh", "pcg_xr", "lattice_prolong3", "k_spmv_sell<0", "k_vec_diff", "k_scale_sell"))}
+                                   any(s in k for s in ("poisson_system", "p1_row_walk", "restrict_bricks", "prolong_mesh", "pcg_xr", "lattice_prolong3", "lattice_coarse_m", "k_spmv_sell<0", "k_vec_diff", "k_scale_sell"))}
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])
