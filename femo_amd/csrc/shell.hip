@@ -90,6 +90,13 @@ struct femo_shell {
   // points, then rotation points), (a, b, c) of the node-level transfers, composed weights of the levels above the
   // coarse solve ([level][point][8], finest included) and of the coarse-solve level, composite restriction
   bool hermite = false, hermite_on = false;             // uploaded / in use for the current stiffness
+  // Weight of the node-block levels in the additive sum (round 4).  The levels between the coarse solve and the finest
+  // lattice overlap each other and the point-block smoother; summed with weight 1 they overshoot (the same reason the
+  // Poisson BPX carries theta = 0.6).  Measured on the roof, iterations per solve for weights 1 / 0.5 / 0.3 / 0.25 / 0.12:
+  // 362^2 (three block levels) 145 / 113 / 105 / 105 / 118, 256^2 118 / 107 / 104 / 102, 128^2 (two) 113 / 103 / 101 / 101,
+  // 64^2 (one) 104 / 100 / 101 / 101; trilinear spaces at 362^2: 252 / 205 / 200.  A weight on the coarse solve (0.7, 2, 4)
+  // or per-level weights change nothing beyond that.
+  double w_levels = 0.3, w_coarse = 1.0;
   float4* d_fin_w4 = nullptr;
   int64_t* d_hp_rowptr = nullptr;
   int32_t* d_hp_cols = nullptr;
@@ -115,6 +122,11 @@ struct femo_shell {
   int32_t *d_send_idx = nullptr, *d_recv_idx = nullptr;
   double *d_send_buf = nullptr, *d_recv_buf = nullptr;
 };
+
+// relative weights of the additive parts of the preconditioner (femo_shell_pc_weights; applied at set-up time: the inverse
+// node blocks of the levels above the coarse solve and the factor of the coarse inverse are scaled once per stiffness)
+static double shell_level_weight(const femo_shell* s, int) { return s->w_levels; }
+static double shell_coarse_weight(const femo_shell* s) { return s->w_coarse; }
 
 // plain view of the device arrays for kernels
 struct femo_shell_view {
@@ -1823,8 +1835,8 @@ __global__ void k_pc_coarse_mirror(int64_t N, double* __restrict__ A) {
 // the factors of the coarse inverse as the iteration reads them: single precision (round 3).  M_c^-1 = B^T B with B = fl32(L^-1)
 // is symmetric positive semi-definite whatever the rounding did, a relative 6e-8 away from the fp64 one -- nothing an
 // iteration count sees --, and the two triangular products per iteration stream half the bytes (products and sums in fp64).
-__global__ void k_pc_coarse_to_float(int64_t count, const double* __restrict__ A, float* __restrict__ Af) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) Af[i] = (float)A[i];
+__global__ void k_pc_coarse_to_float(int64_t count, const double* __restrict__ A, float* __restrict__ Af, double scale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) Af[i] = (float)(scale * A[i]);
 }
 
 // one workgroup per row of the triangular factor: lower = 1: y = L^-1 x (entries 0 .. r of row r); 0: y = L^-T x (r .. n).
@@ -2137,7 +2149,7 @@ __global__ void k_pt_block_inv(int64_t n_pts, const int64_t* __restrict__ brow, 
 
 // in-place inverse of every node's 6 x 6 block (symmetric positive definite on the fields that have free dofs; a field
 // without any gets a zero row and column): Gauss-Jordan without pivoting on the symmetrised block
-__global__ void k_pc_invert_blocks(int64_t node0, int64_t node1, double* __restrict__ blk) {
+__global__ void k_pc_invert_blocks(int64_t node0, int64_t node1, double* __restrict__ blk, double scale) {
   const int64_t node = node0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (node >= node1) return;
   double* B = blk + 36 * node;
@@ -2174,7 +2186,7 @@ __global__ void k_pc_invert_blocks(int64_t node0, int64_t node1, double* __restr
 #pragma unroll
   for (int r = 0; r < 6; ++r)
 #pragma unroll
-    for (int c = 0; c < 6; ++c) B[6 * r + c] = (dead[r] || dead[c]) ? 0.0 : 0.5 * (inv[r][c] + inv[c][r]);
+    for (int c = 0; c < 6; ++c) B[6 * r + c] = (dead[r] || dead[c]) ? 0.0 : scale * 0.5 * (inv[r][c] + inv[c][r]);
 }
 
 // all levels between the coarse-solve level and the finest lattice at once: g[node] = sum over the finest lattice's
@@ -2857,7 +2869,7 @@ static int shell_pc_coarse_setup(femo_shell* s, const femo_vec* vals, const uint
   for (int i = 1; i < nblk; ++i) hipLaunchKernelGGL(k_trinv_row, dim3(i), dim3(256), 0, st, N, i, s->d_cs_A, s->d_cs_dinv);
   hipLaunchKernelGGL(k_trinv_diag, dim3(nblk), dim3(256), 0, st, N, s->d_cs_A, s->d_cs_dinv);
   hipLaunchKernelGGL(k_pc_coarse_mirror, dim3(sgrid(N, 256), (unsigned)N), dim3(256), 0, st, N, s->d_cs_A);
-  if (s->d_cs_Af != nullptr) hipLaunchKernelGGL(k_pc_coarse_to_float, dim3(2048), dim3(256), 0, st, N * N, s->d_cs_A, s->d_cs_Af);
+  if (s->d_cs_Af != nullptr) hipLaunchKernelGGL(k_pc_coarse_to_float, dim3(2048), dim3(256), 0, st, N * N, s->d_cs_A, s->d_cs_Af, std::sqrt(shell_coarse_weight(s)));
   FEMO_HIP_CHECK(hipGetLastError());
   int32_t info[4] = {0, 0, 0, 0};
   FEMO_HIP_CHECK(hipMemcpyAsync(info, s->d_cs_info, sizeof info, hipMemcpyDeviceToHost, st));
@@ -3043,6 +3055,14 @@ int femo_shell_pc_coarse(femo_shell* s, int level, const int32_t* node_xyz, int6
   }
   FEMO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pc_coarse_galerkin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CG_LDS));
   s->cs_level = level; s->cs_n = n; s->cs_N = N; s->cs_items = n_items;
+  s->pc_vals_uid = 0; s->pc_vals_gen = 0;                 // next solve recomputes the preconditioner's numbers
+  return 0;
+}
+
+int femo_shell_pc_weights(femo_shell* s, double w_levels, double w_coarse) {
+  FEMO_REQUIRE(s != nullptr, "null argument");
+  FEMO_REQUIRE(w_levels > 0.0 && w_coarse > 0.0, "the weights of the preconditioner's parts must be positive (M^-1 stays positive definite)");
+  s->w_levels = w_levels; s->w_coarse = w_coarse;
   s->pc_vals_uid = 0; s->pc_vals_gen = 0;                 // next solve recomputes the preconditioner's numbers
   return 0;
 }
@@ -3493,7 +3513,10 @@ static int shell_pc_setup(femo_shell* s, const femo_vec* vals, const uint8_t* fi
                            s->n_unode, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_lvl_node, s->d_lvl_w, s->d_cblk, first_slot);
       FEMO_HIP_CHECK(hipGetLastError());
       FEMO_TRY(shell_allreduce(s, s->d_cblk + 36 * nd0, (nd1 - nd0) * 36, st));
-      hipLaunchKernelGGL(k_pc_invert_blocks, dim3(sgrid(nd1 - nd0, 256)), dim3(256), 0, st, nd0, nd1, s->d_cblk);
+      for (int l = s->cs_level + 1; l < s->pc_levels; ++l) {
+        const int64_t a0 = s->level_off[l], a1 = s->level_off[l + 1];
+        if (a1 > a0) hipLaunchKernelGGL(k_pc_invert_blocks, dim3(sgrid(a1 - a0, 256)), dim3(256), 0, st, a0, a1, s->d_cblk, shell_level_weight(s, l));
+      }
       s->blk_ready = true;
     } else {
       FEMO_HIP_CHECK(hipMemsetAsync(s->d_coarse, 0, s->n_lat * sizeof(double), st));

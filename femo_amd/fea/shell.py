@@ -607,6 +607,13 @@ class DeviceShell:
                                                  q(A["chi_w5"]), q(A["lvl_w4"]), q(A["cs_w4"]), q(dn.get("rowptr")), q(dn.get("cols")), q(dn.get("w5"))))
             self.hermite = True
 
+    LEVEL_WEIGHT = 0.3          # the library's default (femo_shell_pc_weights; oracle: LatticePreconditioner.level_weight)
+
+    def pc_weights(self, level_weight: float = LEVEL_WEIGHT, coarse_weight: float = 1.0) -> None:
+        """Weights of the node-block levels / of the exact coarse solve in the additive preconditioner (`femo_shell_pc_weights`);
+        takes effect at the next solve."""
+        check(self.lib.femo_shell_pc_weights(self.handle, float(level_weight), float(coarse_weight)))
+
     def pc_apply(self, vals: Vec, r: Vec, z: Vec, fixed: Optional[np.ndarray] = None) -> Vec:
         """z = M^-1 r of the lattice preconditioner for ``vals`` and the mask (`femo_shell_pc_apply`): for tests."""
         mask = np.ascontiguousarray(fixed, dtype=np.uint8) if fixed is not None else None

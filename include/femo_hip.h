@@ -477,6 +477,11 @@ int femo_shell_pc_coarse(femo_shell* s, int level, const int32_t* node_xyz, int6
 int femo_shell_pc_hermite(femo_shell* s, const float* fin_w4, const int64_t* hp_rowptr, const int32_t* hp_cols, const float* hp_w4,
                           const double* par_w5, const double* chi_w5, const float* lvl_w4, const float* cs_w4,
                           const int64_t* down_rowptr, const int32_t* down_cols, const double* down_w5);
+/* Weights of the additive parts of the lattice preconditioner: w_levels multiplies the node-block corrections of the levels
+ * between the coarse solve and the finest lattice (default 0.3: the overlapping levels overshoot when summed with weight 1,
+ * like the Poisson BPX's theta; 145 -> 105 iterations on the 1.97 M-dof roof), w_coarse the exact coarse solve (default 1).
+ * Both must be positive.  Takes effect at the next set-up (the next solve).                                               */
+int femo_shell_pc_weights(femo_shell* s, double w_levels, double w_coarse);
 /* z = M^-1 r of the lattice preconditioner for the stiffness `vals` and the mask (set up if needed): what the parity tests
  * compare with the oracle's operator.  One rank.                                                                      */
 int femo_shell_pc_apply(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_host, const femo_vec* r, femo_vec* z);

@@ -535,7 +535,7 @@ def simply_supported_plate(n: int, h: float = 0.01, E: float = 1.0e7, nu: float 
 # femo/fea/utils_dolfinx.py:476-512), so there is nothing in /root/reference to pin it against.  What the tests check: the
 # HIP kernels apply exactly the operator written down here (transfers, Galerkin node blocks, dense coarse operator), the
 # operator is symmetric positive definite, and the iteration counts below are pinned (tests/test_oracle_shell.py).
-#   M^-1 = B_pt^-1 + sum_{l > c} P_l B_l^-1 P_l^T + P_c (P_c^T K P_c)^-1 P_c^T
+#   M^-1 = B_pt^-1 + w sum_{l > c} P_l B_l^-1 P_l^T + P_c (P_c^T K P_c)^-1 P_c^T,   w = level_weight = 0.3
 # B_pt: 3 x 3 point blocks of K; B_l: 6 x 6 node blocks of P_l^T K P_l; P_l = P_L T_{L-1} ... T_l (nested lattices of
 # 2, 4, ..., m cells per axis over the bounding cube).  hermite = True: the nodal rotations of a lattice are the slopes of
 # its displacement interpolation (u = sum_n [alpha_n U_n + Theta_n x sigma_n], cubic Hermite shapes per axis), both from the
@@ -670,13 +670,15 @@ class LatticePreconditioner:
     unknowns of the exact-solve level (the finest level below the top with at most that many)."""
 
     def __init__(self, V: ShellSpace, K: sp.csr_matrix, fixed: Sequence[int], hermite: bool = True, finest: Optional[int] = None,
-                 coarse_max: int = 3200, ridge: float = 1e-12, hermite_mesh: Optional[bool] = None):
+                 coarse_max: int = 3200, ridge: float = 1e-12, hermite_mesh: Optional[bool] = None, level_weight: float = 0.3):
         import scipy.sparse.linalg as spla
         nd = V.n_dof
         mask = np.ones(nd)
         mask[np.asarray(fixed, dtype=np.int64)] = 0.0
         Dm = sp.diags(mask)
         self.mask = mask
+        # weight of the node-block levels in the additive sum (femo_shell_pc_weights: the overlapping levels overshoot with 1)
+        self.level_weight = float(level_weight)
         self.Kf = (Dm @ K @ Dm + sp.diags(1.0 - mask)).tocsr()
         self.levels, lo, ext = lattice_levels(V, finest)
         self.sets = lattice_node_sets(V, self.levels, lo, ext)
@@ -725,7 +727,7 @@ class LatticePreconditioner:
             z += self.P[self.c] @ (self.Ac_inv @ (self.P[self.c].T @ r))
         for l, B in self.Bl.items():
             g = (self.P[l].T @ r).reshape(-1, 6)
-            z += self.P[l] @ np.einsum("nij,nj->ni", B, g).ravel()
+            z += self.level_weight * (self.P[l] @ np.einsum("nij,nj->ni", B, g).ravel())
         return z
 
     def pcg(self, b: np.ndarray, rtol: float = 1e-10, max_it: int = 5000):

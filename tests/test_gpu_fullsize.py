@@ -160,7 +160,7 @@ def test_config3_shell_at_full_size(ctx):
     prob.set_thickness(h)
     prob.set_load([0.0, 0.0, -90.0])
     w = prob.solve(rtol=1e-10)
-    assert prob.last_info.converged == 1 and prob.last_info.iterations < 160        # 145 with the Hermite-type lattice spaces (round 4); 252 trilinear, 1.3 k with diagonal levels only
+    assert prob.last_info.converged == 1 and prob.last_info.iterations < 125        # 105 with the Hermite-type lattice spaces and the level weight 0.3 (round 4; 145 with weight 1); 252 trilinear, 1.3 k with diagonal levels only
     free = ~prob.fixed.astype(bool)
     r = prob.residual(w)
     Fn = np.abs(r[~free]).max()                                                     # reactions: the scale of the forces

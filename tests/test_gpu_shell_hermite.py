@@ -57,8 +57,8 @@ def test_hermite_operator_matches_the_oracle(ctx, n, coarse):
 
 
 def test_hermite_iteration_counts(ctx):
-    """The counts of the oracle's PCG with the same operator are reproduced (16 x 16: 156, 32 x 32: 89 -- pinned in
-    tests/test_oracle_shell.py), they are well below the trilinear hierarchy's (269 / 168), and the solution is the direct one."""
+    """The counts of the oracle's PCG with the same operator are reproduced (16 x 16: 153, 32 x 32: 85 -- pinned in
+    tests/test_oracle_shell.py), they are well below the trilinear hierarchy's (258 / 149), and the solution is the direct one."""
     res = {}
     for n in (16, 32):
         for herm in (False, True):
@@ -71,5 +71,5 @@ def test_hermite_iteration_counts(ctx):
         for herm in (False, True):
             assert res[(n, herm)][1] == 1
             assert rel(res[(n, herm)][2], w_ref) <= 1e-7
-    assert abs(res[(16, True)][0] - 156) <= 6 and abs(res[(32, True)][0] - 89) <= 4
-    assert res[(16, True)][0] < 0.7 * res[(16, False)][0] and res[(32, True)][0] < 0.6 * res[(32, False)][0]
+    assert abs(res[(16, True)][0] - 153) <= 6 and abs(res[(32, True)][0] - 85) <= 4
+    assert res[(16, True)][0] < 0.7 * res[(16, False)][0] and res[(32, True)][0] < 0.65 * res[(32, False)][0]
