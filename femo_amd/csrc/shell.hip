@@ -1582,6 +1582,204 @@ __global__ __launch_bounds__(256) void k_pc_coarse_galerkin_h(int pass, int c, i
   }
 }
 
+// Dense Galerkin operator of the coarse-solve level on the fp64 matrix cores (round 4).  A = P_c^T (K P_c) is GEMM shaped:
+// all points of an item (one coarse cell, one field group) share the cell's 8 nodes a -- the 48 rows (f, a) of their
+// P_c^T -- and every column point of their blocks has its 8 nodes in the 4 x 4 x 4 node window of the cell -- the 384
+// columns (f', bl) of Y = K P_c restricted to the item's rows.  Per chunk of MM_PTS points:
+//   1. the chunk's 3 x 3 blocks are staged in LDS (one per thread: masked values, the column point's 8 weights, its cell
+//      offset), as in k_pc_coarse_galerkin_h;
+//   2. Y[(p, fa)][(f', bl)] += (K_pq W_q,k')[fa][f']: one wave per point walks its blocks, lanes = (f', k'), plain LDS
+//      read-modify-writes (a wave's LDS operations execute in order, the rows of a point belong to one wave);
+//   3. W^T[(f, a)][(p, fa)] = W_p,a[fa][f];
+//   4. D[(f, a)][(f', bl)] += W^T Y with v_mfma_f64_16x16x4 (K = 3 MM_PTS = 24: six steps), accumulators in registers across
+//      the chunks of the item: 3 x 24 tiles of 16 x 16, nine per wave.
+// The tiles (Theta_1/2 rows, U columns) are not formed: k_pc_coarse_mirror_tu fills the (Theta, U) quadrant from (U, Theta).
+// LDS atomics of the version before (k_pc_coarse_galerkin_h, 15 G of them at 1.97 M dofs): 18.7 ms; this kernel: see DESIGN.md.
+constexpr int MM_PTS = 8, MM_K = 3 * MM_PTS, MM_YP = 400, MM_WP = 25, MM_STAGE = 256, MM_THREADS = 512;
+constexpr size_t MM_LDS = (size_t)MM_K * MM_YP * 8 + 48 * MM_WP * 8 + MM_STAGE * 9 * 8 + MM_STAGE * 8 * 16 + MM_STAGE * 4 + MM_PTS * 8 * 16 + 4 * (MM_PTS + 1) + 4 * MM_PTS * 2;
+__global__ __launch_bounds__(MM_THREADS) void k_pc_coarse_galerkin_mm(int c, int width, int64_t off_c, int64_t lda, int64_t n_unode,
+                                                                      const int64_t* __restrict__ item_ptr, const int32_t* __restrict__ item_pts,
+                                                                      const int32_t* __restrict__ item_nbr, const int32_t* __restrict__ pcell,
+                                                                      const int64_t* __restrict__ brow, const int32_t* __restrict__ bcols,
+                                                                      const double* __restrict__ vals, const uint8_t* __restrict__ fixed,
+                                                                      const int32_t* __restrict__ ell_idx, const float4* __restrict__ cs_w4,
+                                                                      double* __restrict__ A, int32_t* __restrict__ info) {
+  extern __shared__ double mm_lds[];
+  double (*Y)[MM_YP] = reinterpret_cast<double (*)[MM_YP]>(mm_lds);                         // [3 pl + fa][64 f' + bl]
+  double (*Wt)[MM_WP] = reinterpret_cast<double (*)[MM_WP]>(mm_lds + MM_K * MM_YP);          // [8 f + a][3 pl + fa]
+  double (*s_val)[9] = reinterpret_cast<double (*)[9]>(&Wt[48][0]);
+  float4 (*s_wb)[8] = reinterpret_cast<float4 (*)[8]>(s_val + MM_STAGE);
+  int32_t* s_meta = reinterpret_cast<int32_t*>(s_wb + MM_STAGE);
+  float4 (*s_wpt)[8] = reinterpret_cast<float4 (*)[8]>(s_meta + MM_STAGE);
+  int32_t* s_scan = reinterpret_cast<int32_t*>(s_wpt + MM_PTS);
+  int32_t* s_k0 = s_scan + MM_PTS + 1;
+  int32_t* s_fi = s_k0 + MM_PTS;
+  const int64_t item = blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int64_t pbeg = item_ptr[item], pend = item_ptr[item + 1];
+  const int32_t pfirst = item_pts[pbeg];
+  const int gi = pfirst >= n_unode ? 1 : 0;                                // 0: displacement points (rows U and Theta), 1: rotation points (Theta)
+  const int64_t e0 = (int64_t)(3 * pfirst) * width + 8 * c;
+  const int32_t pk0 = pcell[pfirst];
+  const int bx = pk0 & 1023, by = (pk0 >> 10) & 1023, bz = pk0 >> 20;
+  const int li = lane & 15, lk = lane >> 4;
+  // accumulators: N-tiles nt = wv + 8 j (j = 0..2), M-tiles mt = 0..2
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  d4 acc[3][3];
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[mt][j] = d4{0.0, 0.0, 0.0, 0.0};
+  int far = 0;
+  for (int64_t p0 = pbeg; p0 < pend; p0 += MM_PTS) {
+    const int npts = (int)min((int64_t)MM_PTS, pend - p0);
+    __syncthreads();                                                       // the MFMA phase of the chunk before has read Y and Wt
+    for (int idx = t; idx < MM_K * MM_YP; idx += MM_THREADS) (&Y[0][0])[idx] = 0.0;
+    if (t < MM_PTS) {
+      int32_t k0 = 0, len = 0, fi = 0;
+      if (t < npts) {
+        const int32_t i = item_pts[p0 + t];
+        const int64_t b0 = brow[i];
+        k0 = (int32_t)b0; len = (int32_t)(brow[i + 1] - b0);
+        fi = fixed == nullptr ? 0 : (fixed[3 * i] ? 1 : 0) | (fixed[3 * i + 1] ? 2 : 0) | (fixed[3 * i + 2] ? 4 : 0);
+      }
+      s_k0[t] = k0; s_scan[t + 1] = len; s_fi[t] = fi;
+    }
+    if (t >= 64 && t < 64 + MM_PTS * 8) {
+      const int q = (t - 64) >> 3, a = (t - 64) & 7;
+      s_wpt[q][a] = q < npts ? cs_w4[(int64_t)item_pts[p0 + q] * 8 + a] : float4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    if (t == 0) {
+      int32_t run = 0;
+      s_scan[0] = 0;
+      for (int q = 0; q < MM_PTS; ++q) { run += s_scan[q + 1]; s_scan[q + 1] = run; }
+    }
+    // W^T of the chunk: entry (m = 8 f + a, k = 3 pl + fa) = W_p,a[fa][f]
+    for (int idx = t; idx < 48 * MM_K; idx += MM_THREADS) {
+      const int m = idx / MM_K, k = idx - m * MM_K;
+      const int f = m >> 3, a = m & 7, pl = k / 3, fa = k - 3 * pl;
+      const float4 w = s_wpt[pl][a];
+      double v = 0.0;
+      if (gi == 0) {
+        if (f < 3) v = f == fa ? (double)w.x : 0.0;
+        else {
+          // (-[sigma]x)[fa][j]: rows (0, s2, -s1), (-s2, 0, s0), (s1, -s0, 0)
+          const int j = f - 3;
+          const double s0 = (double)w.y, s1 = (double)w.z, s2 = (double)w.w;
+          if (fa == 0) v = j == 1 ? s2 : (j == 2 ? -s1 : 0.0);
+          else if (fa == 1) v = j == 0 ? -s2 : (j == 2 ? s0 : 0.0);
+          else v = j == 0 ? s1 : (j == 1 ? -s0 : 0.0);
+        }
+      } else if (f >= 3) {
+        v = (f - 3) == fa ? (double)w.x : 0.0;
+      }
+      Wt[m][k] = v;
+    }
+    __syncthreads();
+    const int B = s_scan[MM_PTS];
+    for (int base = 0; base < B; base += MM_STAGE) {
+      const int fblk = base + t;
+      if (t < MM_STAGE && fblk < B) {
+        int q = 0;
+#pragma unroll
+        for (int qq = 1; qq < MM_PTS; ++qq) q += s_scan[qq] <= fblk ? 1 : 0;
+        const int lkk = fblk - s_scan[q];
+        const int64_t k0 = s_k0[q];
+        const int64_t len = 3 * (int64_t)(s_scan[q + 1] - s_scan[q]);
+        const int32_t cj = bcols[k0 + lkk];
+        const int32_t pk = pcell[cj / 3];
+        const int ox = (pk & 1023) - bx + 1, oy = ((pk >> 10) & 1023) - by + 1, oz = (pk >> 20) - bz + 1;
+        if ((unsigned)ox > 2u || (unsigned)oy > 2u || (unsigned)oz > 2u) {
+          far = 1;
+          s_meta[t] = -1;
+        } else {
+          s_meta[t] = ox | (oy << 2) | (oz << 4) | ((cj >= 3 * n_unode ? 1 : 0) << 6);
+          const double* v = vals + 9 * k0 + 3 * lkk;
+          const int fi = s_fi[q];
+          const int fj = fixed == nullptr ? 0 : (fixed[cj] ? 1 : 0) | (fixed[cj + 1] ? 2 : 0) | (fixed[cj + 2] ? 4 : 0);
+#pragma unroll
+          for (int fa = 0; fa < 3; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < 3; ++fb) s_val[t][3 * fa + fb] = ((fi >> fa) & 1) || ((fj >> fb) & 1) ? 0.0 : v[fa * len + fb];
+          const float4* wj = cs_w4 + (int64_t)(cj / 3) * 8;
+#pragma unroll
+          for (int b = 0; b < 8; ++b) s_wb[t][b] = wj[b];
+        }
+      }
+      __syncthreads();
+      // Y of point pl = wv: its staged blocks are the slots [scan[wv], scan[wv + 1]) of this round
+      {
+        const int pl = wv;
+        const int e_lo = max(s_scan[pl], base) - base, e_hi = min(s_scan[pl + 1], base + MM_STAGE) - base;
+        const int kq = lane & 7, fc = lane >> 3;
+        if (fc < 6) {
+          double* y0 = &Y[3 * pl][64 * fc];
+          for (int e = e_lo; e < e_hi; ++e) {
+            const int32_t m = s_meta[e];
+            if (m < 0) continue;
+            const int ox = m & 3, oy = (m >> 2) & 3, oz = (m >> 4) & 3, gj = (m >> 6) & 1;
+            const float4 wq = s_wb[e][kq];
+            // column f' = fc of W_q,k' as a 3-vector u: (K W)[fa][f'] = K[fa][.] . u
+            double u0, u1, u2;
+            if (gj == 0) {
+              if (fc < 3) { u0 = fc == 0 ? (double)wq.x : 0.0; u1 = fc == 1 ? (double)wq.x : 0.0; u2 = fc == 2 ? (double)wq.x : 0.0; }
+              else if (fc == 3) { u0 = 0.0; u1 = -(double)wq.w; u2 = (double)wq.z; }
+              else if (fc == 4) { u0 = (double)wq.w; u1 = 0.0; u2 = -(double)wq.y; }
+              else { u0 = -(double)wq.z; u1 = (double)wq.y; u2 = 0.0; }
+            } else {
+              u0 = fc == 3 ? (double)wq.x : 0.0; u1 = fc == 4 ? (double)wq.x : 0.0; u2 = fc == 5 ? (double)wq.x : 0.0;
+            }
+            const double* K = s_val[e];
+            const int bl = (ox + (kq & 1)) + 4 * (oy + ((kq >> 1) & 1)) + 16 * (oz + (kq >> 2));
+#pragma unroll
+            for (int fa = 0; fa < 3; ++fa) y0[fa * MM_YP + bl] += K[3 * fa] * u0 + K[3 * fa + 1] * u1 + K[3 * fa + 2] * u2;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    // D += W^T Y
+#pragma unroll
+    for (int ks = 0; ks < MM_K / 4; ++ks) {
+      const int kk = 4 * ks + lk;
+      double av[3];
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt) av[mt] = Wt[16 * mt + li][kk];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int nt = wv + 8 * j;
+        const double bv = Y[kk][16 * nt + li];
+        if (gi == 0) acc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv, acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv, acc[1][j], 0, 0, 0);
+        if (nt >= 12) acc[2][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv, acc[2][j], 0, 0, 0);
+      }
+    }
+  }
+  if (far && info != nullptr) atomicOr(&info[1], 1);
+  // flush: lane holds D[16 mt + lk + 4 i][16 nt + li]
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int nt = wv + 8 * j;
+    const int n = 16 * nt + li, fp = n >> 6, bl = n & 63;
+    const int32_t nb = item_nbr[item * 64 + bl];
+    if (nb < 0) continue;
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) {
+      if (mt == 2 && nt < 12) continue;
+      if (mt == 0 && gi == 1) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = 16 * mt + lk + 4 * i, f = m >> 3, a = m & 7;
+        const double v = acc[mt][j][i];
+        if (v == 0.0) continue;
+        const int64_t na = ell_idx[e0 + a] / 6 - off_c;
+        atomicAdd(&A[(6 * na + f) * lda + 6 * (int64_t)nb + fp], v);
+      }
+    }
+  }
+}
+
 // the (Theta, U) quadrant of every node pair = transpose of (U, Theta): A[6 a + 3 + i, 6 b + j] = A[6 b + j, 6 a + 3 + i]
 __global__ void k_pc_coarse_mirror_tu(int64_t n, int64_t lda, double* __restrict__ A) {
   const int64_t r = blockIdx.y;
@@ -2836,10 +3034,16 @@ static int shell_pc_coarse_setup(femo_shell* s, const femo_vec* vals, const uint
   FEMO_HIP_CHECK(hipMemsetAsync(s->d_cs_A, 0, N * N * sizeof(double), st));
   FEMO_HIP_CHECK(hipMemsetAsync(s->d_cs_info, 0, 4 * sizeof(int32_t), st));
   if (s->hermite && s->d_lvl_node != nullptr && !femo_env_flag("FEMO_SHELL_TRILINEAR") && !femo_env_flag("FEMO_SHELL_NO_BLOCKS")) {
-    for (int pass = 0; pass < 2; ++pass)
-      hipLaunchKernelGGL(k_pc_coarse_galerkin_h, dim3((unsigned)s->cs_items), dim3(256), CGH_LDS, st, pass, s->cs_level, s->pc_width, s->level_off[s->cs_level], N,
+    if (femo_env_flag("FEMO_SHELL_CG_ATOMIC")) {
+      for (int pass = 0; pass < 2; ++pass)
+        hipLaunchKernelGGL(k_pc_coarse_galerkin_h, dim3((unsigned)s->cs_items), dim3(256), CGH_LDS, st, pass, s->cs_level, s->pc_width, s->level_off[s->cs_level], N,
+                           s->n_unode, s->d_cs_ptr, s->d_cs_pts, s->d_cs_nbr, s->d_cs_pcell, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_ell_idx,
+                           s->d_cs_w4, s->d_cs_A, s->d_cs_info);
+    } else {
+      hipLaunchKernelGGL(k_pc_coarse_galerkin_mm, dim3((unsigned)s->cs_items), dim3(MM_THREADS), MM_LDS, st, s->cs_level, s->pc_width, s->level_off[s->cs_level], N,
                          s->n_unode, s->d_cs_ptr, s->d_cs_pts, s->d_cs_nbr, s->d_cs_pcell, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_ell_idx,
                          s->d_cs_w4, s->d_cs_A, s->d_cs_info);
+    }
     hipLaunchKernelGGL(k_pc_coarse_mirror_tu, dim3(sgrid(n, 256), (unsigned)n), dim3(256), 0, st, n, N, s->d_cs_A);
     s->hermite_on = true;
   } else {
@@ -3100,6 +3304,7 @@ int femo_shell_pc_hermite(femo_shell* s, const float* fin_w4, const int64_t* hp_
   }
   FEMO_HIP_CHECK(hipStreamSynchronize(st));
   FEMO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pc_coarse_galerkin_h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CGH_LDS));
+  FEMO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pc_coarse_galerkin_mm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MM_LDS));
   s->hermite = true;
   s->pc_vals_uid = 0; s->pc_vals_gen = 0;
   return 0;
