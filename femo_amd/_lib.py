@@ -110,6 +110,7 @@ PROTOTYPES = {
     "femo_shell_pc_coarse": (C.c_int, [H, C.c_int, C.c_void_p, c_i64] + [C.c_void_p] * 6),
     "femo_shell_pc_coarse_matrix": (C.c_int, [H, H, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(c_i64)]),
     "femo_shell_pc_hermite": (C.c_int, [H] + [C.c_void_p] * 11),
+    "femo_shell_pc_block_items": (C.c_int, [H, C.c_int64] + [C.c_void_p] * 4),
     "femo_shell_pc_weights": (C.c_int, [H, C.c_double, C.c_double]),
     "femo_shell_pc_apply": (C.c_int, [H, H, C.c_void_p, H, H]),
     "femo_shell_pnorm_stress": (C.c_int, [H, C.c_double, C.c_double, H, H, C.c_double, C.c_double, C.c_double, C.c_double,

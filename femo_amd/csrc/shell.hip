@@ -97,6 +97,11 @@ struct femo_shell {
   // 64^2 (one) 104 / 100 / 101 / 101; trilinear spaces at 362^2: 252 / 205 / 200.  A weight on the coarse solve (0.7, 2, 4)
   // or per-level weights change nothing beyond that.
   double w_levels = 0.3, w_coarse = 1.0;
+  // items of k_pc_galerkin_blocks_w (femo_shell_pc_block_items): points grouped by (level above the coarse solve, cell)
+  int64_t bi_items = 0;
+  int64_t* d_bi_ptr = nullptr;
+  int32_t *d_bi_lvl = nullptr, *d_bi_pts = nullptr, *d_bi_pcell = nullptr;
+  uint8_t* d_fixbits = nullptr;
   float4* d_fin_w4 = nullptr;
   int64_t* d_hp_rowptr = nullptr;
   int32_t* d_hp_cols = nullptr;
@@ -1403,6 +1408,183 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_galerkin_blocks_h(int64_t n_pts
     if (key < 0) continue;
     const double val = (&h_val[0][0])[i];
     if (val != 0.0) atomicAdd(&blk[36 * (int64_t)key + (i % 36)], val);
+  }
+}
+
+// 6 x 6 Galerkin node blocks of the levels above the coarse solve, Hermite-type spaces, second version (round 4).  The
+// version above walks every row three times per level from a thread per (point, level, component): K was fetched nine
+// times (9 GB at 1.97 M dofs, 10.5 ms).  Here a WAVE takes an item -- at most 64 points of one cell of one level, so that
+// all of them share the cell's eight nodes -- with lanes = (node a of the cell, column f' of the block):
+//   per point p: the lanes first fetch the point's column indices and the level-l cells of its column points (one per lane:
+//   two dependent loads per POINT, not per block); then, block by block, M[fa] += (K_pq)[fa][.] . u with u the column f' of
+//   W_q,b and b the corner of q's cell that IS node a (b = a - cell offset; no match: nothing) -- the weight gathers of
+//   the blocks are independent of each other; last acc[r] += (W_p,a^T M)[r] (r = 0..5);
+//   per item: one flush of the upper triangles with atomics (the items of a cell and the neighbouring cells share nodes).
+// The cell offset of a column point is at most one cell per axis when elements are smaller than the cells of the finest
+// lattice; a larger one sets info[1] bit 1 and the caller falls back to the kernel above.
+__global__ void k_point_fixbits(int64_t n_pts, const uint8_t* __restrict__ fixed, uint8_t* __restrict__ bits) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pts) return;
+  bits[p] = fixed == nullptr ? 0 : (uint8_t)((fixed[3 * p] ? 1 : 0) | (fixed[3 * p + 1] ? 2 : 0) | (fixed[3 * p + 2] ? 4 : 0));
+}
+
+__global__ __launch_bounds__(256) void k_pc_galerkin_blocks_w(int64_t n_items, int64_t n_pts, int64_t n_unode, const int64_t* __restrict__ item_ptr,
+                                                              const int32_t* __restrict__ item_lvl, const int32_t* __restrict__ item_pts,
+                                                              const int32_t* __restrict__ pcell, const int64_t* __restrict__ brow,
+                                                              const int32_t* __restrict__ bcols, const double* __restrict__ vals,
+                                                              const uint8_t* __restrict__ fixbits, const int32_t* __restrict__ lvl_node,
+                                                              const float4* __restrict__ lvl_w4, double* __restrict__ blk, int32_t* __restrict__ info) {
+  constexpr int EC = 32;                                                   // blocks staged per round
+  __shared__ double s_K[4][3][3 * EC];                                     // rows fa of the staged blocks (columns of fixed dofs zeroed)
+  __shared__ float4 s_W[4][EC * 8];                                        // [block e][node a of THIS cell]: weight of the corner of q's cell that is node a, or 0
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t item = (int64_t)blockIdx.x * 4 + wv;
+  if (item >= n_items) return;
+  const int a = lane & 7, fc = lane >> 3;                                  // node of the cell, column of the block (fc < 6)
+  // column f' = fc of W_q,b as a 3-vector u = (sg[k] * w[ix[k]])_k with w = (alpha, sigma) of the corner: displacement column
+  // fc < 3: alpha e_fc; fc = 3: (0, -s2, s1); 4: (s2, 0, -s0); 5: (-s1, s0, 0); rotation column: w e_(fc-3) for fc >= 3
+  int ixu[3] = {0, 0, 0};
+  double sgu[3] = {0.0, 0.0, 0.0}, sgr[3] = {0.0, 0.0, 0.0};
+  if (fc < 3) sgu[fc] = 1.0;
+  else if (fc == 3) { ixu[1] = 3; sgu[1] = -1.0; ixu[2] = 2; sgu[2] = 1.0; sgr[0] = 1.0; }
+  else if (fc == 4) { ixu[0] = 3; sgu[0] = 1.0; ixu[2] = 1; sgu[2] = -1.0; sgr[1] = 1.0; }
+  else if (fc == 5) { ixu[0] = 2; sgu[0] = -1.0; ixu[1] = 1; sgu[1] = 1.0; sgr[2] = 1.0; }
+  const int64_t pbeg = item_ptr[item], pend = item_ptr[item + 1];
+  const int lv = item_lvl[item];
+  const int32_t* ln = lvl_node + (int64_t)lv * n_pts * 8;
+  const float4* lw = lvl_w4 + (int64_t)lv * n_pts * 8;
+  const int32_t* pc = pcell + (int64_t)lv * n_pts;
+  const int32_t pfirst = item_pts[pbeg];
+  const int32_t node_a = ln[(int64_t)pfirst * 8 + a];
+  const int32_t ck = pc[pfirst];
+  const int cx = ck & 1023, cy = (ck >> 10) & 1023, cz = ck >> 20;
+  double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  int far = 0;
+  double (*sK)[3 * EC] = s_K[wv];
+  float4* sW = s_W[wv];
+  const float* sWf = reinterpret_cast<const float*>(sW);
+  // three-stage software pipeline over the item's points: every iteration issues ONE level of the chain point id -> row
+  // extent (+ the point's own weights and Dirichlet bits) -> column indices for a later point, after the loads of the current
+  // point, so that a point's round starts with its column indices in registers
+  const int64_t npt = pend - pbeg;
+  int32_t p_2 = npt > 2 ? item_pts[pbeg + 2] : 0;
+  int32_t p_1 = npt > 1 ? item_pts[pbeg + 1] : 0;
+  int64_t k0_1 = 0; int nb_1 = 0; float4 wp_1 = float4{0.f, 0.f, 0.f, 0.f}; int fi_1 = 0;
+  if (npt > 1) {
+    k0_1 = brow[p_1]; nb_1 = (int)(brow[p_1 + 1] - k0_1); wp_1 = lw[(int64_t)p_1 * 8 + a]; fi_1 = fixbits == nullptr ? 0 : fixbits[p_1];
+  }
+  int32_t p_0 = pfirst;
+  int64_t k0_0 = brow[p_0];
+  int nb_0 = (int)(brow[p_0 + 1] - k0_0);
+  float4 wp_0 = lw[(int64_t)p_0 * 8 + a];
+  int fi_0 = fixbits == nullptr ? 0 : fixbits[p_0];
+  int32_t cj_0 = lane < min(EC, nb_0) ? bcols[k0_0 + lane] : 0;
+  auto advance = [&](int64_t ip) {
+    const int64_t left = pend - ip;
+    cj_0 = left > 1 && lane < min(EC, nb_1) ? bcols[k0_1 + lane] : 0;
+    p_0 = p_1; k0_0 = k0_1; nb_0 = nb_1; wp_0 = wp_1; fi_0 = fi_1;
+    if (left > 2) {
+      k0_1 = brow[p_2]; nb_1 = (int)(brow[p_2 + 1] - k0_1); wp_1 = lw[(int64_t)p_2 * 8 + a]; fi_1 = fixbits == nullptr ? 0 : fixbits[p_2];
+    }
+    p_1 = p_2;
+    p_2 = left > 3 ? item_pts[ip + 3] : 0;
+  };
+  for (int64_t ip = pbeg; ip < pend; ++ip) {
+    const int32_t p = p_0;
+    const int64_t k0 = k0_0;
+    const int nb = nb_0;
+    const int64_t len = 3 * (int64_t)nb;
+    const float4 wp = wp_0;
+    const int fi = fi_0;
+    const int32_t cj_first = cj_0;
+    const bool pu = p < n_unode;
+    double M0 = 0.0, M1 = 0.0, M2 = 0.0;
+    if (nb == 0) advance(ip);
+    for (int e0 = 0; e0 < nb; e0 += EC) {
+      const int cnt = min(EC, nb - e0);
+      // the round's loads, all issued before anything is used: the blocks' rows (3 x 3 cnt contiguous doubles), lane e < cnt the
+      // column index of block e0 + e, then -- one dependent step -- its level-l cell and Dirichlet bits and the eight weights
+      double kv[2][3];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int fa = 0; fa < 3; ++fa) {
+          const int idx = lane + 64 * h;
+          kv[h][fa] = idx < 3 * cnt ? vals[9 * k0 + fa * len + 3 * e0 + idx] : 0.0;
+        }
+      int32_t my_cj = cj_first, my_meta = -1;
+      if (e0 > 0) my_cj = lane < cnt ? bcols[k0 + e0 + lane] : 0;
+      float4 wl[4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int idx = lane + 64 * h, e = idx >> 3;
+        const int32_t cje = __shfl(my_cj, e);
+        wl[h] = e < cnt ? lw[(int64_t)(cje / 3) * 8 + (idx & 7)] : float4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (lane < cnt) {
+        const int32_t q = my_cj / 3;
+        const int32_t pk = pc[q];
+        const int ox = (pk & 1023) - cx + 1, oy = ((pk >> 10) & 1023) - cy + 1, oz = (pk >> 20) - cz + 1;
+        if ((unsigned)ox > 2u || (unsigned)oy > 2u || (unsigned)oz > 2u) far = 1;
+        else my_meta = ox | (oy << 2) | (oz << 4) | ((fixbits == nullptr ? 0 : fixbits[q]) << 6) | ((my_cj < 3 * n_unode ? 1 : 0) << 9);
+      }
+      if (e0 == 0) advance(ip);                            // the pipeline's loads for the points after this one
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int idx = lane + 64 * h;
+        const int32_t me = __shfl(my_meta, idx / 3);
+        const bool off = idx >= 3 * cnt || me < 0 || ((me >> (6 + idx % 3)) & 1);       // column of a fixed dof
+#pragma unroll
+        for (int fa = 0; fa < 3; ++fa)
+          if (idx < 3 * EC) sK[fa][idx] = off ? 0.0 : kv[h][fa];
+      }
+      // weights: entry (e, corner b of q's cell) goes to the slot of the node a = b + cell offset of THIS cell, if it is one
+#pragma unroll
+      for (int h = 0; h < 4; ++h) sW[lane + 64 * h] = float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int idx = lane + 64 * h, e = idx >> 3, b = idx & 7;
+        const int32_t me = __shfl(my_meta, e);
+        const int tx = (b & 1) + (me & 3) - 1, ty = ((b >> 1) & 1) + ((me >> 2) & 3) - 1, tz = (b >> 2) + ((me >> 4) & 3) - 1;
+        if (e < cnt && me >= 0 && (unsigned)tx < 2u && (unsigned)ty < 2u && (unsigned)tz < 2u) sW[8 * e + tx + 2 * ty + 4 * tz] = wl[h];
+      }
+      const uint64_t qmask = __ballot(lane < cnt && my_meta >= 0 && ((my_meta >> 9) & 1));      // blocks with a displacement column
+      // LDS only (the wave's LDS operations execute in order): a fence would also wait for the loads of the pipeline
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const float* wa = sWf + 4 * a;
+#pragma unroll 2
+      for (int e = 0; e < cnt; ++e) {
+        const float* w = wa + 32 * e;
+        double u0, u1, u2;
+        if ((qmask >> e) & 1) { u0 = sgu[0] * (double)w[ixu[0]]; u1 = sgu[1] * (double)w[ixu[1]]; u2 = sgu[2] * (double)w[ixu[2]]; }
+        else { const double al = (double)w[0]; u0 = sgr[0] * al; u1 = sgr[1] * al; u2 = sgr[2] * al; }
+        const double* k = &sK[0][3 * e];
+        M0 += k[0] * u0 + k[1] * u1 + k[2] * u2;
+        M1 += k[3 * EC] * u0 + k[3 * EC + 1] * u1 + k[3 * EC + 2] * u2;
+        M2 += k[6 * EC] * u0 + k[6 * EC + 1] * u1 + k[6 * EC + 2] * u2;
+      }
+      // LDS only (the wave's LDS operations execute in order): a fence would also wait for the loads of the pipeline
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (fi & 1) M0 = 0.0;
+    if (fi & 2) M1 = 0.0;
+    if (fi & 4) M2 = 0.0;
+    if (pu) {
+      const double al = (double)wp.x, s0 = (double)wp.y, s1 = (double)wp.z, s2 = (double)wp.w;
+      acc[0] += al * M0; acc[1] += al * M1; acc[2] += al * M2;
+      acc[3] += -s2 * M1 + s1 * M2;
+      acc[4] += s2 * M0 - s0 * M2;
+      acc[5] += -s1 * M0 + s0 * M1;
+    } else {
+      const double w = (double)wp.x;
+      acc[3] += w * M0; acc[4] += w * M1; acc[5] += w * M2;
+    }
+  }
+  if (far && info != nullptr) atomicOr(&info[1], 2);
+  if (fc < 6 && node_a >= 0) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+      if (r <= fc && acc[r] != 0.0) atomicAdd(&blk[36 * (int64_t)node_a + 6 * r + fc], acc[r]);
   }
 }
 
@@ -2936,6 +3118,7 @@ int femo_shell_destroy(femo_shell* s) {
   hipFree(s->d_r); hipFree(s->d_p); hipFree(s->d_q); hipFree(s->d_dinv); hipFree(s->d_scal); hipFree(s->d_part); hipFree(s->d_flag);
   hipFree(s->d_ell_idx); hipFree(s->d_ell_w);
   hipFree(s->d_par_rowptr); hipFree(s->d_par_cols); hipFree(s->d_par_vals); hipFree(s->d_chi_rowptr); hipFree(s->d_chi_cols); hipFree(s->d_chi_vals);
+  hipFree(s->d_bi_ptr); hipFree(s->d_bi_lvl); hipFree(s->d_bi_pts); hipFree(s->d_bi_pcell); hipFree(s->d_fixbits);
   hipFree(s->d_coarse); hipFree(s->d_cblk); hipFree(s->d_lvl_node); hipFree(s->d_lvl_w); hipFree(s->d_dinv3); hipFree(s->d_t); hipFree(s->d_e); hipFree(s->d_z); hipFree(s->d_fin_idx); hipFree(s->d_fin_w);
   delete s;
   return 0;
@@ -3260,6 +3443,33 @@ int femo_shell_pc_coarse(femo_shell* s, int level, const int32_t* node_xyz, int6
   FEMO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pc_coarse_galerkin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CG_LDS));
   s->cs_level = level; s->cs_n = n; s->cs_N = N; s->cs_items = n_items;
   s->pc_vals_uid = 0; s->pc_vals_gen = 0;                 // next solve recomputes the preconditioner's numbers
+  return 0;
+}
+
+// Items of the node-block set-up kernel for the Hermite-type spaces (fea/shell.py::node_block_items): the points of every
+// level above the coarse solve grouped by lattice cell, at most 64 per item; pcell[level][point] = packed cell coordinates.
+int femo_shell_pc_block_items(femo_shell* s, int64_t n_items, const int64_t* item_ptr, const int32_t* item_lvl, const int32_t* item_pts,
+                              const int32_t* pcell) {
+  FEMO_REQUIRE(s && item_ptr && item_lvl && item_pts && pcell && n_items > 0, "null argument");
+  FEMO_REQUIRE(s->hermite, "femo_shell_pc_block_items needs femo_shell_pc_hermite first");
+  FEMO_REQUIRE(s->d_bi_ptr == nullptr, "the shell already has its node-block items");
+  hipStream_t st = s->ctx->stream;
+  FEMO_HIP_CHECK(hipSetDevice(s->ctx->device));
+  const int64_t n_pts = s->n_dof / 3;
+  const int n_above = s->pc_levels - 1 - s->cs_level;
+  for (int64_t i = 0; i < n_items; ++i) {
+    FEMO_REQUIRE(item_lvl[i] >= 0 && item_lvl[i] < n_above, "item level out of range");
+    FEMO_REQUIRE(item_ptr[i + 1] > item_ptr[i] && item_ptr[i + 1] - item_ptr[i] <= 64, "an item holds 1 .. 64 points");
+  }
+  FEMO_REQUIRE(item_ptr[0] == 0 && item_ptr[n_items] == (int64_t)n_above * n_pts, "every point belongs to one item per level");
+  FEMO_TRY(to_device(&s->d_bi_ptr, item_ptr, n_items + 1, st));
+  FEMO_TRY(to_device(&s->d_bi_lvl, item_lvl, n_items, st));
+  FEMO_TRY(to_device(&s->d_bi_pts, item_pts, item_ptr[n_items], st));
+  FEMO_TRY(to_device(&s->d_bi_pcell, pcell, (int64_t)n_above * n_pts, st));
+  FEMO_HIP_CHECK(hipMalloc(&s->d_fixbits, n_pts));
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  s->bi_items = n_items;
+  s->pc_vals_uid = 0; s->pc_vals_gen = 0;
   return 0;
 }
 
@@ -3710,7 +3920,23 @@ static int shell_pc_setup(femo_shell* s, const femo_vec* vals, const uint8_t* fi
     if (s->cs_ready && s->d_lvl_node != nullptr && getenv("FEMO_SHELL_NO_BLOCKS") == nullptr) {
       const int64_t nd0 = s->level_off[s->cs_level + 1], nd1 = s->level_off[s->pc_levels];
       FEMO_HIP_CHECK(hipMemsetAsync(s->d_cblk + 36 * nd0, 0, (nd1 - nd0) * 36 * sizeof(double), st));
-      if (s->hermite_on)
+      bool by_items = s->hermite_on && s->bi_items > 0 && !femo_env_flag("FEMO_SHELL_BLOCKS_BY_ROWS");
+      if (by_items) {
+        hipLaunchKernelGGL(k_point_fixbits, dim3(sgrid(n / 3, 256)), dim3(256), 0, st, n / 3, d_fixed, s->d_fixbits);
+        hipLaunchKernelGGL(k_pc_galerkin_blocks_w, dim3((unsigned)((s->bi_items + 3) / 4)), dim3(256), 0, st, s->bi_items, n / 3, s->n_unode, s->d_bi_ptr,
+                           s->d_bi_lvl, s->d_bi_pts, s->d_bi_pcell, s->d_brow, s->d_bcols, vals->d, (const uint8_t*)s->d_fixbits, s->d_lvl_node,
+                           s->d_lvl_w4, s->d_cblk, s->d_cs_info);
+        int32_t binfo[4] = {0, 0, 0, 0};
+        FEMO_HIP_CHECK(hipMemcpyAsync(binfo, s->d_cs_info, sizeof binfo, hipMemcpyDeviceToHost, st));
+        FEMO_HIP_CHECK(hipStreamSynchronize(st));
+        if (binfo[1] & 2) {                                 // an element spans more than a cell of some level: the row-wise kernel has no such limit
+          by_items = false;
+          s->bi_items = 0;
+          FEMO_HIP_CHECK(hipMemsetAsync(s->d_cblk + 36 * nd0, 0, (nd1 - nd0) * 36 * sizeof(double), st));
+        }
+      }
+      if (by_items) {
+      } else if (s->hermite_on)
         hipLaunchKernelGGL(k_pc_galerkin_blocks_h, dim3(sgrid(n / 3), 3 * ((s->pc_width - first_slot) / 8)), dim3(SH_BLOCK), 0, st, n / 3, s->n_unode,
                            s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_lvl_node, s->d_lvl_w4, s->d_cblk);
       else

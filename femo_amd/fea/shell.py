@@ -488,6 +488,34 @@ def hermite_device_arrays(space: ShellSpace, L: dict, cs_level: int) -> dict:
                 par_w5=H["par_w5"], chi_w5=H["chi_w5"], lvl_w4=lvl_w4, cs_w4=cs_w4, down=down)
 
 
+def node_block_items(L: dict, first_level: int, chunk: int = 64):
+    """Arrays of `femo_shell_pc_block_items`: for the levels ``first_level`` .. finest of ``lattice_pc`` the points grouped by
+    the lattice cell that contains them (all points of a cell share its eight nodes), cut into items of at most ``chunk``
+    points, and the packed cell coordinates of every point per level."""
+    levels, off = L["levels"], L["level_offsets"]
+    n_pts = L["ell_idx"].shape[0] // 3
+    ptrs, lvls, pts, cells = [np.zeros(1, dtype=np.int64)], [], [], []
+    base = 0
+    for j, l in enumerate(range(first_level, len(levels))):
+        m, g = levels[l], L["level_nodes"][l]
+        node0 = L["ell_idx"][0::3, 8 * l].astype(np.int64) // 6 - off[l]      # corner (0, 0, 0) of every point's cell
+        gid = g[node0]
+        if m + 1 > 1023:
+            raise ValueError("lattice level too fine for the packed cell coordinates")
+        cells.append((gid % (m + 1)) | (((gid // (m + 1)) % (m + 1)) << 10) | ((gid // ((m + 1) ** 2)) << 20))
+        order = np.argsort(node0, kind="stable")
+        skey = node0[order]
+        starts = np.flatnonzero(np.r_[True, skey[1:] != skey[:-1]])
+        ends = np.r_[starts[1:], skey.size]
+        cuts = np.concatenate([np.arange(a, b, chunk) for a, b in zip(starts, ends)])
+        ptrs.append(base + np.r_[cuts[1:], skey.size].astype(np.int64))
+        lvls.append(np.full(cuts.size, j, dtype=np.int32))
+        pts.append(order.astype(np.int32))
+        base += n_pts
+    return dict(item_ptr=np.ascontiguousarray(np.concatenate(ptrs)), item_lvl=np.ascontiguousarray(np.concatenate(lvls)),
+                item_pts=np.ascontiguousarray(np.concatenate(pts)), pcell=np.ascontiguousarray(np.stack(cells).astype(np.int32)))
+
+
 def coarse_solve_plan(L: dict, max_unknowns: int = 3200, chunk: int = 256):
     """Arrays of `femo_shell_pc_coarse` for the lattice levels of ``lattice_pc``: the coarse-solve level is the finest
     level (never the finest of the hierarchy) with at most ``max_unknowns`` unknowns; its points are grouped by (coarse
@@ -606,6 +634,8 @@ class DeviceShell:
             check(self.lib.femo_shell_pc_hermite(self.handle, q(A["fin_w4"]), q(A["hp_rowptr"]), q(A["hp_cols"]), q(A["hp_w4"]), q(A["par_w5"]),
                                                  q(A["chi_w5"]), q(A["lvl_w4"]), q(A["cs_w4"]), q(dn.get("rowptr")), q(dn.get("cols")), q(dn.get("w5"))))
             self.hermite = True
+            B = node_block_items(L, self.coarse_level + 1)
+            check(self.lib.femo_shell_pc_block_items(self.handle, B["item_lvl"].size, q(B["item_ptr"]), q(B["item_lvl"]), q(B["item_pts"]), q(B["pcell"])))
 
     LEVEL_WEIGHT = 0.3          # the library's default (femo_shell_pc_weights; oracle: LatticePreconditioner.level_weight)
 

@@ -126,3 +126,35 @@ def test_shell_pde_small_members():
     w = np.arange(S.n_dof, dtype=np.float64)
     ux, uy, uz = pde.compute_nodal_disp(w)
     assert np.array_equal(np.stack([ux, uy, uz], axis=1), S.vertex_displacement(w))
+
+
+def test_node_block_items_group_points_by_cell():
+    """`node_block_items` (plan of k_pc_galerkin_blocks_w): per level above the coarse solve every point appears once, the points of
+    an item share their eight lattice nodes, items hold 1 .. 64 points, and the packed cell coordinates are those of the
+    item's corner node."""
+    from femo_amd.fea.mesh import createCylindricalRoofMesh
+    from femo_amd.fea.shell import ShellSpace, coarse_solve_plan, lattice_pc, node_block_items
+    x, conn = createCylindricalRoofMesh(12, 12)
+    space = ShellSpace(np.asarray(x), np.asarray(conn))
+    L = lattice_pc(space)
+    c = coarse_solve_plan(L, 300)["level"]
+    B = node_block_items(L, c + 1)
+    n_pts = L["ell_idx"].shape[0] // 3
+    n_above = len(L["levels"]) - 1 - c
+    assert n_above >= 2 and B["pcell"].shape == (n_above, n_pts)
+    ptr, lvl, pts = B["item_ptr"], B["item_lvl"], B["item_pts"]
+    assert ptr[0] == 0 and ptr[-1] == n_above * n_pts and np.all(np.diff(ptr) >= 1) and np.all(np.diff(ptr) <= 64)
+    for j in range(n_above):
+        l = c + 1 + j
+        sel = np.flatnonzero(lvl == j)
+        allp = np.concatenate([pts[ptr[i]:ptr[i + 1]] for i in sel])
+        assert np.array_equal(np.sort(allp), np.arange(n_pts))
+        nodes = L["ell_idx"][0::3, 8 * l:8 * l + 8] // 6
+        mm = L["levels"][l]
+        for i in sel[:: max(1, sel.size // 40)]:
+            p = pts[ptr[i]:ptr[i + 1]]
+            assert np.all(nodes[p] == nodes[p[0]])
+            g = L["level_nodes"][l][nodes[p[0], 0] - L["level_offsets"][l]]
+            ck = B["pcell"][j, p[0]]
+            assert (ck & 1023, (ck >> 10) & 1023, ck >> 20) == (g % (mm + 1), (g // (mm + 1)) % (mm + 1), g // (mm + 1) ** 2)
+            assert np.all(B["pcell"][j, p] == ck)
