@@ -76,6 +76,7 @@ struct femo_shell {
   // diagonal levels 0 .. cs_level
   int cs_level = -1;
   int64_t cs_n = 0, cs_N = 0, cs_items = 0;            // unknowns of the level (6 x nodes), padded to 64s, items of the Galerkin kernel
+  int64_t cs_max_item = 0;                             // points of the largest item
   bool cs_ready = false;                               // d_cs_A holds the factors of the inverse for the current stiffness and mask
   int64_t* d_cd_rowptr = nullptr;                      // composite restriction finest lattice -> levels cs_level .. L - 2
   int32_t* d_cd_cols = nullptr;
@@ -1776,9 +1777,14 @@ __global__ __launch_bounds__(256) void k_pc_coarse_galerkin_h(int pass, int c, i
 //   4. D[(f, a)][(f', bl)] += W^T Y with v_mfma_f64_16x16x4 (K = 3 MM_PTS = 24: six steps), accumulators in registers across
 //      the chunks of the item: 3 x 24 tiles of 16 x 16, nine per wave.
 // The tiles (Theta_1/2 rows, U columns) are not formed: k_pc_coarse_mirror_tu fills the (Theta, U) quadrant from (U, Theta).
-// LDS atomics of the version before (k_pc_coarse_galerkin_h, 15 G of them at 1.97 M dofs): 18.7 ms; this kernel: see DESIGN.md.
-constexpr int MM_PTS = 8, MM_K = 3 * MM_PTS, MM_YP = 400, MM_WP = 25, MM_STAGE = 256, MM_THREADS = 512;
-constexpr size_t MM_LDS = (size_t)MM_K * MM_YP * 8 + 48 * MM_WP * 8 + MM_STAGE * 9 * 8 + MM_STAGE * 8 * 16 + MM_STAGE * 4 + MM_PTS * 8 * 16 + 4 * (MM_PTS + 1) + 4 * MM_PTS * 2;
+// LDS atomics of the version before (k_pc_coarse_galerkin_h, 15 G of them at 1.97 M dofs): 18.7 ms; this kernel 6.9 ms as first
+// written, 5.5 with the item's row extents loaded once and the next chunk's column indices and values prefetched under the
+// MFMA phase, the operands of block e + 1 fetched before the read-modify-writes of block e, and the f' blocks of Y 66
+// doubles apart.  Phase times at 248 k dofs (0.92 ms): step 2 0.49, MFMA 0.19, staging 0.12 -- step 2 is bound by the LDS
+// instruction rate (per block and wave: 13 operand reads, 9 of them broadcasts of the block's values, and 6 for Y).
+constexpr int MM_PTS = 8, MM_K = 3 * MM_PTS, MM_YP = 400, MM_YF = 66, MM_WP = 25, MM_STAGE = 256, MM_THREADS = 512, MM_ITEM = 256;
+constexpr size_t MM_LDS = (size_t)MM_K * MM_YP * 8 + 48 * MM_WP * 8 + MM_STAGE * 9 * 8 + MM_STAGE * 8 * 16 + MM_STAGE * 4 + MM_PTS * 8 * 16 +
+                          4 * (MM_ITEM + 1) + 4 * MM_ITEM * 2 + MM_ITEM + 64;
 __global__ __launch_bounds__(MM_THREADS) void k_pc_coarse_galerkin_mm(int c, int width, int64_t off_c, int64_t lda, int64_t n_unode,
                                                                       const int64_t* __restrict__ item_ptr, const int32_t* __restrict__ item_pts,
                                                                       const int32_t* __restrict__ item_nbr, const int32_t* __restrict__ pcell,
@@ -1787,24 +1793,54 @@ __global__ __launch_bounds__(MM_THREADS) void k_pc_coarse_galerkin_mm(int c, int
                                                                       const int32_t* __restrict__ ell_idx, const float4* __restrict__ cs_w4,
                                                                       double* __restrict__ A, int32_t* __restrict__ info) {
   extern __shared__ double mm_lds[];
-  double (*Y)[MM_YP] = reinterpret_cast<double (*)[MM_YP]>(mm_lds);                         // [3 pl + fa][64 f' + bl]
+  double (*Y)[MM_YP] = reinterpret_cast<double (*)[MM_YP]>(mm_lds);                         // [3 pl + fa][MM_YF f' + bl]
   double (*Wt)[MM_WP] = reinterpret_cast<double (*)[MM_WP]>(mm_lds + MM_K * MM_YP);          // [8 f + a][3 pl + fa]
   double (*s_val)[9] = reinterpret_cast<double (*)[9]>(&Wt[48][0]);
   float4 (*s_wb)[8] = reinterpret_cast<float4 (*)[8]>(s_val + MM_STAGE);
   int32_t* s_meta = reinterpret_cast<int32_t*>(s_wb + MM_STAGE);
   float4 (*s_wpt)[8] = reinterpret_cast<float4 (*)[8]>(s_meta + MM_STAGE);
-  int32_t* s_scan = reinterpret_cast<int32_t*>(s_wpt + MM_PTS);
-  int32_t* s_k0 = s_scan + MM_PTS + 1;
-  int32_t* s_fi = s_k0 + MM_PTS;
+  int32_t* s_S = reinterpret_cast<int32_t*>(s_wpt + MM_PTS);               // blocks before point i of the item (MM_ITEM + 1 entries)
+  int32_t* s_ik0 = s_S + MM_ITEM + 1;                                      // first block of point i
+  int32_t* s_ipt = s_ik0 + MM_ITEM;                                        // point i of the item
+  uint8_t* s_ifi = reinterpret_cast<uint8_t*>(s_ipt + MM_ITEM);            // its Dirichlet bits
+  int32_t* s_wsum = reinterpret_cast<int32_t*>(s_ifi + MM_ITEM);           // scan scratch (4 waves)
   const int64_t item = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int64_t pbeg = item_ptr[item], pend = item_ptr[item + 1];
+  const int np = (int)(pend - pbeg);                                       // <= MM_ITEM (femo_shell_pc_coarse checks)
   const int32_t pfirst = item_pts[pbeg];
   const int gi = pfirst >= n_unode ? 1 : 0;                                // 0: displacement points (rows U and Theta), 1: rotation points (Theta)
   const int64_t e0 = (int64_t)(3 * pfirst) * width + 8 * c;
   const int32_t pk0 = pcell[pfirst];
   const int bx = pk0 & 1023, by = (pk0 >> 10) & 1023, bz = pk0 >> 20;
   const int li = lane & 15, lk = lane >> 4;
+  // the item's points, their block rows and Dirichlet bits, once: two dependent loads per ITEM instead of per chunk
+  {
+    int32_t len = 0;
+    if (t < MM_ITEM) {
+      int32_t i = 0, k0 = 0, fi = 0;
+      if (t < np) {
+        i = item_pts[pbeg + t];
+        const int64_t b0 = brow[i];
+        k0 = (int32_t)b0; len = (int32_t)(brow[i + 1] - b0);
+        fi = fixed == nullptr ? 0 : (fixed[3 * i] ? 1 : 0) | (fixed[3 * i + 1] ? 2 : 0) | (fixed[3 * i + 2] ? 4 : 0);
+      }
+      s_ipt[t] = i; s_ik0[t] = k0; s_ifi[t] = (uint8_t)fi;
+      int32_t v = len;                                                     // inclusive scan within the wave
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const int32_t u = __shfl_up(v, d); if (lane >= d) v += u; }
+      if (lane == 63) s_wsum[wv] = v;
+      len = v;
+    }
+    __syncthreads();
+    if (t < MM_ITEM) {
+      int32_t base = 0;
+      for (int w = 0; w < wv; ++w) base += s_wsum[w];
+      s_S[t + 1] = base + len;
+      if (t == 0) s_S[0] = 0;
+    }
+    __syncthreads();
+  }
   // accumulators: N-tiles nt = wv + 8 j (j = 0..2), M-tiles mt = 0..2
   typedef double d4 __attribute__((ext_vector_type(4)));
   d4 acc[3][3];
@@ -1813,29 +1849,136 @@ __global__ __launch_bounds__(MM_THREADS) void k_pc_coarse_galerkin_mm(int c, int
 #pragma unroll
     for (int j = 0; j < 3; ++j) acc[mt][j] = d4{0.0, 0.0, 0.0, 0.0};
   int far = 0;
-  for (int64_t p0 = pbeg; p0 < pend; p0 += MM_PTS) {
-    const int npts = (int)min((int64_t)MM_PTS, pend - p0);
+  // block t of a chunk: which of its points, which block of that point's row
+  auto locate = [&](int i0, int npts, int f, int& q, int& lkk) {
+    q = 0;
+#pragma unroll
+    for (int qq = 1; qq < MM_PTS; ++qq) q += (qq < npts && s_S[i0 + qq] <= f) ? 1 : 0;
+    lkk = f - s_S[i0 + q];
+  };
+  // prefetch registers: column index and values of this thread's block of the NEXT chunk (issued before the MFMA phase)
+  int32_t pf_cj = 0;
+  double pf_v[9];
+  bool pf_ok = false;
+  auto prefetch = [&](int i0) {
+    pf_ok = false;
+    if (i0 >= np || t >= MM_STAGE) return;
+    const int npts = min(MM_PTS, np - i0);
+    const int f = s_S[i0] + t;
+    if (f >= s_S[i0 + npts]) return;
+    int q, lkk;
+    locate(i0, npts, f, q, lkk);
+    const int64_t k0 = s_ik0[i0 + q];
+    const int64_t len = 3 * (int64_t)(s_S[i0 + q + 1] - s_S[i0 + q]);
+    pf_cj = bcols[k0 + lkk];
+    const double* v = vals + 9 * k0 + 3 * lkk;
+#pragma unroll
+    for (int fa = 0; fa < 3; ++fa)
+#pragma unroll
+      for (int fb = 0; fb < 3; ++fb) pf_v[3 * fa + fb] = v[fa * len + fb];
+    pf_ok = true;
+  };
+  prefetch(0);
+  for (int i0 = 0; i0 < np; i0 += MM_PTS) {
+    const int npts = min(MM_PTS, np - i0);
     __syncthreads();                                                       // the MFMA phase of the chunk before has read Y and Wt
     for (int idx = t; idx < MM_K * MM_YP; idx += MM_THREADS) (&Y[0][0])[idx] = 0.0;
-    if (t < MM_PTS) {
-      int32_t k0 = 0, len = 0, fi = 0;
-      if (t < npts) {
-        const int32_t i = item_pts[p0 + t];
-        const int64_t b0 = brow[i];
-        k0 = (int32_t)b0; len = (int32_t)(brow[i + 1] - b0);
-        fi = fixed == nullptr ? 0 : (fixed[3 * i] ? 1 : 0) | (fixed[3 * i + 1] ? 2 : 0) | (fixed[3 * i + 2] ? 4 : 0);
-      }
-      s_k0[t] = k0; s_scan[t + 1] = len; s_fi[t] = fi;
-    }
     if (t >= 64 && t < 64 + MM_PTS * 8) {
       const int q = (t - 64) >> 3, a = (t - 64) & 7;
-      s_wpt[q][a] = q < npts ? cs_w4[(int64_t)item_pts[p0 + q] * 8 + a] : float4{0.f, 0.f, 0.f, 0.f};
+      s_wpt[q][a] = q < npts ? cs_w4[(int64_t)s_ipt[i0 + q] * 8 + a] : float4{0.f, 0.f, 0.f, 0.f};
     }
-    __syncthreads();
-    if (t == 0) {
-      int32_t run = 0;
-      s_scan[0] = 0;
-      for (int q = 0; q < MM_PTS; ++q) { run += s_scan[q + 1]; s_scan[q + 1] = run; }
+    const int S0 = s_S[i0], B = s_S[i0 + npts] - S0;
+    for (int base = 0; base < B; base += MM_STAGE) {
+      const int fblk = base + t;
+      if (t < MM_STAGE && fblk < B) {
+        int q, lkk;
+        locate(i0, npts, S0 + fblk, q, lkk);
+        int32_t cj;
+        double v9[9];
+        if (base == 0 && pf_ok) {
+          cj = pf_cj;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) v9[k] = pf_v[k];
+        } else {                                                           // rounds beyond the first (rare): not prefetched
+          const int64_t k0 = s_ik0[i0 + q];
+          const int64_t len = 3 * (int64_t)(s_S[i0 + q + 1] - s_S[i0 + q]);
+          cj = bcols[k0 + lkk];
+          const double* v = vals + 9 * k0 + 3 * lkk;
+#pragma unroll
+          for (int fa = 0; fa < 3; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < 3; ++fb) v9[3 * fa + fb] = v[fa * len + fb];
+        }
+        const int32_t pk = pcell[cj / 3];
+        const int ox = (pk & 1023) - bx + 1, oy = ((pk >> 10) & 1023) - by + 1, oz = (pk >> 20) - bz + 1;
+        if ((unsigned)ox > 2u || (unsigned)oy > 2u || (unsigned)oz > 2u) {
+          far = 1;                                                         // flagged; contributes nothing here
+          s_meta[t] = 1 | (1 << 2) | (1 << 4);
+#pragma unroll
+          for (int k = 0; k < 9; ++k) s_val[t][k] = 0.0;
+#pragma unroll
+          for (int b = 0; b < 8; ++b) s_wb[t][b] = float4{0.f, 0.f, 0.f, 0.f};
+        } else {
+          s_meta[t] = ox | (oy << 2) | (oz << 4) | ((cj >= 3 * n_unode ? 1 : 0) << 6) | (q << 8);
+          const int fi = s_ifi[i0 + q];
+          const int fj = fixed == nullptr ? 0 : (fixed[cj] ? 1 : 0) | (fixed[cj + 1] ? 2 : 0) | (fixed[cj + 2] ? 4 : 0);
+          const float4* wj = cs_w4 + (int64_t)(cj / 3) * 8;
+          float4 w8[8];
+#pragma unroll
+          for (int b = 0; b < 8; ++b) w8[b] = wj[b];
+#pragma unroll
+          for (int fa = 0; fa < 3; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < 3; ++fb) s_val[t][3 * fa + fb] = ((fi >> fa) & 1) || ((fj >> fb) & 1) ? 0.0 : v9[3 * fa + fb];
+#pragma unroll
+          for (int b = 0; b < 8; ++b) s_wb[t][b] = w8[b];
+        }
+      }
+      __syncthreads();
+      // Y of point pl = wv: its staged blocks are the slots [S[i0 + wv], S[i0 + wv + 1]) - S0 of this round.  Software
+      // pipelined: the meta words of up to 64 blocks sit in the lanes (readlane, no LDS round trip), the weight and the nine
+      // values of block e + 1 are loaded before the three read-modify-writes of block e -- per block one LDS latency, not three
+      if (wv < npts) {
+        const int pl = wv;
+        const int e_lo = max(s_S[i0 + pl] - S0, base) - base, e_hi = min(s_S[i0 + pl + 1] - S0, base + MM_STAGE) - base;
+        const int kq = lane & 7, fc = lane >> 3;
+        // column f' = fc of W_q,k' as a 3-vector u = (sg[k] w[ix[k]])_k, w = (alpha, sigma): displacement column fc < 3: alpha e_fc;
+        // 3: (0, -s2, s1); 4: (s2, 0, -s0); 5: (-s1, s0, 0); rotation column: w e_(fc - 3)
+        int ix0 = 0, ix1 = 0, ix2 = 0;
+        double sg0 = 0.0, sg1 = 0.0, sg2 = 0.0, sr0 = 0.0, sr1 = 0.0, sr2 = 0.0;
+        if (fc == 0) sg0 = 1.0; else if (fc == 1) sg1 = 1.0; else if (fc == 2) sg2 = 1.0;
+        else if (fc == 3) { ix1 = 3; sg1 = -1.0; ix2 = 2; sg2 = 1.0; sr0 = 1.0; }
+        else if (fc == 4) { ix0 = 3; sg0 = 1.0; ix2 = 1; sg2 = -1.0; sr1 = 1.0; }
+        else if (fc == 5) { ix0 = 2; sg0 = -1.0; ix1 = 1; sg1 = 1.0; sr2 = 1.0; }
+        const int fcl = fc < 6 ? fc : 0;
+        double* y0 = &Y[3 * pl][MM_YF * fcl];      // f' blocks 66 apart: with 64 the six f' lanes of a corner share their LDS banks
+        for (int eb = e_lo; eb < e_hi; eb += 64) {
+          const int cnt = min(64, e_hi - eb);
+          const int32_t my_m = lane < cnt ? s_meta[eb + lane] : 0;
+          const float* wf = reinterpret_cast<const float*>(&s_wb[eb][kq]);
+          float w0 = wf[ix0], w1 = wf[ix1], w2 = wf[ix2], wa = wf[0];
+          double K[9];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) K[k] = s_val[eb][k];
+          for (int e = 0; e < cnt; ++e) {
+            const int32_t m = __builtin_amdgcn_readlane(my_m, e);
+            const bool gj = (m >> 6) & 1;
+            const double u0 = gj ? sr0 * (double)wa : sg0 * (double)w0, u1 = gj ? sr1 * (double)wa : sg1 * (double)w1,
+                         u2 = gj ? sr2 * (double)wa : sg2 * (double)w2;
+            const double c0 = K[0] * u0 + K[1] * u1 + K[2] * u2, c1 = K[3] * u0 + K[4] * u1 + K[5] * u2, c2 = K[6] * u0 + K[7] * u1 + K[8] * u2;
+            if (e + 1 < cnt) {                                             // block e + 1's operands, before this block's read-modify-writes
+              const float* wn = reinterpret_cast<const float*>(&s_wb[eb + e + 1][kq]);
+              w0 = wn[ix0]; w1 = wn[ix1]; w2 = wn[ix2]; wa = wn[0];
+#pragma unroll
+              for (int k = 0; k < 9; ++k) K[k] = s_val[eb + e + 1][k];
+            }
+            const int ox = m & 3, oy = (m >> 2) & 3, oz = (m >> 4) & 3;
+            const int bl = (ox + (kq & 1)) + 4 * (oy + ((kq >> 1) & 1)) + 16 * (oz + (kq >> 2));
+            if (fc < 6) { y0[bl] += c0; y0[MM_YP + bl] += c1; y0[2 * MM_YP + bl] += c2; }
+          }
+        }
+      }
+      __syncthreads();
     }
     // W^T of the chunk: entry (m = 8 f + a, k = 3 pl + fa) = W_p,a[fa][f]
     for (int idx = t; idx < 48 * MM_K; idx += MM_THREADS) {
@@ -1858,69 +2001,8 @@ __global__ __launch_bounds__(MM_THREADS) void k_pc_coarse_galerkin_mm(int c, int
       }
       Wt[m][k] = v;
     }
+    prefetch(i0 + MM_PTS);                                                 // in flight during the MFMA phase
     __syncthreads();
-    const int B = s_scan[MM_PTS];
-    for (int base = 0; base < B; base += MM_STAGE) {
-      const int fblk = base + t;
-      if (t < MM_STAGE && fblk < B) {
-        int q = 0;
-#pragma unroll
-        for (int qq = 1; qq < MM_PTS; ++qq) q += s_scan[qq] <= fblk ? 1 : 0;
-        const int lkk = fblk - s_scan[q];
-        const int64_t k0 = s_k0[q];
-        const int64_t len = 3 * (int64_t)(s_scan[q + 1] - s_scan[q]);
-        const int32_t cj = bcols[k0 + lkk];
-        const int32_t pk = pcell[cj / 3];
-        const int ox = (pk & 1023) - bx + 1, oy = ((pk >> 10) & 1023) - by + 1, oz = (pk >> 20) - bz + 1;
-        if ((unsigned)ox > 2u || (unsigned)oy > 2u || (unsigned)oz > 2u) {
-          far = 1;
-          s_meta[t] = -1;
-        } else {
-          s_meta[t] = ox | (oy << 2) | (oz << 4) | ((cj >= 3 * n_unode ? 1 : 0) << 6);
-          const double* v = vals + 9 * k0 + 3 * lkk;
-          const int fi = s_fi[q];
-          const int fj = fixed == nullptr ? 0 : (fixed[cj] ? 1 : 0) | (fixed[cj + 1] ? 2 : 0) | (fixed[cj + 2] ? 4 : 0);
-#pragma unroll
-          for (int fa = 0; fa < 3; ++fa)
-#pragma unroll
-            for (int fb = 0; fb < 3; ++fb) s_val[t][3 * fa + fb] = ((fi >> fa) & 1) || ((fj >> fb) & 1) ? 0.0 : v[fa * len + fb];
-          const float4* wj = cs_w4 + (int64_t)(cj / 3) * 8;
-#pragma unroll
-          for (int b = 0; b < 8; ++b) s_wb[t][b] = wj[b];
-        }
-      }
-      __syncthreads();
-      // Y of point pl = wv: its staged blocks are the slots [scan[wv], scan[wv + 1]) of this round
-      {
-        const int pl = wv;
-        const int e_lo = max(s_scan[pl], base) - base, e_hi = min(s_scan[pl + 1], base + MM_STAGE) - base;
-        const int kq = lane & 7, fc = lane >> 3;
-        if (fc < 6) {
-          double* y0 = &Y[3 * pl][64 * fc];
-          for (int e = e_lo; e < e_hi; ++e) {
-            const int32_t m = s_meta[e];
-            if (m < 0) continue;
-            const int ox = m & 3, oy = (m >> 2) & 3, oz = (m >> 4) & 3, gj = (m >> 6) & 1;
-            const float4 wq = s_wb[e][kq];
-            // column f' = fc of W_q,k' as a 3-vector u: (K W)[fa][f'] = K[fa][.] . u
-            double u0, u1, u2;
-            if (gj == 0) {
-              if (fc < 3) { u0 = fc == 0 ? (double)wq.x : 0.0; u1 = fc == 1 ? (double)wq.x : 0.0; u2 = fc == 2 ? (double)wq.x : 0.0; }
-              else if (fc == 3) { u0 = 0.0; u1 = -(double)wq.w; u2 = (double)wq.z; }
-              else if (fc == 4) { u0 = (double)wq.w; u1 = 0.0; u2 = -(double)wq.y; }
-              else { u0 = -(double)wq.z; u1 = (double)wq.y; u2 = 0.0; }
-            } else {
-              u0 = fc == 3 ? (double)wq.x : 0.0; u1 = fc == 4 ? (double)wq.x : 0.0; u2 = fc == 5 ? (double)wq.x : 0.0;
-            }
-            const double* K = s_val[e];
-            const int bl = (ox + (kq & 1)) + 4 * (oy + ((kq >> 1) & 1)) + 16 * (oz + (kq >> 2));
-#pragma unroll
-            for (int fa = 0; fa < 3; ++fa) y0[fa * MM_YP + bl] += K[3 * fa] * u0 + K[3 * fa + 1] * u1 + K[3 * fa + 2] * u2;
-          }
-        }
-      }
-      __syncthreads();
-    }
     // D += W^T Y
 #pragma unroll
     for (int ks = 0; ks < MM_K / 4; ++ks) {
@@ -1931,7 +2013,7 @@ __global__ __launch_bounds__(MM_THREADS) void k_pc_coarse_galerkin_mm(int c, int
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int nt = wv + 8 * j;
-        const double bv = Y[kk][16 * nt + li];
+        const double bv = Y[kk][MM_YF * (nt >> 2) + 16 * (nt & 3) + li];
         if (gi == 0) acc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv, acc[0][j], 0, 0, 0);
         acc[1][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv, acc[1][j], 0, 0, 0);
         if (nt >= 12) acc[2][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv, acc[2][j], 0, 0, 0);
@@ -3217,7 +3299,7 @@ static int shell_pc_coarse_setup(femo_shell* s, const femo_vec* vals, const uint
   FEMO_HIP_CHECK(hipMemsetAsync(s->d_cs_A, 0, N * N * sizeof(double), st));
   FEMO_HIP_CHECK(hipMemsetAsync(s->d_cs_info, 0, 4 * sizeof(int32_t), st));
   if (s->hermite && s->d_lvl_node != nullptr && !femo_env_flag("FEMO_SHELL_TRILINEAR") && !femo_env_flag("FEMO_SHELL_NO_BLOCKS")) {
-    if (femo_env_flag("FEMO_SHELL_CG_ATOMIC")) {
+    if (femo_env_flag("FEMO_SHELL_CG_ATOMIC") || s->cs_max_item > MM_ITEM) {      // (items above 256 points: only with FEMO_SHELL_CG_CHUNK)
       for (int pass = 0; pass < 2; ++pass)
         hipLaunchKernelGGL(k_pc_coarse_galerkin_h, dim3((unsigned)s->cs_items), dim3(256), CGH_LDS, st, pass, s->cs_level, s->pc_width, s->level_off[s->cs_level], N,
                            s->n_unode, s->d_cs_ptr, s->d_cs_pts, s->d_cs_nbr, s->d_cs_pcell, s->d_brow, s->d_bcols, vals->d, d_fixed, s->d_ell_idx,
@@ -3404,7 +3486,11 @@ int femo_shell_pc_coarse(femo_shell* s, int level, const int32_t* node_xyz, int6
   const int64_t nodes = s->level_off[level + 1] - s->level_off[level];
   const int64_t n = 6 * nodes;
   FEMO_REQUIRE(n <= 8192, "coarse-solve level too large for a dense inverse");
-  for (int64_t it = 0; it < n_items; ++it) FEMO_REQUIRE(item_ptr[it + 1] > item_ptr[it], "empty Galerkin item");
+  s->cs_max_item = 0;
+  for (int64_t it = 0; it < n_items; ++it) {
+    FEMO_REQUIRE(item_ptr[it + 1] > item_ptr[it], "empty Galerkin item");
+    s->cs_max_item = std::max<int64_t>(s->cs_max_item, item_ptr[it + 1] - item_ptr[it]);
+  }
   FEMO_TRY(to_device(&s->d_cs_xyz, node_xyz, 3 * nodes, st));
   FEMO_TRY(to_device(&s->d_cs_ptr, item_ptr, n_items + 1, st));
   FEMO_TRY(to_device(&s->d_cs_pts, item_pts, item_ptr[n_items], st));
