@@ -1050,19 +1050,39 @@ struct MergedCarry {
 };
 
 __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int dim, const int32_t* __restrict__ done, MergedCarry mc) {
-  if (done != nullptr && *done) return;
+  // every load the scalars need is issued before the first one is used: the exit flag, gamma and the partials were three
+  // dependent round trips to L2 (~3 us at the head of a 14-30 us kernel that is the critical path of small iterations)
   __shared__ double red[1024 / 64];
-  double alpha = -1.0, pq = 0.0;
+  const int32_t stop = done != nullptr ? *done : 0;
+  const double gamma = mc.init ? 0.0 : mc.S[MS_GAMMA + mc.cur];
+  double a_pq = 0.0;
   if (!mc.init) {
     if (mc.multi) {
-      pq = mc.S[MS_RED];
+      a_pq = mc.S[MS_RED];
     } else {
-      double a = 0.0;
-      for (int i = threadIdx.x; i < mc.nb_pq; i += 1024) a += mc.pq_partials[i];
-      for (int i = threadIdx.x; i < mc.nb_pq2; i += 1024) a += mc.pq_partials2[i];
-      pq = femo_block_sum_all<1024>(a, red);
+      for (int i = threadIdx.x; i < mc.nb_pq; i += 1024) a_pq += mc.pq_partials[i];
+      for (int i = threadIdx.x; i < mc.nb_pq2; i += 1024) a_pq += mc.pq_partials2[i];
     }
-    const double gamma = mc.S[MS_GAMMA + mc.cur];
+  }
+  // workgroup 0: the operands of its top level as well (they do not depend on alpha)
+  constexpr int TOPR = 4;
+  double pre_h[TOPR], pre_g[TOPR], pre_c[TOPR];
+  if (blockIdx.x == 0 && mc.dbg != 1) {
+    const int top = L.n_levels;
+    const int64_t n_top = L.nodes[top];
+#pragma unroll
+    for (int q = 0; q < TOPR; ++q) {
+      const int64_t idx = threadIdx.x + q * 1024;
+      const bool in = idx < n_top;
+      pre_h[q] = in && mc.hres != nullptr ? mc.hres[idx] : 0.0;
+      pre_g[q] = in ? mc.gs_top[idx] : 0.0;
+      pre_c[q] = in ? L.coef[top][idx] : 0.0;
+    }
+  }
+  if (stop) return;
+  double alpha = -1.0, pq = 0.0;
+  if (!mc.init) {
+    pq = mc.multi ? a_pq : femo_block_sum_all<1024>(a_pq, red);
     alpha = pq != 0.0 ? gamma / pq : 0.0;
   }
   if (blockIdx.x > 0) {
@@ -1124,7 +1144,6 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
   extern __shared__ double coarse_lds[];
   const int top = L.n_levels;
   const int tid = threadIdx.x;
-  constexpr int TOPR = 4;
   const int64_t n_top = L.nodes[top];
   double* g_top_lds = coarse_lds + L.off[top];
   double gt[TOPR], ct[TOPR];
@@ -1138,9 +1157,9 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
   for (int q = 0; q < TOPR; ++q) {
     const int64_t idx = tid + q * 1024;
     const bool in = idx < n_top;
-    const double hres = !in ? 0.0 : (mc.hres != nullptr ? mc.hres[idx] : lattice_restrict_node32((int)idx, L.n[top], L.finer_n, dim, L.finer_g));
-    const double g0 = in ? mc.gs_top[idx] : 0.0;
-    ct[q] = in ? L.coef[top][idx] : 0.0;
+    const double hres = !in ? 0.0 : (mc.hres != nullptr ? pre_h[q] : lattice_restrict_node32((int)idx, L.n[top], L.finer_n, dim, L.finer_g));
+    const double g0 = pre_g[q];
+    ct[q] = pre_c[q];
     gt[q] = g0 - alpha * hres;
     dot += ct[q] * gt[q] * gt[q];
   }

@@ -11,13 +11,13 @@ from tests.test_gpu_shell import E_ROOF, FZ, H_ROOF, NU_ROOF, rel, roof_fixed
 pytestmark = pytest.mark.gpu
 
 
-def _problem(ctx, n, hermite=True, coarse=None):
+def _problem(ctx, n, hermite=True, coarse=None, finest=None):
     from femo_amd.fea.shell import ShellProblem
     pts, conn = so.scordelis_lo_mesh(n, n)
     V0 = so.ShellSpace(pts, conn)
     fixed = roof_fixed(V0)
     prob = ShellProblem(pts, conn, E_ROOF, NU_ROOF, fixed_dofs=fixed, ctx=ctx, pc="lattice")
-    prob.dev.enable_lattice_pc(hermite=hermite, coarse_unknowns=coarse)
+    prob.dev.enable_lattice_pc(finest=finest, hermite=hermite, coarse_unknowns=coarse)
     prob.set_thickness(H_ROOF)
     prob.set_load([0.0, 0.0, FZ])
     return prob, V0, fixed
@@ -96,3 +96,26 @@ def test_node_blocks_by_items_equal_the_row_wise_kernel(ctx, n, coarse, monkeypa
             r = np.random.default_rng(7).standard_normal(V0.n_dof)
             zs.append(prob.dev.pc_apply(prob._stiffness(), Vec(ctx, V0.n_dof).set(r), Vec(ctx, V0.n_dof), mask).get())
         assert np.abs(zs[0] - zs[1]).max() <= 1e-5 * np.abs(zs[0]).max()      # measured 2e-9 / 5e-7: the sums' order through the blocks' conditioning
+
+
+def test_node_blocks_fall_back_when_elements_span_lattice_cells(ctx, monkeypatch):
+    """A finest lattice finer than the mesh (8 x 8 roof, 64 cells per axis): column points lie more than one cell away, the
+    cell-per-wave kernel flags it on the device and the set-up takes the row-wise kernel -- same M^-1 r as when the row-wise
+    kernel is asked for, and the solve still reaches the direct solution."""
+    from femo_amd.engine import Vec
+    zs = []
+    for by_rows in (True, False):
+        if by_rows:
+            monkeypatch.setenv("FEMO_SHELL_BLOCKS_BY_ROWS", "1")
+        else:
+            monkeypatch.delenv("FEMO_SHELL_BLOCKS_BY_ROWS", raising=False)
+        prob, V0, fixed = _problem(ctx, 8, finest=64)
+        mask = np.zeros(V0.n_dof, dtype=np.uint8)
+        mask[fixed] = 1
+        r = np.random.default_rng(11).standard_normal(V0.n_dof)
+        zs.append(prob.dev.pc_apply(prob._stiffness(), Vec(ctx, V0.n_dof).set(r), Vec(ctx, V0.n_dof), mask).get())
+    assert np.abs(zs[0] - zs[1]).max() <= 1e-9 * np.abs(zs[0]).max()
+    w = prob.solve(rtol=1e-10)
+    K = so.assemble(V0, so.element_stiffness(V0, np.full(V0.n_vert, H_ROOF), E_ROOF, NU_ROOF)).tocsr()
+    F = so.load_vector(V0, np.tile([0.0, 0.0, FZ], (V0.n_vert, 1)))
+    assert prob.last_info.converged in (1, 2) and rel(w, so.solve(K, F, fixed)) <= 1e-6
