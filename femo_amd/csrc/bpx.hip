@@ -1021,6 +1021,76 @@ __global__ __launch_bounds__(256) void k_lattice_prolong3(FineLevels P, const in
 //                        the other workgroups: x += alpha p, r -= alpha q (+ partial r.r), gs -= alpha h on levels T and L-1
 //   k_lattice_prolong3_m gs_L -= alpha h_L in place (one tile owns a node), e of the three finest levels, partial sum C g^2
 //   k_prolong_mesh       gamma' = r.r + sum_l C g^2, beta, p = z + beta p, stopping test
+// 27-point restriction of a 3-D lattice level as three 1-D passes (x, y, z: out = 0.5 f[2i-1] + f[2i] + 0.5 f[2i+1] per axis) through
+// two LDS scratch arrays.  The 27-tap form costs one thread ~500 instructions of index arithmetic per node and only the coarse
+// level's nodes have a thread (343 of 1024 for 13^3 -> 7^3): 3.7 us per level in workgroup 0 of k_lattice_coarse_m, the critical
+// path of an iteration on small and partitioned meshes; the passes take ~40 instructions per output on up to all 1024 threads.
+// Ends with a barrier (out is visible).  fine may be global or LDS.
+__device__ __forceinline__ void lattice_restrict3_sep(const double* __restrict__ fine, const int* nf, const int* nc, double* out, double* t1, double* t2, int tid) {
+  const int fx = nf[0] + 1, fy = nf[1] + 1, fz = nf[2] + 1, cx = nc[0] + 1, cy = nc[1] + 1, cz = nc[2] + 1;
+  for (int idx = tid; idx < cx * fy * fz; idx += 1024) {
+    const int i = idx % cx, r = idx / cx;
+    const double* row = fine + r * fx;
+    const int f = 2 * i;
+    double v = row[f];
+    if (f > 0) v += 0.5 * row[f - 1];
+    if (f + 1 < fx) v += 0.5 * row[f + 1];
+    t1[idx] = v;
+  }
+  lds_barrier();
+  for (int idx = tid; idx < cx * cy * fz; idx += 1024) {
+    const int i = idx % cx, r = idx / cx, j = r % cy, k = r / cy;
+    const int f = 2 * j;
+    const double* col = t1 + (k * fy) * cx + i;
+    double v = col[f * cx];
+    if (f > 0) v += 0.5 * col[(f - 1) * cx];
+    if (f + 1 < fy) v += 0.5 * col[(f + 1) * cx];
+    t2[idx] = v;
+  }
+  lds_barrier();
+  const int cxy = cx * cy;
+  for (int idx = tid; idx < cxy * cz; idx += 1024) {
+    const int ij = idx % cxy, k = idx / cxy;
+    const int f = 2 * k;
+    double v = t2[f * cxy + ij];
+    if (f > 0) v += 0.5 * t2[(f - 1) * cxy + ij];
+    if (f + 1 < fz) v += 0.5 * t2[(f + 1) * cxy + ij];
+    out[idx] = v;
+  }
+  lds_barrier();
+}
+
+// The kernel arguments of the lattice kernels are structs of 0.3-1.1 KB; the compiler fetches each field with a scalar load
+// where it is first needed, and every first touch of a 64-byte line of the argument segment is a miss of the scalar cache
+// (~0.5-1 us, one after the other along the critical path: 9 us between the launch and alpha in workgroup 0 of
+// k_lattice_coarse_m, measured with early exits).  One dword of every line, loaded back to back at the kernel's entry, turns
+// the chain into a single round trip.
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warm() {
+  typedef const __attribute__((address_space(4))) uint32_t* karg_ptr;
+  karg_ptr ka = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  static_assert(BYTES >= 64 && BYTES <= 20 * 64, "kernarg_warm covers 20 lines");
+  constexpr int LAST = (BYTES - 4) & ~3;                      // never past the segment: lines beyond it repeat its last dword
+#define FEMO_KA(i) ((i) * 64 < LAST ? (i) * 64 : LAST)
+  uint32_t t0, t1, t2, t3, t4, t5, t6, t7, t8, t9;
+  // (inline assembly: written as ordinary loads the compiler folds them into the argument values and drops them)
+  asm volatile("s_load_dword %0, %10, %11\n\ts_load_dword %1, %10, %12\n\ts_load_dword %2, %10, %13\n\ts_load_dword %3, %10, %14\n\t"
+               "s_load_dword %4, %10, %15\n\ts_load_dword %5, %10, %16\n\ts_load_dword %6, %10, %17\n\ts_load_dword %7, %10, %18\n\t"
+               "s_load_dword %8, %10, %19\n\ts_load_dword %9, %10, %20\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7), "=&s"(t8), "=&s"(t9)
+               : "s"(ka), "n"(FEMO_KA(0)), "n"(FEMO_KA(1)), "n"(FEMO_KA(2)), "n"(FEMO_KA(3)), "n"(FEMO_KA(4)), "n"(FEMO_KA(5)), "n"(FEMO_KA(6)),
+                 "n"(FEMO_KA(7)), "n"(FEMO_KA(8)), "n"(FEMO_KA(9)));
+  if (BYTES > 10 * 64) {
+    asm volatile("s_load_dword %0, %10, %11\n\ts_load_dword %1, %10, %12\n\ts_load_dword %2, %10, %13\n\ts_load_dword %3, %10, %14\n\t"
+                 "s_load_dword %4, %10, %15\n\ts_load_dword %5, %10, %16\n\ts_load_dword %6, %10, %17\n\ts_load_dword %7, %10, %18\n\t"
+                 "s_load_dword %8, %10, %19\n\ts_load_dword %9, %10, %20\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7), "=&s"(t8), "=&s"(t9)
+                 : "s"(ka), "n"(FEMO_KA(10)), "n"(FEMO_KA(11)), "n"(FEMO_KA(12)), "n"(FEMO_KA(13)), "n"(FEMO_KA(14)), "n"(FEMO_KA(15)),
+                   "n"(FEMO_KA(16)), "n"(FEMO_KA(17)), "n"(FEMO_KA(18)), "n"(FEMO_KA(19)));
+  }
+#undef FEMO_KA
+}
+
 struct MergedCarry {
   double* S;
   int cur, multi, init;
@@ -1047,11 +1117,13 @@ struct MergedCarry {
   // kernel on several): the 27-point restriction of 2197 nodes is ~14 us of index arithmetic on ONE compute unit, the
   // critical path of an iteration when the mesh-sized streams of the carriers are short (partitioned / small meshes)
   const double* hres;
+  int64_t sep_off;                  // LDS offset (doubles) of the scratch of lattice_restrict3_sep, -1: the 27-tap restrictions
 };
 
 __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int dim, const int32_t* __restrict__ done, MergedCarry mc) {
   // every load the scalars need is issued before the first one is used: the exit flag, gamma and the partials were three
   // dependent round trips to L2 (~3 us at the head of a 14-30 us kernel that is the critical path of small iterations)
+  kernarg_warm<sizeof(CoarseLevels) + 16 + sizeof(MergedCarry)>();
   __shared__ double red[1024 / 64];
   const int32_t stop = done != nullptr ? *done : 0;
   const double gamma = mc.init ? 0.0 : mc.S[MS_GAMMA + mc.cur];
@@ -1080,6 +1152,22 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
     }
   }
   if (stop) return;
+  extern __shared__ double coarse_lds[];
+  // one rank: R h_T for the top level by separable passes into LDS, before alpha is needed (it does not depend on alpha)
+  double* const sep = mc.sep_off >= 0 ? coarse_lds + mc.sep_off : nullptr;
+  if (blockIdx.x == 0 && mc.dbg != 1 && sep != nullptr && mc.hres == nullptr) {
+    const int top = L.n_levels;
+    const int64_t n_top = L.nodes[top];
+    const int64_t s1 = (int64_t)(L.n[top][0] + 1) * (L.finer_n[1] + 1) * (L.finer_n[2] + 1);
+    const int64_t s2 = (int64_t)(L.n[top][0] + 1) * (L.n[top][1] + 1) * (L.finer_n[2] + 1);
+    lattice_restrict3_sep(L.finer_g, L.finer_n, L.n[top], sep + s1 + s2, sep, sep + s1, threadIdx.x);
+#pragma unroll
+    for (int q = 0; q < TOPR; ++q) {
+      const int64_t idx = threadIdx.x + q * 1024;
+      pre_h[q] = idx < n_top ? sep[s1 + s2 + idx] : 0.0;
+    }
+    lds_barrier();                                      // the scratch is reused by the levels below
+  }
   double alpha = -1.0, pq = 0.0;
   if (!mc.init) {
     pq = mc.multi ? a_pq : femo_block_sum_all<1024>(a_pq, red);
@@ -1139,9 +1227,8 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
     return;
   }
   if (threadIdx.x == 0) { mc.S[MS_ALPHA] = alpha; mc.S[MS_PQ] = pq; }
-  if (mc.dbg == 1) return;
+  if (mc.dbg == 1 || mc.dbg == 3) return;
   // workgroup 0: the LDS-resident coarse end, as k_lattice_coarse with restrict_top and emit_top, on the updated state
-  extern __shared__ double coarse_lds[];
   const int top = L.n_levels;
   const int tid = threadIdx.x;
   const int64_t n_top = L.nodes[top];
@@ -1157,7 +1244,7 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
   for (int q = 0; q < TOPR; ++q) {
     const int64_t idx = tid + q * 1024;
     const bool in = idx < n_top;
-    const double hres = !in ? 0.0 : (mc.hres != nullptr ? pre_h[q] : lattice_restrict_node32((int)idx, L.n[top], L.finer_n, dim, L.finer_g));
+    const double hres = !in ? 0.0 : ((mc.hres != nullptr || sep != nullptr) ? pre_h[q] : lattice_restrict_node32((int)idx, L.n[top], L.finer_n, dim, L.finer_g));
     const double g0 = pre_g[q];
     ct[q] = pre_c[q];
     gt[q] = g0 - alpha * hres;
@@ -1171,13 +1258,20 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
     if (idx < n_top) { g_top_lds[idx] = gt[q]; mc.gs_top[idx] = gt[q]; }
   }
   lds_barrier();
+  if (mc.dbg == 4) return;
   for (int l = top - 1; l >= 0; --l) {
     const int64_t total = L.nodes[l];
     const double* fine = l + 1 == top ? g_top_lds : coarse_lds + L.off[l + 1];
     double* gl = coarse_lds + L.off[l];
-    for (int64_t idx = tid; idx < total; idx += 1024) gl[idx] = lattice_restrict_node32((int)idx, L.n[l], L.n[l + 1], dim, fine);
-    lds_barrier();
+    if (sep != nullptr) {
+      const int64_t s1 = (int64_t)(L.n[l][0] + 1) * (L.n[l + 1][1] + 1) * (L.n[l + 1][2] + 1);
+      lattice_restrict3_sep(fine, L.n[l + 1], L.n[l], gl, sep, sep + s1, tid);
+    } else {
+      for (int64_t idx = tid; idx < total; idx += 1024) gl[idx] = lattice_restrict_node32((int)idx, L.n[l], L.n[l + 1], dim, fine);
+      lds_barrier();
+    }
   }
+  if (mc.dbg == 5) return;
   for (int l = 0; l < top; ++l) {
     const int64_t total = L.nodes[l];
     const double* gl = coarse_lds + L.off[l];
@@ -1195,6 +1289,7 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
     c_cur = c_nxt;
     lds_barrier();
   }
+  if (mc.dbg == 6) return;
   if (top > 0) {
     const double* ec = coarse_lds + L.off[top - 1] + L.nodes[top - 1];
 #pragma unroll
@@ -2090,7 +2185,25 @@ int femo_pc_merged_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, c
   static const int dbg_coarse = FEMO_TUNE_ENV("FEMO_DEBUG_COARSE") ? atoi(FEMO_TUNE_ENV("FEMO_DEBUG_COARSE")) : 0;
   mc.dbg = dbg_coarse;
   mc.hres = multi ? pc->L[T - 1].g : nullptr;
-  hipLaunchKernelGGL(k_lattice_coarse_m, dim3(1 + n_carry), dim3(1024), lds, st, CL, pc->dim, done, mc);
+  // scratch of the separable restrictions (3-D): the largest of the top restriction (one rank: level T -> T-1, + its output)
+  // and the LDS-resident ones; behind the levels when it fits
+  size_t lds_all = lds;
+  mc.sep_off = -1;
+  if (pc->dim == 3 && !femo_env_flag("FEMO_BPX_TAPS27")) {
+    auto need = [&](const int* nc, const int* nfn, bool with_out) -> int64_t {
+      const int64_t s1 = (int64_t)(nc[0] + 1) * (nfn[1] + 1) * (nfn[2] + 1), s2 = (int64_t)(nc[0] + 1) * (nc[1] + 1) * (nfn[2] + 1);
+      return s1 + s2 + (with_out ? (int64_t)(nc[0] + 1) * (nc[1] + 1) * (nc[2] + 1) : 0);
+    };
+    int64_t scratch = multi ? 0 : need(pc->L[T - 1].n, pc->L[T].n, true);
+    for (int l = 0; l + 1 <= T - 1; ++l) scratch = std::max(scratch, need(pc->L[l].n, pc->L[l + 1].n, false));
+    const int64_t off = (int64_t)(lds / sizeof(double));
+    if ((off + scratch) * (int64_t)sizeof(double) <= 158 * 1024) { mc.sep_off = off; lds_all = (size_t)(off + scratch) * sizeof(double); }
+  }
+  if (lds_all > 64 * 1024 && !merged_lds_set) {
+    FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_coarse_m, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+    merged_lds_set = true;
+  }
+  hipLaunchKernelGGL(k_lattice_coarse_m, dim3(1 + n_carry), dim3(1024), lds_all, st, CL, pc->dim, done, mc);
   FineLevels FL;
   const LatticeLevel &Lcc = pc->L[nl - 4], &Lc = pc->L[nl - 3], &Lm = pc->L[nl - 2];
   for (int k = 0; k < 3; ++k) { FL.ncc[k] = Lcc.n[k]; FL.nc[k] = Lc.n[k]; FL.nm[k] = Lm.n[k]; FL.nf[k] = F.n[k]; }
