@@ -3574,7 +3574,6 @@ int femo_shell_pc_hermite(femo_shell* s, const float* fin_w4, const int64_t* hp_
   FEMO_REQUIRE(s && fin_w4 && hp_rowptr && hp_cols && hp_w4 && par_w5 && chi_w5 && lvl_w4 && cs_w4, "null argument");
   FEMO_REQUIRE(s->pc_width > 0 && s->cs_level >= 0, "femo_shell_pc_hermite needs femo_shell_pc_create and femo_shell_pc_coarse first");
   FEMO_REQUIRE(!s->hermite, "the shell already has its Hermite-type lattice data");
-  FEMO_REQUIRE(s->d_owned == nullptr, "Hermite-type lattice spaces are not available on a partitioned shell");
   hipStream_t st = s->ctx->stream;
   FEMO_HIP_CHECK(hipSetDevice(s->ctx->device));
   const int64_t n_pts = s->n_dof / 3;

@@ -627,7 +627,7 @@ class DeviceShell:
                                                     q(plan["down_rowptr"]), q(plan["down_cols"]), q(plan["down_vals"])))
                 self.coarse_level = plan["level"]
         self.hermite = False
-        if hermite and self.coarse_level is not None and self.partition is None:
+        if hermite and self.coarse_level is not None:
             A = hermite_device_arrays(self.space, L, self.coarse_level)
             q = lambda a: None if a is None else C.c_void_p(a.ctypes.data)
             dn = A["down"] or {}

@@ -473,7 +473,8 @@ int femo_shell_pc_coarse(femo_shell* s, int level, const int32_t* node_xyz, int6
  * lattice ((w, 0, 0, 0) for rotation points); hp_*: P_L^T by finest node -- row 2 k lists the displacement points of node k
  * (first dof, w4), row 2 k + 1 its rotation points; par_w5 / chi_w5: (a, b, c) per entry of the parent / child CSR;
  * lvl_w4: composed weights of the levels above the coarse solve, [level][point][8][4]; cs_w4: of the coarse-solve level;
- * down_*: composite restriction finest lattice -> levels cs .. L - 2 in (A, B, C) form (optional).  One rank only.        */
+ * down_*: composite restriction finest lattice -> levels cs .. L - 2 in (A, B, C) form (optional).  On a partitioned shell: the
+ * rows of the rank's local points on the global lattice (the Galerkin sums are all-reduced like the trilinear ones).       */
 int femo_shell_pc_hermite(femo_shell* s, const float* fin_w4, const int64_t* hp_rowptr, const int32_t* hp_cols, const float* hp_w4,
                           const double* par_w5, const double* chi_w5, const float* lvl_w4, const float* cs_w4,
                           const int64_t* down_rowptr, const int32_t* down_cols, const double* down_w5);

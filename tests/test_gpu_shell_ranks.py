@@ -84,7 +84,7 @@ def test_partitioned_solves_match_the_oracle_and_one_rank(world):
         it_f = prob.last_info.iterations
         assert prob.last_info.converged in (1, 2)
         lam = prob.solve_adjoint(P.local_state(c))
-        return dict(P=P, w=wl, lam=lam, it=(it_f, prob.last_info.iterations), coarse=prob.dev.coarse_level)
+        return dict(P=P, w=wl, lam=lam, it=(it_f, prob.last_info.iterations), coarse=prob.dev.coarse_level, hermite=prob.dev.hermite)
 
     res = _run_ranks(world, rank_fn)
     one = _run_ranks(1, lambda rank, ctx: rank_fn(rank, ctx, 1))[0]
@@ -101,6 +101,18 @@ def test_partitioned_solves_match_the_oracle_and_one_rank(world):
     # the partitioned preconditioner IS the serial one (global lattice, all-reduced Galerkin operators): same counts up to rounding
     for a, b in zip(res[0]["it"], one["it"]):
         assert abs(a - b) <= max(3, 0.03 * b)
+    # round 4: the partitioned problems use the Hermite-type lattice spaces too, and their count is the count of the plain
+    # (unpartitioned) problem with the same spaces
+    assert all(r["hermite"] for r in res) and one["hermite"]
+
+    def serial_fn(rank, ctx):
+        prob = ShellProblem(pts, conn, E_ROOF, 0.3, fixed_dofs=fixed, ctx=ctx)
+        prob.set_thickness(h)
+        prob.set_load(f)
+        prob.solve()
+        return prob.last_info.iterations, prob.dev.hermite
+    it_serial, herm_serial = _run_ranks(1, serial_fn)[0]
+    assert herm_serial and abs(res[0]["it"][0] - it_serial) <= max(3, 0.03 * it_serial)
 
 
 def test_compliance_gradient_on_three_ranks():
