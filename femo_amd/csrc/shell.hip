@@ -86,6 +86,7 @@ struct femo_shell {
   double *d_cs_A = nullptr, *d_cs_tmp = nullptr;       // L^-T above / L^-1 below the diagonal (row-major, N x N); L^-1 g
   float* d_cs_Af = nullptr;                            // the same factors in single precision: what the iteration applies
   double* d_cs_dinv = nullptr;                         // inverses of the diagonal tiles of L
+  double* d_cs_T = nullptr;                            // scratch of the level-wise triangular inversion (N x N)
   // Hermite-type lattice spaces (femo_shell_pc_hermite; used when the coarse solve and the node blocks are ready, else the
   // trilinear data above takes over): finest transfer weights per (point, corner), P_L^T rows per finest node (displacement
   // points, then rotation points), (a, b, c) of the node-level transfers, composed weights of the levels above the
@@ -2277,6 +2278,68 @@ __global__ __launch_bounds__(256) void k_trinv_row(int64_t N, int i, double* __r
   tile_foreach(out, [&](int r, int c, double v) { g[(int64_t)c * N + r] = -v; });
 }
 
+// W = L^-1 by recursive doubling (round 4): with the diagonal tiles inverted (dinv), level s joins pairs of inverted diagonal
+// blocks of 2^s tiles, [W_CC 0; W_RC W_RR] with W_RC = -W_RR (L_RC W_CC) -- two launches of independent tile products per
+// level, 2 x 6 launches for 48 tiles, where the row-by-row version (k_trinv_row) is 47 dependent launches whose last ones
+// loop over 47 tile products per workgroup (4.5 ms at n = 3060).  phase 0: T_ij = sum_{k = j .. c1 - 1} L_ik W_kj, stored
+// TRANSPOSED in T (what phase 1 reads as its B operand); phase 1: W_ij = -sum_{k = r0 .. i} W_ik T_kj, stored transposed in
+// the upper triangle of A like every finished tile of W.  Operands: L below the diagonal of A, finished W tiles (k, j), k > j,
+// at tile (j, k) of A transposed, diagonal ones in dinv.
+__global__ __launch_bounds__(256) void k_trinv_level(int64_t N, int nt, int B, int phase, double* __restrict__ A, const double* __restrict__ dinv,
+                                                     double* __restrict__ T) {
+  __shared__ double sa[DT][DP];
+  __shared__ double sb[DT][DP];
+  const int per = B * B;
+  const int b = blockIdx.x / per, ij = blockIdx.x % per;
+  const int c0 = 2 * b * B, r0 = c0 + B;
+  const int i = r0 + ij / B, j = c0 + ij % B;
+  if (i >= nt) return;
+  const int k_lo = phase == 0 ? j : r0, k_hi = phase == 0 ? r0 : i + 1;          // [k_lo, k_hi)
+  TileAcc acc;
+  double ra[16], rb[16];
+  // operand tiles of step k as [row][k] arrays: phase 0: a = L_ik (tile (i, k), direct), b^T = W_kj: tile (j, k) direct, or dinv_j transposed;
+  // phase 1: a = W_ik: tile (k, i) transposed, or dinv_i direct; b^T = T_kj^T: tile (k, j) of T, direct
+  auto fetch = [&](int k) {
+    const double *ga, *gb;
+    int64_t lda, ldb;
+    if (phase == 0) {
+      ga = A + ((int64_t)i * DT) * N + (int64_t)k * DT; lda = N;
+      if (k == j) { gb = dinv + (int64_t)j * DT * DT; ldb = DT; } else { gb = A + ((int64_t)j * DT) * N + (int64_t)k * DT; ldb = N; }
+    } else {
+      if (k == i) { ga = dinv + (int64_t)i * DT * DT; lda = DT; } else { ga = A + ((int64_t)k * DT) * N + (int64_t)i * DT; lda = N; }
+      gb = T + ((int64_t)k * DT) * N + (int64_t)j * DT; ldb = N;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int idx = threadIdx.x + 256 * q, r = idx / DT, c = idx % DT;
+      ra[q] = ga[(int64_t)r * lda + c];
+      rb[q] = gb[(int64_t)r * ldb + c];
+    }
+  };
+  fetch(k_lo);
+  for (int k = k_lo; k < k_hi; ++k) {
+    __syncthreads();
+    const bool ta = phase == 1 && k != i;                  // a arrives transposed
+    const bool tb = phase == 0 && k == j;                  // b^T arrives transposed
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int idx = threadIdx.x + 256 * q, r = idx / DT, c = idx % DT;
+      if (ta) sa[c][r] = ra[q]; else sa[r][c] = ra[q];
+      if (tb) sb[c][r] = rb[q]; else sb[r][c] = rb[q];
+    }
+    __syncthreads();
+    if (k + 1 < k_hi) fetch(k + 1);
+    tile_mma(acc, sa, sb);
+  }
+  if (phase == 0) {
+    double* g = T + ((int64_t)i * DT) * N + (int64_t)j * DT;                                     // T_ij^T: element (c, r)
+    tile_foreach(acc, [&](int r, int c, double v) { g[(int64_t)c * N + r] = v; });
+  } else {
+    double* g = A + ((int64_t)j * DT) * N + (int64_t)i * DT;                                     // tile (j, i) = W_ij^T
+    tile_foreach(acc, [&](int r, int c, double v) { g[(int64_t)c * N + r] = -v; });
+  }
+}
+
 // diagonal tiles of the result: L_kk^-T above, L_kk^-1 below the diagonal
 __global__ __launch_bounds__(256) void k_trinv_diag(int64_t N, double* __restrict__ A, const double* __restrict__ dinv) {
   const int kb = blockIdx.x;
@@ -3190,7 +3253,7 @@ int femo_shell_destroy(femo_shell* s) {
   hipStreamSynchronize(s->ctx->stream);
   hipFree(s->d_x); hipFree(s->d_conn); hipFree(s->d_cedge); hipFree(s->d_rowptr); hipFree(s->d_cols); hipFree(s->d_epos); hipFree(s->d_brow); hipFree(s->d_bcols); hipFree(s->d_bs_off); hipFree(s->d_bs_cols); hipFree(s->d_bs_vals);
   hipFree(s->d_ptp_rowptr); hipFree(s->d_ptp_cols); hipFree(s->d_ptp_vals);
-  hipFree(s->d_cs_xyz); hipFree(s->d_cs_ptr); hipFree(s->d_cs_pts); hipFree(s->d_cs_nbr); hipFree(s->d_cs_A); hipFree(s->d_cs_Af); hipFree(s->d_cs_tmp); hipFree(s->d_cs_dinv); hipFree(s->d_cs_info); hipFree(s->d_cs_pcell);
+  hipFree(s->d_cs_xyz); hipFree(s->d_cs_ptr); hipFree(s->d_cs_pts); hipFree(s->d_cs_nbr); hipFree(s->d_cs_A); hipFree(s->d_cs_Af); hipFree(s->d_cs_tmp); hipFree(s->d_cs_dinv); hipFree(s->d_cs_T); hipFree(s->d_cs_info); hipFree(s->d_cs_pcell);
   hipFree(s->d_cd_rowptr); hipFree(s->d_cd_cols); hipFree(s->d_cd_vals);
   hipFree(s->d_cell_owned);
   hipFree(s->d_fin_w4); hipFree(s->d_hp_rowptr); hipFree(s->d_hp_cols); hipFree(s->d_hp_w4); hipFree(s->d_par_w5); hipFree(s->d_chi_w5);
@@ -3335,7 +3398,15 @@ static int shell_pc_coarse_setup(femo_shell* s, const femo_vec* vals, const uint
     }
   }
   auto t2 = now();
-  for (int i = 1; i < nblk; ++i) hipLaunchKernelGGL(k_trinv_row, dim3(i), dim3(256), 0, st, N, i, s->d_cs_A, s->d_cs_dinv);
+  if (s->d_cs_T != nullptr && !femo_env_flag("FEMO_SHELL_TRINV_ROWS")) {
+    for (int B = 1; B < nblk; B *= 2) {
+      const int nb = (nblk + 2 * B - 1) / (2 * B);
+      for (int phase = 0; phase < 2; ++phase)
+        hipLaunchKernelGGL(k_trinv_level, dim3((unsigned)(nb * B * B)), dim3(256), 0, st, N, nblk, B, phase, s->d_cs_A, s->d_cs_dinv, s->d_cs_T);
+    }
+  } else {
+    for (int i = 1; i < nblk; ++i) hipLaunchKernelGGL(k_trinv_row, dim3(i), dim3(256), 0, st, N, i, s->d_cs_A, s->d_cs_dinv);
+  }
   hipLaunchKernelGGL(k_trinv_diag, dim3(nblk), dim3(256), 0, st, N, s->d_cs_A, s->d_cs_dinv);
   hipLaunchKernelGGL(k_pc_coarse_mirror, dim3(sgrid(N, 256), (unsigned)N), dim3(256), 0, st, N, s->d_cs_A);
   if (s->d_cs_Af != nullptr) hipLaunchKernelGGL(k_pc_coarse_to_float, dim3(2048), dim3(256), 0, st, N * N, s->d_cs_A, s->d_cs_Af, std::sqrt(shell_coarse_weight(s)));
@@ -3500,6 +3571,7 @@ int femo_shell_pc_coarse(femo_shell* s, int level, const int32_t* node_xyz, int6
   if (!femo_env_flag("FEMO_SHELL_COARSE_FP64")) FEMO_HIP_CHECK(hipMalloc(&s->d_cs_Af, N * N * sizeof(float)));
   FEMO_HIP_CHECK(hipMalloc(&s->d_cs_tmp, N * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&s->d_cs_dinv, N * DT * sizeof(double)));
+  FEMO_HIP_CHECK(hipMalloc(&s->d_cs_T, N * N * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&s->d_cs_info, 4 * sizeof(int32_t)));
   FEMO_REQUIRE(s->level_off[level + 1] - s->level_off[level] > 0 && (1 << 10) > (1 << (level + 1)), "lattice too fine for 10-bit coordinates");
   FEMO_HIP_CHECK(hipMalloc(&s->d_cs_pcell, (s->n_dof / 3) * sizeof(int32_t)));
