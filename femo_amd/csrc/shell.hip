@@ -2133,12 +2133,10 @@ __device__ __forceinline__ void tile_foreach(const TileAcc& acc, F f) {
 
 // diagonal tile kb: unblocked Cholesky in LDS, L_kk written back (lower part), its inverse (lower triangular, full
 // 64 x 64 with zeros above) into dinv[kb]; info[2] = 1 if a pivot is not positive
-__global__ __launch_bounds__(256) void k_chol_diag(int64_t N, int kb, double* __restrict__ A, double* __restrict__ dinv, int32_t* __restrict__ info) {
-  __shared__ double a[DT][DP];
-  __shared__ double w[DT][DP];
-  double* g = A + ((int64_t)kb * DT) * N + (int64_t)kb * DT;
-  tile_load(a, g, N, false);
-  __syncthreads();
+// the diagonal tile in LDS `a` (all threads have passed a barrier after filling it): Cholesky factor in place, its inverse in
+// `w`; L_kk goes to g (lower part), the inverse to dinv_k.  256 threads, ends without a barrier.
+__device__ __forceinline__ void chol_diag_tile(double (*a)[DP], double (*w)[DP], double* __restrict__ g, int64_t N, double* __restrict__ dinv_k,
+                                               int32_t* __restrict__ info) {
   // One wave factorises the tile column by column, lane r holding row r in registers (static indices: both loops
   // unrolled); the finished entries live in LDS as well, where the other lanes read row c as broadcasts:
   //   L[r][c] = (A[r][c] - sum_{k < c} L[r][k] L[c][k]) / L[c][c].
@@ -2195,8 +2193,20 @@ __global__ __launch_bounds__(256) void k_chol_diag(int64_t N, int kb, double* __
   for (int idx = threadIdx.x; idx < DT * DT; idx += 256) {
     const int r = idx / DT, c = idx % DT;
     if (r >= c) g[(int64_t)r * N + c] = a[r][c];
-    dinv[(int64_t)kb * DT * DT + idx] = w[r][c];
+    dinv_k[idx] = w[r][c];
   }
+}
+
+// diagonal tile kb: unblocked Cholesky in LDS, L_kk written back (lower part), its inverse (lower triangular, full
+// 64 x 64 with zeros above) into dinv[kb]; info[2] = 1 if a pivot is not positive.  Launched for kb = 0 only: the later
+// diagonal tiles are factorised by the workgroup of k_chol_update that completes them.
+__global__ __launch_bounds__(256) void k_chol_diag(int64_t N, int kb, double* __restrict__ A, double* __restrict__ dinv, int32_t* __restrict__ info) {
+  __shared__ double a[DT][DP];
+  __shared__ double w[DT][DP];
+  double* g = A + ((int64_t)kb * DT) * N + (int64_t)kb * DT;
+  tile_load(a, g, N, false);
+  __syncthreads();
+  chol_diag_tile(a, w, g, N, dinv + (int64_t)kb * DT * DT, info);
 }
 
 // panel below the diagonal tile: L_ik = A_ik L_kk^-T = A_ik (dinv_k)^T, block rows i = kb + 1 + blockIdx.x
@@ -2214,7 +2224,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(int64_t N, int kb, double* _
 }
 
 // trailing update: A_ij -= L_ik L_jk^T for kb < j <= i; blockIdx.x enumerates the pairs (i, j) of the trailing triangle
-__global__ __launch_bounds__(256) void k_chol_update(int64_t N, int kb, double* __restrict__ A) {
+__global__ __launch_bounds__(256) void k_chol_update(int64_t N, int kb, double* __restrict__ A, double* __restrict__ dinv, int32_t* __restrict__ info) {
   __shared__ double sa[DT][DP];
   __shared__ double sb[DT][DP];
   // pair index -> (ii >= jj) in the triangle of edge m = nblk - kb - 1
@@ -2229,6 +2239,15 @@ __global__ __launch_bounds__(256) void k_chol_update(int64_t N, int kb, double* 
   TileAcc acc;
   tile_mma(acc, sa, sb);
   double* g = A + ((int64_t)i * DT) * N + (int64_t)j * DT;
+  if (blockIdx.x == 0) {
+    // tile (kb + 1, kb + 1) is complete with this update: factorise it here, while the other workgroups update the rest of the
+    // trailing matrix -- the next step then starts with its panel (the separate diagonal launch was 51 of a step's 92 us)
+    __syncthreads();                                       // the products have read sa / sb
+    tile_foreach(acc, [&](int r, int c, double v) { sa[r][c] = g[(int64_t)r * N + c] - v; });
+    __syncthreads();
+    chol_diag_tile(sa, sb, g, N, dinv + (int64_t)(kb + 1) * DT * DT, info);
+    return;
+  }
   tile_foreach(acc, [&](int r, int c, double v) { g[(int64_t)r * N + c] -= v; });
 }
 
@@ -3390,11 +3409,11 @@ static int shell_pc_coarse_setup(femo_shell* s, const femo_vec* vals, const uint
   FEMO_HIP_CHECK(hipGetLastError());
   auto t1 = now();
   for (int kb = 0; kb < nblk; ++kb) {
-    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, st, N, kb, s->d_cs_A, s->d_cs_dinv, s->d_cs_info);
+    if (kb == 0) hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, st, N, kb, s->d_cs_A, s->d_cs_dinv, s->d_cs_info);
     const int m = nblk - kb - 1;
     if (m > 0) {
       hipLaunchKernelGGL(k_chol_panel, dim3(m), dim3(256), 0, st, N, kb, s->d_cs_A, s->d_cs_dinv);
-      hipLaunchKernelGGL(k_chol_update, dim3(m * (m + 1) / 2), dim3(256), 0, st, N, kb, s->d_cs_A);
+      hipLaunchKernelGGL(k_chol_update, dim3(m * (m + 1) / 2), dim3(256), 0, st, N, kb, s->d_cs_A, s->d_cs_dinv, s->d_cs_info);   // also factorises tile kb + 1
     }
   }
   auto t2 = now();
