@@ -600,7 +600,7 @@ class DeviceShell:
     def enable_lattice_pc(self, finest: Optional[int] = None, coarse_unknowns: Optional[int] = None, hermite: Optional[bool] = None) -> None:
         """Build and upload the lattice preconditioner once per mesh (used by ``solve(pc='lattice')``).
         ``coarse_unknowns``: size limit of the level that gets an exact (dense) coarse solve, 0 = none; default 3200
-        (``FEMO_SHELL_COARSE`` overrides).  ``hermite`` (default on, one rank, needs the coarse solve; ``FEMO_SHELL_TRILINEAR``
+        (``FEMO_SHELL_COARSE`` overrides).  ``hermite`` (default on, one rank or partitioned, needs the coarse solve; ``FEMO_SHELL_TRILINEAR``
         switches it off): Hermite-type lattice spaces -- the rotations of a lattice as the slopes of its displacements."""
         import os
         if hermite is None:
