@@ -119,3 +119,49 @@ def test_node_blocks_fall_back_when_elements_span_lattice_cells(ctx, monkeypatch
     K = so.assemble(V0, so.element_stiffness(V0, np.full(V0.n_vert, H_ROOF), E_ROOF, NU_ROOF)).tocsr()
     F = so.load_vector(V0, np.tile([0.0, 0.0, FZ], (V0.n_vert, 1)))
     assert prob.last_info.converged in (1, 2) and rel(w, so.solve(K, F, fixed)) <= 1e-6
+
+
+def test_set_up_kernels_on_a_high_valence_mesh(ctx, monkeypatch):
+    """A fan of 16 triangles around one vertex (valence 16: 66 node blocks in that vertex's row, three staging rounds of the
+    cell-per-wave kernel, more than 64 blocks of one point in the matrix-core kernel's accumulation): the default set-up kernels
+    against the row-wise node-block kernel and the LDS-atomic dense Galerkin kernel, and the solve against the oracle."""
+    from femo_amd.engine import Vec
+    from femo_amd.fea.shell import ShellProblem
+    ns = 16
+    ang = 2.0 * np.pi * np.arange(ns) / ns
+    ring = lambda rad, z: np.stack([rad * np.cos(ang), rad * np.sin(ang), np.full(ns, z)], axis=1)
+    pts = np.concatenate([[[0.0, 0.0, 0.3]], ring(1.0, 0.2), ring(2.0, 0.0)])                # a shallow cap
+    tri = []
+    for k in range(ns):
+        k1 = (k + 1) % ns
+        tri.append([0, 1 + k, 1 + k1])
+        tri.append([1 + k, 1 + ns + k, 1 + ns + k1])
+        tri.append([1 + k, 1 + ns + k1, 1 + k1])
+    conn = np.asarray(tri, dtype=np.int32)
+    V0 = so.ShellSpace(pts, conn)
+    outer = np.arange(1 + ns, 1 + 2 * ns)
+    on_rim = np.flatnonzero(np.isclose(np.hypot(V0.unode_x[:, 0], V0.unode_x[:, 1]), 2.0, atol=0.05) | (np.hypot(V0.unode_x[:, 0], V0.unode_x[:, 1]) > 1.9))
+    fixed = np.unique(np.concatenate([V0.u_dof(on_rim, c) for c in range(3)] + [V0.theta_dof(outer, c) for c in range(3)]))
+    h = np.full(V0.n_vert, 0.05)
+    mask = np.zeros(V0.n_dof, dtype=np.uint8)
+    mask[fixed] = 1
+    r = np.random.default_rng(13).standard_normal(V0.n_dof)
+    zs = {}
+    for rows, atomic in ((True, True), (False, False)):
+        for name, on in (("FEMO_SHELL_BLOCKS_BY_ROWS", rows), ("FEMO_SHELL_CG_ATOMIC", atomic)):
+            if on:
+                monkeypatch.setenv(name, "1")
+            else:
+                monkeypatch.delenv(name, raising=False)
+        prob = ShellProblem(pts, conn, 2.0e8, 0.3, fixed_dofs=fixed, ctx=ctx, pc="lattice")
+        prob.dev.enable_lattice_pc(coarse_unknowns=400)
+        assert prob.dev.hermite and prob.dev.coarse_level is not None
+        prob.set_thickness(h)
+        prob.set_load([0.0, 0.0, -1.0e3])
+        zs[(rows, atomic)] = prob.dev.pc_apply(prob._stiffness(), Vec(ctx, V0.n_dof).set(r), Vec(ctx, V0.n_dof), mask).get()
+    a, b = zs[(True, True)], zs[(False, False)]
+    assert np.abs(a - b).max() <= 1e-6 * np.abs(a).max()
+    w = prob.solve(rtol=1e-11)
+    K = so.assemble(V0, so.element_stiffness(V0, h, 2.0e8, 0.3)).tocsr()
+    F = so.load_vector(V0, np.tile([0.0, 0.0, -1.0e3], (V0.n_vert, 1)))
+    assert prob.last_info.converged in (1, 2) and rel(w, so.solve(K, F, fixed)) <= 1e-6
