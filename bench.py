@@ -301,17 +301,31 @@ class _Centroid:
 # iteration counts, the roofline of its dominant kernel (HIP events inside its own loop) and a CPU baseline at a
 # stated size (nothing scaled).
 # ---------------------------------------------------------------------------------------------------------------
-def _roofline(kernel: str, bytes_per_launch: int, ms: float, samples: int, note: str = "", stored: int = 0) -> dict:
+def _pmc_traffic(key: str):
+    """Bytes per launch from the committed hardware-counter pass of exactly this kernel at exactly this size
+    (profiles/r04_pmc_traffic.json, scripts/collect_profiles_r04.sh), or None."""
+    if not key:
+        return None
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"))).get(key)
+    except Exception:
+        return None
+
+
+def _roofline(kernel: str, bytes_per_launch: int, ms: float, samples: int, note: str = "", stored: int = 0, traffic_key: str = "") -> dict:
     """One byte convention for every configuration: `achieved` / `frac` from the ALGORITHMIC bytes (CSR
-    formula; for the shell the block format is the algorithm's own), `frac_physical` from the bytes the stored format
-    makes the kernel move (no PMC pass for these legs: `traffic` null, `physical_bytes_source` says so)."""
+    formula; for the shell the block format is the algorithm's own), `traffic` / `frac_physical` from the PMC pass of this
+    kernel at this size where one is committed (configs 2 and 3), else from the bytes the stored format makes the kernel
+    move (`physical_bytes_source` says which)."""
     ok = bool(ms and ms == ms and ms > 0)
     ach = bytes_per_launch / (ms * 1e-3) / 1e9 if ok else None
     stored = int(stored or bytes_per_launch)
+    traffic = _pmc_traffic(traffic_key)
+    phys = traffic if traffic else stored
     return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": None, "algorithmic_bytes_per_launch": int(bytes_per_launch),
-            "stored_bytes_per_launch": stored, "frac_physical": stored / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ok else None,
-            "physical_bytes_source": "stored bytes of the format the kernel reads",
+            "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": traffic, "algorithmic_bytes_per_launch": int(bytes_per_launch),
+            "stored_bytes_per_launch": stored, "frac_physical": phys / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ok else None,
+            "physical_bytes_source": "PMC (2*FETCH_SIZE + WRITE_SIZE, profiles/r04_pmc_traffic.json)" if traffic else "stored bytes of the format the kernel reads",
             "avg_launch_ms": ms, "launches_timed": samples,
             "timed": "single launches inside the timed solver loops (HIP events on the library's stream)" + (("; " + note) if note else "")}
 
@@ -368,7 +382,7 @@ def bench_config2(ctx, steps: int) -> dict:
            "cg_iterations_per_cycle": [i["iterations"] for i in infos[:per]],
            "roofline": _roofline("k_spmv_sell<1,true>", spmv_algorithmic_bytes(nnz, mesh.n_vert), spmv_ms, ns,
                                  "the matrix of this size (~140 MB stored) sits in the 256 MB Infinity Cache: an HBM fraction means little here",
-                                 stored=stored_bytes(dm.info, mesh.n_vert)),
+                                 stored=stored_bytes(dm.info, mesh.n_vert), traffic_key="spmv_n100"),
            "check": {"u_rel_err": rel(np.asarray(sim['u']), ref["u"]), "grad_rel_err": rel(np.asarray(E.host_wait(g)), ref["grad"]),
                      "against": "DST-exact cycle (oracle/c_port.py::poisson_cycle_dst)", "tolerance": 1e-10},
            "cpu_baseline": {"value": om.n_vert / cpu["times"]["cycle"], "unit": "DOFs/s", "cores": int(cpu["threads"]), "kind": "port",
@@ -630,7 +644,7 @@ def bench_config3(ctx, steps: int, n: int = 362, cpu_n: int = 48) -> dict:
             "cg_iterations_per_cycle": its[-1], "tip_deflection": tip_w, "tip_reference": -0.3024,
             "roofline": _roofline("k_bsell_spmv", b_spmv, spmv_ms / max(spmv_n, 1), spmv_n,
                                   "bytes in the block-SELL format the kernel reads (8.44 B per scalar entry), not scalar-CSR bytes: the "
-                                  "algorithmic and the stored count coincide", stored=b_spmv),
+                                  "algorithmic and the stored count coincide", stored=b_spmv, traffic_key="bsell_spmv_n362" if n == 362 else ""),
             "check": check,
             "cpu_baseline": {"value": cpu["n_dof"] / t_cpu, "unit": "DOFs/s", "cores": 1, "kind": "port",
                              "sample": f"oracle/shell_oracle.py::reference_cycle (NumPy assembly, SciPy SuperLU: 3 Newton factorisations + 1 for the "

@@ -38,11 +38,17 @@ for P in "FETCH_SIZE" "WRITE_SIZE L2CacheHit" "GRBM_GUI_ACTIVE VALUBusy MemUnitB
 done
 python3 scripts/pmc_table.py $O/pmc_kernels_n215.csv $O/pmc_215_FETCH_SIZE $O/pmc_215_WRITE_SIZE $O/pmc_215_GRBM_GUI_ACTIVE > /dev/null
 rm -rf $O/pmc_215_*
-python3 scripts/pmc_traffic.py $O/pmc_traffic.json $O/pmc_kernels_n215.csv > /dev/null
 for P in "FETCH_SIZE" "WRITE_SIZE L2CacheHit" "GRBM_GUI_ACTIVE VALUBusy MemUnitBusy MemUnitStalled"; do
   D=$O/pmc_shell_$(echo $P | cut -d" " -f1)
   (cd /tmp && FEMO_SHELL_PMC_ITS=4 timeout 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $D -- python3 $R/scripts/pmc_shell_kernels.py 362 > $D.log 2>&1)
 done
 python3 scripts/pmc_table.py $O/shell_pmc_kernels_n362.csv $O/pmc_shell_FETCH_SIZE $O/pmc_shell_WRITE_SIZE $O/pmc_shell_GRBM_GUI_ACTIVE > /dev/null
 rm -rf $O/pmc_shell_*
+for P in "FETCH_SIZE" "WRITE_SIZE L2CacheHit"; do
+  D=$O/pmc_100_$(echo $P | cut -d" " -f1)
+  (cd /tmp && timeout 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $D -- python3 $R/scripts/pmc_pc_kernels.py 100 > $D.log 2>&1)
+done
+python3 scripts/pmc_table.py $O/pmc_kernels_n100.csv $O/pmc_100_FETCH_SIZE $O/pmc_100_WRITE_SIZE > /dev/null
+rm -rf $O/pmc_100_*
+python3 scripts/pmc_traffic.py $O/pmc_traffic.json $O/pmc_kernels_n215.csv --also "spmv_n100=$O/pmc_kernels_n100.csv:k_spmv_sell<1, true>" "bsell_spmv_n362=$O/shell_pmc_kernels_n362.csv:k_bsell_spmv" > /dev/null
 ls -la $O
