@@ -754,6 +754,12 @@ __global__ __launch_bounds__(256) void k_lattice_prolong(int nf0, int nf1, int n
 // launches they cost ~4.7 us each in launch latency alone (2 x top launches per iteration).
 // Their g and e stay in LDS: with global memory between the phases the kernel took 36 us at C4
 // (six dependent round trips), more than the launches it replaced.
+// The top level of the single-workgroup coarse kernels lives in registers, FEMO_COARSE_TOPR entries per thread of 1024: up to
+// 5120 nodes (round 4: was 4096 -- a 2-D lattice of 64 bins has 65^2 = 4225 nodes and a 3-D one of 16 bins 17^3 = 4913, and
+// with those as top level the whole cycle fell back to one launch per lattice level: config 5 ran 14 launches per iteration).
+constexpr int FEMO_COARSE_TOPR = 5;
+constexpr int64_t FEMO_COARSE_TOP_MAX = 1024 * FEMO_COARSE_TOPR;
+
 struct CoarseLevels {
   int n_levels;                 // levels 0 .. n_levels-1 are handled here; level n_levels is `top`
   int n[FEMO_PC_MAX_LEVELS][3];
@@ -764,7 +770,7 @@ struct CoarseLevels {
   int64_t off[FEMO_PC_MAX_LEVELS];     // LDS offset (doubles) of level l: g at off, e at off + nodes
   int emit_top;                        // also e_top = coef_top g_top + I e_{top-1} (global), g_top cleared: the level the
                                        // brick kernel filled, so that no multi-block restriction / prolongation touches it
-  int top_in_lds;                      // g_top is copied to LDS at off[top] first (<= 4096 nodes and room for it)
+  int top_in_lds;                      // g_top is copied to LDS at off[top] first (<= FEMO_COARSE_TOP_MAX nodes and room for it)
   // restrict_top: g_top is not read but formed here, g_top = R g_finer (27-point restriction from the level the
   // brick kernel filled): the launch that did it (k_lattice_restrict, 5.6 us = one launch floor) is folded in
   const double* finer_g;
@@ -800,7 +806,7 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse(CoarseLevels L, int dim
   extern __shared__ double coarse_lds[];
   const int top = L.n_levels;
   const int tid = threadIdx.x;
-  constexpr int TOPR = 4;                           // g_top / coef_top entries per thread kept in registers
+  constexpr int TOPR = FEMO_COARSE_TOPR;                           // g_top / coef_top entries per thread kept in registers
   const int64_t n_top = L.nodes[top];
   double* g_top_lds = coarse_lds + L.off[top];      // the host reserves nodes[top] doubles there when they fit
   const bool top_in_lds = L.top_in_lds != 0;
@@ -1137,7 +1143,7 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
     }
   }
   // workgroup 0: the operands of its top level as well (they do not depend on alpha)
-  constexpr int TOPR = 4;
+  constexpr int TOPR = FEMO_COARSE_TOPR;
   double pre_h[TOPR], pre_g[TOPR], pre_c[TOPR];
   if (blockIdx.x == 0 && mc.dbg != 1) {
     const int top = L.n_levels;
@@ -1914,7 +1920,7 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
   int64_t below = 0;
   for (int l = 0; l + 1 < T; ++l) below += pc->L[l].nodes;
   const bool fused_cycle = nf >= 2 && T >= 2 && T < FEMO_PC_MAX_LEVELS - 1 && below * 2 * (int64_t)sizeof(double) <= 144 * 1024 &&
-                           pc->L[T - 1].nodes <= 4096 && FEMO_TUNE_ENV("FEMO_BPX_UNFUSED_LATTICE") == nullptr;
+                           pc->L[T - 1].nodes <= FEMO_COARSE_TOP_MAX && FEMO_TUNE_ENV("FEMO_BPX_UNFUSED_LATTICE") == nullptr;
   pc->fused_cycle_seen = fused_cycle;
   FEMO_REQUIRE(xupdate == nullptr || fused_cycle, "femo_pc_apply: the x update rides in the fused lattice cycle only");
   if (fused_cycle) {
@@ -1928,7 +1934,7 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
       CL.off[l] = l == 0 ? 0 : CL.off[l - 1] + 2 * CL.nodes[l - 1];
     }
     size_t lds = (size_t)below * 2 * sizeof(double);
-    CL.top_in_lds = (CL.nodes[T - 1] <= 4096 && lds + (size_t)CL.nodes[T - 1] * sizeof(double) <= 150 * 1024) ? 1 : 0;
+    CL.top_in_lds = (CL.nodes[T - 1] <= FEMO_COARSE_TOP_MAX && lds + (size_t)CL.nodes[T - 1] * sizeof(double) <= 150 * 1024) ? 1 : 0;
     if (CL.top_in_lds) lds += (size_t)CL.nodes[T - 1] * sizeof(double);
     CL.restrict_top = CL.top_in_lds;
     CL.finer_g = G(T, par);
@@ -1975,7 +1981,7 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
     // levels 0 .. cut-1 go through the single-workgroup kernel, which reads g of level `cut` from
     // global memory: one CU gathers 27 values per coarse node, so that level must stay small (with
     // 15.6 k nodes the phase alone took 25 us at C4)
-    constexpr int64_t COARSE_TOP_NODES = 4096;
+    constexpr int64_t COARSE_TOP_NODES = FEMO_COARSE_TOP_MAX;
     int cut = 0;
     int64_t coarse_total = 0;
     while (cut < nl - 1 - nf && cut < FEMO_PC_MAX_LEVELS - 1 && pc->L[cut + 1].nodes <= COARSE_TOP_NODES) coarse_total += pc->L[cut++].nodes;
@@ -1995,7 +2001,7 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
         CL.off[l] = l == 0 ? 0 : CL.off[l - 1] + 2 * CL.nodes[l - 1];
       }
       size_t lds = (size_t)coarse_total * 2 * sizeof(double);
-      CL.top_in_lds = (CL.nodes[cut] <= 4096 && lds + (size_t)CL.nodes[cut] * sizeof(double) <= 150 * 1024) ? 1 : 0;
+      CL.top_in_lds = (CL.nodes[cut] <= FEMO_COARSE_TOP_MAX && lds + (size_t)CL.nodes[cut] * sizeof(double) <= 150 * 1024) ? 1 : 0;
       if (CL.top_in_lds) lds += (size_t)CL.nodes[cut] * sizeof(double);
       CL.restrict_top = 0; CL.finer_g = nullptr; CL.finer_n[0] = CL.finer_n[1] = CL.finer_n[2] = 0;
       if (lds > 64 * 1024 && !pc->coarse_lds_set) {
@@ -2061,7 +2067,7 @@ static bool merged_shape_ok(const femo_pc* pc) {
   int64_t below = 0;
   for (int l = 0; l + 1 < T; ++l) below += pc->L[l].nodes;
   const int64_t lds = below * 2 * (int64_t)sizeof(double) + pc->L[T - 1].nodes * (int64_t)sizeof(double);
-  return pc->L[T - 1].nodes <= 4096 && below * 2 * (int64_t)sizeof(double) <= 144 * 1024 && lds <= 150 * 1024;
+  return pc->L[T - 1].nodes <= FEMO_COARSE_TOP_MAX && below * 2 * (int64_t)sizeof(double) <= 144 * 1024 && lds <= 150 * 1024;
 }
 
 bool femo_pc_merged_ok(femo_mesh* m) {
