@@ -392,6 +392,177 @@ def bench_config2(ctx, steps: int) -> dict:
     return rec
 
 
+def _rss_mb() -> float:
+    try:
+        with open("/proc/self/statm") as fh:
+            return int(fh.read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 1e6
+    except Exception:
+        return 0.0
+
+
+def bench_distributed(args, rank: int, world: int, local_rank: int):
+    """bench.py for N > 1: the 10 M-DOF mesh is partitioned over the ranks (strong scaling).
+    Returns the result line on rank 0 (None elsewhere); bench.py prints it.  A rank that fails takes the job
+    down instead of leaving the others in a barrier."""
+    from femo_amd.dist import TorchControl
+    from femo_amd.engine import Context
+    from femo_amd.fea import utils_hip
+    control = TorchControl(rank, world)
+    try:
+        ctx = Context(local_rank)
+        utils_hip.set_context(ctx)
+        control.init_comm(ctx)
+        result = run_distributed_bench(args, ctx, control)
+        control.barrier()
+        return result
+    except BaseException:                        # noqa: BLE001
+        import sys
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)                              # torchrun tears the other ranks down
+
+
+def run_distributed_bench(args, ctx, control, cpu_baseline: bool = True):
+    """One rank's part of the N > 1 benchmark: rank-local mesh, the operator stack on it, the timed cycles,
+    the JSON line on rank 0.  ``ctx`` already has its communicator (RCCL or emulated)."""
+    import sys
+    B = sys.modules[__name__]                                  # (moved out of femo_amd/dist: the package must not import its harness)
+    from femo_amd.dist import local_unit_mesh, _grid
+    from femo_amd.engine import Vec, host_wait as E_host_wait, pinned_array
+    from femo_amd.fea import utils_hip
+
+    rank, world = control.rank, control.world
+    utils_hip.KSP_OPTIONS["pc"] = B.PC = getattr(args, "pc", "bpx")
+    t0 = time.perf_counter()
+    rss0 = _rss_mb()
+    mesh = local_unit_mesh(args.n, 3, rank, world, jitter=getattr(args, "jitter", 0.0))
+    mesh._occupancy = float(control.allreduce([mesh.lattice_occupancy()], "max")[0])    # one choice of preconditioner for all
+    n_dof, n_cell_g = mesh.n_vert_global, mesh.n_cell_global
+    # like N = 1: NumPy arrays at the operator boundary, every rank holding its own share of f, u and dJ/df in
+    # pinned host memory (a distributed driver; each GPU has its own PCIe link)
+    sim, fea = B.build_problem(mesh, device=False)
+    dm = mesh.device(ctx)
+    K, W = args.steps, args.warmup
+    f_host = [pinned_array(f) for f in B.source_fields(mesh, min(K + W, 4))]
+    from femo_amd.engine import pinned_full
+    u0 = pinned_full(mesh.n_vert, 0.0)
+    setup_s = time.perf_counter() - t0
+    rss_setup = _rss_mb() - rss0
+
+    # pinned pool sized during set-up (see bench.py: two generations of result blocks are alive at a time)
+    from femo_amd.engine import pinned_empty
+    n_f, n_u = int(np.size(sim['f'])), int(np.size(sim['u']))          # sizes of the arrays that cross the boundary
+    prime = [pinned_empty(n_f) for _ in range(4)] + [pinned_empty(n_u) for _ in range(8)]
+    del prime
+    g = None
+    for w in range(W):
+        g = B.one_cycle(sim, fea, f_host[w % len(f_host)], u0)
+    ctx.sync()
+    control.barrier()
+    if rank == 0:
+        del utils_hip.LAST_KSP_INFO[:]
+    control.barrier()
+    ctx.comm_stats(reset=True)
+    t0 = time.perf_counter()
+    for k in range(K):
+        g = B.one_cycle(sim, fea, f_host[(W + k) % len(f_host)], u0)   # the gradient is the caller's: held until replaced
+    ctx.sync()
+    control.barrier()
+    elapsed = float(control.allreduce([time.perf_counter() - t0], "max")[0])
+    comm = ctx.comm_stats()
+    ms_per_step = elapsed / max(K, 1) * 1e3
+
+    import threading
+    me = threading.get_ident()                               # emulated ranks are threads sharing the module's log
+    infos = [i for i in utils_hip.LAST_KSP_INFO if i.get("thread") == me]
+    per = len(infos) // K if K else 0
+    its_per_step = [i["iterations"] for i in infos[:per]]
+    cg_ms = sum(i["solve_ms"] for i in infos) / max(K, 1)
+    A_mat = [w[1] for k, w in utils_hip._WORK.items() if k[1] == "newton_A" and w[0] is mesh][0].mat
+    xv = Vec(ctx, mesh.n_vert).set(np.random.default_rng(rank).standard_normal(mesh.n_vert))
+    yv = Vec(ctx, mesh.n_vert)
+    control.barrier()
+    spmv_ms = min(A_mat.bench_spmv(xv, yv, 50) for _ in range(3))      # local rows only, no halo: the kernel's own rate
+    local_nnz = dm.info["nnz"]
+    B_A = B.spmv_algorithmic_bytes(local_nnz, mesh.n_owned)
+    achieved = B_A / (spmv_ms * 1e-3) / 1e9
+    L = mesh.local
+    lat = dm.pc_info()
+    # bytes a rank moves per CG iteration besides its HBM traffic: ghost values in and out, the lattice all-reduce
+    halo_out, halo_in = int(L.send_ptr[-1]) * 8, int(L.recv_ptr[-1]) * 8
+    stats = control.gather([mesh.n_owned, mesh.n_vert - mesh.n_owned, len(L.nbr), halo_out, halo_in, achieved, spmv_ms,
+                            B.stored_bytes(dm.info, mesh.n_owned), rss_setup, setup_s])
+    # ---- self-check of the partitioned run (outside the timed region): one more cycle; rank 0 computes the DST-exact
+    # cycle of the WHOLE mesh (oracle/c_port.py::poisson_cycle_dst, no iterative solve), every rank compares the entries
+    # it owns, the largest error over the ranks goes into the record.  Structured cube only.
+    check = None
+    if not getattr(args, "no_check", False) and not getattr(args, "jitter", 0.0):
+        kc = (W + K) % len(f_host)
+        g_chk = np.array(E_host_wait(B.one_cycle(sim, fea, f_host[kc], u0)), copy=True)
+        u_chk = np.array(sim['u'], copy=True)
+        n_cell_g = mesh.n_cell_global
+        ref_u = ref_g = None
+        if rank == 0:
+            ref_u, ref_g = B.dst_reference_cycle(args.n, kc, min(K + W, 4))     # the checker lives with the harness, not in the package
+        ref_u = control.broadcast(ref_u, n_dof)
+        ref_g = control.broadcast(ref_g, n_cell_g)
+        own_v, own_c = L.vert_global[:L.n_owned], L.cell_global[L.cell_owned]
+        eu = float(np.abs(u_chk[:L.n_owned] - ref_u[own_v]).max()) if L.n_owned else 0.0
+        eg = float(np.abs(g_chk[L.cell_owned] - ref_g[own_c]).max()) if own_c.size else 0.0
+        errs = control.allreduce([eu, eg], "max")
+        check = {"u_rel_err": float(errs[0] / np.abs(ref_u).max()), "grad_rel_err": float(errs[1] / np.abs(ref_g).max()),
+                 "tolerance": 1e-10, "norm": "max over all ranks' owned entries, relative to the largest entry",
+                 "against": "DST-exact cycle of the whole mesh on rank 0 (oracle/c_port.py::poisson_cycle_dst)"}
+        del ref_u, ref_g
+    if rank != 0:
+        return None
+    result = {
+        "metric": B.METRIC, "value": n_dof / (ms_per_step * 1e-3), "unit": "DOFs/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": (f"3-D linear Poisson, P1 tets, unit cube n={args.n}: {n_dof} DOFs, {n_cell_g} cells, "
+                         f"{world}-way block partition {'x'.join(str(g) for g in _grid(world))} (rank-local mesh generation), "
+                         f"ghost-DOF halo (ncclSend/Recv) + RCCL all-reduce {B.PC.upper()}-CG; same cycle as N=1, every rank with "
+                         f"NumPy arrays of its share of f, u and dJ/df at the operator boundary"),
+            "boundary": "host (per rank: NumPy in pinned blocks; H2D + D2H inside the timed region)",
+            "preconditioner": B.PC, "pc_lattice": lat,
+            "n": args.n, "n_dof": n_dof, "n_cell": n_cell_g, "parallelism": f"block{world}",
+            "owned_per_rank": [int(s[0]) for s in stats], "ghosts_per_rank": [int(s[1]) for s in stats],
+            "neighbours_per_rank": [int(s[2]) for s in stats],
+            "halo_bytes_sent_per_exchange_per_rank": [int(s[3]) for s in stats],
+            "halo_bytes_received_per_exchange_per_rank": [int(s[4]) for s in stats],
+            # counted on rank 0 over the timed cycles (femo_comm_stats); the merged loop issues one all-reduce and one
+            # halo exchange per ENQUEUED iteration (batches: a few iterations behind the converged one are enqueued too)
+            "allreduce_per_cg_iteration": (sum(i.get("loop_allreduces", 0) for i in infos) / max(sum(i["iterations"] for i in infos), 1)),
+            "collectives_per_step_rank0": {k: v / max(K, 1) for k, v in comm.items()},
+            "allreduce_payload": "shared finest-lattice nodes + levels L-1, L-2 whole + 7 scalars (p.q, r.q, q.q, r.r, 3 lattice sums) in ONE ncclAllReduce per iteration",
+            "linear_solves_per_step": per, "cg_iterations_per_step": its_per_step, "cg_ms_per_step": cg_ms,
+            "non_cg_ms_per_step": ms_per_step - cg_ms,
+            "setup_s_per_rank": [float(s[9]) for s in stats], "setup_rss_mb_per_rank": [float(s[8]) for s in stats],
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": float(stats[0][5]), "peak": B.HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": float(stats[0][5]) / B.HBM_PEAK_GBS, "traffic": None,
+            "frac_physical": float(stats[0][7]) / (float(stats[0][6]) * 1e-3) / 1e9 / B.HBM_PEAK_GBS,
+            "physical_bytes_source": "stored bytes of the SELL format (no PMC pass at N > 1)",
+            "kernel": "k_spmv_sell<1,true> on rank 0's local rows (per GPU), 150 back-to-back launches",
+            "algorithmic_bytes_per_launch": B_A, "avg_launch_ms": float(stats[0][6]), "launches_timed": 150,
+            "achieved_per_rank": [float(s[5]) for s in stats],
+        },
+    }
+    if check is not None:
+        result["check"] = check
+    if cpu_baseline and not getattr(args, "no_cpu_baseline", False):
+        counts = its_per_step if its_per_step else [0]
+        n = args.n
+        nnz = n_dof + 2 * (3 * n * (n + 1) ** 2 + 3 * n * n * (n + 1) + n ** 3)      # SURVEY.md section 8
+        result["cpu_baseline"] = B.cpu_baseline(args, counts, n_dof, n_cell_g, nnz)
+    return result
+
+
 def bench_scaling_model(ctx, n_global: int, steps: int, headline_ms: float, headline_split: dict) -> dict:
     """What one rank of the 8-GPU run does, measured on THIS GPU ("prove the budget on one GPU"): the block
     of the 2 x 2 x 2 partition -- an (n/2)^3 cube in one octant of the unit cube, 1.26 M DOFs at n = 215 -- with the
@@ -630,7 +801,7 @@ def bench_config3(ctx, steps: int, n: int = 362, cpu_n: int = 48) -> dict:
     check = {"free_dof_residual_over_reactions": float(np.abs(r_free).max() / reaction), "residual_tolerance": 1e-7,
              "adjoint_identity_rel": float(abs(lhs - rhs) / abs(lhs)), "adjoint_identity_tolerance": 1e-7,
              "tip_deflection_rel_to_reference": float(abs(tip_w + 0.3024) / 0.3024), "tip_tolerance": 0.01,
-             "lattice_spaces": "Hermite-type" if getattr(prob.dev, "hermite", False) else "trilinear",
+             "lattice_spaces": "Hermite-type" if prob.dev.pc_state()["hermite_in_use"] else "trilinear",    # the device's state, not the request
              "against": "properties of the configuration itself: K w = F on the free dofs (against the reaction forces on the imposed ones), <w, c> = <F, K^-1 c>, Scordelis-Lo tip deflection -0.3024 "
                         "(tolerances follow eps * cond(K) ~ 1e-8 of a thin shell, DESIGN.md section 8)"}
     # CPU: the oracle's direct-solver cycle (the reference factorises: 3 Newton steps + 1 adjoint factorisation)
@@ -702,7 +873,6 @@ def _run(args):
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if world > 1 or os.environ.get("FEMO_BENCH_FORCE_DIST", "0") not in ("", "0"):   # the env switch runs the N>1 code path on one rank (tests)
-        from femo_amd.dist import bench_distributed
         return bench_distributed(args, rank, world, local_rank)
 
     from femo_amd import engine as E

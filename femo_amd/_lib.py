@@ -19,7 +19,7 @@ c_i64p = C.POINTER(C.c_int64)
 c_f64p = C.POINTER(C.c_double)
 H = C.c_void_p  # opaque handle
 
-ABI_VERSION = 7            # include/femo_hip.h FEMO_ABI_VERSION
+ABI_VERSION = 8            # include/femo_hip.h FEMO_ABI_VERSION
 MESH_INFO_COUNT = 12
 MESH_INFO_KEYS = ("tdim", "n_vert", "n_rows", "n_cell", "nnz", "sell_entries", "max_rowlen",
                   "max_valence", "n_slices", "visit_entries", "regular_slices", "short_slices")
@@ -102,6 +102,7 @@ PROTOTYPES = {
     "femo_emu_group_create": (C.c_int, [C.c_int, C.POINTER(H)]),
     "femo_emu_group_destroy": (C.c_int, [H]),
     "femo_comm_emulate": (C.c_int, [H, H, C.c_int]),
+    "femo_comm_model": (C.c_int, [H, C.c_int, C.c_int]),
     "femo_comm_stats": (C.c_int, [H, C.POINTER(C.c_int64), C.c_int]),
     # Reissner-Mindlin shell
     "femo_shell_create": (C.c_int, [H, c_i64, C.c_void_p, c_i64, C.c_void_p, c_i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(H)]),
@@ -110,6 +111,7 @@ PROTOTYPES = {
     "femo_shell_pc_coarse": (C.c_int, [H, C.c_int, C.c_void_p, c_i64] + [C.c_void_p] * 6),
     "femo_shell_pc_coarse_matrix": (C.c_int, [H, H, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(c_i64)]),
     "femo_shell_pc_hermite": (C.c_int, [H] + [C.c_void_p] * 11),
+    "femo_shell_pc_info": (C.c_int, [H, C.POINTER(C.c_int32)]),
     "femo_shell_pc_block_items": (C.c_int, [H, C.c_int64] + [C.c_void_p] * 4),
     "femo_shell_pc_weights": (C.c_int, [H, C.c_double, C.c_double]),
     "femo_shell_pc_apply": (C.c_int, [H, H, C.c_void_p, H, H]),

@@ -214,6 +214,7 @@ int femo_ctx_destroy(femo_ctx* c) {
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   if (c->comm_stream) hipStreamSynchronize(c->comm_stream);
+  if (c->comm_halo) ncclCommDestroy(c->comm_halo);
   if (c->comm) ncclCommDestroy(c->comm);
   if (c->comm_stream) hipStreamDestroy(c->comm_stream);
   if (c->ev_main) hipEventDestroy(c->ev_main);
@@ -273,6 +274,10 @@ int femo_vec_destroy(femo_vec* v) {
     hipEventSynchronize(v->d2h_ev);                    // a copy-out may still be reading the vector
     hipEventDestroy(v->d2h_ev);
   }
+  if (v->h2d_ev) {
+    hipEventSynchronize(v->h2d_ev);                    // ... or a deferred upload still writing it
+    hipEventDestroy(v->h2d_ev);
+  }
   if (v->owned && v->d) {
     hipStreamSynchronize(v->ctx->stream);
     hipFree(v->d);
@@ -305,6 +310,7 @@ int femo_vec_fill(femo_vec* v, double value) {
 int femo_vec_copy(femo_vec* dst, const femo_vec* src) {
   FEMO_REQUIRE(dst && src, "null argument");
   FEMO_REQUIRE(dst->n == src->n, "size mismatch in vec_copy");
+  FEMO_TRY(femo_vec_await(src));
   femo_vec_touch(dst);
   FEMO_HIP_CHECK(hipMemcpyAsync(dst->d, src->d, src->n * sizeof(double), hipMemcpyDeviceToDevice, dst->ctx->stream));
   return 0;
@@ -314,6 +320,7 @@ int femo_vec_axpy(femo_vec* y, double a, const femo_vec* x) {
   FEMO_REQUIRE(y && x, "null argument");
   FEMO_REQUIRE(y->n == x->n, "size mismatch in vec_axpy");
   if (y->n == 0) return 0;
+  FEMO_TRY(femo_vec_await(x));
   femo_vec_touch(y);
   hipLaunchKernelGGL(k_axpy, dim3(grid_for(y->n)), dim3(256), 0, y->ctx->stream, y->n, a, x->d, y->d);
   FEMO_HIP_CHECK(hipGetLastError());
@@ -584,13 +591,11 @@ int femo_assemble_system(femo_mesh* m, int pde, const double* params, const femo
   if (rhs) {
     FEMO_REQUIRE(u && f, "the Newton right-hand side needs u and f");
     FEMO_REQUIRE(u->n >= m->n_vert && f->n >= m->n_cell && rhs->n >= m->n_rows, "vector size mismatch in assemble_system");
-    if (m->n_nbr > 0) FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(u)));
-  } else if (u && m->n_nbr > 0 && pde != FEMO_PDE_POISSON) {
-    FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(u)));
   }
   FEMO_REQUIRE(aux == nullptr || aux->n >= m->n_vert, "aux field shorter than n_vert");
-  FEMO_TRY(femo_vec_await(u));
+  FEMO_TRY(femo_vec_await(u));          // before the halo exchange packs it
   FEMO_TRY(femo_vec_await(aux));
+  if (u && m->n_nbr > 0 && (rhs || pde != FEMO_PDE_POISSON)) FEMO_TRY(femo_halo_exchange(m, const_cast<femo_vec*>(u)));
   if (J_nobc) { J_nobc->valsT_valid = false; J_nobc->scaled_valid = false; J_nobc->s_valid = false; FEMO_TRY(note_pinned_vertices(J_nobc, pde, params, nullptr)); }
   femo_vec_touch(rhs);
   if (A_bc) { A_bc->valsT_valid = false; A_bc->scaled_valid = false; A_bc->s_valid = false; FEMO_TRY(note_pinned_vertices(A_bc, pde, params, bc)); }
@@ -789,6 +794,12 @@ int femo_comm_init(femo_ctx* ctx, const char id[128], int rank, int nranks) {
   FEMO_NCCL_CHECK(ncclCommInitRank(&ctx->comm, nranks, u, rank));
   ctx->rank = rank;
   ctx->nranks = nranks;
+  // second communicator for the neighbour exchanges (femo_internal.h: comm_halo); collective: every rank calls it here
+  ctx->comm_halo = nullptr;
+  if (!femo_env_flag("FEMO_SINGLE_COMM")) {
+    ncclComm_t split = nullptr;
+    if (ncclCommSplit(ctx->comm, 0, rank, &split, nullptr) == ncclSuccess && split != nullptr) ctx->comm_halo = split;
+  }
   return 0;
 }
 

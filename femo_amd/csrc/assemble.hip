@@ -1674,7 +1674,11 @@ int femo_launch_system(femo_mesh* m, int pde, const double* params, const double
   }
   auto finish_deferred = [&]() -> int {
     if (!defer) return 0;
-    if (A_solve != nullptr) FEMO_TRY(femo_mat_prescale(A_solve));      // S, S A S: what the solve with this matrix starts with
+    // S, S A S: what the solve with this matrix starts with.  One rank only: whether an upload was
+    // deferred is a rank-local fact (block size, pool state), and on a partitioned mesh ensure_s refreshes the ghost entries
+    // of S with a neighbour exchange -- ranks that disagreed would enqueue it on different sides of the Newton residual's
+    // all-reduce.  Everything else on this path is rank-local.
+    if (A_solve != nullptr && m->ctx->nranks == 1 && m->n_nbr == 0) FEMO_TRY(femo_mat_prescale(A_solve));
     FEMO_TRY(femo_vec_await(f_vec));
     FEMO_TRY(ensure_load_vector(m, f, f_uid, f_gen));
     hipLaunchKernelGGL(k_rhs_sub_load, dim3(cell_grid(m->n_rows)), dim3(FEMO_BLOCK), 0, m->ctx->stream, m->n_rows, m->d_load, bcmask, rhs);

@@ -105,6 +105,7 @@ int emu_neighbors(femo_ctx* ctx, int n_nbr, const int32_t* nbr, const int64_t* s
 int femo_coll_allreduce(femo_ctx* ctx, double* d, int64_t count, hipStream_t st) {
   if (count <= 0) return 0;
   ++ctx->n_allreduce; ctx->allreduce_doubles += count;
+  if (ctx->model) return 0;                                   // femo_comm_model: the rank's own contribution is the sum
   if (ctx->emu != nullptr) return emu_allreduce(ctx, d, count, st);
   FEMO_REQUIRE(ctx->comm != nullptr, "collective before femo_comm_init");
   FEMO_NCCL_CHECK(ncclAllReduce(d, d, (size_t)count, ncclDouble, ncclSum, ctx->comm, st));
@@ -116,14 +117,16 @@ int femo_coll_neighbors(femo_ctx* ctx, int n_nbr, const int32_t* nbr, const int6
                         const int64_t* recv_ptr, double* d_recv, hipStream_t st) {
   if (n_nbr == 0) return 0;
   ++ctx->n_neighbor; ctx->neighbor_doubles += send_ptr[n_nbr];
+  if (ctx->model) return 0;                                   // femo_comm_model: the ghost entries stay as they are
   if (ctx->emu != nullptr) return emu_neighbors(ctx, n_nbr, nbr, send_ptr, d_send, recv_ptr, d_recv, st);
   FEMO_REQUIRE(ctx->comm != nullptr, "halo exchange before femo_comm_init");
+  const ncclComm_t comm = ctx->comm_halo != nullptr ? ctx->comm_halo : ctx->comm;
   FEMO_NCCL_CHECK(ncclGroupStart());
   for (int k = 0; k < n_nbr; ++k) {
     const int64_t sc = send_ptr[k + 1] - send_ptr[k];
     const int64_t rc = recv_ptr[k + 1] - recv_ptr[k];
-    if (sc > 0) FEMO_NCCL_CHECK(ncclSend(d_send + send_ptr[k], (size_t)sc, ncclDouble, nbr[k], ctx->comm, st));
-    if (rc > 0) FEMO_NCCL_CHECK(ncclRecv(d_recv + recv_ptr[k], (size_t)rc, ncclDouble, nbr[k], ctx->comm, st));
+    if (sc > 0) FEMO_NCCL_CHECK(ncclSend(d_send + send_ptr[k], (size_t)sc, ncclDouble, nbr[k], comm, st));
+    if (rc > 0) FEMO_NCCL_CHECK(ncclRecv(d_recv + recv_ptr[k], (size_t)rc, ncclDouble, nbr[k], comm, st));
   }
   FEMO_NCCL_CHECK(ncclGroupEnd());
   return 0;
@@ -149,6 +152,16 @@ int femo_emu_group_create(int nranks, femo_emu_group** out) {
 
 int femo_emu_group_destroy(femo_emu_group* g) {
   delete g;
+  return 0;
+}
+
+int femo_comm_model(femo_ctx* ctx, int rank, int nranks) {
+  FEMO_REQUIRE(ctx != nullptr, "null argument");
+  FEMO_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank %d of %d", rank, nranks);
+  FEMO_REQUIRE(ctx->comm == nullptr && ctx->emu == nullptr, "communicator already initialised");
+  ctx->model = true;
+  ctx->rank = rank;
+  ctx->nranks = nranks;
   return 0;
 }
 

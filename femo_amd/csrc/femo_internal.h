@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "femo_hip.h"
+#include "femo_hip_test.h"
 
 // ---------------------------------------------------------------- errors ----
 void femo_set_error(const char* fmt, ...);
@@ -119,7 +120,13 @@ struct femo_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> ev_pool;
   ncclComm_t comm = nullptr;
+  // The neighbour exchanges (ncclSend/ncclRecv on the comm stream, overlapped with the interior SpMV) have a communicator
+  // of their own (ncclCommSplit of `comm`, round 5): RCCL serialises the operations of ONE communicator, so on a shared
+  // one the halo exchange of iteration k+1 and the all-reduce of iteration k could not be in flight together.  Falls back
+  // to `comm` when the split fails.
+  ncclComm_t comm_halo = nullptr;
   struct femo_emu_group* emu = nullptr;      // in-process rank emulation (tests; comm.cpp)
+  bool model = false;                        // femo_comm_model: N-rank code paths, collectives complete without moving data
   int rank = 0, nranks = 1;
   // collectives issued through femo_coll_allreduce / femo_coll_neighbors since the last femo_comm_stats(reset):
   // calls and doubles moved (per rank) -- the bench's scaling record and the tests count them per CG iteration

@@ -719,6 +719,7 @@ static int get_host_impl(const femo_vec* v, double* host, int64_t n, int op, boo
   if (n == 0) return 0;
   femo_ctx* c = v->ctx;
   FEMO_HIP_CHECK(hipSetDevice(c->device));
+  FEMO_TRY(femo_vec_await(v));                           // a deferred upload of v must have landed before it is read back
   FEMO_TRY(wait_block(host));                            // an earlier copy-out into the block must not land after this one
   bool pinned = false, exact_base = false;
   femo_vec* mirror = nullptr;                            // live vector the block is an exact copy of (op 1)

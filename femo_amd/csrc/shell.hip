@@ -91,7 +91,8 @@ struct femo_shell {
   // trilinear data above takes over): finest transfer weights per (point, corner), P_L^T rows per finest node (displacement
   // points, then rotation points), (a, b, c) of the node-level transfers, composed weights of the levels above the
   // coarse solve ([level][point][8], finest included) and of the coarse-solve level, composite restriction
-  bool hermite = false, hermite_on = false;             // uploaded / in use for the current stiffness
+  bool hermite = false, hermite_on = false;             // enabled (uploaded and not fallen back) / in use for the current stiffness
+  bool hermite_loaded = false;                          // the device arrays exist (guards a second upload; survives a fallback)
   // Weight of the node-block levels in the additive sum (round 4).  The levels between the coarse solve and the finest
   // lattice overlap each other and the point-block smoother; summed with weight 1 they overshoot (the same reason the
   // Poisson BPX carries theta = 0.6).  Measured on the roof, iterations per solve for weights 1 / 0.5 / 0.3 / 0.25 / 0.12:
@@ -3446,7 +3447,8 @@ static int shell_pc_coarse_setup(femo_shell* s, const femo_vec* vals, const uint
     s->cs_ready = all == 0.0;
   }
   if (s->hermite_on && !s->cs_ready) {
-    if (dbg) fprintf(stderr, "[femo] coarse solve: the Hermite-type operator could not be factorised (far %d, pivot %d): trilinear hierarchy\n", info[1], info[2]);
+    // said once per shell: bench and tests read the state back through femo_shell_pc_info
+    fprintf(stderr, "[femo] warning: the Hermite-type coarse operator could not be factorised (far %d, pivot %d); this shell falls back to the trilinear hierarchy\n", info[1], info[2]);
     // the Hermite-type transfers need their own (composed) coarse operator: without it the trilinear hierarchy takes over,
     // whose dense operator is formed now (the preconditioner changes, the solution does not)
     s->hermite = false;
@@ -3664,7 +3666,7 @@ int femo_shell_pc_hermite(femo_shell* s, const float* fin_w4, const int64_t* hp_
                           const int64_t* down_rowptr, const int32_t* down_cols, const double* down_w5) {
   FEMO_REQUIRE(s && fin_w4 && hp_rowptr && hp_cols && hp_w4 && par_w5 && chi_w5 && lvl_w4 && cs_w4, "null argument");
   FEMO_REQUIRE(s->pc_width > 0 && s->cs_level >= 0, "femo_shell_pc_hermite needs femo_shell_pc_create and femo_shell_pc_coarse first");
-  FEMO_REQUIRE(!s->hermite, "the shell already has its Hermite-type lattice data");
+  FEMO_REQUIRE(!s->hermite_loaded, "the shell already has its Hermite-type lattice data");
   hipStream_t st = s->ctx->stream;
   FEMO_HIP_CHECK(hipSetDevice(s->ctx->device));
   const int64_t n_pts = s->n_dof / 3;
@@ -3692,7 +3694,21 @@ int femo_shell_pc_hermite(femo_shell* s, const float* fin_w4, const int64_t* hp_
   FEMO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pc_coarse_galerkin_h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CGH_LDS));
   FEMO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pc_coarse_galerkin_mm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MM_LDS));
   s->hermite = true;
+  s->hermite_loaded = true;
   s->pc_vals_uid = 0; s->pc_vals_gen = 0;
+  return 0;
+}
+
+// State of the lattice preconditioner as the DEVICE side has it: out = {Hermite-type data uploaded, Hermite-type spaces in use
+// for the current stiffness, coarse solve factorised, node blocks ready}.  After a failed factorisation of the Hermite-type
+// coarse operator the library falls back to the trilinear hierarchy for good; callers that report or pin iteration counts
+// read the state here instead of remembering what they asked for.
+int femo_shell_pc_info(const femo_shell* s, int32_t out[4]) {
+  FEMO_REQUIRE(s && out, "null argument");
+  out[0] = s->hermite_loaded ? 1 : 0;
+  out[1] = (s->hermite && s->hermite_on && s->cs_ready && s->blk_ready) ? 1 : 0;
+  out[2] = s->cs_ready ? 1 : 0;
+  out[3] = s->blk_ready ? 1 : 0;
   return 0;
 }
 

@@ -992,7 +992,7 @@ int femo_halo_exchange_on(femo_mesh* m, femo_vec* x, hipStream_t st) {
   if (m->n_nbr == 0) return 0;
   femo_vec_touch(x);                                  // ghost entries change
   femo_ctx* ctx = m->ctx;
-  FEMO_REQUIRE(ctx->comm != nullptr || ctx->emu != nullptr, "halo exchange before femo_comm_init");
+  FEMO_REQUIRE(ctx->comm != nullptr || ctx->emu != nullptr || ctx->model, "halo exchange before femo_comm_init");
   FEMO_REQUIRE(x->n >= m->n_vert, "vector shorter than n_vert");
   const int64_t ns = m->send_ptr[m->n_nbr];
   if (ns > 0) {
@@ -1018,7 +1018,7 @@ static int halo_raw(femo_mesh* m, double* x) {
 static int halo_reverse_add(femo_mesh* m, double* y, hipStream_t st) {
   if (m->n_nbr == 0) return 0;
   femo_ctx* ctx = m->ctx;
-  FEMO_REQUIRE(ctx->comm != nullptr || ctx->emu != nullptr, "halo exchange before femo_comm_init");
+  FEMO_REQUIRE(ctx->comm != nullptr || ctx->emu != nullptr || ctx->model, "halo exchange before femo_comm_init");
   const int64_t ns = m->send_ptr[m->n_nbr];
   // roles swapped: what this rank receives in a forward exchange (its ghost tail) is what it sends back
   FEMO_TRY(femo_coll_neighbors(ctx, m->n_nbr, m->nbr.data(), m->recv_ptr.data(), y + m->n_rows, m->send_ptr.data(), m->d_send_buf, st));
@@ -1052,6 +1052,7 @@ extern "C" int femo_mat_spmv(const femo_mat* A, int transpose, const femo_vec* x
   femo_mesh* m = A->mesh;
   FEMO_REQUIRE(x->n >= m->n_vert && y->n >= m->n_rows, "vector size mismatch in spmv");
   FEMO_REQUIRE(x->d != y->d, "spmv cannot run in place");
+  FEMO_TRY(femo_vec_await(x));             // a deferred upload of x (every reader awaits)
   femo_vec_touch(y);
   const double* vals = A->d_vals;
   if (transpose && !transpose_is_local(m)) {
@@ -1072,6 +1073,8 @@ extern "C" int femo_mat_spmv(const femo_mat* A, int transpose, const femo_vec* x
 extern "C" int femo_vec_dot(const femo_vec* x, const femo_vec* y, int64_t n, double* out) {
   FEMO_REQUIRE(x && y && out, "null argument");
   FEMO_REQUIRE(n <= x->n && n <= y->n, "dot length exceeds vector size");
+  FEMO_TRY(femo_vec_await(x));
+  FEMO_TRY(femo_vec_await(y));
   femo_ctx* ctx = x->ctx;
   const int g = vec_grid(ctx, n);
   hipLaunchKernelGGL(k_dot, dim3(g), dim3(FEMO_BLOCK), 0, ctx->stream, n, x->d, y->d, ctx->d_partials);
@@ -1107,6 +1110,8 @@ extern "C" int femo_vec_dots(int k, const femo_vec* const* x, const femo_vec* co
     const int jj = j < k ? j : 0;
     FEMO_REQUIRE(x[jj] && y[jj] && n <= x[jj]->n && n <= y[jj]->n, "dot length exceeds vector size");
     d.a[j] = x[jj]->d; d.b[j] = y[jj]->d;
+    FEMO_TRY(femo_vec_await(x[jj]));
+    FEMO_TRY(femo_vec_await(y[jj]));
   }
   femo_ctx* ctx = x[0]->ctx;
   const int g = vec_grid(ctx, n);
@@ -1314,6 +1319,7 @@ static int solve_pcg_bpx_merged(femo_mat* A, const femo_vec* b, femo_vec* x, con
     float ms0 = 0.f;
     FEMO_HIP_CHECK(hipEventElapsedTime(&ms0, ctx->ev0, ctx->ev1));
     info->iterations = 0;
+    info->loop_allreduces = 0;
     info->converged = (h_flags[2] || !(rho0 == rho0)) ? -1 : 1;
     info->residual_norm = std::sqrt(rho0);
     info->solve_ms = ms0;

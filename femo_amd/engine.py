@@ -323,6 +323,12 @@ class Context:
         self.rank, self.nranks = int(rank), group.nranks
         self._emu_group = group            # keep it alive as long as the context
 
+    def comm_model(self, rank: int, nranks: int) -> None:
+        """Run the N-rank code paths alone on this GPU: collectives are counted but complete without moving data
+        (`femo_comm_model`, include/femo_hip_test.h; bench.py's scaling model)."""
+        check(self.lib.femo_comm_model(self.handle, int(rank), int(nranks)))
+        self.rank, self.nranks = int(rank), int(nranks)
+
     def comm_init(self, unique_id: bytes, rank: int, nranks: int) -> None:
         assert len(unique_id) == 128
         check(self.lib.femo_comm_init(self.handle, unique_id, rank, nranks))

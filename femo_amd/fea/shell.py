@@ -637,6 +637,13 @@ class DeviceShell:
             B = node_block_items(L, self.coarse_level + 1)
             check(self.lib.femo_shell_pc_block_items(self.handle, B["item_lvl"].size, q(B["item_ptr"]), q(B["item_lvl"]), q(B["item_pts"]), q(B["pcell"])))
 
+    def pc_state(self) -> dict:
+        """What the DEVICE side runs with (`femo_shell_pc_info`): ``self.hermite`` only says what was uploaded; the library
+        falls back to the trilinear hierarchy when the Hermite-type coarse operator cannot be factorised."""
+        out = (C.c_int32 * 4)()
+        check(self.lib.femo_shell_pc_info(self.handle, out))
+        return {"hermite_loaded": bool(out[0]), "hermite_in_use": bool(out[1]), "coarse_solve_ready": bool(out[2]), "node_blocks_ready": bool(out[3])}
+
     LEVEL_WEIGHT = 0.3          # the library's default (femo_shell_pc_weights; oracle: LatticePreconditioner.level_weight)
 
     def pc_weights(self, level_weight: float = LEVEL_WEIGHT, coarse_weight: float = 1.0) -> None:

@@ -33,14 +33,13 @@
 extern "C" {
 #endif
 
-#define FEMO_ABI_VERSION 7
+#define FEMO_ABI_VERSION 8
 
 typedef struct femo_ctx  femo_ctx;   /* device + stream + reduction workspace (+ RCCL communicator) */
 typedef struct femo_vec  femo_vec;   /* fp64 device vector  (dolfinx Function.vector / PETSc Vec)     */
 typedef struct femo_mesh femo_mesh;  /* P1 simplex mesh + vertex->cell incidence + sparsity pattern   */
 typedef struct femo_bc   femo_bc;    /* strong Dirichlet set (fea_dolfinx.py:169-176 add_strong_bc)   */
 typedef struct femo_mat  femo_mat;   /* N x N sparse matrix on the mesh pattern (PETSc Mat)           */
-typedef struct femo_emu_group femo_emu_group;  /* in-process rank emulation, tests only (see below)  */
 typedef struct femo_shell femo_shell; /* Reissner-Mindlin shell space CG2^3 x CG1^3 on a triangulated surface (below) */
 
 /* closed catalogue of residual forms (UFL is not available) */
@@ -356,15 +355,6 @@ int femo_mesh_set_halo(femo_mesh* mesh, int n_nbr, const int32_t* nbr,
 int femo_halo_exchange(femo_mesh* mesh, femo_vec* x);
 int femo_allreduce_sum(femo_ctx* ctx, double* host_inout, int n);
 
-/* ---- rank emulation on ONE GPU (tests) -----------------------------------------------------------
- * RCCL cannot place two ranks on one device.  With a femo_emu_group, `nranks` contexts on the same GPU,
- * each driven by its own host thread, behave as the ranks of a job: every collective of the library
- * (halo exchange, all-reduced scalars, all-reduced lattice accumulators) is staged through host memory
- * and a barrier instead of RCCL, so the multi-rank code paths run for real on a one-GPU box.  A rank
- * that never reaches a collective makes the others fail after 60 s instead of hanging.             */
-int femo_emu_group_create(int nranks, femo_emu_group** out);
-int femo_emu_group_destroy(femo_emu_group* group);
-int femo_comm_emulate(femo_ctx* ctx, femo_emu_group* group, int rank);
 /* Collectives issued on this context since the last reset: out = {all-reduce calls, doubles all-reduced, neighbour
  * exchanges, doubles sent}.  What `bench.py`'s scaling record and the tests divide by the CG iteration count (the
  * reference's only collective is the ghost update of utils_dolfinx.py:32,236).                                    */
@@ -478,6 +468,10 @@ int femo_shell_pc_coarse(femo_shell* s, int level, const int32_t* node_xyz, int6
 int femo_shell_pc_hermite(femo_shell* s, const float* fin_w4, const int64_t* hp_rowptr, const int32_t* hp_cols, const float* hp_w4,
                           const double* par_w5, const double* chi_w5, const float* lvl_w4, const float* cs_w4,
                           const int64_t* down_rowptr, const int32_t* down_cols, const double* down_w5);
+/* What the device side runs with: out = {Hermite-type data uploaded, Hermite-type spaces in use for the last stiffness set
+ * up, coarse solve factorised, node blocks ready}.  The library falls back to the trilinear hierarchy (once, with a warning
+ * on stderr) when the Hermite-type coarse operator cannot be factorised; reports and pinned iteration counts read this.  */
+int femo_shell_pc_info(const femo_shell* s, int32_t out[4]);
 /* Items of the node-block set-up for the Hermite-type spaces (optional; without it the blocks are formed row by row, 10.5
  * instead of ~2 ms at 1.97 M dofs): for every level above the coarse solve (item_lvl = level - cs_level - 1) the points grouped by
  * the lattice cell that contains them, at most 64 per item (item_ptr into item_pts; every point once per level);

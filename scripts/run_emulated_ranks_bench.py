@@ -9,7 +9,8 @@ import threading
 from argparse import Namespace
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from femo_amd.dist import ThreadControl, run_distributed_bench
+from femo_amd.dist import ThreadControl
+from bench import run_distributed_bench
 from femo_amd.engine import Context, EmuGroup
 from femo_amd.fea import utils_hip
 

@@ -436,11 +436,12 @@ def test_projection_on_two_emulated_ranks():
 
 
 def test_distributed_bench_record_on_eight_emulated_ranks():
-    """`bench.py --gpus 8` end to end with the eight ranks emulated on one GPU (dist.run_distributed_bench with a
+    """`bench.py --gpus 8` end to end with the eight ranks emulated on one GPU (bench.run_distributed_bench with a
     thread control plane instead of torch.distributed + RCCL): rank-local mesh generation under the 2 x 2 x 2
     block partition, NumPy arrays at every rank's operator boundary, and a record whose counts are consistent."""
     from argparse import Namespace
-    from femo_amd.dist import ThreadControl, run_distributed_bench
+    from femo_amd.dist import ThreadControl
+    from bench import run_distributed_bench
     from femo_amd.engine import Context, EmuGroup
     from femo_amd.fea import utils_hip
     world, n = 8, 48

@@ -38,6 +38,7 @@ def test_hermite_operator_matches_the_oracle(ctx, n, coarse):
     mask[fixed] = 1
     vals = prob._stiffness()
     A = prob.dev.coarse_matrix(vals, mask)
+    assert prob.dev.pc_state()["hermite_in_use"], "the device fell back to the trilinear hierarchy"
     A_ref = (M.P[M.c].T @ M.Kf @ M.P[M.c]).toarray()
     # (the oracle's P has zero rows on the fixed dofs, so the identity rows of Kf do not enter)
     assert A.shape == A_ref.shape

@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _header_symbols():
-    text = open(os.path.join(ROOT, "include", "femo_hip.h")).read()
+    # the product ABI (femo_hip.h) and the test-only entry points (femo_hip_test.h: rank emulation, model communicator)
+    text = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("femo_hip.h", "femo_hip_test.h"))
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(femo_[a-zA-Z0-9_]+)\s*\(", text)))
 
@@ -26,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/femo_hip.h but not exported"
     assert set(_lib.PROTOTYPES) == set(syms), set(_lib.PROTOTYPES) ^ set(syms)
-    assert lib.femo_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.femo_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_no_cpu_fallback():
