@@ -83,18 +83,27 @@ struct femo_pc {
   int64_t gs_n = 0;
   double* d_lat_partials = nullptr;   // per carrier workgroup of k_lattice_coarse_m: sum C g^2 over its part of levels T, L-1
   double* d_rr_partials = nullptr;    // ... and r.r of its part of the updated residual
-  // N > 1: what the single all-reduce needs besides the shared nodes
-  int64_t n_int = 0;
-  int32_t* d_int_idx = nullptr;       // finest-lattice nodes that only this rank touches
-  double* d_pack_scratch = nullptr;   // [3][PACK_GRID] per-block partials of the single-rank sums
-  uint32_t* d_ticket = nullptr;
+  // N > 1, merged loop (round 5): the three brick-filled levels T, L-1, L are ALL exchanged sparsely.  Indices below
+  // address the contiguous range [T | L-1 | L] (the layout of g_all / g_alt / gs + nodes(T-1) / coef_all from level T on).
+  //   d_mshared_idx: nodes that several ranks touch (same list on every rank): their partial sums travel, every rank keeps
+  //                  their state and adds their part of the lattice dot itself;
+  //   d_mint_idx:    nodes only this rank touches: updated locally, their part of the lattice dot travels as 3 scalars;
+  //                  the first n_mint_coarse entries lie on levels T and L-1 (the carriers of k_lattice_coarse_m update
+  //                  them; the finest level's are updated tile by tile in k_lattice_prolong3_m).
+  // Level T-1 (a few thousand nodes, where the replicated single-workgroup hierarchy starts) travels dense, already
+  // restricted: the pack kernel applies R to the rank's PARTIAL h_T (restriction is linear).  Round 4 sent levels T and L-1
+  // whole (133 k of the 138 k doubles of an all-reduce at C4 on 8 ranks) and scattered the sums back with an unpack launch.
+  int64_t n_mshared = 0, n_mint = 0, n_mint_coarse = 0;
+  int32_t* d_mshared_idx = nullptr;
+  int32_t* d_mint_idx = nullptr;
+  double* d_mbuf = nullptr;           // [shared nodes of T, L-1, L | R h_T on level T-1 | MS_NRED scalars]: the one all-reduce per iteration
+  bool merged_lds_set = false;        // k_lattice_coarse_m's LDS limit raised on this context's device (was a process-wide static)
   // ... and the part of the finest three levels this rank needs: the 8^3 (16^2) tiles of k_lattice_prolong3_m that hold a
-  // node it touches (1/N of the lattice plus the interface layers); the shared nodes outside them are kept current
-  // by the carriers of k_lattice_coarse_m (d_shared_out = 1 there)
+  // node it touches (1/N of the lattice plus the interface layers)
   int64_t n_my_tiles = 0;
   int32_t* d_my_tiles = nullptr;
   std::vector<uint8_t> tile_mine;     // host copy of the tile mask (from the brick list: every node a local vertex touches lies in one of them)
-  uint8_t* d_shared_out = nullptr;    // per shared node: 1 = not inside one of this rank's tiles
+  double* coef_all = nullptr;         // the coef arrays of all levels, coarsest first, contiguous (like g_all)
 };
 
 namespace {
@@ -1113,16 +1122,18 @@ struct MergedCarry {
   int64_t n_lvl[2];
   double* lat_partials;
   double* gs_top;             // state of level T-1
-  // N > 1: the finest-level nodes several ranks touch -- every rank holds their sums after the exchange and adds their
-  // part of the lattice dot itself; those outside this rank's tiles are also updated here (k_lattice_prolong3_m
-  // only visits the rank's own tiles)
-  int64_t n_shared; const int32_t* shared_idx; const uint8_t* shared_out;
-  double* gs_f; double* h_f; const double* coef_f;
+  // N > 1 (round 5): the reduced buffer of this iteration [sums on the shared nodes of levels T, L-1, L | R h_T on level T-1 |
+  // MS_NRED scalars] is read in place -- no unpack launch.  Indices address the contiguous range [T | L-1 | L] (gs_c, h_c,
+  // coef_c: its state, this apply's accumulators, its coefficients).  Every rank keeps the state of ALL shared nodes and adds
+  // their part of the lattice dot itself; of the nodes only this rank touches, those on levels T and L-1 are updated here
+  // (int_idx), the finest level's tile by tile in k_lattice_prolong3_m.  Accumulators are cleared in place: workgroup 0 reads
+  // R h_T from the buffer, nothing else reads them in this launch.
+  const double* buf;
+  int64_t n_shared; const int32_t* shared_idx;
+  int64_t n_intc; const int32_t* int_idx;
+  double* gs_c; double* h_c; const double* coef_c;
+  int64_t n_top_buf;                // nodes of level T-1 (the dense part of the buffer)
   int dbg;                          // timing experiments (FEMO_TUNING builds): 1 = workgroup 0 returns early, 2 = the carriers do
-  // R h_T (level T-1) formed before this launch by a multi-workgroup kernel (k_lattice_restrict on one rank, the unpack
-  // kernel on several): the 27-point restriction of 2197 nodes is ~14 us of index arithmetic on ONE compute unit, the
-  // critical path of an iteration when the mesh-sized streams of the carriers are short (partitioned / small meshes)
-  const double* hres;
   int64_t sep_off;                  // LDS offset (doubles) of the scratch of lattice_restrict3_sep, -1: the 27-tap restrictions
 };
 
@@ -1136,7 +1147,7 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
   double a_pq = 0.0;
   if (!mc.init) {
     if (mc.multi) {
-      a_pq = mc.S[MS_RED];
+      a_pq = mc.buf[mc.n_shared + mc.n_top_buf];          // p.q, reduced
     } else {
       for (int i = threadIdx.x; i < mc.nb_pq; i += 1024) a_pq += mc.pq_partials[i];
       for (int i = threadIdx.x; i < mc.nb_pq2; i += 1024) a_pq += mc.pq_partials2[i];
@@ -1152,7 +1163,7 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
     for (int q = 0; q < TOPR; ++q) {
       const int64_t idx = threadIdx.x + q * 1024;
       const bool in = idx < n_top;
-      pre_h[q] = in && mc.hres != nullptr ? mc.hres[idx] : 0.0;
+      pre_h[q] = in && mc.multi ? mc.buf[mc.n_shared + idx] : 0.0;     // N ranks: R h_T, restricted by the pack kernels and summed
       pre_g[q] = in ? mc.gs_top[idx] : 0.0;
       pre_c[q] = in ? L.coef[top][idx] : 0.0;
     }
@@ -1161,7 +1172,7 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
   extern __shared__ double coarse_lds[];
   // one rank: R h_T for the top level by separable passes into LDS, before alpha is needed (it does not depend on alpha)
   double* const sep = mc.sep_off >= 0 ? coarse_lds + mc.sep_off : nullptr;
-  if (blockIdx.x == 0 && mc.dbg != 1 && sep != nullptr && mc.hres == nullptr) {
+  if (blockIdx.x == 0 && mc.dbg != 1 && sep != nullptr && !mc.multi) {
     const int top = L.n_levels;
     const int64_t n_top = L.nodes[top];
     const int64_t s1 = (int64_t)(L.n[top][0] + 1) * (L.finer_n[1] + 1) * (L.finer_n[2] + 1);
@@ -1208,23 +1219,32 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
         rr += ri * ri;
       }
     }
+    if (!mc.multi) {
 #pragma unroll
-    for (int l = 0; l < 2; ++l) {
-      double* gs = mc.gs_lvl[l];
-      const double* h = mc.h_lvl[l];
-      const double* cf = mc.coef_lvl[l];
-      for (int64_t i = (int64_t)b * 1024 + threadIdx.x; i < mc.n_lvl[l]; i += (int64_t)nc * 1024) {
-        const double g = gs[i] - alpha * h[i];
-        gs[i] = g;
-        mc.h_other[l][i] = 0.0;
-        lat += cf[i] * g * g;
+      for (int l = 0; l < 2; ++l) {
+        double* gs = mc.gs_lvl[l];
+        const double* h = mc.h_lvl[l];
+        const double* cf = mc.coef_lvl[l];
+        for (int64_t i = (int64_t)b * 1024 + threadIdx.x; i < mc.n_lvl[l]; i += (int64_t)nc * 1024) {
+          const double g = gs[i] - alpha * h[i];
+          gs[i] = g;
+          mc.h_other[l][i] = 0.0;
+          lat += cf[i] * g * g;
+        }
       }
-    }
-    for (int64_t i = (int64_t)b * 1024 + threadIdx.x; i < mc.n_shared; i += (int64_t)nc * 1024) {
-      const int32_t j = mc.shared_idx[i];
-      const double g = mc.gs_f[j] - alpha * mc.h_f[j];
-      if (mc.shared_out[i]) { mc.gs_f[j] = g; mc.h_f[j] = 0.0; }
-      lat += mc.coef_f[j] * g * g;
+    } else {
+      for (int64_t i = (int64_t)b * 1024 + threadIdx.x; i < mc.n_shared; i += (int64_t)nc * 1024) {
+        const int32_t j = mc.shared_idx[i];
+        const double g = mc.gs_c[j] - alpha * mc.buf[i];
+        mc.gs_c[j] = g;
+        mc.h_c[j] = 0.0;                     // k_lattice_prolong3_m then finds nothing to subtract on the finest level's shared nodes
+        lat += mc.coef_c[j] * g * g;         // replicated: every rank adds the shared nodes' terms from the same numbers
+      }
+      for (int64_t i = (int64_t)b * 1024 + threadIdx.x; i < mc.n_intc; i += (int64_t)nc * 1024) {
+        const int32_t j = mc.int_idx[i];
+        mc.gs_c[j] -= alpha * mc.h_c[j];     // (their part of the lattice dot travelled as three scalars)
+        mc.h_c[j] = 0.0;
+      }
     }
     const double t0 = femo_block_sum<1024>(rr, red);
     if (threadIdx.x == 0) mc.rr_partials[b] = t0;
@@ -1233,6 +1253,13 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
     return;
   }
   if (threadIdx.x == 0) { mc.S[MS_ALPHA] = alpha; mc.S[MS_PQ] = pq; }
+  // N ranks: the reduced scalars where k_prolong_mesh looks for them
+  // (and the three sums the next pack launch accumulates with atomics are left zeroed)
+  if (mc.multi && threadIdx.x < MS_NRED) {
+    double* tail = const_cast<double*>(mc.buf) + mc.n_shared + mc.n_top_buf;
+    mc.S[MS_RED + threadIdx.x] = tail[threadIdx.x];
+    if (threadIdx.x >= 4) tail[threadIdx.x] = 0.0;
+  }
   if (mc.dbg == 1 || mc.dbg == 3) return;
   // workgroup 0: the LDS-resident coarse end, as k_lattice_coarse with restrict_top and emit_top, on the updated state
   const int top = L.n_levels;
@@ -1244,13 +1271,13 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
   // The 27-point restriction of h_T to level T-1 is ~14 us of index arithmetic when ONE compute unit does all 2197 nodes
   // of the 96^3 lattice's level (measured with the carriers switched off: 32 us for this workgroup, 21 without the
   // restriction; staging h_T in LDS first changed nothing -- it is instruction issue, not the gathers).  On N ranks the
-  // unpack kernel forms it (mc.hres); on one rank the carriers' mesh-sized streams hide this workgroup at the sizes where
-  // the lattice is that large.
+  // pack kernels form it before the all-reduce (pre_h, from the reduced buffer); on one rank the carriers' mesh-sized
+  // streams hide this workgroup at the sizes where the lattice is that large.
 #pragma unroll
   for (int q = 0; q < TOPR; ++q) {
     const int64_t idx = tid + q * 1024;
     const bool in = idx < n_top;
-    const double hres = !in ? 0.0 : ((mc.hres != nullptr || sep != nullptr) ? pre_h[q] : lattice_restrict_node32((int)idx, L.n[top], L.finer_n, dim, L.finer_g));
+    const double hres = !in ? 0.0 : ((mc.multi || sep != nullptr) ? pre_h[q] : lattice_restrict_node32((int)idx, L.n[top], L.finer_n, dim, L.finer_g));
     const double g0 = pre_g[q];
     ct[q] = pre_c[q];
     gt[q] = g0 - alpha * hres;
@@ -1448,77 +1475,61 @@ __global__ __launch_bounds__(256) void k_lattice_prolong3_m(FineLevels P, double
   }
 }
 
-// N > 1: what the single all-reduce of an iteration carries -- [h_L on the shared nodes | h_T, h_{L-1} whole | 7 scalars].
-// The scalars: p.q, r.q, q.q (partials of the SpMV launches), r.r (partials of the previous iteration's carriers) and,
-// over the finest-lattice nodes only this rank touches, sum C g g, C g h, C h h.  The last workgroup to finish (ticket)
-// folds every per-block partial in a fixed order.
+// N > 1: what the single all-reduce of an iteration carries -- [h on the shared nodes of levels T, L-1, L | R h_T on level T-1
+// (dense; formed here from the rank's PARTIAL h_T: restriction is linear, so the sum over the ranks is R of the summed h_T) |
+// 7 scalars].  The scalars: p.q, r.q, q.q (partials of the SpMV launches), r.r (partials of the previous iteration's
+// carriers) -- folded by workgroup 0 from partials that earlier LAUNCHES wrote -- and, over the nodes of the three levels
+// that only this rank touches, sum C g g, C g h, C h h: one fp64 atomic per workgroup and sum into the tail (which
+// k_lattice_coarse_m leaves zeroed).  No workgroup waits for another: round 4's last-block ticket cost two device-scope
+// fences on the critical path (21 us for this launch, 33 us with every thread fencing; measured round 5).  No unpack launch
+// follows the all-reduce: k_lattice_coarse_m reads the sums straight from this buffer.
 constexpr int PACK_GRID = 256;
 struct PackArgs {
-  int64_t n_shared; const int32_t* shared_idx; const double* h_f;
-  int64_t n_dense; const double* h_dense;
-  int64_t n_int; const int32_t* int_idx; const double* gs_f; const double* coef_f;
+  int64_t n_shared; const int32_t* shared_idx;        // into the contiguous [T | L-1 | L] range
+  const double* h;                                     // this apply's accumulators of that range
+  int64_t n_top; int nc[3], nf[3], dim;                // level T-1 <- level T (which leads the range)
+  int64_t n_int; const int32_t* int_idx; const double* gs; const double* coef;
   int nb_q[2]; const double* Pq[2];
   int nb_rr; const double* Prr;
-  double* buf; double* scratch; uint32_t* ticket;
+  double* buf;
+  int dbg;
 };
 __global__ __launch_bounds__(256) void k_pack_merged(PackArgs a, const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
   __shared__ double red[256 / 64];
-  __shared__ uint32_t s_last;
   const int64_t stride = (int64_t)gridDim.x * 256;
   const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  for (int64_t i = t0; i < a.n_shared + a.n_dense; i += stride) a.buf[i] = i < a.n_shared ? a.h_f[a.shared_idx[i]] : a.h_dense[i - a.n_shared];
-  double gg = 0.0, gh = 0.0, hh = 0.0;
-  for (int64_t i = t0; i < a.n_int; i += stride) {
-    const int32_t j = a.int_idx[i];
-    const double c = a.coef_f[j], g = a.gs_f[j], h = a.h_f[j];
-    gg += c * g * g; gh += c * g * h; hh += c * h * h;
-  }
+  double* tail = a.buf + a.n_shared + a.n_top;
   double t;
-  t = femo_block_sum<256>(gg, red); if (threadIdx.x == 0) a.scratch[blockIdx.x] = t;
-  t = femo_block_sum<256>(gh, red); if (threadIdx.x == 0) a.scratch[PACK_GRID + blockIdx.x] = t;
-  t = femo_block_sum<256>(hh, red); if (threadIdx.x == 0) a.scratch[2 * PACK_GRID + blockIdx.x] = t;
-  __threadfence();
-  if (threadIdx.x == 0) s_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  double* tail = a.buf + a.n_shared + a.n_dense;
-  // p.q, q.q, r.q: slots 0, 1, 2 of each SpMV launch's triple; tail order p.q, r.q, q.q, r.r, gg, gh, hh
-  const int slot_of[3] = {0, 2, 1};
-  for (int k = 0; k < 3; ++k) {
-    double acc = 0.0;
-    for (int l = 0; l < 2; ++l)
-      for (int i = threadIdx.x; i < a.nb_q[l]; i += 256) acc += a.Pq[l][(int64_t)slot_of[k] * FEMO_MAX_PARTIALS + i];
-    t = femo_block_sum<256>(acc, red);
-    if (threadIdx.x == 0) tail[k] = t;
+  if (blockIdx.x == 0) {
+    // p.q, q.q, r.q: slots 0, 1, 2 of each SpMV launch's triple; tail order p.q, r.q, q.q, r.r, gg, gh, hh
+    const int slot_of[3] = {0, 2, 1};
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      for (int l = 0; l < 2; ++l)
+        for (int i = threadIdx.x; i < a.nb_q[l]; i += 256) acc[k] += a.Pq[l][(int64_t)slot_of[k] * FEMO_MAX_PARTIALS + i];
+    for (int i = threadIdx.x; i < a.nb_rr; i += 256) acc[3] += a.Prr[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      t = femo_block_sum<256>(acc[k], red);
+      if (threadIdx.x == 0) tail[k] = t;
+    }
   }
-  {
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < a.nb_rr; i += 256) acc += a.Prr[i];
-    t = femo_block_sum<256>(acc, red);
-    if (threadIdx.x == 0) tail[3] = t;
-  }
-  for (int k = 0; k < 3; ++k) {
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) acc += a.scratch[k * PACK_GRID + i];
-    t = femo_block_sum<256>(acc, red);
-    if (threadIdx.x == 0) tail[4 + k] = t;
-  }
-  if (threadIdx.x == 0) *a.ticket = 0u;
-}
-struct TopRestrict { int nc[3], nf[3], dim; int64_t n_top; double* hres; };
-__global__ void k_unpack_merged(int64_t n_shared, const int32_t* __restrict__ idx, double* __restrict__ h_f, int64_t n_dense,
-                                double* __restrict__ h_dense, const double* __restrict__ buf, double* __restrict__ S,
-                                TopRestrict tr, const int32_t* __restrict__ done) {
-  if (done != nullptr && *done) return;
-  if (blockIdx.x == 0 && threadIdx.x < MS_NRED) S[MS_RED + threadIdx.x] = buf[n_shared + n_dense + threadIdx.x];
-  // R h_T for the coarse-lattice workgroup of the next launch, straight from the reduced buffer (level T leads the dense part)
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tr.n_top; i += (int64_t)gridDim.x * blockDim.x)
-    tr.hres[i] = lattice_restrict_node32((int)i, tr.nc, tr.nf, tr.dim, buf + n_shared);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_shared + n_dense; i += (int64_t)gridDim.x * blockDim.x) {
-    if (i < n_shared) h_f[idx[i]] = buf[i];
-    else h_dense[i - n_shared] = buf[i];
+  for (int64_t i = t0; i < a.n_shared; i += stride) a.buf[i] = a.h[a.shared_idx[i]];
+  if (!(a.dbg & 2))
+    for (int64_t i = t0; i < a.n_top; i += stride) a.buf[a.n_shared + i] = lattice_restrict_node32((int)i, a.nc, a.nf, a.dim, a.h);
+  double gg = 0.0, gh = 0.0, hh = 0.0;
+  if (!(a.dbg & 1))
+    for (int64_t i = t0; i < a.n_int; i += stride) {
+      const int32_t j = a.int_idx[i];
+      const double c = a.coef[j], g = a.gs[j], h = a.h[j];
+      gg += c * g * g; gh += c * g * h; hh += c * h * h;
+    }
+  if (t0 - threadIdx.x < a.n_int) {                  // workgroups that saw entries of the list (wave-uniform)
+    t = femo_block_sum<256>(gg, red); if (threadIdx.x == 0) atomicAdd(&tail[4], t);
+    t = femo_block_sum<256>(gh, red); if (threadIdx.x == 0) atomicAdd(&tail[5], t);
+    t = femo_block_sum<256>(hh, red); if (threadIdx.x == 0) atomicAdd(&tail[6], t);
   }
 }
 
@@ -1595,7 +1606,11 @@ int femo_pc_build(femo_mesh* m) {
     L.H = P.H[l];
     total += L.nodes;
     FEMO_HIP_CHECK(hipMalloc(&L.e, L.nodes * sizeof(double)));
-    FEMO_HIP_CHECK(hipMalloc(&L.coef, L.nodes * sizeof(double)));
+  }
+  FEMO_HIP_CHECK(hipMalloc(&pc->coef_all, total * sizeof(double)));
+  {
+    int64_t off = 0;
+    for (auto& L : pc->L) { L.coef = pc->coef_all + off; off += L.nodes; }
   }
   // every level once, then a second copy of the levels the brick kernel accumulates into (sized for the largest
   // n_fused: the three / four finest levels), see femo_pc::g_alt
@@ -1670,14 +1685,15 @@ int femo_pc_build(femo_mesh* m) {
 
 void femo_pc_destroy(femo_mesh* m) {
   if (!m->pc) return;
-  for (auto& L : m->pc->L) { (void)hipFree(L.e); (void)hipFree(L.coef); }
+  for (auto& L : m->pc->L) (void)hipFree(L.e);
+  (void)hipFree(m->pc->coef_all);
   (void)hipFree(m->pc->g_all);
   (void)hipFree(m->pc->d_perm); (void)hipFree(m->pc->d_pk); (void)hipFree(m->pc->d_pk_sorted); (void)hipFree(m->pc->d_w_sorted); (void)hipFree(m->pc->d_sinv); (void)hipFree(m->pc->d_dot_partials);
   (void)hipFree(m->pc->d_shared_idx); (void)hipFree(m->pc->d_dot_weight); (void)hipFree(m->pc->d_xbuf); (void)hipFree(m->pc->d_dot_scalar);
   (void)hipFree(m->pc->d_brick_ptr); (void)hipFree(m->pc->d_bin_ptr); (void)hipFree(m->pc->d_brick_base);
   (void)hipFree(m->pc->gs); (void)hipFree(m->pc->d_lat_partials); (void)hipFree(m->pc->d_rr_partials);
-  (void)hipFree(m->pc->d_my_tiles); (void)hipFree(m->pc->d_shared_out);
-  (void)hipFree(m->pc->d_int_idx); (void)hipFree(m->pc->d_pack_scratch); (void)hipFree(m->pc->d_ticket);
+  (void)hipFree(m->pc->d_my_tiles);
+  (void)hipFree(m->pc->d_mshared_idx); (void)hipFree(m->pc->d_mint_idx); (void)hipFree(m->pc->d_mbuf);
   delete m->pc;
   m->pc = nullptr;
 }
@@ -1751,76 +1767,103 @@ static int bricks_per_cu(int dim, int pf) {
     }                                                                                                                              \
   } while (0)
 
-// Which finest-lattice nodes do several ranks touch?  A rank's restriction only reaches the nodes
-// around its own vertices and its prolongation only reads those, so between ranks it is enough to
-// complete the sums on the nodes that more than one rank touches (the layers along the partition
-// interfaces, ~10 % of the lattice for 8 blocks of the cube); the next coarser level is summed
-// densely because every rank runs the coarse hierarchy on the whole lattice.  Collective, once per mesh.
+// Which lattice nodes do several ranks touch?  A rank's restriction only reaches the nodes around its own vertices (on
+// the finest lattice and, through the fused restrictions of the brick kernel, on the next coarser ones) and its
+// prolongation only reads those, so between ranks it is enough to complete the sums on the nodes that more than one
+// rank touches (the layers along the partition interfaces).  Collective, once per mesh.  Two sets of lists:
+//   classic loop (femo_pc_apply): the finest level's shared nodes; the coarser fused levels travel whole;
+//   merged loop (femo_pc_merged_apply, round 5): shared / single-rank nodes of ALL brick-filled levels (femo_pc::d_mshared_idx).
+static bool merged_shape_ok(const femo_pc* pc);
 static int pc_setup_shared(femo_mesh* m) {
   femo_pc* pc = m->pc;
   if (pc->shared_ready) return 0;
   femo_ctx* ctx = m->ctx;
   hipStream_t st = ctx->stream;
-  const int nl = pc->n_levels;
+  const int nl = pc->n_levels, nf = pc->n_fused;
+  const int T = nl - 1 - nf;
   LatticeLevel& F = pc->L[nl - 1];
   const Lat lat = make_lat(pc, F);
+  double* first = pc->L[T].g;                                // accumulators of levels T .. L (first copy), contiguous
+  const int64_t n_all = (F.g + F.nodes) - first;
+  const int64_t off_F = F.g - first;
   // touched pattern: restrict the constant 1 with unit weights (all interpolation weights are >= 0)
-  double* ones = nullptr;
+  double *ones = nullptr, *tmp = nullptr;
   FEMO_HIP_CHECK(hipMalloc(&ones, std::max<int64_t>(m->n_vert, 1) * sizeof(double)));
+  FEMO_HIP_CHECK(hipMalloc(&tmp, n_all * sizeof(double)));
   hipLaunchKernelGGL(k_fill_ones, dim3(lat_grid(m->n_vert)), dim3(256), 0, st, m->n_vert, ones);
   hipLaunchKernelGGL(k_fill_ones, dim3(lat_grid(m->n_rows)), dim3(256), 0, st, std::max<int64_t>(m->n_rows, 0), pc->d_w_sorted);
-  FEMO_HIP_CHECK(hipMemsetAsync(F.g, 0, F.nodes * sizeof(double), st));
+  FEMO_HIP_CHECK(hipMemsetAsync(first, 0, n_all * sizeof(double), st));
   if (pc->n_bricks > 0) {
     const unsigned gb = (unsigned)std::min<int64_t>(pc->n_bricks, (int64_t)ctx->n_cu * bricks_per_cu(pc->dim, pc->brick_pf));
-    FEMO_LAUNCH_BRICKS(pc, gb, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, ones, pc->d_w_sorted, F.g, 0, (const int32_t*)nullptr);
+    FEMO_LAUNCH_BRICKS(pc, gb, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, ones, pc->d_w_sorted, F.g, nf, (const int32_t*)nullptr);
   }
-  hipLaunchKernelGGL(k_mark_touched, dim3(lat_grid(F.nodes)), dim3(256), 0, st, F.nodes, F.g, F.e);
+  hipLaunchKernelGGL(k_mark_touched, dim3(lat_grid(n_all)), dim3(256), 0, st, n_all, first, tmp);
   FEMO_HIP_CHECK(hipGetLastError());
-  std::vector<double> mine((size_t)F.nodes), cnt((size_t)F.nodes);
-  FEMO_HIP_CHECK(hipMemcpyAsync(mine.data(), F.e, F.nodes * sizeof(double), hipMemcpyDeviceToHost, st));
-  FEMO_TRY(femo_coll_allreduce(ctx, F.e, F.nodes, st));
-  FEMO_HIP_CHECK(hipMemcpyAsync(cnt.data(), F.e, F.nodes * sizeof(double), hipMemcpyDeviceToHost, st));
+  std::vector<double> mine((size_t)n_all), cnt((size_t)n_all);
+  FEMO_HIP_CHECK(hipMemcpyAsync(mine.data(), tmp, n_all * sizeof(double), hipMemcpyDeviceToHost, st));
+  FEMO_TRY(femo_coll_allreduce(ctx, tmp, n_all, st));
+  FEMO_HIP_CHECK(hipMemcpyAsync(cnt.data(), tmp, n_all * sizeof(double), hipMemcpyDeviceToHost, st));
   FEMO_HIP_CHECK(hipStreamSynchronize(st));
   (void)hipFree(ones);
+  (void)hipFree(tmp);
+  if (ctx->model) {
+    // femo_comm_model (one context standing in for a rank of an N-GPU job): nobody else contributes touch counts.  The
+    // nodes a real neighbour would share are the outer layers of the touched box that face the inside of the lattice --
+    // two layers per cut face on every level (what the emulated 8-rank runs show for block partitions).
+    for (int l = T; l < nl; ++l) {
+      const LatticeLevel& Lv = pc->L[l];
+      const int64_t off = Lv.g - first;
+      const int64_t n0 = Lv.n[0] + 1, n1 = Lv.n[1] + 1;
+      int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-1, -1, -1};
+      for (int64_t i = 0; i < Lv.nodes; ++i) {
+        if (mine[(size_t)(off + i)] == 0.0) continue;
+        const int c[3] = {(int)(i % n0), (int)((i / n0) % n1), (int)(i / (n0 * n1))};
+        for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], c[k]); hi[k] = std::max(hi[k], c[k]); }
+      }
+      for (int64_t i = 0; i < Lv.nodes; ++i) {
+        if (mine[(size_t)(off + i)] == 0.0) continue;
+        const int c[3] = {(int)(i % n0), (int)((i / n0) % n1), (int)(i / (n0 * n1))};
+        bool sh = false;
+        for (int k = 0; k < pc->dim; ++k) sh = sh || (hi[k] < Lv.n[k] && c[k] >= hi[k] - 1) || (lo[k] > 0 && c[k] <= lo[k] + 1);
+        if (sh) cnt[(size_t)(off + i)] = 2.0;
+      }
+    }
+  }
+  // classic loop: the finest level
   std::vector<int32_t> shared;
   std::vector<double> weight((size_t)F.nodes, 0.0);
   for (int64_t i = 0; i < F.nodes; ++i) {
-    if (cnt[(size_t)i] >= 1.5) shared.push_back((int32_t)i);
-    if (mine[(size_t)i] != 0.0) weight[(size_t)i] = 1.0 / cnt[(size_t)i];
+    if (cnt[(size_t)(off_F + i)] >= 1.5) shared.push_back((int32_t)i);
+    if (mine[(size_t)(off_F + i)] != 0.0) weight[(size_t)i] = 1.0 / cnt[(size_t)(off_F + i)];
   }
   pc->n_shared = (int64_t)shared.size();
-  {
-    // merged loop: the nodes only this rank touches (their part of the lattice dot travels as three scalars)
-    std::vector<int32_t> interior;
-    for (int64_t i = 0; i < F.nodes; ++i)
-      if (cnt[(size_t)i] < 1.5 && mine[(size_t)i] != 0.0) interior.push_back((int32_t)i);
-    pc->n_int = (int64_t)interior.size();
-    FEMO_HIP_CHECK(hipMalloc(&pc->d_int_idx, std::max<size_t>(interior.size(), 1) * sizeof(int32_t)));
-    if (!interior.empty()) FEMO_HIP_CHECK(hipMemcpy(pc->d_int_idx, interior.data(), interior.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    // the shared nodes outside this rank's tiles (femo_pc_build) are kept current by the carriers of k_lattice_coarse_m
-    const int TF = pc->dim == 3 ? 8 : 16;
-    int tn[3] = {1, 1, 1};
-    for (int k = 0; k < pc->dim; ++k) tn[k] = (F.n[k] + TF) / TF;
-    const std::vector<uint8_t>& tile_mine = pc->tile_mine;
-    const int64_t n0 = F.n[0] + 1, n1 = F.n[1] + 1;
-    auto tile_of = [&](int64_t i) -> int64_t {
-      const int64_t ix = i % n0, iy = (i / n0) % n1, iz = i / (n0 * n1);
-      return ((iz / TF) * tn[1] + iy / TF) * tn[0] + ix / TF;
-    };
-    std::vector<uint8_t> sh_out(std::max<size_t>(shared.size(), 1), 0);
-    for (size_t q = 0; q < shared.size(); ++q) sh_out[q] = tile_mine[(size_t)tile_of(shared[q])] ? 0 : 1;
-    FEMO_HIP_CHECK(hipMalloc(&pc->d_shared_out, sh_out.size()));
-    FEMO_HIP_CHECK(hipMemcpy(pc->d_shared_out, sh_out.data(), sh_out.size(), hipMemcpyHostToDevice));
+  auto upload_i32 = [&](int32_t** dst, const std::vector<int32_t>& v) -> int {
+    FEMO_HIP_CHECK(hipMalloc(dst, std::max<size_t>(v.size(), 1) * sizeof(int32_t)));
+    if (!v.empty()) FEMO_HIP_CHECK(hipMemcpy(*dst, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return 0;
+  };
+  if (merged_shape_ok(pc)) {
+    FEMO_REQUIRE(n_all < (int64_t(1) << 31), "lattice too large for 32-bit node lists");
+    std::vector<int32_t> msh, mint;
+    const int64_t n_coarse_nodes = off_F;                     // levels T and L-1 lead the range
+    int64_t n_int_coarse = 0;
+    for (int64_t i = 0; i < n_all; ++i) {
+      if (cnt[(size_t)i] >= 1.5) msh.push_back((int32_t)i);
+      else if (mine[(size_t)i] != 0.0) { mint.push_back((int32_t)i); if (i < n_coarse_nodes) ++n_int_coarse; }
+    }
+    pc->n_mshared = (int64_t)msh.size(); pc->n_mint = (int64_t)mint.size(); pc->n_mint_coarse = n_int_coarse;
+    FEMO_TRY(upload_i32(&pc->d_mshared_idx, msh));
+    FEMO_TRY(upload_i32(&pc->d_mint_idx, mint));
+    FEMO_HIP_CHECK(hipMalloc(&pc->d_mbuf, (pc->n_mshared + pc->L[T - 1].nodes + MS_NRED) * sizeof(double)));
+    FEMO_HIP_CHECK(hipMemsetAsync(pc->d_mbuf, 0, (pc->n_mshared + pc->L[T - 1].nodes + MS_NRED) * sizeof(double), st));
   }
-  const int64_t n_coarse = F.g - pc->L[nl - 1 - pc->n_fused].g;      // the coarser fused levels travel whole
-  FEMO_HIP_CHECK(hipMalloc(&pc->d_shared_idx, std::max<size_t>(shared.size(), 1) * sizeof(int32_t)));
+  const int64_t n_coarse = off_F;                             // classic loop: the coarser fused levels travel whole
+  FEMO_TRY(upload_i32(&pc->d_shared_idx, shared));
   FEMO_HIP_CHECK(hipMalloc(&pc->d_dot_weight, F.nodes * sizeof(double)));
-  FEMO_HIP_CHECK(hipMalloc(&pc->d_xbuf, (pc->n_shared + n_coarse + 1 + MS_NRED) * sizeof(double)));
+  FEMO_HIP_CHECK(hipMalloc(&pc->d_xbuf, (pc->n_shared + n_coarse + 1) * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&pc->d_dot_scalar, sizeof(double)));
-  if (!shared.empty()) FEMO_HIP_CHECK(hipMemcpy(pc->d_shared_idx, shared.data(), shared.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   FEMO_HIP_CHECK(hipMemcpy(pc->d_dot_weight, weight.data(), F.nodes * sizeof(double), hipMemcpyHostToDevice));
-  FEMO_HIP_CHECK(hipMemsetAsync(F.g, 0, F.nodes * sizeof(double), st));
-  FEMO_HIP_CHECK(hipMemsetAsync(F.e, 0, F.nodes * sizeof(double), st));
+  FEMO_HIP_CHECK(hipMemsetAsync(first, 0, n_all * sizeof(double), st));
   pc->shared_ready = true;
   return 0;
 }
@@ -2091,9 +2134,6 @@ int femo_pc_merged_begin(femo_mesh* m, const double* s, const uint8_t* mask) {
     FEMO_HIP_CHECK(hipMalloc(&pc->gs, pc->gs_n * sizeof(double)));
     FEMO_HIP_CHECK(hipMalloc(&pc->d_lat_partials, FEMO_MAX_PARTIALS * sizeof(double)));
     FEMO_HIP_CHECK(hipMalloc(&pc->d_rr_partials, FEMO_MAX_PARTIALS * sizeof(double)));
-    FEMO_HIP_CHECK(hipMalloc(&pc->d_pack_scratch, 3 * PACK_GRID * sizeof(double)));
-    FEMO_HIP_CHECK(hipMalloc(&pc->d_ticket, sizeof(uint32_t)));
-    FEMO_HIP_CHECK(hipMemsetAsync(pc->d_ticket, 0, sizeof(uint32_t), st));
   }
   if (m->n_rows > 0) hipLaunchKernelGGL(k_pc_weights, dim3(lat_grid(m->n_rows)), dim3(256), 0, st, m->n_rows, pc->d_perm, s, mask, pc->d_w_sorted, pc->d_sinv);
   double* first = pc->L[T].g;
@@ -2131,23 +2171,23 @@ int femo_pc_merged_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, c
     const unsigned gb = (unsigned)std::min<int64_t>(pc->n_bricks, (int64_t)ctx->n_cu * bricks_per_cu(pc->dim, pc->brick_pf));
     FEMO_LAUNCH_BRICKS(pc, gb, st, pc->n_bricks, pc->d_brick_ptr, pc->d_brick_base, pc->d_bin_ptr, pc->d_perm, pc->d_pk_sorted, lat, init ? (const double*)V.r : V.q, pc->d_w_sorted, hF, nf, done);
   }
+  const int64_t n_top = pc->L[T - 1].nodes;
   if (multi) {
-    FEMO_REQUIRE(pc->shared_ready, "femo_pc_merged_apply: the sparse lattice exchange is not set up");
+    FEMO_REQUIRE(pc->shared_ready && pc->d_mbuf != nullptr, "femo_pc_merged_apply: the sparse lattice exchange is not set up");
     PackArgs a;
-    a.n_shared = pc->n_shared; a.shared_idx = pc->d_shared_idx; a.h_f = hF;
-    a.h_dense = H(T, par); a.n_dense = hF - H(T, par);
-    a.n_int = pc->n_int; a.int_idx = pc->d_int_idx; a.gs_f = GS(nl - 1); a.coef_f = F.coef;
+    a.n_shared = pc->n_mshared; a.shared_idx = pc->d_mshared_idx; a.h = H(T, par);
+    a.n_top = n_top; a.dim = pc->dim;
+    for (int k = 0; k < 3; ++k) { a.nc[k] = pc->L[T - 1].n[k]; a.nf[k] = pc->L[T].n[k]; }
+    a.n_int = pc->n_mint; a.int_idx = pc->d_mint_idx; a.gs = GS(T); a.coef = pc->L[T].coef;
     for (int l = 0; l < 2; ++l) { a.nb_q[l] = init ? 0 : V.nb_q[l]; a.Pq[l] = V.Pq[l]; }
     a.nb_rr = init ? 0 : std::max(1, ctx->n_cu - 1); a.Prr = pc->d_rr_partials;
-    a.buf = pc->d_xbuf; a.scratch = pc->d_pack_scratch; a.ticket = pc->d_ticket;
-    const int64_t count = a.n_shared + a.n_dense;
-    const unsigned gp = (unsigned)std::min<int64_t>(PACK_GRID, std::max<int64_t>(1, (std::max(count, a.n_int) + 255) / 256));
+    a.buf = pc->d_mbuf;
+    static const int dbg_pack = FEMO_TUNE_ENV("FEMO_DEBUG_PACK") ? atoi(FEMO_TUNE_ENV("FEMO_DEBUG_PACK")) : 0;
+    a.dbg = dbg_pack;
+    const int64_t work = std::max(std::max(a.n_shared, a.n_int), n_top);
+    const unsigned gp = (unsigned)std::min<int64_t>(PACK_GRID, std::max<int64_t>(1, (work + 255) / 256));
     hipLaunchKernelGGL(k_pack_merged, dim3(gp), dim3(256), 0, st, a, done);
-    FEMO_TRY(femo_coll_allreduce(ctx, pc->d_xbuf, count + MS_NRED, st));
-    TopRestrict tr;
-    for (int k = 0; k < 3; ++k) { tr.nc[k] = pc->L[T - 1].n[k]; tr.nf[k] = pc->L[T].n[k]; }
-    tr.dim = pc->dim; tr.n_top = pc->L[T - 1].nodes; tr.hres = pc->L[T - 1].g;
-    hipLaunchKernelGGL(k_unpack_merged, dim3(lat_grid(std::max<int64_t>(std::max(count, tr.n_top), 1))), dim3(256), 0, st, a.n_shared, pc->d_shared_idx, hF, a.n_dense, H(T, par), pc->d_xbuf, S, tr, done);
+    FEMO_TRY(femo_coll_allreduce(ctx, pc->d_mbuf, a.n_shared + n_top + MS_NRED, st));
   }
   // workgroup 0: the LDS-resident levels; the others: vector and lattice updates
   CoarseLevels CL;
@@ -2169,11 +2209,6 @@ int femo_pc_merged_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, c
     FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_coarse, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     pc->coarse_lds_set = true;
   }
-  static bool merged_lds_set = false;
-  if (lds > 64 * 1024 && !merged_lds_set) {
-    FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_coarse_m, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-    merged_lds_set = true;
-  }
   const int n_carry = std::max(1, ctx->n_cu - 1);
   MergedCarry mc;
   mc.S = S; mc.cur = V.cur; mc.multi = multi ? 1 : 0; mc.init = init ? 1 : 0;
@@ -2186,11 +2221,13 @@ int femo_pc_merged_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, c
     mc.h_other[l] = H(lev, par ^ 1);
   }
   mc.gs_top = GS(T - 1);
-  mc.n_shared = multi ? pc->n_shared : 0; mc.shared_idx = pc->d_shared_idx; mc.shared_out = pc->d_shared_out;
-  mc.gs_f = GS(nl - 1); mc.h_f = hF; mc.coef_f = F.coef;
+  mc.buf = multi ? pc->d_mbuf : nullptr;
+  mc.n_shared = multi ? pc->n_mshared : 0; mc.shared_idx = pc->d_mshared_idx;
+  mc.n_intc = multi ? pc->n_mint_coarse : 0; mc.int_idx = pc->d_mint_idx;
+  mc.gs_c = GS(T); mc.h_c = H(T, par); mc.coef_c = pc->L[T].coef;
+  mc.n_top_buf = n_top;
   static const int dbg_coarse = FEMO_TUNE_ENV("FEMO_DEBUG_COARSE") ? atoi(FEMO_TUNE_ENV("FEMO_DEBUG_COARSE")) : 0;
   mc.dbg = dbg_coarse;
-  mc.hres = multi ? pc->L[T - 1].g : nullptr;
   // scratch of the separable restrictions (3-D): the largest of the top restriction (one rank: level T -> T-1, + its output)
   // and the LDS-resident ones; behind the levels when it fits
   size_t lds_all = lds;
@@ -2205,9 +2242,9 @@ int femo_pc_merged_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, c
     const int64_t off = (int64_t)(lds / sizeof(double));
     if ((off + scratch) * (int64_t)sizeof(double) <= 158 * 1024) { mc.sep_off = off; lds_all = (size_t)(off + scratch) * sizeof(double); }
   }
-  if (lds_all > 64 * 1024 && !merged_lds_set) {
+  if (lds_all > 64 * 1024 && !pc->merged_lds_set) {
     FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_coarse_m, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-    merged_lds_set = true;
+    pc->merged_lds_set = true;
   }
   hipLaunchKernelGGL(k_lattice_coarse_m, dim3(1 + n_carry), dim3(1024), lds_all, st, CL, pc->dim, done, mc);
   FineLevels FL;

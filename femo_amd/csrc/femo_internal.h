@@ -229,6 +229,7 @@ struct femo_mesh {
   double* d_zero_load = nullptr; // zeros of the same length (deferred-upload path of femo_launch_system)
   uint64_t load_uid = 0, load_gen = 0;
   int pcg_last_iters = 0, pcg_prev_iters = 0;   // iterations of the last two converged BPX-PCG solves on this mesh (size the first batch)
+  double pcg_rate = 0.0;                        // ln(gamma_0 / gamma_end) / iterations of the last converged merged BPX-PCG solve with >= 4 iterations
   struct femo_mat* mass = nullptr;  // P1 mass matrix on the operator pattern (geometry only; built on first use): dJ/du = M (u - u_d)
   double* d_mass_e = nullptr;       // n_vert: the difference the mass product is applied to
   double* d_mass_g = nullptr;       // n_rows: M (u - u_d) of the vectors identified by mass_key (functional value -> grad_u)

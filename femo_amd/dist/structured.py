@@ -8,8 +8,8 @@ mesh is exactly what ``build_local_mesh`` extracts from the whole mesh for the s
 
 The owner map is a block decomposition -- what recursive coordinate bisection gives on these grids when the
 cuts fall between grid planes (METIS, which BASELINE.json names, is not installed): ``nranks`` is factorised
-into a process grid, slowest axis first, so 2 ranks cut z, 4 ranks z and y, 8 ranks 2 x 2 x 2 blocks with at
-most 7 neighbours each.
+into a process grid over the slower axes -- the fastest axis stays whole on one node (``process_grid``): 2 ranks
+cut z, 4 ranks z and y, 8 ranks are 1 x 2 x 4 pencils with at most 5 neighbours each.
 """
 from __future__ import annotations
 
@@ -23,8 +23,17 @@ _KUHN = ((0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0))      
 
 
 def process_grid(nranks: int, dim: int) -> Tuple[int, ...]:
-    """Factorisation of nranks into ``dim`` factors (x, y[, z]), as even as possible, larger factors on the
-    slower axes (slabs of the slowest axis are contiguous in the lexicographic numbering)."""
+    """Factorisation of nranks into ``dim`` factors (x, y[, z]), as even as possible, larger factors on the slower axes
+    (slabs of the slowest axis are contiguous in the lexicographic numbering).
+
+    Round 5: **the fastest axis is never cut on one node** (up to 8 ranks in 2-D, 64 in 3-D): 8 ranks are 1 x 2 x 4 pencils,
+    not 2 x 2 x 2 blocks.  A SELL slice is 64 consecutive vertices of an x-line; with a cut x-face every x-line ends in a
+    vertex that couples to ghosts, so ~60 % of a block's slices read ghost columns -- they lose the regular (index-free)
+    SpMV path and all count as "boundary" slices that must wait for the halo exchange (measured on rank 0's 108^3 block of
+    the 215^3 cube: interior launch 16 us, boundary launch 29 us, 45 us together against 30 us for the same rows without a
+    cut x-face).  With x whole the ghost-coupled rows are whole x-lines on the y- and z-faces: ~5 % of the slices.  The
+    price is surface: 58 k ghosts instead of 35 k on a rank of the 215^3 cube (latency-bound messages either way) and at
+    most 5 neighbours instead of 7."""
     grid = [1] * dim
     rest = nranks
     p = 2
@@ -34,8 +43,10 @@ def process_grid(nranks: int, dim: int) -> Tuple[int, ...]:
             factors.append(p)
             rest //= p
         p += 1
+    keep_x = dim >= 2 and nranks <= (8 if dim == 2 else 64)
+    axes = range(1, dim) if keep_x else range(dim)
     for f in sorted(factors, reverse=True):
-        k = min(range(dim), key=lambda a: (grid[a], -a))      # the smallest factor so far, slowest axis first
+        k = min(axes, key=lambda a: (grid[a], -a))          # the smallest factor so far, slowest axis first
         grid[k] *= f
     return tuple(grid)
 

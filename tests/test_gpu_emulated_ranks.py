@@ -437,7 +437,7 @@ def test_projection_on_two_emulated_ranks():
 
 def test_distributed_bench_record_on_eight_emulated_ranks():
     """`bench.py --gpus 8` end to end with the eight ranks emulated on one GPU (bench.run_distributed_bench with a
-    thread control plane instead of torch.distributed + RCCL): rank-local mesh generation under the 2 x 2 x 2
+    thread control plane instead of torch.distributed + RCCL): rank-local mesh generation under the 1 x 2 x 4
     block partition, NumPy arrays at every rank's operator boundary, and a record whose counts are consistent."""
     from argparse import Namespace
     from femo_amd.dist import ThreadControl
@@ -481,7 +481,7 @@ def test_distributed_bench_record_on_eight_emulated_ranks():
     assert r["n_gpus"] == 8 and r["scaling"] == "strong" and c["n_dof"] == N and c["parallelism"] == "block8"
     assert abs(r["value"] - N / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
     assert sum(c["owned_per_rank"]) == N and max(c["owned_per_rank"]) - min(c["owned_per_rank"]) <= 3 * (n + 1) ** 2
-    assert all(3 <= k <= 7 for k in c["neighbours_per_rank"])                  # 3 face + 3 edge + 1 corner blocks
+    assert all(3 <= k <= 5 for k in c["neighbours_per_rank"])                  # 1 x 2 x 4 pencils: the y neighbour, one or two z neighbours and their diagonals
     assert all(b > 0 for b in c["halo_bytes_sent_per_exchange_per_rank"])
     assert sum(c["halo_bytes_sent_per_exchange_per_rank"]) == sum(c["halo_bytes_received_per_exchange_per_rank"])
     # the partitioned run checks itself against the DST-exact cycle of the whole mesh (rank 0 computes, every rank compares)
