@@ -378,7 +378,7 @@ int femo_mesh_destroy(femo_mesh* m) {
   hipFree(m->d_bvmask); hipFree(m->d_visit_rec); hipFree(m->d_load); hipFree(m->d_zero_load); hipFree(m->d_pipe_dummy); hipFree(m->d_ubc);
   if (m->mass) { femo_mat_destroy(m->mass); m->mass = nullptr; }
   hipFree(m->d_mass_e); hipFree(m->d_mass_g); hipFree(m->d_cellvol); hipFree(m->d_cellvol_own); hipFree(m->d_cell_t);
-  hipFree(m->d_sdelta); hipFree(m->d_cols16); hipFree(m->d_bfacets); hipFree(m->d_tperm); hipFree(m->d_send_idx); hipFree(m->d_send_buf); hipFree(m->d_scratch); hipFree(m->d_slices_int); hipFree(m->d_slices_bnd);
+  hipFree(m->d_sdelta); hipFree(m->d_cols16); hipFree(m->d_bfacets); hipFree(m->d_tperm); hipFree(m->d_send_idx); hipFree(m->d_send_uvert); hipFree(m->d_send_uptr); hipFree(m->d_send_uslot); hipFree(m->d_send_flag); hipFree(m->d_send_buf); hipFree(m->d_scratch); hipFree(m->d_slices_int); hipFree(m->d_slices_bnd);
   delete m;
   return 0;
 }
@@ -815,6 +815,8 @@ int femo_mesh_set_halo(femo_mesh* m, int n_nbr, const int32_t* nbr, const int64_
   FEMO_REQUIRE(m && n_nbr >= 0, "bad argument");
   FEMO_REQUIRE(n_nbr == 0 || (nbr && send_ptr && recv_ptr), "null halo plan");
   hipFree(m->d_send_idx); hipFree(m->d_send_buf); hipFree(m->d_slices_int); hipFree(m->d_slices_bnd);
+  hipFree(m->d_send_uvert); hipFree(m->d_send_uptr); hipFree(m->d_send_uslot); hipFree(m->d_send_flag);
+  m->d_send_uvert = m->d_send_uptr = m->d_send_uslot = nullptr; m->d_send_flag = nullptr; m->n_send_verts = 0;
   m->d_send_idx = nullptr; m->d_send_buf = nullptr; m->d_slices_int = m->d_slices_bnd = nullptr;
   m->n_int = m->n_bnd = 0;
   m->n_nbr = n_nbr;
@@ -832,6 +834,30 @@ int femo_mesh_set_halo(femo_mesh* m, int n_nbr, const int32_t* nbr, const int64_
   if (ns > 0) {
     FEMO_HIP_CHECK(hipMemcpyAsync(m->d_send_idx, send_idx, ns * sizeof(int32_t), hipMemcpyHostToDevice, m->ctx->stream));
     FEMO_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+  }
+  {
+    // the send list by vertex (femo_internal.h: d_send_uvert)
+    FEMO_REQUIRE(ns < (int64_t(1) << 31), "halo plan too large for 32-bit slots");
+    std::vector<int32_t> order((size_t)ns);
+    for (int64_t i = 0; i < ns; ++i) order[(size_t)i] = (int32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return send_idx[a] < send_idx[b]; });
+    std::vector<int32_t> uvert, uptr, uslot((size_t)ns);
+    std::vector<uint8_t> flag((size_t)std::max<int64_t>(m->n_rows, 1), 0);
+    for (int64_t k = 0; k < ns; ++k) {
+      const int32_t v = send_idx[order[(size_t)k]];
+      if (uvert.empty() || uvert.back() != v) { uvert.push_back(v); uptr.push_back((int32_t)k); flag[(size_t)v] = 1; }
+      uslot[(size_t)k] = order[(size_t)k];
+    }
+    uptr.push_back((int32_t)ns);
+    m->n_send_verts = (int64_t)uvert.size();
+    FEMO_HIP_CHECK(hipMalloc(&m->d_send_uvert, std::max<size_t>(uvert.size(), 1) * sizeof(int32_t)));
+    FEMO_HIP_CHECK(hipMalloc(&m->d_send_uptr, uptr.size() * sizeof(int32_t)));
+    FEMO_HIP_CHECK(hipMalloc(&m->d_send_uslot, std::max<size_t>(uslot.size(), 1) * sizeof(int32_t)));
+    FEMO_HIP_CHECK(hipMalloc(&m->d_send_flag, flag.size()));
+    if (!uvert.empty()) FEMO_HIP_CHECK(hipMemcpy(m->d_send_uvert, uvert.data(), uvert.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    FEMO_HIP_CHECK(hipMemcpy(m->d_send_uptr, uptr.data(), uptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (!uslot.empty()) FEMO_HIP_CHECK(hipMemcpy(m->d_send_uslot, uslot.data(), uslot.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    FEMO_HIP_CHECK(hipMemcpy(m->d_send_flag, flag.data(), flag.size(), hipMemcpyHostToDevice));
   }
   // slices without ghost columns can be multiplied while the halo is in flight
   return femo_mesh_classify_slices(m);

@@ -506,6 +506,15 @@ struct MergedScal {
   double atol2;                             // absolute threshold on r.r (0: none)
 };
 
+// Partitioned meshes (round 5): the launch is split in two.  The FIRST (hf.n_verts > 0, hf.skip == nullptr) computes the new
+// direction only on the vertices of the halo send list and writes it to the vector AND to the send buffer -- the pack kernel
+// of the ghost refresh is gone and the exchange starts before the bulk of the vector exists; it takes every decision the full
+// launch takes but leaves the scalars and flags alone.  The SECOND (hf.skip != nullptr) does everything else and skips those
+// vertices (their old p is gone).
+struct HaloFirst {
+  int64_t n_verts; const int32_t* verts; const int32_t* slot_ptr; const int32_t* slots; double* send_buf;   // first launch
+  const uint8_t* skip;                                                                                        // second launch
+};
 template <int D>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat lat, const uint32_t* __restrict__ pk,
                                                              const double* __restrict__ rh, const double* __restrict__ sinv,
@@ -514,7 +523,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat
                                                              const double* __restrict__ dot_partials, const double* __restrict__ dot_global,
                                                              int nb_rho, const double* __restrict__ rho_partials, double* __restrict__ rho,
                                                              const double* __restrict__ gamma_cur, double* __restrict__ gamma_nxt,
-                                                             const int32_t* __restrict__ done, PcgStop st, MergedScal ms) {
+                                                             const int32_t* __restrict__ done, PcgStop st, MergedScal ms, HaloFirst hf) {
   if (done != nullptr && *done) return;
   __shared__ double lds[2 * (FEMO_BLOCK / 64)];
   double beta = 0.0;
@@ -553,7 +562,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat
     }
     const double g1 = rr + ge, g0 = *gamma_cur;
     if (mode == 1) beta = g0 != 0.0 ? g1 / g0 : 0.0;
-    const bool first = blockIdx.x == 0 && threadIdx.x == 0;
+    const bool first = blockIdx.x == 0 && threadIdx.x == 0 && hf.n_verts == 0;      // (the halo-first launch writes no scalar)
     if (first) {
       *gamma_nxt = g1;
       if (nb_rho > 0 || ms.S != nullptr) *rho = rr;
@@ -586,7 +595,10 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat
       }
     }
   }
-  for (int64_t v = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; v < n_rows; v += (int64_t)gridDim.x * FEMO_BLOCK) {
+  const int64_t n_walk = hf.n_verts > 0 ? hf.n_verts : n_rows;
+  for (int64_t w_i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; w_i < n_walk; w_i += (int64_t)gridDim.x * FEMO_BLOCK) {
+    const int64_t v = hf.n_verts > 0 ? (int64_t)hf.verts[w_i] : w_i;
+    if (hf.skip != nullptr && hf.skip[v]) continue;
     double z = rh[v];
     if (!(mask != nullptr && mask[v])) {
       int i0[3] = {0, 0, 0};
@@ -608,7 +620,10 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat
       }
       z += sum * sinv[v];          // the same rounded 1/s the restriction multiplies with (k_pc_weights)
     }
-    out[v] = mode == 1 ? z + beta * out[v] : z;
+    const double pv = mode == 1 ? z + beta * out[v] : z;
+    out[v] = pv;
+    if (hf.n_verts > 0)
+      for (int32_t q = hf.slot_ptr[w_i]; q < hf.slot_ptr[w_i + 1]; ++q) hf.send_buf[hf.slots[q]] = pv;
   }
 }
 
@@ -1497,8 +1512,9 @@ struct PackArgs {
 __global__ __launch_bounds__(256) void k_pack_merged(PackArgs a, const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
   __shared__ double red[256 / 64];
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // workgroup 0 folds, the others share the lists (one workgroup with both would be the launch's critical path)
+  const int64_t stride = (int64_t)(gridDim.x - 1) * 256;
+  const int64_t t0 = (int64_t)(blockIdx.x - 1) * 256 + threadIdx.x;
   double* tail = a.buf + a.n_shared + a.n_top;
   double t;
   if (blockIdx.x == 0) {
@@ -1515,6 +1531,7 @@ __global__ __launch_bounds__(256) void k_pack_merged(PackArgs a, const int32_t* 
       t = femo_block_sum<256>(acc[k], red);
       if (threadIdx.x == 0) tail[k] = t;
     }
+    return;
   }
   for (int64_t i = t0; i < a.n_shared; i += stride) a.buf[i] = a.h[a.shared_idx[i]];
   if (!(a.dbg & 2))
@@ -2076,9 +2093,9 @@ int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const do
   ps.flags = stop ? stop->flags : nullptr;
   ps.it = stop ? stop->it : 0;
   if (pc->dim == 3)
-    hipLaunchKernelGGL(k_prolong_mesh<3>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, pc->d_sinv, mask, F.e, out, mode, nb_dot, pc->d_dot_partials, dot_global, nb_rho, rho_partials, rho, gamma_cur, gamma_nxt, done, ps, MergedScal{});
+    hipLaunchKernelGGL(k_prolong_mesh<3>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, pc->d_sinv, mask, F.e, out, mode, nb_dot, pc->d_dot_partials, dot_global, nb_rho, rho_partials, rho, gamma_cur, gamma_nxt, done, ps, MergedScal{}, HaloFirst{});
   else
-    hipLaunchKernelGGL(k_prolong_mesh<2>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, pc->d_sinv, mask, F.e, out, mode, nb_dot, pc->d_dot_partials, dot_global, nb_rho, rho_partials, rho, gamma_cur, gamma_nxt, done, ps, MergedScal{});
+    hipLaunchKernelGGL(k_prolong_mesh<2>, dim3(gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, rh, pc->d_sinv, mask, F.e, out, mode, nb_dot, pc->d_dot_partials, dot_global, nb_rho, rho_partials, rho, gamma_cur, gamma_nxt, done, ps, MergedScal{}, HaloFirst{});
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -2185,7 +2202,7 @@ int femo_pc_merged_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, c
     static const int dbg_pack = FEMO_TUNE_ENV("FEMO_DEBUG_PACK") ? atoi(FEMO_TUNE_ENV("FEMO_DEBUG_PACK")) : 0;
     a.dbg = dbg_pack;
     const int64_t work = std::max(std::max(a.n_shared, a.n_int), n_top);
-    const unsigned gp = (unsigned)std::min<int64_t>(PACK_GRID, std::max<int64_t>(1, (work + 255) / 256));
+    const unsigned gp = 1u + (unsigned)std::min<int64_t>(PACK_GRID, std::max<int64_t>(1, (work + 255) / 256));
     hipLaunchKernelGGL(k_pack_merged, dim3(gp), dim3(256), 0, st, a, done);
     FEMO_TRY(femo_coll_allreduce(ctx, pc->d_mbuf, a.n_shared + n_top + MS_NRED, st));
   }
@@ -2282,12 +2299,34 @@ int femo_pc_merged_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, c
   const int mode = init ? 2 : 1;
   double* gamma_cur = S + MS_GAMMA + V.cur;
   double* gamma_nxt = init ? S + MS_GAMMA + V.cur : S + MS_GAMMA + (V.cur ^ 1);
-  if (pc->dim == 3)
-    hipLaunchKernelGGL(k_prolong_mesh<3>, dim3(V.gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, (const double*)V.r, pc->d_sinv, mask, F.e, V.p, mode, nb_dot, pc->d_dot_partials, (const double*)nullptr, 0, (const double*)nullptr, S + MS_RR, (const double*)gamma_cur, gamma_nxt, done, ps, ms);
-  else
-    hipLaunchKernelGGL(k_prolong_mesh<2>, dim3(V.gv), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, (const double*)V.r, pc->d_sinv, mask, F.e, V.p, mode, nb_dot, pc->d_dot_partials, (const double*)nullptr, 0, (const double*)nullptr, S + MS_RR, (const double*)gamma_cur, gamma_nxt, done, ps, ms);
+  auto prolong = [&](unsigned grid, const HaloFirst& hf) {
+    if (pc->dim == 3)
+      hipLaunchKernelGGL(k_prolong_mesh<3>, dim3(grid), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, (const double*)V.r, pc->d_sinv, mask, F.e, V.p, mode, nb_dot, pc->d_dot_partials, (const double*)nullptr, 0, (const double*)nullptr, S + MS_RR, (const double*)gamma_cur, gamma_nxt, done, ps, ms, hf);
+    else
+      hipLaunchKernelGGL(k_prolong_mesh<2>, dim3(grid), dim3(FEMO_BLOCK), 0, st, m->n_rows, lat, pc->d_pk, (const double*)V.r, pc->d_sinv, mask, F.e, V.p, mode, nb_dot, pc->d_dot_partials, (const double*)nullptr, 0, (const double*)nullptr, S + MS_RR, (const double*)gamma_cur, gamma_nxt, done, ps, ms, hf);
+  };
+  if (femo_pc_merged_sends_halo(m)) {
+    // the interface vertices first, straight into the send buffer; the exchange of the new direction then travels on the
+    // communication stream under the bulk of the prolongation and the interior slices of the next SpMV (solver.hip:
+    // femo_halo_spmv_inflight waits for it before the boundary slices)
+    HaloFirst h1 = {m->n_send_verts, m->d_send_uvert, m->d_send_uptr, m->d_send_uslot, m->d_send_buf, nullptr};
+    prolong((unsigned)std::max<int64_t>(1, std::min<int64_t>((m->n_send_verts + FEMO_BLOCK - 1) / FEMO_BLOCK, V.gv)), h1);
+    FEMO_HIP_CHECK(hipEventRecord(ctx->ev_main, st));
+    FEMO_HIP_CHECK(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_main, 0));
+    FEMO_TRY(femo_coll_neighbors(ctx, m->n_nbr, m->nbr.data(), m->send_ptr.data(), m->d_send_buf, m->recv_ptr.data(), V.p + m->n_rows, ctx->comm_stream));
+    FEMO_HIP_CHECK(hipEventRecord(ctx->ev_comm, ctx->comm_stream));
+    HaloFirst h2 = {0, nullptr, nullptr, nullptr, nullptr, m->d_send_flag};
+    prolong((unsigned)V.gv, h2);
+  } else {
+    prolong((unsigned)V.gv, HaloFirst{});
+  }
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
+}
+
+bool femo_pc_merged_sends_halo(const femo_mesh* m) {
+  return m->ctx->nranks > 1 && m->n_nbr > 0 && m->d_slices_int != nullptr && m->n_send_verts > 0 && m->d_send_flag != nullptr &&
+         m->ctx->comm_stream != nullptr;
 }
 
 // can the PCG loop hand its partial rh.rh to femo_pc_apply instead of all-reducing it itself?

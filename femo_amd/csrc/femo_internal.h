@@ -248,6 +248,14 @@ struct femo_mesh {
   std::vector<int64_t> send_ptr, recv_ptr;
   int32_t* d_send_idx = nullptr;
   double* d_send_buf = nullptr;
+  // the send list by VERTEX (round 5; a vertex sent to several neighbours occupies several slots): the merged BPX-PCG loop
+  // computes the new search direction on these vertices first, straight into the send buffer (k_prolong_mesh), so that the
+  // exchange travels under the rest of the prolongation and the interior SpMV and no pack kernel competes with the SpMV
+  int64_t n_send_verts = 0;
+  int32_t* d_send_uvert = nullptr;   // distinct owned vertices that are sent, ascending
+  int32_t* d_send_uptr = nullptr;    // n_send_verts + 1: their slots in the send buffer ...
+  int32_t* d_send_uslot = nullptr;   // ... listed here
+  uint8_t* d_send_flag = nullptr;    // n_rows bytes: 1 = the vertex is on the send list
   double* d_scratch = nullptr;  // n_vert doubles, lazily allocated (Dirichlet lifting)
   // slices without / with ghost columns (set with the halo plan)
   int32_t* d_slices_int = nullptr; int32_t* d_slices_bnd = nullptr;
@@ -426,6 +434,9 @@ bool femo_pc_merged_ok(femo_mesh* m);                 // the fused lattice cycle
 int femo_pc_merged_begin(femo_mesh* m, const double* s, const uint8_t* mask);
 int femo_pc_merged_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const FemoMergedVecs& V, double* S,
                          const int32_t* done, const struct FemoPcgStop* stop);
+// N > 1: does femo_pc_merged_apply start the halo exchange of the direction it produces (interface vertices first, send buffer
+// filled by the prolongation itself)?  Then the loop's SpMV must not exchange again: femo_halo_spmv_inflight.
+bool femo_pc_merged_sends_halo(const femo_mesh* m);
 int femo_pc_merged_collectives(const femo_mesh* m);   // all-reduces per iteration of the merged loop on this mesh (0 on one rank)
 // nb_rho > 0: rho = rh.rh is folded from rho_partials[0:nb_rho] inside the apply (and stored to *rho)
 int femo_pc_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const double* s, const double* rh, double* out,

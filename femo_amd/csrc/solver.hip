@@ -914,6 +914,27 @@ static int halo_spmv_overlapped(const femo_mat* A, const double* vals, double* x
   return 0;
 }
 
+// The same product when the ghost refresh of x is ALREADY in flight on the communication stream (the merged BPX-PCG's
+// prolongation started it, femo_pc_merged_apply): interior slices now, boundary slices behind the halo event.
+static int halo_spmv_inflight(const femo_mat* A, const double* vals, double* x, double* y, double* partials,
+                              const int32_t* done, bool unit, int* g_int, int* g_bnd, const double* dvec, int n_slots) {
+  femo_mesh* m = A->mesh;
+  femo_ctx* ctx = m->ctx;
+  hipStream_t st = ctx->stream;
+  auto grid_of = [&](int64_t n_walk) {
+    int64_t g = femo_spmv_grid(m);
+    return (int)std::min<int64_t>(g, std::max<int64_t>(8, ((n_walk + 3) / 4 + 7) & ~int64_t(7)));
+  };
+  if (g_int) *g_int = grid_of(m->n_int);
+  if (g_bnd) *g_bnd = grid_of(m->n_bnd);
+  const bool dot3 = n_slots == 3;
+  FEMO_TRY(launch_spmv(A, vals, x, y, partials, done, unit, false, m->d_slices_int, m->n_int, st, dvec, false, dot3));
+  FEMO_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_comm, 0));
+  FEMO_TRY(launch_spmv(A, vals, x, y, partials ? partials + n_slots * FEMO_MAX_PARTIALS : nullptr, done, unit, false,
+                       m->d_slices_bnd, m->n_bnd, st, dvec, false, dot3));
+  return 0;
+}
+
 int femo_launch_spmv(const femo_mat* A, const double* vals, const double* x, double* y, double* partials) {
   return launch_spmv(A, vals, x, y, partials, nullptr);
 }
@@ -1367,7 +1388,9 @@ static int solve_pcg_bpx_merged(femo_mat* A, const femo_vec* b, femo_vec* x, con
       if (sample) FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_ev], st));
       int g1 = gs, g2 = 0;
       if (multi) {
-        if (m->n_nbr > 0 && m->d_slices_int != nullptr) {
+        if (femo_pc_merged_sends_halo(m)) {
+          FEMO_TRY(halo_spmv_inflight(A, A->d_valsS, w.p, w.q, Pq_int, ctx->d_flags, true, &g1, &g2, w.r, 3));
+        } else if (m->n_nbr > 0 && m->d_slices_int != nullptr) {
           FEMO_TRY(halo_spmv_overlapped(A, A->d_valsS, w.p, w.q, Pq_int, ctx->d_flags, true, false, &g1, &g2, w.r, 3));
         } else {
           if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, w.p));

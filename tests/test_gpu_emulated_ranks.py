@@ -481,7 +481,7 @@ def test_distributed_bench_record_on_eight_emulated_ranks():
     assert r["n_gpus"] == 8 and r["scaling"] == "strong" and c["n_dof"] == N and c["parallelism"] == "block8"
     assert abs(r["value"] - N / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
     assert sum(c["owned_per_rank"]) == N and max(c["owned_per_rank"]) - min(c["owned_per_rank"]) <= 3 * (n + 1) ** 2
-    assert all(3 <= k <= 5 for k in c["neighbours_per_rank"])                  # 1 x 2 x 4 pencils: the y neighbour, one or two z neighbours and their diagonals
+    assert all(2 <= k <= 5 for k in c["neighbours_per_rank"])                  # 1 x 2 x 4 pencils: the y neighbour, one or two z neighbours and the diagonals the Kuhn split couples
     assert all(b > 0 for b in c["halo_bytes_sent_per_exchange_per_rank"])
     assert sum(c["halo_bytes_sent_per_exchange_per_rank"]) == sum(c["halo_bytes_received_per_exchange_per_rank"])
     # the partitioned run checks itself against the DST-exact cycle of the whole mesh (rank 0 computes, every rank compares)
@@ -529,8 +529,10 @@ def test_merged_pcg_one_allreduce_per_iteration_on_emulated_ranks(monkeypatch):
         x = np.zeros(m.n_vert)
         for r in res:
             assert r["conv"] == 1 and r["levels"] >= 4
-            if world > 1:
-                assert r["loop_ar"] == (r["st"]["neighbor_calls"] if not classic else r["loop_ar"])      # merged: one per enqueued iteration
+            if world > 1 and not classic:
+                # merged: one all-reduce per enqueued iteration; one halo exchange per preconditioner application (round 5: the
+                # prolongation starts the exchange of the direction it produces -- the first application included)
+                assert r["loop_ar"] == r["st"]["neighbor_calls"] - 1
             x[r["gid"]] = r["x"]
         assert len({r["its"] for r in res}) == 1
         return x, res[0]["its"], [r["st"] for r in res]
@@ -548,7 +550,7 @@ def test_merged_pcg_one_allreduce_per_iteration_on_emulated_ranks(monkeypatch):
             # per solve: the set-up reduction of (r0.r0, b.b) and the first preconditioner application, then ONE
             # all-reduce and ONE halo exchange per enqueued iteration (the host enqueues in batches: up to a batch
             # of iterations behind the converged one is enqueued and returns at once on the device)
-            enqueued = st["neighbor_calls"]
+            enqueued = st["neighbor_calls"] - 1
             assert its <= enqueued < its + 8, (world, st, its)
             assert st["allreduce_calls"] == enqueued + 2, (world, st, its)
         _, its_c, stats_c = solve(world, True)

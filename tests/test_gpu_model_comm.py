@@ -39,9 +39,10 @@ def test_model_communicator_runs_the_n_rank_merged_loop(world, rank):
     st = ctx.comm_stats()
     assert info.converged == 1 and dm.pc_info()["levels"] >= 4
     # the merged loop: one all-reduce and one neighbour exchange per enqueued iteration (+ the set-up reduction and the first apply)
-    assert info.loop_allreduces == st["neighbor_calls"]
-    assert info.iterations <= st["neighbor_calls"] < info.iterations + 8
-    assert st["allreduce_calls"] == st["neighbor_calls"] + 2
+    enqueued = st["neighbor_calls"] - 1                       # (the first application of the preconditioner starts an exchange too)
+    assert info.loop_allreduces == enqueued
+    assert info.iterations <= enqueued < info.iterations + 8
+    assert st["allreduce_calls"] == enqueued + 2
     # what it solved: the owned-row block of the local operator (ghost values are never refreshed: they stay zero)
     om = fo.OMesh(3, np.ascontiguousarray(L.x), np.ascontiguousarray(L.conn))
     K = fo.eliminate_bc(fo.stiffness(om).tocsr(), bd).tocsr()
