@@ -1278,259 +1278,6 @@ __global__ __launch_bounds__(64) void k_poisson_system_pipe(
   rows_out(prev_row, prev_mb, prev_wm, Rp, cu_prev);
 }
 
-// ------------------- linear Poisson, persistent HALF-SLICE waves, two per SIMD (round 5) ---
-// k_poisson_system_pipe runs ONE wave per SIMD (28 KB of LDS per 64-row slice) and its counters say what that costs:
-// VALUBusy 43 %, MemUnitStalled 0.2 % -- the dependent fp64 chains of the pair arithmetic and the LDS reads of a visit
-// with nothing else to issue (7.7 cycles per instruction against ~3.5 of pure issue).  Here a wave owns HALF a slice:
-//     lane = (r, h),  r = lane & 31 the row inside the half, h = lane >> 5
-// so the LDS neighbourhood is 14 KB and two waves share every SIMD.  The two lanes of a row split everything the row does:
-//   * prefetch: lane h gathers the neighbours in the columns k = 2 i + h (half the registers of the one-wave kernel);
-//   * walk: lane h takes the visits v = 2 t + h.  Both add into the row's ONE strip entry per column, h = 0 in an
-//     instruction of its own BEFORE h = 1 (the LDS pipeline keeps instruction order), so every entry is summed in ascending
-//     visit = ascending cell order exactly like the one-wave kernel: the same bits, K[a][b] == K[b][a] bit for bit;
-//   * rows out: lane h writes the column pairs i = 2 j + h; the partner's u' comes through one cross-lane move per pair.
-//     The diagonal and the right-hand side are the sums of the two lanes' halves (a different association than the
-//     one-wave kernel's ascending-k sum: last-bit differences there, documented in DESIGN.md).
-// Same pipeline shape as the one-wave kernel (table of half-slice s+3, columns of s+2, neighbourhood + row data of s+1 in
-// flight while s is walked; every vector-memory instruction unconditional).
-template <int D, int NB, bool WANT_RHS, bool HAS_V0, bool HAS_V1, bool HAVE_BC = true, bool LDS_ATOMIC = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_poisson_system_pipe2(
-    int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ vptr, const P1Rec12* __restrict__ visit_rec,
-    const int64_t* __restrict__ mptr, const int32_t* __restrict__ cols, const int32_t* __restrict__ rowlen,
-    const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ ubc,
-    const double* __restrict__ load, const double* __restrict__ bcval,
-    double* __restrict__ diag0, double* __restrict__ vals0, double* __restrict__ diag1, double* __restrict__ vals1,
-    double* __restrict__ rhs, const uint64_t* __restrict__ bc_rowmask, double* __restrict__ dummy, int dbg) {
-  static_assert(NB % 2 == 0, "column pairs");
-  constexpr int NH = NB / 2;                     // neighbours per lane
-  constexpr int NJ = (NH + 1) / 2;               // column pairs per lane in the output step
-  constexpr int CH = 4;                          // visit records in flight per lane (8 visits of the row)
-  extern __shared__ double lds_row[];
-  double* strip = lds_row;                       // [NB][32]
-  double* nx = lds_row + NB * 32;                // [NB][D][32]
-  const int lane = threadIdx.x;
-  const int r = lane & 31, h = lane >> 5;
-  const int64_t n_half = 2 * n_slices;
-  const int64_t wv = femo_xcd_block(blockIdx.x, gridDim.x);
-  const int64_t per = (n_half + gridDim.x - 1) / gridDim.x;
-  const int64_t s_begin = wv * per, s_end = s_begin + per < n_half ? s_begin + per : n_half;
-  if (s_begin >= s_end) return;
-  struct Meta { int64_t vb, mb; int nvis, wm, rowl; };
-  auto clamp_half = [&](int64_t hs) -> int64_t { return hs < n_half ? hs : n_half - 1; };
-  auto load_meta = [&](int64_t hs) -> Meta {
-    const int64_t hc = clamp_half(hs);
-    const int64_t sc = hc >> 1;
-    Meta M;
-    M.vb = vptr[sc]; M.nvis = (int)((vptr[sc + 1] - M.vb) >> 6);
-    M.mb = mptr[sc]; M.wm = (int)((mptr[sc + 1] - M.mb) >> 6);
-    M.rowl = (int)(hc & 1) * 32 + r;            // row inside the 64-row slice
-    return M;
-  };
-  auto load_cols = [&](const Meta& M, uint32_t (&c)[NH]) {
-    const int32_t* cs = cols + M.mb;
-#pragma unroll
-    for (int i = 0; i < NH; ++i) {
-      const int k = 2 * i + h;
-      const int kk = (dbg & 8) ? 0 : (k < M.wm ? k : M.wm - 1);                             // (timing experiment: one column per row)
-      c[i] = (uint32_t)ldg32<int32_t>(cs, ((uint32_t)(kk >> 1) * 128u + (uint32_t)M.rowl * 2u + (uint32_t)(kk & 1)) * 4u);
-    }
-  };
-  auto load_nbhd = [&](const uint32_t (&c)[NH], double (&px)[NH][D], double (&pu)[NH]) {
-#pragma unroll
-    for (int i = 0; i < NH; ++i) ldg_point<D>(x, c[i], px[i]);
-    if constexpr (WANT_RHS) {
-#pragma unroll
-      for (int i = 0; i < NH; ++i) pu[i] = ldg32<double>(ubc, c[i] * 8u);
-    }
-  };
-  struct RowData { double xo[D]; double ld, ur, gr; uint64_t rmask; int len; };
-  auto load_row = [&](int64_t hs) -> RowData {
-    const int64_t hc = clamp_half(hs);
-    const int64_t row = (hc >> 1) * 64 + (hc & 1) * 32 + r;
-    const int64_t r0 = row < n_rows ? row : 0;
-    RowData R;
-    R.len = rowlen[row];
-    ldg_point<D>(x, (uint32_t)r0, R.xo);
-    R.rmask = 0;
-    if constexpr (HAVE_BC) R.rmask = bc_rowmask[row];
-    R.ld = 0.0; R.ur = 0.0; R.gr = 0.0;
-    if constexpr (WANT_RHS) { R.ld = load[r0]; R.ur = u[r0]; }
-    if constexpr (WANT_RHS && HAVE_BC) R.gr = bcval[r0];
-    return R;
-  };
-  // record of visit 2 t + h of the lane's row; visits beyond the slice's list add zeros to slot 0
-  auto fetch = [&](const Meta& M, int t) -> P1Rec12 {
-    const int v = 2 * t + h;
-    const int sc = (dbg & 2) ? 0 : (v < M.nvis ? v : (M.nvis > 0 ? M.nvis - 1 : 0));     // (timing experiment: one record per slice)
-    P1Rec12 q = ldg32<P1Rec12>(visit_rec + M.vb, (uint32_t)(sc * 64 + M.rowl) * 12u);
-    if (v >= M.nvis) { q.sl = 0u; q.wlo = 0u; q.whi = 0u; }
-    return q;
-  };
-  double* const my_dummy = dummy + lane * 2;
-
-  Meta M0 = load_meta(s_begin), M1 = load_meta(s_begin + 1), M2 = load_meta(s_begin + 2);
-  uint32_t c0[NH], c1[NH];
-  double px[NH][D], pu[NH];
-  load_cols(M0, c0);
-  load_cols(M1, c1);
-  load_nbhd(c0, px, pu);
-  RowData R0 = load_row(s_begin);
-  bool have_prev = false;
-  int64_t prev_row = 0, prev_mb = 0;
-  int prev_wm = 0, prev_rowl = 0;
-  double cu_prev[NH];
-  RowData Rp = R0;
-#pragma unroll
-  for (int i = 0; i < NH; ++i) cu_prev[i] = 0.0;
-
-  auto rows_out = [&](int64_t row, int64_t mb, int wm, int rowl, const RowData& R, const double (&cu)[NH]) {
-    const bool valid = row < n_rows;
-    const bool row_bc = valid && (R.rmask >> 63) != 0;
-    double racc = 0.0, osum = 0.0;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      // this lane's column pair i = 2 j + h: entries k = 2 i, 2 i + 1
-      const int i = 2 * j + h;
-      const int k = 2 * i;
-      const bool in = i < NH && k < wm;
-      const int64_t idx = mb + (int64_t)i * 128 + rowl * 2;
-      double2 o;
-      o.x = (in && k < R.len) ? strip[k * 32 + r] : 0.0;
-      o.y = (in && (k + 1) < R.len) ? strip[(k + 1) * 32 + r] : 0.0;
-      osum += o.x; osum += o.y;
-      const bool st_ok = in && !(dbg & 4);                      // (timing experiment: stores to the dummy line)
-      if constexpr (HAS_V0) *reinterpret_cast<double2*>(st_ok ? vals0 + idx : my_dummy) = o;
-      if constexpr (WANT_RHS) {
-        // u' in column 2 i is held by the row's lane 0 (its neighbour i), in column 2 i + 1 by lane 1; this lane holds one
-        // of the two and gets the other from its partner, who needs the one of ITS pair 2 j + (1 - h)
-        const int io = 2 * j + 1 < NH ? 2 * j + 1 : NH - 1;
-        const double own = h ? cu[io] : cu[2 * j];
-        const double give = h ? cu[2 * j] : cu[io];
-        const double got = __shfl_xor(give, 32, 64);
-        const double ce = h ? got : own, co = h ? own : got;
-        racc += o.x * ce + o.y * co;
-      }
-      const bool bx = ((R.rmask >> k) & 1) != 0, by = ((R.rmask >> (k + 1)) & 1) != 0;
-      if (row_bc || bx) o.x = 0.0;
-      if (row_bc || by) o.y = 0.0;
-      if constexpr (HAS_V1) *reinterpret_cast<double2*>(st_ok ? vals1 + idx : my_dummy) = o;
-    }
-    osum += __shfl_xor(osum, 32, 64);                       // a + b == b + a: both lanes hold the same bits
-    const double dsum = -osum;
-    const bool writer = valid && h == 0;
-    if constexpr (HAS_V0) *(h == 0 ? diag0 + row : my_dummy) = valid ? dsum : 1.0;       // the diagonal arrays are padded to whole slices
-    if constexpr (HAS_V1) *(h == 0 ? diag1 + row : my_dummy) = (valid && !row_bc) ? dsum : 1.0;
-    if constexpr (WANT_RHS) {
-      racc += __shfl_xor(racc, 32, 64);
-      racc += dsum * R.ur - R.ld;
-      double* const dst = writer ? rhs + row : my_dummy;
-      *dst = row_bc ? (R.ur - R.gr) : racc;
-    }
-  };
-
-  for (int64_t s = s_begin; s < s_end; ++s) {
-    // (1) drain: the prefetch issued before the previous walk.  Neighbourhood of this half-slice to LDS.
-    double cu[NH];
-#pragma unroll
-    for (int i = 0; i < NH; ++i) {
-      cu[i] = WANT_RHS ? pu[i] : 0.0;
-#pragma unroll
-      for (int d = 0; d < D; ++d) nx[((2 * i + h) * D + d) * 32 + r] = px[i][d];
-    }
-    const RowData R = R0;
-    // (2) first records
-    P1Rec12 cur[CH], nxt[CH];
-#pragma unroll
-    for (int t = 0; t < CH; ++t) cur[t] = fetch(M0, t);
-    // (3) rows of the previous half-slice out of the strip, then clear it
-    if (have_prev) rows_out(prev_row, prev_mb, prev_wm, prev_rowl, Rp, cu_prev);
-#pragma unroll
-    for (int i = 0; i < NH; ++i) strip[(2 * i + h) * 32 + r] = 0.0;
-    // (4) prefetch: table of s+3, columns of s+2, neighbourhood and row data of s+1
-    const Meta M3 = load_meta(s + 3);
-    uint32_t c2[NH];
-    load_cols(M2, c2);
-    load_nbhd(c1, px, pu);
-    R0 = load_row(s + 1);
-    // (5) the walk: lane h takes the visits 2 t + h
-    const int nsteps = (M0.nvis + 1) >> 1;
-    struct Nbr { double o[D][D]; int pos[D]; double wt; };
-    auto gather = [&](const P1Rec12 q) -> Nbr {
-      Nbr V;
-      const uint32_t sl = q.sl;
-      V.wt = __hiloint2double((int)q.whi, (int)q.wlo);
-#pragma unroll
-      for (int j = 0; j < D; ++j) {
-        V.pos[j] = (int)((sl >> (8 * j)) & 0xFFu);
-#pragma unroll
-        for (int d = 0; d < D; ++d) V.o[j][d] = nx[(V.pos[j] * D + d) * 32 + r];
-      }
-      return V;
-    };
-    auto accumulate = [&](const Nbr& V) {
-      double kk[D];
-      if (dbg & 1) {                                           // timing experiment: no pair arithmetic
-#pragma unroll
-        for (int j = 0; j < D; ++j) kk[j] = V.wt + V.o[j][0];
-      } else {
-        poisson_pairs<D>(R.xo, V.o, V.wt, kk);
-      }
-      if (dbg & 16) return;                                    // ... no accumulation
-      // visit 2 t (lane 0 of the row) before visit 2 t + 1 (lane 1): two groups of LDS instructions, in program order (the
-      // LDS pipeline executes in order, so lane 1's read sees lane 0's write).  Plain read-add-write: ds_add_f64 costs the
-      // LDS ~one clock per LANE (measured round 5: the one-wave kernel's 72 atomics per slice = 4.6 k of its 5.4 k cycles per
-      // slice and CU -- it was bound by the LDS atomic rate, not by latency, which is why a second wave per SIMD alone changed
-      // nothing); with two waves per SIMD the latency of the read-add-write chain hides behind the other wave's arithmetic.
-      auto add3 = [&]() {
-        if constexpr (LDS_ATOMIC) {
-#pragma unroll
-          for (int j = 0; j < D; ++j) (void)__hip_atomic_fetch_add(&strip[V.pos[j] * 32 + r], kk[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        } else {
-          double cur3[D];
-#pragma unroll
-          for (int j = 0; j < D; ++j) cur3[j] = strip[V.pos[j] * 32 + r];
-#pragma unroll
-          for (int j = 0; j < D; ++j) strip[V.pos[j] * 32 + r] = __dadd_rn(cur3[j], kk[j]);
-        }
-      };
-      if (h == 0) add3();
-      // (cross-lane order is not a per-thread dependency: without the fences the compiler hoists lane 1's reads above lane 0's
-      // writes -- measured: 1.3 M asymmetric entries on the 48^3 cube)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (h == 1) add3();
-    };
-    int base = 0;
-    for (; base + CH <= nsteps; base += CH) {
-#pragma unroll
-      for (int t = 0; t < CH; ++t) nxt[t] = fetch(M0, base + CH + t);
-      Nbr V = gather(cur[0]);
-#pragma unroll
-      for (int t = 0; t < CH; ++t) {
-        Nbr W = V;
-        if (t + 1 < CH) W = gather(cur[t + 1]);
-        accumulate(V);
-        V = W;
-      }
-#pragma unroll
-      for (int t = 0; t < CH; ++t) cur[t] = nxt[t];
-    }
-#pragma unroll
-    for (int t = 0; t < CH; ++t) {
-      if (base + t < nsteps) accumulate(gather(cur[t]));          // wave-uniform tail
-    }
-    // rotate
-    have_prev = true;
-    prev_row = (s >> 1) * 64 + M0.rowl; prev_mb = M0.mb; prev_wm = M0.wm; prev_rowl = M0.rowl;
-    Rp = R;
-#pragma unroll
-    for (int i = 0; i < NH; ++i) { cu_prev[i] = cu[i]; c0[i] = c1[i]; c1[i] = c2[i]; }
-    M0 = M1; M1 = M2; M2 = M3;
-  }
-  rows_out(prev_row, prev_mb, prev_wm, prev_rowl, Rp, cu_prev);
-}
-
 // -------------------------------------------------------------------- dRdf --
 // dR/dt of the beam: column e = (E width t_e^2 / 4) * Khat u_e  (4 entries aligned with conn[e])
 __global__ __launch_bounds__(FEMO_BLOCK) void k_dRdt_beam(int64_t n_cell, double Ey, double width, const int32_t* __restrict__ conn,
@@ -1956,9 +1703,12 @@ int femo_launch_system(femo_mesh* m, int pde, const double* params, const double
     } while (0)
     // persistent pipelined kernel: rows of up to 16 entries, a Dirichlet set with its row masks, and one of the
     // three combinations the operators ask for: A + rhs, dR/du + A, rhs only
-    // 3 (default, round 5): half-slice waves, two per SIMD (k_poisson_system_pipe2); 1: one wave per SIMD; 2: the same without
-    // LDS atomics; 0: the LDS kernel
-    static const int pipe_mode = FEMO_TUNE_ENV("FEMO_ASSEMBLY_PIPE") ? atoi(FEMO_TUNE_ENV("FEMO_ASSEMBLY_PIPE")) : 3;
+    // 1 (default): persistent waves, one per SIMD; 2: the same without LDS atomics; 0: the LDS kernel.  Round 5 tried a third
+    // form -- half-slice waves, two per SIMD, the two lanes of a row splitting its visits (commit 8f1a594, DESIGN_LOG.md) --
+    // which produced the same off-diagonal bits and the same time: the kernel is bound by neither latency nor the LDS atomics
+    // but by its instruction stream (57 fp64 instructions per visit at 8 cycles each on the half-rate fp64 pipe of gfx950,
+    // plus 9 LDS gathers), i.e. by the 12 pair evaluations per cell of the owner-computes formulation.
+    static const int pipe_mode = FEMO_TUNE_ENV("FEMO_ASSEMBLY_PIPE") ? atoi(FEMO_TUNE_ENV("FEMO_ASSEMBLY_PIPE")) : 1;
     const int NBp = m->tdim == 3 ? (nbr <= 14 ? 14 : 16) : 8;
     const bool combo_a = rhs && !vals0 && vals1, combo_b = !rhs && vals0 && vals1, combo_c = rhs && !vals0 && !vals1;
     const bool no_bc_residual = combo_c && bcmask == nullptr;          // evaluate_residuals: K u - L, no Dirichlet treatment
@@ -1987,29 +1737,6 @@ int femo_launch_system(femo_mesh* m, int pde, const double* params, const double
            else FEMO_SYS_PIPE(D, NB, true, false, false, false); }                                                             \
            else if (combo_a) FEMO_SYS_PIPE(D, NB, true, false, true, true); else if (combo_b) FEMO_SYS_PIPE(D, NB, false, true, true, true);  \
            else FEMO_SYS_PIPE(D, NB, true, false, false, true); } while (0)
-      if (pipe_mode == 3 || pipe_mode == 4) {
-        // 8 waves per CU = 2 per SIMD: the LDS request keeps a ninth workgroup off the CU
-        const size_t lds2 = std::max<size_t>((size_t)NBp * (m->tdim + 1) * 32 * sizeof(double), 18 * 1024);
-        const unsigned grid2 = (unsigned)std::min<int64_t>(2 * ns, (int64_t)m->ctx->n_cu * 8);
-#define FEMO_SYS_PIPE2(D, NB, R, V0, V1, BC)                                                                                   \
-        do { if (pipe_mode == 4) hipLaunchKernelGGL((k_poisson_system_pipe2<D, NB, R, V0, V1, BC, true>), dim3(grid2), dim3(64), lds2, st, m->n_rows, ns, m->d_vptr, rec, \
-                           m->d_mptr, m->d_cols, m->d_rowlen, m->d_x, u, ubc, load, bcval, diag0, vals0, diag1, vals1, rhs,   \
-                           bc_rowmask, m->d_pipe_dummy, dbg);                                                                  \
-        else hipLaunchKernelGGL((k_poisson_system_pipe2<D, NB, R, V0, V1, BC, false>), dim3(grid2), dim3(64), lds2, st, m->n_rows, ns, m->d_vptr, rec, \
-                           m->d_mptr, m->d_cols, m->d_rowlen, m->d_x, u, ubc, load, bcval, diag0, vals0, diag1, vals1, rhs,   \
-                           bc_rowmask, m->d_pipe_dummy, dbg); } while (0)
-#define FEMO_SYS_PIPE2_COMBO(D, NB)                                                                                          \
-        do { if (no_bc_residual) FEMO_SYS_PIPE2(D, NB, true, false, false, false);                                            \
-             else if (combo_a) FEMO_SYS_PIPE2(D, NB, true, false, true, true);                                                \
-             else if (combo_b) FEMO_SYS_PIPE2(D, NB, false, true, true, true);                                                \
-             else FEMO_SYS_PIPE2(D, NB, true, false, false, true); } while (0)
-        if (m->tdim == 3) { if (NBp == 14) FEMO_SYS_PIPE2_COMBO(3, 14); else FEMO_SYS_PIPE2_COMBO(3, 16); }
-        else FEMO_SYS_PIPE2_COMBO(2, 8);
-#undef FEMO_SYS_PIPE2_COMBO
-#undef FEMO_SYS_PIPE2
-        FEMO_HIP_CHECK(hipGetLastError());
-        return finish_deferred();
-      }
       if (m->tdim == 3) { if (NBp == 14) FEMO_SYS_PIPE_COMBO(3, 14); else FEMO_SYS_PIPE_COMBO(3, 16); }
       else FEMO_SYS_PIPE_COMBO(2, 8);
 #undef FEMO_SYS_PIPE_COMBO

@@ -23,7 +23,22 @@ def entry(c):
     return {"fetch_KiB": f, "write_KiB": w, "bytes_2F_plus_W": (2 * f + w) * 1024}
 
 
-out = {"note": __doc__.split("\n", 3)[3].strip()}
+import os
+import subprocess
+
+
+def _commit():
+    # the build the counters were collected from: FEMO_COLLECT_COMMIT (set by the collection script: the GPU box has no .git) or git
+    c = os.environ.get("FEMO_COLLECT_COMMIT")
+    if c:
+        return c
+    try:
+        return subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or "unknown"
+    except Exception:
+        return "unknown"
+
+
+out = {"note": __doc__.split("\n", 3)[3].strip(), "collected_at_commit": _commit()}
 args = sys.argv[2:]
 also = []
 if "--also" in args:
