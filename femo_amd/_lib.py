@@ -136,6 +136,8 @@ PROTOTYPES = {
     "femo_shell_penalty_apply": (C.c_int, [H, H, H, C.c_int, H]),
     "femo_shell_inertia_apply": (C.c_int, [H, C.c_double, H, H, C.c_int, H]),
     "femo_shell_inertia_dh": (C.c_int, [H, C.c_double, H, H, H, C.c_int, H]),
+    "femo_shell_inertia_dh_fwd": (C.c_int, [H, C.c_double, H, H, H, C.c_int, H]),
+    "femo_shell_dform_dh_fwd": (C.c_int, [H, C.c_double, C.c_double, H, H, H, C.c_int, H]),
     "femo_shell_solve": (C.c_int, [H, H, C.c_void_p, H, H, H, C.POINTER(SolverOpts), C.POINTER(SolveInfo)]),
     "femo_shell_set_partition": (C.c_int, [H, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "femo_shell_set_owned_cells": (C.c_int, [H, C.c_void_p]),

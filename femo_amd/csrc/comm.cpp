@@ -117,7 +117,11 @@ int femo_coll_neighbors(femo_ctx* ctx, int n_nbr, const int32_t* nbr, const int6
                         const int64_t* recv_ptr, double* d_recv, hipStream_t st) {
   if (n_nbr == 0) return 0;
   ++ctx->n_neighbor; ctx->neighbor_doubles += send_ptr[n_nbr];
-  if (ctx->model) return 0;                                   // femo_comm_model: the ghost entries stay as they are
+  if (ctx->model) {                                           // femo_comm_model: nobody answers -- the ghost entries are ZERO
+    const int64_t nr = recv_ptr[n_nbr];                       // (defined values: the receive area may be recycled memory)
+    if (nr > 0) FEMO_HIP_CHECK(hipMemsetAsync(d_recv, 0, (size_t)nr * sizeof(double), st));
+    return 0;
+  }
   if (ctx->emu != nullptr) return emu_neighbors(ctx, n_nbr, nbr, send_ptr, d_send, recv_ptr, d_recv, st);
   FEMO_REQUIRE(ctx->comm != nullptr, "halo exchange before femo_comm_init");
   const ncclComm_t comm = ctx->comm_halo != nullptr ? ctx->comm_halo : ctx->comm;

@@ -384,6 +384,55 @@ __global__ __launch_bounds__(SH_BLOCK) void k_shell_dform_dh(femo_shell_view S, 
   }
 }
 
+// y += (dK/dh [dh]) w: the FORWARD product with the thickness partial of the elastic residual (state_model.py:176-188, fwd
+// mode: d_residuals += dR/dh . d_h).  Element by element from the strains of w: sigma' = (d/dh of the section weights in the
+// direction dh) D B w_e at every quadrature point, y_e = sum_q B^T sigma'.  One thread per cell, 27 atomics (the reverse
+// product k_shell_dform_dh is its exact transpose: <v, y> = <dh, out> -- tests/test_gpu_shell_round3.py).
+__global__ __launch_bounds__(SH_BLOCK) void k_shell_dform_dh_fwd(femo_shell_view S, double E, double nu, const double* __restrict__ h,
+                                                                 const double* __restrict__ dh, const double* __restrict__ w,
+                                                                 double* __restrict__ y) {
+  const int64_t c = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x;
+  if (c >= S.n_cell) return;
+  Facet F;
+  facet_frame(S.x, S.conn, c, F);
+  const Material m = material(E, nu);
+  const double hv[3] = {h[S.conn[c * 3]], h[S.conn[c * 3 + 1]], h[S.conn[c * 3 + 2]]};
+  const double dv[3] = {dh[S.conn[c * 3]], dh[S.conn[c * 3 + 1]], dh[S.conn[c * 3 + 2]]};
+  double we[27], acc[27];
+  for (int i = 0; i < 27; ++i) { we[i] = w[shell_gdof(S, c, i)]; acc[i] = 0.0; }
+  for (int q = 0; q < 6; ++q) {
+    const double* lam = c_lam6[q];
+    const double hq = hv[0] * lam[0] + hv[1] * lam[1] + hv[2] * lam[2];
+    const double dq = dv[0] * lam[0] + dv[1] * lam[1] + dv[2] * lam[2];
+    const double wq = c_w6[q] * F.area;
+    const double dm = wq * dq, db = wq * 0.25 * hq * hq * dq, dd = wq * 3.0 * m.E * hq * hq * dq;   // d/dh of h, h^3/12, E h^3
+    double sw[9];
+    element_strain(F, lam, we, sw);
+    const double s0 = dm * (m.c11 * sw[0] + m.c12 * sw[1]), s1 = dm * (m.c12 * sw[0] + m.c11 * sw[1]), s2 = dm * m.c33 * sw[2];
+    const double s3 = db * (m.c11 * sw[3] + m.c12 * sw[4]), s4 = db * (m.c12 * sw[3] + m.c11 * sw[4]), s5 = db * m.c33 * sw[5];
+    const double s8 = dd * sw[8];
+    for (int i = 0; i < 27; ++i) {
+      double bi[9];
+      strain_column(F, lam, i, bi);
+      acc[i] += bi[0] * s0 + bi[1] * s1 + bi[2] * s2 + bi[3] * s3 + bi[4] * s4 + bi[5] * s5 + bi[8] * s8;
+    }
+  }
+  for (int q = 0; q < 3; ++q) {
+    const double* lam = c_lam3[q];
+    const double dq = dv[0] * lam[0] + dv[1] * lam[1] + dv[2] * lam[2];
+    const double ds = (1.0 / 3.0) * F.area * m.mu_s * dq;
+    double sw[9];
+    element_strain(F, lam, we, sw);
+    const double s6 = ds * sw[6], s7 = ds * sw[7];
+    for (int i = 0; i < 27; ++i) {
+      double bi[9];
+      strain_column(F, lam, i, bi);
+      acc[i] += bi[6] * s6 + bi[7] * s7;
+    }
+  }
+  for (int i = 0; i < 27; ++i) atomicAdd(&y[shell_gdof(S, c, i)], acc[i]);
+}
+
 // F += int f . v  (f: CG1 vector field at the vertices, force per unit area), sign * that
 __global__ __launch_bounds__(SH_BLOCK) void k_shell_load(femo_shell_view S, const double* __restrict__ f, double sign, double* __restrict__ Fv) {
   const int64_t c = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x;
@@ -650,8 +699,11 @@ __global__ void k_shell_penalty_apply(int64_t n_e, const int32_t* __restrict__ n
 // Inertial residual (shell_pde.py:255-256 kinetic_residual -> inertialResidual [ext]):
 //   y += M(h) a,  M = int rho h  N_a N_b (displacements, P2) + int rho h^3 / 12  phi_a phi_b (rotations, P1), degree-4 rule;
 //   out_h[b] += lam^T (dM/dh_b) a   when lam != nullptr (y is not written then).  One thread per cell.
+//   dh != nullptr (with lam == nullptr): y += (dM/dh [dh]) a, the forward product -- the section weights h and h^3/12 replaced
+//   by their derivatives in the direction dh.
 __global__ __launch_bounds__(SH_BLOCK) void k_shell_inertia(femo_shell_view S, double rho, const double* __restrict__ h, const double* __restrict__ a,
-                                                            const double* __restrict__ lam_state, double* __restrict__ y, double* __restrict__ out_h) {
+                                                            const double* __restrict__ lam_state, double* __restrict__ y, double* __restrict__ out_h,
+                                                            const double* __restrict__ dh = nullptr) {
   const int64_t c = (int64_t)blockIdx.x * SH_BLOCK + threadIdx.x;
   if (c >= S.n_cell) return;
   Facet F;
@@ -680,7 +732,11 @@ __global__ __launch_bounds__(SH_BLOCK) void k_shell_inertia(femo_shell_view S, d
 #pragma unroll
       for (int k = 0; k < 3; ++k) { tq[k] += lam[b] * ae[18 + 3 * b + k]; lt[k] += lam[b] * le[18 + 3 * b + k]; }
     if (lam_state == nullptr) {
-      const double cu = wq * hq, ct = wq * hq * hq * hq * (1.0 / 12.0);
+      double cu = wq * hq, ct = wq * hq * hq * hq * (1.0 / 12.0);
+      if (dh != nullptr) {
+        const double dq = dh[S.conn[c * 3]] * lam[0] + dh[S.conn[c * 3 + 1]] * lam[1] + dh[S.conn[c * 3 + 2]] * lam[2];
+        cu = wq * dq; ct = wq * 0.25 * hq * hq * dq;
+      }
       for (int n = 0; n < 6; ++n) {
         const double N = p2_value(lam, n) * cu;
 #pragma unroll
@@ -3699,14 +3755,14 @@ int femo_shell_pc_hermite(femo_shell* s, const float* fin_w4, const int64_t* hp_
   return 0;
 }
 
-// State of the lattice preconditioner as the DEVICE side has it: out = {Hermite-type data uploaded, Hermite-type spaces in use
-// for the current stiffness, coarse solve factorised, node blocks ready}.  After a failed factorisation of the Hermite-type
+// State of the lattice preconditioner as the DEVICE side has it: out = {Hermite-type data uploaded, bit 0: Hermite-type spaces
+// enabled (uploaded and not fallen back) | bit 1: in use for the stiffness last set up, coarse solve factorised, node blocks ready}.  After a failed factorisation of the Hermite-type
 // coarse operator the library falls back to the trilinear hierarchy for good; callers that report or pin iteration counts
 // read the state here instead of remembering what they asked for.
 int femo_shell_pc_info(const femo_shell* s, int32_t out[4]) {
   FEMO_REQUIRE(s && out, "null argument");
   out[0] = s->hermite_loaded ? 1 : 0;
-  out[1] = (s->hermite && s->hermite_on && s->cs_ready && s->blk_ready) ? 1 : 0;
+  out[1] = (s->hermite ? 1 : 0) | ((s->hermite && s->hermite_on && s->cs_ready && s->blk_ready) ? 2 : 0);
   out[2] = s->cs_ready ? 1 : 0;
   out[3] = s->blk_ready ? 1 : 0;
   return 0;
@@ -3822,6 +3878,18 @@ int femo_shell_dform_dh(femo_shell* s, double E, double nu, const femo_vec* h, c
                      energy ? s->d_part : nullptr);
   FEMO_HIP_CHECK(hipGetLastError());
   if (energy) FEMO_TRY(reduce_partials(s->ctx, s->d_part, (int)g, energy));
+  return 0;
+}
+
+// y (+)= (dK/dh [dh]) w: forward product with the thickness partial of the elastic residual
+int femo_shell_dform_dh_fwd(femo_shell* s, double E, double nu, const femo_vec* h, const femo_vec* dh, const femo_vec* w, int accumulate, femo_vec* y) {
+  FEMO_REQUIRE(s && h && dh && w && y, "null argument");
+  FEMO_REQUIRE(h->n >= s->n_vert && dh->n >= s->n_vert && w->n >= s->n_dof && y->n >= s->n_dof && w->d != y->d, "vector size mismatch in shell_dform_dh_fwd");
+  hipStream_t st = s->ctx->stream;
+  femo_vec_touch(y);
+  if (!accumulate) FEMO_HIP_CHECK(hipMemsetAsync(y->d, 0, s->n_dof * sizeof(double), st));
+  hipLaunchKernelGGL(k_shell_dform_dh_fwd, dim3(sgrid(s->n_cell)), dim3(SH_BLOCK), 0, st, view(s), E, nu, h->d, dh->d, w->d, y->d);
+  FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
@@ -4051,6 +4119,18 @@ int femo_shell_inertia_dh(femo_shell* s, double rho, const femo_vec* h, const fe
   femo_vec_touch(out);
   if (!accumulate) FEMO_HIP_CHECK(hipMemsetAsync(out->d, 0, s->n_vert * sizeof(double), st));
   hipLaunchKernelGGL(k_shell_inertia, dim3(sgrid(s->n_cell)), dim3(SH_BLOCK), 0, st, view(s), rho, h->d, acc->d, lam->d, (double*)nullptr, out->d);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// y (+)= (dM/dh [dh]) acc: the thickness partial of the inertial residual, forward mode
+int femo_shell_inertia_dh_fwd(femo_shell* s, double rho, const femo_vec* h, const femo_vec* dh, const femo_vec* acc, int accumulate, femo_vec* y) {
+  FEMO_REQUIRE(s && h && dh && acc && y, "null argument");
+  FEMO_REQUIRE(h->n >= s->n_vert && dh->n >= s->n_vert && acc->n >= s->n_dof && y->n >= s->n_dof && acc->d != y->d, "vector size mismatch in shell_inertia_dh_fwd");
+  hipStream_t st = s->ctx->stream;
+  femo_vec_touch(y);
+  if (!accumulate) FEMO_HIP_CHECK(hipMemsetAsync(y->d, 0, s->n_dof * sizeof(double), st));
+  hipLaunchKernelGGL(k_shell_inertia, dim3(sgrid(s->n_cell)), dim3(SH_BLOCK), 0, st, view(s), rho, h->d, acc->d, (const double*)nullptr, y->d, (double*)nullptr, dh->d);
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;
 }

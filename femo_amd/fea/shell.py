@@ -642,7 +642,9 @@ class DeviceShell:
         falls back to the trilinear hierarchy when the Hermite-type coarse operator cannot be factorised."""
         out = (C.c_int32 * 4)()
         check(self.lib.femo_shell_pc_info(self.handle, out))
-        return {"hermite_loaded": bool(out[0]), "hermite_in_use": bool(out[1]), "coarse_solve_ready": bool(out[2]), "node_blocks_ready": bool(out[3])}
+        return {"hermite_loaded": bool(out[0]), "hermite_enabled": bool(out[1] & 1), "hermite_in_use": bool(out[1] & 2),
+                "fell_back_to_trilinear": bool(out[0]) and not bool(out[1] & 1),
+                "coarse_solve_ready": bool(out[2]), "node_blocks_ready": bool(out[3])}
 
     LEVEL_WEIGHT = 0.3          # the library's default (femo_shell_pc_weights; oracle: LatticePreconditioner.level_weight)
 
@@ -767,6 +769,16 @@ class DeviceShell:
         check(self.lib.femo_shell_inertia_dh(self.handle, float(rho), h.handle, lam.handle, acc.handle, int(accumulate), out.handle))
         return out
 
+    def inertia_dh_fwd(self, rho: float, h: Vec, dh: Vec, acc: Vec, y: Vec, accumulate: bool = False) -> Vec:
+        """y (+)= (dM/dh [dh]) acc (`femo_shell_inertia_dh_fwd`)."""
+        check(self.lib.femo_shell_inertia_dh_fwd(self.handle, float(rho), h.handle, dh.handle, acc.handle, int(accumulate), y.handle))
+        return y
+
+    def dform_dh_fwd(self, Ey, nu, h: Vec, dh: Vec, w: Vec, y: Vec, accumulate: bool = False) -> Vec:
+        """y (+)= (dK/dh [dh]) w (`femo_shell_dform_dh_fwd`): the forward product with the thickness partial of the elastic residual."""
+        check(self.lib.femo_shell_dform_dh_fwd(self.handle, float(Ey), float(nu), h.handle, dh.handle, w.handle, int(accumulate), y.handle))
+        return y
+
     def mass(self, rho: float, h: Vec, grad: Optional[Vec] = None, value: bool = True, accumulate: bool = False):
         val = C.c_double(0.0)
         check(self.lib.femo_shell_mass(self.handle, float(rho), h.handle, C.byref(val) if value else None, int(accumulate),
@@ -801,22 +813,54 @@ class DeviceShell:
             wk = self._proj_work = [Vec(ctx, nv) for _ in range(6)]
         b, ml, r, z, p, q = wk
         self.vm_rhs(Ey, nu, h, w, surface, b, ml)
+        part = self.partition
+        if part is None:
+            own = lambda v: v                       # one rank: every vertex is owned, nothing to refresh
+            refresh = lambda v: v
+            dot = lambda x, y: x.dot(y, nv)
+        else:
+            # Partitioned (round 5): a rank keeps every cell around the vertices it owns, so b, the lumped mass and the rows of the
+            # P1 mass matrix are COMPLETE on owned vertices.  CG runs on the owned entries: residuals are masked (divided by a
+            # vector that is 1 on owned vertices and inf on the others: x / inf = 0), dot products are all-reduced, and the
+            # search direction is refreshed on the ghost vertices before every product -- it rides in the rotation dofs of a
+            # state-sized vector through the shell's own halo plan (`femo_shell_halo`; vertex v = rotation point n_unode + v).
+            # Host-staged: the projection is an output, not part of the solve loop.
+            nu_l = self.space.n_unode
+            if self.__dict__.get("_proj_own") is None:
+                owned_v = np.asarray(part.owned_points[nu_l:nu_l + nv], dtype=bool)
+                self._proj_own = Vec(ctx, nv).set(np.where(owned_v, 1.0, np.inf))
+                self._proj_state = Vec(ctx, self.n_dof)
+            own = lambda v: E.pointwise_divide(v, v, self._proj_own, nv)
+            rot0 = 3 * nu_l + 3 * np.arange(nv)
+
+            def refresh(v):
+                st = np.zeros(self.n_dof)
+                st[rot0] = np.asarray(v.get(nv))
+                self._proj_state.set(st)
+                self.halo(self._proj_state)
+                v.set(np.ascontiguousarray(np.asarray(self._proj_state.get())[rot0]))
+                return v
+            dot = lambda x, y: float(ctx.allreduce_sum([x.dot(y, nv)])[0])       # x is masked: the rank's share
         if lump_mass:
-            return E.pointwise_divide(out, b, ml, nv)
+            return refresh(E.pointwise_divide(out, b, ml, nv)) if part is not None else E.pointwise_divide(out, b, ml, nv)
         out.fill(0.0)
         r.copy_from(b)
+        own(r)
         E.pointwise_divide(z, r, ml, nv)
         p.copy_from(z)
-        g = g0 = r.dot(z, nv)
+        g = g0 = dot(r, z)
         for _ in range(max_it):
             if g <= (rtol * rtol) * g0 or g0 == 0.0:
-                return out
+                return refresh(out) if part is not None else out
+            refresh(p)
             self.p1_mass(p, q)
-            a = g / p.dot(q, nv)
+            own(q)
+            own(p)
+            a = g / dot(q, p)
             out.axpy(a, p)
             r.axpy(-a, q)
             E.pointwise_divide(z, r, ml, nv)
-            g1 = r.dot(z, nv)
+            g1 = dot(r, z)
             z.axpy(g1 / g, p)                    # z <- z + beta p, then p <- z
             p.copy_from(z)
             g = g1
@@ -947,11 +991,6 @@ class ShellProblem:
         return np.array(self.gf.get()).reshape(-1, 3)
 
     # outputs --------------------------------------------------------------------------------------
-    def _serial_only(self, what: str) -> None:
-        if self.partition is not None:
-            raise NotImplementedError(f"ShellProblem.{what} on a partitioned shell: the projection's mass-matrix solve is not "
-                                      "distributed; the scalar outputs (compliance, mass, p-norm stress, elastic energy) are")
-
     def compliance(self, w: Optional[np.ndarray] = None, grad: bool = False):
         if w is not None:
             self.w.set(np.ascontiguousarray(w, dtype=np.float64))
@@ -997,7 +1036,6 @@ class ShellProblem:
 
     def von_mises_field(self, w: Optional[np.ndarray] = None, surface: float = 1.0, lump_mass: bool = False) -> np.ndarray:
         """The von Mises stress on the top / mid / bottom surface projected onto the vertices (shell_pde.py:315-332)."""
-        self._serial_only("von_mises_field")
         if w is not None:
             self.w.set(np.ascontiguousarray(w, dtype=np.float64))
         self.dev.project_von_mises(self.E, self.nu, self.h, self.w, surface, self.gh, lump_mass=lump_mass)

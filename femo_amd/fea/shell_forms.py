@@ -249,9 +249,11 @@ class _ShellPartial:
         return (S.n_dof, S.n_vert if self.wrt == "h" else 3 * S.n_vert)
 
     def mult(self, x: Vec, y: Vec) -> Vec:
+        dev, F = self.mesh.device(_ctx()), self.form
         if self.wrt == "h":
-            raise NotImplementedError("forward-mode product with dR/dh of the shell is not built (reverse mode is)")
-        return self.mesh.device(_ctx()).load(x, y, sign=-1.0)
+            # d_residuals += dR/dh . d_h (state_model.py:176-188, fwd mode): (dK/dh [d_h]) w, element by element
+            return dev.dform_dh_fwd(F.E, F.nu, F.h.vec, x, F.w.vec, y)
+        return dev.load(x, y, sign=-1.0)
 
     def multTranspose(self, x: Vec, y: Vec) -> Vec:
         dev, F = self.mesh.device(_ctx()), self.form
@@ -486,9 +488,9 @@ class _InertiaOperator:
         return (S.n_dof, S.n_dof if self.wrt == "a" else S.n_vert)
 
     def mult(self, x: Vec, y: Vec) -> Vec:
-        if self.wrt == "h":
-            raise NotImplementedError("forward-mode product with dM/dh is not built (reverse mode is)")
         F = self.form
+        if self.wrt == "h":
+            return self.mesh.device(_ctx()).inertia_dh_fwd(F.rho, F.h.vec, x, F.acc.vec, y)
         return self.mesh.device(_ctx()).inertia_apply(F.rho, F.h.vec, x, y)
 
     def multTranspose(self, x: Vec, y: Vec) -> Vec:

@@ -386,6 +386,10 @@ int femo_shell_load_T(femo_shell* s, const femo_vec* lam, double sign, int accum
 /* out_b (+)= v^T (dK/dh_b) w -- (dR/dh)^T lambda for R = K(h) w - F with v = lambda; *energy = 1/2 v^T K w (shell_pde.py:299-302) */
 int femo_shell_dform_dh(femo_shell* s, double E, double nu, const femo_vec* h, const femo_vec* v, const femo_vec* w,
                         int accumulate, femo_vec* out, double* energy);
+/* y (+)= (dK/dh [dh]) w: the FORWARD product with the thickness partial of the elastic residual (the fwd branch of
+ * compute_jacvec_product, state_model.py:176-188); the exact transpose of femo_shell_dform_dh: <v, y> = <dh, out>.         */
+int femo_shell_dform_dh_fwd(femo_shell* s, double E, double nu, const femo_vec* h, const femo_vec* dh, const femo_vec* w,
+                            int accumulate, femo_vec* y);
 /* 1/2 int u_mid . u_mid (shell_pde.py:287-288) and its gradient; int rho h (shell_pde.py:293-294) and its gradient */
 int femo_shell_compliance(femo_shell* s, const femo_vec* w, double* value, int accumulate, femo_vec* grad);
 int femo_shell_mass(femo_shell* s, double rho, const femo_vec* h, double* value, int accumulate, femo_vec* grad);
@@ -414,6 +418,8 @@ int femo_shell_penalty_apply(femo_shell* s, const femo_vec* x, const femo_vec* g
  * femo_shell_inertia_dh: out_b (+)= lam^T (dM/dh_b) acc, its thickness partial transposed.                             */
 int femo_shell_inertia_apply(femo_shell* s, double rho, const femo_vec* h, const femo_vec* acc, int accumulate, femo_vec* y);
 int femo_shell_inertia_dh(femo_shell* s, double rho, const femo_vec* h, const femo_vec* lam, const femo_vec* acc, int accumulate, femo_vec* out);
+/* y (+)= (dM/dh [dh]) acc: the same for the inertial residual.                                                           */
+int femo_shell_inertia_dh_fwd(femo_shell* s, double rho, const femo_vec* h, const femo_vec* dh, const femo_vec* acc, int accumulate, femo_vec* y);
 /* L2 projection of the von Mises stress onto CG1 (shell_pde.py:315-332; the field output of the shell drivers,
  * shell_dynamic_pde.py:82-83,129): rhs_i = int sigma_vm phi_i, lumped_i = row sum of the P1 mass matrix (may be NULL);
  * femo_shell_p1_mass: y = M x with that mass matrix (the host side runs Jacobi-CG with it, utils_dolfinx.py:549-583). */
@@ -468,8 +474,8 @@ int femo_shell_pc_coarse(femo_shell* s, int level, const int32_t* node_xyz, int6
 int femo_shell_pc_hermite(femo_shell* s, const float* fin_w4, const int64_t* hp_rowptr, const int32_t* hp_cols, const float* hp_w4,
                           const double* par_w5, const double* chi_w5, const float* lvl_w4, const float* cs_w4,
                           const int64_t* down_rowptr, const int32_t* down_cols, const double* down_w5);
-/* What the device side runs with: out = {Hermite-type data uploaded, Hermite-type spaces in use for the last stiffness set
- * up, coarse solve factorised, node blocks ready}.  The library falls back to the trilinear hierarchy (once, with a warning
+/* What the device side runs with: out = {Hermite-type data uploaded, bit 0: Hermite-type spaces enabled (not fallen back) |
+ * bit 1: in use for the last stiffness set up, coarse solve factorised, node blocks ready}.  The library falls back to the trilinear hierarchy (once, with a warning
  * on stderr) when the Hermite-type coarse operator cannot be factorised; reports and pinned iteration counts read this.  */
 int femo_shell_pc_info(const femo_shell* s, int32_t out[4]);
 /* Items of the node-block set-up for the Hermite-type spaces (optional; without it the blocks are formed row by row, 10.5

@@ -26,10 +26,10 @@ int femo_comm_emulate(femo_ctx* ctx, femo_emu_group* group, int rank);
  * Makes ONE context run the N-rank code paths of the library alone on its GPU: ctx behaves as rank `rank` of
  * `nranks` (partitioned-mesh branches of the solvers, the pack kernel of the merged BPX-PCG loop, the split
  * interior / boundary SpMV with its halo pack), while every collective completes at once without moving a byte
- * -- an all-reduce leaves the rank's own contribution in place, a neighbour exchange leaves the ghost entries as
- * they are.  The collectives are still counted (femo_comm_stats).  What this measures: everything a rank of an
- * N-GPU job does per iteration except the time on the wire.  The numbers it computes are those of the rank's
- * block solved on its own (ghost values stay zero), not of the global problem.                              */
+ * -- an all-reduce leaves the rank's own contribution in place, a neighbour exchange fills the ghost entries with
+ * zeros (one memset on the stream).  The collectives are still counted (femo_comm_stats).  What this measures:
+ * everything a rank of an N-GPU job does per iteration except the time on the wire.  The numbers it computes
+ * are those of the rank's block solved on its own (zero ghost values), not of the global problem.           */
 int femo_comm_model(femo_ctx* ctx, int rank, int nranks);
 
 #ifdef __cplusplus

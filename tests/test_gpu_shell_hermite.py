@@ -38,7 +38,8 @@ def test_hermite_operator_matches_the_oracle(ctx, n, coarse):
     mask[fixed] = 1
     vals = prob._stiffness()
     A = prob.dev.coarse_matrix(vals, mask)
-    assert prob.dev.pc_state()["hermite_in_use"], "the device fell back to the trilinear hierarchy"
+    st = prob.dev.pc_state()
+    assert st["hermite_enabled"] and st["coarse_solve_ready"] and not st["fell_back_to_trilinear"], st
     A_ref = (M.P[M.c].T @ M.Kf @ M.P[M.c]).toarray()
     # (the oracle's P has zero rows on the fixed dofs, so the identity rows of Kf do not enter)
     assert A.shape == A_ref.shape

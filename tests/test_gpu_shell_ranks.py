@@ -137,16 +137,27 @@ def test_compliance_gradient_on_three_ranks():
         prob.set_thickness(h)
         prob.set_load(f)
         J, g, w = prob.compliance_gradient()
-        with pytest.raises(NotImplementedError):
-            prob.von_mises_field()                                   # the projection's mass solve is not distributed
-        return P, J, g
+        # round 5: the projected von Mises field on a partitioned shell (mass-matrix CG over the shell's halo; lumped too)
+        vm, vml = prob.von_mises_field(), prob.von_mises_field(lump_mass=True)
+        return P, J, g, vm, vml
 
     res = _run_ranks(world, rank_fn)
+
+    def serial_fn(rank, ctx):
+        prob = ShellProblem(pts, conn, E_ROOF, 0.3, fixed_dofs=fixed, ctx=ctx)
+        prob.set_thickness(h)
+        prob.set_load(f)
+        prob.solve()
+        return prob.von_mises_field(), prob.von_mises_field(lump_mass=True)
+    vm_ref, vml_ref = _run_ranks(1, serial_fn)[0]
     grad = np.full(V.n_vert, np.nan)
-    for P, J, g in res:
+    for P, J, g, vm, vml in res:
         assert abs(J - Jref) <= 1e-8 * abs(Jref)                     # every rank holds the all-reduced value
         ov = P.owned_vertices()
         grad[P.vert_global[ov]] = g[ov]
+        # every rank holds the field on ALL its local vertices (owned: solved; ghosts: the owners' values)
+        assert np.abs(vm - vm_ref[P.vert_global]).max() <= 1e-6 * np.abs(vm_ref).max()
+        assert np.abs(vml - vml_ref[P.vert_global]).max() <= 1e-6 * np.abs(vml_ref).max()
     assert not np.isnan(grad).any()
     print(f"compliance gradient on 3 ranks: {rel(grad, gref):.2e}")
     assert rel(grad, gref) <= 1e-7

@@ -121,6 +121,37 @@ def test_thickness_partial_of_the_stiffness_is_exact(wing):
     assert rel(out.get(), so.dform_dh(V, h, E_Y, NU, v, w)) <= 1e-12
 
 
+def test_forward_products_with_the_thickness_partials(wing):
+    """Round 5 (missing #4): compute_jacvec_product(mode='fwd') with dR/dh and dM/dh
+    (state_model.py:176-188).  The forward product is the exact transpose of the reverse one, <v, (dK/dh [dh]) w> =
+    <dh, dform_dh(v, w)>, and a directional derivative of the residual: K is cubic in h, so a Richardson-extrapolated
+    central difference of the oracle's K(h) w is exact up to round-off; the same for M(h) a.  Through the form layer too
+    (`_ShellPartial.mult`, `_InertiaOperator.mult`), where the reference's fwd branch would call them."""
+    V, S, dev, h, rng, ctx, Vec = (wing[k] for k in ("V", "S", "dev", "h", "rng", "ctx", "Vec"))
+    v, w = rng.standard_normal(S.n_dof), rng.standard_normal(S.n_dof)
+    dh = 0.1 * h * rng.standard_normal(V.n_vert)
+    hv, dhv, wv = Vec(ctx, V.n_vert).set(h), Vec(ctx, V.n_vert).set(dh), Vec(ctx, S.n_dof).set(w)
+    y = np.array(dev.dform_dh_fwd(E_Y, NU, hv, dhv, wv, Vec(ctx, S.n_dof)).get())
+    out = np.array(dev.dform_dh(E_Y, NU, hv, Vec(ctx, S.n_dof).set(v), wv, out=Vec(ctx, V.n_vert)).get())
+    assert v @ y == pytest.approx(dh @ out, rel=1e-12)
+    Kw = lambda hh: so.assemble(V, so.element_stiffness(V, hh, E_Y, NU)).tocsr() @ w
+    d1, d2 = (Kw(h + dh) - Kw(h - dh)) / 2.0, (Kw(h + 2 * dh) - Kw(h - 2 * dh)) / 4.0
+    assert rel(y, (4 * d1 - d2) / 3) <= 1e-10
+    y2 = Vec(ctx, S.n_dof).set(w)                                               # accumulate
+    dev.dform_dh_fwd(E_Y, NU, hv, dhv, wv, y2, accumulate=True)
+    assert rel(y2.get(), w + y) <= 1e-13
+    # inertia
+    rho = 2710.0
+    a, lam = rng.standard_normal(S.n_dof), rng.standard_normal(S.n_dof)
+    av = Vec(ctx, S.n_dof).set(a)
+    ym = np.array(dev.inertia_dh_fwd(rho, hv, dhv, av, Vec(ctx, S.n_dof)).get())
+    gm = np.array(dev.inertia_dh(rho, hv, Vec(ctx, S.n_dof).set(lam), av, Vec(ctx, V.n_vert)).get())
+    assert lam @ ym == pytest.approx(dh @ gm, rel=1e-12)
+    Ma = lambda hh: so.inertia_apply(V, hh, rho, a)
+    d1, d2 = (Ma(h + dh) - Ma(h - dh)) / 2.0, (Ma(h + 2 * dh) - Ma(h - 2 * dh)) / 4.0
+    assert rel(ym, (4 * d1 - d2) / 3) <= 1e-10
+
+
 def _penalty_problem(wing, beta):
     from femo_amd.csdl_opt.fea_model import FEAModel
     from femo_amd.csdl_opt.simulator import Simulator
@@ -193,6 +224,18 @@ def test_operator_cycle_with_penalty_boundary_conditions(wing):
     rref = (K + Kp) @ wref - F - Kp @ gv
     assert np.abs(r - rref).max() <= 1e-9 * np.abs(Kp @ gv).max()
     X["g_fn"].vector.set(0.0)
+    # forward mode of the operator (round 5): d_residuals += dR/dh . d_h + dR/df . d_f through compute_jacvec_product
+    op = [o for _, o in sim.ops if hasattr(o, 'apply_inverse_jacobian')][0]
+    ins, outs = {'thickness': sim.values['thickness'], 'F_solid': sim.values['F_solid']}, {'disp_solid': sim.values['disp_solid']}
+    op.compute_derivatives(ins, outs, {})
+    rng5 = np.random.default_rng(5)
+    dh, df = 0.1 * h * rng5.standard_normal(V.n_vert), rng5.standard_normal(3 * V.n_vert)
+    d_res = {'disp_solid': np.zeros(V.n_dof)}
+    op.compute_jacvec_product(ins, outs, {'thickness': dh, 'F_solid': df}, {}, d_res, 'fwd')
+    Kw = lambda hh: so.assemble(V, so.element_stiffness(V, hh, E_Y, NU)).tocsr() @ w
+    d1, d2 = (Kw(h + dh) - Kw(h - dh)) / 2.0, (Kw(h + 2 * dh) - Kw(h - 2 * dh)) / 4.0
+    ref_fwd = (4 * d1 - d2) / 3 - so.load_vector(V, df.reshape(-1, 3))
+    assert rel(np.asarray(d_res['disp_solid']), ref_fwd) <= 1e-9
     # strong-BC limit: clamp every dof on the tagged edges strongly
     un = np.unique(np.concatenate([V.edge_vertices[np.concatenate([ext, inte])].ravel(), V.n_vert + np.concatenate([ext, inte])]))
     vn = un[un < V.n_vert]
