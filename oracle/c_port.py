@@ -208,6 +208,97 @@ def poisson_cycle(tdim: int, x: np.ndarray, conn: np.ndarray, f: np.ndarray, u_d
                 threads=L.oc_num_threads(), nnz=int(rowptr[-1]), pc=pc)
 
 
+def nl_residual(tdim, x, conn, u, f, u_ex, bmask, beta, sgn=1.0):
+    r = np.empty(x.shape[0])
+    lib().oc_nl_residual(tdim, _i64(x.shape[0]), _p(x), _i64(conn.shape[0]), _p(conn), _p(u), _p(f), _p(u_ex), _p(bmask),
+                         C.c_double(beta), C.c_double(sgn), _p(r))
+    return r
+
+
+def nl_jacobian(tdim, x, conn, u, bmask, beta, rowptr, col, sgn=1.0):
+    val = np.empty(rowptr[-1], np.float64)
+    lib().oc_nl_jacobian(tdim, _i64(x.shape[0]), _p(x), _i64(conn.shape[0]), _p(conn), _p(u), _p(bmask), C.c_double(beta),
+                         C.c_double(sgn), _p(rowptr), _p(col), _p(val))
+    return val
+
+
+def nl_cycle(tdim: int, x: np.ndarray, conn: np.ndarray, f: np.ndarray, u_ex: np.ndarray, bmask: np.ndarray, alpha: float,
+             beta: float = 10.0, rtol_bpx: float = 1e-11, threads: Optional[int] = None, max_newton: int = 100,
+             snes_tol: float = 1e-13, stol: float = 1e-8, cg_cap: Optional[int] = None) -> Dict:
+    """BASELINE config 5's cycle on the host cores (round 5; the cycle bench.py::bench_config5 times on the GPU): SNES
+    (Newton, full step, Jacobian reassembled every step -- utils_dolfinx.py:376-416) from u = 1 with BPX-preconditioned CG
+    where the reference factorises (the engine's algorithm and stopping rules: utils_hip._NewtonBase / SNESSolver), then J,
+    dJ/du, the Jacobian at the converged state, the adjoint solve and dJ/df = alpha f |T| - dR/df^T lambda.  Symmetric
+    Nitsche (sgn = +1): the Jacobian is symmetric, so CG serves the transposed solve as well."""
+    L = lib()
+    if threads:
+        L.oc_set_num_threads(int(threads))
+    x = np.ascontiguousarray(x, np.float64)
+    conn = np.ascontiguousarray(conn, np.int32)
+    f = np.ascontiguousarray(f, np.float64)
+    u_ex = np.ascontiguousarray(u_ex, np.float64)
+    bmask = np.ascontiguousarray(bmask, np.uint8)
+    nv, nc = x.shape[0], conn.shape[0]
+    T: Dict[str, float] = {}
+    t0 = time.perf_counter()
+    rowptr, col = pattern(tdim, nv, conn)
+    T["pattern_setup"] = time.perf_counter() - t0
+    # the vertices of the Nitsche facets are pinned in the preconditioner (femo_amd/csrc/bpx.hip: the penalty pins them)
+    pinned = np.zeros(nv, np.uint8)
+    d1 = tdim + 1
+    for k in range(d1):
+        cells = np.nonzero((bmask >> k) & 1)[0]
+        if cells.size:
+            pinned[np.delete(conn[cells], k, axis=1).ravel()] = 1
+    t0 = time.perf_counter()
+    B = Bpx(x, pinned)
+    T["bpx_setup"] = time.perf_counter() - t0
+    max_it = cg_cap if cg_cap else 100000
+    diag_at = _diag_index(rowptr, col)
+    eps = np.finfo(np.float64).eps
+    t_cycle = time.perf_counter()
+    u = np.ones(nv)                                        # CSDL's default state value
+    F = nl_residual(tdim, x, conn, u, f, u_ex, bmask, beta)
+    r0 = r = float(np.linalg.norm(F))
+    its, newton = [], 0
+    atol = atol_pc = 0.0
+    z0 = None
+    while newton < max_newton:
+        if r < snes_tol or (newton > 0 and r < snes_tol * r0):
+            break
+        A = nl_jacobian(tdim, x, conn, u, bmask, beta, rowptr, col)
+        dx, it, _ = pcg_bpx(B, rowptr, col, A, F, rtol_bpx, atol, max_it, atol_pc)
+        its.append(it)
+        if z0 is None:
+            z0 = float(np.sqrt(F @ (F / A[diag_at])))
+        u -= dx
+        newton += 1
+        atol = max(1e-14 * z0, 64.0 * eps * float(np.sqrt(u @ u)))                       # utils_hip._NewtonBase.NOISE_FACTOR
+        atol_pc = rtol_bpx * float(np.sqrt(max(u @ spmv(rowptr, col, A, u), 0.0)))
+        F = nl_residual(tdim, x, conn, u, f, u_ex, bmask, beta)
+        r = float(np.linalg.norm(F))
+        if float(np.sqrt(dx @ dx)) < stol * float(np.sqrt(u @ u)):                        # PETSc SNES stol [ext]
+            break
+    T["newton_total"] = time.perf_counter() - t_cycle
+    t0 = time.perf_counter()
+    J = L.oc_functional(tdim, _p(x), _i64(nc), _p(conn), _p(u), _p(f), _p(u_ex), C.c_double(alpha))
+    dJdu = np.empty(nv)
+    L.oc_functional_du(tdim, _i64(nv), _p(x), _i64(nc), _p(conn), _p(u), _p(u_ex), _p(dJdu))
+    dJdf = np.empty(nc)
+    L.oc_functional_df(tdim, _p(x), _i64(nc), _p(conn), _p(f), C.c_double(alpha), _p(dJdf))
+    A = nl_jacobian(tdim, x, conn, u, bmask, beta, rowptr, col)
+    T["output_linearize"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    lam, it_adj, _ = pcg_bpx(B, rowptr, col, A, dJdu, rtol_bpx, 0.0, max_it, 0.0)
+    T["cg_adj"] = time.perf_counter() - t0
+    g = np.empty(nc)
+    L.oc_dRdfT_apply(tdim, _p(x), _i64(nc), _p(conn), _p(lam), _p(g))
+    grad = dJdf - g
+    T["cycle"] = time.perf_counter() - t_cycle
+    return dict(u=u, J=J, grad=grad, lam=lam, newton_its=newton, it_fwd=its, it_adj=it_adj, times=T, threads=L.oc_num_threads(),
+                nnz=int(rowptr[-1]), residual_norm=r)
+
+
 def poisson_cycle_dst(n: int, tdim: int, x: np.ndarray, conn: np.ndarray, f: np.ndarray, u_d: np.ndarray,
                       bc_dofs: np.ndarray, alpha: float, threads: Optional[int] = None) -> Dict:
     """The cycle of ``poisson_cycle`` with BOTH linear solves done exactly: on the un-jittered, lexicographically

@@ -574,6 +574,141 @@ void oc_dRdfT_apply(int d, const double* x, int64_t n_cell, const int32_t* conn,
   }
 }
 
+/* ---- nonlinear Poisson + Nitsche (BASELINE config 5): femo_oracle.py::nl_residual / nl_jacobian in C/OpenMP -------------
+ * R(u; f) = int grad u . grad v + int u^3 v - int f v  + the symmetric (sgn = +1, penalty beta / h_E) or unsymmetric (sgn = -1)
+ * Nitsche terms on the exterior facets, u_ex the CG1 interpolant of the Dirichlet data (run_nonlinear_poisson_opt.py:88-116).
+ * The cubic term uses the closed-form P1 monomial integrals int prod phi^alpha = |T| d! prod(alpha!) / (|alpha| + d)!.
+ * Round 5: so that bench.py's config-5 CPU baseline runs at the configuration's own size on all host cores. */
+static double fact(int n) { double f = 1.0; for (int i = 2; i <= n; ++i) f *= i; return f; }
+
+/* T3[a][b][c][e] = int phi_a phi_b phi_c phi_e / |T| */
+static void cubic_table(int d, double T3[4][4][4][4]) {
+  const int nv = d + 1;
+  for (int a = 0; a < nv; ++a) for (int b = 0; b < nv; ++b) for (int c = 0; c < nv; ++c) for (int e = 0; e < nv; ++e) {
+    int mult[4] = {0, 0, 0, 0};
+    mult[a]++; mult[b]++; mult[c]++; mult[e]++;
+    double p = fact(d);
+    for (int k = 0; k < nv; ++k) p *= fact(mult[k]);
+    T3[a][b][c][e] = p / fact(4 + d);
+  }
+}
+
+typedef struct { double meas, hE, gn[4], nrm[3]; } oc_facet;
+
+/* facet opposite local vertex k of the cell with gradients g and volume vol */
+static void facet_piece(int d, const double* x, const int32_t* v, double vol, double g[4][3], int k, oc_facet* F) {
+  const int nv = d + 1;
+  double ng = 0.0;
+  for (int j = 0; j < d; ++j) ng += g[k][j] * g[k][j];
+  ng = sqrt(ng);
+  for (int j = 0; j < d; ++j) F->nrm[j] = -g[k][j] / ng;          /* outward normal */
+  F->meas = d * vol * ng;                                          /* |F_k| = d |T| |grad phi_k| */
+  double hE = 0.0;
+  for (int a = 0; a < nv; ++a)
+    for (int b = a + 1; b < nv; ++b) {
+      double s = 0.0;
+      for (int j = 0; j < d; ++j) { const double t = x[d * (int64_t)v[a] + j] - x[d * (int64_t)v[b] + j]; s += t * t; }
+      s = sqrt(s);
+      if (s > hE) hE = s;
+    }
+  F->hE = hE;
+  for (int a = 0; a < nv; ++a) {
+    double s = 0.0;
+    for (int j = 0; j < d; ++j) s += g[a][j] * F->nrm[j];
+    F->gn[a] = s;
+  }
+}
+
+void oc_nl_residual(int d, int64_t n_vert, const double* x, int64_t n_cell, const int32_t* conn, const double* u,
+                    const double* f, const double* uex, const uint8_t* bmask, double beta, double sgn, double* r) {
+  const int nv = d + 1;
+  double T3[4][4][4][4];
+  cubic_table(d, T3);
+  memset(r, 0, (size_t)n_vert * sizeof(double));
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < n_cell; ++c) {
+    const int32_t* v = conn + c * nv;
+    double vol, g[4][3], gu[3] = {0, 0, 0}, ue[4], Re[4];
+    geom(d, x, v, &vol, g);
+    for (int b = 0; b < nv; ++b) {
+      ue[b] = u[v[b]];
+      for (int k = 0; k < d; ++k) gu[k] += g[b][k] * ue[b];
+    }
+    for (int a = 0; a < nv; ++a) {
+      double s = 0.0, cub = 0.0;
+      for (int k = 0; k < d; ++k) s += g[a][k] * gu[k];
+      for (int b = 0; b < nv; ++b) for (int cc = 0; cc < nv; ++cc) for (int e = 0; e < nv; ++e) cub += T3[a][b][cc][e] * ue[b] * ue[cc] * ue[e];
+      Re[a] = vol * s - f[c] * vol / nv + vol * cub;
+    }
+    if (bmask && bmask[c]) {
+      for (int k = 0; k < nv; ++k) {
+        if (!((bmask[c] >> k) & 1)) continue;
+        oc_facet F;
+        facet_piece(d, x, v, vol, g, k, &F);
+        double dun = 0.0, s_on = 0.0, er[4];
+        for (int a = 0; a < nv; ++a) { er[a] = ue[a] - uex[v[a]]; dun += F.gn[a] * ue[a]; if (a != k) s_on += er[a]; }
+        const double mean_e = s_on / d;
+        for (int a = 0; a < nv; ++a) Re[a] += sgn * F.gn[a] * (-mean_e) * F.meas;               /* nitsche_2 */
+        for (int a = 0; a < nv; ++a) {
+          if (a == k) continue;
+          Re[a] += -dun * F.meas / d;                                                           /* nitsche_1 */
+          Re[a] += beta / F.hE * F.meas / (d * (d + 1)) * (er[a] + s_on);                       /* penalty (facet mass) */
+        }
+      }
+    }
+    for (int a = 0; a < nv; ++a) {
+#pragma omp atomic
+      r[v[a]] += Re[a];
+    }
+  }
+}
+
+void oc_nl_jacobian(int d, int64_t n_vert, const double* x, int64_t n_cell, const int32_t* conn, const double* u,
+                    const uint8_t* bmask, double beta, double sgn, const int64_t* rowptr, const int32_t* col, double* val) {
+  const int nv = d + 1;
+  double T3[4][4][4][4];
+  cubic_table(d, T3);
+  memset(val, 0, (size_t)rowptr[n_vert] * sizeof(double));
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < n_cell; ++c) {
+    const int32_t* v = conn + c * nv;
+    double vol, g[4][3], ue[4], Ke[4][4];
+    geom(d, x, v, &vol, g);
+    for (int b = 0; b < nv; ++b) ue[b] = u[v[b]];
+    for (int a = 0; a < nv; ++a)
+      for (int b = 0; b < nv; ++b) {
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < d; ++k) s += g[a][k] * g[b][k];
+        for (int cc = 0; cc < nv; ++cc) for (int e = 0; e < nv; ++e) q += T3[a][b][cc][e] * ue[cc] * ue[e];
+        Ke[a][b] = vol * (s + 3.0 * q);
+      }
+    if (bmask && bmask[c]) {
+      for (int k = 0; k < nv; ++k) {
+        if (!((bmask[c] >> k) & 1)) continue;
+        oc_facet F;
+        facet_piece(d, x, v, vol, g, k, &F);
+        for (int a = 0; a < nv; ++a) {
+          if (a == k) continue;
+          for (int b = 0; b < nv; ++b) {
+            Ke[a][b] += -F.gn[b] * F.meas / d;                 /* nitsche_1: -(g_b.n) int_F phi_a */
+            Ke[b][a] += -sgn * F.gn[b] * F.meas / d;           /* nitsche_2: -sgn (g_b.n) int_F phi_a */
+          }
+          for (int b = 0; b < nv; ++b) {
+            if (b == k) continue;
+            Ke[a][b] += beta / F.hE * F.meas / (d * (d + 1)) * (a == b ? 2.0 : 1.0);
+          }
+        }
+      }
+    }
+    for (int a = 0; a < nv; ++a)
+      for (int b = 0; b < nv; ++b) {
+        const int64_t p = find(rowptr, col, v[a], v[b]);
+#pragma omp atomic
+        val[p] += Ke[a][b];
+      }
+  }
+}
+
 int oc_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

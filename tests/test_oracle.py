@@ -154,6 +154,34 @@ def test_c_port_pieces():
 
 
 # ---- nonlinear Poisson + symmetric Nitsche (examples/nonlinear_poisson_opt) ----
+def test_c_port_nonlinear_cycle_matches_the_numpy_oracle():
+    """Round 5: the C/OpenMP port's nonlinear Poisson + Nitsche pieces (bench.py's config-5 CPU baseline at full size) against
+    the NumPy oracle: residual and Jacobian to round-off on jittered 2-D / 3-D meshes, the whole SNES + adjoint cycle
+    (BPX-CG where the oracle factorises) to solver accuracy."""
+    from oracle import c_port as cp
+    import scipy.sparse as sp
+    rng = np.random.default_rng(0)
+    for d, n in ((2, 16), (3, 6)):
+        m = fo.unit_square_mesh(n, 0.2) if d == 2 else fo.unit_cube_mesh(n, 0.2)
+        u, f = rng.standard_normal(m.n_vert), 1 + rng.random(m.n_cell)
+        uex, bm = fo.u_exact_nl(m.x), fo.boundary_facets(m)
+        for sgn, beta in ((1.0, fo.BETA_NITSCHE), (-1.0, 0.0)):
+            R = fo.nl_residual(m, u, f, uex, bm, beta, sgn)
+            Rc = cp.nl_residual(d, m.x, m.conn, u, f, uex, bm, beta, sgn)
+            assert np.abs(R - Rc).max() <= 1e-13 * np.abs(R).max()
+            J = fo.nl_jacobian(m, u, bm, beta, sgn).tocsr()
+            rp, col = cp.pattern(d, m.n_vert, m.conn)
+            Jc = sp.csr_matrix((cp.nl_jacobian(d, m.x, m.conn, u, bm, beta, rp, col, sgn), col, rp), shape=J.shape)
+            assert abs(J - Jc).max() <= 1e-13 * abs(J).max()
+    m = fo.unit_square_mesh(40)
+    f = np.full(m.n_cell, 0.1)
+    ref = fo.nl_reference_cycle(m, f, fo.u_exact_nl(m.x), fo.boundary_facets(m), fo.ALPHA_NL)
+    out = cp.nl_cycle(2, m.x, m.conn, f, fo.u_exact_nl(m.x), fo.boundary_facets(m), fo.ALPHA_NL)
+    rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
+    assert rel(out["u"], ref["u"]) <= 1e-9 and rel(out["grad"], ref["grad"]) <= 1e-9
+    assert abs(out["J"] - ref["J"][0]) <= 1e-10 * abs(ref["J"][0]) and out["newton_its"] == ref["newton_its"]
+
+
 @pytest.mark.parametrize("d,n", [(2, 8), (3, 4)])
 def test_nl_oracle_consistency(d, n):
     m = fo.unit_square_mesh(n, 0.2) if d == 2 else fo.unit_cube_mesh(n, 0.2)
