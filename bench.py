@@ -938,7 +938,7 @@ def bench_config5(ctx, steps: int, n: int = 2236) -> dict:
            "n_dof": mesh.n_vert, "steps": steps, "ms_per_cycle": ms, "dofs_per_s": mesh.n_vert / (ms * 1e-3),
            "newton_linear_solves_per_cycle": per - 1, "cg_iterations_per_cycle": [i["iterations"] for i in infos[:per]],
            "J": J, "roofline": _roofline("k_spmv_sell<1,true>", spmv_algorithmic_bytes(nnz, mesh.n_vert), spmv_ms, ns,
-                                         stored=stored_bytes(dm.info, mesh.n_vert)),
+                                         stored=stored_bytes(dm.info, mesh.n_vert), traffic_key=f"spmv_sq{n}"),
            "check": check,
            "cpu_baseline": {"value": mesh.n_vert / t_cpu, "unit": "DOFs/s", "cores": int(out["threads"]), "kind": "port",
                             "sample": f"oracle/femo_oracle_c.c + oracle/c_port.py::nl_cycle: one whole cycle at n={n} (this configuration's own size, "

@@ -8,11 +8,14 @@ import numpy as np
 
 from femo_amd import engine as E
 from femo_amd.engine import Context, Vec
-from femo_amd.fea.mesh import createUnitCubeMesh
+from femo_amd.fea.mesh import createUnitCubeMesh, createUnitSquareMesh
 
 n3 = int(sys.argv[1]) if len(sys.argv) > 1 else 215
 ctx = Context(0)
-mesh = createUnitCubeMesh(n3)
+if len(sys.argv) > 2 and sys.argv[2] == "square":
+    mesh = createUnitSquareMesh(n3)               # the pattern (and SpMV traffic) of BASELINE config 5's n x n square
+else:
+    mesh = createUnitCubeMesh(n3)
 if len(sys.argv) > 2 and sys.argv[2] == "permute":
     mesh = mesh.permuted(seed=20240807)          # bench.py --permute
 dm = mesh.device(ctx)
