@@ -1851,7 +1851,8 @@ static int pc_setup_shared(femo_mesh* m) {
   std::vector<double> weight((size_t)F.nodes, 0.0);
   for (int64_t i = 0; i < F.nodes; ++i) {
     if (cnt[(size_t)(off_F + i)] >= 1.5) shared.push_back((int32_t)i);
-    if (mine[(size_t)(off_F + i)] != 0.0) weight[(size_t)i] = 1.0 / cnt[(size_t)(off_F + i)];
+    // (model communicator: the all-reduce of the classic loop's weighted dot is the identity, so the rank's share is the whole)
+    if (mine[(size_t)(off_F + i)] != 0.0) weight[(size_t)i] = ctx->model ? 1.0 : 1.0 / cnt[(size_t)(off_F + i)];
   }
   pc->n_shared = (int64_t)shared.size();
   auto upload_i32 = [&](int32_t** dst, const std::vector<int32_t>& v) -> int {
