@@ -1643,7 +1643,9 @@ int femo_pc_build(femo_mesh* m) {
   // (2-D) levels and running the lattice restrictions separately measure the same (72-75 ms per bench
   // cycle either way).  On partitioned meshes the bricks produce the finest level (exchanged sparsely,
   // pc_setup_shared) and the next one (summed densely); FEMO_BPX_FUSED overrides on one rank (tests, tuning).
-  pc->n_fused = ctx->nranks > 1 ? std::min(2, pc->n_levels - 1) : std::min(D == 3 ? 2 : 3, pc->n_levels - 1);
+  // (round 5: partitioned 2-D meshes fuse three levels like one rank does -- with two, level T-1 of the 1024^2 lattice of the
+  // 5 M-DOF square has 129^2 nodes, beyond what the single-workgroup coarse kernel keeps, and the merged loop was refused)
+  pc->n_fused = std::min(D == 3 ? 2 : 3, pc->n_levels - 1);
   if (const char* e = getenv("FEMO_BPX_FUSED"); e != nullptr && ctx->nranks == 1) pc->n_fused = std::max(0, std::min(std::min(D == 3 ? 2 : 3, pc->n_levels - 1), atoi(e)));
   {
     // second copy of the fused levels: the same layout as the first, right behind all levels
@@ -1790,7 +1792,7 @@ static int bricks_per_cu(int dim, int pf) {
 // rank touches (the layers along the partition interfaces).  Collective, once per mesh.  Two sets of lists:
 //   classic loop (femo_pc_apply): the finest level's shared nodes; the coarser fused levels travel whole;
 //   merged loop (femo_pc_merged_apply, round 5): shared / single-rank nodes of ALL brick-filled levels (femo_pc::d_mshared_idx).
-static bool merged_shape_ok(const femo_pc* pc);
+static bool merged_shape_ok(const femo_pc* pc, bool multi);
 static int pc_setup_shared(femo_mesh* m) {
   femo_pc* pc = m->pc;
   if (pc->shared_ready) return 0;
@@ -1860,7 +1862,7 @@ static int pc_setup_shared(femo_mesh* m) {
     if (!v.empty()) FEMO_HIP_CHECK(hipMemcpy(*dst, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     return 0;
   };
-  if (merged_shape_ok(pc)) {
+  if (merged_shape_ok(pc, true)) {
     FEMO_REQUIRE(n_all < (int64_t(1) << 31), "lattice too large for 32-bit node lists");
     std::vector<int32_t> msh, mint;
     const int64_t n_coarse_nodes = off_F;                     // levels T and L-1 lead the range
@@ -2121,10 +2123,13 @@ int femo_pc_begin(femo_mesh* m, const double* s, const uint8_t* mask) {
 
 // ---- merged BPX-PCG: host side ---------------------------------------------------------------------------------------
 // the shape the merged kernels are written for: two brick-fused levels, everything below level T-1 (and g_{T-1}) in LDS
-static bool merged_shape_ok(const femo_pc* pc) {
+// (one rank: exactly two fused levels -- the carriers' dense loops and the tile kernel cover T, L-1, L; N ranks: the node lists
+// are generic over the brick-filled levels, so the 2-D lattice's three fused levels work too: the level between T and the
+// tile kernel's three gets its correction from a k_lattice_prolong launch on the state)
+static bool merged_shape_ok(const femo_pc* pc, bool multi) {
   const int nl = pc->n_levels, nf = pc->n_fused;
   const int T = nl - 1 - nf;
-  if (nf != 2 || T < 1 || T >= FEMO_PC_MAX_LEVELS - 1) return false;
+  if (!(nf == 2 || (nf == 3 && multi && pc->dim == 2)) || T < 1 || T >= FEMO_PC_MAX_LEVELS - 1) return false;
   int64_t below = 0;
   for (int l = 0; l + 1 < T; ++l) below += pc->L[l].nodes;
   const int64_t lds = below * 2 * (int64_t)sizeof(double) + pc->L[T - 1].nodes * (int64_t)sizeof(double);
@@ -2135,7 +2140,7 @@ bool femo_pc_merged_ok(femo_mesh* m) {
   // FEMO_PCG_CLASSIC: A/B switch and the tests of the classic loop (read per solve, never per launch)
   if (femo_env_flag("FEMO_PCG_CLASSIC") || femo_env_flag("FEMO_BPX_DENSE_ALLREDUCE") || femo_env_flag("FEMO_BPX_UNFUSED_LATTICE")) return false;
   if (femo_pc_build(m) != 0) return false;
-  return merged_shape_ok(m->pc);
+  return merged_shape_ok(m->pc, m->ctx->nranks > 1);
 }
 
 int femo_pc_merged_collectives(const femo_mesh* m) { return m->ctx->nranks > 1 ? 1 : 0; }
@@ -2176,7 +2181,7 @@ int femo_pc_merged_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, c
   const hipStream_t st = ctx->stream;
   const int nl = pc->n_levels, nf = pc->n_fused;
   const int T = nl - 1 - nf;
-  FEMO_REQUIRE(merged_shape_ok(pc) && pc->gs != nullptr, "femo_pc_merged_apply: lattice shape not supported / begin not called");
+  FEMO_REQUIRE(merged_shape_ok(pc, ctx->nranks > 1) && pc->gs != nullptr, "femo_pc_merged_apply: lattice shape not supported / begin not called");
   LatticeLevel& F = pc->L[nl - 1];
   const Lat lat = make_lat(pc, F);
   const int par = pc->parity;
@@ -2265,6 +2270,10 @@ int femo_pc_merged_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, c
     pc->merged_lds_set = true;
   }
   hipLaunchKernelGGL(k_lattice_coarse_m, dim3(1 + n_carry), dim3(1024), lds_all, st, CL, pc->dim, done, mc);
+  for (int l = T; l <= nl - 4; ++l) {            // N ranks, 2-D (three fused levels): the level between T-1 and the tile kernel's three
+    LatticeLevel& Fi = pc->L[l];
+    hipLaunchKernelGGL(k_lattice_prolong, dim3(lat_grid(Fi.nodes)), dim3(256), 0, st, Fi.n[0], Fi.n[1], Fi.n[2], pc->L[l - 1].n[0], pc->L[l - 1].n[1], pc->L[l - 1].n[2], pc->dim, pc->L[l - 1].e, Fi.coef, GS(l), 0, Fi.e, (double*)nullptr, (const double*)nullptr, done);
+  }
   FineLevels FL;
   const LatticeLevel &Lcc = pc->L[nl - 4], &Lc = pc->L[nl - 3], &Lm = pc->L[nl - 2];
   for (int k = 0; k < 3; ++k) { FL.ncc[k] = Lcc.n[k]; FL.nc[k] = Lc.n[k]; FL.nm[k] = Lm.n[k]; FL.nf[k] = F.n[k]; }

@@ -617,9 +617,12 @@ def test_nonlinear_cycle_on_four_emulated_ranks():
                 sim.run()
                 g = np.asarray(sim.compute_totals('l2_functional', 'f')).ravel()
                 u = np.asarray(sim['u'])
-                its = [i["iterations"] for i in list(utils_hip.LAST_KSP_INFO) if i.get("thread") == me]
+                mine = [i for i in list(utils_hip.LAST_KSP_INFO) if i.get("thread") == me]
+                its = [i["iterations"] for i in mine]
+                loop_ar = sum(i.get("loop_allreduces", 0) for i in mine)
                 return dict(gid=L.vert_global[:L.n_owned], u=u[:L.n_owned], cells=L.cell_global[L.cell_owned], g=g[L.cell_owned],
-                            J=float(np.asarray(sim['l2_functional']).ravel()[0]), its=its, levels=mesh.device(ctx).pc_info()["levels"])
+                            J=float(np.asarray(sim['l2_functional']).ravel()[0]), its=its, loop_ar=loop_ar,
+                            levels=mesh.device(ctx).pc_info()["levels"])
             finally:
                 utils_hip.set_context(None, thread_local=True)
         del utils_hip.LAST_KSP_INFO[:]                      # (thread idents are recycled between the two runs)
@@ -638,5 +641,8 @@ def test_nonlinear_cycle_on_four_emulated_ranks():
         # the partitioned run is the one-rank algorithm: as many linear solves (Newton steps + the adjoint), the same counts
         assert len(r["its"]) == len(one["its"]) and all(abs(a - b) <= 1 for a, b in zip(r["its"], one["its"])), (r["its"], one["its"])
     assert len({tuple(r["its"]) for r in res}) == 1
+    # the MERGED loop runs on the partitioned 2-D lattice (round 5: three fused levels on N ranks too): one all-reduce per
+    # enqueued iteration, where the classic loop issues three
+    assert all(sum(r["its"]) <= r["loop_ar"] <= sum(r["its"]) + 8 * len(r["its"]) for r in res), [(r["its"], r["loop_ar"]) for r in res]
     assert np.abs(u - ref["u"]).max() < 1e-10 * np.abs(ref["u"]).max()
     assert np.abs(g - ref["grad"]).max() < 1e-10 * np.abs(ref["grad"]).max()
