@@ -1130,11 +1130,11 @@ struct MergedCarry {
   const double *p, *q;
   int64_t n;
   double* rr_partials;
-  double* gs_lvl[2];          // state of levels T and L-1
-  const double* h_lvl[2];     // this apply's accumulators of those levels
-  double* h_other[2];         // the other parity's accumulators of those levels: cleared here for the restriction after the next
-  const double* coef_lvl[2];
-  int64_t n_lvl[2];
+  // one rank: the brick-filled levels below the finest as ONE contiguous range of n_dense nodes (state gs_c, this apply's
+  // accumulators h_c, coefficients coef_c -- below); h_c_other: the other parity's accumulators, cleared here for the
+  // restriction after the next
+  double* h_c_other;
+  int64_t n_dense;
   double* lat_partials;
   double* gs_top;             // state of level T-1
   // N > 1 (round 5): the reduced buffer of this iteration [sums on the shared nodes of levels T, L-1, L | R h_T on level T-1 |
@@ -1235,17 +1235,12 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
       }
     }
     if (!mc.multi) {
-#pragma unroll
-      for (int l = 0; l < 2; ++l) {
-        double* gs = mc.gs_lvl[l];
-        const double* h = mc.h_lvl[l];
-        const double* cf = mc.coef_lvl[l];
-        for (int64_t i = (int64_t)b * 1024 + threadIdx.x; i < mc.n_lvl[l]; i += (int64_t)nc * 1024) {
-          const double g = gs[i] - alpha * h[i];
-          gs[i] = g;
-          mc.h_other[l][i] = 0.0;
-          lat += cf[i] * g * g;
-        }
+      // one rank: every brick-filled level but the finest, one contiguous range (two levels in 3-D, three in 2-D)
+      for (int64_t i = (int64_t)b * 1024 + threadIdx.x; i < mc.n_dense; i += (int64_t)nc * 1024) {
+        const double g = mc.gs_c[i] - alpha * mc.h_c[i];
+        mc.gs_c[i] = g;
+        mc.h_c_other[i] = 0.0;
+        lat += mc.coef_c[i] * g * g;
       }
     } else {
       for (int64_t i = (int64_t)b * 1024 + threadIdx.x; i < mc.n_shared; i += (int64_t)nc * 1024) {
@@ -2123,13 +2118,13 @@ int femo_pc_begin(femo_mesh* m, const double* s, const uint8_t* mask) {
 
 // ---- merged BPX-PCG: host side ---------------------------------------------------------------------------------------
 // the shape the merged kernels are written for: two brick-fused levels, everything below level T-1 (and g_{T-1}) in LDS
-// (one rank: exactly two fused levels -- the carriers' dense loops and the tile kernel cover T, L-1, L; N ranks: the node lists
-// are generic over the brick-filled levels, so the 2-D lattice's three fused levels work too: the level between T and the
-// tile kernel's three gets its correction from a k_lattice_prolong launch on the state)
+// (two fused levels in 3-D, three in 2-D: the carriers' loops and the node lists are generic over the brick-filled levels; in
+// 2-D the level between T-1 and the tile kernel's three gets its correction from a k_lattice_prolong launch on the state)
 static bool merged_shape_ok(const femo_pc* pc, bool multi) {
   const int nl = pc->n_levels, nf = pc->n_fused;
   const int T = nl - 1 - nf;
-  if (!(nf == 2 || (nf == 3 && multi && pc->dim == 2)) || T < 1 || T >= FEMO_PC_MAX_LEVELS - 1) return false;
+  (void)multi;
+  if (!(nf == 2 || (nf == 3 && pc->dim == 2)) || T < 1 || T >= FEMO_PC_MAX_LEVELS - 1) return false;
   int64_t below = 0;
   for (int l = 0; l + 1 < T; ++l) below += pc->L[l].nodes;
   const int64_t lds = below * 2 * (int64_t)sizeof(double) + pc->L[T - 1].nodes * (int64_t)sizeof(double);
@@ -2238,11 +2233,8 @@ int femo_pc_merged_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, c
   mc.nb_pq = V.nb_q[0]; mc.nb_pq2 = V.nb_q[1]; mc.pq_partials = V.Pq[0]; mc.pq_partials2 = V.Pq[1];
   mc.x = V.x; mc.r = V.r; mc.p = V.p; mc.q = V.q; mc.n = V.n;
   mc.rr_partials = pc->d_rr_partials; mc.lat_partials = pc->d_lat_partials;
-  for (int l = 0; l < 2; ++l) {
-    const int lev = T + l;
-    mc.gs_lvl[l] = GS(lev); mc.h_lvl[l] = H(lev, par); mc.coef_lvl[l] = pc->L[lev].coef; mc.n_lvl[l] = pc->L[lev].nodes;
-    mc.h_other[l] = H(lev, par ^ 1);
-  }
+  mc.h_c_other = H(T, par ^ 1);
+  mc.n_dense = hF - H(T, par);
   mc.gs_top = GS(T - 1);
   mc.buf = multi ? pc->d_mbuf : nullptr;
   mc.n_shared = multi ? pc->n_mshared : 0; mc.shared_idx = pc->d_mshared_idx;
