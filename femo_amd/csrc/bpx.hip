@@ -1150,6 +1150,7 @@ struct MergedCarry {
   int64_t n_top_buf;                // nodes of level T-1 (the dense part of the buffer)
   int dbg;                          // timing experiments (FEMO_TUNING builds): 1 = workgroup 0 returns early, 2 = the carriers do
   int64_t sep_off;                  // LDS offset (doubles) of the scratch of lattice_restrict3_sep, -1: the 27-tap restrictions
+  int flat;                         // 3-D, 1 <= levels below T-1 <= 4, scratch fits: the chain below level T-1 in ONE down and ONE up step (below)
 };
 
 __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int dim, const int32_t* __restrict__ done, MergedCarry mc) {
@@ -1302,6 +1303,105 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
   }
   lds_barrier();
   if (mc.dbg == 4) return;
+  if (mc.flat) {
+    // Round 5: the levels below T-1 are linear images of g_{T-1}: level T-1-k is its restriction with the hat of half-width 2^k
+    // per axis (R^k; clipping at the range ends commutes with the composition), and the correction on level T-1 is
+    // C g_{T-1} + sum_k (trilinear interpolation of C_k g_k from level T-1-k) (I^k).  So instead of a chain of 3 barriers per
+    // level down and one per level up (9 + 2 at the 13^3 -> 7^3 -> 4^3 lattices of C4: workgroup 0 is the critical path of an
+    // iteration at <= 1.3 M rows), ALL levels go through the three separable passes together and one pass builds e_{T-1}:
+    // 4 barriers.  Same operator, different association of the sums (the classic apply, which the oracle parity tests use,
+    // keeps the level-by-level form).
+    const int fx = L.n[top][0] + 1, fy = L.n[top][1] + 1, fz = L.n[top][2] + 1;
+    double cpre[4];
+#pragma unroll
+    for (int k = 1; k <= 4; ++k) cpre[k - 1] = (k <= top && tid < L.nodes[top - k]) ? L.coef[top - k][tid] : 0.0;
+    int64_t o = 0;
+    for (int k = 1; k <= top; ++k) {                                   // x
+      const int cx = L.n[top - k][0] + 1, w = 1 << k, cnt = cx * fy * fz;
+      const double inv = 1.0 / w;
+      double* t1 = sep + o;
+      for (int idx = tid; idx < cnt; idx += 1024) {
+        const int i = idx % cx, r = idx / cx, f0 = i << k;
+        const double* row = g_top_lds + r * fx;
+        double v = row[f0];
+        for (int j = 1; j < w; ++j) {
+          const double wt = 1.0 - j * inv;
+          if (f0 - j >= 0) v += wt * row[f0 - j];
+          if (f0 + j < fx) v += wt * row[f0 + j];
+        }
+        t1[idx] = v;
+      }
+      o += cnt;
+    }
+    lds_barrier();
+    int64_t o1 = 0, o2 = o;
+    for (int k = 1; k <= top; ++k) {                                   // y
+      const int cx = L.n[top - k][0] + 1, cy = L.n[top - k][1] + 1, w = 1 << k, cnt = cx * cy * fz;
+      const double inv = 1.0 / w;
+      const double* t1 = sep + o1;
+      double* t2 = sep + o2;
+      for (int idx = tid; idx < cnt; idx += 1024) {
+        const int i = idx % cx, r = idx / cx, j0 = r % cy, z = r / cy, f0 = j0 << k;
+        const double* col = t1 + (z * fy) * cx + i;
+        double v = col[f0 * cx];
+        for (int j = 1; j < w; ++j) {
+          const double wt = 1.0 - j * inv;
+          if (f0 - j >= 0) v += wt * col[(f0 - j) * cx];
+          if (f0 + j < fy) v += wt * col[(f0 + j) * cx];
+        }
+        t2[idx] = v;
+      }
+      o1 += cx * fy * fz; o2 += cnt;
+    }
+    lds_barrier();
+    o2 = o;
+    for (int k = 1; k <= top; ++k) {                                   // z; stores C g and adds C g^2
+      const int l = top - k, cx = L.n[l][0] + 1, cy = L.n[l][1] + 1, cz = L.n[l][2] + 1, w = 1 << k, cxy = cx * cy;
+      const double inv = 1.0 / w;
+      const double* t2 = sep + o2;
+      double* cg = coarse_lds + L.off[l];
+      for (int idx = tid; idx < cxy * cz; idx += 1024) {               // (<= 1024 nodes per level: at most one trip, idx == tid)
+        const int ij = idx % cxy, k0 = idx / cxy, f0 = k0 << k;
+        double v = t2[f0 * cxy + ij];
+        for (int j = 1; j < w; ++j) {
+          const double wt = 1.0 - j * inv;
+          if (f0 - j >= 0) v += wt * t2[(f0 - j) * cxy + ij];
+          if (f0 + j < fz) v += wt * t2[(f0 + j) * cxy + ij];
+        }
+        const double c = cpre[k - 1] * v;
+        dot += c * v;
+        cg[idx] = c;
+      }
+      o2 += cxy * fz;
+    }
+    lds_barrier();
+    if (mc.dbg == 6) return;
+#pragma unroll
+    for (int q = 0; q < TOPR; ++q) {
+      const int idx = tid + q * 1024;
+      if (idx < n_top) {
+        const int i = idx % fx, jk = idx / fx, j = jk % fy, kk = jk / fy;
+        double v = ct[q] * gt[q];
+        for (int k = 1; k <= top; ++k) {
+          const int l = top - k, cx = L.n[l][0] + 1, cy = L.n[l][1] + 1, w = 1 << k;
+          const double inv = 1.0 / w;
+          const double* cg = coarse_lds + L.off[l];
+          const int a0 = i >> k, a1 = j >> k, a2 = kk >> k;
+          const double t0 = (i & (w - 1)) * inv, t1 = (j & (w - 1)) * inv, t2 = (kk & (w - 1)) * inv;
+          const int b0 = min(a0 + 1, L.n[l][0]), b1 = min(a1 + 1, L.n[l][1]), b2 = min(a2 + 1, L.n[l][2]);
+          const double x00 = cg[(a2 * cy + a1) * cx + a0] * (1.0 - t0) + cg[(a2 * cy + a1) * cx + b0] * t0;
+          const double x10 = cg[(a2 * cy + b1) * cx + a0] * (1.0 - t0) + cg[(a2 * cy + b1) * cx + b0] * t0;
+          const double x01 = cg[(b2 * cy + a1) * cx + a0] * (1.0 - t0) + cg[(b2 * cy + a1) * cx + b0] * t0;
+          const double x11 = cg[(b2 * cy + b1) * cx + a0] * (1.0 - t0) + cg[(b2 * cy + b1) * cx + b0] * t0;
+          v += (x00 * (1.0 - t1) + x10 * t1) * (1.0 - t2) + (x01 * (1.0 - t1) + x11 * t1) * t2;
+        }
+        L.e[top][idx] = v;
+      }
+    }
+    const double tf = femo_block_sum<1024>(dot, red);
+    if (tid == 0) mc.S[MS_DOTC] = tf;
+    return;
+  }
   for (int l = top - 1; l >= 0; --l) {
     const int64_t total = L.nodes[l];
     const double* fine = l + 1 == top ? g_top_lds : coarse_lds + L.off[l + 1];
@@ -2247,6 +2347,7 @@ int femo_pc_merged_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, c
   // and the LDS-resident ones; behind the levels when it fits
   size_t lds_all = lds;
   mc.sep_off = -1;
+  mc.flat = 0;
   if (pc->dim == 3 && !femo_env_flag("FEMO_BPX_TAPS27")) {
     auto need = [&](const int* nc, const int* nfn, bool with_out) -> int64_t {
       const int64_t s1 = (int64_t)(nc[0] + 1) * (nfn[1] + 1) * (nfn[2] + 1), s2 = (int64_t)(nc[0] + 1) * (nc[1] + 1) * (nfn[2] + 1);
@@ -2254,8 +2355,24 @@ int femo_pc_merged_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, c
     };
     int64_t scratch = multi ? 0 : need(pc->L[T - 1].n, pc->L[T].n, true);
     for (int l = 0; l + 1 <= T - 1; ++l) scratch = std::max(scratch, need(pc->L[l].n, pc->L[l + 1].n, false));
+    // the flattened chain (k_lattice_coarse_m: mc.flat): x- and y-pass outputs of ALL levels below T-1 at once
+    int64_t flat_need = 0;
+    const int top = T - 1;
+    if (top >= 1 && top <= 4 && !femo_env_flag("FEMO_BPX_CHAIN")) {
+      const int* nt = pc->L[top].n;
+      for (int k = 1; k <= top; ++k) {
+        const int* nc = pc->L[top - k].n;
+        flat_need += (int64_t)(nc[0] + 1) * (nt[1] + 1) * (nt[2] + 1) + (int64_t)(nc[0] + 1) * (nc[1] + 1) * (nt[2] + 1);
+      }
+    }
     const int64_t off = (int64_t)(lds / sizeof(double));
+    mc.flat = 0;
+    if (flat_need > 0 && (off + std::max(scratch, flat_need)) * (int64_t)sizeof(double) <= 158 * 1024) {
+      mc.flat = 1;
+      scratch = std::max(scratch, flat_need);
+    }
     if ((off + scratch) * (int64_t)sizeof(double) <= 158 * 1024) { mc.sep_off = off; lds_all = (size_t)(off + scratch) * sizeof(double); }
+    else mc.flat = 0;
   }
   if (lds_all > 64 * 1024 && !pc->merged_lds_set) {
     FEMO_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_coarse_m, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
