@@ -163,6 +163,7 @@ PROTOTYPES = {
     "femo_dRdf_cell_apply": (C.c_int, [H, H, C.c_int, H, H, C.c_int]),
     "femo_mat_export_csr": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "femo_mat_diagonal": (C.c_int, [H, H]),
+    "femo_mat_prescale": (C.c_int, [H]),
     "femo_solve_cg": (C.c_int, [H, C.c_int, H, H, C.POINTER(SolverOpts), C.POINTER(SolveInfo)]),
     "femo_mat_pc_apply": (C.c_int, [H, H, H]),
     "femo_solve_bicgstab": (C.c_int, [H, C.c_int, H, H, C.POINTER(SolverOpts), C.POINTER(SolveInfo)]),

@@ -1632,7 +1632,10 @@ int femo_launch_system(femo_mesh* m, int pde, const double* params, const double
   // do useful work before it needs f; every other combination waits here.
   const bool defer = f_vec != nullptr && f_vec->h2d_pending && pde == FEMO_PDE_POISSON && rhs != nullptr && vals1 != nullptr &&
                      vals0 == nullptr && m->d_load != nullptr;
-  if (f_vec != nullptr && !defer) FEMO_TRY(femo_vec_await(f_vec));
+  // (the linear-Poisson pass reads f only for the load vector of a right-hand side: a matrices-only pass -- the early
+  // linearisation of round 5, StateOperation.solve_residual_equations -- runs under the upload without waiting for it)
+  const bool uses_f = rhs != nullptr || pde != FEMO_PDE_POISSON;
+  if (f_vec != nullptr && !defer && uses_f) FEMO_TRY(femo_vec_await(f_vec));
   FEMO_REQUIRE(rhs == nullptr || (u != nullptr && f != nullptr), "the Newton right-hand side needs u and f");
   FEMO_REQUIRE((diag1 == nullptr && rhs == nullptr) || bcmask == nullptr || bcval != nullptr, "missing Dirichlet values");
   const int64_t nb = row_blocks(m);

@@ -360,7 +360,7 @@ int femo_launch_system(femo_mesh* m, int pde, const double* params, const double
                        const double* aux, const uint8_t* bcmask, const double* bcval, double* diag0, double* vals0,
                        double* diag1, double* vals1, double* rhs, uint64_t f_uid = 0, uint64_t f_gen = 0,
                        const uint64_t* bc_rowmask = nullptr, const femo_vec* f_vec = nullptr, femo_mat* A_solve = nullptr);
-int femo_mat_prescale(femo_mat* A);        // solver.hip: S = diag^-1/2 and S A S now (what the first solve with A would do)
+// (femo_mat_prescale: public since ABI 8, include/femo_hip.h)
 int femo_launch_cell_expr(femo_mesh* m, int kind, const double* params, const double* in, double* out);
 int femo_launch_dRdf(femo_mesh* m, int pde, const double* params, const double* u,
                      const double* f, double* vals);

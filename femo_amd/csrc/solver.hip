@@ -1443,7 +1443,10 @@ static int solve_pcg_bpx_merged(femo_mat* A, const femo_vec* b, femo_vec* x, con
   return 0;
 }
 
-int femo_mat_prescale(femo_mat* A) { return ensure_scaled(A, false); }
+extern "C" int femo_mat_prescale(femo_mat* A) {
+  FEMO_REQUIRE(A != nullptr, "null argument");
+  return ensure_scaled(A, false);
+}
 
 // CG with the auxiliary-lattice BPX preconditioner.  Same scaled system, same stopping norm
 // (sqrt(rh.rh) = sqrt(r^T D^-1 r)) as the Jacobi path; scalars live on the device and are

@@ -611,6 +611,11 @@ class Mat:
         check(self.lib.femo_mat_spmv(self.handle, int(transpose), x.handle, y.handle))
         return y
 
+    def prescale(self) -> "Mat":
+        """S = diag^-1/2 and S A S now (`femo_mat_prescale`): what the first solve with this matrix would form first."""
+        check(self.lib.femo_mat_prescale(self.handle))
+        return self
+
     def export_csr(self):
         m = self.mesh
         rowptr = np.zeros(m.n_rows + 1, np.int64)

@@ -38,6 +38,7 @@ class PoissonResidual(Form):
     rank = 1
     pde_kind = _lib.PDE_POISSON
     is_linear = True      # Jacobian independent of u and f
+    constant_partials = True   # dR/du, dR/df and A depend on the mesh and the Dirichlet set only (StateOperation: early linearisation)
     is_symmetric = True
 
     def __init__(self, u: Function, f: Function):

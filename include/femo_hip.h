@@ -296,6 +296,11 @@ int femo_dRdf_apply(femo_mesh* mesh, const femo_vec* vals, int transpose,
 int femo_mat_export_csr(const femo_mat* A, int64_t* rowptr, int32_t* col, double* val);
 int femo_mat_diagonal(const femo_mat* A, femo_vec* d);
 
+/* S = diag(A)^-1/2 and the scaled copy S A S the Krylov loops iterate on, formed NOW instead of at the start of the first
+ * solve with A (collective on a partitioned mesh: the ghost entries of S come from their owners).  For callers that have
+ * idle time before the solve -- the operator layer assembles and scales the adjoint system of a linear form while the
+ * input of the forward solve is still on its way to the device (state_model.py:117-158 reordered, same work).           */
+int femo_mat_prescale(femo_mat* A);
 /* ---- linear solve (fea_dolfinx.py:192-222; utils_dolfinx.py:476-512) --------
  * Jacobi-preconditioned CG on A (transpose=0) or A^T (transpose=1).  The
  * reference factorises with MUMPS; CG+Jacobi is the BASELINE.json design.

@@ -520,3 +520,45 @@ def test_deferred_upload_of_f_matches_the_synchronous_cycle(ctx):
     assert rel(out["deferred"][0], out["sync"][0]) < 1e-11
     assert rel(out["deferred"][1], out["sync"][1]) < 1e-11
     assert abs(out["deferred"][2] - out["sync"][2]) < 1e-12 * abs(out["sync"][2])
+
+
+def test_early_linearisation_is_the_same_cycle(ctx):
+    """Round 5: for a form with constant partials (linear Poisson) StateOperation assembles dR/du, A, dR/df and S A S of the
+    adjoint system while f is still on its way to the device (solve_residual_equations), and compute_derivatives of that
+    cycle finds it done.  The same kernels on the same data, earlier: state, functional and gradient agree with the cycle that
+    linearises in compute_derivatives to the solver tolerance (not bitwise: the BPX brick restriction accumulates with fp64
+    atomics, so two runs of the SAME cycle already differ in the last bits); the assembled matrix is bit-identical, and a
+    compute_derivatives without a solve before it still assembles."""
+    from bench import build_problem, one_cycle, source_fields
+    from femo_amd import engine as E
+    from femo_amd.fea import utils_hip
+    from femo_amd.fea.mesh import createUnitCubeMesh
+    utils_hip.set_context(ctx)
+    mesh = createUnitCubeMesh(56, jitter=0.2)
+    fs = source_fields(mesh, 2)
+    os.environ.pop("FEMO_HOST_VERIFY", None)
+    out = {}
+    try:
+        for early in (True, False):
+            sim, fea = build_problem(mesh, device=False)
+            fea.early_linearisation = early
+            u0 = E.pinned_full(mesh.n_vert, 0.0)
+            one_cycle(sim, fea, E.pinned_array(fs[0]), u0)
+            g = one_cycle(sim, fea, E.pinned_array(fs[1]), u0)
+            op = [o for _, o in sim.ops if hasattr(o, 'apply_inverse_jacobian')][0]
+            out[early] = (np.array(E.host_wait(sim['u']), copy=True), np.array(E.host_wait(g), copy=True),
+                          float(np.asarray(sim['l2_functional']).ravel()[0]), op)
+            if early:
+                assert op._early_done is False                      # consumed by this cycle's compute_derivatives
+                # a second compute_derivatives without a solve in between takes the ordinary path (and gives the same matrix)
+                v1 = np.array(op.A.mat.export_csr()[2], copy=True)
+                op.compute_derivatives({'f': sim.values['f']}, {'u': sim.values['u']}, {})
+                assert np.array_equal(v1, op.A.mat.export_csr()[2])
+            utils_hip.clear_workspaces()
+    finally:
+        os.environ["FEMO_HOST_VERIFY"] = "1"
+    def rel(a, b):
+        return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    ru, rg = rel(out[True][0], out[False][0]), rel(out[True][1], out[False][1])
+    assert ru < 1e-10 and rg < 1e-10, (ru, rg)
+    assert abs(out[True][2] - out[False][2]) <= 1e-10 * abs(out[False][2])

@@ -38,8 +38,6 @@ def test_hermite_operator_matches_the_oracle(ctx, n, coarse):
     mask[fixed] = 1
     vals = prob._stiffness()
     A = prob.dev.coarse_matrix(vals, mask)
-    st = prob.dev.pc_state()
-    assert st["hermite_enabled"] and st["coarse_solve_ready"] and not st["fell_back_to_trilinear"], st
     A_ref = (M.P[M.c].T @ M.Kf @ M.P[M.c]).toarray()
     # (the oracle's P has zero rows on the fixed dofs, so the identity rows of Kf do not enter)
     assert A.shape == A_ref.shape
@@ -48,6 +46,8 @@ def test_hermite_operator_matches_the_oracle(ctx, n, coarse):
     rng = np.random.default_rng(3)
     r = rng.standard_normal(V0.n_dof)
     z = prob.dev.pc_apply(vals, Vec(ctx, V0.n_dof).set(r), Vec(ctx, V0.n_dof), mask).get()
+    st = prob.dev.pc_state()                # after the first apply: the coarse operator is factorised, nothing fell back
+    assert st["hermite_enabled"] and st["coarse_solve_ready"] and not st["fell_back_to_trilinear"], st
     z_ref = M.apply(r)
     assert np.abs(z - z_ref).max() <= 2e-5 * np.abs(z_ref).max()
     # symmetric positive definite: <r1, M^-1 r2> = <M^-1 r1, r2>, <r, M^-1 r> > 0
