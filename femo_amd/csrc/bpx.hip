@@ -62,10 +62,13 @@ struct femo_pc {
   // owned vertices sorted by brick (BRICK^dim bins of the finest lattice), for the restriction
   int64_t n_bricks = 0;
   int32_t* d_perm = nullptr;        // sorted position -> vertex
-  uint32_t* d_pk = nullptr;         // packed lattice coordinates, dim words per owned vertex (vertex order)
+  uint32_t* d_pk = nullptr;         // packed lattice coordinates, 8 B per owned vertex (vertex order)
   uint32_t* d_pk_sorted = nullptr;  // the same in sorted order
-  double* d_w_sorted = nullptr;     // 1/s (0 on pinned vertices) in sorted order, refreshed per solve
-  double* d_sinv = nullptr;         // 1/s in mesh order (same reciprocals), refreshed per solve
+  // 1/s ROUNDED TO SINGLE PRECISION, 0 on pinned vertices, refreshed per solve: in sorted order for the restriction and in mesh
+  // order for the prolongation (the same numbers, so S^-1 P and P^T S^-1 stay transposes; the rounding perturbs the
+  // preconditioner's scaling by 6e-8 relative, the solution not at all)
+  float* d_w_sorted = nullptr;
+  float* d_sinv = nullptr;
   double* d_dot_partials = nullptr; // per-block partials of g_L.e_L (2048)
   // partitioned meshes: only the finest-lattice nodes that several ranks touch are exchanged
   bool shared_ready = false;
@@ -161,15 +164,33 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_mesh(int64_t n_rows, La
   }
 }
 
-// Lattice coordinates of a vertex on the finest lattice, one 32-bit word per axis: bin << 20 | t,
-// t = fraction inside the bin in 20-bit fixed point.  Both transfers decode the same words, so P
-// and P^T stay exact transposes; the 1e-6 quantisation of the weights only perturbs the
-// preconditioner.  12 B per vertex instead of 24 B of coordinates.
+// Lattice coordinates of a vertex on the finest lattice, 8 bytes per vertex (femo_internal.h): 2-D two words
+// bin << 20 | 20-bit fraction, 3-D one 64-bit word of three fields bin << 12 | 12-bit fraction.  Both transfers decode the
+// same words, so P and P^T stay exact transposes; the quantisation of the weights only perturbs the preconditioner.
+// Rounds 1-4 spent 12 B per 3-D vertex (three 20-bit words); the 24 B of coordinates were never read by the transfers.
 constexpr int PK_BITS = FEMO_PK_BITS;
 constexpr uint32_t PK_MASK = (1u << PK_BITS) - 1u;
-__device__ __forceinline__ void unpack_coord(uint32_t w, int& bin, double& t) {
-  bin = (int)(w >> PK_BITS);
-  t = (double)(w & PK_MASK) * (1.0 / (double)(1u << PK_BITS));
+constexpr int PK3_BITS = FEMO_PK3_BITS, PK3_FIELD = FEMO_PK3_FIELD;
+constexpr uint32_t PK3_MASK = (1u << PK3_BITS) - 1u, PK3_FMASK = (1u << PK3_FIELD) - 1u;
+__device__ __forceinline__ uint2 load_pk(const uint32_t* __restrict__ pk, int64_t v) { return reinterpret_cast<const uint2*>(pk)[v]; }
+template <int D>
+__device__ __forceinline__ uint32_t pk_field(const uint2 w, int k) {
+  if constexpr (D == 2) return k == 0 ? w.x : w.y;
+  const uint64_t q = (uint64_t)w.x | ((uint64_t)w.y << 32);
+  return (uint32_t)(q >> (PK3_FIELD * k)) & PK3_FMASK;
+}
+template <int D>
+__device__ __forceinline__ void unpack_coord(const uint2 w, int k, int& bin, double& t) {
+  const uint32_t f = pk_field<D>(w, k);
+  if constexpr (D == 2) { bin = (int)(f >> PK_BITS); t = (double)(f & PK_MASK) * (1.0 / (double)(1u << PK_BITS)); }
+  else { bin = (int)(f >> PK3_BITS); t = (double)(f & PK3_MASK) * (1.0 / (double)(1u << PK3_BITS)); }
+}
+// the fraction alone, exact in fp32 (20 / 12 bits)
+template <int D>
+__device__ __forceinline__ float pk_fraction(const uint2 w, int k) {
+  const uint32_t f = pk_field<D>(w, k);
+  if constexpr (D == 2) return (float)(f & PK_MASK) * (1.0f / (float)(1u << PK_BITS));
+  return (float)(f & PK3_MASK) * (1.0f / (float)(1u << PK3_BITS));
 }
 
 // The restriction every iteration runs.  Vertices are sorted by brick (B^D bins of the finest
@@ -193,11 +214,11 @@ template <int D> struct Brick { static constexpr int B = D == 3 ? 4 : 8; static 
 // sinv[v] = 1/s of vertex v in mesh order: the mesh prolongation multiplies with the same rounded reciprocal (round 3: it
 // divided per vertex and iteration, ~12 of its ~100 instructions)
 __global__ void k_pc_weights(int64_t n, const int32_t* __restrict__ perm, const double* __restrict__ s,
-                             const uint8_t* __restrict__ mask, double* __restrict__ w, double* __restrict__ sinv) {
+                             const uint8_t* __restrict__ mask, float* __restrict__ w, float* __restrict__ sinv) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int32_t v = perm[i];
-    const double r = 1.0 / s[v];
-    w[i] = (mask != nullptr && mask[v]) ? 0.0 : r;
+    const float r = (mask != nullptr && mask[v]) ? 0.0f : (float)(1.0 / s[v]);
+    w[i] = r;
     sinv[v] = r;
   }
 }
@@ -288,12 +309,15 @@ __device__ __forceinline__ void brick_flush_level(const double* src, double* gl,
   }
 }
 
+#ifndef FEMO_BRICK_WAVES
+#define FEMO_BRICK_WAVES 4      // <= 128 VGPRs: four workgroups per CU instead of three (89 -> 84 us at C4)
+#endif
 template <int D, int PF>
-__global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks, const int64_t* __restrict__ brick_ptr,
+__global__ __launch_bounds__(FEMO_BLOCK, FEMO_BRICK_WAVES) void k_restrict_bricks(int64_t n_bricks, const int64_t* __restrict__ brick_ptr,
                                                                 const int32_t* __restrict__ brick_base, const uint32_t* __restrict__ bin_ptr,
                                                                 const int32_t* __restrict__ perm, const uint32_t* __restrict__ pk,
                                                                 Lat lat, const double* __restrict__ val,
-                                                                const double* __restrict__ w_sorted,
+                                                                const float* __restrict__ w_sorted,
                                                                 double* __restrict__ g, int n_fused, const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
   constexpr int B = Brick<D>::B, N1 = Brick<D>::N1, NLOC = Brick<D>::NLOC, NC = Brick<D>::NC;
@@ -333,16 +357,15 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
       p[q] = perm[entry(M, q, live)];
     }
   };
-  auto load_vals = [&](const Meta& M, const int32_t (&p)[PF], double (&v)[PF], double (&w)[PF], uint32_t (&k)[PF][D]) {
+  auto load_vals = [&](const Meta& M, const int32_t (&p)[PF], double (&v)[PF], float (&w)[PF], uint2 (&k)[PF]) {
 #pragma unroll
     for (int q = 0; q < PF; ++q) {
       bool live;
       const int64_t i = entry(M, q, live);
       v[q] = val[(int64_t)p[q]];
-      const double ws = w_sorted[i];
-      w[q] = live ? ws : 0.0;
-#pragma unroll
-      for (int d = 0; d < D; ++d) k[q][d] = pk[i * D + d];
+      const float ws = w_sorted[i];
+      w[q] = live ? ws : 0.0f;
+      k[q] = load_pk(pk, i);
     }
   };
   auto flush = [&](const double* nd, int b0, int b1, int b2) {
@@ -364,8 +387,9 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
   int32_t p0[PF], p1[PF];
   load_perm(M0, p0);
   load_perm(M1, p1);
-  double v0[PF], w0[PF];
-  uint32_t k0[PF][D];
+  double v0[PF];
+  float w0[PF];
+  uint2 k0[PF];
   load_vals(M0, p0, v0, w0, k0);
   int cur = 0;
   bool have_prev = false;
@@ -381,9 +405,9 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
 #pragma unroll
     for (int q = 0; q < PF; ++q) {
       const int j = tid + q * FEMO_BLOCK;
-      sval[j] = v0[q] * w0[q];
+      sval[j] = v0[q] * (double)w0[q];
 #pragma unroll
-      for (int d = 0; d < D; ++d) st[d][j] = (float)(k0[q][d] & PK_MASK) * (1.0f / (float)(1u << PK_BITS));
+      for (int d = 0; d < D; ++d) st[d][j] = pk_fraction<D>(k0[q], d);
     }
     lds_barrier();            // staging visible; wave 0 has finished the fused levels of the previous brick
     // (2) all global traffic of the iteration in one burst: the previous brick's atomics ...
@@ -392,8 +416,9 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
     const Meta M3 = load_meta(brick + 3 * G);
     int32_t p2[PF];
     load_perm(M2, p2);
-    double v1[PF], w1[PF];
-    uint32_t k1[PF][D];
+    double v1[PF];
+    float w1[PF];
+    uint2 k1[PF];
     load_vals(M1, p1, v1, w1, k1);
     // (3) LDS phases
     for (int64_t chunk = start; chunk < end; chunk += BRICK_CHUNK) {
@@ -401,9 +426,10 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
       if (chunk > start) {                        // bricks above BRICK_CHUNK vertices (rare): unpipelined passes
         lds_barrier();
         for (int64_t i = chunk + tid; i < chunk_end; i += FEMO_BLOCK) {
-          sval[i - chunk] = val[perm[i]] * w_sorted[i];
+          sval[i - chunk] = val[perm[i]] * (double)w_sorted[i];
+          const uint2 wk = load_pk(pk, i);
 #pragma unroll
-          for (int k = 0; k < D; ++k) st[k][i - chunk] = (float)(pk[i * D + k] & PK_MASK) * (1.0f / (float)(1u << PK_BITS));
+          for (int k = 0; k < D; ++k) st[k][i - chunk] = pk_fraction<D>(wk, k);
         }
         lds_barrier();
       }
@@ -469,8 +495,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_restrict_bricks(int64_t n_bricks
     for (int q = 0; q < PF; ++q) {
       p1[q] = p2[q];
       v0[q] = v1[q]; w0[q] = w1[q];
-#pragma unroll
-      for (int d = 0; d < D; ++d) k0[q][d] = k1[q][d];
+      k0[q] = k1[q];
     }
   }
   lds_barrier();
@@ -517,7 +542,7 @@ struct HaloFirst {
 };
 template <int D>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat lat, const uint32_t* __restrict__ pk,
-                                                             const double* __restrict__ rh, const double* __restrict__ sinv,
+                                                             const double* __restrict__ rh, const float* __restrict__ sinv,
                                                              const uint8_t* __restrict__ mask, const double* __restrict__ e,
                                                              double* __restrict__ out, int mode, int nb_dot,
                                                              const double* __restrict__ dot_partials, const double* __restrict__ dot_global,
@@ -596,31 +621,35 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat
     }
   }
   const int64_t n_walk = hf.n_verts > 0 ? hf.n_verts : n_rows;
-  for (int64_t w_i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; w_i < n_walk; w_i += (int64_t)gridDim.x * FEMO_BLOCK) {
+  // 36 B per vertex: r 8, packed coordinates 8, 1/s 4 (single precision, 0 on pinned vertices: the mask byte is not read),
+  // p 8 + 8.  Rounds 1-4: 45 B (12 B of coordinates, 1/s in double precision, the mask).
+  auto direction = [&](int64_t v) -> double {
+    const uint2 wk = load_pk(pk, v);
+    int i0[3] = {0, 0, 0};
+    double t[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < D; ++k) unpack_coord<D>(wk, k, i0[k], t[k]);
+    double sum = 0.0;
+#pragma unroll
+    for (int c = 0; c < (1 << D); ++c) {
+      double w = 1.0;
+      int ijk[3] = {i0[0], i0[1], i0[2]};
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const int bit = (c >> k) & 1;
+        w *= bit ? t[k] : 1.0 - t[k];
+        ijk[k] += bit;
+      }
+      sum += w * e[node_index(lat.n, ijk[0], ijk[1], ijk[2])];
+    }
+    const double z = rh[v] + sum * (double)sinv[v];          // the same rounded 1/s the restriction multiplies with (k_pc_weights)
+    return mode == 1 ? z + beta * out[v] : z;
+  };
+  const int64_t stride = (int64_t)gridDim.x * FEMO_BLOCK;
+  for (int64_t w_i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; w_i < n_walk; w_i += stride) {
     const int64_t v = hf.n_verts > 0 ? (int64_t)hf.verts[w_i] : w_i;
     if (hf.skip != nullptr && hf.skip[v]) continue;
-    double z = rh[v];
-    if (!(mask != nullptr && mask[v])) {
-      int i0[3] = {0, 0, 0};
-      double t[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-      for (int k = 0; k < D; ++k) unpack_coord(pk[v * D + k], i0[k], t[k]);
-      double sum = 0.0;
-#pragma unroll
-      for (int c = 0; c < (1 << D); ++c) {
-        double w = 1.0;
-        int ijk[3] = {i0[0], i0[1], i0[2]};
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-          const int bit = (c >> k) & 1;
-          w *= bit ? t[k] : 1.0 - t[k];
-          ijk[k] += bit;
-        }
-        sum += w * e[node_index(lat.n, ijk[0], ijk[1], ijk[2])];
-      }
-      z += sum * sinv[v];          // the same rounded 1/s the restriction multiplies with (k_pc_weights)
-    }
-    const double pv = mode == 1 ? z + beta * out[v] : z;
+    const double pv = direction(v);
     out[v] = pv;
     if (hf.n_verts > 0)
       for (int32_t q = hf.slot_ptr[w_i]; q < hf.slot_ptr[w_i + 1]; ++q) hf.send_buf[hf.slots[q]] = pv;
@@ -1790,8 +1819,8 @@ int femo_pc_build(femo_mesh* m) {
     pc->n_my_tiles = (int64_t)tiles.size();
     FEMO_TRY(upload(&pc->d_my_tiles, tiles));
   }
-  FEMO_HIP_CHECK(hipMalloc(&pc->d_w_sorted, std::max<size_t>(P.perm.size(), 1) * sizeof(double)));
-  FEMO_HIP_CHECK(hipMalloc(&pc->d_sinv, std::max<size_t>(P.perm.size(), 1) * sizeof(double)));
+  FEMO_HIP_CHECK(hipMalloc(&pc->d_w_sorted, std::max<size_t>(P.perm.size(), 1) * sizeof(float)));
+  FEMO_HIP_CHECK(hipMalloc(&pc->d_sinv, std::max<size_t>(P.perm.size(), 1) * sizeof(float)));
   FEMO_HIP_CHECK(hipMalloc(&pc->d_dot_partials, 2048 * sizeof(double)));
   m->pc = pc;
   return 0;
@@ -1816,7 +1845,8 @@ void femo_pc_destroy(femo_mesh* m) {
 __global__ void k_mark_touched(int64_t n, const double* __restrict__ g, double* __restrict__ t) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) t[i] = g[i] != 0.0 ? 1.0 : 0.0;
 }
-__global__ void k_fill_ones(int64_t n, double* __restrict__ a) {
+template <class T>
+__global__ void k_fill_ones(int64_t n, T* __restrict__ a) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a[i] = 1.0;
 }
 // buf = [g_fine[shared_idx] | g_coarse | *piggy]: a scalar of the caller rides along (r.r of the PCG loop)
@@ -1904,8 +1934,8 @@ static int pc_setup_shared(femo_mesh* m) {
   double *ones = nullptr, *tmp = nullptr;
   FEMO_HIP_CHECK(hipMalloc(&ones, std::max<int64_t>(m->n_vert, 1) * sizeof(double)));
   FEMO_HIP_CHECK(hipMalloc(&tmp, n_all * sizeof(double)));
-  hipLaunchKernelGGL(k_fill_ones, dim3(lat_grid(m->n_vert)), dim3(256), 0, st, m->n_vert, ones);
-  hipLaunchKernelGGL(k_fill_ones, dim3(lat_grid(m->n_rows)), dim3(256), 0, st, std::max<int64_t>(m->n_rows, 0), pc->d_w_sorted);
+  hipLaunchKernelGGL(k_fill_ones<double>, dim3(lat_grid(m->n_vert)), dim3(256), 0, st, m->n_vert, ones);
+  hipLaunchKernelGGL(k_fill_ones<float>, dim3(lat_grid(m->n_rows)), dim3(256), 0, st, std::max<int64_t>(m->n_rows, 0), pc->d_w_sorted);
   FEMO_HIP_CHECK(hipMemsetAsync(first, 0, n_all * sizeof(double), st));
   if (pc->n_bricks > 0) {
     const unsigned gb = (unsigned)std::min<int64_t>(pc->n_bricks, (int64_t)ctx->n_cu * bricks_per_cu(pc->dim, pc->brick_pf));

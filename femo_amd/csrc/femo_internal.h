@@ -187,7 +187,16 @@ struct femo_pc;   // auxiliary-lattice BPX hierarchy (bpx.hip)
 
 // host-side plan of that hierarchy (pc_plan.cpp)
 constexpr int FEMO_PC_MAX_LEVELS = 14;
-constexpr int FEMO_PK_BITS = 20;          // packed lattice coordinate: bin << 20 | 20-bit fraction
+// Packed lattice coordinates of a vertex on the finest lattice: 8 bytes per vertex in both dimensions.
+//   2-D: two 32-bit words (x, y), each bin << 20 | 20-bit fraction;
+//   3-D (round 5): ONE 64-bit word of three 21-bit fields (x in bits 0..20, y in 21..41, z in 42..62), each
+//        bin << 12 | 12-bit fraction (bins <= 511 per axis; the fraction's 2.4e-4 of a bin only perturbs the preconditioner --
+//        both transfers decode the same words, so P and P^T stay exact transposes).  Round 1-4 kept three 32-bit words.
+constexpr int FEMO_PK_BITS = 20;
+constexpr int FEMO_PK3_BITS = 12;
+constexpr int FEMO_PK3_FIELD = 21;
+constexpr int FEMO_PK_WORDS = 2;          // 32-bit words per vertex
+inline int femo_pk_frac_bits(int dim) { return dim == 3 ? FEMO_PK3_BITS : FEMO_PK_BITS; }
 struct FemoPcPlan {
   int dim = 0, n_levels = 0;
   int n[FEMO_PC_MAX_LEVELS][3] = {};      // bins per axis, coarsest level first
@@ -195,7 +204,7 @@ struct FemoPcPlan {
   double H[FEMO_PC_MAX_LEVELS] = {};
   double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
   int64_t n_bricks = 0;
-  std::vector<uint32_t> pk, pk_sorted;    // dim words per owned vertex, vertex order / sorted order
+  std::vector<uint32_t> pk, pk_sorted;    // FEMO_PK_WORDS words per owned vertex, vertex order / sorted order
   std::vector<int32_t> perm;              // sorted position -> vertex
   std::vector<int64_t> brick_ptr;         // n_bricks + 1
   std::vector<int32_t> brick_base;        // 3 per brick

@@ -47,34 +47,40 @@ int femo_pc_make_plan(int dim, int64_t n_rows, const double* x, const double* lo
   const int D = dim, B = D == 3 ? 4 : 8, L = best_lv - 1;
   const int* nF = P.n[L];
   for (int k = 0; k < D; ++k)
-    FEMO_REQUIRE(nF[k] < (1 << (32 - FEMO_PK_BITS)), "preconditioner lattice too fine for packed coordinates");
+    FEMO_REQUIRE(nF[k] < (D == 3 ? (1 << (FEMO_PK3_FIELD - FEMO_PK3_BITS)) : (1 << (32 - FEMO_PK_BITS))), "preconditioner lattice too fine for packed coordinates");
   int nbr[3] = {1, 1, 1};
   double inv_h[3] = {0, 0, 0};
   for (int k = 0; k < D; ++k) { nbr[k] = (nF[k] + B - 1) / B; inv_h[k] = nF[k] / ext[k]; }
   const int64_t n_all = (int64_t)nbr[0] * nbr[1] * nbr[2];
   FEMO_REQUIRE(n_all < (int64_t(1) << 24), "preconditioner lattice too fine");
   const int64_t nr = n_rows;
-  P.pk.assign((size_t)std::max<int64_t>(nr * D, 1), 0u);
+  constexpr int W = FEMO_PK_WORDS;
+  P.pk.assign((size_t)std::max<int64_t>(nr * W, 1), 0u);
   std::vector<int32_t> key((size_t)std::max<int64_t>(nr, 1));     // brick id * 64 + bin inside the brick
   std::vector<int64_t> count((size_t)n_all * 64 + 1, 0);
-  const uint32_t pk_mask = (1u << FEMO_PK_BITS) - 1u;
+  const int frac_bits = femo_pk_frac_bits(D);
+  const uint32_t pk_mask = (1u << frac_bits) - 1u;
   for (int64_t v = 0; v < nr; ++v) {
     int64_t brick = 0, bstride = 1;
     int local = 0, lstride = 1;
+    uint64_t word3 = 0;
     for (int k = 0; k < D; ++k) {
       const double gk = (x[v * D + k] - lo[k]) * inv_h[k];
       int b = (int)std::floor(gk);
       b = b < 0 ? 0 : (b > nF[k] - 1 ? nF[k] - 1 : b);
       double t = gk - b;
       t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
-      uint32_t tq = (uint32_t)(t * (double)(1u << FEMO_PK_BITS) + 0.5);
+      uint32_t tq = (uint32_t)(t * (double)(1u << frac_bits) + 0.5);
       if (tq > pk_mask) tq = pk_mask;
-      P.pk[v * D + k] = ((uint32_t)b << FEMO_PK_BITS) | tq;
+      const uint32_t field = ((uint32_t)b << frac_bits) | tq;
+      if (D == 3) word3 |= (uint64_t)field << (FEMO_PK3_FIELD * k);
+      else P.pk[v * W + k] = field;
       brick += (int64_t)(b / B) * bstride;
       bstride *= nbr[k];
       local += (b % B) * lstride;
       lstride *= B;
     }
+    if (D == 3) { P.pk[v * W] = (uint32_t)word3; P.pk[v * W + 1] = (uint32_t)(word3 >> 32); }
     key[v] = (int32_t)(brick * 64 + local);
     ++count[(size_t)key[v] + 1];
   }
@@ -92,13 +98,13 @@ int femo_pc_make_plan(int dim, int64_t n_rows, const double* x, const double* lo
   }
   P.n_bricks = (int64_t)P.brick_ptr.size() - 1;
   P.perm.assign((size_t)std::max<int64_t>(nr, 1), 0);
-  P.pk_sorted.assign((size_t)std::max<int64_t>(nr * D, 1), 0u);
+  P.pk_sorted.assign((size_t)std::max<int64_t>(nr * W, 1), 0u);
   {
     std::vector<int64_t> fill(count.begin(), count.end() - 1);
     for (int64_t v = 0; v < nr; ++v) {      // stable: vertices of a bin stay in index order
       const int64_t at = fill[(size_t)key[v]]++;
       P.perm[at] = (int32_t)v;
-      for (int k = 0; k < D; ++k) P.pk_sorted[at * D + k] = P.pk[v * D + k];
+      for (int k = 0; k < W; ++k) P.pk_sorted[at * W + k] = P.pk[v * W + k];
     }
   }
   if (P.brick_base.empty()) P.brick_base.assign(3, 0);
@@ -124,7 +130,7 @@ extern "C" int femo_pc_plan_host(int dim, int64_t n_rows, const double* x, const
   if (bins)
     for (int l = 0; l < P.n_levels; ++l)
       for (int k = 0; k < 3; ++k) bins[l * 3 + k] = P.n[l][k];
-  if (pk) std::copy(P.pk.begin(), P.pk.begin() + n_rows * dim, pk);
+  if (pk) std::copy(P.pk.begin(), P.pk.begin() + n_rows * FEMO_PK_WORDS, pk);
   if (perm) std::copy(P.perm.begin(), P.perm.begin() + n_rows, perm);
   if (brick_ptr) std::copy(P.brick_ptr.begin(), P.brick_ptr.end(), brick_ptr);
   if (brick_base) std::copy(P.brick_base.begin(), P.brick_base.begin() + 3 * P.n_bricks, brick_base);

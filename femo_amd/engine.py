@@ -779,7 +779,7 @@ def pc_plan_host(x: np.ndarray, lo=None, hi=None, n_vert_global: Optional[int] =
     check(lib.femo_pc_plan_host(d, n, _ptr(x), _ptr(lo), _ptr(hi), ng, C.byref(nl), None, C.byref(nb),
                                 None, None, None, None, None))
     bins = np.zeros((nl.value, 3), np.int32)
-    pk = np.zeros((n, d), np.uint32)
+    pk = np.zeros((n, 2), np.uint32)          # 8 bytes per vertex in both dimensions (femo_internal.h: FEMO_PK_WORDS)
     perm = np.zeros(n, np.int32)
     brick_ptr = np.zeros(nb.value + 1, np.int64)
     brick_base = np.zeros((max(nb.value, 1), 3), np.int32)

@@ -233,7 +233,8 @@ int femo_topology_build_host(int tdim, int64_t n_vert, int64_t n_rows, int64_t n
 
 /* Host-only plan of the BPX preconditioner lattice for `n_rows` owned vertices (no GPU touched; CPU
  * test-suite): levels and bins per axis (bins[3*l + k], coarsest level first), packed lattice
- * coordinates pk[n_rows*dim] (bin << 20 | 20-bit fraction), the (brick, bin) sort perm[n_rows] with
+ * coordinates pk[n_rows*2] (8 B per vertex; 2-D: two words bin << 20 | 20-bit fraction, 3-D: one 64-bit word of three
+ * 21-bit fields bin << 12 | 12-bit fraction), the (brick, bin) sort perm[n_rows] with
  * brick_ptr[n_bricks+1], brick_base[3*n_bricks], bin_ptr[65*n_bricks].  Array arguments may be NULL
  * (first call: sizes).                                                                           */
 int femo_pc_plan_host(int dim, int64_t n_rows, const double* x, const double* lo, const double* hi,

@@ -6,7 +6,8 @@ bench.py) may import this, as the checker of ``femo_amd/csrc/bpx.hip``.
 The preconditioner is this repository's own design (the reference factorises with MUMPS,
 ``femo/fea/utils_dolfinx.py:476-512``; BASELINE.json asks for CG), so there is nothing in
 /root/reference to pin it against.  What is checked instead: (1) the HIP kernels apply exactly the
-operator written down here -- lattice choice, 20-bit packed coordinates, keep rule, level weights,
+operator written down here -- lattice choice, packed coordinates (20-bit fractions in 2-D, 12-bit in 3-D), single-precision
+1/s in the mesh transfers, keep rule, level weights,
 nested transfers -- to rounding error (tests/test_gpu_bpx.py), (2) the operator is symmetric
 positive definite and PCG with it reaches the direct solution in a mesh-independent number of
 iterations (tests/test_oracle_bpx.py).
@@ -26,7 +27,20 @@ import scipy.sparse as sp
 
 THETA = 0.6
 KEEP_FRACTION = 0.3
-PK_BITS = 20
+PK_BITS = 20            # 2-D: two 32-bit words per vertex, bin << 20 | 20-bit fraction
+PK3_BITS = 12           # 3-D (round 5): one 64-bit word, three 21-bit fields bin << 12 | 12-bit fraction (femo_internal.h)
+
+
+def pk_bits(dim: int) -> int:
+    return PK3_BITS if dim == 3 else PK_BITS
+
+
+def single_precision_scaling(diag: np.ndarray) -> np.ndarray:
+    """tau = s fl32(1/s), s = 1/sqrt(diag): the device works in the scaled variables S A S and carries 1/s of the two mesh
+    transfers in SINGLE precision (k_pc_weights; the same rounded number in P and P^T, so the operator stays symmetric).  In
+    the original variables the lattice part of M^-1 is T P C P^T T with T = diag(tau) = I + O(6e-8)."""
+    s = 1.0 / np.sqrt(np.asarray(diag, float))
+    return s * (1.0 / s).astype(np.float32).astype(np.float64)
 
 
 def choose_lattice(lo: np.ndarray, hi: np.ndarray, n_vert_global: int, spacing: float = 2.0
@@ -56,9 +70,10 @@ def _locate(x: np.ndarray, lo: np.ndarray, hi: np.ndarray, n: np.ndarray, quanti
     g = (x - lo) * (n / (hi - lo))
     b = np.clip(np.floor(g).astype(np.int64), 0, n - 1)
     t = np.clip(g - b, 0.0, 1.0)
-    if quantise:                                   # the packed 20-bit fractions both HIP transfers decode
-        tq = np.minimum(np.floor(t * float(1 << PK_BITS) + 0.5), float((1 << PK_BITS) - 1))
-        t = tq / float(1 << PK_BITS)
+    if quantise:                                   # the packed 20-bit (3-D: 12-bit) fractions both HIP transfers decode
+        bits = pk_bits(x.shape[1])
+        tq = np.minimum(np.floor(t * float(1 << bits) + 0.5), float((1 << bits) - 1))
+        t = tq / float(1 << bits)
     return b, t
 
 
@@ -125,7 +140,8 @@ class BPX:
         P_exact = interpolation(x, self.lo, self.hi, nL, quantise=False)
         wf, wd = self.reduce(P_exact.T @ free), self.reduce(P_exact.T @ (1.0 - free))
         keep = (wf > 0.0) & (wd <= KEEP_FRACTION * (wf + wd))
-        self.P = (sp.diags(free) @ interpolation(x, self.lo, self.hi, nL, quantise=True)).tocsr()
+        self.tau = single_precision_scaling(diag)
+        self.P = (sp.diags(free * self.tau) @ interpolation(x, self.lo, self.hi, nL, quantise=True)).tocsr()
         self.I = [lattice_interpolation(self.bins[l]) for l in range(len(self.bins) - 1)]   # level l -> l+1
         self.coef = [None] * len(self.bins)
         keep_l = keep

@@ -247,7 +247,8 @@ int oc_pcg_jacobi(int64_t n, const int64_t* rowptr, const int32_t* col, const do
 
 /* ---- auxiliary-lattice BPX preconditioner (oracle/bpx_oracle.py in C/OpenMP) -------------
  * M^-1 = D^-1 + theta sum_l P_l C_l P_l^T; nested multilinear lattices over the bounding box,
- * 20-bit quantised vertex fractions, pinned vertices masked, lattice nodes on the pinned
+ * quantised vertex fractions (20 bits in 2-D, 12 in 3-D), single-precision 1/s in the mesh transfers (tau below), pinned
+ * vertices masked, lattice nodes on the pinned
  * boundary dropped (30 % rule on the finest level, injection to the coarser ones).          */
 #define OC_MAX_LEVELS 14
 typedef struct {
@@ -415,9 +416,11 @@ oc_bpx* oc_bpx_create(int d, int64_t n_vert, const double* x, const uint8_t* pin
   }
 #pragma omp parallel for schedule(static)
   for (int64_t v = 0; v < n_vert * d; ++v) {
-    double tq = floor(B->t[v] * 1048576.0 + 0.5);
-    if (tq > 1048575.0) tq = 1048575.0;
-    B->t[v] = tq / 1048576.0;
+    /* packed fractions of the device: 20 bits in 2-D, 12 bits in 3-D (femo_internal.h, round 5) */
+    const double q = d == 3 ? 4096.0 : 1048576.0;
+    double tq = floor(B->t[v] * q + 0.5);
+    if (tq > q - 1.0) tq = q - 1.0;
+    B->t[v] = tq / q;
   }
   return B;
 }
@@ -425,9 +428,20 @@ oc_bpx* oc_bpx_create(int d, int64_t n_vert, const double* x, const uint8_t* pin
 int oc_bpx_levels(const oc_bpx* B) { return B->n_levels; }
 
 /* z = dinv r + P (sum_l ...) P^T r */
+/* tau = s fl32(1/s), s = 1/sqrt(diag): the device carries 1/s of the two mesh transfers in single precision
+ * (bpx_oracle.py::single_precision_scaling) */
+static inline double bpx_tau(double dinv) {
+  const double s = 1.0 / sqrt(1.0 / dinv);
+  return s * (double)(float)(1.0 / s);
+}
+
 void oc_bpx_apply(oc_bpx* B, const double* dinv, const double* r, double* z) {
   const int L = B->n_levels - 1, d = B->dim;
-  bpx_restrict_mesh(B, r, 0, 1, B->g[L]);
+  double* rt = (double*)malloc(B->n_vert * sizeof(double));
+#pragma omp parallel for schedule(static)
+  for (int64_t v = 0; v < B->n_vert; ++v) rt[v] = bpx_tau(dinv[v]) * r[v];
+  bpx_restrict_mesh(B, rt, 0, 1, B->g[L]);
+  free(rt);
   for (int l = L - 1; l >= 0; --l) bpx_lattice_restrict(B, l);
   for (int l = 0; l <= L; ++l) bpx_lattice_prolong(B, l);
   const double* e = B->e[L];
@@ -446,7 +460,7 @@ void oc_bpx_apply(oc_bpx* B, const double* dinv, const double* r, double* z) {
         }
         sum += w * e[node_id(B->n[L], ijk[0], ijk[1], ijk[2])];
       }
-      zz += sum;
+      zz += bpx_tau(dinv[v]) * sum;
     }
     z[v] = zz;
   }

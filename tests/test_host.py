@@ -166,8 +166,19 @@ def test_pc_plan_host_matches_the_oracle(d, n, jit):
     assert P["levels"] == len(bins) and np.array_equal(P["bins"], np.array(bins))
     nF = bins[-1]
     b, t = bo._locate(m.x, lo, hi, nF, quantise=True)
-    assert np.array_equal(P["pk"] >> 20, b.astype(np.uint32))
-    assert np.array_equal((P["pk"] & 0xFFFFF).astype(np.float64) / (1 << 20), t)
+    # 8 bytes per vertex: 2-D two words bin << 20 | fraction; 3-D one 64-bit word of three 21-bit fields bin << 12 | fraction
+    pk = P["pk"]
+    assert pk.shape == (m.n_vert, 2) and pk.dtype == np.uint32
+    if d == 2:
+        fields, bits = pk.astype(np.uint64), 20
+    else:
+        word = pk[:, 0].astype(np.uint64) | (pk[:, 1].astype(np.uint64) << np.uint64(32))
+        fields = np.stack([(word >> np.uint64(21 * k)) & np.uint64((1 << 21) - 1) for k in range(3)], axis=1)
+        bits = 12
+        assert not np.any(word >> np.uint64(63))
+    assert bits == bo.pk_bits(d)
+    assert np.array_equal(fields >> np.uint64(bits), b.astype(np.uint64))
+    assert np.array_equal((fields & np.uint64((1 << bits) - 1)).astype(np.float64) / (1 << bits), t)
     # the sort: a permutation; every brick / bin range holds exactly the vertices whose bin says so
     perm = P["perm"]
     assert np.array_equal(np.sort(perm), np.arange(m.n_vert))
