@@ -66,6 +66,7 @@ inline bool femo_env_flag(const char* name) { return getenv(name) != nullptr; }
 constexpr int FEMO_WAVE = 64;            // gfx950 wavefront
 constexpr int FEMO_BLOCK = 256;          // 4 waves = 4 SELL slices per workgroup
 constexpr int FEMO_MAX_PARTIALS = 2048;  // persistent reduction grids: 256 CUs x 8
+constexpr int64_t FEMO_LLC_MATRIX_BYTES = 200ll << 20;   // SELL values up to this size are read with ordinary loads (they stay in the 256 MB Infinity Cache)
 constexpr int FEMO_NSCAL = 32;           // device scalars of the CG recurrence
 constexpr int FEMO_PARTIAL_SLOTS = 12;   // slots of FEMO_MAX_PARTIALS per-block partials each (femo_ctx::d_partials)
 constexpr int FEMO_STAGE_SLOTS = 4;      // pinned staging slots per context (8 MiB each)

@@ -44,6 +44,17 @@ __device__ __forceinline__ int2 nt_load2(const int2* p) {
   const femo_v2i v = __builtin_nontemporal_load(reinterpret_cast<const femo_v2i*>(p));
   return make_int2(v.x, v.y);
 }
+// NT = false (round 5): ordinary loads for operators whose stored values fit the 256 MB Infinity Cache -- they are read again
+// 28 times per solve, and the streaming hint kept them from staying there (1.03 M rows: 27.6 -> 21.0 us per product; at
+// 10 M rows, 1.4 GB of values, the hint is worth 2 %: launch_spmv picks by size)
+template <bool NT> __device__ __forceinline__ double2 mat_load2(const double2* p) {
+  if constexpr (NT) return nt_load2(p);
+  else { const femo_v2d v = *reinterpret_cast<const femo_v2d*>(p); return make_double2(v.x, v.y); }
+}
+template <bool NT> __device__ __forceinline__ int mat_load(const int* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
 
 template <int NP, bool NT>
 __device__ __forceinline__ double row_pairs(const double2* __restrict__ v2, const int2* __restrict__ c2,
@@ -96,15 +107,15 @@ __device__ __forceinline__ double row_sum(int npair, const double2* __restrict__
 
 // Short slice: the columns as 16-bit deltas from the row, two per 4-byte word (one global_load_dword per pair and lane
 // instead of a dwordx2)
-template <int NP>
+template <int NP, bool NT>
 __device__ __forceinline__ double row_pairs_short(const double2* __restrict__ v2, const int* __restrict__ c16,
                                                   const double* __restrict__ xrow, double acc) {
   double2 a[NP];
   int j[NP];
 #pragma unroll
   for (int m = 0; m < NP; ++m) {
-    a[m] = nt_load2(&v2[m * 64]);
-    j[m] = __builtin_nontemporal_load(&c16[m * 64]);
+    a[m] = mat_load2<NT>(&v2[m * 64]);
+    j[m] = mat_load<NT>(&c16[m * 64]);
   }
   double xv[2 * NP];
 #pragma unroll
@@ -120,34 +131,35 @@ __device__ __forceinline__ double row_pairs_short(const double2* __restrict__ v2
   return acc;
 }
 
+template <bool NT>
 __device__ __forceinline__ double row_sum_short(int npair, const double2* __restrict__ v2, const int* __restrict__ c16,
                                                 const double* __restrict__ xrow, double acc) {
   while (npair > 8) {
-    acc = row_pairs_short<8>(v2, c16, xrow, acc);
+    acc = row_pairs_short<8, NT>(v2, c16, xrow, acc);
     v2 += 8 * 64; c16 += 8 * 64; npair -= 8;
   }
   switch (npair) {  // wave-uniform
-    case 8: return row_pairs_short<8>(v2, c16, xrow, acc);
-    case 7: return row_pairs_short<7>(v2, c16, xrow, acc);
-    case 6: return row_pairs_short<6>(v2, c16, xrow, acc);
-    case 5: return row_pairs_short<5>(v2, c16, xrow, acc);
-    case 4: return row_pairs_short<4>(v2, c16, xrow, acc);
-    case 3: return row_pairs_short<3>(v2, c16, xrow, acc);
-    case 2: return row_pairs_short<2>(v2, c16, xrow, acc);
-    case 1: return row_pairs_short<1>(v2, c16, xrow, acc);
+    case 8: return row_pairs_short<8, NT>(v2, c16, xrow, acc);
+    case 7: return row_pairs_short<7, NT>(v2, c16, xrow, acc);
+    case 6: return row_pairs_short<6, NT>(v2, c16, xrow, acc);
+    case 5: return row_pairs_short<5, NT>(v2, c16, xrow, acc);
+    case 4: return row_pairs_short<4, NT>(v2, c16, xrow, acc);
+    case 3: return row_pairs_short<3, NT>(v2, c16, xrow, acc);
+    case 2: return row_pairs_short<2, NT>(v2, c16, xrow, acc);
+    case 1: return row_pairs_short<1, NT>(v2, c16, xrow, acc);
     default: return acc;
   }
 }
 
 // Regular slice: column k of lane l is row + delta[k]; x is read as 64 consecutive
 // doubles per k (one coalesced 512-B load), no column indices are fetched.
-template <int NP>
+template <int NP, bool NT>
 __device__ __forceinline__ double row_pairs_regular(const double2* __restrict__ v2, const int32_t* __restrict__ delta,
                                                     const double* __restrict__ xrow, double acc) {
   double2 a[NP];
 #pragma unroll
   for (int m = 0; m < NP; ++m) {
-    a[m] = nt_load2(&v2[m * 64]);
+    a[m] = mat_load2<NT>(&v2[m * 64]);
   }
   double xv[2 * NP];
 #pragma unroll
@@ -163,21 +175,22 @@ __device__ __forceinline__ double row_pairs_regular(const double2* __restrict__ 
   return acc;
 }
 
+template <bool NT>
 __device__ __forceinline__ double row_sum_regular(int npair, const double2* __restrict__ v2, const int32_t* __restrict__ delta,
                                                   const double* __restrict__ xrow, double acc) {
   while (npair > 8) {
-    acc = row_pairs_regular<8>(v2, delta, xrow, acc);
+    acc = row_pairs_regular<8, NT>(v2, delta, xrow, acc);
     v2 += 8 * 64; delta += 16; npair -= 8;
   }
   switch (npair) {  // wave-uniform
-    case 8: return row_pairs_regular<8>(v2, delta, xrow, acc);
-    case 7: return row_pairs_regular<7>(v2, delta, xrow, acc);
-    case 6: return row_pairs_regular<6>(v2, delta, xrow, acc);
-    case 5: return row_pairs_regular<5>(v2, delta, xrow, acc);
-    case 4: return row_pairs_regular<4>(v2, delta, xrow, acc);
-    case 3: return row_pairs_regular<3>(v2, delta, xrow, acc);
-    case 2: return row_pairs_regular<2>(v2, delta, xrow, acc);
-    case 1: return row_pairs_regular<1>(v2, delta, xrow, acc);
+    case 8: return row_pairs_regular<8, NT>(v2, delta, xrow, acc);
+    case 7: return row_pairs_regular<7, NT>(v2, delta, xrow, acc);
+    case 6: return row_pairs_regular<6, NT>(v2, delta, xrow, acc);
+    case 5: return row_pairs_regular<5, NT>(v2, delta, xrow, acc);
+    case 4: return row_pairs_regular<4, NT>(v2, delta, xrow, acc);
+    case 3: return row_pairs_regular<3, NT>(v2, delta, xrow, acc);
+    case 2: return row_pairs_regular<2, NT>(v2, delta, xrow, acc);
+    case 1: return row_pairs_regular<1, NT>(v2, delta, xrow, acc);
     default: return acc;
   }
 }
@@ -185,7 +198,7 @@ __device__ __forceinline__ double row_sum_regular(int npair, const double2* __re
 // DOT: 0 none; 1 partial d.Ax into partials[block] (d = dvec or x); 2 additionally partial x.x,
 // 3 additionally partial Ax.Ax, into the next slot; 4 (merged BPX-PCG): x.Ax, Ax.Ax and dvec.Ax into three
 // consecutive slots (p.q, q.q, r.q: everything the single all-reduce of an iteration carries besides the lattice)
-template <int DOT, bool UNIT>
+template <int DOT, bool UNIT, bool NT = true>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_spmv_sell(
     int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ mptr,
     const int32_t* __restrict__ cols, const int16_t* __restrict__ cols16, const int32_t* __restrict__ sdelta, int sdelta_stride,
@@ -218,13 +231,13 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_spmv_sell(
     const double2* __restrict__ v2 = reinterpret_cast<const double2*>(vals + base) + lane;
     const int32_t* __restrict__ dl = sdelta + slice * sdelta_stride;
     if (dl[0] != INT32_MIN) {  // wave-uniform (scalar load)
-      acc = row_sum_regular(npair, v2, dl, x + row, acc);
+      acc = row_sum_regular<NT>(npair, v2, dl, x + row, acc);
     } else if (dl[1] == 1) {   // 16-bit column deltas (the clamped row of a lane beyond n_rows still addresses valid entries)
       const int* __restrict__ c16 = reinterpret_cast<const int*>(cols16) + (base >> 1) + lane;
-      acc = row_sum_short(npair, v2, c16, x + row, acc);
+      acc = row_sum_short<NT>(npair, v2, c16, x + row, acc);
     } else {
       const int2* __restrict__ c2 = reinterpret_cast<const int2*>(cols + base) + lane;
-      acc = row_sum<true>(npair, v2, c2, x, acc);
+      acc = row_sum<NT>(npair, v2, c2, x, acc);
     }
     if (row < n_rows) {
       y[row] = acc;
@@ -868,13 +881,21 @@ static int launch_spmv(const femo_mat* A, const double* vals, const double* x, d
   }
   hipStream_t st = stream ? stream : m->ctx->stream;
 #define FEMO_SPMV_ARGS m->n_rows, m->n_slices, m->d_mptr, m->d_cols, m->d_cols16, m->d_sdelta, m->sdelta_stride, vals, A->d_diag, x, y, partials, done, slice_list, n_list, dvec
-  if (partials && unit && dot3) hipLaunchKernelGGL((k_spmv_sell<4, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
-  else if (partials && unit && dot_yy) hipLaunchKernelGGL((k_spmv_sell<3, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
-  else if (partials && unit && dot2) hipLaunchKernelGGL((k_spmv_sell<2, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
-  else if (partials && unit) hipLaunchKernelGGL((k_spmv_sell<1, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
-  else if (partials) hipLaunchKernelGGL((k_spmv_sell<1, false>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
-  else if (unit) hipLaunchKernelGGL((k_spmv_sell<0, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
-  else hipLaunchKernelGGL((k_spmv_sell<0, false>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);
+  // streaming hint on the matrix loads only where the stored values cannot stay in the Infinity Cache between two products
+  const bool nt = (int64_t)m->sell_entries * (int64_t)sizeof(double) > FEMO_LLC_MATRIX_BYTES;
+#define FEMO_SPMV_LAUNCH(DOT, UNIT)                                                                                     \
+  do {                                                                                                                  \
+    if (nt) hipLaunchKernelGGL((k_spmv_sell<DOT, UNIT, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);        \
+    else hipLaunchKernelGGL((k_spmv_sell<DOT, UNIT, false>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);          \
+  } while (0)
+  if (partials && unit && dot3) FEMO_SPMV_LAUNCH(4, true);
+  else if (partials && unit && dot_yy) FEMO_SPMV_LAUNCH(3, true);
+  else if (partials && unit && dot2) FEMO_SPMV_LAUNCH(2, true);
+  else if (partials && unit) FEMO_SPMV_LAUNCH(1, true);
+  else if (partials) FEMO_SPMV_LAUNCH(1, false);
+  else if (unit) FEMO_SPMV_LAUNCH(0, true);
+  else FEMO_SPMV_LAUNCH(0, false);
+#undef FEMO_SPMV_LAUNCH
 #undef FEMO_SPMV_ARGS
   FEMO_HIP_CHECK(hipGetLastError());
   return 0;

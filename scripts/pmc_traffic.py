@@ -46,18 +46,20 @@ if "--also" in args:
     also, args = args[k + 1:], args[:k]
 for tag, path in zip(("n215", "n215_permute"), args):
     t = table(path)
-    spmv = t.get("k_spmv_sell<1, true>", {})
+    spmv_name = next((k for k in t if k.startswith("k_spmv_sell<1, true")), "k_spmv_sell<1, true>")   # (<1, true, NT> since round 5)
+    spmv = t.get(spmv_name, {})
     key = "spmv_" + tag.replace("_permute", "_permuted")
     e = entry(spmv)
     out[key] = e["bytes_2F_plus_W"]
     out[key + "_fetch_KiB"], out[key + "_write_KiB"] = e["fetch_KiB"], e["write_KiB"]
     out["other_kernels_" + tag] = {k: entry(c) for k, c in t.items()
-                                   if k != "k_spmv_sell<1, true>" and ("FETCH_SIZE" in c) and
+                                   if k != spmv_name and ("FETCH_SIZE" in c) and
                                    any(s in k for s in ("poisson_system", "p1_row_walk", "restrict_bricks", "prolong_mesh", "pcg_xr", "lattice_prolong3", "lattice_coarse_m", "k_spmv_sell<0", "k_vec_diff", "k_scale_sell"))}
 for spec in also:
     key, rest = spec.split("=", 1)
     path, kern = rest.split(":", 1)
-    e = entry(table(path).get(kern, {}))
+    tb = table(path)
+    e = entry(tb.get(kern, tb.get(next((k for k in tb if k.startswith(kern.rstrip(">"))), kern), {})))
     if e["fetch_KiB"] > 0:
         out[key] = e["bytes_2F_plus_W"]
         out[key + "_fetch_KiB"], out[key + "_write_KiB"] = e["fetch_KiB"], e["write_KiB"]

@@ -17,7 +17,7 @@ marks = [i for i, e in enumerate(ev) if marker in e[2]]
 i0, i1 = marks[k], marks[k + 1]
 t0 = ev[i0][0]
 print(f"cycle window {(ev[i1][0] - t0) / 1e3:.1f} us, {i1 - i0} events")
-LOOP = ("k_spmv_sell<1, true>", "k_pcg_xr", "k_restrict_bricks", "k_lattice_coarse", "k_lattice_prolong3", "k_prolong_mesh", "k_pcg_")
+LOOP = ("k_spmv_sell<1, true", "k_pcg_xr", "k_restrict_bricks", "k_lattice_coarse", "k_lattice_prolong3", "k_prolong_mesh", "k_pcg_")
 busy = 0.0
 prev_end = ev[i0][0]
 run = None
