@@ -207,6 +207,13 @@ def test_pc_plan_host_errors():
     x = np.array([[0.0, 0.0], [1.0, 0.0], [2.0, 0.0]])           # all on a line: degenerate box in y
     with pytest.raises(FemoError, match="degenerate bounding box"):
         E.pc_plan_host(x)
+    # 3-D packed coordinates hold 9 bits of bin per axis (round 5: three 21-bit fields in one 64-bit word): a lattice finer than
+    # 511 bins -- a mesh of ~2e9 vertices -- is refused, not silently wrapped
+    g = np.linspace(0.0, 1.0, 4)
+    x3 = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    assert E.pc_plan_host(x3, n_vert_global=5 * 10 ** 8)["bins"][-1].max() == 384
+    with pytest.raises(FemoError, match="too fine for packed coordinates"):
+        E.pc_plan_host(x3, n_vert_global=2 * 10 ** 9)
 
 
 def test_lattice_occupancy_flags_graded_meshes():
