@@ -69,7 +69,7 @@ struct femo_pc {
   // preconditioner's scaling by 6e-8 relative, the solution not at all)
   float* d_w_sorted = nullptr;
   float* d_sinv = nullptr;
-  double* d_dot_partials = nullptr; // per-block partials of g_L.e_L (2048)
+  double* d_dot_partials = nullptr; // per-block partials of g_L.e_L (4096)
   // partitioned meshes: only the finest-lattice nodes that several ranks touch are exchanged
   bool shared_ready = false;
   int64_t n_shared = 0;
@@ -1483,8 +1483,11 @@ __global__ __launch_bounds__(1024) void k_lattice_coarse_m(CoarseLevels L, int d
 // FineLevels of the merged variant: g_c / g_m are the STATE of levels T and L-1 (already updated by the carriers of
 // k_lattice_coarse_m), g_f the state of the finest level (updated here), h_f its accumulator (cleared here).  The other
 // parity's accumulators of levels T and L-1 are cleared by the carriers (g_c_other / g_m_other are not used here).
-template <int D>
-__global__ __launch_bounds__(256) void k_lattice_prolong3_m(FineLevels P, double* __restrict__ h_f, const double* __restrict__ S, int init,
+// BT threads per tile (round 5): 128 where the tiles of a lattice outnumber the 2048 workgroups of 256 threads a device holds at once
+// (96^3 bins = 13^3 = 2197 tiles: 149 workgroups took a second tile and the launch lasted two tile latencies, 27 us; with 128
+// threads 2560 workgroups fit and every tile has its own: 25.1 -> 22.1 us; 2-D at n = 2236, 4225 tiles: 24.0 -> 20.8)
+template <int D, int BT>
+__global__ __launch_bounds__(BT) void k_lattice_prolong3_m(FineLevels P, double* __restrict__ h_f, const double* __restrict__ S, int init,
                                                             const int32_t* __restrict__ tile_list, int64_t n_list,
                                                             const int32_t* __restrict__ done) {
   if (done != nullptr && *done) return;
@@ -1492,7 +1495,7 @@ __global__ __launch_bounds__(256) void k_lattice_prolong3_m(FineLevels P, double
   constexpr int NC = D == 3 ? TC * TC * TC : TC * TC, NM = D == 3 ? TM * TM * TM : TM * TM, NT = D == 3 ? TF * TF * TF : TF * TF;
   __shared__ double ec[NC];
   __shared__ double em[NM];
-  __shared__ double red[256 / 64];
+  __shared__ double red[BT / 64];
   const double alpha = init ? -1.0 : S[MS_ALPHA];
   int tn[3] = {1, 1, 1};
 #pragma unroll
@@ -1521,8 +1524,8 @@ __global__ __launch_bounds__(256) void k_lattice_prolong3_m(FineLevels P, double
 #pragma unroll
       for (int k = 0; k < D; ++k) { lo[k] = (int)(t % tn[k]) * TF; t /= tn[k]; mlo[k] = lo[k] >> 1; clo[k] = lo[k] >> 2; }
     }
-    static_assert(NC <= 256 && NM <= 256, "one patch node per thread");
-    constexpr int NQ = NT / 256;
+    static_assert(NC <= BT && NM <= BT && NT % BT == 0, "one patch node per thread");
+    constexpr int NQ = NT / BT;
     const int p = threadIdx.x;
     bool c_in = false, c_own = true;
     int64_t c_idx = 0;
@@ -1571,7 +1574,7 @@ __global__ __launch_bounds__(256) void k_lattice_prolong3_m(FineLevels P, double
     double f_g[NQ], f_coef[NQ], f_w[NQ];
 #pragma unroll
     for (int r = 0; r < NQ; ++r) {
-      int q = p + r * 256;
+      int q = p + r * BT;
       f_in[r] = true;
       fi[r][0] = fi[r][1] = fi[r][2] = 0;
 #pragma unroll
@@ -1609,7 +1612,7 @@ __global__ __launch_bounds__(256) void k_lattice_prolong3_m(FineLevels P, double
     lds_barrier();
   }
   if (P.dot_partials != nullptr) {
-    const double t = femo_block_sum<256>(dot, red);
+    const double t = femo_block_sum<BT>(dot, red);
     if (threadIdx.x == 0) P.dot_partials[blockIdx.x] = t;
   }
 }
@@ -1821,7 +1824,7 @@ int femo_pc_build(femo_mesh* m) {
   }
   FEMO_HIP_CHECK(hipMalloc(&pc->d_w_sorted, std::max<size_t>(P.perm.size(), 1) * sizeof(float)));
   FEMO_HIP_CHECK(hipMalloc(&pc->d_sinv, std::max<size_t>(P.perm.size(), 1) * sizeof(float)));
-  FEMO_HIP_CHECK(hipMalloc(&pc->d_dot_partials, 2048 * sizeof(double)));
+  FEMO_HIP_CHECK(hipMalloc(&pc->d_dot_partials, 4096 * sizeof(double)));
   m->pc = pc;
   return 0;
 }
@@ -2429,10 +2432,18 @@ int femo_pc_merged_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, c
   for (int k = 0; k < pc->dim; ++k) tiles *= (F.n[k] + TF) / TF;
   const int32_t* tile_list = pc->n_my_tiles < tiles ? pc->d_my_tiles : nullptr;      // all of them: walk the plain range
   if (tile_list != nullptr) tiles = pc->n_my_tiles;
-  const int grid3 = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, 2048));
+  // 128 threads per tile when 256-thread workgroups would not all be resident at once (see the kernel)
+  static const int bt_env = FEMO_TUNE_ENV("FEMO_PROLONG3_BT") ? atoi(FEMO_TUNE_ENV("FEMO_PROLONG3_BT")) : 0;
+  const bool small_blocks = bt_env ? bt_env == 128 : tiles > 2048;      // (1.03 M rows, 1000 tiles: 7.7 us with 256 threads, 8.5 with 128)
+  const int grid3 = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, small_blocks ? 4096 : 2048));
   const int nb_dot = multi ? 0 : grid3;
-  if (pc->dim == 3) hipLaunchKernelGGL(k_lattice_prolong3_m<3>, dim3(grid3), dim3(256), 0, st, FL, hF, (const double*)S, init ? 1 : 0, tile_list, tiles, done);
-  else hipLaunchKernelGGL(k_lattice_prolong3_m<2>, dim3(grid3), dim3(256), 0, st, FL, hF, (const double*)S, init ? 1 : 0, tile_list, tiles, done);
+  if (pc->dim == 3) {
+    if (small_blocks) hipLaunchKernelGGL((k_lattice_prolong3_m<3, 128>), dim3(grid3), dim3(128), 0, st, FL, hF, (const double*)S, init ? 1 : 0, tile_list, tiles, done);
+    else hipLaunchKernelGGL((k_lattice_prolong3_m<3, 256>), dim3(grid3), dim3(256), 0, st, FL, hF, (const double*)S, init ? 1 : 0, tile_list, tiles, done);
+  } else {
+    if (small_blocks) hipLaunchKernelGGL((k_lattice_prolong3_m<2, 128>), dim3(grid3), dim3(128), 0, st, FL, hF, (const double*)S, init ? 1 : 0, tile_list, tiles, done);
+    else hipLaunchKernelGGL((k_lattice_prolong3_m<2, 256>), dim3(grid3), dim3(256), 0, st, FL, hF, (const double*)S, init ? 1 : 0, tile_list, tiles, done);
+  }
   pc->parity ^= 1;
   PcgStop ps;
   ps.rtol2_factor = stop ? stop->rtol2_factor : 0.0;
