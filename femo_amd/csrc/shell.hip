@@ -105,6 +105,10 @@ struct femo_shell {
   int64_t* d_bi_ptr = nullptr;
   int32_t *d_bi_lvl = nullptr, *d_bi_pts = nullptr, *d_bi_pcell = nullptr;
   uint8_t* d_fixbits = nullptr;
+  // the Dirichlet mask of the last solve on the device, kept while the caller's array hashes the same (round 5: a solve used
+  // to allocate, upload and free it, and to hash it byte by byte for the preconditioner's cache: 3 ms of idle device per solve)
+  uint8_t* d_fixed_kept = nullptr;
+  uint64_t fixed_kept_hash = 0;
   float4* d_fin_w4 = nullptr;
   int64_t* d_hp_rowptr = nullptr;
   int32_t* d_hp_cols = nullptr;
@@ -3372,7 +3376,7 @@ int femo_shell_destroy(femo_shell* s) {
   hipFree(s->d_r); hipFree(s->d_p); hipFree(s->d_q); hipFree(s->d_dinv); hipFree(s->d_scal); hipFree(s->d_part); hipFree(s->d_flag);
   hipFree(s->d_ell_idx); hipFree(s->d_ell_w);
   hipFree(s->d_par_rowptr); hipFree(s->d_par_cols); hipFree(s->d_par_vals); hipFree(s->d_chi_rowptr); hipFree(s->d_chi_cols); hipFree(s->d_chi_vals);
-  hipFree(s->d_bi_ptr); hipFree(s->d_bi_lvl); hipFree(s->d_bi_pts); hipFree(s->d_bi_pcell); hipFree(s->d_fixbits);
+  hipFree(s->d_fixed_kept); hipFree(s->d_bi_ptr); hipFree(s->d_bi_lvl); hipFree(s->d_bi_pts); hipFree(s->d_bi_pcell); hipFree(s->d_fixbits);
   hipFree(s->d_coarse); hipFree(s->d_cblk); hipFree(s->d_lvl_node); hipFree(s->d_lvl_w); hipFree(s->d_dinv3); hipFree(s->d_t); hipFree(s->d_e); hipFree(s->d_z); hipFree(s->d_fin_idx); hipFree(s->d_fin_w);
   delete s;
   return 0;
@@ -4208,13 +4212,49 @@ int femo_shell_hpower(femo_shell* s, double coef, double p, const femo_vec* h, d
 // preconditioner of femo_shell_pc_create.  K symmetric: the same call serves the adjoint (fea_dolfinx.py:208-222).
 // The preconditioner's numbers for the current stiffness and Dirichlet set (kept while both stay the same): dense coarse
 // operator and its factors, node blocks (or Galerkin diagonals), point blocks.
-static int shell_pc_setup(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_host, const uint8_t* d_fixed) {
+// 64-bit hash of the caller's Dirichlet mask, 32 bytes per step in four independent lanes (identifies the mask for the caches
+// below: the device copy and the preconditioner's numbers)
+static uint64_t shell_mask_hash(const uint8_t* p, int64_t n) {
+  if (p == nullptr) return 1469598103934665603ull;
+  uint64_t h[4] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
+  int64_t i = 0;
+  for (; i + 32 <= n; i += 32) {
+    uint64_t w[4];
+    memcpy(w, p + i, 32);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { h[k] = (h[k] ^ w[k]) * 0x9FB21C651E98DF25ull; h[k] ^= h[k] >> 32; }
+  }
+  uint64_t t = 1469598103934665603ull ^ (uint64_t)n;
+  for (; i < n; ++i) t = (t ^ p[i]) * 1099511628211ull;
+  uint64_t r = t;
+  for (int k = 0; k < 4; ++k) { r = (r ^ h[k]) * 0xD6E8FEB86659FD93ull; r ^= r >> 29; }
+  return r != 0 ? r : 1;
+}
+
+// The mask on the device (nullptr without one) and its hash; the copy belongs to the shell and is re-uploaded only when the
+// caller's array changed.
+static int shell_mask(femo_shell* s, const uint8_t* fixed_host, const uint8_t** d_fixed, uint64_t* hash) {
+  *hash = shell_mask_hash(fixed_host, s->n_dof);
+  *d_fixed = nullptr;
+  if (fixed_host == nullptr) return 0;
+  if (s->d_fixed_kept == nullptr) {
+    FEMO_HIP_CHECK(hipMalloc(&s->d_fixed_kept, std::max<int64_t>(s->n_dof, 1)));
+    s->fixed_kept_hash = 0;
+  }
+  if (s->fixed_kept_hash != *hash) {
+    // (the stream may still run kernels of an earlier call that read the old mask: same stream, ordered)
+    FEMO_HIP_CHECK(hipMemcpyAsync(s->d_fixed_kept, fixed_host, s->n_dof, hipMemcpyHostToDevice, s->ctx->stream));
+    FEMO_HIP_CHECK(hipStreamSynchronize(s->ctx->stream));        // the caller's (pageable) array may change after the call returns
+    s->fixed_kept_hash = *hash;
+  }
+  *d_fixed = s->d_fixed_kept;
+  return 0;
+}
+
+static int shell_pc_setup(femo_shell* s, const femo_vec* vals, uint64_t mh, const uint8_t* d_fixed) {
   hipStream_t st = s->ctx->stream;
   const int64_t n = s->n_dof;
-  // Galerkin diagonals of the current stiffness and Dirichlet set (kept while both stay the same)
-  uint64_t mh = 1469598103934665603ull;
-  if (fixed_host != nullptr)
-    for (int64_t i = 0; i < n; ++i) mh = (mh ^ fixed_host[i]) * 1099511628211ull;
+  // Galerkin diagonals of the current stiffness and Dirichlet set (kept while both stay the same; mh: shell_mask_hash)
   if (s->pc_vals_uid != vals->uid || s->pc_vals_gen != vals->gen || s->pc_mask_hash != mh || vals->uid == 0) {
     FEMO_TRY(shell_pc_coarse_setup(s, vals, d_fixed));
     // levels the coarse solve does not replace: 6 x 6 node blocks (they see the coupling of the displacement
@@ -4282,16 +4322,16 @@ int femo_shell_pc_apply(femo_shell* s, const femo_vec* vals, const uint8_t* fixe
   FEMO_REQUIRE(s->d_owned == nullptr, "femo_shell_pc_apply: one rank only");
   hipStream_t st = s->ctx->stream;
   femo_vec_touch(z);
-  uint8_t* d_fixed = nullptr;
-  if (fixed_host != nullptr) FEMO_TRY(to_device(&d_fixed, fixed_host, n, st));
+  const uint8_t* d_fixed = nullptr;
+  uint64_t mask_hash = 0;
+  FEMO_TRY(shell_mask(s, fixed_host, &d_fixed, &mask_hash));
   const unsigned gv = std::min<unsigned>(sgrid(n), SH_MAXPART);
   hipLaunchKernelGGL(k_rhs_free, dim3(gv), dim3(256), 0, st, n, r->d, d_fixed, s->d_r);
-  FEMO_TRY(shell_pc_setup(s, vals, fixed_host, d_fixed));
+  FEMO_TRY(shell_pc_setup(s, vals, mask_hash, d_fixed));
   const unsigned gz = std::min<unsigned>(sgrid(n / 3, SH_BLOCK / 8), SH_MAXPART);
   FEMO_TRY(shell_pc_apply(s, d_fixed, s->d_part + SH_MAXPART, gz, nullptr));
   FEMO_HIP_CHECK(hipMemcpyAsync(z->d, s->d_z, n * sizeof(double), hipMemcpyDeviceToDevice, st));
   FEMO_HIP_CHECK(hipStreamSynchronize(st));
-  if (d_fixed) (void)hipFree(d_fixed);
   return 0;
 }
 
@@ -4305,8 +4345,9 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
   hipStream_t st = ctx->stream;
   memset(info, 0, sizeof *info);
   femo_vec_touch(x);
-  uint8_t* d_fixed = nullptr;
-  if (fixed_host != nullptr) FEMO_TRY(to_device(&d_fixed, fixed_host, n, st));
+  const uint8_t* d_fixed = nullptr;
+  uint64_t mask_hash = 0;
+  FEMO_TRY(shell_mask(s, fixed_host, &d_fixed, &mask_hash));
   const unsigned gv = std::min<unsigned>(sgrid(n), SH_MAXPART);
   // workgroups of the operator product (their per-block partials of p.q are folded by k_scg_xr*): 16 rows, or 16
   // node blocks of three rows, per workgroup pass
@@ -4352,7 +4393,7 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
   // direction update fused into the prolongation (dofs numbered 3 point + component: every shell pattern of fea/shell.py)
   const bool fused = opts->pc == 1 && n % 3 == 0 && !multi && !femo_env_flag("FEMO_SHELL_UNFUSED");
   if (lattice) {
-    FEMO_TRY(shell_pc_setup(s, vals, fixed_host, d_fixed));
+    FEMO_TRY(shell_pc_setup(s, vals, mask_hash, d_fixed));
     FEMO_TRY(shell_pc_apply(s, d_fixed, Prz, gz, nullptr));
     hipLaunchKernelGGL(k_copy, dim3(gv), dim3(256), 0, st, n, s->d_z, s->d_p);
   } else {
@@ -4485,7 +4526,6 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
   info->iterations = h_flag[0] ? h_flag[1] : it;
   info->converged = h_flag[0] ? (h_flag[2] ? -1 : 1) : (stalled ? 2 : 0);
   info->residual_norm = std::sqrt(std::max(h_flag[0] && h_flag[1] > 0 ? h_scal[4] : h_scal[0], 0.0));
-  if (d_fixed) (void)hipFree(d_fixed);
   return 0;
 }
 

@@ -958,14 +958,14 @@ class ShellProblem:
         self.dev.matvec(K, self.w, self.tmp)
         self.dev.load(self.f, self.tmp, sign=-1.0, accumulate=True)
         self.dev.mask_unowned(self.tmp)                        # partitioned: the rank's share (rows of its points)
-        return np.array(self.tmp.get())
+        return E.writable(self.tmp.get())
 
     def solve(self, rtol: float = 1e-12) -> np.ndarray:
         """solve_residual_equations (state_model.py:87-115): w with the strongly imposed dofs at zero."""
         K = self._stiffness()
         self.dev.load(self.f, self.F)
         self.last_info = self.dev.solve(K, self.F, self.w, fixed=self.fixed, rtol=rtol, pc=self.pc)
-        return np.array(self.w.get())
+        return E.writable(self.w.get())
 
     def solve_adjoint(self, rhs: np.ndarray, rtol: float = 1e-12) -> np.ndarray:
         """apply_inverse_jacobian 'rev' (state_model.py:202-218): K^-T rhs with the Dirichlet rows / columns eliminated
@@ -973,7 +973,7 @@ class ShellProblem:
         K = self._stiffness()
         self.tmp.set(np.ascontiguousarray(rhs, dtype=np.float64))
         self.last_info = self.dev.solve(K, self.tmp, self.lam, fixed=self.fixed, rtol=rtol, pc=self.pc)
-        return np.array(self.lam.get())
+        return E.writable(self.lam.get())
 
     # partials of the residual --------------------------------------------------------------------
     def dRdh_T(self, lam: np.ndarray, w: Optional[np.ndarray] = None) -> np.ndarray:
@@ -982,13 +982,13 @@ class ShellProblem:
             self.w.set(np.ascontiguousarray(w, dtype=np.float64))
         self.lam.set(np.ascontiguousarray(lam, dtype=np.float64))
         self.dev.dform_dh(self.E, self.nu, self.h, self.lam, self.w, out=self.gh)
-        return np.array(self.gh.get())
+        return E.writable(self.gh.get())
 
     def dRdf_T(self, lam: np.ndarray) -> np.ndarray:
         """(dR/df)^T lam = -(dF/df)^T lam, shape (n_vert, 3)."""
         self.lam.set(np.ascontiguousarray(lam, dtype=np.float64))
         self.dev.load_T(self.lam, self.gf, sign=-1.0)
-        return np.array(self.gf.get()).reshape(-1, 3)
+        return E.writable(self.gf.get()).reshape(-1, 3)
 
     # outputs --------------------------------------------------------------------------------------
     def compliance(self, w: Optional[np.ndarray] = None, grad: bool = False):
@@ -999,11 +999,11 @@ class ShellProblem:
             J = self.dev.compliance_dx(self.w, self._cell_owned)
             if grad:
                 self.dev.compliance(self.w, grad=self.tmp, value=False)
-                return J, np.array(self.tmp.get())
+                return J, E.writable(self.tmp.get())
             return J
         if grad:
             J = self.dev.compliance(self.w, grad=self.tmp)
-            return J, np.array(self.tmp.get())
+            return J, E.writable(self.tmp.get())
         return self.dev.compliance(self.w)
 
     def mass(self, rho: float = 1.0, grad: bool = False):
@@ -1011,7 +1011,7 @@ class ShellProblem:
         the gradient on the rank's local vertices (complete on the owned ones)."""
         if grad:
             M = self.dev.mass(rho, self.h, grad=self.gh)
-            return M, np.array(self.gh.get())
+            return M, E.writable(self.gh.get())
         return self.dev.mass(rho, self.h)
 
     def surface_area(self) -> float:
@@ -1031,7 +1031,7 @@ class ShellProblem:
             alpha = self.surface_area()
         if grad:
             J = self.dev.pnorm_stress(self.E, self.nu, self.h, self.w, m, rho, alpha, surface, grad_w=self.tmp, grad_h=self.gh)
-            return J, np.array(self.tmp.get()), np.array(self.gh.get())
+            return J, E.writable(self.tmp.get()), E.writable(self.gh.get())
         return self.dev.pnorm_stress(self.E, self.nu, self.h, self.w, m, rho, alpha, surface)
 
     def von_mises_field(self, w: Optional[np.ndarray] = None, surface: float = 1.0, lump_mass: bool = False) -> np.ndarray:
@@ -1039,7 +1039,7 @@ class ShellProblem:
         if w is not None:
             self.w.set(np.ascontiguousarray(w, dtype=np.float64))
         self.dev.project_von_mises(self.E, self.nu, self.h, self.w, surface, self.gh, lump_mass=lump_mass)
-        return np.array(self.gh.get())
+        return E.writable(self.gh.get())
 
     def elastic_energy(self, w: Optional[np.ndarray] = None) -> float:
         if w is not None:
