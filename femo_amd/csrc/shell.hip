@@ -2903,6 +2903,7 @@ __global__ __launch_bounds__(SH_BLOCK) void k_pc_restrict_h(int64_t m0, int64_t 
 // one lattice level, nodes [n0, n1), a thread per (node, field group):
 //   down: g[p] from the node's children (chi rows), up: e[c] = B_c g_c + (transfer of the parents' e) with the node's
 //   6 x 6 block B; w5 = (a, bx, by, bz, c) per entry.  dot_partials (up, finest level): per-block partial of e . g.
+constexpr int LAT_H_LANES = 4;      // lanes per (node, field group) in k_lat_level_h
 __global__ __launch_bounds__(256) void k_lat_level_h(int64_t n0, int64_t n1, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                                                      const double* __restrict__ w5, double* __restrict__ g, double* __restrict__ e, int up,
                                                      const int32_t* __restrict__ done, const double* __restrict__ blocks,
@@ -2910,13 +2911,18 @@ __global__ __launch_bounds__(256) void k_lat_level_h(int64_t n0, int64_t n1, con
   if (done != nullptr && *done) return;
   __shared__ double lds[256 / 64];
   double dot = 0.0;
+  // Round 5: four lanes share a (node, group) and split its <= 8 entries -- a lane used to walk them one after the other, each a
+  // dependent index -> gather round trip, on levels too small (<= 52 k nodes) to hide it with other waves.
+  const int sub = threadIdx.x & (LAT_H_LANES - 1);
   const int64_t total = (n1 - n0) * 2;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t stride = (int64_t)gridDim.x * (blockDim.x / LAT_H_LANES);
+  // (whole quads take the same trips: the shuffles below are executed by all four lanes)
+  for (int64_t t = (int64_t)blockIdx.x * (blockDim.x / LAT_H_LANES) + (threadIdx.x / LAT_H_LANES); t < total; t += stride) {
     const int64_t node = n0 + (t >> 1);
     const int grp = (int)(t & 1);
     const double* src = up ? e : g;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int64_t k = rowptr[node]; k < rowptr[node + 1]; ++k) {
+    for (int64_t k = rowptr[node] + sub; k < rowptr[node + 1]; k += LAT_H_LANES) {
       const double* w = w5 + 5 * k;
       const double* sv = src + 6 * (int64_t)cols[k];
       if (up) {
@@ -2937,6 +2943,11 @@ __global__ __launch_bounds__(256) void k_lat_level_h(int64_t n0, int64_t n1, con
         }
       }
     }
+#pragma unroll
+    for (int off = LAT_H_LANES / 2; off > 0; off >>= 1) {
+      s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64);
+    }
+    if (sub != 0) continue;
     double* out = (up ? e : g) + 6 * node + 3 * grp;
     if (!up) { out[0] = s0; out[1] = s1; out[2] = s2; continue; }
     const double* B = blocks + 36 * node + 18 * grp;
@@ -3568,7 +3579,7 @@ static int shell_pc_apply(femo_shell* s, const uint8_t* d_fixed, double* Prz, un
     const int64_t n0 = s->level_off[l], n1 = s->level_off[l + 1];
     const bool last = l == L - 1 && Pte != nullptr;
     if (herm) {
-      const unsigned g = last ? std::min<unsigned>(sgrid((n1 - n0) * 2, 256), 1024u) : sgrid((n1 - n0) * 2, 256);
+      const unsigned g = last ? std::min<unsigned>(sgrid((n1 - n0) * 2 * LAT_H_LANES, 256), 1024u) : sgrid((n1 - n0) * 2 * LAT_H_LANES, 256);
       if (last && nb_te) *nb_te = (int)g;
       hipLaunchKernelGGL(k_lat_level_h, dim3(g), dim3(256), 0, st, n0, n1, s->d_par_rowptr, s->d_par_cols, s->d_par_w5, s->d_t, s->d_e, 1, done, blocks,
                          last ? Pte : (double*)nullptr);
@@ -3603,7 +3614,7 @@ static int shell_pc_apply(femo_shell* s, const uint8_t* d_fixed, double* Prz, un
     } else if (herm) {
       for (int l = L - 2; l >= cs; --l) {
         const int64_t n0 = s->level_off[l], n1 = s->level_off[l + 1];
-        hipLaunchKernelGGL(k_lat_level_h, dim3(sgrid((n1 - n0) * 2, 256)), dim3(256), 0, st, n0, n1, s->d_chi_rowptr, s->d_chi_cols, s->d_chi_w5, s->d_t, s->d_e, 0,
+        hipLaunchKernelGGL(k_lat_level_h, dim3(sgrid((n1 - n0) * 2 * LAT_H_LANES, 256)), dim3(256), 0, st, n0, n1, s->d_chi_rowptr, s->d_chi_cols, s->d_chi_w5, s->d_t, s->d_e, 0,
                            done, (const double*)nullptr, (double*)nullptr);
       }
     } else if (s->d_cd_rowptr != nullptr && L - 1 > cs) {
