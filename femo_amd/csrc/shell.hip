@@ -4483,7 +4483,11 @@ int femo_shell_solve(femo_shell* s, const femo_vec* vals, const uint8_t* fixed_h
                              s->dinv3_ready ? s->d_dinv3 : (const float*)nullptr, x->d, s->d_r, Prz, s->d_flag);
           FEMO_TRY(shell_pc_apply(s, d_fixed, Prz, gz, s->d_flag, Pte, &nb_te));
         }
-        hipLaunchKernelGGL(k_pc_prolong_fused, dim3(gz), dim3(SH_BLOCK), 0, st, n / 3, it, (int)gx, Prz, nb_te, Pte, s->d_scal, s->d_fin_idx, s->d_fin_w,
+        // 2048 workgroups = one resident round of 8 waves per SIMD, ten trips each: 45.0 us at 1.97 M dofs against 49.3 with 4096,
+        // 56.6 with 8192, 61.5 with 1024 (every workgroup starts with two folds and three dependent scalar reads; fewer
+        // partials to fold change nothing: 44.4 - 46.3 us with 256 - 1024 of each)
+        const unsigned gzf = std::min<unsigned>(gz, 2048u);
+        hipLaunchKernelGGL(k_pc_prolong_fused, dim3(gzf), dim3(SH_BLOCK), 0, st, n / 3, it, (int)gx, Prz, nb_te, Pte, s->d_scal, s->d_fin_idx, s->d_fin_w,
                            d_fixed, s->d_dinv, s->dinv3_ready ? s->d_dinv3 : (const float*)nullptr, s->d_r, s->d_e, s->d_p, s->d_flag, gam,
                            (s->hermite_on && s->cs_ready && s->blk_ready) ? s->d_fin_w4 : (const float4*)nullptr, s->n_unode);
       } else if (lattice) {
