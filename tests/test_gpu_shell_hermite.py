@@ -167,3 +167,30 @@ def test_set_up_kernels_on_a_high_valence_mesh(ctx, monkeypatch):
     K = so.assemble(V0, so.element_stiffness(V0, h, 2.0e8, 0.3)).tocsr()
     F = so.load_vector(V0, np.tile([0.0, 0.0, -1.0e3], (V0.n_vert, 1)))
     assert prob.last_info.converged in (1, 2) and rel(w, so.solve(K, F, fixed)) <= 1e-6
+
+
+def test_dirichlet_mask_kept_on_the_device_follows_the_callers_array(ctx):
+    """Round 5: the shell keeps the Dirichlet mask of the last solve on the device behind a hash of the caller's array
+    (`shell_mask`, shell.hip) instead of uploading it per solve.  Another mask must replace it -- state, preconditioner
+    set-up and imposed dofs all follow --, and coming back to the first mask gives the first result again."""
+    from femo_amd.engine import Vec
+    prob, V0, fixed = _problem(ctx, 16)
+    vals = prob._stiffness()
+    prob.dev.load(prob.f, prob.F)
+    n = V0.n_dof
+    mask_a = np.zeros(n, dtype=np.uint8)
+    mask_a[fixed] = 1
+    extra = np.setdiff1d(np.arange(0, n, 97), fixed)[:25]          # pin two dozen more dofs: another problem
+    mask_b = mask_a.copy()
+    mask_b[extra] = 1
+    out = []
+    for mask in (mask_a, mask_b, mask_a, mask_b.copy()):          # (the last one: equal content in another array)
+        x = Vec(ctx, n)
+        info = prob.dev.solve(vals, prob.F, x, fixed=mask, rtol=1e-11, pc="lattice")
+        assert info.converged in (1, 2)
+        out.append(np.array(x.get()))
+    xa, xb, xa2, xb2 = out
+    assert np.all(xa[fixed] == 0.0) and np.all(xb[fixed] == 0.0) and np.all(xb[extra] == 0.0)
+    assert np.abs(xa[extra]).max() > 0.0                           # ... which were free under the first mask
+    assert rel(xa2, xa) < 1e-9 and rel(xb2, xb) < 1e-9             # (two PCG runs: equal to the solver tolerance)
+    assert rel(xb, xa) > 1e-3                                      # and the two problems do differ
