@@ -194,3 +194,20 @@ def test_dirichlet_mask_kept_on_the_device_follows_the_callers_array(ctx):
     assert np.abs(xa[extra]).max() > 0.0                           # ... which were free under the first mask
     assert rel(xa2, xa) < 1e-9 and rel(xb2, xb) < 1e-9             # (two PCG runs: equal to the solver tolerance)
     assert rel(xb, xa) > 1e-3                                      # and the two problems do differ
+
+
+def test_results_are_the_callers_own_arrays(ctx):
+    """`ShellProblem` hands out the pinned blocks its results landed in as writable arrays (round 5: no pageable copy):
+    the caller may write into them, and a later call neither sees that nor overwrites what was handed out."""
+    prob, V0, fixed = _problem(ctx, 16)
+    w1 = prob.solve(rtol=1e-11)
+    assert w1.flags.writeable and w1.dtype == np.float64 and w1.size == V0.n_dof
+    keep = w1.copy()
+    J1, dJdw = prob.compliance(grad=True)
+    dJdw[fixed] = 0.0                                              # (what the operators do with it)
+    w1 *= 2.0                                                      # the caller's array now
+    w2 = prob.solve(rtol=1e-11)
+    assert w2 is not w1 and w2.ctypes.data != w1.ctypes.data
+    assert rel(w2, keep) < 1e-9 and np.array_equal(w1, 2.0 * keep)
+    J2, _ = prob.compliance(grad=True)
+    assert abs(J2 - J1) <= 1e-9 * abs(J1)
