@@ -194,6 +194,7 @@ def cpu_baseline(args, gpu_counts, n_dof_gpu, n_cell_gpu, nnz_gpu):
     size by default (about 10 s of CPU work with BPX-CG), so nothing is extrapolated.  ``--cpu-n`` selects a
     smaller cube; the figure is then scaled by cells / nnz and says so."""
     from oracle import c_port
+    c_port.use_native()            # the port compiled for THIS box's CPU when gcc is here (the shipped .so is x86-64-v3)
     from oracle import femo_oracle as fo
     n = args.cpu_n if args.cpu_n else args.n
     m = _canonical_mesh(n, args.jitter)
@@ -228,6 +229,7 @@ def dst_reference_cycle(n: int, k: int, count: int):
     transform (oracle/c_port.py::poisson_cycle_dst): the checker of the N > 1 run, computed on rank 0 outside the timed region
     (`femo_amd/dist` calls back into the harness for it: the package itself never touches ``oracle/``)."""
     from oracle import c_port
+    c_port.use_native()            # the port compiled for THIS box's CPU when gcc is here (the shipped .so is x86-64-v3)
     from oracle import femo_oracle as fo
     canon = _canonical_mesh(n, 0.0)
     fg = source_fields(_Centroid(canon), count)[k]
@@ -246,6 +248,7 @@ def self_check(args, mesh, f, u, J, grad):
     cycle with a 100x tighter CG tolerance stands in and ``kind`` says so.
     Reference algebra: femo/csdl_opt/state_model.py:87-115, 202-218."""
     from oracle import c_port
+    c_port.use_native()            # the port compiled for THIS box's CPU when gcc is here (the shipped .so is x86-64-v3)
     from oracle import femo_oracle as fo
     n, d = args.n, mesh.tdim
     t0 = time.perf_counter()
@@ -337,7 +340,7 @@ def _judge(check: dict, pairs) -> dict:
     return check
 
 
-_PMC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json")
+_PMC_FILES = ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json")
 
 
 def _pmc_lookup(key: str):
@@ -362,19 +365,27 @@ def _pmc_traffic(key: str):
 
 
 def _roofline(kernel: str, bytes_per_launch: int, ms: float, samples: int, note: str = "", stored: int = 0, traffic_key: str = "") -> dict:
-    """One byte convention for every configuration: `achieved` / `frac` from the ALGORITHMIC bytes (CSR
-    formula; for the shell the block format is the algorithm's own), `traffic` / `frac_physical` from the PMC pass of this
-    kernel at this size where one is committed (configs 2 and 3), else from the bytes the stored format makes the kernel
-    move (`physical_bytes_source` says which)."""
+    """One byte convention for every configuration (round 6): `achieved` / `frac` are PHYSICAL --
+    the bytes the kernel really moves per launch (the PMC pass of this kernel at this size where one is committed, else the
+    bytes of the stored format; `physical_bytes_source` says which) over the launch time measured in THIS run, against the
+    8 TB/s peak.  `achieved_algorithmic` / `frac_algorithmic` price the same time with the ALGORITHMIC bytes of SURVEY.md
+    8(d) (the CSR formula; for the shell the block format is the algorithm's own): a CSR-equivalent rate -- it says how fast
+    a plain CSR kernel would have to stream to finish in the same time, and it exceeds the physical rate by the factor the
+    compressed format saves (`format_compression`)."""
     ok = bool(ms and ms == ms and ms > 0)
-    ach = bytes_per_launch / (ms * 1e-3) / 1e9 if ok else None
+    alg = bytes_per_launch / (ms * 1e-3) / 1e9 if ok else None
     stored = int(stored or bytes_per_launch)
     traffic, pmc_file, pmc_commit = _pmc_lookup(traffic_key)
     phys = traffic if traffic else stored
+    ach = phys / (ms * 1e-3) / 1e9 if ok else None
     return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": traffic, "algorithmic_bytes_per_launch": int(bytes_per_launch),
-            "stored_bytes_per_launch": stored, "frac_physical": phys / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ok else None,
+            "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": traffic,
+            "physical_bytes_per_launch": phys,
             "physical_bytes_source": f"PMC (2*FETCH_SIZE + WRITE_SIZE, profiles/{pmc_file}, collected at commit {pmc_commit})" if traffic else "stored bytes of the format the kernel reads",
+            "achieved_algorithmic": alg, "frac_algorithmic": alg / HBM_PEAK_GBS if alg else None,
+            "algorithmic_bytes_per_launch": int(bytes_per_launch), "stored_bytes_per_launch": stored,
+            "format_compression": bytes_per_launch / phys if phys else None,
+            "frac_physical": ach / HBM_PEAK_GBS if ach else None,          # (rounds 2-5 name of `frac`; kept for readers of old lines)
             "avg_launch_ms": ms, "launches_timed": samples,
             "timed": "single launches inside the timed solver loops (HIP events on the library's stream)" + (("; " + note) if note else "")}
 
@@ -419,6 +430,7 @@ def bench_config2(ctx, steps: int) -> dict:
     spmv_ms, ns = _spmv_in_loop(infos)
     nnz = dm.info["nnz"]
     from oracle import c_port
+    c_port.use_native()            # the port compiled for THIS box's CPU when gcc is here (the shipped .so is x86-64-v3)
     from oracle import femo_oracle as fo
     om = _canonical_mesh(n, 0.0)
     bd = fo.boundary_vertices_box(om.x)
@@ -440,6 +452,89 @@ def bench_config2(ctx, steps: int) -> dict:
                                       f"{cpu['times']['cycle']:.2f} s, CG its {cpu['it_fwd']}+{cpu['it_adj']}; nothing scaled"}}
     utils_hip.clear_workspaces()
     return rec
+
+
+def bench_unstructured(ctx, n: int, steps: int = 3) -> dict:
+    """The headline's cycle on the SAME cube with the numbering a foreign mesh has: vertices and
+    cells renumbered at random (`Mesh.permuted`), then `Mesh.reordered()` -- what `import_mesh` does to a mesh it reads
+    (Morton curve).  No lexicographic x-lines, hence no index-free "regular" SELL slices: the SpMV fetches its column
+    indices and gathers through the caches.  Host boundary, same tolerances, same check (DST-exact cycle, vertex / cell
+    numbering mapped back through the coordinates)."""
+    import types
+    from femo_amd import engine as E
+    from femo_amd.fea import utils_hip
+    from femo_amd.fea.mesh import createUnitCubeMesh
+    t0 = time.perf_counter()
+    mesh = createUnitCubeMesh(n).permuted(seed=20240807).reordered()
+    sim, fea = build_problem(mesh, device=False)
+    dm = mesh.device(ctx)
+    _prime_pool(sim)
+    f_host = source_fields(mesh, 3)
+    fs = [E.pinned_array(f) for f in f_host]
+    u0 = E.pinned_full(mesh.n_vert, 0.0)
+    setup_s = time.perf_counter() - t0
+    for k in range(2):
+        one_cycle(sim, fea, fs[k], u0)
+    ctx.sync()
+    del utils_hip.LAST_KSP_INFO[:]
+    ms, g = _timed_cycles(ctx, lambda k: one_cycle(sim, fea, fs[k % 3], u0), steps, 0)
+    infos = list(utils_hip.LAST_KSP_INFO)
+    per = len(infos) // steps
+    spmv_ms, ns = _spmv_in_loop(infos)
+    nnz = dm.info["nnz"]
+    kc = (steps - 1) % 3
+    args = types.SimpleNamespace(n=n, jitter=0.0, permute=True, reorder=True)
+    check = self_check(args, mesh, f_host[kc], np.array(sim['u'], copy=True), float(np.asarray(sim['l2_functional']).ravel()[0]),
+                       np.array(E.host_wait(g), copy=True))
+    rec = {"workload": f"the headline's cycle on the n={n} cube with random vertex / cell numbering renumbered by Mesh.reordered() (Morton curve), "
+                       f"{mesh.n_vert} DOFs: the rate of an imported unstructured mesh; host boundary",
+           "n_dof": mesh.n_vert, "steps": steps, "ms_per_cycle": ms, "dofs_per_s": mesh.n_vert / (ms * 1e-3), "setup_s": setup_s,
+           "cg_iterations_per_cycle": [i["iterations"] for i in infos[:per]],
+           "sell_slices": dm.info["n_slices"], "regular_slices": dm.info["regular_slices"], "short_slices": dm.info.get("short_slices", 0),
+           "roofline": _roofline("k_spmv_sell<1,true>", spmv_algorithmic_bytes(nnz, mesh.n_vert), spmv_ms, ns,
+                                 "general slices: 16- or 32-bit column indices are fetched, x is gathered through L2 / Infinity Cache",
+                                 stored=stored_bytes(dm.info, mesh.n_vert), traffic_key=f"spmv_n{n}_permuted_reordered"),
+           "check": check}
+    sim = fea = fs = u0 = g = None
+    utils_hip.clear_workspaces()
+    mesh._device = None
+    return rec
+
+
+def fenicsx_probe() -> dict:
+    """is the reference's own stack on this box?  (Expected: no -- SURVEY.md section 8(c).)"""
+    missing = []
+    for name in ("dolfinx", "petsc4py", "ufl", "mpi4py"):
+        try:
+            __import__(name)
+        except Exception as e:                                   # noqa: BLE001
+            missing.append(f"{name}: {type(e).__name__}")
+    return {"present": not missing, "detail": "importable" if not missing else "; ".join(missing),
+            "consequence": "the CPU legs below are the in-repo restatement (oracle/), labelled kind 'port' / 'direct' -- not FEniCSx" if missing
+                           else "dolfinx is importable: a FEniCSx CPU leg could be run on this box (not implemented: never observed)"}
+
+
+def cpu_direct_legs(cube_n: int = 28) -> list:
+    """the reference-FAITHFUL direct cycle on the host -- what femo does with MUMPS, restated
+    with SciPy's SuperLU (oracle/femo_oracle.py::reference_cycle): Newton's three passes each assemble and FACTORISE
+    (utils_dolfinx.py:419-449), the adjoint builds the transpose and factorises once more (fea_dolfinx.py:208-222 ->
+    utils_dolfinx.py:476-493, 241-245).  Config 1 (64 x 64 square) and the largest cube whose cycle stays inside the time
+    bound of this leg: sparse LU of a 3-D P1 operator fills as N^(4/3) and costs N^2 flops (10 s at 15.6 k DOFs, 57 s at 36 k,
+    336 s at 69 k in the build container) -- the reason the 10 M-DOF configuration cannot be timed this way at all."""
+    from oracle import femo_oracle as fo
+    out = []
+    for label, d, n in (("C1", 2, 64), ("cube", 3, cube_n)):
+        m = fo.unit_square_mesh(n) if d == 2 else fo.unit_cube_mesh(n)
+        bd = fo.boundary_vertices_box(m.x)
+        f = fo.f_star(fo.centroids(m))
+        t0 = time.perf_counter()
+        fo.reference_cycle(m, f, fo.u_target(m.x), bd, np.zeros(len(bd)))
+        t = time.perf_counter() - t0
+        out.append({"config": label, "workload": f"{d}-D linear Poisson, n={n}: {m.n_vert} DOFs", "n_dof": int(m.n_vert), "seconds": t,
+                    "value": m.n_vert / t, "unit": "DOFs/s", "cores": 1, "kind": "direct",
+                    "sample": "oracle/femo_oracle.py::reference_cycle: NumPy assembly + scipy.sparse.linalg.splu, 3 factorisations (Newton) + 1 of the "
+                              "transpose (adjoint), one core (SuperLU is serial; the reference's MUMPS is not installable here); measured at this size, nothing scaled"})
+    return out
 
 
 def _rss_mb() -> float:
@@ -589,15 +684,18 @@ def run_distributed_bench(args, ctx, control, cpu_baseline: bool = True):
             # halo exchange per ENQUEUED iteration (batches: a few iterations behind the converged one are enqueued too)
             "allreduce_per_cg_iteration": (sum(i.get("loop_allreduces", 0) for i in infos) / max(sum(i["iterations"] for i in infos), 1)),
             "collectives_per_step_rank0": {k: v / max(K, 1) for k, v in comm.items()},
-            "allreduce_payload": "shared finest-lattice nodes + levels L-1, L-2 whole + 7 scalars (p.q, r.q, q.q, r.r, 3 lattice sums) in ONE ncclAllReduce per iteration",
+            "allreduce_payload": "ONE ncclAllReduce per iteration: h on the lattice nodes SEVERAL ranks touch of the three brick-filled levels (L, L-1, L-2; sparse lists), "
+                                 "level L-3 dense (restricted from the rank's partial sums before the exchange), 7 scalars (p.q, r.q, q.q, r.r, 3 single-rank lattice sums)",
             "linear_solves_per_step": per, "cg_iterations_per_step": its_per_step, "cg_ms_per_step": cg_ms,
             "non_cg_ms_per_step": ms_per_step - cg_ms,
             "setup_s_per_rank": [float(s[9]) for s in stats], "setup_rss_mb_per_rank": [float(s[8]) for s in stats],
         },
         "roofline": {
-            "bound": "hbm", "achieved": float(stats[0][5]), "peak": B.HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": float(stats[0][5]) / B.HBM_PEAK_GBS, "traffic": None,
+            "bound": "hbm", "achieved": float(stats[0][7]) / (float(stats[0][6]) * 1e-3) / 1e9, "peak": B.HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": float(stats[0][7]) / (float(stats[0][6]) * 1e-3) / 1e9 / B.HBM_PEAK_GBS, "traffic": None,
+            "achieved_algorithmic": float(stats[0][5]), "frac_algorithmic": float(stats[0][5]) / B.HBM_PEAK_GBS,
             "frac_physical": float(stats[0][7]) / (float(stats[0][6]) * 1e-3) / 1e9 / B.HBM_PEAK_GBS,
+            "physical_bytes_per_launch": float(stats[0][7]),
             "physical_bytes_source": "stored bytes of the SELL format (no PMC pass at N > 1)",
             "kernel": "k_spmv_sell<1,true> on rank 0's local rows (per GPU), 150 back-to-back launches",
             "algorithmic_bytes_per_launch": B_A, "avg_launch_ms": float(stats[0][6]), "launches_timed": 150,
@@ -911,6 +1009,7 @@ def bench_config5(ctx, steps: int, n: int = 2236) -> dict:
     # Newton step, BPX-preconditioned CG with the engine's stopping rules, adjoint solve) at THIS configuration's own size on all
     # host cores (oracle/c_port.py::nl_cycle).  Rounds 1-4 timed the NumPy / SuperLU oracle on one core at 148 k DOFs.
     from oracle import c_port
+    c_port.use_native()            # the port compiled for THIS box's CPU when gcc is here (the shipped .so is x86-64-v3)
     from oracle import femo_oracle as fo
     x_h, conn_h = np.ascontiguousarray(mesh.x), np.ascontiguousarray(mesh.conn)
     bmask = np.ascontiguousarray(mesh.boundary_facet_mask(), dtype=np.uint8)
@@ -1229,11 +1328,18 @@ def _run(args):
         "device_resident": {"value": n_dof / (dev_ms * 1e-3) if dev_ms else None, "unit": "DOFs/s", "ms_per_step": dev_ms,
                             "steps": Kd, "note": "same cycle with DeviceArray inputs/outputs (no PCIe); round 1's headline"},
         "roofline": {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "frac_physical": physical / (spmv_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            # round 6: `achieved` / `frac` are PHYSICAL -- the bytes the kernel really moves (PMC pass of
+            # this kernel at this size, else the stored format's bytes) over the launch time measured in this run; the SURVEY
+            # 8(d) CSR bytes over the same time are the CSR-equivalent rate `achieved_algorithmic` / `frac_algorithmic`
+            "bound": "hbm", "achieved": physical / (spmv_avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": physical / (spmv_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
             "physical_bytes_per_launch": physical,
             "physical_bytes_source": f"PMC (2*FETCH_SIZE + WRITE_SIZE, profiles/{pmc_file}, collected at commit {pmc_commit})" if traffic else "stored bytes of the SELL format",
+            "achieved_algorithmic": achieved, "frac_algorithmic": achieved / HBM_PEAK_GBS,
+            "format_compression": B_A / physical,
+            "frac_algorithmic_note": "CSR-equivalent rate: SURVEY.md 8(d) bytes (12 B per entry + 20 B per row) over the measured launch time; the regular-slice SELL format "
+                                     "fetches no column indices and stores no unit diagonal, so the kernel moves format_compression x fewer bytes than the formula counts",
+            "frac_physical": physical / (spmv_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "kernel": "k_spmv_sell<1,true> (SELL-64 SpMV + fused p.Ap, one launch per CG iteration)",
             "algorithmic_bytes_per_launch": B_A, "avg_launch_ms": spmv_avg_ms, "launches_timed": n_in_cg,
             "timed": "single launches inside the timed PCG loops (HIP events on the library's stream)",
@@ -1321,6 +1427,10 @@ def _run(args):
         result["scaling_model"] = bench_scaling_model(ctx, args.n, 10, ms_per_step, result["config"]["split_ms_per_step"], global_its=its_per_step)
         result["configs"] = {"c2": bench_config2(ctx, 40), "c5_nl": bench_config5(ctx, 5), "c3_shell": bench_config3(ctx, 3)}
         try:
+            result["unstructured"] = bench_unstructured(ctx, args.n, 3)
+        except Exception as e:                                   # noqa: BLE001 - a leg of the report, never the headline
+            result["unstructured"] = {"error": repr(e)}
+        try:
             result["scaling_model_c5"] = bench_scaling_model_c5(ctx, 4, result["configs"]["c5_nl"])
         except Exception as e:                                   # noqa: BLE001 - a leg of the report, never the headline
             result["scaling_model_c5"] = {"error": repr(e)}
@@ -1331,6 +1441,13 @@ def _run(args):
     if not args.no_cpu_baseline:
         counts = its_per_step if its_per_step else [0]
         result["cpu_baseline"] = cpu_baseline(args, counts, n_dof, mesh.n_cell, nnz)
+        # step 1 (is FEniCSx here?) and step 2a (the reference-faithful direct cycle where it fits)
+        result["cpu_baseline"]["fenicsx_probe"] = fenicsx_probe()
+        if args.n == 215 and not args.no_configs:
+            try:
+                result["cpu_baseline"]["direct"] = cpu_direct_legs()
+            except Exception as e:                               # noqa: BLE001
+                result["cpu_baseline"]["direct"] = {"error": repr(e)}
     return result
 
 

@@ -124,9 +124,11 @@ class StateOperation(CustomImplicitOperation):
             # while f is still on its way to the device, and compute_derivatives of this cycle finds it done.  The same
             # kernels once per cycle, earlier: 2.1 ms of the 10 M-DOF cycle move under the upload.  Only with deferred uploads
             # (a backend that declared it honours asynchronous arrays) and never twice: a compute_derivatives without a
-            # solve before it assembles as always.
+            # solve before it assembles as always.  Round 6: only once this operation HAS been asked for
+            # its derivatives -- a forward-only evaluation (no compute_derivatives ever) neither assembles nor keeps them.
             self._early_done = False
             if defer and getattr(res, 'constant_partials', False) and getattr(fea, 'early_linearisation', _EARLY_DEFAULT) \
+                    and getattr(self, '_derivatives_requested', False) \
                     and self.state['dR_du'] is None and self.state['dR_df_list'] is None:
                 self._linearise()
                 if hasattr(self.A, 'mat') and KSP_OPTIONS.get('pc') in ('bpx', 'jacobi'):
@@ -143,7 +145,10 @@ class StateOperation(CustomImplicitOperation):
         """Assembles and keeps: dRdu and dRdf[arg] with NO Dirichlet elimination, A with it
         (state_model.py:117-158).  dRdu and A come out of one pass over the mesh."""
         self._load(inputs, outputs)
+        self._derivatives_requested = True                 # from the next solve on the constant partials are assembled early
         if getattr(self, '_early_done', False):            # assembled under the upload of this cycle's input (solve_residual_equations)
+            # valid only because these partials depend on neither the inputs nor the state
+            assert getattr(self.state['residual_form'], 'constant_partials', False), "early linearisation of a form whose partials are not constant"
             self._early_done = False
             return
         self._linearise()

@@ -794,11 +794,23 @@ int femo_comm_init(femo_ctx* ctx, const char id[128], int rank, int nranks) {
   FEMO_NCCL_CHECK(ncclCommInitRank(&ctx->comm, nranks, u, rank));
   ctx->rank = rank;
   ctx->nranks = nranks;
-  // second communicator for the neighbour exchanges (femo_internal.h: comm_halo); collective: every rank calls it here
+  // Second communicator for the neighbour exchanges (femo_internal.h: comm_halo).  OPT-IN (FEMO_SPLIT_COMM=1) until a
+  // multi-GPU run has exercised halo traffic on one communicator concurrently with the all-reduce on another (ADVICE
+  // round 5): the default is the single communicator, on which RCCL orders the two streams' operations itself.  When
+  // asked for, the decision is COLLECTIVE: every rank calls the split, the ranks all-reduce "my split worked" over
+  // `comm`, and comm_halo is used only if it worked everywhere -- a rank that fell back on its own while its peers sent
+  // on comm_halo would hang the job.
   ctx->comm_halo = nullptr;
-  if (!femo_env_flag("FEMO_SINGLE_COMM")) {
+  if (femo_env_flag("FEMO_SPLIT_COMM") && !femo_env_flag("FEMO_SINGLE_COMM")) {
     ncclComm_t split = nullptr;
-    if (ncclCommSplit(ctx->comm, 0, rank, &split, nullptr) == ncclSuccess && split != nullptr) ctx->comm_halo = split;
+    const bool ok = ncclCommSplit(ctx->comm, 0, rank, &split, nullptr) == ncclSuccess && split != nullptr;
+    ctx->h_scal[0] = ok ? 0.0 : 1.0;                          // number of ranks whose split failed
+    FEMO_HIP_CHECK(hipMemcpyAsync(ctx->d_scal, ctx->h_scal, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    FEMO_NCCL_CHECK(ncclAllReduce(ctx->d_scal, ctx->d_scal, 1, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+    FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    FEMO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_scal[0] == 0.0) ctx->comm_halo = split;
+    else if (ok) ncclCommDestroy(split);
   }
   return 0;
 }

@@ -642,7 +642,8 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat
       }
       sum += w * e[node_index(lat.n, ijk[0], ijk[1], ijk[2])];
     }
-    const double z = rh[v] + sum * (double)sinv[v];          // the same rounded 1/s the restriction multiplies with (k_pc_weights)
+    const float si = sinv[v];                               // the same rounded 1/s the restriction multiplies with (k_pc_weights)
+    const double z = si == 0.0f ? rh[v] : rh[v] + sum * (double)si;   // pinned rows stay r even if the correction is not finite
     return mode == 1 ? z + beta * out[v] : z;
   };
   const int64_t stride = (int64_t)gridDim.x * FEMO_BLOCK;
@@ -2294,6 +2295,13 @@ int femo_pc_merged_begin(femo_mesh* m, const double* s, const uint8_t* mask) {
   z.p[0] = first; z.n[0] = count;
   z.p[1] = pc->g_alt; z.n[1] = count;
   z.p[2] = pc->gs; z.n[2] = pc->gs_n;
+  if (ctx->nranks > 1 && pc->d_mbuf != nullptr) {
+    // the scalar tail of the all-reduce buffer: k_pack_merged ADDS the three single-rank lattice sums into it and relies on
+    // the coarse kernel of the same application to clear them again -- a solve that ended between the two (failed
+    // collective, an early return) must not leak its sums into the next one
+    z.p[3] = pc->d_mbuf + pc->n_mshared + pc->L[T - 1].nodes; z.n[3] = MS_NRED;
+    z.count = 4;
+  }
   hipLaunchKernelGGL(k_zero_regions, dim3(lat_grid(std::max(count, pc->gs_n))), dim3(256), 0, st, z);
   FEMO_HIP_CHECK(hipGetLastError());
   pc->parity = 0;
@@ -2391,7 +2399,10 @@ int femo_pc_merged_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, c
     // the flattened chain (k_lattice_coarse_m: mc.flat): x- and y-pass outputs of ALL levels below T-1 at once
     int64_t flat_need = 0;
     const int top = T - 1;
-    if (top >= 1 && top <= 4 && !femo_env_flag("FEMO_BPX_CHAIN")) {
+    // (the z-pass of the flattened chain reads the prefetched coefficient of node `tid`: one trip per level, i.e. every level
+    // below T-1 must have at most 1024 nodes -- true for the m0 in {2, 3} doubling lattices with TOP_MAX = 5120; checked here)
+    const bool one_trip = top >= 1 && pc->L[top - 1].nodes <= 1024;
+    if (top >= 1 && top <= 4 && one_trip && !femo_env_flag("FEMO_BPX_CHAIN")) {
       const int* nt = pc->L[top].n;
       for (int k = 1; k <= top; ++k) {
         const int* nc = pc->L[top - k].n;

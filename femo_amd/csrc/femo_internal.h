@@ -123,8 +123,9 @@ struct femo_ctx {
   ncclComm_t comm = nullptr;
   // The neighbour exchanges (ncclSend/ncclRecv on the comm stream, overlapped with the interior SpMV) have a communicator
   // of their own (ncclCommSplit of `comm`, round 5): RCCL serialises the operations of ONE communicator, so on a shared
-  // one the halo exchange of iteration k+1 and the all-reduce of iteration k could not be in flight together.  Falls back
-  // to `comm` when the split fails.
+  // one the halo exchange of iteration k+1 and the all-reduce of iteration k could not be in flight together.  Opt-in
+  // (FEMO_SPLIT_COMM=1, round 6) and agreed on collectively in femo_comm_init: null on EVERY rank unless the split worked on
+  // every rank; the default is the single communicator.
   ncclComm_t comm_halo = nullptr;
   struct femo_emu_group* emu = nullptr;      // in-process rank emulation (tests; comm.cpp)
   bool model = false;                        // femo_comm_model: N-rank code paths, collectives complete without moving data

@@ -28,8 +28,12 @@ int femo_pc_make_plan(int dim, int64_t n_rows, const double* x, const double* lo
   const double target = std::max(2.0, ext_max / (spacing * h));
   int best_m0 = 2, best_lv = 1;
   double best = 1e300;
+  // 3-D: the 8-byte packed coordinates hold 9 bits of bin per axis, so the finest lattice is capped at 384 = 3 * 2^7 bins
+  // on its longest axis; a finer mesh (beyond ~800^3 vertices) gets a coarser mesh-to-lattice ratio instead of an error
+  const int max_bins = dim == 3 ? (1 << (FEMO_PK3_FIELD - FEMO_PK3_BITS)) - 1 : (1 << (32 - FEMO_PK_BITS)) - 1;
   for (int m0 = 2; m0 <= 3; ++m0)
     for (int lv = 1; lv <= 12; ++lv) {
+      if ((m0 << (lv - 1)) > max_bins) continue;
       const double score = std::fabs(std::log(m0 * std::ldexp(1.0, lv - 1) / target));
       if (score < best) { best = score; best_m0 = m0; best_lv = lv; }
     }

@@ -53,8 +53,11 @@ def choose_lattice(lo: np.ndarray, hi: np.ndarray, n_vert_global: int, spacing: 
     h = (float(np.prod(ext)) / float(n_vert_global)) ** (1.0 / dim)
     target = max(2.0, ext_max / (spacing * h))
     best, best_m0, best_lv = 1e300, 2, 1
+    max_bins = (1 << 9) - 1 if dim == 3 else (1 << (32 - PK_BITS)) - 1      # bin fields of the packed coordinates
     for m0 in (2, 3):
         for lv in range(1, 13):
+            if (m0 << (lv - 1)) > max_bins:
+                continue
             score = abs(math.log(m0 * 2.0 ** (lv - 1) / target))
             if score < best:
                 best, best_m0, best_lv = score, m0, lv

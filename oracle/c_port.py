@@ -21,6 +21,53 @@ def build() -> str:
     return _LIB_PATH
 
 
+def _cpu_signature() -> str:
+    """Model name + instruction-set flags of the first core: what a -march=native build depends on."""
+    try:
+        model = flags = ""
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name") and not model:
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("flags") and not flags:
+                    flags = " ".join(sorted(line.split(":", 1)[1].split()))
+                if model and flags:
+                    break
+        import hashlib
+        return model + " " + hashlib.sha1(flags.encode()).hexdigest()
+    except Exception:
+        return "unknown"
+
+
+def use_native() -> bool:
+    """Build the port for THIS host's CPU (``make native``) and use that library from now on -- bench.py's cpu_baseline leg
+    calls this on the GPU box so the baseline is not held back by the portable x86-64-v3 build that travels with the
+    snapshot.  The native library is rebuilt unless a sidecar file says it was built on a CPU with the same model and flags
+    (a -march=native object from another machine may use instructions this one lacks).  Returns False (and keeps the
+    portable library) when it cannot be built or the portable one was loaded already."""
+    global _LIB_PATH
+    if _lib is not None:
+        return _LIB_PATH.endswith("_native.so")
+    native = os.path.join(_HERE, "libfemo_oracle_native.so")
+    stamp = native + ".cpu"
+    try:
+        src = os.path.join(_HERE, "femo_oracle_c.c")
+        sig = _cpu_signature()
+        fresh = (os.path.exists(native) and os.path.exists(stamp) and open(stamp).read() == sig and sig != "unknown"
+                 and os.path.getmtime(native) >= os.path.getmtime(src))
+        if not fresh:
+            if os.path.exists(native):
+                os.remove(native)
+            subprocess.run(["make", "-s", "-C", _HERE, "native"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            with open(stamp, "w") as fh:
+                fh.write(sig)
+        C.CDLL(native)
+    except Exception:
+        return False
+    _LIB_PATH = native
+    return True
+
+
 def lib():
     global _lib
     if _lib is None:

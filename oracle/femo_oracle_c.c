@@ -357,8 +357,10 @@ oc_bpx* oc_bpx_create(int d, int64_t n_vert, const double* x, const uint8_t* pin
   if (target < 2.0) target = 2.0;
   int best_m0 = 2, best_lv = 1;
   double best = 1e300;
+  const int max_bins = d == 3 ? 511 : 4095;         /* the packed coordinates' bin fields (femo_amd/csrc/pc_plan.cpp) */
   for (int m0 = 2; m0 <= 3; ++m0)
     for (int lv = 1; lv <= 12; ++lv) {
+      if ((m0 << (lv - 1)) > max_bins) continue;
       const double score = fabs(log(m0 * ldexp(1.0, lv - 1) / target));
       if (score < best) { best = score; best_m0 = m0; best_lv = lv; }
     }

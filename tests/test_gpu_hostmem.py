@@ -543,9 +543,16 @@ def test_early_linearisation_is_the_same_cycle(ctx):
             sim, fea = build_problem(mesh, device=False)
             fea.early_linearisation = early
             u0 = E.pinned_full(mesh.n_vert, 0.0)
-            one_cycle(sim, fea, E.pinned_array(fs[0]), u0)
-            g = one_cycle(sim, fea, E.pinned_array(fs[1]), u0)
             op = [o for _, o in sim.ops if hasattr(o, 'apply_inverse_jacobian')][0]
+            if early:
+                # round 6: a forward-only evaluation linearises nothing -- the early path starts with the
+                # first solve AFTER derivatives have been asked for once
+                sim['f'] = E.pinned_array(fs[0]); sim['u'] = u0
+                sim.run()
+                assert getattr(op, 'A', None) is None and not getattr(op, '_early_done', False)
+            one_cycle(sim, fea, E.pinned_array(fs[0]), u0)
+            assert not getattr(op, '_early_done', False)
+            g = one_cycle(sim, fea, E.pinned_array(fs[1]), u0)
             out[early] = (np.array(E.host_wait(sim['u']), copy=True), np.array(E.host_wait(g), copy=True),
                           float(np.asarray(sim['l2_functional']).ravel()[0]), op)
             if early:

@@ -207,13 +207,17 @@ def test_pc_plan_host_errors():
     x = np.array([[0.0, 0.0], [1.0, 0.0], [2.0, 0.0]])           # all on a line: degenerate box in y
     with pytest.raises(FemoError, match="degenerate bounding box"):
         E.pc_plan_host(x)
-    # 3-D packed coordinates hold 9 bits of bin per axis (round 5: three 21-bit fields in one 64-bit word): a lattice finer than
-    # 511 bins -- a mesh of ~2e9 vertices -- is refused, not silently wrapped
+    # 3-D packed coordinates hold 9 bits of bin per axis (round 5: three 21-bit fields in one 64-bit word).  Round 6 (ADVICE
+    # round 5): a mesh that would ask for 512 bins or more -- ~1e9 vertices -- gets the finest lattice that fits (384 bins, a
+    # coarser mesh-to-lattice ratio) instead of an error; the NumPy restatement makes the same choice
+    from oracle import bpx_oracle as bo
     g = np.linspace(0.0, 1.0, 4)
     x3 = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
-    assert E.pc_plan_host(x3, n_vert_global=5 * 10 ** 8)["bins"][-1].max() == 384
-    with pytest.raises(FemoError, match="too fine for packed coordinates"):
-        E.pc_plan_host(x3, n_vert_global=2 * 10 ** 9)
+    for nvg in (5 * 10 ** 8, 2 * 10 ** 9, 10 ** 11):
+        bins = E.pc_plan_host(x3, n_vert_global=nvg)["bins"]
+        assert bins[-1].max() == 384
+        ob, _ = bo.choose_lattice(np.zeros(3), np.ones(3), nvg)
+        assert len(ob) == len(bins) and list(ob[-1]) == list(bins[-1])
 
 
 def test_lattice_occupancy_flags_graded_meshes():
