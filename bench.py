@@ -489,7 +489,7 @@ def bench_unstructured(ctx, n: int, steps: int = 3) -> dict:
     rec = {"workload": f"the headline's cycle on the n={n} cube with random vertex / cell numbering renumbered by Mesh.reordered() (Morton curve), "
                        f"{mesh.n_vert} DOFs: the rate of an imported unstructured mesh; host boundary",
            "n_dof": mesh.n_vert, "steps": steps, "ms_per_cycle": ms, "dofs_per_s": mesh.n_vert / (ms * 1e-3), "setup_s": setup_s,
-           "cg_iterations_per_cycle": [i["iterations"] for i in infos[:per]],
+           "cg_iterations_per_cycle": [i["iterations"] for i in infos[:per]], "cg_ms_per_cycle": sum(i["solve_ms"] for i in infos) / steps,
            "sell_slices": dm.info["n_slices"], "regular_slices": dm.info["regular_slices"], "short_slices": dm.info.get("short_slices", 0),
            "roofline": _roofline("k_spmv_sell<1,true>", spmv_algorithmic_bytes(nnz, mesh.n_vert), spmv_ms, ns,
                                  "general slices: 16- or 32-bit column indices are fetched, x is gathered through L2 / Infinity Cache",

@@ -37,6 +37,33 @@ def test_two_rank_bench_over_rccl():
     assert r["check"]["u_rel_err"] < 1e-10 and r["check"]["grad_rel_err"] < 1e-10
 
 
+@pytest.mark.parametrize("world", [4, 8])
+def test_rank_ladder_bench_over_rccl(world):
+    """Round 6: the rest of the ladder -- `bench.py --gpus 4` and `--gpus 8` under torchrun, real
+    RCCL over xGMI -- so that the first multi-GPU box runs 2, 4 and 8 ranks unattended.  n = 64: every rank of the 1 x 2 x 4
+    pencils keeps >= 16 x-lines per cut direction and the whole mesh's lattice has the depth the merged loop needs.  The
+    one-GPU iteration counts must be reproduced (the partition does not change the Krylov iteration), one all-reduce per
+    iteration, and the run checks itself against the DST-exact cycle of the whole mesh."""
+    from femo_amd import _lib
+    if _lib.device_count() < world:
+        pytest.skip(f"needs {world} GPUs")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--mesh-n", "64", "--steps", "3",
+                        "--warmup", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    c = r["config"]
+    assert r["n_gpus"] == world and c["n_dof"] == 65 ** 3 and sum(c["owned_per_rank"]) == 65 ** 3
+    assert len(c["owned_per_rank"]) == world and max(c["neighbours_per_rank"]) <= 8
+    its = c["cg_iterations_per_step"]
+    assert c["linear_solves_per_step"] == 4 and 10 < its[0] <= 40 and its[1] <= 2 and its[2] <= 2 and 10 < its[3] <= 40
+    assert 1.0 <= c["allreduce_per_cg_iteration"] <= 1.3, c["allreduce_per_cg_iteration"]
+    assert r["check"]["passed"] and r["check"]["u_rel_err"] < 1e-10 and r["check"]["grad_rel_err"] < 1e-10
+    assert r["checks_passed"] is True
+
+
 def test_two_rank_shell_over_rccl():
     """The partitioned shell (femo_shell_set_partition) with real ncclSend/ncclRecv + ncclAllReduce: tests/_shell_rccl_worker.py
     on two GPUs against the oracle's direct solve and exact adjoint gradient."""
