@@ -424,7 +424,9 @@ def bench_config2(ctx, steps: int) -> dict:
         g = one_cycle(sim, fea, fs[k % 3], u0)
     ctx.sync()
     del utils_hip.LAST_KSP_INFO[:]
+    E.host_syncs(reset=True)
     ms, g = _timed_cycles(ctx, lambda k: one_cycle(sim, fea, fs[k % 3], u0), steps, 0)
+    host_syncs = (E.host_syncs() - 1) / steps
     infos = list(utils_hip.LAST_KSP_INFO)
     per = len(infos) // steps
     spmv_ms, ns = _spmv_in_loop(infos)
@@ -440,7 +442,7 @@ def bench_config2(ctx, steps: int) -> dict:
     rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
     rec = {"workload": f"3-D linear Poisson, unit cube n={n}: {mesh.n_vert} DOFs, nnz {nnz}; the headline's operator cycle (host boundary, BPX-CG)",
            "n_dof": mesh.n_vert, "steps": steps, "ms_per_cycle": ms, "dofs_per_s": mesh.n_vert / (ms * 1e-3),
-           "cg_iterations_per_cycle": [i["iterations"] for i in infos[:per]],
+           "cg_iterations_per_cycle": [i["iterations"] for i in infos[:per]], "host_syncs_per_cycle": host_syncs,
            "roofline": _roofline("k_spmv_sell<1,true>", spmv_algorithmic_bytes(nnz, mesh.n_vert), spmv_ms, ns,
                                  "the matrix of this size (~140 MB stored) sits in the 256 MB Infinity Cache: an HBM fraction means little here",
                                  stored=stored_bytes(dm.info, mesh.n_vert), traffic_key="spmv_n100"),
@@ -726,7 +728,9 @@ def _block_leg(ctx, mesh, steps: int) -> dict:
     ctx.sync()
     del utils_hip.LAST_KSP_INFO[:]
     ctx.comm_stats(reset=True)
+    E.host_syncs(reset=True)
     ms, _ = _timed_cycles(ctx, lambda k: one_cycle(sim, fea, fs[k % 3], u0), steps, 0)
+    host_syncs = (E.host_syncs() - 1) / steps
     comm = ctx.comm_stats()
     infos = list(utils_hip.LAST_KSP_INFO)
     per = len(infos) // steps
@@ -739,6 +743,7 @@ def _block_leg(ctx, mesh, steps: int) -> dict:
     lat = dm.pc_info()
     out = {"n_vert": int(mesh.n_vert), "ms_per_cycle": ms, "cg_iterations_per_cycle": its, "cg_ms_per_cycle": cg_ms,
            "non_cg_ms_per_cycle": ms - cg_ms, "us_per_cg_iteration_wall": us_per_it, "spmv_us": spmv_ms * 1e3 if ns else None,
+           "host_syncs_per_cycle": host_syncs, "halo": dm.halo_direct_info() if hasattr(dm, "halo_direct_info") else None,
            "pc_lattice": lat,
            "collectives_per_cycle": {k: v / steps for k, v in comm.items()},
            "allreduce_per_cg_iteration": sum(i.get("loop_allreduces", 0) for i in infos) / n_it,
@@ -820,7 +825,10 @@ def bench_scaling_model(ctx, n_global: int, steps: int, headline_ms: float, head
             "ms_per_cycle_measured_on_the_model_problem": ms_measured,
             "cg_iterations_per_cycle": leg["cg_iterations_per_cycle"], "cg_ms_per_cycle": leg["cg_ms_per_cycle"],
             "non_cg_ms_per_cycle": leg["non_cg_ms_per_cycle"],
-            "us_per_cg_iteration_wall": us_per_it, "spmv_us": leg["spmv_us"],
+            "us_per_cg_iteration_wall": us_per_it, "spmv_us": leg["spmv_us"], "host_syncs_per_cycle": leg["host_syncs_per_cycle"],
+            "ghost_refresh": ("device-initiated (stores into the neighbours' inboxes + counters, include/femo_hip.h ABI 9; here against the rank's own scratch: "
+                              "loopback of the model communicator)" if (leg.get("halo") or {}).get("enabled") else "ncclSend/ncclRecv-shaped (comm stream + events)"),
+            "ghost_refresh_info": leg.get("halo"),
             "launches_per_cg_iteration": {"one_rank": 5, "n_ranks": 7 + 1, "kernels": "halo pack (communication stream), SpMV over the interior slices, SpMV over the boundary slices, brick "
                                           "restriction of q, pack (shared lattice nodes of three levels + R h_T + 7 scalars), coarse lattice + vector updates (reads the "
                                           "reduced buffer in place: round 4's unpack launch is gone), fine lattice (own tiles), mesh prolongation + direction update"},
@@ -1242,7 +1250,9 @@ def _run(args):
     ctx.sync()
     del utils_hip.LAST_KSP_INFO[:]
     E.host_stats(reset=True)
+    E.host_syncs(reset=True)
     ms_per_step, g = _timed_cycles(ctx, lambda k: host_cycle(W + k), K, 0)   # never the source of the step before
+    host_syncs = (E.host_syncs() - 1) / max(K, 1)                            # (- the ctx.sync() that ends the timed region)
     if not isinstance(g, np.ndarray) and K:
         raise SystemExit("bench: the host-boundary cycle must return a NumPy gradient")
     infos = list(utils_hip.LAST_KSP_INFO)
@@ -1312,6 +1322,9 @@ def _run(args):
             "sell_slices": dm.info["n_slices"], "regular_slices": dm.info["regular_slices"], "short_slices": dm.info.get("short_slices", 0),
             "linear_solves_per_step": per, "cg_iterations_per_step": its_per_step, "cg_ms_per_step": cg_ms,
             "non_cg_ms_per_step": ms_per_step - cg_ms, "setup_s": setup_s,
+            # blocking waits of the host on the device inside the library per cycle (femo_host_sync_stats): each is an idle
+            # device for one host round trip (20-50 us) -- what the cycles of small meshes / of one rank of eight are made of
+            "host_syncs_per_step": host_syncs,
             # SURVEY.md section 8(d) split: Newton's linear solves / the transposed (adjoint) solve /
             # host<->device traffic and host-side passes / the rest (assembly, functional, dR/df^T lambda)
             "split_ms_per_step": {"forward_solves": fwd_ms, "adjoint_solve": adj_ms,

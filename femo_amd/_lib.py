@@ -19,7 +19,7 @@ c_i64p = C.POINTER(C.c_int64)
 c_f64p = C.POINTER(C.c_double)
 H = C.c_void_p  # opaque handle
 
-ABI_VERSION = 8            # include/femo_hip.h FEMO_ABI_VERSION
+ABI_VERSION = 9            # include/femo_hip.h FEMO_ABI_VERSION
 MESH_INFO_COUNT = 12
 MESH_INFO_KEYS = ("tdim", "n_vert", "n_rows", "n_cell", "nnz", "sell_entries", "max_rowlen",
                   "max_valence", "n_slices", "visit_entries", "regular_slices", "short_slices")
@@ -56,6 +56,7 @@ class HostStats(C.Structure):
 PROTOTYPES = {
     "femo_last_error": (C.c_char_p, []),
     "femo_abi_version": (C.c_int, []),
+    "femo_host_sync_stats": (C.c_int, [C.POINTER(C.c_int64), C.c_int]),
     "femo_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "femo_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(H)]),
     "femo_ctx_destroy": (C.c_int, [H]),
@@ -178,6 +179,11 @@ PROTOTYPES = {
     "femo_comm_rank": (C.c_int, [H, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "femo_mesh_set_halo": (C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "femo_halo_exchange": (C.c_int, [H, H]),
+    "femo_mesh_halo_direct_export": (C.c_int, [H, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
+    "femo_mesh_halo_direct_connect": (C.c_int, [H, C.c_int, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "femo_mesh_halo_direct_selftest": (C.c_int, [H, C.POINTER(C.c_int)]),
+    "femo_mesh_halo_direct_enable": (C.c_int, [H, C.c_int]),
+    "femo_mesh_halo_direct_info": (C.c_int, [H, C.POINTER(C.c_int64)]),
     "femo_allreduce_sum": (C.c_int, [H, c_f64p, C.c_int]),
 }
 

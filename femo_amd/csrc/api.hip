@@ -7,6 +7,8 @@
 
 #include "femo_internal.h"
 
+std::atomic<long long> femo_host_sync_count{0};
+
 namespace {
 
 __global__ void k_fill(int64_t n, double v, double* __restrict__ x) {
@@ -161,6 +163,13 @@ int femo_launch_scale(double* out, double a, const double* x, int64_t n, hipStre
 extern "C" {
 
 int femo_abi_version(void) { return FEMO_ABI_VERSION; }
+
+int femo_host_sync_stats(int64_t* count, int reset) {
+  FEMO_REQUIRE(count != nullptr, "null argument");
+  *count = (int64_t)femo_host_sync_count.load(std::memory_order_relaxed);
+  if (reset) femo_host_sync_count.store(0, std::memory_order_relaxed);
+  return 0;
+}
 
 int femo_device_count(int* n) {
   FEMO_REQUIRE(n != nullptr, "null argument");
@@ -375,6 +384,7 @@ int femo_mesh_destroy(femo_mesh* m) {
   hipFree(m->d_x); hipFree(m->d_conn); hipFree(m->d_vptr); hipFree(m->d_visit_cell);
   hipFree(m->d_visit_slots); hipFree(m->d_mptr); hipFree(m->d_cols); hipFree(m->d_rowlen); hipFree(m->d_rowreal);
   femo_pc_destroy(m);
+  femo_halo_direct_free(m);
   hipFree(m->d_bvmask); hipFree(m->d_visit_rec); hipFree(m->d_load); hipFree(m->d_zero_load); hipFree(m->d_pipe_dummy); hipFree(m->d_ubc);
   if (m->mass) { femo_mat_destroy(m->mass); m->mass = nullptr; }
   hipFree(m->d_mass_e); hipFree(m->d_mass_g); hipFree(m->d_cellvol); hipFree(m->d_cellvol_own); hipFree(m->d_cell_t);
@@ -831,6 +841,7 @@ int femo_mesh_set_halo(femo_mesh* m, int n_nbr, const int32_t* nbr, const int64_
   m->d_send_uvert = m->d_send_uptr = m->d_send_uslot = nullptr; m->d_send_flag = nullptr; m->n_send_verts = 0;
   m->d_send_idx = nullptr; m->d_send_buf = nullptr; m->d_slices_int = m->d_slices_bnd = nullptr;
   m->n_int = m->n_bnd = 0;
+  femo_halo_direct_free(m);                 // a direct plan belongs to the halo plan it was connected for
   m->n_nbr = n_nbr;
   m->nbr.assign(nbr, nbr + n_nbr);
   m->send_ptr.assign(send_ptr, send_ptr + n_nbr + (n_nbr ? 1 : 0));
@@ -872,7 +883,18 @@ int femo_mesh_set_halo(femo_mesh* m, int n_nbr, const int32_t* nbr, const int64_
     FEMO_HIP_CHECK(hipMemcpy(m->d_send_flag, flag.data(), flag.size(), hipMemcpyHostToDevice));
   }
   // slices without ghost columns can be multiplied while the halo is in flight
-  return femo_mesh_classify_slices(m);
+  FEMO_TRY(femo_mesh_classify_slices(m));
+  // The model communicator (femo_comm_model) has no peers to connect to: its device-initiated ghost refresh runs against
+  // the rank's own scratch (loopback) -- the same producer stores, counter bumps and consumer waits as a real rank, no
+  // wire.  FEMO_HALO_RCCL=1 keeps the model on the ncclSend/Recv-shaped path (comparison runs).
+  if (m->ctx->model && n_nbr <= FEMO_MAX_NBR && !femo_env_flag("FEMO_HALO_RCCL")) {
+    char handle[64]; uint64_t addr = 0; int32_t nb = 0; int ok = 0;
+    FEMO_TRY(femo_mesh_halo_direct_export(m, handle, &addr, &nb));
+    FEMO_TRY(femo_mesh_halo_direct_connect(m, 2, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+    FEMO_TRY(femo_mesh_halo_direct_selftest(m, &ok));
+    FEMO_TRY(femo_mesh_halo_direct_enable(m, ok));
+  }
+  return 0;
 }
 
 int femo_allreduce_sum(femo_ctx* ctx, double* host_inout, int n) {

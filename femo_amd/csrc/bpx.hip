@@ -539,6 +539,10 @@ struct MergedScal {
 struct HaloFirst {
   int64_t n_verts; const int32_t* verts; const int32_t* slot_ptr; const int32_t* slots; double* send_buf;   // first launch
   const uint8_t* skip;                                                                                        // second launch
+  // round 6, device-initiated refresh: the first launch stores the new direction of a send vertex straight into the
+  // neighbours' inboxes (no send buffer) and every workgroup of it bumps their counters on its way out -- also when
+  // the solve has converged and it has nothing to store (femo_internal.h: FemoHaloDirect)
+  const FemoHaloPeers* peers; unsigned long long epoch;
 };
 template <int D>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat lat, const uint32_t* __restrict__ pk,
@@ -549,7 +553,11 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat
                                                              int nb_rho, const double* __restrict__ rho_partials, double* __restrict__ rho,
                                                              const double* __restrict__ gamma_cur, double* __restrict__ gamma_nxt,
                                                              const int32_t* __restrict__ done, PcgStop st, MergedScal ms, HaloFirst hf) {
-  if (done != nullptr && *done) return;
+  const bool signals = hf.n_verts > 0 && hf.peers != nullptr;       // this launch is the producer of a ghost refresh
+  if (done != nullptr && *done) {
+    if (signals) femo_halo_signal(hf.peers);
+    return;
+  }
   __shared__ double lds[2 * (FEMO_BLOCK / 64)];
   double beta = 0.0;
   if (mode != 0) {
@@ -614,6 +622,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat
             __threadfence();
             st.flags[0] = st.it + 1;
           }
+          if (signals) femo_halo_signal(hf.peers);
           return;
         }
         if (first) st.flags[1] = st.it + 1;
@@ -652,9 +661,14 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat
     if (hf.skip != nullptr && hf.skip[v]) continue;
     const double pv = direction(v);
     out[v] = pv;
-    if (hf.n_verts > 0)
-      for (int32_t q = hf.slot_ptr[w_i]; q < hf.slot_ptr[w_i + 1]; ++q) hf.send_buf[hf.slots[q]] = pv;
+    if (hf.n_verts > 0) {
+      if (hf.peers != nullptr)
+        for (int32_t q = hf.slot_ptr[w_i]; q < hf.slot_ptr[w_i + 1]; ++q) femo_halo_store(hf.peers, hf.epoch, hf.slots[q], pv);
+      else
+        for (int32_t q = hf.slot_ptr[w_i]; q < hf.slot_ptr[w_i + 1]; ++q) hf.send_buf[hf.slots[q]] = pv;
+    }
   }
+  if (signals) femo_halo_signal(hf.peers);
 }
 
 // coarse[I] = sum over the fine nodes 2I-1, 2I, 2I+1 (per axis) with weights 1/2, 1, 1/2
@@ -2275,7 +2289,7 @@ bool femo_pc_merged_ok(femo_mesh* m) {
 int femo_pc_merged_collectives(const femo_mesh* m) { return m->ctx->nranks > 1 ? 1 : 0; }
 
 // start of a solve with the merged loop: weights of the current operator, clean accumulators, zero state
-int femo_pc_merged_begin(femo_mesh* m, const double* s, const uint8_t* mask) {
+int femo_pc_merged_begin(femo_mesh* m, const double* s, const uint8_t* mask, const FemoZeroExtra* extra) {
   femo_pc* pc = m->pc;
   femo_ctx* ctx = m->ctx;
   const hipStream_t st = ctx->stream;
@@ -2302,6 +2316,11 @@ int femo_pc_merged_begin(femo_mesh* m, const double* s, const uint8_t* mask) {
     z.p[3] = pc->d_mbuf + pc->n_mshared + pc->L[T - 1].nodes; z.n[3] = MS_NRED;
     z.count = 4;
   }
+  // the caller's small fills (ghost tails of the Krylov vectors on a partitioned mesh) ride along: round 5's set-up issued
+  // them as three memsets of 5 us each, one launch + one gap apiece
+  if (extra != nullptr)
+    for (int k = 0; k < extra->count && z.count < 8; ++k)
+      if (extra->p[k] != nullptr && extra->n[k] > 0) { z.p[z.count] = extra->p[k]; z.n[z.count] = extra->n[k]; ++z.count; }
   hipLaunchKernelGGL(k_zero_regions, dim3(lat_grid(std::max(count, pc->gs_n))), dim3(256), 0, st, z);
   FEMO_HIP_CHECK(hipGetLastError());
   pc->parity = 0;
@@ -2480,13 +2499,23 @@ int femo_pc_merged_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, c
     // the interface vertices first, straight into the send buffer; the exchange of the new direction then travels on the
     // communication stream under the bulk of the prolongation and the interior slices of the next SpMV (solver.hip:
     // femo_halo_spmv_inflight waits for it before the boundary slices)
-    HaloFirst h1 = {m->n_send_verts, m->d_send_uvert, m->d_send_uptr, m->d_send_uslot, m->d_send_buf, nullptr};
-    prolong((unsigned)std::max<int64_t>(1, std::min<int64_t>((m->n_send_verts + FEMO_BLOCK - 1) / FEMO_BLOCK, V.gv)), h1);
-    FEMO_HIP_CHECK(hipEventRecord(ctx->ev_main, st));
-    FEMO_HIP_CHECK(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_main, 0));
-    FEMO_TRY(femo_coll_neighbors(ctx, m->n_nbr, m->nbr.data(), m->send_ptr.data(), m->d_send_buf, m->recv_ptr.data(), V.p + m->n_rows, ctx->comm_stream));
-    FEMO_HIP_CHECK(hipEventRecord(ctx->ev_comm, ctx->comm_stream));
-    HaloFirst h2 = {0, nullptr, nullptr, nullptr, nullptr, m->d_send_flag};
+    if (femo_halo_direct_ready(m)) {
+      // device-initiated (round 6): the stores go to the neighbours' inboxes, the workgroups bump their counters; the
+      // consumer is the small pull launch in front of the next product's boundary slices (solver.hip: halo_spmv_inflight)
+      ++ctx->n_neighbor; ctx->neighbor_doubles += m->send_ptr[m->n_nbr];
+      const unsigned long long epoch = femo_halo_direct_begin(m);
+      m->hd->loop_epoch = epoch;
+      HaloFirst h1 = {m->n_send_verts, m->d_send_uvert, m->d_send_uptr, m->d_send_uslot, nullptr, nullptr, m->hd->d_peers, epoch};
+      prolong((unsigned)m->hd->n_blocks, h1);
+    } else {
+      HaloFirst h1 = {m->n_send_verts, m->d_send_uvert, m->d_send_uptr, m->d_send_uslot, m->d_send_buf, nullptr, nullptr, 0ull};
+      prolong((unsigned)std::max<int64_t>(1, std::min<int64_t>((m->n_send_verts + FEMO_BLOCK - 1) / FEMO_BLOCK, V.gv)), h1);
+      FEMO_HIP_CHECK(hipEventRecord(ctx->ev_main, st));
+      FEMO_HIP_CHECK(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_main, 0));
+      FEMO_TRY(femo_coll_neighbors(ctx, m->n_nbr, m->nbr.data(), m->send_ptr.data(), m->d_send_buf, m->recv_ptr.data(), V.p + m->n_rows, ctx->comm_stream));
+      FEMO_HIP_CHECK(hipEventRecord(ctx->ev_comm, ctx->comm_stream));
+    }
+    HaloFirst h2 = {0, nullptr, nullptr, nullptr, nullptr, m->d_send_flag, nullptr, 0ull};
     prolong((unsigned)V.gv, h2);
   } else {
     prolong((unsigned)V.gv, HaloFirst{});

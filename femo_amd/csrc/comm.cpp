@@ -101,6 +101,15 @@ int emu_neighbors(femo_ctx* ctx, int n_nbr, const int32_t* nbr, const int64_t* s
 
 }  // namespace
 
+// Emulated ranks meet on the host: everything this rank enqueued on `st` has completed when the barrier opens
+// (halo_direct.hip: between the producer and the consumer half of a device-initiated ghost refresh).
+int femo_emu_rendezvous(femo_ctx* ctx, hipStream_t st) {
+  if (ctx->emu == nullptr) return 0;
+  FEMO_HIP_CHECK(hipStreamSynchronize(st));
+  FEMO_REQUIRE(emu_barrier(ctx->emu, [] {}) == 0, "emulated ghost refresh: a rank did not arrive");
+  return 0;
+}
+
 // d[0..count) <- sum over the ranks, in place, ordered on `st`
 int femo_coll_allreduce(femo_ctx* ctx, double* d, int64_t count, hipStream_t st) {
   if (count <= 0) return 0;

@@ -18,6 +18,20 @@
 // ---------------------------------------------------------------- errors ----
 void femo_set_error(const char* fmt, ...);
 
+// ------------------------------------------------- host synchronisations ----
+// Every blocking wait of the host on the device inside the library is counted (femo_host_sync_stats, include/femo_hip.h;
+// bench.py reports host_syncs_per_step): each one is an idle device for the round trip -- 20-50 us -- which is what a
+// cycle on a small mesh or on one rank of eight is made of.  The three HIP entry points are
+// shadowed for the translation units of the library, which all include this header after hip_runtime.h.
+#include <atomic>
+extern std::atomic<long long> femo_host_sync_count;
+inline hipError_t femo_counted_stream_sync(hipStream_t s) { femo_host_sync_count.fetch_add(1, std::memory_order_relaxed); return hipStreamSynchronize(s); }
+inline hipError_t femo_counted_event_sync(hipEvent_t e) { femo_host_sync_count.fetch_add(1, std::memory_order_relaxed); return hipEventSynchronize(e); }
+inline hipError_t femo_counted_device_sync() { femo_host_sync_count.fetch_add(1, std::memory_order_relaxed); return hipDeviceSynchronize(); }
+#define hipStreamSynchronize(s) femo_counted_stream_sync(s)
+#define hipEventSynchronize(e) femo_counted_event_sync(e)
+#define hipDeviceSynchronize() femo_counted_device_sync()
+
 #define FEMO_HIP_CHECK(expr)                                                        \
   do {                                                                              \
     hipError_t e__ = (expr);                                                        \
@@ -271,6 +285,7 @@ struct femo_mesh {
   // slices without / with ghost columns (set with the halo plan)
   int32_t* d_slices_int = nullptr; int32_t* d_slices_bnd = nullptr;
   int64_t n_int = 0, n_bnd = 0;
+  struct FemoHaloDirect* hd = nullptr;   // device-initiated ghost refresh (round 6), see FemoHaloDirect
   // geometry of the whole (global) mesh for the BPX lattice; local values until femo_mesh_set_global
   double bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};
   int64_t n_vert_global = 0;
@@ -278,6 +293,78 @@ struct femo_mesh {
   uint64_t bfacets_version = 0;
   femo_pc* pc = nullptr;         // built on first use
 };
+
+// ---- device-initiated ghost refresh (round 6; halo_direct.hip) ------------------------------------------------------
+// Every rank owns an INBOX per mesh -- uncached device memory: two generations of one double per ghost vertex and one
+// 64-byte counter line per neighbour -- that its neighbours map (hipIpcOpenMemHandle between processes, the plain
+// address between the emulated ranks of one process).  A producer kernel stores the owned values a neighbour needs
+// straight into that neighbour's inbox and, workgroup by workgroup, bumps the neighbour's counter for this rank
+// (system-scope release); a consumer spins on its own counters until they reach epoch x (workgroups per exchange of
+// that neighbour) and reads its ghosts from its own inbox.  No send buffer, no pack launch, no second stream, no event
+// hop, no RCCL launch: the exchange is two kernels of the compute stream, or none where the producer is the kernel
+// that computes the values anyway (k_prolong_mesh of the merged BPX-PCG) .
+//   generation = epoch & 1: a rank may run ONE exchange ahead of a neighbour (it cannot finish exchange e + 1 before
+//   the neighbour has produced e + 1, which the neighbour's stream orders behind its own consumption of e), so two
+//   generations make overwriting unread ghosts impossible without any acknowledgement traffic.
+//   every producer of a mesh uses the same number of workgroups (n_blocks) and bumps even when it has nothing to do
+//   (a solve that converged before the launch ran): the counters stay epoch x n_blocks whatever the kernels decided.
+constexpr int FEMO_MAX_NBR = 32;
+constexpr int FEMO_HALO_CNT_STRIDE = 8;              // counters sit 64 bytes apart
+struct FemoHaloPeers {                               // lives in device memory (femo_mesh::hd->d_peers), read with scalar loads
+  int32_t n_nbr;
+  int32_t n_send;                                    // slots of the send list
+  int32_t send_ptr[FEMO_MAX_NBR + 1];                // slot ranges by neighbour
+  double* seg[FEMO_MAX_NBR];                         // neighbour k: start of this rank's segment in ITS inbox (generation 0)
+  int64_t stride[FEMO_MAX_NBR];                      // ... and the distance to generation 1 (its ghost count)
+  unsigned long long* cnt[FEMO_MAX_NBR];             // ... and its counter for this rank
+  const uint8_t* slot_nbr;                           // neighbour index of every send slot
+};
+struct FemoHaloDirect {
+  bool ready = false;
+  bool same_process = false, loopback = false;       // emulated ranks / the model communicator (own scratch as "peer")
+  void* inbox_raw = nullptr;                         // [2 x n_ghost doubles | pad | n_nbr counter lines]
+  double* inbox = nullptr;
+  unsigned long long* counters = nullptr;
+  int64_t n_ghost = 0;
+  int n_blocks = 0;                                  // workgroups (= counter bumps per neighbour) of this rank's producers
+  FemoHaloPeers* d_peers = nullptr;
+  int32_t* d_blocks = nullptr;                       // [n_nbr]: bumps per exchange of neighbour k's producers
+  uint8_t* d_slot_nbr = nullptr;
+  double* d_loop = nullptr;                          // loopback: absorbs the producer's stores
+  int32_t* d_err = nullptr;                          // set by a consumer that gave up waiting
+  unsigned long long epoch = 0;                      // exchanges issued on this mesh (host side; SPMD: the same on every rank)
+  unsigned long long loop_epoch = 0;                 // the exchange the merged BPX-PCG's last prolongation produced (consumed by the next product)
+  std::vector<void*> opened;                         // IPC mappings (closed with the mesh)
+  int64_t exchanges = 0;
+};
+struct femo_mesh;
+void femo_halo_direct_free(femo_mesh* m);
+bool femo_halo_direct_ready(const femo_mesh* m);
+// y[n_rows + i] <- the owners' x, through the inboxes, on `st`
+int femo_halo_direct_exchange(femo_mesh* m, const double* x_owned, double* ghost_tail, hipStream_t st);
+// consumer half only (the producer was another kernel: k_prolong_mesh), and the epoch bookkeeping of such a producer
+unsigned long long femo_halo_direct_begin(femo_mesh* m);                 // returns the epoch of the exchange now being produced
+int femo_halo_direct_pull(femo_mesh* m, unsigned long long epoch, double* ghost_tail, hipStream_t st);
+#if defined(__HIPCC__)
+// producer side, at the end of a workgroup that stored into the peers' inboxes (or had nothing to store): uniform per block
+// The inboxes are UNCACHED memory for every mapper (hipDeviceMallocUncached: the stores above left for their owner's memory
+// and no cache on the way keeps them), so what the bump needs is ORDER, not a cache flush: every wave waits until its own
+// stores have been acknowledged (vmcnt), the waves of the workgroup meet, then the counters are bumped with relaxed
+// system-scope atomics (executed at the owner's memory).  The by-the-book alternative -- __threadfence_system() + a release
+// atomic -- writes this XCD's whole L2 back on gfx950 (buffer_wbl2 sc1) once per producer workgroup: measured +11 us per
+// PCG iteration on the 1.26 M-row block, more than the two event hops the design removes.  The self-test of the plan
+// (femo_mesh_halo_direct_selftest: three rounds of epoch-dependent patterns) is what checks the assumption on a given box.
+__device__ __forceinline__ void femo_halo_signal(const FemoHaloPeers* P) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if ((int)threadIdx.x < P->n_nbr)
+    (void)__hip_atomic_fetch_add(P->cnt[threadIdx.x], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void femo_halo_store(const FemoHaloPeers* P, unsigned long long epoch, int32_t slot, double v) {
+  const int k = P->slot_nbr[slot];
+  P->seg[k][(int64_t)(epoch & 1ull) * P->stride[k] + (slot - P->send_ptr[k])] = v;
+}
+#endif
 
 struct femo_bc {
   femo_mesh* mesh = nullptr;
@@ -442,7 +529,8 @@ struct FemoMergedVecs {
   double atol2;                                        // absolute threshold on r.r (0: none)
 };
 bool femo_pc_merged_ok(femo_mesh* m);                 // the fused lattice cycle with two brick-fused levels runs on this mesh
-int femo_pc_merged_begin(femo_mesh* m, const double* s, const uint8_t* mask);
+struct FemoZeroExtra { double* p[3]; int64_t n[3]; int count; };     // small regions the caller wants cleared by the same launch
+int femo_pc_merged_begin(femo_mesh* m, const double* s, const uint8_t* mask, const FemoZeroExtra* extra = nullptr);
 int femo_pc_merged_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, const FemoMergedVecs& V, double* S,
                          const int32_t* done, const struct FemoPcgStop* stop);
 // N > 1: does femo_pc_merged_apply start the halo exchange of the direction it produces (interface vertices first, send buffer

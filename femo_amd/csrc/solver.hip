@@ -950,7 +950,14 @@ static int halo_spmv_inflight(const femo_mat* A, const double* vals, double* x, 
   if (g_bnd) *g_bnd = grid_of(m->n_bnd);
   const bool dot3 = n_slots == 3;
   FEMO_TRY(launch_spmv(A, vals, x, y, partials, done, unit, false, m->d_slices_int, m->n_int, st, dvec, false, dot3));
-  FEMO_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_comm, 0));
+  if (femo_halo_direct_ready(m)) {
+    // device-initiated refresh (round 6): the neighbours' prolongations stored the new direction into this rank's inbox
+    // while the interior slices were multiplied; one small launch of the SAME stream waits for their counters and moves
+    // the generation into the ghost tail -- no second stream, no event
+    FEMO_TRY(femo_halo_direct_pull(m, m->hd->loop_epoch, x + m->n_rows, st));
+  } else {
+    FEMO_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_comm, 0));
+  }
   FEMO_TRY(launch_spmv(A, vals, x, y, partials ? partials + n_slots * FEMO_MAX_PARTIALS : nullptr, done, unit, false,
                        m->d_slices_bnd, m->n_bnd, st, dvec, false, dot3));
   return 0;
@@ -1036,6 +1043,7 @@ int femo_halo_exchange_on(femo_mesh* m, femo_vec* x, hipStream_t st) {
   femo_ctx* ctx = m->ctx;
   FEMO_REQUIRE(ctx->comm != nullptr || ctx->emu != nullptr || ctx->model, "halo exchange before femo_comm_init");
   FEMO_REQUIRE(x->n >= m->n_vert, "vector shorter than n_vert");
+  if (femo_halo_direct_ready(m)) return femo_halo_direct_exchange(m, x->d, x->d + m->n_rows, st);   // device-initiated (round 6)
   const int64_t ns = m->send_ptr[m->n_nbr];
   if (ns > 0) {
     hipLaunchKernelGGL(k_pack, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, ns, m->d_send_idx, x->d, m->d_send_buf);
@@ -1301,21 +1309,29 @@ static int solve_pcg_bpx_merged(femo_mat* A, const femo_vec* b, femo_vec* x, con
   FEMO_TRY(ensure_s(A));
   CgWork w;
   const bool multi = ctx->nranks > 1;
-  FEMO_TRY(ensure_work(ctx, n, m->n_vert, w, 0, /*zero=*/m->n_vert > n));
+  // k_cg_init writes every owned entry of r, p and x^; only the ghost tails have to be defined (zero) -- they and the ghost
+  // tail of the solution are cleared by the preconditioner's own clearing launch (round 6; round 5: three memsets)
+  FEMO_TRY(ensure_work(ctx, n, m->n_vert, w, 0, /*zero=*/false));
   const int gv = vec_grid(ctx, n);
   const int gs = femo_spmv_grid(m);
   int32_t* h_flags = reinterpret_cast<int32_t*>(ctx->h_scal + FEMO_NSCAL);
   double* P = ctx->d_partials;
   double* S = ctx->d_scal;
   const uint8_t* mask = A->pc_has_mask ? A->d_pcmask : nullptr;
-  FEMO_TRY(femo_pc_merged_begin(m, A->d_s, mask));
+  FemoZeroExtra ze;
+  ze.count = 0;
+  if (m->n_vert > n) {
+    const int64_t tail = ctx->cg_n - n;                          // (ensure_work: vectors of max(n_rows, n_vert) + 2 entries)
+    ze.p[ze.count] = w.p + n; ze.n[ze.count++] = tail;
+    ze.p[ze.count] = w.r + n; ze.n[ze.count++] = tail;
+  }
+  if (opts->zero_guess && x->n > n) { ze.p[ze.count] = x->d + n; ze.n[ze.count++] = x->n - n; }   // ghost tail of the solution, as the classic loop leaves it
+  FEMO_TRY(femo_pc_merged_begin(m, A->d_s, mask, &ze));
   const double* q0 = nullptr;
   if (!opts->zero_guess) {
     if (m->n_nbr > 0) FEMO_TRY(halo_raw(m, x->d));
     FEMO_TRY(launch_spmv(A, A->d_vals, x->d, w.q, nullptr, nullptr));
     q0 = w.q;
-  } else if (x->n > n) {
-    FEMO_HIP_CHECK(hipMemsetAsync(x->d + n, 0, (x->n - n) * sizeof(double), st));     // ghost tail of the solution, as the classic loop leaves it
   }
   hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(FEMO_BLOCK), 0, st, n, b->d, q0, A->d_s, w.r, w.p, w.xh, P, A->has_idrows ? A->d_idrows : nullptr);
   const double atol2 = opts->atol * opts->atol;

@@ -61,8 +61,52 @@ class DistMesh(Mesh):
                 dm.set_global(self.bbox[0], self.bbox[1], self.n_vert_global)
             if L.nranks > 1:
                 dm.set_halo(L.nbr, L.send_ptr, L.send_idx, L.recv_ptr)
+                control = getattr(ctx, "control", None)
+                if control is not None:
+                    connect_halo_direct(control, dm, L)        # collective: every rank builds its device mesh at the same point
             self._device, self._ctx = dm, ctx
         return self._device
+
+
+def connect_halo_direct(control, dm, L) -> bool:
+    """Collective set-up of the device-initiated ghost refresh for one partitioned mesh (include/femo_hip.h, ABI 9):
+    export the inbox, exchange handles and halo plans over the control plane, connect to the neighbours, run the
+    self-test, and enable the plan only if EVERY rank passed -- otherwise every rank keeps ncclSend/ncclRecv.
+    ``FEMO_HALO_RCCL=1`` skips it (comparison runs).  Returns whether the plan is in use."""
+    if os.environ.get("FEMO_HALO_RCCL", "0") not in ("", "0"):
+        return False
+    rank = int(control.rank)
+    info = dict(rank=rank, pid=os.getpid(), nbr=[int(v) for v in L.nbr], recv_ptr=[int(v) for v in L.recv_ptr],
+                n_ghost=int(L.recv_ptr[-1]) if len(L.recv_ptr) else 0, ok=True, handle=None, addr=0, blocks=0)
+    try:
+        if not info["nbr"]:
+            raise RuntimeError("no neighbours")
+        info["handle"], info["addr"], info["blocks"] = dm.halo_direct_export()
+    except Exception as e:                                   # noqa: BLE001 - e.g. more neighbours than the plan supports
+        info["ok"], info["why"] = False, repr(e)
+    everyone = control.gather_objects(info)
+    ok = all(r["ok"] for r in everyone)
+    if ok:
+        same = all(r["pid"] == info["pid"] for r in everyone)
+        try:
+            handles, addrs, off, ng, slot, blocks = [], [], [], [], [], []
+            for j in info["nbr"]:
+                R = everyone[j]
+                kk = R["nbr"].index(rank)                    # this rank's place in the neighbour's plan
+                handles.append(R["handle"]); addrs.append(R["addr"])
+                off.append(R["recv_ptr"][kk]); ng.append(R["n_ghost"]); slot.append(kk); blocks.append(R["blocks"])
+            dm.halo_direct_connect(1 if same else 0, None if same else handles, addrs, off, ng, slot, blocks)
+        except Exception:                                    # noqa: BLE001
+            ok = False
+    ok = all(control.gather_objects(bool(ok)))               # every rank connected (or nobody goes on)
+    if ok:
+        try:
+            ok = dm.halo_direct_selftest()
+        except Exception:                                    # noqa: BLE001
+            ok = False
+        ok = all(control.gather_objects(bool(ok)))
+    dm.halo_direct_enable(ok)
+    return ok
 
 
 def partition_mesh(mesh: Mesh, rank: int, nranks: int, facets: bool = False) -> DistMesh:
@@ -140,9 +184,16 @@ class TorchControl:
 
     def init_comm(self, ctx) -> None:
         init_comm(ctx, self.rank, self.world)
+        ctx.control = self                       # DistMesh.device() sets the device-initiated ghost refresh up through it
 
     def barrier(self) -> None:
         self.dist.barrier()
+
+    def gather_objects(self, obj) -> list:
+        """Small Python objects from every rank, in rank order (set-up data: IPC handles, halo plans)."""
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
 
     def allreduce(self, values, op: str = "sum") -> np.ndarray:
         import torch
@@ -180,9 +231,17 @@ class ThreadControl:
 
     def init_comm(self, ctx) -> None:
         ctx.comm_emulate(self._group, self.rank)
+        ctx.control = self
 
     def barrier(self) -> None:
         self._s.barrier.wait()
+
+    def gather_objects(self, obj) -> list:
+        self._s.slots[self.rank] = obj
+        self._s.barrier.wait()
+        out = list(self._s.slots)
+        self._s.barrier.wait()
+        return out
 
     def gather(self, values) -> np.ndarray:
         self._s.slots[self.rank] = np.asarray(values, dtype=np.float64).ravel().copy()

@@ -300,6 +300,13 @@ class EmuGroup:
             self.lib.femo_emu_group_destroy(h)
 
 
+def host_syncs(reset: bool = False) -> int:
+    """Blocking host waits on the device the library executed since the last reset (femo_host_sync_stats)."""
+    n = C.c_int64(0)
+    check(_lib.load().femo_host_sync_stats(C.byref(n), int(reset)))
+    return int(n.value)
+
+
 class Context:
     """Device + HIP stream (+ RCCL communicator).  Stands in for PETSc/MPI global state."""
 
@@ -567,6 +574,34 @@ class DeviceMesh:
 
     def halo_exchange(self, v: Vec) -> None:
         check(self.lib.femo_halo_exchange(self.handle, v.handle))
+
+    # -- device-initiated ghost refresh (include/femo_hip.h, ABI 9): the collective set-up lives in femo_amd/dist --
+    def halo_direct_export(self):
+        """(64-byte IPC handle, device address, workgroups per producer launch) of this rank's inbox."""
+        buf = C.create_string_buffer(64)
+        addr, nb = C.c_uint64(0), C.c_int32(0)
+        check(self.lib.femo_mesh_halo_direct_export(self.handle, buf, C.byref(addr), C.byref(nb)))
+        return buf.raw, int(addr.value), int(nb.value)
+
+    def halo_direct_connect(self, mode: int, handles, addresses, remote_offset, remote_n_ghost, remote_slot, remote_blocks) -> None:
+        hb = b"".join(handles) if handles else None
+        addresses = np.ascontiguousarray(addresses, np.uint64)
+        ro, rg = np.ascontiguousarray(remote_offset, np.int64), np.ascontiguousarray(remote_n_ghost, np.int64)
+        rs, rb = _i32(remote_slot), _i32(remote_blocks)
+        check(self.lib.femo_mesh_halo_direct_connect(self.handle, int(mode), hb, _ptr(addresses), _ptr(ro), _ptr(rg), _ptr(rs), _ptr(rb)))
+
+    def halo_direct_selftest(self) -> bool:
+        ok = C.c_int(0)
+        check(self.lib.femo_mesh_halo_direct_selftest(self.handle, C.byref(ok)))
+        return bool(ok.value)
+
+    def halo_direct_enable(self, on: bool) -> None:
+        check(self.lib.femo_mesh_halo_direct_enable(self.handle, int(bool(on))))
+
+    def halo_direct_info(self) -> Dict[str, int]:
+        out = (C.c_int64 * 4)()
+        check(self.lib.femo_mesh_halo_direct_info(self.handle, out))
+        return dict(enabled=int(out[0]), exchanges=int(out[1]), timeouts=int(out[2]), producer_blocks=int(out[3]))
 
     def __del__(self):
         try:

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FEMO_ABI_VERSION 8
+#define FEMO_ABI_VERSION 9
 
 typedef struct femo_ctx  femo_ctx;   /* device + stream + reduction workspace (+ RCCL communicator) */
 typedef struct femo_vec  femo_vec;   /* fp64 device vector  (dolfinx Function.vector / PETSc Vec)     */
@@ -360,6 +360,38 @@ int femo_mesh_set_halo(femo_mesh* mesh, int n_nbr, const int32_t* nbr,
                        const int64_t* recv_ptr);
 int femo_halo_exchange(femo_mesh* mesh, femo_vec* x);
 int femo_allreduce_sum(femo_ctx* ctx, double* host_inout, int n);
+
+/* ---- device-initiated ghost refresh (ABI 9; new design -- the reference's ghost updates are implicit PETSc scatters,
+ * utils_dolfinx.py:167,200 [ext]; SURVEY.md section 5 "distributed comm backend": IPC-mapped peer buffers over xGMI) ----
+ * Instead of ncclSend/ncclRecv, a rank's producer kernels store the values a neighbour needs straight into that
+ * neighbour's INBOX (uncached device memory the neighbour exported) and bump a counter there; consumers wait on their own
+ * counters.  Two kernels of the compute stream per refresh -- none where the producer is the kernel that computes the
+ * values anyway (the merged BPX-PCG's prolongation).  Set-up, collective over the ranks that share `mesh`'s halo plan
+ * (femo_amd/dist does it through the control plane):
+ *   1. every rank: femo_mesh_halo_direct_export -> 64-byte hipIpcMemHandle (other processes) / device address (same
+ *      process), workgroups per producer launch;
+ *   2. ranks exchange {handle, address, workgroups, their neighbour list and recv_ptr};
+ *   3. every rank: femo_mesh_halo_direct_connect, per neighbour k of its plan: the neighbour's handle / address
+ *      (mode 0 = handles of other processes, 1 = addresses in this process), remote_offset[k] = the neighbour's recv_ptr
+ *      entry for THIS rank, remote_n_ghost[k] = its ghost count, remote_slot[k] = this rank's index in ITS neighbour
+ *      list, remote_blocks[k] = its workgroups per producer launch;
+ *   4. every rank: femo_mesh_halo_direct_selftest (one exchange of a known pattern through the solver's device code);
+ *   5. the ranks reduce the results; femo_mesh_halo_direct_enable(mesh, all passed) -- all or none.
+ * Without an enabled plan femo_halo_exchange and the solvers use ncclSend/ncclRecv as before.                        */
+int femo_mesh_halo_direct_export(femo_mesh* mesh, char ipc_handle[64], uint64_t* address, int32_t* n_blocks);
+int femo_mesh_halo_direct_connect(femo_mesh* mesh, int mode, const char* handles, const uint64_t* addresses,
+                                  const int64_t* remote_offset, const int64_t* remote_n_ghost,
+                                  const int32_t* remote_slot, const int32_t* remote_blocks);
+int femo_mesh_halo_direct_selftest(femo_mesh* mesh, int* ok);
+int femo_mesh_halo_direct_enable(femo_mesh* mesh, int on);
+/* out = {enabled, exchanges issued, consumer time-outs seen, workgroups per producer launch} */
+int femo_mesh_halo_direct_info(femo_mesh* mesh, int64_t out[4]);
+
+/* Blocking waits of the host on the device (hipStreamSynchronize / hipEventSynchronize / hipDeviceSynchronize) the library
+ * has executed in this process since the last reset -- each costs an idle device for one host round trip.  bench.py
+ * divides by the cycle count (`host_syncs_per_step`).  (The reference synchronises implicitly in every PETSc / dolfinx
+ * call: it has no asynchronous path, utils_dolfinx.py:155-212.)                                                      */
+int femo_host_sync_stats(int64_t* count, int reset);
 
 /* Collectives issued on this context since the last reset: out = {all-reduce calls, doubles all-reduced, neighbour
  * exchanges, doubles sent}.  What `bench.py`'s scaling record and the tests divide by the CG iteration count (the

@@ -17,15 +17,19 @@ pytestmark = pytest.mark.gpu
 
 
 def _run_ranks(world, fn):
-    """fn(rank, ctx) on `world` threads; returns the per-rank results, re-raises the first failure."""
+    """fn(rank, ctx) on `world` threads; returns the per-rank results, re-raises the first failure.  Every context carries a
+    control plane (ThreadControl): meshes whose halo plan is installed through `_set_halo` / DistMesh.device() get the
+    device-initiated ghost refresh (round 6) unless FEMO_HALO_RCCL=1 keeps the host-staged neighbour exchange."""
+    from femo_amd.dist import ThreadControl
     from femo_amd.engine import Context, EmuGroup
     group = EmuGroup(world)
+    shared = ThreadControl.Shared(world)
     out, err = [None] * world, [None] * world
 
     def body(rank):
         try:
             ctx = Context(0)
-            ctx.comm_emulate(group, rank)
+            ThreadControl(rank, shared, group).init_comm(ctx)
             out[rank] = fn(rank, ctx)
             ctx.sync()
         except BaseException as e:          # noqa: BLE001 - reported below, the other ranks time out on their own
@@ -43,6 +47,13 @@ def _run_ranks(world, fn):
     return out
 
 
+def _set_halo(ctx, dm, L):
+    """The rank's halo plan + (collectively) the device-initiated refresh for it, as DistMesh.device() does."""
+    from femo_amd.dist import connect_halo_direct
+    dm.set_halo(L.nbr, L.send_ptr, L.send_idx, L.recv_ptr)
+    return connect_halo_direct(ctx.control, dm, L)
+
+
 def _local_problem(ctx, m, part, rank, world, seed=0):
     """Rank-local Poisson system with Dirichlet data on the box boundary (values from a global field)."""
     from femo_amd import engine as E
@@ -50,7 +61,7 @@ def _local_problem(ctx, m, part, rank, world, seed=0):
     dm = E.DeviceMesh(ctx, L.x, L.conn, n_rows=L.n_owned)
     dm.set_global(m.x.min(axis=0), m.x.max(axis=0), m.n_vert)
     if world > 1:
-        dm.set_halo(L.nbr, L.send_ptr, L.send_idx, L.recv_ptr)
+        _set_halo(ctx, dm, L)
     rng = np.random.default_rng(seed)
     g_global = 0.3 * rng.standard_normal(m.n_vert)
     f_global = 1.0 + rng.random(m.n_cell)
@@ -76,10 +87,17 @@ def _reference(m, seed=0):
     return spla.spsolve(fo.eliminate_bc(K, bd).tocsc(), rhs), rhs
 
 
+@pytest.mark.parametrize("halo", ["direct", "staged"])
 @pytest.mark.parametrize("world", [2, 4, 8])
 @pytest.mark.parametrize("pc", ["jacobi", "bpx"])
-def test_partitioned_solve_with_emulated_ranks(world, pc):
+def test_partitioned_solve_with_emulated_ranks(world, pc, halo, monkeypatch):
+    """`halo`: direct = device-initiated ghost refresh (stores into the neighbours' inboxes + counters, round 6);
+    staged = the ncclSend/Recv-shaped neighbour exchange of the emulation (host-staged)."""
     from femo_amd import engine as E
+    if halo == "staged":
+        monkeypatch.setenv("FEMO_HALO_RCCL", "1")
+    else:
+        monkeypatch.delenv("FEMO_HALO_RCCL", raising=False)
     m = fo.unit_cube_mesh(12, 0.2)
     part = rcb_partition(m.x, world)
     x_ref, rhs_ref = _reference(m)
@@ -89,13 +107,17 @@ def test_partitioned_solve_with_emulated_ranks(world, pc):
         x = E.Vec(ctx, len(L.x))
         info = A.solve_cg(b, x, rtol=1e-14, pc=pc)
         return dict(gid=L.vert_global[:L.n_owned], x=x.get(L.n_owned), b=b.get(), its=info.iterations,
-                    conv=info.converged, nbr=len(L.nbr), levels=dm.pc_info()["levels"] if pc == "bpx" else 0)
+                    conv=info.converged, nbr=len(L.nbr), levels=dm.pc_info()["levels"] if pc == "bpx" else 0,
+                    hd=dm.halo_direct_info())
 
     res = _run_ranks(world, rank_fn)
     x = np.zeros(m.n_vert)
     b = np.zeros(m.n_vert)
     for r in res:
         assert r["conv"] == 1 and r["nbr"] >= 1
+        # the transport the test asked for was the one in use, and no consumer ever gave up waiting
+        assert r["hd"]["enabled"] == (1 if halo == "direct" else 0) and r["hd"]["timeouts"] == 0
+        assert (r["hd"]["exchanges"] > r["its"]) == (halo == "direct")
         x[r["gid"]] = r["x"]
         b[r["gid"]] = r["b"]
     assert len({r["its"] for r in res}) == 1                       # every rank stopped at the same iteration
@@ -134,7 +156,7 @@ def test_emulated_halo_and_dot_products():
     def rank_fn(rank, ctx):
         L = build_local_mesh(m.x, m.conn, part, rank, world)
         dm = E.DeviceMesh(ctx, L.x, L.conn, n_rows=L.n_owned)
-        dm.set_halo(L.nbr, L.send_ptr, L.send_idx, L.recv_ptr)
+        assert _set_halo(ctx, dm, L)                       # device-initiated refresh: connected, self-test passed on both ranks
         J = E.Mat(dm)
         E.assemble_jacobian(dm, 0, None, None, None, None, J)
         ul = np.full(len(L.x), 1e30)                       # ghosts hold garbage until the exchange

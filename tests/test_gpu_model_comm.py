@@ -38,6 +38,10 @@ def test_model_communicator_runs_the_n_rank_merged_loop(world, rank):
     info = A.solve_cg(b, x, rtol=1e-11, pc="bpx")
     st = ctx.comm_stats()
     assert info.converged == 1 and dm.pc_info()["levels"] >= 4
+    # round 6: the model rank refreshes its ghosts the device-initiated way against its own scratch (loopback): the same
+    # producer stores, counter bumps and consumer waits as a real rank, and no consumer ever gave up waiting
+    hd = dm.halo_direct_info()
+    assert hd["enabled"] == 1 and hd["timeouts"] == 0 and hd["exchanges"] >= st["neighbor_calls"]
     # the merged loop: one all-reduce and one neighbour exchange per enqueued iteration (+ the set-up reduction and the first apply)
     enqueued = st["neighbor_calls"] - 1                       # (the first application of the preconditioner starts an exchange too)
     assert info.loop_allreduces == enqueued
