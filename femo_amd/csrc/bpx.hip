@@ -543,6 +543,9 @@ struct HaloFirst {
   // neighbours' inboxes (no send buffer) and every workgroup of it bumps their counters on its way out -- also when
   // the solve has converged and it has nothing to store (femo_internal.h: FemoHaloDirect)
   const FemoHaloPeers* peers; unsigned long long epoch;
+  // n_send_blocks > 0: ONE launch plays both parts -- workgroups [0, n_send_blocks) the first (list walk, stores, counter
+  // bumps), the others the second (everything else, send vertices skipped): one launch and one scalar prologue less
+  int n_send_blocks;
 };
 template <int D>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat lat, const uint32_t* __restrict__ pk,
@@ -553,7 +556,11 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat
                                                              int nb_rho, const double* __restrict__ rho_partials, double* __restrict__ rho,
                                                              const double* __restrict__ gamma_cur, double* __restrict__ gamma_nxt,
                                                              const int32_t* __restrict__ done, PcgStop st, MergedScal ms, HaloFirst hf) {
-  const bool signals = hf.n_verts > 0 && hf.peers != nullptr;       // this launch is the producer of a ghost refresh
+  const bool both = hf.n_send_blocks > 0;
+  const bool role_send = both ? (int)blockIdx.x < hf.n_send_blocks : hf.n_verts > 0;   // this workgroup walks the send list
+  const int bid = (both && !role_send) ? (int)blockIdx.x - hf.n_send_blocks : (int)blockIdx.x;
+  const int nblk = both ? (role_send ? hf.n_send_blocks : (int)gridDim.x - hf.n_send_blocks) : (int)gridDim.x;
+  const bool signals = role_send && hf.peers != nullptr;            // ... and is a producer of a device-initiated ghost refresh
   if (done != nullptr && *done) {
     if (signals) femo_halo_signal(hf.peers);
     return;
@@ -595,7 +602,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat
     }
     const double g1 = rr + ge, g0 = *gamma_cur;
     if (mode == 1) beta = g0 != 0.0 ? g1 / g0 : 0.0;
-    const bool first = blockIdx.x == 0 && threadIdx.x == 0 && hf.n_verts == 0;      // (the halo-first launch writes no scalar)
+    const bool first = bid == 0 && threadIdx.x == 0 && !role_send;      // (the halo-first part writes no scalar)
     if (first) {
       *gamma_nxt = g1;
       if (nb_rho > 0 || ms.S != nullptr) *rho = rr;
@@ -629,7 +636,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat
       }
     }
   }
-  const int64_t n_walk = hf.n_verts > 0 ? hf.n_verts : n_rows;
+  const int64_t n_walk = role_send ? hf.n_verts : n_rows;
   // 36 B per vertex: r 8, packed coordinates 8, 1/s 4 (single precision, 0 on pinned vertices: the mask byte is not read),
   // p 8 + 8.  Rounds 1-4: 45 B (12 B of coordinates, 1/s in double precision, the mask).
   auto direction = [&](int64_t v) -> double {
@@ -655,13 +662,13 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_prolong_mesh(int64_t n_rows, Lat
     const double z = si == 0.0f ? rh[v] : rh[v] + sum * (double)si;   // pinned rows stay r even if the correction is not finite
     return mode == 1 ? z + beta * out[v] : z;
   };
-  const int64_t stride = (int64_t)gridDim.x * FEMO_BLOCK;
-  for (int64_t w_i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; w_i < n_walk; w_i += stride) {
-    const int64_t v = hf.n_verts > 0 ? (int64_t)hf.verts[w_i] : w_i;
-    if (hf.skip != nullptr && hf.skip[v]) continue;
+  const int64_t stride = (int64_t)nblk * FEMO_BLOCK;
+  for (int64_t w_i = (int64_t)bid * FEMO_BLOCK + threadIdx.x; w_i < n_walk; w_i += stride) {
+    const int64_t v = role_send ? (int64_t)hf.verts[w_i] : w_i;
+    if (!role_send && hf.skip != nullptr && hf.skip[v]) continue;
     const double pv = direction(v);
     out[v] = pv;
-    if (hf.n_verts > 0) {
+    if (role_send) {
       if (hf.peers != nullptr)
         for (int32_t q = hf.slot_ptr[w_i]; q < hf.slot_ptr[w_i + 1]; ++q) femo_halo_store(hf.peers, hf.epoch, hf.slots[q], pv);
       else
@@ -2505,17 +2512,20 @@ int femo_pc_merged_apply(femo_mesh* m, const uint8_t* mask, uint64_t mask_key, c
       ++ctx->n_neighbor; ctx->neighbor_doubles += m->send_ptr[m->n_nbr];
       const unsigned long long epoch = femo_halo_direct_begin(m);
       m->hd->loop_epoch = epoch;
-      HaloFirst h1 = {m->n_send_verts, m->d_send_uvert, m->d_send_uptr, m->d_send_uslot, nullptr, nullptr, m->hd->d_peers, epoch};
-      prolong((unsigned)m->hd->n_blocks, h1);
+      // ONE launch: the first n_blocks workgroups walk the send list, the others everything else
+      HaloFirst h1 = {m->n_send_verts, m->d_send_uvert, m->d_send_uptr, m->d_send_uslot, nullptr, m->d_send_flag, m->hd->d_peers, epoch, m->hd->n_blocks};
+      prolong((unsigned)(m->hd->n_blocks + V.gv), h1);
+      FEMO_HIP_CHECK(hipGetLastError());
+      return 0;
     } else {
-      HaloFirst h1 = {m->n_send_verts, m->d_send_uvert, m->d_send_uptr, m->d_send_uslot, m->d_send_buf, nullptr, nullptr, 0ull};
+      HaloFirst h1 = {m->n_send_verts, m->d_send_uvert, m->d_send_uptr, m->d_send_uslot, m->d_send_buf, nullptr, nullptr, 0ull, 0};
       prolong((unsigned)std::max<int64_t>(1, std::min<int64_t>((m->n_send_verts + FEMO_BLOCK - 1) / FEMO_BLOCK, V.gv)), h1);
       FEMO_HIP_CHECK(hipEventRecord(ctx->ev_main, st));
       FEMO_HIP_CHECK(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_main, 0));
       FEMO_TRY(femo_coll_neighbors(ctx, m->n_nbr, m->nbr.data(), m->send_ptr.data(), m->d_send_buf, m->recv_ptr.data(), V.p + m->n_rows, ctx->comm_stream));
       FEMO_HIP_CHECK(hipEventRecord(ctx->ev_comm, ctx->comm_stream));
     }
-    HaloFirst h2 = {0, nullptr, nullptr, nullptr, nullptr, m->d_send_flag, nullptr, 0ull};
+    HaloFirst h2 = {0, nullptr, nullptr, nullptr, nullptr, m->d_send_flag, nullptr, 0ull, 0};
     prolong((unsigned)V.gv, h2);
   } else {
     prolong((unsigned)V.gv, HaloFirst{});

@@ -318,6 +318,8 @@ struct FemoHaloPeers {                               // lives in device memory (
   int64_t stride[FEMO_MAX_NBR];                      // ... and the distance to generation 1 (its ghost count)
   unsigned long long* cnt[FEMO_MAX_NBR];             // ... and its counter for this rank
   const uint8_t* slot_nbr;                           // neighbour index of every send slot
+  double* const* dst[2];                             // per send slot: its address in the owner's inbox, generation 0 / 1 (one
+                                                     // coalesced pointer load per store instead of four dependent table lookups)
 };
 struct FemoHaloDirect {
   bool ready = false;
@@ -330,6 +332,7 @@ struct FemoHaloDirect {
   FemoHaloPeers* d_peers = nullptr;
   int32_t* d_blocks = nullptr;                       // [n_nbr]: bumps per exchange of neighbour k's producers
   uint8_t* d_slot_nbr = nullptr;
+  double** d_dst = nullptr;                          // [2][n_send]: FemoHaloPeers::dst
   double* d_loop = nullptr;                          // loopback: absorbs the producer's stores
   int32_t* d_err = nullptr;                          // set by a consumer that gave up waiting
   unsigned long long epoch = 0;                      // exchanges issued on this mesh (host side; SPMD: the same on every rank)
@@ -361,8 +364,7 @@ __device__ __forceinline__ void femo_halo_signal(const FemoHaloPeers* P) {
     (void)__hip_atomic_fetch_add(P->cnt[threadIdx.x], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ __forceinline__ void femo_halo_store(const FemoHaloPeers* P, unsigned long long epoch, int32_t slot, double v) {
-  const int k = P->slot_nbr[slot];
-  P->seg[k][(int64_t)(epoch & 1ull) * P->stride[k] + (slot - P->send_ptr[k])] = v;
+  *(P->dst[epoch & 1ull][slot]) = v;
 }
 #endif
 

@@ -92,7 +92,7 @@ void femo_halo_direct_free(femo_mesh* m) {
   FemoHaloDirect* h = m->hd;
   if (!h) return;
   for (void* p : h->opened) hipIpcCloseMemHandle(p);
-  hipFree(h->inbox_raw); hipFree(h->d_peers); hipFree(h->d_blocks); hipFree(h->d_slot_nbr); hipFree(h->d_loop); hipFree(h->d_err);
+  hipFree(h->inbox_raw); hipFree(h->d_peers); hipFree(h->d_blocks); hipFree(h->d_slot_nbr); hipFree(h->d_dst); hipFree(h->d_loop); hipFree(h->d_err);
   delete h;
   m->hd = nullptr;
 }
@@ -145,7 +145,8 @@ int femo_mesh_halo_direct_export(femo_mesh* m, char ipc_handle[64], uint64_t* ad
   h->n_ghost = m->n_vert - m->n_rows;
   const int64_t ns = m->send_ptr[m->n_nbr];
   FEMO_REQUIRE(ns < (int64_t(1) << 31), "direct halo: send list too long");
-  h->n_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(64, (std::max<int64_t>(m->n_send_verts, 1) + FEMO_BLOCK - 1) / FEMO_BLOCK));
+  // one workgroup per 256 send vertices, at most one per CU (64 was measured to double the prolongation's halo-first part)
+  h->n_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(256, (std::max<int64_t>(m->n_send_verts, 1) + FEMO_BLOCK - 1) / FEMO_BLOCK));
   const size_t data_bytes = (((size_t)2 * (size_t)std::max<int64_t>(h->n_ghost, 1) * sizeof(double)) + 63) & ~size_t(63);
   const size_t cnt_bytes = (size_t)m->n_nbr * FEMO_HALO_CNT_STRIDE * sizeof(unsigned long long);
   // uncached: the neighbours' stores arrive behind this GPU's L2, so its own reads must not be served from there
@@ -226,6 +227,17 @@ int femo_mesh_halo_direct_connect(femo_mesh* m, int mode, const char* handles /*
   FEMO_HIP_CHECK(hipMalloc(&h->d_slot_nbr, slot_nbr.size()));
   FEMO_HIP_CHECK(hipMemcpy(h->d_slot_nbr, slot_nbr.data(), slot_nbr.size(), hipMemcpyHostToDevice));
   P.slot_nbr = h->d_slot_nbr;
+  {
+    const size_t n1 = (size_t)std::max<int64_t>(ns, 1);
+    std::vector<double*> dst(2 * n1, nullptr);
+    for (int g = 0; g < 2; ++g)
+      for (int k = 0; k < nn; ++k)
+        for (int64_t i = m->send_ptr[k]; i < m->send_ptr[k + 1]; ++i)
+          dst[(size_t)g * n1 + (size_t)i] = P.seg[k] + (int64_t)g * P.stride[k] + (i - m->send_ptr[k]);
+    FEMO_HIP_CHECK(hipMalloc(&h->d_dst, dst.size() * sizeof(double*)));
+    FEMO_HIP_CHECK(hipMemcpy(h->d_dst, dst.data(), dst.size() * sizeof(double*), hipMemcpyHostToDevice));
+    P.dst[0] = h->d_dst; P.dst[1] = h->d_dst + n1;
+  }
   FEMO_HIP_CHECK(hipMalloc(&h->d_peers, sizeof P));
   FEMO_HIP_CHECK(hipMemcpy(h->d_peers, &P, sizeof P, hipMemcpyHostToDevice));
   FEMO_HIP_CHECK(hipMalloc(&h->d_blocks, (size_t)nn * sizeof(int32_t)));
