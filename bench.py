@@ -416,9 +416,9 @@ def bench_config2(ctx, steps: int) -> dict:
     mesh = createUnitCubeMesh(n)
     sim, fea = build_problem(mesh, device=False)
     dm = mesh.device(ctx)
-    _prime_pool(sim)
     fs = [E.pinned_array(f) for f in source_fields(mesh, 3)]
     u0 = E.pinned_full(mesh.n_vert, 0.0)
+    _prime_pool(sim)                                                  # after the inputs took their blocks (see bench_unstructured)
     g = None
     for k in range(10):                                               # a 9 ms cycle: ten of them until the clocks have settled
         g = one_cycle(sim, fea, fs[k % 3], u0)
@@ -470,12 +470,13 @@ def bench_unstructured(ctx, n: int, steps: int = 3) -> dict:
     mesh = createUnitCubeMesh(n).permuted(seed=20240807).reordered()
     sim, fea = build_problem(mesh, device=False)
     dm = mesh.device(ctx)
-    _prime_pool(sim)
     f_host = source_fields(mesh, 3)
     fs = [E.pinned_array(f) for f in f_host]
     u0 = E.pinned_full(mesh.n_vert, 0.0)
+    _prime_pool(sim)             # AFTER the inputs took their blocks: the result generations must not meet an empty pool (a first
+    #                              hipHostMalloc of 477 MB costs 60-90 ms and would land in the three timed cycles)
     setup_s = time.perf_counter() - t0
-    for k in range(2):
+    for k in range(3):
         one_cycle(sim, fea, fs[k], u0)
     ctx.sync()
     del utils_hip.LAST_KSP_INFO[:]
@@ -720,10 +721,10 @@ def _block_leg(ctx, mesh, steps: int) -> dict:
     from femo_amd.fea import utils_hip
     sim, fea = build_problem(mesh, device=False)
     dm = mesh.device(ctx)
-    _prime_pool(sim)
     fs = [E.pinned_array(f) for f in source_fields(mesh, 3)]
     u0 = E.pinned_full(mesh.n_vert, 0.0)
-    for k in range(2):
+    _prime_pool(sim)                                                  # after the inputs took their blocks (see bench_unstructured)
+    for k in range(3):
         one_cycle(sim, fea, fs[k], u0)
     ctx.sync()
     del utils_hip.LAST_KSP_INFO[:]
@@ -812,8 +813,15 @@ def bench_scaling_model(ctx, n_global: int, steps: int, headline_ms: float, head
     ms = leg["non_cg_ms_per_cycle"] + its_total * us_per_it * 1e-3
     ar_doubles = leg["allreduce_doubles_per_call_in_loop"]
     proj = {}
+    # What of the ghost refresh stays exposed on the wire.  ncclSend/Recv-shaped path (round 5): +10 us per iteration, as
+    # before.  Device-initiated path (round 6): the stores into the neighbours' inboxes are issued by the FIRST workgroups of
+    # the prolongation launch and consumed by the waves of the boundary slices at the END of the next product -- the bulk of
+    # the prolongation and the interior slices (>= 14 + 27 us on this block, see the timeline in profiles/) lie in between,
+    # against ~117 KB per neighbour over a dedicated xGMI link (~2.5 us at 50 GB/s + a few us of latency): priced at 0.
+    direct = bool((leg.get("halo") or {}).get("enabled"))
+    halo_exposed_us = 0.0 if direct else 10.0
     for lat_us in (15.0, 30.0, 60.0):
-        t_it = us_per_it + lat_us + 10.0                  # + one all-reduce on the wire + the exposed part of one halo exchange
+        t_it = us_per_it + lat_us + halo_exposed_us       # + one all-reduce on the wire + the exposed part of one halo exchange
         cyc = ms + its_total * (t_it - us_per_it) * 1e-3
         proj[f"allreduce_{int(lat_us)}us"] = {"us_per_iteration": t_it, "ms_per_cycle": cyc, "speedup_vs_1gpu": headline_ms / cyc}
     return {"what": f"rank {model_rank} of the 1x2x4 partition of the headline mesh, run alone on this GPU through the N-rank code path (model communicator: "
@@ -829,9 +837,13 @@ def bench_scaling_model(ctx, n_global: int, steps: int, headline_ms: float, head
             "ghost_refresh": ("device-initiated (stores into the neighbours' inboxes + counters, include/femo_hip.h ABI 9; here against the rank's own scratch: "
                               "loopback of the model communicator)" if (leg.get("halo") or {}).get("enabled") else "ncclSend/ncclRecv-shaped (comm stream + events)"),
             "ghost_refresh_info": leg.get("halo"),
-            "launches_per_cg_iteration": {"one_rank": 5, "n_ranks": 7 + 1, "kernels": "halo pack (communication stream), SpMV over the interior slices, SpMV over the boundary slices, brick "
-                                          "restriction of q, pack (shared lattice nodes of three levels + R h_T + 7 scalars), coarse lattice + vector updates (reads the "
-                                          "reduced buffer in place: round 4's unpack launch is gone), fine lattice (own tiles), mesh prolongation + direction update"},
+            "launches_per_cg_iteration": {"one_rank": 5, "n_ranks": 6 if direct else 8,
+                                          "kernels": ("device-initiated ghost refresh (round 6), ONE stream: SpMV (interior slices, then the slices with ghost columns: their waves wait "
+                                                      "for the neighbours' counters and read the inbox), brick restriction of q, pack (shared lattice nodes of three levels + R h_T + 7 "
+                                                      "scalars), [ncclAllReduce], coarse lattice + vector updates, fine lattice (own tiles), mesh prolongation (send vertices first: stores "
+                                                      "into the neighbours' inboxes + counter bumps)") if direct else
+                                                     ("SpMV over the interior slices, [halo event], SpMV over the boundary slices, brick restriction of q, pack, [ncclAllReduce], coarse lattice "
+                                                      "+ vector updates, fine lattice, mesh prolongation on the send vertices, [ncclSend/Recv on the comm stream], mesh prolongation")},
             "collectives_per_cg_iteration": {"allreduce": leg["allreduce_per_cg_iteration"], "halo_exchange": 1,
                                              "allreduce_doubles": ar_doubles,
                                              "round4_allreduce_doubles": 138000,
@@ -841,10 +853,13 @@ def bench_scaling_model(ctx, n_global: int, steps: int, headline_ms: float, head
             "headline_1gpu_ms": headline_ms,
             "ideal_speedup_without_communication": headline_ms / ms,
             "projection": proj,
+            "halo_exposed_us_assumed": halo_exposed_us,
             "assumptions": "each rank has its own PCIe link (the block's transfers are inside ms_per_cycle_block); per iteration the stated all-reduce "
-                           "latency (the pack launch and the host enqueue of the collectives are measured, the wire is not) and +10 us of halo exchange not hidden "
-                           "behind the interior SpMV; the collectives outside the CG loops (a dozen scalar all-reduces and halo refreshes per cycle) are not priced; "
-                           "no multi-GPU box was available: RCCL latencies are assumptions, everything else is measured"}
+                           "latency (the pack launch and the host enqueue of the collectives are measured, the wire is not) and halo_exposed_us_assumed of ghost "
+                           "refresh not hidden (0 with the device-initiated refresh: its stores have the bulk of the prolongation and the interior slices "
+                           "of the product, > 40 us, to cross a dedicated link; 10 with ncclSend/Recv); the collectives outside the CG loops (a dozen scalar "
+                           "all-reduces and halo refreshes per cycle) are not priced; no multi-GPU box was available: wire latencies are assumptions, "
+                           "everything else is measured"}
 
 
 def build_problem_nl(mesh, device: bool = False):
@@ -886,10 +901,10 @@ def bench_scaling_model_c5(ctx, steps: int, one_gpu: dict, n: int = 2236, world:
         mesh = local_unit_mesh(n, 2, model_rank, world)
         sim, fea = build_problem_nl(mesh)
         dm = mesh.device(ctx4)
-        _prime_pool(sim)
         xc = mesh.centroids()
         fs = [E.pinned_array(0.1 * (1.0 + 0.2 * np.sin(np.pi * (k + 1) * xc[:, 0]) * xc[:, 1])) for k in range(3)]
         u1 = E.pinned_full(mesh.n_vert, 1.0)
+        _prime_pool(sim)
         ufn = fea.states_dict['u']['function']
 
         def cycle(k):
@@ -915,7 +930,9 @@ def bench_scaling_model_c5(ctx, steps: int, one_gpu: dict, n: int = 2236, world:
         non_cg = ms_model - sum(i["solve_ms"] for i in infos) / steps
         lat = dm.pc_info()
         L = mesh.local
-        halo = {"neighbours": int(len(L.nbr)), "ghosts": int(mesh.n_vert - mesh.n_owned), "bytes_sent_per_exchange": int(L.send_ptr[-1]) * 8}
+        hd = dm.halo_direct_info()
+        halo = {"neighbours": int(len(L.nbr)), "ghosts": int(mesh.n_vert - mesh.n_owned), "bytes_sent_per_exchange": int(L.send_ptr[-1]) * 8,
+                "device_initiated": bool(hd["enabled"]), "consumer_timeouts": hd["timeouts"]}
         n_owned = int(mesh.n_owned)
         utils_hip.clear_workspaces()
         mesh._device = None
@@ -925,8 +942,9 @@ def bench_scaling_model_c5(ctx, steps: int, one_gpu: dict, n: int = 2236, world:
     n_global = int(sum(its_global)) if its_global else n_it // max(steps, 1)
     ms = non_cg + n_global * us_per_it * 1e-3
     proj = {}
+    halo_exposed_us = 0.0 if halo["device_initiated"] else 10.0        # as in scaling_model
     for lat_us in (15.0, 30.0, 60.0):
-        cyc = ms + n_global * (lat_us + 10.0) * 1e-3
+        cyc = ms + n_global * (lat_us + halo_exposed_us) * 1e-3
         proj[f"allreduce_{int(lat_us)}us"] = {"ms_per_cycle": cyc, "speedup_vs_1gpu": one_gpu["ms_per_cycle"] / cyc}
     return {"what": f"rank {model_rank} of the 1x{world} slabs of the n = {n} square (BASELINE config 5: 4 GPUs), run alone on this GPU through the N-rank code path "
                     "(model communicator), whole-mesh 2-D lattice", "owned_dofs": n_owned, "halo": halo, "pc_lattice": lat,
@@ -938,7 +956,8 @@ def bench_scaling_model_c5(ctx, steps: int, one_gpu: dict, n: int = 2236, world:
             "collectives_per_cycle": {k: v / steps for k, v in comm.items()},
             "one_gpu_ms_per_cycle": one_gpu["ms_per_cycle"], "ideal_speedup_without_communication": one_gpu["ms_per_cycle"] / ms,
             "projection": proj,
-            "assumptions": "as scaling_model: the stated all-reduce latency and +10 us of exposed halo exchange per iteration; collectives outside the CG loops not priced"}
+            "halo_exposed_us_assumed": halo_exposed_us,
+            "assumptions": "as scaling_model: the stated all-reduce latency and halo_exposed_us_assumed of exposed ghost refresh per iteration; collectives outside the CG loops not priced"}
 
 
 def bench_config5(ctx, steps: int, n: int = 2236) -> dict:
@@ -951,10 +970,10 @@ def bench_config5(ctx, steps: int, n: int = 2236) -> dict:
     mesh = createUnitSquareMesh(n)
     sim, fea = build_problem_nl(mesh)
     dm = mesh.device(ctx)
-    _prime_pool(sim)
     xc = mesh.centroids()
     fs = [E.pinned_array(0.1 * (1.0 + 0.2 * np.sin(np.pi * (k + 1) * xc[:, 0]) * xc[:, 1])) for k in range(3)]   # run_nonlinear...:230-232: f = 0.1
     u1 = E.pinned_full(mesh.n_vert, 1.0)
+    _prime_pool(sim)
     ufn = fea.states_dict['u']['function']
 
     def cycle(k):

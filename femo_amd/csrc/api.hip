@@ -388,7 +388,7 @@ int femo_mesh_destroy(femo_mesh* m) {
   hipFree(m->d_bvmask); hipFree(m->d_visit_rec); hipFree(m->d_load); hipFree(m->d_zero_load); hipFree(m->d_pipe_dummy); hipFree(m->d_ubc);
   if (m->mass) { femo_mat_destroy(m->mass); m->mass = nullptr; }
   hipFree(m->d_mass_e); hipFree(m->d_mass_g); hipFree(m->d_cellvol); hipFree(m->d_cellvol_own); hipFree(m->d_cell_t);
-  hipFree(m->d_sdelta); hipFree(m->d_cols16); hipFree(m->d_bfacets); hipFree(m->d_tperm); hipFree(m->d_send_idx); hipFree(m->d_send_uvert); hipFree(m->d_send_uptr); hipFree(m->d_send_uslot); hipFree(m->d_send_flag); hipFree(m->d_send_buf); hipFree(m->d_scratch); hipFree(m->d_slices_int); hipFree(m->d_slices_bnd);
+  hipFree(m->d_sdelta); hipFree(m->d_cols16); hipFree(m->d_bfacets); hipFree(m->d_tperm); hipFree(m->d_send_idx); hipFree(m->d_send_uvert); hipFree(m->d_send_uptr); hipFree(m->d_send_uslot); hipFree(m->d_send_flag); hipFree(m->d_send_buf); hipFree(m->d_scratch); hipFree(m->d_slices_int); hipFree(m->d_slices_bnd); hipFree(m->d_slices_all);
   delete m;
   return 0;
 }
@@ -836,7 +836,8 @@ int femo_mesh_set_halo(femo_mesh* m, int n_nbr, const int32_t* nbr, const int64_
                        const int32_t* send_idx, const int64_t* recv_ptr) {
   FEMO_REQUIRE(m && n_nbr >= 0, "bad argument");
   FEMO_REQUIRE(n_nbr == 0 || (nbr && send_ptr && recv_ptr), "null halo plan");
-  hipFree(m->d_send_idx); hipFree(m->d_send_buf); hipFree(m->d_slices_int); hipFree(m->d_slices_bnd);
+  hipFree(m->d_send_idx); hipFree(m->d_send_buf); hipFree(m->d_slices_int); hipFree(m->d_slices_bnd); hipFree(m->d_slices_all);
+  m->d_slices_all = nullptr;
   hipFree(m->d_send_uvert); hipFree(m->d_send_uptr); hipFree(m->d_send_uslot); hipFree(m->d_send_flag);
   m->d_send_uvert = m->d_send_uptr = m->d_send_uslot = nullptr; m->d_send_flag = nullptr; m->n_send_verts = 0;
   m->d_send_idx = nullptr; m->d_send_buf = nullptr; m->d_slices_int = m->d_slices_bnd = nullptr;

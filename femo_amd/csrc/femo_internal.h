@@ -285,6 +285,7 @@ struct femo_mesh {
   // slices without / with ghost columns (set with the halo plan)
   int32_t* d_slices_int = nullptr; int32_t* d_slices_bnd = nullptr;
   int64_t n_int = 0, n_bnd = 0;
+  int32_t* d_slices_all = nullptr;       // both, XCD eighth by XCD eighth: interior first, ghost-column slices (sign bit) last
   struct FemoHaloDirect* hd = nullptr;   // device-initiated ghost refresh (round 6), see FemoHaloDirect
   // geometry of the whole (global) mesh for the BPX lattice; local values until femo_mesh_set_global
   double bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};
@@ -342,6 +343,7 @@ struct FemoHaloDirect {
 };
 struct femo_mesh;
 void femo_halo_direct_free(femo_mesh* m);
+int femo_emu_rendezvous(femo_ctx* ctx, hipStream_t st);   // comm.cpp: emulated ranks meet on the host (no-op for real ranks)
 bool femo_halo_direct_ready(const femo_mesh* m);
 // y[n_rows + i] <- the owners' x, through the inboxes, on `st`
 int femo_halo_direct_exchange(femo_mesh* m, const double* x_owned, double* ghost_tail, hipStream_t st);
@@ -360,11 +362,17 @@ int femo_halo_direct_pull(femo_mesh* m, unsigned long long epoch, double* ghost_
 __device__ __forceinline__ void femo_halo_signal(const FemoHaloPeers* P) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if ((int)threadIdx.x < P->n_nbr)
-    (void)__hip_atomic_fetch_add(P->cnt[threadIdx.x], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if ((int)threadIdx.x < P->n_nbr)      // (global address space spelled out: pointers loaded from memory would make these flat_ instructions)
+    (void)__hip_atomic_fetch_add((__attribute__((address_space(1))) unsigned long long*)P->cnt[threadIdx.x], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// Payload stores and loads are `sc0 sc1` instructions (relaxed system-scope atomics) on top of the uncached mapping: every
+// byte leaves for / comes from the memory side whatever the page attributes a mapper ended up with (MI355X_MICROARCH.md,
+// "Valid forms": {sc0 sc1 stores and loads both sides} + every storing wave's vmcnt wait + barrier before the counter add).
 __device__ __forceinline__ void femo_halo_store(const FemoHaloPeers* P, unsigned long long epoch, int32_t slot, double v) {
-  *(P->dst[epoch & 1ull][slot]) = v;
+  __hip_atomic_store((__attribute__((address_space(1))) double*)P->dst[epoch & 1ull][slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ double femo_halo_load(const double* p) {
+  return __hip_atomic_load((const __attribute__((address_space(1))) double*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 #endif
 

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_halo_pull(const unsigned long lo
   halo_wait(cnt, blocks, n_nbr, epoch, err);
   const double* src = inbox + (int64_t)(epoch & 1ull) * n_ghost;
   for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n_ghost; i += (int64_t)gridDim.x * FEMO_BLOCK)
-    tail[i] = __builtin_nontemporal_load(src + i);
+    tail[i] = femo_halo_load(src + i);
 }
 
 // self-test: every slot carries a number both sides can compute
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_halo_test_check(const unsigned l
     int k = 0;
     while (k + 1 < n_nbr && i >= recv_ptr[k + 1]) ++k;
     const double want = test_value(nbr_rank[k], my_rank, i - recv_ptr[k], epoch);
-    if (__builtin_nontemporal_load(src + i) != want) atomicAdd(bad, 1);
+    if (femo_halo_load(src + i) != want) atomicAdd(bad, 1);
   }
 }
 
@@ -108,7 +108,6 @@ unsigned long long femo_halo_direct_begin(femo_mesh* m) {
 // Emulated ranks are host threads of one process on ONE GPU: a consumer grid spinning for a producer another thread has
 // not launched yet could keep that producer off the device.  The emulation therefore meets on the host between the two
 // halves (like its other collectives, comm.cpp); real ranks never do.
-int femo_emu_rendezvous(femo_ctx* ctx, hipStream_t st);     // comm.cpp
 
 int femo_halo_direct_pull(femo_mesh* m, unsigned long long epoch, double* ghost_tail, hipStream_t st) {
   FemoHaloDirect* h = m->hd;

@@ -195,17 +195,81 @@ __device__ __forceinline__ double row_sum_regular(int npair, const double2* __re
   }
 }
 
+// ---- boundary slices of a partitioned mesh inside the ONE launch of the merged loop (round 6) -------------------------
+// With the device-initiated ghost refresh the product needs no second launch and no copy of the inbox: the slices with
+// ghost columns sit at the END of every XCD's range of the slice list (flagged by the sign bit), the wave that reaches one
+// first waits for the neighbours' counters (they have had the whole interior to arrive) and then gathers ghost columns
+// straight from its own inbox generation.  femo_internal.h: FemoHaloDirect.
+struct SpmvGhost {
+  const unsigned long long* cnt; const int32_t* blocks; int n_nbr; unsigned long long epoch; int32_t* err;
+  const double* ghost;          // inbox generation of this exchange, ghost k at ghost[k]
+  int64_t n_own;
+};
+__device__ __forceinline__ void spmv_halo_wait_wave(const SpmvGhost& g, int lane) {
+  if (lane < g.n_nbr) {
+    const unsigned long long want = g.epoch * (unsigned long long)g.blocks[lane];
+    const unsigned long long* c = g.cnt + (size_t)lane * FEMO_HALO_CNT_STRIDE;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > 400000000ll) { atomicExch(g.err, 1); break; }
+    }
+  }
+  // the wave reconverges here; nothing below may be issued before the counters were seen (the inbox is uncached memory:
+  // no fence beyond ordering is needed, see femo_halo_signal)
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+template <int NP, bool NT>
+__device__ __forceinline__ double row_pairs_gh(const double2* __restrict__ v2, const int2* __restrict__ c2,
+                                               const double* __restrict__ x, const double* __restrict__ gbase, int n_own, double acc) {
+  double2 a[NP];
+  int2 j[NP];
+#pragma unroll
+  for (int m = 0; m < NP; ++m) { a[m] = mat_load2<NT>(&v2[m * 64]); j[m] = c2[m * 64]; }
+  double xv[2 * NP];
+#pragma unroll
+  for (int m = 0; m < NP; ++m) {
+    // (one `sc0 sc1` load either way: the ghost entries must come from the memory side, femo_halo_store; the owned entries of
+    // these few slices can afford to)
+    xv[2 * m] = femo_halo_load((j[m].x < n_own ? x : gbase) + j[m].x);
+    xv[2 * m + 1] = femo_halo_load((j[m].y < n_own ? x : gbase) + j[m].y);
+  }
+#pragma unroll
+  for (int m = 0; m < NP; ++m) {
+    acc += a[m].x * xv[2 * m];
+    acc += a[m].y * xv[2 * m + 1];
+  }
+  return acc;
+}
+template <bool NT>
+__device__ __forceinline__ double row_sum_gh(int npair, const double2* __restrict__ v2, const int2* __restrict__ c2,
+                                             const double* __restrict__ x, const double* __restrict__ gbase, int n_own, double acc) {
+  while (npair > 4) {
+    acc = row_pairs_gh<4, NT>(v2, c2, x, gbase, n_own, acc);
+    v2 += 4 * 64; c2 += 4 * 64; npair -= 4;
+  }
+  switch (npair) {  // wave-uniform
+    case 4: return row_pairs_gh<4, NT>(v2, c2, x, gbase, n_own, acc);
+    case 3: return row_pairs_gh<3, NT>(v2, c2, x, gbase, n_own, acc);
+    case 2: return row_pairs_gh<2, NT>(v2, c2, x, gbase, n_own, acc);
+    case 1: return row_pairs_gh<1, NT>(v2, c2, x, gbase, n_own, acc);
+    default: return acc;
+  }
+}
+
 // DOT: 0 none; 1 partial d.Ax into partials[block] (d = dvec or x); 2 additionally partial x.x,
 // 3 additionally partial Ax.Ax, into the next slot; 4 (merged BPX-PCG): x.Ax, Ax.Ax and dvec.Ax into three
 // consecutive slots (p.q, q.q, r.q: everything the single all-reduce of an iteration carries besides the lattice)
-template <int DOT, bool UNIT, bool NT = true>
+template <int DOT, bool UNIT, bool NT = true, bool GH = false>
 __global__ __launch_bounds__(FEMO_BLOCK) void k_spmv_sell(
     int64_t n_rows, int64_t n_slices, const int64_t* __restrict__ mptr,
     const int32_t* __restrict__ cols, const int16_t* __restrict__ cols16, const int32_t* __restrict__ sdelta, int sdelta_stride,
     const double* __restrict__ vals, const double* __restrict__ diag, const double* __restrict__ x,
     double* __restrict__ y, double* __restrict__ partials, const int32_t* __restrict__ done,
-    const int32_t* __restrict__ slice_list, int64_t n_list, const double* __restrict__ dvec) {
+    const int32_t* __restrict__ slice_list, int64_t n_list, const double* __restrict__ dvec, SpmvGhost gh = SpmvGhost{}) {
   if (done != nullptr && *done) return;
+  bool waited = false;
   __shared__ double lds[FEMO_BLOCK / 64];
   const int lane = threadIdx.x & 63;
   // wave-uniform by construction: tell the compiler, so that slice metadata (offsets, the
@@ -222,15 +286,21 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_spmv_sell(
   const int64_t s_lo = n_walk * xcd / 8, s_hi = n_walk * (xcd + 1) / 8;
   double dot = 0.0, dot2 = 0.0, dot3 = 0.0;
   for (int64_t si = s_lo + blk_in_xcd * (FEMO_BLOCK / 64) + wave; si < s_hi; si += waves_per_xcd) {
-    const int64_t slice = slice_list ? (int64_t)slice_list[si] : si;
+    const int32_t entry = slice_list ? slice_list[si] : (int32_t)si;
+    const bool bnd = GH && entry < 0;                      // sign bit: the slice has ghost columns (wave-uniform)
+    const int64_t slice = GH ? (int64_t)(entry & 0x7FFFFFFF) : (slice_list ? (int64_t)entry : si);
     const int64_t base = mptr[slice];
     const int npair = (int)((mptr[slice + 1] - base) >> 7);
     const int64_t row = (slice << 6) + lane;
+    if (GH && bnd && !waited) { spmv_halo_wait_wave(gh, lane); waited = true; }
     const double xr = x[row < n_rows ? row : 0];
     double acc = UNIT ? xr : diag[row] * xr;   // UNIT: symmetrically scaled operator, diagonal == 1
     const double2* __restrict__ v2 = reinterpret_cast<const double2*>(vals + base) + lane;
     const int32_t* __restrict__ dl = sdelta + slice * sdelta_stride;
-    if (dl[0] != INT32_MIN) {  // wave-uniform (scalar load)
+    if (GH && bnd) {           // 32-bit columns whatever the slice's class; ghost columns come from the inbox
+      const int2* __restrict__ c2 = reinterpret_cast<const int2*>(cols + base) + lane;
+      acc = row_sum_gh<NT>(npair, v2, c2, x, gh.ghost - gh.n_own, (int)gh.n_own, acc);
+    } else if (dl[0] != INT32_MIN) {  // wave-uniform (scalar load)
       acc = row_sum_regular<NT>(npair, v2, dl, x + row, acc);
     } else if (dl[1] == 1) {   // 16-bit column deltas (the clamped row of a lane beyond n_rows still addresses valid entries)
       const int* __restrict__ c16 = reinterpret_cast<const int*>(cols16) + (base >> 1) + lane;
@@ -871,7 +941,7 @@ int femo_spmv_grid(const femo_mesh* m) {
 static int launch_spmv(const femo_mat* A, const double* vals, const double* x, double* y,
                        double* partials, const int32_t* done, bool unit = false, bool dot2 = false,
                        const int32_t* slice_list = nullptr, int64_t n_list = 0, hipStream_t stream = nullptr,
-                       const double* dvec = nullptr, bool dot_yy = false, bool dot3 = false) {
+                       const double* dvec = nullptr, bool dot_yy = false, bool dot3 = false, const SpmvGhost* gh = nullptr) {
   const femo_mesh* m = A->mesh;
   const int64_t n_walk = slice_list ? n_list : m->n_slices;
   if (n_walk == 0 && !partials) return 0;
@@ -888,7 +958,12 @@ static int launch_spmv(const femo_mat* A, const double* vals, const double* x, d
     if (nt) hipLaunchKernelGGL((k_spmv_sell<DOT, UNIT, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);        \
     else hipLaunchKernelGGL((k_spmv_sell<DOT, UNIT, false>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS);          \
   } while (0)
-  if (partials && unit && dot3) FEMO_SPMV_LAUNCH(4, true);
+  if (gh != nullptr) {                                    // the merged loop's one launch over [interior | boundary] slices
+    FEMO_REQUIRE(partials && unit && dot3 && slice_list, "ghost-aware product: merged-loop variant only");
+    if (nt) hipLaunchKernelGGL((k_spmv_sell<4, true, true, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS, *gh);
+    else hipLaunchKernelGGL((k_spmv_sell<4, true, false, true>), dim3(g), dim3(FEMO_BLOCK), 0, st, FEMO_SPMV_ARGS, *gh);
+  }
+  else if (partials && unit && dot3) FEMO_SPMV_LAUNCH(4, true);
   else if (partials && unit && dot_yy) FEMO_SPMV_LAUNCH(3, true);
   else if (partials && unit && dot2) FEMO_SPMV_LAUNCH(2, true);
   else if (partials && unit) FEMO_SPMV_LAUNCH(1, true);
@@ -949,6 +1024,18 @@ static int halo_spmv_inflight(const femo_mat* A, const double* vals, double* x, 
   if (g_int) *g_int = grid_of(m->n_int);
   if (g_bnd) *g_bnd = grid_of(m->n_bnd);
   const bool dot3 = n_slots == 3;
+  if (femo_halo_direct_ready(m) && m->d_slices_all != nullptr && dot3 && unit && partials != nullptr) {
+    // round 6: ONE launch.  Interior slices first in every XCD's range, the slices with ghost columns behind them; their
+    // waves wait for the neighbours' counters and read the ghosts from this rank's inbox (k_spmv_sell<.., GH = true>).
+    FemoHaloDirect* h = m->hd;
+    if (ctx->emu != nullptr) FEMO_TRY(femo_emu_rendezvous(ctx, st));       // (emulated ranks meet on the host, halo_direct.hip)
+    SpmvGhost gh;
+    gh.cnt = h->counters; gh.blocks = h->d_blocks; gh.n_nbr = m->n_nbr; gh.epoch = h->loop_epoch; gh.err = h->d_err;
+    gh.ghost = h->inbox + (int64_t)(h->loop_epoch & 1ull) * h->n_ghost; gh.n_own = m->n_rows;
+    if (g_int) *g_int = femo_spmv_grid(m);
+    if (g_bnd) *g_bnd = 0;
+    return launch_spmv(A, vals, x, y, partials, done, unit, false, m->d_slices_all, m->n_slices, st, dvec, false, dot3, &gh);
+  }
   FEMO_TRY(launch_spmv(A, vals, x, y, partials, done, unit, false, m->d_slices_int, m->n_int, st, dvec, false, dot3));
   if (femo_halo_direct_ready(m)) {
     // device-initiated refresh (round 6): the neighbours' prolongations stored the new direction into this rank's inbox
@@ -1029,6 +1116,21 @@ int femo_mesh_classify_slices(femo_mesh* m) {
   m->n_int = (int64_t)li.size(); m->n_bnd = (int64_t)lb.size();
   FEMO_HIP_CHECK(hipMalloc(&m->d_slices_int, std::max<size_t>(li.size(), 1) * sizeof(int32_t)));
   FEMO_HIP_CHECK(hipMalloc(&m->d_slices_bnd, std::max<size_t>(lb.size(), 1) * sizeof(int32_t)));
+  // one list for the single-launch product of the merged loop (round 6): the kernel gives XCD k the k-th eighth of the list;
+  // inside every eighth the interior slices come first, the slices with ghost columns (sign bit set) last
+  hipFree(m->d_slices_all); m->d_slices_all = nullptr;
+  if (!lb.empty() && femo_env_flag("FEMO_SPMV_TWO_LAUNCHES") == false) {
+    std::vector<int32_t> all((size_t)m->n_slices);
+    size_t w = 0;
+    for (int xcd = 0; xcd < 8; ++xcd) {
+      const int64_t lo = m->n_slices * xcd / 8, hi = m->n_slices * (xcd + 1) / 8;
+      for (int64_t sl = lo; sl < hi; ++sl) if (!flag[(size_t)sl]) all[w++] = (int32_t)sl;
+      for (int64_t sl = lo; sl < hi; ++sl) if (flag[(size_t)sl]) all[w++] = (int32_t)sl | (int32_t)0x80000000;
+    }
+    FEMO_HIP_CHECK(hipMalloc(&m->d_slices_all, all.size() * sizeof(int32_t)));
+    FEMO_HIP_CHECK(hipMemcpyAsync(m->d_slices_all, all.data(), all.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    FEMO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  }
   if (!li.empty()) FEMO_HIP_CHECK(hipMemcpyAsync(m->d_slices_int, li.data(), li.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
   if (!lb.empty()) FEMO_HIP_CHECK(hipMemcpyAsync(m->d_slices_bnd, lb.data(), lb.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
   FEMO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
