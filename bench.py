@@ -637,6 +637,7 @@ def run_distributed_bench(args, ctx, control, cpu_baseline: bool = True):
     achieved = B_A / (spmv_ms * 1e-3) / 1e9
     L = mesh.local
     lat = dm.pc_info()
+    hd = dm.halo_direct_info()
     # bytes a rank moves per CG iteration besides its HBM traffic: ghost values in and out, the lattice all-reduce
     halo_out, halo_in = int(L.send_ptr[-1]) * 8, int(L.recv_ptr[-1]) * 8
     stats = control.gather([mesh.n_owned, mesh.n_vert - mesh.n_owned, len(L.nbr), halo_out, halo_in, achieved, spmv_ms,
@@ -674,7 +675,8 @@ def run_distributed_bench(args, ctx, control, cpu_baseline: bool = True):
         "config": {
             "workload": (f"3-D linear Poisson, P1 tets, unit cube n={args.n}: {n_dof} DOFs, {n_cell_g} cells, "
                          f"{world}-way block partition {'x'.join(str(g) for g in _grid(world))} (rank-local mesh generation), "
-                         f"ghost-DOF halo (ncclSend/Recv) + RCCL all-reduce {B.PC.upper()}-CG; same cycle as N=1, every rank with "
+                         f"ghost-DOF halo ({'device-initiated: stores into the neighbours hipIpc-mapped inboxes + counters' if hd['enabled'] else 'ncclSend/Recv'}) "
+                         f"+ RCCL all-reduce {B.PC.upper()}-CG; same cycle as N=1, every rank with "
                          f"NumPy arrays of its share of f, u and dJ/df at the operator boundary"),
             "boundary": "host (per rank: NumPy in pinned blocks; H2D + D2H inside the timed region)",
             "preconditioner": B.PC, "pc_lattice": lat,
@@ -687,6 +689,7 @@ def run_distributed_bench(args, ctx, control, cpu_baseline: bool = True):
             # halo exchange per ENQUEUED iteration (batches: a few iterations behind the converged one are enqueued too)
             "allreduce_per_cg_iteration": (sum(i.get("loop_allreduces", 0) for i in infos) / max(sum(i["iterations"] for i in infos), 1)),
             "collectives_per_step_rank0": {k: v / max(K, 1) for k, v in comm.items()},
+            "ghost_refresh_rank0": hd,          # {enabled, exchanges, consumer time-outs, producer workgroups} of the device-initiated plan (all zero: ncclSend/Recv)
             "allreduce_payload": "ONE ncclAllReduce per iteration: h on the lattice nodes SEVERAL ranks touch of the three brick-filled levels (L, L-1, L-2; sparse lists), "
                                  "level L-3 dense (restricted from the rank's partial sums before the exchange), 7 scalars (p.q, r.q, q.q, r.r, 3 single-rank lattice sums)",
             "linear_solves_per_step": per, "cg_iterations_per_step": its_per_step, "cg_ms_per_step": cg_ms,

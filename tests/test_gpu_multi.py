@@ -14,11 +14,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_rank_bench_over_rccl():
+@pytest.mark.parametrize("halo", ["direct", "rccl"])
+def test_two_rank_bench_over_rccl(halo):
+    """`halo`: the ghost refresh -- device-initiated over hipIpc-mapped inboxes (round 6; falls back collectively to
+    ncclSend/Recv if its self-test fails on the box, which the record then shows) or ncclSend/Recv by request."""
     from femo_amd import _lib
     if _lib.device_count() < 2:
         pytest.skip("needs two GPUs")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("FEMO_HALO_RCCL", None)
+    if halo == "rccl":
+        env["FEMO_HALO_RCCL"] = "1"
     # n = 48: the smallest cube whose lattice has the four levels the merged loop (one all-reduce per iteration) needs
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mesh-n", "48", "--steps", "3",
                         "--warmup", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
@@ -35,6 +41,10 @@ def test_two_rank_bench_over_rccl():
     # the main stream (counted inside the solver loops); the run checks itself against the DST-exact cycle
     assert 1.0 <= c["allreduce_per_cg_iteration"] <= 1.3, c["allreduce_per_cg_iteration"]
     assert r["check"]["u_rel_err"] < 1e-10 and r["check"]["grad_rel_err"] < 1e-10
+    hd = c["ghost_refresh_rank0"]
+    assert hd["timeouts"] == 0 and (hd["enabled"] == 0 if halo == "rccl" else hd["enabled"] in (0, 1))
+    if hd["enabled"]:
+        assert hd["exchanges"] > sum(its)                # every iteration refreshed its ghosts through the inboxes
 
 
 @pytest.mark.parametrize("world", [4, 8])
