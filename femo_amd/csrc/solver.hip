@@ -892,6 +892,15 @@ __global__ void k_unscale(int64_t n, int add, const double* __restrict__ s, cons
     x[i] = (add ? x[i] : 0.0) + s[i] * xh[i];
 }
 
+// the same, but only once the loop has converged (flags[0] != 0): enqueued behind every batch of the merged loop so that
+// the poll that finds the solve converged finds the solution too -- one host round trip less per solve (round 6)
+__global__ void k_unscale_done(int64_t n, int add, const double* __restrict__ s, const double* __restrict__ xh, double* __restrict__ x,
+                               const int32_t* __restrict__ flags) {
+  if (flags[0] == 0) return;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = (add ? x[i] : 0.0) + s[i] * xh[i];
+}
+
 __global__ __launch_bounds__(FEMO_BLOCK) void k_dot(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
                                                     double* __restrict__ partials) {
   __shared__ double lds[FEMO_BLOCK / 64];
@@ -1545,20 +1554,28 @@ static int solve_pcg_bpx_merged(femo_mat* A, const femo_vec* b, femo_vec* x, con
       FEMO_TRY(femo_pc_merged_apply(m, mask, A->pc_key, V, S, ctx->d_flags, &stop));
     }
     FEMO_HIP_CHECK(hipGetLastError());
+    // the poll carries everything the end of a converged solve needs: x (unscaled on the device only if the flag is set),
+    // the flags and the scalars -- the batch that converges costs ONE host round trip, not two (round 6)
+    if (n > 0) hipLaunchKernelGGL(k_unscale_done, dim3(2048), dim3(256), 0, st, n, opts->zero_guess ? 0 : 1, A->d_s, w.xh, x->d, ctx->d_flags);
     FEMO_HIP_CHECK(hipMemcpyAsync(h_flags, ctx->d_flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, S, FEMO_NSCAL * sizeof(double), hipMemcpyDeviceToHost, st));
     FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_sample], st));
     FEMO_HIP_CHECK(hipEventSynchronize(ctx->ev_pool[2 * n_sample]));
     if (h_flags[0] || it >= max_it) done = true;
   }
   info->loop_allreduces = (int32_t)(ctx->n_allreduce - ar0);
-  // x, the final scalars and the time with one more synchronisation
-  if (n > 0) hipLaunchKernelGGL(k_unscale, dim3(2048), dim3(256), 0, st, n, opts->zero_guess ? 0 : 1, A->d_s, w.xh, x->d);
-  FEMO_HIP_CHECK(hipMemcpyAsync(h_flags, ctx->d_flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, S, FEMO_NSCAL * sizeof(double), hipMemcpyDeviceToHost, st));
-  FEMO_HIP_CHECK(hipEventRecord(ctx->ev1, st));
-  FEMO_HIP_CHECK(hipEventSynchronize(ctx->ev1));
   float ms = 0.f;
-  FEMO_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  if (h_flags[0]) {
+    FEMO_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev_pool[2 * n_sample]));
+  } else {
+    // not converged within max_it: x of the last iterate, the final scalars and the time with one more synchronisation
+    if (n > 0) hipLaunchKernelGGL(k_unscale, dim3(2048), dim3(256), 0, st, n, opts->zero_guess ? 0 : 1, A->d_s, w.xh, x->d);
+    FEMO_HIP_CHECK(hipMemcpyAsync(h_flags, ctx->d_flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, S, FEMO_NSCAL * sizeof(double), hipMemcpyDeviceToHost, st));
+    FEMO_HIP_CHECK(hipEventRecord(ctx->ev1, st));
+    FEMO_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    FEMO_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  }
   const int iters = h_flags[1];
   const int conv = h_flags[0] ? (h_flags[2] ? -1 : 1) : 0;
   if (conv == 1 && iters > 0) { m->pcg_prev_iters = m->pcg_last_iters; m->pcg_last_iters = iters; }
