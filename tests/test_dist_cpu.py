@@ -401,3 +401,72 @@ def test_two_process_control_plane(tmp_path):
         z = np.load(tmp_path / f"ctl{r}.npz")
         assert np.array_equal(z["got"], ref) and z["s"].tolist() == [3.0, 4.0] and z["mx"].tolist() == [1.0]
         assert z["g"].tolist() == [[0.0, 0.0], [1.0, 10.0]]
+
+
+def test_connect_halo_direct_plans_and_collective_verdict():
+    """Host logic of the device-initiated ghost refresh (femo_amd/dist::connect_halo_direct, include/femo_hip.h ABI 9) with
+    stand-in device meshes: every rank hands its neighbours' handles / addresses to `connect` in the order of ITS halo plan,
+    with the neighbour's receive offset, ghost count, counter slot and producer workgroups for THIS rank; the plan is enabled
+    on all ranks or on none (one failing self-test, one rank without neighbours, FEMO_HALO_RCCL)."""
+    import threading
+    import types
+    from femo_amd.dist import ThreadControl, connect_halo_direct
+
+    # three ranks in a line: 0 - 1 - 2; rank 1 lists its neighbours as [2, 0] (plans need not be sorted)
+    plans = {0: dict(nbr=[1], recv_ptr=[0, 5]), 1: dict(nbr=[2, 0], recv_ptr=[0, 7, 11]), 2: dict(nbr=[1], recv_ptr=[0, 3])}
+
+    class FakeMesh:
+        def __init__(self, rank, selftest_ok=True):
+            self.rank, self.selftest_ok, self.connected, self.enabled = rank, selftest_ok, None, None
+
+        def halo_direct_export(self):
+            return bytes([self.rank]) * 64, 1000 + self.rank, 10 + self.rank
+
+        def halo_direct_connect(self, mode, handles, addrs, off, ng, slot, blocks):
+            self.connected = dict(mode=mode, handles=handles, addrs=list(addrs), off=list(off), ng=list(ng), slot=list(slot), blocks=list(blocks))
+
+        def halo_direct_selftest(self):
+            return self.selftest_ok
+
+        def halo_direct_enable(self, on):
+            self.enabled = bool(on)
+
+    def run(world, make_mesh, ranks_plans):
+        shared = ThreadControl.Shared(world)
+        meshes = [make_mesh(r) for r in range(world)]
+        out = [None] * world
+
+        def body(r):
+            L = types.SimpleNamespace(nbr=np.array(ranks_plans[r]["nbr"], np.int32), recv_ptr=np.array(ranks_plans[r]["recv_ptr"], np.int64))
+            out[r] = connect_halo_direct(ThreadControl(r, shared, None), meshes[r], L)
+
+        ts = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+        [t.start() for t in ts]
+        [t.join(timeout=60) for t in ts]
+        assert not any(t.is_alive() for t in ts)
+        return out, meshes
+
+    os.environ.pop("FEMO_HALO_RCCL", None)
+    out, meshes = run(3, FakeMesh, plans)
+    assert out == [True, True, True] and all(m.enabled for m in meshes)
+    c1 = meshes[1].connected                     # rank 1, neighbours in ITS order [2, 0]
+    assert c1["mode"] == 1 and c1["handles"] is None                      # one process: addresses, no IPC handles
+    assert c1["addrs"] == [1002, 1000] and c1["blocks"] == [12, 10]
+    assert c1["off"] == [0, 0] and c1["ng"] == [3, 5] and c1["slot"] == [0, 0]      # rank 1 is neighbour 0 of both
+    c0, c2 = meshes[0].connected, meshes[2].connected
+    assert c0["addrs"] == [1001] and c0["off"] == [7] and c0["slot"] == [1] and c0["ng"] == [11]   # rank 0 is rank 1's SECOND neighbour: recv_ptr[1]
+    assert c2["addrs"] == [1001] and c2["off"] == [0] and c2["slot"] == [0] and c2["ng"] == [11]
+    # one rank's self-test fails: nobody uses the plan
+    out, meshes = run(3, lambda r: FakeMesh(r, selftest_ok=(r != 2)), plans)
+    assert out == [False, False, False] and not any(m.enabled for m in meshes)
+    # a rank without neighbours cannot export: nobody uses the plan
+    lonely = {0: dict(nbr=[1], recv_ptr=[0, 5]), 1: dict(nbr=[0], recv_ptr=[0, 5]), 2: dict(nbr=[], recv_ptr=[0])}
+    out, meshes = run(3, FakeMesh, lonely)
+    assert out == [False, False, False] and not any(m.enabled for m in meshes)
+    # the switch
+    os.environ["FEMO_HALO_RCCL"] = "1"
+    try:
+        out, meshes = run(3, FakeMesh, plans)
+        assert out == [False, False, False] and all(m.connected is None for m in meshes)
+    finally:
+        del os.environ["FEMO_HALO_RCCL"]
