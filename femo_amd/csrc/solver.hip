@@ -1557,10 +1557,15 @@ static int solve_pcg_bpx_merged(femo_mat* A, const femo_vec* b, femo_vec* x, con
     // the poll carries everything the end of a converged solve needs: x (unscaled on the device only if the flag is set),
     // the flags and the scalars -- the batch that converges costs ONE host round trip, not two (round 6)
     if (n > 0) hipLaunchKernelGGL(k_unscale_done, dim3(2048), dim3(256), 0, st, n, opts->zero_guess ? 0 : 1, A->d_s, w.xh, x->d, ctx->d_flags);
+    // a consumer of the device-initiated ghost refresh that gave up waiting (4 s) must not pass for a result: its flag
+    // travels in the spare word of the poll
+    if (femo_halo_direct_ready(m)) FEMO_HIP_CHECK(hipMemcpyAsync(ctx->d_flags + 3, m->hd->d_err, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     FEMO_HIP_CHECK(hipMemcpyAsync(h_flags, ctx->d_flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, S, FEMO_NSCAL * sizeof(double), hipMemcpyDeviceToHost, st));
     FEMO_HIP_CHECK(hipEventRecord(ctx->ev_pool[2 * n_sample], st));
     FEMO_HIP_CHECK(hipEventSynchronize(ctx->ev_pool[2 * n_sample]));
+    FEMO_REQUIRE(!(femo_halo_direct_ready(m) && h_flags[3] != 0),
+                 "ghost refresh: a consumer waited 4 s for a neighbour's stores and gave up (rank %d of %d) -- the solve is void", ctx->rank, ctx->nranks);
     if (h_flags[0] || it >= max_it) done = true;
   }
   info->loop_allreduces = (int32_t)(ctx->n_allreduce - ar0);
