@@ -1468,7 +1468,7 @@ static int solve_pcg_bpx_merged(femo_mat* A, const femo_vec* b, femo_vec* x, con
   // identity rows, solved by k_cg_init) is written speculatively in front of it -- 6 us that save such a solve (Newton's
   // later passes) a second stream drain; an iterating solve overwrites it at the end.
   const bool spec_x = n > 0 && opts->zero_guess;
-  if (spec_x) hipLaunchKernelGGL(k_unscale, dim3(2048), dim3(256), 0, st, n, 0, A->d_s, w.xh, x->d);
+  if (spec_x) hipLaunchKernelGGL(k_unscale_done, dim3(2048), dim3(256), 0, st, n, 0, A->d_s, w.xh, x->d, ctx->d_flags);   // (only if the flag says so: an iterating solve skips the 44 us at C4)
   FEMO_HIP_CHECK(hipMemcpyAsync(h_flags, ctx->d_flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   FEMO_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, S, FEMO_NSCAL * sizeof(double), hipMemcpyDeviceToHost, st));
   FEMO_HIP_CHECK(hipEventRecord(ctx->ev1, st));

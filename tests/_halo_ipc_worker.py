@@ -4,6 +4,7 @@ context runs under the model communicator (no RCCL: it cannot place two ranks on
 neighbour exchange to be real."""
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -40,6 +41,8 @@ def main():
         ul = np.full(len(L.x), 1e30)                             # ghosts hold garbage until the neighbour's stores arrive
         ul[:L.n_owned] = u[own]
         U, Y = E.Vec(ctx, len(L.x)).set(ul), E.Vec(ctx, len(L.x))
+        if rep % 2 == rank:
+            time.sleep(0.25)                                     # skew: the other process's consumer really WAITS on its counters
         J.mult(U, Y)
         ref = (K @ u)[own]
         worst = max(worst, float(np.abs(Y.get(L.n_owned) - ref).max() / np.abs(ref).max()))
