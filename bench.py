@@ -385,6 +385,8 @@ def _roofline(kernel: str, bytes_per_launch: int, ms: float, samples: int, note:
             "achieved_algorithmic": alg, "frac_algorithmic": alg / HBM_PEAK_GBS if alg else None,
             "algorithmic_bytes_per_launch": int(bytes_per_launch), "stored_bytes_per_launch": stored,
             "format_compression": bytes_per_launch / phys if phys else None,
+            "frac_algorithmic_note": "CSR-equivalent rate over the HBM peak, not a hardware fraction: the kernel moves format_compression x fewer bytes than the "
+                                     "SURVEY.md 8(d) formula counts (and an operator that fits the 256 MB Infinity Cache is not read from HBM at all)",
             "frac_physical": ach / HBM_PEAK_GBS if ach else None,          # (rounds 2-5 name of `frac`; kept for readers of old lines)
             "avg_launch_ms": ms, "launches_timed": samples,
             "timed": "single launches inside the timed solver loops (HIP events on the library's stream)" + (("; " + note) if note else "")}

@@ -470,3 +470,29 @@ def test_connect_halo_direct_plans_and_collective_verdict():
         assert out == [False, False, False] and all(m.connected is None for m in meshes)
     finally:
         del os.environ["FEMO_HALO_RCCL"]
+
+
+@pytest.mark.parametrize("world", [2, 3, 5, 8])
+def test_inbox_addressing_delivers_every_ghost(world):
+    """The addressing of the device-initiated ghost refresh, replayed in NumPy on RCB partitions of a jittered cube: every rank
+    writes segment k of its send list at offset recv_ptr_j[kk] of neighbour j's inbox (kk = its place in j's neighbour list --
+    exactly what connect_halo_direct hands to femo_mesh_halo_direct_connect), generation = epoch & 1.  After one exchange every
+    inbox holds the owners' values of all its ghosts, in ghost order; a second exchange lands in the other generation."""
+    m = fo.unit_cube_mesh(7, 0.2)
+    part = rcb_partition(m.x, world)
+    Ls = [build_local_mesh(m.x, m.conn, part, r, world) for r in range(world)]
+    inbox = [np.full((2, max(len(L.x) - L.n_owned, 1)), np.nan) for L in Ls]
+    for epoch, seed in ((1, 0), (2, 1)):
+        xg = np.random.default_rng(seed).standard_normal(m.n_vert)
+        for r, L in enumerate(Ls):
+            for k, j in enumerate(L.nbr):
+                Lj = Ls[int(j)]
+                kk = list(Lj.nbr).index(r)
+                seg = L.send_idx[L.send_ptr[k]:L.send_ptr[k + 1]]
+                off = int(Lj.recv_ptr[kk])
+                assert len(seg) == int(Lj.recv_ptr[kk + 1]) - off           # both sides agree on the segment's length
+                inbox[int(j)][epoch & 1, off:off + len(seg)] = xg[L.vert_global[seg]]
+        for r, L in enumerate(Ls):
+            ng = len(L.x) - L.n_owned
+            assert int(L.recv_ptr[-1]) == ng
+            assert np.array_equal(inbox[r][epoch & 1, :ng], xg[L.vert_global[L.n_owned:]])
