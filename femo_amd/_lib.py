@@ -19,7 +19,7 @@ c_i64p = C.POINTER(C.c_int64)
 c_f64p = C.POINTER(C.c_double)
 H = C.c_void_p  # opaque handle
 
-ABI_VERSION = 9            # include/femo_hip.h FEMO_ABI_VERSION
+ABI_VERSION = 10            # include/femo_hip.h FEMO_ABI_VERSION
 MESH_INFO_COUNT = 12
 MESH_INFO_KEYS = ("tdim", "n_vert", "n_rows", "n_cell", "nnz", "sell_entries", "max_rowlen",
                   "max_valence", "n_slices", "visit_entries", "regular_slices", "short_slices")
@@ -94,6 +94,8 @@ PROTOTYPES = {
     "femo_vec_axpy": (C.c_int, [H, C.c_double, H]),
     "femo_vec_dot": (C.c_int, [H, H, c_i64, c_f64p]),
     "femo_vec_dots": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), c_i64, c_f64p]),
+    "femo_vec_dots_rhs": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), c_i64, c_f64p, H, H]),
+    "femo_mat_identity_solve": (C.c_int, [H, H, H]),
     "femo_mesh_create": (C.c_int, [H, C.c_int, c_i64, c_i64, C.c_void_p, c_i64, C.c_void_p, C.POINTER(H)]),
     "femo_mesh_destroy": (C.c_int, [H]),
     "femo_mesh_info": (C.c_int, [H, c_i64p]),

@@ -1244,14 +1244,23 @@ extern "C" int femo_vec_dot(const femo_vec* x, const femo_vec* y, int64_t n, dou
 }
 
 namespace {
-struct DotPairs { const double* a[4]; const double* b[4]; int k; };
+// rb != nullptr: one more sum behind the k pairs (slot k) -- rho_0 of the Krylov loops for the right-hand side rb and the
+// operator with diagonal `diag`, sum over the rows that are not identity rows of (rb_i / sqrt(diag_i))^2, formed exactly as
+// k_invsqrt_diag + k_cg_init form it: Newton takes the solver's own "nothing to iterate on" decision from it (round 6)
+struct DotPairs { const double* a[4]; const double* b[4]; int k; const double* rb; const double* diag; const uint8_t* idrow; };
 __global__ __launch_bounds__(FEMO_BLOCK) void k_dots(int64_t n, DotPairs d, double* __restrict__ partials) {
   __shared__ double lds[FEMO_BLOCK / 64];
   double s[4] = {0.0, 0.0, 0.0, 0.0};
+  double rho = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * FEMO_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FEMO_BLOCK) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (j < d.k) s[j] += d.a[j][i] * d.b[j][i];
+    if (d.rb != nullptr && !(d.idrow != nullptr && d.idrow[i])) {
+      const double si = 1.0 / sqrt(d.diag[i]);
+      const double ri = si * d.rb[i];
+      rho += ri * ri;
+    }
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -1260,13 +1269,56 @@ __global__ __launch_bounds__(FEMO_BLOCK) void k_dots(int64_t n, DotPairs d, doub
       if (threadIdx.x == 0) partials[(int64_t)j * FEMO_MAX_PARTIALS + blockIdx.x] = t;
     }
   }
+  if (d.rb != nullptr) {
+    const double t = femo_block_sum<FEMO_BLOCK>(rho, lds);
+    if (threadIdx.x == 0) partials[(int64_t)d.k * FEMO_MAX_PARTIALS + blockIdx.x] = t;
+  }
 }
 }  // namespace
 
+// x = what a Krylov solve of A x = b returns when it decides not to iterate from the zero guess: b_i / diag_i on the identity
+// rows of the last assembly (the loops solve them up front, k_cg_init), 0 elsewhere
+__global__ void k_identity_solve(int64_t n, int64_t n_all, const double* __restrict__ b, const double* __restrict__ diag,
+                                 const uint8_t* __restrict__ idrow, double* __restrict__ x) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += (int64_t)gridDim.x * blockDim.x) {
+    double v = 0.0;
+    if (i < n && idrow != nullptr && idrow[i]) { const double si = 1.0 / sqrt(diag[i]); v = si * (si * b[i]); }
+    x[i] = v;
+  }
+}
+extern "C" int femo_mat_identity_solve(const femo_mat* A, const femo_vec* b, femo_vec* x) {
+  FEMO_REQUIRE(A && b && x, "null argument");
+  const femo_mesh* m = A->mesh;
+  FEMO_REQUIRE(b->n >= m->n_rows && x->n >= m->n_rows, "vector size mismatch");
+  FEMO_TRY(femo_vec_await(b));
+  femo_vec_touch(x);
+  if (x->n == 0) return 0;
+  hipLaunchKernelGGL(k_identity_solve, dim3(2048), dim3(256), 0, m->ctx->stream, m->n_rows, x->n, b->d, A->d_diag, A->has_idrows ? A->d_idrows : nullptr, x->d);
+  FEMO_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+static int vec_dots(int k, const femo_vec* const* x, const femo_vec* const* y, int64_t n, double* out, const femo_mat* A, const femo_vec* rb);
 extern "C" int femo_vec_dots(int k, const femo_vec* const* x, const femo_vec* const* y, int64_t n, double* out) {
+  return vec_dots(k, x, y, n, out, nullptr, nullptr);
+}
+// ... and out[k] = rho_0 a Krylov solve of A with right-hand side rb would start from (see k_dots): the same launch, the same
+// reduction, the same host synchronisation
+extern "C" int femo_vec_dots_rhs(int k, const femo_vec* const* x, const femo_vec* const* y, int64_t n, double* out,
+                                 const femo_mat* A, const femo_vec* rb) {
+  FEMO_REQUIRE(A && rb && A->d_diag, "femo_vec_dots_rhs: null matrix / right-hand side");
+  FEMO_REQUIRE(n <= rb->n && n <= A->mesh->n_rows, "femo_vec_dots_rhs: length exceeds the operator's rows");
+  return vec_dots(k, x, y, n, out, A, rb);
+}
+static int vec_dots(int k, const femo_vec* const* x, const femo_vec* const* y, int64_t n, double* out, const femo_mat* A, const femo_vec* rb) {
   FEMO_REQUIRE(x && y && out && k >= 1 && k <= 4, "femo_vec_dots: 1..4 pairs");
   DotPairs d;
   d.k = k;
+  d.rb = nullptr; d.diag = nullptr; d.idrow = nullptr;
+  if (A != nullptr) {
+    FEMO_TRY(femo_vec_await(rb));
+    d.rb = rb->d; d.diag = A->d_diag; d.idrow = A->has_idrows ? A->d_idrows : nullptr;
+  }
   for (int j = 0; j < 4; ++j) {
     const int jj = j < k ? j : 0;
     FEMO_REQUIRE(x[jj] && y[jj] && n <= x[jj]->n && n <= y[jj]->n, "dot length exceeds vector size");
@@ -1278,7 +1330,7 @@ extern "C" int femo_vec_dots(int k, const femo_vec* const* x, const femo_vec* co
   const int g = vec_grid(ctx, n);
   hipLaunchKernelGGL(k_dots, dim3(g), dim3(FEMO_BLOCK), 0, ctx->stream, n, d, ctx->d_partials);
   FEMO_HIP_CHECK(hipGetLastError());
-  return femo_reduce_to_host(ctx, g, k, out);
+  return femo_reduce_to_host(ctx, g, k + (A != nullptr ? 1 : 0), out);
 }
 
 static int ensure_scaled(femo_mat* A, bool transpose);

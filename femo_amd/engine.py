@@ -453,6 +453,18 @@ class Vec:
         check(pairs[0][0].lib.femo_vec_dots(k, xs, ys, int(n), out))
         return [float(v) for v in out]
 
+    @staticmethod
+    def dots_rhs(pairs, n: int, mat: "Mat", rhs: "Vec") -> List[float]:
+        """``dots(pairs, n)`` plus, as the last value, rho_0 = sum over the non-identity rows of (rhs_i / sqrt(diag_i))^2 for
+        the operator ``mat``: what a Krylov solve of it with right-hand side ``rhs`` starts from (femo_vec_dots_rhs) -- the
+        same launch, reduction and host synchronisation."""
+        k = len(pairs)
+        xs = (C.c_void_p * k)(*[p[0].handle for p in pairs])
+        ys = (C.c_void_p * k)(*[p[1].handle for p in pairs])
+        out = (C.c_double * (k + 1))()
+        check(pairs[0][0].lib.femo_vec_dots_rhs(k, xs, ys, int(n), out, mat.handle, rhs.handle))
+        return [float(v) for v in out]
+
     @property
     def device_ptr(self) -> int:
         """Mutable device address: the library assumes the holder writes through it (include/femo_hip.h)."""
@@ -645,6 +657,12 @@ class Mat:
     def mult(self, x: Vec, y: Vec, transpose: bool = False) -> Vec:
         check(self.lib.femo_mat_spmv(self.handle, int(transpose), x.handle, y.handle))
         return y
+
+    def identity_solve(self, b: Vec, x: Vec) -> Vec:
+        """x = the result of a solve that decides not to iterate from the zero guess: b_i / diag_i on the identity rows of the
+        last assembly, 0 elsewhere (femo_mat_identity_solve)."""
+        check(self.lib.femo_mat_identity_solve(self.handle, b.handle, x.handle))
+        return x
 
     def prescale(self) -> "Mat":
         """S = diag^-1/2 and S A S now (`femo_mat_prescale`): what the first solve with this matrix would form first."""

@@ -637,6 +637,7 @@ class _NewtonBase:
         # after the assembly pass (Vec.dots); rounds 1-3 drained the stream for each of them.
         unorm = uAu = None
         g2 = None
+        rho_b = None               # rho_0 of the NEXT solve, when the last reduction carried it (round 6)
         while not converged and it < self.max_it:
             if it > 0:
                 opts["atol"] = max(KSP_OPTIONS["atol"], KSP_OPTIONS["rtol"] * z0, self.NOISE_FACTOR * eps * unorm)
@@ -667,11 +668,27 @@ class _NewtonBase:
                                     ds._g2_own = (n_own, g2)
                         energy_scale = float(np.sqrt(max(uAu - g2, 0.0)))
                     opts["atol_pc"] = opts.get("rtol_bpx", 1e-11) * energy_scale
-            ksp = KSP(A, opts)
-            ksp.solve(b, dx)
-            if z0 is None:
-                z0 = ksp.info.rhs_norm
-            self.ksp_iterations.append(ksp.info.iterations)
+            # Round 6: the solver's own first decision -- "nothing to iterate on": rho_0 = b^T D^-1 b over the non-identity
+            # rows is zero or not above atol^2 (k_pcg_setup / the classic loops) -- taken HERE from the number that came back
+            # with this pass's reduction (Vec.dots_rhs), so that a pass whose correction is below the rounding error of the
+            # assembled residual (Newton's passes 2 and 3 of a linear form) costs one small launch instead of a solver
+            # set-up, a first application and a host round trip.  Same numbers, same rule, same result (identity rows solved,
+            # zero elsewhere); the solve is still reported (0 iterations).
+            skip = (rho_b is not None and A.symmetric and not hasattr(A, "backend_solve")
+                    and (rho_b == 0.0 or not (np.sqrt(rho_b) > opts["atol"])))
+            if skip:
+                A.mat.identity_solve(b, dx)
+                ksp_its = 0
+                LAST_KSP_INFO.append(dict(thread=threading.get_ident(), iterations=0, converged=1, residual_norm=float(np.sqrt(rho_b)),
+                                          rhs_norm=float(np.sqrt(rho_b)), pc_residual_norm=0.0, pc_rhs_norm=0.0, solve_ms=0.0, spmv_ms=0.0,
+                                          spmv_samples=0, loop_allreduces=0, skipped_by_newton=True))
+            else:
+                ksp = KSP(A, opts)
+                ksp.solve(b, dx)
+                if z0 is None:
+                    z0 = ksp.info.rhs_norm
+                ksp_its = ksp.info.iterations
+            self.ksp_iterations.append(ksp_its)
             func.vec.axpy(-1.0, dx)
             it += 1
             # next pass: residual for the convergence test and, in the same launch, the Jacobian the
@@ -690,7 +707,14 @@ class _NewtonBase:
                 Au = _work(mesh, "newton_Au", lambda: Vec(ctx, n))
                 A.mult(func.vec, Au)
                 pairs.append((func.vec, Au))
-            vals = Vec.dots(pairs, n_own)
+            # (with another solve to come and its operator just assembled: rho_0 of that solve rides in the same reduction)
+            probe = more and F.is_symmetric and getattr(self, "newton_probe", True)
+            if probe:
+                vals = Vec.dots_rhs(pairs, n_own, A.mat, b)
+                rho_b = vals.pop()
+            else:
+                vals = Vec.dots(pairs, n_own)
+                rho_b = None
             r = float(np.sqrt(vals[0]))
             unorm = float(np.sqrt(vals[1])) if len(vals) > 1 else None
             step_small = self.stol > 0.0 and vals[2] < (self.stol ** 2) * vals[1]

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FEMO_ABI_VERSION 9
+#define FEMO_ABI_VERSION 10
 
 typedef struct femo_ctx  femo_ctx;   /* device + stream + reduction workspace (+ RCCL communicator) */
 typedef struct femo_vec  femo_vec;   /* fp64 device vector  (dolfinx Function.vector / PETSc Vec)     */
@@ -152,6 +152,15 @@ int     femo_vec_dot(const femo_vec* x, const femo_vec* y, int64_t n, double* ou
  * host synchronisation for all of them -- the norms a Newton step of utils_dolfinx.py:419-449 looks at
  * (||F||, ||u||, u.Au) used to cost a stream drain each.                                                    */
 int     femo_vec_dots(int k, const femo_vec* const* x, const femo_vec* const* y, int64_t n, double* out);
+/* ABI 10: the same, plus out[k] = rho_0 = sum over the non-identity rows of (rb_i / sqrt(diag(A)_i))^2 -- the squared
+ * Jacobi norm of the right-hand side `rb` the Krylov loops of A start from.  Newton (utils_dolfinx.py:419-449: always three
+ * passes) reads it in the one host synchronisation it has after an assembly pass and takes the solver's own "nothing to
+ * iterate on" decision (rho_0 <= atol^2) without launching the solve.                                                  */
+int     femo_vec_dots_rhs(int k, const femo_vec* const* x, const femo_vec* const* y, int64_t n, double* out,
+                          const femo_mat* A, const femo_vec* rb);
+/* ... and what such a solve returns when it does not iterate from the zero guess: x_i = b_i / diag_i on the identity rows of A's
+ * last assembly, 0 elsewhere (one small launch, no synchronisation).                                                    */
+int     femo_mat_identity_solve(const femo_mat* A, const femo_vec* b, femo_vec* x);
 
 /* ---- host memory of the array boundary (csrc/hostmem.cpp) -------------------------------------
  * The CSDL operators exchange NumPy arrays with the FE layer in every method (state_model.py:81-84,

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/femo_hip.h but not exported"
     assert set(_lib.PROTOTYPES) == set(syms), set(_lib.PROTOTYPES) ^ set(syms)
-    assert lib.femo_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.femo_abi_version() == _lib.ABI_VERSION == 10
 
 
 def test_no_cpu_fallback():
