@@ -605,6 +605,9 @@ class _NewtonBase:
     # ||D^-1 (fl(F(u)) - F(u))||_2 ~ c eps ||u||_2 (measured c ~ 20 on the 10 M-DOF cube,
     # DESIGN.md section 6).  Linear solves stop there instead of iterating on round-off.
     NOISE_FACTOR = 64.0
+    # Newton reads rho_0 of the next solve with its own reduction and skips a solve the solver would not iterate on (round 6;
+    # False leaves the decision to the solver: tests compare the two)
+    newton_probe = True
 
     def solve(self, func: Function):
         """dolfinx.nls.petsc.NewtonSolver.solve [ext]: F; while not converged and
@@ -708,7 +711,7 @@ class _NewtonBase:
                 A.mult(func.vec, Au)
                 pairs.append((func.vec, Au))
             # (with another solve to come and its operator just assembled: rho_0 of that solve rides in the same reduction)
-            probe = more and F.is_symmetric and getattr(self, "newton_probe", True)
+            probe = more and F.is_symmetric and self.newton_probe
             if probe:
                 vals = Vec.dots_rhs(pairs, n_own, A.mat, b)
                 rho_b = vals.pop()

@@ -1,0 +1,105 @@
+"""Round 6: the probe with which Newton takes the solver's "nothing to iterate on" decision itself (femo_vec_dots_rhs,
+femo_mat_identity_solve; femo_amd/fea/utils_hip.py::_NewtonBase.solve), and the host-synchronisation counter."""
+import numpy as np
+import pytest
+
+from oracle import femo_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from femo_amd import _lib
+    from femo_amd.engine import Context
+    if _lib.device_count() < 1:
+        pytest.fail("no HIP device")
+    return Context(0)
+
+
+def test_dots_rhs_and_identity_solve_match_numpy(ctx):
+    """rho_0 = sum over the non-identity rows of (b_i / sqrt(diag_i))^2 next to the ordinary pairs, and the zero-iteration
+    solution b_i / diag_i on the identity rows, against NumPy on the oracle's eliminated operator."""
+    from femo_amd import engine as E
+    m = fo.unit_cube_mesh(9, 0.2)
+    dm = E.DeviceMesh(ctx, m.x, m.conn)
+    bd = fo.boundary_vertices_box(m.x)
+    A = E.Mat(dm)
+    E.assemble_jacobian(dm, 0, None, None, None, E.DirichletSet(dm, bd, 0.0), A)
+    Ao = fo.eliminate_bc(fo.stiffness(m), bd).tocsr()
+    rng = np.random.default_rng(4)
+    b, u = rng.standard_normal(m.n_vert), rng.standard_normal(m.n_vert)
+    B, U, X = E.Vec(ctx, m.n_vert).set(b), E.Vec(ctx, m.n_vert).set(u), E.Vec(ctx, m.n_vert).set(np.full(m.n_vert, 7.0))
+    vals = E.Vec.dots_rhs([(B, B), (U, B)], m.n_vert, A, B)
+    free = np.ones(m.n_vert, bool)
+    free[bd] = False
+    rho = float(np.sum(b[free] ** 2 / Ao.diagonal()[free]))
+    assert abs(vals[0] - b @ b) < 1e-12 * (b @ b) and abs(vals[1] - u @ b) < 1e-12 * abs(b @ b)
+    assert abs(vals[2] - rho) < 1e-12 * rho
+    A.identity_solve(B, X)
+    ref = np.zeros(m.n_vert)
+    ref[bd] = b[bd]                                    # identity rows: diagonal 1
+    assert np.array_equal(X.get(), ref)
+    # an operator without identity rows: rho_0 runs over every row, the zero-iteration solution is zero
+    A2 = E.Mat(dm)
+    E.assemble_jacobian(dm, 0, None, None, None, None, A2)
+    v2 = E.Vec.dots_rhs([(B, B)], m.n_vert, A2, B)
+    d2 = fo.stiffness(m).diagonal()
+    assert abs(v2[1] - float(np.sum(b * b / d2))) < 1e-12 * float(np.sum(b * b / d2))
+    A2.identity_solve(B, X)
+    assert not X.get().any()
+
+
+def test_newton_probe_takes_the_solvers_decision(ctx):
+    """The cycle with the probe (passes 2 and 3 of the linear form skipped by Newton: one small launch each) and with the
+    decision left to the solver (its set-up, its k_pcg_setup verdict, a host round trip): the same state bit for bit, the same
+    reported solves [n, 0, 0], two host synchronisations fewer."""
+    from bench import build_problem, source_fields
+    from femo_amd import engine as E
+    from femo_amd.fea import utils_hip
+    from femo_amd.fea.mesh import createUnitCubeMesh
+    utils_hip.set_context(ctx)
+    mesh = createUnitCubeMesh(40, jitter=0.2)
+    f = source_fields(mesh, 1)[0]
+    out = {}
+    try:
+        for probe in (True, False):
+            utils_hip._NewtonBase.newton_probe = probe
+            sim, fea = build_problem(mesh, device=False)
+            sim['f'] = E.pinned_array(f)
+            sim['u'] = np.zeros(mesh.n_vert)
+            sim.run()                                                  # warm: pools, lattice, rate prediction
+            del utils_hip.LAST_KSP_INFO[:]
+            fea.states_dict['u']['function'].vector.set(0.0)
+            sim['u'] = np.zeros(mesh.n_vert)
+            E.host_syncs(reset=True)
+            sim.run()
+            syncs = E.host_syncs()
+            infos = list(utils_hip.LAST_KSP_INFO)
+            out[probe] = (np.array(E.host_wait(sim['u']), copy=True), [i["iterations"] for i in infos],
+                          [bool(i.get("skipped_by_newton")) for i in infos], syncs)
+            utils_hip.clear_workspaces()
+    finally:
+        utils_hip._NewtonBase.newton_probe = True
+    (u1, its1, sk1, s1), (u0, its0, sk0, s0) = out[True], out[False]
+    assert its1 == its0 and len(its1) == 3 and its1[0] > 10 and its1[1] == 0 and its1[2] == 0
+    assert sk1 == [False, True, True] and sk0 == [False, False, False]
+    assert np.array_equal(u1, u0)
+    assert s1 <= s0 - 2, (s1, s0)
+    bd = fo.boundary_vertices_box(mesh.x)
+    om = fo.unit_cube_mesh(40, jitter=0.2)
+    ref = fo.reference_cycle(om, f, fo.u_target(om.x), bd, np.zeros(len(bd)))
+    assert np.abs(u1 - ref['u']).max() < 1e-10 * np.abs(ref['u']).max()
+
+
+def test_host_sync_counter_counts(ctx):
+    from femo_amd import engine as E
+    E.host_syncs(reset=True)
+    v = E.Vec(ctx, 1000).fill(2.0)
+    assert E.host_syncs() == 0 or E.host_syncs() <= 1           # a fill is asynchronous
+    n0 = E.host_syncs()
+    assert abs(v.dot(v) - 4000.0) < 1e-9                        # a dot product is one reduction + one blocking wait
+    assert E.host_syncs() == n0 + 1
+    ctx.sync()
+    assert E.host_syncs() == n0 + 2
+    assert E.host_syncs(reset=True) == n0 + 2 and E.host_syncs() == 0
