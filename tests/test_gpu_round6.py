@@ -52,16 +52,22 @@ def test_dots_rhs_and_identity_solve_match_numpy(ctx):
 
 def test_newton_probe_takes_the_solvers_decision(ctx):
     """The cycle with the probe (passes 2 and 3 of the linear form skipped by Newton: one small launch each) and with the
-    decision left to the solver (its set-up, its k_pcg_setup verdict, a host round trip): the same state bit for bit, the same
+    decision left to the solver (its set-up, its k_pcg_setup verdict, a host round trip): the same state (to the solver's own run-to-run noise), the same
     reported solves [n, 0, 0], two host synchronisations fewer."""
     from bench import build_problem, source_fields
     from femo_amd import engine as E
     from femo_amd.fea import utils_hip
     from femo_amd.fea.mesh import createUnitCubeMesh
     utils_hip.set_context(ctx)
-    mesh = createUnitCubeMesh(40, jitter=0.2)
+    mesh = createUnitCubeMesh(24, jitter=0.2)
     f = source_fields(mesh, 1)[0]
     out = {}
+    # Which of the solver's two stopping rules ends passes 2 and 3 depends on the mesh: on the 10 M-DOF cube it is the
+    # Jacobi-norm noise floor (the rule the probe evaluates), on small meshes the energy-norm threshold after the first
+    # application (which the probe leaves to the solver).  A larger noise factor -- the same in both runs -- puts this mesh
+    # on the first rule.
+    noise0 = utils_hip._NewtonBase.NOISE_FACTOR
+    utils_hip._NewtonBase.NOISE_FACTOR = 1e7
     try:
         for probe in (True, False):
             utils_hip._NewtonBase.newton_probe = probe
@@ -81,13 +87,16 @@ def test_newton_probe_takes_the_solvers_decision(ctx):
             utils_hip.clear_workspaces()
     finally:
         utils_hip._NewtonBase.newton_probe = True
+        utils_hip._NewtonBase.NOISE_FACTOR = noise0
     (u1, its1, sk1, s1), (u0, its0, sk0, s0) = out[True], out[False]
     assert its1 == its0 and len(its1) == 3 and its1[0] > 10 and its1[1] == 0 and its1[2] == 0
     assert sk1 == [False, True, True] and sk0 == [False, False, False]
-    assert np.array_equal(u1, u0)
+    # (not bitwise: the brick restriction of the first pass's solve accumulates with fp64 atomics, two runs of the SAME cycle
+    # already differ in the last bits -- tests/test_gpu_hostmem.py::test_early_linearisation_is_the_same_cycle)
+    assert np.abs(u1 - u0).max() < 1e-11 * np.abs(u0).max()
     assert s1 <= s0 - 2, (s1, s0)
     bd = fo.boundary_vertices_box(mesh.x)
-    om = fo.unit_cube_mesh(40, jitter=0.2)
+    om = fo.unit_cube_mesh(24, jitter=0.2)
     ref = fo.reference_cycle(om, f, fo.u_target(om.x), bd, np.zeros(len(bd)))
     assert np.abs(u1 - ref['u']).max() < 1e-10 * np.abs(ref['u']).max()
 
