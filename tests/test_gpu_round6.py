@@ -74,7 +74,10 @@ def test_newton_probe_takes_the_solvers_decision(ctx):
             sim, fea = build_problem(mesh, device=False)
             sim['f'] = E.pinned_array(f)
             sim['u'] = np.zeros(mesh.n_vert)
-            sim.run()                                                  # warm: pools, lattice, rate prediction
+            for _ in range(3):                                         # warm: pools, lattice, and the SAME history for the
+                fea.states_dict['u']['function'].vector.set(0.0)       # loop's batch prediction in both runs (it sizes the
+                sim['u'] = np.zeros(mesh.n_vert)                        # first batch from the last solves on the mesh: a cold
+                sim.run()                                              # history polls more often)
             del utils_hip.LAST_KSP_INFO[:]
             fea.states_dict['u']['function'].vector.set(0.0)
             sim['u'] = np.zeros(mesh.n_vert)
