@@ -253,9 +253,13 @@ int femo_mesh_halo_direct_selftest(femo_mesh* m, int* ok) {
   femo_ctx* ctx = m->ctx;
   hipStream_t st = ctx->stream;
   const int nn = m->n_nbr;
-  int32_t* d_nbr = nullptr; int64_t* d_recv = nullptr;
-  FEMO_HIP_CHECK(hipMalloc(&d_nbr, (size_t)nn * sizeof(int32_t)));
-  FEMO_HIP_CHECK(hipMalloc(&d_recv, (size_t)(nn + 1) * sizeof(int64_t)));
+  struct Scratch {                                    // freed on every way out (the macros below return early)
+    int32_t* nbr = nullptr; int64_t* recv = nullptr;
+    ~Scratch() { hipFree(nbr); hipFree(recv); }
+  } scratch;
+  FEMO_HIP_CHECK(hipMalloc(&scratch.nbr, (size_t)nn * sizeof(int32_t)));
+  FEMO_HIP_CHECK(hipMalloc(&scratch.recv, (size_t)(nn + 1) * sizeof(int64_t)));
+  int32_t* const d_nbr = scratch.nbr; int64_t* const d_recv = scratch.recv;
   FEMO_HIP_CHECK(hipMemcpy(d_nbr, m->nbr.data(), (size_t)nn * sizeof(int32_t), hipMemcpyHostToDevice));
   FEMO_HIP_CHECK(hipMemcpy(d_recv, m->recv_ptr.data(), (size_t)(nn + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
   FEMO_HIP_CHECK(hipMemsetAsync(h->d_err, 0, 2 * sizeof(int32_t), st));
@@ -276,7 +280,6 @@ int femo_mesh_halo_direct_selftest(femo_mesh* m, int* ok) {
   FEMO_HIP_CHECK(hipGetLastError());
   FEMO_HIP_CHECK(hipMemcpyAsync(res, h->d_err, sizeof res, hipMemcpyDeviceToHost, st));
   FEMO_HIP_CHECK(hipStreamSynchronize(st));
-  hipFree(d_nbr); hipFree(d_recv);
   FEMO_HIP_CHECK(hipMemsetAsync(h->d_err, 0, 2 * sizeof(int32_t), st));
   *ok = (res[0] == 0 && res[1] == 0) ? 1 : 0;
   return 0;
