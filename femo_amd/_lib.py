@@ -206,6 +206,12 @@ def load() -> C.CDLL:
         raise FemoError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C femo_amd/csrc`).  femo_amd has no CPU fallback.")
+    # A context drives three HIP streams (compute, copies, neighbour exchange) and RCCL adds its own.  The HIP runtime maps
+    # streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): streams that SHARE a queue serialise -- a copy stream's wait
+    # for a 60 MB PCIe transfer then holds up the compute stream behind it (round 6: measured on the model rank of the
+    # scaling model, whose process keeps two contexts alive: 2.4 ms of a 12.5 ms cycle).  Ask for 8 unless the user has set
+    # the variable; it is read when the HIP runtime initialises, i.e. before the first HIP call of the process.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the header and the library disagree

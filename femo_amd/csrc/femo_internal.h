@@ -173,6 +173,10 @@ struct femo_vec {
   // provenance of host copies (hostmem.cpp): process-unique id (0 = wrapped memory, never trusted)
   // and a generation that every entry point writing the vector bumps
   uint64_t uid = 0, gen = 0;
+  // generation at which the ghost tail was last refreshed from the owners (partitioned meshes): a refresh of a vector nobody
+  // has written since is skipped -- no exchange, no new generation (round 6).  Every writer bumps `gen` (femo_vec_touch), so
+  // the comparison is exact; vectors wrapped on the fly (solver work vectors) never match.
+  uint64_t ghost_gen = UINT64_MAX;
   // an asynchronous copy-out of this vector is (or was) in flight on the context's copy stream: the next writer
   // makes the compute stream wait for it (every writing entry point calls femo_vec_touch BEFORE it launches)
   hipEvent_t d2h_ev = nullptr;

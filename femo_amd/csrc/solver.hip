@@ -1150,7 +1150,14 @@ int femo_mesh_classify_slices(femo_mesh* m) {
 int femo_halo_exchange_on(femo_mesh* m, femo_vec* x, hipStream_t st) {
   FEMO_REQUIRE(m && x, "null argument");
   if (m->n_nbr == 0) return 0;
+  // Nobody has written x since its ghosts were refreshed: they are still the owners' values.  Skipping is SPMD-consistent
+  // (every rank runs the same sequence of writes and refreshes) and it keeps host mirrors of x valid: round 5 refreshed u
+  // for J, dJ/du, ... after its copy-out, each refresh a new generation, each new generation a real re-upload of the host
+  // copy by the next operator call (two blocking PCIe uploads + their waits per cycle and rank, round 6).
+  static const bool always = femo_env_flag("FEMO_HALO_ALWAYS");       // (comparison runs; read once)
+  if (!always && x->ghost_gen == x->gen && x->uid != 0 && x->n >= m->n_vert) return 0;
   femo_vec_touch(x);                                  // ghost entries change
+  x->ghost_gen = x->gen;
   femo_ctx* ctx = m->ctx;
   FEMO_REQUIRE(ctx->comm != nullptr || ctx->emu != nullptr || ctx->model, "halo exchange before femo_comm_init");
   FEMO_REQUIRE(x->n >= m->n_vert, "vector shorter than n_vert");

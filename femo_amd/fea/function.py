@@ -52,6 +52,10 @@ class _VectorView:
         self._fn = fn
 
     def getArray(self) -> np.ndarray:
+        # the reference refreshes ghosts before handing the array out (utils_dolfinx.py:155-159 -> 200, 205: ghostUpdate);
+        # here it also means the host copy and the device vector agree INCLUDING the ghost tail, at one generation: later
+        # operators find the ghosts fresh (no further exchange) and the host copy a valid mirror (no re-upload)
+        self.ghostUpdate()
         return self._fn.vec.get()
 
     def set(self, value) -> None:
@@ -78,7 +82,16 @@ class _VectorView:
         pass
 
     def ghostUpdate(self, *a, **k) -> None:
-        pass
+        """Ghost entries <- the owners' values on a partitioned mesh (PETSc ``Vec.ghostUpdate`` [ext]); a no-op on one rank, for
+        cell-wise (DG0) functions, and when nothing has written the vector since its last refresh (femo_halo_exchange)."""
+        fs = self._fn.function_space
+        mesh = fs.mesh
+        local = getattr(mesh, "local", None)
+        dm = getattr(mesh, "_device", None)
+        if local is None or local.nranks <= 1 or dm is None or fs.family != "CG" or len(local.nbr) == 0:
+            return
+        if self._fn.vec.n >= dm.n_vert:
+            dm.halo_exchange(self._fn.vec)
 
 
 class _XView:
