@@ -33,6 +33,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# before anything in this process can initialise the HIP runtime (torch's control plane included): a context's compute, copy
+# and exchange streams -- and RCCL's -- must not share hardware queues (femo_amd/_lib.py, DESIGN_LOG.md R6.6)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 METRIC = "DOFs/sec assemble+adjoint-solve, 10M-DOF Poisson, 1/2/4/8 MI355X"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
